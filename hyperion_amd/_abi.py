@@ -1,0 +1,224 @@
+"""ctypes mirror of ``include/hyperion_amd.h`` and the marshalling of a
+:class:`hyperion_amd.problem.Problem` into it.  The structs are plain C (no
+torch types); the same layout is used by the test oracle (``oracle/hyp_oracle.h``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .problem import Problem, SUBLIMATION_MODES, TRACK_ORIGIN
+
+MAX_DUST = 8
+_dp = C.POINTER(C.c_double)
+
+
+class DustDesc(C.Structure):
+    _fields_ = [
+        ("n_nu", C.c_int32), ("n_mu", C.c_int32), ("n_jnu", C.c_int32), ("n_enu", C.c_int32),
+        ("n_e", C.c_int32), ("sublimation_mode", C.c_int32), ("version", C.c_int32), ("is_lte", C.c_int32),
+        ("sublimation_specific_energy", C.c_double), ("minimum_specific_energy", C.c_double),
+        ("nu", _dp), ("albedo", _dp), ("chi", _dp), ("mu", _dp),
+        ("P1", _dp), ("P2", _dp), ("P3", _dp), ("P4", _dp),
+        ("emiss_nu", _dp), ("emiss_jnu", _dp), ("emiss_var", _dp),
+        ("mo_specific_energy", _dp), ("mo_chi_rosseland", _dp),
+    ]
+
+
+class SourceDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("spectrum_type", C.c_int32), ("peeloff", C.c_int32), ("n_spec", C.c_int32),
+        ("luminosity", C.c_double), ("temperature", C.c_double),
+        ("position", C.c_double * 3), ("radius", C.c_double), ("box", C.c_double * 6),
+        ("spec_nu", _dp), ("spec_fnu", _dp),
+    ]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("n3", C.c_int32),
+        ("w1", _dp), ("w2", _dp), ("w3", _dp),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("seed", C.c_int64), ("n_inter_max", C.c_int64), ("n_reabs_max", C.c_int64),
+        ("kill_on_absorb", C.c_int32), ("kill_on_scatter", C.c_int32),
+        ("sample_sources_evenly", C.c_int32), ("enforce_energy_range", C.c_int32),
+        ("forced_first_interaction", C.c_int32), ("forced_first_interaction_algorithm", C.c_int32),
+        ("specific_energy_type", C.c_int32), ("reserved0", C.c_int32),
+        ("baes16_xi", C.c_double), ("propagation_check_frequency", C.c_double),
+    ]
+
+
+class PeeledDesc(C.Structure):
+    _fields_ = [
+        ("n_view", C.c_int32), ("inside_observer", C.c_int32), ("ignore_optical_depth", C.c_int32),
+        ("compute_image", C.c_int32), ("compute_sed", C.c_int32), ("n_x", C.c_int32), ("n_y", C.c_int32),
+        ("n_ap", C.c_int32), ("n_nu", C.c_int32), ("track_origin", C.c_int32), ("track_n_scat", C.c_int32),
+        ("uncertainties", C.c_int32), ("compute_stokes", C.c_int32), ("reserved0", C.c_int32),
+        ("x_min", C.c_double), ("x_max", C.c_double), ("y_min", C.c_double), ("y_max", C.c_double),
+        ("ap_min", C.c_double), ("ap_max", C.c_double), ("nu_min", C.c_double), ("nu_max", C.c_double),
+        ("d_min", C.c_double), ("d_max", C.c_double), ("peeloff_origin", C.c_double * 3),
+        ("theta", _dp), ("phi", _dp),
+    ]
+
+
+class ProblemDesc(C.Structure):
+    _fields_ = [
+        ("grid", GridDesc), ("config", Config),
+        ("n_dust", C.c_int32), ("n_sources", C.c_int32), ("n_peeled", C.c_int32), ("reserved0", C.c_int32),
+        ("dust", C.POINTER(DustDesc)), ("sources", C.POINTER(SourceDesc)), ("peeled", C.POINTER(PeeledDesc)),
+        ("density", _dp), ("specific_energy", _dp),
+    ]
+
+
+class IterStats(C.Structure):
+    _fields_ = [
+        ("energy_current", C.c_double), ("energy_abs_tot", C.c_double * MAX_DUST),
+        ("killed_geo", C.c_uint64), ("killed_int", C.c_uint64),
+        ("crossings", C.c_uint64), ("interactions", C.c_uint64), ("n_packets", C.c_uint64),
+    ]
+
+    def as_dict(self):
+        return {"energy_current": self.energy_current, "energy_abs_tot": list(self.energy_abs_tot),
+                "killed_geo": self.killed_geo, "killed_int": self.killed_int,
+                "crossings": self.crossings, "interactions": self.interactions,
+                "n_packets": self.n_packets}
+
+
+SOURCE_TYPES = {"point": 1}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+class MarshalledProblem:
+    """Owns the C structs and keeps every referenced numpy buffer alive."""
+
+    def __init__(self, prob: Problem):
+        self._keep = []
+        keep = self._keep.append
+
+        def arr(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep(a)
+            return _ptr(a)
+
+        if prob.grid_type != "car":
+            raise ValueError("grid is not cartesian")
+        n1, n2, n3 = prob.shape
+        d = ProblemDesc()
+        d.grid.type = 1
+        d.grid.n1, d.grid.n2, d.grid.n3 = n1, n2, n3
+        d.grid.w1, d.grid.w2, d.grid.w3 = (arr(w) for w in prob.walls)
+
+        c = prob.config
+        d.config.seed = int(c.seed)
+        d.config.n_inter_max = int(c.n_inter_max)
+        d.config.n_reabs_max = int(c.n_reabs_max)
+        d.config.kill_on_absorb = int(c.kill_on_absorb)
+        d.config.kill_on_scatter = int(c.kill_on_scatter)
+        d.config.sample_sources_evenly = int(c.sample_sources_evenly)
+        d.config.enforce_energy_range = int(c.enforce_energy_range)
+        d.config.forced_first_interaction = int(c.forced_first_interaction)
+        algo = {"wr99": 1, "baes16": 2}.get(c.forced_first_interaction_algorithm)
+        if algo is None:
+            raise ValueError("Unknown forced first interaction algorithm: %s"
+                             % c.forced_first_interaction_algorithm)
+        d.config.forced_first_interaction_algorithm = algo
+        if c.specific_energy_type not in ("initial", "additional"):
+            raise ValueError("specific_energy_type should be 'additional' or 'initial'")
+        d.config.specific_energy_type = 1 if c.specific_energy_type == "additional" else 0
+        d.config.baes16_xi = float(c.baes16_xi)
+        d.config.propagation_check_frequency = float(c.propagation_check_frequency)
+
+        nd = prob.n_dust
+        if nd > MAX_DUST:
+            raise ValueError("at most %d dust species are supported" % MAX_DUST)
+        dusts = (DustDesc * max(nd, 1))()
+        for i, du in enumerate(prob.dust):
+            x = dusts[i]
+            x.n_nu, x.n_mu = du.nu.size, du.mu.size
+            x.n_jnu, x.n_enu = du.emiss_var.size, du.emiss_nu.size
+            x.n_e = 0 if du.mo_specific_energy is None else du.mo_specific_energy.size
+            x.sublimation_mode = SUBLIMATION_MODES[du.sublimation_mode]
+            x.version = int(du.version)
+            x.is_lte = int(du.is_lte)
+            x.sublimation_specific_energy = float(du.sublimation_specific_energy)
+            x.minimum_specific_energy = float(du.minimum_specific_energy)
+            for k in ("nu", "albedo", "chi", "mu", "P1", "P2", "P3", "P4",
+                      "emiss_nu", "emiss_jnu", "emiss_var"):
+                setattr(x, k, arr(getattr(du, k)))
+            x.mo_specific_energy = arr(du.mo_specific_energy) if du.mo_specific_energy is not None else None
+            x.mo_chi_rosseland = arr(du.mo_chi_rosseland) if du.mo_chi_rosseland is not None else None
+        keep(dusts)
+        d.n_dust = nd
+        d.dust = C.cast(dusts, C.POINTER(DustDesc))
+
+        ns = len(prob.sources)
+        srcs = (SourceDesc * max(ns, 1))()
+        for i, s in enumerate(prob.sources):
+            x = srcs[i]
+            if s.type not in SOURCE_TYPES:
+                raise ValueError("unknown type in source list: %s" % s.type)
+            x.type = SOURCE_TYPES[s.type]
+            x.peeloff = int(s.peeloff)
+            x.luminosity = float(s.luminosity)
+            for k in range(3):
+                x.position[k] = float(s.position[k])
+            if s.spectrum_nu is not None:
+                x.spectrum_type = 1
+                x.n_spec = int(np.size(s.spectrum_nu))
+                x.spec_nu = arr(s.spectrum_nu)
+                x.spec_fnu = arr(s.spectrum_fnu)
+            elif s.temperature is not None:
+                x.spectrum_type = 2
+                x.temperature = float(s.temperature)
+            else:
+                raise ValueError("source needs a spectrum or a temperature")
+        keep(srcs)
+        d.n_sources = ns
+        d.sources = C.cast(srcs, C.POINTER(SourceDesc))
+
+        npl = len(prob.peeled)
+        pls = (PeeledDesc * max(npl, 1))()
+        for i, p in enumerate(prob.peeled):
+            x = pls[i]
+            x.n_view = p.n_view
+            x.inside_observer = int(p.inside_observer)
+            x.ignore_optical_depth = int(p.ignore_optical_depth)
+            x.compute_image = int(p.compute_image)
+            x.compute_sed = int(p.compute_sed)
+            x.n_x, x.n_y, x.n_ap, x.n_nu = int(p.n_x), int(p.n_y), int(p.n_ap), int(p.n_wav)
+            x.track_origin = TRACK_ORIGIN[p.track_origin]
+            x.track_n_scat = int(p.track_n_scat)
+            x.uncertainties = int(p.uncertainties)
+            x.compute_stokes = int(p.compute_stokes)
+            x.x_min, x.x_max, x.y_min, x.y_max = p.x_min, p.x_max, p.y_min, p.y_max
+            x.ap_min, x.ap_max = p.ap_min, p.ap_max
+            x.nu_min, x.nu_max = p.nu_min, p.nu_max
+            x.d_min, x.d_max = p.d_min, p.d_max
+            for k in range(3):
+                x.peeloff_origin[k] = float(p.peeloff_origin[k])
+            x.theta = arr(p.theta)
+            x.phi = arr(p.phi)
+        keep(pls)
+        d.n_peeled = npl
+        d.peeled = C.cast(pls, C.POINTER(PeeledDesc))
+
+        d.density = arr(prob.density)
+        d.specific_energy = arr(prob.specific_energy) if prob.specific_energy is not None else None
+        self.desc = d
+        self.problem = prob
+
+    def peeled_shapes(self, g, n_orig):
+        """(sed_shape, img_shape) of group g in the .rtout layout."""
+        p = self.problem.peeled[g]
+        ns = 4 if p.compute_stokes else 1
+        sed = (ns, n_orig, p.n_view, p.n_ap, p.n_wav) if p.compute_sed else None
+        img = (ns, n_orig, p.n_view, p.n_y, p.n_x, p.n_wav) if p.compute_image else None
+        return sed, img

@@ -1,0 +1,278 @@
+"""In-memory description of one radiative-transfer run: the flat-array form of
+a Hyperion ``.rtin`` input file.
+
+The reference passes a model from its Python front-end to its Fortran core as
+an HDF5 file (``hyperion/model/model.py:1025-1080`` -> ``src/main/main.f90``);
+this module is the array-level equivalent that crosses our C-ABI
+(``include/hyperion_amd.h``).  Field names and meaning follow the ``.rtin``
+contract (``docs/advanced/model_file.rst`` of the reference, readers
+``src/main/setup_rt.f90:38-302``, ``src/dust/dust_type_4elem.f90:78-293``,
+``src/sources/source_type.f90:102-322``,
+``src/grid/grid_geometry_cartesian_3d.f90:77-134``).
+
+A Problem can be stored as a plain ``.npz`` (no pickles) so that inputs made in
+a container with h5py travel to a box without it.
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+SUBLIMATION_MODES = {"no": 0, "fast": 1, "slow": 2, "cap": 3}
+TRACK_ORIGIN = {"no": 0, "basic": 1, "yes": 1, "detailed": 2, "scatterings": 3}
+C_CGS = 29979245800.0
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+@dataclass
+class Dust:
+    """One ``/Dust/dust_NNN`` group."""
+    nu: np.ndarray
+    albedo: np.ndarray
+    chi: np.ndarray
+    mu: np.ndarray
+    P1: np.ndarray  # (n_nu, n_mu)
+    P2: np.ndarray
+    P3: np.ndarray
+    P4: np.ndarray
+    emiss_nu: np.ndarray
+    emiss_jnu: np.ndarray  # (n_enu, n_jnu)
+    emiss_var: np.ndarray  # (n_jnu,) specific energies
+    mo_specific_energy: Optional[np.ndarray] = None
+    mo_chi_rosseland: Optional[np.ndarray] = None
+    version: int = 2
+    is_lte: bool = True
+    sublimation_mode: str = "no"
+    sublimation_specific_energy: float = 0.0
+    minimum_specific_energy: float = 0.0
+
+    def __post_init__(self):
+        for k in ("nu", "albedo", "chi", "mu", "P1", "P2", "P3", "P4",
+                  "emiss_nu", "emiss_jnu", "emiss_var"):
+            setattr(self, k, _f64(getattr(self, k)))
+        for k in ("mo_specific_energy", "mo_chi_rosseland"):
+            v = getattr(self, k)
+            if v is not None:
+                setattr(self, k, _f64(v))
+        n_nu, n_mu = self.nu.size, self.mu.size
+        for k in ("P1", "P2", "P3", "P4"):
+            if getattr(self, k).shape != (n_nu, n_mu):
+                raise ValueError("%s should have shape (n_nu, n_mu)" % k)
+        if self.emiss_jnu.shape != (self.emiss_nu.size, self.emiss_var.size):
+            raise ValueError("emiss_jnu should have shape (n_enu, n_jnu)")
+        if self.sublimation_mode not in SUBLIMATION_MODES:
+            raise ValueError("Unknown dust sublimation mode: %s" % self.sublimation_mode)
+
+
+@dataclass
+class Source:
+    """One ``/Sources/source_NNNNN`` group (point sources for now)."""
+    type: str = "point"
+    luminosity: float = 0.0
+    position: tuple = (0.0, 0.0, 0.0)
+    temperature: Optional[float] = None
+    spectrum_nu: Optional[np.ndarray] = None
+    spectrum_fnu: Optional[np.ndarray] = None
+    peeloff: bool = True
+
+
+@dataclass
+class PeeledImages:
+    """One ``/Output/Peeled/group_NNNNN`` group
+    (``src/images/images_peeled.f90:272-380``, ``image_type.f90:153-335``)."""
+    theta: np.ndarray
+    phi: np.ndarray
+    n_wav: int = 1
+    wav_min: float = 1.0      # micron
+    wav_max: float = 1000.0   # micron
+    compute_image: bool = True
+    n_x: int = 1
+    n_y: int = 1
+    x_min: float = -1.0
+    x_max: float = 1.0
+    y_min: float = -1.0
+    y_max: float = 1.0
+    compute_sed: bool = True
+    n_ap: int = 1
+    ap_min: float = 1.0
+    ap_max: float = 1.0
+    track_origin: str = "no"
+    track_n_scat: int = 0
+    uncertainties: bool = False
+    compute_stokes: bool = True
+    inside_observer: bool = False
+    ignore_optical_depth: bool = False
+    d_min: float = -np.inf
+    d_max: float = np.inf
+    peeloff_origin: tuple = (0.0, 0.0, 0.0)
+
+    def __post_init__(self):
+        self.theta = _f64(np.atleast_1d(self.theta))
+        self.phi = _f64(np.atleast_1d(self.phi))
+
+    @property
+    def n_view(self):
+        return self.theta.size
+
+    @property
+    def nu_min(self):
+        return C_CGS / (self.wav_max * 1.0e-4)
+
+    @property
+    def nu_max(self):
+        return C_CGS / (self.wav_min * 1.0e-4)
+
+
+@dataclass
+class RunConfig:
+    """Root attributes of the ``.rtin`` with the reference's defaults
+    (``hyperion/conf/conf_files.py:48-73``, ``src/main/setup_rt.f90:38-302``)."""
+    seed: int = -124902
+    n_inter_max: int = 1000000
+    n_reabs_max: int = 1000000
+    kill_on_absorb: bool = False
+    kill_on_scatter: bool = False
+    sample_sources_evenly: bool = False
+    enforce_energy_range: bool = True
+    forced_first_interaction: bool = True
+    forced_first_interaction_algorithm: str = "wr99"
+    baes16_xi: float = 0.5
+    propagation_check_frequency: float = 1.0e-3
+    specific_energy_type: str = "initial"
+    n_initial_iter: int = 5
+    n_initial_photons: int = 0
+    n_last_photons: int = 0
+    check_convergence: bool = False
+    convergence_absolute: float = 0.0
+    convergence_relative: float = 0.0
+    convergence_percentile: float = 100.0
+    output_specific_energy: str = "last"
+    output_density: str = "none"
+    mrw: bool = False
+    pda: bool = False
+    monochromatic: bool = False
+    raytracing: bool = False
+
+
+@dataclass
+class Problem:
+    walls: List[np.ndarray]               # [x(n1+1), y(n2+1), z(n3+1)]
+    density: np.ndarray                   # (n_dust, n3, n2, n1)
+    dust: List[Dust]
+    sources: List[Source]
+    config: RunConfig = field(default_factory=RunConfig)
+    peeled: List[PeeledImages] = field(default_factory=list)
+    specific_energy: Optional[np.ndarray] = None
+    grid_type: str = "car"
+    geometry_id: str = ""
+
+    def __post_init__(self):
+        self.walls = [_f64(w) for w in self.walls]
+        self.density = _f64(self.density)
+        if self.density.ndim == 3:
+            self.density = self.density[None]
+        n1, n2, n3 = self.shape
+        if self.density.shape != (len(self.dust), n3, n2, n1):
+            raise ValueError("density array has wrong shape %r, expected %r"
+                             % (self.density.shape, (len(self.dust), n3, n2, n1)))
+        if self.specific_energy is not None:
+            self.specific_energy = _f64(self.specific_energy)
+            if self.specific_energy.shape != self.density.shape:
+                raise ValueError("specific_energy array has wrong number of dust types")
+
+    @property
+    def shape(self):
+        return tuple(w.size - 1 for w in self.walls)
+
+    @property
+    def n_cells(self):
+        n1, n2, n3 = self.shape
+        return n1 * n2 * n3
+
+    @property
+    def n_dust(self):
+        return len(self.dust)
+
+    @property
+    def volumes(self):
+        dx, dy, dz = (np.diff(w) for w in self.walls)
+        return dz[:, None, None] * dy[None, :, None] * dx[None, None, :]
+
+    # ---------------------------------------------------------------- npz I/O
+    def to_npz(self, path):
+        arrays = {}
+        meta = {"grid_type": self.grid_type, "geometry_id": self.geometry_id,
+                "config": self.config.__dict__, "dust": [], "sources": [], "peeled": []}
+        for i, w in enumerate(self.walls):
+            arrays["walls_%d" % (i + 1)] = w
+        arrays["density"] = self.density
+        if self.specific_energy is not None:
+            arrays["specific_energy"] = self.specific_energy
+        for i, d in enumerate(self.dust):
+            m = {}
+            for k, v in d.__dict__.items():
+                if isinstance(v, np.ndarray):
+                    arrays["dust%d/%s" % (i, k)] = v
+                elif v is not None:
+                    m[k] = v
+            meta["dust"].append(m)
+        for i, s in enumerate(self.sources):
+            m = {}
+            for k, v in s.__dict__.items():
+                if isinstance(v, np.ndarray):
+                    arrays["source%d/%s" % (i, k)] = v
+                elif v is not None:
+                    m[k] = list(v) if isinstance(v, tuple) else v
+            meta["sources"].append(m)
+        for i, p in enumerate(self.peeled):
+            m = {}
+            for k, v in p.__dict__.items():
+                if isinstance(v, np.ndarray):
+                    arrays["peeled%d/%s" % (i, k)] = v
+                else:
+                    m[k] = list(v) if isinstance(v, tuple) else v
+            meta["peeled"].append(m)
+        arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+        np.savez_compressed(path, **arrays)
+
+    @classmethod
+    def from_npz(cls, path):
+        z = np.load(path, allow_pickle=False)
+        meta = json.loads(bytes(z["meta_json"]).decode())
+
+        def sub(prefix):
+            return {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+
+        dust = []
+        for i, m in enumerate(meta["dust"]):
+            kw = dict(m)
+            kw.update(sub("dust%d/" % i))
+            dust.append(Dust(**kw))
+        sources = []
+        for i, m in enumerate(meta["sources"]):
+            kw = dict(m)
+            kw.update(sub("source%d/" % i))
+            if "position" in kw:
+                kw["position"] = tuple(kw["position"])
+            sources.append(Source(**kw))
+        peeled = []
+        for i, m in enumerate(meta["peeled"]):
+            kw = dict(m)
+            kw.update(sub("peeled%d/" % i))
+            for k in ("d_min", "d_max"):
+                if kw.get(k) is None:
+                    kw.pop(k, None)
+            if "peeloff_origin" in kw:
+                kw["peeloff_origin"] = tuple(kw["peeloff_origin"])
+            peeled.append(PeeledImages(**kw))
+        cfg = RunConfig(**meta["config"])
+        return cls(walls=[z["walls_1"], z["walls_2"], z["walls_3"]], density=z["density"],
+                   dust=dust, sources=sources, config=cfg, peeled=peeled,
+                   specific_energy=z["specific_energy"] if "specific_energy" in z.files else None,
+                   grid_type=meta.get("grid_type", "car"), geometry_id=meta.get("geometry_id", ""))

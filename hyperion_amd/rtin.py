@@ -1,0 +1,170 @@
+"""Reader for Hyperion ``.rtin`` HDF5 input files -> :class:`Problem`.
+
+This is the file-contract side of the drop-in boundary
+(``scripts/hyperion:39-92`` + ``src/main/setup_rt.f90`` of the reference).
+It needs ``h5py``; where h5py is absent (the system Python of this image) use a
+``.npz`` written by :meth:`Problem.to_npz` instead.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .problem import Dust, PeeledImages, Problem, RunConfig, Source
+
+
+def _s(v):
+    if isinstance(v, (bytes, np.bytes_)):
+        return v.decode()
+    return str(v)
+
+
+def _b(v):
+    s = _s(v).strip().lower()
+    if s in ("yes", "y", "true"):
+        return True
+    if s in ("no", "n", "false"):
+        return False
+    raise ValueError("cannot interpret %r as a boolean" % (v,))
+
+
+def read_dust_group(g, minimum_specific_energy=0.0):
+    """``src/dust/dust_type_4elem.f90:78-293``"""
+    a = g.attrs
+    op = g["optical_properties"][...]
+    em = g["emissivities"][...]
+    mo = g["mean_opacities"][...]
+    version = int(a["version"])
+    kw = dict(
+        nu=op["nu"], albedo=op["albedo"], chi=op["chi"],
+        mu=g["scattering_angles"][...]["mu"],
+        P1=op["P1"], P2=op["P2"], P3=op["P3"], P4=op["P4"],
+        emiss_nu=em["nu"], emiss_jnu=em["jnu"],
+        emiss_var=g["emissivity_variable"][...]["specific_energy"],
+        mo_specific_energy=mo["specific_energy"],
+        mo_chi_rosseland=mo["chi_rosseland"],
+        version=version, is_lte=_b(a["lte"]),
+        sublimation_mode=_s(a["sublimation_mode"]).strip(),
+        minimum_specific_energy=float(minimum_specific_energy),
+    )
+    if _s(a["emissvar"]).strip() != "E":
+        raise ValueError("Only emissvar='E' supported at this time")
+    if kw["sublimation_mode"] != "no":
+        kw["sublimation_specific_energy"] = float(a["sublimation_specific_energy"])
+    return Dust(**kw)
+
+
+def read_rtin(path):
+    import h5py  # deliberately local: the engine itself never needs HDF5
+
+    with h5py.File(path, "r") as f:
+        a = f.attrs
+        cfg = RunConfig()
+        cfg.seed = int(a["seed"]) if "seed" in a else -124902
+        cfg.n_inter_max = int(a["n_inter_max"])
+        cfg.n_reabs_max = int(a["n_reabs_max"])
+        cfg.kill_on_absorb = _b(a["kill_on_absorb"])
+        cfg.kill_on_scatter = _b(a["kill_on_scatter"]) if "kill_on_scatter" in a else False
+        cfg.sample_sources_evenly = _b(a["sample_sources_evenly"]) if "sample_sources_evenly" in a else False
+        cfg.enforce_energy_range = _b(a["enforce_energy_range"]) if "enforce_energy_range" in a else True
+        if "forced_first_scattering" in a:
+            cfg.forced_first_interaction = _b(a["forced_first_scattering"])
+        else:
+            cfg.forced_first_interaction = _b(a["forced_first_interaction"])
+            cfg.forced_first_interaction_algorithm = _s(a["forced_first_interaction_algorithm"]).strip()
+            if "forced_first_interaction_baes16_xi" in a:
+                cfg.baes16_xi = float(a["forced_first_interaction_baes16_xi"])
+        cfg.propagation_check_frequency = float(a["propagation_check_frequency"]) \
+            if "propagation_check_frequency" in a else 1.0e-3
+        cfg.specific_energy_type = _s(a["specific_energy_type"]).strip() if "specific_energy_type" in a else "initial"
+        cfg.n_initial_iter = int(a["n_initial_iter"])
+        cfg.n_initial_photons = int(a["n_initial_photons"]) if cfg.n_initial_iter > 0 else 0
+        cfg.mrw = _b(a["mrw"])
+        cfg.pda = _b(a["pda"])
+        cfg.monochromatic = _b(a["monochromatic"])
+        cfg.raytracing = _b(a["raytracing"])
+        cfg.n_last_photons = int(a["n_last_photons"]) if "n_last_photons" in a else 0
+        if cfg.n_initial_iter > 0:
+            cfg.check_convergence = _b(a["check_convergence"])
+            if cfg.check_convergence:
+                cfg.convergence_absolute = float(a["convergence_absolute"])
+                cfg.convergence_relative = float(a["convergence_relative"])
+                cfg.convergence_percentile = float(a["convergence_percentile"])
+        out = f["Output"].attrs
+        cfg.output_specific_energy = _s(out["output_specific_energy"]).strip()
+        cfg.output_density = _s(out["output_density"]).strip()
+
+        geo = f["Grid/Geometry"]
+        grid_type = _s(geo.attrs["grid_type"]).strip()
+        if grid_type != "car":
+            raise NotImplementedError("grid type %r is not supported yet" % grid_type)
+        walls = [geo["walls_1"][...]["x"], geo["walls_2"][...]["y"], geo["walls_3"][...]["z"]]
+        q = f["Grid/Quantities"]
+        density = q["density"][...]
+        spec = q["specific_energy"][...] if "specific_energy" in q else None
+        n_dust = density.shape[0]
+        mse = np.zeros(n_dust)
+        if "minimum_specific_energy" in q.attrs:
+            mse = np.atleast_1d(q.attrs["minimum_specific_energy"]).astype(float)
+
+        dust = []
+        names = sorted(f["Dust"].keys())
+        if len(names) != n_dust:
+            raise ValueError("density array has wrong number of dust types")
+        for i, n in enumerate(names):
+            dust.append(read_dust_group(f["Dust"][n], mse[i]))
+
+        sources = []
+        for n in sorted(f["Sources"].keys()):
+            g = f["Sources"][n]
+            sa = g.attrs
+            t = _s(sa["type"]).strip()
+            s = Source(type=t, luminosity=float(sa["luminosity"]), peeloff=_b(sa["peeloff"]))
+            if t == "point":
+                s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+            else:
+                raise NotImplementedError("source type %r is not supported yet" % t)
+            st = _s(sa["spectrum"]).strip()
+            if st == "temperature":
+                s.temperature = float(sa["temperature"])
+            elif st == "spectrum":
+                tab = g["spectrum"][...]
+                s.spectrum_nu = np.asarray(tab["nu"], dtype=float)
+                s.spectrum_fnu = np.asarray(tab["fnu"], dtype=float)
+            else:
+                raise ValueError("Point source cannot have LTE spectrum")
+            sources.append(s)
+
+        peeled = []
+        if "Peeled" in f["Output"]:
+            for n in sorted(f["Output/Peeled"].keys()):
+                g = f["Output/Peeled"][n]
+                pa = g.attrs
+                ang = g["angles"][...]
+                p = PeeledImages(theta=ang["theta"], phi=ang["phi"])
+                p.inside_observer = _b(pa["inside_observer"])
+                p.ignore_optical_depth = _b(pa["ignore_optical_depth"])
+                p.d_min, p.d_max = float(pa["d_min"]), float(pa["d_max"])
+                if p.inside_observer:
+                    p.peeloff_origin = tuple(float(pa["observer_" + k]) for k in "xyz")
+                else:
+                    p.peeloff_origin = tuple(float(pa["peeloff_" + k]) for k in "xyz")
+                p.n_wav = int(pa["n_wav"])
+                p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])
+                p.compute_image = _b(pa["compute_image"])
+                if p.compute_image:
+                    p.n_x, p.n_y = int(pa["n_x"]), int(pa["n_y"])
+                    p.x_min, p.x_max = float(pa["x_min"]), float(pa["x_max"])
+                    p.y_min, p.y_max = float(pa["y_min"]), float(pa["y_max"])
+                p.compute_sed = _b(pa["compute_sed"])
+                if p.compute_sed:
+                    p.n_ap = int(pa["n_ap"])
+                    p.ap_min, p.ap_max = float(pa["ap_min"]), float(pa["ap_max"])
+                p.track_origin = _s(pa["track_origin"]).strip()
+                p.track_n_scat = int(pa["track_n_scat"]) if "track_n_scat" in pa else 0
+                p.uncertainties = _b(pa["uncertainties"])
+                p.compute_stokes = _b(pa["compute_stokes"]) if "compute_stokes" in pa else True
+                peeled.append(p)
+
+        return Problem(walls=walls, density=density, dust=dust, sources=sources, config=cfg,
+                       peeled=peeled, specific_energy=spec, grid_type=grid_type,
+                       geometry_id=_s(geo.attrs["geometry"]))

@@ -1,0 +1,1596 @@
+/*
+ * hyp_oracle.c -- TEST INFRASTRUCTURE ONLY (see hyp_oracle.h).
+ *
+ * Plain-C FP64 restatement of the reference's photon-packet path.  Every
+ * function cites the reference file:line (relative to /root/reference) it
+ * follows.  Random numbers: the reference uses fortranlib's generator (source
+ * absent); here every packet owns two counter-based Philox4x32-10 streams keyed
+ * by (seed, iteration) and indexed by the global packet id, so results do not
+ * depend on thread count or on how packets are sharded:
+ *   stream A: FP64 uniforms, consumed in the reference's order of `random`
+ *             calls (emit -> random_exp -> interact ...);
+ *   stream B: 32-bit uniforms for the per-crossing propagation check
+ *             (grid_propagate_3d.f90:108).
+ */
+#include "hyp_oracle.h"
+
+#include <math.h>
+#include <float.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define PI 3.14159265358979323846
+#define TWOPI 6.28318530717958647692
+/* cgs constants, hyperion/util/constants.py:1-20 (same values as fortranlib lib_constants) */
+#define H_CGS 6.6260755e-27
+#define K_CGS 1.380658e-16
+
+static char g_error[512];
+
+/* ------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al. 2011)                                   */
+/* ------------------------------------------------------------------ */
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+typedef struct {
+    uint32_t key[2];
+    uint64_t id;
+    uint32_t blk_a, blk_b;
+    int have_a, pos_b;
+    double buf_a;
+    uint32_t buf_b[4];
+} rng_t;
+
+static uint32_t seed_key(int64_t seed)
+{
+    uint64_t s = (uint64_t)(seed < 0 ? -seed : seed);
+    return (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+
+static void rng_init(rng_t *g, int64_t seed, uint32_t iter_tag, uint64_t id)
+{
+    g->key[0] = seed_key(seed); g->key[1] = iter_tag;
+    g->id = id; g->blk_a = 0; g->blk_b = 0; g->have_a = 0; g->pos_b = 4;
+}
+
+static inline double u64_to_unit(uint32_t hi, uint32_t lo)
+{
+    uint64_t u = (((uint64_t)hi << 32) | lo) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+}
+
+/* uniform in [0,1): the reference's `random(xi)` */
+static double rng_uniform(rng_t *g)
+{
+    if (g->have_a) { g->have_a = 0; return g->buf_a; }
+    uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_a++, 0u}, o[4];
+    orc_philox4x32_10(ctr, g->key, o);
+    g->buf_a = u64_to_unit(o[2], o[3]); g->have_a = 1;
+    return u64_to_unit(o[0], o[1]);
+}
+
+static uint32_t rng_check_u32(rng_t *g)
+{
+    if (g->pos_b == 4) {
+        uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_b++, 1u};
+        orc_philox4x32_10(ctr, g->key, g->buf_b);
+        g->pos_b = 0;
+    }
+    return g->buf_b[g->pos_b++];
+}
+
+/* fortranlib random_exp: tau = -log(1 - xi) */
+static double rng_exp(rng_t *g) { return -log(1.0 - rng_uniform(g)); }
+
+/* ------------------------------------------------------------------ */
+/* fortranlib lib_array restated                                       */
+/* ------------------------------------------------------------------ */
+
+/* locate (0-based): j with x[j] <= xv < x[j+1]; xv==x[n-1] -> n-2; -1 if
+ * outside.  Ascending arrays only (all call sites on this path). */
+static int locate(const double *x, int n, double xv)
+{
+    if (!(xv >= x[0]) || !(xv <= x[n - 1])) return -1;
+    if (xv == x[n - 1]) return n - 2;
+    int jl = 0, ju = n - 1;
+    while (ju - jl > 1) {
+        int jm = (ju + jl) >> 1;
+        if (xv >= x[jm]) jl = jm; else ju = jm;
+    }
+    return jl;
+}
+
+/* interp1d_loglog: log-log where both ordinates are positive, linear
+ * otherwise (same rule as hyperion/util/_interpolate_core.c:277-300). */
+static double interp1d_loglog(const double *x, const double *y, int n, double xv)
+{
+    int j = locate(x, n, xv);
+    if (j < 0) return NAN;
+    double y1 = y[j], y2 = y[j + 1];
+    if (y1 > 0.0 && y2 > 0.0) {
+        double f = (log10(xv) - log10(x[j])) / (log10(x[j + 1]) - log10(x[j]));
+        return pow(10.0, log10(y1) + f * (log10(y2) - log10(y1)));
+    }
+    return y1 + (xv - x[j]) / (x[j + 1] - x[j]) * (y2 - y1);
+}
+
+/* interp2d: bilinear, array a[iy][ix] with ix fastest (Fortran a(ix,iy)) */
+static double interp2d(const double *x, int nx, const double *y, int ny,
+                       const double *a, double xv, double yv)
+{
+    int i = locate(x, nx, xv), j = locate(y, ny, yv);
+    if (i < 0 || j < 0) return NAN;
+    double fx = (xv - x[i]) / (x[i + 1] - x[i]);
+    double fy = (yv - y[j]) / (y[j + 1] - y[j]);
+    double a00 = a[(size_t)j * nx + i], a10 = a[(size_t)j * nx + i + 1];
+    double a01 = a[(size_t)(j + 1) * nx + i], a11 = a[(size_t)(j + 1) * nx + i + 1];
+    return a00 * (1 - fx) * (1 - fy) + a10 * fx * (1 - fy) + a01 * (1 - fx) * fy + a11 * fx * fy;
+}
+
+/* one log-log trapezium segment (hyperion/util/_integrate_core.c:317-326) */
+static double seg_loglog(double x1, double x2, double y1, double y2)
+{
+    if (!(y1 > 0.0 && y2 > 0.0)) return 0.0;
+    double b = log10(y1 / y2) / log10(x1 / x2);
+    if (fabs(b + 1.0) < 1e-10) return x1 * y1 * log(x2 / x1);
+    return y1 * (x2 * pow(x2 / x1, b) - x1) / (b + 1.0);
+}
+
+/* integral_linlog: x linear, y logarithmic (_integrate_core.c:236-246) */
+static double integral_linlog(const double *x, const double *y, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n - 1; i++) {
+        double y1 = y[i], y2 = y[i + 1], dx = x[i + 1] - x[i];
+        if (y1 == y2) s += y1 * dx;
+        else if (y1 > 0.0 && y2 > 0.0) s += (y2 - y1) * dx / log(y2 / y1);
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------ */
+/* fortranlib type_pdf restated                                        */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    int n;
+    double *x, *pdf, *cdf, *bp1; /* bp1[j] = power-law index + 1 of bin j */
+} pdf_t;
+
+/* set_pdf(p, x, y, log=.true.) */
+static int pdf_set_log(pdf_t *p, const double *x, const double *y, int n, int stride)
+{
+    p->n = n;
+    p->x = malloc(sizeof(double) * n); p->pdf = malloc(sizeof(double) * n);
+    p->cdf = malloc(sizeof(double) * n); p->bp1 = malloc(sizeof(double) * n);
+    double norm = 0.0;
+    for (int i = 0; i < n; i++) { p->x[i] = x[i]; p->pdf[i] = y[(size_t)i * stride]; }
+    for (int i = 0; i < n - 1; i++) norm += seg_loglog(p->x[i], p->x[i + 1], p->pdf[i], p->pdf[i + 1]);
+    if (!(norm > 0.0)) return -1;
+    for (int i = 0; i < n; i++) p->pdf[i] /= norm;
+    p->cdf[0] = 0.0;
+    for (int i = 1; i < n; i++)
+        p->cdf[i] = p->cdf[i - 1] + seg_loglog(p->x[i - 1], p->x[i], p->pdf[i - 1], p->pdf[i]);
+    double last = p->cdf[n - 1];
+    for (int i = 0; i < n; i++) p->cdf[i] /= last;
+    for (int i = 0; i < n - 1; i++) {
+        if (p->pdf[i] > 0.0 && p->pdf[i + 1] > 0.0)
+            p->bp1[i] = log10(p->pdf[i + 1] / p->pdf[i]) / log10(p->x[i + 1] / p->x[i]) + 1.0;
+        else p->bp1[i] = NAN;
+    }
+    p->bp1[n - 1] = NAN;
+    return 0;
+}
+
+static void pdf_free(pdf_t *p) { free(p->x); free(p->pdf); free(p->cdf); free(p->bp1); }
+
+/* sample_pdf(p, xi) for a log pdf: invert the piecewise power-law CDF */
+static double pdf_sample_log(const pdf_t *p, double xi)
+{
+    int j = locate(p->cdf, p->n, xi);
+    if (j < 0) j = 0;
+    double c1 = p->cdf[j], c2 = p->cdf[j + 1];
+    double f = (c2 > c1) ? (xi - c1) / (c2 - c1) : 0.0;
+    double x1 = p->x[j], x2 = p->x[j + 1], bp1 = p->bp1[j];
+    if (bp1 != bp1) return x1 + f * (x2 - x1);
+    if (fabs(bp1) < 1e-10) return x1 * pow(x2 / x1, f);
+    return x1 * pow(1.0 + f * (pow(x2 / x1, bp1) - 1.0), 1.0 / bp1);
+}
+
+/* discrete pdf (fortranlib pdf_discrete): smallest i with xi < cdf[i] */
+static int sample_discrete(const double *cdf, int n, double xi)
+{
+    for (int i = 0; i < n - 1; i++) if (xi < cdf[i]) return i;
+    return n - 1;
+}
+
+/* ------------------------------------------------------------------ */
+/* Angles (fortranlib type_angle3d restated)                            */
+/* ------------------------------------------------------------------ */
+
+typedef struct { double cost, sint, cosp, sinp; } angle_t;
+
+static inline void angle_to_vector(const angle_t *a, double v[3])
+{
+    v[0] = a->sint * a->cosp; v[1] = a->sint * a->sinp; v[2] = a->cost;
+}
+
+/* random_sphere_angle3d: mu uniform in [-1,1], phi uniform in [0,2pi) */
+static void random_sphere_angle(rng_t *g, angle_t *a)
+{
+    double mu = 2.0 * rng_uniform(g) - 1.0;
+    double phi = TWOPI * rng_uniform(g);
+    a->cost = mu; a->sint = sqrt(1.0 - mu * mu);
+    a->cosp = cos(phi); a->sinp = sin(phi);
+}
+
+/* rotate_angle3d(a_local, a_coord, a_final): add the local (scattering)
+ * angle to the direction a_coord.  Spherical triangle pole / old / new with
+ * sides a=old theta, b=local theta, c=new theta and angle C = local phi at
+ * the old direction, B = |new phi - old phi| at the pole.  Orientation as in
+ * Code & Whitney (1995): local phi in (0,pi) -> new phi = old phi - B.  This
+ * is the convention scatter_stokes (dust_type_4elem.f90:603-690) assumes. */
+static void rotate_angle(const angle_t *loc, const angle_t *co, angle_t *fin)
+{
+    double cos_a = co->cost, sin_a = co->sint;
+    double cos_b = loc->cost, sin_b = loc->sint;
+    double cos_C = loc->cosp, sin_C = fabs(loc->sinp);
+    double cos_c = cos_a * cos_b + sin_a * sin_b * cos_C;
+    if (cos_c > 1.0) cos_c = 1.0;
+    if (cos_c < -1.0) cos_c = -1.0;
+    double sin_c = sqrt(1.0 - cos_c * cos_c);
+    double cos_B, sin_B;
+    if (sin_a < 1e-12 || sin_c < 1e-12) {
+        /* old or new direction along the pole: azimuth difference is the
+         * local azimuth itself (old at pole) or arbitrary (new at pole) */
+        if (sin_a < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
+        else { cos_B = 1.0; sin_B = 0.0; }
+    } else {
+        cos_B = (cos_b - cos_a * cos_c) / (sin_a * sin_c);
+        if (cos_B > 1.0) cos_B = 1.0;
+        if (cos_B < -1.0) cos_B = -1.0;
+        sin_B = sqrt(1.0 - cos_B * cos_B);
+    }
+    fin->cost = cos_c; fin->sint = sin_c;
+    if (loc->sinp < 0.0) { /* new phi = old phi + B */
+        fin->cosp = co->cosp * cos_B - co->sinp * sin_B;
+        fin->sinp = co->sinp * cos_B + co->cosp * sin_B;
+    } else {               /* new phi = old phi - B */
+        fin->cosp = co->cosp * cos_B + co->sinp * sin_B;
+        fin->sinp = co->sinp * cos_B - co->cosp * sin_B;
+    }
+}
+
+/* difference_angle3d(a_coord, a_final, a_local): inverse of rotate_angle */
+static void difference_angle(const angle_t *co, const angle_t *fin, angle_t *loc)
+{
+    double cos_a = co->cost, sin_a = co->sint;
+    double cos_c = fin->cost, sin_c = fin->sint;
+    double cos_B = co->cosp * fin->cosp + co->sinp * fin->sinp;   /* cos(old-new) */
+    double sin_Bs = co->sinp * fin->cosp - co->cosp * fin->sinp;  /* sin(old-new) */
+    double cos_b = cos_a * cos_c + sin_a * sin_c * cos_B;
+    if (cos_b > 1.0) cos_b = 1.0;
+    if (cos_b < -1.0) cos_b = -1.0;
+    double sin_b = sqrt(1.0 - cos_b * cos_b);
+    loc->cost = cos_b; loc->sint = sin_b;
+    if (sin_b < 1e-12 || sin_a < 1e-12) {
+        if (sin_a < 1e-12 && sin_b >= 1e-12) {
+            loc->cosp = (cos_a > 0 ? -cos_B : cos_B); loc->sinp = sin_Bs;
+        } else { loc->cosp = 1.0; loc->sinp = 0.0; }
+        return;
+    }
+    double cos_C = (cos_c - cos_a * cos_b) / (sin_a * sin_b);
+    if (cos_C > 1.0) cos_C = 1.0;
+    if (cos_C < -1.0) cos_C = -1.0;
+    double sin_C = sqrt(1.0 - cos_C * cos_C);
+    loc->cosp = cos_C;
+    loc->sinp = (sin_Bs >= 0.0) ? sin_C : -sin_C;
+}
+
+/* ------------------------------------------------------------------ */
+/* State                                                                */
+/* ------------------------------------------------------------------ */
+
+typedef struct {
+    int n_nu, n_mu, n_jnu, n_enu, n_e;
+    int sublimation_mode, version, zero_p2;
+    double sublimation_specific_energy, minimum_specific_energy;
+    double *nu, *albedo, *chi;
+    double *mu, mu_min, mu_max;
+    double *P1, *P2, *P3, *P4;         /* normalised, [n_nu][n_mu] */
+    double *P1_cdf, *P2_cdf;            /* [n_nu][n_mu] */
+    double *j_nu_var, *log10_j_nu_var;  /* [n_jnu] */
+    pdf_t *j_nu;                        /* [n_jnu] */
+    double e_min, e_max;                /* mean_opacities specific_energy range */
+    int have_e_range;
+    double *mo_e, *mo_chi_ross;
+} dust_t;
+
+typedef struct {
+    int type, spectrum_type, peeloff;
+    double luminosity, temperature, position[3];
+    pdf_t spectrum;
+} source_t;
+
+typedef struct {
+    orc_peeled_desc d;
+    double *theta, *phi;
+    angle_t *view;          /* [n_view] */
+    int n_orig, n_stokes;
+    double log10_nu_min, log10_nu_max, log10_ap_min, log10_ap_max;
+    double *sed, *sed2, *img, *img2;
+    size_t sed_size, img_size;
+} peeled_t;
+
+struct orc_state {
+    char err[512];
+    int n1, n2, n3;
+    size_t n_cells;
+    double *w[3], *ew[3];
+    int n[3];
+    double *volume;
+    orc_config cfg;
+    int n_dust, n_sources, n_peeled;
+    dust_t *dust;
+    source_t *src;
+    double *lum_pdf, *lum_cdf;
+    double energy_total;
+    peeled_t *peeled;
+    double *density;            /* [n_dust][n_cells] */
+    double *specific_energy;    /* [n_dust][n_cells] */
+    double *specific_energy_add;
+    double *specific_energy_sum;
+    int32_t *jnu_var_id;        /* [n_dust][n_cells] */
+    double *jnu_var_frac;
+    double energy_abs_tot[ORC_MAX_DUST];
+    /* pending accumulate totals */
+    orc_iter_stats pending;
+    int fatal;                  /* set by update_optconsts range error */
+};
+
+const char *orc_last_error(const orc_state *st) { return st ? st->err : g_error; }
+const char *orc_global_error(void) { return g_error; }
+const double *orc_specific_energy_sum(const orc_state *st) { return st->specific_energy_sum; }
+const double *orc_specific_energy(const orc_state *st) { return st->specific_energy; }
+const double *orc_density(const orc_state *st) { return st->density; }
+
+/* ------------------------------------------------------------------ */
+/* Dust set-up: dust_type_4elem.f90:78-293                              */
+/* ------------------------------------------------------------------ */
+
+static double *dup(const double *a, size_t n)
+{
+    double *r = malloc(sizeof(double) * (n ? n : 1));
+    if (a) memcpy(r, a, sizeof(double) * n);
+    return r;
+}
+
+static int dust_setup(dust_t *d, const orc_dust_desc *in, char *err)
+{
+    memset(d, 0, sizeof(*d));
+    d->n_nu = in->n_nu; d->n_mu = in->n_mu; d->n_jnu = in->n_jnu; d->n_enu = in->n_enu; d->n_e = in->n_e;
+    d->sublimation_mode = in->sublimation_mode; d->version = in->version;
+    d->sublimation_specific_energy = in->sublimation_specific_energy;
+    d->minimum_specific_energy = in->minimum_specific_energy;
+    int nn = d->n_nu, nm = d->n_mu;
+    d->nu = dup(in->nu, nn); d->albedo = dup(in->albedo, nn); d->chi = dup(in->chi, nn);
+    d->mu = dup(in->mu, nm);
+    size_t np = (size_t)nn * nm;
+    d->P1 = dup(in->P1, np); d->P2 = dup(in->P2, np); d->P3 = dup(in->P3, np); d->P4 = dup(in->P4, np);
+    d->zero_p2 = 1;
+    for (size_t i = 0; i < np; i++) if (d->P2[i] != 0.0) { d->zero_p2 = 0; break; }
+    d->mu_min = d->mu[0]; d->mu_max = d->mu[nm - 1];
+    double dmu = d->mu_max - d->mu_min;
+    /* :183-193 normalise so that the integral over mu is dmu */
+    for (int j = 0; j < nn; j++) {
+        double norm = integral_linlog(d->mu, d->P1 + (size_t)j * nm, nm);
+        if (norm == 0.0) { snprintf(err, 512, "P1 matrix normalization is zero"); return -1; }
+        for (int i = 0; i < nm; i++) {
+            size_t k = (size_t)j * nm + i;
+            d->P1[k] = d->P1[k] / norm * dmu; d->P2[k] = d->P2[k] / norm * dmu;
+            d->P3[k] = d->P3[k] / norm * dmu; d->P4[k] = d->P4[k] / norm * dmu;
+        }
+    }
+    /* :195-212 cumulative (trapezium) integrals, normalised to the last value */
+    d->P1_cdf = calloc(np, sizeof(double)); d->P2_cdf = calloc(np, sizeof(double));
+    for (int j = 0; j < nn; j++) {
+        double *c1 = d->P1_cdf + (size_t)j * nm, *c2 = d->P2_cdf + (size_t)j * nm;
+        const double *p1 = d->P1 + (size_t)j * nm, *p2 = d->P2 + (size_t)j * nm;
+        c1[0] = 0.0; c2[0] = 0.0;
+        for (int i = 1; i < nm; i++) {
+            double dx = d->mu[i] - d->mu[i - 1];
+            c1[i] = c1[i - 1] + 0.5 * (p1[i] + p1[i - 1]) * dx;
+            c2[i] = c2[i - 1] + 0.5 * (p2[i] + p2[i - 1]) * dx;
+        }
+        int all0 = 1; for (int i = 0; i < nm; i++) if (c1[i] != 0.0) all0 = 0;
+        if (!all0) { double l = c1[nm - 1]; for (int i = 0; i < nm; i++) c1[i] /= l; }
+        all0 = 1; for (int i = 0; i < nm; i++) if (c2[i] != 0.0) all0 = 0;
+        if (!all0) { double l = c2[nm - 1]; for (int i = 0; i < nm; i++) c2[i] /= l; }
+    }
+    /* :214-262 mean opacities: only the specific-energy range is used here */
+    if (in->n_e > 0 && in->mo_specific_energy) {
+        d->mo_e = dup(in->mo_specific_energy, in->n_e);
+        d->e_min = d->mo_e[0]; d->e_max = d->mo_e[in->n_e - 1]; d->have_e_range = 1;
+        if (in->mo_chi_rosseland) d->mo_chi_ross = dup(in->mo_chi_rosseland, in->n_e);
+    }
+    /* :264-291 emissivities */
+    d->j_nu_var = dup(in->emiss_var, d->n_jnu);
+    d->log10_j_nu_var = malloc(sizeof(double) * d->n_jnu);
+    for (int i = 0; i < d->n_jnu; i++) d->log10_j_nu_var[i] = log10(d->j_nu_var[i]);
+    d->j_nu = calloc(d->n_jnu, sizeof(pdf_t));
+    for (int i = 0; i < d->n_jnu; i++) {
+        if (pdf_set_log(&d->j_nu[i], in->emiss_nu, in->emiss_jnu + i, d->n_enu, d->n_jnu)) {
+            snprintf(err, 512, "emissivity %d has zero integral", i); return -1;
+        }
+    }
+    return 0;
+}
+
+static void dust_free(dust_t *d)
+{
+    free(d->nu); free(d->albedo); free(d->chi); free(d->mu);
+    free(d->P1); free(d->P2); free(d->P3); free(d->P4); free(d->P1_cdf); free(d->P2_cdf);
+    free(d->j_nu_var); free(d->log10_j_nu_var); free(d->mo_e); free(d->mo_chi_ross);
+    if (d->j_nu) { for (int i = 0; i < d->n_jnu; i++) pdf_free(&d->j_nu[i]); free(d->j_nu); }
+}
+
+/* dust_jnu_var_pos_frac: dust_type_4elem.f90:295-320 (0-based id) */
+static void dust_jnu_var_pos_frac(const dust_t *d, double e, int32_t *id, double *frac)
+{
+    int n = d->n_jnu;
+    if (e < d->j_nu_var[0]) { *id = 0; *frac = 0.0; }
+    else if (e > d->j_nu_var[n - 1]) { *id = n - 2; *frac = 1.0; }
+    else {
+        int j = locate(d->j_nu_var, n, e);
+        *id = j;
+        *frac = (log10(e) - d->log10_j_nu_var[j]) / (d->log10_j_nu_var[j + 1] - d->log10_j_nu_var[j]);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* grid_physics_3d.f90: check_energy_abs :555-603, update_energy_abs_tot
+ * :605-611, precompute_jnu_var :613-629, update_energy_abs :500-553,
+ * sublimate_dust :420-498                                             */
+/* ------------------------------------------------------------------ */
+
+static void update_energy_abs_tot(orc_state *st)
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        double s = 0.0;
+        const double *e = st->specific_energy + (size_t)d * st->n_cells;
+        const double *rho = st->density + (size_t)d * st->n_cells;
+        for (size_t ic = 0; ic < st->n_cells; ic++) s += e[ic] * rho[ic] * st->volume[ic];
+        st->energy_abs_tot[d] = s;
+    }
+}
+
+static void check_energy_abs(orc_state *st)
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        const dust_t *du = &st->dust[d];
+        double *e = st->specific_energy + (size_t)d * st->n_cells;
+        for (size_t ic = 0; ic < st->n_cells; ic++)
+            if (e[ic] < du->minimum_specific_energy) e[ic] = du->minimum_specific_energy;
+        if (st->cfg.enforce_energy_range && du->have_e_range) {
+            for (size_t ic = 0; ic < st->n_cells; ic++) {
+                if (e[ic] < du->e_min) e[ic] = du->e_min;
+                if (e[ic] > du->e_max) e[ic] = du->e_max;
+            }
+        }
+    }
+    update_energy_abs_tot(st);
+}
+
+static void precompute_jnu_var(orc_state *st)
+{
+    for (int d = 0; d < st->n_dust; d++)
+        for (size_t ic = 0; ic < st->n_cells; ic++) {
+            size_t k = (size_t)d * st->n_cells + ic;
+            dust_jnu_var_pos_frac(&st->dust[d], st->specific_energy[k], &st->jnu_var_id[k], &st->jnu_var_frac[k]);
+        }
+}
+
+static double chi_rosseland(const dust_t *d, double e)
+{
+    return interp1d_loglog(d->mo_e, d->mo_chi_ross, d->n_e, e);
+}
+
+static void sublimate_dust(orc_state *st)
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        const dust_t *du = &st->dust[d];
+        double *e = st->specific_energy + (size_t)d * st->n_cells;
+        double *rho = st->density + (size_t)d * st->n_cells;
+        double es = du->sublimation_specific_energy;
+        switch (du->sublimation_mode) {
+        case 1:
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                if (e[ic] > es) { rho[ic] = 0.0; e[ic] = du->minimum_specific_energy; }
+            break;
+        case 2:
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                if (e[ic] > es) {
+                    double r = chi_rosseland(du, e[ic]) / chi_rosseland(du, es);
+                    rho[ic] = rho[ic] * es / e[ic] * r * r;
+                    e[ic] = es;
+                }
+            break;
+        case 3:
+            for (size_t ic = 0; ic < st->n_cells; ic++) if (e[ic] > es) e[ic] = es;
+            break;
+        default: break;
+        }
+    }
+    update_energy_abs_tot(st);
+    check_energy_abs(st);
+}
+
+static void update_energy_abs(orc_state *st, double scale)
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        double *e = st->specific_energy + (size_t)d * st->n_cells;
+        const double *s = st->specific_energy_sum + (size_t)d * st->n_cells;
+        for (size_t ic = 0; ic < st->n_cells; ic++) {
+            e[ic] = s[ic] * scale / st->volume[ic];
+            if (st->volume[ic] == 0.0) e[ic] = 0.0;
+        }
+    }
+    if (st->cfg.specific_energy_type == 1 && st->specific_energy_add) {
+        size_t n = (size_t)st->n_dust * st->n_cells;
+        for (size_t k = 0; k < n; k++) st->specific_energy[k] += st->specific_energy_add[k];
+    }
+    update_energy_abs_tot(st);
+    check_energy_abs(st);
+}
+
+/* ------------------------------------------------------------------ */
+/* create / destroy                                                    */
+/* ------------------------------------------------------------------ */
+
+static double spacing(double x)
+{
+    x = fabs(x);
+    if (x == 0.0) return DBL_MIN;
+    return nextafter(x, INFINITY) - x;
+}
+
+static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in);
+static void peeled_free(peeled_t *p);
+
+int orc_create(const orc_problem *pr, orc_state **out)
+{
+    g_error[0] = 0;
+    if (!pr || !out) { snprintf(g_error, sizeof g_error, "null argument"); return 1; }
+    if (pr->grid.type != 1) { snprintf(g_error, sizeof g_error, "grid is not cartesian"); return 1; }
+    if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
+    orc_state *st = calloc(1, sizeof(*st));
+    st->cfg = pr->config;
+    st->n1 = pr->grid.n1; st->n2 = pr->grid.n2; st->n3 = pr->grid.n3;
+    st->n[0] = st->n1; st->n[1] = st->n2; st->n[2] = st->n3;
+    st->n_cells = (size_t)st->n1 * st->n2 * st->n3;
+    const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
+    for (int a = 0; a < 3; a++) {
+        st->w[a] = dup(win[a], st->n[a] + 1);
+        st->ew[a] = malloc(sizeof(double) * (st->n[a] + 1));
+        /* grid_geometry_cartesian_3d.f90:130-132: ew = 3*spacing(w) */
+        for (int i = 0; i <= st->n[a]; i++) st->ew[a][i] = 3.0 * spacing(st->w[a][i]);
+        for (int i = 0; i < st->n[a]; i++)
+            if (!(st->w[a][i + 1] - st->w[a][i] > 0.0)) {
+                snprintf(g_error, sizeof g_error, "all d%c values should be greater than zero", "xyz"[a]);
+                orc_destroy(st); return 1;
+            }
+    }
+    st->volume = malloc(sizeof(double) * st->n_cells);
+    for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++)
+        st->volume[((size_t)k * st->n2 + j) * st->n1 + i] =
+            (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
+
+    st->n_dust = pr->n_dust;
+    st->dust = calloc(st->n_dust ? st->n_dust : 1, sizeof(dust_t));
+    for (int d = 0; d < st->n_dust; d++)
+        if (dust_setup(&st->dust[d], &pr->dust[d], g_error)) { orc_destroy(st); return 1; }
+
+    /* sources: source.f90:47-84, source_type.f90:102-322 */
+    st->n_sources = pr->n_sources;
+    st->src = calloc(st->n_sources ? st->n_sources : 1, sizeof(source_t));
+    st->lum_pdf = calloc(st->n_sources ? st->n_sources : 1, sizeof(double));
+    st->lum_cdf = calloc(st->n_sources ? st->n_sources : 1, sizeof(double));
+    st->energy_total = 0.0;
+    for (int i = 0; i < st->n_sources; i++) {
+        const orc_source_desc *s = &pr->sources[i];
+        source_t *t = &st->src[i];
+        t->type = s->type; t->spectrum_type = s->spectrum_type; t->peeloff = s->peeloff;
+        t->luminosity = s->luminosity; t->temperature = s->temperature;
+        memcpy(t->position, s->position, sizeof t->position);
+        if (s->type != 1) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        if (s->spectrum_type == 1) {
+            for (int k = 0; k + 1 < s->n_spec; k++)
+                if (s->spec_nu[k + 1] < s->spec_nu[k]) {
+                    snprintf(g_error, sizeof g_error, "spectrum frequency should be monotonically increasing");
+                    orc_destroy(st); return 1;
+                }
+            if (pdf_set_log(&t->spectrum, s->spec_nu, s->spec_fnu, s->n_spec, 1)) {
+                snprintf(g_error, sizeof g_error, "source spectrum has zero integral"); orc_destroy(st); return 1;
+            }
+        } else if (s->spectrum_type != 2) {
+            snprintf(g_error, sizeof g_error, "Point source cannot have LTE spectrum"); orc_destroy(st); return 1;
+        }
+        st->energy_total += s->luminosity;
+    }
+    {
+        double c = 0.0;
+        for (int i = 0; i < st->n_sources; i++) {
+            st->lum_pdf[i] = st->src[i].luminosity / st->energy_total;
+            c += st->lum_pdf[i]; st->lum_cdf[i] = c;
+        }
+        if (st->n_sources) for (int i = 0; i < st->n_sources; i++) st->lum_cdf[i] /= c;
+    }
+
+    size_t ntot = (size_t)st->n_dust * st->n_cells;
+    st->density = dup(pr->density, ntot);
+    st->specific_energy = malloc(sizeof(double) * (ntot ? ntot : 1));
+    st->specific_energy_sum = calloc(ntot ? ntot : 1, sizeof(double));
+    st->jnu_var_id = calloc(ntot ? ntot : 1, sizeof(int32_t));
+    st->jnu_var_frac = calloc(ntot ? ntot : 1, sizeof(double));
+    /* grid_physics_3d.f90:176-253 */
+    if (pr->specific_energy) {
+        memcpy(st->specific_energy, pr->specific_energy, sizeof(double) * ntot);
+        if (st->cfg.specific_energy_type == 1) {
+            st->specific_energy_add = dup(pr->specific_energy, ntot);
+            for (int d = 0; d < st->n_dust; d++)
+                for (size_t ic = 0; ic < st->n_cells; ic++)
+                    st->specific_energy[(size_t)d * st->n_cells + ic] = st->dust[d].minimum_specific_energy;
+        }
+    } else {
+        if (st->cfg.specific_energy_type == 1) {
+            snprintf(g_error, sizeof g_error, "cannot specify specific_energy_type since specific_energy was not given");
+            orc_destroy(st); return 1;
+        }
+        for (int d = 0; d < st->n_dust; d++)
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                st->specific_energy[(size_t)d * st->n_cells + ic] = st->dust[d].minimum_specific_energy;
+    }
+    check_energy_abs(st);
+
+    st->n_peeled = pr->n_peeled;
+    st->peeled = calloc(st->n_peeled ? st->n_peeled : 1, sizeof(peeled_t));
+    for (int g = 0; g < st->n_peeled; g++)
+        if (peeled_setup(st, &st->peeled[g], &pr->peeled[g])) { orc_destroy(st); return 1; }
+    *out = st;
+    return 0;
+}
+
+void orc_destroy(orc_state *st)
+{
+    if (!st) return;
+    for (int a = 0; a < 3; a++) { free(st->w[a]); free(st->ew[a]); }
+    free(st->volume);
+    if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
+    if (st->src) {
+        for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
+        free(st->src);
+    }
+    if (st->peeled) { for (int g = 0; g < st->n_peeled; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
+    free(st->lum_pdf); free(st->lum_cdf);
+    free(st->density); free(st->specific_energy); free(st->specific_energy_add);
+    free(st->specific_energy_sum); free(st->jnu_var_id); free(st->jnu_var_frac);
+    free(st);
+}
+
+/* ------------------------------------------------------------------ */
+/* Photon packet: src/core/type_photon.f90:14-73                        */
+/* ------------------------------------------------------------------ */
+
+enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
+
+typedef struct {
+    double r[3], v[3];
+    angle_t a;
+    double s[4];
+    double nu, energy;
+    int ic[3];          /* 0-based cell indices */
+    int on_wall[3];     /* -1 lower wall, +1 upper wall, 0 none */
+    int in_cell, killed;
+    double chi[ORC_MAX_DUST], albedo[ORC_MAX_DUST], kappa[ORC_MAX_DUST];
+    int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id;
+    angle_t a_prev; double s_prev[4], v_prev[3];
+} photon_t;
+
+typedef struct {
+    double *sum;        /* thread-local specific_energy_sum or NULL (noenergy) */
+    uint64_t killed_geo, killed_int, crossings, interactions;
+    double energy_current;
+    int fatal; char err[256];
+    /* thread-local image accumulators (final iteration) */
+    double **sed, **sed2, **img, **img2;
+} acc_t;
+
+/* update_optconsts: dust.f90:64-79 */
+static int update_optconsts(const orc_state *st, photon_t *p, acc_t *acc)
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        const dust_t *du = &st->dust[d];
+        if (p->nu < du->nu[0] || p->nu > du->nu[du->n_nu - 1]) {
+            if (!acc->fatal) {
+                acc->fatal = 1;
+                snprintf(acc->err, sizeof acc->err,
+                         "photon frequency (%10.4E Hz) is outside the range defined for the dust optical properties (%10.4E to %10.4E Hz)",
+                         p->nu, du->nu[0], du->nu[du->n_nu - 1]);
+            }
+            p->killed = 1;
+            return -1;
+        }
+        p->chi[d] = interp1d_loglog(du->nu, du->chi, du->n_nu, p->nu);
+        p->albedo[d] = interp1d_loglog(du->nu, du->albedo, du->n_nu, p->nu);
+        p->kappa[d] = p->chi[d] * (1.0 - p->albedo[d]);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Cartesian geometry: grid_geometry_cartesian_3d.f90                   */
+/* ------------------------------------------------------------------ */
+
+static inline size_t cell_index(const orc_state *st, const int ic[3])
+{
+    return ((size_t)ic[2] * st->n2 + ic[1]) * st->n1 + ic[0];
+}
+
+/* escaped_cell :267-275 */
+static inline int escaped(const orc_state *st, const int ic[3])
+{
+    return ic[0] < 0 || ic[0] >= st->n1 || ic[1] < 0 || ic[1] >= st->n2 || ic[2] < 0 || ic[2] >= st->n3;
+}
+
+/* find_cell :143-166 ; returns 0 if outside */
+static int find_cell(const orc_state *st, const double r[3], int ic[3])
+{
+    for (int a = 0; a < 3; a++) {
+        int i = locate(st->w[a], st->n[a] + 1, r[a]);
+        if (i < 0 || i >= st->n[a]) return 0;
+        ic[a] = i;
+    }
+    return 1;
+}
+
+/* adjust_wall :168-232 */
+static void adjust_wall(const orc_state *st, photon_t *p)
+{
+    for (int a = 0; a < 3; a++) {
+        p->on_wall[a] = 0;
+        const double *w = st->w[a];
+        int i = p->ic[a];
+        if (p->v[a] > 0.0) {
+            if (p->r[a] == w[i]) p->on_wall[a] = -1;
+            else if (p->r[a] == w[i + 1]) { p->on_wall[a] = -1; p->ic[a] = i + 1; }
+        } else if (p->v[a] < 0.0) {
+            if (p->r[a] == w[i]) { p->on_wall[a] = +1; p->ic[a] = i - 1; }
+            else if (p->r[a] == w[i + 1]) p->on_wall[a] = +1;
+        }
+    }
+}
+
+/* place_in_cell :234-253 */
+static void place_in_cell(const orc_state *st, photon_t *p, acc_t *acc)
+{
+    if (!find_cell(st, p->r, p->ic)) {
+        acc->killed_geo++; p->killed = 1;
+    } else {
+        p->in_cell = 1;
+        adjust_wall(st, p);
+    }
+}
+
+/* in_correct_cell :330-381 */
+static int in_correct_cell(const orc_state *st, const photon_t *p)
+{
+    int act[3];
+    int found = find_cell(st, p->r, act);
+    const double thr = 1e-3;
+    int on_wall = p->on_wall[0] || p->on_wall[1] || p->on_wall[2];
+    if (on_wall) {
+        int ok = 1;
+        for (int a = 0; a < 3; a++) {
+            const double *w = st->w[a];
+            int i = p->ic[a];
+            if (p->on_wall[a] == -1) {
+                double f = (p->r[a] - w[i]) / (w[i + 1] - w[i]);
+                ok = ok && fabs(f) < thr;
+            } else if (p->on_wall[a] == +1) {
+                double f = (p->r[a] - w[i + 1]) / (w[i + 1] - w[i]);
+                ok = ok && fabs(f) < thr;
+            } else {
+                ok = ok && found && act[a] == i;
+            }
+        }
+        return ok;
+    }
+    return found && act[0] == p->ic[0] && act[1] == p->ic[1] && act[2] == p->ic[2];
+}
+
+/* find_wall :424-521 with insert_t :482-512.  Returns 0 if no wall. */
+static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    double tmin = DBL_MAX, emin = 0.0;
+    int imin[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++) {
+        const double *w = st->w[a], *ew = st->ew[a];
+        int i = p->ic[a];
+        for (int side = 0; side < 2; side++) {
+            int dir = side ? +1 : -1;
+            if (p->on_wall[a] == dir) continue;
+            int iw = i + side;
+            double t = (w[iw] - p->r[a]) / p->v[a];
+            double e = ew[iw];
+            if (t > 0.0) {
+                double emax = e > emin ? e : emin;
+                if (t < tmin - emax) {
+                    tmin = t; imin[0] = imin[1] = imin[2] = 0; emin = emax; imin[a] = dir;
+                } else if (t < tmin + emax) {
+                    emin = emax; imin[a] = dir;
+                }
+            }
+        }
+    }
+    *tnearest = tmin;
+    id_min[0] = imin[0]; id_min[1] = imin[1]; id_min[2] = imin[2];
+    return imin[0] || imin[1] || imin[2];
+}
+
+/* ------------------------------------------------------------------ */
+/* grid_integrate: grid_propagate_3d.f90:35-234 (deposit != NULL) and
+ * grid_integrate_noenergy :237-375 (deposit == NULL)                   */
+/* ------------------------------------------------------------------ */
+
+static void grid_integrate(const orc_state *st, photon_t *p, double tau_required,
+                           rng_t *g, acc_t *acc, double *deposit)
+{
+    double tau_achieved = 0.0;
+    if (escaped(st, p->ic)) return;
+    if (tau_required == 0.0) return;
+    uint64_t thr = (uint64_t)(st->cfg.propagation_check_frequency * 4294967296.0);
+    for (;;) {
+        if ((uint64_t)rng_check_u32(g) < thr) {
+            if (!in_correct_cell(st, p)) { acc->killed_geo++; p->killed = 1; return; }
+        }
+        double tau_needed = tau_required - tau_achieved;
+        double tmin; int id_min[3];
+        if (!find_wall(st, p, &tmin, id_min)) { acc->killed_geo++; p->killed = 1; return; }
+        size_t ic = cell_index(st, p->ic);
+        double chi_rho_total = 0.0;
+        for (int d = 0; d < st->n_dust; d++) chi_rho_total += p->chi[d] * st->density[(size_t)d * st->n_cells + ic];
+        double tau_cell = chi_rho_total * tmin;
+        acc->crossings++;
+        if (tau_cell < tau_needed) {
+            for (int a = 0; a < 3; a++) p->r[a] = p->r[a] + tmin * p->v[a];
+            tau_achieved += tau_cell;
+            if (deposit)
+                for (int d = 0; d < st->n_dust; d++)
+                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
+                        deposit[(size_t)d * st->n_cells + ic] += tmin * p->kappa[d] * p->energy;
+            for (int a = 0; a < 3; a++) { p->ic[a] += id_min[a]; p->on_wall[a] = -id_min[a]; }
+            if (escaped(st, p->ic)) return;
+        } else {
+            double tact = tmin * (tau_needed / tau_cell);
+            for (int a = 0; a < 3; a++) p->r[a] = p->r[a] + tact * p->v[a];
+            tau_achieved += tau_needed;
+            p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
+            if (deposit)
+                for (int d = 0; d < st->n_dust; d++)
+                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
+                        deposit[(size_t)d * st->n_cells + ic] += tact * p->kappa[d] * p->energy;
+            return;
+        }
+    }
+}
+
+/* grid_escape_tau: grid_propagate_3d.f90:377-480 -- optical depth from the
+ * packet to the grid edge (or tmax) along its direction; works on a copy. */
+static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, double tmax,
+                              rng_t *g, acc_t *acc, int *killed)
+{
+    photon_t p = *p_orig;
+    double tau = 0.0, t_achieved = 0.0;
+    *killed = 0;
+    if (escaped(st, p.ic)) return 0.0;
+    uint64_t thr = (uint64_t)(st->cfg.propagation_check_frequency * 4294967296.0);
+    for (;;) {
+        if ((uint64_t)rng_check_u32(g) < thr) {
+            if (!in_correct_cell(st, &p)) { acc->killed_geo++; *killed = 1; return tau; }
+        }
+        double tmin; int id_min[3];
+        if (!find_wall(st, &p, &tmin, id_min)) { acc->killed_geo++; *killed = 1; return tau; }
+        size_t ic = cell_index(st, p.ic);
+        int finished = 0;
+        if (t_achieved + tmin > tmax) { tmin = tmax - t_achieved; finished = 1; }
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
+        t_achieved += tmin;
+        for (int d = 0; d < st->n_dust; d++) tau += p.chi[d] * st->density[(size_t)d * st->n_cells + ic] * tmin;
+        acc->crossings++;
+        if (finished) return tau;
+        for (int a = 0; a < 3; a++) { p.ic[a] += id_min[a]; p.on_wall[a] = -id_min[a]; }
+        if (escaped(st, p.ic)) return tau;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* Sources: source.f90:100-179, source_type.f90:398-564                 */
+/* ------------------------------------------------------------------ */
+
+/* fortranlib random_planck_frequency: Carter & Cashwell (1975) sampling of
+ * x = h nu / k T from the Planck function (5 uniforms). */
+static double random_planck_frequency(rng_t *g, double T)
+{
+    double xi0 = rng_uniform(g);
+    double target = xi0 * (PI * PI * PI * PI / 90.0);
+    double sum = 0.0; int m = 0;
+    do { m++; sum += 1.0 / ((double)m * m * m * m); } while (sum < target && m < 1000);
+    double x1 = rng_uniform(g), x2 = rng_uniform(g), x3 = rng_uniform(g), x4 = rng_uniform(g);
+    double x = -log((1.0 - x1) * (1.0 - x2) * (1.0 - x3) * (1.0 - x4)) / (double)m;
+    return x * K_CGS * T / H_CGS;
+}
+
+static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
+{
+    memset(p, 0, sizeof(*p));
+    int is = 0;
+    if (st->n_sources > 1) {
+        double xi = rng_uniform(g);
+        if (st->cfg.sample_sources_evenly) is = (int)(xi * st->n_sources);
+        else is = sample_discrete(st->lum_cdf, st->n_sources, xi);
+    }
+    p->source_id = is;
+    const source_t *s = &st->src[is];
+    /* emit_from_point :539-564 */
+    p->r[0] = s->position[0]; p->r[1] = s->position[1]; p->r[2] = s->position[2];
+    random_sphere_angle(g, &p->a);
+    p->s[0] = 1.0; p->s[1] = p->s[2] = p->s[3] = 0.0;
+    p->last_isotropic = 1;
+    p->energy = 1.0;
+    if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
+    else p->nu = random_planck_frequency(g, s->temperature);
+    angle_to_vector(&p->a, p->v);
+    if (st->cfg.sample_sources_evenly) p->energy = p->energy * st->lum_pdf[is] * st->n_sources;
+    acc->energy_current += p->energy;
+    if (update_optconsts(st, p, acc)) return -1;
+    p->last = LAST_SR;
+    p->a_prev = p->a; memcpy(p->s_prev, p->s, sizeof p->s); memcpy(p->v_prev, p->v, sizeof p->v);
+    place_in_cell(st, p, acc);
+    if (p->killed) {
+        if (!acc->fatal) {
+            acc->fatal = 1;
+            snprintf(acc->err, sizeof acc->err,
+                     "photon was not emitted inside a cell - this usually indicates that a source is not inside the grid");
+        }
+        return -1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Dust interaction: dust_interact.f90:22-79, dust_type_4elem.f90       */
+/* ------------------------------------------------------------------ */
+
+/* dust_sample_j_nu :379-398 */
+static double dust_sample_j_nu(const dust_t *d, int id, double frac, double xi)
+{
+    double nu1 = pdf_sample_log(&d->j_nu[id], xi);
+    double nu2 = pdf_sample_log(&d->j_nu[id + 1], xi);
+    return pow(10.0, log10(nu1) + frac * (log10(nu2) - log10(nu1)));
+}
+
+/* scatter_stokes :603-690 */
+static void scatter_stokes(double s[4], const angle_t *a_coord, const angle_t *a_scat,
+                           const angle_t *a_final, double P1, double P2, double P3, double P4)
+{
+    double cos_a = a_coord->cost, sin_a = a_coord->sint;
+    double cos_b = a_scat->cost, sin_b = a_scat->sint;
+    double cos_c = a_final->cost, sin_c = a_final->sint;
+    double cos_big_b = a_coord->cosp * a_final->cosp + a_coord->sinp * a_final->sinp;
+    double cos_big_c = a_scat->cosp, sin_big_c = fabs(a_scat->sinp);
+    double cos_big_a, sin_big_a;
+    if (sin_big_c < 10.0 * DBL_MIN && sin_c < 10.0 * DBL_MIN) {
+        cos_big_a = -cos_big_b * cos_big_c;
+        sin_big_a = sqrt(1.0 - cos_big_a * cos_big_a);
+    } else {
+        cos_big_a = (cos_a - cos_b * cos_c) / (sin_b * sin_c);
+        sin_big_a = sin_big_c * sin_a / sin_c;
+    }
+    double cos_i2 = cos_big_a, sin_i2 = sin_big_a;
+    double cos_2_i2 = 1.0 - 2.0 * sin_i2 * sin_i2;
+    double sin_2_i2 = 2.0 * sin_i2 * cos_i2;
+    double cos_2_alpha = 1.0 - 2.0 * a_scat->sinp * a_scat->sinp;
+    double sin_2_alpha = -2.0 * a_scat->sinp * a_scat->cosp;
+    double cos_2_beta = cos_2_i2, sin_2_beta;
+    if (a_scat->sinp < 0.0) sin_2_beta = sin_2_i2; else sin_2_beta = -sin_2_i2;
+    double I = s[0], Q = s[1], U = s[2], V = s[3];
+    double RLS1 = P1 * I + P2 * (cos_2_alpha * Q + sin_2_alpha * U);
+    double RLS2 = P2 * I + P1 * (cos_2_alpha * Q + sin_2_alpha * U);
+    double RLS3 = -P4 * V + P3 * (-sin_2_alpha * Q + cos_2_alpha * U);
+    double RLS4 = P3 * V + P4 * (-sin_2_alpha * Q + cos_2_alpha * U);
+    s[0] = RLS1;
+    s[1] = cos_2_beta * RLS2 + sin_2_beta * RLS3;
+    s[2] = -sin_2_beta * RLS2 + cos_2_beta * RLS3;
+    s[3] = RLS4;
+}
+
+/* dust_scatter :446-566 */
+static void dust_scatter(const dust_t *d, double nu, angle_t *a, double s[4], rng_t *g)
+{
+    angle_t a_scat, a_final;
+    random_sphere_angle(g, &a_scat);
+    double sin_2_i1 = 2.0 * a_scat.sinp * a_scat.cosp;
+    double cos_2_i1 = 1.0 - 2.0 * a_scat.sinp * a_scat.sinp;
+    double c1 = s[0], c2 = cos_2_i1 * s[1] - sin_2_i1 * s[2];
+    double ctot = c1 + c2;
+    c1 /= ctot; c2 /= ctot;
+    int nm = d->n_mu;
+    int inu = locate(d->nu, d->n_nu, nu);
+    double P1, P2, P3, P4;
+    if (inu == -1) {
+        P1 = 1.0; P2 = 0.0; P3 = 1.0; P4 = 0.0;
+    } else {
+        double xi = rng_uniform(g);
+        const double *C1 = d->P1_cdf + (size_t)inu * nm, *C2 = d->P2_cdf + (size_t)inu * nm;
+        int imin = 0, imax = nm - 1, imu = 0;
+        double cdf1 = 0, cdf2 = 1;
+        /* bisection of :508-536 (1-based imin=1, imax=n_mu there) */
+        for (int it = 0; it < 1000000; it++) {
+            imu = ((imax + 1) + (imin + 1)) / 2 - 1;
+            if (d->zero_p2) { cdf1 = C1[imu]; cdf2 = C1[imu + 1]; }
+            else { cdf1 = c1 * C1[imu] + c2 * C2[imu]; cdf2 = c1 * C1[imu + 1] + c2 * C2[imu + 1]; }
+            if (xi > cdf2) imin = imu;
+            else if (xi < cdf1) imax = imu;
+            else break;
+            if (imin == imax) break;
+        }
+        a_scat.cost = (xi - cdf1) / (cdf2 - cdf1) * (d->mu[imu + 1] - d->mu[imu]) + d->mu[imu];
+        a_scat.sint = sqrt(1.0 - a_scat.cost * a_scat.cost);
+        P1 = interp2d(d->mu, nm, d->nu, d->n_nu, d->P1, a_scat.cost, nu);
+        P2 = interp2d(d->mu, nm, d->nu, d->n_nu, d->P2, a_scat.cost, nu);
+        P3 = interp2d(d->mu, nm, d->nu, d->n_nu, d->P3, a_scat.cost, nu);
+        P4 = interp2d(d->mu, nm, d->nu, d->n_nu, d->P4, a_scat.cost, nu);
+    }
+    rotate_angle(&a_scat, a, &a_final);
+    scatter_stokes(s, a, &a_scat, &a_final, P1, P2, P3, P4);
+    *a = a_final;
+    double norm = 1.0 / s[0];
+    s[0] = 1.0; s[1] *= norm; s[2] *= norm; s[3] *= norm;
+}
+
+/* dust_scatter_peeloff :421-444 */
+static void dust_scatter_peeloff(const dust_t *d, double nu, angle_t *a, double s[4], const angle_t *a_req)
+{
+    angle_t a_scat;
+    difference_angle(a, a_req, &a_scat);
+    if (a_scat.cost < d->mu_min || a_scat.cost > d->mu_max) {
+        s[0] = s[1] = s[2] = s[3] = 0.0;
+    } else {
+        double P1 = interp2d(d->mu, d->n_mu, d->nu, d->n_nu, d->P1, a_scat.cost, nu);
+        double P2 = interp2d(d->mu, d->n_mu, d->nu, d->n_nu, d->P2, a_scat.cost, nu);
+        double P3 = interp2d(d->mu, d->n_mu, d->nu, d->n_nu, d->P3, a_scat.cost, nu);
+        double P4 = interp2d(d->mu, d->n_mu, d->nu, d->n_nu, d->P4, a_scat.cost, nu);
+        scatter_stokes(s, a, &a_scat, a_req, P1, P2, P3, P4);
+    }
+    *a = *a_req;
+}
+
+/* interact: dust_interact.f90:22-79 (+ select_dust_chi_rho grid_physics_3d.f90:87-99) */
+static void interact(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
+{
+    size_t ic = cell_index(st, p->ic);
+    int id = 0;
+    if (st->n_dust > 1) {
+        double cdf[ORC_MAX_DUST], c = 0.0;
+        for (int d = 0; d < st->n_dust; d++) { c += p->chi[d] * st->density[(size_t)d * st->n_cells + ic]; cdf[d] = c; }
+        for (int d = 0; d < st->n_dust; d++) cdf[d] /= c;
+        id = sample_discrete(cdf, st->n_dust, rng_uniform(g));
+    }
+    double albedo = p->albedo[id];
+    p->a_prev = p->a; memcpy(p->v_prev, p->v, sizeof p->v); memcpy(p->s_prev, p->s, sizeof p->s);
+    double xi = rng_uniform(g);
+    acc->interactions++;
+    if (xi > albedo) {
+        /* dust_emit :334-354 */
+        size_t k = (size_t)id * st->n_cells + ic;
+        p->nu = dust_sample_j_nu(&st->dust[id], st->jnu_var_id[k], st->jnu_var_frac[k], rng_uniform(g));
+        p->s[0] = 1.0; p->s[1] = p->s[2] = p->s[3] = 0.0;
+        random_sphere_angle(g, &p->a);
+        update_optconsts(st, p, acc);
+        p->scattered = 0; p->reprocessed = 1; p->last_isotropic = 1; p->dust_id = id; p->last = LAST_DE;
+    } else {
+        dust_scatter(&st->dust[id], p->nu, &p->a, p->s, g);
+        p->scattered = 1; p->last_isotropic = 0; p->dust_id = id; p->last = LAST_DS; p->n_scat++;
+    }
+    angle_to_vector(&p->a, p->v);
+}
+
+/* ------------------------------------------------------------------ */
+/* do_lucy: iter_lucy.f90:66-237                                        */
+/* ------------------------------------------------------------------ */
+
+static void lucy_packet(const orc_state *st, uint64_t id, int iter, acc_t *acc)
+{
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, (uint32_t)iter, id);
+    if (emit(st, &p, &g, acc)) return;
+    for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
+        double tau = rng_exp(&g);
+        grid_integrate(st, &p, tau, &g, acc, acc->sum);
+        if (p.killed || escaped(st, p.ic)) break;
+        if (inter == st->cfg.n_inter_max + 1) { acc->killed_int++; p.killed = 1; break; }
+        interact(st, &p, &g, acc);
+        if (p.killed) break; /* fatal frequency-range error */
+        p.killed = (st->cfg.kill_on_scatter && p.scattered) || (st->cfg.kill_on_absorb && !p.scattered);
+        if (p.killed) break;
+    }
+}
+
+static int resolve_threads(int n_threads)
+{
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+    return n_threads;
+#else
+    (void)n_threads; return 1;
+#endif
+}
+
+int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int iter,
+                        int n_threads, orc_iter_stats *stats)
+{
+    size_t ntot = (size_t)st->n_dust * st->n_cells;
+    int nt = resolve_threads(n_threads);
+    if ((uint64_t)nt > n_local && n_local > 0) nt = (int)n_local;
+    if (nt < 1) nt = 1;
+    memset(st->specific_energy_sum, 0, sizeof(double) * ntot);   /* grid_reset_energy */
+    precompute_jnu_var(st);                                      /* iter_lucy.f90:107 */
+    acc_t *accs = calloc(nt, sizeof(acc_t));
+    for (int t = 0; t < nt; t++) accs[t].sum = (t == 0) ? st->specific_energy_sum : calloc(ntot ? ntot : 1, sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        acc_t *acc = &accs[t];
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (int64_t i = 0; i < (int64_t)n_local; i++) {
+            if (acc->fatal) continue;
+            lucy_packet(st, first_id + (uint64_t)i, iter, acc);
+        }
+    }
+    memset(&st->pending, 0, sizeof st->pending);
+    int fatal = 0;
+    for (int t = 0; t < nt; t++) {
+        if (t > 0) {
+            for (size_t k = 0; k < ntot; k++) st->specific_energy_sum[k] += accs[t].sum[k];
+            free(accs[t].sum);
+        }
+        st->pending.energy_current += accs[t].energy_current;
+        st->pending.killed_geo += accs[t].killed_geo;
+        st->pending.killed_int += accs[t].killed_int;
+        st->pending.crossings += accs[t].crossings;
+        st->pending.interactions += accs[t].interactions;
+        if (accs[t].fatal && !fatal) { fatal = 1; snprintf(st->err, sizeof st->err, "%s", accs[t].err); }
+    }
+    st->pending.n_packets = n_local;
+    free(accs);
+    if (stats) *stats = st->pending;
+    return fatal;
+}
+
+int orc_lucy_finish(orc_state *st, double *specific_energy_out, orc_iter_stats *stats)
+{
+    if (!(st->pending.energy_current > 0.0)) { snprintf(st->err, sizeof st->err, "no energy emitted"); return 1; }
+    update_energy_abs(st, st->energy_total / st->pending.energy_current); /* iter_lucy.f90:224 */
+    sublimate_dust(st);                                                    /* :235 */
+    for (int d = 0; d < st->n_dust; d++) st->pending.energy_abs_tot[d] = st->energy_abs_tot[d];
+    if (specific_energy_out) memcpy(specific_energy_out, st->specific_energy, sizeof(double) * st->n_dust * st->n_cells);
+    if (stats) *stats = st->pending;
+    return 0;
+}
+
+int orc_lucy_iteration(orc_state *st, uint64_t n_packets, int iter, int n_threads,
+                       double *specific_energy_out, orc_iter_stats *stats)
+{
+    if (n_packets == 0) return 0;
+    int rc = orc_lucy_accumulate(st, 0, n_packets, iter, n_threads, NULL);
+    if (rc) return rc;
+    return orc_lucy_finish(st, specific_energy_out, stats);
+}
+
+/* ------------------------------------------------------------------ */
+/* Peel-off imaging: images_peeled.f90:95-270, image_type.f90          */
+/* ------------------------------------------------------------------ */
+
+#define C_CGS 29979245800.0
+
+static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
+{
+    memset(p, 0, sizeof *p);
+    p->d = *in;
+    if (in->inside_observer) { snprintf(g_error, sizeof g_error, "inside observers not supported by the oracle"); return 1; }
+    p->theta = dup(in->theta, in->n_view); p->phi = dup(in->phi, in->n_view);
+    p->d.theta = p->theta; p->d.phi = p->phi;
+    p->view = malloc(sizeof(angle_t) * in->n_view);
+    for (int i = 0; i < in->n_view; i++) {
+        /* angle3d_deg(theta, phi) */
+        double t = in->theta[i] * PI / 180.0, f = in->phi[i] * PI / 180.0;
+        p->view[i].cost = cos(t); p->view[i].sint = sin(t); p->view[i].cosp = cos(f); p->view[i].sinp = sin(f);
+    }
+    p->n_stokes = in->compute_stokes ? 4 : 1;
+    /* image_type.f90:283-300 */
+    switch (in->track_origin) {
+    case 0: p->n_orig = 1; break;
+    case 1: p->n_orig = 4; break;
+    case 2: p->n_orig = 2 * (st->n_sources + st->n_dust); break;
+    case 3: p->n_orig = 2 * (in->track_n_scat + 2); break;
+    default: snprintf(g_error, sizeof g_error, "unknown track_origin"); return 1;
+    }
+    p->log10_nu_min = log10(in->nu_min); p->log10_nu_max = log10(in->nu_max);
+    if (in->compute_sed) {
+        p->log10_ap_min = log10(in->ap_min); p->log10_ap_max = log10(in->ap_max);
+        p->sed_size = (size_t)p->n_stokes * p->n_orig * in->n_view * in->n_ap * in->n_nu;
+        p->sed = calloc(p->sed_size, sizeof(double)); p->sed2 = calloc(p->sed_size, sizeof(double));
+    }
+    if (in->compute_image) {
+        p->img_size = (size_t)p->n_stokes * p->n_orig * in->n_view * in->n_y * in->n_x * in->n_nu;
+        p->img = calloc(p->img_size, sizeof(double)); p->img2 = calloc(p->img_size, sizeof(double));
+    }
+    return 0;
+}
+
+static void peeled_free(peeled_t *p)
+{
+    free(p->theta); free(p->phi); free(p->view); free(p->sed); free(p->sed2); free(p->img); free(p->img2);
+}
+
+int orc_peeled_n_orig(const orc_state *st, int g) { return st->peeled[g].n_orig; }
+const double *orc_peeled_sed(const orc_state *st, int g) { return st->peeled[g].sed; }
+const double *orc_peeled_img(const orc_state *st, int g) { return st->peeled[g].img; }
+const double *orc_peeled_sed2(const orc_state *st, int g) { return st->peeled[g].sed2; }
+const double *orc_peeled_img2(const orc_state *st, int g) { return st->peeled[g].img2; }
+
+/* fortranlib ipos(xmin, xmax, x, n): 1-based bin of x in n equal bins; here
+ * 0-based, -1 / n when outside (callers test the range). */
+static int ipos0(double xmin, double xmax, double x, int n)
+{
+    double f = (x - xmin) / (xmax - xmin);
+    if (f < 0.0) return -1;
+    int i = (int)floor(f * n);
+    if (f == 1.0) i = n - 1;
+    return i;
+}
+
+/* origin slot (0-based): image_type.f90:112-134 orig() and :442-465 */
+static int origin_slot(const orc_state *st, const peeled_t *pg, const photon_t *p)
+{
+    int o; /* 1 source, 2 dust, 3 scattered source, 4 scattered dust */
+    if (p->scattered) o = p->reprocessed ? 4 : 3; else o = p->reprocessed ? 2 : 1;
+    switch (pg->d.track_origin) {
+    case 0: return 0;
+    case 1: return o - 1;
+    case 2:
+        /* detailed: [source emit per source | dust emit per dust | source scat per source | dust scat per dust] */
+        switch (o) {
+        case 1: return p->source_id;
+        case 2: return st->n_sources + p->dust_id;
+        case 3: return st->n_sources + st->n_dust + p->source_id;
+        default: return 2 * st->n_sources + st->n_dust + p->dust_id;
+        }
+    case 3: {
+        int ns = p->n_scat < pg->d.track_n_scat + 1 ? p->n_scat : pg->d.track_n_scat + 1;
+        return (p->reprocessed ? (pg->d.track_n_scat + 2) : 0) + ns;
+    }
+    }
+    return 0;
+}
+
+/* image_bin :408-524 */
+static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_image, double y_image,
+                      int iv, acc_t *acc)
+{
+    const peeled_t *pg = &st->peeled[ig];
+    const orc_peeled_desc *d = &pg->d;
+    int inu = ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
+    if (inu < 0 || inu >= d->n_nu) return;
+    int io = origin_slot(st, pg, p);
+    int ns = pg->n_stokes;
+    if (d->compute_image) {
+        int ix = ipos0(d->x_min, d->x_max, x_image, d->n_x);
+        int iy = ipos0(d->y_min, d->y_max, y_image, d->n_y);
+        if (ix >= 0 && ix < d->n_x && iy >= 0 && iy < d->n_y) {
+            for (int is = 0; is < ns; is++) {
+                size_t k = (((((size_t)is * pg->n_orig + io) * d->n_view + iv) * d->n_y + iy) * d->n_x + ix) * d->n_nu + inu;
+                double val = p->s[is] * p->energy;
+                acc->img[ig][k] += val;
+                if (d->uncertainties) acc->img2[ig][k] += val * val;
+            }
+        }
+    }
+    if (d->compute_sed) {
+        /* find_sed_bin :337-356 */
+        double lr = log10(sqrt(x_image * x_image + y_image * y_image));
+        int ir;
+        if (lr < pg->log10_ap_min || d->n_ap == 1) ir = 0;
+        else ir = ipos0(pg->log10_ap_min, pg->log10_ap_max, lr, d->n_ap - 1) + 1;
+        if (ir >= 0 && ir < d->n_ap) {
+            for (int is = 0; is < ns; is++) {
+                size_t k = ((((size_t)is * pg->n_orig + io) * d->n_view + iv) * d->n_ap + ir) * d->n_nu + inu;
+                double val = p->s[is] * p->energy;
+                acc->sed[ig][k] += val;
+                if (d->uncertainties) acc->sed2[ig][k] += val * val;
+            }
+        }
+    }
+}
+
+/* in_image :374-406 */
+static int in_image(const peeled_t *pg, double x, double y)
+{
+    const orc_peeled_desc *d = &pg->d;
+    if (d->compute_image) {
+        if ((x >= d->x_min && x <= d->x_max) || (x <= d->x_min && x >= d->x_max))
+            if ((y >= d->y_min && y <= d->y_max) || (y <= d->y_min && y >= d->y_max)) return 1;
+    }
+    if (d->compute_sed && x * x + y * y <= d->ap_max * d->ap_max) return 1;
+    return 0;
+}
+
+/* peeloff_photon :95-270 (external observers) */
+static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g, acc_t *acc)
+{
+    for (int ig = 0; ig < st->n_peeled; ig++) {
+        const peeled_t *pg = &st->peeled[ig];
+        for (int iv = 0; iv < pg->d.n_view; iv++) {
+            photon_t p = *p_orig;
+            memcpy(p.s, p.s_prev, sizeof p.s); p.a = p.a_prev; memcpy(p.v, p.v_prev, sizeof p.v);
+            angle_t a_req = pg->view[iv];
+            double v_req[3]; angle_to_vector(&a_req, v_req);
+            if (p.last_isotropic) {
+                p.s[0] = 1.0; p.s[1] = p.s[2] = p.s[3] = 0.0;
+                p.a = a_req; memcpy(p.v, v_req, sizeof v_req);
+            } else {
+                if (p.last == LAST_SR) {
+                    /* source_emit_peeloff: point sources are isotropic -> never here */
+                    p.a = a_req;
+                } else if (p.last == LAST_DS) {
+                    dust_scatter_peeloff(&st->dust[p.dust_id], p.nu, &p.a, p.s, &a_req);
+                } else {
+                    p.a = a_req;
+                }
+                angle_to_vector(&p.a, p.v);
+            }
+            p.killed = 0;
+            place_in_cell(st, &p, acc);
+            if (p.killed) continue;
+            double dd = -(v_req[0] * p.r[0] + v_req[1] * p.r[1] + v_req[2] * p.r[2]);
+            if (dd < pg->d.d_min || dd > pg->d.d_max) continue;
+            double dr[3] = {p.r[0] - pg->d.peeloff_origin[0], p.r[1] - pg->d.peeloff_origin[1], p.r[2] - pg->d.peeloff_origin[2]};
+            double x_image = dr[1] * p.a.cosp - dr[0] * p.a.sinp;
+            double y_image = dr[2] * p.a.sint - dr[1] * p.a.cost * p.a.sinp - dr[0] * p.a.cost * p.a.cosp;
+            if (!in_image(pg, x_image, y_image)) continue;
+            double tau = 0.0; int killed = 0;
+            if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, DBL_MAX, g, acc, &killed);
+            if (killed) continue;
+            double att = exp(-tau);
+            for (int k = 0; k < 4; k++) p.s[k] *= att;
+            image_bin(st, ig, &p, x_image, y_image, iv, acc);
+        }
+    }
+}
+
+/* forced_interaction_wr99: forced_interaction.f90:23-58 */
+static void forced_interaction_wr99(double tau_escape, double xi, double *tau, double *weight)
+{
+    double ome = tau_escape > 1e-7 ? 1.0 - exp(-tau_escape) : tau_escape;
+    *tau = -log(1.0 - xi * ome);
+    *weight = ome;
+}
+
+/* forced_interaction_baes16: forced_interaction.f90:60-133 */
+static void forced_interaction_baes16(double tau_escape, double bxi, double xi, double *tau, double *weight)
+{
+    double ome = tau_escape > 1e-7 ? 1.0 - exp(-tau_escape) : tau_escape;
+    double alpha = (1.0 - bxi) / ome, beta = bxi / tau_escape;
+    double tmin = 0.0, tmax = tau_escape, t = 0.0;
+    for (int i = 0; i < 60; i++) {
+        t = 0.5 * (tmin + tmax);
+        double test = t > 1e-7 ? alpha * (1.0 - exp(-t)) + beta * t : alpha * t + beta * t;
+        if (test > xi) tmax = t; else tmin = t;
+    }
+    t = 0.5 * (tmin + tmax);
+    *tau = t;
+    *weight = 1.0 / (alpha + beta * exp(t));
+}
+
+/* do_final + propagate: iter_final.f90:60-273 */
+static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
+{
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, 0x10000u, id);
+    if (emit(st, &p, &g, acc)) return;
+    if (st->n_peeled) peeloff_photon(st, &p, &g, acc);
+    for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
+        double tau;
+        if (inter == 1 && st->cfg.forced_first_interaction) {
+            int killed = 0;
+            double tau_escape = grid_escape_tau(st, &p, DBL_MAX, &g, acc, &killed);
+            if (tau_escape > 1e-10 && !killed) {
+                double weight, xi = rng_uniform(&g);
+                if (st->cfg.forced_first_interaction_algorithm == 2)
+                    forced_interaction_baes16(tau_escape, st->cfg.baes16_xi, xi, &tau, &weight);
+                else
+                    forced_interaction_wr99(tau_escape, xi, &tau, &weight);
+                p.energy *= weight;
+            } else tau = rng_exp(&g);
+        } else tau = rng_exp(&g);
+        grid_integrate(st, &p, tau, &g, acc, NULL);
+        if (p.killed || escaped(st, p.ic)) break;
+        if (inter == st->cfg.n_inter_max + 1) { acc->killed_int++; p.killed = 1; break; }
+        interact(st, &p, &g, acc);
+        if (p.killed) break;
+        p.killed = (st->cfg.kill_on_scatter && p.scattered) || (st->cfg.kill_on_absorb && !p.scattered);
+        if (p.killed) break;
+        if (st->n_peeled) peeloff_photon(st, &p, &g, acc);
+    }
+}
+
+int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
+{
+    int nt = resolve_threads(n_threads);
+    if ((uint64_t)nt > n_packets && n_packets > 0) nt = (int)n_packets;
+    if (nt < 1) nt = 1;
+    precompute_jnu_var(st); /* iter_final.f90:99 */
+    acc_t *accs = calloc(nt, sizeof(acc_t));
+    int ng = st->n_peeled;
+    for (int t = 0; t < nt; t++) {
+        accs[t].sed = calloc(ng ? ng : 1, sizeof(double *)); accs[t].sed2 = calloc(ng ? ng : 1, sizeof(double *));
+        accs[t].img = calloc(ng ? ng : 1, sizeof(double *)); accs[t].img2 = calloc(ng ? ng : 1, sizeof(double *));
+        for (int g = 0; g < ng; g++) {
+            peeled_t *pg = &st->peeled[g];
+            if (t == 0) {
+                if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
+                if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
+                accs[t].sed[g] = pg->sed; accs[t].sed2[g] = pg->sed2; accs[t].img[g] = pg->img; accs[t].img2[g] = pg->img2;
+            } else {
+                if (pg->sed) { accs[t].sed[g] = calloc(pg->sed_size, sizeof(double)); accs[t].sed2[g] = calloc(pg->sed_size, sizeof(double)); }
+                if (pg->img) { accs[t].img[g] = calloc(pg->img_size, sizeof(double)); accs[t].img2[g] = calloc(pg->img_size, sizeof(double)); }
+            }
+        }
+    }
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nt)
+#endif
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        acc_t *acc = &accs[t];
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 256)
+#endif
+        for (int64_t i = 0; i < (int64_t)n_packets; i++) {
+            if (acc->fatal) continue;
+            final_packet(st, (uint64_t)i, acc);
+        }
+    }
+    orc_iter_stats tot; memset(&tot, 0, sizeof tot);
+    int fatal = 0;
+    for (int t = 0; t < nt; t++) {
+        for (int g = 0; g < ng; g++) {
+            peeled_t *pg = &st->peeled[g];
+            if (t > 0) {
+                if (pg->sed) for (size_t k = 0; k < pg->sed_size; k++) { pg->sed[k] += accs[t].sed[g][k]; pg->sed2[k] += accs[t].sed2[g][k]; }
+                if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] += accs[t].img[g][k]; pg->img2[k] += accs[t].img2[g][k]; }
+                free(accs[t].sed[g]); free(accs[t].sed2[g]); free(accs[t].img[g]); free(accs[t].img2[g]);
+            }
+        }
+        free(accs[t].sed); free(accs[t].sed2); free(accs[t].img); free(accs[t].img2);
+        tot.energy_current += accs[t].energy_current;
+        tot.killed_geo += accs[t].killed_geo; tot.killed_int += accs[t].killed_int;
+        tot.crossings += accs[t].crossings; tot.interactions += accs[t].interactions;
+        if (accs[t].fatal && !fatal) { fatal = 1; snprintf(st->err, sizeof st->err, "%s", accs[t].err); }
+    }
+    tot.n_packets = n_packets;
+    free(accs);
+    if (fatal) return 1;
+    /* peeled_images_adjust_scale(energy_total/energy_current): image_type.f90:136-151 */
+    if (tot.energy_current > 0.0) {
+        double scale = st->energy_total / tot.energy_current;
+        for (int g = 0; g < ng; g++) {
+            peeled_t *pg = &st->peeled[g];
+            if (pg->sed) for (size_t k = 0; k < pg->sed_size; k++) { pg->sed[k] *= scale; pg->sed2[k] *= scale * scale; }
+            if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] *= scale; pg->img2[k] *= scale * scale; }
+        }
+    }
+    if (stats) *stats = tot;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* Probes for unit tests                                               */
+/* ------------------------------------------------------------------ */
+
+int orc_walk_ray(const orc_state *st, const double r0[3], const double v[3], double *path_out)
+{
+    photon_t p; acc_t acc; memset(&p, 0, sizeof p); memset(&acc, 0, sizeof acc);
+    memcpy(p.r, r0, sizeof p.r); memcpy(p.v, v, sizeof p.v);
+    place_in_cell(st, &p, &acc);
+    if (p.killed) return -1;
+    int n = 0; double path = 0.0;
+    while (!escaped(st, p.ic)) {
+        double tmin; int id_min[3];
+        if (!find_wall(st, &p, &tmin, id_min)) return -2;
+        for (int a = 0; a < 3; a++) { p.r[a] = p.r[a] + tmin * p.v[a]; p.ic[a] += id_min[a]; p.on_wall[a] = -id_min[a]; }
+        path += tmin; n++;
+        if (n > 100000000) return -3;
+    }
+    if (path_out) *path_out = path;
+    return n;
+}
+
+double orc_probe_uniform(int64_t seed, int iter, uint64_t packet_id, int k)
+{
+    rng_t g; rng_init(&g, seed, (uint32_t)iter, packet_id);
+    double x = 0; for (int i = 0; i <= k; i++) x = rng_uniform(&g);
+    return x;
+}
+
+void orc_probe_scatter(const orc_state *st, int dust, double nu, const double a_in[4], const double s_in[4],
+                       int64_t seed, uint64_t packet_id, double a_out[4], double s_out[4])
+{
+    rng_t g; rng_init(&g, seed, 1u, packet_id);
+    angle_t a = {a_in[0], a_in[1], a_in[2], a_in[3]};
+    double s[4] = {s_in[0], s_in[1], s_in[2], s_in[3]};
+    dust_scatter(&st->dust[dust], nu, &a, s, &g);
+    a_out[0] = a.cost; a_out[1] = a.sint; a_out[2] = a.cosp; a_out[3] = a.sinp;
+    memcpy(s_out, s, sizeof s);
+}
+
+double orc_probe_sample_jnu(const orc_state *st, int dust, int jid, double frac, double xi)
+{
+    return dust_sample_j_nu(&st->dust[dust], jid, frac, xi);
+}
+
+double orc_probe_planck(double T, int64_t seed, uint64_t packet_id)
+{
+    rng_t g; rng_init(&g, seed, 1u, packet_id);
+    return random_planck_frequency(&g, T);
+}
+
+void orc_probe_optconsts(const orc_state *st, int dust, double nu, double out3[3])
+{
+    const dust_t *du = &st->dust[dust];
+    out3[0] = interp1d_loglog(du->nu, du->chi, du->n_nu, nu);
+    out3[1] = interp1d_loglog(du->nu, du->albedo, du->n_nu, nu);
+    out3[2] = out3[0] * (1.0 - out3[1]);
+}

@@ -1,0 +1,208 @@
+/*
+ * hyp_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C, FP64) of the Hyperion Monte Carlo photon-packet
+ * path: src/main/iter_lucy.f90, src/main/iter_final.f90 and what they call
+ * under src/{core,grid,dust,sources,images} of the reference.  It is the
+ * parity checker for the HIP product path and the `cpu_baseline` leg of
+ * bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * may load this library; the product (hyperion_amd/) never does.
+ *
+ * Parity status: the reference Fortran cannot be built here (its `fortranlib`
+ * submodule, github.com/astrofrog/fortranlib @ unknown SHA, is absent), so the
+ * random-number stream and the fortranlib sampling/interpolation arithmetic are
+ * restated from their published behaviour ("parity unpinned at source level").
+ * The oracle IS pinned statistically against the reference's own golden
+ * outputs hyperion/model/tests/data/test_specific_energy.grid_type=car.*.rtout
+ * and test_peeloff.grid_type=car.*.rtout (see tests/test_oracle_golden.py).
+ *
+ * The descriptor structs below have the same memory layout as the product's
+ * include/hyperion_amd.h so one ctypes builder serves both; the two
+ * implementations share no code.
+ */
+#ifndef HYP_ORACLE_H
+#define HYP_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_DUST 8
+
+/* One dust species: raw tables exactly as stored in the .rtin /Dust/dust_NNN
+ * group (reader: src/dust/dust_type_4elem.f90:78-293). */
+typedef struct orc_dust_desc {
+    int32_t n_nu;               /* optical_properties rows */
+    int32_t n_mu;               /* scattering_angles rows */
+    int32_t n_jnu;              /* emissivity_variable rows */
+    int32_t n_enu;              /* emissivities rows (frequencies) */
+    int32_t n_e;                /* mean_opacities rows (0 if not supplied) */
+    int32_t sublimation_mode;   /* 0 no, 1 fast, 2 slow, 3 cap */
+    int32_t version;            /* dust file version attr */
+    int32_t is_lte;
+    double  sublimation_specific_energy;
+    double  minimum_specific_energy; /* Grid/Quantities attr, this species */
+    const double *nu;           /* [n_nu] */
+    const double *albedo;       /* [n_nu] */
+    const double *chi;          /* [n_nu] */
+    const double *mu;           /* [n_mu] */
+    const double *P1;           /* [n_nu][n_mu] */
+    const double *P2;
+    const double *P3;
+    const double *P4;
+    const double *emiss_nu;     /* [n_enu] */
+    const double *emiss_jnu;    /* [n_enu][n_jnu] */
+    const double *emiss_var;    /* [n_jnu] specific energies */
+    const double *mo_specific_energy; /* [n_e] or NULL */
+    const double *mo_chi_rosseland;   /* [n_e] or NULL (sublimation mode 2) */
+} orc_dust_desc;
+
+/* One source (reader: src/sources/source_type.f90:102-322). */
+typedef struct orc_source_desc {
+    int32_t type;          /* 1 point; (5 extern_sph, 6 extern_box: later) */
+    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
+    int32_t peeloff;
+    int32_t n_spec;
+    double  luminosity;
+    double  temperature;
+    double  position[3];
+    double  radius;
+    double  box[6];        /* xmin,xmax,ymin,ymax,zmin,zmax */
+    const double *spec_nu;  /* [n_spec] */
+    const double *spec_fnu; /* [n_spec] */
+} orc_source_desc;
+
+/* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */
+typedef struct orc_grid_desc {
+    int32_t type;          /* 1 = cartesian */
+    int32_t n1, n2, n3;
+    const double *w1;      /* [n1+1] */
+    const double *w2;      /* [n2+1] */
+    const double *w3;      /* [n3+1] */
+} orc_grid_desc;
+
+/* Run configuration: the root attributes of the .rtin
+ * (reader: src/main/setup_rt.f90:38-302). */
+typedef struct orc_config {
+    int64_t seed;                    /* negative int, default -124902 */
+    int64_t n_inter_max;
+    int64_t n_reabs_max;
+    int32_t kill_on_absorb;
+    int32_t kill_on_scatter;
+    int32_t sample_sources_evenly;
+    int32_t enforce_energy_range;
+    int32_t forced_first_interaction;
+    int32_t forced_first_interaction_algorithm; /* 1 wr99, 2 baes16 */
+    int32_t specific_energy_type;    /* 0 initial, 1 additional */
+    int32_t reserved0;
+    double  baes16_xi;
+    double  propagation_check_frequency;
+} orc_config;
+
+/* One peeled image group (reader: src/images/images_peeled.f90:272-380,
+ * src/images/image_type.f90:153-335). */
+typedef struct orc_peeled_desc {
+    int32_t n_view;
+    int32_t inside_observer;
+    int32_t ignore_optical_depth;
+    int32_t compute_image;
+    int32_t compute_sed;
+    int32_t n_x, n_y;
+    int32_t n_ap;
+    int32_t n_nu;
+    int32_t track_origin;    /* 0 no, 1 basic, 2 detailed, 3 scatterings */
+    int32_t track_n_scat;
+    int32_t uncertainties;
+    int32_t compute_stokes;
+    int32_t reserved0;
+    double  x_min, x_max, y_min, y_max;
+    double  ap_min, ap_max;
+    double  nu_min, nu_max;  /* Hz (converted from wav_max/wav_min) */
+    double  d_min, d_max;
+    double  peeloff_origin[3];
+    const double *theta;     /* [n_view] degrees */
+    const double *phi;       /* [n_view] degrees */
+} orc_peeled_desc;
+
+typedef struct orc_problem {
+    orc_grid_desc grid;
+    orc_config    config;
+    int32_t n_dust;
+    int32_t n_sources;
+    int32_t n_peeled;
+    int32_t reserved0;
+    const orc_dust_desc   *dust;     /* [n_dust] */
+    const orc_source_desc *sources;  /* [n_sources] */
+    const orc_peeled_desc *peeled;   /* [n_peeled] */
+    const double *density;           /* [n_dust][n_cells] (n_dust,nz,ny,nx) */
+    const double *specific_energy;   /* [n_dust][n_cells] or NULL */
+} orc_problem;
+
+typedef struct orc_iter_stats {
+    double   energy_current;   /* sum of emitted packet energies */
+    double   energy_abs_tot[ORC_MAX_DUST];
+    uint64_t killed_geo;
+    uint64_t killed_int;
+    uint64_t crossings;        /* cell-wall crossings + partial steps */
+    uint64_t interactions;     /* absorb+scatter events */
+    uint64_t n_packets;
+} orc_iter_stats;
+
+typedef struct orc_state orc_state;
+
+int  orc_create(const orc_problem *prob, orc_state **out);
+void orc_destroy(orc_state *st);
+const char *orc_last_error(const orc_state *st);
+const char *orc_global_error(void);
+
+/* One Lucy iteration (src/main/iter_lucy.f90:66-237) over packet ids
+ * [first_id, first_id+n_local) of an iteration with n_total packets.  `iter`
+ * is the 1-based Lucy iteration number (part of the RNG key).  With
+ * n_local==n_total this is the whole iteration incl. update_energy_abs;
+ * otherwise call orc_lucy_accumulate() + orc_lucy_finish(). */
+int orc_lucy_iteration(orc_state *st, uint64_t n_packets, int iter,
+                       int n_threads, double *specific_energy_out,
+                       orc_iter_stats *stats);
+int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local,
+                        int iter, int n_threads, orc_iter_stats *stats);
+int orc_lucy_finish(orc_state *st, double *specific_energy_out,
+                    orc_iter_stats *stats);
+/* raw accumulators after accumulate: [n_dust][n_cells] */
+const double *orc_specific_energy_sum(const orc_state *st);
+const double *orc_specific_energy(const orc_state *st);
+const double *orc_density(const orc_state *st);
+
+/* Final (imaging) iteration with peel-off (src/main/iter_final.f90:60-273).
+ * Image/SED cubes are returned scaled (image_scale) but not dnu-normalised;
+ * layout per group: sed[n_stokes][n_orig][n_view][n_ap][n_nu],
+ * img[n_stokes][n_orig][n_view][n_y][n_x][n_nu] (the .rtout layout). */
+int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads,
+                        orc_iter_stats *stats);
+int orc_peeled_n_orig(const orc_state *st, int group);
+const double *orc_peeled_sed(const orc_state *st, int group);
+const double *orc_peeled_img(const orc_state *st, int group);
+const double *orc_peeled_sed2(const orc_state *st, int group);
+const double *orc_peeled_img2(const orc_state *st, int group);
+
+/* Unit-level probes used by tests (known-answer checks). */
+void   orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2],
+                         uint32_t out[4]);
+int    orc_walk_ray(const orc_state *st, const double r0[3],
+                    const double v[3], double *path_out);
+double orc_probe_uniform(int64_t seed, int iter, uint64_t packet_id, int k);
+void   orc_probe_scatter(const orc_state *st, int dust, double nu,
+                         const double a_in[4], const double s_in[4],
+                         int64_t seed, uint64_t packet_id,
+                         double a_out[4], double s_out[4]);
+double orc_probe_sample_jnu(const orc_state *st, int dust, int jid,
+                            double frac, double xi);
+double orc_probe_planck(double T, int64_t seed, uint64_t packet_id);
+void   orc_probe_optconsts(const orc_state *st, int dust, double nu,
+                           double out3[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,209 @@
+#!/opt/conda/bin/python3.9
+"""Generate the golden fixtures under tests/golden/ by importing the REFERENCE
+Python front-end (hyperion-rt/hyperion at /root/reference) in this container.
+
+Run (only where /root/reference exists; the GPU box never runs this):
+
+    # one-off: stage an importable copy of the reference package
+    mkdir -p /tmp/hyp_probe && cp -r /root/reference/hyperion /root/reference/setup.py /tmp/hyp_probe/
+    echo "version = '0.9.12.dev0'" > /tmp/hyp_probe/hyperion/_version.py
+    (cd /tmp/hyp_probe && chmod -R u+w . && /opt/conda/bin/python3.9 setup.py build_ext --inplace)
+    # then
+    /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
+
+What it writes (all plain .npz, inputs + expected outputs only):
+
+  car_specific_energy.{evenly}.{multi}.npz
+      inputs : the model of hyperion/model/tests/test_bit_level.py:137-173
+               (TestBasic.test_specific_energy, grid_type='car'), built with the
+               reference classes, written with Model.write() and read back
+               from the .rtin with hyperion_amd.rtin.read_rtin
+      golden : iteration_0000{1..5}/specific_energy of the reference's own
+               committed regression output
+               hyperion/model/tests/data/test_specific_energy.grid_type=car.*.rtout
+  car_peeloff.{evenly}.npz
+      inputs : test_bit_level.py:175-236 (TestBasic.test_peeloff, 'car',
+               raytracing=False); golden: Peeled/group_0000{1,2,3}/{seds,images}
+               (+ _unc) and iteration_00005/specific_energy of
+               test_peeloff.grid_type=car.raytracing=False.*.rtout
+  test_dust.npz
+      the grey isotropic LTE test dust of hyperion/model/tests/test_helpers.py:14-18
+      (IsotropicDust([3e9,3e16],[.5,.5],[1,1]) + set_lte_emissivities(10,0.1,1600))
+      as written by the reference's SphericalDust.write(); also copied to
+      hyperion_amd/data/ for the benchmark configuration.
+"""
+import os
+import sys
+import tempfile
+import warnings
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.environ.get("HYPERION_REFERENCE_COPY", "/tmp/hyp_probe"))
+warnings.filterwarnings("ignore")
+
+import numpy as np
+
+# astropy 4.3 (the one in /opt/conda) predates the removal of these aliases
+for name, fn in [("asscalar", lambda a: a.item()), ("alen", lambda a: len(a))]:
+    if not hasattr(np, name):
+        setattr(np, name, fn)
+for name, t in [("float", float), ("int", int), ("bool", bool), ("object", object), ("str", str), ("complex", complex)]:
+    if not hasattr(np, name):
+        setattr(np, name, t)
+
+import h5py  # noqa: E402
+from hyperion.model import Model  # noqa: E402
+from hyperion.grid import CartesianGrid  # noqa: E402
+from hyperion.dust import IsotropicDust  # noqa: E402
+from hyperion.util.constants import pc, lsun  # noqa: E402
+
+from hyperion_amd.rtin import read_rtin, read_dust_group  # noqa: E402
+
+DATA = "/root/reference/hyperion/model/tests/data"
+DUST_FILE = os.path.join(DATA, "kmh_lite.hdf5")
+
+
+def car_grid_and_densities():
+    """test_bit_level.py:37-115 (setup_all_grid_types), Cartesian part only.
+    The random draws for the other grid types are consumed in the same order
+    so the Cartesian densities are the ones the reference test uses."""
+    u, d = pc, 1.0e-20
+    np.random.seed(141412)
+    x = np.linspace(-u, u, 8)
+    y = np.linspace(-u, u, 6)
+    z = np.linspace(-u, u, 4)
+    grid = CartesianGrid(x, y, z)
+    # AMR level 1 and 2 densities are drawn before the per-grid densities
+    for _ in range(3):
+        np.random.random((4, 6, 8))
+    for _ in range(3):
+        np.random.random((20, 6, 4))
+    shape_cyl = (6 - 1, 4 - 1, 8 - 1)
+    shape_sph = (4 - 1, 8 - 1, 6 - 1)
+    dens = []
+    for _ in range(3):
+        dens.append(np.random.random(grid.shape) * d)
+        np.random.random(shape_cyl)
+        np.random.random(shape_sph)
+        np.random.random(25)
+    return grid, dens
+
+
+def add_sources(m):
+    np.random.seed(12345)
+    for _ in range(5):
+        s = m.add_point_source()
+        s.luminosity = np.random.random() * lsun
+        s.temperature = np.random.uniform(2000., 10000.)
+        s.position = np.random.uniform(-pc, pc, 3)
+
+
+def write_and_read(m, tmp):
+    path = os.path.join(tmp, "model.rtin")
+    m.set_copy_input(False)
+    m.write(path, copy=False, absolute_paths=True)
+    return read_rtin(path)
+
+
+def save(path, prob, golden):
+    ptmp = path + ".problem.npz"
+    prob.to_npz(ptmp)
+    z = dict(np.load(ptmp))
+    os.remove(ptmp)
+    for k, v in golden.items():
+        z["golden/" + k] = v
+    np.savez_compressed(path, **z)
+    print("wrote", path, os.path.getsize(path))
+
+
+def main():
+    grid, dens = car_grid_and_densities()
+    with tempfile.TemporaryDirectory() as tmp:
+        # --- test_specific_energy -------------------------------------------
+        for evenly in (False, True):
+            for multi in (False, True):
+                m = Model()
+                m.set_grid(grid)
+                m.add_density_grid(dens[0], DUST_FILE)
+                if multi:
+                    m.add_density_grid(dens[1], DUST_FILE)
+                    m.add_density_grid(dens[2], DUST_FILE)
+                add_sources(m)
+                m.set_n_photons(initial=10000, imaging=0)
+                m.set_sample_sources_evenly(evenly)
+                m.conf.output.output_specific_energy = 'all'
+                prob = write_and_read(m, tmp)
+                ref = os.path.join(DATA, "test_specific_energy.grid_type=car.sample_sources_evenly=%s.multiple_densities=%s.rtout" % (evenly, multi))
+                with h5py.File(ref, "r") as f:
+                    assert f["iteration_00001/specific_energy"].attrs["geometry"].decode() == prob.geometry_id
+                    se = np.array([f["iteration_%05d/specific_energy" % i][...] for i in range(1, 6)])
+                    killed = np.array([[f["iteration_%05d" % i].attrs["killed_photons_geo"],
+                                        f["iteration_%05d" % i].attrs["killed_photons_int"]] for i in range(1, 6)])
+                save(os.path.join(HERE, "car_specific_energy.%s.%s.npz" % (evenly, multi)), prob,
+                     {"specific_energy": se, "killed": killed})
+
+        # --- test_peeloff (raytracing=False) ----------------------------------
+        for evenly in (False, True):
+            m = Model()
+            m.set_grid(grid)
+            m.add_density_grid(dens[0], DUST_FILE)
+            add_sources(m)
+            m.set_raytracing(False)
+            m.set_n_photons(initial=1000, imaging=5000)
+            m.set_sample_sources_evenly(evenly)
+            i_p = m.add_peeled_images()
+            i_p.set_wavelength_range(5, 0.05, 200.)
+            i_p.set_viewing_angles([33.4, 110.], [65.4, 103.2])
+            i_p.set_image_size(4, 5)
+            i_p.set_image_limits(-0.8 * pc, 0.8 * pc, -pc, pc)
+            i_p.set_aperture_radii(5, 0.1 * pc, pc)
+            i_p.set_stokes(True)
+            for track in ('basic', 'detailed'):
+                i_p = m.add_peeled_images()
+                i_p.set_wavelength_range(4, 0.05, 200.)
+                i_p.set_viewing_angles([22.1], [203.2])
+                i_p.set_image_size(6, 6)
+                i_p.set_image_limits(-pc, pc, -pc, pc)
+                i_p.set_aperture_radii(2, 0.5 * pc, pc)
+                i_p.set_track_origin(track)
+                i_p.set_stokes(True)
+            prob = write_and_read(m, tmp)
+            ref = os.path.join(DATA, "test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=%s.rtout" % evenly)
+            golden = {}
+            with h5py.File(ref, "r") as f:
+                for g in range(1, 4):
+                    grp = f["Peeled/group_%05d" % g]
+                    for name in ("seds", "images", "seds_unc", "images_unc"):
+                        if name in grp:
+                            golden["group%d/%s" % (g, name)] = grp[name][...]
+                    for k in ("numin", "numax", "apmin", "apmax"):
+                        golden["group%d/seds_%s" % (g, k)] = np.float64(grp["seds"].attrs[k])
+                    for k in ("numin", "numax", "xmin", "xmax", "ymin", "ymax"):
+                        golden["group%d/images_%s" % (g, k)] = np.float64(grp["images"].attrs[k])
+                n_it = int(f.attrs["iterations"])
+                golden["specific_energy_last"] = f["iteration_%05d/specific_energy" % n_it][...]
+            save(os.path.join(HERE, "car_peeloff.%s.npz" % evenly), prob, golden)
+
+        # --- grey isotropic test dust (test_helpers.py:14-18) -------------------
+        dust = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
+        dust.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)
+        dpath = os.path.join(tmp, "test_dust.hdf5")
+        dust.write(dpath)
+        with h5py.File(dpath, "r") as f:
+            d = read_dust_group(f)
+            mo = f["mean_opacities"][...]
+            extra = {"mo_temperature": np.asarray(mo["temperature"], dtype=float),
+                     "mo_kappa_planck": np.asarray(mo["kappa_planck"], dtype=float)}
+        arrays = {k: v for k, v in d.__dict__.items() if isinstance(v, np.ndarray)}
+        arrays.update(extra)
+        arrays["version"] = np.int64(d.version)
+        for out in (os.path.join(HERE, "test_dust.npz"), os.path.join(ROOT, "hyperion_amd", "data", "test_dust.npz")):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            np.savez_compressed(out, **arrays)
+            print("wrote", out, os.path.getsize(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""ctypes wrapper of the CPU oracle (oracle/hyp_oracle.c).  Test infrastructure:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hyperion_amd._abi import IterStats, MarshalledProblem, ProblemDesc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "build", "libhyp_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+
+
+def build_oracle(force=False):
+    src = os.path.join(ORACLE_DIR, "hyp_oracle.c")
+    hdr = os.path.join(ORACLE_DIR, "hyp_oracle.h")
+    stale = (not os.path.exists(ORACLE_SO)
+             or (os.path.exists(src) and max(os.path.getmtime(src), os.path.getmtime(hdr)) > os.path.getmtime(ORACLE_SO)))
+    if force or stale:
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"] + (["-B"] if force else []))
+    return ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build_oracle())
+        L.orc_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_void_p)]
+        L.orc_create.restype = C.c_int
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_destroy.restype = None
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_global_error.restype = C.c_char_p
+        L.orc_lucy_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, _dp, C.POINTER(IterStats)]
+        L.orc_lucy_accumulate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
+        L.orc_lucy_finish.argtypes = [C.c_void_p, _dp, C.POINTER(IterStats)]
+        for f in ("orc_specific_energy_sum", "orc_specific_energy", "orc_density"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = _dp
+        L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_peeled_n_orig.argtypes = [C.c_void_p, C.c_int]
+        for f in ("orc_peeled_sed", "orc_peeled_img", "orc_peeled_sed2", "orc_peeled_img2"):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+            getattr(L, f).restype = _dp
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.orc_philox4x32_10.restype = None
+        L.orc_walk_ray.argtypes = [C.c_void_p, _dp, _dp, _dp]
+        L.orc_probe_uniform.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int]
+        L.orc_probe_uniform.restype = C.c_double
+        L.orc_probe_scatter.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp, _dp, C.c_int64, C.c_uint64, _dp, _dp]
+        L.orc_probe_scatter.restype = None
+        L.orc_probe_sample_jnu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.orc_probe_sample_jnu.restype = C.c_double
+        L.orc_probe_planck.argtypes = [C.c_double, C.c_int64, C.c_uint64]
+        L.orc_probe_planck.restype = C.c_double
+        L.orc_probe_optconsts.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp]
+        L.orc_probe_optconsts.restype = None
+        _lib = L
+    return _lib
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+class Oracle:
+    """CPU oracle for one Problem (same call sequence as hyperion_amd.Engine)."""
+
+    def __init__(self, problem):
+        self.m = MarshalledProblem(problem)
+        self.problem = problem
+        self.h = C.c_void_p()
+        rc = lib().orc_create(C.byref(self.m.desc), C.byref(self.h))
+        if rc != 0:
+            raise OracleError(lib().orc_global_error().decode())
+        self.shape = problem.density.shape
+
+    def close(self):
+        if self.h:
+            lib().orc_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _err(self):
+        return lib().orc_last_error(self.h).decode()
+
+    def lucy_iteration(self, n_packets, iteration, n_threads=0):
+        out = np.empty(self.shape, dtype=np.float64)
+        st = IterStats()
+        rc = lib().orc_lucy_iteration(self.h, n_packets, iteration, n_threads,
+                                      out.ctypes.data_as(_dp), C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return out, st.as_dict()
+
+    def lucy_accumulate(self, first_id, n_local, iteration, n_threads=0):
+        st = IterStats()
+        rc = lib().orc_lucy_accumulate(self.h, first_id, n_local, iteration, n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        n = int(np.prod(self.shape))
+        s = np.ctypeslib.as_array(lib().orc_specific_energy_sum(self.h), shape=(n,)).reshape(self.shape).copy()
+        return s, st.as_dict()
+
+    def specific_energy(self):
+        n = int(np.prod(self.shape))
+        return np.ctypeslib.as_array(lib().orc_specific_energy(self.h), shape=(n,)).reshape(self.shape).copy()
+
+    def final_iteration(self, n_packets, n_threads=0):
+        st = IterStats()
+        rc = lib().orc_final_iteration(self.h, n_packets, n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        out = []
+        for g in range(len(self.problem.peeled)):
+            n_orig = lib().orc_peeled_n_orig(self.h, g)
+            sed_shape, img_shape = self.m.peeled_shapes(g, n_orig)
+            grp = {}
+            for name, shape, fn, fn2 in (("sed", sed_shape, lib().orc_peeled_sed, lib().orc_peeled_sed2),
+                                         ("img", img_shape, lib().orc_peeled_img, lib().orc_peeled_img2)):
+                if shape is None:
+                    continue
+                n = int(np.prod(shape))
+                grp[name] = np.ctypeslib.as_array(fn(self.h, g), shape=(n,)).reshape(shape).copy()
+                grp[name + "2"] = np.ctypeslib.as_array(fn2(self.h, g), shape=(n,)).reshape(shape).copy()
+            out.append(grp)
+        return out, st.as_dict()
+
+    def walk_ray(self, r0, v):
+        r0 = np.ascontiguousarray(r0, dtype=np.float64)
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        path = C.c_double()
+        n = lib().orc_walk_ray(self.h, r0.ctypes.data_as(_dp), v.ctypes.data_as(_dp), C.byref(path))
+        return n, path.value
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return list(o)
