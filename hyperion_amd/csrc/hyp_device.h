@@ -1,0 +1,313 @@
+// hyp_device.h -- device-side data layout and math helpers of the photon-packet
+// engine (gfx950).  Product code: never includes anything from oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HYP_MAXD 8
+#define HYP_PI 3.14159265358979323846
+#define HYP_TWOPI 6.28318530717958647692
+#define HYP_H_CGS 6.6260755e-27
+#define HYP_K_CGS 1.380658e-16
+#define HYP_DBL_MAX 1.7976931348623157e308
+#define HYP_DBL_MIN 2.2250738585072014e-308
+
+// One dust species, tables resident in HBM (read-mostly, L2/MALL cached).
+// Built on the host by build_dust_tables() following dust_type_4elem.f90:78-293.
+struct DDust {
+    int n_nu, n_mu, n_jnu, n_enu;
+    int zero_p2, have_e_range, sublimation_mode, pad0;
+    double nu_min, nu_max, mu_min, mu_max;
+    double e_min, e_max;                     // mean-opacity specific-energy range
+    double minimum_specific_energy, sublimation_specific_energy;
+    const double *nu, *log10_nu;             // [n_nu]
+    const double *chi, *albedo;              // [n_nu]
+    const double *log10_chi, *log10_albedo;  // [n_nu] (NaN where <= 0)
+    const double *mu;                        // [n_mu]
+    const double *P1, *P2, *P3, *P4;         // [n_nu][n_mu] normalised
+    const double *P1_cdf, *P2_cdf;           // [n_nu][n_mu]
+    const double *emiss_x;                   // [n_enu]
+    const double *emiss_cdf;                 // [n_jnu][n_enu]
+    const double *emiss_bp1;                 // [n_jnu][n_enu] power-law index+1 per bin
+    const double *jnu_var, *log10_jnu_var;   // [n_jnu]
+    const double *mo_e, *mo_chi_ross;        // [n_e] (sublimation mode 2) or null
+    int n_e, pad1;
+};
+
+struct DSource {
+    double pos[3];
+    double temperature;
+    double lum_pdf, lum_cdf;
+    int spectrum_type, n_spec;
+    const double *spec_x, *spec_cdf, *spec_bp1;
+};
+
+struct DPeeled {
+    int n_view, ignore_optical_depth, compute_image, compute_sed;
+    int n_x, n_y, n_ap, n_nu;
+    int track_origin, track_n_scat, uncertainties, n_stokes;
+    int n_orig, pad0;
+    double x_min, x_max, y_min, y_max, ap_min, ap_max;
+    double log10_nu_min, log10_nu_max, log10_ap_min, log10_ap_max;
+    double d_min, d_max, origin[3];
+    const double *view;     // [n_view][4] cost,sint,cosp,sinp
+    double *sed, *sed2, *img, *img2;
+};
+
+// Slots of the scalar tail that follows the per-cell accumulators.
+enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
+       TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
+
+enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2 };
+
+struct DProblem {
+    int n1, n2, n3, n_dust;
+    int n_sources, n_peeled, sample_sources_evenly, kill_on_absorb;
+    int kill_on_scatter, forced_first, forced_algo, pad0;
+    long long n_inter_max;
+    unsigned long long n_cells;
+    double baes16_xi;
+    unsigned long long check_threshold;   // propagation_check_frequency * 2^32
+    uint32_t seed_key, pad1;
+    const double *w[3], *ew[3];           // walls and 3*spacing(wall)
+    const double *density;                // [n_cells][n_dust]   (cell-major)
+    double *sum;                          // [n_copies][n_cells][n_dust] accumulators
+    unsigned long long copy_stride;       // doubles between accumulator copies
+    int n_copies, pad2;
+    double *tail;                         // [TAIL_SIZE]
+    const int *jnu_id;                    // [n_cells][n_dust]
+    const double *jnu_frac;               // [n_cells][n_dust]
+    unsigned long long *counter;          // packet-id dispenser
+    int *err;                             // [0] code
+    double *err_data;                     // [0..2]
+    const DSource *sources;
+    const DPeeled *peeled;
+    DDust dust[HYP_MAXD];
+};
+
+struct LaunchParams {
+    unsigned long long first_id, end_id;
+    uint32_t iter_tag;
+    int chunk;
+    int interact_threshold, emit_threshold;
+};
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10, one stream pair per packet (counter = packet id, block, stream)
+// ---------------------------------------------------------------------------
+struct Rng {
+    uint32_t key0, key1;
+    uint32_t id_lo, id_hi;
+    uint32_t blk_a, blk_b;
+    uint32_t b0, b1, b2, b3;   // stream-B buffer (propagation-check draws)
+    double buf_a;
+    int have_a, pos_b;
+};
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t o[4])
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+__device__ __forceinline__ double u64_to_unit(uint32_t hi, uint32_t lo)
+{
+    unsigned long long u = (((unsigned long long)hi << 32) | lo) >> 11;
+    return (double)u * (1.0 / 9007199254740992.0);
+}
+
+__device__ __forceinline__ void rng_init(Rng &g, uint32_t key0, uint32_t key1, unsigned long long id)
+{
+    g.key0 = key0; g.key1 = key1; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+    g.blk_a = 0; g.blk_b = 0; g.have_a = 0; g.pos_b = 4; g.buf_a = 0.0;
+    g.b0 = g.b1 = g.b2 = g.b3 = 0;
+}
+
+__device__ __forceinline__ double rng_uniform(Rng &g)
+{
+    if (g.have_a) { g.have_a = 0; return g.buf_a; }
+    uint32_t o[4];
+    philox4x32_10(g.id_lo, g.id_hi, g.blk_a, 0u, g.key0, g.key1, o);
+    g.blk_a++;
+    g.buf_a = u64_to_unit(o[2], o[3]); g.have_a = 1;
+    return u64_to_unit(o[0], o[1]);
+}
+
+__device__ __forceinline__ uint32_t rng_check_u32(Rng &g)
+{
+    if (g.pos_b == 4) {
+        uint32_t o[4];
+        philox4x32_10(g.id_lo, g.id_hi, g.blk_b, 1u, g.key0, g.key1, o);
+        g.blk_b++;
+        g.b0 = o[0]; g.b1 = o[1]; g.b2 = o[2]; g.b3 = o[3];
+        g.pos_b = 0;
+    }
+    uint32_t r = g.pos_b == 0 ? g.b0 : g.pos_b == 1 ? g.b1 : g.pos_b == 2 ? g.b2 : g.b3;
+    g.pos_b++;
+    return r;
+}
+
+__device__ __forceinline__ double rng_exp(Rng &g) { return -log(1.0 - rng_uniform(g)); }
+
+// ---------------------------------------------------------------------------
+// table helpers (fortranlib lib_array / type_pdf semantics)
+// ---------------------------------------------------------------------------
+
+// j with x[j] <= xv < x[j+1]; xv == x[n-1] -> n-2; -1 outside (ascending x)
+__device__ __forceinline__ int locate(const double *__restrict__ x, int n, double xv)
+{
+    if (!(xv >= x[0]) || !(xv <= x[n - 1])) return -1;
+    if (xv == x[n - 1]) return n - 2;
+    int jl = 0, ju = n - 1;
+    while (ju - jl > 1) {
+        int jm = (ju + jl) >> 1;
+        if (xv >= x[jm]) jl = jm; else ju = jm;
+    }
+    return jl;
+}
+
+// log-log interpolation with precomputed log10 tables; linear where an
+// ordinate is not positive.  j = bracketing bin, lxv = log10(xv).
+__device__ __forceinline__ double interp_loglog_at(const double *__restrict__ x, const double *__restrict__ lx,
+                                                   const double *__restrict__ y, const double *__restrict__ ly,
+                                                   int j, double xv, double lxv)
+{
+    double y1 = y[j], y2 = y[j + 1];
+    if (y1 > 0.0 && y2 > 0.0) {
+        double f = (lxv - lx[j]) / (lx[j + 1] - lx[j]);
+        return exp10(ly[j] + f * (ly[j + 1] - ly[j]));
+    }
+    return y1 + (xv - x[j]) / (x[j + 1] - x[j]) * (y2 - y1);
+}
+
+// bilinear, a[iy][ix]
+__device__ __forceinline__ double bilinear(const double *__restrict__ a, int nx, int i, int j, double fx, double fy)
+{
+    const double *r0 = a + (size_t)j * nx + i, *r1 = r0 + nx;
+    double a00 = r0[0], a10 = r0[1], a01 = r1[0], a11 = r1[1];
+    return a00 * (1 - fx) * (1 - fy) + a10 * fx * (1 - fy) + a01 * (1 - fx) * fy + a11 * fx * fy;
+}
+
+// invert a piecewise power-law CDF (type_pdf sample_pdf with log=.true.)
+__device__ __forceinline__ double sample_log_pdf(const double *__restrict__ x, const double *__restrict__ cdf,
+                                                 const double *__restrict__ bp1, int n, double xi)
+{
+    int j = locate(cdf, n, xi);
+    if (j < 0) j = 0;
+    double c1 = cdf[j], c2 = cdf[j + 1];
+    double f = (c2 > c1) ? (xi - c1) / (c2 - c1) : 0.0;
+    double x1 = x[j], x2 = x[j + 1], b = bp1[j];
+    if (b != b) return x1 + f * (x2 - x1);
+    if (fabs(b) < 1e-10) return x1 * pow(x2 / x1, f);
+    return x1 * pow(1.0 + f * (pow(x2 / x1, b) - 1.0), 1.0 / b);
+}
+
+// ---------------------------------------------------------------------------
+// angles (fortranlib type_angle3d semantics; orientation of Code & Whitney 1995)
+// ---------------------------------------------------------------------------
+struct Angle { double cost, sint, cosp, sinp; };
+
+__device__ __forceinline__ void angle_to_vector(const Angle &a, double &vx, double &vy, double &vz)
+{
+    vx = a.sint * a.cosp; vy = a.sint * a.sinp; vz = a.cost;
+}
+
+__device__ __forceinline__ void random_sphere_angle(Rng &g, Angle &a)
+{
+    double mu = 2.0 * rng_uniform(g) - 1.0;
+    double phi = HYP_TWOPI * rng_uniform(g);
+    a.cost = mu; a.sint = sqrt(1.0 - mu * mu);
+    double s, c;
+    sincos(phi, &s, &c);
+    a.cosp = c; a.sinp = s;
+}
+
+__device__ __forceinline__ double clamp1(double x) { return x > 1.0 ? 1.0 : (x < -1.0 ? -1.0 : x); }
+
+// new direction = old direction `co` deflected by the local angle `loc`
+__device__ __forceinline__ void rotate_angle(const Angle &loc, const Angle &co, Angle &fin)
+{
+    double cos_a = co.cost, sin_a = co.sint, cos_b = loc.cost, sin_b = loc.sint;
+    double cos_C = loc.cosp, sin_C = fabs(loc.sinp);
+    double cos_c = clamp1(cos_a * cos_b + sin_a * sin_b * cos_C);
+    double sin_c = sqrt(1.0 - cos_c * cos_c);
+    double cos_B, sin_B;
+    if (sin_a < 1e-12 || sin_c < 1e-12) {
+        if (sin_a < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
+        else { cos_B = 1.0; sin_B = 0.0; }
+    } else {
+        cos_B = clamp1((cos_b - cos_a * cos_c) / (sin_a * sin_c));
+        sin_B = sqrt(1.0 - cos_B * cos_B);
+    }
+    fin.cost = cos_c; fin.sint = sin_c;
+    if (loc.sinp < 0.0) {
+        fin.cosp = co.cosp * cos_B - co.sinp * sin_B;
+        fin.sinp = co.sinp * cos_B + co.cosp * sin_B;
+    } else {
+        fin.cosp = co.cosp * cos_B + co.sinp * sin_B;
+        fin.sinp = co.sinp * cos_B - co.cosp * sin_B;
+    }
+}
+
+// local angle that takes `co` to `fin` (inverse of rotate_angle)
+__device__ __forceinline__ void difference_angle(const Angle &co, const Angle &fin, Angle &loc)
+{
+    double cos_a = co.cost, sin_a = co.sint, cos_c = fin.cost, sin_c = fin.sint;
+    double cos_B = co.cosp * fin.cosp + co.sinp * fin.sinp;
+    double sin_Bs = co.sinp * fin.cosp - co.cosp * fin.sinp;
+    double cos_b = clamp1(cos_a * cos_c + sin_a * sin_c * cos_B);
+    double sin_b = sqrt(1.0 - cos_b * cos_b);
+    loc.cost = cos_b; loc.sint = sin_b;
+    if (sin_b < 1e-12 || sin_a < 1e-12) {
+        if (sin_a < 1e-12 && sin_b >= 1e-12) { loc.cosp = (cos_a > 0 ? -cos_B : cos_B); loc.sinp = sin_Bs; }
+        else { loc.cosp = 1.0; loc.sinp = 0.0; }
+        return;
+    }
+    double cos_C = clamp1((cos_c - cos_a * cos_b) / (sin_a * sin_b));
+    double sin_C = sqrt(1.0 - cos_C * cos_C);
+    loc.cosp = cos_C;
+    loc.sinp = (sin_Bs >= 0.0) ? sin_C : -sin_C;
+}
+
+// dust_type_4elem.f90:603-690
+__device__ __forceinline__ void scatter_stokes(double s[4], const Angle &a_coord, const Angle &a_scat,
+                                               const Angle &a_final, double P1, double P2, double P3, double P4)
+{
+    double cos_a = a_coord.cost, sin_a = a_coord.sint;
+    double cos_b = a_scat.cost, sin_b = a_scat.sint;
+    double cos_c = a_final.cost, sin_c = a_final.sint;
+    double cos_big_b = a_coord.cosp * a_final.cosp + a_coord.sinp * a_final.sinp;
+    double cos_big_c = a_scat.cosp, sin_big_c = fabs(a_scat.sinp);
+    double cos_big_a, sin_big_a;
+    if (sin_big_c < 10.0 * HYP_DBL_MIN && sin_c < 10.0 * HYP_DBL_MIN) {
+        cos_big_a = -cos_big_b * cos_big_c;
+        sin_big_a = sqrt(1.0 - cos_big_a * cos_big_a);
+    } else {
+        cos_big_a = (cos_a - cos_b * cos_c) / (sin_b * sin_c);
+        sin_big_a = sin_big_c * sin_a / sin_c;
+    }
+    double cos_2_i2 = 1.0 - 2.0 * sin_big_a * sin_big_a;
+    double sin_2_i2 = 2.0 * sin_big_a * cos_big_a;
+    double cos_2_alpha = 1.0 - 2.0 * a_scat.sinp * a_scat.sinp;
+    double sin_2_alpha = -2.0 * a_scat.sinp * a_scat.cosp;
+    double cos_2_beta = cos_2_i2;
+    double sin_2_beta = (a_scat.sinp < 0.0) ? sin_2_i2 : -sin_2_i2;
+    double I = s[0], Q = s[1], U = s[2], V = s[3];
+    double RLS1 = P1 * I + P2 * (cos_2_alpha * Q + sin_2_alpha * U);
+    double RLS2 = P2 * I + P1 * (cos_2_alpha * Q + sin_2_alpha * U);
+    double RLS3 = -P4 * V + P3 * (-sin_2_alpha * Q + cos_2_alpha * U);
+    double RLS4 = P3 * V + P4 * (-sin_2_alpha * Q + cos_2_alpha * U);
+    s[0] = RLS1;
+    s[1] = cos_2_beta * RLS2 + sin_2_beta * RLS3;
+    s[2] = -sin_2_beta * RLS2 + cos_2_beta * RLS3;
+    s[3] = RLS4;
+}

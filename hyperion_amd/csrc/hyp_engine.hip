@@ -1,0 +1,732 @@
+// hyp_engine.hip -- host side of the C-ABI (include/hyperion_amd.h): table
+// construction, device residency, kernel launches, iteration epilogue.
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics
+#include "../../include/hyperion_amd.h"
+#include "hyp_kernels.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_error;   // message of a failed hyp_create
+
+#define HIP_TRY(call)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            set_error(std::string(#call) + ": " + hipGetErrorString(e_));                  \
+            return 1;                                                                      \
+        }                                                                                  \
+    } while (0)
+
+// A host-side pool of doubles that becomes one device allocation; tables are
+// addressed by offset until upload, then by pointer.
+struct Blob {
+    std::vector<double> h;
+    size_t put(const double *a, size_t n) { size_t o = h.size(); h.insert(h.end(), a, a + n); return o; }
+    size_t put(const std::vector<double> &v) { return put(v.data(), v.size()); }
+};
+
+double seg_loglog(double x1, double x2, double y1, double y2)
+{
+    if (!(y1 > 0.0 && y2 > 0.0)) return 0.0;
+    double b = std::log10(y1 / y2) / std::log10(x1 / x2);
+    if (std::fabs(b + 1.0) < 1e-10) return x1 * y1 * std::log(x2 / x1);
+    return y1 * (x2 * std::pow(x2 / x1, b) - x1) / (b + 1.0);
+}
+
+// type_pdf set_pdf(x, y, log=.true.): normalised pdf, cdf and per-bin power-law
+// index (+1) used by the device-side inversion.  Returns false if the integral
+// vanishes.
+bool build_log_pdf(const double *x, const double *y, int n, size_t stride,
+                   std::vector<double> &cdf, std::vector<double> &bp1)
+{
+    std::vector<double> pdf(n);
+    for (int i = 0; i < n; i++) pdf[i] = y[(size_t)i * stride];
+    double norm = 0.0;
+    for (int i = 0; i + 1 < n; i++) norm += seg_loglog(x[i], x[i + 1], pdf[i], pdf[i + 1]);
+    if (!(norm > 0.0)) return false;
+    for (int i = 0; i < n; i++) pdf[i] /= norm;
+    cdf.assign(n, 0.0); bp1.assign(n, std::nan(""));
+    for (int i = 1; i < n; i++) cdf[i] = cdf[i - 1] + seg_loglog(x[i - 1], x[i], pdf[i - 1], pdf[i]);
+    double last = cdf[n - 1];
+    for (int i = 0; i < n; i++) cdf[i] /= last;
+    for (int i = 0; i + 1 < n; i++)
+        if (pdf[i] > 0.0 && pdf[i + 1] > 0.0)
+            bp1[i] = std::log10(pdf[i + 1] / pdf[i]) / std::log10(x[i + 1] / x[i]) + 1.0;
+    return true;
+}
+
+double integral_linlog(const double *x, const double *y, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i + 1 < n; i++) {
+        double y1 = y[i], y2 = y[i + 1], dx = x[i + 1] - x[i];
+        if (y1 == y2) s += y1 * dx;
+        else if (y1 > 0.0 && y2 > 0.0) s += (y2 - y1) * dx / std::log(y2 / y1);
+    }
+    return s;
+}
+
+double spacing(double x)
+{
+    x = std::fabs(x);
+    if (x == 0.0) return DBL_MIN;
+    return std::nextafter(x, INFINITY) - x;
+}
+
+struct DustOffsets {
+    size_t nu, log10_nu, chi, albedo, log10_chi, log10_albedo, mu, P1, P2, P3, P4, P1_cdf, P2_cdf;
+    size_t emiss_x, emiss_cdf, emiss_bp1, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
+    bool have_mo_e, have_mo_chi;
+};
+
+struct SourceOffsets { size_t x, cdf, bp1; bool have; };
+struct PeeledOffsets { size_t view; };
+
+}  // namespace
+
+struct hyp_engine {
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    int n_cu = 0;
+
+    DProblem hp;               // host copy of the device problem descriptor
+    DProblem *d_problem = nullptr;
+    double *d_blob = nullptr;
+    DSource *d_sources = nullptr;
+    DPeeled *d_peeled = nullptr;
+    double *d_density = nullptr, *d_specific_energy = nullptr, *d_additional = nullptr;
+    double *d_accum = nullptr;          // [copy0 | tail | pad][copy1]...
+    size_t accum_stride = 0;            // doubles per copy slot
+    int accum_copies_alloc = 0;
+    int *d_jnu_id = nullptr;
+    double *d_jnu_frac = nullptr;
+    double *d_energy_abs_tot = nullptr;
+    double *d_scratch = nullptr;        // [n_dust*n_cells] layout conversions
+    unsigned long long *d_counter = nullptr;
+    int *d_err = nullptr;
+    double *d_err_data = nullptr;
+    double *d_img_accum = nullptr;      // all peeled cubes + tail
+    size_t img_accum_n = 0;
+    std::vector<size_t> sed_off, img_off, sed_n, img_n;
+    std::vector<DPeeled> h_peeled;
+
+    size_t n_cells = 0, n_elem = 0;
+    int n_dust = 0;
+    hyp_config cfg{};
+    double energy_total = 0.0;
+    bool lucy_pending = false, final_pending = false;
+    uint64_t pending_packets = 0;
+    float last_propagate_ms = 0.f, last_finish_ms = 0.f;
+    hyp_iter_stats last_stats{};
+
+    // options
+    int interact_threshold = 24, emit_threshold = 16, accum_copies = 1, blocks_per_cu = 0, chunk = 0;
+
+    int set_error(const std::string &m) { err = m; return 1; }
+};
+
+namespace {
+
+int set_error(const std::string &m) { g_error = m; return 1; }
+
+template <typename T>
+void free_dev(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+size_t lds_bytes(const DProblem &P) { return sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
+
+using LucyKernel = void (*)(const DProblem *, LaunchParams);
+
+LucyKernel pick_lucy_kernel(int nd)
+{
+    switch (nd) {
+    case 1: return lucy_kernel<1>;
+    case 2: return lucy_kernel<2>;
+    case 3: return lucy_kernel<3>;
+    case 4: return lucy_kernel<4>;
+    default: return lucy_kernel<HYP_MAXD>;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int hyp_abi_version(void) { return HYP_ABI_VERSION; }
+
+const char *hyp_last_error(hyp_handle h) { return h ? h->err.c_str() : g_error.c_str(); }
+
+void hyp_destroy(hyp_handle h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
+    free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
+    free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
+    free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
+    free_dev(h->d_img_accum);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->ev2) (void)hipEventDestroy(h->ev2);
+    if (h->ev3) (void)hipEventDestroy(h->ev3);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref);
+
+int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
+{
+    g_error.clear();
+    if (out) *out = nullptr;
+    if (!pr || !out) return set_error("null argument");
+    if (pr->grid.type != 1) return set_error("grid is not cartesian");
+    if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
+    if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
+    const int n[3] = {pr->grid.n1, pr->grid.n2, pr->grid.n3};
+    const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
+    for (int a = 0; a < 3; a++) {
+        if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
+        for (int i = 0; i < n[a]; i++)
+            if (!(win[a][i + 1] - win[a][i] > 0.0))
+                return set_error(std::string("all d") + "xyz"[a] + " values should be greater than zero");
+    }
+    if ((size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error("no HIP device available: the photon-packet engine requires an AMD GPU (gfx950)");
+    if (device < 0 || device >= ndev) return set_error("invalid device ordinal");
+    HIP_TRY(hipSetDevice(device));
+
+    hyp_engine *h = new hyp_engine();
+    h->device = device;
+    h->cfg = pr->config;
+    h->n_dust = pr->n_dust;
+    h->n_cells = (size_t)n[0] * n[1] * n[2];
+    h->n_elem = h->n_cells * h->n_dust;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
+    if (h->n_cu <= 0) h->n_cu = 256;
+
+#define FAIL(msg) do { g_error = (msg); hyp_destroy(h); return 1; } while (0)
+#define HIPC(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_error = std::string(#call) + ": " + hipGetErrorString(e_); hyp_destroy(h); return 1; } } while (0)
+
+    Blob B;
+    DProblem &P = h->hp;
+    std::memset(&P, 0, sizeof(P));
+    P.n1 = n[0]; P.n2 = n[1]; P.n3 = n[2]; P.n_dust = pr->n_dust;
+    P.n_sources = pr->n_sources; P.n_peeled = pr->n_peeled;
+    P.sample_sources_evenly = pr->config.sample_sources_evenly;
+    P.kill_on_absorb = pr->config.kill_on_absorb; P.kill_on_scatter = pr->config.kill_on_scatter;
+    P.forced_first = pr->config.forced_first_interaction; P.forced_algo = pr->config.forced_first_interaction_algorithm;
+    P.n_inter_max = pr->config.n_inter_max; P.n_cells = h->n_cells; P.baes16_xi = pr->config.baes16_xi;
+    {
+        double f = pr->config.propagation_check_frequency * 4294967296.0;
+        P.check_threshold = f <= 0.0 ? 0ull : (unsigned long long)f;
+        int64_t sd = pr->config.seed;
+        uint64_t s = (uint64_t)(sd < 0 ? -sd : sd);
+        P.seed_key = (uint32_t)s ^ (uint32_t)(s >> 32);
+    }
+
+    // walls + 3*spacing(w): grid_geometry_cartesian_3d.f90:97-132
+    size_t w_off[3], ew_off[3];
+    for (int a = 0; a < 3; a++) {
+        w_off[a] = B.put(win[a], n[a] + 1);
+        std::vector<double> ew(n[a] + 1);
+        for (int i = 0; i <= n[a]; i++) ew[i] = 3.0 * spacing(win[a][i]);
+        ew_off[a] = B.put(ew);
+    }
+
+    // dust tables: dust_type_4elem.f90:78-293
+    std::vector<DustOffsets> doff(pr->n_dust);
+    for (int d = 0; d < pr->n_dust; d++) {
+        const hyp_dust_desc &in = pr->dust[d];
+        DDust &D = P.dust[d];
+        DustOffsets &O = doff[d];
+        const int nn = in.n_nu, nm = in.n_mu;
+        if (nn < 2 || nm < 2 || in.n_jnu < 2 || in.n_enu < 2) FAIL("dust tables too short");
+        D.n_nu = nn; D.n_mu = nm; D.n_jnu = in.n_jnu; D.n_enu = in.n_enu; D.n_e = in.n_e;
+        D.sublimation_mode = in.sublimation_mode;
+        D.sublimation_specific_energy = in.sublimation_specific_energy;
+        D.minimum_specific_energy = in.minimum_specific_energy;
+        D.nu_min = in.nu[0]; D.nu_max = in.nu[nn - 1];
+        D.mu_min = in.mu[0]; D.mu_max = in.mu[nm - 1];
+        for (int i = 0; i + 1 < nn; i++) if (!(in.nu[i + 1] > in.nu[i])) FAIL("dust frequencies should be monotonically increasing");
+        std::vector<double> lnu(nn), lchi(nn), lalb(nn);
+        for (int i = 0; i < nn; i++) {
+            lnu[i] = std::log10(in.nu[i]);
+            lchi[i] = in.chi[i] > 0.0 ? std::log10(in.chi[i]) : std::nan("");
+            lalb[i] = in.albedo[i] > 0.0 ? std::log10(in.albedo[i]) : std::nan("");
+        }
+        O.nu = B.put(in.nu, nn); O.log10_nu = B.put(lnu);
+        O.chi = B.put(in.chi, nn); O.albedo = B.put(in.albedo, nn);
+        O.log10_chi = B.put(lchi); O.log10_albedo = B.put(lalb);
+        O.mu = B.put(in.mu, nm);
+        const size_t np = (size_t)nn * nm;
+        std::vector<double> P1(in.P1, in.P1 + np), P2(in.P2, in.P2 + np), P3(in.P3, in.P3 + np), P4(in.P4, in.P4 + np);
+        D.zero_p2 = 1;
+        for (size_t i = 0; i < np; i++) if (P2[i] != 0.0) { D.zero_p2 = 0; break; }
+        const double dmu = D.mu_max - D.mu_min;
+        std::vector<double> C1(np, 0.0), C2(np, 0.0);
+        for (int j = 0; j < nn; j++) {
+            double *p1 = &P1[(size_t)j * nm], *p2 = &P2[(size_t)j * nm], *p3 = &P3[(size_t)j * nm], *p4 = &P4[(size_t)j * nm];
+            double norm = integral_linlog(in.mu, p1, nm);
+            if (norm == 0.0) FAIL("P1 matrix normalization is zero");
+            for (int i = 0; i < nm; i++) {
+                p1[i] = p1[i] / norm * dmu; p2[i] = p2[i] / norm * dmu;
+                p3[i] = p3[i] / norm * dmu; p4[i] = p4[i] / norm * dmu;
+            }
+            double *c1 = &C1[(size_t)j * nm], *c2 = &C2[(size_t)j * nm];
+            for (int i = 1; i < nm; i++) {
+                double dx = in.mu[i] - in.mu[i - 1];
+                c1[i] = c1[i - 1] + 0.5 * (p1[i] + p1[i - 1]) * dx;
+                c2[i] = c2[i - 1] + 0.5 * (p2[i] + p2[i - 1]) * dx;
+            }
+            bool z1 = true, z2 = true;
+            for (int i = 0; i < nm; i++) { if (c1[i] != 0.0) z1 = false; if (c2[i] != 0.0) z2 = false; }
+            if (!z1) { double l = c1[nm - 1]; for (int i = 0; i < nm; i++) c1[i] /= l; }
+            if (!z2) { double l = c2[nm - 1]; for (int i = 0; i < nm; i++) c2[i] /= l; }
+        }
+        O.P1 = B.put(P1); O.P2 = B.put(P2); O.P3 = B.put(P3); O.P4 = B.put(P4);
+        O.P1_cdf = B.put(C1); O.P2_cdf = B.put(C2);
+        // emissivities
+        O.emiss_x = B.put(in.emiss_nu, in.n_enu);
+        std::vector<double> cdf_all, bp1_all, cdf, bp1;
+        for (int i = 0; i < in.n_jnu; i++) {
+            if (!build_log_pdf(in.emiss_nu, in.emiss_jnu + i, in.n_enu, in.n_jnu, cdf, bp1)) FAIL("emissivity has zero integral");
+            cdf_all.insert(cdf_all.end(), cdf.begin(), cdf.end());
+            bp1_all.insert(bp1_all.end(), bp1.begin(), bp1.end());
+        }
+        O.emiss_cdf = B.put(cdf_all); O.emiss_bp1 = B.put(bp1_all);
+        std::vector<double> ljv(in.n_jnu);
+        for (int i = 0; i < in.n_jnu; i++) ljv[i] = std::log10(in.emiss_var[i]);
+        O.jnu_var = B.put(in.emiss_var, in.n_jnu); O.log10_jnu_var = B.put(ljv);
+        O.have_mo_e = in.n_e > 0 && in.mo_specific_energy;
+        O.have_mo_chi = O.have_mo_e && in.mo_chi_rosseland;
+        if (O.have_mo_e) {
+            for (int i = 1; i < in.n_e; i++)
+                if (in.mo_specific_energy[i] < in.mo_specific_energy[i - 1]) FAIL("energy per unit mass is not monotonically increasing");
+            O.mo_e = B.put(in.mo_specific_energy, in.n_e);
+            D.e_min = in.mo_specific_energy[0]; D.e_max = in.mo_specific_energy[in.n_e - 1]; D.have_e_range = 1;
+        }
+        if (O.have_mo_chi) O.mo_chi_ross = B.put(in.mo_chi_rosseland, in.n_e);
+        if (in.sublimation_mode == 2 && !O.have_mo_chi) FAIL("slow sublimation needs the Rosseland mean opacity table");
+    }
+
+    // sources: source.f90:47-84, source_type.f90:102-322
+    std::vector<DSource> hs(pr->n_sources);
+    std::vector<SourceOffsets> soff(pr->n_sources);
+    h->energy_total = 0.0;
+    for (int i = 0; i < pr->n_sources; i++) h->energy_total += pr->sources[i].luminosity;
+    {
+        double c = 0.0;
+        for (int i = 0; i < pr->n_sources; i++) {
+            const hyp_source_desc &s = pr->sources[i];
+            DSource &S = hs[i];
+            std::memset(&S, 0, sizeof(S));
+            if (s.type != 1) FAIL("unknown type in source list: " + std::to_string(s.type));
+            S.pos[0] = s.position[0]; S.pos[1] = s.position[1]; S.pos[2] = s.position[2];
+            S.temperature = s.temperature; S.spectrum_type = s.spectrum_type; S.n_spec = s.n_spec;
+            S.lum_pdf = s.luminosity / h->energy_total;
+            c += S.lum_pdf; S.lum_cdf = c;
+            soff[i].have = false;
+            if (s.spectrum_type == 1) {
+                for (int k = 0; k + 1 < s.n_spec; k++)
+                    if (s.spec_nu[k + 1] < s.spec_nu[k]) FAIL("spectrum frequency should be monotonically increasing");
+                std::vector<double> cdf, bp1;
+                if (!build_log_pdf(s.spec_nu, s.spec_fnu, s.n_spec, 1, cdf, bp1)) FAIL("source spectrum has zero integral");
+                soff[i].x = B.put(s.spec_nu, s.n_spec); soff[i].cdf = B.put(cdf); soff[i].bp1 = B.put(bp1);
+                soff[i].have = true;
+            } else if (s.spectrum_type != 2) FAIL("Point source cannot have LTE spectrum");
+        }
+        for (int i = 0; i < pr->n_sources; i++) hs[i].lum_cdf /= c;
+    }
+
+    // peeled image groups: images_peeled.f90:272-380, image_type.f90:153-335
+    h->h_peeled.resize(pr->n_peeled);
+    std::vector<PeeledOffsets> poff(pr->n_peeled);
+    h->sed_off.assign(pr->n_peeled, 0); h->img_off.assign(pr->n_peeled, 0);
+    h->sed_n.assign(pr->n_peeled, 0); h->img_n.assign(pr->n_peeled, 0);
+    size_t img_total = 0;
+    for (int g = 0; g < pr->n_peeled; g++) {
+        const hyp_peeled_desc &in = pr->peeled[g];
+        DPeeled &G = h->h_peeled[g];
+        std::memset(&G, 0, sizeof(G));
+        if (in.inside_observer) FAIL("inside observers are not supported yet");
+        if (in.n_view < 1) FAIL("n_view should be a positive integer");
+        G.n_view = in.n_view; G.ignore_optical_depth = in.ignore_optical_depth;
+        G.compute_image = in.compute_image; G.compute_sed = in.compute_sed;
+        G.n_x = in.n_x; G.n_y = in.n_y; G.n_ap = in.n_ap; G.n_nu = in.n_nu;
+        G.track_origin = in.track_origin; G.track_n_scat = in.track_n_scat; G.uncertainties = in.uncertainties;
+        G.n_stokes = in.compute_stokes ? 4 : 1;
+        switch (in.track_origin) {
+        case 0: G.n_orig = 1; break;
+        case 1: G.n_orig = 4; break;
+        case 2: G.n_orig = 2 * (pr->n_sources + pr->n_dust); break;
+        case 3: G.n_orig = 4 + 2 * in.track_n_scat; break;
+        default: FAIL("unknown track_origin flag");
+        }
+        G.x_min = in.x_min; G.x_max = in.x_max; G.y_min = in.y_min; G.y_max = in.y_max;
+        G.ap_min = in.ap_min; G.ap_max = in.ap_max;
+        G.log10_nu_min = std::log10(in.nu_min); G.log10_nu_max = std::log10(in.nu_max);
+        if (in.compute_sed) { G.log10_ap_min = std::log10(in.ap_min); G.log10_ap_max = std::log10(in.ap_max); }
+        G.d_min = in.d_min; G.d_max = in.d_max;
+        for (int k = 0; k < 3; k++) G.origin[k] = in.peeloff_origin[k];
+        std::vector<double> view((size_t)in.n_view * 4);
+        for (int v = 0; v < in.n_view; v++) {
+            double t = in.theta[v] * HYP_PI / 180.0, f = in.phi[v] * HYP_PI / 180.0;
+            view[4 * v + 0] = std::cos(t); view[4 * v + 1] = std::sin(t);
+            view[4 * v + 2] = std::cos(f); view[4 * v + 3] = std::sin(f);
+        }
+        poff[g].view = B.put(view);
+        if (in.compute_sed) {
+            h->sed_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_ap * in.n_nu;
+            h->sed_off[g] = img_total; img_total += 2 * h->sed_n[g];
+        }
+        if (in.compute_image) {
+            h->img_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_y * in.n_x * in.n_nu;
+            h->img_off[g] = img_total; img_total += 2 * h->img_n[g];
+        }
+    }
+
+    // ---- device allocations ----
+    HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPC(hipEventCreate(&h->ev0)); HIPC(hipEventCreate(&h->ev1));
+    HIPC(hipEventCreate(&h->ev2)); HIPC(hipEventCreate(&h->ev3));
+    HIPC(hipMalloc(&h->d_blob, sizeof(double) * B.h.size()));
+    HIPC(hipMemcpy(h->d_blob, B.h.data(), sizeof(double) * B.h.size(), hipMemcpyHostToDevice));
+    const double *db = h->d_blob;
+    for (int a = 0; a < 3; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    for (int d = 0; d < pr->n_dust; d++) {
+        DDust &D = P.dust[d]; const DustOffsets &O = doff[d];
+        D.nu = db + O.nu; D.log10_nu = db + O.log10_nu; D.chi = db + O.chi; D.albedo = db + O.albedo;
+        D.log10_chi = db + O.log10_chi; D.log10_albedo = db + O.log10_albedo; D.mu = db + O.mu;
+        D.P1 = db + O.P1; D.P2 = db + O.P2; D.P3 = db + O.P3; D.P4 = db + O.P4;
+        D.P1_cdf = db + O.P1_cdf; D.P2_cdf = db + O.P2_cdf;
+        D.emiss_x = db + O.emiss_x; D.emiss_cdf = db + O.emiss_cdf; D.emiss_bp1 = db + O.emiss_bp1;
+        D.jnu_var = db + O.jnu_var; D.log10_jnu_var = db + O.log10_jnu_var;
+        D.mo_e = O.have_mo_e ? db + O.mo_e : nullptr;
+        D.mo_chi_ross = O.have_mo_chi ? db + O.mo_chi_ross : nullptr;
+    }
+    for (int i = 0; i < pr->n_sources; i++)
+        if (soff[i].have) { hs[i].spec_x = db + soff[i].x; hs[i].spec_cdf = db + soff[i].cdf; hs[i].spec_bp1 = db + soff[i].bp1; }
+    HIPC(hipMalloc(&h->d_sources, sizeof(DSource) * hs.size()));
+    HIPC(hipMemcpy(h->d_sources, hs.data(), sizeof(DSource) * hs.size(), hipMemcpyHostToDevice));
+    P.sources = h->d_sources;
+
+    const size_t ne = h->n_elem;
+    HIPC(hipMalloc(&h->d_density, sizeof(double) * ne));
+    HIPC(hipMalloc(&h->d_specific_energy, sizeof(double) * ne));
+    HIPC(hipMalloc(&h->d_scratch, sizeof(double) * ne));
+    HIPC(hipMalloc(&h->d_jnu_id, sizeof(int) * ne));
+    HIPC(hipMalloc(&h->d_jnu_frac, sizeof(double) * ne));
+    HIPC(hipMalloc(&h->d_energy_abs_tot, sizeof(double) * HYP_MAXD));
+    HIPC(hipMalloc(&h->d_counter, sizeof(unsigned long long)));
+    HIPC(hipMalloc(&h->d_err, sizeof(int)));
+    HIPC(hipMalloc(&h->d_err_data, sizeof(double) * 4));
+    HIPC(hipMemset(h->d_err, 0, sizeof(int)));
+    h->accum_stride = ((ne + TAIL_SIZE + 31) / 32) * 32;
+    h->accum_copies_alloc = 8;
+    HIPC(hipMalloc(&h->d_accum, sizeof(double) * h->accum_stride * h->accum_copies_alloc));
+    HIPC(hipMemset(h->d_accum, 0, sizeof(double) * h->accum_stride * h->accum_copies_alloc));
+
+    if (img_total > 0) {
+        h->img_accum_n = img_total + TAIL_SIZE;
+        HIPC(hipMalloc(&h->d_img_accum, sizeof(double) * h->img_accum_n));
+        HIPC(hipMemset(h->d_img_accum, 0, sizeof(double) * h->img_accum_n));
+    }
+    for (int g = 0; g < pr->n_peeled; g++) {
+        DPeeled &G = h->h_peeled[g];
+        G.view = db + poff[g].view;
+        if (h->sed_n[g]) { G.sed = h->d_img_accum + h->sed_off[g]; G.sed2 = G.sed + h->sed_n[g]; }
+        if (h->img_n[g]) { G.img = h->d_img_accum + h->img_off[g]; G.img2 = G.img + h->img_n[g]; }
+    }
+    if (pr->n_peeled > 0) {
+        HIPC(hipMalloc(&h->d_peeled, sizeof(DPeeled) * pr->n_peeled));
+        HIPC(hipMemcpy(h->d_peeled, h->h_peeled.data(), sizeof(DPeeled) * pr->n_peeled, hipMemcpyHostToDevice));
+    }
+    P.peeled = h->d_peeled;
+
+    // density / specific energy: reference layout -> cell-major device layout
+    HIPC(hipMemcpy(h->d_scratch, pr->density, sizeof(double) * ne, hipMemcpyHostToDevice));
+    to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_density, h->n_cells, h->n_dust);
+    HIPC(hipStreamSynchronize(h->stream));
+    // grid_physics_3d.f90:176-253
+    std::vector<double> se(ne);
+    if (pr->specific_energy) {
+        if (pr->config.specific_energy_type == 1) {
+            HIPC(hipMalloc(&h->d_additional, sizeof(double) * ne));
+            HIPC(hipMemcpy(h->d_scratch, pr->specific_energy, sizeof(double) * ne, hipMemcpyHostToDevice));
+            to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_additional, h->n_cells, h->n_dust);
+            HIPC(hipStreamSynchronize(h->stream));
+            for (int d = 0; d < h->n_dust; d++)
+                for (size_t ic = 0; ic < h->n_cells; ic++) se[(size_t)d * h->n_cells + ic] = pr->dust[d].minimum_specific_energy;
+        } else {
+            std::memcpy(se.data(), pr->specific_energy, sizeof(double) * ne);
+        }
+    } else {
+        if (pr->config.specific_energy_type == 1) FAIL("cannot specify specific_energy_type since specific_energy was not given");
+        for (int d = 0; d < h->n_dust; d++)
+            for (size_t ic = 0; ic < h->n_cells; ic++) se[(size_t)d * h->n_cells + ic] = pr->dust[d].minimum_specific_energy;
+    }
+    HIPC(hipMemcpy(h->d_scratch, se.data(), sizeof(double) * ne, hipMemcpyHostToDevice));
+    to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_specific_energy, h->n_cells, h->n_dust);
+    HIPC(hipStreamSynchronize(h->stream));
+
+    P.density = h->d_density;
+    P.sum = h->d_accum;
+    P.copy_stride = h->accum_stride;
+    P.n_copies = 1;
+    P.tail = h->d_accum + ne;
+    P.jnu_id = h->d_jnu_id; P.jnu_frac = h->d_jnu_frac;
+    P.counter = h->d_counter; P.err = h->d_err; P.err_data = h->d_err_data;
+    HIPC(hipMalloc(&h->d_problem, sizeof(DProblem)));
+    HIPC(hipMemcpy(h->d_problem, &P, sizeof(DProblem), hipMemcpyHostToDevice));
+
+    // check_energy_abs at set-up (grid_physics_3d.f90:277) + first jnu_var
+    if (run_finish_kernel(h, 1, 1.0, nullptr)) { g_error = h->err; hyp_destroy(h); return 1; }
+    HIPC(hipStreamSynchronize(h->stream));
+#undef FAIL
+#undef HIPC
+    *out = h;
+    return 0;
+}
+
+static int sync_problem(hyp_handle h)
+{
+    hipError_t e = hipMemcpyAsync(h->d_problem, &h->hp, sizeof(DProblem), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(problem): ") + hipGetErrorString(e));
+    return 0;
+}
+
+static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref)
+{
+    FinishParams F;
+    F.scale = scale; F.enforce_energy_range = h->cfg.enforce_energy_range;
+    F.additional = (h->d_additional != nullptr); F.write_out = d_out_ref != nullptr; F.pad = 0;
+    hipError_t e = hipMemsetAsync(h->d_energy_abs_tot, 0, sizeof(double) * HYP_MAXD, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync: ") + hipGetErrorString(e));
+    int blocks = h->n_cu * 8;
+    size_t need = (h->n_elem + 255) / 256;
+    if ((size_t)blocks > need) blocks = (int)need;
+    if (blocks < 1) blocks = 1;
+    finish_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, F, mode, h->d_specific_energy, h->d_density,
+                                                 h->d_additional, h->d_jnu_id, h->d_jnu_frac, h->d_energy_abs_tot, d_out_ref);
+    e = hipGetLastError();
+    if (e != hipSuccess) return h->set_error(std::string("finish_kernel launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
+static int check_device_error(hyp_handle h)
+{
+    int code = 0;
+    double data[3] = {0, 0, 0};
+    if (hipMemcpy(&code, h->d_err, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return h->set_error("cannot read device error flag");
+    if (code == ERR_NONE) return 0;
+    (void)hipMemcpy(data, h->d_err_data, sizeof(data), hipMemcpyDeviceToHost);
+    (void)hipMemset(h->d_err, 0, sizeof(int));
+    char buf[512];
+    if (code == ERR_NU_RANGE) {
+        // message of src/dust/dust.f90:71
+        std::snprintf(buf, sizeof buf,
+                      "photon frequency (%10.4E Hz) is outside the range defined for the dust optical properties (%10.4E to %10.4E Hz)",
+                      data[0], data[1], data[2]);
+    } else if (code == ERR_NOT_IN_CELL) {
+        // message of src/sources/source.f90:177
+        std::snprintf(buf, sizeof buf,
+                      "photon was not emitted inside a cell - this usually indicates that a source is not inside the grid");
+    } else std::snprintf(buf, sizeof buf, "device error %d", code);
+    return h->set_error(buf);
+}
+
+int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration)
+{
+    if (!h) return 1;
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    DProblem &P = h->hp;
+    int copies = h->accum_copies;
+    if (copies < 1) copies = 1;
+    if (copies > h->accum_copies_alloc) copies = h->accum_copies_alloc;
+    P.sum = h->d_accum; P.tail = h->d_accum + h->n_elem; P.n_copies = copies; P.copy_stride = h->accum_stride;
+    if (sync_problem(h)) return 1;
+    hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(accum): ") + hipGetErrorString(e));
+    unsigned long long first = first_id;
+    e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
+
+    LucyKernel k = pick_lucy_kernel(h->n_dust);
+    const size_t lds = lds_bytes(P);
+    int bpc = h->blocks_per_cu;
+    if (bpc <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+        bpc = occ;
+    }
+    long long blocks = (long long)h->n_cu * bpc;
+    long long need_blocks = (long long)((n_local + 255) / 256);
+    if (need_blocks < 1) need_blocks = 1;
+    if (blocks > need_blocks) blocks = need_blocks;
+    LaunchParams L;
+    L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = (uint32_t)iteration;
+    int chunk = h->chunk;
+    if (chunk <= 0) {
+        unsigned long long waves = (unsigned long long)blocks * 4ull;
+        unsigned long long c = n_local / (waves * 8ull);
+        if (c < 64) c = 64;
+        if (c > 4096) c = 4096;
+        chunk = (int)c;
+    }
+    L.chunk = chunk;
+    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    (void)hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    e = hipGetLastError();
+    (void)hipEventRecord(h->ev1, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("lucy_kernel launch: ") + hipGetErrorString(e));
+    h->lucy_pending = true;
+    h->pending_packets = n_local;
+    return 0;
+}
+
+int hyp_lucy_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
+{
+    if (!h) return 1;
+    if (!h->lucy_pending) return h->set_error("hyp_lucy_accumulators called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    if (h->hp.n_copies > 1) {
+        int blocks = h->n_cu * 8;
+        reduce_copies_kernel<<<blocks, 256, 0, h->stream>>>(h->d_accum, h->n_elem + TAIL_SIZE, h->accum_stride, h->hp.n_copies);
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
+    (void)hipEventElapsedTime(&h->last_propagate_ms, h->ev0, h->ev1);
+    if (check_device_error(h)) { h->lucy_pending = false; return 1; }
+    if (device_ptr) *device_ptr = h->d_accum;
+    if (n_doubles) *n_doubles = h->n_elem + TAIL_SIZE;
+    return 0;
+}
+
+int hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (!h->lucy_pending) return h->set_error("hyp_lucy_finish called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    h->lucy_pending = false;
+    double tail[TAIL_SIZE];
+    hipError_t e = hipMemcpy(tail, h->d_accum + h->n_elem, sizeof(tail), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    hyp_iter_stats st;
+    std::memset(&st, 0, sizeof st);
+    st.energy_current = tail[TAIL_ENERGY];
+    st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];
+    st.crossings = (uint64_t)tail[TAIL_CROSSINGS]; st.interactions = (uint64_t)tail[TAIL_INTERACTIONS];
+    st.n_packets = h->pending_packets;
+    if (!(st.energy_current > 0.0)) return h->set_error("no energy emitted");
+    // update_energy_abs(energy_total/energy_current): iter_lucy.f90:224
+    (void)hipEventRecord(h->ev2, h->stream);
+    double *d_out = (specific_energy_out && h->n_dust > 1) ? h->d_scratch : nullptr;
+    if (run_finish_kernel(h, 0, h->energy_total / st.energy_current, d_out)) return 1;
+    (void)hipEventRecord(h->ev3, h->stream);
+    double tot[HYP_MAXD];
+    e = hipMemcpyAsync(tot, h->d_energy_abs_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess && specific_energy_out)
+        e = hipMemcpyAsync(specific_energy_out, h->n_dust > 1 ? h->d_scratch : h->d_specific_energy,
+                           sizeof(double) * h->n_elem, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("finish failed: ") + hipGetErrorString(e));
+    (void)hipEventElapsedTime(&h->last_finish_ms, h->ev2, h->ev3);
+    for (int d = 0; d < h->n_dust; d++) st.energy_abs_tot[d] = tot[d];
+    h->last_stats = st;
+    if (stats) *stats = st;
+    return 0;
+}
+
+int hyp_lucy_iteration(hyp_handle h, uint64_t n_packets, int iteration, double *specific_energy_out, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (n_packets == 0) return 0;   // "Skipping": iter_lucy.f90:87-94
+    if (hyp_lucy_launch(h, 0, n_packets, iteration)) return 1;
+    if (hyp_lucy_accumulators(h, nullptr, nullptr)) return 1;
+    return hyp_lucy_finish(h, specific_energy_out, stats);
+}
+
+static int copy_out_ref_layout(hyp_handle h, const double *d_src, double *out)
+{
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    const double *src = d_src;
+    if (h->n_dust > 1) {
+        to_ref_layout_kernel<<<1024, 256, 0, h->stream>>>(d_src, h->d_scratch, h->n_cells, h->n_dust);
+        src = h->d_scratch;
+    }
+    hipError_t e = hipMemcpyAsync(out, src, sizeof(double) * h->n_elem, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("copy out failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int hyp_get_specific_energy(hyp_handle h, double *out)
+{
+    if (!h || !out) return 1;
+    return copy_out_ref_layout(h, h->d_specific_energy, out);
+}
+
+int hyp_get_density(hyp_handle h, double *out)
+{
+    if (!h || !out) return 1;
+    return copy_out_ref_layout(h, h->d_density, out);
+}
+
+int hyp_set_specific_energy(hyp_handle h, const double *in)
+{
+    if (!h || !in) return 1;
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    hipError_t e = hipMemcpyAsync(h->d_scratch, in, sizeof(double) * h->n_elem, hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync: ") + hipGetErrorString(e));
+    to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_specific_energy, h->n_cells, h->n_dust);
+    if (run_finish_kernel(h, 1, 1.0, nullptr)) return 1;
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("set_specific_energy failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+int hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms)
+{
+    if (!h) return 1;
+    if (propagate_ms) *propagate_ms = h->last_propagate_ms;
+    if (finish_ms) *finish_ms = h->last_finish_ms;
+    return 0;
+}
+
+int hyp_set_option(hyp_handle h, const char *name, int64_t value)
+{
+    if (!h || !name) return 1;
+    std::string n(name);
+    if (n == "interact_threshold") h->interact_threshold = (int)value;
+    else if (n == "emit_threshold") h->emit_threshold = (int)value;
+    else if (n == "accum_copies") h->accum_copies = (int)value;
+    else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
+    else if (n == "chunk") h->chunk = (int)value;
+    else return h->set_error("unknown option: " + n);
+    return 0;
+}
+
+// ---- imaging iteration: implemented in a later milestone -------------------
+int hyp_final_launch(hyp_handle h, uint64_t, uint64_t) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+int hyp_final_accumulators(hyp_handle h, void **, uint64_t *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+int hyp_final_finish(hyp_handle h, hyp_iter_stats *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+int hyp_final_iteration(hyp_handle h, uint64_t, hyp_iter_stats *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+int hyp_peeled_get(hyp_handle h, int, int, double *, uint64_t *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+int hyp_peeled_n_orig(hyp_handle h, int g) { return (h && g >= 0 && g < (int)h->h_peeled.size()) ? h->h_peeled[g].n_orig : -1; }
+
+}  // extern "C"

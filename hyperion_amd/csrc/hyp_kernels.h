@@ -1,0 +1,674 @@
+// hyp_kernels.h -- HIP kernels of the photon-packet engine (gfx950 / MI355X).
+//
+// Mapping: ONE PACKET PER LANE, 64 packets per wavefront, persistent waves that
+// pull packet ids from a global dispenser in chunks.  Lanes of a wave are in one
+// of three phases (walk / interact / emit); the expensive, rare phases
+// (interaction, emission) are deferred until enough lanes of the wave wait for
+// them (wave ballot + popcount) so that the hot cell-walk loop runs with little
+// divergence.  Grid walls live in LDS; density / accumulators / dust tables in
+// HBM (L2 + Infinity-Cache resident at 128^3).  Energy deposits are FP64
+// hardware atomics (global_atomic_add_f64) into one of `n_copies` accumulator
+// replicas selected by the XCD the workgroup runs on.
+#pragma once
+
+#include "hyp_device.h"
+
+enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3 };
+enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
+
+template <int NDT>
+struct Packet {
+    double r[3], v[3];
+    Angle a;
+    double s[4];
+    double nu, energy;
+    double tau_req, tau_ach;
+    double chi[NDT], albedo[NDT], kappa[NDT];
+    int ic[3], ow[3];
+    int inter;
+};
+
+// extra state carried only by the imaging (final) iteration
+struct PeelState {
+    Angle a_prev;
+    double s_prev[4], v_prev[3];
+    int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id;
+};
+
+struct Counters {
+    double energy_current;
+    unsigned long long crossings;
+    unsigned int killed_geo, killed_int, interactions;
+};
+
+template <int NDT>
+__device__ __forceinline__ int ndust(const DProblem &P) { return NDT == HYP_MAXD ? P.n_dust : NDT; }
+
+__device__ __forceinline__ void raise_error(const DProblem &P, int code, double d0, double d1, double d2)
+{
+    if (atomicCAS(P.err, 0, code) == 0) { P.err_data[0] = d0; P.err_data[1] = d1; P.err_data[2] = d2; }
+}
+
+// dust.f90:64-79
+template <int NDT>
+__device__ __forceinline__ bool update_optconsts(const DProblem &P, Packet<NDT> &p)
+{
+    const int nd = ndust<NDT>(P);
+    double lnu = log10(p.nu);
+#pragma unroll
+    for (int d = 0; d < NDT; d++) {
+        if (d < nd) {
+            const DDust &D = P.dust[d];
+            if (p.nu < D.nu_min || p.nu > D.nu_max) {
+                raise_error(P, ERR_NU_RANGE, p.nu, D.nu_min, D.nu_max);
+                return false;
+            }
+            int j = locate(D.nu, D.n_nu, p.nu);
+            double chi = interp_loglog_at(D.nu, D.log10_nu, D.chi, D.log10_chi, j, p.nu, lnu);
+            double alb = interp_loglog_at(D.nu, D.log10_nu, D.albedo, D.log10_albedo, j, p.nu, lnu);
+            p.chi[d] = chi; p.albedo[d] = alb; p.kappa[d] = chi * (1.0 - alb);
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool escaped(const DProblem &P, const int ic[3])
+{
+    return ic[0] < 0 || ic[0] >= P.n1 || ic[1] < 0 || ic[1] >= P.n2 || ic[2] < 0 || ic[2] >= P.n3;
+}
+
+__device__ __forceinline__ size_t cell_index(const DProblem &P, const int ic[3])
+{
+    return ((size_t)ic[2] * P.n2 + ic[1]) * P.n1 + ic[0];
+}
+
+struct Walls {            // LDS-resident copies of the wall tables
+    const double *w[3];
+    const double *ew[3];
+    int n[3];
+};
+
+// grid_geometry_cartesian_3d.f90:143-166
+__device__ __forceinline__ bool find_cell(const Walls &W, const double r[3], int ic[3])
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int i = locate(W.w[a], W.n[a] + 1, r[a]);
+        if (i < 0 || i >= W.n[a]) return false;
+        ic[a] = i;
+    }
+    return true;
+}
+
+// place_in_cell + adjust_wall, grid_geometry_cartesian_3d.f90:168-253
+__device__ __forceinline__ bool place_in_cell(const Walls &W, const double r[3], const double v[3], int ic[3], int ow[3])
+{
+    if (!find_cell(W, r, ic)) return false;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        ow[a] = 0;
+        int i = ic[a];
+        double wl = W.w[a][i], wu = W.w[a][i + 1];
+        if (v[a] > 0.0) {
+            if (r[a] == wl) ow[a] = -1;
+            else if (r[a] == wu) { ow[a] = -1; ic[a] = i + 1; }
+        } else if (v[a] < 0.0) {
+            if (r[a] == wl) { ow[a] = +1; ic[a] = i - 1; }
+            else if (r[a] == wu) ow[a] = +1;
+        }
+    }
+    return true;
+}
+
+// grid_geometry_cartesian_3d.f90:330-381
+__device__ __forceinline__ bool in_correct_cell(const Walls &W, const double r[3], const int ic[3], const int ow[3])
+{
+    int act[3] = {0, 0, 0};
+    bool found = find_cell(W, r, act);
+    const double thr = 1e-3;
+    if (ow[0] | ow[1] | ow[2]) {
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            int i = ic[a];
+            double wl = W.w[a][i], wu = W.w[a][i + 1];
+            if (ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
+            else if (ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
+            else ok = ok && found && act[a] == i;
+        }
+        return ok;
+    }
+    return found && act[0] == ic[0] && act[1] == ic[1] && act[2] == ic[2];
+}
+
+// find_wall + insert_t, grid_geometry_cartesian_3d.f90:424-521.  The six
+// candidate distances of the reference are (w - r)/v for the lower and upper
+// wall of each axis, kept only when positive; a quotient is positive exactly
+// when numerator and denominator have the same sign, so the divide is issued
+// only for candidates that can win (normally one per axis).
+__device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], const double v[3], const int ic[3],
+                                          const int ow[3], double &tnear, int im[3])
+{
+    double tmin = HYP_DBL_MAX, emin = 0.0;
+    im[0] = im[1] = im[2] = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int i = ic[a];
+        double wl = W.w[a][i], wu = W.w[a][i + 1];
+        double d1 = wl - r[a], d2 = wu - r[a], va = v[a];
+        bool c1 = (ow[a] != -1) && ((d1 > 0.0 && va > 0.0) || (d1 < 0.0 && va < 0.0));
+        bool c2 = (ow[a] != +1) && ((d2 > 0.0 && va > 0.0) || (d2 < 0.0 && va < 0.0));
+        if (c1 || c2) {
+            double t = (c1 ? d1 : d2) / va;
+            double e = W.ew[a][i + (c1 ? 0 : 1)];
+            int dir = c1 ? -1 : +1;
+            double emax = fmax(e, emin);
+            if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = dir; }
+            else if (t < tmin + emax) { emin = emax; im[a] = dir; }
+            if (c1 && c2) {   // both walls ahead: only after round-off misplacement
+                t = d2 / va; e = W.ew[a][i + 1];
+                emax = fmax(e, emin);
+                if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = +1; }
+                else if (t < tmin + emax) { emin = emax; im[a] = +1; }
+            }
+        }
+    }
+    tnear = tmin;
+    return (im[0] | im[1] | im[2]) != 0;
+}
+
+// One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
+// / grid_integrate_noenergy (:237-375).  Returns the lane's next phase;
+// ST_NEED_EMIT means the packet left the grid or was killed.
+template <int NDT, bool DEPOSIT>
+__device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Packet<NDT> &p, Rng &g,
+                                         double *__restrict__ sum, Counters &cnt)
+{
+    const int nd = ndust<NDT>(P);
+    if ((unsigned long long)rng_check_u32(g) < P.check_threshold) {
+        if (!in_correct_cell(W, p.r, p.ic, p.ow)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+    }
+    double tmin; int im[3];
+    if (!find_wall(W, p.r, p.v, p.ic, p.ow, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+    const size_t base = cell_index(P, p.ic) * (size_t)nd;
+    double rho[NDT];
+    double chi_rho = 0.0;
+#pragma unroll
+    for (int d = 0; d < NDT; d++) {
+        rho[d] = 0.0;
+        if (d < nd) { rho[d] = P.density[base + d]; chi_rho += p.chi[d] * rho[d]; }
+    }
+    double tau_cell = chi_rho * tmin;
+    double tau_needed = p.tau_req - p.tau_ach;
+    cnt.crossings++;
+    if (tau_cell < tau_needed) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
+        p.tau_ach += tau_cell;
+        if (DEPOSIT) {
+#pragma unroll
+            for (int d = 0; d < NDT; d++)
+                if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) { p.ic[a] += im[a]; p.ow[a] = -im[a]; }
+        return escaped(P, p.ic) ? ST_NEED_EMIT : ST_WALK;
+    } else {
+        double tact = tmin * (tau_needed / tau_cell);
+#pragma unroll
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tact * p.v[a];
+        p.tau_ach += tau_needed;
+        p.ow[0] = p.ow[1] = p.ow[2] = 0;
+        if (DEPOSIT) {
+#pragma unroll
+            for (int d = 0; d < NDT; d++)
+                if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tact * p.kappa[d] * p.energy);
+        }
+        return ST_NEED_INTERACT;
+    }
+}
+
+// fortranlib random_planck_frequency (Carter & Cashwell 1975)
+__device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
+{
+    double target = rng_uniform(g) * (HYP_PI * HYP_PI * HYP_PI * HYP_PI / 90.0);
+    double sum = 0.0; int m = 0;
+    do { m++; double dm = (double)m; sum += 1.0 / (dm * dm * dm * dm); } while (sum < target && m < 1000);
+    double x1 = rng_uniform(g), x2 = rng_uniform(g), x3 = rng_uniform(g), x4 = rng_uniform(g);
+    double x = -log((1.0 - x1) * (1.0 - x2) * (1.0 - x3) * (1.0 - x4)) / (double)m;
+    return x * HYP_K_CGS * T / HYP_H_CGS;
+}
+
+// emit: source.f90:100-179 + source_emit/emit_from_point source_type.f90:398-564.
+// Returns false on a fatal error (flag raised).
+template <int NDT>
+__device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT> &p, Rng &g,
+                                            Counters &cnt, int &source_id)
+{
+    int is = 0;
+    if (P.n_sources > 1) {
+        double xi = rng_uniform(g);
+        if (P.sample_sources_evenly) is = (int)(xi * P.n_sources);
+        else {
+            is = P.n_sources - 1;
+            for (int i = 0; i < P.n_sources - 1; i++) if (xi < P.sources[i].lum_cdf) { is = i; break; }
+        }
+    }
+    source_id = is;
+    const DSource &S = P.sources[is];
+    p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+    random_sphere_angle(g, p.a);
+    p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
+    p.energy = 1.0;
+    if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
+    else p.nu = random_planck_frequency(g, S.temperature);
+    angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
+    cnt.energy_current += p.energy;
+    if (!update_optconsts<NDT>(P, p)) return false;
+    if (!place_in_cell(W, p.r, p.v, p.ic, p.ow)) {
+        cnt.killed_geo++;
+        raise_error(P, ERR_NOT_IN_CELL, p.r[0], p.r[1], p.r[2]);
+        return false;
+    }
+    p.inter = 1;
+    return true;
+}
+
+// dust_sample_j_nu: dust_type_4elem.f90:379-398
+__device__ __forceinline__ double dust_sample_j_nu(const DDust &D, int jid, double frac, double xi)
+{
+    const size_t o = (size_t)jid * D.n_enu;
+    double nu1 = sample_log_pdf(D.emiss_x, D.emiss_cdf + o, D.emiss_bp1 + o, D.n_enu, xi);
+    double nu2 = sample_log_pdf(D.emiss_x, D.emiss_cdf + o + D.n_enu, D.emiss_bp1 + o + D.n_enu, D.n_enu, xi);
+    double l1 = log10(nu1);
+    return exp10(l1 + frac * (log10(nu2) - l1));
+}
+
+__device__ __forceinline__ void interp_P(const DDust &D, double mu, double nu, double &P1, double &P2, double &P3, double &P4)
+{
+    int i = locate(D.mu, D.n_mu, mu), j = locate(D.nu, D.n_nu, nu);
+    if (i < 0 || j < 0) { P1 = P2 = P3 = P4 = __builtin_nan(""); return; }
+    double fx = (mu - D.mu[i]) / (D.mu[i + 1] - D.mu[i]);
+    double fy = (nu - D.nu[j]) / (D.nu[j + 1] - D.nu[j]);
+    P1 = bilinear(D.P1, D.n_mu, i, j, fx, fy);
+    P2 = bilinear(D.P2, D.n_mu, i, j, fx, fy);
+    P3 = bilinear(D.P3, D.n_mu, i, j, fx, fy);
+    P4 = bilinear(D.P4, D.n_mu, i, j, fx, fy);
+}
+
+// dust_scatter: dust_type_4elem.f90:446-566
+__device__ __forceinline__ void dust_scatter(const DDust &D, double nu, Angle &a, double s[4], Rng &g)
+{
+    Angle a_scat, a_final;
+    random_sphere_angle(g, a_scat);
+    double sin_2_i1 = 2.0 * a_scat.sinp * a_scat.cosp;
+    double cos_2_i1 = 1.0 - 2.0 * a_scat.sinp * a_scat.sinp;
+    double c1 = s[0], c2 = cos_2_i1 * s[1] - sin_2_i1 * s[2];
+    double ctot = c1 + c2;
+    c1 /= ctot; c2 /= ctot;
+    const int nm = D.n_mu;
+    int inu = locate(D.nu, D.n_nu, nu);
+    double P1, P2, P3, P4;
+    if (inu == -1) {
+        P1 = 1.0; P2 = 0.0; P3 = 1.0; P4 = 0.0;
+    } else {
+        double xi = rng_uniform(g);
+        const double *C1 = D.P1_cdf + (size_t)inu * nm, *C2 = D.P2_cdf + (size_t)inu * nm;
+        int imin = 0, imax = nm - 1, imu = 0;
+        double cdf1 = 0.0, cdf2 = 1.0;
+        for (int it = 0; it < 64; it++) {
+            imu = ((imax + 1) + (imin + 1)) / 2 - 1;
+            if (D.zero_p2) { cdf1 = C1[imu]; cdf2 = C1[imu + 1]; }
+            else { cdf1 = c1 * C1[imu] + c2 * C2[imu]; cdf2 = c1 * C1[imu + 1] + c2 * C2[imu + 1]; }
+            if (xi > cdf2) imin = imu;
+            else if (xi < cdf1) imax = imu;
+            else break;
+            if (imin == imax) break;
+        }
+        a_scat.cost = (xi - cdf1) / (cdf2 - cdf1) * (D.mu[imu + 1] - D.mu[imu]) + D.mu[imu];
+        a_scat.sint = sqrt(1.0 - a_scat.cost * a_scat.cost);
+        interp_P(D, a_scat.cost, nu, P1, P2, P3, P4);
+    }
+    rotate_angle(a_scat, a, a_final);
+    scatter_stokes(s, a, a_scat, a_final, P1, P2, P3, P4);
+    a = a_final;
+    double norm = 1.0 / s[0];
+    s[0] = 1.0; s[1] *= norm; s[2] *= norm; s[3] *= norm;
+}
+
+// interact: dust_interact.f90:22-79 (+ select_dust_chi_rho grid_physics_3d.f90:87-99).
+// Returns false on a fatal error.  `scattered`/`dust_id` report what happened.
+template <int NDT>
+__device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT> &p, Rng &g, Counters &cnt,
+                                         int &scattered, int &dust_id)
+{
+    const int nd = ndust<NDT>(P);
+    const size_t base = cell_index(P, p.ic) * (size_t)nd;
+    int id = 0;
+    double albedo = p.albedo[0];
+    if (NDT > 1 && nd > 1) {
+        double cdf[NDT], c = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * P.density[base + d]; cdf[d] = c; }
+        double xi = rng_uniform(g);
+        id = nd - 1; albedo = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int d = 0; d < NDT; d++) {
+            if (d < nd) {
+                if (!found && d < nd - 1 && xi < cdf[d] / c) { id = d; found = true; }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < NDT; d++) if (d == id) albedo = p.albedo[d];
+    }
+    dust_id = id;
+    cnt.interactions++;
+    double xi = rng_uniform(g);
+    if (xi > albedo) {
+        const DDust &D = P.dust[id];
+        int jid = P.jnu_id[base + id];
+        double frac = P.jnu_frac[base + id];
+        p.nu = dust_sample_j_nu(D, jid, frac, rng_uniform(g));
+        p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
+        random_sphere_angle(g, p.a);
+        scattered = 0;
+        if (!update_optconsts<NDT>(P, p)) return false;
+    } else {
+        dust_scatter(P.dust[id], p.nu, p.a, p.s, g);
+        scattered = 1;
+    }
+    angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    return true;
+}
+
+// wave-level sum of a double (64 lanes)
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ unsigned int xcc_id()
+{
+    unsigned int x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 0xf;
+}
+
+// Hands out packet ids to the lanes of a wave that need one.  The wave owns a
+// private range [next, end) refilled `chunk` ids at a time from the global
+// dispenser, so the global atomic is hit once per `chunk` packets.
+struct Dispenser {
+    unsigned long long next, end;
+};
+
+__device__ __forceinline__ bool take_id(const DProblem &P, const LaunchParams &L, Dispenser &dsp, bool need,
+                                        unsigned long long &id)
+{
+    bool got = false;
+    unsigned long long mask = __ballot(need);
+    const unsigned int lane = __lane_id();
+    while (mask) {
+        if (dsp.next >= dsp.end) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(P.counter, (unsigned long long)L.chunk);
+            b = __shfl(b, 0, 64);
+            if (b >= L.end_id) break;       // pool exhausted
+            dsp.next = b;
+            dsp.end = (b + (unsigned long long)L.chunk < L.end_id) ? b + (unsigned long long)L.chunk : L.end_id;
+        }
+        unsigned long long avail = dsp.end - dsp.next;
+        unsigned int rank = __popcll(mask & ((1ull << lane) - 1ull));
+        bool mine = ((mask >> lane) & 1ull) && rank < avail;
+        if (mine) { id = dsp.next + rank; got = true; }
+        unsigned long long taken = __ballot(mine);
+        dsp.next += __popcll(taken);
+        mask &= ~taken;
+    }
+    return got;
+}
+
+// ---------------------------------------------------------------------------
+// Lucy iteration: do_lucy packet loop, iter_lucy.f90:119-209
+// ---------------------------------------------------------------------------
+template <int NDT>
+__global__ __launch_bounds__(256) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    {
+        const int m1 = P.n1 + 1, m2 = P.n2 + 1, m3 = P.n3 + 1;
+        double *w0 = lds, *w1 = w0 + m1, *w2 = w1 + m2;
+        double *e0 = w2 + m3, *e1 = e0 + m1, *e2 = e1 + m2;
+        for (int i = threadIdx.x; i < m1; i += blockDim.x) { w0[i] = P.w[0][i]; e0[i] = P.ew[0][i]; }
+        for (int i = threadIdx.x; i < m2; i += blockDim.x) { w1[i] = P.w[1][i]; e1[i] = P.ew[1][i]; }
+        for (int i = threadIdx.x; i < m3; i += blockDim.x) { w2[i] = P.w[2][i]; e2[i] = P.ew[2][i]; }
+        W.w[0] = w0; W.w[1] = w1; W.w[2] = w2; W.ew[0] = e0; W.ew[1] = e1; W.ew[2] = e2;
+        W.n[0] = P.n1; W.n[1] = P.n2; W.n[2] = P.n3;
+        __syncthreads();
+    }
+    double *sum = P.sum;
+    if (P.n_copies > 1) sum += (size_t)(xcc_id() % (unsigned)P.n_copies) * P.copy_stride;
+
+    Packet<NDT> p;
+    Rng g;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    Dispenser dsp; dsp.next = 0; dsp.end = 0;
+    int st = ST_NEED_EMIT;
+    bool pool_empty = false;
+    rng_init(g, P.seed_key, L.iter_tag, 0);
+    p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+
+    for (;;) {
+        unsigned long long m_walk = __ballot(st == ST_WALK);
+        unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
+        unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
+        if (!(m_walk | m_int | m_emit)) break;
+
+        // ---- interaction phase (deferred until enough lanes wait) ----
+        if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
+            if (st == ST_NEED_INTERACT) {
+                if ((long long)p.inter == P.n_inter_max + 1) {
+                    cnt.killed_int++; st = ST_NEED_EMIT;
+                } else {
+                    int scattered, dust_id;
+                    bool ok = interact<NDT>(P, p, g, cnt, scattered, dust_id);
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                    if (killed) st = ST_NEED_EMIT;
+                    else {
+                        p.inter++;
+                        p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
+        // ---- emission phase ----
+        if (m_emit && !pool_empty && (__popcll(m_emit) >= L.emit_threshold || !m_walk)) {
+            unsigned long long id = 0;
+            bool got = take_id(P, L, dsp, st == ST_NEED_EMIT, id);
+            if (st == ST_NEED_EMIT) {
+                if (!got) st = ST_DONE;
+                else {
+                    rng_init(g, P.seed_key, L.iter_tag, id);
+                    int source_id;
+                    bool ok = emit_packet<NDT>(P, W, p, g, cnt, source_id);
+                    if (!ok) st = ST_NEED_EMIT;
+                    else if (escaped(P, p.ic)) st = ST_NEED_EMIT;
+                    else {
+                        p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    }
+                }
+            }
+            if (__ballot(st == ST_DONE)) pool_empty = true;
+            if (*((volatile int *)P.err) != 0) { if (st == ST_NEED_EMIT) st = ST_DONE; pool_empty = true; }
+        } else if (m_emit && pool_empty) {
+            if (st == ST_NEED_EMIT) st = ST_DONE;
+        }
+
+        // ---- walk phase: a few cell crossings per outer iteration ----
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            if (st == ST_WALK) st = walk_step<NDT, true>(P, W, p, g, sum, cnt);
+        }
+    }
+
+    // per-wave reduction of the scalar tallies, one atomic per wave and slot
+    double e = wave_sum(cnt.energy_current);
+    double c = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    double ki = wave_sum((double)cnt.killed_int);
+    double ni = wave_sum((double)cnt.interactions);
+    if (__lane_id() == 0) {
+        unsafeAtomicAdd(&P.tail[TAIL_ENERGY], e);
+        unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], c);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
+        unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Elementwise kernels of the iteration epilogue
+// ---------------------------------------------------------------------------
+
+// sum[0][k] += sum[c][k], c = 1..n_copies-1  (before the collective)
+__global__ void reduce_copies_kernel(double *__restrict__ sum, size_t n, size_t stride, int n_copies)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        double s = sum[i];
+        for (int c = 1; c < n_copies; c++) s += sum[i + (size_t)c * stride];
+        sum[i] = s;
+    }
+}
+
+struct FinishParams {
+    double scale;           // energy_total / energy_current
+    int enforce_energy_range, additional, write_out, pad;
+};
+
+// dust_jnu_var_pos_frac: dust_type_4elem.f90:295-320
+__device__ __forceinline__ void jnu_var_pos_frac(const DDust &D, double e, int &id, double &frac)
+{
+    int n = D.n_jnu;
+    if (e < D.jnu_var[0]) { id = 0; frac = 0.0; }
+    else if (e > D.jnu_var[n - 1]) { id = n - 2; frac = 1.0; }
+    else {
+        int j = locate(D.jnu_var, n, e);
+        id = j;
+        frac = (log10(e) - D.log10_jnu_var[j]) / (D.log10_jnu_var[j + 1] - D.log10_jnu_var[j]);
+    }
+}
+
+__device__ __forceinline__ double clamp_energy(const DDust &D, double e, int enforce)
+{
+    if (e < D.minimum_specific_energy) e = D.minimum_specific_energy;
+    if (enforce && D.have_e_range) {
+        if (e < D.e_min) e = D.e_min;
+        if (e > D.e_max) e = D.e_max;
+    }
+    return e;
+}
+
+__device__ __forceinline__ double chi_rosseland(const DDust &D, double e)
+{
+    int j = locate(D.mo_e, D.n_e, e);
+    if (j < 0) return __builtin_nan("");
+    double y1 = D.mo_chi_ross[j], y2 = D.mo_chi_ross[j + 1];
+    if (y1 > 0.0 && y2 > 0.0) {
+        double f = (log10(e) - log10(D.mo_e[j])) / (log10(D.mo_e[j + 1]) - log10(D.mo_e[j]));
+        return exp10(log10(y1) + f * (log10(y2) - log10(y1)));
+    }
+    return y1 + (e - D.mo_e[j]) / (D.mo_e[j + 1] - D.mo_e[j]) * (y2 - y1);
+}
+
+// update_energy_abs + check_energy_abs + sublimate_dust + update_energy_abs_tot
+// + precompute_jnu_var fused (grid_physics_3d.f90:420-629).  One thread per
+// (cell, dust) element of the cell-major arrays.  mode 0: full update from the
+// accumulators; mode 1: only clamp + jnu_var + totals (used at create time).
+__global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, int mode,
+                              double *__restrict__ specific_energy, double *__restrict__ density,
+                              const double *__restrict__ additional, int *__restrict__ jnu_id,
+                              double *__restrict__ jnu_frac, double *__restrict__ energy_abs_tot,
+                              double *__restrict__ out_ref_layout)
+{
+    const DProblem &P = *Pp;
+    const int nd = P.n_dust;
+    const size_t n = (size_t)P.n_cells * nd;
+    double local_tot[HYP_MAXD];
+#pragma unroll
+    for (int d = 0; d < HYP_MAXD; d++) local_tot[d] = 0.0;
+    size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        size_t ic = k / nd;
+        int d = (int)(k - ic * nd);
+        int i1 = (int)(ic % P.n1);
+        size_t t = ic / P.n1;
+        int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
+        double vol = (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
+        const DDust &D = P.dust[d];
+        double e;
+        if (mode == 0) {
+            e = P.sum[k] * F.scale / vol;
+            if (vol == 0.0) e = 0.0;
+            if (F.additional) e += additional[k];
+        } else {
+            e = specific_energy[k];
+        }
+        e = clamp_energy(D, e, F.enforce_energy_range);
+        double rho = density[k];
+        if (mode == 0 && D.sublimation_mode != 0) {
+            double es = D.sublimation_specific_energy;
+            if (e > es) {
+                if (D.sublimation_mode == 1) { rho = 0.0; e = D.minimum_specific_energy; }
+                else if (D.sublimation_mode == 2) {
+                    double r = chi_rosseland(D, e) / chi_rosseland(D, es);
+                    rho = rho * es / e * r * r; e = es;
+                } else e = es;
+                density[k] = rho;
+            }
+            e = clamp_energy(D, e, F.enforce_energy_range);
+        }
+        specific_energy[k] = e;
+        if (out_ref_layout) out_ref_layout[(size_t)d * P.n_cells + ic] = e;
+        int id; double fr;
+        jnu_var_pos_frac(D, e, id, fr);
+        jnu_id[k] = id; jnu_frac[k] = fr;
+#pragma unroll
+        for (int dd = 0; dd < HYP_MAXD; dd++) if (dd == d) local_tot[dd] += e * rho * vol;
+    }
+    for (int d = 0; d < nd; d++) {
+        double s = wave_sum(local_tot[d]);
+        if (__lane_id() == 0 && s != 0.0) unsafeAtomicAdd(&energy_abs_tot[d], s);
+    }
+}
+
+// [n_dust][n_cells] (reference layout) <-> [n_cells][n_dust] (device layout)
+__global__ void to_cell_major_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
+{
+    size_t n = n_cells * nd, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        size_t ic = k / nd; int d = (int)(k - ic * nd);
+        out[k] = in[(size_t)d * n_cells + ic];
+    }
+}
+
+__global__ void to_ref_layout_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
+{
+    size_t n = n_cells * nd, step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        size_t ic = k / nd; int d = (int)(k - ic * nd);
+        out[(size_t)d * n_cells + ic] = in[k];
+    }
+}

@@ -1,0 +1,210 @@
+"""ctypes binding of the C-ABI in ``include/hyperion_amd.h`` (the HIP engine).
+
+There is no CPU fallback: if the shared library is missing or no GPU is
+present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import IterStats, MarshalledProblem, ProblemDesc
+from .build import LIB
+
+_dp = C.POINTER(C.c_double)
+
+EXPORTS = [
+    "hyp_abi_version", "hyp_create", "hyp_destroy", "hyp_last_error",
+    "hyp_lucy_iteration", "hyp_lucy_launch", "hyp_lucy_accumulators", "hyp_lucy_finish",
+    "hyp_final_iteration", "hyp_final_launch", "hyp_final_accumulators", "hyp_final_finish",
+    "hyp_peeled_get", "hyp_peeled_n_orig",
+    "hyp_get_specific_energy", "hyp_get_density", "hyp_set_specific_energy",
+    "hyp_last_kernel_ms", "hyp_set_option",
+]
+
+
+class EngineError(RuntimeError):
+    """Raised when the engine reports a non-zero status; carries the message
+    the reference would have printed before stopping."""
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libhyperion_amd.so and declare the prototypes.  Raises if absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB
+    if not os.path.exists(path):
+        raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    H = C.c_void_p
+    L.hyp_abi_version.restype = C.c_int
+    L.hyp_create.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.POINTER(H)]
+    L.hyp_destroy.argtypes = [H]
+    L.hyp_destroy.restype = None
+    L.hyp_last_error.argtypes = [H]
+    L.hyp_last_error.restype = C.c_char_p
+    L.hyp_lucy_iteration.argtypes = [H, C.c_uint64, C.c_int, _dp, C.POINTER(IterStats)]
+    L.hyp_lucy_launch.argtypes = [H, C.c_uint64, C.c_uint64, C.c_int]
+    L.hyp_lucy_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.hyp_lucy_finish.argtypes = [H, _dp, C.POINTER(IterStats)]
+    L.hyp_final_iteration.argtypes = [H, C.c_uint64, C.POINTER(IterStats)]
+    L.hyp_final_launch.argtypes = [H, C.c_uint64, C.c_uint64]
+    L.hyp_final_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.hyp_final_finish.argtypes = [H, C.POINTER(IterStats)]
+    L.hyp_peeled_get.argtypes = [H, C.c_int, C.c_int, _dp, C.POINTER(C.c_uint64)]
+    L.hyp_peeled_n_orig.argtypes = [H, C.c_int]
+    L.hyp_get_specific_energy.argtypes = [H, _dp]
+    L.hyp_get_density.argtypes = [H, _dp]
+    L.hyp_set_specific_energy.argtypes = [H, _dp]
+    L.hyp_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hyp_set_option.argtypes = [H, C.c_char_p, C.c_int64]
+    if path == LIB:
+        _lib = L
+    return L
+
+
+class _DeviceBlock:
+    """Exposes a raw device pointer through ``__cuda_array_interface__`` so that
+    torch can alias it (zero-copy) for the RCCL all-reduce."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {
+            "shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None,
+        }
+
+
+class Engine:
+    """One problem resident on one GPU.  Mirrors the reference's run sequence
+    (``src/main/main.f90:167-234``): create -> N x lucy_iteration -> final."""
+
+    def __init__(self, problem, device=0):
+        self._lib = load_library()
+        self._m = MarshalledProblem(problem)
+        self.problem = problem
+        self.shape = problem.density.shape
+        self._h = C.c_void_p()
+        rc = self._lib.hyp_create(C.byref(self._m.desc), int(device), C.byref(self._h))
+        if rc != 0:
+            raise EngineError(self._lib.hyp_last_error(None).decode())
+        self.device = int(device)
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hyp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise EngineError(self._lib.hyp_last_error(self._h).decode())
+
+    def set_option(self, name, value):
+        self._check(self._lib.hyp_set_option(self._h, name.encode(), int(value)))
+
+    # -- Lucy iteration ---------------------------------------------------------
+    def lucy_iteration(self, n_packets, iteration, want_output=True):
+        out = np.empty(self.shape, dtype=np.float64) if want_output else None
+        st = IterStats()
+        self._check(self._lib.hyp_lucy_iteration(self._h, int(n_packets), int(iteration),
+                                                 out.ctypes.data_as(_dp) if out is not None else None, C.byref(st)))
+        return out, st.as_dict()
+
+    def lucy_launch(self, first_id, n_local, iteration):
+        self._check(self._lib.hyp_lucy_launch(self._h, int(first_id), int(n_local), int(iteration)))
+
+    def lucy_accumulators(self):
+        """(device pointer, n_doubles) of the accumulator block; waits for the kernel."""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self._lib.hyp_lucy_accumulators(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def lucy_accumulators_tensor(self):
+        import torch
+        ptr, n = self.lucy_accumulators()
+        return torch.as_tensor(_DeviceBlock(ptr, n), device="cuda:%d" % self.device)
+
+    def lucy_finish(self, want_output=True):
+        out = np.empty(self.shape, dtype=np.float64) if want_output else None
+        st = IterStats()
+        self._check(self._lib.hyp_lucy_finish(self._h, out.ctypes.data_as(_dp) if out is not None else None, C.byref(st)))
+        return out, st.as_dict()
+
+    # -- final iteration -------------------------------------------------------
+    def final_iteration(self, n_packets):
+        st = IterStats()
+        self._check(self._lib.hyp_final_iteration(self._h, int(n_packets), C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    def final_launch(self, first_id, n_local):
+        self._check(self._lib.hyp_final_launch(self._h, int(first_id), int(n_local)))
+
+    def final_accumulators_tensor(self):
+        import torch
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self._lib.hyp_final_accumulators(self._h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DeviceBlock(p.value, n.value), device="cuda:%d" % self.device)
+
+    def final_finish(self):
+        st = IterStats()
+        self._check(self._lib.hyp_final_finish(self._h, C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    def peeled_results(self):
+        out = []
+        for g in range(len(self.problem.peeled)):
+            n_orig = self._lib.hyp_peeled_n_orig(self._h, g)
+            sed_shape, img_shape = self._m.peeled_shapes(g, n_orig)
+            grp = {}
+            for which, name, shape in ((0, "sed", sed_shape), (1, "sed2", sed_shape),
+                                       (2, "img", img_shape), (3, "img2", img_shape)):
+                if shape is None:
+                    continue
+                a = np.empty(shape, dtype=np.float64)
+                n = C.c_uint64(a.size)
+                self._check(self._lib.hyp_peeled_get(self._h, g, which, a.ctypes.data_as(_dp), C.byref(n)))
+                grp[name] = a
+            out.append(grp)
+        return out
+
+    # -- state -------------------------------------------------------------------
+    def specific_energy(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self._check(self._lib.hyp_get_specific_energy(self._h, out.ctypes.data_as(_dp)))
+        return out
+
+    def density(self):
+        out = np.empty(self.shape, dtype=np.float64)
+        self._check(self._lib.hyp_get_density(self._h, out.ctypes.data_as(_dp)))
+        return out
+
+    def set_specific_energy(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != self.shape:
+            raise ValueError("specific_energy array has wrong shape")
+        self._check(self._lib.hyp_set_specific_energy(self._h, a.ctypes.data_as(_dp)))
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        self._check(self._lib.hyp_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value

@@ -1,0 +1,209 @@
+/*
+ * hyperion_amd.h -- C-ABI of the MI355X photon-packet engine.
+ *
+ * The reference (hyperion-rt/hyperion) has no in-process FFI for this path:
+ * its Python front-end writes an HDF5 .rtin and spawns the Fortran binary
+ * (hyperion/model/model.py:1025-1080 -> scripts/hyperion:39-92 ->
+ * src/main/main.f90).  This header is the array-based seam a maintainer would
+ * bind instead of that subprocess (see INTEGRATION.md for the ctypes stub):
+ * each entry point cites the reference routine it replaces.  Plain pointers
+ * and sizes only; the caller owns every host buffer; descriptors are borrowed
+ * for the duration of hyp_create() and copied to the device.
+ *
+ * Error convention (mirrors "non-zero exit + message in the log",
+ * scripts/hyperion:98-104, hyperion/model/tests/test_fortran.py): every
+ * function returns 0 on success and non-zero on failure; hyp_last_error()
+ * then carries the reference's message text (e.g. "photon was not emitted
+ * inside a cell", src/sources/source.f90:177).  No exceptions cross the ABI.
+ * A handle is not thread-safe (the reference keeps the same state in
+ * process-global Fortran module variables).
+ */
+#ifndef HYPERION_AMD_H
+#define HYPERION_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYP_MAX_DUST 8
+#define HYP_ABI_VERSION 1
+
+/* /Dust/dust_NNN of the .rtin -- src/dust/dust_type_4elem.f90:78-293 */
+typedef struct hyp_dust_desc {
+    int32_t n_nu;               /* optical_properties rows */
+    int32_t n_mu;               /* scattering_angles rows */
+    int32_t n_jnu;              /* emissivity_variable rows */
+    int32_t n_enu;              /* emissivities rows */
+    int32_t n_e;                /* mean_opacities rows (0 if absent) */
+    int32_t sublimation_mode;   /* 0 no, 1 fast, 2 slow, 3 cap */
+    int32_t version;
+    int32_t is_lte;
+    double  sublimation_specific_energy;
+    double  minimum_specific_energy;  /* Grid/Quantities attr for this species */
+    const double *nu;           /* [n_nu] Hz, increasing */
+    const double *albedo;       /* [n_nu] */
+    const double *chi;          /* [n_nu] cm^2/g */
+    const double *mu;           /* [n_mu] */
+    const double *P1;           /* [n_nu][n_mu] */
+    const double *P2;
+    const double *P3;
+    const double *P4;
+    const double *emiss_nu;     /* [n_enu] */
+    const double *emiss_jnu;    /* [n_enu][n_jnu] */
+    const double *emiss_var;    /* [n_jnu] specific energy */
+    const double *mo_specific_energy; /* [n_e] or NULL */
+    const double *mo_chi_rosseland;   /* [n_e] or NULL */
+} hyp_dust_desc;
+
+/* /Sources/source_NNNNN -- src/sources/source_type.f90:102-322 */
+typedef struct hyp_source_desc {
+    int32_t type;          /* 1 point */
+    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
+    int32_t peeloff;
+    int32_t n_spec;
+    double  luminosity;
+    double  temperature;
+    double  position[3];
+    double  radius;
+    double  box[6];
+    const double *spec_nu;
+    const double *spec_fnu;
+} hyp_source_desc;
+
+/* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 */
+typedef struct hyp_grid_desc {
+    int32_t type;          /* 1 cartesian */
+    int32_t n1, n2, n3;
+    const double *w1;      /* [n1+1] */
+    const double *w2;
+    const double *w3;
+} hyp_grid_desc;
+
+/* root attributes -- src/main/setup_rt.f90:38-302 */
+typedef struct hyp_config {
+    int64_t seed;
+    int64_t n_inter_max;
+    int64_t n_reabs_max;
+    int32_t kill_on_absorb;
+    int32_t kill_on_scatter;
+    int32_t sample_sources_evenly;
+    int32_t enforce_energy_range;
+    int32_t forced_first_interaction;
+    int32_t forced_first_interaction_algorithm; /* 1 wr99, 2 baes16 */
+    int32_t specific_energy_type;               /* 0 initial, 1 additional */
+    int32_t reserved0;
+    double  baes16_xi;
+    double  propagation_check_frequency;
+} hyp_config;
+
+/* /Output/Peeled/group_NNNNN -- src/images/images_peeled.f90:272-380,
+ * src/images/image_type.f90:153-335 */
+typedef struct hyp_peeled_desc {
+    int32_t n_view;
+    int32_t inside_observer;
+    int32_t ignore_optical_depth;
+    int32_t compute_image;
+    int32_t compute_sed;
+    int32_t n_x, n_y;
+    int32_t n_ap;
+    int32_t n_nu;
+    int32_t track_origin;    /* 0 no, 1 basic, 2 detailed, 3 scatterings */
+    int32_t track_n_scat;
+    int32_t uncertainties;
+    int32_t compute_stokes;
+    int32_t reserved0;
+    double  x_min, x_max, y_min, y_max;
+    double  ap_min, ap_max;
+    double  nu_min, nu_max;
+    double  d_min, d_max;
+    double  peeloff_origin[3];
+    const double *theta;     /* [n_view] deg */
+    const double *phi;       /* [n_view] deg */
+} hyp_peeled_desc;
+
+typedef struct hyp_problem {
+    hyp_grid_desc grid;
+    hyp_config    config;
+    int32_t n_dust;
+    int32_t n_sources;
+    int32_t n_peeled;
+    int32_t reserved0;
+    const hyp_dust_desc   *dust;
+    const hyp_source_desc *sources;
+    const hyp_peeled_desc *peeled;
+    const double *density;           /* [n_dust][n3][n2][n1] as in the .rtin */
+    const double *specific_energy;   /* same shape, or NULL */
+} hyp_problem;
+
+typedef struct hyp_iter_stats {
+    double   energy_current;               /* src/sources/source.f90:163 */
+    double   energy_abs_tot[HYP_MAX_DUST]; /* grid_physics_3d.f90:605-611 */
+    uint64_t killed_geo;                   /* src/main/counters.f90:8-10 */
+    uint64_t killed_int;
+    uint64_t crossings;                    /* cell steps taken (roofline unit) */
+    uint64_t interactions;
+    uint64_t n_packets;
+} hyp_iter_stats;
+
+typedef struct hyp_engine *hyp_handle;
+
+/* setup_initial (src/main/setup_rt.f90:27): build tables, copy to the GPU
+ * selected by `device` (HIP ordinal).  On failure *out is NULL and the message
+ * is available from hyp_last_error(NULL). */
+int  hyp_create(const hyp_problem *problem, int device, hyp_handle *out);
+void hyp_destroy(hyp_handle h);
+const char *hyp_last_error(hyp_handle h);
+int  hyp_abi_version(void);
+
+/* do_lucy (src/main/iter_lucy.f90:66-237): one whole temperature iteration on
+ * one GPU.  `iteration` is the 1-based Lucy iteration (part of the RNG key).
+ * specific_energy_out: [n_dust][n_cells] host buffer or NULL. */
+int  hyp_lucy_iteration(hyp_handle h, uint64_t n_packets, int iteration,
+                        double *specific_energy_out, hyp_iter_stats *stats);
+
+/* The same iteration split for multi-GPU sharding (replaces the MPI chunk
+ * dispatcher + MPI_Reduce/Bcast of src/mpi/mpi_routines.f90:62-323):
+ *   launch      : zero the accumulators and propagate packet ids
+ *                 [first_id, first_id + n_local) asynchronously;
+ *   accumulators: device pointer + length (in doubles) of the contiguous
+ *                 accumulator block [specific_energy_sum | energy_current |
+ *                 killed_geo | killed_int | crossings | interactions]; waits
+ *                 for the propagation to finish.  The caller all-reduces this
+ *                 block in place across ranks (one RCCL call);
+ *   finish      : update_energy_abs + sublimate_dust on the (reduced) block. */
+int  hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration);
+int  hyp_lucy_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
+int  hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *stats);
+
+/* do_final + peeloff_photon (src/main/iter_final.f90:60-273,
+ * src/images/images_peeled.f90:95-270).  Same split as above; the accumulator
+ * block is [all sed/img cubes | energy_current | killed counters ...]. */
+int  hyp_final_iteration(hyp_handle h, uint64_t n_packets, hyp_iter_stats *stats);
+int  hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local);
+int  hyp_final_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
+int  hyp_final_finish(hyp_handle h, hyp_iter_stats *stats);
+/* image cubes after hyp_final_finish, .rtout layout, scaled by
+ * energy_total/energy_current (image_type.f90:136-151) but not yet
+ * normalised by d(nu) (done at write time, image_type.f90:652-688).
+ * which: 0 sed, 1 sed^2, 2 img, 3 img^2.  out may be NULL to query n. */
+int  hyp_peeled_get(hyp_handle h, int group, int which, double *out, uint64_t *n_doubles);
+int  hyp_peeled_n_orig(hyp_handle h, int group);
+
+/* current state, reference layout [n_dust][n_cells] */
+int  hyp_get_specific_energy(hyp_handle h, double *out);
+int  hyp_get_density(hyp_handle h, double *out);
+int  hyp_set_specific_energy(hyp_handle h, const double *in);
+
+/* measurement hooks for bench.py: duration (ms, HIP events on the engine's
+ * stream) of the last propagation kernel and of the last finish step. */
+int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
+/* tuning knobs (environment-independent): name in {"interact_threshold",
+ * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk"} */
+int  hyp_set_option(hyp_handle h, const char *name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
