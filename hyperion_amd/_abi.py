@@ -1,6 +1,6 @@
 """ctypes mirror of ``include/hyperion_amd.h`` and the marshalling of a
 :class:`hyperion_amd.problem.Problem` into it.  The structs are plain C (no
-torch types); the same layout is used by the test oracle (``oracle/hyp_oracle.h``).
+torch types).
 """
 from __future__ import annotations
 

@@ -130,7 +130,7 @@ struct hyp_engine {
     hyp_iter_stats last_stats{};
 
     // options
-    int interact_threshold = 24, emit_threshold = 16, accum_copies = 1, blocks_per_cu = 0, chunk = 0;
+    int interact_threshold = 24, emit_threshold = 16, accum_copies = 8, blocks_per_cu = 0, chunk = 0;
 
     int set_error(const std::string &m) { err = m; return 1; }
 };

@@ -1,0 +1,53 @@
+"""Multi-GPU sharding of one iteration: one process per GPU, packets split into
+contiguous global-id ranges, ONE all-reduce of the accumulator block.
+
+Replaces the reference's MPI master/worker chunk dispatcher and
+``MPI_Reduce`` + ``MPI_Bcast`` (``src/mpi/mpi_routines.f90:62-323``): because the
+per-packet Philox streams are keyed by the global packet id, the result does not
+depend on the number of ranks (up to FP64 summation order), and because every
+rank applies ``update_energy_abs`` to the same reduced block no broadcast is
+needed.
+"""
+from __future__ import annotations
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous id range [first, first + n_local) of `rank`."""
+    first = (n_total * rank) // world_size
+    last = (n_total * (rank + 1)) // world_size
+    return first, last - first
+
+
+def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all_reduce=None, want_output=True):
+    """One Lucy iteration of `n_total` packets over `world_size` ranks.
+
+    `engine` provides lucy_launch / lucy_accumulators_tensor / lucy_finish
+    (hyperion_amd.Engine); `all_reduce(tensor)` sums in place across ranks
+    (``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
+    first, n_local = shard_range(n_total, rank, world_size)
+    engine.lucy_launch(first, n_local, iteration)
+    acc = engine.lucy_accumulators_tensor()
+    if world_size > 1:
+        if all_reduce is None:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        else:
+            all_reduce(acc)
+    out, stats = engine.lucy_finish(want_output=want_output)
+    stats["n_packets"] = n_total
+    return out, stats
+
+
+def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=None):
+    first, n_local = shard_range(n_total, rank, world_size)
+    engine.final_launch(first, n_local)
+    acc = engine.final_accumulators_tensor()
+    if world_size > 1:
+        if all_reduce is None:
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        else:
+            all_reduce(acc)
+    res, stats = engine.final_finish()
+    stats["n_packets"] = n_total
+    return res, stats

@@ -1216,6 +1216,21 @@ int orc_lucy_finish(orc_state *st, double *specific_energy_out, orc_iter_stats *
     return 0;
 }
 
+/* overwrite the pending accumulators (used by the 2-rank gloo test after the
+ * all-reduce): block = [sum (n_dust*n_cells) | energy_current | killed_geo |
+ * killed_int | crossings | interactions] */
+int orc_set_accumulators(orc_state *st, const double *block)
+{
+    size_t ntot = (size_t)st->n_dust * st->n_cells;
+    memcpy(st->specific_energy_sum, block, sizeof(double) * ntot);
+    st->pending.energy_current = block[ntot];
+    st->pending.killed_geo = (uint64_t)block[ntot + 1];
+    st->pending.killed_int = (uint64_t)block[ntot + 2];
+    st->pending.crossings = (uint64_t)block[ntot + 3];
+    st->pending.interactions = (uint64_t)block[ntot + 4];
+    return 0;
+}
+
 int orc_lucy_iteration(orc_state *st, uint64_t n_packets, int iter, int n_threads,
                        double *specific_energy_out, orc_iter_stats *stats)
 {

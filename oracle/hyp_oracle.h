@@ -169,6 +169,7 @@ int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local,
                         int iter, int n_threads, orc_iter_stats *stats);
 int orc_lucy_finish(orc_state *st, double *specific_energy_out,
                     orc_iter_stats *stats);
+int orc_set_accumulators(orc_state *st, const double *block);
 /* raw accumulators after accumulate: [n_dust][n_cells] */
 const double *orc_specific_energy_sum(const orc_state *st);
 const double *orc_specific_energy(const orc_state *st);

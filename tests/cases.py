@@ -1,0 +1,55 @@
+"""Shared problem builders for the tests (small cases of BASELINE.json's configs
+and the edge cases the reference's own tests exercise)."""
+import os
+
+import numpy as np
+
+from hyperion_amd.benchmark import LSUN, PC, load_test_dust, make_benchmark_problem
+from hyperion_amd.problem import Problem, RunConfig, Source
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_problem(name):
+    path = os.path.join(GOLDEN, name)
+    return Problem.from_npz(path), np.load(path, allow_pickle=False)
+
+
+def ragged_grid_problem(scale=1.0, seed=3, n_sources=2, vertex_source=True):
+    """Irregular (ragged) wall spacing, random density with some empty cells,
+    sources on cell vertices / edges (hyperion/model/tests/test_propagation.py:24-135)
+    and an arbitrary overall length scale (:138-149 uses 1e-20 .. 1e20)."""
+    rng = np.random.RandomState(seed)
+    def walls(n):
+        w = np.sort(rng.uniform(-1.0, 1.0, n - 1))
+        return np.concatenate([[-1.0], w, [1.0]]) * scale
+    w = [walls(6), walls(5), walls(7)]
+    n1, n2, n3 = (a.size - 1 for a in w)
+    rho = rng.uniform(0.2, 3.0, (1, n3, n2, n1)) / scale
+    rho[0][rng.uniform(size=(n3, n2, n1)) < 0.15] = 0.0      # empty cells
+    srcs = []
+    for i in range(n_sources):
+        if vertex_source and i == 0:
+            pos = (w[0][2], w[1][2], w[2][3])                 # exactly on a vertex
+        elif vertex_source and i == 1:
+            pos = (w[0][3], 0.123 * scale, w[2][1])           # on an edge
+        else:
+            pos = tuple(rng.uniform(-0.9, 0.9, 3) * scale)
+        srcs.append(Source(type="point", luminosity=LSUN * (i + 1), position=pos, temperature=3000.0 + 2000.0 * i))
+    return Problem(walls=w, density=rho, dust=[load_test_dust()], sources=srcs, config=RunConfig())
+
+
+def spectrum_source_problem():
+    p = make_benchmark_problem(12, tau=2.0)
+    nu = np.logspace(12.0, 15.5, 40)
+    fnu = nu ** -0.7 * np.exp(-nu / 2e15)
+    p.sources = [Source(type="point", luminosity=LSUN, position=(0.1 * PC, -0.2 * PC, 0.3 * PC),
+                        spectrum_nu=nu, spectrum_fnu=fnu)]
+    return p
+
+
+def assert_parity(a, b, rtol=1e-9):
+    """GPU vs oracle on identical Philox streams.  rtol covers FP64 atomic
+    summation order and 1-ulp libm differences; the absolute term covers cells
+    whose whole content is one cancellation-dominated partial step."""
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-12 * np.abs(b).max())

@@ -42,6 +42,7 @@ def lib():
         L.orc_lucy_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_int, _dp, C.POINTER(IterStats)]
         L.orc_lucy_accumulate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
         L.orc_lucy_finish.argtypes = [C.c_void_p, _dp, C.POINTER(IterStats)]
+        L.orc_set_accumulators.argtypes = [C.c_void_p, _dp]
         for f in ("orc_specific_energy_sum", "orc_specific_energy", "orc_density"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = _dp
@@ -114,6 +115,18 @@ class Oracle:
         n = int(np.prod(self.shape))
         s = np.ctypeslib.as_array(lib().orc_specific_energy_sum(self.h), shape=(n,)).reshape(self.shape).copy()
         return s, st.as_dict()
+
+    def lucy_finish(self, block=None):
+        """update_energy_abs on the pending (or the given, all-reduced) accumulator block."""
+        if block is not None:
+            block = np.ascontiguousarray(block, dtype=np.float64)
+            lib().orc_set_accumulators(self.h, block.ctypes.data_as(_dp))
+        out = np.empty(self.shape, dtype=np.float64)
+        st = IterStats()
+        rc = lib().orc_lucy_finish(self.h, out.ctypes.data_as(_dp), C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return out, st.as_dict()
 
     def specific_energy(self):
         n = int(np.prod(self.shape))

@@ -1,0 +1,78 @@
+"""N>1 path on CPU: two gloo ranks shard one Lucy iteration by packet-id range,
+all-reduce the accumulator block once, and finish redundantly -- the result must
+equal the single-process run (FP64 summation order only).  The per-rank work is
+done by the CPU oracle behind the same three-call interface the HIP engine
+exposes (launch / accumulators / finish), so this exercises exactly
+hyperion_amd.distributed."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cases import golden_problem, ragged_grid_problem
+from hyperion_amd.distributed import lucy_iteration_sharded
+from oracle_lib import Oracle
+
+
+class OracleAsEngine:
+    """Adapter: the oracle behind Engine's sharded-iteration interface."""
+
+    def __init__(self, prob):
+        self.o = Oracle(prob)
+        self.n = int(np.prod(prob.density.shape))
+
+    def lucy_launch(self, first, n_local, iteration):
+        self.s, self.st = self.o.lucy_accumulate(first, n_local, iteration, n_threads=2)
+
+    def lucy_accumulators_tensor(self):
+        blk = np.concatenate([self.s.ravel(), [self.st["energy_current"], self.st["killed_geo"], self.st["killed_int"],
+                                               self.st["crossings"], self.st["interactions"], 0, 0, 0]])
+        self.t = torch.from_numpy(blk)
+        return self.t
+
+    def lucy_finish(self, want_output=True):
+        return self.o.lucy_finish(self.t.numpy())
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, which, n_total, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = golden_problem("car_specific_energy.False.True.npz")[0] if which == "kmh3" else ragged_grid_problem()
+    eng = OracleAsEngine(prob)
+    res = []
+    for it in (1, 2):
+        se, st = lucy_iteration_sharded(eng, n_total, it, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        res.append(se)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), se=np.array(res), crossings=st["crossings"], energy=st["energy_current"],
+             n=st["n_packets"])
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("which", ["kmh3", "ragged"])
+def test_two_rank_sharded_iteration_equals_single_process(tmp_path, which):
+    n_total = 20001          # odd: uneven shards
+    mp.spawn(_worker, args=(2, _free_port(), which, n_total, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["se"], r1["se"])          # every rank ends with the same state
+    assert int(r0["n"]) == n_total
+    prob = golden_problem("car_specific_energy.False.True.npz")[0] if which == "kmh3" else ragged_grid_problem()
+    o = Oracle(prob)
+    for k, it in enumerate((1, 2)):
+        se, st = o.lucy_iteration(n_total, it, n_threads=2)
+        np.testing.assert_allclose(r0["se"][k], se, rtol=1e-12)
+    assert int(r0["crossings"]) == st["crossings"]
+    assert float(r0["energy"]) == pytest.approx(st["energy_current"], rel=1e-14)

@@ -1,0 +1,203 @@
+"""Parity tests proper: the HIP path (through the C-ABI) against the CPU oracle
+on identical per-packet Philox streams.  Tolerance: rtol 1e-9 on
+specific_energy (FP64 atomic summation order + 1-ulp libm differences, see
+cases.assert_parity); the integer tallies (crossings, interactions, killed
+packets) must agree exactly."""
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import assert_parity, golden_problem, ragged_grid_problem, spectrum_source_problem
+from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
+
+
+def run_both(prob, n, iters=1, **opts):
+    eng = hyperion_amd.Engine(prob)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    orc = Oracle(prob)
+    out = []
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-13)
+        np.testing.assert_allclose(sa["energy_abs_tot"], sb["energy_abs_tot"], rtol=1e-9)
+        assert_parity(a, b)
+        np.testing.assert_array_equal(a == 0, b == 0)
+        out.append((a, sa))
+    eng.close()
+    orc.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["False.False", "True.False", "False.True", "True.True"])
+def test_reference_test_model_kmh_dust(name):
+    """The reference's own regression model (test_bit_level.py:137-173): 7x5x3
+    cells, five blackbody point sources, polarised anisotropic kmh dust, 1 or 3
+    dust species, luminosity- or evenly-sampled sources; 3 Lucy iterations."""
+    prob, _ = golden_problem("car_specific_energy.%s.npz" % name)
+    run_both(prob, 30000, iters=3)
+
+
+def test_benchmark_configuration_small():
+    run_both(make_benchmark_problem(16), 100000, iters=2)
+    run_both(make_benchmark_problem(24, density="powerlaw"), 50000)
+
+
+@pytest.mark.parametrize("scale", [1e-20, 1.0, 1e20])
+def test_ragged_grid_vertex_sources_any_scale(scale):
+    """test_propagation.py:24-149: sources on vertices/edges, empty cells,
+    grids scaled by 1e-20..1e20 -- no packet may be killed."""
+    prob = ragged_grid_problem(scale=scale)
+    (a, st), = run_both(prob, 40000)
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0
+
+
+def test_source_on_outer_boundary_and_corner():
+    p = make_benchmark_problem(8)
+    p.sources[0].position = (PC, 0.0, 0.0)              # on the outer face: half escape at once
+    (a, st), = run_both(p, 20000)
+    p.sources[0].position = (-PC, -PC, PC)              # on a corner of the grid
+    (a, st2), = run_both(p, 20000)
+    assert st2["crossings"] < st["crossings"]
+
+
+def test_spectrum_source_and_offcentre():
+    run_both(spectrum_source_problem(), 40000, iters=2)
+
+
+def test_interaction_limits_and_kill_flags():
+    p = make_benchmark_problem(8, tau=5.0)
+    p.config.n_inter_max = 3
+    (a, st), = run_both(p, 20000)
+    assert st["killed_int"] > 0
+    p = make_benchmark_problem(8, tau=2.0)
+    p.config.kill_on_absorb = True
+    run_both(p, 20000)
+    p = make_benchmark_problem(8, tau=2.0)
+    p.config.kill_on_scatter = True
+    run_both(p, 20000)
+
+
+def test_always_check_propagation():
+    p = ragged_grid_problem()
+    p.config.propagation_check_frequency = 1.0          # in_correct_cell at every step
+    (a, st), = run_both(p, 20000)
+    assert st["killed_geo"] == 0
+
+
+def test_initial_and_additional_specific_energy():
+    p = make_benchmark_problem(8)
+    p.specific_energy = np.full(p.density.shape, 3.0e-3)
+    run_both(p, 20000, iters=2)
+    p.config.specific_energy_type = "additional"
+    run_both(p, 20000, iters=2)
+    p = make_benchmark_problem(8)
+    p.dust[0].minimum_specific_energy = 1.0e-2
+    run_both(p, 20000)
+
+
+@pytest.mark.parametrize("mode", ["fast", "slow", "cap"])
+def test_dust_sublimation(mode):
+    p = make_benchmark_problem(8, tau=2.0)
+    p.dust[0].sublimation_mode = mode
+    p.dust[0].sublimation_specific_energy = 2.0e-3
+    eng = hyperion_amd.Engine(p)
+    orc = Oracle(p)
+    for it in (1, 2):
+        a, _ = eng.lucy_iteration(30000, it)
+        b, _ = orc.lucy_iteration(30000, it)
+        assert_parity(a, b)
+    np.testing.assert_allclose(eng.density(), np.ctypeslib.as_array(
+        __import__("oracle_lib").lib().orc_density(orc.h), shape=(p.n_cells,)).reshape(p.density.shape), rtol=1e-9)
+    assert (a <= 2.0e-3 * (1 + 1e-12)).all() or mode == "fast"
+
+
+def test_tuning_options_do_not_change_results():
+    p = make_benchmark_problem(16)
+    base = run_both(p, 60000)[0][0]
+    for opts in ({"accum_copies": 8}, {"interact_threshold": 1, "emit_threshold": 1},
+                 {"interact_threshold": 64, "emit_threshold": 64}, {"chunk": 7}, {"blocks_per_cu": 1}):
+        a = run_both(p, 60000, **opts)[0][0]
+        np.testing.assert_allclose(a, base, rtol=1e-11, atol=1e-13 * base.max())
+
+
+def test_sharded_launch_equals_whole_iteration():
+    """Multi-GPU contract on one GPU: two id ranges accumulated separately and
+    summed equal the whole iteration (counter-based RNG keyed by packet id)."""
+    import torch
+    p, _ = golden_problem("car_specific_energy.False.True.npz")
+    n = 30001
+    eng = hyperion_amd.Engine(p)
+    whole, st = eng.lucy_iteration(n, 1)
+    eng2 = hyperion_amd.Engine(p)
+    eng2.lucy_launch(0, 12000, 1)
+    part0 = eng2.lucy_accumulators_tensor().clone()
+    eng2.lucy_launch(12000, n - 12000, 1)
+    acc = eng2.lucy_accumulators_tensor()
+    acc += part0                                    # what the all-reduce does
+    torch.cuda.synchronize()
+    out, st2 = eng2.lucy_finish()
+    assert st2["crossings"] == st["crossings"] and st2["energy_current"] == st["energy_current"]
+    np.testing.assert_allclose(out, whole, rtol=1e-11)
+
+
+def test_error_messages_match_the_reference():
+    p = make_benchmark_problem(4)
+    p.sources[0].position = (5 * PC, 0.0, 0.0)
+    eng = hyperion_amd.Engine(p)
+    with pytest.raises(hyperion_amd.EngineError, match="photon was not emitted inside a cell"):
+        eng.lucy_iteration(1000, 1)
+    p = make_benchmark_problem(4)
+    p.sources[0].temperature = 1e9
+    eng = hyperion_amd.Engine(p)
+    with pytest.raises(hyperion_amd.EngineError, match=r"photon frequency .* is outside the range defined for the dust optical properties"):
+        eng.lucy_iteration(1000, 1)
+    # the engine stays usable after an error is reported
+    p = make_benchmark_problem(4)
+    p.sources[0].temperature = None
+    p.sources[0].spectrum_nu = np.array([1e12, 1e14, 1e13])
+    p.sources[0].spectrum_fnu = np.ones(3)
+    with pytest.raises(hyperion_amd.EngineError, match="spectrum frequency should be monotonically increasing"):
+        hyperion_amd.Engine(p)
+
+
+def test_empty_iteration_is_skipped():
+    p = make_benchmark_problem(4)
+    eng = hyperion_amd.Engine(p)
+    before = eng.specific_energy()
+    eng.lucy_iteration(0, 1, want_output=False)
+    np.testing.assert_array_equal(eng.specific_energy(), before)
+
+
+def test_full_size_properties_128():
+    """BASELINE config 2 size (128^3), 2e7 packets: size-independent properties.
+    (a) conservation: sum(E rho V) equals the engine's own absorbed-energy tally
+    and the expected absorbed fraction of L; (b) no packet lost; (c) packets per
+    crossing statistics of the walk (173 +- 1 crossings per packet at tau=1);
+    (d) 8-fold symmetry of the central source in a uniform cube."""
+    p = make_benchmark_problem(128)
+    eng = hyperion_amd.Engine(p)
+    n = 20_000_000
+    se, st = eng.lucy_iteration(n, 1)
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0 and st["energy_current"] == n
+    tot = (se * p.density * p.volumes).sum()
+    assert tot == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
+    assert 0.85 < tot / LSUN < 0.93
+    assert 172.0 < st["crossings"] / n < 175.0
+    e = se[0]
+    oct_sums = [e[a:a + 64, b:b + 64, c:c + 64].sum() for a in (0, 64) for b in (0, 64) for c in (0, 64)]
+    assert np.ptp(oct_sums) / np.mean(oct_sums) < 5e-3
+    # optically-thin-like radial fall-off far from the source is monotonic in shells
+    c = 0.5 * (p.walls[0][1:] + p.walls[0][:-1])
+    z, y, x = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z) / PC
+    shells = [e[(r > a) & (r <= a + 0.1)].mean() for a in np.arange(0.1, 0.9, 0.1)]
+    assert np.all(np.diff(shells) < 0)
