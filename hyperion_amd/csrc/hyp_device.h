@@ -68,7 +68,7 @@ struct DProblem {
     long long n_inter_max;
     unsigned long long n_cells;
     double baes16_xi;
-    unsigned long long check_threshold;   // propagation_check_frequency * 2^32
+    double check_p, check_log1mp;         // propagation_check_frequency p, log(1-p)
     uint32_t seed_key, pad1;
     const double *w[3], *ew[3];           // walls and 3*spacing(wall)
     const double *density;                // [n_cells][n_dust]   (cell-major)
@@ -100,9 +100,9 @@ struct Rng {
     uint32_t key0, key1;
     uint32_t id_lo, id_hi;
     uint32_t blk_a, blk_b;
-    uint32_t b0, b1, b2, b3;   // stream-B buffer (propagation-check draws)
     double buf_a;
-    int have_a, pos_b;
+    int have_a;
+    int countdown;             // cell steps left until the next propagation check
 };
 
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
@@ -128,8 +128,7 @@ __device__ __forceinline__ double u64_to_unit(uint32_t hi, uint32_t lo)
 __device__ __forceinline__ void rng_init(Rng &g, uint32_t key0, uint32_t key1, unsigned long long id)
 {
     g.key0 = key0; g.key1 = key1; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
-    g.blk_a = 0; g.blk_b = 0; g.have_a = 0; g.pos_b = 4; g.buf_a = 0.0;
-    g.b0 = g.b1 = g.b2 = g.b3 = 0;
+    g.blk_a = 0; g.blk_b = 0; g.have_a = 0; g.countdown = 0; g.buf_a = 0.0;
 }
 
 __device__ __forceinline__ double rng_uniform(Rng &g)
@@ -142,18 +141,19 @@ __device__ __forceinline__ double rng_uniform(Rng &g)
     return u64_to_unit(o[0], o[1]);
 }
 
-__device__ __forceinline__ uint32_t rng_check_u32(Rng &g)
+// The reference draws one uniform per cell step and checks the packet's cell
+// with probability p (grid_propagate_3d.f90:108).  The same Bernoulli process is
+// generated from its gap distribution: steps until the next check
+// = floor(log(1-u)/log(1-p)), one stream-B draw per check instead of per step.
+__device__ __forceinline__ int rng_check_gap(Rng &g, double p, double log1mp)
 {
-    if (g.pos_b == 4) {
-        uint32_t o[4];
-        philox4x32_10(g.id_lo, g.id_hi, g.blk_b, 1u, g.key0, g.key1, o);
-        g.blk_b++;
-        g.b0 = o[0]; g.b1 = o[1]; g.b2 = o[2]; g.b3 = o[3];
-        g.pos_b = 0;
-    }
-    uint32_t r = g.pos_b == 0 ? g.b0 : g.pos_b == 1 ? g.b1 : g.pos_b == 2 ? g.b2 : g.b3;
-    g.pos_b++;
-    return r;
+    if (p >= 1.0) return 0;
+    if (!(p > 0.0)) return 2147483647;
+    uint32_t o[4];
+    philox4x32_10(g.id_lo, g.id_hi, g.blk_b, 1u, g.key0, g.key1, o);
+    g.blk_b++;
+    double gap = floor(log(1.0 - u64_to_unit(o[0], o[1])) / log1mp);
+    return gap >= 2147483647.0 ? 2147483647 : (int)gap;
 }
 
 __device__ __forceinline__ double rng_exp(Rng &g) { return -log(1.0 - rng_uniform(g)); }

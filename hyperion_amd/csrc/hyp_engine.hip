@@ -130,7 +130,7 @@ struct hyp_engine {
     hyp_iter_stats last_stats{};
 
     // options
-    int interact_threshold = 24, emit_threshold = 16, accum_copies = 8, blocks_per_cu = 0, chunk = 0;
+    int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
 
     int set_error(const std::string &m) { err = m; return 1; }
 };
@@ -148,6 +148,10 @@ using LucyKernel = void (*)(const DProblem *, LaunchParams);
 
 LucyKernel pick_lucy_kernel(int nd)
 {
+#ifdef HYP_ONLY_ND1   // tuning builds (tools/variants.py) instantiate one species only
+    (void)nd;
+    return lucy_kernel<1>;
+#else
     switch (nd) {
     case 1: return lucy_kernel<1>;
     case 2: return lucy_kernel<2>;
@@ -155,6 +159,7 @@ LucyKernel pick_lucy_kernel(int nd)
     case 4: return lucy_kernel<4>;
     default: return lucy_kernel<HYP_MAXD>;
     }
+#endif
 }
 
 }  // namespace
@@ -231,8 +236,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     P.forced_first = pr->config.forced_first_interaction; P.forced_algo = pr->config.forced_first_interaction_algorithm;
     P.n_inter_max = pr->config.n_inter_max; P.n_cells = h->n_cells; P.baes16_xi = pr->config.baes16_xi;
     {
-        double f = pr->config.propagation_check_frequency * 4294967296.0;
-        P.check_threshold = f <= 0.0 ? 0ull : (unsigned long long)f;
+        P.check_p = pr->config.propagation_check_frequency;
+        P.check_log1mp = (P.check_p > 0.0 && P.check_p < 1.0) ? std::log1p(-P.check_p) : -1.0;
         int64_t sd = pr->config.seed;
         uint64_t s = (uint64_t)(sd < 0 ? -sd : sd);
         P.seed_key = (uint32_t)s ^ (uint32_t)(s >> 32);
@@ -556,7 +561,15 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     DProblem &P = h->hp;
     int copies = h->accum_copies;
     if (copies < 1) copies = 1;
-    if (copies > h->accum_copies_alloc) copies = h->accum_copies_alloc;
+    if (copies > 256) copies = 256;
+    if (copies > h->accum_copies_alloc) {   // grow the replica pool on demand
+        double *nb = nullptr;
+        if (hipMalloc(&nb, sizeof(double) * h->accum_stride * copies) != hipSuccess)
+            return h->set_error("cannot allocate accumulator replicas");
+        (void)hipStreamSynchronize(h->stream);
+        (void)hipFree(h->d_accum);
+        h->d_accum = nb; h->accum_copies_alloc = copies;
+    }
     P.sum = h->d_accum; P.tail = h->d_accum + h->n_elem; P.n_copies = copies; P.copy_stride = h->accum_stride;
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);

@@ -18,7 +18,7 @@ enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
 template <int NDT>
 struct Packet {
-    double r[3], v[3];
+    double r[3], v[3], iv[3];   // position, direction, 1/direction
     Angle a;
     double s[4];
     double nu, energy;
@@ -145,9 +145,11 @@ __device__ __forceinline__ bool in_correct_cell(const Walls &W, const double r[3
 // candidate distances of the reference are (w - r)/v for the lower and upper
 // wall of each axis, kept only when positive; a quotient is positive exactly
 // when numerator and denominator have the same sign, so the divide is issued
-// only for candidates that can win (normally one per axis).
-__device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], const double v[3], const int ic[3],
-                                          const int ow[3], double &tnear, int im[3])
+// only for candidates that can win (normally one per axis), and it is issued as
+// a multiplication by 1/v (refreshed whenever the direction changes): t differs
+// from the reference's quotient by at most 1 ulp.
+__device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], const double v[3], const double iv[3],
+                                          const int ic[3], const int ow[3], double &tnear, int im[3])
 {
     double tmin = HYP_DBL_MAX, emin = 0.0;
     im[0] = im[1] = im[2] = 0;
@@ -159,14 +161,14 @@ __device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], con
         bool c1 = (ow[a] != -1) && ((d1 > 0.0 && va > 0.0) || (d1 < 0.0 && va < 0.0));
         bool c2 = (ow[a] != +1) && ((d2 > 0.0 && va > 0.0) || (d2 < 0.0 && va < 0.0));
         if (c1 || c2) {
-            double t = (c1 ? d1 : d2) / va;
+            double t = (c1 ? d1 : d2) * iv[a];
             double e = W.ew[a][i + (c1 ? 0 : 1)];
             int dir = c1 ? -1 : +1;
             double emax = fmax(e, emin);
             if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = dir; }
             else if (t < tmin + emax) { emin = emax; im[a] = dir; }
             if (c1 && c2) {   // both walls ahead: only after round-off misplacement
-                t = d2 / va; e = W.ew[a][i + 1];
+                t = d2 * iv[a]; e = W.ew[a][i + 1];
                 emax = fmax(e, emin);
                 if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = +1; }
                 else if (t < tmin + emax) { emin = emax; im[a] = +1; }
@@ -185,11 +187,12 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
                                          double *__restrict__ sum, Counters &cnt)
 {
     const int nd = ndust<NDT>(P);
-    if ((unsigned long long)rng_check_u32(g) < P.check_threshold) {
+    if (g.countdown == 0) {
+        g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
         if (!in_correct_cell(W, p.r, p.ic, p.ow)) { cnt.killed_geo++; return ST_NEED_EMIT; }
-    }
+    } else g.countdown--;
     double tmin; int im[3];
-    if (!find_wall(W, p.r, p.v, p.ic, p.ow, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+    if (!find_wall(W, p.r, p.v, p.iv, p.ic, p.ow, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
     const size_t base = cell_index(P, p.ic) * (size_t)nd;
     double rho[NDT];
     double chi_rho = 0.0;
@@ -263,9 +266,11 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    p.iv[0] = 1.0 / p.v[0]; p.iv[1] = 1.0 / p.v[1]; p.iv[2] = 1.0 / p.v[2];
     if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
     cnt.energy_current += p.energy;
     if (!update_optconsts<NDT>(P, p)) return false;
+    g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
     if (!place_in_cell(W, p.r, p.v, p.ic, p.ow)) {
         cnt.killed_geo++;
         raise_error(P, ERR_NOT_IN_CELL, p.r[0], p.r[1], p.r[2]);
@@ -380,6 +385,7 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT> &p, Rng 
         scattered = 1;
     }
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    p.iv[0] = 1.0 / p.v[0]; p.iv[1] = 1.0 / p.v[1]; p.iv[2] = 1.0 / p.v[2];
     return true;
 }
 
@@ -434,8 +440,14 @@ __device__ __forceinline__ bool take_id(const DProblem &P, const LaunchParams &L
 // ---------------------------------------------------------------------------
 // Lucy iteration: do_lucy packet loop, iter_lucy.f90:119-209
 // ---------------------------------------------------------------------------
+#ifndef HYP_LUCY_WAVES
+#define HYP_LUCY_WAVES 2
+#endif
+#ifndef HYP_WALK_STEPS
+#define HYP_WALK_STEPS 4
+#endif
 template <int NDT>
-__global__ __launch_bounds__(256) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+__global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
@@ -452,7 +464,18 @@ __global__ __launch_bounds__(256) void lucy_kernel(const DProblem *__restrict__ 
         __syncthreads();
     }
     double *sum = P.sum;
-    if (P.n_copies > 1) sum += (size_t)(xcc_id() % (unsigned)P.n_copies) * P.copy_stride;
+    // accumulator replica of this workgroup: replicas are spread first over the
+    // XCDs (no line is shared between two L2s), then over workgroups of an XCD
+    if (P.n_copies > 1) {
+        unsigned c = xcc_id();
+        if (P.n_copies > 8) c += 8u * ((blockIdx.x >> 3) % (unsigned)(P.n_copies >> 3));
+        sum += (size_t)(c % (unsigned)P.n_copies) * P.copy_stride;
+    }
+#ifdef HYP_NO_DEPOSIT
+    constexpr bool kDeposit = false;
+#else
+    constexpr bool kDeposit = true;
+#endif
 
     Packet<NDT> p;
     Rng g;
@@ -517,8 +540,8 @@ __global__ __launch_bounds__(256) void lucy_kernel(const DProblem *__restrict__ 
 
         // ---- walk phase: a few cell crossings per outer iteration ----
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
-            if (st == ST_WALK) st = walk_step<NDT, true>(P, W, p, g, sum, cnt);
+        for (int k = 0; k < HYP_WALK_STEPS; k++) {
+            if (st == ST_WALK) st = walk_step<NDT, kDeposit>(P, W, p, g, sum, cnt);
         }
     }
 

@@ -9,8 +9,12 @@
  * depend on thread count or on how packets are sharded:
  *   stream A: FP64 uniforms, consumed in the reference's order of `random`
  *             calls (emit -> random_exp -> interact ...);
- *   stream B: 32-bit uniforms for the per-crossing propagation check
- *             (grid_propagate_3d.f90:108).
+ *   stream B: the per-crossing propagation check of grid_propagate_3d.f90:108
+ *             (`random(xi); if(xi < frac_check)`), a Bernoulli(frac_check)
+ *             trial per cell step, is realised through its gap distribution:
+ *             the number of steps until the next check is drawn from the
+ *             geometric law (1-p)^k p with one uniform of stream B per check
+ *             (identical in distribution, one draw per ~1/p steps).
  */
 #include "hyp_oracle.h"
 
@@ -56,9 +60,9 @@ typedef struct {
     uint32_t key[2];
     uint64_t id;
     uint32_t blk_a, blk_b;
-    int have_a, pos_b;
+    int have_a;
+    int32_t countdown;      /* cell steps left until the next propagation check */
     double buf_a;
-    uint32_t buf_b[4];
 } rng_t;
 
 static uint32_t seed_key(int64_t seed)
@@ -70,7 +74,7 @@ static uint32_t seed_key(int64_t seed)
 static void rng_init(rng_t *g, int64_t seed, uint32_t iter_tag, uint64_t id)
 {
     g->key[0] = seed_key(seed); g->key[1] = iter_tag;
-    g->id = id; g->blk_a = 0; g->blk_b = 0; g->have_a = 0; g->pos_b = 4;
+    g->id = id; g->blk_a = 0; g->blk_b = 0; g->have_a = 0; g->countdown = 0;
 }
 
 static inline double u64_to_unit(uint32_t hi, uint32_t lo)
@@ -89,14 +93,16 @@ static double rng_uniform(rng_t *g)
     return u64_to_unit(o[0], o[1]);
 }
 
-static uint32_t rng_check_u32(rng_t *g)
+/* number of cell steps before the next propagation check: geometric gap of a
+ * Bernoulli(p) process, gap = floor(log(1-u) / log(1-p)), clamped to int32 */
+static int32_t rng_check_gap(rng_t *g, double p, double log1mp)
 {
-    if (g->pos_b == 4) {
-        uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_b++, 1u};
-        orc_philox4x32_10(ctr, g->key, g->buf_b);
-        g->pos_b = 0;
-    }
-    return g->buf_b[g->pos_b++];
+    if (p >= 1.0) return 0;
+    if (!(p > 0.0)) return INT32_MAX;
+    uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_b++, 1u}, o[4];
+    orc_philox4x32_10(ctr, g->key, o);
+    double gap = floor(log(1.0 - u64_to_unit(o[0], o[1])) / log1mp);
+    return gap >= 2147483647.0 ? INT32_MAX : (int32_t)gap;
 }
 
 /* fortranlib random_exp: tau = -log(1 - xi) */
@@ -350,6 +356,7 @@ struct orc_state {
     int n[3];
     double *volume;
     orc_config cfg;
+    double check_p, check_log1mp;
     int n_dust, n_sources, n_peeled;
     dust_t *dust;
     source_t *src;
@@ -585,6 +592,8 @@ int orc_create(const orc_problem *pr, orc_state **out)
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
+    st->check_p = pr->config.propagation_check_frequency;
+    st->check_log1mp = (st->check_p > 0.0 && st->check_p < 1.0) ? log1p(-st->check_p) : -1.0;
     st->n1 = pr->grid.n1; st->n2 = pr->grid.n2; st->n3 = pr->grid.n3;
     st->n[0] = st->n1; st->n[1] = st->n2; st->n[2] = st->n3;
     st->n_cells = (size_t)st->n1 * st->n2 * st->n3;
@@ -868,11 +877,11 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
     double tau_achieved = 0.0;
     if (escaped(st, p->ic)) return;
     if (tau_required == 0.0) return;
-    uint64_t thr = (uint64_t)(st->cfg.propagation_check_frequency * 4294967296.0);
     for (;;) {
-        if ((uint64_t)rng_check_u32(g) < thr) {
+        if (g->countdown == 0) {
+            g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
             if (!in_correct_cell(st, p)) { acc->killed_geo++; p->killed = 1; return; }
-        }
+        } else g->countdown--;
         double tau_needed = tau_required - tau_achieved;
         double tmin; int id_min[3];
         if (!find_wall(st, p, &tmin, id_min)) { acc->killed_geo++; p->killed = 1; return; }
@@ -913,11 +922,11 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
     double tau = 0.0, t_achieved = 0.0;
     *killed = 0;
     if (escaped(st, p.ic)) return 0.0;
-    uint64_t thr = (uint64_t)(st->cfg.propagation_check_frequency * 4294967296.0);
     for (;;) {
-        if ((uint64_t)rng_check_u32(g) < thr) {
+        if (g->countdown == 0) {
+            g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
             if (!in_correct_cell(st, &p)) { acc->killed_geo++; *killed = 1; return tau; }
-        }
+        } else g->countdown--;
         double tmin; int id_min[3];
         if (!find_wall(st, &p, &tmin, id_min)) { acc->killed_geo++; *killed = 1; return tau; }
         size_t ic = cell_index(st, p.ic);
@@ -975,6 +984,7 @@ static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
     if (update_optconsts(st, p, acc)) return -1;
     p->last = LAST_SR;
     p->a_prev = p->a; memcpy(p->s_prev, p->s, sizeof p->s); memcpy(p->v_prev, p->v, sizeof p->v);
+    g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
     place_in_cell(st, p, acc);
     if (p->killed) {
         if (!acc->fatal) {

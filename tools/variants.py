@@ -1,0 +1,67 @@
+"""Build tuning variants of the HIP library into build/variants/ (they travel to
+the GPU box with the snapshot) and, on the GPU box, time each one.
+  python tools/variants.py build name1:"-DFOO=1 -DBAR=2" name2:"..."
+  python tools/variants.py run [photons] [option=value ...]
+"""
+import json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "build", "variants")
+
+
+def build(specs):
+    from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc
+    os.makedirs(VDIR, exist_ok=True)
+    procs = []
+    for spec in specs:
+        name, _, flags = spec.partition(":")
+        out = os.path.join(VDIR, name + ".so")
+        cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + ["-DHYP_ONLY_ND1", "hyp_engine.hip", "-o", out,
+                                                          "-Rpass-analysis=kernel-resource-usage"]
+        procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
+    for name, p in procs:
+        err = p.communicate()[1]
+        info = [l.split("remark:")[1].strip() for l in err.split("\n")
+                if "remark:" in l and any(k in l for k in ("VGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
+        # keep only the lucy kernel block (first after its Function Name)
+        blocks = err.split("Function Name: ")
+        for b in blocks:
+            if b.startswith("_Z11lucy_kernelILi1E"):
+                info = [l.split("remark:")[1].strip() for l in b.split("\n") if "remark:" in l and
+                        any(k in l for k in (" VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
+        print(name, "rc", p.returncode, "|", "; ".join(info))
+        if p.returncode:
+            print(err[-2000:])
+
+
+def run_one(lib, photons, opts):
+    import hyperion_amd.engine as E
+    import ctypes as C
+    E._lib = None
+    L = E.load_library(lib)
+    E._lib = L
+    import hyperion_amd
+    from hyperion_amd.benchmark import make_benchmark_problem
+    p = make_benchmark_problem(128)
+    eng = hyperion_amd.Engine(p)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    eng.lucy_iteration(photons // 4, 1, want_output=False)
+    best = 1e30
+    for it in (2, 3):
+        _, st = eng.lucy_iteration(photons, it, want_output=False)
+        best = min(best, eng.last_kernel_ms()[0])
+    print(json.dumps({"lib": os.path.basename(lib), "opts": opts, "ms": best, "packets_per_s": photons / best * 1e3,
+                      "crossings_per_s": st["crossings"] / best * 1e3}), flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "build":
+        build(sys.argv[2:])
+    elif sys.argv[1] == "one":
+        run_one(sys.argv[2], int(float(sys.argv[3])), {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[4:]})
+    else:
+        photons = sys.argv[2] if len(sys.argv) > 2 else "2e7"
+        for f in sorted(os.listdir(VDIR)):
+            if f.endswith(".so"):
+                subprocess.call([sys.executable, __file__, "one", os.path.join(VDIR, f), photons] + sys.argv[3:])
