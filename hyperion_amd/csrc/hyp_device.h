@@ -212,7 +212,9 @@ __device__ __forceinline__ double sample_log_pdf(const double *__restrict__ x, c
 }
 
 // ---------------------------------------------------------------------------
-// angles (fortranlib type_angle3d semantics; orientation of Code & Whitney 1995)
+// angles (fortranlib type_angle3d semantics).  Orientation: local azimuth in
+// (0,pi) turns the direction towards increasing phi; pinned by the sign of
+// Stokes U in the reference's golden peel-off outputs.
 // ---------------------------------------------------------------------------
 struct Angle { double cost, sint, cosp, sinp; };
 
@@ -249,12 +251,12 @@ __device__ __forceinline__ void rotate_angle(const Angle &loc, const Angle &co, 
         sin_B = sqrt(1.0 - cos_B * cos_B);
     }
     fin.cost = cos_c; fin.sint = sin_c;
-    if (loc.sinp < 0.0) {
-        fin.cosp = co.cosp * cos_B - co.sinp * sin_B;
-        fin.sinp = co.sinp * cos_B + co.cosp * sin_B;
-    } else {
+    if (loc.sinp < 0.0) {   // new phi = old phi - B
         fin.cosp = co.cosp * cos_B + co.sinp * sin_B;
         fin.sinp = co.sinp * cos_B - co.cosp * sin_B;
+    } else {                // new phi = old phi + B
+        fin.cosp = co.cosp * cos_B - co.sinp * sin_B;
+        fin.sinp = co.sinp * cos_B + co.cosp * sin_B;
     }
 }
 
@@ -263,7 +265,7 @@ __device__ __forceinline__ void difference_angle(const Angle &co, const Angle &f
 {
     double cos_a = co.cost, sin_a = co.sint, cos_c = fin.cost, sin_c = fin.sint;
     double cos_B = co.cosp * fin.cosp + co.sinp * fin.sinp;
-    double sin_Bs = co.sinp * fin.cosp - co.cosp * fin.sinp;
+    double sin_Bs = co.cosp * fin.sinp - co.sinp * fin.cosp;   // sin(new phi - old phi)
     double cos_b = clamp1(cos_a * cos_c + sin_a * sin_c * cos_B);
     double sin_b = sqrt(1.0 - cos_b * cos_b);
     loc.cost = cos_b; loc.sint = sin_b;

@@ -162,6 +162,22 @@ LucyKernel pick_lucy_kernel(int nd)
 #endif
 }
 
+LucyKernel pick_final_kernel(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return final_kernel<1>;
+#else
+    switch (nd) {
+    case 1: return final_kernel<1>;
+    case 2: return final_kernel<2>;
+    case 3: return final_kernel<3>;
+    case 4: return final_kernel<4>;
+    default: return final_kernel<HYP_MAXD>;
+    }
+#endif
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +204,8 @@ void hyp_destroy(hyp_handle h)
 }
 
 static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref);
+static int sync_problem(hyp_handle h);
+static int check_device_error(hyp_handle h);
 
 int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 {
@@ -734,12 +752,133 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     return 0;
 }
 
-// ---- imaging iteration: implemented in a later milestone -------------------
-int hyp_final_launch(hyp_handle h, uint64_t, uint64_t) { return h ? h->set_error("final iteration not implemented yet") : 1; }
-int hyp_final_accumulators(hyp_handle h, void **, uint64_t *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
-int hyp_final_finish(hyp_handle h, hyp_iter_stats *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
-int hyp_final_iteration(hyp_handle h, uint64_t, hyp_iter_stats *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
-int hyp_peeled_get(hyp_handle h, int, int, double *, uint64_t *) { return h ? h->set_error("final iteration not implemented yet") : 1; }
+// ---- imaging iteration -------------------------------------------------------
+
+int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
+{
+    if (!h) return 1;
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    DProblem &P = h->hp;
+    double *tail;
+    if (h->d_img_accum) {
+        hipError_t e = hipMemsetAsync(h->d_img_accum, 0, sizeof(double) * h->img_accum_n, h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(images): ") + hipGetErrorString(e));
+        tail = h->d_img_accum + (h->img_accum_n - TAIL_SIZE);
+    } else {
+        hipError_t e = hipMemsetAsync(h->d_accum + h->n_elem, 0, sizeof(double) * TAIL_SIZE, h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(tail): ") + hipGetErrorString(e));
+        tail = h->d_accum + h->n_elem;
+    }
+    P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
+    if (sync_problem(h)) return 1;
+    unsigned long long first = first_id;
+    hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
+    LucyKernel k = pick_final_kernel(h->n_dust);
+    const size_t lds = lds_bytes(P);
+    int bpc = h->blocks_per_cu;
+    if (bpc <= 0) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+        bpc = occ;
+    }
+    long long blocks = (long long)h->n_cu * bpc;
+    long long need_blocks = (long long)((n_local + 255) / 256);
+    if (need_blocks < 1) need_blocks = 1;
+    if (blocks > need_blocks) blocks = need_blocks;
+    LaunchParams L;
+    L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = 0x10000u;
+    int chunk = h->chunk;
+    if (chunk <= 0) {
+        unsigned long long c = n_local / ((unsigned long long)blocks * 32ull);
+        if (c < 64) c = 64;
+        if (c > 4096) c = 4096;
+        chunk = (int)c;
+    }
+    L.chunk = chunk;
+    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    (void)hipEventRecord(h->ev0, h->stream);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    e = hipGetLastError();
+    (void)hipEventRecord(h->ev1, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("final_kernel launch: ") + hipGetErrorString(e));
+    h->final_pending = true;
+    h->pending_packets = n_local;
+    return 0;
+}
+
+int hyp_final_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
+{
+    if (!h) return 1;
+    if (!h->final_pending) return h->set_error("hyp_final_accumulators called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    hipError_t e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
+    (void)hipEventElapsedTime(&h->last_propagate_ms, h->ev0, h->ev1);
+    if (check_device_error(h)) { h->final_pending = false; return 1; }
+    if (h->d_img_accum) {
+        if (device_ptr) *device_ptr = h->d_img_accum;
+        if (n_doubles) *n_doubles = h->img_accum_n;
+    } else {
+        if (device_ptr) *device_ptr = h->d_accum + h->n_elem;
+        if (n_doubles) *n_doubles = TAIL_SIZE;
+    }
+    return 0;
+}
+
+int hyp_final_finish(hyp_handle h, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (!h->final_pending) return h->set_error("hyp_final_finish called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    h->final_pending = false;
+    double tail[TAIL_SIZE];
+    hipError_t e = hipMemcpy(tail, h->hp.tail, sizeof(tail), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    hyp_iter_stats st;
+    std::memset(&st, 0, sizeof st);
+    st.energy_current = tail[TAIL_ENERGY];
+    st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];
+    st.crossings = (uint64_t)tail[TAIL_CROSSINGS]; st.interactions = (uint64_t)tail[TAIL_INTERACTIONS];
+    st.n_packets = h->pending_packets;
+    // peeled_images_adjust_scale(energy_total/energy_current): iter_final.f90:142-143
+    if (st.energy_current > 0.0) {
+        double scale = h->energy_total / st.energy_current;
+        for (size_t g = 0; g < h->h_peeled.size(); g++) {
+            if (h->sed_n[g]) image_scale_kernel<<<256, 256, 0, h->stream>>>(h->d_img_accum + h->sed_off[g], h->sed_n[g], scale);
+            if (h->img_n[g]) image_scale_kernel<<<1024, 256, 0, h->stream>>>(h->d_img_accum + h->img_off[g], h->img_n[g], scale);
+        }
+        e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("image scaling failed: ") + hipGetErrorString(e));
+    }
+    h->last_stats = st;
+    if (stats) *stats = st;
+    return 0;
+}
+
+int hyp_final_iteration(hyp_handle h, uint64_t n_packets, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (n_packets == 0) return 0;   // "Skipping": iter_final.f90:78-85
+    if (hyp_final_launch(h, 0, n_packets)) return 1;
+    if (hyp_final_accumulators(h, nullptr, nullptr)) return 1;
+    return hyp_final_finish(h, stats);
+}
+
 int hyp_peeled_n_orig(hyp_handle h, int g) { return (h && g >= 0 && g < (int)h->h_peeled.size()) ? h->h_peeled[g].n_orig : -1; }
+
+int hyp_peeled_get(hyp_handle h, int g, int which, double *out, uint64_t *n_doubles)
+{
+    if (!h) return 1;
+    if (g < 0 || g >= (int)h->h_peeled.size() || which < 0 || which > 3) return h->set_error("hyp_peeled_get: bad group or selector");
+    size_t n = (which < 2) ? h->sed_n[g] : h->img_n[g];
+    size_t off = ((which < 2) ? h->sed_off[g] : h->img_off[g]) + ((which & 1) ? n : 0);
+    if (n_doubles) *n_doubles = n;
+    if (!out || n == 0) return 0;
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    hipError_t e = hipMemcpy(out, h->d_img_accum + off, sizeof(double) * n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(images): ") + hipGetErrorString(e));
+    return 0;
+}
 
 }  // extern "C"

@@ -561,6 +561,312 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 }
 
 // ---------------------------------------------------------------------------
+// Imaging iteration: do_final / propagate (iter_final.f90:60-273) with
+// peeloff_photon (images_peeled.f90:95-270)
+// ---------------------------------------------------------------------------
+
+// grid_escape_tau: grid_propagate_3d.f90:377-480 -- optical depth from (r, ic, ow)
+// along v to the edge of the grid (external observers: tmax = huge).
+template <int NDT>
+__device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
+                                             const double iv[3], const int ic0[3], const int ow0[3],
+                                             const double chi[NDT], Rng &g, Counters &cnt, bool &killed)
+{
+    const int nd = ndust<NDT>(P);
+    double r[3] = {r0[0], r0[1], r0[2]};
+    int ic[3] = {ic0[0], ic0[1], ic0[2]}, ow[3] = {ow0[0], ow0[1], ow0[2]};
+    double tau = 0.0;
+    killed = false;
+    if (escaped(P, ic)) return 0.0;
+    for (;;) {
+        if (g.countdown == 0) {
+            g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+            if (!in_correct_cell(W, r, ic, ow)) { cnt.killed_geo++; killed = true; return tau; }
+        } else g.countdown--;
+        double tmin; int im[3];
+        if (!find_wall(W, r, v, iv, ic, ow, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
+        const size_t base = cell_index(P, ic) * (size_t)nd;
+#pragma unroll
+        for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+#pragma unroll
+        for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * P.density[base + d] * tmin;
+        cnt.crossings++;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { ic[a] += im[a]; ow[a] = -im[a]; }
+        if (escaped(P, ic)) return tau;
+    }
+}
+
+// fortranlib ipos: 0-based bin of x in n equal bins over [xmin, xmax]; -1 / n outside
+__device__ __forceinline__ int ipos0(double xmin, double xmax, double x, int n)
+{
+    double f = (x - xmin) / (xmax - xmin);
+    if (f < 0.0) return -1;
+    if (f == 1.0) return n - 1;
+    if (!(f < 1.0)) return n;
+    return (int)floor(f * n);
+}
+
+struct PeelFlags { int scattered, reprocessed, n_scat, dust_id, source_id; };
+
+// image_bin / image_bin_single: image_type.f90:408-524
+__device__ __forceinline__ void image_bin(const DProblem &P, const DPeeled &G, double nu, double energy,
+                                          const double s[4], const PeelFlags &f, double x_image, double y_image, int iv)
+{
+    int inu = ipos0(G.log10_nu_min, G.log10_nu_max, log10(nu), G.n_nu);
+    if (inu < 0 || inu >= G.n_nu) return;
+    if (energy != energy || s[0] != s[0]) return;
+    int o = f.scattered ? (f.reprocessed ? 4 : 3) : (f.reprocessed ? 2 : 1);
+    int io = 0;
+    if (G.track_origin == 1) io = o - 1;
+    else if (G.track_origin == 2) {
+        io = (o == 1) ? f.source_id : (o == 2) ? P.n_sources + f.dust_id
+           : (o == 3) ? P.n_sources + P.n_dust + f.source_id : 2 * P.n_sources + P.n_dust + f.dust_id;
+    } else if (G.track_origin == 3) {
+        int ns = f.n_scat < G.track_n_scat + 1 ? f.n_scat : G.track_n_scat + 1;
+        io = (f.reprocessed ? (G.track_n_scat + 2) : 0) + ns;
+    }
+    const int nst = G.n_stokes;
+    if (G.compute_image) {
+        int ix = ipos0(G.x_min, G.x_max, x_image, G.n_x);
+        int iy = ipos0(G.y_min, G.y_max, y_image, G.n_y);
+        if (ix >= 0 && ix < G.n_x && iy >= 0 && iy < G.n_y) {
+            for (int is = 0; is < nst; is++) {
+                size_t k = (((((size_t)is * G.n_orig + io) * G.n_view + iv) * G.n_y + iy) * G.n_x + ix) * G.n_nu + inu;
+                double val = s[is] * energy;
+                unsafeAtomicAdd(&G.img[k], val);
+                if (G.uncertainties) unsafeAtomicAdd(&G.img2[k], val * val);
+            }
+        }
+    }
+    if (G.compute_sed) {
+        double lr = log10(sqrt(x_image * x_image + y_image * y_image));
+        int ir;
+        if (lr < G.log10_ap_min || G.n_ap == 1) ir = 0;
+        else ir = ipos0(G.log10_ap_min, G.log10_ap_max, lr, G.n_ap - 1) + 1;
+        if (ir >= 0 && ir < G.n_ap) {
+            for (int is = 0; is < nst; is++) {
+                size_t k = ((((size_t)is * G.n_orig + io) * G.n_view + iv) * G.n_ap + ir) * G.n_nu + inu;
+                double val = s[is] * energy;
+                unsafeAtomicAdd(&G.sed[k], val);
+                if (G.uncertainties) unsafeAtomicAdd(&G.sed2[k], val * val);
+            }
+        }
+    }
+}
+
+// peeloff_photon, external observers: images_peeled.f90:95-270
+template <int NDT>
+__device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT> &p, const Angle &a_prev,
+                                        const double s_prev[4], int last, bool last_isotropic, const PeelFlags &f,
+                                        Rng &g, Counters &cnt)
+{
+    for (int ig = 0; ig < P.n_peeled; ig++) {
+        const DPeeled &G = P.peeled[ig];
+        for (int iv = 0; iv < G.n_view; iv++) {
+            Angle a_req;
+            a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
+            a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+            double s[4];
+            if (last_isotropic || last != LAST_DS) {
+                s[0] = last_isotropic ? 1.0 : s_prev[0]; s[1] = last_isotropic ? 0.0 : s_prev[1];
+                s[2] = last_isotropic ? 0.0 : s_prev[2]; s[3] = last_isotropic ? 0.0 : s_prev[3];
+            } else {
+                // dust_scatter_peeloff: dust_type_4elem.f90:421-444
+                const DDust &D = P.dust[f.dust_id];
+                s[0] = s_prev[0]; s[1] = s_prev[1]; s[2] = s_prev[2]; s[3] = s_prev[3];
+                Angle a_scat;
+                difference_angle(a_prev, a_req, a_scat);
+                if (a_scat.cost < D.mu_min || a_scat.cost > D.mu_max) { s[0] = s[1] = s[2] = s[3] = 0.0; }
+                else {
+                    double P1, P2, P3, P4;
+                    interp_P(D, a_scat.cost, p.nu, P1, P2, P3, P4);
+                    scatter_stokes(s, a_prev, a_scat, a_req, P1, P2, P3, P4);
+                }
+            }
+            double v[3], iv3[3];
+            angle_to_vector(a_req, v[0], v[1], v[2]);
+            iv3[0] = 1.0 / v[0]; iv3[1] = 1.0 / v[1]; iv3[2] = 1.0 / v[2];
+            int ic[3], ow[3];
+            if (!place_in_cell(W, p.r, v, ic, ow)) { cnt.killed_geo++; continue; }
+            double d = -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
+            if (d < G.d_min || d > G.d_max) continue;
+            double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
+            double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
+            double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+            bool inside = false;
+            if (G.compute_image)
+                inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
+                         ((y_image >= G.y_min && y_image <= G.y_max) || (y_image <= G.y_min && y_image >= G.y_max));
+            if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
+            if (!inside) continue;
+            double tau = 0.0; bool killed = false;
+            if (!G.ignore_optical_depth) tau = escape_tau<NDT>(P, W, p.r, v, iv3, ic, ow, p.chi, g, cnt, killed);
+            if (killed) continue;
+            double att = exp(-tau);
+            s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
+            image_bin(P, G, p.nu, p.energy, s, f, x_image, y_image, iv);
+        }
+    }
+}
+
+// forced first interaction: forced_interaction.f90:23-133
+__device__ __forceinline__ void forced_interaction(const DProblem &P, double tau_escape, double xi, double &tau, double &weight)
+{
+    double ome = tau_escape > 1e-7 ? 1.0 - exp(-tau_escape) : tau_escape;
+    if (P.forced_algo == 2) {
+        double alpha = (1.0 - P.baes16_xi) / ome, beta = P.baes16_xi / tau_escape;
+        double tlo = 0.0, thi = tau_escape, t = 0.0;
+        for (int i = 0; i < 60; i++) {
+            t = 0.5 * (tlo + thi);
+            double test = t > 1e-7 ? alpha * (1.0 - exp(-t)) + beta * t : alpha * t + beta * t;
+            if (test > xi) thi = t; else tlo = t;
+        }
+        t = 0.5 * (tlo + thi);
+        tau = t; weight = 1.0 / (alpha + beta * exp(t));
+    } else {
+        tau = -log(1.0 - xi * ome); weight = ome;
+    }
+}
+
+template <int NDT>
+__global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    {
+        const int m1 = P.n1 + 1, m2 = P.n2 + 1, m3 = P.n3 + 1;
+        double *w0 = lds, *w1 = w0 + m1, *w2 = w1 + m2;
+        double *e0 = w2 + m3, *e1 = e0 + m1, *e2 = e1 + m2;
+        for (int i = threadIdx.x; i < m1; i += blockDim.x) { w0[i] = P.w[0][i]; e0[i] = P.ew[0][i]; }
+        for (int i = threadIdx.x; i < m2; i += blockDim.x) { w1[i] = P.w[1][i]; e1[i] = P.ew[1][i]; }
+        for (int i = threadIdx.x; i < m3; i += blockDim.x) { w2[i] = P.w[2][i]; e2[i] = P.ew[2][i]; }
+        W.w[0] = w0; W.w[1] = w1; W.w[2] = w2; W.ew[0] = e0; W.ew[1] = e1; W.ew[2] = e2;
+        W.n[0] = P.n1; W.n[1] = P.n2; W.n[2] = P.n3;
+        __syncthreads();
+    }
+    Packet<NDT> p;
+    Rng g;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    Dispenser dsp; dsp.next = 0; dsp.end = 0;
+    PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
+    int st = ST_NEED_EMIT;
+    bool pool_empty = false;
+    rng_init(g, P.seed_key, L.iter_tag, 0);
+    p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+
+    for (;;) {
+        unsigned long long m_walk = __ballot(st == ST_WALK);
+        unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
+        unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
+        if (!(m_walk | m_int | m_emit)) break;
+
+        // peel: 0 none, 1 after emission, 2 after interaction
+        int peel = 0;
+        Angle a_prev = p.a;
+        double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
+        int last = LAST_SR; bool last_iso = true;
+
+        if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
+            if (st == ST_NEED_INTERACT) {
+                if ((long long)p.inter == P.n_inter_max + 1) {
+                    cnt.killed_int++; st = ST_NEED_EMIT;
+                } else {
+                    a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
+                    int scattered, dust_id;
+                    bool ok = interact<NDT>(P, p, g, cnt, scattered, dust_id);
+                    f.dust_id = dust_id;
+                    if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
+                    else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                    if (killed) st = ST_NEED_EMIT;
+                    else { p.inter++; peel = 2; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
+        if (m_emit && !pool_empty && (__popcll(m_emit) >= L.emit_threshold || !m_walk)) {
+            unsigned long long id = 0;
+            bool got = take_id(P, L, dsp, st == ST_NEED_EMIT, id);
+            if (st == ST_NEED_EMIT) {
+                if (!got) st = ST_DONE;
+                else {
+                    rng_init(g, P.seed_key, L.iter_tag, id);
+                    int source_id = 0;
+                    bool ok = emit_packet<NDT>(P, W, p, g, cnt, source_id);
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    if (!ok) st = ST_NEED_EMIT;
+                    else { peel = 1; last = LAST_SR; last_iso = true; st = ST_DONE + 1; /* placed, awaiting tau */ }
+                }
+            }
+            if (__ballot(st == ST_DONE)) pool_empty = true;
+            if (*((volatile int *)P.err) != 0) { if (st == ST_NEED_EMIT) st = ST_DONE; pool_empty = true; }
+        } else if (m_emit && pool_empty) {
+            if (st == ST_NEED_EMIT) st = ST_DONE;
+        }
+
+        // ---- peel-off + optical depth sampling for lanes that just emitted / interacted ----
+        if (__ballot(peel != 0)) {
+            if (peel != 0) {
+                if (P.n_peeled > 0) peeloff<NDT>(P, W, p, a_prev, s_prev, last, last_iso, f, g, cnt);
+                if (peel == 1) {
+                    // first propagation after emission: iter_final.f90:191-209
+                    if (escaped(P, p.ic)) st = ST_NEED_EMIT;
+                    else {
+                        bool sampled = false;
+                        if (P.forced_first) {
+                            bool killed = false;
+                            double tau_escape = escape_tau<NDT>(P, W, p.r, p.v, p.iv, p.ic, p.ow, p.chi, g, cnt, killed);
+                            if (tau_escape > 1e-10 && !killed) {
+                                double weight, tau;
+                                forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                                p.tau_req = tau; p.energy *= weight; sampled = true;
+                            }
+                        }
+                        if (!sampled) p.tau_req = rng_exp(g);
+                        p.tau_ach = 0.0;
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    }
+                } else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                }
+            }
+        }
+
+#pragma unroll 1
+        for (int k = 0; k < HYP_WALK_STEPS; k++) {
+            if (st == ST_WALK) st = walk_step<NDT, false>(P, W, p, g, nullptr, cnt);
+        }
+    }
+
+    double e = wave_sum(cnt.energy_current);
+    double c = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    double ki = wave_sum((double)cnt.killed_int);
+    double ni = wave_sum((double)cnt.interactions);
+    if (__lane_id() == 0) {
+        unsafeAtomicAdd(&P.tail[TAIL_ENERGY], e);
+        unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], c);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
+        unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
+    }
+}
+
+// image_scale: image_type.f90:136-151 -- x *= scale over [0,n), x *= scale^2 over [n,2n)
+__global__ void image_scale_kernel(double *__restrict__ a, size_t n, double scale)
+{
+    size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < 2 * n; k += step)
+        a[k] *= (k < n) ? scale : scale * scale;
+}
+
+// ---------------------------------------------------------------------------
 // Elementwise kernels of the iteration epilogue
 // ---------------------------------------------------------------------------
 

@@ -253,9 +253,11 @@ static void random_sphere_angle(rng_t *g, angle_t *a)
 /* rotate_angle3d(a_local, a_coord, a_final): add the local (scattering)
  * angle to the direction a_coord.  Spherical triangle pole / old / new with
  * sides a=old theta, b=local theta, c=new theta and angle C = local phi at
- * the old direction, B = |new phi - old phi| at the pole.  Orientation as in
- * Code & Whitney (1995): local phi in (0,pi) -> new phi = old phi - B.  This
- * is the convention scatter_stokes (dust_type_4elem.f90:603-690) assumes. */
+ * the old direction, B = |new phi - old phi| at the pole.  Orientation: local
+ * phi in (0,pi) -> new phi = old phi + B.  fortranlib's source is absent; the
+ * orientation is pinned by the sign of Stokes U in the reference's golden
+ * test_peeloff outputs (tests/test_oracle_golden.py): the mirror choice gives
+ * the opposite sign of U at the same Q. */
 static void rotate_angle(const angle_t *loc, const angle_t *co, angle_t *fin)
 {
     double cos_a = co->cost, sin_a = co->sint;
@@ -278,12 +280,12 @@ static void rotate_angle(const angle_t *loc, const angle_t *co, angle_t *fin)
         sin_B = sqrt(1.0 - cos_B * cos_B);
     }
     fin->cost = cos_c; fin->sint = sin_c;
-    if (loc->sinp < 0.0) { /* new phi = old phi + B */
-        fin->cosp = co->cosp * cos_B - co->sinp * sin_B;
-        fin->sinp = co->sinp * cos_B + co->cosp * sin_B;
-    } else {               /* new phi = old phi - B */
+    if (loc->sinp < 0.0) { /* new phi = old phi - B */
         fin->cosp = co->cosp * cos_B + co->sinp * sin_B;
         fin->sinp = co->sinp * cos_B - co->cosp * sin_B;
+    } else {               /* new phi = old phi + B */
+        fin->cosp = co->cosp * cos_B - co->sinp * sin_B;
+        fin->sinp = co->sinp * cos_B + co->cosp * sin_B;
     }
 }
 
@@ -292,8 +294,8 @@ static void difference_angle(const angle_t *co, const angle_t *fin, angle_t *loc
 {
     double cos_a = co->cost, sin_a = co->sint;
     double cos_c = fin->cost, sin_c = fin->sint;
-    double cos_B = co->cosp * fin->cosp + co->sinp * fin->sinp;   /* cos(old-new) */
-    double sin_Bs = co->sinp * fin->cosp - co->cosp * fin->sinp;  /* sin(old-new) */
+    double cos_B = co->cosp * fin->cosp + co->sinp * fin->sinp;   /* cos(new-old) */
+    double sin_Bs = co->cosp * fin->sinp - co->sinp * fin->cosp;  /* sin(new-old) */
     double cos_b = cos_a * cos_c + sin_a * sin_c * cos_B;
     if (cos_b > 1.0) cos_b = 1.0;
     if (cos_b < -1.0) cos_b = -1.0;
@@ -1345,6 +1347,7 @@ static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_i
     const orc_peeled_desc *d = &pg->d;
     int inu = ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
     if (inu < 0 || inu >= d->n_nu) return;
+    if (p->energy != p->energy || p->s[0] != p->s[0]) return;   /* :421-429 NaN energy / flux ignored */
     int io = origin_slot(st, pg, p);
     int ns = pg->n_stokes;
     if (d->compute_image) {
@@ -1618,4 +1621,14 @@ void orc_probe_optconsts(const orc_state *st, int dust, double nu, double out3[3
     out3[0] = interp1d_loglog(du->nu, du->chi, du->n_nu, nu);
     out3[1] = interp1d_loglog(du->nu, du->albedo, du->n_nu, nu);
     out3[2] = out3[0] * (1.0 - out3[1]);
+}
+
+/* rotate_angle followed by difference_angle (must return the local angle) */
+void orc_probe_rotate(const double loc_in[4], const double co_in[4], double fin_out[4], double loc_back[4])
+{
+    angle_t loc = {loc_in[0], loc_in[1], loc_in[2], loc_in[3]}, co = {co_in[0], co_in[1], co_in[2], co_in[3]}, fin, back;
+    rotate_angle(&loc, &co, &fin);
+    difference_angle(&co, &fin, &back);
+    fin_out[0] = fin.cost; fin_out[1] = fin.sint; fin_out[2] = fin.cosp; fin_out[3] = fin.sinp;
+    loc_back[0] = back.cost; loc_back[1] = back.sint; loc_back[2] = back.cosp; loc_back[3] = back.sinp;
 }

@@ -200,6 +200,8 @@ void   orc_probe_scatter(const orc_state *st, int dust, double nu,
 double orc_probe_sample_jnu(const orc_state *st, int dust, int jid,
                             double frac, double xi);
 double orc_probe_planck(double T, int64_t seed, uint64_t packet_id);
+void   orc_probe_rotate(const double loc_in[4], const double co_in[4],
+                        double fin_out[4], double loc_back[4]);
 void   orc_probe_optconsts(const orc_state *st, int dust, double nu,
                            double out3[3]);
 

@@ -53,3 +53,16 @@ def assert_parity(a, b, rtol=1e-9):
     summation order and 1-ulp libm differences; the absolute term covers cells
     whose whole content is one cancellation-dominated partial step."""
     np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-12 * np.abs(b).max())
+
+
+def imaging_problem(n=12, tau=1.0, n_x=16, n_y=16, **peeled_kw):
+    """Small version of BASELINE config 4's imaging set-up on a Cartesian grid:
+    central source, one peeled group, one view (45, 45), Stokes on."""
+    from hyperion_amd.problem import PeeledImages
+    p = make_benchmark_problem(n, tau=tau)
+    kw = dict(theta=[45.0], phi=[45.0], n_wav=3, wav_min=0.1, wav_max=1000.0,
+              n_x=n_x, n_y=n_y, x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC,
+              n_ap=3, ap_min=0.2 * PC, ap_max=2.0 * PC, compute_stokes=True)
+    kw.update(peeled_kw)
+    p.peeled = [PeeledImages(**kw)]
+    return p

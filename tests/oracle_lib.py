@@ -62,6 +62,8 @@ def lib():
         L.orc_probe_sample_jnu.restype = C.c_double
         L.orc_probe_planck.argtypes = [C.c_double, C.c_int64, C.c_uint64]
         L.orc_probe_planck.restype = C.c_double
+        L.orc_probe_rotate.argtypes = [_dp, _dp, _dp, _dp]
+        L.orc_probe_rotate.restype = None
         L.orc_probe_optconsts.argtypes = [C.c_void_p, C.c_int, C.c_double, _dp]
         L.orc_probe_optconsts.restype = None
         _lib = L

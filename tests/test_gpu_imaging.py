@@ -1,0 +1,136 @@
+"""Imaging (final) iteration with peel-off: HIP path vs CPU oracle on identical
+Philox streams, plus the RNG-free analytic answers the reference's own tests
+state (hyperion/model/tests/test_image.py, test_sed.py)."""
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import golden_problem, imaging_problem
+from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem
+from hyperion_amd.images import finalize_peeled
+from hyperion_amd.problem import PeeledImages
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
+
+
+def run_both(prob, n_lucy, n_img, lucy_iters=1):
+    eng = hyperion_amd.Engine(prob)
+    orc = Oracle(prob)
+    for it in range(1, lucy_iters + 1):
+        eng.lucy_iteration(n_lucy, it, want_output=False)
+        orc.lucy_iteration(n_lucy, it)
+    ra, sa = eng.final_iteration(n_img)
+    rb, sb = orc.final_iteration(n_img)
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+    for ga, gb in zip(ra, rb):
+        assert set(ga) == set(gb)
+        for name in gb:
+            scale = np.nanmax(np.abs(gb[name]))
+            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * scale, err_msg=name)
+    eng.close()
+    orc.close()
+    return ra, sa
+
+
+@pytest.mark.parametrize("evenly", [False, True])
+def test_reference_peeloff_model(evenly):
+    """test_bit_level.py:175-236: three groups, polarised kmh dust, origin tracking."""
+    prob, _ = golden_problem("car_peeloff.%s.npz" % evenly)
+    res, st = run_both(prob, 5000, 20000, lucy_iters=2)
+    assert res[1]["sed"].shape == (4, 4, 1, 2, 4) and res[2]["img"].shape == (4, 12, 1, 6, 6, 4)
+    assert np.abs(res[0]["sed"][1]).max() > 0 and np.abs(res[0]["sed"][2]).max() > 0     # Q, U populated
+
+
+@pytest.mark.parametrize("kw", [
+    {}, {"uncertainties": True}, {"ignore_optical_depth": True}, {"compute_sed": False}, {"compute_image": False},
+    {"compute_stokes": False}, {"track_origin": "scatterings", "track_n_scat": 2}, {"track_origin": "detailed"},
+    {"d_min": -0.3 * PC, "d_max": 0.4 * PC}, {"theta": [0.5, 90.0, 179.5, 33.0], "phi": [0.0, 270.0, 45.0, 359.0]},
+    {"n_ap": 1, "ap_min": 0.5 * PC, "ap_max": 0.5 * PC},
+])
+def test_image_configurations(kw):
+    run_both(imaging_problem(**kw), 20000, 30000)
+
+
+@pytest.mark.parametrize("algo", ["none", "wr99", "baes16"])
+def test_forced_first_interaction(algo):
+    p = imaging_problem(tau=0.3)
+    p.config.forced_first_interaction = algo != "none"
+    if algo != "none":
+        p.config.forced_first_interaction_algorithm = algo
+    run_both(p, 10000, 30000)
+
+
+def test_multi_dust_imaging():
+    prob, _ = golden_problem("car_specific_energy.False.True.npz")
+    prob.peeled = [PeeledImages(theta=[60.0, 120.0], phi=[10.0, 200.0], n_wav=4, wav_min=0.05, wav_max=500.0,
+                                n_x=8, n_y=8, x_min=-PC, x_max=PC, y_min=-PC, y_max=PC,
+                                n_ap=2, ap_min=0.3 * PC, ap_max=1.5 * PC, track_origin="detailed", uncertainties=True)]
+    run_both(prob, 5000, 20000)
+
+
+def test_direct_source_attenuation_is_exp_minus_tau():
+    """test_image.py:876-915: a source seen through uniform, purely absorbing
+    dust is dimmed by exp(-chi rho d).  Here: central source, tau = 1 to the face
+    along the line of sight (theta=90, phi=0), kill_on_absorb so that only direct
+    light reaches the image; ratio to the dust-free run = e^-1."""
+    def flux(tau):
+        p = make_benchmark_problem(10, tau=tau)
+        p.dust[0].albedo[:] = 0.0
+        p.config.kill_on_absorb = True
+        p.config.forced_first_interaction = False
+        p.peeled = [PeeledImages(theta=[90.0], phi=[0.0], n_wav=1, wav_min=0.01, wav_max=1e5, compute_image=False,
+                                 n_ap=1, ap_min=3 * PC, ap_max=3 * PC, compute_stokes=False)]
+        eng = hyperion_amd.Engine(p)
+        res, st = eng.final_iteration(100000)
+        return res[0]["sed"].sum()
+    assert flux(1.0) / flux(1e-12) == pytest.approx(np.exp(-1.0), rel=1e-6)
+
+
+def test_sed_uncertainty_is_one_over_sqrt_n():
+    """test_sed.py:473-501: for equal-weight packets sigma/F = 1/sqrt(N)."""
+    p = make_benchmark_problem(6, tau=1e-12)
+    p.config.forced_first_interaction = False
+    p.peeled = [PeeledImages(theta=[30.0], phi=[60.0], n_wav=1, wav_min=0.001, wav_max=1e6, compute_image=False,
+                             n_ap=1, ap_min=3 * PC, ap_max=3 * PC, uncertainties=True, compute_stokes=False)]
+    n = 40000
+    eng = hyperion_amd.Engine(p)
+    res, st = eng.final_iteration(n)
+    out = finalize_peeled(p.peeled[0], res[0])
+    assert out["seds_unc"].sum() / out["seds"].sum() == pytest.approx(1.0 / np.sqrt(n), rel=1e-3)
+    # and the flux itself: L / (4 pi) per steradian, nu F_nu summed over the one bin
+    from hyperion_amd.images import dnunorm
+    assert out["seds"].sum() * dnunorm(p.peeled[0]) == pytest.approx(LSUN, rel=1e-9)
+
+
+def test_total_is_source_plus_dust_components():
+    """test_image.py:672-677 with basic origin tracking."""
+    p = imaging_problem(track_origin="basic")
+    q = imaging_problem()
+    a, _ = run_both(p, 20000, 30000)
+    b, _ = run_both(q, 20000, 30000)
+    np.testing.assert_allclose(a[0]["img"].sum(axis=1), b[0]["img"][:, 0], rtol=1e-9, atol=1e-12 * b[0]["img"].max())
+
+
+def test_full_size_image_512():
+    """BASELINE config 4's detector (512 x 512, one view, Stokes) on the 128^3
+    Cartesian grid, 5e6 imaging packets: image total equals SED of the largest
+    aperture, flux conservation against the no-dust case bound."""
+    p = make_benchmark_problem(128)
+    p.peeled = [PeeledImages(theta=[45.0], phi=[45.0], n_wav=1, wav_min=0.01, wav_max=1e5,
+                             n_x=512, n_y=512, x_min=-2 * PC, x_max=2 * PC, y_min=-2 * PC, y_max=2 * PC,
+                             n_ap=1, ap_min=4 * PC, ap_max=4 * PC)]
+    eng = hyperion_amd.Engine(p)
+    eng.lucy_iteration(2_000_000, 1, want_output=False)
+    res, st = eng.final_iteration(5_000_000)
+    img, sed = res[0]["img"], res[0]["sed"]
+    assert img.shape == (4, 1, 1, 512, 512, 1)
+    assert img[0].sum() == pytest.approx(sed[0].sum(), rel=1e-9)
+    assert 0.3 * LSUN < sed[0].sum() < 1.0 * LSUN          # attenuated but not lost
+    assert st["killed_geo"] == 0
+    # the central pixel block holds the direct source light
+    c = img[0, 0, 0, 254:258, 254:258, 0].sum()
+    assert c > 0.1 * img[0].sum()

@@ -69,3 +69,55 @@ def test_converged_iterations_match_reference_golden():
     # per-cell: iteration-5 golden vs the low-noise oracle, scatter consistent with 1e4 packets
     r = gold[4] / se
     assert np.median(r) == pytest.approx(1.0, abs=0.05)
+
+
+def _peeloff_run(prob, seed, n_lucy, n_img):
+    from hyperion_amd.images import finalize_peeled
+    prob.config.seed = seed
+    o = Oracle(prob)
+    for it in range(1, prob.config.n_initial_iter + 1):
+        o.lucy_iteration(n_lucy, it)
+    res, st = o.final_iteration(n_img)
+    o.close()
+    return [finalize_peeled(p, r) for p, r in zip(prob.peeled, res)], st
+
+
+@pytest.mark.parametrize("evenly", [False, True])
+def test_peeloff_seds_and_images_match_reference_golden(evenly):
+    """test_peeloff.grid_type=car.raytracing=False.*.rtout (test_bit_level.py:175-236):
+    3 image groups (no / basic / detailed origin tracking, Stokes on), 5x1e3 Lucy
+    + 5e3 imaging packets.  Stokes I per (view, wavelength) bin of the largest
+    aperture and summed images within the Monte Carlo noise; the signs of Q and U
+    (which pin the scattering-geometry orientation) by a two-hypothesis chi^2."""
+    prob, z = golden_problem("car_peeloff.%s.npz" % evenly)
+    big, st = _peeloff_run(prob, -5, 100000, 600000)
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0
+    K = 12
+    samples = [_peeloff_run(prob, -(100 + k), 1000, 5000)[0] for k in range(K)]
+    chi_plus = {1: 0.0, 2: 0.0}
+    chi_minus = {1: 0.0, 2: 0.0}
+    for g in range(3):
+        gold = z["golden/group%d/seds" % (g + 1)]
+        assert gold.shape == big[g]["seds"].shape
+        assert z["golden/group%d/images" % (g + 1)].shape == big[g]["images"].shape
+        b = big[g]["seds"]
+        sig = np.std([s[g]["seds"] for s in samples], axis=0, ddof=1)
+        I = b[0][:, :, -1, :]
+        sel = (sig[0][:, :, -1, :] > 0) & (I > 0.02 * I.max())
+        zI = ((gold[0][:, :, -1, :] - I)[sel] / sig[0][:, :, -1, :][sel])
+        assert np.abs(zI).max() < 5.0 and (zI ** 2).mean() < 2.5
+        # total flux over all bins of the largest aperture, and summed images
+        assert gold[0][:, :, -1, :].sum() == pytest.approx(I.sum(), rel=0.06)
+        gi = z["golden/group%d/images" % (g + 1)][0]
+        assert gi.sum() == pytest.approx(big[g]["images"][0].sum(), rel=0.08)
+        for ist in (1, 2):
+            x, s_ = b[ist][:, :, -1, :][sel], sig[ist][:, :, -1, :][sel]
+            ok = s_ > 0
+            chi_plus[ist] += ((((gold[ist][:, :, -1, :][sel] - x)[ok]) / s_[ok]) ** 2).sum()
+            chi_minus[ist] += ((((gold[ist][:, :, -1, :][sel] + x)[ok]) / s_[ok]) ** 2).sum()
+        # Stokes V is identically zero for this dust (P4 = 0)
+        assert np.all(gold[3] == 0) and np.all(b[3] == 0)
+    for ist in (1, 2):
+        assert chi_plus[ist] < chi_minus[ist] - 10.0, (ist, chi_plus, chi_minus)
+    # golden uncertainty cubes exist only if requested
+    assert "golden/group1/seds_unc" not in z.files
