@@ -6,5 +6,6 @@ implemented, as hand-written HIP behind the C-ABI of ``include/hyperion_amd.h``.
 """
 from .problem import Dust, PeeledImages, Problem, RunConfig, Source  # noqa: F401
 from .engine import Engine, EngineError, load_library  # noqa: F401
+from .run import run, run_problem  # noqa: F401
 
-__all__ = ["Dust", "PeeledImages", "Problem", "RunConfig", "Source", "Engine", "EngineError", "load_library"]
+__all__ = ["Dust", "PeeledImages", "Problem", "RunConfig", "Source", "Engine", "EngineError", "load_library", "run", "run_problem"]

@@ -26,7 +26,11 @@ def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all
     (``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
     first, n_local = shard_range(n_total, rank, world_size)
     engine.lucy_launch(first, n_local, iteration)
-    acc = engine.lucy_accumulators_tensor()
+    if world_size == 1 and all_reduce is None:
+        engine.lucy_accumulators()           # no collective: no torch needed
+        acc = None
+    else:
+        acc = engine.lucy_accumulators_tensor()
     if world_size > 1:
         if all_reduce is None:
             import torch.distributed as dist
@@ -41,7 +45,11 @@ def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all
 def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=None):
     first, n_local = shard_range(n_total, rank, world_size)
     engine.final_launch(first, n_local)
-    acc = engine.final_accumulators_tensor()
+    if world_size == 1 and all_reduce is None:
+        engine.final_accumulators()
+        acc = None
+    else:
+        acc = engine.final_accumulators_tensor()
     if world_size > 1:
         if all_reduce is None:
             import torch.distributed as dist

@@ -158,12 +158,16 @@ class Engine:
     def final_launch(self, first_id, n_local):
         self._check(self._lib.hyp_final_launch(self._h, int(first_id), int(n_local)))
 
-    def final_accumulators_tensor(self):
-        import torch
+    def final_accumulators(self):
         p = C.c_void_p()
         n = C.c_uint64()
         self._check(self._lib.hyp_final_accumulators(self._h, C.byref(p), C.byref(n)))
-        return torch.as_tensor(_DeviceBlock(p.value, n.value), device="cuda:%d" % self.device)
+        return p.value, n.value
+
+    def final_accumulators_tensor(self):
+        import torch
+        ptr, n = self.final_accumulators()
+        return torch.as_tensor(_DeviceBlock(ptr, n), device="cuda:%d" % self.device)
 
     def final_finish(self):
         st = IterStats()

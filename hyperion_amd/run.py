@@ -1,0 +1,326 @@
+"""Counterpart of ``Model.run()`` + ``scripts/hyperion`` + ``program main``:
+iteration sequencing, convergence test and the ``.rtout`` file contract
+(``hyperion/model/model.py:1025-1080``, ``scripts/hyperion:39-104``,
+``src/main/main.f90:99-344``), driving the HIP engine through the C-ABI.
+
+    python -m hyperion_amd [-f] [-m N] input.rtin output.rtout
+
+Failure convention of the reference: the message goes to the log / stderr, the
+output file lacks ``date_ended`` and the caller raises
+``SystemExit("An error occurred, and the run did not complete")``.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+import sys
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from .distributed import final_iteration_sharded, lucy_iteration_sharded
+from .engine import Engine, EngineError
+from .images import finalize_peeled
+from .problem import Problem
+
+FORTRAN_VERSION = "1.0.0"      # src/main/main.f90 `fortran_version`
+
+
+def quantile(values, percent):
+    """fortranlib lib_statistics `quantile` (source absent): nearest-rank element
+    of the sorted sample at fraction percent/100."""
+    v = np.sort(np.asarray(values, dtype=np.float64).ravel())
+    if v.size == 0:
+        return 0.0
+    ipos = int(round(percent / 100.0 * (v.size - 1)))
+    return float(v[min(max(ipos, 0), v.size - 1)])
+
+
+class ConvergenceCheck:
+    """specific_energy_converged: src/grid/grid_physics_3d.f90:637-689."""
+
+    def __init__(self, absolute, relative, percentile, log=None):
+        self.absolute, self.relative, self.percentile = absolute, relative, percentile
+        self.prev = None
+        self.value_prev = np.inf
+        self.log = log or (lambda *a: None)
+        self.value = None
+
+    def __call__(self, se):
+        if self.prev is None:
+            self.prev = se.copy()
+            return False
+        prev = self.prev
+        if np.all(prev == se):
+            value = 0.0
+        elif np.all((prev == se) | (prev == 0) | (se == 0)):
+            self.log(" [specific_energy_converged] could not check for convergence, as the only cells that changed had zero value before or after")
+            return False
+        else:
+            m = (prev > 0) & (se > 0) & (prev != se)
+            a, b = prev[m], se[m]
+            value = quantile(np.maximum(a / b, b / a), self.percentile)
+        self.value = value
+        if self.value_prev < np.inf:
+            if value == 0.0:
+                converged = True
+            else:
+                ratio = max(self.value_prev / value, value / self.value_prev)
+                converged = value < self.absolute and abs(ratio) < self.relative
+        else:
+            converged = False
+        self.prev = se.copy()
+        self.value_prev = value
+        return converged
+
+
+@dataclass
+class IterationRecord:
+    index: int
+    killed_geo: int
+    killed_int: int
+    specific_energy: Optional[np.ndarray] = None
+    density: Optional[np.ndarray] = None
+    stats: dict = field(default_factory=dict)
+    seconds: float = 0.0
+
+
+@dataclass
+class RunResult:
+    iterations: List[IterationRecord]
+    converged: bool
+    n_iterations: int
+    peeled: List[dict]
+    final_stats: dict
+    cpu_time: float
+    date_started: str
+    date_ended: str
+
+
+def _now():
+    return datetime.datetime.now().strftime("%d %B %Y at %H:%M:%S")
+
+
+def _want(mode, it, n_iter):
+    return mode == "all" or (mode == "last" and it == n_iter)
+
+
+def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engine_options=None) -> RunResult:
+    """The iteration sequence of ``program main`` (src/main/main.f90:167-344)."""
+    log = log or (lambda *a: None)
+    cfg = problem.config
+    for flag, name in ((cfg.mrw, "MRW"), (cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode"), (cfg.raytracing, "raytracing")):
+        if flag:
+            raise EngineError("%s is not supported by the MI355X engine yet" % name)
+    date_started = _now()
+    t0 = time.time()
+    eng = Engine(problem, device=device)
+    for k, v in (engine_options or {}).items():
+        eng.set_option(k, v)
+    log(" [main] using random seed = %d" % cfg.seed)
+    records = []
+    converged = False
+    check = ConvergenceCheck(cfg.convergence_absolute, cfg.convergence_relative, cfg.convergence_percentile, log) \
+        if cfg.check_convergence else None
+    n_iter = cfg.n_initial_iter
+    n_done = n_iter
+    for it in range(1, n_iter + 1):
+        log(" [main] starting Lucy iteration %d" % it)
+        ti = time.time()
+        se, st = lucy_iteration_sharded(eng, cfg.n_initial_photons, it, rank, world_size)
+        log(" [main] exiting Lucy iteration")
+        if check is not None:
+            converged = check(se)
+            if converged:
+                log("      ------ Specific energy calculation converged -----")
+        last = it if (check is not None and converged) else n_iter
+        rec = IterationRecord(it, st["killed_geo"], st["killed_int"], stats=st, seconds=time.time() - ti)
+        if _want(cfg.output_specific_energy, it, last):
+            rec.specific_energy = se
+        if _want(cfg.output_density, it, last):
+            rec.density = eng.density()
+        records.append(rec)
+        if check is not None and converged:
+            n_done = it
+            break
+    peeled, fstats = [], {"killed_geo": 0, "killed_int": 0}
+    log(" [main] starting final iteration")
+    if cfg.n_last_photons > 0:
+        raw, fstats = final_iteration_sharded(eng, cfg.n_last_photons, rank, world_size)
+        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, raw)]
+    else:
+        log("      ------------------ Skipping ------------------")
+        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, eng.peeled_results())]
+    log(" [main] exiting final iteration")
+    eng.close()
+    return RunResult(records, converged, n_done, peeled, fstats, time.time() - t0, date_started, _now())
+
+
+def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy_input=False):
+    """The ``.rtout`` layout (src/main/main.f90:130-344, grid_generic.f90:29-130,
+    image_type.f90:608-788).  Needs h5py."""
+    import h5py
+
+    def b(s):
+        return np.bytes_(s)
+
+    with h5py.File(path, "w") as f:
+        f.attrs["date_started"] = b(result.date_started)
+        f.attrs["fortran_version"] = b(FORTRAN_VERSION)
+        if input_path is not None:
+            if copy_input:
+                with h5py.File(input_path, "r") as fi:
+                    g = f.create_group("Input")
+                    for k in fi:
+                        fi.copy(k, g)
+                    for k, v in fi.attrs.items():
+                        g.attrs[k] = v
+            else:
+                f["Input"] = h5py.ExternalLink(os.path.abspath(input_path), "/")
+        geo = b(problem.geometry_id)
+        for rec in result.iterations:
+            g = f.create_group("iteration_%05d" % rec.index)
+            g.attrs["killed_photons_geo"] = np.int32(rec.killed_geo)
+            g.attrs["killed_photons_int"] = np.int32(rec.killed_int)
+            for name in ("specific_energy", "density"):
+                a = getattr(rec, name)
+                if a is not None:
+                    d = g.create_dataset(name, data=a, compression="gzip")
+                    d.attrs["geometry"] = geo
+        f.attrs["converged"] = b("yes" if result.converged else "no")
+        f.attrs["iterations"] = np.int32(result.n_iterations)
+        if problem.peeled:
+            gp = f.create_group("Peeled")
+            for ig, (pl, cubes) in enumerate(zip(problem.peeled, result.peeled)):
+                g = gp.create_group("group_%05d" % (ig + 1))
+                g.attrs["inside_observer"] = b("yes" if pl.inside_observer else "no")
+                g.attrs["d_min"] = np.float64(pl.d_min)
+                g.attrs["d_max"] = np.float64(pl.d_max)
+                for name, extra in (("seds", {"apmin": pl.ap_min, "apmax": pl.ap_max}),
+                                    ("images", {"xmin": pl.x_min, "xmax": pl.x_max, "ymin": pl.y_min, "ymax": pl.y_max})):
+                    if name not in cubes:
+                        continue
+                    d = g.create_dataset(name, data=cubes[name], compression="gzip")
+                    d.attrs["numin"] = np.float64(pl.nu_min)
+                    d.attrs["numax"] = np.float64(pl.nu_max)
+                    for k, v in extra.items():
+                        d.attrs[k] = np.float64(v)
+                    d.attrs["track_origin"] = b(pl.track_origin)
+                    if pl.track_origin == "detailed":
+                        d.attrs["n_sources"] = np.int32(len(problem.sources))
+                        d.attrs["n_dust"] = np.int32(problem.n_dust)
+                    elif pl.track_origin == "scatterings":
+                        d.attrs["track_n_scat"] = np.int32(pl.track_n_scat)
+                    if name + "_unc" in cubes:
+                        g.create_dataset(name + "_unc", data=cubes[name + "_unc"], compression="gzip")
+        f.attrs["killed_photons_geo_final"] = np.int32(result.final_stats.get("killed_geo", 0))
+        f.attrs["killed_photons_int_final"] = np.int32(result.final_stats.get("killed_int", 0))
+        f.attrs["killed_photons_geo_raytracing"] = np.int32(0)
+        f.attrs["killed_photons_int_raytracing"] = np.int32(0)
+        f.attrs["cpu_time"] = np.float64(result.cpu_time)
+        f.attrs["date_ended"] = b(result.date_ended)      # last: its presence marks success
+
+
+def write_npz_output(path, problem, result):
+    """HDF5-free rendition of the same content (where h5py is unavailable)."""
+    out = {"converged": np.bool_(result.converged), "iterations": np.int32(result.n_iterations),
+           "cpu_time": np.float64(result.cpu_time)}
+    for rec in result.iterations:
+        out["iteration_%05d/killed" % rec.index] = np.array([rec.killed_geo, rec.killed_int])
+        if rec.specific_energy is not None:
+            out["iteration_%05d/specific_energy" % rec.index] = rec.specific_energy
+        if rec.density is not None:
+            out["iteration_%05d/density" % rec.index] = rec.density
+    for ig, cubes in enumerate(result.peeled):
+        for k, v in cubes.items():
+            out["Peeled/group_%05d/%s" % (ig + 1, k)] = v
+    np.savez_compressed(path, **out)
+
+
+def run(input_file, output_file=None, overwrite=False, logfile=None, device=None, engine_options=None):
+    """``Model.run()`` counterpart: ``.rtin`` (or a Problem ``.npz``) in,
+    ``.rtout`` (or ``.npz``) out.  Returns the output path."""
+    if output_file is None:
+        output_file = input_file.replace(".rtin", ".rtout") if ".rtin" in input_file else input_file + ".rtout"
+    if os.path.exists(output_file):
+        if not overwrite:
+            raise SystemExit("Output file %s already exists (use -f / overwrite=True)" % output_file)
+        os.remove(output_file)
+    flog = open(logfile, "w") if logfile else None
+
+    def log(*a):
+        print(*a, file=flog or sys.stdout, flush=True)
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    try:
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", rank=rank, world_size=world)
+        if input_file.endswith(".npz"):
+            problem = Problem.from_npz(input_file)
+        else:
+            from .rtin import read_rtin
+            problem = read_rtin(input_file)
+        log(" " + "-" * 60)
+        log(" Hyperion-AMD (C-ABI v1) on device %d, rank %d of %d" % (local_rank if device is None else device, rank, world))
+        log(" Input:  %s" % input_file)
+        log(" Output: %s" % output_file)
+        log(" " + "-" * 60)
+        result = run_problem(problem, device=local_rank if device is None else device, rank=rank, world_size=world,
+                             log=log, engine_options=engine_options)
+        if rank == 0:
+            if output_file.endswith(".npz"):
+                write_npz_output(output_file, problem, result)
+            else:
+                write_rtout(output_file, problem, result, input_path=None if input_file.endswith(".npz") else input_file)
+        log(" Total CPU time elapsed: %16.2f" % result.cpu_time)
+    except (EngineError, NotImplementedError, ValueError) as e:
+        print(" ERROR: %s" % e, file=flog or sys.stderr, flush=True)
+        raise SystemExit("An error occurred, and the run did not complete")
+    finally:
+        if dist is not None and dist.is_initialized():
+            dist.destroy_process_group()
+        if flog:
+            flog.close()
+    return output_file
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="hyperion_amd", description="Run the MI355X photon-packet engine on a Hyperion input file")
+    ap.add_argument("-f", action="store_true", help="overwrite output file if it already exists")
+    ap.add_argument("-m", type=int, dest="n_gpus", metavar="n_gpus", help="shard the packets over this many GPUs of the node")
+    ap.add_argument("input")
+    ap.add_argument("output")
+    a = ap.parse_args(argv)
+    if a.n_gpus and a.n_gpus > 1 and "RANK" not in os.environ:
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.n_gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(29500 + os.getpid() % 1000), "-m", "hyperion_amd"]
+        cmd += (["-f"] if a.f else []) + [a.input, a.output]
+        rc = subprocess.call(cmd)
+    else:
+        try:
+            run(a.input, a.output, overwrite=a.f)
+            rc = 0
+        except SystemExit as e:
+            print(e, file=sys.stderr)
+            rc = 1
+    # scripts/hyperion:98-104: success == the output carries date_ended
+    if rc == 0 and not a.output.endswith(".npz"):
+        try:
+            import h5py
+            with h5py.File(a.output, "r") as f:
+                f.attrs["date_ended"]
+        except Exception:
+            print("Run did not complete successfully: output file appears to be corrupt")
+            rc = 1
+    return rc

@@ -26,6 +26,12 @@ What it writes (all plain .npz, inputs + expected outputs only):
                raytracing=False); golden: Peeled/group_0000{1,2,3}/{seds,images}
                (+ _unc) and iteration_00005/specific_energy of
                test_peeloff.grid_type=car.raytracing=False.*.rtout
+  car_peeloff.False.rtin
+      the reference-written HDF5 input of the same peel-off model with the
+      external dust links materialised (input of the file-level drop-in test)
+  rtout_layout.car_peeloff.json
+      names / shapes / attribute types of every object in the reference's golden
+      test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=False.rtout
   test_dust.npz
       the grey isotropic LTE test dust of hyperion/model/tests/test_helpers.py:14-18
       (IsotropicDust([3e9,3e16],[.5,.5],[1,1]) + set_lte_emissivities(10,0.1,1600))
@@ -100,10 +106,19 @@ def add_sources(m):
         s.position = np.random.uniform(-pc, pc, 3)
 
 
-def write_and_read(m, tmp):
+def write_and_read(m, tmp, keep_as=None):
     path = os.path.join(tmp, "model.rtin")
     m.set_copy_input(False)
     m.write(path, copy=False, absolute_paths=True)
+    if keep_as is not None:
+        # self-contained copy of the .rtin (external dust links materialised) so
+        # that the file-level drop-in can be exercised where /root/reference is absent
+        with h5py.File(path, "r") as fi, h5py.File(keep_as, "w") as fo:
+            for k, v in fi.attrs.items():
+                fo.attrs[k] = v
+            for k in fi:
+                fi.copy(k, fo, expand_external=True, expand_soft=True)
+        print("wrote", keep_as, os.path.getsize(keep_as))
     return read_rtin(path)
 
 
@@ -169,7 +184,7 @@ def main():
                 i_p.set_aperture_radii(2, 0.5 * pc, pc)
                 i_p.set_track_origin(track)
                 i_p.set_stokes(True)
-            prob = write_and_read(m, tmp)
+            prob = write_and_read(m, tmp, keep_as=None if evenly else os.path.join(HERE, "car_peeloff.False.rtin"))
             ref = os.path.join(DATA, "test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=%s.rtout" % evenly)
             golden = {}
             with h5py.File(ref, "r") as f:
@@ -185,6 +200,21 @@ def main():
                 n_it = int(f.attrs["iterations"])
                 golden["specific_energy_last"] = f["iteration_%05d/specific_energy" % n_it][...]
             save(os.path.join(HERE, "car_peeloff.%s.npz" % evenly), prob, golden)
+
+        # --- layout of the golden .rtout (names, shapes, attribute types) ------
+        import json
+        ref = os.path.join(DATA, "test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=False.rtout")
+        with h5py.File(ref, "r") as f:
+            lay = {"root_attrs": {k: type(v).__name__ for k, v in f.attrs.items()}, "items": {}}
+
+            def visit(n, o):
+                e = {"attrs": {k: type(v).__name__ for k, v in o.attrs.items()}}
+                if isinstance(o, h5py.Dataset):
+                    e["shape"] = list(o.shape)
+                    e["dtype"] = str(o.dtype)
+                lay["items"][n] = e
+            f.visititems(visit)
+        json.dump(lay, open(os.path.join(HERE, "rtout_layout.car_peeloff.json"), "w"), indent=1, sort_keys=True)
 
         # --- grey isotropic test dust (test_helpers.py:14-18) -------------------
         dust = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])

@@ -1,0 +1,98 @@
+"""The run() counterpart end to end on the GPU: iteration sequencing, outputs,
+failure convention, and the file-level drop-in (.rtin in, .rtout out)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import GOLDEN, golden_problem
+from hyperion_amd.benchmark import PC, make_benchmark_problem
+from hyperion_amd.run import run, run_problem
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONDA = "/opt/conda/bin/python3.9"
+
+
+def test_iteration_sequence_and_output_modes():
+    prob, z = golden_problem("car_peeloff.False.npz")
+    prob.config.n_initial_photons = 20000
+    prob.config.n_last_photons = 20000
+    prob.config.output_specific_energy = "all"
+    r = run_problem(prob)
+    assert [it.index for it in r.iterations] == [1, 2, 3, 4, 5] and r.n_iterations == 5 and not r.converged
+    assert all(it.specific_energy is not None and it.killed_geo == 0 for it in r.iterations)
+    assert r.peeled[1]["seds"].shape == z["golden/group2/seds"].shape
+    assert r.peeled[2]["images"].shape == z["golden/group3/images"].shape
+    # SED apertures are cumulative after normalisation
+    s = r.peeled[0]["seds"][0]
+    assert np.all(np.diff(s, axis=2) >= -1e-12 * s.max())
+    # total absorbed luminosity in line with the golden (which used 1e3 packets: ~5 % noise)
+    w = prob.density * prob.volumes
+    assert (r.iterations[-1].specific_energy * w).sum() == pytest.approx((z["golden/specific_energy_last"] * w).sum(), rel=0.15)
+    prob.config.output_specific_energy = "last"
+    r2 = run_problem(prob)
+    assert [it.specific_energy is not None for it in r2.iterations] == [False] * 4 + [True]
+    np.testing.assert_allclose(r2.iterations[-1].specific_energy, r.iterations[-1].specific_energy, rtol=1e-10)
+
+
+def test_convergence_stops_the_iterations():
+    p = make_benchmark_problem(8, n_photons=200000, n_iter=10)
+    p.config.check_convergence = True
+    p.config.convergence_absolute = 2.0
+    p.config.convergence_relative = 2.0
+    p.config.convergence_percentile = 90.0
+    p.config.output_specific_energy = "last"
+    r = run_problem(p)
+    assert r.converged and r.n_iterations < 10
+    assert r.iterations[-1].index == r.n_iterations and r.iterations[-1].specific_energy is not None
+
+
+def test_npz_round_trip_and_failure_convention(tmp_path):
+    p = make_benchmark_problem(8, n_photons=20000, n_iter=2)
+    src = str(tmp_path / "in.npz")
+    p.to_npz(src)
+    out = run(src, str(tmp_path / "out.npz"), overwrite=True, logfile=str(tmp_path / "log.txt"))
+    z = np.load(out)
+    assert z["iteration_00002/specific_energy"].shape == (1, 8, 8, 8) and int(z["iterations"]) == 2
+    assert "starting Lucy iteration 2" in open(tmp_path / "log.txt").read()
+    with pytest.raises(SystemExit, match="already exists"):
+        run(src, out)
+    # a source outside the grid: message in the log, SystemExit with the reference's text
+    p.sources[0].position = (5 * PC, 0, 0)
+    p.to_npz(src)
+    with pytest.raises(SystemExit, match="An error occurred, and the run did not complete"):
+        run(src, out, overwrite=True, logfile=str(tmp_path / "log2.txt"))
+    assert "photon was not emitted inside a cell" in open(tmp_path / "log2.txt").read()
+    assert not os.path.exists(out)
+    # unsupported modes are refused, not silently ignored
+    p = make_benchmark_problem(8, n_photons=1000, n_iter=1)
+    p.config.mrw = True
+    with pytest.raises(hyperion_amd.EngineError, match="MRW is not supported"):
+        run_problem(p)
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")
+def test_file_level_drop_in_rtin_to_rtout(tmp_path):
+    """`hyperion [-f] in.rtin out.rtout` counterpart on a .rtin written by the
+    reference front-end; success == the output carries date_ended
+    (scripts/hyperion:98-104)."""
+    out = str(tmp_path / "model.rtout")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    rc = subprocess.call([CONDA, "-W", "ignore", "-m", "hyperion_amd", "-f", os.path.join(GOLDEN, "car_peeloff.False.rtin"), out],
+                         env=env, cwd=ROOT)
+    assert rc == 0
+    code = ("import h5py, numpy as np\n"
+            "f = h5py.File(%r, 'r')\n"
+            "assert f.attrs['date_ended'] and f.attrs['iterations'] == 5\n"
+            "assert f['iteration_00005/specific_energy'].shape == (1, 3, 5, 7)\n"
+            "assert f['Peeled/group_00003/images'].shape == (4, 12, 1, 6, 6, 4)\n"
+            "assert float(np.nansum(f['Peeled/group_00001/seds'][0])) > 0\n") % out
+    subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        shutil.copy(out, os.path.join(keep, "car_peeloff.False.gpu.rtout"))

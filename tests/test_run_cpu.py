@@ -1,0 +1,101 @@
+"""Host logic of the run() counterpart that needs no GPU: convergence test,
+.rtin reader and .rtout writer (HDF5 side through /opt/conda's python, which
+has h5py; the system python does not)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN, golden_problem
+from hyperion_amd.run import ConvergenceCheck, IterationRecord, RunResult, quantile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONDA = "/opt/conda/bin/python3.9"
+needs_h5py = pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")
+
+
+def test_quantile_nearest_rank():
+    assert quantile(np.arange(101), 99.0) == 99.0
+    assert quantile([3.0, 1.0, 2.0], 100.0) == 3.0 and quantile([3.0, 1.0, 2.0], 0.0) == 1.0
+    assert quantile([], 50.0) == 0.0
+
+
+def test_convergence_follows_reference_rules():
+    """grid_physics_3d.f90:637-689"""
+    c = ConvergenceCheck(absolute=2.0, relative=1.5, percentile=99.0)
+    a = np.ones((1, 2, 2, 2))
+    assert c(a) is False                       # first call only stores the state
+    assert c(a * 1.5) is False                 # no previous value yet
+    assert c(a * 1.5 * 1.2) is True            # 1.2 < 2 and 1.5/1.2 < 1.5
+    assert c(a * 1.5 * 1.2) is True            # unchanged -> exact convergence
+    c = ConvergenceCheck(absolute=1.1, relative=1.5, percentile=99.0)
+    c(a); c(a * 1.5)
+    assert c(a * 1.5 * 1.2) is False           # value 1.2 above the absolute threshold
+    c = ConvergenceCheck(absolute=2.0, relative=1.5, percentile=99.0)
+    z = np.zeros_like(a)
+    c(z)
+    assert c(a) is False                       # only zero -> non-zero changes: cannot check
+
+
+@needs_h5py
+def test_rtin_reader_matches_fixture(tmp_path):
+    out = tmp_path / "p.npz"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from hyperion_amd.rtin import read_rtin\n"
+            "read_rtin(%r).to_npz(%r)\n") % (ROOT, os.path.join(GOLDEN, "car_peeloff.False.rtin"), str(out))
+    subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+    from hyperion_amd.problem import Problem
+    p = Problem.from_npz(str(out))
+    q, _ = golden_problem("car_peeloff.False.npz")
+    assert p.config == q.config and p.geometry_id == q.geometry_id
+    np.testing.assert_array_equal(p.density, q.density)
+    for k in ("nu", "chi", "albedo", "P1", "P2", "emiss_jnu", "emiss_var", "mo_specific_energy"):
+        np.testing.assert_array_equal(getattr(p.dust[0], k), getattr(q.dust[0], k))
+    assert [s.temperature for s in p.sources] == [s.temperature for s in q.sources]
+    assert [(g.n_x, g.n_y, g.n_ap, g.n_wav, g.track_origin) for g in p.peeled] == \
+        [(g.n_x, g.n_y, g.n_ap, g.n_wav, g.track_origin) for g in q.peeled]
+
+
+@needs_h5py
+def test_rtout_writer_reproduces_the_golden_layout(tmp_path):
+    """Object names, shapes and attribute types of a written .rtout equal those
+    of the reference's golden output for the same model."""
+    out = tmp_path / "o.rtout"
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+import numpy as np, h5py
+from hyperion_amd.problem import Problem
+from hyperion_amd.run import IterationRecord, RunResult, write_rtout
+p = Problem.from_npz(%r)
+its = [IterationRecord(i, 0, 0) for i in range(1, 6)]
+its[-1].specific_energy = np.ones(p.density.shape)
+peeled = []
+for g, n_orig in zip(p.peeled, (1, 4, 12)):
+    peeled.append({"seds": np.zeros((4, n_orig, g.n_view, g.n_ap, g.n_wav)),
+                   "images": np.zeros((4, n_orig, g.n_view, g.n_y, g.n_x, g.n_wav))})
+r = RunResult(its, False, 5, peeled, {"killed_geo": 0, "killed_int": 0}, 1.0, "now", "later")
+write_rtout(%r, p, r, input_path=%r)
+lay = {"root_attrs": {}, "items": {}}
+with h5py.File(%r, "r") as f:
+    lay["root_attrs"] = {k: type(v).__name__ for k, v in f.attrs.items()}
+    def visit(n, o):
+        e = {"attrs": {k: type(v).__name__ for k, v in o.attrs.items()}}
+        if isinstance(o, h5py.Dataset):
+            e["shape"] = list(o.shape); e["dtype"] = str(o.dtype)
+        lay["items"][n] = e
+    for k in f:
+        if k != "Input":
+            visit(k, f[k])
+            if isinstance(f[k], h5py.Group):
+                f[k].visititems(lambda n, o, k=k: visit(k + "/" + n, o))
+    assert f.get("Input", getlink=True).__class__.__name__ == "ExternalLink"
+print(json.dumps(lay))
+''' % (ROOT, os.path.join(GOLDEN, "car_peeloff.False.npz"), str(out), os.path.join(GOLDEN, "car_peeloff.False.rtin"), str(out))
+    got = json.loads(subprocess.check_output([CONDA, "-W", "ignore", "-c", code]).decode().strip().split("\n")[-1])
+    want = json.load(open(os.path.join(GOLDEN, "rtout_layout.car_peeloff.json")))
+    assert got["root_attrs"] == want["root_attrs"]
+    assert got["items"] == want["items"]
