@@ -18,13 +18,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+# rocprofv3 PMC, lucy_kernel<1>, 128^3 uniform benchmark (profiles/r01b_summary.md):
+# FETCH_SIZE 8.08522e7 KiB and WRITE_SIZE 1.08239e8 KiB per launch of 3.46321e9 crossings
+PMC_FETCH_B_PER_CROSSING = 8.08522e7 * 1024 / 3.46321e9
+PMC_WRITE_B_PER_CROSSING = 1.08239e8 * 1024 / 3.46321e9
+
+
 def cpu_baseline(prob, n_sample):
     """Oracle (CPU restatement) timed on this host's cores on a bounded sample
     of the same workload.  Test infrastructure used as the reported baseline,
     never as the product."""
     from oracle_lib import Oracle
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)
+    threads = min(cores, 64)         # per-thread accumulators: 64 x 16 MiB at 128^3
     orc = Oracle(prob)
     orc.lucy_iteration(min(n_sample, 20000), 1, n_threads=threads)   # warm-up (page faults, thread pool)
     t0 = time.time()
@@ -119,8 +125,17 @@ def main():
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "note": "24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; 32 MiB working set is L2/Infinity-Cache resident"},
+                         "frac": achieved / 8000.0,
+                         # L2<->fabric bytes per launch from the committed PMC passes of this kernel/config
+                         # (profiles/r01b_summary.md: FETCH_SIZE 23.9 B + WRITE_SIZE 32.0 B per crossing,
+                         # KiB units x1024, separate --pmc runs; the x2 wide-load correction of the guide does
+                         # not apply to 8-byte scattered loads, one 64-B request each = TCC_EA0_RDREQ x 64).
+                         "traffic": (PMC_FETCH_B_PER_CROSSING + PMC_WRITE_B_PER_CROSSING) * crossings / world / 1e9
+                                    if args.grid == 128 and args.density == "uniform" else None,
+                         "traffic_unit": "GB per launch (L2<->fabric; Infinity-Cache hits included, not HBM-only)",
+                         "note": "24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
+                                 "the kernel is bound by the memory-side scattered-atomic rate (2.38e10/s measured, profiles/r01_atomic_rate_ubench.md): "
+                                 "atomic-rate fraction %.2f" % (crossings / world / (k_ms * 1e-3) / 2.38e10)},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_prob = make_benchmark_problem(args.grid, density=args.density, n_photons=int(args.cpu_sample), n_iter=1)
