@@ -39,6 +39,8 @@ class GridDesc(C.Structure):
     _fields_ = [
         ("type", C.c_int32), ("n1", C.c_int32), ("n2", C.c_int32), ("n3", C.c_int32),
         ("w1", _dp), ("w2", _dp), ("w3", _dp),
+        ("n_cells", C.c_int64), ("refined", C.POINTER(C.c_int32)),
+        ("oct_center", C.c_double * 3), ("oct_half", C.c_double * 3),
     ]
 
 
@@ -108,13 +110,24 @@ class MarshalledProblem:
             keep(a)
             return _ptr(a)
 
-        if prob.grid_type != "car":
-            raise ValueError("grid is not cartesian")
-        n1, n2, n3 = prob.shape
         d = ProblemDesc()
-        d.grid.type = 1
-        d.grid.n1, d.grid.n2, d.grid.n3 = n1, n2, n3
-        d.grid.w1, d.grid.w2, d.grid.w3 = (arr(w) for w in prob.walls)
+        if prob.grid_type == "car":
+            n1, n2, n3 = prob.shape
+            d.grid.type = 1
+            d.grid.n1, d.grid.n2, d.grid.n3 = n1, n2, n3
+            d.grid.w1, d.grid.w2, d.grid.w3 = (arr(w) for w in prob.walls)
+            d.grid.n_cells = n1 * n2 * n3
+        elif prob.grid_type == "oct":
+            d.grid.type = 2
+            ref = np.ascontiguousarray(prob.refined, dtype=np.int32)
+            keep(ref)
+            d.grid.n_cells = ref.size
+            d.grid.refined = ref.ctypes.data_as(C.POINTER(C.c_int32))
+            for k in range(3):
+                d.grid.oct_center[k] = float(prob.oct_center[k])
+                d.grid.oct_half[k] = float(prob.oct_half[k])
+        else:
+            raise ValueError("Unexpected coordinate type: %s" % prob.grid_type)
 
         c = prob.config
         d.config.seed = int(c.seed)

@@ -55,6 +55,17 @@ struct DPeeled {
     double *sed, *sed2, *img, *img2;
 };
 
+// Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
+// Half-widths are root half-width * 2^-level.
+struct OctCell {
+    double x, y, z;
+    int parent;              // -1 for the root
+    signed char subcell;     // position inside the parent, bit0 = x, bit1 = y, bit2 = z
+    unsigned char level;
+    unsigned char refined;
+    unsigned char pad;
+};
+
 // Slots of the scalar tail that follows the per-cell accumulators.
 enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
        TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
@@ -70,7 +81,11 @@ struct DProblem {
     double baes16_xi;
     double check_p, check_log1mp;         // propagation_check_frequency p, log(1-p)
     uint32_t seed_key, pad1;
+    int grid_type, pad3;                  // 1 cartesian, 2 octree
     const double *w[3], *ew[3];           // walls and 3*spacing(wall)
+    const OctCell *oct_cells;             // [n_cells]
+    const int *oct_children;              // [n_cells][8], -1 where not refined
+    double oct_half[3], oct_box[6], oct_eps;
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

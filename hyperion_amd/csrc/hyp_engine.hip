@@ -102,6 +102,8 @@ struct hyp_engine {
     DProblem hp;               // host copy of the device problem descriptor
     DProblem *d_problem = nullptr;
     double *d_blob = nullptr;
+    OctCell *d_oct_cells = nullptr;
+    int *d_oct_children = nullptr;
     DSource *d_sources = nullptr;
     DPeeled *d_peeled = nullptr;
     double *d_density = nullptr, *d_specific_energy = nullptr, *d_additional = nullptr;
@@ -142,40 +144,52 @@ int set_error(const std::string &m) { g_error = m; return 1; }
 template <typename T>
 void free_dev(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-size_t lds_bytes(const DProblem &P) { return sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
+size_t lds_bytes(const DProblem &P) { return P.grid_type == 2 ? 0 : sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
 
 using LucyKernel = void (*)(const DProblem *, LaunchParams);
 
-LucyKernel pick_lucy_kernel(int nd)
+template <int GEOM>
+LucyKernel pick_lucy_kernel_g(int nd)
 {
 #ifdef HYP_ONLY_ND1   // tuning builds (tools/variants.py) instantiate one species only
     (void)nd;
-    return lucy_kernel<1>;
+    return lucy_kernel<1, GEOM>;
 #else
     switch (nd) {
-    case 1: return lucy_kernel<1>;
-    case 2: return lucy_kernel<2>;
-    case 3: return lucy_kernel<3>;
-    case 4: return lucy_kernel<4>;
-    default: return lucy_kernel<HYP_MAXD>;
+    case 1: return lucy_kernel<1, GEOM>;
+    case 2: return lucy_kernel<2, GEOM>;
+    case 3: return lucy_kernel<3, GEOM>;
+    case 4: return lucy_kernel<4, GEOM>;
+    default: return lucy_kernel<HYP_MAXD, GEOM>;
     }
 #endif
 }
 
-LucyKernel pick_final_kernel(int nd)
+template <int GEOM>
+LucyKernel pick_final_kernel_g(int nd)
 {
 #ifdef HYP_ONLY_ND1
     (void)nd;
-    return final_kernel<1>;
+    return final_kernel<1, GEOM>;
 #else
     switch (nd) {
-    case 1: return final_kernel<1>;
-    case 2: return final_kernel<2>;
-    case 3: return final_kernel<3>;
-    case 4: return final_kernel<4>;
-    default: return final_kernel<HYP_MAXD>;
+    case 1: return final_kernel<1, GEOM>;
+    case 2: return final_kernel<2, GEOM>;
+    case 3: return final_kernel<3, GEOM>;
+    case 4: return final_kernel<4, GEOM>;
+    default: return final_kernel<HYP_MAXD, GEOM>;
     }
 #endif
+}
+
+LucyKernel pick_lucy_kernel(int nd, int grid_type)
+{
+    return grid_type == 2 ? pick_lucy_kernel_g<GEOM_OCT>(nd) : pick_lucy_kernel_g<GEOM_CAR>(nd);
+}
+
+LucyKernel pick_final_kernel(int nd, int grid_type)
+{
+    return grid_type == 2 ? pick_final_kernel_g<GEOM_OCT>(nd) : pick_final_kernel_g<GEOM_CAR>(nd);
 }
 
 }  // namespace
@@ -191,6 +205,7 @@ void hyp_destroy(hyp_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
+    free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
@@ -212,18 +227,59 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     g_error.clear();
     if (out) *out = nullptr;
     if (!pr || !out) return set_error("null argument");
-    if (pr->grid.type != 1) return set_error("grid is not cartesian");
+    if (pr->grid.type != 1 && pr->grid.type != 2) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
     if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
-    const int n[3] = {pr->grid.n1, pr->grid.n2, pr->grid.n3};
+    const bool is_oct = pr->grid.type == 2;
+    const int n[3] = {is_oct ? 0 : pr->grid.n1, is_oct ? 0 : pr->grid.n2, is_oct ? 0 : pr->grid.n3};
     const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
-    for (int a = 0; a < 3; a++) {
-        if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
-        for (int i = 0; i < n[a]; i++)
-            if (!(win[a][i + 1] - win[a][i] > 0.0))
-                return set_error(std::string("all d") + "xyz"[a] + " values should be greater than zero");
+    std::vector<OctCell> oct_cells;
+    std::vector<int> oct_children;
+    if (!is_oct) {
+        for (int a = 0; a < 3; a++) {
+            if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
+            for (int i = 0; i < n[a]; i++)
+                if (!(win[a][i + 1] - win[a][i] > 0.0))
+                    return set_error(std::string("all d") + "xyz"[a] + " values should be greater than zero");
+        }
+        if ((size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
+    } else {
+        // setup_grid_geometry + octree_setup_indiv: grid_geometry_octree.f90:147-246
+        const int64_t nc = pr->grid.n_cells;
+        if (nc < 1 || nc > 2000000000ll || !pr->grid.refined) return set_error("octree needs a refined list");
+        oct_cells.resize((size_t)nc);
+        oct_children.assign((size_t)nc * 8, -1);
+        for (int a = 0; a < 3; a++) if (!(pr->grid.oct_half[a] > 0.0)) return set_error("all volumes should be greater than zero");
+        std::vector<double> hx((size_t)nc);   // x half-widths only to detect underflow of the level encoding
+        OctCell &root = oct_cells[0];
+        root.x = pr->grid.oct_center[0]; root.y = pr->grid.oct_center[1]; root.z = pr->grid.oct_center[2];
+        root.parent = -1; root.subcell = -1; root.level = 0; root.refined = pr->grid.refined[0] == 1; root.pad = 0;
+        std::vector<std::pair<int, int>> stack;
+        if (root.refined) stack.push_back({0, 0});
+        int64_t filled = 1;
+        while (!stack.empty()) {
+            int par = stack.back().first, k = stack.back().second;
+            if (k == 8) { stack.pop_back(); continue; }
+            stack.back().second = k + 1;
+            if (filled >= nc) return set_error("refined array is not self-consistent");
+            int c = (int)filled++;
+            oct_children[(size_t)par * 8 + k] = c;
+            const OctCell &pc = oct_cells[par];
+            const int lev = pc.level;
+            OctCell &cc = oct_cells[c];
+            const double hpx = std::ldexp(pr->grid.oct_half[0], -lev), hpy = std::ldexp(pr->grid.oct_half[1], -lev),
+                         hpz = std::ldexp(pr->grid.oct_half[2], -lev);
+            cc.x = pc.x + ((k & 1) ? 1 : -1) * hpx / 2.0;
+            cc.y = pc.y + ((k & 2) ? 1 : -1) * hpy / 2.0;
+            cc.z = pc.z + ((k & 4) ? 1 : -1) * hpz / 2.0;
+            cc.parent = par; cc.subcell = (signed char)k; cc.pad = 0;
+            if (lev + 1 > 200) return set_error("octree too deep");
+            cc.level = (unsigned char)(lev + 1);
+            cc.refined = pr->grid.refined[c] == 1;
+            if (cc.refined) stack.push_back({c, 0});
+        }
+        if (filled != nc) return set_error("refined array is not self-consistent");
     }
-    if ((size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -235,7 +291,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     h->device = device;
     h->cfg = pr->config;
     h->n_dust = pr->n_dust;
-    h->n_cells = (size_t)n[0] * n[1] * n[2];
+    h->n_cells = is_oct ? (size_t)pr->grid.n_cells : (size_t)n[0] * n[1] * n[2];
     h->n_elem = h->n_cells * h->n_dust;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
@@ -248,6 +304,17 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     DProblem &P = h->hp;
     std::memset(&P, 0, sizeof(P));
     P.n1 = n[0]; P.n2 = n[1]; P.n3 = n[2]; P.n_dust = pr->n_dust;
+    P.grid_type = pr->grid.type;
+    if (is_oct) {
+        double m = 0.0;
+        for (int a = 0; a < 3; a++) {
+            P.oct_half[a] = pr->grid.oct_half[a];
+            P.oct_box[2 * a] = pr->grid.oct_center[a] - pr->grid.oct_half[a];
+            P.oct_box[2 * a + 1] = pr->grid.oct_center[a] + pr->grid.oct_half[a];
+            if (pr->grid.oct_half[a] > m) m = pr->grid.oct_half[a];
+        }
+        P.oct_eps = spacing(m) * 3.0;   // grid_geometry_octree.f90:243
+    }
     P.n_sources = pr->n_sources; P.n_peeled = pr->n_peeled;
     P.sample_sources_evenly = pr->config.sample_sources_evenly;
     P.kill_on_absorb = pr->config.kill_on_absorb; P.kill_on_scatter = pr->config.kill_on_scatter;
@@ -262,8 +329,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     }
 
     // walls + 3*spacing(w): grid_geometry_cartesian_3d.f90:97-132
-    size_t w_off[3], ew_off[3];
-    for (int a = 0; a < 3; a++) {
+    size_t w_off[3] = {0, 0, 0}, ew_off[3] = {0, 0, 0};
+    for (int a = 0; a < 3 && !is_oct; a++) {
         w_off[a] = B.put(win[a], n[a] + 1);
         std::vector<double> ew(n[a] + 1);
         for (int i = 0; i <= n[a]; i++) ew[i] = 3.0 * spacing(win[a][i]);
@@ -429,7 +496,14 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     HIPC(hipMalloc(&h->d_blob, sizeof(double) * B.h.size()));
     HIPC(hipMemcpy(h->d_blob, B.h.data(), sizeof(double) * B.h.size(), hipMemcpyHostToDevice));
     const double *db = h->d_blob;
-    for (int a = 0; a < 3; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    for (int a = 0; a < 3 && !is_oct; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    if (is_oct) {
+        HIPC(hipMalloc(&h->d_oct_cells, sizeof(OctCell) * oct_cells.size()));
+        HIPC(hipMemcpy(h->d_oct_cells, oct_cells.data(), sizeof(OctCell) * oct_cells.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_oct_children, sizeof(int) * oct_children.size()));
+        HIPC(hipMemcpy(h->d_oct_children, oct_children.data(), sizeof(int) * oct_children.size(), hipMemcpyHostToDevice));
+        P.oct_cells = h->d_oct_cells; P.oct_children = h->d_oct_children;
+    }
     for (int d = 0; d < pr->n_dust; d++) {
         DDust &D = P.dust[d]; const DustOffsets &O = doff[d];
         D.nu = db + O.nu; D.log10_nu = db + O.log10_nu; D.chi = db + O.chi; D.albedo = db + O.albedo;
@@ -481,7 +555,14 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     P.peeled = h->d_peeled;
 
     // density / specific energy: reference layout -> cell-major device layout
-    HIPC(hipMemcpy(h->d_scratch, pr->density, sizeof(double) * ne, hipMemcpyHostToDevice));
+    {
+        std::vector<double> dens(pr->density, pr->density + ne);
+        if (is_oct)   // density is reset to zero in masked (refined) cells: grid_physics_3d.f90:152-160
+            for (int d = 0; d < h->n_dust; d++)
+                for (size_t ic = 0; ic < h->n_cells; ic++)
+                    if (oct_cells[ic].refined) dens[(size_t)d * h->n_cells + ic] = 0.0;
+        HIPC(hipMemcpy(h->d_scratch, dens.data(), sizeof(double) * ne, hipMemcpyHostToDevice));
+    }
     to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_density, h->n_cells, h->n_dust);
     HIPC(hipStreamSynchronize(h->stream));
     // grid_physics_3d.f90:176-253
@@ -596,7 +677,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
 
-    LucyKernel k = pick_lucy_kernel(h->n_dust);
+    LucyKernel k = pick_lucy_kernel(h->n_dust, h->hp.grid_type);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {
@@ -774,7 +855,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     unsigned long long first = first_id;
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {

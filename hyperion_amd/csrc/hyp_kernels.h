@@ -16,15 +16,23 @@
 enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
-template <int NDT>
+enum { GEOM_CAR = 0, GEOM_OCT = 1 };
+
+// Where a packet is: Cartesian = three cell indices; octree = cell id plus a
+// register copy of the leaf's record (centre, level, parent, sub-cell).
+template <int GEOM> struct Cell;
+template <> struct Cell<GEOM_CAR> { int ic[3], ow[3]; };
+template <> struct Cell<GEOM_OCT> { int id, ow[3]; double c[3]; int parent, level, subcell; };
+
+template <int NDT, int GEOM>
 struct Packet {
-    double r[3], v[3], iv[3];   // position, direction, 1/direction
+    double r[3], v[3];          // position, direction
     Angle a;
     double s[4];
     double nu, energy;
     double tau_req, tau_ach;
     double chi[NDT], albedo[NDT], kappa[NDT];
-    int ic[3], ow[3];
+    Cell<GEOM> cell;
     int inter;
 };
 
@@ -50,8 +58,8 @@ __device__ __forceinline__ void raise_error(const DProblem &P, int code, double 
 }
 
 // dust.f90:64-79
-template <int NDT>
-__device__ __forceinline__ bool update_optconsts(const DProblem &P, Packet<NDT> &p)
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool update_optconsts(const DProblem &P, Packet<NDT, GEOM> &p)
 {
     const int nd = ndust<NDT>(P);
     double lnu = log10(p.nu);
@@ -72,24 +80,25 @@ __device__ __forceinline__ bool update_optconsts(const DProblem &P, Packet<NDT> 
     return true;
 }
 
-__device__ __forceinline__ bool escaped(const DProblem &P, const int ic[3])
-{
-    return ic[0] < 0 || ic[0] >= P.n1 || ic[1] < 0 || ic[1] >= P.n2 || ic[2] < 0 || ic[2] >= P.n3;
-}
-
-__device__ __forceinline__ size_t cell_index(const DProblem &P, const int ic[3])
-{
-    return ((size_t)ic[2] * P.n2 + ic[1]) * P.n1 + ic[0];
-}
-
-struct Walls {            // LDS-resident copies of the wall tables
+struct Walls {            // LDS-resident copies of the wall tables (Cartesian)
     const double *w[3];
     const double *ew[3];
     int n[3];
 };
 
+// ----------------------------- Cartesian -----------------------------------
+__device__ __forceinline__ bool geo_escaped(const DProblem &P, const Cell<GEOM_CAR> &c)
+{
+    return c.ic[0] < 0 || c.ic[0] >= P.n1 || c.ic[1] < 0 || c.ic[1] >= P.n2 || c.ic[2] < 0 || c.ic[2] >= P.n3;
+}
+
+__device__ __forceinline__ size_t geo_index(const DProblem &P, const Cell<GEOM_CAR> &c)
+{
+    return ((size_t)c.ic[2] * P.n2 + c.ic[1]) * P.n1 + c.ic[0];
+}
+
 // grid_geometry_cartesian_3d.f90:143-166
-__device__ __forceinline__ bool find_cell(const Walls &W, const double r[3], int ic[3])
+__device__ __forceinline__ bool find_cell_car(const Walls &W, const double r[3], int ic[3])
 {
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -101,74 +110,76 @@ __device__ __forceinline__ bool find_cell(const Walls &W, const double r[3], int
 }
 
 // place_in_cell + adjust_wall, grid_geometry_cartesian_3d.f90:168-253
-__device__ __forceinline__ bool place_in_cell(const Walls &W, const double r[3], const double v[3], int ic[3], int ow[3])
+__device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, const double r[3], const double v[3], Cell<GEOM_CAR> &c)
 {
-    if (!find_cell(W, r, ic)) return false;
+    if (!find_cell_car(W, r, c.ic)) return false;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        ow[a] = 0;
-        int i = ic[a];
+        c.ow[a] = 0;
+        int i = c.ic[a];
         double wl = W.w[a][i], wu = W.w[a][i + 1];
         if (v[a] > 0.0) {
-            if (r[a] == wl) ow[a] = -1;
-            else if (r[a] == wu) { ow[a] = -1; ic[a] = i + 1; }
+            if (r[a] == wl) c.ow[a] = -1;
+            else if (r[a] == wu) { c.ow[a] = -1; c.ic[a] = i + 1; }
         } else if (v[a] < 0.0) {
-            if (r[a] == wl) { ow[a] = +1; ic[a] = i - 1; }
-            else if (r[a] == wu) ow[a] = +1;
+            if (r[a] == wl) { c.ow[a] = +1; c.ic[a] = i - 1; }
+            else if (r[a] == wu) c.ow[a] = +1;
         }
     }
     return true;
 }
 
 // grid_geometry_cartesian_3d.f90:330-381
-__device__ __forceinline__ bool in_correct_cell(const Walls &W, const double r[3], const int ic[3], const int ow[3])
+__device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_CAR> &c)
 {
     int act[3] = {0, 0, 0};
-    bool found = find_cell(W, r, act);
+    bool found = find_cell_car(W, r, act);
     const double thr = 1e-3;
-    if (ow[0] | ow[1] | ow[2]) {
+    if (c.ow[0] | c.ow[1] | c.ow[2]) {
         bool ok = true;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            int i = ic[a];
+            int i = c.ic[a];
             double wl = W.w[a][i], wu = W.w[a][i + 1];
-            if (ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
-            else if (ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
+            if (c.ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
+            else if (c.ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
             else ok = ok && found && act[a] == i;
         }
         return ok;
     }
-    return found && act[0] == ic[0] && act[1] == ic[1] && act[2] == ic[2];
+    return found && act[0] == c.ic[0] && act[1] == c.ic[1] && act[2] == c.ic[2];
 }
 
 // find_wall + insert_t, grid_geometry_cartesian_3d.f90:424-521.  The six
 // candidate distances of the reference are (w - r)/v for the lower and upper
 // wall of each axis, kept only when positive; a quotient is positive exactly
-// when numerator and denominator have the same sign, so the divide is issued
-// only for candidates that can win (normally one per axis), and it is issued as
-// a multiplication by 1/v (refreshed whenever the direction changes): t differs
-// from the reference's quotient by at most 1 ulp.
-__device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], const double v[3], const double iv[3],
-                                          const int ic[3], const int ow[3], double &tnear, int im[3])
+// when numerator and denominator have the same sign, so the (IEEE) divide is
+// issued only for candidates that can win (normally one per axis).  The walk
+// arithmetic is kept bit-identical to the reference formulation (true division,
+// no FMA contraction: the library is built with -ffp-contract=off) because
+// degenerate set-ups -- sources on cell vertices, views along cell diagonals --
+// sit on knife edges that 1-ulp differences tip over.
+__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_CAR> &c, double &tnear, int im[3])
 {
     double tmin = HYP_DBL_MAX, emin = 0.0;
     im[0] = im[1] = im[2] = 0;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        int i = ic[a];
+        int i = c.ic[a];
         double wl = W.w[a][i], wu = W.w[a][i + 1];
         double d1 = wl - r[a], d2 = wu - r[a], va = v[a];
-        bool c1 = (ow[a] != -1) && ((d1 > 0.0 && va > 0.0) || (d1 < 0.0 && va < 0.0));
-        bool c2 = (ow[a] != +1) && ((d2 > 0.0 && va > 0.0) || (d2 < 0.0 && va < 0.0));
+        bool c1 = (c.ow[a] != -1) && ((d1 > 0.0 && va > 0.0) || (d1 < 0.0 && va < 0.0));
+        bool c2 = (c.ow[a] != +1) && ((d2 > 0.0 && va > 0.0) || (d2 < 0.0 && va < 0.0));
         if (c1 || c2) {
-            double t = (c1 ? d1 : d2) * iv[a];
+            double t = (c1 ? d1 : d2) / va;
             double e = W.ew[a][i + (c1 ? 0 : 1)];
             int dir = c1 ? -1 : +1;
             double emax = fmax(e, emin);
             if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = dir; }
             else if (t < tmin + emax) { emin = emax; im[a] = dir; }
             if (c1 && c2) {   // both walls ahead: only after round-off misplacement
-                t = d2 * iv[a]; e = W.ew[a][i + 1];
+                t = d2 / va; e = W.ew[a][i + 1];
                 emax = fmax(e, emin);
                 if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = +1; }
                 else if (t < tmin + emax) { emin = emax; im[a] = +1; }
@@ -179,21 +190,132 @@ __device__ __forceinline__ bool find_wall(const Walls &W, const double r[3], con
     return (im[0] | im[1] | im[2]) != 0;
 }
 
+// next_cell_wall_id :303-328 + opposite_wall
+__device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_CAR> &c, const int im[3])
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) { c.ic[a] += im[a]; c.ow[a] = -im[a]; }
+}
+
+// ------------------------------- octree -------------------------------------
+// grid_geometry_octree.f90.  Cell records are 32 B (centre, parent, sub-cell,
+// level, refined); half-widths are root half-width * 2^-level (exact).
+__device__ __forceinline__ void oct_load(const DProblem &P, int id, Cell<GEOM_OCT> &c)
+{
+    const OctCell &o = P.oct_cells[id];
+    c.id = id; c.c[0] = o.x; c.c[1] = o.y; c.c[2] = o.z;
+    c.parent = o.parent; c.level = o.level; c.subcell = o.subcell;
+}
+
+// locate_cell :135-146: descend from `id` to the leaf containing r
+__device__ __forceinline__ int oct_locate(const DProblem &P, const double r[3], int id)
+{
+    for (;;) {
+        const OctCell &o = P.oct_cells[id];
+        if (!o.refined) return id;
+        int sub = (r[0] < o.x ? 0 : 1) | (r[1] < o.y ? 0 : 2) | (r[2] < o.z ? 0 : 4);
+        id = P.oct_children[8 * (size_t)id + sub];
+    }
+}
+
+__device__ __forceinline__ bool geo_escaped(const DProblem &P, const Cell<GEOM_OCT> &c) { return (unsigned long long)c.id == P.n_cells; }
+__device__ __forceinline__ size_t geo_index(const DProblem &P, const Cell<GEOM_OCT> &c) { return (size_t)c.id; }
+
+// find_cell :260-283 + place_in_cell :285-296 (no wall adjustment in the octree)
+__device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, const double r[3], const double v[3], Cell<GEOM_OCT> &c)
+{
+    if (r[0] < P.oct_box[0] || r[0] > P.oct_box[1] || r[1] < P.oct_box[2] || r[1] > P.oct_box[3] ||
+        r[2] < P.oct_box[4] || r[2] > P.oct_box[5]) return false;
+    oct_load(P, oct_locate(P, r, 0), c);
+    return true;
+}
+
+// :366-392
+__device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_OCT> &c)
+{
+    if (c.ow[0] | c.ow[1] | c.ow[2]) {
+        double f[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) f[a] = fabs(r[a] - c.c[a]) / ldexp(P.oct_half[a], -c.level);
+        double frac = 0.0; bool ok = false;
+        if (c.ow[0] != 0) { frac = f[0] - 1.0; ok = f[1] < 1.0 && f[2] < 1.0; }
+        if (c.ow[1] != 0) { frac = f[1] - 1.0; ok = f[0] < 1.0 && f[2] < 1.0; }
+        if (c.ow[2] != 0) { frac = f[2] - 1.0; ok = f[0] < 1.0 && f[1] < 1.0; }
+        return fabs(frac) < 1e-3 && ok;
+    }
+    bool inside = !(r[0] < P.oct_box[0] || r[0] > P.oct_box[1] || r[1] < P.oct_box[2] || r[1] > P.oct_box[3] ||
+                    r[2] < P.oct_box[4] || r[2] > P.oct_box[5]);
+    return inside && oct_locate(P, r, 0) == c.id;
+}
+
+// find_wall :438-537: nearest of the three faces ahead
+__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_OCT> &c, double &tnear, int im[3])
+{
+    double t[3]; bool pos[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double h = ldexp(P.oct_half[a], -c.level);
+        pos[a] = v[a] > 0.0;
+        if (pos[a]) t[a] = (c.c[a] + h - r[a]) / v[a];
+        else if (v[a] < 0.0) t[a] = (c.c[a] - h - r[a]) / v[a];
+        else t[a] = HYP_DBL_MAX;
+    }
+    im[0] = im[1] = im[2] = 0;
+    int a;
+    if (t[0] < t[2]) a = (t[0] < t[1]) ? 0 : 1;
+    else a = (t[2] < t[1]) ? 2 : 1;
+    double tmin = a == 0 ? t[0] : a == 1 ? t[1] : t[2];
+    bool up = a == 0 ? pos[0] : a == 1 ? pos[1] : pos[2];
+    if (a == 0) im[0] = up ? 1 : -1; else if (a == 1) im[1] = up ? 1 : -1; else im[2] = up ? 1 : -1;
+    if (tmin < 0.0) {
+        if (tmin > -10.0 * P.oct_eps) tmin = 0.0;
+        else { im[0] = im[1] = im[2] = 0; }
+    }
+    tnear = tmin;
+    return (im[0] | im[1] | im[2]) != 0;
+}
+
+// next_cell_int :328-347 (climb until a sibling exists on that side, then
+// descend to the leaf that contains the intersection point) + opposite_wall
+__device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_OCT> &c, const int im[3])
+{
+    const int axis = im[0] ? 0 : im[1] ? 1 : 2;
+    const int up = (im[0] + im[1] + im[2]) > 0 ? 1 : 0;
+    c.ow[0] = -im[0]; c.ow[1] = -im[1]; c.ow[2] = -im[2];
+    int id = c.id, parent = c.parent, sub = c.subcell;
+    for (;;) {
+        if (id == 0) { c.id = (int)P.n_cells; return; }
+        int bit = (sub >> axis) & 1;
+        if (bit != up) {
+            int sib = up ? (sub | (1 << axis)) : (sub & ~(1 << axis));
+            oct_load(P, oct_locate(P, r, P.oct_children[8 * (size_t)parent + sib]), c);
+            return;
+        }
+        id = parent;
+        const OctCell &o = P.oct_cells[id];
+        parent = o.parent; sub = o.subcell;
+    }
+}
+
+template <int GEOM>
+__device__ __forceinline__ void geo_clear_wall(Cell<GEOM> &c) { c.ow[0] = c.ow[1] = c.ow[2] = 0; }
+
 // One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
 // / grid_integrate_noenergy (:237-375).  Returns the lane's next phase;
 // ST_NEED_EMIT means the packet left the grid or was killed.
-template <int NDT, bool DEPOSIT>
-__device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Packet<NDT> &p, Rng &g,
+template <int NDT, int GEOM, bool DEPOSIT>
+__device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
                                          double *__restrict__ sum, Counters &cnt)
 {
     const int nd = ndust<NDT>(P);
     if (g.countdown == 0) {
         g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-        if (!in_correct_cell(W, p.r, p.ic, p.ow)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+        if (!geo_in_correct_cell(P, W, p.r, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }
     } else g.countdown--;
     double tmin; int im[3];
-    if (!find_wall(W, p.r, p.v, p.iv, p.ic, p.ow, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
-    const size_t base = cell_index(P, p.ic) * (size_t)nd;
+    if (!geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+    const size_t base = geo_index(P, p.cell) * (size_t)nd;
     double rho[NDT];
     double chi_rho = 0.0;
 #pragma unroll
@@ -213,15 +335,14 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
             for (int d = 0; d < NDT; d++)
                 if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
         }
-#pragma unroll
-        for (int a = 0; a < 3; a++) { p.ic[a] += im[a]; p.ow[a] = -im[a]; }
-        return escaped(P, p.ic) ? ST_NEED_EMIT : ST_WALK;
+        geo_advance(P, p.r, p.cell, im);
+        return geo_escaped(P, p.cell) ? ST_NEED_EMIT : ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
 #pragma unroll
         for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tact * p.v[a];
         p.tau_ach += tau_needed;
-        p.ow[0] = p.ow[1] = p.ow[2] = 0;
+        geo_clear_wall(p.cell);
         if (DEPOSIT) {
 #pragma unroll
             for (int d = 0; d < NDT; d++)
@@ -244,8 +365,8 @@ __device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
 
 // emit: source.f90:100-179 + source_emit/emit_from_point source_type.f90:398-564.
 // Returns false on a fatal error (flag raised).
-template <int NDT>
-__device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT> &p, Rng &g,
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
                                             Counters &cnt, int &source_id)
 {
     int is = 0;
@@ -266,12 +387,12 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
-    p.iv[0] = 1.0 / p.v[0]; p.iv[1] = 1.0 / p.v[1]; p.iv[2] = 1.0 / p.v[2];
     if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
     cnt.energy_current += p.energy;
-    if (!update_optconsts<NDT>(P, p)) return false;
+    if (!update_optconsts<NDT, GEOM>(P, p)) return false;
     g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-    if (!place_in_cell(W, p.r, p.v, p.ic, p.ow)) {
+    geo_clear_wall(p.cell);
+    if (!geo_place(P, W, p.r, p.v, p.cell)) {
         cnt.killed_geo++;
         raise_error(P, ERR_NOT_IN_CELL, p.r[0], p.r[1], p.r[2]);
         return false;
@@ -344,12 +465,12 @@ __device__ __forceinline__ void dust_scatter(const DDust &D, double nu, Angle &a
 
 // interact: dust_interact.f90:22-79 (+ select_dust_chi_rho grid_physics_3d.f90:87-99).
 // Returns false on a fatal error.  `scattered`/`dust_id` report what happened.
-template <int NDT>
-__device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT> &p, Rng &g, Counters &cnt,
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt,
                                          int &scattered, int &dust_id)
 {
     const int nd = ndust<NDT>(P);
-    const size_t base = cell_index(P, p.ic) * (size_t)nd;
+    const size_t base = geo_index(P, p.cell) * (size_t)nd;
     int id = 0;
     double albedo = p.albedo[0];
     if (NDT > 1 && nd > 1) {
@@ -379,13 +500,12 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT> &p, Rng 
         p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
         random_sphere_angle(g, p.a);
         scattered = 0;
-        if (!update_optconsts<NDT>(P, p)) return false;
+        if (!update_optconsts<NDT, GEOM>(P, p)) return false;
     } else {
         dust_scatter(P.dust[id], p.nu, p.a, p.s, g);
         scattered = 1;
     }
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
-    p.iv[0] = 1.0 / p.v[0]; p.iv[1] = 1.0 / p.v[1]; p.iv[2] = 1.0 / p.v[2];
     return true;
 }
 
@@ -437,22 +557,11 @@ __device__ __forceinline__ bool take_id(const DProblem &P, const LaunchParams &L
     return got;
 }
 
-// ---------------------------------------------------------------------------
-// Lucy iteration: do_lucy packet loop, iter_lucy.f90:119-209
-// ---------------------------------------------------------------------------
-#ifndef HYP_LUCY_WAVES
-#define HYP_LUCY_WAVES 2
-#endif
-#ifndef HYP_WALK_STEPS
-#define HYP_WALK_STEPS 4
-#endif
-template <int NDT>
-__global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+// Copies the Cartesian wall tables into LDS (nothing to stage for the octree).
+template <int GEOM>
+__device__ __forceinline__ void stage_walls(const DProblem &P, double *lds, Walls &W)
 {
-    extern __shared__ double lds[];
-    const DProblem &P = *Pp;
-    Walls W;
-    {
+    if (GEOM == GEOM_CAR) {
         const int m1 = P.n1 + 1, m2 = P.n2 + 1, m3 = P.n3 + 1;
         double *w0 = lds, *w1 = w0 + m1, *w2 = w1 + m2;
         double *e0 = w2 + m3, *e1 = e0 + m1, *e2 = e1 + m2;
@@ -462,7 +571,28 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
         W.w[0] = w0; W.w[1] = w1; W.w[2] = w2; W.ew[0] = e0; W.ew[1] = e1; W.ew[2] = e2;
         W.n[0] = P.n1; W.n[1] = P.n2; W.n[2] = P.n3;
         __syncthreads();
+    } else {
+        W.w[0] = W.w[1] = W.w[2] = nullptr; W.ew[0] = W.ew[1] = W.ew[2] = nullptr;
+        W.n[0] = W.n[1] = W.n[2] = 0;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Lucy iteration: do_lucy packet loop, iter_lucy.f90:119-209
+// ---------------------------------------------------------------------------
+#ifndef HYP_LUCY_WAVES
+#define HYP_LUCY_WAVES 2
+#endif
+#ifndef HYP_WALK_STEPS
+#define HYP_WALK_STEPS 4
+#endif
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
     double *sum = P.sum;
     // accumulator replica of this workgroup: replicas are spread first over the
     // XCDs (no line is shared between two L2s), then over workgroups of an XCD
@@ -477,7 +607,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
     constexpr bool kDeposit = true;
 #endif
 
-    Packet<NDT> p;
+    Packet<NDT, GEOM> p;
     Rng g;
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
@@ -500,7 +630,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     cnt.killed_int++; st = ST_NEED_EMIT;
                 } else {
                     int scattered, dust_id;
-                    bool ok = interact<NDT>(P, p, g, cnt, scattered, dust_id);
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id);
                     bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                     if (killed) st = ST_NEED_EMIT;
                     else {
@@ -523,9 +653,9 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                 else {
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id;
-                    bool ok = emit_packet<NDT>(P, W, p, g, cnt, source_id);
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id);
                     if (!ok) st = ST_NEED_EMIT;
-                    else if (escaped(P, p.ic)) st = ST_NEED_EMIT;
+                    else if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
@@ -541,7 +671,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
         // ---- walk phase: a few cell crossings per outer iteration ----
 #pragma unroll 1
         for (int k = 0; k < HYP_WALK_STEPS; k++) {
-            if (st == ST_WALK) st = walk_step<NDT, kDeposit>(P, W, p, g, sum, cnt);
+            if (st == ST_WALK) st = walk_step<NDT, GEOM, kDeposit>(P, W, p, g, sum, cnt);
         }
     }
 
@@ -567,33 +697,32 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 
 // grid_escape_tau: grid_propagate_3d.f90:377-480 -- optical depth from (r, ic, ow)
 // along v to the edge of the grid (external observers: tmax = huge).
-template <int NDT>
+template <int NDT, int GEOM>
 __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
-                                             const double iv[3], const int ic0[3], const int ow0[3],
+                                             const Cell<GEOM> &cell0,
                                              const double chi[NDT], Rng &g, Counters &cnt, bool &killed)
 {
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
-    int ic[3] = {ic0[0], ic0[1], ic0[2]}, ow[3] = {ow0[0], ow0[1], ow0[2]};
+    Cell<GEOM> c = cell0;
     double tau = 0.0;
     killed = false;
-    if (escaped(P, ic)) return 0.0;
+    if (geo_escaped(P, c)) return 0.0;
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-            if (!in_correct_cell(W, r, ic, ow)) { cnt.killed_geo++; killed = true; return tau; }
+            if (!geo_in_correct_cell(P, W, r, c)) { cnt.killed_geo++; killed = true; return tau; }
         } else g.countdown--;
         double tmin; int im[3];
-        if (!find_wall(W, r, v, iv, ic, ow, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
-        const size_t base = cell_index(P, ic) * (size_t)nd;
+        if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
+        const size_t base = geo_index(P, c) * (size_t)nd;
 #pragma unroll
         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
         for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * P.density[base + d] * tmin;
         cnt.crossings++;
-#pragma unroll
-        for (int a = 0; a < 3; a++) { ic[a] += im[a]; ow[a] = -im[a]; }
-        if (escaped(P, ic)) return tau;
+        geo_advance(P, r, c, im);
+        if (geo_escaped(P, c)) return tau;
     }
 }
 
@@ -656,8 +785,8 @@ __device__ __forceinline__ void image_bin(const DProblem &P, const DPeeled &G, d
 }
 
 // peeloff_photon, external observers: images_peeled.f90:95-270
-template <int NDT>
-__device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT> &p, const Angle &a_prev,
+template <int NDT, int GEOM>
+__device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, const Angle &a_prev,
                                         const double s_prev[4], int last, bool last_isotropic, const PeelFlags &f,
                                         Rng &g, Counters &cnt)
 {
@@ -684,11 +813,11 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                     scatter_stokes(s, a_prev, a_scat, a_req, P1, P2, P3, P4);
                 }
             }
-            double v[3], iv3[3];
+            double v[3];
             angle_to_vector(a_req, v[0], v[1], v[2]);
-            iv3[0] = 1.0 / v[0]; iv3[1] = 1.0 / v[1]; iv3[2] = 1.0 / v[2];
-            int ic[3], ow[3];
-            if (!place_in_cell(W, p.r, v, ic, ow)) { cnt.killed_geo++; continue; }
+            // the copy keeps the packet's wall flags; Cartesian place_in_cell resets them
+            Cell<GEOM> c = p.cell;
+            if (!geo_place(P, W, p.r, v, c)) { cnt.killed_geo++; continue; }
             double d = -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
             if (d < G.d_min || d > G.d_max) continue;
             double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
@@ -701,7 +830,7 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
             if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
             if (!inside) continue;
             double tau = 0.0; bool killed = false;
-            if (!G.ignore_optical_depth) tau = escape_tau<NDT>(P, W, p.r, v, iv3, ic, ow, p.chi, g, cnt, killed);
+            if (!G.ignore_optical_depth) tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed);
             if (killed) continue;
             double att = exp(-tau);
             s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
@@ -729,24 +858,14 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
     }
 }
 
-template <int NDT>
+template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
     Walls W;
-    {
-        const int m1 = P.n1 + 1, m2 = P.n2 + 1, m3 = P.n3 + 1;
-        double *w0 = lds, *w1 = w0 + m1, *w2 = w1 + m2;
-        double *e0 = w2 + m3, *e1 = e0 + m1, *e2 = e1 + m2;
-        for (int i = threadIdx.x; i < m1; i += blockDim.x) { w0[i] = P.w[0][i]; e0[i] = P.ew[0][i]; }
-        for (int i = threadIdx.x; i < m2; i += blockDim.x) { w1[i] = P.w[1][i]; e1[i] = P.ew[1][i]; }
-        for (int i = threadIdx.x; i < m3; i += blockDim.x) { w2[i] = P.w[2][i]; e2[i] = P.ew[2][i]; }
-        W.w[0] = w0; W.w[1] = w1; W.w[2] = w2; W.ew[0] = e0; W.ew[1] = e1; W.ew[2] = e2;
-        W.n[0] = P.n1; W.n[1] = P.n2; W.n[2] = P.n3;
-        __syncthreads();
-    }
-    Packet<NDT> p;
+    stage_walls<GEOM>(P, lds, W);
+    Packet<NDT, GEOM> p;
     Rng g;
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
@@ -776,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                 } else {
                     a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
                     int scattered, dust_id;
-                    bool ok = interact<NDT>(P, p, g, cnt, scattered, dust_id);
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id);
                     f.dust_id = dust_id;
                     if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
                     else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
@@ -797,7 +916,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                 else {
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
-                    bool ok = emit_packet<NDT>(P, W, p, g, cnt, source_id);
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id);
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else { peel = 1; last = LAST_SR; last_iso = true; st = ST_DONE + 1; /* placed, awaiting tau */ }
@@ -812,15 +931,15 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
         // ---- peel-off + optical depth sampling for lanes that just emitted / interacted ----
         if (__ballot(peel != 0)) {
             if (peel != 0) {
-                if (P.n_peeled > 0) peeloff<NDT>(P, W, p, a_prev, s_prev, last, last_iso, f, g, cnt);
+                if (P.n_peeled > 0) peeloff<NDT, GEOM>(P, W, p, a_prev, s_prev, last, last_iso, f, g, cnt);
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
-                    if (escaped(P, p.ic)) st = ST_NEED_EMIT;
+                    if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
                         bool sampled = false;
                         if (P.forced_first) {
                             bool killed = false;
-                            double tau_escape = escape_tau<NDT>(P, W, p.r, p.v, p.iv, p.ic, p.ow, p.chi, g, cnt, killed);
+                            double tau_escape = escape_tau<NDT, GEOM>(P, W, p.r, p.v, p.cell, p.chi, g, cnt, killed);
                             if (tau_escape > 1e-10 && !killed) {
                                 double weight, tau;
                                 forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
@@ -840,7 +959,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
 
 #pragma unroll 1
         for (int k = 0; k < HYP_WALK_STEPS; k++) {
-            if (st == ST_WALK) st = walk_step<NDT, false>(P, W, p, g, nullptr, cnt);
+            if (st == ST_WALK) st = walk_step<NDT, GEOM, false>(P, W, p, g, nullptr, cnt);
         }
     }
 
@@ -942,10 +1061,16 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
         size_t ic = k / nd;
         int d = (int)(k - ic * nd);
-        int i1 = (int)(ic % P.n1);
-        size_t t = ic / P.n1;
-        int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
-        double vol = (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
+        double vol;
+        if (P.grid_type == 2) {
+            int lev = P.oct_cells[ic].level;
+            vol = ldexp(P.oct_half[0], -lev) * ldexp(P.oct_half[1], -lev) * ldexp(P.oct_half[2], -lev) * 8.0;
+        } else {
+            int i1 = (int)(ic % P.n1);
+            size_t t = ic / P.n1;
+            int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
+            vol = (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
+        }
         const DDust &D = P.dust[d];
         double e;
         if (mode == 0) {

@@ -162,8 +162,12 @@ class RunConfig:
 
 @dataclass
 class Problem:
-    walls: List[np.ndarray]               # [x(n1+1), y(n2+1), z(n3+1)]
-    density: np.ndarray                   # (n_dust, n3, n2, n1)
+    """grid_type 'car': `walls` = [x(n1+1), y(n2+1), z(n3+1)], density
+    (n_dust, n3, n2, n1).  grid_type 'oct': `refined` (depth-first flags of all
+    cells), `oct_center`, `oct_half` (half-widths of the top cell), density
+    (n_dust, n_cells) -- src/grid/grid_geometry_octree.f90:184-246."""
+    walls: List[np.ndarray]
+    density: np.ndarray
     dust: List[Dust]
     sources: List[Source]
     config: RunConfig = field(default_factory=RunConfig)
@@ -171,16 +175,29 @@ class Problem:
     specific_energy: Optional[np.ndarray] = None
     grid_type: str = "car"
     geometry_id: str = ""
+    refined: Optional[np.ndarray] = None
+    oct_center: tuple = (0.0, 0.0, 0.0)
+    oct_half: tuple = (1.0, 1.0, 1.0)
 
     def __post_init__(self):
         self.walls = [_f64(w) for w in self.walls]
         self.density = _f64(self.density)
-        if self.density.ndim == 3:
-            self.density = self.density[None]
-        n1, n2, n3 = self.shape
-        if self.density.shape != (len(self.dust), n3, n2, n1):
-            raise ValueError("density array has wrong shape %r, expected %r"
-                             % (self.density.shape, (len(self.dust), n3, n2, n1)))
+        if self.grid_type == "car":
+            if self.density.ndim == 3:
+                self.density = self.density[None]
+            n1, n2, n3 = self.shape
+            want = (len(self.dust), n3, n2, n1)
+        elif self.grid_type == "oct":
+            self.refined = np.ascontiguousarray(np.asarray(self.refined).astype(np.int32))
+            if self.refined.ndim != 1 or (self.refined.size - 1) % 8 != 0:
+                raise ValueError("refined should have shape 8 * n + 1")
+            if self.density.ndim == 1:
+                self.density = self.density[None]
+            want = (len(self.dust), self.refined.size)
+        else:
+            raise ValueError("Unexpected coordinate type: %s" % self.grid_type)
+        if self.density.shape != want:
+            raise ValueError("density array has wrong shape %r, expected %r" % (self.density.shape, want))
         if self.specific_energy is not None:
             self.specific_energy = _f64(self.specific_energy)
             if self.specific_energy.shape != self.density.shape:
@@ -188,39 +205,80 @@ class Problem:
 
     @property
     def shape(self):
+        if self.grid_type == "oct":
+            return (self.refined.size,)
         return tuple(w.size - 1 for w in self.walls)
 
     @property
     def n_cells(self):
-        n1, n2, n3 = self.shape
-        return n1 * n2 * n3
+        return int(np.prod(self.shape))
 
     @property
     def n_dust(self):
         return len(self.dust)
 
+    def octree_cells(self):
+        """(centres (n,3), half-widths (n,3), level (n,)) of every octree cell in
+        file order (pre-order depth-first, children x-fastest)."""
+        n = self.refined.size
+        c = np.zeros((n, 3)); h = np.zeros((n, 3)); lev = np.zeros(n, dtype=np.int32)
+        c[0] = self.oct_center; h[0] = self.oct_half
+        stack = [[0, 0]] if self.refined[0] else []
+        filled = 1
+        while stack:
+            par, k = stack[-1]
+            if k == 8:
+                stack.pop(); continue
+            stack[-1][1] = k + 1
+            i = filled; filled += 1
+            s = np.array([1 if k & 1 else -1, 1 if k & 2 else -1, 1 if k & 4 else -1])
+            c[i] = c[par] + s * h[par] / 2.0
+            h[i] = h[par] / 2.0
+            lev[i] = lev[par] + 1
+            if self.refined[i]:
+                stack.append([i, 0])
+        if filled != n:
+            raise ValueError("refined array is not self-consistent")
+        return c, h, lev
+
     @property
     def volumes(self):
+        if self.grid_type == "oct":
+            _, h, _ = self.octree_cells()
+            return 8.0 * h[:, 0] * h[:, 1] * h[:, 2]
         dx, dy, dz = (np.diff(w) for w in self.walls)
         return dz[:, None, None] * dy[None, :, None] * dx[None, None, :]
 
     # ---------------------------------------------------------------- npz I/O
-    def to_npz(self, path):
+    def to_npz(self, path, dust_library=None):
+        """dust_library: optional {filename: Dust}; a species whose tables equal a
+        library entry is stored as a reference to that sibling .npz file."""
         arrays = {}
         meta = {"grid_type": self.grid_type, "geometry_id": self.geometry_id,
-                "config": self.config.__dict__, "dust": [], "sources": [], "peeled": []}
+                "config": self.config.__dict__, "dust": [], "sources": [], "peeled": [],
+                "oct_center": list(self.oct_center), "oct_half": list(self.oct_half)}
         for i, w in enumerate(self.walls):
             arrays["walls_%d" % (i + 1)] = w
+        if self.refined is not None:
+            arrays["refined"] = self.refined
         arrays["density"] = self.density
         if self.specific_energy is not None:
             arrays["specific_energy"] = self.specific_energy
         for i, d in enumerate(self.dust):
             m = {}
+            ref = None
+            for fname, lib in (dust_library or {}).items():
+                if all(np.array_equal(getattr(d, k), getattr(lib, k)) for k in
+                       ("nu", "chi", "albedo", "mu", "P1", "P2", "P3", "P4", "emiss_nu", "emiss_jnu", "emiss_var")):
+                    ref = fname
             for k, v in d.__dict__.items():
                 if isinstance(v, np.ndarray):
-                    arrays["dust%d/%s" % (i, k)] = v
+                    if ref is None:
+                        arrays["dust%d/%s" % (i, k)] = v
                 elif v is not None:
                     m[k] = v
+            if ref is not None:
+                m["__tables_from__"] = ref
             meta["dust"].append(m)
         for i, s in enumerate(self.sources):
             m = {}
@@ -252,6 +310,11 @@ class Problem:
         dust = []
         for i, m in enumerate(meta["dust"]):
             kw = dict(m)
+            ref = kw.pop("__tables_from__", None)
+            if ref is not None:
+                import os
+                lib = np.load(os.path.join(os.path.dirname(os.path.abspath(path)), ref), allow_pickle=False)
+                kw.update({k: lib[k] for k in lib.files if k not in ("version",)})
             kw.update(sub("dust%d/" % i))
             dust.append(Dust(**kw))
         sources = []
@@ -272,7 +335,11 @@ class Problem:
                 kw["peeloff_origin"] = tuple(kw["peeloff_origin"])
             peeled.append(PeeledImages(**kw))
         cfg = RunConfig(**meta["config"])
-        return cls(walls=[z["walls_1"], z["walls_2"], z["walls_3"]], density=z["density"],
+        walls = [z[k] for k in ("walls_1", "walls_2", "walls_3") if k in z.files]
+        return cls(walls=walls, density=z["density"],
                    dust=dust, sources=sources, config=cfg, peeled=peeled,
                    specific_energy=z["specific_energy"] if "specific_energy" in z.files else None,
-                   grid_type=meta.get("grid_type", "car"), geometry_id=meta.get("geometry_id", ""))
+                   grid_type=meta.get("grid_type", "car"), geometry_id=meta.get("geometry_id", ""),
+                   refined=z["refined"] if "refined" in z.files else None,
+                   oct_center=tuple(meta.get("oct_center", (0.0, 0.0, 0.0))),
+                   oct_half=tuple(meta.get("oct_half", (1.0, 1.0, 1.0))))

@@ -95,9 +95,17 @@ def read_rtin(path):
 
         geo = f["Grid/Geometry"]
         grid_type = _s(geo.attrs["grid_type"]).strip()
-        if grid_type != "car":
+        extra = {}
+        if grid_type == "car":
+            walls = [geo["walls_1"][...]["x"], geo["walls_2"][...]["y"], geo["walls_3"][...]["z"]]
+        elif grid_type == "oct":
+            walls = []
+            ga = geo.attrs
+            extra = dict(refined=np.asarray(geo["cells"][...]["refined"]).astype(np.int32),
+                         oct_center=(float(ga["x"]), float(ga["y"]), float(ga["z"])),
+                         oct_half=(float(ga["dx"]), float(ga["dy"]), float(ga["dz"])))
+        else:
             raise NotImplementedError("grid type %r is not supported yet" % grid_type)
-        walls = [geo["walls_1"][...]["x"], geo["walls_2"][...]["y"], geo["walls_3"][...]["z"]]
         q = f["Grid/Quantities"]
         density = q["density"][...]
         spec = q["specific_energy"][...] if "specific_energy" in q else None
@@ -167,4 +175,4 @@ def read_rtin(path):
 
         return Problem(walls=walls, density=density, dust=dust, sources=sources, config=cfg,
                        peeled=peeled, specific_energy=spec, grid_type=grid_type,
-                       geometry_id=_s(geo.attrs["geometry"]))
+                       geometry_id=_s(geo.attrs["geometry"]), **extra)

@@ -72,13 +72,18 @@ typedef struct hyp_source_desc {
     const double *spec_fnu;
 } hyp_source_desc;
 
-/* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 */
+/* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),
+ * src/grid/grid_geometry_octree.f90:184-246 (type 2) */
 typedef struct hyp_grid_desc {
-    int32_t type;          /* 1 cartesian */
-    int32_t n1, n2, n3;
-    const double *w1;      /* [n1+1] */
+    int32_t type;          /* 1 cartesian, 2 octree */
+    int32_t n1, n2, n3;    /* cartesian: cells per axis */
+    const double *w1;      /* cartesian: [n1+1] walls */
     const double *w2;
     const double *w3;
+    int64_t n_cells;       /* octree: number of cells, refined ones included */
+    const int32_t *refined;/* octree: [n_cells] depth-first refinement flags (table `cells`) */
+    double oct_center[3];  /* octree: attrs x, y, z of the top cell */
+    double oct_half[3];    /* octree: attrs dx, dy, dz (half-widths) */
 } hyp_grid_desc;
 
 /* root attributes -- src/main/setup_rt.f90:38-302 */
@@ -133,7 +138,7 @@ typedef struct hyp_problem {
     const hyp_dust_desc   *dust;
     const hyp_source_desc *sources;
     const hyp_peeled_desc *peeled;
-    const double *density;           /* [n_dust][n3][n2][n1] as in the .rtin */
+    const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree), as in the .rtin */
     const double *specific_energy;   /* same shape, or NULL */
 } hyp_problem;
 

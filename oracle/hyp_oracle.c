@@ -350,10 +350,18 @@ typedef struct {
     size_t sed_size, img_size;
 } peeled_t;
 
+enum { GRID_CAR = 1, GRID_OCT = 2 };
+
 struct orc_state {
     char err[512];
+    int grid_type;
     int n1, n2, n3;
     size_t n_cells;
+    /* octree: type_grid_octree.f90:14-22 (0-based ids; -1 = none) */
+    double *ox, *oy, *oz, *odx, *ody, *odz;
+    uint8_t *orefined; int8_t *osubcell;
+    int32_t *oparent, *ochildren;   /* ochildren[8*id + k] */
+    double oct_eps, obox[6];
     double *w[3], *ew[3];
     int n[3];
     double *volume;
@@ -586,35 +594,93 @@ static double spacing(double x)
 static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in);
 static void peeled_free(peeled_t *p);
 
+/* setup_grid_geometry + octree_setup_indiv: grid_geometry_octree.f90:147-246.
+ * Cells are numbered depth-first (pre-order) as the `refined` list is read. */
+static int octree_setup(orc_state *st, const orc_grid_desc *gd)
+{
+    size_t n = (size_t)gd->n_cells;
+    if (n < 1 || !gd->refined) { snprintf(g_error, sizeof g_error, "octree needs a refined list"); return 1; }
+    st->n_cells = n;
+    st->ox = malloc(sizeof(double) * n); st->oy = malloc(sizeof(double) * n); st->oz = malloc(sizeof(double) * n);
+    st->odx = malloc(sizeof(double) * n); st->ody = malloc(sizeof(double) * n); st->odz = malloc(sizeof(double) * n);
+    st->orefined = malloc(n); st->osubcell = malloc(n);
+    st->oparent = malloc(sizeof(int32_t) * n); st->ochildren = malloc(sizeof(int32_t) * 8 * n);
+    for (size_t i = 0; i < n; i++) { st->orefined[i] = gd->refined[i] == 1; st->oparent[i] = -1; st->osubcell[i] = -1; }
+    for (size_t i = 0; i < 8 * n; i++) st->ochildren[i] = -1;
+    st->ox[0] = gd->oct_center[0]; st->oy[0] = gd->oct_center[1]; st->oz[0] = gd->oct_center[2];
+    st->odx[0] = gd->oct_half[0]; st->ody[0] = gd->oct_half[1]; st->odz[0] = gd->oct_half[2];
+    /* explicit stack of (parent, next child slot) reproducing the recursion order */
+    int32_t *stack_p = malloc(sizeof(int32_t) * 64); int *stack_k = malloc(sizeof(int) * 64);
+    int depth = 0; size_t filled = 1;
+    if (st->orefined[0]) { stack_p[0] = 0; stack_k[0] = 0; depth = 1; }
+    while (depth > 0) {
+        int32_t par = stack_p[depth - 1]; int k = stack_k[depth - 1];
+        if (k == 8) { depth--; continue; }
+        stack_k[depth - 1] = k + 1;
+        if (filled >= n) { snprintf(g_error, sizeof g_error, "refined array is not self-consistent"); free(stack_p); free(stack_k); return 1; }
+        int32_t c = (int32_t)filled++;
+        st->ochildren[8 * (size_t)par + k] = c;
+        int sx = (k & 1) ? 1 : -1, sy = (k & 2) ? 1 : -1, sz = (k & 4) ? 1 : -1;
+        st->ox[c] = st->ox[par] + sx * st->odx[par] / 2.0;
+        st->oy[c] = st->oy[par] + sy * st->ody[par] / 2.0;
+        st->oz[c] = st->oz[par] + sz * st->odz[par] / 2.0;
+        st->odx[c] = st->odx[par] / 2.0; st->ody[c] = st->ody[par] / 2.0; st->odz[c] = st->odz[par] / 2.0;
+        st->oparent[c] = par; st->osubcell[c] = (int8_t)k;
+        if (st->orefined[c]) {
+            if (depth >= 63) { snprintf(g_error, sizeof g_error, "octree too deep"); free(stack_p); free(stack_k); return 1; }
+            stack_p[depth] = c; stack_k[depth] = 0; depth++;
+        }
+    }
+    free(stack_p); free(stack_k);
+    if (filled != n) { snprintf(g_error, sizeof g_error, "refined array is not self-consistent"); return 1; }
+    st->volume = malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; i++) {
+        st->volume[i] = st->odx[i] * st->ody[i] * st->odz[i] * 8.0;
+        if (st->volume[i] == 0.0) { snprintf(g_error, sizeof g_error, "all volumes should be greater than zero"); return 1; }
+    }
+    st->obox[0] = st->ox[0] - st->odx[0]; st->obox[1] = st->ox[0] + st->odx[0];
+    st->obox[2] = st->oy[0] - st->ody[0]; st->obox[3] = st->oy[0] + st->ody[0];
+    st->obox[4] = st->oz[0] - st->odz[0]; st->obox[5] = st->oz[0] + st->odz[0];
+    double m = st->odx[0] > st->ody[0] ? st->odx[0] : st->ody[0];
+    if (st->odz[0] > m) m = st->odz[0];
+    st->oct_eps = spacing(m) * 3.0;
+    return 0;
+}
+
 int orc_create(const orc_problem *pr, orc_state **out)
 {
     g_error[0] = 0;
     if (!pr || !out) { snprintf(g_error, sizeof g_error, "null argument"); return 1; }
-    if (pr->grid.type != 1) { snprintf(g_error, sizeof g_error, "grid is not cartesian"); return 1; }
+    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
+    st->grid_type = pr->grid.type;
     st->check_p = pr->config.propagation_check_frequency;
     st->check_log1mp = (st->check_p > 0.0 && st->check_p < 1.0) ? log1p(-st->check_p) : -1.0;
-    st->n1 = pr->grid.n1; st->n2 = pr->grid.n2; st->n3 = pr->grid.n3;
-    st->n[0] = st->n1; st->n[1] = st->n2; st->n[2] = st->n3;
-    st->n_cells = (size_t)st->n1 * st->n2 * st->n3;
-    const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
-    for (int a = 0; a < 3; a++) {
-        st->w[a] = dup(win[a], st->n[a] + 1);
-        st->ew[a] = malloc(sizeof(double) * (st->n[a] + 1));
-        /* grid_geometry_cartesian_3d.f90:130-132: ew = 3*spacing(w) */
-        for (int i = 0; i <= st->n[a]; i++) st->ew[a][i] = 3.0 * spacing(st->w[a][i]);
-        for (int i = 0; i < st->n[a]; i++)
-            if (!(st->w[a][i + 1] - st->w[a][i] > 0.0)) {
-                snprintf(g_error, sizeof g_error, "all d%c values should be greater than zero", "xyz"[a]);
-                orc_destroy(st); return 1;
-            }
+    if (st->grid_type == GRID_CAR) {
+        st->n1 = pr->grid.n1; st->n2 = pr->grid.n2; st->n3 = pr->grid.n3;
+        st->n[0] = st->n1; st->n[1] = st->n2; st->n[2] = st->n3;
+        st->n_cells = (size_t)st->n1 * st->n2 * st->n3;
+        const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
+        for (int a = 0; a < 3; a++) {
+            st->w[a] = dup(win[a], st->n[a] + 1);
+            st->ew[a] = malloc(sizeof(double) * (st->n[a] + 1));
+            /* grid_geometry_cartesian_3d.f90:130-132: ew = 3*spacing(w) */
+            for (int i = 0; i <= st->n[a]; i++) st->ew[a][i] = 3.0 * spacing(st->w[a][i]);
+            for (int i = 0; i < st->n[a]; i++)
+                if (!(st->w[a][i + 1] - st->w[a][i] > 0.0)) {
+                    snprintf(g_error, sizeof g_error, "all d%c values should be greater than zero", "xyz"[a]);
+                    orc_destroy(st); return 1;
+                }
+        }
+        st->volume = malloc(sizeof(double) * st->n_cells);
+        for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++)
+            st->volume[((size_t)k * st->n2 + j) * st->n1 + i] =
+                (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
+    } else {
+        if (octree_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     }
-    st->volume = malloc(sizeof(double) * st->n_cells);
-    for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++)
-        st->volume[((size_t)k * st->n2 + j) * st->n1 + i] =
-            (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
 
     st->n_dust = pr->n_dust;
     st->dust = calloc(st->n_dust ? st->n_dust : 1, sizeof(dust_t));
@@ -659,6 +725,10 @@ int orc_create(const orc_problem *pr, orc_state **out)
 
     size_t ntot = (size_t)st->n_dust * st->n_cells;
     st->density = dup(pr->density, ntot);
+    if (st->grid_type == GRID_OCT)   /* reset density to zero in masked (refined) cells: grid_physics_3d.f90:152-160 */
+        for (int d = 0; d < st->n_dust; d++)
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                if (st->orefined[ic]) st->density[(size_t)d * st->n_cells + ic] = 0.0;
     st->specific_energy = malloc(sizeof(double) * (ntot ? ntot : 1));
     st->specific_energy_sum = calloc(ntot ? ntot : 1, sizeof(double));
     st->jnu_var_id = calloc(ntot ? ntot : 1, sizeof(int32_t));
@@ -696,6 +766,8 @@ void orc_destroy(orc_state *st)
     if (!st) return;
     for (int a = 0; a < 3; a++) { free(st->w[a]); free(st->ew[a]); }
     free(st->volume);
+    free(st->ox); free(st->oy); free(st->oz); free(st->odx); free(st->ody); free(st->odz);
+    free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
@@ -764,18 +836,59 @@ static int update_optconsts(const orc_state *st, photon_t *p, acc_t *acc)
 
 static inline size_t cell_index(const orc_state *st, const int ic[3])
 {
+    if (st->grid_type == GRID_OCT) return (size_t)ic[0];
     return ((size_t)ic[2] * st->n2 + ic[1]) * st->n1 + ic[0];
 }
 
 /* escaped_cell :267-275 */
 static inline int escaped(const orc_state *st, const int ic[3])
 {
+    /* octree: escaped_cell grid_geometry_octree.f90:320-326 (ic == n_cells+1) */
+    if (st->grid_type == GRID_OCT) return (size_t)ic[0] == st->n_cells;
     return ic[0] < 0 || ic[0] >= st->n1 || ic[1] < 0 || ic[1] >= st->n2 || ic[2] < 0 || ic[2] >= st->n3;
 }
 
-/* find_cell :143-166 ; returns 0 if outside */
+/* ---- octree: grid_geometry_octree.f90 ---------------------------------- */
+
+/* subcell_id :101-133 (0-based: bit0 = x, bit1 = y, bit2 = z) */
+static inline int oct_subcell(const orc_state *st, int32_t id, const double r[3])
+{
+    return (r[0] < st->ox[id] ? 0 : 1) | (r[1] < st->oy[id] ? 0 : 2) | (r[2] < st->oz[id] ? 0 : 4);
+}
+
+/* locate_cell :135-146 */
+static int32_t oct_locate(const orc_state *st, const double r[3], int32_t id)
+{
+    while (st->orefined[id]) id = st->ochildren[8 * (size_t)id + oct_subcell(st, id, r)];
+    return id;
+}
+
+/* next_cell_int :328-347: wall 0..5 = -x,+x,-y,+y,-z,+z; opposite_cell table :53-59 */
+static int32_t oct_next_cell(const orc_state *st, int32_t id, int wall, const double r[3])
+{
+    for (;;) {
+        if (id == 0) return (int32_t)st->n_cells;
+        int sub = st->osubcell[id], axis = wall >> 1, up = wall & 1;
+        int bit = (sub >> axis) & 1;
+        int32_t par = st->oparent[id];
+        if (bit != up) {   /* the sibling on that side exists inside the parent */
+            int sib = up ? (sub | (1 << axis)) : (sub & ~(1 << axis));
+            return oct_locate(st, r, st->ochildren[8 * (size_t)par + sib]);
+        }
+        id = par;
+    }
+}
+
+/* find_cell :143-166 (car) / :260-283 (oct); returns 0 if outside */
 static int find_cell(const orc_state *st, const double r[3], int ic[3])
 {
+    if (st->grid_type == GRID_OCT) {
+        if (r[0] < st->obox[0] || r[0] > st->obox[1]) return 0;
+        if (r[1] < st->obox[2] || r[1] > st->obox[3]) return 0;
+        if (r[2] < st->obox[4] || r[2] > st->obox[5]) return 0;
+        ic[0] = oct_locate(st, r, 0); ic[1] = ic[2] = 0;
+        return 1;
+    }
     for (int a = 0; a < 3; a++) {
         int i = locate(st->w[a], st->n[a] + 1, r[a]);
         if (i < 0 || i >= st->n[a]) return 0;
@@ -808,7 +921,7 @@ static void place_in_cell(const orc_state *st, photon_t *p, acc_t *acc)
         acc->killed_geo++; p->killed = 1;
     } else {
         p->in_cell = 1;
-        adjust_wall(st, p);
+        if (st->grid_type == GRID_CAR) adjust_wall(st, p);   /* octree place_in_cell :285-296 has none */
     }
 }
 
@@ -819,6 +932,20 @@ static int in_correct_cell(const orc_state *st, const photon_t *p)
     int found = find_cell(st, p->r, act);
     const double thr = 1e-3;
     int on_wall = p->on_wall[0] || p->on_wall[1] || p->on_wall[2];
+    if (st->grid_type == GRID_OCT) {   /* grid_geometry_octree.f90:366-392 */
+        int32_t id = p->ic[0];
+        if (on_wall) {
+            double f1 = fabs(p->r[0] - st->ox[id]) / st->odx[id];
+            double f2 = fabs(p->r[1] - st->oy[id]) / st->ody[id];
+            double f3 = fabs(p->r[2] - st->oz[id]) / st->odz[id];
+            double frac = 0.0; int ok = 0;
+            if (abs(p->on_wall[0]) == 1) { frac = f1 - 1.0; ok = f2 < 1.0 && f3 < 1.0; }
+            if (abs(p->on_wall[1]) == 1) { frac = f2 - 1.0; ok = f1 < 1.0 && f3 < 1.0; }
+            if (abs(p->on_wall[2]) == 1) { frac = f3 - 1.0; ok = f1 < 1.0 && f2 < 1.0; }
+            return fabs(frac) < thr && ok;
+        }
+        return found && act[0] == id;
+    }
     if (on_wall) {
         int ok = 1;
         for (int a = 0; a < 3; a++) {
@@ -840,8 +967,47 @@ static int in_correct_cell(const orc_state *st, const photon_t *p)
 }
 
 /* find_wall :424-521 with insert_t :482-512.  Returns 0 if no wall. */
+static int find_wall_oct(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    /* grid_geometry_octree.f90:438-537 */
+    int32_t id = p->ic[0];
+    const double c[3] = {st->ox[id], st->oy[id], st->oz[id]}, h[3] = {st->odx[id], st->ody[id], st->odz[id]};
+    double t[3]; int pos[3];
+    for (int a = 0; a < 3; a++) {
+        pos[a] = p->v[a] > 0.0;
+        if (pos[a]) t[a] = (c[a] + h[a] - p->r[a]) / p->v[a];
+        else if (p->v[a] < 0.0) t[a] = (c[a] - h[a] - p->r[a]) / p->v[a];
+        else t[a] = DBL_MAX;
+    }
+    id_min[0] = id_min[1] = id_min[2] = 0;
+    double tmin; int a;
+    if (t[0] < t[2]) { if (t[0] < t[1]) a = 0; else a = 1; }
+    else { if (t[2] < t[1]) a = 2; else a = 1; }
+    tmin = t[a]; id_min[a] = pos[a] ? +1 : -1;
+    if (tmin < 0.0) {
+        if (tmin > -10.0 * st->oct_eps) tmin = 0.0;
+        else { id_min[0] = id_min[1] = id_min[2] = 0; }
+    }
+    *tnearest = tmin;
+    return id_min[0] || id_min[1] || id_min[2];
+}
+
+/* p%icell = next_cell(p%icell, id_min, intersection=p%r); p%on_wall_id = opposite_wall(id_min) */
+static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
+{
+    if (st->grid_type == GRID_OCT) {
+        /* next_cell_wall_id :349-364: the first non-zero component decides */
+        int wall = id_min[0] ? (id_min[0] > 0 ? 1 : 0) : id_min[1] ? (id_min[1] > 0 ? 3 : 2) : (id_min[2] > 0 ? 5 : 4);
+        p->ic[0] = oct_next_cell(st, p->ic[0], wall, p->r);
+        for (int a = 0; a < 3; a++) p->on_wall[a] = -id_min[a];
+        return;
+    }
+    for (int a = 0; a < 3; a++) { p->ic[a] += id_min[a]; p->on_wall[a] = -id_min[a]; }
+}
+
 static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
 {
+    if (st->grid_type == GRID_OCT) return find_wall_oct(st, p, tnearest, id_min);
     double tmin = DBL_MAX, emin = 0.0;
     int imin[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
@@ -899,7 +1065,7 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
                 for (int d = 0; d < st->n_dust; d++)
                     if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
                         deposit[(size_t)d * st->n_cells + ic] += tmin * p->kappa[d] * p->energy;
-            for (int a = 0; a < 3; a++) { p->ic[a] += id_min[a]; p->on_wall[a] = -id_min[a]; }
+            advance_cell(st, p, id_min);
             if (escaped(st, p->ic)) return;
         } else {
             double tact = tmin * (tau_needed / tau_cell);
@@ -939,7 +1105,7 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
         for (int d = 0; d < st->n_dust; d++) tau += p.chi[d] * st->density[(size_t)d * st->n_cells + ic] * tmin;
         acc->crossings++;
         if (finished) return tau;
-        for (int a = 0; a < 3; a++) { p.ic[a] += id_min[a]; p.on_wall[a] = -id_min[a]; }
+        advance_cell(st, &p, id_min);
         if (escaped(st, p.ic)) return tau;
     }
 }
@@ -1490,6 +1656,9 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
     }
 }
 
+static uint64_t g_final_first_id = 0;   /* debugging aid: id offset of the next final iteration */
+void orc_set_final_first_id(uint64_t first) { g_final_first_id = first; }
+
 int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
 {
     int nt = resolve_threads(n_threads);
@@ -1528,7 +1697,7 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
 #endif
         for (int64_t i = 0; i < (int64_t)n_packets; i++) {
             if (acc->fatal) continue;
-            final_packet(st, (uint64_t)i, acc);
+            final_packet(st, g_final_first_id + (uint64_t)i, acc);
         }
     }
     orc_iter_stats tot; memset(&tot, 0, sizeof tot);
@@ -1578,7 +1747,8 @@ int orc_walk_ray(const orc_state *st, const double r0[3], const double v[3], dou
     while (!escaped(st, p.ic)) {
         double tmin; int id_min[3];
         if (!find_wall(st, &p, &tmin, id_min)) return -2;
-        for (int a = 0; a < 3; a++) { p.r[a] = p.r[a] + tmin * p.v[a]; p.ic[a] += id_min[a]; p.on_wall[a] = -id_min[a]; }
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
+        advance_cell(st, &p, id_min);
         path += tmin; n++;
         if (n > 100000000) return -3;
     }

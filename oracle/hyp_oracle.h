@@ -76,11 +76,17 @@ typedef struct orc_source_desc {
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */
 typedef struct orc_grid_desc {
-    int32_t type;          /* 1 = cartesian */
+    int32_t type;          /* 1 = cartesian, 2 = octree */
     int32_t n1, n2, n3;
     const double *w1;      /* [n1+1] */
     const double *w2;      /* [n2+1] */
     const double *w3;      /* [n3+1] */
+    /* octree (src/grid/grid_geometry_octree.f90:184-246): depth-first
+     * `refined` flags of ALL cells, centre and half-widths of the top cell */
+    int64_t n_cells;
+    const int32_t *refined;
+    double oct_center[3];
+    double oct_half[3];
 } orc_grid_desc;
 
 /* Run configuration: the root attributes of the .rtin

@@ -11,9 +11,9 @@ Run (only where /root/reference exists; the GPU box never runs this):
     # then
     /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
 
-What it writes (all plain .npz, inputs + expected outputs only):
+What it writes (inputs + expected outputs only); {grid} = car, oct:
 
-  car_specific_energy.{evenly}.{multi}.npz
+  {grid}_specific_energy.{evenly}.{multi}.npz
       inputs : the model of hyperion/model/tests/test_bit_level.py:137-173
                (TestBasic.test_specific_energy, grid_type='car'), built with the
                reference classes, written with Model.write() and read back
@@ -21,7 +21,7 @@ What it writes (all plain .npz, inputs + expected outputs only):
       golden : iteration_0000{1..5}/specific_energy of the reference's own
                committed regression output
                hyperion/model/tests/data/test_specific_energy.grid_type=car.*.rtout
-  car_peeloff.{evenly}.npz
+  {grid}_peeloff.{evenly}.npz
       inputs : test_bit_level.py:175-236 (TestBasic.test_peeloff, 'car',
                raytracing=False); golden: Peeled/group_0000{1,2,3}/{seds,images}
                (+ _unc) and iteration_00005/specific_energy of
@@ -32,6 +32,9 @@ What it writes (all plain .npz, inputs + expected outputs only):
   rtout_layout.car_peeloff.json
       names / shapes / attribute types of every object in the reference's golden
       test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=False.rtout
+  kmh_lite.npz
+      the tables of hyperion/model/tests/data/kmh_lite.hdf5 (version-1 dust file,
+      polarised anisotropic scattering), referenced by the model fixtures
   test_dust.npz
       the grey isotropic LTE test dust of hyperion/model/tests/test_helpers.py:14-18
       (IsotropicDust([3e9,3e16],[.5,.5],[1,1]) + set_lte_emissivities(10,0.1,1600))
@@ -61,7 +64,7 @@ for name, t in [("float", float), ("int", int), ("bool", bool), ("object", objec
 
 import h5py  # noqa: E402
 from hyperion.model import Model  # noqa: E402
-from hyperion.grid import CartesianGrid  # noqa: E402
+from hyperion.grid import CartesianGrid, OctreeGrid  # noqa: E402
 from hyperion.dust import IsotropicDust  # noqa: E402
 from hyperion.util.constants import pc, lsun  # noqa: E402
 
@@ -88,13 +91,16 @@ def car_grid_and_densities():
         np.random.random((20, 6, 4))
     shape_cyl = (6 - 1, 4 - 1, 8 - 1)
     shape_sph = (4 - 1, 8 - 1, 6 - 1)
-    dens = []
+    refined = [1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+               0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0]
+    grid_oct = OctreeGrid(0., 0., 0., u, u, u, np.array(refined).astype(bool))
+    dens, dens_oct = [], []
     for _ in range(3):
         dens.append(np.random.random(grid.shape) * d)
         np.random.random(shape_cyl)
         np.random.random(shape_sph)
-        np.random.random(25)
-    return grid, dens
+        dens_oct.append(np.random.random(25) * d)
+    return {"car": grid, "oct": grid_oct}, {"car": dens, "oct": dens_oct}
 
 
 def add_sources(m):
@@ -122,9 +128,25 @@ def write_and_read(m, tmp, keep_as=None):
     return read_rtin(path)
 
 
+_KMH = {}
+
+
+def kmh_library():
+    """kmh_lite.hdf5 tables stored once (tests/golden/kmh_lite.npz); the model
+    fixtures reference it instead of embedding 750 KB of dust tables each."""
+    if not _KMH:
+        with h5py.File(DUST_FILE, "r") as f:
+            d = read_dust_group(f)
+        arrays = {k: v for k, v in d.__dict__.items() if isinstance(v, np.ndarray)}
+        np.savez_compressed(os.path.join(HERE, "kmh_lite.npz"), **arrays)
+        print("wrote", os.path.join(HERE, "kmh_lite.npz"))
+        _KMH["kmh_lite.npz"] = d
+    return _KMH
+
+
 def save(path, prob, golden):
     ptmp = path + ".problem.npz"
-    prob.to_npz(ptmp)
+    prob.to_npz(ptmp, dust_library=kmh_library())
     z = dict(np.load(ptmp))
     os.remove(ptmp)
     for k, v in golden.items():
@@ -133,73 +155,83 @@ def save(path, prob, golden):
     print("wrote", path, os.path.getsize(path))
 
 
-def main():
-    grid, dens = car_grid_and_densities()
-    with tempfile.TemporaryDirectory() as tmp:
-        # --- test_specific_energy -------------------------------------------
-        for evenly in (False, True):
-            for multi in (False, True):
-                m = Model()
-                m.set_grid(grid)
-                m.add_density_grid(dens[0], DUST_FILE)
-                if multi:
-                    m.add_density_grid(dens[1], DUST_FILE)
-                    m.add_density_grid(dens[2], DUST_FILE)
-                add_sources(m)
-                m.set_n_photons(initial=10000, imaging=0)
-                m.set_sample_sources_evenly(evenly)
-                m.conf.output.output_specific_energy = 'all'
-                prob = write_and_read(m, tmp)
-                ref = os.path.join(DATA, "test_specific_energy.grid_type=car.sample_sources_evenly=%s.multiple_densities=%s.rtout" % (evenly, multi))
-                with h5py.File(ref, "r") as f:
-                    assert f["iteration_00001/specific_energy"].attrs["geometry"].decode() == prob.geometry_id
-                    se = np.array([f["iteration_%05d/specific_energy" % i][...] for i in range(1, 6)])
-                    killed = np.array([[f["iteration_%05d" % i].attrs["killed_photons_geo"],
-                                        f["iteration_%05d" % i].attrs["killed_photons_int"]] for i in range(1, 6)])
-                save(os.path.join(HERE, "car_specific_energy.%s.%s.npz" % (evenly, multi)), prob,
-                     {"specific_energy": se, "killed": killed})
+def build_model(grid, dens, evenly, multi=False):
+    m = Model()
+    m.set_grid(grid)
+    m.add_density_grid(dens[0], DUST_FILE)
+    if multi:
+        m.add_density_grid(dens[1], DUST_FILE)
+        m.add_density_grid(dens[2], DUST_FILE)
+    add_sources(m)
+    m.set_sample_sources_evenly(evenly)
+    return m
 
-        # --- test_peeloff (raytracing=False) ----------------------------------
-        for evenly in (False, True):
-            m = Model()
-            m.set_grid(grid)
-            m.add_density_grid(dens[0], DUST_FILE)
-            add_sources(m)
-            m.set_raytracing(False)
-            m.set_n_photons(initial=1000, imaging=5000)
-            m.set_sample_sources_evenly(evenly)
-            i_p = m.add_peeled_images()
-            i_p.set_wavelength_range(5, 0.05, 200.)
-            i_p.set_viewing_angles([33.4, 110.], [65.4, 103.2])
-            i_p.set_image_size(4, 5)
-            i_p.set_image_limits(-0.8 * pc, 0.8 * pc, -pc, pc)
-            i_p.set_aperture_radii(5, 0.1 * pc, pc)
-            i_p.set_stokes(True)
-            for track in ('basic', 'detailed'):
-                i_p = m.add_peeled_images()
-                i_p.set_wavelength_range(4, 0.05, 200.)
-                i_p.set_viewing_angles([22.1], [203.2])
-                i_p.set_image_size(6, 6)
-                i_p.set_image_limits(-pc, pc, -pc, pc)
-                i_p.set_aperture_radii(2, 0.5 * pc, pc)
-                i_p.set_track_origin(track)
-                i_p.set_stokes(True)
-            prob = write_and_read(m, tmp, keep_as=None if evenly else os.path.join(HERE, "car_peeloff.False.rtin"))
-            ref = os.path.join(DATA, "test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=%s.rtout" % evenly)
-            golden = {}
-            with h5py.File(ref, "r") as f:
-                for g in range(1, 4):
-                    grp = f["Peeled/group_%05d" % g]
-                    for name in ("seds", "images", "seds_unc", "images_unc"):
-                        if name in grp:
-                            golden["group%d/%s" % (g, name)] = grp[name][...]
-                    for k in ("numin", "numax", "apmin", "apmax"):
-                        golden["group%d/seds_%s" % (g, k)] = np.float64(grp["seds"].attrs[k])
-                    for k in ("numin", "numax", "xmin", "xmax", "ymin", "ymax"):
-                        golden["group%d/images_%s" % (g, k)] = np.float64(grp["images"].attrs[k])
-                n_it = int(f.attrs["iterations"])
-                golden["specific_energy_last"] = f["iteration_%05d/specific_energy" % n_it][...]
-            save(os.path.join(HERE, "car_peeloff.%s.npz" % evenly), prob, golden)
+
+def specific_energy_fixture(gt, grid, dens, evenly, multi, tmp):
+    """test_bit_level.py:137-173"""
+    m = build_model(grid, dens, evenly, multi)
+    m.set_n_photons(initial=10000, imaging=0)
+    m.conf.output.output_specific_energy = 'all'
+    prob = write_and_read(m, tmp)
+    ref = os.path.join(DATA, "test_specific_energy.grid_type=%s.sample_sources_evenly=%s.multiple_densities=%s.rtout" % (gt, evenly, multi))
+    with h5py.File(ref, "r") as f:
+        assert f["iteration_00001/specific_energy"].attrs["geometry"].decode() == prob.geometry_id
+        se = np.array([f["iteration_%05d/specific_energy" % i][...] for i in range(1, 6)])
+        killed = np.array([[f["iteration_%05d" % i].attrs["killed_photons_geo"],
+                            f["iteration_%05d" % i].attrs["killed_photons_int"]] for i in range(1, 6)])
+    save(os.path.join(HERE, "%s_specific_energy.%s.%s.npz" % (gt, evenly, multi)), prob,
+         {"specific_energy": se, "killed": killed})
+
+
+def peeloff_fixture(gt, grid, dens, evenly, tmp):
+    """test_bit_level.py:175-236, raytracing=False"""
+    m = build_model(grid, dens, evenly)
+    m.set_raytracing(False)
+    m.set_n_photons(initial=1000, imaging=5000)
+    i_p = m.add_peeled_images()
+    i_p.set_wavelength_range(5, 0.05, 200.)
+    i_p.set_viewing_angles([33.4, 110.], [65.4, 103.2])
+    i_p.set_image_size(4, 5)
+    i_p.set_image_limits(-0.8 * pc, 0.8 * pc, -pc, pc)
+    i_p.set_aperture_radii(5, 0.1 * pc, pc)
+    i_p.set_stokes(True)
+    for track in ('basic', 'detailed'):
+        i_p = m.add_peeled_images()
+        i_p.set_wavelength_range(4, 0.05, 200.)
+        i_p.set_viewing_angles([22.1], [203.2])
+        i_p.set_image_size(6, 6)
+        i_p.set_image_limits(-pc, pc, -pc, pc)
+        i_p.set_aperture_radii(2, 0.5 * pc, pc)
+        i_p.set_track_origin(track)
+        i_p.set_stokes(True)
+    keep = os.path.join(HERE, "car_peeloff.False.rtin") if (gt == "car" and not evenly) else None
+    prob = write_and_read(m, tmp, keep_as=keep)
+    ref = os.path.join(DATA, "test_peeloff.grid_type=%s.raytracing=False.sample_sources_evenly=%s.rtout" % (gt, evenly))
+    golden = {}
+    with h5py.File(ref, "r") as f:
+        for g in range(1, 4):
+            grp = f["Peeled/group_%05d" % g]
+            for name in ("seds", "images", "seds_unc", "images_unc"):
+                if name in grp:
+                    golden["group%d/%s" % (g, name)] = grp[name][...]
+            for k in ("numin", "numax", "apmin", "apmax"):
+                golden["group%d/seds_%s" % (g, k)] = np.float64(grp["seds"].attrs[k])
+            for k in ("numin", "numax", "xmin", "xmax", "ymin", "ymax"):
+                golden["group%d/images_%s" % (g, k)] = np.float64(grp["images"].attrs[k])
+        n_it = int(f.attrs["iterations"])
+        golden["specific_energy_last"] = f["iteration_%05d/specific_energy" % n_it][...]
+    save(os.path.join(HERE, "%s_peeloff.%s.npz" % (gt, evenly)), prob, golden)
+
+
+def main():
+    grids, denss = car_grid_and_densities()
+    with tempfile.TemporaryDirectory() as tmp:
+        for gt in ("car", "oct"):
+            for evenly in (False, True):
+                for multi in (False, True):
+                    specific_energy_fixture(gt, grids[gt], denss[gt], evenly, multi, tmp)
+            for evenly in (False, True):
+                peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp)
 
         # --- layout of the golden .rtout (names, shapes, attribute types) ------
         import json
