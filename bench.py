@@ -69,7 +69,7 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: always exercise RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -90,13 +90,13 @@ def main():
     it = 0
     for _ in range(args.warmup):
         it += 1
-        lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False)
+        lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False, force_collective=dist is not None)
     barrier()
     t0 = time.perf_counter()
     kernel_ms, crossings, finish_ms = [], 0, []
     for _ in range(args.steps):
         it += 1
-        _, st = lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False)
+        _, st = lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False, force_collective=dist is not None)
         a, b = eng.last_kernel_ms()
         kernel_ms.append(a)
         finish_ms.append(b)

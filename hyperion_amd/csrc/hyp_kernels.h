@@ -738,13 +738,55 @@ __device__ __forceinline__ int ipos0(double xmin, double xmax, double x, int n)
 
 struct PeelFlags { int scattered, reprocessed, n_scat, dust_id, source_id; };
 
-// image_bin / image_bin_single: image_type.f90:408-524
-__device__ __forceinline__ void image_bin(const DProblem &P, const DPeeled &G, double nu, double energy,
-                                          const double s[4], const PeelFlags &f, double x_image, double y_image, int iv)
+// Wave-cooperative accumulation of one value per lane into cube[key + i*stride],
+// i = 0..n-1 (the Stokes components).  Lanes that hit the same element are summed
+// in registers first (up to three distinct keys per call; the direct light of a
+// point source puts every lane of the wave on ONE pixel, which would otherwise
+// serialise as same-address atomics), the rest falls back to one atomic per lane.
+// Must be called with all 64 lanes active; `key < 0` = nothing to add.
+__device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, double *__restrict__ cube2, long long key,
+                                                size_t stride, int n, const double val[4])
 {
+    unsigned long long todo = __ballot(key >= 0);
+    for (int round = 0; round < 3 && todo; round++) {
+        int leader = __ffsll((long long)todo) - 1;
+        long long k0 = __shfl(key, leader, 64);
+        bool same = key == k0;
+        unsigned long long grp = __ballot(same);
+        if (__popcll(grp) > 1) {
+            for (int i = 0; i < n; i++) {
+                double v = same ? val[i] : 0.0;
+                double t = wave_sum(v);
+                double t2 = cube2 ? wave_sum(v * v) : 0.0;
+                if ((int)__lane_id() == leader) {
+                    unsafeAtomicAdd(&cube[k0 + (long long)i * (long long)stride], t);
+                    if (cube2) unsafeAtomicAdd(&cube2[k0 + (long long)i * (long long)stride], t2);
+                }
+            }
+            if (same) key = -1;
+        } else {
+            break;   // keys are scattered: no point in grouping further
+        }
+        todo = __ballot(key >= 0);
+    }
+    if (key >= 0) {
+        for (int i = 0; i < n; i++) {
+            unsafeAtomicAdd(&cube[key + (long long)i * (long long)stride], val[i]);
+            if (cube2) unsafeAtomicAdd(&cube2[key + (long long)i * (long long)stride], val[i] * val[i]);
+        }
+    }
+}
+
+// image_bin / image_bin_single: image_type.f90:408-524 -- element indices of the
+// Stokes-I entry in the image and SED cubes (-1 = not binned)
+__device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled &G, double nu, double energy, double s0,
+                                               const PeelFlags &f, double x_image, double y_image, int iv,
+                                               long long &k_img, long long &k_sed)
+{
+    k_img = -1; k_sed = -1;
     int inu = ipos0(G.log10_nu_min, G.log10_nu_max, log10(nu), G.n_nu);
     if (inu < 0 || inu >= G.n_nu) return;
-    if (energy != energy || s[0] != s[0]) return;
+    if (energy != energy || s0 != s0) return;
     int o = f.scattered ? (f.reprocessed ? 4 : 3) : (f.reprocessed ? 2 : 1);
     int io = 0;
     if (G.track_origin == 1) io = o - 1;
@@ -755,86 +797,91 @@ __device__ __forceinline__ void image_bin(const DProblem &P, const DPeeled &G, d
         int ns = f.n_scat < G.track_n_scat + 1 ? f.n_scat : G.track_n_scat + 1;
         io = (f.reprocessed ? (G.track_n_scat + 2) : 0) + ns;
     }
-    const int nst = G.n_stokes;
     if (G.compute_image) {
         int ix = ipos0(G.x_min, G.x_max, x_image, G.n_x);
         int iy = ipos0(G.y_min, G.y_max, y_image, G.n_y);
-        if (ix >= 0 && ix < G.n_x && iy >= 0 && iy < G.n_y) {
-            for (int is = 0; is < nst; is++) {
-                size_t k = (((((size_t)is * G.n_orig + io) * G.n_view + iv) * G.n_y + iy) * G.n_x + ix) * G.n_nu + inu;
-                double val = s[is] * energy;
-                unsafeAtomicAdd(&G.img[k], val);
-                if (G.uncertainties) unsafeAtomicAdd(&G.img2[k], val * val);
-            }
-        }
+        if (ix >= 0 && ix < G.n_x && iy >= 0 && iy < G.n_y)
+            k_img = (long long)((((((size_t)0 * G.n_orig + io) * G.n_view + iv) * G.n_y + iy) * G.n_x + ix) * G.n_nu + inu);
     }
     if (G.compute_sed) {
         double lr = log10(sqrt(x_image * x_image + y_image * y_image));
         int ir;
         if (lr < G.log10_ap_min || G.n_ap == 1) ir = 0;
         else ir = ipos0(G.log10_ap_min, G.log10_ap_max, lr, G.n_ap - 1) + 1;
-        if (ir >= 0 && ir < G.n_ap) {
-            for (int is = 0; is < nst; is++) {
-                size_t k = ((((size_t)is * G.n_orig + io) * G.n_view + iv) * G.n_ap + ir) * G.n_nu + inu;
-                double val = s[is] * energy;
-                unsafeAtomicAdd(&G.sed[k], val);
-                if (G.uncertainties) unsafeAtomicAdd(&G.sed2[k], val * val);
-            }
-        }
+        if (ir >= 0 && ir < G.n_ap)
+            k_sed = (long long)(((((size_t)0 * G.n_orig + io) * G.n_view + iv) * G.n_ap + ir) * G.n_nu + inu);
     }
 }
 
-// peeloff_photon, external observers: images_peeled.f90:95-270
+// peeloff_photon, external observers: images_peeled.f90:95-270.  Called by ALL
+// lanes of the wave (`active` = this lane has a packet to peel) so that the image
+// deposits can be combined across lanes.
 template <int NDT, int GEOM>
-__device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, const Angle &a_prev,
-                                        const double s_prev[4], int last, bool last_isotropic, const PeelFlags &f,
-                                        Rng &g, Counters &cnt)
+__device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, bool active,
+                                        const Angle &a_prev, const double s_prev[4], int last, bool last_isotropic,
+                                        const PeelFlags &f, Rng &g, Counters &cnt)
 {
     for (int ig = 0; ig < P.n_peeled; ig++) {
         const DPeeled &G = P.peeled[ig];
         for (int iv = 0; iv < G.n_view; iv++) {
-            Angle a_req;
-            a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
-            a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
-            double s[4];
-            if (last_isotropic || last != LAST_DS) {
-                s[0] = last_isotropic ? 1.0 : s_prev[0]; s[1] = last_isotropic ? 0.0 : s_prev[1];
-                s[2] = last_isotropic ? 0.0 : s_prev[2]; s[3] = last_isotropic ? 0.0 : s_prev[3];
-            } else {
-                // dust_scatter_peeloff: dust_type_4elem.f90:421-444
-                const DDust &D = P.dust[f.dust_id];
-                s[0] = s_prev[0]; s[1] = s_prev[1]; s[2] = s_prev[2]; s[3] = s_prev[3];
-                Angle a_scat;
-                difference_angle(a_prev, a_req, a_scat);
-                if (a_scat.cost < D.mu_min || a_scat.cost > D.mu_max) { s[0] = s[1] = s[2] = s[3] = 0.0; }
-                else {
-                    double P1, P2, P3, P4;
-                    interp_P(D, a_scat.cost, p.nu, P1, P2, P3, P4);
-                    scatter_stokes(s, a_prev, a_scat, a_req, P1, P2, P3, P4);
+            long long k_img = -1, k_sed = -1;
+            double val[4] = {0.0, 0.0, 0.0, 0.0};
+            if (active) {
+                Angle a_req;
+                a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
+                a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+                double s[4];
+                if (last_isotropic || last != LAST_DS) {
+                    s[0] = last_isotropic ? 1.0 : s_prev[0]; s[1] = last_isotropic ? 0.0 : s_prev[1];
+                    s[2] = last_isotropic ? 0.0 : s_prev[2]; s[3] = last_isotropic ? 0.0 : s_prev[3];
+                } else {
+                    // dust_scatter_peeloff: dust_type_4elem.f90:421-444
+                    const DDust &D = P.dust[f.dust_id];
+                    s[0] = s_prev[0]; s[1] = s_prev[1]; s[2] = s_prev[2]; s[3] = s_prev[3];
+                    Angle a_scat;
+                    difference_angle(a_prev, a_req, a_scat);
+                    if (a_scat.cost < D.mu_min || a_scat.cost > D.mu_max) { s[0] = s[1] = s[2] = s[3] = 0.0; }
+                    else {
+                        double P1, P2, P3, P4;
+                        interp_P(D, a_scat.cost, p.nu, P1, P2, P3, P4);
+                        scatter_stokes(s, a_prev, a_scat, a_req, P1, P2, P3, P4);
+                    }
+                }
+                double v[3];
+                angle_to_vector(a_req, v[0], v[1], v[2]);
+                // the copy keeps the packet's wall flags; Cartesian place_in_cell resets them
+                Cell<GEOM> c = p.cell;
+                bool ok = geo_place(P, W, p.r, v, c);
+                if (!ok) cnt.killed_geo++;
+                double d = -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
+                ok = ok && !(d < G.d_min || d > G.d_max);
+                double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
+                double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
+                double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                bool inside = false;
+                if (G.compute_image)
+                    inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
+                             ((y_image >= G.y_min && y_image <= G.y_max) || (y_image <= G.y_min && y_image >= G.y_max));
+                if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
+                ok = ok && inside;
+                if (ok) {
+                    double tau = 0.0; bool killed = false;
+                    if (!G.ignore_optical_depth) tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed);
+                    if (!killed) {
+                        double att = exp(-tau);
+                        s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
+                        image_bin_keys(P, G, p.nu, p.energy, s[0], f, x_image, y_image, iv, k_img, k_sed);
+                        val[0] = s[0] * p.energy; val[1] = s[1] * p.energy; val[2] = s[2] * p.energy; val[3] = s[3] * p.energy;
+                    }
                 }
             }
-            double v[3];
-            angle_to_vector(a_req, v[0], v[1], v[2]);
-            // the copy keeps the packet's wall flags; Cartesian place_in_cell resets them
-            Cell<GEOM> c = p.cell;
-            if (!geo_place(P, W, p.r, v, c)) { cnt.killed_geo++; continue; }
-            double d = -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
-            if (d < G.d_min || d > G.d_max) continue;
-            double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
-            double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
-            double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
-            bool inside = false;
+            // wave-uniform from here: combine lanes that hit the same pixel / SED bin
             if (G.compute_image)
-                inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
-                         ((y_image >= G.y_min && y_image <= G.y_max) || (y_image <= G.y_min && y_image >= G.y_max));
-            if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
-            if (!inside) continue;
-            double tau = 0.0; bool killed = false;
-            if (!G.ignore_optical_depth) tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed);
-            if (killed) continue;
-            double att = exp(-tau);
-            s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
-            image_bin(P, G, p.nu, p.energy, s, f, x_image, y_image, iv);
+                wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img,
+                                (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, G.n_stokes, val);
+            if (G.compute_sed)
+                wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed,
+                                (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu, G.n_stokes, val);
         }
     }
 }
@@ -930,8 +977,8 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
 
         // ---- peel-off + optical depth sampling for lanes that just emitted / interacted ----
         if (__ballot(peel != 0)) {
+            if (P.n_peeled > 0) peeloff<NDT, GEOM>(P, W, p, peel != 0, a_prev, s_prev, last, last_iso, f, g, cnt);
             if (peel != 0) {
-                if (P.n_peeled > 0) peeloff<NDT, GEOM>(P, W, p, a_prev, s_prev, last, last_iso, f, g, cnt);
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;

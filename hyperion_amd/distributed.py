@@ -18,7 +18,8 @@ def shard_range(n_total, rank, world_size):
     return first, last - first
 
 
-def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all_reduce=None, want_output=True):
+def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all_reduce=None, want_output=True,
+                           force_collective=False):
     """One Lucy iteration of `n_total` packets over `world_size` ranks.
 
     `engine` provides lucy_launch / lucy_accumulators_tensor / lucy_finish
@@ -26,15 +27,18 @@ def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all
     (``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
     first, n_local = shard_range(n_total, rank, world_size)
     engine.lucy_launch(first, n_local, iteration)
-    if world_size == 1 and all_reduce is None:
+    if world_size == 1 and all_reduce is None and not force_collective:
         engine.lucy_accumulators()           # no collective: no torch needed
         acc = None
     else:
         acc = engine.lucy_accumulators_tensor()
-    if world_size > 1:
+    if world_size > 1 or force_collective:
         if all_reduce is None:
+            import torch
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            # the engine reads the block on its own HIP stream: wait for RCCL's stream
+            torch.cuda.synchronize()
         else:
             all_reduce(acc)
     out, stats = engine.lucy_finish(want_output=want_output)
@@ -52,8 +56,10 @@ def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=No
         acc = engine.final_accumulators_tensor()
     if world_size > 1:
         if all_reduce is None:
+            import torch
             import torch.distributed as dist
             dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
         else:
             all_reduce(acc)
     res, stats = engine.final_finish()

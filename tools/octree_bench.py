@@ -1,0 +1,20 @@
+"""Throughput of BASELINE config 4 (adaptive octree depth 7 + 512x512 peel-off)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hyperion_amd
+from hyperion_amd.benchmark import make_octree_problem
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
+p = make_octree_problem(max_level=7)
+print("cells", p.n_cells, "refined", int(p.refined.sum()))
+eng = hyperion_amd.Engine(p)
+eng.lucy_iteration(n // 10, 1, want_output=False)
+for it in (2, 3):
+    _, st = eng.lucy_iteration(n, it, want_output=False)
+    ms = eng.last_kernel_ms()[0]
+    print("lucy  n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet, %.3e crossings/s, killed_geo %d"
+          % (n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3, st["killed_geo"]))
+res, st = eng.final_iteration(n)
+ms = eng.last_kernel_ms()[0]
+print("final n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet (incl. peel-off walks), %.3e crossings/s"
+      % (n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3))
