@@ -41,6 +41,8 @@ class GridDesc(C.Structure):
         ("w1", _dp), ("w2", _dp), ("w3", _dp),
         ("n_cells", C.c_int64), ("refined", C.POINTER(C.c_int32)),
         ("oct_center", C.c_double * 3), ("oct_half", C.c_double * 3),
+        ("vor_sites", _dp), ("vor_volume", _dp),
+        ("vor_idx", C.POINTER(C.c_int32)), ("vor_neighs", C.POINTER(C.c_int32)), ("vor_box", C.c_double * 6),
     ]
 
 
@@ -91,7 +93,7 @@ class IterStats(C.Structure):
                 "n_packets": self.n_packets}
 
 
-SOURCE_TYPES = {"point": 1}
+SOURCE_TYPES = {"point": 1, "extern_sph": 5, "extern_box": 6}
 
 
 def _ptr(a):
@@ -126,6 +128,19 @@ class MarshalledProblem:
             for k in range(3):
                 d.grid.oct_center[k] = float(prob.oct_center[k])
                 d.grid.oct_half[k] = float(prob.oct_half[k])
+        elif prob.grid_type == "vor":
+            d.grid.type = 3
+            d.grid.n_cells = prob.vor_sites.shape[0]
+            d.grid.vor_sites = arr(prob.vor_sites)
+            d.grid.vor_volume = arr(prob.vor_volume)
+            idx = np.ascontiguousarray(prob.vor_idx, dtype=np.int32)
+            nei = np.ascontiguousarray(prob.vor_neighs, dtype=np.int32)
+            keep(idx)
+            keep(nei)
+            d.grid.vor_idx = idx.ctypes.data_as(C.POINTER(C.c_int32))
+            d.grid.vor_neighs = nei.ctypes.data_as(C.POINTER(C.c_int32))
+            for k in range(6):
+                d.grid.vor_box[k] = float(prob.vor_box[k])
         else:
             raise ValueError("Unexpected coordinate type: %s" % prob.grid_type)
 
@@ -183,6 +198,9 @@ class MarshalledProblem:
             x.luminosity = float(s.luminosity)
             for k in range(3):
                 x.position[k] = float(s.position[k])
+            x.radius = float(s.radius)
+            for k in range(6):
+                x.box[k] = float(s.box[k])
             if s.spectrum_nu is not None:
                 x.spectrum_type = 1
                 x.n_spec = int(np.size(s.spectrum_nu))

@@ -41,6 +41,8 @@ struct DSource {
     double lum_pdf, lum_cdf;
     int spectrum_type, n_spec;
     const double *spec_x, *spec_cdf, *spec_bp1;
+    int type, peeloff;        // 1 point, 5 extern_sph, 6 extern_box
+    double radius, box[6], face_cdf[6];
 };
 
 struct DPeeled {
@@ -81,11 +83,17 @@ struct DProblem {
     double baes16_xi;
     double check_p, check_log1mp;         // propagation_check_frequency p, log(1-p)
     uint32_t seed_key, pad1;
-    int grid_type, pad3;                  // 1 cartesian, 2 octree
+    int grid_type, pad3;                  // 1 cartesian, 2 octree, 3 voronoi
     const double *w[3], *ew[3];           // walls and 3*spacing(wall)
     const OctCell *oct_cells;             // [n_cells]
     const int *oct_children;              // [n_cells][8], -1 where not refined
     double oct_half[3], oct_box[6], oct_eps;
+    const double *vor_sites;              // voronoi: [n_cells][3]
+    const int *vor_idx, *vor_neigh;       // CSR neighbour lists (ids >= 0, walls -1..-6)
+    const int *vor_seed;                  // [vor_g^3] start site of the nearest-site walk
+    const double *vor_volume;             // [n_cells]
+    double vor_box[6];
+    int vor_g, pad4;
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies
@@ -258,8 +266,8 @@ __device__ __forceinline__ void rotate_angle(const Angle &loc, const Angle &co, 
     double cos_c = clamp1(cos_a * cos_b + sin_a * sin_b * cos_C);
     double sin_c = sqrt(1.0 - cos_c * cos_c);
     double cos_B, sin_B;
-    if (sin_a < 1e-12 || sin_c < 1e-12) {
-        if (sin_a < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
+    if (fabs(sin_a) < 1e-12 || sin_c < 1e-12) {
+        if (fabs(sin_a) < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
         else { cos_B = 1.0; sin_B = 0.0; }
     } else {
         cos_B = clamp1((cos_b - cos_a * cos_c) / (sin_a * sin_c));

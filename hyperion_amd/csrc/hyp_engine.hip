@@ -104,6 +104,8 @@ struct hyp_engine {
     double *d_blob = nullptr;
     OctCell *d_oct_cells = nullptr;
     int *d_oct_children = nullptr;
+    double *d_vor_sites = nullptr, *d_vor_volume = nullptr;
+    int *d_vor_idx = nullptr, *d_vor_neigh = nullptr, *d_vor_seed = nullptr;
     DSource *d_sources = nullptr;
     DPeeled *d_peeled = nullptr;
     double *d_density = nullptr, *d_specific_energy = nullptr, *d_additional = nullptr;
@@ -144,7 +146,7 @@ int set_error(const std::string &m) { g_error = m; return 1; }
 template <typename T>
 void free_dev(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
-size_t lds_bytes(const DProblem &P) { return P.grid_type == 2 ? 0 : sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
+size_t lds_bytes(const DProblem &P) { return P.grid_type != 1 ? 0 : sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
 
 using LucyKernel = void (*)(const DProblem *, LaunchParams);
 
@@ -184,12 +186,14 @@ LucyKernel pick_final_kernel_g(int nd)
 
 LucyKernel pick_lucy_kernel(int nd, int grid_type)
 {
-    return grid_type == 2 ? pick_lucy_kernel_g<GEOM_OCT>(nd) : pick_lucy_kernel_g<GEOM_CAR>(nd);
+    return grid_type == 3 ? pick_lucy_kernel_g<GEOM_VOR>(nd)
+         : grid_type == 2 ? pick_lucy_kernel_g<GEOM_OCT>(nd) : pick_lucy_kernel_g<GEOM_CAR>(nd);
 }
 
 LucyKernel pick_final_kernel(int nd, int grid_type)
 {
-    return grid_type == 2 ? pick_final_kernel_g<GEOM_OCT>(nd) : pick_final_kernel_g<GEOM_CAR>(nd);
+    return grid_type == 3 ? pick_final_kernel_g<GEOM_VOR>(nd)
+         : grid_type == 2 ? pick_final_kernel_g<GEOM_OCT>(nd) : pick_final_kernel_g<GEOM_CAR>(nd);
 }
 
 }  // namespace
@@ -206,6 +210,7 @@ void hyp_destroy(hyp_handle h)
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
+    free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
@@ -227,15 +232,57 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     g_error.clear();
     if (out) *out = nullptr;
     if (!pr || !out) return set_error("null argument");
-    if (pr->grid.type != 1 && pr->grid.type != 2) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree)");
+    if (pr->grid.type < 1 || pr->grid.type > 3) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
     if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
-    const bool is_oct = pr->grid.type == 2;
-    const int n[3] = {is_oct ? 0 : pr->grid.n1, is_oct ? 0 : pr->grid.n2, is_oct ? 0 : pr->grid.n3};
+    const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_car = pr->grid.type == 1;
+    const int n[3] = {is_car ? pr->grid.n1 : 0, is_car ? pr->grid.n2 : 0, is_car ? pr->grid.n3 : 0};
+    std::vector<int> vor_seed;
+    int vor_g = 1;
     const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
     std::vector<OctCell> oct_cells;
     std::vector<int> oct_children;
-    if (!is_oct) {
+    if (is_vor) {
+        // setup_grid_geometry: grid_geometry_voronoi.f90:96-188
+        const int64_t nc = pr->grid.n_cells;
+        if (nc < 1 || nc > 2000000000ll || !pr->grid.vor_sites || !pr->grid.vor_idx || !pr->grid.vor_neighs || !pr->grid.vor_volume)
+            return set_error("voronoi grid needs sites, volumes and neighbour lists");
+        const int32_t *idx = pr->grid.vor_idx, *nei = pr->grid.vor_neighs;
+        for (int64_t i = 0; i < nc; i++) if (idx[i + 1] < idx[i]) return set_error("sparse_idx should be non-decreasing");
+        for (int64_t k = 0; k < idx[nc]; k++) if (nei[k] < -6 || nei[k] >= nc) return set_error("neighbour index out of range");
+        for (int a = 0; a < 3; a++) if (!(pr->grid.vor_box[2 * a + 1] > pr->grid.vor_box[2 * a])) return set_error("voronoi domain is empty");
+        // seed grid of the nearest-site walk: nearest site of every seed-cell centre
+        const double *S = pr->grid.vor_sites, *B = pr->grid.vor_box;
+        auto d2 = [&](int i, const double r[3]) {
+            double dx = S[3 * (size_t)i] - r[0], dy = S[3 * (size_t)i + 1] - r[1], dz = S[3 * (size_t)i + 2] - r[2];
+            return dx * dx + dy * dy + dz * dz;
+        };
+        auto nearest_from = [&](const double r[3], int seed) {
+            int cur = seed; double dcur = d2(cur, r);
+            for (;;) {
+                int best = cur; double dbest = dcur;
+                for (int k = idx[cur]; k < idx[cur + 1]; k++) {
+                    int nb = nei[k];
+                    if (nb < 0) continue;
+                    double d = d2(nb, r);
+                    if (d < dbest) { dbest = d; best = nb; }
+                }
+                if (best == cur) return cur;
+                cur = best; dcur = dbest;
+            }
+        };
+        vor_g = (int)std::ceil(std::cbrt((double)nc / 4.0));
+        if (vor_g < 1) vor_g = 1;
+        if (vor_g > 256) vor_g = 256;
+        vor_seed.resize((size_t)vor_g * vor_g * vor_g);
+        int last = 0;
+        for (int k = 0; k < vor_g; k++) for (int j = 0; j < vor_g; j++) for (int i = 0; i < vor_g; i++) {
+            double c[3] = {B[0] + (i + 0.5) / vor_g * (B[1] - B[0]), B[2] + (j + 0.5) / vor_g * (B[3] - B[2]),
+                           B[4] + (k + 0.5) / vor_g * (B[5] - B[4])};
+            last = nearest_from(c, last);
+            vor_seed[((size_t)k * vor_g + j) * vor_g + i] = last;
+        }
+    } else if (is_car) {
         for (int a = 0; a < 3; a++) {
             if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
             for (int i = 0; i < n[a]; i++)
@@ -291,7 +338,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     h->device = device;
     h->cfg = pr->config;
     h->n_dust = pr->n_dust;
-    h->n_cells = is_oct ? (size_t)pr->grid.n_cells : (size_t)n[0] * n[1] * n[2];
+    h->n_cells = is_car ? (size_t)n[0] * n[1] * n[2] : (size_t)pr->grid.n_cells;
     h->n_elem = h->n_cells * h->n_dust;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
@@ -330,7 +377,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 
     // walls + 3*spacing(w): grid_geometry_cartesian_3d.f90:97-132
     size_t w_off[3] = {0, 0, 0}, ew_off[3] = {0, 0, 0};
-    for (int a = 0; a < 3 && !is_oct; a++) {
+    for (int a = 0; a < 3 && is_car; a++) {
         w_off[a] = B.put(win[a], n[a] + 1);
         std::vector<double> ew(n[a] + 1);
         for (int i = 0; i <= n[a]; i++) ew[i] = 3.0 * spacing(win[a][i]);
@@ -424,7 +471,16 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             const hyp_source_desc &s = pr->sources[i];
             DSource &S = hs[i];
             std::memset(&S, 0, sizeof(S));
-            if (s.type != 1) FAIL("unknown type in source list: " + std::to_string(s.type));
+            if (s.type != 1 && s.type != 5 && s.type != 6) FAIL("unknown type in source list: " + std::to_string(s.type));
+            S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius;
+            for (int k = 0; k < 6; k++) S.box[k] = s.box[k];
+            if (s.type == 6) {   // face pdf ~ face areas: source_type.f90:233-237
+                double dx = s.box[1] - s.box[0], dy = s.box[3] - s.box[2], dz = s.box[5] - s.box[4];
+                double a[6] = {dy * dz, dy * dz, dz * dx, dz * dx, dx * dy, dx * dy}, cc = 0.0, tot = 0.0;
+                for (int k = 0; k < 6; k++) tot += a[k];
+                for (int k = 0; k < 6; k++) { cc += a[k] / tot; S.face_cdf[k] = cc; }
+                for (int k = 0; k < 6; k++) S.face_cdf[k] /= cc;
+            }
             S.pos[0] = s.position[0]; S.pos[1] = s.position[1]; S.pos[2] = s.position[2];
             S.temperature = s.temperature; S.spectrum_type = s.spectrum_type; S.n_spec = s.n_spec;
             S.lum_pdf = s.luminosity / h->energy_total;
@@ -437,7 +493,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 if (!build_log_pdf(s.spec_nu, s.spec_fnu, s.n_spec, 1, cdf, bp1)) FAIL("source spectrum has zero integral");
                 soff[i].x = B.put(s.spec_nu, s.n_spec); soff[i].cdf = B.put(cdf); soff[i].bp1 = B.put(bp1);
                 soff[i].have = true;
-            } else if (s.spectrum_type != 2) FAIL("Point source cannot have LTE spectrum");
+            } else if (s.spectrum_type != 2)
+                FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : "Point source") + " cannot have LTE spectrum");
         }
         for (int i = 0; i < pr->n_sources; i++) hs[i].lum_cdf /= c;
     }
@@ -496,7 +553,25 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     HIPC(hipMalloc(&h->d_blob, sizeof(double) * B.h.size()));
     HIPC(hipMemcpy(h->d_blob, B.h.data(), sizeof(double) * B.h.size(), hipMemcpyHostToDevice));
     const double *db = h->d_blob;
-    for (int a = 0; a < 3 && !is_oct; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    for (int a = 0; a < 3 && is_car; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    if (is_vor) {
+        const size_t nc = h->n_cells, nn = (size_t)pr->grid.vor_idx[nc];
+        std::vector<double> vol(nc);
+        for (size_t i = 0; i < nc; i++) vol[i] = pr->grid.vor_volume[i] < 0.0 ? 0.0 : pr->grid.vor_volume[i];
+        HIPC(hipMalloc(&h->d_vor_sites, sizeof(double) * 3 * nc));
+        HIPC(hipMemcpy(h->d_vor_sites, pr->grid.vor_sites, sizeof(double) * 3 * nc, hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_vor_volume, sizeof(double) * nc));
+        HIPC(hipMemcpy(h->d_vor_volume, vol.data(), sizeof(double) * nc, hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_vor_idx, sizeof(int) * (nc + 1)));
+        HIPC(hipMemcpy(h->d_vor_idx, pr->grid.vor_idx, sizeof(int) * (nc + 1), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_vor_neigh, sizeof(int) * (nn ? nn : 1)));
+        HIPC(hipMemcpy(h->d_vor_neigh, pr->grid.vor_neighs, sizeof(int) * nn, hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_vor_seed, sizeof(int) * vor_seed.size()));
+        HIPC(hipMemcpy(h->d_vor_seed, vor_seed.data(), sizeof(int) * vor_seed.size(), hipMemcpyHostToDevice));
+        P.vor_sites = h->d_vor_sites; P.vor_volume = h->d_vor_volume; P.vor_idx = h->d_vor_idx;
+        P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g;
+        for (int k = 0; k < 6; k++) P.vor_box[k] = pr->grid.vor_box[k];
+    }
     if (is_oct) {
         HIPC(hipMalloc(&h->d_oct_cells, sizeof(OctCell) * oct_cells.size()));
         HIPC(hipMemcpy(h->d_oct_cells, oct_cells.data(), sizeof(OctCell) * oct_cells.size(), hipMemcpyHostToDevice));
@@ -561,6 +636,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (int d = 0; d < h->n_dust; d++)
                 for (size_t ic = 0; ic < h->n_cells; ic++)
                     if (oct_cells[ic].refined) dens[(size_t)d * h->n_cells + ic] = 0.0;
+        if (is_vor)   // mask = volume > 0: grid_geometry_voronoi.f90:161-173
+            for (int d = 0; d < h->n_dust; d++)
+                for (size_t ic = 0; ic < h->n_cells; ic++)
+                    if (!(pr->grid.vor_volume[ic] > 0.0)) dens[(size_t)d * h->n_cells + ic] = 0.0;
         HIPC(hipMemcpy(h->d_scratch, dens.data(), sizeof(double) * ne, hipMemcpyHostToDevice));
     }
     to_cell_major_kernel<<<1024, 256, 0, h->stream>>>(h->d_scratch, h->d_density, h->n_cells, h->n_dust);

@@ -16,13 +16,14 @@
 enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
-enum { GEOM_CAR = 0, GEOM_OCT = 1 };
+enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2 };
 
 // Where a packet is: Cartesian = three cell indices; octree = cell id plus a
 // register copy of the leaf's record (centre, level, parent, sub-cell).
 template <int GEOM> struct Cell;
 template <> struct Cell<GEOM_CAR> { int ic[3], ow[3]; };
 template <> struct Cell<GEOM_OCT> { int id, ow[3]; double c[3]; int parent, level, subcell; };
+template <> struct Cell<GEOM_VOR> { int id, ow[3]; };   // ow[1] = -(previous cell + 1)
 
 template <int NDT, int GEOM>
 struct Packet {
@@ -298,6 +299,114 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
     }
 }
 
+// ------------------------------- voronoi ------------------------------------
+// grid_geometry_voronoi.f90: walls are the bisector planes with the neighbouring
+// sites (CSR lists), the next cell is the neighbour itself.
+__device__ __forceinline__ double vor_dist2(const DProblem &P, int i, const double r[3])
+{
+    const double *s = P.vor_sites + 3 * (size_t)i;
+    double dx = s[0] - r[0], dy = s[1] - r[1], dz = s[2] - r[2];
+    return dx * dx + dy * dy + dz * dz;
+}
+
+// nearest site by steepest descent over the neighbour graph (the reference asks
+// a kd-tree, kdtree2_n_nearest :224; same answer)
+__device__ __forceinline__ int vor_nearest_from(const DProblem &P, const double r[3], int seed)
+{
+    int cur = seed;
+    double dcur = vor_dist2(P, cur, r);
+    for (;;) {
+        int best = cur; double dbest = dcur;
+        for (int k = P.vor_idx[cur]; k < P.vor_idx[cur + 1]; k++) {
+            int nb = P.vor_neigh[k];
+            if (nb < 0) continue;
+            double d = vor_dist2(P, nb, r);
+            if (d < dbest) { dbest = d; best = nb; }
+        }
+        if (best == cur) return cur;
+        cur = best; dcur = dbest;
+    }
+}
+
+__device__ __forceinline__ int vor_nearest(const DProblem &P, const double r[3])
+{
+    int g = P.vor_g, id[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        double f = (r[a] - P.vor_box[2 * a]) / (P.vor_box[2 * a + 1] - P.vor_box[2 * a]);
+        int i = (int)(f * g);
+        id[a] = i < 0 ? 0 : (i >= g ? g - 1 : i);
+    }
+    return vor_nearest_from(P, r, P.vor_seed[(id[2] * g + id[1]) * g + id[0]]);
+}
+
+__device__ __forceinline__ bool geo_escaped(const DProblem &P, const Cell<GEOM_VOR> &c) { return (unsigned long long)c.id == P.n_cells; }
+__device__ __forceinline__ size_t geo_index(const DProblem &P, const Cell<GEOM_VOR> &c) { return (size_t)c.id; }
+
+// find_cell :196-229 + place_in_cell :231-242
+__device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, const double r[3], const double v[3], Cell<GEOM_VOR> &c)
+{
+    if (r[0] < P.vor_box[0] || r[0] > P.vor_box[1] || r[1] < P.vor_box[2] || r[1] > P.vor_box[3] ||
+        r[2] < P.vor_box[4] || r[2] > P.vor_box[5]) return false;
+    c.id = vor_nearest(P, r);
+    return true;
+}
+
+// :274-283: the cell must be one of the two nearest sites
+__device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_VOR> &c)
+{
+    int n1 = vor_nearest_from(P, r, c.id);
+    if (n1 == c.id) return true;
+    int n2 = -1; double d2 = HYP_DBL_MAX;
+    for (int k = P.vor_idx[n1]; k < P.vor_idx[n1 + 1]; k++) {
+        int nb = P.vor_neigh[k];
+        if (nb < 0) continue;
+        double d = vor_dist2(P, nb, r);
+        if (d < d2) { d2 = d; n2 = nb; }
+    }
+    return n2 == c.id;
+}
+
+// find_wall :322-402; im = (next cell + 1, current cell + 1, 0)
+__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_VOR> &c, double &tnear, int im[3])
+{
+    const int ic = c.id;
+    const double *si = P.vor_sites + 3 * (size_t)ic;
+    const double s0 = si[0], s1 = si[1], s2 = si[2];
+    const int prev = -c.ow[1] - 1;
+    double tmin = HYP_DBL_MAX; int imin = -1; bool found = false;
+    for (int k = P.vor_idx[ic]; k < P.vor_idx[ic + 1]; k++) {
+        int nb = P.vor_neigh[k];
+        double t;
+        if (nb < 0) {
+            int w = -nb - 1, a = w >> 1, up = w & 1;
+            double va = a == 0 ? v[0] : a == 1 ? v[1] : v[2];
+            double ra = a == 0 ? r[0] : a == 1 ? r[1] : r[2];
+            if (up ? !(va > 0.0) : !(va < 0.0)) continue;
+            t = (P.vor_box[w] - ra) / va;
+            if (t > 0.0 && t < tmin) { tmin = t; imin = (int)P.n_cells; found = true; }
+            continue;
+        }
+        if (nb == prev) continue;
+        const double *so = P.vor_sites + 3 * (size_t)nb;
+        double n0 = so[0] - s0, n1 = so[1] - s1, n2 = so[2] - s2;
+        double m0 = 0.5 * (so[0] + s0), m1 = 0.5 * (so[1] + s1), m2 = 0.5 * (so[2] + s2);
+        t = (n0 * (m0 - r[0]) + n1 * (m1 - r[1]) + n2 * (m2 - r[2])) / (n0 * v[0] + n1 * v[1] + n2 * v[2]);
+        if (t > 0.0 && t < tmin) { tmin = t; imin = nb; found = true; }
+    }
+    tnear = tmin;
+    im[0] = found ? imin + 1 : 0; im[1] = ic + 1; im[2] = 0;
+    return found;
+}
+
+// next_cell_wall_id :266-272 (wall id = cell id) + opposite_wall
+__device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_VOR> &c, const int im[3])
+{
+    c.id = im[0] - 1;
+    c.ow[0] = -im[0]; c.ow[1] = -im[1]; c.ow[2] = -im[2];
+}
+
 template <int GEOM>
 __device__ __forceinline__ void geo_clear_wall(Cell<GEOM> &c) { c.ow[0] = c.ow[1] = c.ow[2] = 0; }
 
@@ -367,7 +476,7 @@ __device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
 // Returns false on a fatal error (flag raised).
 template <int NDT, int GEOM>
 __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
-                                            Counters &cnt, int &source_id)
+                                            Counters &cnt, int &source_id, Angle &src_normal)
 {
     int is = 0;
     if (P.n_sources > 1) {
@@ -380,8 +489,52 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     }
     source_id = is;
     const DSource &S = P.sources[is];
-    p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
-    random_sphere_angle(g, p.a);
+    src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
+    if (S.type == 1) {
+        // emit_from_point: source_type.f90:539-564
+        p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+        random_sphere_angle(g, p.a);
+    } else if (S.type == 5) {
+        // emit_from_extern_sph: source_type.f90:748-809
+        Angle a_coord, a_local;
+        random_sphere_angle(g, a_coord);
+        double sp, cp;
+        sincos(HYP_TWOPI * rng_uniform(g), &sp, &cp);
+        a_local.cosp = cp; a_local.sinp = sp;
+        a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        rotate_angle(a_local, a_coord, p.a);
+        p.a.cost = -p.a.cost; p.a.cosp = -p.a.cosp; p.a.sinp = -p.a.sinp;
+        double n0, n1, n2;
+        angle_to_vector(a_coord, n0, n1, n2);
+        p.r[0] = n0 * S.radius + S.pos[0]; p.r[1] = n1 * S.radius + S.pos[1]; p.r[2] = n2 * S.radius + S.pos[2];
+        src_normal = a_coord;
+        src_normal.cost = -a_coord.cost; src_normal.cosp = -a_coord.cosp; src_normal.sinp = -a_coord.sinp;
+    } else {
+        // emit_from_extern_box: source_type.f90:822-907
+        double xi = rng_uniform(g);
+        int face = 5;
+        for (int k = 0; k < 5; k++) if (xi < S.face_cdf[k]) { face = k; break; }
+        Angle a_local, a_coord;
+        double sp, cp;
+        sincos(HYP_TWOPI * rng_uniform(g), &sp, &cp);
+        a_local.cosp = cp; a_local.sinp = sp;
+        a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        const int axis = face >> 1, up = face & 1;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (k == axis) p.r[k] = S.box[2 * k + up];
+            else p.r[k] = S.box[2 * k] + (S.box[2 * k + 1] - S.box[2 * k]) * rng_uniform(g);
+        }
+        // inward normals as written in source_type.f90:864-899 (negative sin(theta) on the max faces)
+        a_coord.cost = axis == 2 ? (up ? -1.0 : 1.0) : 0.0;
+        a_coord.sint = axis == 2 ? 0.0 : (up ? -1.0 : 1.0);
+        a_coord.cosp = axis == 1 ? 0.0 : 1.0;
+        a_coord.sinp = axis == 1 ? 1.0 : 0.0;
+        rotate_angle(a_local, a_coord, p.a);
+        src_normal = a_coord;
+    }
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
     p.energy = 1.0;
     if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
@@ -653,7 +806,8 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                 else {
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id;
-                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id);
+                    Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
                     if (!ok) st = ST_NEED_EMIT;
                     else if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
@@ -831,9 +985,22 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                 a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
                 double s[4];
-                if (last_isotropic || last != LAST_DS) {
-                    s[0] = last_isotropic ? 1.0 : s_prev[0]; s[1] = last_isotropic ? 0.0 : s_prev[1];
-                    s[2] = last_isotropic ? 0.0 : s_prev[2]; s[3] = last_isotropic ? 0.0 : s_prev[3];
+                if (last_isotropic) {
+                    s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+                } else if (last == LAST_SR) {
+                    // source_emit_peeloff + emit_from_extern_{sph,box}_peeloff: source_type.f90:512-533,811-820,909-933
+                    // (a_prev holds the inward surface normal at the emission point)
+                    double mu = 0.0;
+                    if (P.sources[f.source_id].peeloff) {
+                        double n0, n1, n2, q0, q1, q2;
+                        angle_to_vector(a_prev, n0, n1, n2);
+                        angle_to_vector(a_req, q0, q1, q2);
+                        mu = q0 * n0 + q1 * n1 + q2 * n2;
+                        if (mu < 0.0) mu = 0.0;
+                    }
+                    s[0] = 4.0 * mu; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+                } else if (last != LAST_DS) {
+                    s[0] = s_prev[0]; s[1] = s_prev[1]; s[2] = s_prev[2]; s[3] = s_prev[3];
                 } else {
                     // dust_scatter_peeloff: dust_type_4elem.f90:421-444
                     const DDust &D = P.dust[f.dust_id];
@@ -963,10 +1130,16 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                 else {
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
-                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id);
+                    Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
-                    else { peel = 1; last = LAST_SR; last_iso = true; st = ST_DONE + 1; /* placed, awaiting tau */ }
+                    else {
+                        peel = 1; last = LAST_SR; st = ST_DONE + 1;   // placed, awaiting tau
+                        last_iso = P.sources[source_id].type == 1;
+                        // external sources: a_prev carries the inward normal for emit_peeloff
+                        if (!last_iso) a_prev = src_normal;
+                    }
                 }
             }
             if (__ballot(st == ST_DONE)) pool_empty = true;
@@ -1109,7 +1282,9 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
         size_t ic = k / nd;
         int d = (int)(k - ic * nd);
         double vol;
-        if (P.grid_type == 2) {
+        if (P.grid_type == 3) {
+            vol = P.vor_volume[ic];
+        } else if (P.grid_type == 2) {
             int lev = P.oct_cells[ic].level;
             vol = ldexp(P.oct_half[0], -lev) * ldexp(P.oct_half[1], -lev) * ldexp(P.oct_half[2], -lev) * 8.0;
         } else {

@@ -72,10 +72,14 @@ class Dust:
 
 @dataclass
 class Source:
-    """One ``/Sources/source_NNNNN`` group (point sources for now)."""
+    """One ``/Sources/source_NNNNN`` group: 'point', 'extern_sph' (position +
+    radius) or 'extern_box' (box = xmin,xmax,ymin,ymax,zmin,zmax)
+    (``src/sources/source_type.f90:102-322``)."""
     type: str = "point"
     luminosity: float = 0.0
     position: tuple = (0.0, 0.0, 0.0)
+    radius: float = 0.0
+    box: tuple = (0.0, 0.0, 0.0, 0.0, 0.0, 0.0)
     temperature: Optional[float] = None
     spectrum_nu: Optional[np.ndarray] = None
     spectrum_fnu: Optional[np.ndarray] = None
@@ -178,6 +182,13 @@ class Problem:
     refined: Optional[np.ndarray] = None
     oct_center: tuple = (0.0, 0.0, 0.0)
     oct_half: tuple = (1.0, 1.0, 1.0)
+    # grid_type 'vor' (src/grid/grid_geometry_voronoi.f90:96-188): sites (n,3),
+    # cell volumes, CSR neighbour lists (ids 0-based, -1..-6 = domain walls), box
+    vor_sites: Optional[np.ndarray] = None
+    vor_volume: Optional[np.ndarray] = None
+    vor_idx: Optional[np.ndarray] = None
+    vor_neighs: Optional[np.ndarray] = None
+    vor_box: tuple = (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)
 
     def __post_init__(self):
         self.walls = [_f64(w) for w in self.walls]
@@ -194,6 +205,17 @@ class Problem:
             if self.density.ndim == 1:
                 self.density = self.density[None]
             want = (len(self.dust), self.refined.size)
+        elif self.grid_type == "vor":
+            self.vor_sites = _f64(self.vor_sites).reshape(-1, 3)
+            self.vor_volume = _f64(self.vor_volume)
+            self.vor_idx = np.ascontiguousarray(self.vor_idx, dtype=np.int32)
+            self.vor_neighs = np.ascontiguousarray(self.vor_neighs, dtype=np.int32)
+            n = self.vor_sites.shape[0]
+            if self.vor_idx.size != n + 1 or self.vor_volume.size != n or self.vor_idx[-1] != self.vor_neighs.size:
+                raise ValueError("inconsistent Voronoi neighbour lists")
+            if self.density.ndim == 1:
+                self.density = self.density[None]
+            want = (len(self.dust), n)
         else:
             raise ValueError("Unexpected coordinate type: %s" % self.grid_type)
         if self.density.shape != want:
@@ -207,6 +229,8 @@ class Problem:
     def shape(self):
         if self.grid_type == "oct":
             return (self.refined.size,)
+        if self.grid_type == "vor":
+            return (self.vor_sites.shape[0],)
         return tuple(w.size - 1 for w in self.walls)
 
     @property
@@ -246,6 +270,8 @@ class Problem:
         if self.grid_type == "oct":
             _, h, _ = self.octree_cells()
             return 8.0 * h[:, 0] * h[:, 1] * h[:, 2]
+        if self.grid_type == "vor":
+            return np.maximum(self.vor_volume, 0.0)
         dx, dy, dz = (np.diff(w) for w in self.walls)
         return dz[:, None, None] * dy[None, :, None] * dx[None, None, :]
 
@@ -256,11 +282,14 @@ class Problem:
         arrays = {}
         meta = {"grid_type": self.grid_type, "geometry_id": self.geometry_id,
                 "config": self.config.__dict__, "dust": [], "sources": [], "peeled": [],
-                "oct_center": list(self.oct_center), "oct_half": list(self.oct_half)}
+                "oct_center": list(self.oct_center), "oct_half": list(self.oct_half), "vor_box": list(self.vor_box)}
         for i, w in enumerate(self.walls):
             arrays["walls_%d" % (i + 1)] = w
         if self.refined is not None:
             arrays["refined"] = self.refined
+        for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs"):
+            if getattr(self, k) is not None:
+                arrays[k] = getattr(self, k)
         arrays["density"] = self.density
         if self.specific_energy is not None:
             arrays["specific_energy"] = self.specific_energy
@@ -323,6 +352,8 @@ class Problem:
             kw.update(sub("source%d/" % i))
             if "position" in kw:
                 kw["position"] = tuple(kw["position"])
+            if "box" in kw:
+                kw["box"] = tuple(kw["box"])
             sources.append(Source(**kw))
         peeled = []
         for i, m in enumerate(meta["peeled"]):
@@ -342,4 +373,6 @@ class Problem:
                    grid_type=meta.get("grid_type", "car"), geometry_id=meta.get("geometry_id", ""),
                    refined=z["refined"] if "refined" in z.files else None,
                    oct_center=tuple(meta.get("oct_center", (0.0, 0.0, 0.0))),
-                   oct_half=tuple(meta.get("oct_half", (1.0, 1.0, 1.0))))
+                   oct_half=tuple(meta.get("oct_half", (1.0, 1.0, 1.0))),
+                   vor_box=tuple(meta.get("vor_box", (0.0, 1.0, 0.0, 1.0, 0.0, 1.0))),
+                   **{k: z[k] for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs") if k in z.files})

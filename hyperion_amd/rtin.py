@@ -104,6 +104,15 @@ def read_rtin(path):
             extra = dict(refined=np.asarray(geo["cells"][...]["refined"]).astype(np.int32),
                          oct_center=(float(ga["x"]), float(ga["y"]), float(ga["z"])),
                          oct_half=(float(ga["dx"]), float(ga["dy"]), float(ga["dz"])))
+        elif grid_type == "vor":
+            walls = []
+            ga = geo.attrs
+            cells = geo["cells"][...]
+            extra = dict(vor_sites=np.asarray(cells["coordinates"], dtype=float),
+                         vor_volume=np.asarray(cells["volume"], dtype=float),
+                         vor_idx=np.asarray(geo["sparse_idx"][...]).astype(np.int32),
+                         vor_neighs=np.asarray(geo["sparse_neighs"][...]).astype(np.int32),
+                         vor_box=tuple(float(ga[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")))
         else:
             raise NotImplementedError("grid type %r is not supported yet" % grid_type)
         q = f["Grid/Quantities"]
@@ -129,6 +138,11 @@ def read_rtin(path):
             s = Source(type=t, luminosity=float(sa["luminosity"]), peeloff=_b(sa["peeloff"]))
             if t == "point":
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+            elif t == "extern_sph":
+                s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+                s.radius = float(sa["r"])
+            elif t == "extern_box":
+                s.box = tuple(float(sa[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"))
             else:
                 raise NotImplementedError("source type %r is not supported yet" % t)
             st = _s(sa["spectrum"]).strip()

@@ -59,7 +59,7 @@ typedef struct hyp_dust_desc {
 
 /* /Sources/source_NNNNN -- src/sources/source_type.f90:102-322 */
 typedef struct hyp_source_desc {
-    int32_t type;          /* 1 point */
+    int32_t type;          /* 1 point, 5 extern_sph (position, radius), 6 extern_box (box) */
     int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
     int32_t peeloff;
     int32_t n_spec;
@@ -73,9 +73,10 @@ typedef struct hyp_source_desc {
 } hyp_source_desc;
 
 /* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),
- * src/grid/grid_geometry_octree.f90:184-246 (type 2) */
+ * src/grid/grid_geometry_octree.f90:184-246 (type 2),
+ * src/grid/grid_geometry_voronoi.f90:96-188 (type 3) */
 typedef struct hyp_grid_desc {
-    int32_t type;          /* 1 cartesian, 2 octree */
+    int32_t type;          /* 1 cartesian, 2 octree, 3 voronoi */
     int32_t n1, n2, n3;    /* cartesian: cells per axis */
     const double *w1;      /* cartesian: [n1+1] walls */
     const double *w2;
@@ -84,6 +85,12 @@ typedef struct hyp_grid_desc {
     const int32_t *refined;/* octree: [n_cells] depth-first refinement flags (table `cells`) */
     double oct_center[3];  /* octree: attrs x, y, z of the top cell */
     double oct_half[3];    /* octree: attrs dx, dy, dz (half-widths) */
+    /* voronoi (type 3), src/grid/grid_geometry_voronoi.f90:96-188; n_cells sites */
+    const double *vor_sites;    /* [n_cells][3] table cells.coordinates */
+    const double *vor_volume;   /* [n_cells] table cells.volume (<= 0: masked) */
+    const int32_t *vor_idx;     /* [n_cells+1] sparse_idx (CSR offsets) */
+    const int32_t *vor_neighs;  /* sparse_neighs: 0-based ids; -1..-6 = xmin,xmax,ymin,ymax,zmin,zmax walls */
+    double vor_box[6];          /* attrs xmin,xmax,ymin,ymax,zmin,zmax */
 } hyp_grid_desc;
 
 /* root attributes -- src/main/setup_rt.f90:38-302 */
@@ -138,7 +145,7 @@ typedef struct hyp_problem {
     const hyp_dust_desc   *dust;
     const hyp_source_desc *sources;
     const hyp_peeled_desc *peeled;
-    const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree), as in the .rtin */
+    const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree, voronoi), as in the .rtin */
     const double *specific_energy;   /* same shape, or NULL */
 } hyp_problem;
 

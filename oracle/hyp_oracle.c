@@ -268,10 +268,10 @@ static void rotate_angle(const angle_t *loc, const angle_t *co, angle_t *fin)
     if (cos_c < -1.0) cos_c = -1.0;
     double sin_c = sqrt(1.0 - cos_c * cos_c);
     double cos_B, sin_B;
-    if (sin_a < 1e-12 || sin_c < 1e-12) {
+    if (fabs(sin_a) < 1e-12 || sin_c < 1e-12) {
         /* old or new direction along the pole: azimuth difference is the
          * local azimuth itself (old at pole) or arbitrary (new at pole) */
-        if (sin_a < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
+        if (fabs(sin_a) < 1e-12) { cos_B = (cos_a > 0 ? -cos_C : cos_C); sin_B = sin_C; }
         else { cos_B = 1.0; sin_B = 0.0; }
     } else {
         cos_B = (cos_b - cos_a * cos_c) / (sin_a * sin_c);
@@ -336,7 +336,7 @@ typedef struct {
 
 typedef struct {
     int type, spectrum_type, peeloff;
-    double luminosity, temperature, position[3];
+    double luminosity, temperature, position[3], radius, box[6], face_cdf[6];
     pdf_t spectrum;
 } source_t;
 
@@ -350,7 +350,7 @@ typedef struct {
     size_t sed_size, img_size;
 } peeled_t;
 
-enum { GRID_CAR = 1, GRID_OCT = 2 };
+enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3 };
 
 struct orc_state {
     char err[512];
@@ -362,6 +362,12 @@ struct orc_state {
     uint8_t *orefined; int8_t *osubcell;
     int32_t *oparent, *ochildren;   /* ochildren[8*id + k] */
     double oct_eps, obox[6];
+    /* voronoi: type_grid_voronoi.f90 (0-based ids; walls -1..-6) */
+    double *vsite;              /* [n][3] */
+    int32_t *vidx, *vneigh;
+    double vbox[6];
+    int vg;                     /* seed grid for the nearest-site search: vg^3 cells */
+    int32_t *vseed;
     double *w[3], *ew[3];
     int n[3];
     double *volume;
@@ -594,6 +600,84 @@ static double spacing(double x)
 static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in);
 static void peeled_free(peeled_t *p);
 
+/* ---- voronoi: grid_geometry_voronoi.f90 -------------------------------- */
+
+static inline double vdist2(const orc_state *st, int32_t i, const double r[3])
+{
+    const double *s = st->vsite + 3 * (size_t)i;
+    double dx = s[0] - r[0], dy = s[1] - r[1], dz = s[2] - r[2];
+    return dx * dx + dy * dy + dz * dz;
+}
+
+/* nearest site by steepest descent over the neighbour (Delaunay) graph from
+ * `seed`: the reference uses a kd-tree (kdtree2_n_nearest, :224); both return the
+ * nearest site. */
+static int32_t vor_nearest_from(const orc_state *st, const double r[3], int32_t seed)
+{
+    int32_t cur = seed;
+    double dcur = vdist2(st, cur, r);
+    for (;;) {
+        int32_t best = cur; double dbest = dcur;
+        for (int32_t k = st->vidx[cur]; k < st->vidx[cur + 1]; k++) {
+            int32_t nb = st->vneigh[k];
+            if (nb < 0) continue;
+            double d = vdist2(st, nb, r);
+            if (d < dbest) { dbest = d; best = nb; }
+        }
+        if (best == cur) return cur;
+        cur = best; dcur = dbest;
+    }
+}
+
+static inline int vor_seed_cell(const orc_state *st, const double r[3])
+{
+    int g = st->vg, id[3];
+    for (int a = 0; a < 3; a++) {
+        double f = (r[a] - st->vbox[2 * a]) / (st->vbox[2 * a + 1] - st->vbox[2 * a]);
+        int i = (int)(f * g);
+        id[a] = i < 0 ? 0 : (i >= g ? g - 1 : i);
+    }
+    return (id[2] * g + id[1]) * g + id[0];
+}
+
+static int32_t vor_nearest(const orc_state *st, const double r[3])
+{
+    return vor_nearest_from(st, r, st->vseed[vor_seed_cell(st, r)]);
+}
+
+static int voronoi_setup(orc_state *st, const orc_grid_desc *gd)
+{
+    size_t n = (size_t)gd->n_cells;
+    if (n < 1 || !gd->vor_sites || !gd->vor_idx || !gd->vor_neighs || !gd->vor_volume) {
+        snprintf(g_error, sizeof g_error, "voronoi grid needs sites, volumes and neighbour lists"); return 1;
+    }
+    st->n_cells = n;
+    st->vsite = dup(gd->vor_sites, 3 * n);
+    st->vidx = malloc(sizeof(int32_t) * (n + 1)); memcpy(st->vidx, gd->vor_idx, sizeof(int32_t) * (n + 1));
+    size_t nn = (size_t)st->vidx[n];
+    st->vneigh = malloc(sizeof(int32_t) * (nn ? nn : 1)); memcpy(st->vneigh, gd->vor_neighs, sizeof(int32_t) * nn);
+    for (size_t k = 0; k < nn; k++)
+        if (st->vneigh[k] < -6 || st->vneigh[k] >= (int32_t)n) { snprintf(g_error, sizeof g_error, "neighbour index out of range"); return 1; }
+    memcpy(st->vbox, gd->vor_box, sizeof st->vbox);
+    st->volume = malloc(sizeof(double) * n);
+    for (size_t i = 0; i < n; i++) st->volume[i] = gd->vor_volume[i] < 0.0 ? 0.0 : gd->vor_volume[i];
+    /* seed grid: nearest site of each grid-cell centre (walk from the previous answer) */
+    int g = (int)ceil(cbrt((double)n / 4.0));
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    st->vg = g;
+    st->vseed = malloc(sizeof(int32_t) * (size_t)g * g * g);
+    int32_t last = 0;
+    for (int k = 0; k < g; k++) for (int j = 0; j < g; j++) for (int i = 0; i < g; i++) {
+        double c[3] = {st->vbox[0] + (i + 0.5) / g * (st->vbox[1] - st->vbox[0]),
+                       st->vbox[2] + (j + 0.5) / g * (st->vbox[3] - st->vbox[2]),
+                       st->vbox[4] + (k + 0.5) / g * (st->vbox[5] - st->vbox[4])};
+        last = vor_nearest_from(st, c, last);
+        st->vseed[((size_t)k * g + j) * g + i] = last;
+    }
+    return 0;
+}
+
 /* setup_grid_geometry + octree_setup_indiv: grid_geometry_octree.f90:147-246.
  * Cells are numbered depth-first (pre-order) as the `refined` list is read. */
 static int octree_setup(orc_state *st, const orc_grid_desc *gd)
@@ -651,7 +735,7 @@ int orc_create(const orc_problem *pr, orc_state **out)
 {
     g_error[0] = 0;
     if (!pr || !out) { snprintf(g_error, sizeof g_error, "null argument"); return 1; }
-    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
+    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT && pr->grid.type != GRID_VOR) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
@@ -678,8 +762,10 @@ int orc_create(const orc_problem *pr, orc_state **out)
         for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++)
             st->volume[((size_t)k * st->n2 + j) * st->n1 + i] =
                 (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
-    } else {
+    } else if (st->grid_type == GRID_OCT) {
         if (octree_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
+    } else {
+        if (voronoi_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     }
 
     st->n_dust = pr->n_dust;
@@ -699,7 +785,15 @@ int orc_create(const orc_problem *pr, orc_state **out)
         t->type = s->type; t->spectrum_type = s->spectrum_type; t->peeloff = s->peeloff;
         t->luminosity = s->luminosity; t->temperature = s->temperature;
         memcpy(t->position, s->position, sizeof t->position);
-        if (s->type != 1) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        if (s->type != 1 && s->type != 5 && s->type != 6) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        t->radius = s->radius; memcpy(t->box, s->box, sizeof t->box);
+        if (s->type == 6) {   /* source_type.f90:233-237: face pdf ~ face areas */
+            double dx = s->box[1] - s->box[0], dy = s->box[3] - s->box[2], dz = s->box[5] - s->box[4];
+            double a[6] = {dy * dz, dy * dz, dz * dx, dz * dx, dx * dy, dx * dy}, c = 0.0, tot = 0.0;
+            for (int k = 0; k < 6; k++) tot += a[k];
+            for (int k = 0; k < 6; k++) { c += a[k] / tot; t->face_cdf[k] = c; }
+            for (int k = 0; k < 6; k++) t->face_cdf[k] /= c;
+        }
         if (s->spectrum_type == 1) {
             for (int k = 0; k + 1 < s->n_spec; k++)
                 if (s->spec_nu[k + 1] < s->spec_nu[k]) {
@@ -710,7 +804,9 @@ int orc_create(const orc_problem *pr, orc_state **out)
                 snprintf(g_error, sizeof g_error, "source spectrum has zero integral"); orc_destroy(st); return 1;
             }
         } else if (s->spectrum_type != 2) {
-            snprintf(g_error, sizeof g_error, "Point source cannot have LTE spectrum"); orc_destroy(st); return 1;
+            snprintf(g_error, sizeof g_error, "%s cannot have LTE spectrum",
+                     s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : "Point source");
+            orc_destroy(st); return 1;
         }
         st->energy_total += s->luminosity;
     }
@@ -729,6 +825,10 @@ int orc_create(const orc_problem *pr, orc_state **out)
         for (int d = 0; d < st->n_dust; d++)
             for (size_t ic = 0; ic < st->n_cells; ic++)
                 if (st->orefined[ic]) st->density[(size_t)d * st->n_cells + ic] = 0.0;
+    if (st->grid_type == GRID_VOR)   /* mask = volume > 0: grid_geometry_voronoi.f90:161-173 */
+        for (int d = 0; d < st->n_dust; d++)
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                if (!(st->volume[ic] > 0.0)) st->density[(size_t)d * st->n_cells + ic] = 0.0;
     st->specific_energy = malloc(sizeof(double) * (ntot ? ntot : 1));
     st->specific_energy_sum = calloc(ntot ? ntot : 1, sizeof(double));
     st->jnu_var_id = calloc(ntot ? ntot : 1, sizeof(int32_t));
@@ -768,6 +868,7 @@ void orc_destroy(orc_state *st)
     free(st->volume);
     free(st->ox); free(st->oy); free(st->oz); free(st->odx); free(st->ody); free(st->odz);
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
+    free(st->vsite); free(st->vidx); free(st->vneigh); free(st->vseed);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
@@ -795,8 +896,9 @@ typedef struct {
     int on_wall[3];     /* -1 lower wall, +1 upper wall, 0 none */
     int in_cell, killed;
     double chi[ORC_MAX_DUST], albedo[ORC_MAX_DUST], kappa[ORC_MAX_DUST];
-    int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id;
+    int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id, face_id;
     angle_t a_prev; double s_prev[4], v_prev[3];
+    angle_t source_a;   /* inward normal at the emission point of an external source */
 } photon_t;
 
 typedef struct {
@@ -836,7 +938,7 @@ static int update_optconsts(const orc_state *st, photon_t *p, acc_t *acc)
 
 static inline size_t cell_index(const orc_state *st, const int ic[3])
 {
-    if (st->grid_type == GRID_OCT) return (size_t)ic[0];
+    if (st->grid_type != GRID_CAR) return (size_t)ic[0];
     return ((size_t)ic[2] * st->n2 + ic[1]) * st->n1 + ic[0];
 }
 
@@ -844,7 +946,7 @@ static inline size_t cell_index(const orc_state *st, const int ic[3])
 static inline int escaped(const orc_state *st, const int ic[3])
 {
     /* octree: escaped_cell grid_geometry_octree.f90:320-326 (ic == n_cells+1) */
-    if (st->grid_type == GRID_OCT) return (size_t)ic[0] == st->n_cells;
+    if (st->grid_type != GRID_CAR) return (size_t)ic[0] == st->n_cells;
     return ic[0] < 0 || ic[0] >= st->n1 || ic[1] < 0 || ic[1] >= st->n2 || ic[2] < 0 || ic[2] >= st->n3;
 }
 
@@ -882,6 +984,13 @@ static int32_t oct_next_cell(const orc_state *st, int32_t id, int wall, const do
 /* find_cell :143-166 (car) / :260-283 (oct); returns 0 if outside */
 static int find_cell(const orc_state *st, const double r[3], int ic[3])
 {
+    if (st->grid_type == GRID_VOR) {   /* grid_geometry_voronoi.f90:196-229 */
+        if (r[0] < st->vbox[0] || r[0] > st->vbox[1]) return 0;
+        if (r[1] < st->vbox[2] || r[1] > st->vbox[3]) return 0;
+        if (r[2] < st->vbox[4] || r[2] > st->vbox[5]) return 0;
+        ic[0] = vor_nearest(st, r); ic[1] = ic[2] = 0;
+        return 1;
+    }
     if (st->grid_type == GRID_OCT) {
         if (r[0] < st->obox[0] || r[0] > st->obox[1]) return 0;
         if (r[1] < st->obox[2] || r[1] > st->obox[3]) return 0;
@@ -932,6 +1041,18 @@ static int in_correct_cell(const orc_state *st, const photon_t *p)
     int found = find_cell(st, p->r, act);
     const double thr = 1e-3;
     int on_wall = p->on_wall[0] || p->on_wall[1] || p->on_wall[2];
+    if (st->grid_type == GRID_VOR) {   /* :274-283: the cell must be one of the two nearest sites */
+        int32_t n1 = vor_nearest_from(st, p->r, p->ic[0]);
+        if (n1 == p->ic[0]) return 1;
+        int32_t n2 = -1; double d2 = DBL_MAX;
+        for (int32_t k = st->vidx[n1]; k < st->vidx[n1 + 1]; k++) {
+            int32_t nb = st->vneigh[k];
+            if (nb < 0) continue;
+            double d = vdist2(st, nb, p->r);
+            if (d < d2) { d2 = d; n2 = nb; }
+        }
+        return n2 == p->ic[0];
+    }
     if (st->grid_type == GRID_OCT) {   /* grid_geometry_octree.f90:366-392 */
         int32_t id = p->ic[0];
         if (on_wall) {
@@ -992,9 +1113,44 @@ static int find_wall_oct(const orc_state *st, const photon_t *p, double *tneares
     return id_min[0] || id_min[1] || id_min[2];
 }
 
+/* find_wall: grid_geometry_voronoi.f90:322-402.  id_min = (next cell + 1, current cell + 1, 0) */
+static int find_wall_vor(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    int32_t ic = p->ic[0];
+    const double *si = st->vsite + 3 * (size_t)ic;
+    int32_t prev = -p->on_wall[1] - 1;      /* cell just left (on_wall_id%w2), -1 if none */
+    double tmin = DBL_MAX; int32_t imin = -1; int found = 0;
+    for (int32_t k = st->vidx[ic]; k < st->vidx[ic + 1]; k++) {
+        int32_t nb = st->vneigh[k];
+        double t;
+        if (nb < 0) {
+            int w = -nb - 1, a = w >> 1, up = w & 1;     /* 0..5 = xmin,xmax,ymin,ymax,zmin,zmax */
+            if (up ? !(p->v[a] > 0.0) : !(p->v[a] < 0.0)) continue;
+            t = (st->vbox[w] - p->r[a]) / p->v[a];
+            if (t > 0.0 && t < tmin) { tmin = t; imin = (int32_t)st->n_cells; found = 1; }
+            continue;
+        }
+        if (nb == prev) continue;
+        const double *so = st->vsite + 3 * (size_t)nb;
+        double n[3] = {so[0] - si[0], so[1] - si[1], so[2] - si[2]};
+        double m[3] = {0.5 * (so[0] + si[0]), 0.5 * (so[1] + si[1]), 0.5 * (so[2] + si[2])};
+        t = (n[0] * (m[0] - p->r[0]) + n[1] * (m[1] - p->r[1]) + n[2] * (m[2] - p->r[2])) /
+            (n[0] * p->v[0] + n[1] * p->v[1] + n[2] * p->v[2]);
+        if (t > 0.0 && t < tmin) { tmin = t; imin = nb; found = 1; }
+    }
+    *tnearest = tmin;
+    id_min[0] = found ? imin + 1 : 0; id_min[1] = ic + 1; id_min[2] = 0;
+    return found;
+}
+
 /* p%icell = next_cell(p%icell, id_min, intersection=p%r); p%on_wall_id = opposite_wall(id_min) */
 static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
 {
+    if (st->grid_type == GRID_VOR) {   /* next_cell_wall_id :266-272: wall id = cell id */
+        p->ic[0] = id_min[0] - 1;
+        for (int a = 0; a < 3; a++) p->on_wall[a] = -id_min[a];
+        return;
+    }
     if (st->grid_type == GRID_OCT) {
         /* next_cell_wall_id :349-364: the first non-zero component decides */
         int wall = id_min[0] ? (id_min[0] > 0 ? 1 : 0) : id_min[1] ? (id_min[1] > 0 ? 3 : 2) : (id_min[2] > 0 ? 5 : 4);
@@ -1008,6 +1164,7 @@ static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
 static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
 {
     if (st->grid_type == GRID_OCT) return find_wall_oct(st, p, tnearest, id_min);
+    if (st->grid_type == GRID_VOR) return find_wall_vor(st, p, tnearest, id_min);
     double tmin = DBL_MAX, emin = 0.0;
     int imin[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
@@ -1127,6 +1284,14 @@ static double random_planck_frequency(rng_t *g, double T)
     return x * K_CGS * T / H_CGS;
 }
 
+/* inward normals of the six box faces as written in source_type.f90:864-899
+ * (note the negative sin(theta) used for the "max" faces) */
+static void box_face_normal(int face, angle_t *a)
+{
+    static const double tab[6][4] = {{0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, 1}, {0, -1, 0, 1}, {1, 0, 1, 0}, {-1, 0, 1, 0}};
+    a->cost = tab[face][0]; a->sint = tab[face][1]; a->cosp = tab[face][2]; a->sinp = tab[face][3];
+}
+
 static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
 {
     memset(p, 0, sizeof(*p));
@@ -1138,11 +1303,45 @@ static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
     }
     p->source_id = is;
     const source_t *s = &st->src[is];
-    /* emit_from_point :539-564 */
-    p->r[0] = s->position[0]; p->r[1] = s->position[1]; p->r[2] = s->position[2];
-    random_sphere_angle(g, &p->a);
+    if (s->type == 1) {
+        /* emit_from_point :539-564 */
+        p->r[0] = s->position[0]; p->r[1] = s->position[1]; p->r[2] = s->position[2];
+        random_sphere_angle(g, &p->a);
+        p->last_isotropic = 1;
+    } else if (s->type == 5) {
+        /* emit_from_extern_sph :748-809 */
+        angle_t a_coord, a_local;
+        random_sphere_angle(g, &a_coord);
+        double phi = TWOPI * rng_uniform(g);
+        a_local.cosp = cos(phi); a_local.sinp = sin(phi);
+        a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        rotate_angle(&a_local, &a_coord, &p->a);
+        p->a.cost = -p->a.cost; p->a.cosp = -p->a.cosp; p->a.sinp = -p->a.sinp;   /* point inwards */
+        double n[3]; angle_to_vector(&a_coord, n);
+        for (int k = 0; k < 3; k++) p->r[k] = n[k] * s->radius + s->position[k];
+        p->last_isotropic = 0;
+        p->source_a = a_coord;
+        p->source_a.cost = -a_coord.cost; p->source_a.cosp = -a_coord.cosp; p->source_a.sinp = -a_coord.sinp;
+    } else {
+        /* emit_from_extern_box :822-907 */
+        int face = sample_discrete(s->face_cdf, 6, rng_uniform(g));
+        angle_t a_local, a_coord;
+        double phi = TWOPI * rng_uniform(g);
+        a_local.cosp = cos(phi); a_local.sinp = sin(phi);
+        a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        int axis = face >> 1, up = face & 1;
+        for (int k = 0; k < 3; k++) {
+            if (k == axis) p->r[k] = s->box[2 * k + up];
+            else p->r[k] = s->box[2 * k] + (s->box[2 * k + 1] - s->box[2 * k]) * rng_uniform(g);
+        }
+        box_face_normal(face, &a_coord);
+        rotate_angle(&a_local, &a_coord, &p->a);
+        p->last_isotropic = 0;
+        p->face_id = face;
+    }
     p->s[0] = 1.0; p->s[1] = p->s[2] = p->s[3] = 0.0;
-    p->last_isotropic = 1;
     p->energy = 1.0;
     if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
     else p->nu = random_planck_frequency(g, s->temperature);
@@ -1572,7 +1771,16 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
                 p.a = a_req; memcpy(p.v, v_req, sizeof v_req);
             } else {
                 if (p.last == LAST_SR) {
-                    /* source_emit_peeloff: point sources are isotropic -> never here */
+                    /* source_emit_peeloff :512-533, emit_from_extern_*_peeloff :811-820,909-933 */
+                    const source_t *src = &st->src[p.source_id];
+                    if (src->peeloff) {
+                        angle_t nrm;
+                        if (src->type == 5) nrm = p.source_a; else box_face_normal(p.face_id, &nrm);
+                        double vn[3]; angle_to_vector(&nrm, vn);
+                        double mu = v_req[0] * vn[0] + v_req[1] * vn[1] + v_req[2] * vn[2];
+                        if (mu < 0.0) mu = 0.0;
+                        p.s[0] = 4.0 * mu; p.s[1] = p.s[2] = p.s[3] = 0.0;
+                    } else { p.s[0] = p.s[1] = p.s[2] = p.s[3] = 0.0; }
                     p.a = a_req;
                 } else if (p.last == LAST_DS) {
                     dust_scatter_peeloff(&st->dust[p.dust_id], p.nu, &p.a, p.s, &a_req);

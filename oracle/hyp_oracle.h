@@ -61,7 +61,7 @@ typedef struct orc_dust_desc {
 
 /* One source (reader: src/sources/source_type.f90:102-322). */
 typedef struct orc_source_desc {
-    int32_t type;          /* 1 point; (5 extern_sph, 6 extern_box: later) */
+    int32_t type;          /* 1 point, 5 extern_sph, 6 extern_box */
     int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
     int32_t peeloff;
     int32_t n_spec;
@@ -76,7 +76,7 @@ typedef struct orc_source_desc {
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */
 typedef struct orc_grid_desc {
-    int32_t type;          /* 1 = cartesian, 2 = octree */
+    int32_t type;          /* 1 = cartesian, 2 = octree, 3 = voronoi */
     int32_t n1, n2, n3;
     const double *w1;      /* [n1+1] */
     const double *w2;      /* [n2+1] */
@@ -87,6 +87,12 @@ typedef struct orc_grid_desc {
     const int32_t *refined;
     double oct_center[3];
     double oct_half[3];
+    /* voronoi (type 3, src/grid/grid_geometry_voronoi.f90:96-188) */
+    const double *vor_sites;     /* [n_cells][3] */
+    const double *vor_volume;    /* [n_cells] */
+    const int32_t *vor_idx;      /* [n_cells+1] CSR offsets (sparse_idx) */
+    const int32_t *vor_neighs;   /* neighbour ids, -1..-6 = xmin,xmax,ymin,ymax,zmin,zmax walls */
+    double vor_box[6];
 } orc_grid_desc;
 
 /* Run configuration: the root attributes of the .rtin

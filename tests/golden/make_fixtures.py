@@ -9,7 +9,8 @@ Run (only where /root/reference exists; the GPU box never runs this):
     echo "version = '0.9.12.dev0'" > /tmp/hyp_probe/hyperion/_version.py
     (cd /tmp/hyp_probe && chmod -R u+w . && /opt/conda/bin/python3.9 setup.py build_ext --inplace)
     # then
-    /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
+    LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
+    (the preload lets conda's python load the voro++ extension built with the system g++)
 
 What it writes (inputs + expected outputs only); {grid} = car, oct:
 
@@ -32,6 +33,15 @@ What it writes (inputs + expected outputs only); {grid} = car, oct:
   rtout_layout.car_peeloff.json
       names / shapes / attribute types of every object in the reference's golden
       test_peeloff.grid_type=car.raytracing=False.sample_sources_evenly=False.rtout
+  vor_config5.npz, vor_lattice.npz
+      INPUTS ONLY (the reference ships no Voronoi regression output): Voronoi
+      tessellations computed by the reference front-end (voro++ through
+      hyperion.grid.VoronoiGrid) and written/read through the .rtin contract.
+      vor_config5 = small BASELINE config 5: 400 random sites, two
+      Henyey-Greenstein dust species (hyperion/dust/dust_type.py:550-586),
+      a point source plus an external box source, one peeled image group.
+      vor_lattice = sites on a slightly jittered 6^3 lattice with the grey test
+      dust and a central source (compared against the Cartesian grid in tests).
   kmh_lite.npz
       the tables of hyperion/model/tests/data/kmh_lite.hdf5 (version-1 dust file,
       polarised anisotropic scattering), referenced by the model fixtures
@@ -64,8 +74,8 @@ for name, t in [("float", float), ("int", int), ("bool", bool), ("object", objec
 
 import h5py  # noqa: E402
 from hyperion.model import Model  # noqa: E402
-from hyperion.grid import CartesianGrid, OctreeGrid  # noqa: E402
-from hyperion.dust import IsotropicDust  # noqa: E402
+from hyperion.grid import CartesianGrid, OctreeGrid, VoronoiGrid  # noqa: E402
+from hyperion.dust import IsotropicDust, HenyeyGreensteinDust  # noqa: E402
 from hyperion.util.constants import pc, lsun  # noqa: E402
 
 from hyperion_amd.rtin import read_rtin, read_dust_group  # noqa: E402
@@ -232,6 +242,63 @@ def main():
                     specific_energy_fixture(gt, grids[gt], denss[gt], evenly, multi, tmp)
             for evenly in (False, True):
                 peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp)
+
+        # --- Voronoi inputs (BASELINE config 5, small) ----------------------------------
+        np.random.seed(141412)
+        n = 400
+        x, y, z = [np.random.uniform(-pc, pc, n) for _ in range(3)]
+        g = VoronoiGrid(x, y, z, xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
+        nu = [3.e7, 1.e10, 2.e11, 2.e12, 2.e13, 2.e14, 2.e15, 2.e16, 2.e17]
+        chi = [1.e-11, 2.e-6, 2.e-3, 0.2, 13., 90., 1000., 700., 700.]
+        alb = [0., 0., 0., 0., 0.1, 0.5, 0.4, 0.4, 0.4]
+        m = Model()
+        m.set_grid(g)
+        for gg, pl, scale in ((0.6, 0.5, 1.0), (0.3, 0.2, 0.5)):
+            d = HenyeyGreensteinDust(nu, alb, np.array(chi) * scale, np.repeat(gg, 9), np.repeat(pl, 9))
+            d.set_lte_emissivities(n_temp=20, temp_min=0.1, temp_max=10000.)
+            m.add_density_grid(np.random.random(g.shape) * 2.e-21, d)
+        s = m.add_point_source()
+        s.luminosity = lsun
+        s.temperature = 6000.
+        s.position = (0.1 * pc, -0.05 * pc, 0.2 * pc)
+        e = m.add_external_box_source()
+        e.luminosity = 2 * lsun
+        e.temperature = 3000.
+        e.bounds = [[-pc, pc], [-pc, pc], [-pc, pc]]
+        m.set_n_photons(initial=10000, imaging=10000)
+        i_p = m.add_peeled_images()
+        i_p.set_wavelength_range(4, 0.1, 1000.)
+        i_p.set_viewing_angles([40., 120.], [30., 250.])
+        i_p.set_image_size(8, 8)
+        i_p.set_image_limits(-1.5 * pc, 1.5 * pc, -1.5 * pc, 1.5 * pc)
+        i_p.set_aperture_radii(3, 0.3 * pc, 2 * pc)
+        i_p.set_track_origin('basic')
+        i_p.set_stokes(True)
+        path = os.path.join(tmp, "vor5.rtin")
+        m.write(path, copy=True)
+        read_rtin(path).to_npz(os.path.join(HERE, "vor_config5.npz"))
+        print("wrote", os.path.join(HERE, "vor_config5.npz"))
+
+        k = 6
+        c = (np.arange(k) + 0.5) / k * 2 - 1
+        zz, yy, xx = np.meshgrid(c, c, c, indexing="ij")
+        jit = np.random.uniform(-1e-3, 1e-3, (3, k ** 3))
+        g = VoronoiGrid((xx.ravel() + jit[0]) * pc, (yy.ravel() + jit[1]) * pc, (zz.ravel() + jit[2]) * pc,
+                        xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
+        d = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
+        d.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)
+        m = Model()
+        m.set_grid(g)
+        m.add_density_grid(np.ones(g.shape) / pc, d)
+        s = m.add_point_source()
+        s.luminosity = lsun
+        s.temperature = 6000.
+        s.position = (0.03 * pc, 0.02 * pc, 0.01 * pc)
+        m.set_n_photons(initial=10000, imaging=0)
+        path = os.path.join(tmp, "vorl.rtin")
+        m.write(path, copy=True)
+        read_rtin(path).to_npz(os.path.join(HERE, "vor_lattice.npz"))
+        print("wrote", os.path.join(HERE, "vor_lattice.npz"))
 
         # --- layout of the golden .rtout (names, shapes, attribute types) ------
         import json

@@ -1,0 +1,112 @@
+"""Voronoi grid (src/grid/grid_geometry_voronoi.f90), external sources
+(source_type.f90:748-933) and multi-species Henyey-Greenstein dust on the GPU:
+BASELINE config 5 in small, against the CPU oracle on identical Philox streams."""
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import assert_parity, golden_problem
+from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem, make_octree_problem
+from hyperion_amd.problem import PeeledImages, Source
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
+
+
+def run_both(prob, n, iters=1, n_img=0):
+    eng = hyperion_amd.Engine(prob)
+    orc = Oracle(prob)
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+        assert_parity(a, b)
+    res = None
+    if n_img:
+        ra, sa = eng.final_iteration(n_img)
+        rb, sb = orc.final_iteration(n_img)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        for ga, gb in zip(ra, rb):
+            for name in gb:
+                np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
+        res = ra
+    eng.close(); orc.close()
+    return a, sa, res
+
+
+def test_config5_small_voronoi_hg_dust_external_source():
+    prob, _ = golden_problem("vor_config5.npz")
+    assert prob.grid_type == "vor" and prob.n_dust == 2 and [s.type for s in prob.sources] == ["point", "extern_box"]
+    a, st, res = run_both(prob, 60000, iters=3, n_img=40000)
+    assert st["killed_int"] == 0
+    assert res[0]["sed"].shape == (4, 4, 2, 3, 4)
+    assert np.abs(res[0]["sed"][1]).max() > 0          # HG dust with p_lin_max > 0 polarises
+
+
+def test_voronoi_lattice_equals_cartesian():
+    """Sites on a (1e-3 jittered) 6^3 lattice tessellate into the cells of a 6^3
+    Cartesian grid: same Philox streams, same interactions, cell energies within
+    the jitter."""
+    pv, _ = golden_problem("vor_lattice.npz")
+    a, sa, _ = run_both(pv, 200000)
+    pc_ = make_benchmark_problem(6)
+    pc_.sources[0].position = pv.sources[0].position
+    eng = hyperion_amd.Engine(pc_)
+    b, sb = eng.lucy_iteration(200000, 1)
+    assert sa["interactions"] == sb["interactions"]
+    w = np.linspace(-1, 1, 7) * PC
+    ix, iy, iz = (np.searchsorted(w, pv.vor_sites[:, k]) - 1 for k in range(3))
+    np.testing.assert_allclose(a[0], b[0][iz, iy, ix], rtol=0.02, atol=0.01 * b.max())
+    assert a.sum() == pytest.approx(b.sum(), rel=1e-3)
+
+
+@pytest.mark.parametrize("grid", ["car", "oct", "vor"])
+@pytest.mark.parametrize("kind", ["extern_box", "extern_sph"])
+def test_external_sources_on_every_grid(grid, kind):
+    if grid == "car":
+        p = make_benchmark_problem(8, tau=0.7)
+    elif grid == "oct":
+        p = make_octree_problem(max_level=4, imaging=False)
+    else:
+        p, _ = golden_problem("vor_lattice.npz")
+    if kind == "extern_box":
+        src = Source(type="extern_box", luminosity=LSUN, temperature=4000.0, box=(-PC, PC, -PC, PC, -PC, PC))
+    else:
+        src = Source(type="extern_sph", luminosity=LSUN, temperature=4000.0, position=(0.0, 0.0, 0.0), radius=0.95 * PC)
+    p.sources = [src, Source(type="point", luminosity=0.5 * LSUN, temperature=7000.0, position=(0.11 * PC, 0.07 * PC, -0.13 * PC))]
+    p.peeled = [PeeledImages(theta=[35.0, 140.0], phi=[20.0, 200.0], n_wav=2, wav_min=0.1, wav_max=1000.0, n_x=6, n_y=6,
+                             x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.5 * PC,
+                             ap_max=2 * PC, track_origin="detailed")]
+    run_both(p, 30000, iters=2, n_img=30000)
+
+
+def test_external_box_gives_uniform_isotropic_field():
+    """Lambertian emission from the faces of a closed box fills it with a uniform
+    isotropic radiation field: in the optically thin limit every cell absorbs
+    4 kappa L / A per unit mass (A = total face area)."""
+    p = make_benchmark_problem(10, tau=1e-6)
+    p.sources = [Source(type="extern_box", luminosity=LSUN, temperature=5000.0, box=(-PC, PC, -PC, PC, -PC, PC))]
+    eng = hyperion_amd.Engine(p)
+    se, st = eng.lucy_iteration(2_000_000, 1)
+    expect = 4.0 * 0.5 * LSUN / (24.0 * PC * PC)
+    assert se.mean() == pytest.approx(expect, rel=5e-3)
+    assert se.std() / se.mean() < 0.03
+
+
+def test_unpeeled_external_source_and_messages():
+    p = make_benchmark_problem(6)
+    p.sources = [Source(type="extern_sph", luminosity=LSUN, temperature=4000.0, radius=0.9 * PC, peeloff=False)]
+    p.peeled = [PeeledImages(theta=[50.0], phi=[10.0], n_wav=1, wav_min=0.01, wav_max=1e5, compute_image=False,
+                             n_ap=1, ap_min=3 * PC, ap_max=3 * PC, track_origin="basic")]
+    a, st, res = run_both(p, 20000, n_img=20000)
+    assert res[0]["sed"][0, 0].sum() == 0.0            # direct source light is not peeled
+    assert res[0]["sed"][0, 1:].sum() > 0.0            # dust emission / scattered light is
+    p.sources[0].type = "extern_box"
+    p.sources[0].box = (-9 * PC, 9 * PC, -PC, PC, -PC, PC)     # box sticks out of the grid
+    eng = hyperion_amd.Engine(p)
+    with pytest.raises(hyperion_amd.EngineError, match="photon was not emitted inside a cell"):
+        eng.lucy_iteration(1000, 1)

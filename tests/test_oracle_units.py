@@ -226,3 +226,27 @@ def test_rotate_and_difference_are_inverse_and_geometric():
         s = np.sin(dphi)
         if abs(s) > 1e-9:
             assert (s > 0) == (np.sin(pl) > 0)
+
+
+def test_external_box_source_uniform_field_and_voronoi_lattice():
+    """Oracle-level checks of the pieces that have no reference golden: (a) a
+    Lambertian box source fills the box with a uniform isotropic field,
+    E = 4 kappa L / A in the thin limit (source_type.f90:822-907); (b) a Voronoi
+    tessellation of a (jittered) cubic lattice reproduces the Cartesian result on
+    the same Philox streams (grid_geometry_voronoi.f90:322-402)."""
+    from hyperion_amd.benchmark import LSUN
+    p = make_benchmark_problem(8, tau=1e-6)
+    p.sources = [Source(type="extern_box", luminosity=LSUN, temperature=5000.0, box=(-PC, PC, -PC, PC, -PC, PC))]
+    se, st = Oracle(p).lucy_iteration(400000, 1)
+    assert st["killed_geo"] == 0
+    assert se.mean() == pytest.approx(4.0 * 0.5 * LSUN / (24.0 * PC * PC), rel=1e-2)
+    assert se.std() / se.mean() < 0.05
+    pv, _ = golden_problem("vor_lattice.npz")
+    a, sa = Oracle(pv).lucy_iteration(100000, 1)
+    pc_ = make_benchmark_problem(6)
+    pc_.sources[0].position = pv.sources[0].position
+    b, sb = Oracle(pc_).lucy_iteration(100000, 1)
+    assert sa["interactions"] == sb["interactions"] and sa["killed_geo"] == 0
+    w = np.linspace(-1, 1, 7) * PC
+    ix, iy, iz = (np.searchsorted(w, pv.vor_sites[:, k]) - 1 for k in range(3))
+    np.testing.assert_allclose(a[0], b[0][iz, iy, ix], rtol=0.03, atol=0.01 * b.max())
