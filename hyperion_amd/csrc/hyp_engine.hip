@@ -3,6 +3,7 @@
 // Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -munsafe-fp-atomics
 #include "../../include/hyperion_amd.h"
 #include "hyp_kernels.h"
+#include "hyp_tiled.h"
 
 #include <cfloat>
 #include <cmath>
@@ -133,6 +134,17 @@ struct hyp_engine {
     float last_propagate_ms = 0.f, last_finish_ms = 0.f;
     hyp_iter_stats last_stats{};
 
+    // brick-tiled Lucy iteration (hyp_tiled.h)
+    void *d_hot = nullptr, *d_cold = nullptr;
+    int *d_slot_brick = nullptr, *d_order = nullptr;
+    unsigned int *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr;
+    TileTask *d_tasks = nullptr;
+    TileCtl *d_ctl = nullptr;
+    TileCtl *h_ctl = nullptr;           // pinned host copy
+    int tile_slots_alloc = 0, tile_nd_alloc = 0;
+    int lucy_mode = -1, tile_slots = 1 << 23, tile_task = 4096;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
+    int last_generations = 0;
+
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
 
@@ -198,6 +210,120 @@ LucyKernel pick_final_kernel(int nd, int grid_type)
 
 }  // namespace
 
+
+// ---- brick-tiled Lucy iteration (Cartesian grids): host-driven generations ----
+namespace {
+
+// brick shape per number of species: density + accumulators (16 B per cell and
+// species) must leave room for two workgroups per CU in the 160 KB LDS
+template <int ND> struct TileShape { static constexpr int X = 16, Y = 16, Z = 16; };      // 64 KB
+template <> struct TileShape<2> { static constexpr int X = 16, Y = 16, Z = 8; };         // 64 KB
+template <> struct TileShape<3> { static constexpr int X = 16, Y = 8, Z = 8; };          // 48 KB
+template <> struct TileShape<4> { static constexpr int X = 16, Y = 8, Z = 8; };          // 64 KB
+
+void tile_shape(int nd, int &x, int &y, int &z)
+{
+    switch (nd) {
+    case 1: x = TileShape<1>::X; y = TileShape<1>::Y; z = TileShape<1>::Z; break;
+    case 2: x = TileShape<2>::X; y = TileShape<2>::Y; z = TileShape<2>::Z; break;
+    case 3: x = TileShape<3>::X; y = TileShape<3>::Y; z = TileShape<3>::Z; break;
+    default: x = TileShape<4>::X; y = TileShape<4>::Y; z = TileShape<4>::Z; break;
+    }
+}
+
+int tile_bricks(const DProblem &P, int nd)
+{
+    int x, y, z;
+    tile_shape(nd, x, y, z);
+    return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
+}
+
+template <int ND>
+int run_tiled_generations(hyp_handle h, const TileGeom &T, uint64_t n_local)
+{
+    constexpr int TBX = TileShape<ND>::X, TBY = TileShape<ND>::Y, TBZ = TileShape<ND>::Z;
+    HotRec<ND> *hot = (HotRec<ND> *)h->d_hot;
+    ColdRec<ND> *cold = (ColdRec<ND> *)h->d_cold;
+    const size_t lds_w = lds_bytes(h->hp);
+    const size_t lds_walk = lds_w + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)TBX * TBY * TBZ * ND;
+    const int grid_p = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
+    const int grid_s = (T.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
+    const int grid_w = T.n_slots / T.task_size + T.n_bricks + 1;
+    if (hipFuncSetAttribute((const void *)tile_walk_kernel<ND, TBX, TBY, TBZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
+        return h->set_error("cannot reserve LDS for the tiled walk kernel");
+    int gen = 0;
+    for (;; gen++) {
+        tile_prepare_kernel<ND><<<grid_p, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, hot, cold, h->d_slot_brick);
+        tile_count_kernel<<<grid_s, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_counts);
+        tile_scan_kernel<<<1, 1024, 0, h->stream>>>(T, h->d_counts, h->d_offsets, h->d_cursor, h->d_tasks, h->d_ctl);
+        tile_scatter_kernel<<<grid_s, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_offsets, h->d_cursor, h->d_order);
+        tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, h->stream>>>(h->d_problem, T, h->d_ctl, hot, cold, h->d_order, h->d_tasks,
+                                                                                 h->d_slot_brick);
+        if ((gen & 3) == 3 || gen > 200000) {
+            hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) return h->set_error(std::string("tiled generation failed: ") + hipGetErrorString(e));
+            if (h->h_ctl->n_finished >= n_local) break;
+            if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
+            int err = 0;
+            (void)hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost);
+            if (err) break;
+        }
+    }
+    h->last_generations = gen + 1;
+    return 0;
+}
+
+int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration)
+{
+    const DProblem &P = h->hp;
+    TileGeom T;
+    tile_shape(h->n_dust, T.bx, T.by, T.bz);
+    T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
+    T.n_bricks = T.nbx * T.nby * T.nbz;
+    long long slots = std::min<long long>(h->tile_slots, (long long)n_local);
+    slots = ((slots + 255) / 256) * 256;
+    T.n_slots = (int)slots;
+    T.task_size = h->tile_task < 256 ? 256 : h->tile_task;
+    T.iter_tag = (uint32_t)iteration; T.pad = 0;
+    const int nd = h->n_dust;
+    size_t hot_sz = nd == 1 ? sizeof(HotRec<1>) : nd == 2 ? sizeof(HotRec<2>) : nd == 3 ? sizeof(HotRec<3>) : sizeof(HotRec<4>);
+    size_t cold_sz = nd == 1 ? sizeof(ColdRec<1>) : nd == 2 ? sizeof(ColdRec<2>) : nd == 3 ? sizeof(ColdRec<3>) : sizeof(ColdRec<4>);
+    if (T.n_slots > h->tile_slots_alloc || nd != h->tile_nd_alloc) {
+        free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
+       
+        if (hipMalloc(&h->d_hot, hot_sz * T.n_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * T.n_slots) != hipSuccess ||
+            hipMalloc(&h->d_slot_brick, sizeof(int) * T.n_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * T.n_slots) != hipSuccess ||
+            hipMalloc(&h->d_tasks, sizeof(TileTask) * ((size_t)T.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2)) != hipSuccess)
+            return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
+        h->tile_slots_alloc = T.n_slots; h->tile_nd_alloc = nd;
+    }
+    if (!h->d_counts) {
+        if (hipMalloc(&h->d_counts, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
+            hipMalloc(&h->d_offsets, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
+            hipMalloc(&h->d_cursor, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
+            hipMalloc(&h->d_ctl, sizeof(TileCtl)) != hipSuccess || hipHostMalloc(&h->h_ctl, sizeof(TileCtl)) != hipSuccess)
+            return h->set_error("cannot allocate the control blocks of the tiled Lucy iteration");
+    }
+    TileCtl c0; c0.next_id = first_id; c0.end_id = first_id + n_local; c0.n_finished = 0; c0.n_tasks = 0; c0.pad = 0;
+    (void)hipMemsetAsync(h->d_hot, 0, hot_sz * T.n_slots, h->stream);          // state 0 = TS_DEAD
+    (void)hipMemsetD32Async((hipDeviceptr_t)h->d_slot_brick, TILE_NEEDS_PREPARE, (size_t)T.n_slots, h->stream);   // every slot is free
+    (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS, h->stream);
+    (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
+    (void)hipEventRecord(h->ev0, h->stream);
+    int rc;
+    switch (nd) {
+    case 1: rc = run_tiled_generations<1>(h, T, n_local); break;
+    case 2: rc = run_tiled_generations<2>(h, T, n_local); break;
+    case 3: rc = run_tiled_generations<3>(h, T, n_local); break;
+    default: rc = run_tiled_generations<4>(h, T, n_local); break;
+    }
+    (void)hipEventRecord(h->ev1, h->stream);
+    return rc;
+}
+
+}  // namespace
+
 extern "C" {
 
 int hyp_abi_version(void) { return HYP_ABI_VERSION; }
@@ -215,6 +341,9 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
     free_dev(h->d_img_accum);
+    free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
+    free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
+    if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -756,6 +885,16 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
 
+    // The brick-tiled iteration pays off once the grid has many bricks and the
+    // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
+    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS;
+    const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 10000000ull;
+    if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
+        if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;
+        h->lucy_pending = true;
+        h->pending_packets = n_local;
+        return 0;
+    }
     LucyKernel k = pick_lucy_kernel(h->n_dust, h->hp.grid_type);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
@@ -908,6 +1047,9 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "accum_copies") h->accum_copies = (int)value;
     else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
     else if (n == "chunk") h->chunk = (int)value;
+    else if (n == "lucy_mode") h->lucy_mode = (int)value;       // -1 auto, 0 persistent atomics kernel, 1 brick-tiled
+    else if (n == "tile_slots") h->tile_slots = (int)value;
+    else if (n == "tile_task") h->tile_task = (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
 }

@@ -26,7 +26,7 @@ def build(specs):
         # keep only the lucy kernel block (first after its Function Name)
         blocks = err.split("Function Name: ")
         for b in blocks:
-            if b.startswith("_Z11lucy_kernelILi1E"):
+            if b.startswith(os.environ.get("KERNEL", "_Z11lucy_kernelILi1E")):
                 info = [l.split("remark:")[1].strip() for l in b.split("\n") if "remark:" in l and
                         any(k in l for k in (" VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
         print(name, "rc", p.returncode, "|", "; ".join(info))
