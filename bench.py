@@ -103,6 +103,7 @@ def main():
         crossings = st["crossings"]          # whole-job crossings of the last step
     barrier()
     dt = time.perf_counter() - t0
+    tiled = eng.get_option("last_lucy_mode") == 1
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libhyperion_amd.so")
-SOURCES = ["hyp_engine.hip", "hyp_kernels.h", "hyp_device.h"]
+SOURCES = ["hyp_engine.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h"]
 # -ffp-contract=off: the cell-walk arithmetic must round like the reference formulation (see find_wall)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-fPIC", "-shared"]
 

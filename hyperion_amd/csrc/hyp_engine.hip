@@ -142,7 +142,10 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 1 << 23, tile_task = 4096;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
+    int lucy_mode = -1, tile_slots = 3 << 22, tile_task = 4096, tile_pools = 3, tile_drain = 262144, tile_park = 16;
+    int last_lucy_mode = 0;
+    hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
     int last_generations = 0;
 
     // options
@@ -239,38 +242,85 @@ int tile_bricks(const DProblem &P, int nd)
 }
 
 template <int ND>
-int run_tiled_generations(hyp_handle h, const TileGeom &T, uint64_t n_local)
+int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, int n_pools)
 {
     constexpr int TBX = TileShape<ND>::X, TBY = TileShape<ND>::Y, TBZ = TileShape<ND>::Z;
-    HotRec<ND> *hot = (HotRec<ND> *)h->d_hot;
-    ColdRec<ND> *cold = (ColdRec<ND> *)h->d_cold;
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_walk = lds_w + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)TBX * TBY * TBZ * ND;
-    const int grid_p = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
-    const int grid_s = (T.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
-    const int grid_w = T.n_slots / T.task_size + T.n_bricks + 1;
+    const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
+    const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
+    const int grid_w = T0.n_slots / T0.task_size + T0.n_bricks + 1;
     if (hipFuncSetAttribute((const void *)tile_walk_kernel<ND, TBX, TBY, TBZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
         return h->set_error("cannot reserve LDS for the tiled walk kernel");
+    // Each pool of slots runs its own prepare -> sort -> walk sequence on its own stream, so the
+    // latency-bound prepare of one pool overlaps the walk of the other.  The pools share only the
+    // packet-id dispenser, the finished counter and the (atomic) accumulators.
+    const size_t tasks_cap = (size_t)T0.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2;
     int gen = 0;
     for (;; gen++) {
-        tile_prepare_kernel<ND><<<grid_p, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, hot, cold, h->d_slot_brick);
-        tile_count_kernel<<<grid_s, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_counts);
-        tile_scan_kernel<<<1, 1024, 0, h->stream>>>(T, h->d_counts, h->d_offsets, h->d_cursor, h->d_tasks, h->d_ctl);
-        tile_scatter_kernel<<<grid_s, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_offsets, h->d_cursor, h->d_order);
-        tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, h->stream>>>(h->d_problem, T, h->d_ctl, hot, cold, h->d_order, h->d_tasks,
-                                                                                 h->d_slot_brick);
+        for (int pool = 0; pool < n_pools; pool++) {
+            TileGeom T = T0; T.pool = pool;
+            hipStream_t st = pool == 0 ? h->stream : h->pool_stream[pool];
+            HotRec<ND> *hot = (HotRec<ND> *)h->d_hot + (size_t)pool * T.n_slots;
+            ColdRec<ND> *cold = (ColdRec<ND> *)h->d_cold + (size_t)pool * T.n_slots;
+            int *slot_brick = h->d_slot_brick + (size_t)pool * T.n_slots;
+            int *order = h->d_order + (size_t)pool * T.n_slots;
+            TileTask *tasks = h->d_tasks + pool * tasks_cap;
+            unsigned *counts = h->d_counts + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
+                     *cursor = h->d_cursor + pool * HYP_TILE_MAX_BRICKS;
+            tile_prepare_kernel<ND><<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
+            tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
+            tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
+            tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
+            tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick);
+        }
         if ((gen & 3) == 3 || gen > 200000) {
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return h->set_error(std::string("tiled generation failed: ") + hipGetErrorString(e));
             if (h->h_ctl->n_finished >= n_local) break;
             if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
+            // few packets left and no ids to hand out: finish them in one launch
+            const uint64_t in_flight = n_local - h->h_ctl->n_finished;
+            if (h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= (uint64_t)h->tile_drain) {
+                for (int pool = 1; pool < n_pools; pool++) {
+                    (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
+                    (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
+                }
+                TileGeom T = T0; T.n_slots = T0.n_slots * n_pools;
+                const int grid_d = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
+                tile_drain_kernel<ND><<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, (HotRec<ND> *)h->d_hot,
+                                                                         (ColdRec<ND> *)h->d_cold, h->d_slot_brick);
+                e = hipStreamSynchronize(h->stream);
+                if (e != hipSuccess) return h->set_error(std::string("tiled drain failed: ") + hipGetErrorString(e));
+                break;
+            }
             int err = 0;
             (void)hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost);
             if (err) break;
         }
     }
     h->last_generations = gen + 1;
+#ifdef HYP_TILE_CHECK_WALL
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
+    {
+        const double *o = (const double *)&h->h_ctl->dbg[8];
+        fprintf(stderr, "wall check: %llu mismatches;", h->h_ctl->dbg[6]);
+        for (int i = 0; i < 22; i++) fprintf(stderr, " %.17g", o[i]);
+        fprintf(stderr, "\n");
+    }
+#endif
+#ifdef HYP_TILE_STATS
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
+    {
+        const unsigned long long *d = h->h_ctl->dbg;
+        fprintf(stderr, "tile stats: generations %d, outer loops %llu, wave-steps %llu, lane-steps %llu (lane utilisation %.3f), waves %llu, "
+                        "tasks %llu (mean %.0f packets), steps per outer loop %.2f\n", gen + 1, d[0], d[1], d[2], (double)d[2] / (64.0 * d[1]),
+                d[3], d[4], (double)d[5] / d[4], (double)d[1] / d[0]);
+    }
+#endif
     return 0;
 }
 
@@ -281,42 +331,55 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     tile_shape(h->n_dust, T.bx, T.by, T.bz);
     T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
     T.n_bricks = T.nbx * T.nby * T.nbz;
+    int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
     long long slots = std::min<long long>(h->tile_slots, (long long)n_local);
-    slots = ((slots + 255) / 256) * 256;
+    if (slots < 65536) n_pools = 1;
+    slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
+    const size_t all_slots = (size_t)slots * n_pools;
     T.task_size = h->tile_task < 256 ? 256 : h->tile_task;
-    T.iter_tag = (uint32_t)iteration; T.pad = 0;
+    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park;
     const int nd = h->n_dust;
     size_t hot_sz = nd == 1 ? sizeof(HotRec<1>) : nd == 2 ? sizeof(HotRec<2>) : nd == 3 ? sizeof(HotRec<3>) : sizeof(HotRec<4>);
     size_t cold_sz = nd == 1 ? sizeof(ColdRec<1>) : nd == 2 ? sizeof(ColdRec<2>) : nd == 3 ? sizeof(ColdRec<3>) : sizeof(ColdRec<4>);
-    if (T.n_slots > h->tile_slots_alloc || nd != h->tile_nd_alloc) {
+    if (all_slots > h->tile_slots_alloc || nd != h->tile_nd_alloc) {
         free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
-       
-        if (hipMalloc(&h->d_hot, hot_sz * T.n_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * T.n_slots) != hipSuccess ||
-            hipMalloc(&h->d_slot_brick, sizeof(int) * T.n_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * T.n_slots) != hipSuccess ||
-            hipMalloc(&h->d_tasks, sizeof(TileTask) * ((size_t)T.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2)) != hipSuccess)
+        const size_t n_tasks_max = HYP_TILE_MAX_POOLS * ((size_t)all_slots / 256 + HYP_TILE_MAX_BRICKS + 2);
+        if (hipMalloc(&h->d_hot, hot_sz * all_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * all_slots) != hipSuccess ||
+            hipMalloc(&h->d_slot_brick, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * all_slots) != hipSuccess ||
+            hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) != hipSuccess)
             return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
-        h->tile_slots_alloc = T.n_slots; h->tile_nd_alloc = nd;
+        h->tile_slots_alloc = all_slots; h->tile_nd_alloc = nd;
     }
     if (!h->d_counts) {
-        if (hipMalloc(&h->d_counts, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
-            hipMalloc(&h->d_offsets, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
-            hipMalloc(&h->d_cursor, sizeof(unsigned) * HYP_TILE_MAX_BRICKS) != hipSuccess ||
+        const size_t nb = sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
+        if (hipMalloc(&h->d_counts, nb) != hipSuccess || hipMalloc(&h->d_offsets, nb) != hipSuccess || hipMalloc(&h->d_cursor, nb) != hipSuccess ||
             hipMalloc(&h->d_ctl, sizeof(TileCtl)) != hipSuccess || hipHostMalloc(&h->h_ctl, sizeof(TileCtl)) != hipSuccess)
             return h->set_error("cannot allocate the control blocks of the tiled Lucy iteration");
+        if (hipEventCreateWithFlags(&h->ev_pool, hipEventDisableTiming) != hipSuccess)
+            return h->set_error("cannot create the pool event of the tiled Lucy iteration");
     }
-    TileCtl c0; c0.next_id = first_id; c0.end_id = first_id + n_local; c0.n_finished = 0; c0.n_tasks = 0; c0.pad = 0;
-    (void)hipMemsetAsync(h->d_hot, 0, hot_sz * T.n_slots, h->stream);          // state 0 = TS_DEAD
-    (void)hipMemsetD32Async((hipDeviceptr_t)h->d_slot_brick, TILE_NEEDS_PREPARE, (size_t)T.n_slots, h->stream);   // every slot is free
-    (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS, h->stream);
-    (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
+    for (int pool = 1; pool < n_pools; pool++)
+        if (!h->pool_stream[pool] && hipStreamCreateWithFlags(&h->pool_stream[pool], hipStreamNonBlocking) != hipSuccess)
+            return h->set_error("cannot create a stream for the tiled Lucy iteration");
+    TileCtl c0; memset(&c0, 0, sizeof(c0));
+    c0.next_id = first_id; c0.end_id = first_id + n_local;
     (void)hipEventRecord(h->ev0, h->stream);
+    (void)hipMemsetAsync(h->d_hot, 0, hot_sz * all_slots, h->stream);          // state 0 = TS_DEAD
+    (void)hipMemsetD32Async((hipDeviceptr_t)h->d_slot_brick, TILE_NEEDS_PREPARE, all_slots, h->stream);   // every slot is free
+    (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
+    (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
+    (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
     int rc;
     switch (nd) {
-    case 1: rc = run_tiled_generations<1>(h, T, n_local); break;
-    case 2: rc = run_tiled_generations<2>(h, T, n_local); break;
-    case 3: rc = run_tiled_generations<3>(h, T, n_local); break;
-    default: rc = run_tiled_generations<4>(h, T, n_local); break;
+    case 1: rc = run_tiled_generations<1>(h, T, n_local, n_pools); break;
+    case 2: rc = run_tiled_generations<2>(h, T, n_local, n_pools); break;
+    case 3: rc = run_tiled_generations<3>(h, T, n_local, n_pools); break;
+    default: rc = run_tiled_generations<4>(h, T, n_local, n_pools); break;
+    }
+    for (int pool = 1; pool < n_pools; pool++) {      // join the other pools into the engine's stream
+        (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
+        (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
     }
     (void)hipEventRecord(h->ev1, h->stream);
     return rc;
@@ -344,6 +407,8 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
+    for (int i = 1; i < 4; i++) if (h->pool_stream[i]) (void)hipStreamDestroy(h->pool_stream[i]);
+    if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->ev2) (void)hipEventDestroy(h->ev2);
@@ -888,13 +953,15 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     // The brick-tiled iteration pays off once the grid has many bricks and the
     // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
     const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS;
-    const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 10000000ull;
+    const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
     if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
         if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;
+        h->last_lucy_mode = 1;
         h->lucy_pending = true;
         h->pending_packets = n_local;
         return 0;
     }
+    h->last_lucy_mode = 0;
     LucyKernel k = pick_lucy_kernel(h->n_dust, h->hp.grid_type);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
@@ -1050,6 +1117,30 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "lucy_mode") h->lucy_mode = (int)value;       // -1 auto, 0 persistent atomics kernel, 1 brick-tiled
     else if (n == "tile_slots") h->tile_slots = (int)value;
     else if (n == "tile_task") h->tile_task = (int)value;
+    else if (n == "tile_pools") h->tile_pools = (int)value;
+    else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "tile_park") h->tile_park = (int)value;
+    else return h->set_error("unknown option: " + n);
+    return 0;
+}
+
+int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
+{
+    if (!h || !name || !value) return 1;
+    std::string n(name);
+    if (n == "interact_threshold") *value = h->interact_threshold;
+    else if (n == "emit_threshold") *value = h->emit_threshold;
+    else if (n == "accum_copies") *value = h->accum_copies;
+    else if (n == "blocks_per_cu") *value = h->blocks_per_cu;
+    else if (n == "chunk") *value = h->chunk;
+    else if (n == "lucy_mode") *value = h->lucy_mode;
+    else if (n == "tile_slots") *value = h->tile_slots;
+    else if (n == "tile_task") *value = h->tile_task;
+    else if (n == "tile_pools") *value = h->tile_pools;
+    else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "tile_park") *value = h->tile_park;
+    else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with
+    else if (n == "last_generations") *value = h->last_generations;   // generations of the last tiled iteration
     else return h->set_error("unknown option: " + n);
     return 0;
 }

@@ -46,31 +46,40 @@ struct alignas(16) ColdRec {     // only touched at interactions / emission
 
 // slot_brick[] values besides a brick index
 #define TILE_IDLE (-1)            // slot retired (no packet ids left)
-#define TILE_NEEDS_PREPARE (-2)   // packet awaits an interaction, or the slot is free for a new packet
+#define TILE_NEEDS_PREPARE (-2)   // the slot is free for a new packet
+#define TILE_NEEDS_INTERACT (-3)  // the packet in the slot awaits an interaction
 #define HYP_PREP_CHUNK 2048
 // build-time shape of tile_walk_kernel (tools/variants.py sweeps these)
 #ifndef HYP_TILE_WG
 #define HYP_TILE_WG 512          // threads per workgroup (one workgroup per task)
 #endif
-#ifndef HYP_TILE_FUSE
-#define HYP_TILE_FUSE 0          // 1: interactions in place inside the walk kernel
-#endif
 #ifndef HYP_TILE_DENS_LDS
 #define HYP_TILE_DENS_LDS 1      // 1: brick densities staged in LDS, 0: read through L1/L2
 #endif
-// lane states of tile_walk_kernel
-enum { LS_IDLE = 0, LS_WALK = 1, LS_INTERACT = 2 };
+#ifndef HYP_TILE_STEPS
+#define HYP_TILE_STEPS 4         // cell steps between two scheduling decisions of a wave
+#endif
+// timing experiments only (results are wrong with these): tools/variants.py
+#ifdef HYP_TILE_ABLATE_DEPOSIT
+#define TILE_DEPOSIT(p, v) ((void)(p), (void)(v))
+#else
+#define TILE_DEPOSIT(p, v) unsafeAtomicAdd(p, v)
+#endif
 
+#define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
-    unsigned int n_tasks, pad;
+    unsigned int n_tasks[HYP_TILE_MAX_POOLS];     // per slot pool
+    unsigned long long dbg[40];                   // debug builds only
 };
 
 struct TileGeom {
     int bx, by, bz;              // brick size in cells
     int nbx, nby, nbz, n_bricks;
     int n_slots, task_size;
-    uint32_t iter_tag, pad;
+    uint32_t iter_tag;
+    int pool;                    // which slot pool (and stream) this launch belongs to
+    int park;                    // tile_walk: park the last packets of a wave once this few lanes still walk
 };
 
 struct TileTask { int brick, start, len, pad; };
@@ -87,8 +96,11 @@ __device__ __forceinline__ int brick_of(const TileGeom &T, const int ic[3])
 // tile_prepare: interactions and (re-)emission, one lane per slot; writes the
 // brick of every walking packet.
 // ---------------------------------------------------------------------------
+#ifndef HYP_PREP_WAVES
+#define HYP_PREP_WAVES 2
+#endif
 template <int ND>
-__global__ __launch_bounds__(256) void tile_prepare_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+__global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                          HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
                                                          int *__restrict__ slot_brick)
 {
@@ -102,22 +114,28 @@ __global__ __launch_bounds__(256) void tile_prepare_kernel(const DProblem *__res
     // Each workgroup scans a chunk of slot_brick[] (coalesced), gathers the slots marked
     // TILE_NEEDS_PREPARE into an LDS list and then works through that list with full waves.
     __shared__ int list[HYP_PREP_CHUNK];
-    __shared__ int n_list;
+    __shared__ int n_list, n_back;
     const int n_chunks = (T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK;
     for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
     __syncthreads();
-    if (threadIdx.x == 0) n_list = 0;
+    if (threadIdx.x == 0) { n_list = 0; n_back = 0; }
     __syncthreads();
     for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
         const int s = ch * HYP_PREP_CHUNK + k;
-        if (s < T.n_slots && slot_brick[s] == TILE_NEEDS_PREPARE) list[atomicAdd(&n_list, 1)] = s;
+        // interactions from the front, emissions from the back: waves see one kind of work
+        const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
+        if (sb == TILE_NEEDS_INTERACT) list[atomicAdd(&n_list, 1)] = s;
+        else if (sb == TILE_NEEDS_PREPARE) list[HYP_PREP_CHUNK - 1 - atomicAdd(&n_back, 1)] = s;
     }
     __syncthreads();
-    const int nl = n_list;
+    const int n_front = n_list, n_emit = n_back;
+    // emissions start on a wave boundary
+    const int emit0 = (n_front + 63) & ~63;
+    const int nl = emit0 + n_emit;
     for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
         const int k = k0 + (int)threadIdx.x;
-        const bool valid = k < nl;
-        const int slot = valid ? list[k] : 0;
+        const bool valid = k < n_front || (k >= emit0 && k < nl);
+        const int slot = !valid ? 0 : k < n_front ? list[k] : list[HYP_PREP_CHUNK - 1 - (k - emit0)];
         int state = valid ? hot[slot].state : TS_DONE;
         Packet<ND, GEOM_CAR> p;
         Rng g;
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(256) void tile_prepare_kernel(const DProblem *__res
                 C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
                 C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
                 // zero optical depth drawn: interact again in the next generation
-                slot_brick[slot] = state == TS_WALK ? brick_of(T, p.cell.ic) : TILE_NEEDS_PREPARE;
+                slot_brick[slot] = state == TS_WALK ? brick_of(T, p.cell.ic) : TILE_NEEDS_INTERACT;
             } else {
                 hot[slot].state = state;
                 // a new packet that left the grid at once frees the slot again; TS_DONE retires it
@@ -207,6 +225,115 @@ __global__ __launch_bounds__(256) void tile_prepare_kernel(const DProblem *__res
     double nf = wave_sum((double)finished);
     if (__lane_id() == 0) {
         if (e != 0.0) unsafeAtomicAdd(&P.tail[TAIL_ENERGY], e);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
+        if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
+        if (nf != 0.0) atomicAdd(&ctl->n_finished, (unsigned long long)nf);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// tile_drain: once the packet ids are used up and only a few packets are still in
+// flight, generations stop paying (every one of them rescans all slots for a handful of
+// steps).  This kernel takes every remaining packet to its end in one launch, one lane
+// per packet, with the persistent kernel's walk_step (global atomics).
+// ---------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+                                                                       HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
+                                                                       int *__restrict__ slot_brick)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM_CAR>(P, lds, W);
+    double *sum = P.sum;
+    if (P.n_copies > 1) {
+        unsigned c = xcc_id();
+        if (P.n_copies > 8) c += 8u * ((blockIdx.x >> 3) % (unsigned)(P.n_copies >> 3));
+        sum += (size_t)(c % (unsigned)P.n_copies) * P.copy_stride;
+    }
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    unsigned int finished = 0;
+    __shared__ int list[HYP_PREP_CHUNK];
+    __shared__ int n_list;
+    const int n_chunks = (T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK;
+    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) n_list = 0;
+        __syncthreads();
+        for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
+            const int s = ch * HYP_PREP_CHUNK + k;
+            const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
+            if (sb >= 0 || sb == TILE_NEEDS_INTERACT) list[atomicAdd(&n_list, 1)] = s;
+        }
+        __syncthreads();
+        const int nl = n_list;
+        for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
+            const int k = k0 + (int)threadIdx.x;
+            int st = ST_DONE, slot = 0;
+            Packet<ND, GEOM_CAR> p;
+            Rng g;
+            if (k < nl) {
+                slot = list[k];
+                const HotRec<ND> &H = hot[slot];
+                const ColdRec<ND> &C = cold[slot];
+#pragma unroll
+                for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; p.cell.ic[a] = H.ic[a]; }
+                unpack_ow(H.ow, p.cell.ow);
+                p.a = C.a;
+                p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
+                p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
+#pragma unroll
+                for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
+                p.inter = C.inter;
+                const unsigned long long id = H.id;
+                g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+                g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
+                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : ST_WALK;
+            } else {
+                rng_init(g, P.seed_key, T.iter_tag, 0);
+                p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+            }
+            for (;;) {
+                unsigned long long m_walk = __ballot(st == ST_WALK);
+                unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
+                if (!(m_walk | m_int)) break;
+                if (m_int && (__popcll(m_int) >= 16 || !m_walk)) {
+                    if (st == ST_NEED_INTERACT) {
+                        if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; st = ST_DONE; finished++; }
+                        else {
+                            int scattered, dust_id;
+                            bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
+                            bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                            if (killed) { st = ST_DONE; finished++; }
+                            else {
+                                p.inter++;
+                                p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                                st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                            }
+                        }
+                    }
+                }
+#pragma unroll 1
+                for (int q = 0; q < 4; q++) {
+                    if (st == ST_WALK) {
+                        st = walk_step<ND, GEOM_CAR, true>(P, W, p, g, sum, cnt);
+                        if (st == ST_NEED_EMIT) { st = ST_DONE; finished++; }
+                    }
+                }
+            }
+            if (k < nl) { hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE; }
+        }
+    }
+    double c = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    double ki = wave_sum((double)cnt.killed_int);
+    double ni = wave_sum((double)cnt.interactions);
+    double nf = wave_sum((double)finished);
+    if (__lane_id() == 0) {
+        if (c != 0.0) unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], c);
         if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
         if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
         if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
@@ -248,7 +375,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned in
     if (threadIdx.x == 0) {
         unsigned int ac = 0, at = 0;
         for (int i = 0; i < 1024; i++) { unsigned int c = part_c[i], t = part_t[i]; part_c[i] = ac; part_t[i] = at; ac += c; at += t; }
-        ctl->n_tasks = at;
+        ctl->n_tasks[T.pool] = at;
     }
     __syncthreads();
     unsigned int oc = part_c[threadIdx.x], ot = part_t[threadIdx.x];
@@ -291,7 +418,50 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int
 
 // ---------------------------------------------------------------------------
 // tile_walk: one workgroup per task; density and accumulators of the brick in LDS
+//
+// The kernel is VALU-issue bound (profiles/r01c_summary.md), so the per-step code is
+// kept lean: everything that happens once per visit -- finishing the partial step of an
+// interaction, writing the record back, taking the next packet -- is deferred to a
+// "service" phase that runs when at least 16 lanes of the wave wait for it.
 // ---------------------------------------------------------------------------
+
+// find_wall for the common case that r lies inside (or on the walls of) its cell on every
+// axis: then only the wall ahead can be a candidate (wl - r <= 0 <= wu - r), and the result
+// of geo_find_wall is reproduced with one candidate per axis in the same order.  Returns
+// false when the precondition does not hold; the caller then uses geo_find_wall.
+__device__ __forceinline__ bool find_wall_inside(const Walls &W, const double r[3], const double v[3], const Cell<GEOM_CAR> &c,
+                                                 double &tnear, int im[3], bool &found)
+{
+    double tmin = HYP_DBL_MAX, emin = 0.0;
+    im[0] = im[1] = im[2] = 0;
+    bool inside = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int i = c.ic[a];
+        const double wl = W.w[a][i], wu = W.w[a][i + 1];
+        const double ra = r[a], va = v[a];
+        inside = inside && (wl <= ra) && (ra <= wu);
+        const bool up = va > 0.0;
+        const double d = (up ? wu : wl) - ra;
+        const int dir = up ? +1 : -1;
+        // c2 = (ow != +1) && d2 > 0 for va > 0;  c1 = (ow != -1) && d1 < 0 for va < 0
+        const bool cand = (va != 0.0) && (c.ow[a] != dir) && (up ? d > 0.0 : d < 0.0);
+        if (cand) {
+            const double t = d / va;
+            const double e = W.ew[a][i + (up ? 1 : 0)];
+            const double emax = fmax(e, emin);
+            if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = dir; }
+            else if (t < tmin + emax) { emin = emax; im[a] = dir; }
+        }
+    }
+    tnear = tmin;
+    found = (im[0] | im[1] | im[2]) != 0;
+    return inside;
+}
+
+// lane states of tile_walk_kernel
+enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4 };
+
 template <int ND, int BX, int BY, int BZ>
 __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                       HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
@@ -300,7 +470,8 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
-    if (blockIdx.x >= ctl->n_tasks) return;
+    (void)cold;
+    if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
     constexpr int NC = BX * BY * BZ;
     Walls W;
@@ -314,6 +485,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     __shared__ int next_pkt;
     const int bi = tk.brick % T.nbx, bj = (tk.brick / T.nbx) % T.nby, bk = tk.brick / (T.nbx * T.nby);
     const int x0 = bi * BX, y0 = bj * BY, z0 = bk * BZ;
+    const int x1 = min(x0 + BX, P.n1), y1 = min(y0 + BY, P.n2), z1 = min(z0 + BZ, P.n3);
     for (int c = threadIdx.x; c < NC; c += blockDim.x) {
         int lx = c % BX, ly = (c / BX) % BY, lz = c / (BX * BY);
         int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
@@ -334,26 +506,69 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
-    // lane state: the walking part of a packet (the rest stays in its ColdRec until an interaction)
+    // lane state: the walking part of a packet (the rest stays in its ColdRec)
     double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
+    double hit_t = 0.0, hit_tau = 0.0;       // LS_HIT: step length to the wall and optical depth of the cell
+    int hit_lc = 0;
     Cell<GEOM_CAR> cell;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
     int slot = -1;
     int st = LS_IDLE;
-    bool exhausted = false, dirty = false;
+    bool exhausted = false;
 #pragma unroll
     for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; }
 #pragma unroll
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
 
+    bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
+#ifdef HYP_TILE_STATS
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0;
+#endif
     for (;;) {
-        unsigned long long m_walk = __ballot(st == LS_WALK);
-        unsigned long long m_int = __ballot(st == LS_INTERACT);
-        unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted);
-        if (!(m_walk | m_int | m_idle)) break;
-        // refill idle lanes when enough of them wait (or nobody walks)
-        if (m_idle && (__popcll(m_idle) >= 16 || !m_walk)) {
+        if (queue_empty && st == LS_IDLE) exhausted = true;
+        const unsigned long long m_walk = __ballot(st == LS_WALK);
+        const unsigned long long m_out = __ballot(st >= LS_LEFT);
+        const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted);
+        if (!(m_walk | m_out | m_idle)) break;
+        // Tail of a task: the queue is empty and only a few lanes of this wave still walk.  Their
+        // packets go back to their slots as they are (same brick) and continue in the next
+        // generation in a full wave, instead of dragging a nearly empty wave along.
+        const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
+        // ---- service phase: write finished visits back, take new packets ----
+        if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= 16 || !m_walk))) {
+            if (st == LS_HIT) {
+                // the interaction happens inside this cell: grid_propagate_3d.f90:170-200
+                const double tau_needed = tau_req - tau_ach;
+                const double tact = hit_t * (tau_needed / hit_tau);
+#pragma unroll
+                for (int a = 0; a < 3; a++) r[a] = r[a] + tact * v[a];
+                tau_ach += tau_needed;
+                geo_clear_wall(cell);
+#pragma unroll
+                for (int d = 0; d < ND; d++) {
+#if HYP_TILE_DENS_LDS
+                    const double rho = dens[hit_lc * ND + d];
+#else
+                    const double rho = P.density[(((size_t)cell.ic[2] * P.n2 + cell.ic[1]) * P.n1 + cell.ic[0]) * ND + d];
+#endif
+                    if (rho > 0.0) TILE_DEPOSIT(&accum[hit_lc * ND + d], tact * kappa[d] * energy);
+                }
+            }
+            if (st == LS_DEAD) {
+                hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
+                finished++; st = LS_IDLE;
+            } else if (st >= LS_LEFT || (park && st == LS_WALK)) {
+                HotRec<ND> &H = hot[slot];
+#pragma unroll
+                for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
+                H.ow = pack_ow(cell.ow);
+                H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
+                if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
+                else if (st == LS_LEFT) slot_brick[slot] = brick_of(T, cell.ic);     // H.state stays TS_WALK
+                st = LS_IDLE;
+            }
+            if (park) break;
             if (st == LS_IDLE && !exhausted) {
                 int j = atomicAdd(&next_pkt, 1);
                 if (j >= tk.len) exhausted = true;
@@ -369,129 +584,79 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-                    st = LS_WALK; dirty = false;
+                    st = LS_WALK;
                 }
             }
-            m_walk = __ballot(st == LS_WALK);
+            if (__ballot(exhausted)) queue_empty = true;
         }
-        // interactions in place (interact_with_dust, iter_lucy.f90:165-208): the packet stays in
-        // this brick, so it keeps walking here afterwards instead of going through another sort
-#if HYP_TILE_FUSE
-        if (m_int && (__popcll(m_int) >= 16 || !m_walk)) {
-            if (st == LS_INTERACT) {
-                ColdRec<ND> &C = cold[slot];
-                Packet<ND, GEOM_CAR> p;
-#pragma unroll
-                for (int a = 0; a < 3; a++) { p.r[a] = r[a]; p.v[a] = v[a]; }
-                p.cell = cell;
-                p.a = C.a;
-                p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
-                p.nu = C.nu; p.energy = energy; p.tau_req = tau_req; p.tau_ach = tau_ach;
-#pragma unroll
-                for (int d = 0; d < ND; d++) { p.chi[d] = chi[d]; p.kappa[d] = kappa[d]; p.albedo[d] = C.albedo[d]; }
-                p.inter = C.inter;
-                g.blk_a = C.blk_a; g.buf_a = C.buf_a; g.have_a = C.have_a;
-                bool killed;
-                if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; killed = true; }
-                else {
-                    int scattered, dust_id;
-                    bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
-                    killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
-                }
-                if (killed) {
-                    hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
-                    finished++; st = LS_IDLE;
-                } else {
-                    p.inter++;
-                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                    C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
-                    C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
-#pragma unroll
-                    for (int d = 0; d < ND; d++) { C.albedo[d] = p.albedo[d]; chi[d] = p.chi[d]; kappa[d] = p.kappa[d]; }
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { r[a] = p.r[a]; v[a] = p.v[a]; }
-                    cell = p.cell;
-                    energy = p.energy; tau_req = p.tau_req; tau_ach = 0.0;
-                    dirty = true;
-                    st = (tau_req == 0.0) ? LS_INTERACT : LS_WALK;
-                }
-            }
-        }
-#else
-        (void)m_int; (void)cold;
+        // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
+#ifdef HYP_TILE_STATS
+        dbg_outer++;
 #endif
-        // a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232)
 #pragma unroll 1
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < HYP_TILE_STEPS; k++) {
+#ifdef HYP_TILE_STATS
+            { unsigned long long mw = __ballot(st == LS_WALK); if (mw) { dbg_wsteps++; dbg_lsteps += __popcll(mw); } }
+#endif
             if (st == LS_WALK) {
-                int new_state = TS_WALK;
-                bool done = false;
+                bool ok = true;
                 if (g.countdown == 0) {
                     g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-                    if (!geo_in_correct_cell(P, W, r, cell)) { cnt.killed_geo++; new_state = TS_DEAD; done = true; }
+                    ok = geo_in_correct_cell(P, W, r, cell);
                 } else g.countdown--;
-                if (!done) {
-                    double tmin; int im[3];
-                    if (!geo_find_wall(P, W, r, v, cell, tmin, im)) { cnt.killed_geo++; new_state = TS_DEAD; done = true; }
-                    else {
-                        const int lc = ((cell.ic[2] - z0) * BY + (cell.ic[1] - y0)) * BX + (cell.ic[0] - x0);
-                        double rho[ND], chi_rho = 0.0;
-#pragma unroll
-                        for (int d = 0; d < ND; d++) {
-#if HYP_TILE_DENS_LDS
-                            rho[d] = dens[lc * ND + d];
-#else
-                            rho[d] = P.density[(((size_t)cell.ic[2] * P.n2 + cell.ic[1]) * P.n1 + cell.ic[0]) * ND + d];
-#endif
-                            chi_rho += chi[d] * rho[d];
-                        }
-                        double tau_cell = chi_rho * tmin;
-                        double tau_needed = tau_req - tau_ach;
-                        cnt.crossings++;
-                        if (tau_cell < tau_needed) {
-#pragma unroll
-                            for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
-                            tau_ach += tau_cell;
-#pragma unroll
-                            for (int d = 0; d < ND; d++) if (rho[d] > 0.0) unsafeAtomicAdd(&accum[lc * ND + d], tmin * kappa[d] * energy);
-                            geo_advance(P, r, cell, im);
-                            if (geo_escaped(P, cell)) { new_state = TS_DEAD; done = true; }
-                            else if (cell.ic[0] < x0 || cell.ic[0] >= x0 + BX || cell.ic[1] < y0 || cell.ic[1] >= y0 + BY ||
-                                     cell.ic[2] < z0 || cell.ic[2] >= z0 + BZ) done = true;       // left the brick
-                        } else {
-                            double tact = tmin * (tau_needed / tau_cell);
-#pragma unroll
-                            for (int a = 0; a < 3; a++) r[a] = r[a] + tact * v[a];
-                            tau_ach += tau_needed;
-                            geo_clear_wall(cell);
-#pragma unroll
-                            for (int d = 0; d < ND; d++) if (rho[d] > 0.0) unsafeAtomicAdd(&accum[lc * ND + d], tact * kappa[d] * energy);
-#if HYP_TILE_FUSE
-                            st = LS_INTERACT;
-#else
-                            new_state = TS_INTERACT; done = true;    // tile_prepare does the interaction
-#endif
+                double tmin; int im[3];
+                if (ok) {
+                    bool found;
+#ifdef HYP_TILE_NO_FAST_WALL
+                    found = geo_find_wall(P, W, r, v, cell, tmin, im);
+#elif defined(HYP_TILE_CHECK_WALL)
+                    {
+                        double t2; int im2[3]; bool f2;
+                        found = geo_find_wall(P, W, r, v, cell, tmin, im);
+                        bool ins = find_wall_inside(W, r, v, cell, t2, im2, f2);
+                        if (ins && (f2 != found || (found && (t2 != tmin || im2[0] != im[0] || im2[1] != im[1] || im2[2] != im[2])))) {
+                            if (atomicAdd(&ctl->dbg[6], 1ull) == 0) {
+                                double *o = (double *)&ctl->dbg[8];
+                                o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = v[0]; o[4] = v[1]; o[5] = v[2]; o[6] = tmin; o[7] = t2;
+                                o[8] = cell.ic[0]; o[9] = cell.ic[1]; o[10] = cell.ic[2]; o[11] = cell.ow[0]; o[12] = cell.ow[1]; o[13] = cell.ow[2];
+                                o[14] = im[0]; o[15] = im[1]; o[16] = im[2]; o[17] = im2[0]; o[18] = im2[1]; o[19] = im2[2]; o[20] = found; o[21] = f2;
+                            }
                         }
                     }
+#else
+                    if (!find_wall_inside(W, r, v, cell, tmin, im, found)) found = geo_find_wall(P, W, r, v, cell, tmin, im);
+#endif
+                    ok = found;
                 }
-                if (done) {
-                    HotRec<ND> &H = hot[slot];
-                    slot_brick[slot] = new_state == TS_WALK ? brick_of(T, cell.ic) : TILE_NEEDS_PREPARE;
-                    if (new_state == TS_DEAD) { H.state = TS_DEAD; finished++; }
-                    else {
+                if (!ok) { cnt.killed_geo++; st = LS_DEAD; }
+                else {
+                    const int lc = ((cell.ic[2] - z0) * BY + (cell.ic[1] - y0)) * BX + (cell.ic[0] - x0);
+                    double rho[ND], chi_rho = 0.0;
 #pragma unroll
-                        for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
-                        H.ow = pack_ow(cell.ow);
-                        H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b; H.state = new_state;
-                        if (dirty) {     // an interaction changed direction, frequency-dependent opacities and tau_req
-#pragma unroll
-                            for (int a = 0; a < 3; a++) H.v[a] = v[a];
-                            H.tau_req = tau_req; H.energy = energy;
-#pragma unroll
-                            for (int d = 0; d < ND; d++) { H.chi[d] = chi[d]; H.kappa[d] = kappa[d]; }
-                        }
+                    for (int d = 0; d < ND; d++) {
+#if HYP_TILE_DENS_LDS
+                        rho[d] = dens[lc * ND + d];
+#else
+                        rho[d] = P.density[(((size_t)cell.ic[2] * P.n2 + cell.ic[1]) * P.n1 + cell.ic[0]) * ND + d];
+#endif
+                        chi_rho += chi[d] * rho[d];
                     }
-                    st = LS_IDLE;
+                    const double tau_cell = chi_rho * tmin;
+                    cnt.crossings++;
+                    if (tau_cell < tau_req - tau_ach) {
+#pragma unroll
+                        for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+                        tau_ach += tau_cell;
+#pragma unroll
+                        for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[lc * ND + d], tmin * kappa[d] * energy);
+                        geo_advance(P, r, cell, im);
+                        // x1, y1, z1 are clipped to the grid, so leaving the grid is leaving the brick
+                        if (cell.ic[0] < x0 || cell.ic[0] >= x1 || cell.ic[1] < y0 || cell.ic[1] >= y1 ||
+                            cell.ic[2] < z0 || cell.ic[2] >= z1)
+                            st = geo_escaped(P, cell) ? LS_DEAD : LS_LEFT;
+                    } else {
+                        st = LS_HIT; hit_t = tmin; hit_tau = tau_cell; hit_lc = lc;
+                    }
                 }
             }
         }
@@ -511,10 +676,21 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
             size_t gidx = ((size_t)gz * P.n2 + gy) * P.n1 + gx;
             for (int d = 0; d < ND; d++) {
                 double val = accum[c * ND + d];
+#ifndef HYP_TILE_ABLATE_FLUSH
                 if (val != 0.0) unsafeAtomicAdd(&sum[gidx * ND + d], val);
+#else
+                (void)val; (void)sum;
+#endif
             }
         }
     }
+#ifdef HYP_TILE_STATS
+    if (__lane_id() == 0) {
+        atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps);
+        atomicAdd(&ctl->dbg[3], 1ull);
+        if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
+    }
+#endif
     double cr = wave_sum((double)cnt.crossings);
     double kg = wave_sum((double)cnt.killed_geo);
     double ki = wave_sum((double)cnt.killed_int);

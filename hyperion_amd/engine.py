@@ -21,7 +21,7 @@ EXPORTS = [
     "hyp_final_iteration", "hyp_final_launch", "hyp_final_accumulators", "hyp_final_finish",
     "hyp_peeled_get", "hyp_peeled_n_orig",
     "hyp_get_specific_energy", "hyp_get_density", "hyp_set_specific_energy",
-    "hyp_last_kernel_ms", "hyp_set_option",
+    "hyp_last_kernel_ms", "hyp_set_option", "hyp_get_option",
 ]
 
 
@@ -65,6 +65,7 @@ def load_library(path=None):
     L.hyp_set_specific_energy.argtypes = [H, _dp]
     L.hyp_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hyp_set_option.argtypes = [H, C.c_char_p, C.c_int64]
+    L.hyp_get_option.argtypes = [H, C.c_char_p, C.POINTER(C.c_int64)]
     if path == LIB:
         _lib = L
     return L
@@ -119,6 +120,11 @@ class Engine:
 
     def set_option(self, name, value):
         self._check(self._lib.hyp_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64(0)
+        self._check(self._lib.hyp_get_option(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
 
     # -- Lucy iteration ---------------------------------------------------------
     def lucy_iteration(self, n_packets, iteration, want_output=True):

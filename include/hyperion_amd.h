@@ -212,8 +212,12 @@ int  hyp_set_specific_energy(hyp_handle h, const double *in);
  * stream) of the last propagation kernel and of the last finish step. */
 int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
 /* tuning knobs (environment-independent): name in {"interact_threshold",
- * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk"} */
+ * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
+ * (-1 auto, 0 persistent kernel with global atomics, 1 brick-tiled),
+ * "tile_slots", "tile_task", "tile_pools", "tile_drain"}.  hyp_get_option
+ * also reports "last_lucy_mode" and "last_generations". */
 int  hyp_set_option(hyp_handle h, const char *name, int64_t value);
+int  hyp_get_option(hyp_handle h, const char *name, int64_t *value);
 
 #ifdef __cplusplus
 }

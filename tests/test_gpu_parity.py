@@ -219,7 +219,10 @@ def test_tiled_benchmark_many_bricks():
     """40^3 cells = 27 bricks with ragged edges (40 is not a multiple of 16); a slot pool much
     smaller than the packet count forces many refills of freed slots."""
     run_both(make_benchmark_problem(40), 100000, **TILED)
-    run_both(make_benchmark_problem(16), 50000, iters=2, tile_slots=4096, tile_task=256, **TILED)
+    # generations all the way down (no drain launch), one pool and three
+    run_both(make_benchmark_problem(16), 50000, iters=2, tile_slots=4096, tile_task=256, tile_drain=0, **TILED)
+    run_both(make_benchmark_problem(40), 300000, tile_slots=196608, tile_pools=3, tile_drain=0, **TILED)
+    run_both(make_benchmark_problem(40), 300000, tile_slots=196608, tile_pools=2, tile_drain=1000, **TILED)
 
 
 def test_tiled_ragged_grid_and_interaction_limits():
@@ -246,3 +249,18 @@ def test_tiled_matches_persistent_at_scale():
     for k in INT_KEYS:
         assert sa[k] == sb[k], (k, sa, sb)
     assert_parity(a, b)
+
+
+def test_auto_schedule_choice():
+    """lucy_mode -1 (default): tiled only for Cartesian grids with many bricks and long iterations."""
+    eng = hyperion_amd.Engine(make_benchmark_problem(64))
+    assert eng.get_option("lucy_mode") == -1
+    eng.lucy_iteration(100000, 1)
+    assert eng.get_option("last_lucy_mode") == 0
+    eng.lucy_iteration(4000000, 2)
+    assert eng.get_option("last_lucy_mode") == 1 and eng.get_option("last_generations") > 1
+    eng.close()
+    eng = hyperion_amd.Engine(make_benchmark_problem(16))
+    eng.lucy_iteration(4000000, 1)
+    assert eng.get_option("last_lucy_mode") == 0          # one brick: nothing to tile
+    eng.close()

@@ -1,7 +1,6 @@
-for v in t256 t512 t1024 t512f t512g t256g; do
-  python tools/variants.py one build/variants/$v.so 1e8 lucy_mode=1 tile_slots=8388608
-done
-python tools/variants.py one build/variants/t512.so 1e8 lucy_mode=1 tile_slots=16777216
-python tools/variants.py one build/variants/t512g.so 1e8 lucy_mode=1 tile_slots=16777216
-python tools/variants.py one build/variants/t512.so 1e8 lucy_mode=1 tile_slots=8388608 tile_task=2048
-python tools/variants.py one build/variants/t1024.so 1e8 lucy_mode=1 tile_slots=8388608 tile_task=8192
+L=hyperion_amd/csrc/libhyperion_amd.so
+python tools/variants.py one $L 1e8 lucy_mode=1 tile_pools=1 tile_slots=8388608
+for pk in 0 8 16 24 32 48; do python tools/variants.py one $L 1e8 lucy_mode=1 tile_park=$pk; done
+python tools/variants.py one $L 1e8 lucy_mode=1 tile_task=8192
+python tools/variants.py one $L 2e7 lucy_mode=1
+python tools/variants.py one $L 4e6 lucy_mode=1

@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT)
 from hyperion_amd import Engine
 from hyperion_amd.benchmark import make_benchmark_problem
 p = make_benchmark_problem(128)
-eng = Engine(p); eng.set_option("lucy_mode", 1)
+eng = Engine(p); eng.set_option("lucy_mode", 1)  # tiled even for short runs
 for a in sys.argv[1:]:
     k, v = a.split("="); eng.set_option(k, int(v))
 n = int(float(os.environ.get("N", "2e7")))
