@@ -301,16 +301,6 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
         }
     }
     h->last_generations = gen + 1;
-#ifdef HYP_TILE_CHECK_WALL
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
-    {
-        const double *o = (const double *)&h->h_ctl->dbg[8];
-        fprintf(stderr, "wall check: %llu mismatches;", h->h_ctl->dbg[6]);
-        for (int i = 0; i < 22; i++) fprintf(stderr, " %.17g", o[i]);
-        fprintf(stderr, "\n");
-    }
-#endif
 #ifdef HYP_TILE_STATS
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);

@@ -425,42 +425,50 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int
 // "service" phase that runs when at least 16 lanes of the wave wait for it.
 // ---------------------------------------------------------------------------
 
-// find_wall for the common case that r lies inside (or on the walls of) its cell on every
-// axis: then only the wall ahead can be a candidate (wl - r <= 0 <= wu - r), and the result
-// of geo_find_wall is reproduced with one candidate per axis in the same order.  Returns
-// false when the precondition does not hold; the caller then uses geo_find_wall.
-__device__ __forceinline__ bool find_wall_inside(const Walls &W, const double r[3], const double v[3], const Cell<GEOM_CAR> &c,
-                                                 double &tnear, int im[3], bool &found)
+// find_wall for the common case that, on every axis, the wall *behind* the packet is not a
+// candidate of geo_find_wall (it is one only if round-off left the packet outside its cell on
+// an axis where it is not flagged as sitting on that wall).  Then at most the wall ahead is a
+// candidate on each axis, with exactly geo_find_wall's condition, and the candidates are merged
+// in the same order with the same epsilon rules.  Written without control flow: the wall ahead
+// is picked by index arithmetic (iu = 1 where v > 0) and the sign tests are products with
+// sgn = +-1 or 0 (exact), so that the three IEEE divisions can be scheduled together and no
+// lane-divergent branch is left in the step.  Returns false when the precondition fails; the
+// caller then uses geo_find_wall.
+__device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const int iu[3], const double sgn[3],
+                                                const Cell<GEOM_CAR> &c, double &tnear, int im[3], bool &found)
 {
     double tmin = HYP_DBL_MAX, emin = 0.0;
-    im[0] = im[1] = im[2] = 0;
-    bool inside = true;
+    int m0 = 0, m1 = 0, m2 = 0;
+    bool simple = true;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        const int i = c.ic[a];
-        const double wl = W.w[a][i], wu = W.w[a][i + 1];
-        const double ra = r[a], va = v[a];
-        inside = inside && (wl <= ra) && (ra <= wu);
-        const bool up = va > 0.0;
-        const double d = (up ? wu : wl) - ra;
-        const int dir = up ? +1 : -1;
-        // c2 = (ow != +1) && d2 > 0 for va > 0;  c1 = (ow != -1) && d1 < 0 for va < 0
-        const bool cand = (va != 0.0) && (c.ow[a] != dir) && (up ? d > 0.0 : d < 0.0);
-        if (cand) {
-            const double t = d / va;
-            const double e = W.ew[a][i + (up ? 1 : 0)];
-            const double emax = fmax(e, emin);
-            if (t < tmin - emax) { tmin = t; im[0] = im[1] = im[2] = 0; emin = emax; im[a] = dir; }
-            else if (t < tmin + emax) { emin = emax; im[a] = dir; }
-        }
+        const int ia = c.ic[a] + iu[a], ib = c.ic[a] + 1 - iu[a];
+        const double d = W.w[a][ia] - r[a], db = W.w[a][ib] - r[a];
+        const int dir = 2 * iu[a] - 1, ow = c.ow[a];
+        // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
+        const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
+        // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
+        simple = simple & !((ow != -dir) & (db * sgn[a] > 0.0));
+        const double t = d / v[a];
+        const double emax = fmax(W.ew[a][ia], emin);
+        const bool lt = cand & (t < tmin - emax);
+        const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
+        tmin = lt ? t : tmin;
+        emin = any ? emax : emin;
+        const int mine = any ? dir : 0;
+        if (a == 0) m0 = mine;
+        if (a == 1) { m0 = lt ? 0 : m0; m1 = mine; }
+        if (a == 2) { m0 = lt ? 0 : m0; m1 = lt ? 0 : m1; m2 = mine; }
     }
     tnear = tmin;
-    found = (im[0] | im[1] | im[2]) != 0;
-    return inside;
+    im[0] = m0; im[1] = m1; im[2] = m2;
+    found = (m0 | m1 | m2) != 0;
+    return simple;
 }
 
 // lane states of tile_walk_kernel
-enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4 };
+// LS_CHECK: the propagation check is due; LS_SLOW: geo_find_wall is needed for this step
+enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6 };
 
 template <int ND, int BX, int BY, int BZ>
 __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
@@ -508,6 +516,8 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     unsigned int finished = 0;
     // lane state: the walking part of a packet (the rest stays in its ColdRec)
     double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
+    double sgn[3];                            // sign of v per axis (+1, -1, 0) and iu = 1 where v > 0: fixed during a visit
+    int iu[3];
     double hit_t = 0.0, hit_tau = 0.0;       // LS_HIT: step length to the wall and optical depth of the cell
     int hit_lc = 0;
     Cell<GEOM_CAR> cell;
@@ -515,9 +525,9 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
     int slot = -1;
     int st = LS_IDLE;
-    bool exhausted = false;
+    bool exhausted = false, pre = false;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; }
+    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; sgn[a] = 1.0; iu[a] = 1; }
 #pragma unroll
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
 
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     for (;;) {
         if (queue_empty && st == LS_IDLE) exhausted = true;
         const unsigned long long m_walk = __ballot(st == LS_WALK);
-        const unsigned long long m_out = __ballot(st >= LS_LEFT);
+        const unsigned long long m_out = __ballot(st >= LS_LEFT);      // anything the service phase must look at
         const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted);
         if (!(m_walk | m_out | m_idle)) break;
         // Tail of a task: the queue is empty and only a few lanes of this wave still walk.  Their
@@ -537,6 +547,22 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
         const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= 16 || !m_walk))) {
+            // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
+            if (st == LS_CHECK) {
+                const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
+                g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
+                if (geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
+                else { cnt.killed_geo++; st = LS_DEAD; }
+            }
+            // packets that round-off left outside their cell: the general wall search, handed to the
+            // next step through (hit_t, hit_lc)
+            if (st == LS_SLOW) {
+                double tmin; int im[3];
+                if (geo_find_wall(P, W, r, v, cell, tmin, im)) {
+                    hit_t = tmin; hit_lc = (im[0] + 1) | ((im[1] + 1) << 2) | ((im[2] + 1) << 4);
+                    pre = true; st = LS_WALK;
+                } else { cnt.killed_geo++; st = LS_DEAD; }
+            }
             if (st == LS_HIT) {
                 // the interaction happens inside this cell: grid_propagate_3d.f90:170-200
                 const double tau_needed = tau_req - tau_ach;
@@ -558,7 +584,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
             if (st == LS_DEAD) {
                 hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
                 finished++; st = LS_IDLE;
-            } else if (st >= LS_LEFT || (park && st == LS_WALK)) {
+            } else if (st == LS_LEFT || st == LS_HIT || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[slot];
 #pragma unroll
                 for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
@@ -576,7 +602,10 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     slot = order[tk.start + j];
                     const HotRec<ND> &H = hot[slot];
 #pragma unroll
-                    for (int a = 0; a < 3; a++) { r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a]; }
+                    for (int a = 0; a < 3; a++) {
+                        r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a];
+                        iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0);
+                    }
                     unpack_ow(H.ow, cell.ow);
                     tau_req = H.tau_req; tau_ach = H.tau_ach; energy = H.energy;
 #pragma unroll
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-                    st = LS_WALK;
+                    st = LS_WALK; pre = false;
                 }
             }
             if (__ballot(exhausted)) queue_empty = true;
@@ -599,37 +628,20 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
             { unsigned long long mw = __ballot(st == LS_WALK); if (mw) { dbg_wsteps++; dbg_lsteps += __popcll(mw); } }
 #endif
             if (st == LS_WALK) {
-                bool ok = true;
-                if (g.countdown == 0) {
-                    g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-                    ok = geo_in_correct_cell(P, W, r, cell);
-                } else g.countdown--;
-                double tmin; int im[3];
-                if (ok) {
-                    bool found;
-#ifdef HYP_TILE_NO_FAST_WALL
-                    found = geo_find_wall(P, W, r, v, cell, tmin, im);
-#elif defined(HYP_TILE_CHECK_WALL)
-                    {
-                        double t2; int im2[3]; bool f2;
-                        found = geo_find_wall(P, W, r, v, cell, tmin, im);
-                        bool ins = find_wall_inside(W, r, v, cell, t2, im2, f2);
-                        if (ins && (f2 != found || (found && (t2 != tmin || im2[0] != im[0] || im2[1] != im[1] || im2[2] != im[2])))) {
-                            if (atomicAdd(&ctl->dbg[6], 1ull) == 0) {
-                                double *o = (double *)&ctl->dbg[8];
-                                o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = v[0]; o[4] = v[1]; o[5] = v[2]; o[6] = tmin; o[7] = t2;
-                                o[8] = cell.ic[0]; o[9] = cell.ic[1]; o[10] = cell.ic[2]; o[11] = cell.ow[0]; o[12] = cell.ow[1]; o[13] = cell.ow[2];
-                                o[14] = im[0]; o[15] = im[1]; o[16] = im[2]; o[17] = im2[0]; o[18] = im2[1]; o[19] = im2[2]; o[20] = found; o[21] = f2;
-                            }
-                        }
-                    }
-#else
-                    if (!find_wall_inside(W, r, v, cell, tmin, im, found)) found = geo_find_wall(P, W, r, v, cell, tmin, im);
-#endif
-                    ok = found;
+                // rare events wait for the service phase: they would cost every step of the wave
+                // their full code path for one or two lanes
+                double tmin; int im[3]; bool found;
+                bool simple = find_wall_ahead(W, r, v, iu, sgn, cell, tmin, im, found);
+                if (pre) {      // wall found by geo_find_wall in the service phase
+                    tmin = hit_t; im[0] = (hit_lc & 3) - 1; im[1] = ((hit_lc >> 2) & 3) - 1; im[2] = ((hit_lc >> 4) & 3) - 1;
+                    found = true; simple = true;
                 }
-                if (!ok) { cnt.killed_geo++; st = LS_DEAD; }
+                if (g.countdown == 0) st = LS_CHECK;
+                else if (!simple) st = LS_SLOW;
+                else if (!found) { cnt.killed_geo++; st = LS_DEAD; }
                 else {
+                    pre = false;
+                    g.countdown--;
                     const int lc = ((cell.ic[2] - z0) * BY + (cell.ic[1] - y0)) * BX + (cell.ic[0] - x0);
                     double rho[ND], chi_rho = 0.0;
 #pragma unroll
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                             cell.ic[2] < z0 || cell.ic[2] >= z1)
                             st = geo_escaped(P, cell) ? LS_DEAD : LS_LEFT;
                     } else {
-                        st = LS_HIT; hit_t = tmin; hit_tau = tau_cell; hit_lc = lc;
+                        st = LS_HIT; hit_t = tmin; hit_tau = tau_cell; hit_lc = lc;      // finished in the service phase
                     }
                 }
             }
