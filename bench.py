@@ -18,10 +18,14 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-# rocprofv3 PMC, lucy_kernel<1>, 128^3 uniform benchmark (profiles/r01b_summary.md):
-# FETCH_SIZE 8.08522e7 KiB and WRITE_SIZE 1.08239e8 KiB per launch of 3.46321e9 crossings
-PMC_FETCH_B_PER_CROSSING = 8.08522e7 * 1024 / 3.46321e9
-PMC_WRITE_B_PER_CROSSING = 1.08239e8 * 1024 / 3.46321e9
+# L2<->fabric bytes per cell crossing from the committed rocprofv3 PMC passes of the 128^3
+# uniform benchmark (FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc runs):
+#  persistent lucy_kernel<1> (profiles/r01b_summary.md): 8.08522e7 / 1.08239e8 KiB per launch of 3.46321e9 crossings
+#  brick-tiled schedule, all tile_* kernels (profiles/r01c_summary.md): 4.30053e8 / 7.99293e8 KiB over 3 x 1.732e10 crossings
+PMC_B_PER_CROSSING = {
+    0: (8.08522e7 + 1.08239e8) * 1024 / 3.46321e9,
+    1: (4.30053e8 + 7.99293e8) * 1024 / (3 * 1.73190e10),
+}
 
 
 def cpu_baseline(prob, n_sample):
@@ -125,18 +129,25 @@ def main():
                        "packets_per_iteration": n_total, "parallelism": "packets sharded by id range over %d GPU(s), one f64 all-reduce per iteration" % world,
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),
+            "lucy_schedule": "brick-tiled (tile_prepare/sort/tile_walk generations)" if tiled else "persistent kernel, global atomics",
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
-                         # L2<->fabric bytes per launch from the committed PMC passes of this kernel/config
-                         # (profiles/r01b_summary.md: FETCH_SIZE 23.9 B + WRITE_SIZE 32.0 B per crossing,
-                         # KiB units x1024, separate --pmc runs; the x2 wide-load correction of the guide does
+                         # L2<->fabric bytes per launch from the committed PMC passes of this schedule/config
+                         # (KiB units x1024, separate --pmc runs; the x2 wide-load correction of the guide does
                          # not apply to 8-byte scattered loads, one 64-B request each = TCC_EA0_RDREQ x 64).
-                         "traffic": (PMC_FETCH_B_PER_CROSSING + PMC_WRITE_B_PER_CROSSING) * crossings / world / 1e9
+                         "traffic": PMC_B_PER_CROSSING[1 if tiled else 0] * crossings / world / 1e9
                                     if args.grid == 128 and args.density == "uniform" else None,
                          "traffic_unit": "GB per launch (L2<->fabric; Infinity-Cache hits included, not HBM-only)",
-                         "note": "24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
-                                 "the kernel is bound by the memory-side scattered-atomic rate (2.38e10/s measured, profiles/r01_atomic_rate_ubench.md): "
-                                 "atomic-rate fraction %.2f" % (crossings / world / (k_ms * 1e-3) / 2.38e10)},
+                         "note": ("24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
+                                  "launch = the whole propagation of one iteration (all generations of tile_prepare/count/scan/scatter/walk on "
+                                  "three streams), timed with HIP events on the engine's stream.  Density and accumulators of a 16^3 brick "
+                                  "live in LDS, so the algorithmic bytes no longer go to memory: the dominant kernel tile_walk_kernel is "
+                                  "VALU-issue bound (profiles/r01c_summary.md), %.2f x the memory-side atomic rate that bounds the "
+                                  "persistent kernel (2.38e10 atomics/s, profiles/r01_atomic_rate_ubench.md)"
+                                  % (crossings / world / (k_ms * 1e-3) / 2.38e10)) if tiled else
+                                 ("24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
+                                  "the kernel is bound by the memory-side scattered-atomic rate (2.38e10/s measured, profiles/r01_atomic_rate_ubench.md): "
+                                  "atomic-rate fraction %.2f" % (crossings / world / (k_ms * 1e-3) / 2.38e10))},
         }
         if world == 1 and not args.no_cpu_baseline:
             sample_prob = make_benchmark_problem(args.grid, density=args.density, n_photons=int(args.cpu_sample), n_iter=1)

@@ -30,6 +30,8 @@ struct DDust {
     const double *emiss_x;                   // [n_enu]
     const double *emiss_cdf;                 // [n_jnu][n_enu]
     const double *emiss_bp1;                 // [n_jnu][n_enu] power-law index+1 per bin
+    const double *emiss_coarse;              // [n_jnu][n_ecoarse] every HYP_COARSE-th entry of emiss_cdf
+    int n_ecoarse, pad2;
     const double *jnu_var, *log10_jnu_var;   // [n_jnu]
     const double *mo_e, *mo_chi_ross;        // [n_e] (sublimation mode 2) or null
     int n_e, pad1;
@@ -232,6 +234,60 @@ __device__ __forceinline__ double sample_log_pdf(const double *__restrict__ x, c
     if (b != b) return x1 + f * (x2 - x1);
     if (fabs(b) < 1e-10) return x1 * pow(x2 / x1, f);
     return x1 * pow(1.0 + f * (pow(x2 / x1, b) - 1.0), 1.0 / b);
+}
+
+// The same inversion for two CDF rows at once (the two emissivity tables that bracket a cell's
+// specific energy, dust_type_4elem.f90:379-398), with a two-level search: `coarse` holds every
+// HYP_COARSE-th entry of a row (small enough to stay in L1), so the bracket is found with
+// log2(n / HYP_COARSE) short-latency steps plus ONE trip to the row itself, instead of log2(n)
+// dependent trips.  Both searches return the last j with cdf[j] <= xi, like locate() (whose
+// edge rules are reproduced), so the result is the same number.
+#define HYP_COARSE 8
+__device__ __forceinline__ void sample_log_pdf_pair(const double *__restrict__ x, const double *__restrict__ cdf_a, const double *__restrict__ cdf_b,
+                                                    const double *__restrict__ bp1_a, const double *__restrict__ bp1_b,
+                                                    const double *__restrict__ co_a, const double *__restrict__ co_b, int n, int nc, double xi,
+                                                    double &xa, double &xb)
+{
+    const bool in_a = (xi >= cdf_a[0]) && (xi <= cdf_a[n - 1]);
+    const bool in_b = (xi >= cdf_b[0]) && (xi <= cdf_b[n - 1]);
+    int lo_a = 0, hi_a = nc, lo_b = 0, hi_b = nc;
+    while (hi_a - lo_a > 1 || hi_b - lo_b > 1) {
+        const int ma = (lo_a + hi_a) >> 1, mb = (lo_b + hi_b) >> 1;
+        const double va = co_a[ma], vb = co_b[mb];
+        if (hi_a - lo_a > 1) { if (xi >= va) lo_a = ma; else hi_a = ma; }
+        if (hi_b - lo_b > 1) { if (xi >= vb) lo_b = mb; else hi_b = mb; }
+    }
+    const int base_a = lo_a * HYP_COARSE, base_b = lo_b * HYP_COARSE;
+    double wa[HYP_COARSE + 1], wb[HYP_COARSE + 1];
+#pragma unroll
+    for (int k = 0; k <= HYP_COARSE; k++) {      // the window and the entry after it, all loads independent
+        wa[k] = cdf_a[min(base_a + k, n - 1)];
+        wb[k] = cdf_b[min(base_b + k, n - 1)];
+    }
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int k = 1; k < HYP_COARSE; k++) {
+        ca += (base_a + k < n && wa[k] <= xi) ? 1 : 0;
+        cb += (base_b + k < n && wb[k] <= xi) ? 1 : 0;
+    }
+    int ja = base_a + ca, jb = base_b + cb;
+    if (ja == n - 1) ja = n - 2;
+    if (jb == n - 1) jb = n - 2;
+    if (!in_a) ja = 0;           // locate() = -1, sample_log_pdf then uses bin 0
+    if (!in_b) jb = 0;
+    // c1 = cdf[j], c2 = cdf[j+1]: from the window where possible
+    double c1a = cdf_a[ja], c2a = cdf_a[ja + 1], c1b = cdf_b[jb], c2b = cdf_b[jb + 1];
+    (void)wa; (void)wb;
+    const double x1a = x[ja], x2a = x[ja + 1], ba = bp1_a[ja];
+    const double x1b = x[jb], x2b = x[jb + 1], bb = bp1_b[jb];
+    const double fa = (c2a > c1a) ? (xi - c1a) / (c2a - c1a) : 0.0;
+    const double fb = (c2b > c1b) ? (xi - c1b) / (c2b - c1b) : 0.0;
+    if (ba != ba) xa = x1a + fa * (x2a - x1a);
+    else if (fabs(ba) < 1e-10) xa = x1a * pow(x2a / x1a, fa);
+    else xa = x1a * pow(1.0 + fa * (pow(x2a / x1a, ba) - 1.0), 1.0 / ba);
+    if (bb != bb) xb = x1b + fb * (x2b - x1b);
+    else if (fabs(bb) < 1e-10) xb = x1b * pow(x2b / x1b, fb);
+    else xb = x1b * pow(1.0 + fb * (pow(x2b / x1b, bb) - 1.0), 1.0 / bb);
 }
 
 // ---------------------------------------------------------------------------

@@ -84,7 +84,7 @@ double spacing(double x)
 
 struct DustOffsets {
     size_t nu, log10_nu, chi, albedo, log10_chi, log10_albedo, mu, P1, P2, P3, P4, P1_cdf, P2_cdf;
-    size_t emiss_x, emiss_cdf, emiss_bp1, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
+    size_t emiss_x, emiss_cdf, emiss_bp1, emiss_coarse, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
     bool have_mo_e, have_mo_chi;
 };
 
@@ -142,7 +142,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 3 << 22, tile_task = 4096, tile_pools = 3, tile_drain = 262144, tile_park = 16;
+    int lucy_mode = -1, tile_slots = 3 << 21, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -301,6 +301,17 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
         }
     }
     h->last_generations = gen + 1;
+#ifdef HYP_PREP_STATS
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
+    {
+        const unsigned long long *d = h->h_ctl->dbg;
+        double tot = 0; for (int i = 0; i < 5; i++) tot += (double)d[16 + i];
+        fprintf(stderr, "prepare stats: waves %llu; wave-clock share scan %.3f state-load %.3f interact %.3f emit %.3f store %.3f (total %.3e ticks); "
+                        "interact passes %llu (%.1f lanes), emit passes %llu (%.1f lanes)\n", d[28], d[16] / tot, d[17] / tot, d[18] / tot, d[19] / tot,
+                d[20] / tot, tot, d[24], (double)d[26] / (d[24] ? d[24] : 1), d[25], (double)d[27] / (d[25] ? d[25] : 1));
+    }
+#endif
 #ifdef HYP_TILE_STATS
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
@@ -629,6 +640,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             bp1_all.insert(bp1_all.end(), bp1.begin(), bp1.end());
         }
         O.emiss_cdf = B.put(cdf_all); O.emiss_bp1 = B.put(bp1_all);
+        {   // every HYP_COARSE-th CDF entry of each row, for the two-level search of sample_log_pdf_pair
+            const int nc = (in.n_enu + HYP_COARSE - 1) / HYP_COARSE;
+            std::vector<double> coarse((size_t)in.n_jnu * nc);
+            for (int i = 0; i < in.n_jnu; i++)
+                for (int m = 0; m < nc; m++) coarse[(size_t)i * nc + m] = cdf_all[(size_t)i * in.n_enu + (size_t)m * HYP_COARSE];
+            O.emiss_coarse = B.put(coarse);
+        }
         std::vector<double> ljv(in.n_jnu);
         for (int i = 0; i < in.n_jnu; i++) ljv[i] = std::log10(in.emiss_var[i]);
         O.jnu_var = B.put(in.emiss_var, in.n_jnu); O.log10_jnu_var = B.put(ljv);
@@ -770,6 +788,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         D.P1 = db + O.P1; D.P2 = db + O.P2; D.P3 = db + O.P3; D.P4 = db + O.P4;
         D.P1_cdf = db + O.P1_cdf; D.P2_cdf = db + O.P2_cdf;
         D.emiss_x = db + O.emiss_x; D.emiss_cdf = db + O.emiss_cdf; D.emiss_bp1 = db + O.emiss_bp1;
+        D.emiss_coarse = db + O.emiss_coarse; D.n_ecoarse = (D.n_enu + HYP_COARSE - 1) / HYP_COARSE; D.pad2 = 0;
         D.jnu_var = db + O.jnu_var; D.log10_jnu_var = db + O.log10_jnu_var;
         D.mo_e = O.have_mo_e ? db + O.mo_e : nullptr;
         D.mo_chi_ross = O.have_mo_chi ? db + O.mo_chi_ross : nullptr;

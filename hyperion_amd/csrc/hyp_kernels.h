@@ -558,8 +558,10 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
 __device__ __forceinline__ double dust_sample_j_nu(const DDust &D, int jid, double frac, double xi)
 {
     const size_t o = (size_t)jid * D.n_enu;
-    double nu1 = sample_log_pdf(D.emiss_x, D.emiss_cdf + o, D.emiss_bp1 + o, D.n_enu, xi);
-    double nu2 = sample_log_pdf(D.emiss_x, D.emiss_cdf + o + D.n_enu, D.emiss_bp1 + o + D.n_enu, D.n_enu, xi);
+    const size_t oc = (size_t)jid * D.n_ecoarse;
+    double nu1, nu2;
+    sample_log_pdf_pair(D.emiss_x, D.emiss_cdf + o, D.emiss_cdf + o + D.n_enu, D.emiss_bp1 + o, D.emiss_bp1 + o + D.n_enu,
+                        D.emiss_coarse + oc, D.emiss_coarse + oc + D.n_ecoarse, D.n_enu, D.n_ecoarse, xi, nu1, nu2);
     double l1 = log10(nu1);
     return exp10(l1 + frac * (log10(nu2) - l1));
 }

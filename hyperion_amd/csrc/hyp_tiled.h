@@ -99,6 +99,11 @@ __device__ __forceinline__ int brick_of(const TileGeom &T, const int ic[3])
 #ifndef HYP_PREP_WAVES
 #define HYP_PREP_WAVES 2
 #endif
+#ifdef HYP_PREP_STATS
+#define PREP_T(i) do { long long t_now = clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
+#else
+#define PREP_T(i) do { } while (0)
+#endif
 template <int ND>
 __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                          HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
@@ -111,6 +116,10 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
+#ifdef HYP_PREP_STATS
+    long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
+    unsigned long long n_pass_int = 0, n_pass_emit = 0, n_lane_int = 0, n_lane_emit = 0;
+#endif
     // Each workgroup scans a chunk of slot_brick[] (coalesced), gathers the slots marked
     // TILE_NEEDS_PREPARE into an LDS list and then works through that list with full waves.
     __shared__ int list[HYP_PREP_CHUNK];
@@ -129,6 +138,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
     }
     __syncthreads();
     const int n_front = n_list, n_emit = n_back;
+    PREP_T(0);      // scan + barriers
     // emissions start on a wave boundary
     const int emit0 = (n_front + 63) & ~63;
     const int nl = emit0 + n_emit;
@@ -141,6 +151,11 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
         Rng g;
         unsigned long long id = 0;
         bool touched = false;
+#ifdef HYP_PREP_STATS
+        { unsigned long long mi = __ballot(state == TS_INTERACT), me = __ballot(state == TS_DEAD && valid);
+          if (mi) { n_pass_int++; n_lane_int += __popcll(mi); } if (me) { n_pass_emit++; n_lane_emit += __popcll(me); } }
+        if (__ballot(state == TS_INTERACT) == 0 || true) PREP_T(1);   // state load
+#endif
         if (state == TS_INTERACT) {
             touched = true;
             const HotRec<ND> &H = hot[slot];
@@ -171,6 +186,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 }
             }
         }
+        PREP_T(2);      // interactions (record load + interact)
         // (re-)emission into free slots while packet ids remain
         bool want = state == TS_DEAD && valid;
         unsigned long long m = __ballot(want);
@@ -195,6 +211,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 }
             }
         }
+        PREP_T(3);      // emission
         if (valid && touched) {
             if (state == TS_WALK || state == TS_INTERACT) {
                 HotRec<ND> &H = hot[slot];
@@ -216,8 +233,16 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 slot_brick[slot] = state == TS_DEAD ? TILE_NEEDS_PREPARE : TILE_IDLE;
             }
         }
+        PREP_T(4);      // record store
     }
     }
+#ifdef HYP_PREP_STATS
+    if (__lane_id() == 0) {
+        for (int i = 0; i < 5; i++) atomicAdd(&ctl->dbg[16 + i], (unsigned long long)t_acc[i]);
+        atomicAdd(&ctl->dbg[24], n_pass_int); atomicAdd(&ctl->dbg[25], n_pass_emit);
+        atomicAdd(&ctl->dbg[26], n_lane_int); atomicAdd(&ctl->dbg[27], n_lane_emit); atomicAdd(&ctl->dbg[28], 1ull);
+    }
+#endif
     double e = wave_sum(cnt.energy_current);
     double kg = wave_sum((double)cnt.killed_geo);
     double ki = wave_sum((double)cnt.killed_int);

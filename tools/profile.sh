@@ -22,3 +22,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_s
 done
 rocprofv3 -L > $OUT/counters_list.txt 2>&1 || true
 ls -R $OUT | head -60
+# condense on the box (the raw rocpd databases of a 1e8-packet tiled run exceed what gpurun copies back)
+if [ -n "${SUMMARIZE:-}" ]; then
+  SUMMARY_DIR=$REPO/gpurun_out python $REPO/tools/$SUMMARIZE $TAG > /dev/null && rm -rf $OUT/trace $OUT/pmc_*
+fi

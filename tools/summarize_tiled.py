@@ -67,6 +67,6 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 L += ["", "totals over the tile_* kernels, per crossing:", ""]
 for name, v in sorted(tot.items()):
     L.append("- %s: %.6g  (%.4g per crossing)" % (name, v, v / (n_iter * crossings_iter)))
-out = os.path.join(root, "profiles", tag + "_summary.md")
+out = os.path.join(os.environ.get("SUMMARY_DIR", os.path.join(root, "profiles")), tag + "_summary.md")
 open(out, "w").write("\n".join(L) + "\n")
 print("\n".join(L))
