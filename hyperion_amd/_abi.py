@@ -43,6 +43,8 @@ class GridDesc(C.Structure):
         ("oct_center", C.c_double * 3), ("oct_half", C.c_double * 3),
         ("vor_sites", _dp), ("vor_volume", _dp),
         ("vor_idx", C.POINTER(C.c_int32)), ("vor_neighs", C.POINTER(C.c_int32)), ("vor_box", C.c_double * 6),
+        ("n_amr_levels", C.c_int32), ("n_amr_grids", C.c_int32),
+        ("amr_level", C.POINTER(C.c_int32)), ("amr_n", C.POINTER(C.c_int32)), ("amr_bounds", _dp),
     ]
 
 
@@ -141,6 +143,18 @@ class MarshalledProblem:
             d.grid.vor_neighs = nei.ctypes.data_as(C.POINTER(C.c_int32))
             for k in range(6):
                 d.grid.vor_box[k] = float(prob.vor_box[k])
+        elif prob.grid_type == "amr":
+            d.grid.type = 4
+            lev = np.ascontiguousarray(prob.amr_level, dtype=np.int32)
+            nn = np.ascontiguousarray(prob.amr_n, dtype=np.int32)
+            keep(lev)
+            keep(nn)
+            d.grid.n_cells = prob.n_cells
+            d.grid.n_amr_grids = lev.size
+            d.grid.n_amr_levels = int(lev.max())
+            d.grid.amr_level = lev.ctypes.data_as(C.POINTER(C.c_int32))
+            d.grid.amr_n = nn.ctypes.data_as(C.POINTER(C.c_int32))
+            d.grid.amr_bounds = arr(prob.amr_bounds)
         else:
             raise ValueError("Unexpected coordinate type: %s" % prob.grid_type)
 

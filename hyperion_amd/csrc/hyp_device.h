@@ -74,7 +74,17 @@ struct OctCell {
 enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
        TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
 
-enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2 };
+enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3 };
+
+// One grid of an AMR level (type_grid_amr.f90:12-21).  Walls are linspace(lo, hi, n+1) as the
+// reference builds them (grid_geometry_amr.f90:124-137), stored once per grid.
+struct AmrGrid {
+    double lo[3], hi[3];
+    int n[3];
+    int go_off;              // offset of the (n1+2)(n2+2)(n3+2) goto table: grid to continue in + 1, 0 = stay
+    int w_off[3];            // offsets of the three wall arrays in amr_walls
+    unsigned int start;      // unique id of the first cell
+};
 
 struct DProblem {
     int n1, n2, n3, n_dust;
@@ -85,7 +95,7 @@ struct DProblem {
     double baes16_xi;
     double check_p, check_log1mp;         // propagation_check_frequency p, log(1-p)
     uint32_t seed_key, pad1;
-    int grid_type, pad3;                  // 1 cartesian, 2 octree, 3 voronoi
+    int grid_type, pad3;                  // 1 cartesian, 2 octree, 3 voronoi, 4 amr
     const double *w[3], *ew[3];           // walls and 3*spacing(wall)
     const OctCell *oct_cells;             // [n_cells]
     const int *oct_children;              // [n_cells][8], -1 where not refined
@@ -96,6 +106,12 @@ struct DProblem {
     const double *vor_volume;             // [n_cells]
     double vor_box[6];
     int vor_g, pad4;
+    const AmrGrid *amr_grids;             // amr: [n_amr_grids], level by level
+    const int *amr_go;                    // goto tables of all grids
+    const double *amr_walls;              // wall arrays of all grids
+    const int *amr_cell_grid;             // [n_cells] grid of each unique cell id
+    double amr_eps;                       // half the smallest cell width (grid_geometry_amr.f90:350)
+    int n_amr_grids, n_amr_level1;        // level-1 grids come first
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

@@ -5,6 +5,7 @@
 #include "hyp_kernels.h"
 #include "hyp_tiled.h"
 
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -106,6 +107,7 @@ struct hyp_engine {
     OctCell *d_oct_cells = nullptr;
     int *d_oct_children = nullptr;
     double *d_vor_sites = nullptr, *d_vor_volume = nullptr;
+    AmrGrid *d_amr_grids = nullptr; int *d_amr_go = nullptr, *d_amr_cell_grid = nullptr; double *d_amr_walls = nullptr;
     int *d_vor_idx = nullptr, *d_vor_neigh = nullptr, *d_vor_seed = nullptr;
     DSource *d_sources = nullptr;
     DPeeled *d_peeled = nullptr;
@@ -201,13 +203,15 @@ LucyKernel pick_final_kernel_g(int nd)
 
 LucyKernel pick_lucy_kernel(int nd, int grid_type)
 {
-    return grid_type == 3 ? pick_lucy_kernel_g<GEOM_VOR>(nd)
+    return grid_type == 4 ? pick_lucy_kernel_g<GEOM_AMR>(nd)
+         : grid_type == 3 ? pick_lucy_kernel_g<GEOM_VOR>(nd)
          : grid_type == 2 ? pick_lucy_kernel_g<GEOM_OCT>(nd) : pick_lucy_kernel_g<GEOM_CAR>(nd);
 }
 
 LucyKernel pick_final_kernel(int nd, int grid_type)
 {
-    return grid_type == 3 ? pick_final_kernel_g<GEOM_VOR>(nd)
+    return grid_type == 4 ? pick_final_kernel_g<GEOM_AMR>(nd)
+         : grid_type == 3 ? pick_final_kernel_g<GEOM_VOR>(nd)
          : grid_type == 2 ? pick_final_kernel_g<GEOM_OCT>(nd) : pick_final_kernel_g<GEOM_CAR>(nd);
 }
 
@@ -401,6 +405,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
+    free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
@@ -427,10 +432,16 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     g_error.clear();
     if (out) *out = nullptr;
     if (!pr || !out) return set_error("null argument");
-    if (pr->grid.type < 1 || pr->grid.type > 3) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi)");
+    if (pr->grid.type < 1 || pr->grid.type > 4) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi, 4 amr)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
     if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
-    const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_car = pr->grid.type == 1;
+    const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_car = pr->grid.type == 1, is_amr = pr->grid.type == 4;
+    std::vector<AmrGrid> amr_grids;
+    std::vector<int> amr_go, amr_cell_grid;
+    std::vector<double> amr_walls;
+    double amr_eps = 0.0;
+    int amr_level1 = 0;
+    int64_t amr_cells = 0;
     const int n[3] = {is_car ? pr->grid.n1 : 0, is_car ? pr->grid.n2 : 0, is_car ? pr->grid.n3 : 0};
     std::vector<int> vor_seed;
     int vor_g = 1;
@@ -485,6 +496,132 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                     return set_error(std::string("all d") + "xyz"[a] + " values should be greater than zero");
         }
         if ((size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
+    } else if (is_amr) {
+        // read_grid/read_level + setup_grid_geometry: grid_geometry_amr.f90:111-508
+        const int ng = pr->grid.n_amr_grids, nl = pr->grid.n_amr_levels;
+        if (ng < 1 || nl < 1 || !pr->grid.amr_level || !pr->grid.amr_n || !pr->grid.amr_bounds) return set_error("amr grid needs levels and grids");
+        amr_grids.resize(ng);
+        std::vector<int> level(ng);
+        std::vector<std::array<double, 3>> width(ng);
+        double min_width = DBL_MAX;
+        for (int k = 0; k < ng; k++) {
+            AmrGrid &g = amr_grids[k];
+            level[k] = pr->grid.amr_level[k];
+            if (level[k] < 1 || level[k] > nl || (k > 0 && level[k] < level[k - 1])) return set_error("amr grids must be listed level by level");
+            if (level[k] == 1) amr_level1 = k + 1;
+            for (int a = 0; a < 3; a++) {
+                g.n[a] = pr->grid.amr_n[3 * k + a];
+                g.lo[a] = pr->grid.amr_bounds[6 * k + 2 * a]; g.hi[a] = pr->grid.amr_bounds[6 * k + 2 * a + 1];
+                if (g.n[a] < 1 || !(g.hi[a] > g.lo[a])) return set_error("all volumes should be greater than zero");
+                g.w_off[a] = (int)amr_walls.size();
+                // fortranlib linspace: x(i) = (xmax - xmin) * (i - 1) / (n - 1) + xmin
+                for (int i = 0; i <= g.n[a]; i++) amr_walls.push_back((g.hi[a] - g.lo[a]) * (double)i / (double)g.n[a] + g.lo[a]);
+                width[k][a] = (g.hi[a] - g.lo[a]) / (double)g.n[a];
+                if (width[k][a] < min_width) min_width = width[k][a];
+            }
+            if (amr_cells > 2000000000ll) return set_error("amr grid has too many cells");
+            g.start = (unsigned)amr_cells; amr_cells += (int64_t)g.n[0] * g.n[1] * g.n[2];
+            g.go_off = (int)amr_go.size();
+            amr_go.resize(amr_go.size() + (size_t)(g.n[0] + 2) * (g.n[1] + 2) * (g.n[2] + 2), 0);
+        }
+        if (amr_cells > 2000000000ll) return set_error("amr grid has too many cells");
+        amr_eps = min_width / 2.0;
+        auto aligned = [](double x1, double x2, double dx) {
+            double r = std::fmod(std::fabs(x1 - x2), dx);
+            if (r > 0.5 * dx) r = dx - r;
+            return std::fabs(r / dx) < 1.e-8;
+        };
+        auto first_of_level = [&](int l) { for (int q = 0; q < ng; q++) if (level[q] == l) return q; return -1; };
+        char msg[256];
+        for (int k = 0; k < ng; k++) {
+            const int ref = first_of_level(level[k]), igrid = k - ref + 1;
+            for (int a = 0; a < 3; a++) {
+                if (std::fabs(width[k][a] - width[ref][a]) > 1.e-10 * width[k][a]) {
+                    std::snprintf(msg, sizeof msg, "Grids 1 and %d in level %d have differing cell widths in the %c direction", igrid, level[k], "xyz"[a]);
+                    return set_error(msg);
+                }
+                if (!aligned(amr_grids[k].lo[a], amr_grids[ref].lo[a], width[ref][a])) {
+                    std::snprintf(msg, sizeof msg, "Grids 1 and %d in level %d have edges that are not separated by an integer number of cells in the %c direction", igrid, level[k], "xyz"[a]);
+                    return set_error(msg);
+                }
+            }
+            if (level[k] > 1) {
+                const int pref = first_of_level(level[k] - 1);
+                if (pref < 0) return set_error("amr level without grids");
+                for (int a = 0; a < 3; a++) {
+                    const double rf = width[pref][a] / width[ref][a];
+                    if (std::fabs(rf - std::nearbyint(rf)) > 1.e-10) {
+                        std::snprintf(msg, sizeof msg, "Refinement factor in the %c direction between level %d and level %d is not an integer (%.3f)", "xyz"[a], level[k] - 1, level[k], rf);
+                        return set_error(msg);
+                    }
+                    if (!aligned(amr_grids[k].lo[a], amr_grids[pref].lo[a], width[pref][a])) {
+                        std::snprintf(msg, sizeof msg, "Grid %d in level %d is not aligned with cells in level %d in the %c direction", igrid, level[k], level[k] - 1, "xyz"[a]);
+                        return set_error(msg);
+                    }
+                }
+            }
+        }
+        auto in_grid = [&](int k, const double r[3]) {
+            const AmrGrid &g = amr_grids[k];
+            for (int a = 0; a < 3; a++) { if (r[a] < g.lo[a]) return false; if (r[a] > g.hi[a]) return false; }
+            return true;
+        };
+        auto go_at = [&](int k, int i1, int i2, int i3) -> int & {
+            const AmrGrid &g = amr_grids[k];
+            return amr_go[g.go_off + ((size_t)i3 * (g.n[1] + 2) + i2) * (g.n[0] + 2) + i1];
+        };
+        auto wall = [&](int k, int a, int i) { return amr_walls[amr_grids[k].w_off[a] + i]; };
+        // cells overlapped by a grid of the next level (:357-382)
+        for (int l1 = nl - 1; l1 >= 1; l1--)
+            for (int k1 = 0; k1 < ng; k1++) {
+                if (level[k1] != l1) continue;
+                const AmrGrid &g1 = amr_grids[k1];
+                for (int k2 = 0; k2 < ng; k2++) {
+                    if (level[k2] != l1 + 1) continue;
+                    const AmrGrid &g2 = amr_grids[k2];
+                    bool hit = true;
+                    for (int a = 0; a < 3; a++) if (g1.hi[a] < g2.lo[a] || g1.lo[a] > g2.hi[a]) hit = false;
+                    if (!hit) continue;
+                    for (int i1 = 1; i1 <= g1.n[0]; i1++) for (int i2 = 1; i2 <= g1.n[1]; i2++) for (int i3 = 1; i3 <= g1.n[2]; i3++) {
+                        const double r[3] = {0.5 * (wall(k1, 0, i1 - 1) + wall(k1, 0, i1)), 0.5 * (wall(k1, 1, i2 - 1) + wall(k1, 1, i2)),
+                                             0.5 * (wall(k1, 2, i3 - 1) + wall(k1, 2, i3))};
+                        if (in_grid(k2, r)) go_at(k1, i1, i2, i3) = k2 + 1;
+                    }
+                }
+            }
+        // one step outside each grid: the grid of the same or a coarser level found there (:384-486)
+        for (int k1 = 0; k1 < ng; k1++) {
+            const AmrGrid &g1 = amr_grids[k1];
+            for (int l2 = level[k1]; l2 >= 1; l2--)
+                for (int k2 = 0; k2 < ng; k2++) {
+                    if (level[k2] != l2 || k2 == k1) continue;
+                    const AmrGrid &g2 = amr_grids[k2];
+                    bool close = true;
+                    for (int a = 0; a < 3; a++)
+                        if (g1.hi[a] < g2.lo[a] - width[k2][a] * 0.5 || g1.lo[a] > g2.hi[a] + width[k2][a] * 0.5) close = false;
+                    if (!close) continue;
+                    for (int a = 0; a < 3; a++) {
+                        const int b = (a + 1) % 3, c = (a + 2) % 3;
+                        for (int side = 0; side < 2; side++) {
+                            int idx[3]; double r[3];
+                            idx[a] = side ? g1.n[a] + 1 : 0;
+                            r[a] = side ? g1.hi[a] + width[k1][a] * 0.5 : g1.lo[a] - width[k1][a] * 0.5;
+                            for (int ib = 1; ib <= g1.n[b]; ib++) for (int ic = 1; ic <= g1.n[c]; ic++) {
+                                idx[b] = ib; idx[c] = ic;
+                                r[b] = 0.5 * (wall(k1, b, ib - 1) + wall(k1, b, ib)); r[c] = 0.5 * (wall(k1, c, ic - 1) + wall(k1, c, ic));
+                                int &q = go_at(k1, idx[0], idx[1], idx[2]);
+                                if (in_grid(k2, r) && q == 0) q = k2 + 1;
+                            }
+                        }
+                    }
+                }
+        }
+        amr_cell_grid.resize((size_t)amr_cells);
+        for (int k = 0; k < ng; k++) {
+            const AmrGrid &g = amr_grids[k];
+            const size_t nc = (size_t)g.n[0] * g.n[1] * g.n[2];
+            for (size_t c = 0; c < nc; c++) amr_cell_grid[g.start + c] = k;
+        }
     } else {
         // setup_grid_geometry + octree_setup_indiv: grid_geometry_octree.f90:147-246
         const int64_t nc = pr->grid.n_cells;
@@ -533,7 +670,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     h->device = device;
     h->cfg = pr->config;
     h->n_dust = pr->n_dust;
-    h->n_cells = is_car ? (size_t)n[0] * n[1] * n[2] : (size_t)pr->grid.n_cells;
+    h->n_cells = is_car ? (size_t)n[0] * n[1] * n[2] : is_amr ? (size_t)amr_cells : (size_t)pr->grid.n_cells;
     h->n_elem = h->n_cells * h->n_dust;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->n_cu = prop.multiProcessorCount;
@@ -774,6 +911,18 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g;
         for (int k = 0; k < 6; k++) P.vor_box[k] = pr->grid.vor_box[k];
     }
+    if (is_amr) {
+        HIPC(hipMalloc(&h->d_amr_grids, sizeof(AmrGrid) * amr_grids.size()));
+        HIPC(hipMemcpy(h->d_amr_grids, amr_grids.data(), sizeof(AmrGrid) * amr_grids.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_amr_go, sizeof(int) * amr_go.size()));
+        HIPC(hipMemcpy(h->d_amr_go, amr_go.data(), sizeof(int) * amr_go.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_amr_walls, sizeof(double) * amr_walls.size()));
+        HIPC(hipMemcpy(h->d_amr_walls, amr_walls.data(), sizeof(double) * amr_walls.size(), hipMemcpyHostToDevice));
+        HIPC(hipMalloc(&h->d_amr_cell_grid, sizeof(int) * amr_cell_grid.size()));
+        HIPC(hipMemcpy(h->d_amr_cell_grid, amr_cell_grid.data(), sizeof(int) * amr_cell_grid.size(), hipMemcpyHostToDevice));
+        P.amr_grids = h->d_amr_grids; P.amr_go = h->d_amr_go; P.amr_walls = h->d_amr_walls; P.amr_cell_grid = h->d_amr_cell_grid;
+        P.amr_eps = amr_eps; P.n_amr_grids = (int)amr_grids.size(); P.n_amr_level1 = amr_level1;
+    }
     if (is_oct) {
         HIPC(hipMalloc(&h->d_oct_cells, sizeof(OctCell) * oct_cells.size()));
         HIPC(hipMemcpy(h->d_oct_cells, oct_cells.data(), sizeof(OctCell) * oct_cells.size(), hipMemcpyHostToDevice));
@@ -839,6 +988,14 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (int d = 0; d < h->n_dust; d++)
                 for (size_t ic = 0; ic < h->n_cells; ic++)
                     if (oct_cells[ic].refined) dens[(size_t)d * h->n_cells + ic] = 0.0;
+        if (is_amr)   // mask = cells not covered by a finer grid: grid_geometry_amr.f90:489-496
+            for (size_t ic = 0; ic < h->n_cells; ic++) {
+                const AmrGrid &g = amr_grids[amr_cell_grid[ic]];
+                const size_t l = ic - g.start;
+                const int i1 = (int)(l % g.n[0]), i2 = (int)((l / g.n[0]) % g.n[1]), i3 = (int)(l / ((size_t)g.n[0] * g.n[1]));
+                if (amr_go[g.go_off + ((size_t)(i3 + 1) * (g.n[1] + 2) + (i2 + 1)) * (g.n[0] + 2) + (i1 + 1)] != 0)
+                    for (int d = 0; d < h->n_dust; d++) dens[(size_t)d * h->n_cells + ic] = 0.0;
+            }
         if (is_vor)   // mask = volume > 0: grid_geometry_voronoi.f90:161-173
             for (int d = 0; d < h->n_dust; d++)
                 for (size_t ic = 0; ic < h->n_cells; ic++)
@@ -931,6 +1088,9 @@ static int check_device_error(hyp_handle h)
         // message of src/sources/source.f90:177
         std::snprintf(buf, sizeof buf,
                       "photon was not emitted inside a cell - this usually indicates that a source is not inside the grid");
+    } else if (code == ERR_NEGATIVE_T) {
+        // error("find_wall","negative t"), src/grid/grid_geometry_amr.f90:829
+        std::snprintf(buf, sizeof buf, "negative t");
     } else std::snprintf(buf, sizeof buf, "device error %d", code);
     return h->set_error(buf);
 }

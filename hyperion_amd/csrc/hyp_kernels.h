@@ -16,7 +16,7 @@
 enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
-enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2 };
+enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2, GEOM_AMR = 3 };
 
 // Where a packet is: Cartesian = three cell indices; octree = cell id plus a
 // register copy of the leaf's record (centre, level, parent, sub-cell).
@@ -24,6 +24,7 @@ template <int GEOM> struct Cell;
 template <> struct Cell<GEOM_CAR> { int ic[3], ow[3]; };
 template <> struct Cell<GEOM_OCT> { int id, ow[3]; double c[3]; int parent, level, subcell; };
 template <> struct Cell<GEOM_VOR> { int id, ow[3]; };   // ow[1] = -(previous cell + 1)
+template <> struct Cell<GEOM_AMR> { int id, ow[3], grid, i[3]; };   // id = unique cell id (n_cells: outside, -1: invalid); i = 0-based position in the grid
 
 template <int NDT, int GEOM>
 struct Packet {
@@ -407,6 +408,131 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
     c.ow[0] = -im[0]; c.ow[1] = -im[1]; c.ow[2] = -im[2];
 }
 
+
+// ------------------------------- AMR ----------------------------------------
+// grid_geometry_amr.f90: levels of uniform grids; each grid carries a goto table
+// (one ghost layer included) that says in which grid a position continues.
+__device__ __forceinline__ bool geo_escaped(const DProblem &P, const Cell<GEOM_AMR> &c) { return (unsigned long long)c.id == P.n_cells; }
+__device__ __forceinline__ bool geo_invalid(const DProblem &P, const Cell<GEOM_AMR> &c) { return c.id < 0; }
+__device__ __forceinline__ size_t geo_index(const DProblem &P, const Cell<GEOM_AMR> &c) { return (size_t)c.id; }
+
+// ipos (fortranlib): 1-based bin of x in n equal bins of [xmin, xmax]; 0 below, n+1 above
+__device__ __forceinline__ int amr_ipos(double xmin, double xmax, double x, int n)
+{
+    if (x < xmin) return 0;
+    if (x > xmax) return n + 1;
+    if (x < xmax) { int i = (int)((x - xmin) / (xmax - xmin) * (double)n) + 1; return i > n ? n : i; }
+    return n;
+}
+
+// ipos2 :510-519
+__device__ __forceinline__ int amr_ipos2(double xmin, double xmax, double x, int n)
+{
+    const double eps = (xmax - xmin) * 1.e-10;
+    int i = amr_ipos(xmin, xmax, x, n);
+    if (i == 0 && fabs(x - xmin) < eps) i = 1;
+    if (i == n + 1 && fabs(x - xmax) < eps) i = n;
+    return i;
+}
+
+// find_position_in_grid :521-545 (the recursion is a loop over the goto tables)
+__device__ __forceinline__ void amr_find_position(const DProblem &P, const double r[3], int k, Cell<GEOM_AMR> &c)
+{
+    for (;;) {
+        const AmrGrid &g = P.amr_grids[k];
+        int i[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) i[a] = amr_ipos2(g.lo[a], g.hi[a], r[a], g.n[a]);
+        const int go = P.amr_go[g.go_off + (i[2] * (g.n[1] + 2) + i[1]) * (g.n[0] + 2) + i[0]];
+        if (go == 0) {
+            if (i[0] < 1 || i[0] > g.n[0] || i[1] < 1 || i[1] > g.n[1] || i[2] < 1 || i[2] > g.n[2]) { c.id = -1; return; }
+            c.grid = k; c.i[0] = i[0] - 1; c.i[1] = i[1] - 1; c.i[2] = i[2] - 1;
+            c.id = (int)(g.start + (unsigned)((c.i[2] * g.n[1] + c.i[1]) * g.n[0] + c.i[0]));
+            return;
+        }
+        k = go - 1;
+    }
+}
+
+// find_cell_position :560-572 + place_in_cell :574-585 (no wall adjustment)
+__device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, const double r[3], const double v[3], Cell<GEOM_AMR> &c)
+{
+    c.ow[0] = c.ow[1] = c.ow[2] = 0;
+    for (int k = 0; k < P.n_amr_level1; k++) {
+        const AmrGrid &g = P.amr_grids[k];
+        if (r[0] < g.lo[0] || r[0] > g.hi[0] || r[1] < g.lo[1] || r[1] > g.hi[1] || r[2] < g.lo[2] || r[2] > g.hi[2]) continue;
+        amr_find_position(P, r, k, c);
+        return c.id >= 0;
+    }
+    return false;
+}
+
+// in_correct_cell :677-726: position within the packet's own grid
+__device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_AMR> &c)
+{
+    const AmrGrid &g = P.amr_grids[c.grid];
+    const bool on_wall = (c.ow[0] | c.ow[1] | c.ow[2]) != 0;
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double wl = P.amr_walls[g.w_off[a] + c.i[a]], wu = P.amr_walls[g.w_off[a] + c.i[a] + 1];
+        if (on_wall && c.ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < 1e-3;
+        else if (on_wall && c.ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < 1e-3;
+        else ok = ok && (amr_ipos(g.lo[a], g.hi[a], r[a], g.n[a]) - 1 == c.i[a]);
+    }
+    return ok;
+}
+
+// find_wall :775-871: nearest of the three faces ahead; a negative distance stops the reference
+__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_AMR> &c, double &tnear, int im[3])
+{
+    const AmrGrid &g = P.amr_grids[c.grid];
+    double t[3]; bool pos[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        pos[a] = v[a] > 0.0;
+        if (pos[a]) t[a] = (P.amr_walls[g.w_off[a] + c.i[a] + 1] - r[a]) / v[a];
+        else if (v[a] < 0.0) t[a] = (P.amr_walls[g.w_off[a] + c.i[a]] - r[a]) / v[a];
+        else t[a] = HYP_DBL_MAX;
+    }
+    im[0] = im[1] = im[2] = 0;
+    if (fmin(t[0], fmin(t[1], t[2])) < 0.0) { raise_error(P, ERR_NEGATIVE_T, t[0], t[1], t[2]); return false; }
+    int a;
+    if (t[0] < t[2]) a = (t[0] < t[1]) ? 0 : 1;
+    else a = (t[2] < t[1]) ? 2 : 1;
+    tnear = a == 0 ? t[0] : a == 1 ? t[1] : t[2];
+    const bool up = a == 0 ? pos[0] : a == 1 ? pos[1] : pos[2];
+    if (a == 0) im[0] = up ? 1 : -1; else if (a == 1) im[1] = up ? 1 : -1; else im[2] = up ? 1 : -1;
+    return true;
+}
+
+// next_cell_int :599-655 + opposite_wall
+__device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_AMR> &c, const int im[3])
+{
+    const AmrGrid &g = P.amr_grids[c.grid];
+    const int axis = im[0] ? 0 : im[1] ? 1 : 2;
+    const int dir = im[0] + im[1] + im[2];
+    c.ow[0] = -im[0]; c.ow[1] = -im[1]; c.ow[2] = -im[2];
+    int i[3] = {c.i[0] + 1 + im[0], c.i[1] + 1 + im[1], c.i[2] + 1 + im[2]};      // 1-based, ghost layer 0 and n+1
+    const int go = P.amr_go[g.go_off + (i[2] * (g.n[1] + 2) + i[1]) * (g.n[0] + 2) + i[0]];
+    if (go == 0) {
+        if (i[0] == 0 || i[0] == g.n[0] + 1 || i[1] == 0 || i[1] == g.n[1] + 1 || i[2] == 0 || i[2] == g.n[2] + 1) { c.id = (int)P.n_cells; return; }
+        c.i[0] = i[0] - 1; c.i[1] = i[1] - 1; c.i[2] = i[2] - 1;
+        c.id = (int)(g.start + (unsigned)((c.i[2] * g.n[1] + c.i[1]) * g.n[0] + c.i[0]));
+        return;
+    }
+    double rr[3] = {r[0], r[1], r[2]};
+    if (axis == 0) rr[0] = dir > 0 ? rr[0] + P.amr_eps : rr[0] - P.amr_eps;
+    else if (axis == 1) rr[1] = dir > 0 ? rr[1] + P.amr_eps : rr[1] - P.amr_eps;
+    else rr[2] = dir > 0 ? rr[2] + P.amr_eps : rr[2] - P.amr_eps;
+    amr_find_position(P, rr, go - 1, c);
+}
+
+// geometries whose next_cell cannot fail
+template <int GEOM>
+__device__ __forceinline__ bool geo_invalid(const DProblem &P, const Cell<GEOM> &c) { return false; }
+
 template <int GEOM>
 __device__ __forceinline__ void geo_clear_wall(Cell<GEOM> &c) { c.ow[0] = c.ow[1] = c.ow[2] = 0; }
 
@@ -445,6 +571,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
                 if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
         }
         geo_advance(P, p.r, p.cell, im);
+        if (geo_invalid(P, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }     // amr: invalid_cell
         return geo_escaped(P, p.cell) ? ST_NEED_EMIT : ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
@@ -878,6 +1005,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
         for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * P.density[base + d] * tmin;
         cnt.crossings++;
         geo_advance(P, r, c, im);
+        if (geo_invalid(P, c)) { cnt.killed_geo++; killed = true; return tau; }     // amr: invalid_cell
         if (geo_escaped(P, c)) return tau;
     }
 }
@@ -1286,6 +1414,9 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
         double vol;
         if (P.grid_type == 3) {
             vol = P.vor_volume[ic];
+        } else if (P.grid_type == 4) {
+            const AmrGrid &g = P.amr_grids[P.amr_cell_grid[ic]];      // grid%volume, grid_geometry_amr.f90:143-151
+            vol = ((g.hi[0] - g.lo[0]) / (double)g.n[0]) * ((g.hi[1] - g.lo[1]) / (double)g.n[1]) * ((g.hi[2] - g.lo[2]) / (double)g.n[2]);
         } else if (P.grid_type == 2) {
             int lev = P.oct_cells[ic].level;
             vol = ldexp(P.oct_half[0], -lev) * ldexp(P.oct_half[1], -lev) * ldexp(P.oct_half[2], -lev) * 8.0;

@@ -189,6 +189,12 @@ class Problem:
     vor_idx: Optional[np.ndarray] = None
     vor_neighs: Optional[np.ndarray] = None
     vor_box: tuple = (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)
+    # grid_type 'amr' (src/grid/grid_geometry_amr.f90:111-180): the grids of all levels, level by
+    # level: amr_level (g,) 1-based, amr_n (g,3) = n1,n2,n3, amr_bounds (g,6) = xmin,xmax,...;
+    # density (n_dust, n_cells) with the cells of grid after grid, x fastest
+    amr_level: Optional[np.ndarray] = None
+    amr_n: Optional[np.ndarray] = None
+    amr_bounds: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.walls = [_f64(w) for w in self.walls]
@@ -216,6 +222,15 @@ class Problem:
             if self.density.ndim == 1:
                 self.density = self.density[None]
             want = (len(self.dust), n)
+        elif self.grid_type == "amr":
+            self.amr_level = np.ascontiguousarray(self.amr_level, dtype=np.int32).reshape(-1)
+            self.amr_n = np.ascontiguousarray(self.amr_n, dtype=np.int32).reshape(-1, 3)
+            self.amr_bounds = _f64(self.amr_bounds).reshape(-1, 6)
+            if not (self.amr_level.size == self.amr_n.shape[0] == self.amr_bounds.shape[0]) or np.any(np.diff(self.amr_level) < 0):
+                raise ValueError("amr grids must be listed level by level")
+            if self.density.ndim == 1:
+                self.density = self.density[None]
+            want = (len(self.dust), int(np.prod(self.amr_n, axis=1).sum()))
         else:
             raise ValueError("Unexpected coordinate type: %s" % self.grid_type)
         if self.density.shape != want:
@@ -231,6 +246,8 @@ class Problem:
             return (self.refined.size,)
         if self.grid_type == "vor":
             return (self.vor_sites.shape[0],)
+        if self.grid_type == "amr":
+            return (int(np.prod(self.amr_n, axis=1).sum()),)
         return tuple(w.size - 1 for w in self.walls)
 
     @property
@@ -272,6 +289,10 @@ class Problem:
             return 8.0 * h[:, 0] * h[:, 1] * h[:, 2]
         if self.grid_type == "vor":
             return np.maximum(self.vor_volume, 0.0)
+        if self.grid_type == "amr":
+            b, n = self.amr_bounds, self.amr_n
+            v = ((b[:, 1] - b[:, 0]) / n[:, 0]) * ((b[:, 3] - b[:, 2]) / n[:, 1]) * ((b[:, 5] - b[:, 4]) / n[:, 2])
+            return np.repeat(v, np.prod(n, axis=1))
         dx, dy, dz = (np.diff(w) for w in self.walls)
         return dz[:, None, None] * dy[None, :, None] * dx[None, None, :]
 
@@ -287,7 +308,7 @@ class Problem:
             arrays["walls_%d" % (i + 1)] = w
         if self.refined is not None:
             arrays["refined"] = self.refined
-        for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs"):
+        for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds"):
             if getattr(self, k) is not None:
                 arrays[k] = getattr(self, k)
         arrays["density"] = self.density
@@ -375,4 +396,4 @@ class Problem:
                    oct_center=tuple(meta.get("oct_center", (0.0, 0.0, 0.0))),
                    oct_half=tuple(meta.get("oct_half", (1.0, 1.0, 1.0))),
                    vor_box=tuple(meta.get("vor_box", (0.0, 1.0, 0.0, 1.0, 0.0, 1.0))),
-                   **{k: z[k] for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs") if k in z.files})
+                   **{k: z[k] for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds") if k in z.files})

@@ -113,11 +113,31 @@ def read_rtin(path):
                          vor_idx=np.asarray(geo["sparse_idx"][...]).astype(np.int32),
                          vor_neighs=np.asarray(geo["sparse_neighs"][...]).astype(np.int32),
                          vor_box=tuple(float(ga[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")))
+        elif grid_type == "amr":
+            walls = []
+            lev, nn, bounds, paths = [], [], [], []
+            for il in range(1, int(geo.attrs["nlevels"]) + 1):
+                gl = geo["level_%05d" % il]
+                for ig in range(1, int(gl.attrs["ngrids"]) + 1):
+                    ga = gl["grid_%05d" % ig].attrs
+                    lev.append(il)
+                    nn.append([int(ga["n1"]), int(ga["n2"]), int(ga["n3"])])
+                    bounds.append([float(ga[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")])
+                    paths.append("level_%05d/grid_%05d" % (il, ig))
+            extra = dict(amr_level=np.array(lev, dtype=np.int32), amr_n=np.array(nn, dtype=np.int32), amr_bounds=np.array(bounds))
         else:
             raise NotImplementedError("grid type %r is not supported yet" % grid_type)
         q = f["Grid/Quantities"]
-        density = q["density"][...]
-        spec = q["specific_energy"][...] if "specific_energy" in q else None
+        if grid_type == "amr":
+            # read_grid_4d for AMR (src/grid/grid_io_amr_template.f90): one (n_dust, n3, n2, n1) array per grid
+            def gather(name):
+                parts = [np.asarray(q[p][name][...], dtype=float) for p in paths]
+                return np.concatenate([a.reshape(a.shape[0], -1) for a in parts], axis=1)
+            density = gather("density")
+            spec = gather("specific_energy") if "specific_energy" in q[paths[0]] else None
+        else:
+            density = q["density"][...]
+            spec = q["specific_energy"][...] if "specific_energy" in q else None
         n_dust = density.shape[0]
         mse = np.zeros(n_dust)
         if "minimum_specific_energy" in q.attrs:

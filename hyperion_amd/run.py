@@ -186,7 +186,20 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
             g.attrs["killed_photons_int"] = np.int32(rec.killed_int)
             for name in ("specific_energy", "density"):
                 a = getattr(rec, name)
-                if a is not None:
+                if a is None:
+                    continue
+                if problem.grid_type == "amr":
+                    # write_grid_4d for AMR (src/grid/grid_io_amr_template.f90): one (n_dust, n3, n2, n1)
+                    # dataset per level_NNNNN/grid_NNNNN group
+                    a = np.asarray(a).reshape(problem.n_dust, -1)
+                    start, count = 0, {}
+                    for lev, n in zip(problem.amr_level, problem.amr_n):
+                        count[int(lev)] = count.get(int(lev), 0) + 1
+                        nc = int(n[0]) * int(n[1]) * int(n[2])
+                        gg = g.require_group("level_%05d/grid_%05d" % (int(lev), count[int(lev)]))
+                        gg.create_dataset(name, data=a[:, start:start + nc].reshape(problem.n_dust, n[2], n[1], n[0]), compression="gzip")
+                        start += nc
+                else:
                     d = g.create_dataset(name, data=a, compression="gzip")
                     d.attrs["geometry"] = geo
         f.attrs["converged"] = b("yes" if result.converged else "no")

@@ -74,9 +74,10 @@ typedef struct hyp_source_desc {
 
 /* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),
  * src/grid/grid_geometry_octree.f90:184-246 (type 2),
- * src/grid/grid_geometry_voronoi.f90:96-188 (type 3) */
+ * src/grid/grid_geometry_voronoi.f90:96-188 (type 3),
+ * src/grid/grid_geometry_amr.f90:111-508 (type 4) */
 typedef struct hyp_grid_desc {
-    int32_t type;          /* 1 cartesian, 2 octree, 3 voronoi */
+    int32_t type;          /* 1 cartesian, 2 octree, 3 voronoi, 4 amr */
     int32_t n1, n2, n3;    /* cartesian: cells per axis */
     const double *w1;      /* cartesian: [n1+1] walls */
     const double *w2;
@@ -91,6 +92,12 @@ typedef struct hyp_grid_desc {
     const int32_t *vor_idx;     /* [n_cells+1] sparse_idx (CSR offsets) */
     const int32_t *vor_neighs;  /* sparse_neighs: 0-based ids; -1..-6 = xmin,xmax,ymin,ymax,zmin,zmax walls */
     double vor_box[6];          /* attrs xmin,xmax,ymin,ymax,zmin,zmax */
+    /* amr (type 4): level_NNNNN/grid_NNNNN groups flattened level by level; n_cells = sum n1*n2*n3,
+     * cells numbered grid after grid with x fastest (src/core/type_cell_id_amr.f90:57-93) */
+    int32_t n_amr_levels, n_amr_grids;
+    const int32_t *amr_level;   /* [n_amr_grids] 1-based level of each grid, non-decreasing */
+    const int32_t *amr_n;       /* [n_amr_grids][3] attrs n1,n2,n3 */
+    const double *amr_bounds;   /* [n_amr_grids][6] attrs xmin,xmax,ymin,ymax,zmin,zmax */
 } hyp_grid_desc;
 
 /* root attributes -- src/main/setup_rt.f90:38-302 */
@@ -145,7 +152,7 @@ typedef struct hyp_problem {
     const hyp_dust_desc   *dust;
     const hyp_source_desc *sources;
     const hyp_peeled_desc *peeled;
-    const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree, voronoi), as in the .rtin */
+    const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree, voronoi, amr), as in the .rtin */
     const double *specific_energy;   /* same shape, or NULL */
 } hyp_problem;
 

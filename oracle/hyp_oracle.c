@@ -350,7 +350,16 @@ typedef struct {
     size_t sed_size, img_size;
 } peeled_t;
 
-enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3 };
+enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3, GRID_AMR = 4 };
+
+/* one grid of an AMR level: type_grid_amr.f90:12-21 */
+typedef struct amr_grid {
+    int level, n[3];
+    double lo[3], hi[3], width[3], volume;
+    double *w[3];               /* linspace(lo, hi, n+1) */
+    size_t start;               /* unique id of the first cell */
+    int32_t *go;                /* [(n3+2)][(n2+2)][(n1+2)] grid to continue in (global index + 1), 0 = stay */
+} amr_grid;
 
 struct orc_state {
     char err[512];
@@ -368,6 +377,11 @@ struct orc_state {
     double vbox[6];
     int vg;                     /* seed grid for the nearest-site search: vg^3 cells */
     int32_t *vseed;
+    /* amr: grid_geometry_amr.f90 */
+    int n_amr_grids, n_amr_levels;
+    amr_grid *amr;
+    int32_t *amr_cell_grid;     /* [n_cells] grid of each unique id */
+    double amr_eps;
     double *w[3], *ew[3];
     int n[3];
     double *volume;
@@ -678,6 +692,203 @@ static int voronoi_setup(orc_state *st, const orc_grid_desc *gd)
     return 0;
 }
 
+
+/* ---- AMR: grid_geometry_amr.f90 ------------------------------------------- */
+
+static inline int amr_in_grid(const amr_grid *g, const double r[3])   /* in_grid :82-96 */
+{
+    for (int a = 0; a < 3; a++) { if (r[a] < g->lo[a]) return 0; if (r[a] > g->hi[a]) return 0; }
+    return 1;
+}
+
+static inline size_t amr_go_index(const amr_grid *g, int i1, int i2, int i3)   /* indices 0..n+1 */
+{
+    return ((size_t)i3 * (g->n[1] + 2) + i2) * (g->n[0] + 2) + i1;
+}
+
+static int amr_covered(const orc_state *st, size_t ic)
+{
+    const amr_grid *g = &st->amr[st->amr_cell_grid[ic]];
+    size_t l = ic - g->start;
+    int i1 = (int)(l % g->n[0]), i2 = (int)((l / g->n[0]) % g->n[1]), i3 = (int)(l / ((size_t)g->n[0] * g->n[1]));
+    return g->go[amr_go_index(g, i1 + 1, i2 + 1, i3 + 1)] != 0;
+}
+
+/* aligned :184-191 */
+static int amr_aligned(double x1, double x2, double dx)
+{
+    double r = fmod(fabs(x1 - x2), dx);
+    if (r > 0.5 * dx) r = dx - r;
+    return fabs(r / dx) < 1.e-8;
+}
+
+/* read_grid/read_level + setup_grid_geometry :111-508 */
+static int amr_setup(orc_state *st, const orc_grid_desc *gd)
+{
+    int ng = gd->n_amr_grids, nl = gd->n_amr_levels;
+    if (ng < 1 || nl < 1 || !gd->amr_level || !gd->amr_n || !gd->amr_bounds) { snprintf(g_error, sizeof g_error, "amr grid needs levels and grids"); return 1; }
+    st->n_amr_grids = ng; st->n_amr_levels = nl;
+    st->amr = calloc(ng, sizeof(amr_grid));
+    size_t start = 0; double min_width = DBL_MAX;
+    for (int k = 0; k < ng; k++) {
+        amr_grid *g = &st->amr[k];
+        g->level = gd->amr_level[k];
+        if (g->level < 1 || g->level > nl || (k > 0 && g->level < st->amr[k - 1].level)) { snprintf(g_error, sizeof g_error, "amr grids must be listed level by level"); return 1; }
+        for (int a = 0; a < 3; a++) {
+            g->n[a] = gd->amr_n[3 * k + a];
+            g->lo[a] = gd->amr_bounds[6 * k + 2 * a]; g->hi[a] = gd->amr_bounds[6 * k + 2 * a + 1];
+            g->w[a] = malloc(sizeof(double) * (g->n[a] + 1));
+            /* fortranlib linspace: x(i) = (xmax - xmin) * (i - 1) / (n - 1) + xmin */
+            for (int i = 0; i <= g->n[a]; i++) g->w[a][i] = (g->hi[a] - g->lo[a]) * (double)i / (double)g->n[a] + g->lo[a];
+            g->width[a] = (g->hi[a] - g->lo[a]) / (double)g->n[a];
+            if (g->width[a] < min_width) min_width = g->width[a];
+        }
+        g->volume = g->width[0] * g->width[1] * g->width[2];
+        g->start = start; start += (size_t)g->n[0] * g->n[1] * g->n[2];
+        g->go = calloc((size_t)(g->n[0] + 2) * (g->n[1] + 2) * (g->n[2] + 2), sizeof(int32_t));
+    }
+    st->n_cells = start;
+    st->amr_eps = min_width / 2.0;
+    /* consistency checks of :226-305, with the reference's messages */
+    for (int k = 0; k < ng; k++) {
+        const amr_grid *g = &st->amr[k];
+        int ref = -1;
+        for (int q = 0; q < ng; q++) if (st->amr[q].level == g->level) { ref = q; break; }
+        const amr_grid *gr = &st->amr[ref];
+        int igrid = k - ref + 1;
+        for (int a = 0; a < 3; a++) {
+            if (fabs(g->width[a] - gr->width[a]) > 1.e-10 * g->width[a]) {
+                snprintf(g_error, sizeof g_error, "Grids 1 and %d in level %d have differing cell widths in the %c direction", igrid, g->level, "xyz"[a]);
+                return 1;
+            }
+            if (!amr_aligned(g->lo[a], gr->lo[a], gr->width[a])) {
+                snprintf(g_error, sizeof g_error, "Grids 1 and %d in level %d have edges that are not separated by an integer number of cells in the %c direction", igrid, g->level, "xyz"[a]);
+                return 1;
+            }
+        }
+        if (g->level > 1) {
+            int pref = -1;
+            for (int q = 0; q < ng; q++) if (st->amr[q].level == g->level - 1) { pref = q; break; }
+            if (pref < 0) { snprintf(g_error, sizeof g_error, "amr level %d has no grids", g->level - 1); return 1; }
+            const amr_grid *gp = &st->amr[pref];
+            for (int a = 0; a < 3; a++) {
+                double rf = gp->width[a] / gr->width[a];
+                if (fabs(rf - nearbyint(rf)) > 1.e-10) {
+                    snprintf(g_error, sizeof g_error, "Refinement factor in the %c direction between level %d and level %d is not an integer (%.3f)", "xyz"[a], g->level - 1, g->level, rf);
+                    return 1;
+                }
+                if (!amr_aligned(g->lo[a], gp->lo[a], gp->width[a])) {
+                    snprintf(g_error, sizeof g_error, "Grid %d in level %d is not aligned with cells in level %d in the %c direction", igrid, g->level, g->level - 1, "xyz"[a]);
+                    return 1;
+                }
+            }
+        }
+    }
+    st->volume = malloc(sizeof(double) * st->n_cells);
+    st->amr_cell_grid = malloc(sizeof(int32_t) * st->n_cells);
+    for (int k = 0; k < ng; k++) {
+        const amr_grid *g = &st->amr[k];
+        size_t nc = (size_t)g->n[0] * g->n[1] * g->n[2];
+        for (size_t c = 0; c < nc; c++) { st->volume[g->start + c] = g->volume; st->amr_cell_grid[g->start + c] = k; }
+    }
+    /* cells overlapped by a grid of the next level (:357-382); later grids overwrite earlier ones */
+    for (int l1 = nl - 1; l1 >= 1; l1--)
+        for (int k1 = 0; k1 < ng; k1++) {
+            amr_grid *g1 = &st->amr[k1];
+            if (g1->level != l1) continue;
+            for (int k2 = 0; k2 < ng; k2++) {
+                const amr_grid *g2 = &st->amr[k2];
+                if (g2->level != l1 + 1) continue;
+                int hit = 1;
+                for (int a = 0; a < 3; a++) if (g1->hi[a] < g2->lo[a] || g1->lo[a] > g2->hi[a]) hit = 0;   /* grids_intersect */
+                if (!hit) continue;
+                for (int i1 = 1; i1 <= g1->n[0]; i1++) for (int i2 = 1; i2 <= g1->n[1]; i2++) for (int i3 = 1; i3 <= g1->n[2]; i3++) {
+                    double r[3] = {0.5 * (g1->w[0][i1 - 1] + g1->w[0][i1]), 0.5 * (g1->w[1][i2 - 1] + g1->w[1][i2]), 0.5 * (g1->w[2][i3 - 1] + g1->w[2][i3])};
+                    if (amr_in_grid(g2, r)) g1->go[amr_go_index(g1, i1, i2, i3)] = k2 + 1;
+                }
+            }
+        }
+    /* one step outside each grid: which grid of the same or a coarser level is there (:384-486) */
+    for (int k1 = 0; k1 < ng; k1++) {
+        amr_grid *g1 = &st->amr[k1];
+        for (int l2 = g1->level; l2 >= 1; l2--)
+            for (int k2 = 0; k2 < ng; k2++) {
+                const amr_grid *g2 = &st->amr[k2];
+                if (g2->level != l2 || k2 == k1) continue;
+                int close = 1;   /* grids_close :69-80 */
+                for (int a = 0; a < 3; a++)
+                    if (g1->hi[a] < g2->lo[a] - g2->width[a] * 0.5 || g1->lo[a] > g2->hi[a] + g2->width[a] * 0.5) close = 0;
+                if (!close) continue;
+                for (int a = 0; a < 3; a++) {
+                    const int b = (a + 1) % 3, c = (a + 2) % 3;
+                    for (int side = 0; side < 2; side++) {
+                        int idx[3]; double r[3];
+                        idx[a] = side ? g1->n[a] + 1 : 0;
+                        r[a] = side ? g1->hi[a] + g1->width[a] * 0.5 : g1->lo[a] - g1->width[a] * 0.5;
+                        for (int ib = 1; ib <= g1->n[b]; ib++) for (int ic = 1; ic <= g1->n[c]; ic++) {
+                            idx[b] = ib; idx[c] = ic;
+                            r[b] = 0.5 * (g1->w[b][ib - 1] + g1->w[b][ib]); r[c] = 0.5 * (g1->w[c][ic - 1] + g1->w[c][ic]);
+                            size_t q = amr_go_index(g1, idx[0], idx[1], idx[2]);
+                            if (amr_in_grid(g2, r) && g1->go[q] == 0) g1->go[q] = k2 + 1;
+                        }
+                    }
+                }
+            }
+    }
+    return 0;
+}
+
+/* ipos (fortranlib): 1-based bin of x in n equal bins of [xmin, xmax]; 0 below, n+1 above */
+static inline int amr_ipos(double xmin, double xmax, double x, int n)
+{
+    if (x < xmin) return 0;
+    if (x > xmax) return n + 1;
+    if (x < xmax) { int i = (int)((x - xmin) / (xmax - xmin) * (double)n) + 1; return i > n ? n : i; }
+    return n;
+}
+
+/* ipos2 :510-519 */
+static inline int amr_ipos2(double xmin, double xmax, double x, int n)
+{
+    double eps = (xmax - xmin) * 1.e-10;
+    int i = amr_ipos(xmin, xmax, x, n);
+    if (i == 0 && fabs(x - xmin) < eps) i = 1;
+    if (i == n + 1 && fabs(x - xmax) < eps) i = n;
+    return i;
+}
+
+/* find_position_in_grid :521-545: unique id, or -1 (invalid_cell) */
+static int64_t amr_find_position(const orc_state *st, const double r[3], int k)
+{
+    for (;;) {
+        const amr_grid *g = &st->amr[k];
+        int i[3];
+        for (int a = 0; a < 3; a++) i[a] = amr_ipos2(g->lo[a], g->hi[a], r[a], g->n[a]);
+        int32_t go = g->go[amr_go_index(g, i[0], i[1], i[2])];
+        if (go == 0) {
+            for (int a = 0; a < 3; a++) if (i[a] < 1 || i[a] > g->n[a]) return -1;
+            return (int64_t)(g->start + ((size_t)(i[2] - 1) * g->n[1] + (i[1] - 1)) * g->n[0] + (i[0] - 1));
+        }
+        k = go - 1;
+    }
+}
+
+/* find_cell_position :560-572 */
+static int64_t amr_find_cell(const orc_state *st, const double r[3])
+{
+    for (int k = 0; k < st->n_amr_grids && st->amr[k].level == 1; k++)
+        if (amr_in_grid(&st->amr[k], r)) return amr_find_position(st, r, k);
+    return -1;
+}
+
+static inline void amr_cell_coords(const orc_state *st, size_t ic, const amr_grid **gp, int i[3])
+{
+    const amr_grid *g = &st->amr[st->amr_cell_grid[ic]];
+    size_t l = ic - g->start;
+    i[0] = (int)(l % g->n[0]); i[1] = (int)((l / g->n[0]) % g->n[1]); i[2] = (int)(l / ((size_t)g->n[0] * g->n[1]));
+    *gp = g;
+}
+
 /* setup_grid_geometry + octree_setup_indiv: grid_geometry_octree.f90:147-246.
  * Cells are numbered depth-first (pre-order) as the `refined` list is read. */
 static int octree_setup(orc_state *st, const orc_grid_desc *gd)
@@ -735,7 +946,7 @@ int orc_create(const orc_problem *pr, orc_state **out)
 {
     g_error[0] = 0;
     if (!pr || !out) { snprintf(g_error, sizeof g_error, "null argument"); return 1; }
-    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT && pr->grid.type != GRID_VOR) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
+    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT && pr->grid.type != GRID_VOR && pr->grid.type != GRID_AMR) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
@@ -764,6 +975,8 @@ int orc_create(const orc_problem *pr, orc_state **out)
                 (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
     } else if (st->grid_type == GRID_OCT) {
         if (octree_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
+    } else if (st->grid_type == GRID_AMR) {
+        if (amr_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     } else {
         if (voronoi_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     }
@@ -825,6 +1038,10 @@ int orc_create(const orc_problem *pr, orc_state **out)
         for (int d = 0; d < st->n_dust; d++)
             for (size_t ic = 0; ic < st->n_cells; ic++)
                 if (st->orefined[ic]) st->density[(size_t)d * st->n_cells + ic] = 0.0;
+    if (st->grid_type == GRID_AMR)   /* mask = cells not covered by a finer grid: grid_geometry_amr.f90:489-496 */
+        for (int d = 0; d < st->n_dust; d++)
+            for (size_t ic = 0; ic < st->n_cells; ic++)
+                if (amr_covered(st, ic)) st->density[(size_t)d * st->n_cells + ic] = 0.0;
     if (st->grid_type == GRID_VOR)   /* mask = volume > 0: grid_geometry_voronoi.f90:161-173 */
         for (int d = 0; d < st->n_dust; d++)
             for (size_t ic = 0; ic < st->n_cells; ic++)
@@ -869,6 +1086,8 @@ void orc_destroy(orc_state *st)
     free(st->ox); free(st->oy); free(st->oz); free(st->odx); free(st->ody); free(st->odz);
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
     free(st->vsite); free(st->vidx); free(st->vneigh); free(st->vseed);
+    if (st->amr) { for (int g = 0; g < st->n_amr_grids; g++) { free(st->amr[g].go); for (int a = 0; a < 3; a++) free(st->amr[g].w[a]); } free(st->amr); }
+    free(st->amr_cell_grid);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
@@ -991,6 +1210,12 @@ static int find_cell(const orc_state *st, const double r[3], int ic[3])
         ic[0] = vor_nearest(st, r); ic[1] = ic[2] = 0;
         return 1;
     }
+    if (st->grid_type == GRID_AMR) {
+        int64_t id = amr_find_cell(st, r);
+        if (id < 0) return 0;
+        ic[0] = (int)id; ic[1] = ic[2] = 0;
+        return 1;
+    }
     if (st->grid_type == GRID_OCT) {
         if (r[0] < st->obox[0] || r[0] > st->obox[1]) return 0;
         if (r[1] < st->obox[2] || r[1] > st->obox[3]) return 0;
@@ -1052,6 +1277,22 @@ static int in_correct_cell(const orc_state *st, const photon_t *p)
             if (d < d2) { d2 = d; n2 = nb; }
         }
         return n2 == p->ic[0];
+    }
+    if (st->grid_type == GRID_AMR) {   /* grid_geometry_amr.f90:677-726: position within the packet's own grid */
+        const amr_grid *g; int ci[3];
+        amr_cell_coords(st, (size_t)p->ic[0], &g, ci);
+        int ok = 1;
+        for (int a = 0; a < 3; a++) {
+            int actual = amr_ipos(g->lo[a], g->hi[a], p->r[a], g->n[a]) - 1;
+            if (on_wall && p->on_wall[a] == -1) {
+                double f = (p->r[a] - g->w[a][ci[a]]) / (g->w[a][ci[a] + 1] - g->w[a][ci[a]]);
+                ok = ok && fabs(f) < thr;
+            } else if (on_wall && p->on_wall[a] == +1) {
+                double f = (p->r[a] - g->w[a][ci[a] + 1]) / (g->w[a][ci[a] + 1] - g->w[a][ci[a]]);
+                ok = ok && fabs(f) < thr;
+            } else ok = ok && actual == ci[a];
+        }
+        return ok;
     }
     if (st->grid_type == GRID_OCT) {   /* grid_geometry_octree.f90:366-392 */
         int32_t id = p->ic[0];
@@ -1143,9 +1384,54 @@ static int find_wall_vor(const orc_state *st, const photon_t *p, double *tneares
     return found;
 }
 
+/* find_wall: grid_geometry_amr.f90:775-871.  Returns 0 if no wall, -1 on the reference's fatal "negative t". */
+static int find_wall_amr(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    const amr_grid *g; int ci[3];
+    amr_cell_coords(st, (size_t)p->ic[0], &g, ci);
+    double t[3]; int pos[3];
+    for (int a = 0; a < 3; a++) {
+        pos[a] = p->v[a] > 0.0;
+        if (pos[a]) t[a] = (g->w[a][ci[a] + 1] - p->r[a]) / p->v[a];
+        else if (p->v[a] < 0.0) t[a] = (g->w[a][ci[a]] - p->r[a]) / p->v[a];
+        else t[a] = DBL_MAX;
+    }
+    id_min[0] = id_min[1] = id_min[2] = 0;
+    if (fmin(t[0], fmin(t[1], t[2])) < 0.0) return -1;
+    int a;
+    if (t[0] < t[2]) { if (t[0] < t[1]) a = 0; else a = 1; }
+    else { if (t[2] < t[1]) a = 2; else a = 1; }
+    *tnearest = t[a]; id_min[a] = pos[a] ? +1 : -1;
+    return 1;
+}
+
+/* next_cell_int :599-655 */
+static int64_t amr_next_cell(const orc_state *st, size_t ic, int axis, int dir, const double r_in[3])
+{
+    const amr_grid *g; int ci[3];
+    amr_cell_coords(st, ic, &g, ci);
+    int i[3] = {ci[0] + 1, ci[1] + 1, ci[2] + 1};      /* 1-based like the goto tables */
+    i[axis] += dir;
+    int32_t go = g->go[amr_go_index(g, i[0], i[1], i[2])];
+    if (go == 0) {
+        for (int a = 0; a < 3; a++) if (i[a] == 0 || i[a] == g->n[a] + 1) return (int64_t)st->n_cells;   /* outside_cell */
+        return (int64_t)(g->start + ((size_t)(i[2] - 1) * g->n[1] + (i[1] - 1)) * g->n[0] + (i[0] - 1));
+    }
+    double r[3] = {r_in[0], r_in[1], r_in[2]};
+    r[axis] = dir > 0 ? r[axis] + st->amr_eps : r[axis] - st->amr_eps;
+    return amr_find_position(st, r, go - 1);
+}
+
 /* p%icell = next_cell(p%icell, id_min, intersection=p%r); p%on_wall_id = opposite_wall(id_min) */
 static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
 {
+    if (st->grid_type == GRID_AMR) {   /* next_cell_wall_id :657-675 */
+        int axis = id_min[0] ? 0 : id_min[1] ? 1 : 2;
+        int64_t nx = amr_next_cell(st, (size_t)p->ic[0], axis, id_min[axis], p->r);
+        p->ic[0] = (int)nx;            /* -1 = invalid_cell: the caller kills the packet */
+        for (int a = 0; a < 3; a++) p->on_wall[a] = -id_min[a];
+        return;
+    }
     if (st->grid_type == GRID_VOR) {   /* next_cell_wall_id :266-272: wall id = cell id */
         p->ic[0] = id_min[0] - 1;
         for (int a = 0; a < 3; a++) p->on_wall[a] = -id_min[a];
@@ -1165,6 +1451,7 @@ static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, i
 {
     if (st->grid_type == GRID_OCT) return find_wall_oct(st, p, tnearest, id_min);
     if (st->grid_type == GRID_VOR) return find_wall_vor(st, p, tnearest, id_min);
+    if (st->grid_type == GRID_AMR) return find_wall_amr(st, p, tnearest, id_min);
     double tmin = DBL_MAX, emin = 0.0;
     int imin[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
@@ -1196,6 +1483,12 @@ static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, i
  * grid_integrate_noenergy :237-375 (deposit == NULL)                   */
 /* ------------------------------------------------------------------ */
 
+/* find_wall of the AMR grid stops the reference with error("find_wall","negative t") */
+static void amr_negative_t(acc_t *acc)
+{
+    if (!acc->fatal) { acc->fatal = 1; snprintf(acc->err, sizeof acc->err, "negative t"); }
+}
+
 static void grid_integrate(const orc_state *st, photon_t *p, double tau_required,
                            rng_t *g, acc_t *acc, double *deposit)
 {
@@ -1209,7 +1502,9 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
         } else g->countdown--;
         double tau_needed = tau_required - tau_achieved;
         double tmin; int id_min[3];
-        if (!find_wall(st, p, &tmin, id_min)) { acc->killed_geo++; p->killed = 1; return; }
+        int fw = find_wall(st, p, &tmin, id_min);
+        if (fw < 0) { amr_negative_t(acc); p->killed = 1; return; }
+        if (!fw) { acc->killed_geo++; p->killed = 1; return; }
         size_t ic = cell_index(st, p->ic);
         double chi_rho_total = 0.0;
         for (int d = 0; d < st->n_dust; d++) chi_rho_total += p->chi[d] * st->density[(size_t)d * st->n_cells + ic];
@@ -1223,6 +1518,7 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
                     if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
                         deposit[(size_t)d * st->n_cells + ic] += tmin * p->kappa[d] * p->energy;
             advance_cell(st, p, id_min);
+            if (st->grid_type == GRID_AMR && p->ic[0] < 0) { acc->killed_geo++; p->killed = 1; return; }   /* invalid_cell */
             if (escaped(st, p->ic)) return;
         } else {
             double tact = tmin * (tau_needed / tau_cell);
@@ -1253,7 +1549,9 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
             if (!in_correct_cell(st, &p)) { acc->killed_geo++; *killed = 1; return tau; }
         } else g->countdown--;
         double tmin; int id_min[3];
-        if (!find_wall(st, &p, &tmin, id_min)) { acc->killed_geo++; *killed = 1; return tau; }
+        int fw = find_wall(st, &p, &tmin, id_min);
+        if (fw < 0) { amr_negative_t(acc); *killed = 1; return tau; }
+        if (!fw) { acc->killed_geo++; *killed = 1; return tau; }
         size_t ic = cell_index(st, p.ic);
         int finished = 0;
         if (t_achieved + tmin > tmax) { tmin = tmax - t_achieved; finished = 1; }
@@ -1263,6 +1561,7 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
         acc->crossings++;
         if (finished) return tau;
         advance_cell(st, &p, id_min);
+        if (st->grid_type == GRID_AMR && p.ic[0] < 0) { acc->killed_geo++; *killed = 1; return tau; }   /* invalid_cell */
         if (escaped(st, p.ic)) return tau;
     }
 }
@@ -1954,7 +2253,7 @@ int orc_walk_ray(const orc_state *st, const double r0[3], const double v[3], dou
     int n = 0; double path = 0.0;
     while (!escaped(st, p.ic)) {
         double tmin; int id_min[3];
-        if (!find_wall(st, &p, &tmin, id_min)) return -2;
+        if (find_wall(st, &p, &tmin, id_min) <= 0) return -2;
         for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
         advance_cell(st, &p, id_min);
         path += tmin; n++;

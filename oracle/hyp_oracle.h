@@ -76,7 +76,7 @@ typedef struct orc_source_desc {
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */
 typedef struct orc_grid_desc {
-    int32_t type;          /* 1 = cartesian, 2 = octree, 3 = voronoi */
+    int32_t type;          /* 1 = cartesian, 2 = octree, 3 = voronoi, 4 = amr */
     int32_t n1, n2, n3;
     const double *w1;      /* [n1+1] */
     const double *w2;      /* [n2+1] */
@@ -93,6 +93,12 @@ typedef struct orc_grid_desc {
     const int32_t *vor_idx;      /* [n_cells+1] CSR offsets (sparse_idx) */
     const int32_t *vor_neighs;   /* neighbour ids, -1..-6 = xmin,xmax,ymin,ymax,zmin,zmax walls */
     double vor_box[6];
+    /* amr (type 4, src/grid/grid_geometry_amr.f90:111-180): the grids of all levels, level by
+     * level; cells are numbered grid after grid, x fastest (type_cell_id_amr.f90:57-93) */
+    int32_t n_amr_levels, n_amr_grids;
+    const int32_t *amr_level;    /* [n_amr_grids] 1-based level of each grid, non-decreasing */
+    const int32_t *amr_n;        /* [n_amr_grids][3] n1, n2, n3 */
+    const double *amr_bounds;    /* [n_amr_grids][6] xmin, xmax, ymin, ymax, zmin, zmax */
 } orc_grid_desc;
 
 /* Run configuration: the root attributes of the .rtin

@@ -12,7 +12,7 @@ Run (only where /root/reference exists; the GPU box never runs this):
     LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
     (the preload lets conda's python load the voro++ extension built with the system g++)
 
-What it writes (inputs + expected outputs only); {grid} = car, oct:
+What it writes (inputs + expected outputs only); {grid} = car, oct, amr:
 
   {grid}_specific_energy.{evenly}.{multi}.npz
       inputs : the model of hyperion/model/tests/test_bit_level.py:137-173
@@ -74,7 +74,7 @@ for name, t in [("float", float), ("int", int), ("bool", bool), ("object", objec
 
 import h5py  # noqa: E402
 from hyperion.model import Model  # noqa: E402
-from hyperion.grid import CartesianGrid, OctreeGrid, VoronoiGrid  # noqa: E402
+from hyperion.grid import AMRGrid, CartesianGrid, OctreeGrid, VoronoiGrid  # noqa: E402
 from hyperion.dust import IsotropicDust, HenyeyGreensteinDust  # noqa: E402
 from hyperion.util.constants import pc, lsun  # noqa: E402
 
@@ -94,11 +94,18 @@ def car_grid_and_densities():
     y = np.linspace(-u, u, 6)
     z = np.linspace(-u, u, 4)
     grid = CartesianGrid(x, y, z)
-    # AMR level 1 and 2 densities are drawn before the per-grid densities
-    for _ in range(3):
-        np.random.random((4, 6, 8))
-    for _ in range(3):
-        np.random.random((20, 6, 4))
+    # AMR level 1 and 2 densities are drawn before the per-grid densities (test_bit_level.py:64-86)
+    amr = AMRGrid()
+    g1 = amr.add_level().add_grid()
+    g1.xmin, g1.xmax, g1.ymin, g1.ymax, g1.zmin, g1.zmax = -u, u, -u, u, -u, u
+    g1.nx, g1.ny, g1.nz = 8, 6, 4
+    for name in ("density", "density_2", "density_3"):
+        g1.quantities[name] = np.random.random((4, 6, 8)) * d
+    g2 = amr.add_level().add_grid()
+    g2.xmin, g2.xmax, g2.ymin, g2.ymax, g2.zmin, g2.zmax = -u, 0., -u, 0., -u, 0.
+    g2.nx, g2.ny, g2.nz = 4, 6, 20
+    for name in ("density", "density_2", "density_3"):
+        g2.quantities[name] = np.random.random((20, 6, 4)) * d
     shape_cyl = (6 - 1, 4 - 1, 8 - 1)
     shape_sph = (4 - 1, 8 - 1, 6 - 1)
     refined = [1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
@@ -110,7 +117,8 @@ def car_grid_and_densities():
         np.random.random(shape_cyl)
         np.random.random(shape_sph)
         dens_oct.append(np.random.random(25) * d)
-    return {"car": grid, "oct": grid_oct}, {"car": dens, "oct": dens_oct}
+    return ({"car": grid, "oct": grid_oct, "amr": amr},
+            {"car": dens, "oct": dens_oct, "amr": [amr["density"], amr["density_2"], amr["density_3"]]})
 
 
 def add_sources(m):
@@ -177,6 +185,19 @@ def build_model(grid, dens, evenly, multi=False):
     return m
 
 
+def read_specific_energy(group):
+    """(n_dust, ...) array of one iteration; AMR outputs (one dataset per level/grid) are
+    flattened to (n_dust, n_cells) in unique-id order (type_cell_id_amr.f90:57-93)."""
+    if "specific_energy" in group:
+        return group["specific_energy"][...]
+    parts = []
+    for lev in sorted(k for k in group if k.startswith("level_")):
+        for g in sorted(group[lev]):
+            a = group[lev][g]["specific_energy"][...]
+            parts.append(a.reshape(a.shape[0], -1))
+    return np.concatenate(parts, axis=1)
+
+
 def specific_energy_fixture(gt, grid, dens, evenly, multi, tmp):
     """test_bit_level.py:137-173"""
     m = build_model(grid, dens, evenly, multi)
@@ -185,8 +206,9 @@ def specific_energy_fixture(gt, grid, dens, evenly, multi, tmp):
     prob = write_and_read(m, tmp)
     ref = os.path.join(DATA, "test_specific_energy.grid_type=%s.sample_sources_evenly=%s.multiple_densities=%s.rtout" % (gt, evenly, multi))
     with h5py.File(ref, "r") as f:
-        assert f["iteration_00001/specific_energy"].attrs["geometry"].decode() == prob.geometry_id
-        se = np.array([f["iteration_%05d/specific_energy" % i][...] for i in range(1, 6)])
+        if gt != "amr":
+            assert f["iteration_00001/specific_energy"].attrs["geometry"].decode() == prob.geometry_id
+        se = np.array([read_specific_energy(f["iteration_%05d" % i]) for i in range(1, 6)])
         killed = np.array([[f["iteration_%05d" % i].attrs["killed_photons_geo"],
                             f["iteration_%05d" % i].attrs["killed_photons_int"]] for i in range(1, 6)])
     save(os.path.join(HERE, "%s_specific_energy.%s.%s.npz" % (gt, evenly, multi)), prob,
@@ -229,19 +251,24 @@ def peeloff_fixture(gt, grid, dens, evenly, tmp):
             for k in ("numin", "numax", "xmin", "xmax", "ymin", "ymax"):
                 golden["group%d/images_%s" % (g, k)] = np.float64(grp["images"].attrs[k])
         n_it = int(f.attrs["iterations"])
-        golden["specific_energy_last"] = f["iteration_%05d/specific_energy" % n_it][...]
+        golden["specific_energy_last"] = read_specific_energy(f["iteration_%05d" % n_it])
     save(os.path.join(HERE, "%s_peeloff.%s.npz" % (gt, evenly)), prob, golden)
+
+
+ONLY = [a for a in sys.argv[1:] if a in ("car", "oct", "amr")]      # restrict the grid types to regenerate
 
 
 def main():
     grids, denss = car_grid_and_densities()
     with tempfile.TemporaryDirectory() as tmp:
-        for gt in ("car", "oct"):
+        for gt in [g for g in ("car", "oct", "amr") if not ONLY or g in ONLY]:
             for evenly in (False, True):
                 for multi in (False, True):
                     specific_energy_fixture(gt, grids[gt], denss[gt], evenly, multi, tmp)
             for evenly in (False, True):
                 peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp)
+        if ONLY:
+            return
 
         # --- Voronoi inputs (BASELINE config 5, small) ----------------------------------
         np.random.seed(141412)

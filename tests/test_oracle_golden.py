@@ -19,9 +19,9 @@ K = 12
 N_BIG = 600000
 
 
-def _oracle_stats(prob, iteration_state=None):
+def _oracle_stats(prob, iteration_state=None, k=K):
     samples = []
-    for s in range(K):
+    for s in range(k):
         prob.config.seed = -(4000 + s)
         o = Oracle(prob)
         se, _ = o.lucy_iteration(10000, 1)
@@ -34,27 +34,47 @@ def _oracle_stats(prob, iteration_state=None):
     return big, np.std(np.array(samples), axis=0, ddof=1), st
 
 
-@pytest.mark.parametrize("grid", ["car", "oct"])
+def _amr_covered(prob):
+    """Level-1 cells of the reference's AMR test grid that lie under the level-2 grid (they are
+    masked: grid_geometry_amr.f90:489-496)."""
+    b, n = prob.amr_bounds, prob.amr_n
+    assert prob.amr_level.tolist() == [1, 2]
+    c = [b[0, 2 * a] + (np.arange(n[0, a]) + 0.5) * (b[0, 2 * a + 1] - b[0, 2 * a]) / n[0, a] for a in range(3)]
+    ins = [(c[a] >= b[1, 2 * a]) & (c[a] <= b[1, 2 * a + 1]) for a in range(3)]
+    m1 = (ins[2][:, None, None] & ins[1][None, :, None] & ins[0][None, None, :]).reshape(-1)
+    return np.concatenate([m1, np.zeros(int(np.prod(n[1])), dtype=bool)])
+
+
+@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
 @pytest.mark.parametrize("name", ["False.False", "True.False", "False.True", "True.True"])
 def test_first_iteration_matches_reference_golden(grid, name):
     prob, z = golden_problem("%s_specific_energy.%s.npz" % (grid, name))
     gold = z["golden/specific_energy"][0]
-    big, sigma, st = _oracle_stats(prob)
+    big, sigma, st = _oracle_stats(prob, k=60 if grid == "amr" else K)
     assert st["killed_geo"] == 0 and st["killed_int"] == 0
     assert np.all(z["golden/killed"] == 0)
-    if grid == "oct":
+    if grid in ("oct", "amr"):
         # refined (masked) cells hold no dust: the reference leaves them at the
         # minimum specific energy, exactly
-        ref = np.broadcast_to(prob.refined == 1, gold.shape)
+        ref = np.broadcast_to(prob.refined == 1 if grid == "oct" else _amr_covered(prob), gold.shape)
         np.testing.assert_array_equal(gold[ref], big[ref])
         gold, big, sigma = gold[~ref], big[~ref], sigma[~ref]
     zs = (gold - big) / sigma
     # sigma comes from K samples -> z is Student-t with K-1 dof (variance (K-1)/(K-3))
-    assert np.abs(zs).max() < 6.0
+    if grid == "amr":
+        # the 480 level-2 cells are 1/120 of a level-1 cell: a 1e4-packet realisation puts a
+        # handful of path segments in each, so their distribution is skewed (a few cells at
+        # 3-7 x the mean, never far below it); the normal-tail bound applies to well-sampled cells
+        well = sigma < 0.25 * big
+        assert well.sum() > 100
+        assert np.abs(zs[well]).max() < 6.0
+        assert (np.abs(zs) > 4.0).mean() < 0.02 and zs.min() > -6.0
+    else:
+        assert np.abs(zs).max() < 6.0
     assert abs(zs.mean()) < 0.35
     assert 0.6 < (zs ** 2).mean() < 1.9
     w = prob.density * prob.volumes
-    if grid == "oct":
+    if grid in ("oct", "amr"):
         w = w[~ref]
     assert (gold * w).sum() == pytest.approx((big * w).sum(), rel=0.04)
 
@@ -91,7 +111,7 @@ def _peeloff_run(prob, seed, n_lucy, n_img):
     return [finalize_peeled(p, r) for p, r in zip(prob.peeled, res)], st
 
 
-@pytest.mark.parametrize("grid", ["car", "oct"])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
 @pytest.mark.parametrize("evenly", [False, True])
 def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
     """test_peeloff.grid_type=car.raytracing=False.*.rtout (test_bit_level.py:175-236):

@@ -99,3 +99,54 @@ print(json.dumps(lay))
     want = json.load(open(os.path.join(GOLDEN, "rtout_layout.car_peeloff.json")))
     assert got["root_attrs"] == want["root_attrs"]
     assert got["items"] == want["items"]
+
+
+@needs_h5py
+def test_amr_rtin_reader_and_rtout_layout(tmp_path):
+    """AMR file contract: Grid/Geometry/level_NNNNN/grid_NNNNN attrs + one density dataset per
+    grid (hyperion/grid/amr_grid.py:336-420), and iteration outputs per level/grid
+    (golden: test_specific_energy.grid_type=amr.*.rtout)."""
+    q, _ = golden_problem("amr_specific_energy.False.True.npz")
+    rtin, out, rtout = tmp_path / "amr.rtin", tmp_path / "p.npz", tmp_path / "amr.rtout"
+    qn = tmp_path / "q.npz"
+    q.to_npz(str(qn))
+    code = ("import sys, h5py, numpy as np; sys.path.insert(0, %r)\n"
+            "from hyperion_amd.problem import Problem\n"
+            "from hyperion_amd.rtin import read_rtin\n"
+            "from hyperion_amd.run import write_rtout, RunResult, IterationRecord\n"
+            "q = Problem.from_npz(%r)\n"
+            "with h5py.File(%r, 'r') as fi, h5py.File(%r, 'w') as fo:\n"
+            "    for k, v in fi.attrs.items(): fo.attrs[k] = v\n"
+            "    for k in fi:\n"
+            "        if k != 'Grid': fi.copy(k, fo)\n"
+            "    for i in (2, 3): fo.copy(fo['Dust/dust_001'], 'Dust/dust_%%03d' %% i)\n"
+            "    g = fo.create_group('Grid/Geometry'); qq = fo.create_group('Grid/Quantities')\n"
+            "    g.attrs['grid_type'] = np.bytes_('amr'); g.attrs['geometry'] = np.bytes_('abc'); g.attrs['nlevels'] = 2\n"
+            "    start = 0\n"
+            "    for k, (lev, n, b) in enumerate(zip(q.amr_level, q.amr_n, q.amr_bounds)):\n"
+            "        gl = g.require_group('level_%%05d' %% lev); gl.attrs['ngrids'] = 1\n"
+            "        gg = gl.create_group('grid_00001')\n"
+            "        for name, v in zip(('xmin', 'xmax', 'ymin', 'ymax', 'zmin', 'zmax'), b): gg.attrs[name] = v\n"
+            "        for name, v in zip(('n1', 'n2', 'n3'), n): gg.attrs[name] = int(v)\n"
+            "        nc = int(np.prod(n))\n"
+            "        qq.create_group('level_%%05d/grid_00001' %% lev).create_dataset('density', data=q.density[:, start:start + nc].reshape(3, n[2], n[1], n[0]))\n"
+            "        start += nc\n"
+            "p = read_rtin(%r)\n"
+            "p.to_npz(%r)\n"
+            "res = RunResult(iterations=[IterationRecord(index=1, killed_geo=0, killed_int=0, specific_energy=p.density * 2.0)], converged=False,\n"
+            "                n_iterations=1, peeled=[], final_stats={}, cpu_time=0.0, date_started='x', date_ended='y')\n"
+            "write_rtout(%r, p, res)\n"
+            "with h5py.File(%r, 'r') as f:\n"
+            "    a = f['iteration_00001/level_00002/grid_00001/specific_energy'][...]\n"
+            "    assert a.shape == (3, 20, 6, 4), a.shape\n"
+            "    assert np.array_equal(a.reshape(3, -1), 2.0 * p.density[:, 192:])\n"
+            "    assert f['iteration_00001/level_00001/grid_00001/specific_energy'].shape == (3, 4, 6, 8)\n"
+            ) % (ROOT, str(qn), os.path.join(GOLDEN, "car_peeloff.False.rtin"), str(rtin), str(rtin), str(out), str(rtout), str(rtout))
+    subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+    from hyperion_amd.problem import Problem
+    p = Problem.from_npz(str(out))
+    assert p.grid_type == "amr" and p.n_cells == 8 * 6 * 4 + 4 * 6 * 20
+    np.testing.assert_array_equal(p.amr_n, q.amr_n)
+    np.testing.assert_array_equal(p.amr_level, q.amr_level)
+    np.testing.assert_array_equal(p.amr_bounds, q.amr_bounds)
+    np.testing.assert_array_equal(p.density, q.density)
