@@ -144,7 +144,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 3 << 21, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16;
+    int lucy_mode = -1, tile_slots = 3 << 21, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -251,7 +251,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
     constexpr int TBX = TileShape<ND>::X, TBY = TileShape<ND>::Y, TBZ = TileShape<ND>::Z;
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_walk = lds_w + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)TBX * TBY * TBZ * ND;
-    const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
+    const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * h->tile_prep_blocks);
     const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
     const int grid_w = T0.n_slots / T0.task_size + T0.n_bricks + 1;
     if (hipFuncSetAttribute((const void *)tile_walk_kernel<ND, TBX, TBY, TBZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
@@ -1289,6 +1289,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_pools") h->tile_pools = (int)value;
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = (int)value;
+    else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
 }
@@ -1308,6 +1309,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_pools") *value = h->tile_pools;
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
+    else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with
     else if (n == "last_generations") *value = h->last_generations;   // generations of the last tiled iteration
     else return h->set_error("unknown option: " + n);

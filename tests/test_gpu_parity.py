@@ -178,15 +178,17 @@ def test_empty_iteration_is_skipped():
 
 
 def test_full_size_properties_128():
-    """BASELINE config 2 size (128^3), 2e7 packets: size-independent properties.
+    """BASELINE configs[1] at its full size (128^3, 1e8 packets; runs the brick-tiled
+    schedule): size-independent properties.
     (a) conservation: sum(E rho V) equals the engine's own absorbed-energy tally
     and the expected absorbed fraction of L; (b) no packet lost; (c) packets per
     crossing statistics of the walk (173 +- 1 crossings per packet at tau=1);
     (d) 8-fold symmetry of the central source in a uniform cube."""
     p = make_benchmark_problem(128)
     eng = hyperion_amd.Engine(p)
-    n = 20_000_000
+    n = 100_000_000
     se, st = eng.lucy_iteration(n, 1)
+    assert eng.get_option("last_lucy_mode") == 1
     assert st["killed_geo"] == 0 and st["killed_int"] == 0 and st["energy_current"] == n
     tot = (se * p.density * p.volumes).sum()
     assert tot == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
@@ -201,6 +203,21 @@ def test_full_size_properties_128():
     r = np.sqrt(x * x + y * y + z * z) / PC
     shells = [e[(r > a) & (r <= a + 0.1)].mean() for a in np.arange(0.1, 0.9, 0.1)]
     assert np.all(np.diff(shells) < 0)
+    # (e) sharding property at full size: two id ranges, accumulated separately and summed like
+    # the all-reduce does, reproduce the whole iteration (same integer tallies, sums to rounding)
+    import torch
+    eng.lucy_launch(0, 37_000_000, 1)
+    part0 = eng.lucy_accumulators_tensor().clone()
+    eng.lucy_launch(37_000_000, n - 37_000_000, 1)
+    acc = eng.lucy_accumulators_tensor()
+    acc += part0
+    torch.cuda.synchronize()
+    out, st2 = eng.lucy_finish()
+    for k in INT_KEYS:
+        assert st2[k] == st[k], (k, st, st2)
+    assert st2["energy_current"] == st["energy_current"]
+    np.testing.assert_allclose(out, se, rtol=1e-10)
+    eng.close()
 
 
 # --- brick-tiled Lucy iteration (lucy_mode=1): same packets, same answer --------------------
