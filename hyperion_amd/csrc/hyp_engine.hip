@@ -223,7 +223,12 @@ namespace {
 
 // brick shape per number of species: density + accumulators (16 B per cell and
 // species) must leave room for two workgroups per CU in the 160 KB LDS
-template <int ND> struct TileShape { static constexpr int X = 16, Y = 16, Z = 16; };      // 64 KB
+#ifndef HYP_TILE_BX
+#define HYP_TILE_BX 16
+#define HYP_TILE_BY 16
+#define HYP_TILE_BZ 16
+#endif
+template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 64 KB
 template <> struct TileShape<2> { static constexpr int X = 16, Y = 16, Z = 8; };         // 64 KB
 template <> struct TileShape<3> { static constexpr int X = 16, Y = 8, Z = 8; };          // 48 KB
 template <> struct TileShape<4> { static constexpr int X = 16, Y = 8, Z = 8; };          // 64 KB

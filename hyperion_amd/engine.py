@@ -33,6 +33,30 @@ class EngineError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm ships its own libamdhip64.so.  Two HIP runtimes in one process do not
+    share the GPU: whichever initialises second reports "No HIP GPUs are available".  If torch
+    is installed but not imported yet, map ITS runtime first (without importing torch) so that
+    this library binds to the same copy torch will use later; if torch is already imported its
+    runtime is the one in the process and nothing needs doing."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library(path=None):
     """Load libhyperion_amd.so and declare the prototypes.  Raises if absent."""
     global _lib
@@ -42,6 +66,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % path)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(path)
     H = C.c_void_p
     L.hyp_abi_version.restype = C.c_int

@@ -8,7 +8,8 @@ import pytest
 
 import hyperion_amd
 from cases import assert_parity, golden_problem, ragged_grid_problem, spectrum_source_problem
-from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem
+from hyperion_amd.benchmark import LSUN, PC, load_test_dust, make_benchmark_problem
+from hyperion_amd.problem import Problem
 from oracle_lib import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -16,7 +17,7 @@ pytestmark = pytest.mark.gpu
 INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
 
 
-def run_both(prob, n, iters=1, **opts):
+def run_both(prob, n, iters=1, atol_rel=1e-12, **opts):
     eng = hyperion_amd.Engine(prob)
     for k, v in opts.items():
         eng.set_option(k, v)
@@ -29,7 +30,7 @@ def run_both(prob, n, iters=1, **opts):
             assert sa[k] == sb[k], (k, sa, sb)
         assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-13)
         np.testing.assert_allclose(sa["energy_abs_tot"], sb["energy_abs_tot"], rtol=1e-9)
-        assert_parity(a, b)
+        assert_parity(a, b, atol_rel=atol_rel)
         np.testing.assert_array_equal(a == 0, b == 0)
         out.append((a, sa))
     eng.close()
@@ -240,6 +241,35 @@ def test_tiled_benchmark_many_bricks():
     run_both(make_benchmark_problem(16), 50000, iters=2, tile_slots=4096, tile_task=256, tile_drain=0, **TILED)
     run_both(make_benchmark_problem(40), 300000, tile_slots=196608, tile_pools=3, tile_drain=0, **TILED)
     run_both(make_benchmark_problem(40), 300000, tile_slots=196608, tile_pools=2, tile_drain=1000, **TILED)
+
+
+@pytest.mark.parametrize("nd", [2, 3, 4])
+def test_tiled_many_bricks_several_species(nd):
+    """Brick shapes of 2 (16x16x8), 3 and 4 species (16x8x8) on a 40x36x20 grid: ragged bricks on
+    every axis, species with different opacities, one of them absent from a third of the cells.
+
+    Tolerance: tau ~ 3 with high albedo gives chains of 10-20 interactions.  The 1-ulp differences
+    between the device and host libm (sincos, log) grow by about an order of magnitude per
+    interaction along one trajectory -- traced for packet 93875 of the 3-species case: 14
+    interactions, identical event sequence and crossing count, deposits 2e-16 apart after the first
+    interaction and 7e-6 apart on the corner-clipping steps after the last.  Both GPU schedules
+    show the same numbers, so the absolute term is 1e-10 of the peak here (measured 1.9e-11)."""
+    base = make_benchmark_problem(40, density="powerlaw")
+    rng = np.random.default_rng(3)
+    w = [np.linspace(-1, 1, 41) * PC, np.linspace(-1, 1, 37) * PC, np.linspace(-1, 1, 21) * PC]
+    dust, dens = [], []
+    for d in range(nd):
+        du = load_test_dust()
+        du.chi = du.chi * (0.5 + d)
+        du.albedo = np.clip(du.albedo * (0.6 + 0.2 * d), 0.0, 1.0)
+        dust.append(du)
+        rho = (0.3 + rng.random((20, 36, 40))) * 1.2 / PC / nd
+        if d == 1:
+            rho[rng.random(rho.shape) < 0.33] = 0.0
+        dens.append(rho)
+    prob = Problem(walls=w, density=np.array(dens), dust=dust, sources=base.sources, config=base.config)
+    run_both(prob, 120000, atol_rel=1e-10, tile_slots=65536, tile_pools=2, tile_drain=2000, **TILED)
+    run_both(prob, 120000, atol_rel=1e-10, lucy_mode=0)
 
 
 def test_tiled_ragged_grid_and_interaction_limits():
