@@ -54,7 +54,7 @@ class Config(C.Structure):
         ("kill_on_absorb", C.c_int32), ("kill_on_scatter", C.c_int32),
         ("sample_sources_evenly", C.c_int32), ("enforce_energy_range", C.c_int32),
         ("forced_first_interaction", C.c_int32), ("forced_first_interaction_algorithm", C.c_int32),
-        ("specific_energy_type", C.c_int32), ("reserved0", C.c_int32),
+        ("specific_energy_type", C.c_int32), ("raytracing", C.c_int32),
         ("baes16_xi", C.c_double), ("propagation_check_frequency", C.c_double),
     ]
 
@@ -175,6 +175,7 @@ class MarshalledProblem:
         if c.specific_energy_type not in ("initial", "additional"):
             raise ValueError("specific_energy_type should be 'additional' or 'initial'")
         d.config.specific_energy_type = 1 if c.specific_energy_type == "additional" else 0
+        d.config.raytracing = int(bool(c.raytracing))
         d.config.baes16_xi = float(c.baes16_xi)
         d.config.propagation_check_frequency = float(c.propagation_check_frequency)
 

@@ -152,6 +152,8 @@ class RunConfig:
     n_initial_iter: int = 5
     n_initial_photons: int = 0
     n_last_photons: int = 0
+    n_ray_photons_sources: int = 0     # raytracing iteration (src/main/setup_rt.f90:169-245)
+    n_ray_photons_dust: int = 0
     check_convergence: bool = False
     convergence_absolute: float = 0.0
     convergence_relative: float = 0.0

@@ -83,6 +83,9 @@ def read_rtin(path):
         cfg.monochromatic = _b(a["monochromatic"])
         cfg.raytracing = _b(a["raytracing"])
         cfg.n_last_photons = int(a["n_last_photons"]) if "n_last_photons" in a else 0
+        if cfg.raytracing:
+            cfg.n_ray_photons_sources = int(a["n_ray_photons_sources"]) if "n_ray_photons_sources" in a else 0
+            cfg.n_ray_photons_dust = int(a["n_ray_photons_dust"]) if "n_ray_photons_dust" in a else 0
         if cfg.n_initial_iter > 0:
             cfg.check_convergence = _b(a["check_convergence"])
             if cfg.check_convergence:

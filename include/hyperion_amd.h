@@ -112,7 +112,9 @@ typedef struct hyp_config {
     int32_t forced_first_interaction;
     int32_t forced_first_interaction_algorithm; /* 1 wr99, 2 baes16 */
     int32_t specific_energy_type;               /* 0 initial, 1 additional */
-    int32_t reserved0;
+    int32_t raytracing;                         /* root attr `raytracing`: the final iteration peels only scattered packets
+                                                   (do_final(..., peeloff_scattering_only), src/main/main.f90:274) and the
+                                                   image groups cache their binned spectra for hyp_raytracing_* */
     double  baes16_xi;
     double  propagation_check_frequency;
 } hyp_config;

@@ -174,6 +174,39 @@ static double integral_linlog(const double *x, const double *y, int n)
     return s;
 }
 
+/* integral_loglog(x, y[, xmin, xmax]) (fortranlib; the reference's own equivalent is
+ * hyperion/util/integrate.py integrate_loglog_subset): piecewise power laws between the
+ * tabulated points, end points interpolated in log-log, limits clipped to the table. */
+static double interp_seg_loglog(double x1, double x2, double y1, double y2, double x)
+{
+    if (y1 > 0.0 && y2 > 0.0) return y1 * pow(x / x1, log10(y2 / y1) / log10(x2 / x1));
+    return y1 + (x - x1) / (x2 - x1) * (y2 - y1);
+}
+
+static double integral_loglog_range(const double *x, const double *y, int n, double xmin, double xmax)
+{
+    if (xmin < x[0]) xmin = x[0];
+    if (xmax > x[n - 1]) xmax = x[n - 1];
+    if (!(xmax > xmin)) return 0.0;
+    double s = 0.0;
+    for (int i = 0; i < n - 1; i++) {
+        double a = x[i], b = x[i + 1];
+        if (b <= xmin || a >= xmax) continue;
+        double xa = a < xmin ? xmin : a, xb = b > xmax ? xmax : b;
+        double ya = xa == a ? y[i] : interp_seg_loglog(a, b, y[i], y[i + 1], xa);
+        double yb = xb == b ? y[i + 1] : interp_seg_loglog(a, b, y[i], y[i + 1], xb);
+        s += seg_loglog(xa, xb, ya, yb);
+    }
+    return s;
+}
+
+static double integral_loglog_all(const double *x, const double *y, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i < n - 1; i++) s += seg_loglog(x[i], x[i + 1], y[i], y[i + 1]);
+    return s;
+}
+
 /* ------------------------------------------------------------------ */
 /* fortranlib type_pdf restated                                        */
 /* ------------------------------------------------------------------ */
@@ -348,6 +381,11 @@ typedef struct {
     double log10_nu_min, log10_nu_max, log10_ap_min, log10_ap_max;
     double *sed, *sed2, *img, *img2;
     size_t sed_size, img_size;
+    /* raytracing caches (images_peeled.f90:57-82): spectra binned on the image's frequency grid */
+    double *src_spec;       /* [n_sources][n_nu]  get_source_spectrum */
+    double *dust_log10_em;  /* [n_dust][n_jnu][n_nu]  log10 of get_j_nu_binned */
+    double *dust_chi;       /* [n_dust][n_nu]  get_chi_nu_binned */
+    int nj_stride;
 } peeled_t;
 
 enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3, GRID_AMR = 4 };
@@ -385,6 +423,7 @@ struct orc_state {
     double *w[3], *ew[3];
     int n[3];
     double *volume;
+    size_t n_masked; uint32_t *mask_map;   /* valid cells (geo%mask_map of every geometry) */
     orc_config cfg;
     double check_p, check_log1mp;
     int n_dust, n_sources, n_peeled;
@@ -612,6 +651,7 @@ static double spacing(double x)
 }
 
 static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in);
+static void raytracing_caches(const orc_state *st);
 static void peeled_free(peeled_t *p);
 
 /* ---- voronoi: grid_geometry_voronoi.f90 -------------------------------- */
@@ -1046,6 +1086,16 @@ int orc_create(const orc_problem *pr, orc_state **out)
         for (int d = 0; d < st->n_dust; d++)
             for (size_t ic = 0; ic < st->n_cells; ic++)
                 if (!(st->volume[ic] > 0.0)) st->density[(size_t)d * st->n_cells + ic] = 0.0;
+    /* geo%mask / geo%mask_map: cartesian_3d.f90:101, octree.f90:214-225, amr.f90:489-505, voronoi.f90:161-173 */
+    st->mask_map = malloc(sizeof(uint32_t) * (st->n_cells ? st->n_cells : 1));
+    st->n_masked = 0;
+    for (size_t ic = 0; ic < st->n_cells; ic++) {
+        int valid = 1;
+        if (st->grid_type == GRID_OCT) valid = !st->orefined[ic];
+        else if (st->grid_type == GRID_AMR) valid = !amr_covered(st, ic);
+        else if (st->grid_type == GRID_VOR) valid = st->volume[ic] > 0.0;
+        if (valid) st->mask_map[st->n_masked++] = (uint32_t)ic;
+    }
     st->specific_energy = malloc(sizeof(double) * (ntot ? ntot : 1));
     st->specific_energy_sum = calloc(ntot ? ntot : 1, sizeof(double));
     st->jnu_var_id = calloc(ntot ? ntot : 1, sizeof(int32_t));
@@ -1074,6 +1124,7 @@ int orc_create(const orc_problem *pr, orc_state **out)
     st->peeled = calloc(st->n_peeled ? st->n_peeled : 1, sizeof(peeled_t));
     for (int g = 0; g < st->n_peeled; g++)
         if (peeled_setup(st, &st->peeled[g], &pr->peeled[g])) { orc_destroy(st); return 1; }
+    if (st->cfg.raytracing) raytracing_caches(st);
     *out = st;
     return 0;
 }
@@ -1087,7 +1138,7 @@ void orc_destroy(orc_state *st)
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
     free(st->vsite); free(st->vidx); free(st->vneigh); free(st->vseed);
     if (st->amr) { for (int g = 0; g < st->n_amr_grids; g++) { free(st->amr[g].go); for (int a = 0; a < 3; a++) free(st->amr[g].w[a]); } free(st->amr); }
-    free(st->amr_cell_grid);
+    free(st->amr_cell_grid); free(st->mask_map);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
@@ -1118,6 +1169,7 @@ typedef struct {
     int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id, face_id;
     angle_t a_prev; double s_prev[4], v_prev[3];
     angle_t source_a;   /* inward normal at the emission point of an external source */
+    int emiss_type, emiss_var_id; double emiss_var_frac;   /* raytracing: 1/2 source spectrum, 3 dust emissivity */
 } photon_t;
 
 typedef struct {
@@ -1921,6 +1973,76 @@ int orc_lucy_iteration(orc_state *st, uint64_t n_packets, int iter, int n_thread
 /* ------------------------------------------------------------------ */
 
 #define C_CGS 29979245800.0
+#define STEF_BOLTZ 5.67051e-5
+
+
+/* Spectra on the frequency bins of an image group, cached for the raytracing iteration:
+ * get_source_spectrum / get_dust_emissivity / get_dust_extinction (images_peeled.f90:422-538) with
+ * get_spectrum_binned (source_type.f90:1118-1172), get_j_nu_binned and get_chi_nu_binned
+ * (dust_type_4elem.f90:722-750, 793-818). */
+static void raytracing_caches(const orc_state *st)
+{
+    if (st->n_peeled == 0) return;
+    int nj_max = 1;
+    for (int d = 0; d < st->n_dust; d++) if (st->dust[d].n_jnu > nj_max) nj_max = st->dust[d].n_jnu;
+    double **lo = malloc(sizeof(double *) * st->n_peeled), **hi = malloc(sizeof(double *) * st->n_peeled);
+    for (int ig = 0; ig < st->n_peeled; ig++) {
+        peeled_t *p = &st->peeled[ig];
+        const int nn = p->d.n_nu;
+        lo[ig] = malloc(sizeof(double) * nn); hi[ig] = malloc(sizeof(double) * nn);
+        for (int i = 0; i < nn; i++) {
+            lo[ig][i] = pow(10.0, p->log10_nu_min + (p->log10_nu_max - p->log10_nu_min) * (double)i / (double)nn);
+            hi[ig][i] = pow(10.0, p->log10_nu_min + (p->log10_nu_max - p->log10_nu_min) * (double)(i + 1) / (double)nn);
+        }
+        p->src_spec = calloc((size_t)(st->n_sources ? st->n_sources : 1) * nn, sizeof(double));
+        p->dust_log10_em = calloc((size_t)(st->n_dust ? st->n_dust : 1) * nj_max * nn, sizeof(double));
+        p->dust_chi = calloc((size_t)(st->n_dust ? st->n_dust : 1) * nn, sizeof(double));
+        p->nj_stride = nj_max;
+    }
+    /* blackbody tabulated on 100000 points per decade between 3e9 and 3e16 Hz (:1142-1154), once per source */
+    const double l0 = log10(3.e9), l1 = log10(3.e16);
+    const int nb = (int)ceil((l1 - l0) * 100000);
+    double *bnu = NULL, *bfnu = NULL;
+    for (int is = 0; is < st->n_sources; is++) {
+        const source_t *src = &st->src[is];
+        const double *x, *y; int n;
+        if (src->spectrum_type == 1) { x = src->spectrum.x; y = src->spectrum.pdf; n = src->spectrum.n; }
+        else {
+            if (!bnu) {
+                bnu = malloc(sizeof(double) * nb); bfnu = malloc(sizeof(double) * nb);
+                for (int k = 0; k < nb; k++) bnu[k] = pow(10.0, (double)k / (double)(nb - 1) * (l1 - l0) + l0);
+            }
+            const double a = 2.0 * H_CGS / C_CGS / C_CGS / STEF_BOLTZ * PI, b = H_CGS / K_CGS;
+            const double T = src->temperature, T4 = T * T * T * T;
+            for (int k = 0; k < nb; k++) bfnu[k] = a * bnu[k] * bnu[k] * bnu[k] / (exp(b * bnu[k] / T) - 1.0) / T4;   /* normalized_B_nu :1088-1096 */
+            x = bnu; y = bfnu; n = nb;
+        }
+        const double tot = integral_loglog_all(x, y, n);
+        for (int ig = 0; ig < st->n_peeled; ig++) {
+            peeled_t *p = &st->peeled[ig];
+            const int nn = p->d.n_nu;
+            for (int i = 0; i < nn; i++) p->src_spec[(size_t)is * nn + i] = integral_loglog_range(x, y, n, lo[ig][i], hi[ig][i]) / tot;
+        }
+    }
+    free(bnu); free(bfnu);
+    for (int ig = 0; ig < st->n_peeled; ig++) {
+        peeled_t *p = &st->peeled[ig];
+        const int nn = p->d.n_nu;
+        for (int d = 0; d < st->n_dust; d++) {
+            const dust_t *du = &st->dust[d];
+            for (int j = 0; j < du->n_jnu; j++) {
+                const pdf_t *q = &du->j_nu[j];
+                double tot = integral_loglog_all(q->x, q->pdf, q->n);
+                for (int i = 0; i < nn; i++)
+                    p->dust_log10_em[((size_t)d * nj_max + j) * nn + i] = log10(integral_loglog_range(q->x, q->pdf, q->n, lo[ig][i], hi[ig][i]) / tot);
+            }
+            for (int i = 0; i < nn; i++)
+                p->dust_chi[(size_t)d * nn + i] = integral_loglog_range(du->nu, du->chi, du->n_nu, lo[ig][i], hi[ig][i]) / (hi[ig][i] - lo[ig][i]);
+        }
+        free(lo[ig]); free(hi[ig]);
+    }
+    free(lo); free(hi);
+}
 
 static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
 {
@@ -1960,6 +2082,7 @@ static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
 static void peeled_free(peeled_t *p)
 {
     free(p->theta); free(p->phi); free(p->view); free(p->sed); free(p->sed2); free(p->img); free(p->img2);
+    free(p->src_spec); free(p->dust_log10_em); free(p->dust_chi);
 }
 
 int orc_peeled_n_orig(const orc_state *st, int g) { return st->peeled[g].n_orig; }
@@ -2056,7 +2179,71 @@ static int in_image(const peeled_t *pg, double x, double y)
 }
 
 /* peeloff_photon :95-270 (external observers) */
-static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g, acc_t *acc)
+/* image_bin_raytraced: image_type.f90:527-606 -- the whole spectrum goes into Stokes I of one pixel */
+static void image_bin_raytraced(const orc_state *st, int ig, const photon_t *p, double x_image, double y_image,
+                                int iv, const double *spectrum, acc_t *acc)
+{
+    const peeled_t *pg = &st->peeled[ig];
+    const orc_peeled_desc *d = &pg->d;
+    if (p->energy != p->energy || p->s[0] != p->s[0]) return;
+    int io = origin_slot(st, pg, p);
+    if (d->compute_image) {
+        int ix = ipos0(d->x_min, d->x_max, x_image, d->n_x);
+        int iy = ipos0(d->y_min, d->y_max, y_image, d->n_y);
+        if (ix >= 0 && ix < d->n_x && iy >= 0 && iy < d->n_y)
+            for (int iw = 0; iw < d->n_nu; iw++) {
+                size_t k = ((((size_t)io * d->n_view + iv) * d->n_y + iy) * d->n_x + ix) * d->n_nu + iw;
+                acc->img[ig][k] += spectrum[iw];
+                if (d->uncertainties) acc->img2[ig][k] += spectrum[iw] * spectrum[iw];
+            }
+    }
+    if (d->compute_sed) {
+        double lr = log10(sqrt(x_image * x_image + y_image * y_image));
+        int ir;
+        if (lr < pg->log10_ap_min || d->n_ap == 1) ir = 0;
+        else ir = ipos0(pg->log10_ap_min, pg->log10_ap_max, lr, d->n_ap - 1) + 1;
+        if (ir >= 0 && ir < d->n_ap)
+            for (int iw = 0; iw < d->n_nu; iw++) {
+                size_t k = (((size_t)io * d->n_view + iv) * d->n_ap + ir) * d->n_nu + iw;
+                acc->sed[ig][k] += spectrum[iw];
+                if (d->uncertainties) acc->sed2[ig][k] += spectrum[iw] * spectrum[iw];
+            }
+    }
+}
+
+/* grid_escape_column_density: grid_propagate_3d.f90:482-582 */
+static void grid_escape_column_density(const orc_state *st, const photon_t *p_orig, double tmax, double *col,
+                                       rng_t *g, acc_t *acc, int *killed)
+{
+    photon_t p = *p_orig;
+    double t_current = 0.0;
+    *killed = 0;
+    for (int d = 0; d < st->n_dust; d++) col[d] = 0.0;
+    if (escaped(st, p.ic)) return;
+    for (;;) {
+        if (g->countdown == 0) {
+            g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
+            if (!in_correct_cell(st, &p)) { acc->killed_geo++; *killed = 1; return; }
+        } else g->countdown--;
+        double tmin; int id_min[3];
+        int fw = find_wall(st, &p, &tmin, id_min);
+        if (fw < 0) { amr_negative_t(acc); *killed = 1; return; }
+        if (!fw) { acc->killed_geo++; *killed = 1; return; }
+        size_t ic = cell_index(st, p.ic);
+        int finished = 0;
+        if (t_current + tmin > tmax) { tmin = tmax - t_current; finished = 1; }
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
+        t_current += tmin;
+        for (int d = 0; d < st->n_dust; d++) col[d] += st->density[(size_t)d * st->n_cells + ic] * tmin;
+        acc->crossings++;
+        if (finished) return;
+        advance_cell(st, &p, id_min);
+        if (st->grid_type == GRID_AMR && p.ic[0] < 0) { acc->killed_geo++; *killed = 1; return; }
+        if (escaped(st, p.ic)) return;
+    }
+}
+
+static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g, acc_t *acc, int polychromatic)
 {
     for (int ig = 0; ig < st->n_peeled; ig++) {
         const peeled_t *pg = &st->peeled[ig];
@@ -2097,6 +2284,32 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
             double x_image = dr[1] * p.a.cosp - dr[0] * p.a.sinp;
             double y_image = dr[2] * p.a.sint - dr[1] * p.a.cost * p.a.sinp - dr[0] * p.a.cost * p.a.cosp;
             if (!in_image(pg, x_image, y_image)) continue;
+            if (polychromatic) {
+                /* images_peeled.f90:218-254: the packet carries the whole spectrum of its emitter */
+                double col[ORC_MAX_DUST]; int killed_c = 0;
+                for (int d = 0; d < st->n_dust; d++) col[d] = 0.0;
+                if (!pg->d.ignore_optical_depth) grid_escape_column_density(st, &p, DBL_MAX, col, g, acc, &killed_c);
+                if (killed_c) continue;
+                const int nn = pg->d.n_nu;
+                double spec[nn];
+                if (p.emiss_type == 3) {      /* get_dust_emissivity :451-505 */
+                    const double *le = pg->dust_log10_em + ((size_t)p.dust_id * pg->nj_stride + p.emiss_var_id) * nn;
+                    for (int i = 0; i < nn; i++) {
+                        double v = pow(10.0, (le[nn + i] - le[i]) * p.emiss_var_frac + le[i]);
+                        spec[i] = (v != v) ? 0.0 : v;
+                    }
+                } else {
+                    const double *ss = pg->src_spec + (size_t)p.source_id * nn;
+                    for (int i = 0; i < nn; i++) spec[i] = ss[i];
+                }
+                for (int i = 0; i < nn; i++) spec[i] = spec[i] * p.s[0] * p.energy;
+                for (int d = 0; d < st->n_dust; d++) {
+                    const double *chi = pg->dust_chi + (size_t)d * nn;
+                    for (int i = 0; i < nn; i++) spec[i] = spec[i] * exp(-col[d] * chi[i]);
+                }
+                image_bin_raytraced(st, ig, &p, x_image, y_image, iv, spec, acc);
+                continue;
+            }
             double tau = 0.0; int killed = 0;
             if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, DBL_MAX, g, acc, &killed);
             if (killed) continue;
@@ -2137,7 +2350,8 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
     rng_t g; photon_t p;
     rng_init(&g, st->cfg.seed, 0x10000u, id);
     if (emit(st, &p, &g, acc)) return;
-    if (st->n_peeled) peeloff_photon(st, &p, &g, acc);
+    const int scattering_only = st->cfg.raytracing;      /* do_final(..., peeloff_scattering_only=use_raytracing) */
+    if (st->n_peeled && !scattering_only) peeloff_photon(st, &p, &g, acc, 0);
     for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
         double tau;
         if (inter == 1 && st->cfg.forced_first_interaction) {
@@ -2159,19 +2373,23 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
         if (p.killed) break;
         p.killed = (st->cfg.kill_on_scatter && p.scattered) || (st->cfg.kill_on_absorb && !p.scattered);
         if (p.killed) break;
-        if (st->n_peeled) peeloff_photon(st, &p, &g, acc);
+        if (st->n_peeled && (p.scattered || !scattering_only)) peeloff_photon(st, &p, &g, acc, 0);
     }
 }
 
 static uint64_t g_final_first_id = 0;   /* debugging aid: id offset of the next final iteration */
 void orc_set_final_first_id(uint64_t first) { g_final_first_id = first; }
 
-int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
+/* Runs `fn` for n_packets packet ids on n_threads threads with thread-local image cubes and
+ * merges them into the state's cubes (zeroed first if `zero`). */
+typedef void (*image_packet_fn)(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx);
+
+static int image_run(orc_state *st, uint64_t n_packets, int n_threads, uint64_t first_id, image_packet_fn fn,
+                     const void *ctx, int zero, orc_iter_stats *tot_out)
 {
     int nt = resolve_threads(n_threads);
     if ((uint64_t)nt > n_packets && n_packets > 0) nt = (int)n_packets;
     if (nt < 1) nt = 1;
-    precompute_jnu_var(st); /* iter_final.f90:99 */
     acc_t *accs = calloc(nt, sizeof(acc_t));
     int ng = st->n_peeled;
     for (int t = 0; t < nt; t++) {
@@ -2180,8 +2398,10 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
         for (int g = 0; g < ng; g++) {
             peeled_t *pg = &st->peeled[g];
             if (t == 0) {
-                if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
-                if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
+                if (zero) {
+                    if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
+                    if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
+                }
                 accs[t].sed[g] = pg->sed; accs[t].sed2[g] = pg->sed2; accs[t].img[g] = pg->img; accs[t].img2[g] = pg->img2;
             } else {
                 if (pg->sed) { accs[t].sed[g] = calloc(pg->sed_size, sizeof(double)); accs[t].sed2[g] = calloc(pg->sed_size, sizeof(double)); }
@@ -2204,7 +2424,7 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
 #endif
         for (int64_t i = 0; i < (int64_t)n_packets; i++) {
             if (acc->fatal) continue;
-            final_packet(st, g_final_first_id + (uint64_t)i, acc);
+            fn(st, first_id + (uint64_t)i, acc, ctx);
         }
     }
     orc_iter_stats tot; memset(&tot, 0, sizeof tot);
@@ -2226,17 +2446,124 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
     }
     tot.n_packets = n_packets;
     free(accs);
-    if (fatal) return 1;
+    *tot_out = tot;
+    return fatal;
+}
+
+static void final_packet_fn(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx) { (void)ctx; final_packet(st, id, acc); }
+
+int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
+{
+    precompute_jnu_var(st); /* iter_final.f90:99 */
+    orc_iter_stats tot;
+    if (image_run(st, n_packets, n_threads, g_final_first_id, final_packet_fn, NULL, 1, &tot)) return 1;
     /* peeled_images_adjust_scale(energy_total/energy_current): image_type.f90:136-151 */
     if (tot.energy_current > 0.0) {
         double scale = st->energy_total / tot.energy_current;
-        for (int g = 0; g < ng; g++) {
+        for (int g = 0; g < st->n_peeled; g++) {
             peeled_t *pg = &st->peeled[g];
             if (pg->sed) for (size_t k = 0; k < pg->sed_size; k++) { pg->sed[k] *= scale; pg->sed2[k] *= scale * scale; }
             if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] *= scale; pg->img2[k] *= scale * scale; }
         }
     }
     if (stats) *stats = tot;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* do_raytracing: iter_raytracing.f90:30-143                            */
+/* ------------------------------------------------------------------ */
+
+typedef struct { uint64_t n_total; } ray_ctx;
+
+/* source part :56-76: emit, weight energy_total / n_photons_sources, polychromatic peel-off */
+static void ray_source_packet(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx)
+{
+    const ray_ctx *c = ctx;
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, 0x20000u, id);
+    if (emit(st, &p, &g, acc)) return;
+    p.energy = p.energy * st->energy_total / (double)c->n_total;
+    peeloff_photon(st, &p, &g, acc, 1);
+}
+
+/* random_position_cell of each geometry (cartesian_3d.f90:383-394, octree.f90:397-408, amr.f90:728-741) */
+static int random_position_cell(const orc_state *st, size_t ic, photon_t *p, rng_t *g)
+{
+    double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
+    if (st->grid_type == GRID_CAR) {
+        int i1 = (int)(ic % st->n1), i2 = (int)((ic / st->n1) % st->n2), i3 = (int)(ic / ((size_t)st->n1 * st->n2));
+        p->ic[0] = i1; p->ic[1] = i2; p->ic[2] = i3;
+        p->r[0] = x * (st->w[0][i1 + 1] - st->w[0][i1]) + st->w[0][i1];
+        p->r[1] = y * (st->w[1][i2 + 1] - st->w[1][i2]) + st->w[1][i2];
+        p->r[2] = z * (st->w[2][i3 + 1] - st->w[2][i3]) + st->w[2][i3];
+        return 0;
+    }
+    p->ic[0] = (int)ic; p->ic[1] = p->ic[2] = 0;
+    if (st->grid_type == GRID_OCT) {
+        p->r[0] = (2.0 * x - 1.0) * st->odx[ic] + st->ox[ic];
+        p->r[1] = (2.0 * y - 1.0) * st->ody[ic] + st->oy[ic];
+        p->r[2] = (2.0 * z - 1.0) * st->odz[ic] + st->oz[ic];
+        return 0;
+    }
+    if (st->grid_type == GRID_AMR) {
+        const amr_grid *gr; int ci[3];
+        amr_cell_coords(st, ic, &gr, ci);
+        const double u[3] = {x, y, z};
+        for (int a = 0; a < 3; a++) p->r[a] = u[a] * (gr->w[a][ci[a] + 1] - gr->w[a][ci[a]]) + gr->w[a][ci[a]];
+        return 0;
+    }
+    return -1;   /* voronoi: rejection sampling in the reference, not restated */
+}
+
+/* thermal part :96-126 with emit_from_grid (grid_physics_3d.f90:691-753) */
+static void ray_dust_packet(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx)
+{
+    const ray_ctx *c = ctx;
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, 0x30000u, id);
+    memset(&p, 0, sizeof p);
+    double xi = rng_uniform(&g);
+    int d = (int)ceil(xi * (double)st->n_dust); if (d < 1) d = 1;
+    p.dust_id = d - 1;
+    xi = rng_uniform(&g);       /* random_masked_cell: grid_geometry_common_3d.f90:104-115 */
+    long long im = (long long)ceil(xi * (double)st->n_masked); if (im < 1) im = 1;
+    size_t ic = st->mask_map[im - 1];
+    if (random_position_cell(st, ic, &p, &g)) {
+        if (!acc->fatal) { acc->fatal = 1; snprintf(acc->err, sizeof acc->err, "raytracing of dust emission is not available for this grid type"); }
+        return;
+    }
+    p.in_cell = 1;
+    random_sphere_angle(&g, &p.a);
+    angle_to_vector(&p.a, p.v);
+    p.s[0] = 1.0;
+    size_t k = (size_t)p.dust_id * st->n_cells + ic;
+    if (st->energy_abs_tot[p.dust_id] > 0.0) {
+        double mass = st->density[k] * st->volume[ic];
+        p.energy = st->specific_energy[k] * mass * (double)st->n_masked / st->energy_abs_tot[p.dust_id];
+    } else p.energy = 0.0;
+    p.emiss_type = 3; p.emiss_var_id = st->jnu_var_id[k]; p.emiss_var_frac = st->jnu_var_frac[k];
+    p.scattered = 0; p.reprocessed = 1; p.last_isotropic = 1; p.last = LAST_DE;
+    g.countdown = rng_check_gap(&g, st->check_p, st->check_log1mp);
+    if (p.energy > 0.0) {
+        p.energy = p.energy * st->energy_abs_tot[p.dust_id] / (double)c->n_total * (double)st->n_dust;
+        peeloff_photon(st, &p, &g, acc, 1);
+    }
+}
+
+int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats)
+{
+    if (!st->cfg.raytracing) { snprintf(st->err, sizeof st->err, "raytracing was not requested in the configuration"); return 1; }
+    precompute_jnu_var(st);   /* iter_raytracing.f90:49 */
+    orc_iter_stats a, b; memset(&a, 0, sizeof a); memset(&b, 0, sizeof b);
+    ray_ctx c;
+    if (n_sources > 0) { c.n_total = n_sources; if (image_run(st, n_sources, n_threads, 0, ray_source_packet, &c, 0, &a)) return 1; }
+    if (n_dust > 0 && st->n_dust > 0) { c.n_total = n_dust; if (image_run(st, n_dust, n_threads, 0, ray_dust_packet, &c, 0, &b)) return 1; }
+    if (stats) {
+        *stats = a;
+        stats->killed_geo += b.killed_geo; stats->killed_int += b.killed_int; stats->crossings += b.crossings;
+        stats->n_packets += b.n_packets;
+    }
     return 0;
 }
 

@@ -114,7 +114,7 @@ typedef struct orc_config {
     int32_t forced_first_interaction;
     int32_t forced_first_interaction_algorithm; /* 1 wr99, 2 baes16 */
     int32_t specific_energy_type;    /* 0 initial, 1 additional */
-    int32_t reserved0;
+    int32_t raytracing;              /* root attribute `raytracing`: peel only scattered packets in the final iteration */
     double  baes16_xi;
     double  propagation_check_frequency;
 } orc_config;
@@ -197,6 +197,9 @@ const double *orc_density(const orc_state *st);
  * Image/SED cubes are returned scaled (image_scale) but not dnu-normalised;
  * layout per group: sed[n_stokes][n_orig][n_view][n_ap][n_nu],
  * img[n_stokes][n_orig][n_view][n_y][n_x][n_nu] (the .rtout layout). */
+/* do_raytracing (src/main/iter_raytracing.f90:30-143): adds the direct source and the thermal dust
+ * emission to the (already scaled) cubes of the last orc_final_iteration. */
+int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats);
 int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads,
                         orc_iter_stats *stats);
 int orc_peeled_n_orig(const orc_state *st, int group);

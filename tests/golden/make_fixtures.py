@@ -22,6 +22,7 @@ What it writes (inputs + expected outputs only); {grid} = car, oct, amr:
       golden : iteration_0000{1..5}/specific_energy of the reference's own
                committed regression output
                hyperion/model/tests/data/test_specific_energy.grid_type=car.*.rtout
+  {grid}_peeloff_ray.{evenly}.npz   the same model with raytracing=True (2000 source + 3000 dust rays)
   {grid}_peeloff.{evenly}.npz
       inputs : test_bit_level.py:175-236 (TestBasic.test_peeloff, 'car',
                raytracing=False); golden: Peeled/group_0000{1,2,3}/{seds,images}
@@ -215,11 +216,14 @@ def specific_energy_fixture(gt, grid, dens, evenly, multi, tmp):
          {"specific_energy": se, "killed": killed})
 
 
-def peeloff_fixture(gt, grid, dens, evenly, tmp):
-    """test_bit_level.py:175-236, raytracing=False"""
+def peeloff_fixture(gt, grid, dens, evenly, tmp, raytracing=False):
+    """test_bit_level.py:175-236, raytracing=False / True"""
     m = build_model(grid, dens, evenly)
-    m.set_raytracing(False)
-    m.set_n_photons(initial=1000, imaging=5000)
+    m.set_raytracing(raytracing)
+    if raytracing:
+        m.set_n_photons(initial=1000, imaging=5000, raytracing_sources=2000, raytracing_dust=3000)
+    else:
+        m.set_n_photons(initial=1000, imaging=5000)
     i_p = m.add_peeled_images()
     i_p.set_wavelength_range(5, 0.05, 200.)
     i_p.set_viewing_angles([33.4, 110.], [65.4, 103.2])
@@ -236,9 +240,9 @@ def peeloff_fixture(gt, grid, dens, evenly, tmp):
         i_p.set_aperture_radii(2, 0.5 * pc, pc)
         i_p.set_track_origin(track)
         i_p.set_stokes(True)
-    keep = os.path.join(HERE, "car_peeloff.False.rtin") if (gt == "car" and not evenly) else None
+    keep = os.path.join(HERE, "car_peeloff.False.rtin") if (gt == "car" and not evenly and not raytracing) else None
     prob = write_and_read(m, tmp, keep_as=keep)
-    ref = os.path.join(DATA, "test_peeloff.grid_type=%s.raytracing=False.sample_sources_evenly=%s.rtout" % (gt, evenly))
+    ref = os.path.join(DATA, "test_peeloff.grid_type=%s.raytracing=%s.sample_sources_evenly=%s.rtout" % (gt, raytracing, evenly))
     golden = {}
     with h5py.File(ref, "r") as f:
         for g in range(1, 4):
@@ -252,10 +256,11 @@ def peeloff_fixture(gt, grid, dens, evenly, tmp):
                 golden["group%d/images_%s" % (g, k)] = np.float64(grp["images"].attrs[k])
         n_it = int(f.attrs["iterations"])
         golden["specific_energy_last"] = read_specific_energy(f["iteration_%05d" % n_it])
-    save(os.path.join(HERE, "%s_peeloff.%s.npz" % (gt, evenly)), prob, golden)
+    save(os.path.join(HERE, "%s_peeloff%s.%s.npz" % (gt, "_ray" if raytracing else "", evenly)), prob, golden)
 
 
 ONLY = [a for a in sys.argv[1:] if a in ("car", "oct", "amr")]      # restrict the grid types to regenerate
+RAY_ONLY = "ray" in sys.argv[1:]                                      # only the raytracing=True peel-off fixtures
 
 
 def main():
@@ -264,10 +269,13 @@ def main():
         for gt in [g for g in ("car", "oct", "amr") if not ONLY or g in ONLY]:
             for evenly in (False, True):
                 for multi in (False, True):
-                    specific_energy_fixture(gt, grids[gt], denss[gt], evenly, multi, tmp)
+                    if not RAY_ONLY:
+                        specific_energy_fixture(gt, grids[gt], denss[gt], evenly, multi, tmp)
             for evenly in (False, True):
-                peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp)
-        if ONLY:
+                if not RAY_ONLY:
+                    peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp)
+                peeloff_fixture(gt, grids[gt], denss[gt], evenly, tmp, raytracing=True)
+        if ONLY or RAY_ONLY:
             return
 
         # --- Voronoi inputs (BASELINE config 5, small) ----------------------------------

@@ -47,6 +47,7 @@ def lib():
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = _dp
         L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_raytracing_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_peeled_n_orig.argtypes = [C.c_void_p, C.c_int]
         for f in ("orc_peeled_sed", "orc_peeled_img", "orc_peeled_sed2", "orc_peeled_img2"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
@@ -134,11 +135,22 @@ class Oracle:
         n = int(np.prod(self.shape))
         return np.ctypeslib.as_array(lib().orc_specific_energy(self.h), shape=(n,)).reshape(self.shape).copy()
 
+    def raytracing_iteration(self, n_sources, n_dust, n_threads=0):
+        """do_raytracing: adds to the cubes of the last final_iteration; returns them."""
+        st = IterStats()
+        rc = lib().orc_raytracing_iteration(self.h, int(n_sources), int(n_dust), n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return self._peeled(), st.as_dict()
+
     def final_iteration(self, n_packets, n_threads=0):
         st = IterStats()
         rc = lib().orc_final_iteration(self.h, n_packets, n_threads, C.byref(st))
         if rc != 0:
             raise OracleError(self._err())
+        return self._peeled(), st.as_dict()
+
+    def _peeled(self):
         out = []
         for g in range(len(self.problem.peeled)):
             n_orig = lib().orc_peeled_n_orig(self.h, g)
@@ -152,7 +164,7 @@ class Oracle:
                 grp[name] = np.ctypeslib.as_array(fn(self.h, g), shape=(n,)).reshape(shape).copy()
                 grp[name + "2"] = np.ctypeslib.as_array(fn2(self.h, g), shape=(n,)).reshape(shape).copy()
             out.append(grp)
-        return out, st.as_dict()
+        return out
 
     def walk_ray(self, r0, v):
         r0 = np.ascontiguousarray(r0, dtype=np.float64)

@@ -107,6 +107,11 @@ def _peeloff_run(prob, seed, n_lucy, n_img):
     for it in range(1, prob.config.n_initial_iter + 1):
         o.lucy_iteration(n_lucy, it)
     res, st = o.final_iteration(n_img)
+    if prob.config.raytracing:
+        # main.f90:296-303: the raytracing iteration adds direct and thermal emission to the cubes
+        scale = n_img / 5000.0
+        res, st2 = o.raytracing_iteration(int(prob.config.n_ray_photons_sources * scale), int(prob.config.n_ray_photons_dust * scale))
+        st["killed_geo"] += st2["killed_geo"]
     o.close()
     return [finalize_peeled(p, r) for p, r in zip(prob.peeled, res)], st
 
@@ -154,3 +159,39 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
         assert chi_plus[ist] < chi_minus[ist] - 10.0, (ist, chi_plus, chi_minus)
     # golden uncertainty cubes exist only if requested
     assert "golden/group1/seds_unc" not in z.files
+
+
+@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
+@pytest.mark.parametrize("evenly", [False, True])
+def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
+    """test_peeloff.grid_type=*.raytracing=True.*.rtout (test_bit_level.py:175-236 with
+    set_raytracing(True), 2000 source + 3000 dust rays): the final iteration peels only scattered
+    packets and do_raytracing (iter_raytracing.f90) adds the direct and the thermal emission with
+    the emitters' whole binned spectra.  Stokes I per (view, wavelength) bin of the largest
+    aperture within the Monte Carlo noise of the golden's photon numbers; totals within 5 %."""
+    prob, z = golden_problem("%s_peeloff_ray.%s.npz" % (grid, evenly))
+    assert prob.config.raytracing and prob.config.n_ray_photons_sources == 2000 and prob.config.n_ray_photons_dust == 3000
+    K = 30
+    runs = [_peeloff_run(prob, -(100 + k), 1000, 5000) for k in range(K)]
+    samples = [r[0] for r in runs]
+    assert all(r[1]["killed_geo"] == 0 and r[1]["killed_int"] == 0 for r in runs)
+    # The thermal emission depends non-linearly on temperatures that come from 5 x 1000 Lucy
+    # packets, so the expectation is taken over realisations with the golden's own photon
+    # numbers (not from one large run): z = (golden - ensemble mean) / (sigma sqrt(1 + 1/K)).
+    for g in range(3):
+        gold = z["golden/group%d/seds" % (g + 1)]
+        cube = np.array([s[g]["seds"] for s in samples])
+        assert gold.shape == cube.shape[1:]
+        mean, sig = cube.mean(axis=0), cube.std(axis=0, ddof=1) * np.sqrt(1.0 + 1.0 / K)
+        I = mean[0][:, :, -1, :]
+        sel = (sig[0][:, :, -1, :] > 0) & (I > 0.02 * I.max())
+        zI = ((gold[0][:, :, -1, :] - I)[sel] / sig[0][:, :, -1, :][sel])
+        # (skewed far-IR thermal bins: same bound as the non-raytraced peel-off test above)
+        assert np.abs(zI).max() < 5.0 and (zI ** 2).mean() < 4.0, (g, zI)
+        tot = cube[:, 0][:, :, :, -1, :].sum(axis=(1, 2, 3))
+        assert abs(gold[0][:, :, -1, :].sum() - tot.mean()) < 4.0 * tot.std(ddof=1), (g, gold[0][:, :, -1, :].sum(), tot.mean(), tot.std())
+        gi = z["golden/group%d/images" % (g + 1)][0]
+        itot = np.array([s[g]["images"][0].sum() for s in samples])
+        assert abs(gi.sum() - itot.mean()) < 4.0 * itot.std(ddof=1)
+        # raytraced flux is unpolarised: Q, U, V of the golden come from the scattered packets only
+        assert np.all(gold[3] == 0)
