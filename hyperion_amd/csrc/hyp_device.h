@@ -10,6 +10,8 @@
 #define HYP_TWOPI 6.28318530717958647692
 #define HYP_H_CGS 6.6260755e-27
 #define HYP_K_CGS 1.380658e-16
+#define HYP_C_CGS 29979245800.0
+#define HYP_STEF_BOLTZ 5.67051e-5
 #define HYP_DBL_MAX 1.7976931348623157e308
 #define HYP_DBL_MIN 2.2250738585072014e-308
 
@@ -57,6 +59,11 @@ struct DPeeled {
     double d_min, d_max, origin[3];
     const double *view;     // [n_view][4] cost,sint,cosp,sinp
     double *sed, *sed2, *img, *img2;
+    // raytracing caches (images_peeled.f90:57-82): spectra binned on this group's frequency grid
+    const double *src_spec;       // [n_sources][n_nu]
+    const double *dust_log10_em;  // [n_dust][nj_stride][n_nu]
+    const double *dust_chi;       // [n_dust][n_nu]
+    int nj_stride, pad1;
 };
 
 // Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
@@ -74,7 +81,7 @@ struct OctCell {
 enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
        TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
 
-enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3 };
+enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3, ERR_RAY_GRID = 4 };
 
 // One grid of an AMR level (type_grid_amr.f90:12-21).  Walls are linspace(lo, hi, n+1) as the
 // reference builds them (grid_geometry_amr.f90:124-137), stored once per grid.
@@ -112,6 +119,13 @@ struct DProblem {
     const int *amr_cell_grid;             // [n_cells] grid of each unique cell id
     double amr_eps;                       // half the smallest cell width (grid_geometry_amr.f90:350)
     int n_amr_grids, n_amr_level1;        // level-1 grids come first
+    // raytracing (iter_raytracing.f90): valid cells, current specific energy, absorbed energy per species
+    const unsigned int *mask_map;         // [n_masked]
+    unsigned long long n_masked;
+    const double *specific_energy;        // [n_cells][n_dust]
+    const double *energy_abs_tot;         // [n_dust]
+    double energy_total;
+    int peel_scattered_only, pad5;        // final iteration peels only scattered packets (raytracing on)
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

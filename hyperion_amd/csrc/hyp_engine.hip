@@ -65,6 +65,39 @@ bool build_log_pdf(const double *x, const double *y, int n, size_t stride,
     return true;
 }
 
+// integral_loglog(x, y[, xmin, xmax]) of fortranlib (reference equivalent: hyperion/util/integrate.py
+// integrate_loglog_subset): piecewise power laws, end points interpolated in log-log, limits
+// clipped to the table.  `stride` lets y be a column of a row-major table.
+double interp_seg_loglog(double x1, double x2, double y1, double y2, double x)
+{
+    if (y1 > 0.0 && y2 > 0.0) return y1 * std::pow(x / x1, std::log10(y2 / y1) / std::log10(x2 / x1));
+    return y1 + (x - x1) / (x2 - x1) * (y2 - y1);
+}
+
+double integral_loglog_range(const double *x, const double *y, size_t stride, int n, double xmin, double xmax)
+{
+    if (xmin < x[0]) xmin = x[0];
+    if (xmax > x[n - 1]) xmax = x[n - 1];
+    if (!(xmax > xmin)) return 0.0;
+    double s = 0.0;
+    for (int i = 0; i + 1 < n; i++) {
+        const double a = x[i], b = x[i + 1], ya0 = y[(size_t)i * stride], yb0 = y[(size_t)(i + 1) * stride];
+        if (b <= xmin || a >= xmax) continue;
+        const double xa = a < xmin ? xmin : a, xb = b > xmax ? xmax : b;
+        const double ya = xa == a ? ya0 : interp_seg_loglog(a, b, ya0, yb0, xa);
+        const double yb = xb == b ? yb0 : interp_seg_loglog(a, b, ya0, yb0, xb);
+        s += seg_loglog(xa, xb, ya, yb);
+    }
+    return s;
+}
+
+double integral_loglog_all(const double *x, const double *y, size_t stride, int n)
+{
+    double s = 0.0;
+    for (int i = 0; i + 1 < n; i++) s += seg_loglog(x[i], x[i + 1], y[(size_t)i * stride], y[(size_t)(i + 1) * stride]);
+    return s;
+}
+
 double integral_linlog(const double *x, const double *y, int n)
 {
     double s = 0.0;
@@ -90,7 +123,7 @@ struct DustOffsets {
 };
 
 struct SourceOffsets { size_t x, cdf, bp1; bool have; };
-struct PeeledOffsets { size_t view; };
+struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi; };
 
 }  // namespace
 
@@ -107,6 +140,8 @@ struct hyp_engine {
     OctCell *d_oct_cells = nullptr;
     int *d_oct_children = nullptr;
     double *d_vor_sites = nullptr, *d_vor_volume = nullptr;
+    unsigned int *d_mask_map = nullptr;
+    bool ray_pending = false;
     AmrGrid *d_amr_grids = nullptr; int *d_amr_go = nullptr, *d_amr_cell_grid = nullptr; double *d_amr_walls = nullptr;
     int *d_vor_idx = nullptr, *d_vor_neigh = nullptr, *d_vor_seed = nullptr;
     DSource *d_sources = nullptr;
@@ -199,6 +234,32 @@ LucyKernel pick_final_kernel_g(int nd)
     default: return final_kernel<HYP_MAXD, GEOM>;
     }
 #endif
+}
+
+typedef void (*RayKernel)(const DProblem *, LaunchParams, int, double);
+
+template <int GEOM>
+RayKernel pick_ray_kernel_g(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return ray_kernel<1, GEOM>;
+#else
+    switch (nd) {
+    case 1: return ray_kernel<1, GEOM>;
+    case 2: return ray_kernel<2, GEOM>;
+    case 3: return ray_kernel<3, GEOM>;
+    case 4: return ray_kernel<4, GEOM>;
+    default: return ray_kernel<HYP_MAXD, GEOM>;
+    }
+#endif
+}
+
+RayKernel pick_ray_kernel(int nd, int grid_type)
+{
+    return grid_type == 4 ? pick_ray_kernel_g<GEOM_AMR>(nd)
+         : grid_type == 3 ? pick_ray_kernel_g<GEOM_VOR>(nd)
+         : grid_type == 2 ? pick_ray_kernel_g<GEOM_OCT>(nd) : pick_ray_kernel_g<GEOM_CAR>(nd);
 }
 
 LucyKernel pick_lucy_kernel(int nd, int grid_type)
@@ -410,6 +471,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
+    free_dev(h->d_mask_map);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
@@ -846,6 +908,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     // peeled image groups: images_peeled.f90:272-380, image_type.f90:153-335
     h->h_peeled.resize(pr->n_peeled);
     std::vector<PeeledOffsets> poff(pr->n_peeled);
+    std::vector<int> ray_groups;
     h->sed_off.assign(pr->n_peeled, 0); h->img_off.assign(pr->n_peeled, 0);
     h->sed_n.assign(pr->n_peeled, 0); h->img_n.assign(pr->n_peeled, 0);
     size_t img_total = 0;
@@ -880,6 +943,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             view[4 * v + 2] = std::cos(f); view[4 * v + 3] = std::sin(f);
         }
         poff[g].view = B.put(view);
+        if (pr->config.raytracing) ray_groups.push_back(g);
         if (in.compute_sed) {
             h->sed_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_ap * in.n_nu;
             h->sed_off[g] = img_total; img_total += 2 * h->sed_n[g];
@@ -888,6 +952,69 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             h->img_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_y * in.n_x * in.n_nu;
             h->img_off[g] = img_total; img_total += 2 * h->img_n[g];
         }
+    }
+
+    // Raytracing caches (images_peeled.f90:422-538): source spectra, dust emissivities and opacities
+    // binned on each group's frequency grid with get_spectrum_binned (source_type.f90:1118-1172),
+    // get_j_nu_binned and get_chi_nu_binned (dust_type_4elem.f90:722-750, 793-818).
+    int nj_stride = 1;
+    for (int d = 0; d < pr->n_dust; d++) nj_stride = std::max(nj_stride, pr->dust[d].n_jnu);
+    if (!ray_groups.empty()) {
+        const double l0 = std::log10(3.e9), l1 = std::log10(3.e16);
+        const int nb = (int)std::ceil((l1 - l0) * 100000);
+        std::vector<double> bnu, bfnu;
+        std::vector<std::vector<double>> lo(pr->n_peeled), hi(pr->n_peeled), spec(pr->n_peeled), em(pr->n_peeled), chi(pr->n_peeled);
+        for (int g : ray_groups) {
+            const DPeeled &G = h->h_peeled[g];
+            const int nn = G.n_nu;
+            lo[g].resize(nn); hi[g].resize(nn);
+            for (int i = 0; i < nn; i++) {
+                lo[g][i] = std::pow(10.0, G.log10_nu_min + (G.log10_nu_max - G.log10_nu_min) * (double)i / (double)nn);
+                hi[g][i] = std::pow(10.0, G.log10_nu_min + (G.log10_nu_max - G.log10_nu_min) * (double)(i + 1) / (double)nn);
+            }
+            spec[g].assign((size_t)pr->n_sources * nn, 0.0);
+            em[g].assign((size_t)pr->n_dust * nj_stride * nn, 0.0);
+            chi[g].assign((size_t)pr->n_dust * nn, 0.0);
+        }
+        for (int is = 0; is < pr->n_sources; is++) {
+            const hyp_source_desc &src = pr->sources[is];
+            const double *x, *y; int n;
+            if (src.spectrum_type == 1) { x = src.spec_nu; y = src.spec_fnu; n = src.n_spec; }
+            else {
+                // blackbody on 100000 points per decade between 3e9 and 3e16 Hz, normalized_B_nu :1088-1096
+                if (bnu.empty()) {
+                    bnu.resize(nb); bfnu.resize(nb);
+                    for (int k = 0; k < nb; k++) bnu[k] = std::pow(10.0, (double)k / (double)(nb - 1) * (l1 - l0) + l0);
+                }
+                const double a = 2.0 * HYP_H_CGS / HYP_C_CGS / HYP_C_CGS / HYP_STEF_BOLTZ * HYP_PI, b = HYP_H_CGS / HYP_K_CGS;
+                const double T = src.temperature, T4 = T * T * T * T;
+                for (int k = 0; k < nb; k++) bfnu[k] = a * bnu[k] * bnu[k] * bnu[k] / (std::exp(b * bnu[k] / T) - 1.0) / T4;
+                x = bnu.data(); y = bfnu.data(); n = nb;
+            }
+            const double tot = integral_loglog_all(x, y, 1, n);
+            for (int g : ray_groups) {
+                const int nn = h->h_peeled[g].n_nu;
+                for (int i = 0; i < nn; i++) spec[g][(size_t)is * nn + i] = integral_loglog_range(x, y, 1, n, lo[g][i], hi[g][i]) / tot;
+            }
+        }
+        for (int d = 0; d < pr->n_dust; d++) {
+            const hyp_dust_desc &in = pr->dust[d];
+            for (int j = 0; j < in.n_jnu; j++) {
+                const double tot = integral_loglog_all(in.emiss_nu, in.emiss_jnu + j, in.n_jnu, in.n_enu);
+                for (int g : ray_groups) {
+                    const int nn = h->h_peeled[g].n_nu;
+                    for (int i = 0; i < nn; i++)
+                        em[g][((size_t)d * nj_stride + j) * nn + i] =
+                            std::log10(integral_loglog_range(in.emiss_nu, in.emiss_jnu + j, in.n_jnu, in.n_enu, lo[g][i], hi[g][i]) / tot);
+                }
+            }
+            for (int g : ray_groups) {
+                const int nn = h->h_peeled[g].n_nu;
+                for (int i = 0; i < nn; i++)
+                    chi[g][(size_t)d * nn + i] = integral_loglog_range(in.nu, in.chi, 1, in.n_nu, lo[g][i], hi[g][i]) / (hi[g][i] - lo[g][i]);
+            }
+        }
+        for (int g : ray_groups) { poff[g].src_spec = B.put(spec[g]); poff[g].dust_em = B.put(em[g]); poff[g].dust_chi = B.put(chi[g]); }
     }
 
     // ---- device allocations ----
@@ -977,6 +1104,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     for (int g = 0; g < pr->n_peeled; g++) {
         DPeeled &G = h->h_peeled[g];
         G.view = db + poff[g].view;
+        if (pr->config.raytracing) {
+            G.src_spec = db + poff[g].src_spec; G.dust_log10_em = db + poff[g].dust_em; G.dust_chi = db + poff[g].dust_chi;
+            G.nj_stride = nj_stride;
+        }
         if (h->sed_n[g]) { G.sed = h->d_img_accum + h->sed_off[g]; G.sed2 = G.sed + h->sed_n[g]; }
         if (h->img_n[g]) { G.img = h->d_img_accum + h->img_off[g]; G.img2 = G.img + h->img_n[g]; }
     }
@@ -1037,6 +1168,30 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     P.n_copies = 1;
     P.tail = h->d_accum + ne;
     P.jnu_id = h->d_jnu_id; P.jnu_frac = h->d_jnu_frac;
+    P.specific_energy = h->d_specific_energy; P.energy_abs_tot = h->d_energy_abs_tot;
+    P.energy_total = h->energy_total; P.peel_scattered_only = pr->config.raytracing ? 1 : 0;
+    {   // geo%mask_map: cartesian_3d.f90:101, octree.f90:214-225, amr.f90:489-505, voronoi.f90:161-173
+        std::vector<unsigned int> mask;
+        mask.reserve(h->n_cells);
+        for (size_t ic = 0; ic < h->n_cells; ic++) {
+            bool valid = true;
+            if (is_oct) valid = !oct_cells[ic].refined;
+            else if (is_vor) valid = pr->grid.vor_volume[ic] > 0.0;
+            else if (is_amr) {
+                const AmrGrid &g = amr_grids[amr_cell_grid[ic]];
+                const size_t l = ic - g.start;
+                const int i1 = (int)(l % g.n[0]), i2 = (int)((l / g.n[0]) % g.n[1]), i3 = (int)(l / ((size_t)g.n[0] * g.n[1]));
+                valid = amr_go[g.go_off + ((size_t)(i3 + 1) * (g.n[1] + 2) + (i2 + 1)) * (g.n[0] + 2) + (i1 + 1)] == 0;
+            }
+            if (valid) mask.push_back((unsigned int)ic);
+        }
+        P.n_masked = mask.size();
+        if (pr->config.raytracing) {
+            HIPC(hipMalloc(&h->d_mask_map, sizeof(unsigned int) * (mask.size() ? mask.size() : 1)));
+            HIPC(hipMemcpy(h->d_mask_map, mask.data(), sizeof(unsigned int) * mask.size(), hipMemcpyHostToDevice));
+            P.mask_map = h->d_mask_map;
+        }
+    }
     P.counter = h->d_counter; P.err = h->d_err; P.err_data = h->d_err_data;
     HIPC(hipMalloc(&h->d_problem, sizeof(DProblem)));
     HIPC(hipMemcpy(h->d_problem, &P, sizeof(DProblem), hipMemcpyHostToDevice));
@@ -1096,6 +1251,8 @@ static int check_device_error(hyp_handle h)
     } else if (code == ERR_NEGATIVE_T) {
         // error("find_wall","negative t"), src/grid/grid_geometry_amr.f90:829
         std::snprintf(buf, sizeof buf, "negative t");
+    } else if (code == ERR_RAY_GRID) {
+        std::snprintf(buf, sizeof buf, "raytracing of dust emission is not available for this grid type");
     } else std::snprintf(buf, sizeof buf, "device error %d", code);
     return h->set_error(buf);
 }
@@ -1432,6 +1589,90 @@ int hyp_final_iteration(hyp_handle h, uint64_t n_packets, hyp_iter_stats *stats)
     if (hyp_final_launch(h, 0, n_packets)) return 1;
     if (hyp_final_accumulators(h, nullptr, nullptr)) return 1;
     return hyp_final_finish(h, stats);
+}
+
+// ---- raytracing iteration (iter_raytracing.f90) --------------------------------------------
+
+int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first)
+{
+    if (!h) return 1;
+    if (!h->cfg.raytracing) return h->set_error("raytracing was not requested in the configuration");
+    if (which < 0 || which > 1) return h->set_error("hyp_raytracing_launch: which must be 0 (sources) or 1 (dust)");
+    if (!h->d_img_accum) return h->set_error("no peeled images set up");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    DProblem &P = h->hp;
+    double *tail = h->d_img_accum + (h->img_accum_n - TAIL_SIZE);
+    hipError_t e;
+    if (zero_first) e = hipMemsetAsync(h->d_img_accum, 0, sizeof(double) * h->img_accum_n, h->stream);
+    else if (!h->ray_pending) e = hipMemsetAsync(tail, 0, sizeof(double) * TAIL_SIZE, h->stream);
+    else e = hipSuccess;
+    if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(images): ") + hipGetErrorString(e));
+    P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
+    if (sync_problem(h)) return 1;
+    h->ray_pending = true;
+    if (n_local == 0 || n_total == 0) return 0;
+    unsigned long long first = first_id;
+    e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
+    RayKernel k = pick_ray_kernel(h->n_dust, h->hp.grid_type);
+    const size_t lds = lds_bytes(P);
+    long long blocks = (long long)h->n_cu * 2;
+    long long need_blocks = (long long)((n_local + 255) / 256);
+    if (need_blocks < 1) need_blocks = 1;
+    if (blocks > need_blocks) blocks = need_blocks;
+    LaunchParams L;
+    L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = which == 0 ? 0x20000u : 0x30000u;
+    unsigned long long c = n_local / ((unsigned long long)blocks * 32ull);
+    if (c < 64) c = 64;
+    if (c > 4096) c = 4096;
+    L.chunk = (int)c;
+    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, which, (double)n_total);
+    e = hipGetLastError();
+    if (e != hipSuccess) return h->set_error(std::string("ray_kernel launch: ") + hipGetErrorString(e));
+    // the two parts share the id dispenser: finish this launch before the next one resets it
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("raytracing failed: ") + hipGetErrorString(e));
+    if (check_device_error(h)) { h->ray_pending = false; return 1; }
+    return 0;
+}
+
+int hyp_raytracing_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
+{
+    if (!h) return 1;
+    if (!h->ray_pending) return h->set_error("hyp_raytracing_accumulators called without a launched iteration");
+    if (device_ptr) *device_ptr = h->d_img_accum;
+    if (n_doubles) *n_doubles = h->img_accum_n;
+    return 0;
+}
+
+int hyp_raytracing_finish(hyp_handle h, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (!h->ray_pending) return h->set_error("hyp_raytracing_finish called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    h->ray_pending = false;
+    double tail[TAIL_SIZE];
+    hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    hyp_iter_stats st;
+    std::memset(&st, 0, sizeof st);
+    st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];
+    st.crossings = (uint64_t)tail[TAIL_CROSSINGS];
+    if (stats) *stats = st;
+    return 0;
+}
+
+int hyp_raytracing_iteration(hyp_handle h, uint64_t n_sources, uint64_t n_dust, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (hyp_raytracing_launch(h, 0, 0, n_sources, n_sources, 0)) return 1;
+    if (hyp_raytracing_launch(h, 1, 0, n_dust, n_dust, 0)) return 1;
+    hyp_iter_stats st;
+    if (hyp_raytracing_finish(h, &st)) return 1;
+    st.n_packets = n_sources + n_dust;
+    if (stats) *stats = st;
+    return 0;
 }
 
 int hyp_peeled_n_orig(hyp_handle h, int g) { return (h && g >= 0 && g < (int)h->h_peeled.size()) ? h->h_peeled[g].n_orig : -1; }

@@ -1183,6 +1183,273 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
     }
 }
 
+// geo%volume of every geometry
+__device__ __forceinline__ double cell_volume(const DProblem &P, size_t ic)
+{
+    if (P.grid_type == 3) return P.vor_volume[ic];
+    if (P.grid_type == 4) {
+        const AmrGrid &g = P.amr_grids[P.amr_cell_grid[ic]];      // grid%volume, grid_geometry_amr.f90:143-151
+        return ((g.hi[0] - g.lo[0]) / (double)g.n[0]) * ((g.hi[1] - g.lo[1]) / (double)g.n[1]) * ((g.hi[2] - g.lo[2]) / (double)g.n[2]);
+    }
+    if (P.grid_type == 2) {
+        int lev = P.oct_cells[ic].level;
+        return ldexp(P.oct_half[0], -lev) * ldexp(P.oct_half[1], -lev) * ldexp(P.oct_half[2], -lev) * 8.0;
+    }
+    int i1 = (int)(ic % P.n1);
+    size_t t = ic / P.n1;
+    int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
+    return (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
+}
+
+// ---------------------------------------------------------------------------
+// Raytracing iteration: do_raytracing (iter_raytracing.f90:30-143) with the
+// polychromatic branch of peeloff_photon (images_peeled.f90:218-254)
+// ---------------------------------------------------------------------------
+
+// grid_escape_column_density: grid_propagate_3d.f90:482-582
+template <int NDT, int GEOM>
+__device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
+                                              const Cell<GEOM> &cell0, double col[NDT], Rng &g, Counters &cnt, bool &killed)
+{
+    const int nd = ndust<NDT>(P);
+    double r[3] = {r0[0], r0[1], r0[2]};
+    Cell<GEOM> c = cell0;
+    killed = false;
+#pragma unroll
+    for (int d = 0; d < NDT; d++) col[d] = 0.0;
+    if (geo_escaped(P, c)) return;
+    for (;;) {
+        if (g.countdown == 0) {
+            g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+            if (!geo_in_correct_cell(P, W, r, c)) { cnt.killed_geo++; killed = true; return; }
+        } else g.countdown--;
+        double tmin; int im[3];
+        if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return; }
+        const size_t base = geo_index(P, c) * (size_t)nd;
+#pragma unroll
+        for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+#pragma unroll
+        for (int d = 0; d < NDT; d++) if (d < nd) col[d] += P.density[base + d] * tmin;
+        cnt.crossings++;
+        geo_advance(P, r, c, im);
+        if (geo_invalid(P, c)) { cnt.killed_geo++; killed = true; return; }
+        if (geo_escaped(P, c)) return;
+    }
+}
+
+// random_position_cell: cartesian_3d.f90:383-394, octree.f90:397-408, amr.f90:728-741
+template <int GEOM>
+__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3])
+{
+    if (GEOM == GEOM_CAR) {
+        int i1 = (int)(ic % P.n1);
+        size_t t = ic / P.n1;
+        int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
+        r[0] = x * (P.w[0][i1 + 1] - P.w[0][i1]) + P.w[0][i1];
+        r[1] = y * (P.w[1][i2 + 1] - P.w[1][i2]) + P.w[1][i2];
+        r[2] = z * (P.w[2][i3 + 1] - P.w[2][i3]) + P.w[2][i3];
+        return true;
+    }
+    if (GEOM == GEOM_OCT) {
+        const OctCell &o = P.oct_cells[ic];
+        r[0] = (2.0 * x - 1.0) * ldexp(P.oct_half[0], -o.level) + o.x;
+        r[1] = (2.0 * y - 1.0) * ldexp(P.oct_half[1], -o.level) + o.y;
+        r[2] = (2.0 * z - 1.0) * ldexp(P.oct_half[2], -o.level) + o.z;
+        return true;
+    }
+    if (GEOM == GEOM_AMR) {
+        const AmrGrid &g = P.amr_grids[P.amr_cell_grid[ic]];
+        const size_t l = ic - g.start;
+        const int i[3] = {(int)(l % g.n[0]), (int)((l / g.n[0]) % g.n[1]), (int)(l / ((size_t)g.n[0] * g.n[1]))};
+        const double u[3] = {x, y, z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double wl = P.amr_walls[g.w_off[a] + i[a]], wu = P.amr_walls[g.w_off[a] + i[a] + 1];
+            r[a] = u[a] * (wu - wl) + wl;
+        }
+        return true;
+    }
+    return false;      // voronoi: rejection sampling in the reference, not built
+}
+
+// Polychromatic peel-off of a freshly emitted packet: the whole binned spectrum of its emitter,
+// attenuated per frequency bin by the column densities along the line of sight, goes into
+// Stokes I of one pixel / aperture (image_bin_raytraced, image_type.f90:527-606).  Called by all
+// lanes of the wave.  emiss_dust < 0: source packet (spectrum of source f.source_id).
+template <int NDT, int GEOM>
+__device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, const double r[3], bool active, double energy,
+                                             bool isotropic, const Angle &src_normal, int emiss_dust, int var_id, double var_frac,
+                                             const PeelFlags &f, Rng &g, Counters &cnt)
+{
+    const int nd = ndust<NDT>(P);
+    for (int ig = 0; ig < P.n_peeled; ig++) {
+        const DPeeled &G = P.peeled[ig];
+        for (int iv = 0; iv < G.n_view; iv++) {
+            long long k_img = -1, k_sed = -1;
+            double col[NDT], s0 = 0.0;
+#pragma unroll
+            for (int d = 0; d < NDT; d++) col[d] = 0.0;
+            if (active) {
+                Angle a_req;
+                a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
+                a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+                if (isotropic) s0 = 1.0;
+                else {      // source_emit_peeloff of the external sources: source_type.f90:512-533
+                    double mu = 0.0;
+                    if (P.sources[f.source_id].peeloff) {
+                        double n0, n1, n2, q0, q1, q2;
+                        angle_to_vector(src_normal, n0, n1, n2);
+                        angle_to_vector(a_req, q0, q1, q2);
+                        mu = q0 * n0 + q1 * n1 + q2 * n2;
+                        if (mu < 0.0) mu = 0.0;
+                    }
+                    s0 = 4.0 * mu;
+                }
+                double v[3];
+                angle_to_vector(a_req, v[0], v[1], v[2]);
+                Cell<GEOM> c;
+                geo_clear_wall(c);
+                bool ok = geo_place(P, W, r, v, c);
+                if (!ok) cnt.killed_geo++;
+                double d = -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
+                ok = ok && !(d < G.d_min || d > G.d_max);
+                double dr0 = r[0] - G.origin[0], dr1 = r[1] - G.origin[1], dr2 = r[2] - G.origin[2];
+                double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
+                double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                bool inside = false;
+                if (G.compute_image)
+                    inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
+                             ((y_image >= G.y_min && y_image <= G.y_max) || (y_image <= G.y_min && y_image >= G.y_max));
+                if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
+                ok = ok && inside;
+                if (ok) {
+                    bool killed = false;
+                    if (!G.ignore_optical_depth) escape_column<NDT, GEOM>(P, W, r, v, c, col, g, cnt, killed);
+                    if (!killed && energy == energy) {
+                        // origin slot and pixel / aperture of the first frequency bin
+                        int o = f.scattered ? (f.reprocessed ? 4 : 3) : (f.reprocessed ? 2 : 1);
+                        int io = 0;
+                        if (G.track_origin == 1) io = o - 1;
+                        else if (G.track_origin == 2) {
+                            io = (o == 1) ? f.source_id : (o == 2) ? P.n_sources + f.dust_id
+                               : (o == 3) ? P.n_sources + P.n_dust + f.source_id : 2 * P.n_sources + P.n_dust + f.dust_id;
+                        } else if (G.track_origin == 3) {
+                            int ns = f.n_scat < G.track_n_scat + 1 ? f.n_scat : G.track_n_scat + 1;
+                            io = (f.reprocessed ? (G.track_n_scat + 2) : 0) + ns;
+                        }
+                        if (G.compute_image) {
+                            int ix = ipos0(G.x_min, G.x_max, x_image, G.n_x);
+                            int iy = ipos0(G.y_min, G.y_max, y_image, G.n_y);
+                            if (ix >= 0 && ix < G.n_x && iy >= 0 && iy < G.n_y)
+                                k_img = (long long)(((((size_t)io * G.n_view + iv) * G.n_y + iy) * G.n_x + ix) * G.n_nu);
+                        }
+                        if (G.compute_sed) {
+                            double lr = log10(sqrt(x_image * x_image + y_image * y_image));
+                            int ir;
+                            if (lr < G.log10_ap_min || G.n_ap == 1) ir = 0;
+                            else ir = ipos0(G.log10_ap_min, G.log10_ap_max, lr, G.n_ap - 1) + 1;
+                            if (ir >= 0 && ir < G.n_ap) k_sed = (long long)((((size_t)io * G.n_view + iv) * G.n_ap + ir) * G.n_nu);
+                        }
+                    }
+                }
+            }
+            // wave-uniform from here: one frequency bin at a time, lanes on the same pixel combined
+            const double *le = nullptr, *ss = nullptr;
+            if (k_img >= 0 || k_sed >= 0) {
+                if (emiss_dust >= 0) le = G.dust_log10_em + ((size_t)emiss_dust * G.nj_stride + var_id) * G.n_nu;
+                else ss = G.src_spec + (size_t)f.source_id * G.n_nu;
+            }
+            for (int iw = 0; iw < G.n_nu; iw++) {
+                double val[4] = {0.0, 0.0, 0.0, 0.0};
+                if (k_img >= 0 || k_sed >= 0) {
+                    double sp;
+                    if (le) {       // get_dust_emissivity: images_peeled.f90:451-505
+                        sp = exp10((le[G.n_nu + iw] - le[iw]) * var_frac + le[iw]);
+                        if (sp != sp) sp = 0.0;
+                    } else sp = ss[iw];
+                    sp = sp * s0 * energy;
+#pragma unroll
+                    for (int d = 0; d < NDT; d++) if (d < nd) sp = sp * exp(-col[d] * G.dust_chi[(size_t)d * G.n_nu + iw]);
+                    val[0] = sp;
+                }
+                if (G.compute_image)
+                    wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img >= 0 ? k_img + iw : -1, 0, 1, val);
+                if (G.compute_sed)
+                    wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed >= 0 ? k_sed + iw : -1, 0, 1, val);
+            }
+        }
+    }
+}
+
+// which = 0: packets from the sources (:56-76); which = 1: thermal packets from the grid
+// (:96-126 with emit_from_grid, grid_physics_3d.f90:691-753).  L.iter_tag keys the RNG streams.
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict__ Pp, LaunchParams L, int which, double n_total)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
+    Rng g;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    Dispenser dsp; dsp.next = 0; dsp.end = 0;
+    rng_init(g, P.seed_key, L.iter_tag, 0);
+    for (;;) {
+        unsigned long long id = 0;
+        bool got = take_id(P, L, dsp, true, id);
+        if (!__ballot(got)) break;
+        bool active = got;
+        double r[3] = {0.0, 0.0, 0.0}, energy = 0.0, var_frac = 0.0;
+        bool isotropic = true;
+        Angle src_normal; src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
+        int emiss_dust = -1, var_id = 0;
+        PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
+        if (active) {
+            rng_init(g, P.seed_key, L.iter_tag, id);
+            if (which == 0) {
+                Packet<NDT, GEOM> p;
+                int source_id = 0;
+                bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
+                f.source_id = source_id;
+                isotropic = P.sources[source_id].type == 1;
+                r[0] = p.r[0]; r[1] = p.r[1]; r[2] = p.r[2];
+                energy = p.energy * P.energy_total / n_total;
+                active = ok;
+            } else {
+                const int nd = ndust<NDT>(P);
+                double xi = rng_uniform(g);
+                int d = (int)ceil(xi * (double)nd); if (d < 1) d = 1;
+                f.dust_id = d - 1; f.reprocessed = 1; emiss_dust = d - 1;
+                xi = rng_uniform(g);        // random_masked_cell: grid_geometry_common_3d.f90:104-115
+                long long im = (long long)ceil(xi * (double)P.n_masked); if (im < 1) im = 1;
+                const size_t ic = P.mask_map[im - 1];
+                const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
+                if (!random_position_cell<GEOM>(P, ic, x, y, z, r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); active = false; }
+                Angle a; random_sphere_angle(g, a);         // drawn like the reference, not used by the peel-off
+                const size_t k = ic * (size_t)nd + (size_t)(d - 1);
+                const double eat = P.energy_abs_tot[d - 1];
+                if (eat > 0.0) {
+                    const double mass = P.density[k] * cell_volume(P, ic);
+                    energy = P.specific_energy[k] * mass * (double)P.n_masked / eat;
+                } else energy = 0.0;
+                var_id = P.jnu_id[k]; var_frac = P.jnu_frac[k];
+                g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+                if (energy > 0.0) energy = energy * eat / n_total * (double)nd;
+                else active = false;
+            }
+        }
+        peeloff_poly<NDT, GEOM>(P, W, r, active, energy, isotropic, src_normal, emiss_dust, var_id, var_frac, f, g, cnt);
+        if (*((volatile int *)P.err) != 0) break;
+    }
+    double c = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    if (__lane_id() == 0) {
+        unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], c);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+    }
+}
+
 // forced first interaction: forced_interaction.f90:23-133
 __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau_escape, double xi, double &tau, double &weight)
 {
@@ -1280,7 +1547,10 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
 
         // ---- peel-off + optical depth sampling for lanes that just emitted / interacted ----
         if (__ballot(peel != 0)) {
-            if (P.n_peeled > 0) peeloff<NDT, GEOM>(P, W, p, peel != 0, a_prev, s_prev, last, last_iso, f, g, cnt);
+            // with raytracing on only scattered packets are peeled here (iter_final.f90:120,268); direct
+            // and thermal emission come from the raytracing iteration
+            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS));
+            if (P.n_peeled > 0 && __ballot(do_peel)) peeloff<NDT, GEOM>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
             if (peel != 0) {
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
@@ -1411,21 +1681,7 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
         size_t ic = k / nd;
         int d = (int)(k - ic * nd);
-        double vol;
-        if (P.grid_type == 3) {
-            vol = P.vor_volume[ic];
-        } else if (P.grid_type == 4) {
-            const AmrGrid &g = P.amr_grids[P.amr_cell_grid[ic]];      // grid%volume, grid_geometry_amr.f90:143-151
-            vol = ((g.hi[0] - g.lo[0]) / (double)g.n[0]) * ((g.hi[1] - g.lo[1]) / (double)g.n[1]) * ((g.hi[2] - g.lo[2]) / (double)g.n[2]);
-        } else if (P.grid_type == 2) {
-            int lev = P.oct_cells[ic].level;
-            vol = ldexp(P.oct_half[0], -lev) * ldexp(P.oct_half[1], -lev) * ldexp(P.oct_half[2], -lev) * 8.0;
-        } else {
-            int i1 = (int)(ic % P.n1);
-            size_t t = ic / P.n1;
-            int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
-            vol = (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
-        }
+        const double vol = cell_volume(P, ic);
         const DDust &D = P.dust[d];
         double e;
         if (mode == 0) {

@@ -65,3 +65,24 @@ def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=No
     res, stats = engine.final_finish()
     stats["n_packets"] = n_total
     return res, stats
+
+
+def raytracing_iteration_sharded(engine, n_sources, n_dust, rank=0, world_size=1, all_reduce=None):
+    """do_raytracing (src/main/iter_raytracing.f90) sharded by packet id over the ranks.  Rank 0
+    keeps the cubes of the final iteration, the others start from zero, so that ONE all-reduce of
+    the image block yields final + raytraced flux on every rank."""
+    for which, n_total in ((0, n_sources), (1, n_dust)):
+        first, n_local = shard_range(n_total, rank, world_size)
+        engine.raytracing_launch(which, first, n_local, n_total, zero_first=(which == 0 and rank > 0))
+    if world_size > 1:
+        acc = engine.raytracing_accumulators_tensor()
+        if all_reduce is None:
+            import torch
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        else:
+            all_reduce(acc)
+    res, stats = engine.raytracing_finish()
+    stats["n_packets"] = n_sources + n_dust
+    return res, stats

@@ -22,6 +22,7 @@ EXPORTS = [
     "hyp_peeled_get", "hyp_peeled_n_orig",
     "hyp_get_specific_energy", "hyp_get_density", "hyp_set_specific_energy",
     "hyp_last_kernel_ms", "hyp_set_option", "hyp_get_option",
+    "hyp_raytracing_iteration", "hyp_raytracing_launch", "hyp_raytracing_accumulators", "hyp_raytracing_finish",
 ]
 
 
@@ -91,6 +92,10 @@ def load_library(path=None):
     L.hyp_last_kernel_ms.argtypes = [H, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hyp_set_option.argtypes = [H, C.c_char_p, C.c_int64]
     L.hyp_get_option.argtypes = [H, C.c_char_p, C.POINTER(C.c_int64)]
+    L.hyp_raytracing_iteration.argtypes = [H, C.c_uint64, C.c_uint64, C.POINTER(IterStats)]
+    L.hyp_raytracing_launch.argtypes = [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.hyp_raytracing_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.hyp_raytracing_finish.argtypes = [H, C.POINTER(IterStats)]
     if path == LIB:
         _lib = L
     return L
@@ -203,6 +208,28 @@ class Engine:
     def final_finish(self):
         st = IterStats()
         self._check(self._lib.hyp_final_finish(self._h, C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    # -- raytracing iteration ----------------------------------------------------
+    def raytracing_iteration(self, n_sources, n_dust):
+        """do_raytracing: adds direct and thermal emission to the cubes of the last final iteration."""
+        st = IterStats()
+        self._check(self._lib.hyp_raytracing_iteration(self._h, int(n_sources), int(n_dust), C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    def raytracing_launch(self, which, first_id, n_local, n_total, zero_first=False):
+        self._check(self._lib.hyp_raytracing_launch(self._h, int(which), int(first_id), int(n_local), int(n_total), int(bool(zero_first))))
+
+    def raytracing_accumulators_tensor(self):
+        import torch
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self._lib.hyp_raytracing_accumulators(self._h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DeviceBlock(p.value, n.value), device="cuda:%d" % self.device)
+
+    def raytracing_finish(self):
+        st = IterStats()
+        self._check(self._lib.hyp_raytracing_finish(self._h, C.byref(st)))
         return self.peeled_results(), st.as_dict()
 
     def peeled_results(self):

@@ -20,7 +20,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .distributed import final_iteration_sharded, lucy_iteration_sharded
+from .distributed import raytracing_iteration_sharded, final_iteration_sharded, lucy_iteration_sharded
 from .engine import Engine, EngineError
 from .images import finalize_peeled
 from .problem import Problem
@@ -111,7 +111,7 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
     """The iteration sequence of ``program main`` (src/main/main.f90:167-344)."""
     log = log or (lambda *a: None)
     cfg = problem.config
-    for flag, name in ((cfg.mrw, "MRW"), (cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode"), (cfg.raytracing, "raytracing")):
+    for flag, name in ((cfg.mrw, "MRW"), (cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode")):
         if flag:
             raise EngineError("%s is not supported by the MI355X engine yet" % name)
     date_started = _now()
@@ -154,8 +154,17 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
         log("      ------------------ Skipping ------------------")
         peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, eng.peeled_results())]
     log(" [main] exiting final iteration")
+    rstats = {"killed_geo": 0, "killed_int": 0}
+    if cfg.raytracing:
+        # main.f90:296-305: direct and thermal emission with the emitters' whole spectra
+        log(" [main] starting raytracing iteration")
+        raw, rstats = raytracing_iteration_sharded(eng, cfg.n_ray_photons_sources, cfg.n_ray_photons_dust, rank, world_size)
+        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, raw)]
+        log(" [main] exiting raytracing iteration")
     eng.close()
-    return RunResult(records, converged, n_done, peeled, fstats, time.time() - t0, date_started, _now())
+    res = RunResult(records, converged, n_done, peeled, fstats, time.time() - t0, date_started, _now())
+    res.raytracing_stats = rstats
+    return res
 
 
 def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy_input=False):
@@ -230,8 +239,9 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                         g.create_dataset(name + "_unc", data=cubes[name + "_unc"], compression="gzip")
         f.attrs["killed_photons_geo_final"] = np.int32(result.final_stats.get("killed_geo", 0))
         f.attrs["killed_photons_int_final"] = np.int32(result.final_stats.get("killed_int", 0))
-        f.attrs["killed_photons_geo_raytracing"] = np.int32(0)
-        f.attrs["killed_photons_int_raytracing"] = np.int32(0)
+        rst = getattr(result, "raytracing_stats", None) or {}
+        f.attrs["killed_photons_geo_raytracing"] = np.int32(rst.get("killed_geo", 0))
+        f.attrs["killed_photons_int_raytracing"] = np.int32(rst.get("killed_int", 0))
         f.attrs["cpu_time"] = np.float64(result.cpu_time)
         f.attrs["date_ended"] = b(result.date_ended)      # last: its presence marks success
 

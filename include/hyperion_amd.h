@@ -210,6 +210,19 @@ int  hyp_final_finish(hyp_handle h, hyp_iter_stats *stats);
  * normalised by d(nu) (done at write time, image_type.f90:652-688).
  * which: 0 sed, 1 sed^2, 2 img, 3 img^2.  out may be NULL to query n. */
 int  hyp_peeled_get(hyp_handle h, int group, int which, double *out, uint64_t *n_doubles);
+
+/* do_raytracing (src/main/iter_raytracing.f90:30-143), only with config.raytracing: adds the direct
+ * light of the sources (n_sources packets) and the thermal emission of the dust (n_dust packets,
+ * emit_from_grid src/grid/grid_physics_3d.f90:691-753) to the cubes of the last final iteration,
+ * every packet carrying the whole binned spectrum of its emitter (polychromatic peeloff_photon,
+ * src/images/images_peeled.f90:218-254).  Call after hyp_final_finish (or alone if n_last_photons = 0).
+ * Split form for sharding: launch(which = 0 sources / 1 dust) runs ids [first_id, first_id + n_local)
+ * of n_total; zero_first clears the cubes first (ranks other than 0, so that one all-reduce of the
+ * block from hyp_raytracing_accumulators gives final + raytraced flux); finish reports the counters. */
+int  hyp_raytracing_iteration(hyp_handle h, uint64_t n_sources, uint64_t n_dust, hyp_iter_stats *stats);
+int  hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first);
+int  hyp_raytracing_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
+int  hyp_raytracing_finish(hyp_handle h, hyp_iter_stats *stats);
 int  hyp_peeled_n_orig(hyp_handle h, int group);
 
 /* current state, reference layout [n_dust][n_cells] */

@@ -2090,6 +2090,8 @@ const double *orc_peeled_sed(const orc_state *st, int g) { return st->peeled[g].
 const double *orc_peeled_img(const orc_state *st, int g) { return st->peeled[g].img; }
 const double *orc_peeled_sed2(const orc_state *st, int g) { return st->peeled[g].sed2; }
 const double *orc_peeled_img2(const orc_state *st, int g) { return st->peeled[g].img2; }
+double *orc_peeled_sed_rw(orc_state *st, int g) { return st->peeled[g].sed; }
+double *orc_peeled_img_rw(orc_state *st, int g) { return st->peeled[g].img; }
 
 /* fortranlib ipos(xmin, xmax, x, n): 1-based bin of x in n equal bins; here
  * 0-based, -1 / n when outside (callers test the range). */
@@ -2549,6 +2551,26 @@ static void ray_dust_packet(const orc_state *st, uint64_t id, acc_t *acc, const 
         p.energy = p.energy * st->energy_abs_tot[p.dust_id] / (double)c->n_total * (double)st->n_dust;
         peeloff_photon(st, &p, &g, acc, 1);
     }
+}
+
+/* one id range of one part (which = 0 sources, 1 dust); zero_first clears the cubes before */
+int orc_raytracing_accumulate(orc_state *st, int which, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first,
+                              int n_threads, orc_iter_stats *stats)
+{
+    if (!st->cfg.raytracing) { snprintf(st->err, sizeof st->err, "raytracing was not requested in the configuration"); return 1; }
+    if (which == 0) precompute_jnu_var(st);
+    orc_iter_stats a; memset(&a, 0, sizeof a);
+    ray_ctx c; c.n_total = n_total;
+    if (zero_first)
+        for (int g = 0; g < st->n_peeled; g++) {
+            peeled_t *pg = &st->peeled[g];
+            if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
+            if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
+        }
+    if (n_local > 0 && n_total > 0 && (which == 0 || st->n_dust > 0))
+        if (image_run(st, n_local, n_threads, first_id, which == 0 ? ray_source_packet : ray_dust_packet, &c, 0, &a)) return 1;
+    if (stats) *stats = a;
+    return 0;
 }
 
 int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats)

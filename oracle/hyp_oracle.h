@@ -200,6 +200,11 @@ const double *orc_density(const orc_state *st);
 /* do_raytracing (src/main/iter_raytracing.f90:30-143): adds the direct source and the thermal dust
  * emission to the (already scaled) cubes of the last orc_final_iteration. */
 int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats);
+int orc_raytracing_accumulate(orc_state *st, int which, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first,
+                              int n_threads, orc_iter_stats *stats);
+/* writable views of the cubes (tests emulate the all-reduce of the image block) */
+double *orc_peeled_sed_rw(orc_state *st, int g);
+double *orc_peeled_img_rw(orc_state *st, int g);
 int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads,
                         orc_iter_stats *stats);
 int orc_peeled_n_orig(const orc_state *st, int group);

@@ -48,6 +48,11 @@ def lib():
             getattr(L, f).restype = _dp
         L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_raytracing_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
+        L.orc_peeled_sed_rw.argtypes = [C.c_void_p, C.c_int]
+        L.orc_peeled_sed_rw.restype = _dp
+        L.orc_peeled_img_rw.argtypes = [C.c_void_p, C.c_int]
+        L.orc_peeled_img_rw.restype = _dp
         L.orc_peeled_n_orig.argtypes = [C.c_void_p, C.c_int]
         for f in ("orc_peeled_sed", "orc_peeled_img", "orc_peeled_sed2", "orc_peeled_img2"):
             getattr(L, f).argtypes = [C.c_void_p, C.c_int]
@@ -142,6 +147,28 @@ class Oracle:
         if rc != 0:
             raise OracleError(self._err())
         return self._peeled(), st.as_dict()
+
+    def raytracing_accumulate(self, which, first_id, n_local, n_total, zero_first=False, n_threads=0):
+        st = IterStats()
+        rc = lib().orc_raytracing_accumulate(self.h, int(which), int(first_id), int(n_local), int(n_total), int(bool(zero_first)),
+                                             n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return st.as_dict()
+
+    def peeled_views(self):
+        """Writable numpy views (sed, img) of every group's cubes."""
+        out = []
+        for g in range(len(self.problem.peeled)):
+            n_orig = lib().orc_peeled_n_orig(self.h, g)
+            sed_shape, img_shape = self.m.peeled_shapes(g, n_orig)
+            v = {}
+            if sed_shape is not None:
+                v["sed"] = np.ctypeslib.as_array(lib().orc_peeled_sed_rw(self.h, g), shape=(int(np.prod(sed_shape)),))
+            if img_shape is not None:
+                v["img"] = np.ctypeslib.as_array(lib().orc_peeled_img_rw(self.h, g), shape=(int(np.prod(img_shape)),))
+            out.append(v)
+        return out
 
     def final_iteration(self, n_packets, n_threads=0):
         st = IterStats()

@@ -37,6 +37,22 @@ class OracleAsEngine:
     def lucy_finish(self, want_output=True):
         return self.o.lucy_finish(self.t.numpy())
 
+    # raytracing iteration: the image block is the concatenation of all cubes
+    def raytracing_launch(self, which, first, n_local, n_total, zero_first=False):
+        self.o.raytracing_accumulate(which, first, n_local, n_total, zero_first, n_threads=2)
+
+    def raytracing_accumulators_tensor(self):
+        self.views = [v[k] for v in self.o.peeled_views() for k in ("sed", "img") if k in v]
+        self.blk = torch.from_numpy(np.concatenate(self.views))
+        return self.blk
+
+    def raytracing_finish(self):
+        off = 0
+        for v in self.views:
+            v[:] = self.blk.numpy()[off:off + v.size]
+            off += v.size
+        return self.o._peeled(), {"killed_geo": 0, "killed_int": 0}
+
 
 def _free_port():
     s = socket.socket()
@@ -76,3 +92,30 @@ def test_two_rank_sharded_iteration_equals_single_process(tmp_path, which):
         np.testing.assert_allclose(r0["se"][k], se, rtol=1e-12)
     assert int(r0["crossings"]) == st["crossings"]
     assert float(r0["energy"]) == pytest.approx(st["energy_current"], rel=1e-14)
+
+
+def _ray_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperion_amd.distributed import raytracing_iteration_sharded
+    prob = golden_problem("car_peeloff_ray.False.npz")[0]
+    eng = OracleAsEngine(prob)
+    eng.o.lucy_iteration(3000, 1, n_threads=2)
+    eng.o.final_iteration(2000, n_threads=2)          # every rank holds the same final cubes; rank 0's are kept
+    res, st = raytracing_iteration_sharded(eng, 1501, 2001, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    np.savez(os.path.join(out_dir, "ray%d.npz" % rank), sed=res[1]["sed"], img=res[0]["img"])
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_raytracing_equals_single_process(tmp_path):
+    mp.spawn(_ray_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "ray0.npz"), np.load(tmp_path / "ray1.npz")
+    np.testing.assert_array_equal(r0["sed"], r1["sed"])
+    prob = golden_problem("car_peeloff_ray.False.npz")[0]
+    o = Oracle(prob)
+    o.lucy_iteration(3000, 1, n_threads=2)
+    o.final_iteration(2000, n_threads=2)
+    res, _ = o.raytracing_iteration(1501, 2001, n_threads=2)
+    np.testing.assert_allclose(r0["sed"], res[1]["sed"], rtol=1e-12, atol=1e-14 * res[1]["sed"].max())
+    np.testing.assert_allclose(r0["img"], res[0]["img"], rtol=1e-12, atol=1e-14 * res[0]["img"].max())

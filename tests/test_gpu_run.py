@@ -40,6 +40,24 @@ def test_iteration_sequence_and_output_modes():
     np.testing.assert_allclose(r2.iterations[-1].specific_energy, r.iterations[-1].specific_energy, rtol=1e-10)
 
 
+def test_raytracing_run_sequence():
+    """main.f90:255-305 with raytracing on: Lucy iterations, final iteration peeling scattered packets
+    only, raytracing iteration; the golden's SED of the raytraced run within its Monte Carlo noise."""
+    prob, z = golden_problem("car_peeloff_ray.False.npz")
+    prob.config.n_initial_photons = 20000
+    prob.config.n_last_photons = 40000
+    prob.config.n_ray_photons_sources = 20000
+    prob.config.n_ray_photons_dust = 30000
+    r = run_problem(prob)
+    gold = z["golden/group2/seds"]
+    got = r.peeled[1]["seds"]
+    assert got.shape == gold.shape
+    # direct source light (origin slot 0) is noise-free up to source sampling: within 5 % of the golden (2000 rays)
+    assert got[0, 0, 0, -1, :].sum() == pytest.approx(gold[0, 0, 0, -1, :].sum(), rel=0.08)
+    assert got[0, 1].max() > 0 and got[0, 2].max() > 0
+    assert r.raytracing_stats["killed_geo"] == 0
+
+
 def test_convergence_stops_the_iterations():
     p = make_benchmark_problem(8, n_photons=200000, n_iter=10)
     p.config.check_convergence = True
