@@ -29,6 +29,7 @@ class DustDesc(C.Structure):
 class SourceDesc(C.Structure):
     _fields_ = [
         ("type", C.c_int32), ("spectrum_type", C.c_int32), ("peeloff", C.c_int32), ("n_spec", C.c_int32),
+        ("limb_darkening", C.c_int32), ("reserved0", C.c_int32),
         ("luminosity", C.c_double), ("temperature", C.c_double),
         ("position", C.c_double * 3), ("radius", C.c_double), ("box", C.c_double * 6),
         ("spec_nu", _dp), ("spec_fnu", _dp),
@@ -95,7 +96,7 @@ class IterStats(C.Structure):
                 "n_packets": self.n_packets}
 
 
-SOURCE_TYPES = {"point": 1, "extern_sph": 5, "extern_box": 6}
+SOURCE_TYPES = {"point": 1, "sphere": 2, "extern_sph": 5, "extern_box": 6}
 
 
 def _ptr(a):
@@ -210,6 +211,7 @@ class MarshalledProblem:
                 raise ValueError("unknown type in source list: %s" % s.type)
             x.type = SOURCE_TYPES[s.type]
             x.peeloff = int(s.peeloff)
+            x.limb_darkening = int(bool(s.limb_darkening))
             x.luminosity = float(s.luminosity)
             for k in range(3):
                 x.position[k] = float(s.position[k])

@@ -13,6 +13,7 @@
 #define HYP_C_CGS 29979245800.0
 #define HYP_STEF_BOLTZ 5.67051e-5
 #define HYP_DBL_MAX 1.7976931348623157e308
+#define HYP_INF __builtin_huge_val()
 #define HYP_DBL_MIN 2.2250738585072014e-308
 
 // One dust species, tables resident in HBM (read-mostly, L2/MALL cached).
@@ -45,7 +46,8 @@ struct DSource {
     double lum_pdf, lum_cdf;
     int spectrum_type, n_spec;
     const double *spec_x, *spec_cdf, *spec_bp1;
-    int type, peeloff;        // 1 point, 5 extern_sph, 6 extern_box
+    int type, peeloff;        // 1 point, 2 sphere, 5 extern_sph, 6 extern_box
+    int limb_darkening, pad0; // sphere only
     double radius, box[6], face_cdf[6];
 };
 
@@ -125,7 +127,9 @@ struct DProblem {
     const double *specific_energy;        // [n_cells][n_dust]
     const double *energy_abs_tot;         // [n_dust]
     double energy_total;
-    int peel_scattered_only, pad5;        // final iteration peels only scattered packets (raytracing on)
+    int peel_scattered_only;              // final iteration peels only scattered packets (raytracing on)
+    int any_intersect;                    // a source can re-absorb packets (spheres): source.f90:216
+    long long n_reabs_max;
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

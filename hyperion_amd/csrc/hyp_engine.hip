@@ -765,7 +765,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     P.sample_sources_evenly = pr->config.sample_sources_evenly;
     P.kill_on_absorb = pr->config.kill_on_absorb; P.kill_on_scatter = pr->config.kill_on_scatter;
     P.forced_first = pr->config.forced_first_interaction; P.forced_algo = pr->config.forced_first_interaction_algorithm;
-    P.n_inter_max = pr->config.n_inter_max; P.n_cells = h->n_cells; P.baes16_xi = pr->config.baes16_xi;
+    P.n_inter_max = pr->config.n_inter_max; P.n_reabs_max = pr->config.n_reabs_max; P.n_cells = h->n_cells; P.baes16_xi = pr->config.baes16_xi;
     {
         P.check_p = pr->config.propagation_check_frequency;
         P.check_log1mp = (P.check_p > 0.0 && P.check_p < 1.0) ? std::log1p(-P.check_p) : -1.0;
@@ -877,8 +877,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             const hyp_source_desc &s = pr->sources[i];
             DSource &S = hs[i];
             std::memset(&S, 0, sizeof(S));
-            if (s.type != 1 && s.type != 5 && s.type != 6) FAIL("unknown type in source list: " + std::to_string(s.type));
-            S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius;
+            if (s.type != 1 && s.type != 2 && s.type != 5 && s.type != 6) FAIL("unknown type in source list: " + std::to_string(s.type));
+            S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius; S.limb_darkening = s.limb_darkening;
+            if (s.type == 2) P.any_intersect = 1;      // s%intersect = .true.: source_type.f90:148
             for (int k = 0; k < 6; k++) S.box[k] = s.box[k];
             if (s.type == 6) {   // face pdf ~ face areas: source_type.f90:233-237
                 double dx = s.box[1] - s.box[0], dy = s.box[3] - s.box[2], dz = s.box[5] - s.box[4];
@@ -900,7 +901,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 soff[i].x = B.put(s.spec_nu, s.n_spec); soff[i].cdf = B.put(cdf); soff[i].bp1 = B.put(bp1);
                 soff[i].have = true;
             } else if (s.spectrum_type != 2)
-                FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : "Point source") + " cannot have LTE spectrum");
+                FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : s.type == 2 ? "Spherical source" : "Point source") + " cannot have LTE spectrum");
         }
         for (int i = 0; i < pr->n_sources; i++) hs[i].lum_cdf /= c;
     }
@@ -1283,7 +1284,8 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
 
     // The brick-tiled iteration pays off once the grid has many bricks and the
     // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
-    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS;
+    // (sources that re-absorb packets keep a per-integration path length the slot records do not carry)
+    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !P.any_intersect;
     const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
     if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
         if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;

@@ -13,7 +13,7 @@
 
 #include "hyp_device.h"
 
-enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3 };
+enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
 enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2, GEOM_AMR = 3 };
@@ -36,6 +36,11 @@ struct Packet {
     double chi[NDT], albedo[NDT], kappa[NDT];
     Cell<GEOM> cell;
     int inter;
+    // re-absorption by sources (grid_propagate_3d.f90:99-101,139-143): distance to the nearest
+    // intersecting source along v, distance covered in this grid_integrate, that source, and the
+    // number of successive re-emissions (iter_lucy.f90:155-185)
+    double t_src, t_ach;
+    int reabs_id, reabs;
 };
 
 // extra state carried only by the imaging (final) iteration
@@ -536,6 +541,61 @@ __device__ __forceinline__ bool geo_invalid(const DProblem &P, const Cell<GEOM> 
 template <int GEOM>
 __device__ __forceinline__ void geo_clear_wall(Cell<GEOM> &c) { c.ow[0] = c.ow[1] = c.ow[2] = 0; }
 
+// ran_mu_limb(a, b): source_type.f90:982-1086
+__device__ __forceinline__ double ran_mu_limb(double a, double b, double xi_in)
+{
+    double s = a * (1.0 / 3.0), t = b * 0.5;
+    double norm = s + t;
+    s = s / norm; t = t / norm;
+    double xi = -xi_in;
+    double bb = t / s, dd = xi / s;
+    const double alpha = 1.0 / 3.0, gamma = 1.0 / 27.0;
+    double pp = -bb * bb * alpha * alpha;
+    double q = (dd + 2.0 * bb * bb * bb * gamma) * 0.5;
+    double p3 = pp * pp * pp, q2 = q * q;
+    double delta = q2 + p3;
+    if (delta < 0) {
+        double phi = acos(-q / sqrt(fabs(p3)));
+        double y = 2 * sqrt(fabs(pp)) * cos(phi * alpha);
+        return y - bb * alpha;
+    }
+    delta = sqrt(delta);
+    return cbrt(-q + delta) + cbrt(-q - delta) - bb * alpha;
+}
+
+// source_distance (source_type.f90:324-357) over the sources that can intersect: source.f90:206-227
+__device__ __forceinline__ void find_nearest_source(const DProblem &P, const double r[3], const double v[3], double &t_source, int &source_id)
+{
+    source_id = -1; t_source = HYP_INF;
+    if (!P.any_intersect) return;
+    for (int is = 0; is < P.n_sources; is++) {
+        const DSource &S = P.sources[is];
+        if (S.type != 2) continue;
+        const double dr0 = r[0] - S.pos[0], dr1 = r[1] - S.pos[1], dr2 = r[2] - S.pos[2];
+        const double pB = 2.0 * (dr0 * v[0] + dr1 * v[1] + dr2 * v[2]);
+        const double pC = (dr0 * dr0 + dr1 * dr1 + dr2 * dr2) - S.radius * S.radius;
+        // quadratic_pascal_reduced (fortranlib): cancellation-free roots of t^2 + pB t + pC = 0
+        double t1 = -HYP_DBL_MAX, t2 = -HYP_DBL_MAX;
+        const double delta = pB * pB - 4.0 * pC;
+        if (!(delta < 0.0)) {
+            const double q = pB >= 0.0 ? -0.5 * (pB + sqrt(delta)) : -0.5 * (pB - sqrt(delta));
+            t1 = q; t2 = q != 0.0 ? pC / q : 0.0;
+        }
+        double dist = HYP_INF;
+        if (t1 < dist && t1 > 1.e-8 * S.radius) dist = t1;
+        if (t2 < dist && t2 > 1.e-8 * S.radius) dist = t2;
+        if (dist < t_source) { t_source = dist; source_id = is; }
+    }
+}
+
+// start of a grid_integrate call: grid_propagate_3d.f90:99-101
+template <int NDT, int GEOM>
+__device__ __forceinline__ void begin_integrate(const DProblem &P, Packet<NDT, GEOM> &p)
+{
+    p.t_ach = 0.0;
+    find_nearest_source(P, p.r, p.v, p.t_src, p.reabs_id);
+}
+
 // One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
 // / grid_integrate_noenergy (:237-375).  Returns the lane's next phase;
 // ST_NEED_EMIT means the packet left the grid or was killed.
@@ -562,6 +622,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
     double tau_needed = p.tau_req - p.tau_ach;
     cnt.crossings++;
     if (tau_cell < tau_needed) {
+        if (P.any_intersect) { p.t_ach += tmin; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // re-absorbed by a source :139-143
 #pragma unroll
         for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
         p.tau_ach += tau_cell;
@@ -575,6 +636,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
         return geo_escaped(P, p.cell) ? ST_NEED_EMIT : ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
+        if (P.any_intersect) { p.t_ach += tact; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // :184-188
 #pragma unroll
         for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tact * p.v[a];
         p.tau_ach += tau_needed;
@@ -603,7 +665,7 @@ __device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
 // Returns false on a fatal error (flag raised).
 template <int NDT, int GEOM>
 __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
-                                            Counters &cnt, int &source_id, Angle &src_normal)
+                                            Counters &cnt, int &source_id, Angle &src_normal, int reemit_id = -1, double reemit_energy = 0.0)
 {
     int is = 0;
     if (P.n_sources > 1) {
@@ -614,10 +676,26 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
             for (int i = 0; i < P.n_sources - 1; i++) if (xi < P.sources[i].lum_cdf) { is = i; break; }
         }
     }
+    if (reemit_id >= 0) is = reemit_id;      // emit(reemit=.true., reemit_id=...): source.f90:135-141
     source_id = is;
     const DSource &S = P.sources[is];
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
-    if (S.type == 1) {
+    if (S.type == 2) {
+        // emit_from_sphere: source_type.f90:604-690
+        Angle a_coord, a_local;
+        random_sphere_angle(g, a_coord);
+        double sp, cp;
+        sincos(HYP_TWOPI * rng_uniform(g), &sp, &cp);
+        a_local.cosp = cp; a_local.sinp = sp;
+        if (S.limb_darkening) a_local.cost = ran_mu_limb(1.5, 1.0, rng_uniform(g));
+        else a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        rotate_angle(a_local, a_coord, p.a);
+        double n0, n1, n2;
+        angle_to_vector(a_coord, n0, n1, n2);
+        p.r[0] = n0 * S.radius + S.pos[0]; p.r[1] = n1 * S.radius + S.pos[1]; p.r[2] = n2 * S.radius + S.pos[2];
+        src_normal = a_coord;       // outward normal (p%source_a)
+    } else if (S.type == 1) {
         // emit_from_point: source_type.f90:539-564
         p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
         random_sphere_angle(g, p.a);
@@ -667,8 +745,11 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
-    if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
-    cnt.energy_current += p.energy;
+    if (reemit_id >= 0) p.energy = reemit_energy;
+    else {
+        if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
+        cnt.energy_current += p.energy;
+    }
     if (!update_optconsts<NDT, GEOM>(P, p)) return false;
     g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
     geo_clear_wall(p.cell);
@@ -899,15 +980,41 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
     rng_init(g, P.seed_key, L.iter_tag, 0);
     p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
 
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
     for (;;) {
         unsigned long long m_walk = __ballot(st == ST_WALK);
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit)) break;
+        unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+        if (!(m_walk | m_int | m_emit | m_re)) break;
+
+        // ---- packets re-absorbed by a source are re-emitted from it: iter_lucy.f90:155-185 ----
+        if (m_re && (__popcll(m_re) >= L.emit_threshold || !m_walk)) {
+            if (st == ST_NEED_REEMIT) {
+                if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_NEED_EMIT; }
+                else {
+                    const int inter = p.inter, reabs = p.reabs + 1, rid = p.reabs_id;
+                    const double e = p.energy;
+                    int source_id; Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                    p.inter = inter; p.reabs = reabs;
+                    if (!ok || geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
+                    else {
+                        p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        begin_integrate(P, p);
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_int = __ballot(st == ST_NEED_INTERACT);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
 
         // ---- interaction phase (deferred until enough lanes wait) ----
         if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
             if (st == ST_NEED_INTERACT) {
+                p.reabs = 0;
                 if ((long long)p.inter == P.n_inter_max + 1) {
                     cnt.killed_int++; st = ST_NEED_EMIT;
                 } else {
@@ -918,6 +1025,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     else {
                         p.inter++;
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 }
@@ -937,10 +1045,12 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     int source_id;
                     Angle src_normal;
                     bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
+                    p.reabs = 0;
                     if (!ok) st = ST_NEED_EMIT;
                     else if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 }
@@ -991,6 +1101,11 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     double tau = 0.0;
     killed = false;
     if (geo_escaped(P, c)) return 0.0;
+    if (P.any_intersect) {      // a source in the way: grid_propagate_3d.f90:414-420 (tmax = huge for external observers)
+        double t_source; int sid;
+        find_nearest_source(P, r0, v, t_source, sid);
+        if (t_source < HYP_DBL_MAX) { killed = true; return 0.0; }
+    }
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
@@ -1128,7 +1243,10 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                         mu = q0 * n0 + q1 * n1 + q2 * n2;
                         if (mu < 0.0) mu = 0.0;
                     }
-                    s[0] = 4.0 * mu; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+                    // emit_from_sphere_peeloff :692-707 for limb-darkened spheres, 4 mu otherwise
+                    const DSource &S = P.sources[f.source_id];
+                    s[0] = (S.type == 2 && S.limb_darkening) ? 2.0 * (1.5 * mu * mu + mu) : 4.0 * mu;
+                    s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
                 } else if (last != LAST_DS) {
                     s[0] = s_prev[0]; s[1] = s_prev[1]; s[2] = s_prev[2]; s[3] = s_prev[3];
                 } else {
@@ -1218,6 +1336,11 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
 #pragma unroll
     for (int d = 0; d < NDT; d++) col[d] = 0.0;
     if (geo_escaped(P, c)) return;
+    if (P.any_intersect) {      // grid_propagate_3d.f90:516-523
+        double t_source; int sid;
+        find_nearest_source(P, r0, v, t_source, sid);
+        if (t_source < HYP_DBL_MAX) { killed = true; return; }
+    }
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
@@ -1303,7 +1426,8 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                         mu = q0 * n0 + q1 * n1 + q2 * n2;
                         if (mu < 0.0) mu = 0.0;
                     }
-                    s0 = 4.0 * mu;
+                    const DSource &S = P.sources[f.source_id];
+                    s0 = (S.type == 2 && S.limb_darkening) ? 2.0 * (1.5 * mu * mu + mu) : 4.0 * mu;
                 }
                 double v[3];
                 angle_to_vector(a_req, v[0], v[1], v[2]);
@@ -1486,21 +1610,44 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     bool pool_empty = false;
     rng_init(g, P.seed_key, L.iter_tag, 0);
     p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
 
     for (;;) {
         unsigned long long m_walk = __ballot(st == ST_WALK);
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit)) break;
+        unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+        if (!(m_walk | m_int | m_emit | m_re)) break;
 
-        // peel: 0 none, 1 after emission, 2 after interaction
+        // peel: 0 none, 1 after emission, 2 after interaction, 3 after re-emission by a source
         int peel = 0;
         Angle a_prev = p.a;
         double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
         int last = LAST_SR; bool last_iso = true;
 
+        // ---- packets re-absorbed by a source are re-emitted from it: iter_final.f90:213-243 ----
+        if (m_re && (__popcll(m_re) >= L.emit_threshold || !m_walk)) {
+            if (st == ST_NEED_REEMIT) {
+                if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_NEED_EMIT; }
+                else {
+                    const int inter = p.inter, reabs = p.reabs + 1, rid = p.reabs_id;
+                    const double e = p.energy;
+                    int source_id = 0; Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                    p.inter = inter; p.reabs = reabs;
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    if (!ok) st = ST_NEED_EMIT;
+                    else { peel = 3; last = LAST_SR; st = ST_PLACED; last_iso = false; a_prev = src_normal; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_int = __ballot(st == ST_NEED_INTERACT);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
         if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
             if (st == ST_NEED_INTERACT) {
+                p.reabs = 0;
                 if ((long long)p.inter == P.n_inter_max + 1) {
                     cnt.killed_int++; st = ST_NEED_EMIT;
                 } else {
@@ -1532,7 +1679,8 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else {
-                        peel = 1; last = LAST_SR; st = ST_DONE + 1;   // placed, awaiting tau
+                        peel = 1; last = LAST_SR; st = ST_PLACED;   // placed, awaiting tau
+                        p.reabs = 0;
                         last_iso = P.sources[source_id].type == 1;
                         // external sources: a_prev carries the inward normal for emit_peeloff
                         if (!last_iso) a_prev = src_normal;
@@ -1549,7 +1697,8 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
         if (__ballot(peel != 0)) {
             // with raytracing on only scattered packets are peeled here (iter_final.f90:120,268); direct
             // and thermal emission come from the raytracing iteration
-            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS));
+            // (a re-emission by a source is peeled in any case: "a kind of scattering", :226-227)
+            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);
             if (P.n_peeled > 0 && __ballot(do_peel)) peeloff<NDT, GEOM>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
             if (peel != 0) {
                 if (peel == 1) {
@@ -1568,10 +1717,14 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                         }
                         if (!sampled) p.tau_req = rng_exp(g);
                         p.tau_ach = 0.0;
+                        begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
+                } else if (peel == 3 && geo_escaped(P, p.cell)) {
+                    st = ST_NEED_EMIT;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
                     st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                 }
             }

@@ -72,7 +72,8 @@ class Dust:
 
 @dataclass
 class Source:
-    """One ``/Sources/source_NNNNN`` group: 'point', 'extern_sph' (position +
+    """One ``/Sources/source_NNNNN`` group: 'point', 'sphere' (position, radius,
+    limb_darkening; can re-absorb packets), 'extern_sph' (position +
     radius) or 'extern_box' (box = xmin,xmax,ymin,ymax,zmin,zmax)
     (``src/sources/source_type.f90:102-322``)."""
     type: str = "point"
@@ -84,6 +85,7 @@ class Source:
     spectrum_nu: Optional[np.ndarray] = None
     spectrum_fnu: Optional[np.ndarray] = None
     peeloff: bool = True
+    limb_darkening: bool = False
 
 
 @dataclass

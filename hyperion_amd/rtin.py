@@ -161,6 +161,13 @@ def read_rtin(path):
             s = Source(type=t, luminosity=float(sa["luminosity"]), peeloff=_b(sa["peeloff"]))
             if t == "point":
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+            elif t == "sphere":
+                # spots are sub-groups of the source group (source_type.f90:150-188)
+                if any(isinstance(g[k], type(g)) for k in g.keys()):
+                    raise NotImplementedError("spots on spherical sources are not supported yet")
+                s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+                s.radius = float(sa["r"])
+                s.limb_darkening = _b(sa["limb"])
             elif t == "extern_sph":
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
                 s.radius = float(sa["r"])

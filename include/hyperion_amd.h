@@ -59,10 +59,12 @@ typedef struct hyp_dust_desc {
 
 /* /Sources/source_NNNNN -- src/sources/source_type.f90:102-322 */
 typedef struct hyp_source_desc {
-    int32_t type;          /* 1 point, 5 extern_sph (position, radius), 6 extern_box (box) */
+    int32_t type;          /* 1 point, 2 sphere (position, radius, limb_darkening), 5 extern_sph (position, radius), 6 extern_box (box) */
     int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
     int32_t peeloff;
     int32_t n_spec;
+    int32_t limb_darkening; /* sphere: attr `limb` (source_type.f90:142) */
+    int32_t reserved0;
     double  luminosity;
     double  temperature;
     double  position[3];

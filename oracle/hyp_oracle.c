@@ -368,7 +368,7 @@ typedef struct {
 } dust_t;
 
 typedef struct {
-    int type, spectrum_type, peeloff;
+    int type, spectrum_type, peeloff, limb_darkening;
     double luminosity, temperature, position[3], radius, box[6], face_cdf[6];
     pdf_t spectrum;
 } source_t;
@@ -423,6 +423,7 @@ struct orc_state {
     double *w[3], *ew[3];
     int n[3];
     double *volume;
+    int any_intersect;          /* some source can re-absorb packets (spheres) */
     size_t n_masked; uint32_t *mask_map;   /* valid cells (geo%mask_map of every geometry) */
     orc_config cfg;
     double check_p, check_log1mp;
@@ -1035,10 +1036,11 @@ int orc_create(const orc_problem *pr, orc_state **out)
     for (int i = 0; i < st->n_sources; i++) {
         const orc_source_desc *s = &pr->sources[i];
         source_t *t = &st->src[i];
-        t->type = s->type; t->spectrum_type = s->spectrum_type; t->peeloff = s->peeloff;
+        t->type = s->type; t->spectrum_type = s->spectrum_type; t->peeloff = s->peeloff; t->limb_darkening = s->limb_darkening;
+        if (s->type == 2) st->any_intersect = 1;     /* s%intersect = .true., source_type.f90:148 */
         t->luminosity = s->luminosity; t->temperature = s->temperature;
         memcpy(t->position, s->position, sizeof t->position);
-        if (s->type != 1 && s->type != 5 && s->type != 6) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        if (s->type != 1 && s->type != 2 && s->type != 5 && s->type != 6) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
         t->radius = s->radius; memcpy(t->box, s->box, sizeof t->box);
         if (s->type == 6) {   /* source_type.f90:233-237: face pdf ~ face areas */
             double dx = s->box[1] - s->box[0], dy = s->box[3] - s->box[2], dz = s->box[5] - s->box[4];
@@ -1058,7 +1060,7 @@ int orc_create(const orc_problem *pr, orc_state **out)
             }
         } else if (s->spectrum_type != 2) {
             snprintf(g_error, sizeof g_error, "%s cannot have LTE spectrum",
-                     s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : "Point source");
+                     s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : s->type == 2 ? "Spherical source" : "Point source");
             orc_destroy(st); return 1;
         }
         st->energy_total += s->luminosity;
@@ -1169,6 +1171,7 @@ typedef struct {
     int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id, face_id;
     angle_t a_prev; double s_prev[4], v_prev[3];
     angle_t source_a;   /* inward normal at the emission point of an external source */
+    int reabsorbed, reabsorbed_id;
     int emiss_type, emiss_var_id; double emiss_var_frac;   /* raytracing: 1/2 source spectrum, 3 dust emissivity */
 } photon_t;
 
@@ -1535,6 +1538,8 @@ static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, i
  * grid_integrate_noenergy :237-375 (deposit == NULL)                   */
 /* ------------------------------------------------------------------ */
 
+static void find_nearest_source(const orc_state *st, const double r[3], const double v[3], double *t_source, int *source_id);
+
 /* find_wall of the AMR grid stops the reference with error("find_wall","negative t") */
 static void amr_negative_t(acc_t *acc)
 {
@@ -1545,8 +1550,12 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
                            rng_t *g, acc_t *acc, double *deposit)
 {
     double tau_achieved = 0.0;
+    p->reabsorbed = 0;
     if (escaped(st, p->ic)) return;
     if (tau_required == 0.0) return;
+    /* distance to the nearest source that can re-absorb the packet: grid_propagate_3d.f90:99-101 */
+    double t_source, t_achieved = 0.0; int source_id;
+    find_nearest_source(st, p->r, p->v, &t_source, &source_id);
     for (;;) {
         if (g->countdown == 0) {
             g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
@@ -1563,6 +1572,8 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
         double tau_cell = chi_rho_total * tmin;
         acc->crossings++;
         if (tau_cell < tau_needed) {
+            t_achieved += tmin;
+            if (t_achieved > t_source) { p->reabsorbed = 1; p->reabsorbed_id = source_id; return; }   /* :139-143 */
             for (int a = 0; a < 3; a++) p->r[a] = p->r[a] + tmin * p->v[a];
             tau_achieved += tau_cell;
             if (deposit)
@@ -1574,6 +1585,8 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
             if (escaped(st, p->ic)) return;
         } else {
             double tact = tmin * (tau_needed / tau_cell);
+            t_achieved += tact;
+            if (t_achieved > t_source) { p->reabsorbed = 1; p->reabsorbed_id = source_id; return; }   /* :184-188 */
             for (int a = 0; a < 3; a++) p->r[a] = p->r[a] + tact * p->v[a];
             tau_achieved += tau_needed;
             p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
@@ -1595,6 +1608,11 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
     double tau = 0.0, t_achieved = 0.0;
     *killed = 0;
     if (escaped(st, p.ic)) return 0.0;
+    {   /* a source in the way: no point in going on (grid_propagate_3d.f90:414-420) */
+        double t_source; int sid;
+        find_nearest_source(st, p.r, p.v, &t_source, &sid);
+        if (t_source < tmax) { *killed = 1; return 0.0; }
+    }
     for (;;) {
         if (g->countdown == 0) {
             g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
@@ -1643,7 +1661,64 @@ static void box_face_normal(int face, angle_t *a)
     a->cost = tab[face][0]; a->sint = tab[face][1]; a->cosp = tab[face][2]; a->sinp = tab[face][3];
 }
 
-static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
+static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy);
+static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc) { return emit_from(st, p, g, acc, -1, 0.0); }
+
+/* ran_mu_limb(a, b): source_type.f90:982-1086 -- mu from the pdf a mu^2 + b mu by the real root of the cubic */
+static double ran_mu_limb(double a, double b, double xi_in)
+{
+    double s = a * (1.0 / 3.0), t = b * 0.5;
+    double norm = s + t;
+    s = s / norm; t = t / norm;
+    double xi = -xi_in;
+    double bb = t / s, dd = xi / s;
+    const double alpha = 1.0 / 3.0, gamma = 1.0 / 27.0;
+    double pp = -bb * bb * alpha * alpha;
+    double q = (dd + 2.0 * bb * bb * bb * gamma) * 0.5;
+    double p3 = pp * pp * pp, q2 = q * q;
+    double delta = q2 + p3;
+    if (delta < 0) {
+        double phi = acos(-q / sqrt(fabs(p3)));
+        double y = 2 * sqrt(fabs(pp)) * cos(phi * alpha);
+        return y - bb * alpha;
+    }
+    delta = sqrt(delta);
+    return cbrt(-q + delta) + cbrt(-q - delta) - bb * alpha;
+}
+
+/* quadratic_pascal_reduced(b, c, t1, t2) (fortranlib): real roots of t^2 + b t + c = 0 in the
+ * cancellation-free form; no real root -> both set to -huge (never selected by the callers) */
+static void quadratic_pascal_reduced(double b, double c, double *t1, double *t2)
+{
+    double delta = b * b - 4.0 * c;
+    if (delta < 0.0) { *t1 = *t2 = -DBL_MAX; return; }
+    double q = b >= 0.0 ? -0.5 * (b + sqrt(delta)) : -0.5 * (b - sqrt(delta));
+    *t1 = q;
+    *t2 = q != 0.0 ? c / q : 0.0;
+}
+
+/* source_distance :324-357 + find_nearest_source source.f90:206-227 */
+static void find_nearest_source(const orc_state *st, const double r[3], const double v[3], double *t_source, int *source_id)
+{
+    *source_id = -1; *t_source = INFINITY;
+    if (!st->any_intersect) return;
+    for (int is = 0; is < st->n_sources; is++) {
+        const source_t *s = &st->src[is];
+        if (s->type != 2) continue;
+        double dr[3] = {r[0] - s->position[0], r[1] - s->position[1], r[2] - s->position[2]};
+        double pB = 2.0 * (dr[0] * v[0] + dr[1] * v[1] + dr[2] * v[2]);
+        double pC = (dr[0] * dr[0] + dr[1] * dr[1] + dr[2] * dr[2]) - s->radius * s->radius;
+        double t1, t2, dist = INFINITY;
+        quadratic_pascal_reduced(pB, pC, &t1, &t2);
+        const double tol = 1.e-8;
+        if (t1 < dist && t1 > tol * s->radius) dist = t1;
+        if (t2 < dist && t2 > tol * s->radius) dist = t2;
+        if (dist < *t_source) { *t_source = dist; *source_id = is; }
+    }
+}
+
+/* emit: source.f90:100-179; reemit_id >= 0 re-emits from that source with the given energy */
+static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy)
 {
     memset(p, 0, sizeof(*p));
     int is = 0;
@@ -1652,9 +1727,24 @@ static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
         if (st->cfg.sample_sources_evenly) is = (int)(xi * st->n_sources);
         else is = sample_discrete(st->lum_cdf, st->n_sources, xi);
     }
+    if (reemit_id >= 0) is = reemit_id;
     p->source_id = is;
     const source_t *s = &st->src[is];
-    if (s->type == 1) {
+    if (s->type == 2) {
+        /* emit_from_sphere :604-690 */
+        angle_t a_coord, a_local;
+        random_sphere_angle(g, &a_coord);
+        double phi = TWOPI * rng_uniform(g);
+        a_local.cosp = cos(phi); a_local.sinp = sin(phi);
+        if (s->limb_darkening) a_local.cost = ran_mu_limb(1.5, 1.0, rng_uniform(g));
+        else a_local.cost = sqrt(rng_uniform(g));
+        a_local.sint = sqrt(1.0 - a_local.cost * a_local.cost);
+        rotate_angle(&a_local, &a_coord, &p->a);
+        double n[3]; angle_to_vector(&a_coord, n);
+        for (int k = 0; k < 3; k++) p->r[k] = n[k] * s->radius + s->position[k];
+        p->last_isotropic = 0;
+        p->source_a = a_coord;
+    } else if (s->type == 1) {
         /* emit_from_point :539-564 */
         p->r[0] = s->position[0]; p->r[1] = s->position[1]; p->r[2] = s->position[2];
         random_sphere_angle(g, &p->a);
@@ -1697,8 +1787,11 @@ static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
     if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
     else p->nu = random_planck_frequency(g, s->temperature);
     angle_to_vector(&p->a, p->v);
-    if (st->cfg.sample_sources_evenly) p->energy = p->energy * st->lum_pdf[is] * st->n_sources;
-    acc->energy_current += p->energy;
+    if (reemit_id >= 0) p->energy = reemit_energy;
+    else {
+        if (st->cfg.sample_sources_evenly) p->energy = p->energy * st->lum_pdf[is] * st->n_sources;
+        acc->energy_current += p->energy;
+    }
     if (update_optconsts(st, p, acc)) return -1;
     p->last = LAST_SR;
     p->a_prev = p->a; memcpy(p->s_prev, p->s, sizeof p->s); memcpy(p->v_prev, p->v, sizeof p->v);
@@ -1865,6 +1958,17 @@ static void lucy_packet(const orc_state *st, uint64_t id, int iter, acc_t *acc)
     for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
         double tau = rng_exp(&g);
         grid_integrate(st, &p, tau, &g, acc, acc->sum);
+        if (p.reabsorbed) {     /* iter_lucy.f90:155-185: re-emit from the absorbing source until the packet gets away */
+            int64_t ia;
+            for (ia = 1; ia <= st->cfg.n_reabs_max; ia++) {
+                int rid = p.reabsorbed_id; double re = p.energy;
+                if (emit_from(st, &p, &g, acc, rid, re)) return;
+                tau = rng_exp(&g);
+                grid_integrate(st, &p, tau, &g, acc, acc->sum);
+                if (!p.reabsorbed) break;
+            }
+            if (ia == st->cfg.n_reabs_max + 1) { acc->killed_int++; p.killed = 1; break; }
+        }
         if (p.killed || escaped(st, p.ic)) break;
         if (inter == st->cfg.n_inter_max + 1) { acc->killed_int++; p.killed = 1; break; }
         interact(st, &p, &g, acc);
@@ -2222,6 +2326,11 @@ static void grid_escape_column_density(const orc_state *st, const photon_t *p_or
     *killed = 0;
     for (int d = 0; d < st->n_dust; d++) col[d] = 0.0;
     if (escaped(st, p.ic)) return;
+    {   /* grid_propagate_3d.f90:516-523 */
+        double t_source; int sid;
+        find_nearest_source(st, p.r, p.v, &t_source, &sid);
+        if (t_source < tmax) { *killed = 1; return; }
+    }
     for (;;) {
         if (g->countdown == 0) {
             g->countdown = rng_check_gap(g, st->check_p, st->check_log1mp);
@@ -2263,11 +2372,14 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
                     const source_t *src = &st->src[p.source_id];
                     if (src->peeloff) {
                         angle_t nrm;
-                        if (src->type == 5) nrm = p.source_a; else box_face_normal(p.face_id, &nrm);
+                        if (src->type == 5 || src->type == 2) nrm = p.source_a; else box_face_normal(p.face_id, &nrm);
                         double vn[3]; angle_to_vector(&nrm, vn);
                         double mu = v_req[0] * vn[0] + v_req[1] * vn[1] + v_req[2] * vn[2];
                         if (mu < 0.0) mu = 0.0;
-                        p.s[0] = 4.0 * mu; p.s[1] = p.s[2] = p.s[3] = 0.0;
+                        /* emit_from_sphere_peeloff :692-707 (pdfs normalised to 4 pi) */
+                        if (src->type == 2 && src->limb_darkening) p.s[0] = 2.0 * (1.5 * mu * mu + mu);
+                        else p.s[0] = 4.0 * mu;
+                        p.s[1] = p.s[2] = p.s[3] = 0.0;
                     } else { p.s[0] = p.s[1] = p.s[2] = p.s[3] = 0.0; }
                     p.a = a_req;
                 } else if (p.last == LAST_DS) {
@@ -2369,6 +2481,19 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
             } else tau = rng_exp(&g);
         } else tau = rng_exp(&g);
         grid_integrate(st, &p, tau, &g, acc, NULL);
+        if (p.reabsorbed) {     /* iter_final.f90:213-243 */
+            int64_t ia;
+            for (ia = 1; ia <= st->cfg.n_reabs_max; ia++) {
+                int rid = p.reabsorbed_id; double re = p.energy;
+                if (emit_from(st, &p, &g, acc, rid, re)) return;
+                /* peeled even in scattering-only mode: "a kind of scattering" not seen by the raytracing */
+                if (st->n_peeled) peeloff_photon(st, &p, &g, acc, 0);
+                tau = rng_exp(&g);
+                grid_integrate(st, &p, tau, &g, acc, NULL);
+                if (!p.reabsorbed) break;
+            }
+            if (ia == st->cfg.n_reabs_max + 1) { acc->killed_int++; p.killed = 1; break; }
+        }
         if (p.killed || escaped(st, p.ic)) break;
         if (inter == st->cfg.n_inter_max + 1) { acc->killed_int++; p.killed = 1; break; }
         interact(st, &p, &g, acc);

