@@ -29,10 +29,11 @@ class DustDesc(C.Structure):
 class SourceDesc(C.Structure):
     _fields_ = [
         ("type", C.c_int32), ("spectrum_type", C.c_int32), ("peeloff", C.c_int32), ("n_spec", C.c_int32),
-        ("limb_darkening", C.c_int32), ("reserved0", C.c_int32),
+        ("limb_darkening", C.c_int32), ("n_points", C.c_int32),
         ("luminosity", C.c_double), ("temperature", C.c_double),
         ("position", C.c_double * 3), ("radius", C.c_double), ("box", C.c_double * 6),
         ("spec_nu", _dp), ("spec_fnu", _dp),
+        ("direction", C.c_double * 2), ("points", _dp), ("point_lum", _dp),
     ]
 
 
@@ -96,7 +97,7 @@ class IterStats(C.Structure):
                 "n_packets": self.n_packets}
 
 
-SOURCE_TYPES = {"point": 1, "sphere": 2, "extern_sph": 5, "extern_box": 6}
+SOURCE_TYPES = {"point": 1, "sphere": 2, "extern_sph": 5, "extern_box": 6, "plane_parallel": 7, "point_collection": 8}
 
 
 def _ptr(a):
@@ -212,6 +213,12 @@ class MarshalledProblem:
             x.type = SOURCE_TYPES[s.type]
             x.peeloff = int(s.peeloff)
             x.limb_darkening = int(bool(s.limb_darkening))
+            x.direction[0], x.direction[1] = float(s.direction[0]), float(s.direction[1])
+            if s.type == "point_collection":
+                pts = np.ascontiguousarray(s.points, dtype=np.float64).reshape(-1, 3)
+                x.n_points = pts.shape[0]
+                x.points = arr(pts)
+                x.point_lum = arr(s.point_luminosity)
             x.luminosity = float(s.luminosity)
             for k in range(3):
                 x.position[k] = float(s.position[k])

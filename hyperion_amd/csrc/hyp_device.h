@@ -47,7 +47,10 @@ struct DSource {
     int spectrum_type, n_spec;
     const double *spec_x, *spec_cdf, *spec_bp1;
     int type, peeloff;        // 1 point, 2 sphere, 5 extern_sph, 6 extern_box
-    int limb_darkening, pad0; // sphere only
+    int limb_darkening;       // sphere only
+    int n_points;             // point_collection
+    double dir_cost, dir_sint, dir_cosp, dir_sinp;   // plane_parallel: beam direction angle3d_deg(theta, phi)
+    const double *points, *point_cdf;   // point_collection: [n][3] positions, luminosity cdf
     double radius, box[6], face_cdf[6];
 };
 

@@ -122,7 +122,7 @@ struct DustOffsets {
     bool have_mo_e, have_mo_chi;
 };
 
-struct SourceOffsets { size_t x, cdf, bp1; bool have; };
+struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; };
 struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi; };
 
 }  // namespace
@@ -870,16 +870,40 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     std::vector<DSource> hs(pr->n_sources);
     std::vector<SourceOffsets> soff(pr->n_sources);
     h->energy_total = 0.0;
-    for (int i = 0; i < pr->n_sources; i++) h->energy_total += pr->sources[i].luminosity;
+    // luminosity of a point collection = sum of its members (source_type.f90:271)
+    std::vector<double> src_lum(pr->n_sources);
+    for (int i = 0; i < pr->n_sources; i++) {
+        const hyp_source_desc &s = pr->sources[i];
+        src_lum[i] = s.luminosity;
+        if (s.type == 8 && s.point_lum && s.n_points > 0) { src_lum[i] = 0.0; for (int k = 0; k < s.n_points; k++) src_lum[i] += s.point_lum[k]; }
+        h->energy_total += src_lum[i];
+        soff[i].have_points = false;
+    }
     {
         double c = 0.0;
         for (int i = 0; i < pr->n_sources; i++) {
             const hyp_source_desc &s = pr->sources[i];
             DSource &S = hs[i];
             std::memset(&S, 0, sizeof(S));
-            if (s.type != 1 && s.type != 2 && s.type != 5 && s.type != 6) FAIL("unknown type in source list: " + std::to_string(s.type));
+            if (s.type != 1 && s.type != 2 && s.type != 5 && s.type != 6 && s.type != 7 && s.type != 8) FAIL("unknown type in source list: " + std::to_string(s.type));
             S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius; S.limb_darkening = s.limb_darkening;
             if (s.type == 2) P.any_intersect = 1;      // s%intersect = .true.: source_type.f90:148
+            if (s.type == 7) {      // plane_parallel: source_type.f90:239-256
+                const double th = s.direction[0] * HYP_PI / 180.0, ph = s.direction[1] * HYP_PI / 180.0;
+                S.dir_cost = std::cos(th); S.dir_sint = std::sin(th); S.dir_cosp = std::cos(ph); S.dir_sinp = std::sin(ph);
+                if (s.peeloff) FAIL("plane parallel sources cannot be peeled off (source_emit_peeloff has no case for them)");
+            }
+            if (s.type == 8) {      // point_collection: source_type.f90:258-277
+                if (s.n_points < 1 || !s.points || !s.point_lum) FAIL("point source collection needs positions and luminosities");
+                std::vector<double> cdf(s.n_points);
+                double tot = 0.0, c = 0.0;
+                for (int k = 0; k < s.n_points; k++) tot += s.point_lum[k];
+                for (int k = 0; k < s.n_points; k++) { c += s.point_lum[k] / tot; cdf[k] = c; }
+                for (int k = 0; k < s.n_points; k++) cdf[k] /= c;
+                S.n_points = s.n_points;
+                soff[i].points = B.put(s.points, 3 * (size_t)s.n_points); soff[i].point_cdf = B.put(cdf);
+                soff[i].have_points = true;
+            }
             for (int k = 0; k < 6; k++) S.box[k] = s.box[k];
             if (s.type == 6) {   // face pdf ~ face areas: source_type.f90:233-237
                 double dx = s.box[1] - s.box[0], dy = s.box[3] - s.box[2], dz = s.box[5] - s.box[4];
@@ -890,7 +914,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             }
             S.pos[0] = s.position[0]; S.pos[1] = s.position[1]; S.pos[2] = s.position[2];
             S.temperature = s.temperature; S.spectrum_type = s.spectrum_type; S.n_spec = s.n_spec;
-            S.lum_pdf = s.luminosity / h->energy_total;
+            S.lum_pdf = src_lum[i] / h->energy_total;
             c += S.lum_pdf; S.lum_cdf = c;
             soff[i].have = false;
             if (s.spectrum_type == 1) {
@@ -901,7 +925,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 soff[i].x = B.put(s.spec_nu, s.n_spec); soff[i].cdf = B.put(cdf); soff[i].bp1 = B.put(bp1);
                 soff[i].have = true;
             } else if (s.spectrum_type != 2)
-                FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : s.type == 2 ? "Spherical source" : "Point source") + " cannot have LTE spectrum");
+                FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : s.type == 2 ? "Spherical source" : s.type == 7 ? "Plane parallel" : s.type == 8 ? "Point source collection" : "Point source") + " cannot have LTE spectrum");
         }
         for (int i = 0; i < pr->n_sources; i++) hs[i].lum_cdf /= c;
     }
@@ -1077,6 +1101,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     }
     for (int i = 0; i < pr->n_sources; i++)
         if (soff[i].have) { hs[i].spec_x = db + soff[i].x; hs[i].spec_cdf = db + soff[i].cdf; hs[i].spec_bp1 = db + soff[i].bp1; }
+    for (int i = 0; i < pr->n_sources; i++)
+        if (soff[i].have_points) { hs[i].points = db + soff[i].points; hs[i].point_cdf = db + soff[i].point_cdf; }
     HIPC(hipMalloc(&h->d_sources, sizeof(DSource) * hs.size()));
     HIPC(hipMemcpy(h->d_sources, hs.data(), sizeof(DSource) * hs.size(), hipMemcpyHostToDevice));
     P.sources = h->d_sources;

@@ -695,6 +695,29 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         angle_to_vector(a_coord, n0, n1, n2);
         p.r[0] = n0 * S.radius + S.pos[0]; p.r[1] = n1 * S.radius + S.pos[1]; p.r[2] = n2 * S.radius + S.pos[2];
         src_normal = a_coord;       // outward normal (p%source_a)
+    } else if (S.type == 8) {
+        // emit_from_point_collection: source_type.f90:570-598
+        const double xi = rng_uniform(g);
+        int k = S.n_points - 1;
+        for (int i = 0; i < S.n_points - 1; i++) if (xi < S.point_cdf[i]) { k = i; break; }
+        p.r[0] = S.points[3 * k]; p.r[1] = S.points[3 * k + 1]; p.r[2] = S.points[3 * k + 2];
+        random_sphere_angle(g, p.a);
+    } else if (S.type == 7) {
+        // emit_from_plane_parallel: source_type.f90:935-975 (not peeled: source_emit_peeloff has no case for it)
+        const double rr = pow(rng_uniform(g), 0.5) * S.radius;
+        const double phi = 360.0 * rng_uniform(g) * HYP_PI / 180.0;
+        Angle a_local, a_dir, a_final;
+        a_local.cost = cos(90.0 * HYP_PI / 180.0); a_local.sint = sin(90.0 * HYP_PI / 180.0);
+        double sp, cp;
+        sincos(phi, &sp, &cp);
+        a_local.cosp = cp; a_local.sinp = sp;
+        a_dir.cost = S.dir_cost; a_dir.sint = S.dir_sint; a_dir.cosp = S.dir_cosp; a_dir.sinp = S.dir_sinp;
+        rotate_angle(a_local, a_dir, a_final);
+        double n0, n1, n2;
+        angle_to_vector(a_final, n0, n1, n2);
+        p.r[0] = n0 * rr + S.pos[0]; p.r[1] = n1 * rr + S.pos[1]; p.r[2] = n2 * rr + S.pos[2];
+        p.a = a_dir;
+        src_normal = a_dir;
     } else if (S.type == 1) {
         // emit_from_point: source_type.f90:539-564
         p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
@@ -1536,7 +1559,7 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
                 int source_id = 0;
                 bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
                 f.source_id = source_id;
-                isotropic = P.sources[source_id].type == 1;
+                isotropic = P.sources[source_id].type == 1 || P.sources[source_id].type == 8;
                 r[0] = p.r[0]; r[1] = p.r[1]; r[2] = p.r[2];
                 energy = p.energy * P.energy_total / n_total;
                 active = ok;
@@ -1681,7 +1704,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     else {
                         peel = 1; last = LAST_SR; st = ST_PLACED;   // placed, awaiting tau
                         p.reabs = 0;
-                        last_iso = P.sources[source_id].type == 1;
+                        last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8;
                         // external sources: a_prev carries the inward normal for emit_peeloff
                         if (!last_iso) a_prev = src_normal;
                     }

@@ -86,6 +86,9 @@ class Source:
     spectrum_fnu: Optional[np.ndarray] = None
     peeloff: bool = True
     limb_darkening: bool = False
+    direction: tuple = (0.0, 0.0)                       # plane_parallel: theta, phi of the beam (deg)
+    points: Optional[np.ndarray] = None                 # point_collection: (n, 3) positions
+    point_luminosity: Optional[np.ndarray] = None       # point_collection: (n,) luminosities (luminosity = their sum)
 
 
 @dataclass
@@ -379,6 +382,8 @@ class Problem:
                 kw["position"] = tuple(kw["position"])
             if "box" in kw:
                 kw["box"] = tuple(kw["box"])
+            if "direction" in kw:
+                kw["direction"] = tuple(kw["direction"])
             sources.append(Source(**kw))
         peeled = []
         for i, m in enumerate(meta["peeled"]):

@@ -158,7 +158,12 @@ def read_rtin(path):
             g = f["Sources"][n]
             sa = g.attrs
             t = _s(sa["type"]).strip()
-            s = Source(type=t, luminosity=float(sa["luminosity"]), peeloff=_b(sa["peeloff"]))
+            if t == "point_collection":
+                lum = np.asarray(g["luminosity"][...], dtype=float)
+                s = Source(type=t, luminosity=float(lum.sum()), peeloff=_b(sa["peeloff"]), point_luminosity=lum,
+                           points=np.asarray(g["position"][...], dtype=float).reshape(-1, 3))
+            else:
+                s = Source(type=t, luminosity=float(sa["luminosity"]), peeloff=_b(sa["peeloff"]))
             if t == "point":
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
             elif t == "sphere":
@@ -171,6 +176,12 @@ def read_rtin(path):
             elif t == "extern_sph":
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
                 s.radius = float(sa["r"])
+            elif t == "plane_parallel":
+                s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
+                s.radius = float(sa["r"])
+                s.direction = (float(sa["theta"]), float(sa["phi"]))
+            elif t == "point_collection":
+                pass
             elif t == "extern_box":
                 s.box = tuple(float(sa[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"))
             else:

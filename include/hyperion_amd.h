@@ -59,12 +59,13 @@ typedef struct hyp_dust_desc {
 
 /* /Sources/source_NNNNN -- src/sources/source_type.f90:102-322 */
 typedef struct hyp_source_desc {
-    int32_t type;          /* 1 point, 2 sphere (position, radius, limb_darkening), 5 extern_sph (position, radius), 6 extern_box (box) */
+    int32_t type;          /* 1 point, 2 sphere (position, radius, limb_darkening), 5 extern_sph (position, radius), 6 extern_box (box),
+                              7 plane_parallel (position, radius, direction), 8 point_collection (points, point_lum) */
     int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
     int32_t peeloff;
     int32_t n_spec;
     int32_t limb_darkening; /* sphere: attr `limb` (source_type.f90:142) */
-    int32_t reserved0;
+    int32_t n_points;       /* point_collection: number of points */
     double  luminosity;
     double  temperature;
     double  position[3];
@@ -72,6 +73,9 @@ typedef struct hyp_source_desc {
     double  box[6];
     const double *spec_nu;
     const double *spec_fnu;
+    double  direction[2];     /* plane_parallel: attrs theta, phi (deg) of the beam (source_type.f90:239-256) */
+    const double *points;     /* point_collection: [n_points][3] dataset `position` (source_type.f90:258-277) */
+    const double *point_lum;  /* point_collection: [n_points] dataset `luminosity` */
 } hyp_source_desc;
 
 /* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),

@@ -368,8 +368,10 @@ typedef struct {
 } dust_t;
 
 typedef struct {
-    int type, spectrum_type, peeloff, limb_darkening;
+    int type, spectrum_type, peeloff, limb_darkening, n_points;
     double luminosity, temperature, position[3], radius, box[6], face_cdf[6];
+    angle_t direction;          /* plane_parallel: angle3d_deg(theta, phi) */
+    double *points, *point_cdf; /* point_collection: [n][3] positions, luminosity cdf */
     pdf_t spectrum;
 } source_t;
 
@@ -1038,9 +1040,25 @@ int orc_create(const orc_problem *pr, orc_state **out)
         source_t *t = &st->src[i];
         t->type = s->type; t->spectrum_type = s->spectrum_type; t->peeloff = s->peeloff; t->limb_darkening = s->limb_darkening;
         if (s->type == 2) st->any_intersect = 1;     /* s%intersect = .true., source_type.f90:148 */
+        if (s->type == 7) {   /* plane_parallel :239-256 */
+            double th = s->direction[0] * PI / 180.0, ph = s->direction[1] * PI / 180.0;
+            t->direction.cost = cos(th); t->direction.sint = sin(th); t->direction.cosp = cos(ph); t->direction.sinp = sin(ph);
+            if (s->peeloff) { snprintf(g_error, sizeof g_error, "plane parallel sources cannot be peeled off (source_emit_peeloff has no case for them)"); orc_destroy(st); return 1; }
+        }
+        if (s->type == 8) {   /* point_collection :258-277: luminosity = sum, set_pdf(collection_pdf, luminosities) */
+            if (s->n_points < 1 || !s->points || !s->point_lum) { snprintf(g_error, sizeof g_error, "point source collection needs positions and luminosities"); orc_destroy(st); return 1; }
+            t->n_points = s->n_points;
+            t->points = dup(s->points, 3 * (size_t)s->n_points);
+            t->point_cdf = malloc(sizeof(double) * s->n_points);
+            double tot = 0.0, c = 0.0;
+            for (int k = 0; k < s->n_points; k++) tot += s->point_lum[k];
+            for (int k = 0; k < s->n_points; k++) { c += s->point_lum[k] / tot; t->point_cdf[k] = c; }
+            for (int k = 0; k < s->n_points; k++) t->point_cdf[k] /= c;
+            t->luminosity = tot;
+        }
         t->luminosity = s->luminosity; t->temperature = s->temperature;
         memcpy(t->position, s->position, sizeof t->position);
-        if (s->type != 1 && s->type != 2 && s->type != 5 && s->type != 6) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        if (s->type != 1 && s->type != 2 && s->type != 5 && s->type != 6 && s->type != 7 && s->type != 8) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
         t->radius = s->radius; memcpy(t->box, s->box, sizeof t->box);
         if (s->type == 6) {   /* source_type.f90:233-237: face pdf ~ face areas */
             double dx = s->box[1] - s->box[0], dy = s->box[3] - s->box[2], dz = s->box[5] - s->box[4];
@@ -1060,10 +1078,10 @@ int orc_create(const orc_problem *pr, orc_state **out)
             }
         } else if (s->spectrum_type != 2) {
             snprintf(g_error, sizeof g_error, "%s cannot have LTE spectrum",
-                     s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : s->type == 2 ? "Spherical source" : "Point source");
+                     s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : s->type == 2 ? "Spherical source" : s->type == 7 ? "Plane parallel" : s->type == 8 ? "Point source collection" : "Point source");
             orc_destroy(st); return 1;
         }
-        st->energy_total += s->luminosity;
+        st->energy_total += t->luminosity;
     }
     {
         double c = 0.0;
@@ -1143,7 +1161,10 @@ void orc_destroy(orc_state *st)
     free(st->amr_cell_grid); free(st->mask_map);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
-        for (int i = 0; i < st->n_sources; i++) if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
+        for (int i = 0; i < st->n_sources; i++) {
+            if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
+            free(st->src[i].points); free(st->src[i].point_cdf);
+        }
         free(st->src);
     }
     if (st->peeled) { for (int g = 0; g < st->n_peeled; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
@@ -1744,6 +1765,23 @@ static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int
         for (int k = 0; k < 3; k++) p->r[k] = n[k] * s->radius + s->position[k];
         p->last_isotropic = 0;
         p->source_a = a_coord;
+    } else if (s->type == 8) {
+        /* emit_from_point_collection :570-598 */
+        int k = sample_discrete(s->point_cdf, s->n_points, rng_uniform(g));
+        p->r[0] = s->points[3 * k]; p->r[1] = s->points[3 * k + 1]; p->r[2] = s->points[3 * k + 2];
+        random_sphere_angle(g, &p->a);
+        p->last_isotropic = 1;
+    } else if (s->type == 7) {
+        /* emit_from_plane_parallel :935-975 */
+        double rr = pow(rng_uniform(g), 0.5) * s->radius;
+        double phi = 360.0 * rng_uniform(g) * PI / 180.0;      /* random_uni(phi, 0, 360) then angle3d_deg(90, phi) */
+        angle_t a_local, a_final;
+        a_local.cost = cos(90.0 * PI / 180.0); a_local.sint = sin(90.0 * PI / 180.0); a_local.cosp = cos(phi); a_local.sinp = sin(phi);
+        rotate_angle(&a_local, &s->direction, &a_final);
+        double n[3]; angle_to_vector(&a_final, n);
+        for (int k = 0; k < 3; k++) p->r[k] = n[k] * rr + s->position[k];
+        p->a = s->direction;
+        p->last_isotropic = 0;
     } else if (s->type == 1) {
         /* emit_from_point :539-564 */
         p->r[0] = s->position[0]; p->r[1] = s->position[1]; p->r[2] = s->position[2];

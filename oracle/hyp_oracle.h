@@ -61,12 +61,12 @@ typedef struct orc_dust_desc {
 
 /* One source (reader: src/sources/source_type.f90:102-322). */
 typedef struct orc_source_desc {
-    int32_t type;          /* 1 point, 2 sphere, 5 extern_sph, 6 extern_box */
+    int32_t type;          /* 1 point, 2 sphere, 5 extern_sph, 6 extern_box, 7 plane_parallel, 8 point_collection */
     int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
     int32_t peeloff;
     int32_t n_spec;
     int32_t limb_darkening; /* sphere: attr `limb` (source_type.f90:142) */
-    int32_t reserved0;
+    int32_t n_points;       /* point_collection: number of points */
     double  luminosity;
     double  temperature;
     double  position[3];
@@ -74,6 +74,9 @@ typedef struct orc_source_desc {
     double  box[6];        /* xmin,xmax,ymin,ymax,zmin,zmax */
     const double *spec_nu;  /* [n_spec] */
     const double *spec_fnu; /* [n_spec] */
+    double  direction[2];     /* plane_parallel: attrs theta, phi (deg) of the beam (source_type.f90:239-256) */
+    const double *points;     /* point_collection: [n_points][3] dataset `position` (source_type.f90:258-277) */
+    const double *point_lum;  /* point_collection: [n_points] dataset `luminosity` */
 } orc_source_desc;
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */

@@ -87,3 +87,22 @@ def test_persistent_schedule_is_used_with_intersecting_sources():
     eng.lucy_iteration(4000000, 1, want_output=False)
     assert eng.get_option("last_lucy_mode") == 0
     eng.close()
+
+
+def test_plane_parallel_and_point_collection_sources():
+    """emit_from_plane_parallel (source_type.f90:935-975: a disc of parallel rays, never peeled) and
+    emit_from_point_collection (:570-598: one member picked by luminosity)."""
+    p = imaging_problem(12, tau=1.0)
+    rng = np.random.default_rng(11)
+    pts = rng.uniform(-0.8 * PC, 0.8 * PC, (7, 3))
+    lum = rng.uniform(0.1, 1.0, 7) * LSUN
+    p.sources = [Source(type="plane_parallel", luminosity=0.7 * LSUN, position=(0.0, 0.0, 0.7 * PC), radius=0.5 * PC,
+                        direction=(160.0, 30.0), temperature=4500.0, peeloff=False),
+                 Source(type="point_collection", luminosity=float(lum.sum()), points=pts, point_luminosity=lum, temperature=7000.0)]
+    a, st = run_both(p, 60000, iters=2, n_img=60000)
+    assert st["killed_geo"] == 0
+    # the beam travels towards -z (theta = 160 deg): its entry side is the hotter one
+    assert a[0][-3:].mean() > a[0][:3].mean()
+    p.sources[0].peeloff = True
+    with pytest.raises(hyperion_amd.EngineError, match="plane parallel sources cannot be peeled"):
+        hyperion_amd.Engine(p)
