@@ -1310,8 +1310,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
 
     // The brick-tiled iteration pays off once the grid has many bricks and the
     // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
-    // (sources that re-absorb packets keep a per-integration path length the slot records do not carry)
-    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !P.any_intersect;
+    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS;
     const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
     if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
         if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;

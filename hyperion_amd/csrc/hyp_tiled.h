@@ -15,7 +15,7 @@
 
 #include "hyp_kernels.h"
 
-enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3 };
+enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3, TS_REEMIT = 4 };   // TS_REEMIT: re-absorbed by a source
 
 #define HYP_TILE_MAX_BRICKS 8192
 
@@ -42,12 +42,16 @@ struct alignas(16) ColdRec {     // only touched at interactions / emission
     double buf_a;
     unsigned int blk_a;
     int have_a, inter, pad;
+    // re-absorption by sources (only used when P.any_intersect): see Packet
+    double t_src, t_ach;
+    int reabs_id, reabs;
 };
 
 // slot_brick[] values besides a brick index
 #define TILE_IDLE (-1)            // slot retired (no packet ids left)
 #define TILE_NEEDS_PREPARE (-2)   // the slot is free for a new packet
 #define TILE_NEEDS_INTERACT (-3)  // the packet in the slot awaits an interaction
+#define TILE_NEEDS_REEMIT (-4)    // the packet was re-absorbed by a source and awaits its re-emission
 #define HYP_PREP_CHUNK 2048
 // build-time shape of tile_walk_kernel (tools/variants.py sweeps these)
 #ifndef HYP_TILE_WG
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
         const int s = ch * HYP_PREP_CHUNK + k;
         // interactions from the front, emissions from the back: waves see one kind of work
         const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
-        if (sb == TILE_NEEDS_INTERACT) list[atomicAdd(&n_list, 1)] = s;
+        if (sb == TILE_NEEDS_INTERACT || sb == TILE_NEEDS_REEMIT) list[atomicAdd(&n_list, 1)] = s;
         else if (sb == TILE_NEEDS_PREPARE) list[HYP_PREP_CHUNK - 1 - atomicAdd(&n_back, 1)] = s;
     }
     __syncthreads();
@@ -156,7 +160,30 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
           if (mi) { n_pass_int++; n_lane_int += __popcll(mi); } if (me) { n_pass_emit++; n_lane_emit += __popcll(me); } }
         if (__ballot(state == TS_INTERACT) == 0 || true) PREP_T(1);   // state load
 #endif
-        if (state == TS_INTERACT) {
+        p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+        if (state == TS_REEMIT) {
+            // iter_lucy.f90:155-185: re-emission from the source that absorbed the packet
+            touched = true;
+            const HotRec<ND> &H = hot[slot];
+            const ColdRec<ND> &C = cold[slot];
+            id = H.id;
+            g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+            g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
+            const int inter = C.inter, reabs = C.reabs, rid = C.reabs_id;
+            const double e = H.energy;
+            if ((long long)reabs == P.n_reabs_max) { cnt.killed_int++; state = TS_DEAD; finished++; }
+            else {
+                int source_id; Angle src_normal;
+                bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                p.inter = inter; p.reabs = reabs + 1;
+                if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
+                else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
+                }
+            }
+        } else if (state == TS_INTERACT) {
             touched = true;
             const HotRec<ND> &H = hot[slot];
             const ColdRec<ND> &C = cold[slot];
@@ -182,6 +209,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 else {
                     p.inter++;
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
                     state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
                 }
             }
@@ -206,6 +234,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                     if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        begin_integrate(P, p);
                         state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
                     }
                 }
@@ -225,6 +254,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 H.id = id; H.countdown = g.countdown; H.blk_b = g.blk_b; H.state = state;
                 C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
                 C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
+                if (P.any_intersect) { C.t_src = p.t_src; C.t_ach = p.t_ach; C.reabs_id = p.reabs_id; C.reabs = p.reabs; }
                 // zero optical depth drawn: interact again in the next generation
                 slot_brick[slot] = state == TS_WALK ? brick_of(T, p.cell.ic) : TILE_NEEDS_INTERACT;
             } else {
@@ -291,7 +321,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
         for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
             const int s = ch * HYP_PREP_CHUNK + k;
             const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
-            if (sb >= 0 || sb == TILE_NEEDS_INTERACT) list[atomicAdd(&n_list, 1)] = s;
+            if (sb >= 0 || sb == TILE_NEEDS_INTERACT || sb == TILE_NEEDS_REEMIT) list[atomicAdd(&n_list, 1)] = s;
         }
         __syncthreads();
         const int nl = n_list;
@@ -316,17 +346,42 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                 const unsigned long long id = H.id;
                 g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                 g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
-                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : ST_WALK;
+                p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+                if (P.any_intersect) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }
+                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : H.state == TS_REEMIT ? ST_NEED_REEMIT : ST_WALK;
             } else {
                 rng_init(g, P.seed_key, T.iter_tag, 0);
                 p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+                p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
             }
             for (;;) {
                 unsigned long long m_walk = __ballot(st == ST_WALK);
                 unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
-                if (!(m_walk | m_int)) break;
+                unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+                if (!(m_walk | m_int | m_re)) break;
+                if (m_re && (__popcll(m_re) >= 16 || !m_walk)) {      // iter_lucy.f90:155-185
+                    if (st == ST_NEED_REEMIT) {
+                        if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_DONE; finished++; }
+                        else {
+                            const int inter = p.inter, reabs = p.reabs + 1, rid = p.reabs_id;
+                            const double e = p.energy;
+                            int source_id; Angle src_normal;
+                            bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                            p.inter = inter; p.reabs = reabs;
+                            if (!ok || geo_escaped(P, p.cell)) { st = ST_DONE; finished++; }
+                            else {
+                                p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                                begin_integrate(P, p);
+                                st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                            }
+                        }
+                    }
+                    m_walk = __ballot(st == ST_WALK);
+                    m_int = __ballot(st == ST_NEED_INTERACT);
+                }
                 if (m_int && (__popcll(m_int) >= 16 || !m_walk)) {
                     if (st == ST_NEED_INTERACT) {
+                        p.reabs = 0;
                         if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; st = ST_DONE; finished++; }
                         else {
                             int scattered, dust_id;
@@ -336,6 +391,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                             else {
                                 p.inter++;
                                 p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                                begin_integrate(P, p);
                                 st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                             }
                         }
@@ -493,7 +549,8 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
 
 // lane states of tile_walk_kernel
 // LS_CHECK: the propagation check is due; LS_SLOW: geo_find_wall is needed for this step
-enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6 };
+// LS_REABS: the step would run into a source (grid_propagate_3d.f90:139-143)
+enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6, LS_REABS = 7 };
 
 template <int ND, int BX, int BY, int BZ>
 __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
@@ -503,7 +560,6 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
-    (void)cold;
     if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
     constexpr int NC = BX * BY * BZ;
@@ -544,6 +600,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     double sgn[3];                            // sign of v per axis (+1, -1, 0) and iu = 1 where v > 0: fixed during a visit
     int iu[3];
     double hit_t = 0.0, hit_tau = 0.0;       // LS_HIT: step length to the wall and optical depth of the cell
+    double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
     int hit_lc = 0;
     Cell<GEOM_CAR> cell;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
@@ -588,6 +645,11 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     pre = true; st = LS_WALK;
                 } else { cnt.killed_geo++; st = LS_DEAD; }
             }
+            if (st == LS_HIT && P.any_intersect) {
+                const double tact0 = hit_t * ((tau_req - tau_ach) / hit_tau);
+                t_ach += tact0;
+                if (t_ach > t_src) st = LS_REABS;       // grid_propagate_3d.f90:184-188
+            }
             if (st == LS_HIT) {
                 // the interaction happens inside this cell: grid_propagate_3d.f90:170-200
                 const double tau_needed = tau_req - tau_ach;
@@ -609,13 +671,15 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
             if (st == LS_DEAD) {
                 hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
                 finished++; st = LS_IDLE;
-            } else if (st == LS_LEFT || st == LS_HIT || (park && st == LS_WALK)) {
+            } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[slot];
 #pragma unroll
                 for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
                 H.ow = pack_ow(cell.ow);
                 H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
-                if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
+                if (P.any_intersect) cold[slot].t_ach = t_ach;
+                if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
+                else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                 else if (st == LS_LEFT) slot_brick[slot] = brick_of(T, cell.ic);     // H.state stays TS_WALK
                 st = LS_IDLE;
             }
@@ -638,6 +702,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
+                    if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     st = LS_WALK; pre = false;
                 }
             }
@@ -680,7 +745,10 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                     }
                     const double tau_cell = chi_rho * tmin;
                     cnt.crossings++;
-                    if (tau_cell < tau_req - tau_ach) {
+                    bool reabs = false;
+                    if (P.any_intersect && tau_cell < tau_req - tau_ach) { t_ach += tmin; reabs = t_ach > t_src; }
+                    if (reabs) st = LS_REABS;
+                    else if (tau_cell < tau_req - tau_ach) {
 #pragma unroll
                         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
                         tau_ach += tau_cell;

@@ -22,8 +22,10 @@ def star_problem(limb, tau=3.0, n=16, radius=0.3):
     return p
 
 
-def run_both(prob, n, iters=1, n_img=0, ray=None):
+def run_both(prob, n, iters=1, n_img=0, ray=None, **opts):
     eng, orc = hyperion_amd.Engine(prob), Oracle(prob)
+    for k, v in opts.items():
+        eng.set_option(k, v)
     for it in range(1, iters + 1):
         a, sa = eng.lucy_iteration(n, it)
         b, sb = orc.lucy_iteration(n, it)
@@ -81,11 +83,31 @@ def test_star_imaging_and_raytracing():
     run_both(p, 30000, n_img=40000, ray=(20000, 20000))
 
 
-def test_persistent_schedule_is_used_with_intersecting_sources():
+@pytest.mark.parametrize("limb", [False, True])
+def test_star_in_the_brick_tiled_schedule(limb):
+    """The slot records carry the path length of the current integration and the nearest source,
+    so re-absorption works across brick visits; re-emission happens in tile_prepare."""
+    p = star_problem(limb, n=40, tau=3.0)
+    run_both(p, 150000, iters=2, lucy_mode=1, tile_slots=32768, tile_pools=2, tile_drain=0)
+    run_both(p, 150000, lucy_mode=1, tile_slots=32768, tile_drain=50000)
+
+
+def test_two_stars_tiled_with_reabsorption_limit():
+    p = star_problem(False, n=40, tau=0.2)
+    p.sources = [Source(type="sphere", luminosity=LSUN, position=(-0.35 * PC, 0.0, 0.0), radius=0.3 * PC, temperature=5000.0),
+                 Source(type="sphere", luminosity=LSUN, position=(0.35 * PC, 0.0, 0.0), radius=0.3 * PC, temperature=4000.0, limb_darkening=True)]
+    p.config.n_reabs_max = 1
+    a, st = run_both(p, 100000, lucy_mode=1, tile_slots=32768, tile_drain=0)
+    assert st["killed_int"] > 100
+    a, st = run_both(p, 100000, lucy_mode=1, tile_slots=32768, tile_drain=10 ** 9)      # everything through the drain kernel
+    assert st["killed_int"] > 100
+
+
+def test_auto_schedule_with_a_star_is_tiled():
     p = star_problem(False, n=64, tau=1.0, radius=0.05)
     eng = hyperion_amd.Engine(p)
     eng.lucy_iteration(4000000, 1, want_output=False)
-    assert eng.get_option("last_lucy_mode") == 0
+    assert eng.get_option("last_lucy_mode") == 1
     eng.close()
 
 
