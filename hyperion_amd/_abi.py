@@ -23,6 +23,7 @@ class DustDesc(C.Structure):
         ("P1", _dp), ("P2", _dp), ("P3", _dp), ("P4", _dp),
         ("emiss_nu", _dp), ("emiss_jnu", _dp), ("emiss_var", _dp),
         ("mo_specific_energy", _dp), ("mo_chi_rosseland", _dp),
+        ("mo_kappa_planck", _dp), ("mo_chi_inv_planck", _dp),
     ]
 
 
@@ -58,6 +59,7 @@ class Config(C.Structure):
         ("forced_first_interaction", C.c_int32), ("forced_first_interaction_algorithm", C.c_int32),
         ("specific_energy_type", C.c_int32), ("raytracing", C.c_int32),
         ("baes16_xi", C.c_double), ("propagation_check_frequency", C.c_double),
+        ("n_inter_mrw_max", C.c_int64), ("mrw_gamma", C.c_double), ("mrw", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 
@@ -178,6 +180,9 @@ class MarshalledProblem:
             raise ValueError("specific_energy_type should be 'additional' or 'initial'")
         d.config.specific_energy_type = 1 if c.specific_energy_type == "additional" else 0
         d.config.raytracing = int(bool(c.raytracing))
+        d.config.mrw = int(bool(c.mrw))
+        d.config.mrw_gamma = float(c.mrw_gamma)
+        d.config.n_inter_mrw_max = int(c.n_inter_mrw_max)
         d.config.baes16_xi = float(c.baes16_xi)
         d.config.propagation_check_frequency = float(c.propagation_check_frequency)
 
@@ -200,6 +205,8 @@ class MarshalledProblem:
                 setattr(x, k, arr(getattr(du, k)))
             x.mo_specific_energy = arr(du.mo_specific_energy) if du.mo_specific_energy is not None else None
             x.mo_chi_rosseland = arr(du.mo_chi_rosseland) if du.mo_chi_rosseland is not None else None
+            x.mo_kappa_planck = arr(du.mo_kappa_planck) if du.mo_kappa_planck is not None else None
+            x.mo_chi_inv_planck = arr(du.mo_chi_inv_planck) if du.mo_chi_inv_planck is not None else None
         keep(dusts)
         d.n_dust = nd
         d.dust = C.cast(dusts, C.POINTER(DustDesc))

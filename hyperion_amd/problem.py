@@ -46,6 +46,9 @@ class Dust:
     emiss_var: np.ndarray  # (n_jnu,) specific energies
     mo_specific_energy: Optional[np.ndarray] = None
     mo_chi_rosseland: Optional[np.ndarray] = None
+    mo_kappa_planck: Optional[np.ndarray] = None      # MRW: dust.f90:88-100
+    mo_chi_inv_planck: Optional[np.ndarray] = None
+    mo_temperature: Optional[np.ndarray] = None       # not used by the engine: specific energy <-> temperature
     version: int = 2
     is_lte: bool = True
     sublimation_mode: str = "no"
@@ -56,7 +59,7 @@ class Dust:
         for k in ("nu", "albedo", "chi", "mu", "P1", "P2", "P3", "P4",
                   "emiss_nu", "emiss_jnu", "emiss_var"):
             setattr(self, k, _f64(getattr(self, k)))
-        for k in ("mo_specific_energy", "mo_chi_rosseland"):
+        for k in ("mo_specific_energy", "mo_chi_rosseland", "mo_kappa_planck", "mo_chi_inv_planck", "mo_temperature"):
             v = getattr(self, k)
             if v is not None:
                 setattr(self, k, _f64(v))
@@ -166,6 +169,8 @@ class RunConfig:
     output_specific_energy: str = "last"
     output_density: str = "none"
     mrw: bool = False
+    mrw_gamma: float = 1.0             # src/main/setup_rt.f90:106-113
+    n_inter_mrw_max: int = 1000
     pda: bool = False
     monochromatic: bool = False
     raytracing: bool = False

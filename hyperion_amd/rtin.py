@@ -42,6 +42,11 @@ def read_dust_group(g, minimum_specific_energy=0.0):
         emiss_var=g["emissivity_variable"][...]["specific_energy"],
         mo_specific_energy=mo["specific_energy"],
         mo_chi_rosseland=mo["chi_rosseland"],
+        mo_kappa_planck=mo["kappa_planck"] if "kappa_planck" in mo.dtype.names else None,
+        # dust_type_4elem.f90:231-237: version-1 files carry the Rosseland mean in its place
+        mo_chi_inv_planck=mo["chi_rosseland" if version == 1 else "chi_inv_planck"]
+        if ("chi_rosseland" if version == 1 else "chi_inv_planck") in mo.dtype.names else None,
+        mo_temperature=mo["temperature"] if "temperature" in mo.dtype.names else None,
         version=version, is_lte=_b(a["lte"]),
         sublimation_mode=_s(a["sublimation_mode"]).strip(),
         minimum_specific_energy=float(minimum_specific_energy),
@@ -79,6 +84,9 @@ def read_rtin(path):
         cfg.n_initial_iter = int(a["n_initial_iter"])
         cfg.n_initial_photons = int(a["n_initial_photons"]) if cfg.n_initial_iter > 0 else 0
         cfg.mrw = _b(a["mrw"])
+        if cfg.mrw:
+            cfg.mrw_gamma = float(a["mrw_gamma"])
+            cfg.n_inter_mrw_max = int(a["n_inter_mrw_max"])
         cfg.pda = _b(a["pda"])
         cfg.monochromatic = _b(a["monochromatic"])
         cfg.raytracing = _b(a["raytracing"])

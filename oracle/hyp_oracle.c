@@ -365,6 +365,8 @@ typedef struct {
     double e_min, e_max;                /* mean_opacities specific_energy range */
     int have_e_range;
     double *mo_e, *mo_chi_ross;
+    double *mo_kappa_planck, *mo_chi_inv_planck;   /* MRW: dust.f90:88-100 */
+    pdf_t *b_nu;                        /* [n_jnu] emissivity / kappa_nu: dust_type_4elem.f90:289-291 */
 } dust_t;
 
 typedef struct {
@@ -426,6 +428,9 @@ struct orc_state {
     int n[3];
     double *volume;
     int any_intersect;          /* some source can re-absorb packets (spheres) */
+    /* modified random walk: grid_mrw_3d.f90 */
+    double *alpha_inv_planck, *diff_coeff;      /* [n_cells], refreshed by prepare_mrw every iteration */
+    double mrw_x[100], mrw_y[100];              /* cumulative of Min et al. (2009) eq. 6 */
     size_t n_masked; uint32_t *mask_map;   /* valid cells (geo%mask_map of every geometry) */
     orc_config cfg;
     double check_p, check_log1mp;
@@ -511,6 +516,8 @@ static int dust_setup(dust_t *d, const orc_dust_desc *in, char *err)
         d->mo_e = dup(in->mo_specific_energy, in->n_e);
         d->e_min = d->mo_e[0]; d->e_max = d->mo_e[in->n_e - 1]; d->have_e_range = 1;
         if (in->mo_chi_rosseland) d->mo_chi_ross = dup(in->mo_chi_rosseland, in->n_e);
+        if (in->mo_kappa_planck) d->mo_kappa_planck = dup(in->mo_kappa_planck, in->n_e);
+        if (in->mo_chi_inv_planck) d->mo_chi_inv_planck = dup(in->mo_chi_inv_planck, in->n_e);
     }
     /* :264-291 emissivities */
     d->j_nu_var = dup(in->emiss_var, d->n_jnu);
@@ -522,6 +529,23 @@ static int dust_setup(dust_t *d, const orc_dust_desc *in, char *err)
             snprintf(err, 512, "emissivity %d has zero integral", i); return -1;
         }
     }
+    /* b_nu = j_nu / kappa_nu on the emissivity grid (log pdf): sampled by the MRW (:289-291, 400-419) */
+    d->b_nu = calloc(d->n_jnu, sizeof(pdf_t));
+    {
+        double *kap = malloc(sizeof(double) * nn), *y = malloc(sizeof(double) * d->n_enu);
+        for (int k = 0; k < nn; k++) kap[k] = d->chi[k] * (1.0 - d->albedo[k]);      /* d%kappa_nu */
+        int ok = 1;
+        for (int i = 0; i < d->n_jnu && ok; i++) {
+            for (int k = 0; k < d->n_enu; k++) {
+                double nu = in->emiss_nu[k];
+                double kk = (nu < d->nu[0] || nu > d->nu[nn - 1]) ? NAN : interp1d_loglog(d->nu, kap, nn, nu);
+                y[k] = in->emiss_jnu[(size_t)k * d->n_jnu + i] / kk;
+            }
+            if (pdf_set_log(&d->b_nu[i], in->emiss_nu, y, d->n_enu, 1)) ok = 0;
+        }
+        free(kap); free(y);
+        if (!ok) { for (int i = 0; i < d->n_jnu; i++) if (d->b_nu[i].x) pdf_free(&d->b_nu[i]); free(d->b_nu); d->b_nu = NULL; }
+    }
     return 0;
 }
 
@@ -530,6 +554,8 @@ static void dust_free(dust_t *d)
     free(d->nu); free(d->albedo); free(d->chi); free(d->mu);
     free(d->P1); free(d->P2); free(d->P3); free(d->P4); free(d->P1_cdf); free(d->P2_cdf);
     free(d->j_nu_var); free(d->log10_j_nu_var); free(d->mo_e); free(d->mo_chi_ross);
+    free(d->mo_kappa_planck); free(d->mo_chi_inv_planck);
+    if (d->b_nu) { for (int i = 0; i < d->n_jnu; i++) pdf_free(&d->b_nu[i]); free(d->b_nu); }
     if (d->j_nu) { for (int i = 0; i < d->n_jnu; i++) pdf_free(&d->j_nu[i]); free(d->j_nu); }
 }
 
@@ -1158,7 +1184,7 @@ void orc_destroy(orc_state *st)
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
     free(st->vsite); free(st->vidx); free(st->vneigh); free(st->vseed);
     if (st->amr) { for (int g = 0; g < st->n_amr_grids; g++) { free(st->amr[g].go); for (int a = 0; a < 3; a++) free(st->amr[g].w[a]); } free(st->amr); }
-    free(st->amr_cell_grid); free(st->mask_map);
+    free(st->amr_cell_grid); free(st->mask_map); free(st->alpha_inv_planck); free(st->diff_coeff);
     if (st->dust) { for (int d = 0; d < st->n_dust; d++) dust_free(&st->dust[d]); free(st->dust); }
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) {
@@ -1984,6 +2010,151 @@ static void interact(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
     angle_to_vector(&p->a, p->v);
 }
 
+static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g, acc_t *acc, int polychromatic);
+
+/* ------------------------------------------------------------------ */
+/* Modified random walk: grid_mrw_3d.f90 (Min et al. 2009)              */
+/* ------------------------------------------------------------------ */
+
+/* initialize_cumulative :157-195 */
+static void mrw_initialize_cumulative(orc_state *st)
+{
+    const int n = 100;
+    for (int i = 0; i < n; i++) {
+        st->mrw_x[i] = (double)i / (double)(n - 1);
+        double y = 0.0;
+        if (i == n - 1) y = 0.5;
+        else {
+            for (long long j = 1;; j++) {
+                double term = pow(st->mrw_x[i], (double)(j * j));
+                if (term == 0.0) break;
+                if (j % 2 == 0) y -= term; else y += term;
+            }
+        }
+        st->mrw_y[i] = y * 2.0;
+    }
+}
+
+/* prepare_mrw :29-53 + update_alpha_inv_planck grid_physics_3d.f90:397-418 */
+static int prepare_mrw(orc_state *st)
+{
+    if (st->grid_type == GRID_VOR) { snprintf(st->err, sizeof st->err, "distance_to_closest_wall: not implemented for Voronoi grid"); return 1; }
+    for (int d = 0; d < st->n_dust; d++)
+        if (!st->dust[d].mo_kappa_planck || !st->dust[d].mo_chi_inv_planck || !st->dust[d].b_nu) {
+            snprintf(st->err, sizeof st->err, "MRW needs the kappa_planck and chi_inv_planck mean opacities of every dust type"); return 1;
+        }
+    if (!st->alpha_inv_planck) {
+        st->alpha_inv_planck = malloc(sizeof(double) * st->n_cells);
+        st->diff_coeff = malloc(sizeof(double) * st->n_cells);
+        mrw_initialize_cumulative(st);
+    }
+    for (size_t ic = 0; ic < st->n_cells; ic++) {
+        double a = 0.0, tot = 0.0;
+        for (int d = 0; d < st->n_dust; d++) {
+            const dust_t *du = &st->dust[d];
+            size_t k = (size_t)d * st->n_cells + ic;
+            double c = interp1d_loglog(du->mo_e, du->mo_chi_inv_planck, du->n_e, st->specific_energy[k]);
+            if (st->density[k] > 0.0) a += st->density[k] * c;
+            tot += st->density[k] * c;
+        }
+        st->alpha_inv_planck[ic] = a;
+        st->diff_coeff[ic] = 1.0 / 3.0 / tot;
+    }
+    return 0;
+}
+
+/* distance_to_closest_wall: cartesian_3d.f90:396-430, octree.f90:410-437, amr.f90:743-773 */
+static double distance_to_closest_wall(const orc_state *st, const photon_t *p)
+{
+    double lo[3], hi[3];
+    if (st->grid_type == GRID_CAR) {
+        for (int a = 0; a < 3; a++) { lo[a] = st->w[a][p->ic[a]]; hi[a] = st->w[a][p->ic[a] + 1]; }
+    } else if (st->grid_type == GRID_OCT) {
+        int32_t id = p->ic[0];
+        const double c[3] = {st->ox[id], st->oy[id], st->oz[id]}, h[3] = {st->odx[id], st->ody[id], st->odz[id]};
+        double d = DBL_MAX;
+        for (int a = 0; a < 3; a++) {
+            double d1 = p->r[a] - c[a] + h[a], d2 = c[a] + h[a] - p->r[a];
+            if (d1 < d) d = d1;
+            if (d2 < d) d = d2;
+        }
+        return d < 0.0 ? 0.0 : d;
+    } else {
+        const amr_grid *g; int ci[3];
+        amr_cell_coords(st, (size_t)p->ic[0], &g, ci);
+        for (int a = 0; a < 3; a++) { lo[a] = g->w[a][ci[a]]; hi[a] = g->w[a][ci[a] + 1]; }
+    }
+    double d = DBL_MAX;
+    for (int a = 0; a < 3; a++) {
+        double d1 = p->r[a] - lo[a], d2 = hi[a] - p->r[a];
+        if (d1 < d) d = d1;
+        if (d2 < d) d = d2;
+    }
+    return d < 0.0 ? 0.0 : d;
+}
+
+/* grid_do_mrw :55-107 (deposit != NULL) and grid_do_mrw_noenergy :109-148 */
+static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *deposit)
+{
+    size_t ic = cell_index(st, p->ic);
+    double R0 = distance_to_closest_wall(st, p);
+    if (deposit) {
+        /* sample_cumulative :197-202: interp1d(ycdf, xcdf, xi) */
+        double xi = rng_uniform(g);
+        int j = locate(st->mrw_y, 100, xi);
+        double y = (j < 0) ? NAN : st->mrw_x[j] + (xi - st->mrw_y[j]) / (st->mrw_y[j + 1] - st->mrw_y[j]) * (st->mrw_x[j + 1] - st->mrw_x[j]);
+        double ct = -log(y) / st->diff_coeff[ic] * pow(R0 / PI, 2.0);
+        for (int d = 0; d < st->n_dust; d++) {
+            size_t k = (size_t)d * st->n_cells + ic;
+            if (st->density[k] > 0.0) {
+                const dust_t *du = &st->dust[d];
+                double e = p->energy * ct * interp1d_loglog(du->mo_e, du->mo_kappa_planck, du->n_e, st->specific_energy[k]);
+                deposit[k] += e;
+            }
+        }
+    }
+    /* random_sphere_vector3d + new position on the sphere of radius R0 */
+    angle_t ar; random_sphere_angle(g, &ar);
+    double dr[3]; angle_to_vector(&ar, dr);
+    for (int a = 0; a < 3; a++) p->r[a] = p->r[a] + dr[a] * R0;
+    p->a_prev = p->a; memcpy(p->v_prev, p->v, sizeof p->v); memcpy(p->s_prev, p->s, sizeof p->s);
+    random_sphere_angle(g, &p->a);
+    angle_to_vector(&p->a, p->v);
+    int id = 0;
+    if (st->n_dust > 1) {      /* select_dust_chi_rho: grid_physics_3d.f90:87-99 */
+        double cdf[ORC_MAX_DUST], c = 0.0;
+        for (int d = 0; d < st->n_dust; d++) { c += p->chi[d] * st->density[(size_t)d * st->n_cells + ic]; cdf[d] = c; }
+        for (int d = 0; d < st->n_dust; d++) cdf[d] /= c;
+        id = sample_discrete(cdf, st->n_dust, rng_uniform(g));
+    }
+    {   /* dust_sample_b_nu :400-419 */
+        const dust_t *du = &st->dust[id];
+        size_t k = (size_t)id * st->n_cells + ic;
+        double xi = rng_uniform(g);
+        double nu1 = pdf_sample_log(&du->b_nu[st->jnu_var_id[k]], xi), nu2 = pdf_sample_log(&du->b_nu[st->jnu_var_id[k] + 1], xi);
+        p->nu = pow(10.0, log10(nu1) + st->jnu_var_frac[k] * (log10(nu2) - log10(nu1)));
+    }
+    /* the opacities of the packet are NOT refreshed here (the reference calls update_optconsts only
+     * in emit and interact): the next grid_integrate runs with those of the previous frequency */
+    p->last_isotropic = 1; p->dust_id = id; p->last = LAST_DE;
+    p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
+}
+
+/* the loop of iter_lucy.f90:133-152 / iter_final.f90:165-183; returns 1 if the packet was killed */
+static int mrw_steps(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, double *deposit, int peel)
+{
+    int64_t k;
+    for (k = 1; k <= st->cfg.n_inter_mrw_max; k++) {
+        size_t ic = cell_index(st, p->ic);
+        if (st->alpha_inv_planck[ic] * distance_to_closest_wall(st, p) > st->cfg.mrw_gamma) {
+            grid_do_mrw(st, p, g, deposit);
+            if (peel) peeloff_photon(st, p, g, acc, 0);
+        } else break;
+    }
+    if (k == st->cfg.n_inter_mrw_max + 1) { acc->killed_int++; p->killed = 1; return 1; }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* do_lucy: iter_lucy.f90:66-237                                        */
 /* ------------------------------------------------------------------ */
@@ -1994,6 +2165,7 @@ static void lucy_packet(const orc_state *st, uint64_t id, int iter, acc_t *acc)
     rng_init(&g, st->cfg.seed, (uint32_t)iter, id);
     if (emit(st, &p, &g, acc)) return;
     for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
+        if (st->cfg.mrw && inter > 1 && mrw_steps(st, &p, &g, acc, acc->sum, 0)) break;
         double tau = rng_exp(&g);
         grid_integrate(st, &p, tau, &g, acc, acc->sum);
         if (p.reabsorbed) {     /* iter_lucy.f90:155-185: re-emit from the absorbing source until the packet gets away */
@@ -2035,6 +2207,7 @@ int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int 
     if (nt < 1) nt = 1;
     memset(st->specific_energy_sum, 0, sizeof(double) * ntot);   /* grid_reset_energy */
     precompute_jnu_var(st);                                      /* iter_lucy.f90:107 */
+    if (st->cfg.mrw && prepare_mrw(st)) return 1;                /* iter_lucy.f90:109-112 */
     acc_t *accs = calloc(nt, sizeof(acc_t));
     for (int t = 0; t < nt; t++) accs[t].sum = (t == 0) ? st->specific_energy_sum : calloc(ntot ? ntot : 1, sizeof(double));
 #ifdef _OPENMP
@@ -2506,6 +2679,7 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
     if (st->n_peeled && !scattering_only) peeloff_photon(st, &p, &g, acc, 0);
     for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
         double tau;
+        if (st->cfg.mrw && inter > 1 && mrw_steps(st, &p, &g, acc, NULL, st->n_peeled && !scattering_only)) break;
         if (inter == 1 && st->cfg.forced_first_interaction) {
             int killed = 0;
             double tau_escape = grid_escape_tau(st, &p, DBL_MAX, &g, acc, &killed);
@@ -2620,6 +2794,7 @@ static void final_packet_fn(const orc_state *st, uint64_t id, acc_t *acc, const 
 int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
 {
     precompute_jnu_var(st); /* iter_final.f90:99 */
+    if (st->cfg.mrw && prepare_mrw(st)) return 1;   /* iter_final.f90:93-96 */
     orc_iter_stats tot;
     if (image_run(st, n_packets, n_threads, g_final_first_id, final_packet_fn, NULL, 1, &tot)) return 1;
     /* peeled_images_adjust_scale(energy_total/energy_current): image_type.f90:136-151 */

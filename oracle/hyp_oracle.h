@@ -57,6 +57,8 @@ typedef struct orc_dust_desc {
     const double *emiss_var;    /* [n_jnu] specific energies */
     const double *mo_specific_energy; /* [n_e] or NULL */
     const double *mo_chi_rosseland;   /* [n_e] or NULL (sublimation mode 2) */
+    const double *mo_kappa_planck;    /* [n_e] or NULL; needed with config.mrw (src/dust/dust.f90:88-93) */
+    const double *mo_chi_inv_planck;  /* [n_e] or NULL; column chi_inv_planck (chi_rosseland in version-1 files, dust_type_4elem.f90:231-237) */
 } orc_dust_desc;
 
 /* One source (reader: src/sources/source_type.f90:102-322). */
@@ -122,6 +124,11 @@ typedef struct orc_config {
     int32_t raytracing;              /* root attribute `raytracing`: peel only scattered packets in the final iteration */
     double  baes16_xi;
     double  propagation_check_frequency;
+    /* modified random walk (src/grid/grid_mrw_3d.f90, src/main/setup_rt.f90:106-113) */
+    int64_t n_inter_mrw_max;
+    double  mrw_gamma;
+    int32_t mrw;
+    int32_t reserved1;
 } orc_config;
 
 /* One peeled image group (reader: src/images/images_peeled.f90:272-380,

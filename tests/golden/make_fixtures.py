@@ -263,7 +263,30 @@ ONLY = [a for a in sys.argv[1:] if a in ("car", "oct", "amr")]      # restrict t
 RAY_ONLY = "ray" in sys.argv[1:]                                      # only the raytracing=True peel-off fixtures
 
 
+def mrw_fixture():
+    """realistic_dust.npz: get_realistic_test_dust() of hyperion/model/tests/test_helpers.py:21-30,
+    the dust of the MRW known-answer table (test_mrw.py:10-31), as written by SphericalDust.write()."""
+    nu = [3.e7, 1.e10, 2.e11, 2.e12, 2.e13, 2.e14, 2.e15, 2.e16, 2.e17]
+    chi = [1.e-11, 2.e-6, 2.e-3, 0.2, 13., 90., 1000., 700., 700.]
+    albedo = [0., 0., 0., 0., 0.1, 0.5, 0.4, 0.4, 0.4]
+    dust = IsotropicDust(nu, albedo, chi)
+    dust.set_lte_emissivities(n_temp=40, temp_min=0.1, temp_max=100000.)
+    with tempfile.TemporaryDirectory() as tmp:
+        dpath = os.path.join(tmp, "realistic_dust.hdf5")
+        dust.write(dpath)
+        with h5py.File(dpath, "r") as f:
+            d = read_dust_group(f)
+    arrays = {k: v for k, v in d.__dict__.items() if isinstance(v, np.ndarray)}
+    arrays["version"] = np.int64(d.version)
+    out = os.path.join(HERE, "realistic_dust.npz")
+    np.savez_compressed(out, **arrays)
+    print("wrote", out, os.path.getsize(out))
+
+
 def main():
+    if "mrw" in sys.argv[1:]:
+        mrw_fixture()
+        return
     grids, denss = car_grid_and_densities()
     with tempfile.TemporaryDirectory() as tmp:
         for gt in [g for g in ("car", "oct", "amr") if not ONLY or g in ONLY]:
