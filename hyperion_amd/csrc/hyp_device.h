@@ -38,6 +38,9 @@ struct DDust {
     const double *jnu_var, *log10_jnu_var;   // [n_jnu]
     const double *mo_e, *mo_chi_ross;        // [n_e] (sublimation mode 2) or null
     int n_e, pad1;
+    // modified random walk (grid_mrw_3d.f90): Planck mean opacities and the b_nu = j_nu / kappa_nu pdfs
+    const double *mo_kappa_planck, *mo_chi_inv_planck;   // [n_e] or null
+    const double *bnu_cdf, *bnu_bp1, *bnu_coarse;         // same layout as emiss_cdf / emiss_bp1 / emiss_coarse
 };
 
 struct DSource {
@@ -133,6 +136,13 @@ struct DProblem {
     int peel_scattered_only;              // final iteration peels only scattered packets (raytracing on)
     int any_intersect;                    // a source can re-absorb packets (spheres): source.f90:216
     long long n_reabs_max;
+    // modified random walk: per-iteration tables of mrw_prepare_kernel and the cumulative of Min et al. (2009) eq. 6
+    int mrw, pad5;
+    long long n_inter_mrw_max;
+    double mrw_gamma;
+    const double *mrw_alpha, *mrw_diff;   // [n_cells] alpha_inv_planck, diff_coeff
+    const double *mrw_kp;                 // [n_cells][n_dust] kappa_planck(specific_energy)
+    const double *mrw_x, *mrw_y;          // [100]
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

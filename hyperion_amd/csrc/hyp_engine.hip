@@ -74,6 +74,20 @@ double interp_seg_loglog(double x1, double x2, double y1, double y2, double x)
     return y1 + (x - x1) / (x2 - x1) * (y2 - y1);
 }
 
+// interp1d_loglog of fortranlib at one abscissa inside [x[0], x[n-1]] (NaN outside)
+double interp1d_loglog_host(const double *x, const double *y, int n, double xv)
+{
+    if (!(xv >= x[0] && xv <= x[n - 1])) return std::nan("");
+    int j = (int)(std::upper_bound(x, x + n, xv) - x) - 1;
+    if (j > n - 2) j = n - 2;
+    const double y1 = y[j], y2 = y[j + 1];
+    if (y1 > 0.0 && y2 > 0.0) {
+        const double f = (std::log10(xv) - std::log10(x[j])) / (std::log10(x[j + 1]) - std::log10(x[j]));
+        return std::pow(10.0, std::log10(y1) + f * (std::log10(y2) - std::log10(y1)));
+    }
+    return y1 + (xv - x[j]) / (x[j + 1] - x[j]) * (y2 - y1);
+}
+
 double integral_loglog_range(const double *x, const double *y, size_t stride, int n, double xmin, double xmax)
 {
     if (xmin < x[0]) xmin = x[0];
@@ -119,7 +133,8 @@ double spacing(double x)
 struct DustOffsets {
     size_t nu, log10_nu, chi, albedo, log10_chi, log10_albedo, mu, P1, P2, P3, P4, P1_cdf, P2_cdf;
     size_t emiss_x, emiss_cdf, emiss_bp1, emiss_coarse, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
-    bool have_mo_e, have_mo_chi;
+    size_t mo_kappa_planck, mo_chi_inv_planck, bnu_cdf, bnu_bp1, bnu_coarse;
+    bool have_mo_e, have_mo_chi, have_mrw;
 };
 
 struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; };
@@ -153,6 +168,7 @@ struct hyp_engine {
     int *d_jnu_id = nullptr;
     double *d_jnu_frac = nullptr;
     double *d_energy_abs_tot = nullptr;
+    double *d_mrw_alpha = nullptr, *d_mrw_diff = nullptr, *d_mrw_kp = nullptr;   // per-iteration MRW tables
     double *d_scratch = nullptr;        // [n_dust*n_cells] layout conversions
     unsigned long long *d_counter = nullptr;
     int *d_err = nullptr;
@@ -475,6 +491,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
+    free_dev(h->d_mrw_alpha); free_dev(h->d_mrw_diff); free_dev(h->d_mrw_kp);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
     free_dev(h->d_img_accum);
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
@@ -493,6 +510,7 @@ void hyp_destroy(hyp_handle h)
 static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref);
 static int sync_problem(hyp_handle h);
 static int check_device_error(hyp_handle h);
+static int mrw_prepare(hyp_handle h);
 
 int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 {
@@ -864,6 +882,47 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         }
         if (O.have_mo_chi) O.mo_chi_ross = B.put(in.mo_chi_rosseland, in.n_e);
         if (in.sublimation_mode == 2 && !O.have_mo_chi) FAIL("slow sublimation needs the Rosseland mean opacity table");
+        // modified random walk: Planck means + b_nu = j_nu / kappa_nu pdfs (dust_type_4elem.f90:289-291)
+        O.have_mrw = false;
+        if (pr->config.mrw) {
+            if (!(O.have_mo_e && in.mo_kappa_planck && in.mo_chi_inv_planck))
+                FAIL("MRW needs the kappa_planck and chi_inv_planck mean opacities of every dust type");
+            O.mo_kappa_planck = B.put(in.mo_kappa_planck, in.n_e);
+            O.mo_chi_inv_planck = B.put(in.mo_chi_inv_planck, in.n_e);
+            std::vector<double> kap(nn), y(in.n_enu), bcdf_all, bbp1_all;
+            for (int k = 0; k < nn; k++) kap[k] = in.chi[k] * (1.0 - in.albedo[k]);
+            for (int i = 0; i < in.n_jnu; i++) {
+                for (int k = 0; k < in.n_enu; k++)
+                    y[k] = in.emiss_jnu[(size_t)k * in.n_jnu + i] / interp1d_loglog_host(in.nu, kap.data(), nn, in.emiss_nu[k]);
+                if (!build_log_pdf(in.emiss_nu, y.data(), in.n_enu, 1, cdf, bp1)) FAIL("emissivity / kappa_nu has zero integral");
+                bcdf_all.insert(bcdf_all.end(), cdf.begin(), cdf.end());
+                bbp1_all.insert(bbp1_all.end(), bp1.begin(), bp1.end());
+            }
+            O.bnu_cdf = B.put(bcdf_all); O.bnu_bp1 = B.put(bbp1_all);
+            const int nc = (in.n_enu + HYP_COARSE - 1) / HYP_COARSE;
+            std::vector<double> coarse((size_t)in.n_jnu * nc);
+            for (int i = 0; i < in.n_jnu; i++)
+                for (int m = 0; m < nc; m++) coarse[(size_t)i * nc + m] = bcdf_all[(size_t)i * in.n_enu + (size_t)m * HYP_COARSE];
+            O.bnu_coarse = B.put(coarse);
+            O.have_mrw = true;
+        }
+    }
+    // cumulative of Min et al. (2009) eq. 6 on 100 points: grid_mrw_3d.f90:157-195
+    size_t mrw_x_off = 0, mrw_y_off = 0;
+    if (pr->config.mrw) {
+        std::vector<double> mx(100), my(100);
+        for (int i = 0; i < 100; i++) {
+            mx[i] = (double)i / 99.0;
+            double y = 0.0;
+            if (i == 99) y = 0.5;
+            else for (long long j = 1;; j++) {
+                const double term = std::pow(mx[i], (double)(j * j));
+                if (term == 0.0) break;
+                if (j % 2 == 0) y -= term; else y += term;
+            }
+            my[i] = y * 2.0;
+        }
+        mrw_x_off = B.put(mx); mrw_y_off = B.put(my);
     }
 
     // sources: source.f90:47-84, source_type.f90:102-322
@@ -1098,7 +1157,14 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         D.jnu_var = db + O.jnu_var; D.log10_jnu_var = db + O.log10_jnu_var;
         D.mo_e = O.have_mo_e ? db + O.mo_e : nullptr;
         D.mo_chi_ross = O.have_mo_chi ? db + O.mo_chi_ross : nullptr;
+        D.mo_kappa_planck = O.have_mrw ? db + O.mo_kappa_planck : nullptr;
+        D.mo_chi_inv_planck = O.have_mrw ? db + O.mo_chi_inv_planck : nullptr;
+        D.bnu_cdf = O.have_mrw ? db + O.bnu_cdf : nullptr; D.bnu_bp1 = O.have_mrw ? db + O.bnu_bp1 : nullptr;
+        D.bnu_coarse = O.have_mrw ? db + O.bnu_coarse : nullptr;
     }
+    P.mrw = pr->config.mrw ? 1 : 0; P.pad5 = 0;
+    P.n_inter_mrw_max = pr->config.n_inter_mrw_max; P.mrw_gamma = pr->config.mrw_gamma;
+    P.mrw_x = P.mrw ? db + mrw_x_off : nullptr; P.mrw_y = P.mrw ? db + mrw_y_off : nullptr;
     for (int i = 0; i < pr->n_sources; i++)
         if (soff[i].have) { hs[i].spec_x = db + soff[i].x; hs[i].spec_cdf = db + soff[i].cdf; hs[i].spec_bp1 = db + soff[i].bp1; }
     for (int i = 0; i < pr->n_sources; i++)
@@ -1257,6 +1323,28 @@ static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out
     return 0;
 }
 
+// prepare_mrw + update_alpha_inv_planck at the start of an iteration (iter_lucy.f90:109-112,
+// iter_final.f90:93-96); must run before sync_problem (it sets table pointers of the problem)
+static int mrw_prepare(hyp_handle h)
+{
+    DProblem &P = h->hp;
+    if (!P.mrw) return 0;
+    if (P.grid_type == 3) return h->set_error("distance_to_closest_wall: not implemented for Voronoi grid");
+    if (!h->d_mrw_alpha) {
+        if (hipMalloc(&h->d_mrw_alpha, sizeof(double) * h->n_cells) != hipSuccess ||
+            hipMalloc(&h->d_mrw_diff, sizeof(double) * h->n_cells) != hipSuccess ||
+            hipMalloc(&h->d_mrw_kp, sizeof(double) * h->n_elem) != hipSuccess)
+            return h->set_error("cannot allocate the MRW tables");
+    }
+    P.mrw_alpha = h->d_mrw_alpha; P.mrw_diff = h->d_mrw_diff; P.mrw_kp = h->d_mrw_kp;     // reach the device with the caller's sync_problem
+    unsigned blocks = (unsigned)std::min<size_t>((h->n_cells + 255) / 256, 65535);
+    mrw_prepare_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, h->d_specific_energy, h->d_density,
+                                                      h->d_mrw_alpha, h->d_mrw_diff, h->d_mrw_kp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return h->set_error(std::string("mrw_prepare_kernel launch: ") + hipGetErrorString(e));
+    return 0;
+}
+
 static int check_device_error(hyp_handle h)
 {
     int code = 0;
@@ -1301,6 +1389,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         h->d_accum = nb; h->accum_copies_alloc = copies;
     }
     P.sum = h->d_accum; P.tail = h->d_accum + h->n_elem; P.n_copies = copies; P.copy_stride = h->accum_stride;
+    if (mrw_prepare(h)) return 1;
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(accum): ") + hipGetErrorString(e));
@@ -1523,6 +1612,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         tail = h->d_accum + h->n_elem;
     }
     P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
+    if (mrw_prepare(h)) return 1;
     if (sync_problem(h)) return 1;
     unsigned long long first = first_id;
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);

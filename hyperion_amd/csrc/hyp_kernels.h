@@ -13,7 +13,7 @@
 
 #include "hyp_device.h"
 
-enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5 };
+enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5, ST_MRW = 6 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
 enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2, GEOM_AMR = 3 };
@@ -895,6 +895,121 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p
     return true;
 }
 
+// ---------------------------------------------------------------------------
+// Modified random walk (grid_mrw_3d.f90; Min et al. 2009)
+// ---------------------------------------------------------------------------
+
+// distance_to_closest_wall: grid_geometry_cartesian_3d.f90:396-422, _octree.f90:410-437, _amr.f90:743-773
+__device__ __forceinline__ double geo_closest_wall(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_CAR> &c)
+{
+    double d = HYP_DBL_MAX;
+#pragma unroll
+    for (int a = 0; a < 3; a++) d = fmin(d, fmin(r[a] - W.w[a][c.ic[a]], W.w[a][c.ic[a] + 1] - r[a]));
+    return d < 0.0 ? 0.0 : d;
+}
+__device__ __forceinline__ double geo_closest_wall(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_OCT> &c)
+{
+    double d = HYP_DBL_MAX;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double h = ldexp(P.oct_half[a], -c.level);
+        d = fmin(d, fmin(r[a] - c.c[a] + h, c.c[a] + h - r[a]));
+    }
+    return d < 0.0 ? 0.0 : d;
+}
+__device__ __forceinline__ double geo_closest_wall(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_VOR> &c)
+{
+    return 0.0;     // not defined for Voronoi grids: the engine refuses the combination
+}
+__device__ __forceinline__ double geo_closest_wall(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_AMR> &c)
+{
+    const AmrGrid &g = P.amr_grids[c.grid];
+    double d = HYP_DBL_MAX;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        d = fmin(d, fmin(r[a] - P.amr_walls[g.w_off[a] + c.i[a]], P.amr_walls[g.w_off[a] + c.i[a] + 1] - r[a]));
+    return d < 0.0 ? 0.0 : d;
+}
+
+// tau_inv_planck_to_closest_wall(p) > mrw_gamma: grid_physics_3d.f90:81-85
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool mrw_wanted(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p)
+{
+    return P.mrw_alpha[geo_index(P, p.cell)] * geo_closest_wall(P, W, p.r, p.cell) > P.mrw_gamma;
+}
+
+// dust_sample_b_nu: dust_type_4elem.f90:400-419
+__device__ __forceinline__ double dust_sample_b_nu(const DDust &D, int jid, double frac, double xi)
+{
+    const size_t o = (size_t)jid * D.n_enu;
+    const size_t oc = (size_t)jid * D.n_ecoarse;
+    double nu1, nu2;
+    sample_log_pdf_pair(D.emiss_x, D.bnu_cdf + o, D.bnu_cdf + o + D.n_enu, D.bnu_bp1 + o, D.bnu_bp1 + o + D.n_enu,
+                        D.bnu_coarse + oc, D.bnu_coarse + oc + D.n_ecoarse, D.n_enu, D.n_ecoarse, xi, nu1, nu2);
+    double l1 = log10(nu1);
+    return exp10(l1 + frac * (log10(nu2) - l1));
+}
+
+// grid_do_mrw :55-107 (DEPOSIT) / grid_do_mrw_noenergy :109-148.  The packet's opacities are
+// deliberately left at those of the previous frequency: the reference refreshes them only in
+// emit and interact.  Returns the dust species the new frequency was drawn from.
+template <int NDT, int GEOM, bool DEPOSIT>
+__device__ __forceinline__ int mrw_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, double *__restrict__ sum)
+{
+    const int nd = ndust<NDT>(P);
+    const size_t ic = geo_index(P, p.cell);
+    const size_t base = ic * (size_t)nd;
+    const double R0 = geo_closest_wall(P, W, p.r, p.cell);
+    if (DEPOSIT) {
+        // sample_cumulative :197-202: interp1d(ycdf, xcdf, xi)
+        const double xi = rng_uniform(g);
+        const int j = locate(P.mrw_y, 100, xi);
+        const double y = (j < 0) ? __builtin_nan("")
+                                 : P.mrw_x[j] + (xi - P.mrw_y[j]) / (P.mrw_y[j + 1] - P.mrw_y[j]) * (P.mrw_x[j + 1] - P.mrw_x[j]);
+        const double q = R0 / HYP_PI;
+        const double ct = -log(y) / P.mrw_diff[ic] * (q * q);
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+            if (d < nd && P.density[base + d] > 0.0) unsafeAtomicAdd(&sum[base + d], p.energy * ct * P.mrw_kp[base + d]);
+    }
+    Angle ar;
+    random_sphere_angle(g, ar);
+    double dx, dy, dz;
+    angle_to_vector(ar, dx, dy, dz);
+    p.r[0] = p.r[0] + dx * R0; p.r[1] = p.r[1] + dy * R0; p.r[2] = p.r[2] + dz * R0;
+    random_sphere_angle(g, p.a);
+    angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    int id = 0;
+    if (NDT > 1 && nd > 1) {       // select_dust_chi_rho: grid_physics_3d.f90:87-99
+        double cdf[NDT], c = 0.0;
+#pragma unroll
+        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * P.density[base + d]; cdf[d] = c; }
+        const double xi = rng_uniform(g);
+        id = nd - 1;
+        bool found = false;
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+            if (d < nd && !found && d < nd - 1 && xi < cdf[d] / c) { id = d; found = true; }
+    }
+    p.nu = dust_sample_b_nu(P.dust[id], P.jnu_id[base + id], P.jnu_frac[base + id], rng_uniform(g));
+    return id;
+}
+
+// the loop of iter_lucy.f90:138-152; true = the packet was killed (n_inter_mrw_max steps without leaving the regime)
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool mrw_loop_lucy(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, double *__restrict__ sum,
+                                              Counters &cnt)
+{
+    long long k;
+#pragma unroll 1
+    for (k = 1; k <= P.n_inter_mrw_max; k++) {
+        if (!mrw_wanted(P, W, p)) break;
+        mrw_step<NDT, GEOM, true>(P, W, p, g, sum);
+    }
+    if (k == P.n_inter_mrw_max + 1) { cnt.killed_int++; return true; }
+    return false;
+}
+
 // wave-level sum of a double (64 lanes)
 __device__ __forceinline__ double wave_sum(double x)
 {
@@ -1045,6 +1160,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id);
                     bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                     if (killed) st = ST_NEED_EMIT;
+                    else if (P.mrw && mrw_loop_lucy<NDT, GEOM>(P, W, p, g, sum, cnt)) st = ST_NEED_EMIT;    // iter_lucy.f90:138-152
                     else {
                         p.inter++;
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -1634,13 +1750,15 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     rng_init(g, P.seed_key, L.iter_tag, 0);
     p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
     p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+    long long mrw_k = 1;       // MRW steps of the current interaction (state ST_MRW)
 
     for (;;) {
         unsigned long long m_walk = __ballot(st == ST_WALK);
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
         unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
-        if (!(m_walk | m_int | m_emit | m_re)) break;
+        const unsigned long long m_mrw = P.mrw ? __ballot(st == ST_MRW) : 0ull;
+        if (!(m_walk | m_int | m_emit | m_re | m_mrw)) break;
 
         // peel: 0 none, 1 after emission, 2 after interaction, 3 after re-emission by a source
         int peel = 0;
@@ -1661,6 +1779,27 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else { peel = 3; last = LAST_SR; st = ST_PLACED; last_iso = false; a_prev = src_normal; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_int = __ballot(st == ST_NEED_INTERACT);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
+        // ---- modified random walk, one step per pass, each peeled off as isotropic emission:
+        //      iter_final.f90:165-183 ----
+        if (m_mrw) {
+            if (st == ST_MRW) {
+                if (mrw_k == P.n_inter_mrw_max + 1) { cnt.killed_int++; st = ST_NEED_EMIT; }
+                else if (mrw_wanted(P, W, p)) {
+                    a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
+                    f.dust_id = mrw_step<NDT, GEOM, false>(P, W, p, g, nullptr);
+                    mrw_k++;
+                    peel = 4; last = LAST_DE; last_iso = true;
+                } else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                 }
             }
             m_walk = __ballot(st == ST_WALK);
@@ -1721,7 +1860,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
             // with raytracing on only scattered packets are peeled here (iter_final.f90:120,268); direct
             // and thermal emission come from the raytracing iteration
             // (a re-emission by a source is peeled in any case: "a kind of scattering", :226-227)
-            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);
+            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);   // peel 4 (MRW): :171-173
             if (P.n_peeled > 0 && __ballot(do_peel)) peeloff<NDT, GEOM>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
             if (peel != 0) {
                 if (peel == 1) {
@@ -1745,6 +1884,10 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     }
                 } else if (peel == 3 && geo_escaped(P, p.cell)) {
                     st = ST_NEED_EMIT;
+                } else if (peel == 4) {
+                    // stays in ST_MRW: the next pass decides on another step
+                } else if (peel == 2 && P.mrw) {
+                    st = ST_MRW; mrw_k = 1;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
                     begin_integrate(P, p);
@@ -1835,6 +1978,45 @@ __device__ __forceinline__ double chi_rosseland(const DDust &D, double e)
         return exp10(log10(y1) + f * (log10(y2) - log10(y1)));
     }
     return y1 + (e - D.mo_e[j]) / (D.mo_e[j + 1] - D.mo_e[j]) * (y2 - y1);
+}
+
+// interp1d_loglog on a mean-opacity table (dust.f90:81-100)
+__device__ __forceinline__ double mean_opacity(const DDust &D, const double *__restrict__ y, double e)
+{
+    int j = locate(D.mo_e, D.n_e, e);
+    if (j < 0) return __builtin_nan("");
+    double y1 = y[j], y2 = y[j + 1];
+    if (y1 > 0.0 && y2 > 0.0) {
+        double f = (log10(e) - log10(D.mo_e[j])) / (log10(D.mo_e[j + 1]) - log10(D.mo_e[j]));
+        return exp10(log10(y1) + f * (log10(y2) - log10(y1)));
+    }
+    return y1 + (e - D.mo_e[j]) / (D.mo_e[j + 1] - D.mo_e[j]) * (y2 - y1);
+}
+
+// prepare_mrw (grid_mrw_3d.f90:29-53) + update_alpha_inv_planck (grid_physics_3d.f90:397-418),
+// plus kappa_planck(specific_energy) of every (cell, dust) for the deposits of grid_do_mrw.
+// One thread per cell.
+__global__ void mrw_prepare_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ specific_energy,
+                                   const double *__restrict__ density, double *__restrict__ alpha, double *__restrict__ diff,
+                                   double *__restrict__ kp)
+{
+    const DProblem &P = *Pp;
+    const int nd = P.n_dust;
+    size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t ic = (size_t)blockIdx.x * blockDim.x + threadIdx.x; ic < (size_t)P.n_cells; ic += step) {
+        double a = 0.0, tot = 0.0;
+        for (int d = 0; d < nd; d++) {
+            const DDust &D = P.dust[d];
+            const size_t k = ic * nd + d;
+            const double e = specific_energy[k], rho = density[k];
+            const double c = mean_opacity(D, D.mo_chi_inv_planck, e);
+            if (rho > 0.0) a += rho * c;
+            tot += rho * c;
+            kp[k] = mean_opacity(D, D.mo_kappa_planck, e);
+        }
+        alpha[ic] = a;
+        diff[ic] = 1.0 / 3.0 / tot;
+    }
 }
 
 // update_energy_abs + check_energy_abs + sublimate_dust + update_energy_abs_tot

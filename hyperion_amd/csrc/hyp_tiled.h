@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
                 bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
                 bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                 if (killed) { state = TS_DEAD; finished++; }
+                else if (P.mrw && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
                 else {
                     p.inter++;
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                             bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
                             bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                             if (killed) { st = ST_DONE; finished++; }
+                            else if (P.mrw && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, sum, cnt)) { st = ST_DONE; finished++; }
                             else {
                                 p.inter++;
                                 p.tau_req = rng_exp(g); p.tau_ach = 0.0;

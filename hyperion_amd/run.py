@@ -111,7 +111,7 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
     """The iteration sequence of ``program main`` (src/main/main.f90:167-344)."""
     log = log or (lambda *a: None)
     cfg = problem.config
-    for flag, name in ((cfg.mrw, "MRW"), (cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode")):
+    for flag, name in ((cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode")):
         if flag:
             raise EngineError("%s is not supported by the MI355X engine yet" % name)
     date_started = _now()

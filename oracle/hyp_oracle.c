@@ -2103,7 +2103,8 @@ static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *depo
         double xi = rng_uniform(g);
         int j = locate(st->mrw_y, 100, xi);
         double y = (j < 0) ? NAN : st->mrw_x[j] + (xi - st->mrw_y[j]) / (st->mrw_y[j + 1] - st->mrw_y[j]) * (st->mrw_x[j + 1] - st->mrw_x[j]);
-        double ct = -log(y) / st->diff_coeff[ic] * pow(R0 / PI, 2.0);
+        double q = R0 / PI;
+        double ct = -log(y) / st->diff_coeff[ic] * (q * q);     /* (R0/pi)**2. */
         for (int d = 0; d < st->n_dust; d++) {
             size_t k = (size_t)d * st->n_cells + ic;
             if (st->density[k] > 0.0) {
@@ -2137,7 +2138,6 @@ static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *depo
     /* the opacities of the packet are NOT refreshed here (the reference calls update_optconsts only
      * in emit and interact): the next grid_integrate runs with those of the previous frequency */
     p->last_isotropic = 1; p->dust_id = id; p->last = LAST_DE;
-    p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
 }
 
 /* the loop of iter_lucy.f90:133-152 / iter_final.f90:165-183; returns 1 if the packet was killed */

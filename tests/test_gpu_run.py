@@ -89,8 +89,8 @@ def test_npz_round_trip_and_failure_convention(tmp_path):
     assert not os.path.exists(out)
     # unsupported modes are refused, not silently ignored
     p = make_benchmark_problem(8, n_photons=1000, n_iter=1)
-    p.config.mrw = True
-    with pytest.raises(hyperion_amd.EngineError, match="MRW is not supported"):
+    p.config.pda = True
+    with pytest.raises(hyperion_amd.EngineError, match="PDA is not supported"):
         run_problem(p)
 
 
