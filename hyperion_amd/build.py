@@ -10,9 +10,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libhyperion_amd.so")
-SOURCES = ["hyp_engine.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h"]
+SOURCES = ["hyp_engine.hip", "hyp_geom.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h", "hyp_pick.h"]
+# one translation unit per grid geometry (lucy / final / ray kernels x species counts) + the host side
+GEOMS = {"car": 0, "oct": 1, "vor": 2, "amr": 3}
 # -ffp-contract=off: the cell-walk arithmetic must round like the reference formulation (see find_wall)
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-fPIC"]
+OBJDIR = os.path.join(os.path.dirname(HERE), "build", "obj")
 
 
 def _hipcc():
@@ -31,15 +34,34 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_extension(force=False, verbose=False):
-    if not force and not is_stale():
-        return LIB
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["hyp_engine.hip", "-o", LIB + ".tmp"]
+def compile_units(out, extra_flags=(), objdir=OBJDIR, verbose=False):
+    """hipcc -c every translation unit in parallel, then link them into `out`."""
+    os.makedirs(objdir, exist_ok=True)
+    units = [("engine", "hyp_engine.hip", [])] + [("geom_" + g, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % k]) for g, k in GEOMS.items()]
+    procs = []
+    for name, src, defs in units:
+        obj = os.path.join(objdir, name + ".o")
+        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + defs + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+    objs = []
+    for cmd, obj, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def build_extension(force=False, verbose=False):
+    if not force and not is_stale():
+        return LIB
+    return compile_units(LIB, verbose=verbose)
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@
 #include "../../include/hyperion_amd.h"
 #include "hyp_kernels.h"
 #include "hyp_tiled.h"
+#include "hyp_pick.h"
 
 #include <array>
 #include <cfloat>
@@ -216,80 +217,43 @@ void free_dev(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 size_t lds_bytes(const DProblem &P) { return P.grid_type != 1 ? 0 : sizeof(double) * 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3); }
 
-using LucyKernel = void (*)(const DProblem *, LaunchParams);
-
-template <int GEOM>
-LucyKernel pick_lucy_kernel_g(int nd)
-{
-#ifdef HYP_ONLY_ND1   // tuning builds (tools/variants.py) instantiate one species only
-    (void)nd;
-    return lucy_kernel<1, GEOM>;
-#else
-    switch (nd) {
-    case 1: return lucy_kernel<1, GEOM>;
-    case 2: return lucy_kernel<2, GEOM>;
-    case 3: return lucy_kernel<3, GEOM>;
-    case 4: return lucy_kernel<4, GEOM>;
-    default: return lucy_kernel<HYP_MAXD, GEOM>;
-    }
-#endif
-}
-
-template <int GEOM>
-LucyKernel pick_final_kernel_g(int nd)
-{
-#ifdef HYP_ONLY_ND1
-    (void)nd;
-    return final_kernel<1, GEOM>;
-#else
-    switch (nd) {
-    case 1: return final_kernel<1, GEOM>;
-    case 2: return final_kernel<2, GEOM>;
-    case 3: return final_kernel<3, GEOM>;
-    case 4: return final_kernel<4, GEOM>;
-    default: return final_kernel<HYP_MAXD, GEOM>;
-    }
-#endif
-}
-
-typedef void (*RayKernel)(const DProblem *, LaunchParams, int, double);
-
-template <int GEOM>
-RayKernel pick_ray_kernel_g(int nd)
-{
-#ifdef HYP_ONLY_ND1
-    (void)nd;
-    return ray_kernel<1, GEOM>;
-#else
-    switch (nd) {
-    case 1: return ray_kernel<1, GEOM>;
-    case 2: return ray_kernel<2, GEOM>;
-    case 3: return ray_kernel<3, GEOM>;
-    case 4: return ray_kernel<4, GEOM>;
-    default: return ray_kernel<HYP_MAXD, GEOM>;
-    }
-#endif
-}
-
 RayKernel pick_ray_kernel(int nd, int grid_type)
 {
-    return grid_type == 4 ? pick_ray_kernel_g<GEOM_AMR>(nd)
-         : grid_type == 3 ? pick_ray_kernel_g<GEOM_VOR>(nd)
-         : grid_type == 2 ? pick_ray_kernel_g<GEOM_OCT>(nd) : pick_ray_kernel_g<GEOM_CAR>(nd);
+#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
+    return pick_ray_kernel_g<GEOM_CAR>(nd);
+#endif
+    switch (grid_type) {
+    case 2: return pick_ray_kernel_g<GEOM_OCT>(nd);
+    case 3: return pick_ray_kernel_g<GEOM_VOR>(nd);
+    case 4: return pick_ray_kernel_g<GEOM_AMR>(nd);
+    default: return pick_ray_kernel_g<GEOM_CAR>(nd);
+    }
 }
 
 LucyKernel pick_lucy_kernel(int nd, int grid_type)
 {
-    return grid_type == 4 ? pick_lucy_kernel_g<GEOM_AMR>(nd)
-         : grid_type == 3 ? pick_lucy_kernel_g<GEOM_VOR>(nd)
-         : grid_type == 2 ? pick_lucy_kernel_g<GEOM_OCT>(nd) : pick_lucy_kernel_g<GEOM_CAR>(nd);
+#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
+    return pick_lucy_kernel_g<GEOM_CAR>(nd);
+#endif
+    switch (grid_type) {
+    case 2: return pick_lucy_kernel_g<GEOM_OCT>(nd);
+    case 3: return pick_lucy_kernel_g<GEOM_VOR>(nd);
+    case 4: return pick_lucy_kernel_g<GEOM_AMR>(nd);
+    default: return pick_lucy_kernel_g<GEOM_CAR>(nd);
+    }
 }
 
 LucyKernel pick_final_kernel(int nd, int grid_type)
 {
-    return grid_type == 4 ? pick_final_kernel_g<GEOM_AMR>(nd)
-         : grid_type == 3 ? pick_final_kernel_g<GEOM_VOR>(nd)
-         : grid_type == 2 ? pick_final_kernel_g<GEOM_OCT>(nd) : pick_final_kernel_g<GEOM_CAR>(nd);
+#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
+    return pick_final_kernel_g<GEOM_CAR>(nd);
+#endif
+    switch (grid_type) {
+    case 2: return pick_final_kernel_g<GEOM_OCT>(nd);
+    case 3: return pick_final_kernel_g<GEOM_VOR>(nd);
+    case 4: return pick_final_kernel_g<GEOM_AMR>(nd);
+    default: return pick_final_kernel_g<GEOM_CAR>(nd);
+    }
 }
 
 }  // namespace
@@ -458,11 +422,18 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
     (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
     int rc;
+#ifdef HYP_ONLY_ND1
+    if (nd != 1) return h->set_error("tuning build: one dust species only");
+#endif
     switch (nd) {
     case 1: rc = run_tiled_generations<1>(h, T, n_local, n_pools); break;
+#ifndef HYP_ONLY_ND1
     case 2: rc = run_tiled_generations<2>(h, T, n_local, n_pools); break;
     case 3: rc = run_tiled_generations<3>(h, T, n_local, n_pools); break;
     default: rc = run_tiled_generations<4>(h, T, n_local, n_pools); break;
+#else
+    default: rc = 1; break;
+#endif
     }
     for (int pool = 1; pool < n_pools; pool++) {      // join the other pools into the engine's stream
         (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);

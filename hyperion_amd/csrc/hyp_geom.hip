@@ -1,0 +1,63 @@
+// hyp_geom.hip -- instantiates lucy_kernel / final_kernel / ray_kernel for ONE grid geometry
+// (-DHYP_GEOM_TU=GEOM_xxx; hyperion_amd/build.py compiles this file once per geometry, in
+// parallel, and links the objects with hyp_engine.hip into libhyperion_amd.so).
+#ifndef HYP_GEOM_TU
+#define HYP_GEOM_TU 0   // GEOM_CAR
+#endif
+#include "hyp_kernels.h"
+#include "hyp_pick.h"
+
+template <int GEOM>
+LucyKernel pick_lucy_kernel_g(int nd)
+{
+#ifdef HYP_ONLY_ND1   // tuning builds (tools/variants.py) instantiate one species only
+    (void)nd;
+    return lucy_kernel<1, GEOM>;
+#else
+    switch (nd) {
+    case 1: return lucy_kernel<1, GEOM>;
+    case 2: return lucy_kernel<2, GEOM>;
+    case 3: return lucy_kernel<3, GEOM>;
+    case 4: return lucy_kernel<4, GEOM>;
+    default: return lucy_kernel<HYP_MAXD, GEOM>;
+    }
+#endif
+}
+
+template <int GEOM>
+LucyKernel pick_final_kernel_g(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return final_kernel<1, GEOM>;
+#else
+    switch (nd) {
+    case 1: return final_kernel<1, GEOM>;
+    case 2: return final_kernel<2, GEOM>;
+    case 3: return final_kernel<3, GEOM>;
+    case 4: return final_kernel<4, GEOM>;
+    default: return final_kernel<HYP_MAXD, GEOM>;
+    }
+#endif
+}
+
+template <int GEOM>
+RayKernel pick_ray_kernel_g(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return ray_kernel<1, GEOM>;
+#else
+    switch (nd) {
+    case 1: return ray_kernel<1, GEOM>;
+    case 2: return ray_kernel<2, GEOM>;
+    case 3: return ray_kernel<3, GEOM>;
+    case 4: return ray_kernel<4, GEOM>;
+    default: return ray_kernel<HYP_MAXD, GEOM>;
+    }
+#endif
+}
+
+template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
+template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int);
+template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);

@@ -16,7 +16,12 @@
 enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5, ST_MRW = 6 };
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
-enum { GEOM_CAR = 0, GEOM_OCT = 1, GEOM_VOR = 2, GEOM_AMR = 3 };
+#define GEOM_CAR 0
+#define GEOM_OCT 1
+#define GEOM_VOR 2
+#define GEOM_AMR 3
+#define GEOM_SPH 4
+#define GEOM_CYL 5
 
 // Where a packet is: Cartesian = three cell indices; octree = cell id plus a
 // register copy of the leaf's record (centre, level, parent, sub-cell).
@@ -1916,6 +1921,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     }
 }
 
+#ifndef HYP_GEOM_TU   // the geometry-independent kernels are compiled once, in hyp_engine.hip
 // image_scale: image_type.f90:136-151 -- x *= scale over [0,n), x *= scale^2 over [n,2n)
 __global__ void image_scale_kernel(double *__restrict__ a, size_t n, double scale)
 {
@@ -2095,3 +2101,4 @@ __global__ void to_ref_layout_kernel(const double *__restrict__ in, double *__re
         out[(size_t)d * n_cells + ic] = in[k];
     }
 }
+#endif  // HYP_GEOM_TU

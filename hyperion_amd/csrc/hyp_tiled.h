@@ -517,7 +517,22 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int
 // sgn = +-1 or 0 (exact), so that the three IEEE divisions can be scheduled together and no
 // lane-divergent branch is left in the step.  Returns false when the precondition fails; the
 // caller then uses geo_find_wall.
-__device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const int iu[3], const double sgn[3],
+//
+// The three quotients d / v are formed with the reciprocals inv = RN(1 / v) that the lane
+// computed (with a true IEEE division) when it took the packet -- the direction is fixed during
+// a visit: q0 = RN(d inv), rem = d - q0 v (exact in one FMA), t = RN(q0 + rem inv).  By
+// Markstein's theorem (IBM J. Res. Dev. 34, 1990; Muller et al., Handbook of Floating-Point
+// Arithmetic, 2nd ed., Thm 4.8) t is then the correctly rounded quotient RN(d / v), i.e.
+// bit-for-bit the IEEE division of the reference formulation, for 3 instructions instead of
+// the ~14 of a division (div_scale x2, rcp, 8 FMA steps, div_fmas, div_fixup).  The theorem
+// needs no underflow/overflow in q0, rem and inv: the caller enables this path (v_ok) only when
+// every non-zero direction component is at least 2^-400 in magnitude, the distances d are
+// differences of wall and position coordinates (zero or >= one ulp of a coordinate), and an axis
+// with v = 0 is never a candidate, so its inf/NaN quotient is not looked at.
+// tools/ubench/markstein_check.c compares the sequence with the division on 4e8 operand pairs
+// including all-ones / near-power-of-two / short mantissas: no mismatch.
+__device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const double inv[3],
+                                                const int iu[3], const double sgn[3],
                                                 const Cell<GEOM_CAR> &c, double &tnear, int im[3], bool &found)
 {
     double tmin = HYP_DBL_MAX, emin = 0.0;
@@ -532,7 +547,12 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
         const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
         // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
         simple = simple & !((ow != -dir) & (db * sgn[a] > 0.0));
+#ifdef HYP_TILE_TRUE_DIV
         const double t = d / v[a];
+#else
+        const double q0 = d * inv[a];
+        const double t = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
+#endif
         const double emax = fmax(W.ew[a][ia], emin);
         const bool lt = cand & (t < tmin - emax);
         const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
@@ -600,7 +620,9 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     // lane state: the walking part of a packet (the rest stays in its ColdRec)
     double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
     double sgn[3];                            // sign of v per axis (+1, -1, 0) and iu = 1 where v > 0: fixed during a visit
+    double inv[3];                            // RN(1 / v) per axis, see find_wall_ahead
     int iu[3];
+    bool v_ok = true;                         // no direction component is so small that 1 / v or d / v could overflow
     double hit_t = 0.0, hit_tau = 0.0;       // LS_HIT: step length to the wall and optical depth of the cell
     double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
     int hit_lc = 0;
@@ -611,7 +633,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     int st = LS_IDLE;
     bool exhausted = false, pre = false;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; sgn[a] = 1.0; iu[a] = 1; }
+    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; inv[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; sgn[a] = 1.0; iu[a] = 1; }
 #pragma unroll
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
 
@@ -692,10 +714,13 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                 else {
                     slot = order[tk.start + j];
                     const HotRec<ND> &H = hot[slot];
+                    v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
                         r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a];
                         iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0);
+                        inv[a] = 1.0 / v[a];
+                        v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400);
                     }
                     unpack_ow(H.ow, cell.ow);
                     tau_req = H.tau_req; tau_ach = H.tau_ach; energy = H.energy;
@@ -723,7 +748,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                 // rare events wait for the service phase: they would cost every step of the wave
                 // their full code path for one or two lanes
                 double tmin; int im[3]; bool found;
-                bool simple = find_wall_ahead(W, r, v, iu, sgn, cell, tmin, im, found);
+                bool simple = find_wall_ahead(W, r, v, inv, iu, sgn, cell, tmin, im, found) && v_ok;
                 if (pre) {      // wall found by geo_find_wall in the service phase
                     tmin = hit_t; im[0] = (hit_lc & 3) - 1; im[1] = ((hit_lc >> 2) & 3) - 1; im[2] = ((hit_lc >> 4) & 3) - 1;
                     found = true; simple = true;

@@ -10,28 +10,37 @@ VDIR = os.path.join(ROOT, "build", "variants")
 
 
 def build(specs):
+    """Each variant: hyp_engine.hip (tiled kernels, one species) + the Cartesian geometry unit."""
     from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc
     os.makedirs(VDIR, exist_ok=True)
     procs = []
     for spec in specs:
         name, _, flags = spec.partition(":")
         out = os.path.join(VDIR, name + ".so")
-        cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + ["-DHYP_ONLY_ND1", "hyp_engine.hip", "-o", out,
-                                                          "-Rpass-analysis=kernel-resource-usage"]
-        procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
+        objs = []
+        for unit, src, defs in (("engine", "hyp_engine.hip", ["-DHYP_VARIANT_CAR_ONLY"]), ("car", "hyp_geom.hip", ["-DHYP_GEOM_TU=0"])):
+            obj = os.path.join(VDIR, "%s_%s.o" % (name, unit))
+            cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-DHYP_ONLY_ND1", "-c", src, "-o", obj,
+                                                                    "-Rpass-analysis=kernel-resource-usage"]
+            procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
+            objs.append(obj)
+        procs.append((name, [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out]))
+    pending_link = []
     for name, p in procs:
+        if isinstance(p, list):
+            pending_link.append((name, p))
+            continue
         err = p.communicate()[1]
-        info = [l.split("remark:")[1].strip() for l in err.split("\n")
-                if "remark:" in l and any(k in l for k in ("VGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
-        # keep only the lucy kernel block (first after its Function Name)
         blocks = err.split("Function Name: ")
         for b in blocks:
             if b.startswith(os.environ.get("KERNEL", "_Z11lucy_kernelILi1E")):
                 info = [l.split("remark:")[1].strip() for l in b.split("\n") if "remark:" in l and
                         any(k in l for k in (" VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
-        print(name, "rc", p.returncode, "|", "; ".join(info))
+                print(name, "|", "; ".join(info))
         if p.returncode:
-            print(err[-2000:])
+            print(name, "rc", p.returncode, err[-2000:])
+    for name, cmd in pending_link:
+        print(name, "link rc", subprocess.call(cmd, cwd=CSRC))
 
 
 def run_one(lib, photons, opts):
