@@ -119,9 +119,9 @@ class MarshalledProblem:
             return _ptr(a)
 
         d = ProblemDesc()
-        if prob.grid_type == "car":
+        if prob.grid_type in ("car", "sph_pol", "cyl_pol"):
             n1, n2, n3 = prob.shape
-            d.grid.type = 1
+            d.grid.type = {"car": 1, "sph_pol": 5, "cyl_pol": 6}[prob.grid_type]
             d.grid.n1, d.grid.n2, d.grid.n3 = n1, n2, n3
             d.grid.w1, d.grid.w2, d.grid.w3 = (arr(w) for w in prob.walls)
             d.grid.n_cells = n1 * n2 * n3

@@ -179,7 +179,8 @@ class RunConfig:
 @dataclass
 class Problem:
     """grid_type 'car': `walls` = [x(n1+1), y(n2+1), z(n3+1)], density
-    (n_dust, n3, n2, n1).  grid_type 'oct': `refined` (depth-first flags of all
+    (n_dust, n3, n2, n1).  grid_type 'sph_pol': walls = [r, theta, phi]; 'cyl_pol': walls =
+    [w, z, phi] (src/grid/grid_geometry_spherical_3d.f90:90-203, grid_geometry_cylindrical_3d.f90:90-175).  grid_type 'oct': `refined` (depth-first flags of all
     cells), `oct_center`, `oct_half` (half-widths of the top cell), density
     (n_dust, n_cells) -- src/grid/grid_geometry_octree.f90:184-246."""
     walls: List[np.ndarray]
@@ -211,7 +212,7 @@ class Problem:
     def __post_init__(self):
         self.walls = [_f64(w) for w in self.walls]
         self.density = _f64(self.density)
-        if self.grid_type == "car":
+        if self.grid_type in ("car", "sph_pol", "cyl_pol"):
             if self.density.ndim == 3:
                 self.density = self.density[None]
             n1, n2, n3 = self.shape
@@ -305,6 +306,13 @@ class Problem:
             b, n = self.amr_bounds, self.amr_n
             v = ((b[:, 1] - b[:, 0]) / n[:, 0]) * ((b[:, 3] - b[:, 2]) / n[:, 1]) * ((b[:, 5] - b[:, 4]) / n[:, 2])
             return np.repeat(v, np.prod(n, axis=1))
+        if self.grid_type == "sph_pol":   # grid_geometry_spherical_3d.f90:146-155: dr3 * dcost * dphi / 3
+            r, t, ph = self.walls
+            return (np.diff(ph)[:, None, None] * (np.cos(t[:-1]) - np.cos(t[1:]))[None, :, None]
+                    * np.diff(r ** 3)[None, None, :] / 3.0)
+        if self.grid_type == "cyl_pol":   # grid_geometry_cylindrical_3d.f90:140-147: dw2 * dz * dphi / 2
+            w, z, ph = self.walls
+            return np.diff(ph)[:, None, None] * np.diff(z)[None, :, None] * np.diff(w ** 2)[None, None, :] / 2.0
         dx, dy, dz = (np.diff(w) for w in self.walls)
         return dz[:, None, None] * dy[None, :, None] * dx[None, None, :]
 

@@ -109,6 +109,10 @@ def read_rtin(path):
         extra = {}
         if grid_type == "car":
             walls = [geo["walls_1"][...]["x"], geo["walls_2"][...]["y"], geo["walls_3"][...]["z"]]
+        elif grid_type == "sph_pol":
+            walls = [geo["walls_1"][...]["r"], geo["walls_2"][...]["t"], geo["walls_3"][...]["p"]]
+        elif grid_type == "cyl_pol":
+            walls = [geo["walls_1"][...]["w"], geo["walls_2"][...]["z"], geo["walls_3"][...]["p"]]
         elif grid_type == "oct":
             walls = []
             ga = geo.attrs

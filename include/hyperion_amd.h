@@ -83,10 +83,11 @@ typedef struct hyp_source_desc {
 /* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),
  * src/grid/grid_geometry_octree.f90:184-246 (type 2),
  * src/grid/grid_geometry_voronoi.f90:96-188 (type 3),
- * src/grid/grid_geometry_amr.f90:111-508 (type 4) */
+ * src/grid/grid_geometry_amr.f90:111-508 (type 4),
+ * src/grid/grid_geometry_spherical_3d.f90:90-203 (type 5), src/grid/grid_geometry_cylindrical_3d.f90:90-175 (type 6) */
 typedef struct hyp_grid_desc {
-    int32_t type;          /* 1 cartesian, 2 octree, 3 voronoi, 4 amr */
-    int32_t n1, n2, n3;    /* cartesian: cells per axis */
+    int32_t type;          /* 1 cartesian, 2 octree, 3 voronoi, 4 amr, 5 spherical polar (r, theta, phi), 6 cylindrical polar (w, z, phi) */
+    int32_t n1, n2, n3;    /* cartesian / spherical / cylindrical: cells per axis */
     const double *w1;      /* cartesian: [n1+1] walls */
     const double *w2;
     const double *w3;

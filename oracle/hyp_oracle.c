@@ -392,7 +392,8 @@ typedef struct {
     int nj_stride;
 } peeled_t;
 
-enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3, GRID_AMR = 4 };
+enum { GRID_CAR = 1, GRID_OCT = 2, GRID_VOR = 3, GRID_AMR = 4, GRID_SPH = 5, GRID_CYL = 6 };
+#define GRID_IS_3IDX(t) ((t) == GRID_CAR || (t) == GRID_SPH || (t) == GRID_CYL)
 
 /* one grid of an AMR level: type_grid_amr.f90:12-21 */
 typedef struct amr_grid {
@@ -426,6 +427,10 @@ struct orc_state {
     double amr_eps;
     double *w[3], *ew[3];
     int n[3];
+    /* spherical / cylindrical polar grids: type_grid_spherical_3d.f90:11-20, type_grid_cylindrical_3d.f90 */
+    double *wr2, *wtanp, *wtant, *wtant2, *wcost;
+    int midplane;               /* 0-based index of the theta wall at pi/2, -2 if none (Fortran default -1) */
+    int n_dim;
     double *volume;
     int any_intersect;          /* some source can re-absorb packets (spheres) */
     /* modified random walk: grid_mrw_3d.f90 */
@@ -1011,11 +1016,75 @@ static int octree_setup(orc_state *st, const orc_grid_desc *gd)
     return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* Spherical / cylindrical polar grids: set-up                          */
+/* grid_geometry_spherical_3d.f90:90-203, grid_geometry_cylindrical_3d.f90:90-175 */
+/* ------------------------------------------------------------------ */
+static int polar_setup(orc_state *st, const orc_grid_desc *gd)
+{
+    const int sph = st->grid_type == GRID_SPH;
+    st->n1 = gd->n1; st->n2 = gd->n2; st->n3 = gd->n3;
+    st->n[0] = st->n1; st->n[1] = st->n2; st->n[2] = st->n3;
+    st->n_cells = (size_t)st->n1 * st->n2 * st->n3;
+    const double *win[3] = {gd->w1, gd->w2, gd->w3};
+    for (int a = 0; a < 3; a++) st->w[a] = dup(win[a], st->n[a] + 1);
+    for (int i = 0; i <= st->n1; i++)
+        if (st->w[0][i] < 0.0) { snprintf(g_error, sizeof g_error, sph ? "r walls should be positive" : "w walls should be positive"); return 1; }
+    if (sph) for (int i = 0; i <= st->n2; i++)
+        if (st->w[1][i] < 0.0 || st->w[1][i] > PI) { snprintf(g_error, sizeof g_error, "theta walls should be between 0 and pi"); return 1; }
+    for (int i = 0; i <= st->n3; i++)
+        if (st->w[2][i] < 0.0 || st->w[2][i] > 2.0 * PI) { snprintf(g_error, sizeof g_error, "phi walls should be between 0 and 2*pi"); return 1; }
+    st->volume = malloc(sizeof(double) * st->n_cells);
+    for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++) {
+        const double *w1 = st->w[0], *w2 = st->w[1], *w3 = st->w[2];
+        double dphi = w3[k + 1] - w3[k], vol;
+        if (sph) {
+            double dr3 = w1[i + 1] * w1[i + 1] * w1[i + 1] - w1[i] * w1[i] * w1[i];
+            double dcost = cos(w2[j]) - cos(w2[j + 1]);
+            vol = dr3 * dcost * dphi / 3.0;
+        } else {
+            double dw2 = w1[i + 1] * w1[i + 1] - w1[i] * w1[i];
+            vol = dw2 * (w2[j + 1] - w2[j]) * dphi / 2.0;
+        }
+        st->volume[((size_t)k * st->n2 + j) * st->n1 + i] = vol;
+        if (vol == 0.0) { snprintf(g_error, sizeof g_error, "all volumes should be greater than zero"); return 1; }
+    }
+    static const char *names_s[3] = {"dr", "dt", "dphi"}, *names_c[3] = {"dw", "dz", "dphi"};
+    for (int a = 0; a < 3; a++) for (int i = 0; i < st->n[a]; i++)
+        if (st->w[a][i + 1] - st->w[a][i] == 0.0) {
+            snprintf(g_error, sizeof g_error, "all %s values should be greater than zero", sph ? names_s[a] : names_c[a]); return 1;
+        }
+    st->wr2 = malloc(sizeof(double) * (st->n1 + 1));
+    for (int i = 0; i <= st->n1; i++) st->wr2[i] = st->w[0][i] * st->w[0][i];
+    st->wtanp = malloc(sizeof(double) * (st->n3 + 1));
+    for (int i = 0; i <= st->n3; i++) st->wtanp[i] = tan(st->w[2][i]);
+    st->midplane = -2;
+    if (sph) {
+        st->wtant = malloc(sizeof(double) * (st->n2 + 1));
+        st->wtant2 = malloc(sizeof(double) * (st->n2 + 1));
+        st->wcost = malloc(sizeof(double) * (st->n2 + 1));
+        /* :175 if(any(abs(w2 - pi/2) < 1e-6)) midplane = minloc(abs(w2 - pi/2), 1) */
+        double m = DBL_MAX; int im = 0;
+        for (int i = 0; i <= st->n2; i++) {
+            st->wtant[i] = tan(st->w[1][i]); st->wtant2[i] = st->wtant[i] * st->wtant[i]; st->wcost[i] = cos(st->w[1][i]);
+            double d = fabs(st->w[1][i] - PI / 2.0);
+            if (d < m) { m = d; im = i; }
+        }
+        if (m < 1.e-6) st->midplane = im;
+    }
+    st->n_dim = st->n3 == 1 ? 2 : 3;
+    for (int a = 0; a < 3; a++) st->ew[a] = malloc(sizeof(double) * (st->n[a] + 1));
+    for (int i = 0; i <= st->n1; i++) st->ew[0][i] = 3.0 * spacing(st->w[0][i]);
+    for (int i = 0; i <= st->n2; i++) st->ew[1][i] = sph ? 3.0 * spacing(1.0) : 3.0 * spacing(st->w[1][i]);
+    for (int i = 0; i <= st->n3; i++) st->ew[2][i] = 3.0 * spacing(1.0);
+    return 0;
+}
+
 int orc_create(const orc_problem *pr, orc_state **out)
 {
     g_error[0] = 0;
     if (!pr || !out) { snprintf(g_error, sizeof g_error, "null argument"); return 1; }
-    if (pr->grid.type != GRID_CAR && pr->grid.type != GRID_OCT && pr->grid.type != GRID_VOR && pr->grid.type != GRID_AMR) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
+    if (pr->grid.type < GRID_CAR || pr->grid.type > GRID_CYL) { snprintf(g_error, sizeof g_error, "unknown grid type"); return 1; }
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
@@ -1042,6 +1111,8 @@ int orc_create(const orc_problem *pr, orc_state **out)
         for (int k = 0; k < st->n3; k++) for (int j = 0; j < st->n2; j++) for (int i = 0; i < st->n1; i++)
             st->volume[((size_t)k * st->n2 + j) * st->n1 + i] =
                 (st->w[0][i + 1] - st->w[0][i]) * (st->w[1][j + 1] - st->w[1][j]) * (st->w[2][k + 1] - st->w[2][k]);
+    } else if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) {
+        if (polar_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     } else if (st->grid_type == GRID_OCT) {
         if (octree_setup(st, &pr->grid)) { orc_destroy(st); return 1; }
     } else if (st->grid_type == GRID_AMR) {
@@ -1179,7 +1250,7 @@ void orc_destroy(orc_state *st)
 {
     if (!st) return;
     for (int a = 0; a < 3; a++) { free(st->w[a]); free(st->ew[a]); }
-    free(st->volume);
+    free(st->volume); free(st->wr2); free(st->wtanp); free(st->wtant); free(st->wtant2); free(st->wcost);
     free(st->ox); free(st->oy); free(st->oz); free(st->odx); free(st->ody); free(st->odz);
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
     free(st->vsite); free(st->vidx); free(st->vneigh); free(st->vseed);
@@ -1214,6 +1285,7 @@ typedef struct {
     int ic[3];          /* 0-based cell indices */
     int on_wall[3];     /* -1 lower wall, +1 upper wall, 0 none */
     int in_cell, killed;
+    int radial;         /* (r.v) > 0 at the start of the current integration: grid_propagate_3d.f90:73 */
     double chi[ORC_MAX_DUST], albedo[ORC_MAX_DUST], kappa[ORC_MAX_DUST];
     int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id, face_id;
     angle_t a_prev; double s_prev[4], v_prev[3];
@@ -1259,7 +1331,7 @@ static int update_optconsts(const orc_state *st, photon_t *p, acc_t *acc)
 
 static inline size_t cell_index(const orc_state *st, const int ic[3])
 {
-    if (st->grid_type != GRID_CAR) return (size_t)ic[0];
+    if (!GRID_IS_3IDX(st->grid_type)) return (size_t)ic[0];
     return ((size_t)ic[2] * st->n2 + ic[1]) * st->n1 + ic[0];
 }
 
@@ -1267,6 +1339,8 @@ static inline size_t cell_index(const orc_state *st, const int ic[3])
 static inline int escaped(const orc_state *st, const int ic[3])
 {
     /* octree: escaped_cell grid_geometry_octree.f90:320-326 (ic == n_cells+1) */
+    if (st->grid_type == GRID_SPH) return ic[0] < 0 || ic[0] >= st->n1;      /* spherical_3d.f90:483-490 */
+    if (st->grid_type == GRID_CYL) return ic[0] < 0 || ic[0] >= st->n1 || ic[1] < 0 || ic[1] >= st->n2;   /* cylindrical_3d.f90:381-390 */
     if (st->grid_type != GRID_CAR) return (size_t)ic[0] == st->n_cells;
     return ic[0] < 0 || ic[0] >= st->n1 || ic[1] < 0 || ic[1] >= st->n2 || ic[2] < 0 || ic[2] >= st->n3;
 }
@@ -1303,8 +1377,10 @@ static int32_t oct_next_cell(const orc_state *st, int32_t id, int wall, const do
 }
 
 /* find_cell :143-166 (car) / :260-283 (oct); returns 0 if outside */
-static int find_cell(const orc_state *st, const double r[3], int ic[3])
+static int find_cell_polar(const orc_state *st, const double r[3], const double v[3], int ic[3]);
+static int find_cell(const orc_state *st, const double r[3], const double v[3], int ic[3])
 {
+    if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) return find_cell_polar(st, r, v, ic);
     if (st->grid_type == GRID_VOR) {   /* grid_geometry_voronoi.f90:196-229 */
         if (r[0] < st->vbox[0] || r[0] > st->vbox[1]) return 0;
         if (r[1] < st->vbox[2] || r[1] > st->vbox[3]) return 0;
@@ -1350,14 +1426,189 @@ static void adjust_wall(const orc_state *st, photon_t *p)
     }
 }
 
+
+/* ------------------------------------------------------------------ */
+/* Spherical / cylindrical polar walks: grid_geometry_spherical_3d.f90, */
+/* grid_geometry_cylindrical_3d.f90 (0-based cell and wall indices)     */
+/* ------------------------------------------------------------------ */
+
+/* equal_nulp :49-59 */
+static inline int equal_nulp(double x, double y, int n)
+{
+    if (x == y) return 1;
+    return fabs(x - y) <= n * spacing(x > y ? x : y);
+}
+
+/* theta and phi of a position, from the direction where the position cannot tell (:251-268) */
+static inline double polar_theta(const double r[3], const double v[3], double r_sq)
+{
+    if (r_sq == 0.0) return atan2(sqrt(v[0] * v[0] + v[1] * v[1]), v[2]);
+    return atan2(sqrt(r[0] * r[0] + r[1] * r[1]), r[2]);
+}
+static inline double polar_phi(const double r[3], const double v[3], double w_sq)
+{
+    double phi = w_sq == 0.0 ? atan2(v[1], v[0]) : atan2(r[1], r[0]);
+    if (phi < 0.0) phi = phi + 2.0 * PI;
+    return phi;
+}
+
+/* find_cell: spherical :226-299, cylindrical :183-236 */
+static int find_cell_polar(const orc_state *st, const double r[3], const double v[3], int ic[3])
+{
+    double w_sq = r[0] * r[0] + r[1] * r[1];
+    double phi = polar_phi(r, v, w_sq);
+    int i1, i2;
+    if (st->grid_type == GRID_SPH) {
+        double r_sq = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];      /* p%r .dot. p%r */
+        i1 = locate(st->wr2, st->n1 + 1, r_sq);
+        i2 = locate(st->w[1], st->n2 + 1, polar_theta(r, v, r_sq));
+    } else {
+        i1 = locate(st->wr2, st->n1 + 1, w_sq);
+        i2 = locate(st->w[1], st->n2 + 1, r[2]);
+    }
+    int i3 = locate(st->w[2], st->n3 + 1, phi);
+    if (i1 < 0 || i1 >= st->n1 || i2 < 0 || i2 >= st->n2 || i3 < 0 || i3 >= st->n3) return 0;
+    ic[0] = i1; ic[1] = i2; ic[2] = i3;
+    return 1;
+}
+
+/* the azimuthal part shared by both adjust_wall: spherical :425-462, cylindrical :312-349 */
+static void adjust_wall_phi(const orc_state *st, photon_t *p, double phi)
+{
+    const double *w3 = st->w[2];
+    if (p->r[0] == 0.0 && p->r[1] == 0.0 && p->v[0] == 0.0 && p->v[1] == 0.0) return;   /* on all phi walls at once */
+    if (equal_nulp(phi, w3[p->ic[2]], 3)) {
+        double dphi = atan2(p->v[1], p->v[0]) - w3[p->ic[2]];
+        if (dphi < -PI) dphi = dphi + 2.0 * PI;
+        if (dphi > 0.0) p->on_wall[2] = -1;
+        else { p->on_wall[2] = +1; p->ic[2]--; if (p->ic[2] == -1) p->ic[2] = st->n3 - 1; }
+    } else if (equal_nulp(phi, w3[p->ic[2] + 1], 3)) {
+        double dphi = atan2(p->v[1], p->v[0]) - w3[p->ic[2] + 1];
+        if (dphi < -PI) dphi = dphi + 2.0 * PI;
+        if (dphi > 0.0) { p->on_wall[2] = -1; p->ic[2]++; if (p->ic[2] == st->n3) p->ic[2] = 0; }
+        else p->on_wall[2] = +1;
+    }
+}
+
+/* adjust_wall: spherical :301-466, cylindrical :238-353 */
+static void adjust_wall_polar(const orc_state *st, photon_t *p)
+{
+    p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
+    const double *r = p->r, *v = p->v;
+    double w_sq = r[0] * r[0] + r[1] * r[1];
+    double phi = polar_phi(r, v, w_sq);
+    if (st->grid_type == GRID_CYL) {
+        if (r[0] * v[0] + r[1] * v[1] >= 0.0) {
+            if (equal_nulp(w_sq, st->wr2[p->ic[0]], 3)) p->on_wall[0] = -1;
+            else if (equal_nulp(w_sq, st->wr2[p->ic[0] + 1], 3)) { p->on_wall[0] = -1; p->ic[0]++; }
+        } else {
+            if (equal_nulp(w_sq, st->wr2[p->ic[0]], 3)) { p->on_wall[0] = +1; p->ic[0]--; }
+            else if (equal_nulp(w_sq, st->wr2[p->ic[0] + 1], 3)) p->on_wall[0] = +1;
+        }
+        const double *w2 = st->w[1];
+        if (v[2] > 0.0) {
+            if (equal_nulp(r[2], w2[p->ic[1]], 3)) p->on_wall[1] = -1;
+            else if (equal_nulp(r[2], w2[p->ic[1] + 1], 3)) { p->on_wall[1] = -1; p->ic[1]++; }
+        } else if (v[2] < 0.0) {
+            if (equal_nulp(r[2], w2[p->ic[1]], 3)) { p->on_wall[1] = +1; p->ic[1]--; }
+            else if (equal_nulp(r[2], w2[p->ic[1] + 1], 3)) p->on_wall[1] = +1;
+        }
+        adjust_wall_phi(st, p, phi);
+        return;
+    }
+    double r_sq = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+    double theta = polar_theta(r, v, r_sq);
+    /* radial wall :330-347 */
+    if ((r[0] * v[0] + r[1] * v[1]) + r[2] * v[2] >= 0.0) {
+        if (equal_nulp(r_sq, st->wr2[p->ic[0]], 3)) p->on_wall[0] = -1;
+        else if (equal_nulp(r_sq, st->wr2[p->ic[0] + 1], 3)) { p->on_wall[0] = -1; p->ic[0]++; }
+    } else {
+        if (equal_nulp(r_sq, st->wr2[p->ic[0]], 3)) { p->on_wall[0] = +1; p->ic[0]--; }
+        else if (equal_nulp(r_sq, st->wr2[p->ic[0] + 1], 3)) p->on_wall[0] = +1;
+    }
+    /* theta wall :349-423 */
+    const double *w2 = st->w[1];
+    if (r_sq == 0.0) {
+        if (fabs(v[2]) < 1.0) {
+            double theta_v = atan2(sqrt(v[0] * v[0] + v[1] * v[1]), v[2]);
+            if (equal_nulp(theta_v, w2[p->ic[1]], 3)) p->on_wall[1] = -1;
+            else if (equal_nulp(theta_v, w2[p->ic[1] + 1], 3)) p->on_wall[1] = +1;
+        }
+    } else if (p->ic[1] > 0 && equal_nulp(theta, w2[p->ic[1]], 3)) {
+        if (p->ic[1] == st->midplane) {
+            if (v[2] > 0.0) { p->on_wall[1] = +1; p->ic[1]--; }
+            else p->on_wall[1] = -1;
+        } else {
+            int lhs = sqrt(w_sq) * v[2] * st->wtant[p->ic[1]] - (r[0] * v[0] + r[1] * v[1]) < 0.0;
+            if (lhs == (r[2] > 0.0)) p->on_wall[1] = -1;
+            else { p->on_wall[1] = +1; p->ic[1]--; }
+        }
+    } else if (p->ic[1] + 1 < st->n2 && equal_nulp(theta, w2[p->ic[1] + 1], 3)) {
+        if (p->ic[1] + 1 == st->midplane) {
+            if (v[2] > 0.0) p->on_wall[1] = +1;
+            else { p->on_wall[1] = -1; p->ic[1]++; }
+        } else {
+            int lhs = sqrt(w_sq) * v[2] * st->wtant[p->ic[1] + 1] - (r[0] * v[0] + r[1] * v[1]) < 0.0;
+            if (lhs == (r[2] > 0.0)) { p->on_wall[1] = -1; p->ic[1]++; }
+            else p->on_wall[1] = +1;
+        }
+    }
+    adjust_wall_phi(st, p, phi);
+}
+
+/* in_correct_cell: spherical :553-637, cylindrical :444-516 */
+static int in_correct_cell_polar(const orc_state *st, const photon_t *p)
+{
+    int act[3] = {-1, -1, -1};
+    int found = find_cell_polar(st, p->r, p->v, act);
+    if (!found) act[0] = act[1] = act[2] = -1;     /* invalid_cell */
+    const double thr = 1e-3;
+    const double *r = p->r, *v = p->v;
+    if (!(p->on_wall[0] || p->on_wall[1] || p->on_wall[2]))
+        return act[0] == p->ic[0] && act[1] == p->ic[1] && act[2] == p->ic[2];
+    int ok = 1;
+    double w_sq = r[0] * r[0] + r[1] * r[1];
+    double rad_sq = w_sq;           /* cylindrical: w^2; spherical: r^2 */
+    const double *w1 = st->w[0], *w2 = st->w[1], *w3 = st->w[2];
+    if (st->grid_type == GRID_SPH) {
+        rad_sq = (r[0] * r[0] + r[1] * r[1]) + r[2] * r[2];
+        if (rad_sq == 0.0) return 1;
+    }
+    double phi = polar_phi(r, v, w_sq);
+    if (p->on_wall[0] == -1) {
+        if (w1[p->ic[0]] != sqrt(rad_sq)) ok = ok && fabs(sqrt(rad_sq) / w1[p->ic[0]] - 1.0) < thr;
+    } else if (p->on_wall[0] == +1) {
+        if (w1[p->ic[0] + 1] != sqrt(rad_sq)) ok = ok && fabs(sqrt(rad_sq) / w1[p->ic[0] + 1] - 1.0) < thr;
+    } else ok = ok && act[0] == p->ic[0];
+    if (st->grid_type == GRID_SPH) {
+        double theta = polar_theta(r, v, rad_sq);
+        if (p->on_wall[1] == -1) ok = ok && fabs(theta / w2[p->ic[1]] - 1.0) < thr;
+        else if (p->on_wall[1] == +1) ok = ok && fabs(theta / w2[p->ic[1] + 1] - 1.0) < thr;
+        else ok = ok && act[1] == p->ic[1];
+    } else {
+        double dz = w2[p->ic[1] + 1] - w2[p->ic[1]];
+        if (p->on_wall[1] == -1) ok = ok && fabs((r[2] - w2[p->ic[1]]) / dz) < thr;
+        else if (p->on_wall[1] == +1) ok = ok && fabs((r[2] - w2[p->ic[1] + 1]) / dz) < thr;
+        else ok = ok && act[1] == p->ic[1];
+    }
+    if (p->on_wall[2] != 0) {
+        double dphi = phi - w3[p->ic[2] + (p->on_wall[2] == +1 ? 1 : 0)];
+        if (dphi > PI) dphi = dphi - 2.0 * PI;
+        if (dphi < -PI) dphi = dphi + 2.0 * PI;
+        ok = ok && fabs(dphi / (w3[p->ic[2] + 1] - w3[p->ic[2]])) < thr;
+    } else ok = ok && act[2] == p->ic[2];
+    return ok;
+}
+
 /* place_in_cell :234-253 */
 static void place_in_cell(const orc_state *st, photon_t *p, acc_t *acc)
 {
-    if (!find_cell(st, p->r, p->ic)) {
+    if (!find_cell(st, p->r, p->v, p->ic)) {
         acc->killed_geo++; p->killed = 1;
     } else {
         p->in_cell = 1;
         if (st->grid_type == GRID_CAR) adjust_wall(st, p);   /* octree place_in_cell :285-296 has none */
+        else if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) adjust_wall_polar(st, p);
     }
 }
 
@@ -1365,7 +1616,8 @@ static void place_in_cell(const orc_state *st, photon_t *p, acc_t *acc)
 static int in_correct_cell(const orc_state *st, const photon_t *p)
 {
     int act[3];
-    int found = find_cell(st, p->r, act);
+    if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) return in_correct_cell_polar(st, p);
+    int found = find_cell(st, p->r, p->v, act);
     const double thr = 1e-3;
     int on_wall = p->on_wall[0] || p->on_wall[1] || p->on_wall[2];
     if (st->grid_type == GRID_VOR) {   /* :274-283: the cell must be one of the two nearest sites */
@@ -1524,6 +1776,153 @@ static int64_t amr_next_cell(const orc_state *st, size_t ic, int axis, int dir, 
     return amr_find_position(st, r, go - 1);
 }
 
+
+/* fortranlib quadratic(a, b, c, x1, x2): real roots of a x^2 + b x + c = 0, cancellation-free
+ * (q = -(b + sign(b) sqrt(delta))/2, x1 = q/a, x2 = c/q); no real root -> -huge.  Restated from
+ * the library's published behaviour like quadratic_pascal_reduced below (parity unpinned at
+ * source level; pinned by the reference's spherical goldens). */
+static void quadratic_full(double a, double b, double c, double *x1, double *x2)
+{
+    double delta = b * b - 4.0 * a * c;
+    if (delta < 0.0) { *x1 = *x2 = -DBL_MAX; return; }
+    double q = b >= 0.0 ? -0.5 * (b + sqrt(delta)) : -0.5 * (b - sqrt(delta));
+    *x1 = q / a;
+    *x2 = q != 0.0 ? c / q : 0.0;
+}
+static void quadratic_pascal_reduced(double b, double c, double *t1, double *t2);
+
+typedef struct { double tmin, emin; int imin[3], iext[3]; } wallsel_t;
+
+/* insert_t: spherical_3d.f90:1080-1112 (same in cylindrical_3d.f90) */
+static inline void insert_t(wallsel_t *ws, double t, int iw, int i, double e)
+{
+    if (t > 0.0) {
+        double emax = e > ws->emin ? e : ws->emin;
+        if (t < ws->tmin - emax) {
+            ws->tmin = t; ws->imin[0] = ws->imin[1] = ws->imin[2] = 0; ws->emin = emax; ws->imin[iw] = i;
+        } else if (t < ws->tmin + emax) {
+            ws->emin = emax; ws->imin[iw] = i;
+        }
+    }
+}
+
+/* both roots of a curved wall unless the packet sits on it, then the one that is not the wall itself */
+static inline void insert_pair(wallsel_t *ws, double t1, double t2, int on_it, int iw, int i, double e)
+{
+    if (on_it) insert_t(ws, fabs(t1) < fabs(t2) ? t2 : t1, iw, i, e);
+    else { insert_t(ws, t1, iw, i, e); insert_t(ws, t2, iw, i, e); }
+}
+
+/* the phi walls: spherical_3d.f90:985-1064 = cylindrical_3d.f90:691-767 */
+static void find_wall_phi(const orc_state *st, const photon_t *p, double r2_xy, wallsel_t *ws)
+{
+    if (st->n_dim != 3) return;
+    const double *w3 = st->w[2], *r = p->r, *v = p->v;
+    const int i3 = p->ic[2];
+    double dphi = 0.0;
+    if (p->on_wall[2] == -1) {
+        dphi = atan2(v[1], v[0]) - w3[i3];
+        if (dphi > PI) dphi = dphi - 2.0 * PI;
+        if (dphi < -PI) dphi = dphi + 2.0 * PI;
+    }
+    if (p->on_wall[2] == +1) {
+        dphi = atan2(v[1], v[0]) - w3[i3 + 1];
+        if (dphi > PI) dphi = dphi - 2.0 * PI;
+        if (dphi < -PI) dphi = dphi + 2.0 * PI;
+    }
+    if (p->on_wall[2] == +1 && fabs(dphi) < st->ew[2][i3 + 1]) ws->iext[2] = +1;
+    else if (p->on_wall[2] == -1 && fabs(dphi) < st->ew[2][i3]) ws->iext[2] = -1;
+    else if (r2_xy > 0.0) {
+        for (int side = 0; side < 2; side++) {
+            int dir = side ? +1 : -1;
+            if (p->on_wall[2] == dir) continue;
+            double tp = st->wtanp[i3 + side];
+            double t = -(tp * r[0] - r[1]) / (tp * v[0] - v[1]);
+            double x_i = r[0] + v[0] * t, y_i = r[1] + v[1] * t;
+            double d = fabs(atan2(y_i, x_i) - w3[i3 + side]);
+            if (d > PI) d = fabs(d - 2.0 * PI);
+            if (d < 0.5 * PI) insert_t(ws, t, 2, dir, 0.0);
+        }
+    }
+}
+
+/* one cone wall (side 0 = lower, 1 = upper): spherical_3d.f90:832-980 */
+static void find_wall_cone(const orc_state *st, const photon_t *p, int side, double v2_xy, double v2_z,
+                           double rv_xy, double rv_z, double r2_xy, double r2_z, wallsel_t *ws)
+{
+    const int iw = p->ic[1] + side, dir = side ? +1 : -1;
+    const double *r = p->r, *v = p->v;
+    const double e = st->ew[1][iw], tt = st->wtant[iw], tt2 = st->wtant2[iw];
+    if (p->on_wall[1] == dir && equal_nulp(tt, sqrt(v2_xy) / v[2], 10)
+        && equal_nulp(sqrt(r2_xy) * v[2] * tt, rv_xy, 10)) { ws->iext[1] = dir; return; }   /* moving along the wall */
+    if (iw == st->midplane && v[2] != 0.0) {
+        if (p->on_wall[1] != dir) insert_t(ws, -r[2] / v[2], 1, dir, e);
+        return;
+    }
+    double pA = v2_xy - v2_z * tt2;
+    double pB = rv_xy - rv_z * tt2; pB = pB + pB;
+    double pC = r2_xy - r2_z * tt2;
+    if (fabs(pA) > 0.0) {
+        double t1, t2;
+        quadratic_full(pA, pB, pC, &t1, &t2);
+        double z1 = r[2] + v[2] * t1;
+        if ((z1 > 0.0) != (tt > 0.0)) t1 = DBL_MAX;
+        double z2 = r[2] + v[2] * t2;
+        if ((z2 > 0.0) != (tt > 0.0)) t2 = DBL_MAX;
+        insert_pair(ws, t1, t2, p->on_wall[1] == dir, 1, dir, e);
+    } else if (fabs(pB) > 0.0) {
+        if (p->on_wall[1] != dir) insert_t(ws, -pC / pB, 1, dir, e);
+    }
+}
+
+/* find_wall: spherical_3d.f90:741-1073 */
+static int find_wall_sph(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    wallsel_t ws = {DBL_MAX, 0.0, {0, 0, 0}, {0, 0, 0}};
+    const double *r = p->r, *v = p->v;
+    double v2_xy = v[0] * v[0] + v[1] * v[1], v2_z = v[2] * v[2];
+    double rv_xy = r[0] * v[0] + r[1] * v[1], rv_z = r[2] * v[2];
+    double r2_xy = r[0] * r[0] + r[1] * r[1], r2_z = r[2] * r[2];
+    double pB = rv_xy + rv_z; pB = pB + pB;
+    double pC = r2_xy + r2_z, t1, t2;
+    const int i1 = p->ic[0];
+    if (!p->radial) {
+        quadratic_pascal_reduced(pB, pC - st->wr2[i1], &t1, &t2);
+        insert_pair(&ws, t1, t2, p->on_wall[0] == -1, 0, -1, st->ew[0][i1]);
+    }
+    quadratic_pascal_reduced(pB, pC - st->wr2[i1 + 1], &t1, &t2);
+    insert_pair(&ws, t1, t2, p->on_wall[0] == +1, 0, +1, st->ew[0][i1 + 1]);
+    if (p->ic[1] > 0) find_wall_cone(st, p, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, &ws);
+    if (p->ic[1] < st->n2 - 1) find_wall_cone(st, p, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, &ws);
+    find_wall_phi(st, p, r2_xy, &ws);
+    *tnearest = ws.tmin;
+    for (int a = 0; a < 3; a++) id_min[a] = ws.imin[a] + ws.iext[a];      /* find_next_wall :1114-1121 */
+    return id_min[0] || id_min[1] || id_min[2];
+}
+
+/* find_wall: cylindrical_3d.f90:593-771 */
+static int find_wall_cyl(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
+{
+    wallsel_t ws = {DBL_MAX, 0.0, {0, 0, 0}, {0, 0, 0}};
+    const double *r = p->r, *v = p->v;
+    double v2_xy = v[0] * v[0] + v[1] * v[1];
+    double rv_xy = r[0] * v[0] + r[1] * v[1];
+    double r2_xy = r[0] * r[0] + r[1] * r[1];
+    double pB = rv_xy / v2_xy; pB = pB + pB;
+    double pC = r2_xy / v2_xy, t1, t2;
+    const int i1 = p->ic[0], i2 = p->ic[1];
+    quadratic_pascal_reduced(pB, pC - st->wr2[i1] / v2_xy, &t1, &t2);
+    insert_pair(&ws, t1, t2, p->on_wall[0] == -1, 0, -1, st->ew[0][i1]);
+    quadratic_pascal_reduced(pB, pC - st->wr2[i1 + 1] / v2_xy, &t1, &t2);
+    insert_pair(&ws, t1, t2, p->on_wall[0] == +1, 0, +1, st->ew[0][i1 + 1]);
+    if (p->on_wall[1] != -1) insert_t(&ws, (st->w[1][i2] - r[2]) / v[2], 1, -1, 0.0);
+    if (p->on_wall[1] != +1) insert_t(&ws, (st->w[1][i2 + 1] - r[2]) / v[2], 1, +1, 0.0);
+    find_wall_phi(st, p, r2_xy, &ws);
+    *tnearest = ws.tmin;
+    for (int a = 0; a < 3; a++) id_min[a] = ws.imin[a] + ws.iext[a];
+    return id_min[0] || id_min[1] || id_min[2];
+}
+
 /* p%icell = next_cell(p%icell, id_min, intersection=p%r); p%on_wall_id = opposite_wall(id_min) */
 static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
 {
@@ -1547,6 +1946,10 @@ static void advance_cell(const orc_state *st, photon_t *p, const int id_min[3])
         return;
     }
     for (int a = 0; a < 3; a++) { p->ic[a] += id_min[a]; p->on_wall[a] = -id_min[a]; }
+    if (st->grid_type != GRID_CAR) {   /* phi is periodic: spherical_3d.f90:540-546, cylindrical_3d.f90:434-440 */
+        if (p->ic[2] == -1) p->ic[2] = st->n3 - 1;
+        else if (p->ic[2] == st->n3) p->ic[2] = 0;
+    }
 }
 
 static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, int id_min[3])
@@ -1554,6 +1957,8 @@ static int find_wall(const orc_state *st, const photon_t *p, double *tnearest, i
     if (st->grid_type == GRID_OCT) return find_wall_oct(st, p, tnearest, id_min);
     if (st->grid_type == GRID_VOR) return find_wall_vor(st, p, tnearest, id_min);
     if (st->grid_type == GRID_AMR) return find_wall_amr(st, p, tnearest, id_min);
+    if (st->grid_type == GRID_SPH) return find_wall_sph(st, p, tnearest, id_min);
+    if (st->grid_type == GRID_CYL) return find_wall_cyl(st, p, tnearest, id_min);
     double tmin = DBL_MAX, emin = 0.0;
     int imin[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
@@ -1598,6 +2003,7 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
 {
     double tau_achieved = 0.0;
     p->reabsorbed = 0;
+    p->radial = ((p->r[0] * p->v[0] + p->r[1] * p->v[1]) + p->r[2] * p->v[2]) > 0.0;   /* :73 */
     if (escaped(st, p->ic)) return;
     if (tau_required == 0.0) return;
     /* distance to the nearest source that can re-absorb the packet: grid_propagate_3d.f90:99-101 */
@@ -1652,6 +2058,7 @@ static double grid_escape_tau(const orc_state *st, const photon_t *p_orig, doubl
                               rng_t *g, acc_t *acc, int *killed)
 {
     photon_t p = *p_orig;
+    p.radial = ((p.r[0] * p.v[0] + p.r[1] * p.v[1]) + p.r[2] * p.v[2]) > 0.0;   /* grid_propagate_3d.f90:400,505 */
     double tau = 0.0, t_achieved = 0.0;
     *killed = 0;
     if (escaped(st, p.ic)) return 0.0;
@@ -2067,6 +2474,29 @@ static int prepare_mrw(orc_state *st)
 static double distance_to_closest_wall(const orc_state *st, const photon_t *p)
 {
     double lo[3], hi[3];
+    if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) {   /* spherical_3d.f90:675-739, cylindrical_3d.f90:552-591 */
+        const double *r = p->r;
+        const int i1 = p->ic[0], i2 = p->ic[1], i3 = p->ic[2];
+        double rcyl = sqrt(r[0] * r[0] + r[1] * r[1]);
+        double d1, d2, d3, d4, d5 = DBL_MAX, d6 = DBL_MAX;
+        if (st->grid_type == GRID_SPH) {
+            double rad = sqrt((r[0] * r[0] + r[1] * r[1]) + r[2] * r[2]);
+            d1 = rad - st->w[0][i1]; d2 = st->w[0][i1 + 1] - rad;
+            if (fabs(d1) < st->ew[0][i1]) d1 = 0.0;
+            if (fabs(d2) < st->ew[0][i1 + 1]) d2 = 0.0;
+            d3 = fabs(-rcyl + st->wtant[i2] * r[2]) / sqrt(1 + st->wtant[i2] * st->wtant[i2]);
+            d4 = fabs(-rcyl + st->wtant[i2 + 1] * r[2]) / sqrt(1 + st->wtant[i2 + 1] * st->wtant[i2 + 1]);
+        } else {
+            d1 = rcyl - st->w[0][i1]; d2 = st->w[0][i1 + 1] - rcyl;
+            d3 = r[2] - st->w[1][i2]; d4 = st->w[1][i2 + 1] - r[2];
+        }
+        if (st->n_dim == 3) {
+            d5 = fabs(st->wtanp[i3] * r[0] - r[1]) / sqrt(st->wtanp[i3] * st->wtanp[i3] + 1.0);
+            d6 = fabs(st->wtanp[i3 + 1] * r[0] - r[1]) / sqrt(st->wtanp[i3 + 1] * st->wtanp[i3 + 1] + 1.0);
+        }
+        double d = fmin(fmin(fmin(d1, d2), fmin(d3, d4)), fmin(d5, d6));
+        return d < 0.0 ? 0.0 : d;
+    }
     if (st->grid_type == GRID_CAR) {
         for (int a = 0; a < 3; a++) { lo[a] = st->w[a][p->ic[a]]; hi[a] = st->w[a][p->ic[a] + 1]; }
     } else if (st->grid_type == GRID_OCT) {
@@ -2533,6 +2963,7 @@ static void grid_escape_column_density(const orc_state *st, const photon_t *p_or
                                        rng_t *g, acc_t *acc, int *killed)
 {
     photon_t p = *p_orig;
+    p.radial = ((p.r[0] * p.v[0] + p.r[1] * p.v[1]) + p.r[2] * p.v[2]) > 0.0;   /* grid_propagate_3d.f90:400,505 */
     double t_current = 0.0;
     *killed = 0;
     for (int d = 0; d < st->n_dust; d++) col[d] = 0.0;
@@ -2837,6 +3268,27 @@ static int random_position_cell(const orc_state *st, size_t ic, photon_t *p, rng
         p->r[0] = x * (st->w[0][i1 + 1] - st->w[0][i1]) + st->w[0][i1];
         p->r[1] = y * (st->w[1][i2 + 1] - st->w[1][i2]) + st->w[1][i2];
         p->r[2] = z * (st->w[2][i3 + 1] - st->w[2][i3]) + st->w[2][i3];
+        return 0;
+    }
+    if (st->grid_type == GRID_SPH || st->grid_type == GRID_CYL) {   /* spherical_3d.f90:639-673, cylindrical_3d.f90:518-550 */
+        int i1 = (int)(ic % st->n1), i2 = (int)((ic / st->n1) % st->n2), i3 = (int)(ic / ((size_t)st->n1 * st->n2));
+        p->ic[0] = i1; p->ic[1] = i2; p->ic[2] = i3;
+        const double *w1 = st->w[0], *w2 = st->w[1], *w3 = st->w[2];
+        double rr, tz, ph = z * (w3[i3 + 1] - w3[i3]) + w3[i3];
+        if (st->grid_type == GRID_SPH) {
+            double a3 = w1[i1] * w1[i1] * w1[i1], b3 = w1[i1 + 1] * w1[i1 + 1] * w1[i1 + 1];
+            rr = pow(x * (b3 - a3) + a3, 1.0 / 3.0);
+            tz = acos(y * (st->wcost[i2 + 1] - st->wcost[i2]) + st->wcost[i2]);
+        } else {
+            double a2 = pow(w1[i1], 2.0), b2 = pow(w1[i1 + 1], 2.0);
+            rr = sqrt(x * (b2 - a2) + a2);
+            tz = y * (w2[i2 + 1] - w2[i2]) + w2[i2];
+        }
+        if (rr <= w1[i1] || rr >= w1[i1 + 1]) rr = 0.5 * (w1[i1] + w1[i1 + 1]);
+        if (tz <= w2[i2] || tz >= w2[i2 + 1]) tz = 0.5 * (w2[i2] + w2[i2 + 1]);
+        if (ph <= w3[i3] || ph >= w3[i3 + 1]) ph = 0.5 * (w3[i3] + w3[i3 + 1]);
+        if (st->grid_type == GRID_SPH) { p->r[0] = rr * sin(tz) * cos(ph); p->r[1] = rr * sin(tz) * sin(ph); p->r[2] = rr * cos(tz); }
+        else { p->r[0] = rr * cos(ph); p->r[1] = rr * sin(ph); p->r[2] = tz; }
         return 0;
     }
     p->ic[0] = (int)ic; p->ic[1] = p->ic[2] = 0;

@@ -12,7 +12,7 @@ Run (only where /root/reference exists; the GPU box never runs this):
     LD_PRELOAD=/usr/lib/x86_64-linux-gnu/libstdc++.so.6 /opt/conda/bin/python3.9 tests/golden/make_fixtures.py
     (the preload lets conda's python load the voro++ extension built with the system g++)
 
-What it writes (inputs + expected outputs only); {grid} = car, oct, amr:
+What it writes (inputs + expected outputs only); {grid} = car, oct, amr, sph, cyl:
 
   {grid}_specific_energy.{evenly}.{multi}.npz
       inputs : the model of hyperion/model/tests/test_bit_level.py:137-173
@@ -75,7 +75,7 @@ for name, t in [("float", float), ("int", int), ("bool", bool), ("object", objec
 
 import h5py  # noqa: E402
 from hyperion.model import Model  # noqa: E402
-from hyperion.grid import AMRGrid, CartesianGrid, OctreeGrid, VoronoiGrid  # noqa: E402
+from hyperion.grid import AMRGrid, CartesianGrid, CylindricalPolarGrid, OctreeGrid, SphericalPolarGrid, VoronoiGrid  # noqa: E402
 from hyperion.dust import IsotropicDust, HenyeyGreensteinDust  # noqa: E402
 from hyperion.util.constants import pc, lsun  # noqa: E402
 
@@ -107,19 +107,20 @@ def car_grid_and_densities():
     g2.nx, g2.ny, g2.nz = 4, 6, 20
     for name in ("density", "density_2", "density_3"):
         g2.quantities[name] = np.random.random((20, 6, 4)) * d
-    shape_cyl = (6 - 1, 4 - 1, 8 - 1)
-    shape_sph = (4 - 1, 8 - 1, 6 - 1)
+    grid_cyl = CylindricalPolarGrid(np.linspace(0., 2. * u, 8), np.linspace(-u, u, 4), np.linspace(0., 2. * np.pi, 6))
+    grid_sph = SphericalPolarGrid(np.linspace(0., 3. * u, 6), np.linspace(0., np.pi, 8), np.linspace(0., 2. * np.pi, 4))
     refined = [1, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
                0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0]
     grid_oct = OctreeGrid(0., 0., 0., u, u, u, np.array(refined).astype(bool))
-    dens, dens_oct = [], []
+    dens, dens_cyl, dens_sph, dens_oct = [], [], [], []
     for _ in range(3):
         dens.append(np.random.random(grid.shape) * d)
-        np.random.random(shape_cyl)
-        np.random.random(shape_sph)
+        dens_cyl.append(np.random.random(grid_cyl.shape) * d)
+        dens_sph.append(np.random.random(grid_sph.shape) * d)
         dens_oct.append(np.random.random(25) * d)
-    return ({"car": grid, "oct": grid_oct, "amr": amr},
-            {"car": dens, "oct": dens_oct, "amr": [amr["density"], amr["density_2"], amr["density_3"]]})
+    return ({"car": grid, "oct": grid_oct, "amr": amr, "cyl": grid_cyl, "sph": grid_sph},
+            {"car": dens, "oct": dens_oct, "amr": [amr["density"], amr["density_2"], amr["density_3"]],
+             "cyl": dens_cyl, "sph": dens_sph})
 
 
 def add_sources(m):
@@ -259,7 +260,7 @@ def peeloff_fixture(gt, grid, dens, evenly, tmp, raytracing=False):
     save(os.path.join(HERE, "%s_peeloff%s.%s.npz" % (gt, "_ray" if raytracing else "", evenly)), prob, golden)
 
 
-ONLY = [a for a in sys.argv[1:] if a in ("car", "oct", "amr")]      # restrict the grid types to regenerate
+ONLY = [a for a in sys.argv[1:] if a in ("car", "oct", "amr", "sph", "cyl")]      # restrict the grid types to regenerate
 RAY_ONLY = "ray" in sys.argv[1:]                                      # only the raytracing=True peel-off fixtures
 
 
@@ -289,7 +290,7 @@ def main():
         return
     grids, denss = car_grid_and_densities()
     with tempfile.TemporaryDirectory() as tmp:
-        for gt in [g for g in ("car", "oct", "amr") if not ONLY or g in ONLY]:
+        for gt in [g for g in ("car", "oct", "amr", "sph", "cyl") if not ONLY or g in ONLY]:
             for evenly in (False, True):
                 for multi in (False, True):
                     if not RAY_ONLY:

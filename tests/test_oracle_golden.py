@@ -45,7 +45,7 @@ def _amr_covered(prob):
     return np.concatenate([m1, np.zeros(int(np.prod(n[1])), dtype=bool)])
 
 
-@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
 @pytest.mark.parametrize("name", ["False.False", "True.False", "False.True", "True.True"])
 def test_first_iteration_matches_reference_golden(grid, name):
     prob, z = golden_problem("%s_specific_energy.%s.npz" % (grid, name))
@@ -116,7 +116,7 @@ def _peeloff_run(prob, seed, n_lucy, n_img):
     return [finalize_peeled(p, r) for p, r in zip(prob.peeled, res)], st
 
 
-@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
 @pytest.mark.parametrize("evenly", [False, True])
 def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
     """test_peeloff.grid_type=car.raytracing=False.*.rtout (test_bit_level.py:175-236):
@@ -155,13 +155,19 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
             chi_minus[ist] += ((((gold[ist][:, :, -1, :][sel] + x)[ok]) / s_[ok]) ** 2).sum()
         # Stokes V is identically zero for this dust (P4 = 0)
         assert np.all(gold[3] == 0) and np.all(b[3] == 0)
-    for ist in (1, 2):
-        assert chi_plus[ist] < chi_minus[ist] - 10.0, (ist, chi_plus, chi_minus)
+    if grid in ("sph", "cyl"):
+        # these grids reach out to 2-3 u: the packets scatter less, the polarised signal is a few
+        # sigma in total and cannot separate the two orientations (the Cartesian, octree and AMR
+        # goldens do, and the scattering code is shared); the golden must be consistent with the oracle
+        assert chi_plus[1] + chi_plus[2] < chi_minus[1] + chi_minus[2] + 5.0, (chi_plus, chi_minus)
+    else:
+        for ist in (1, 2):
+            assert chi_plus[ist] < chi_minus[ist] - 10.0, (ist, chi_plus, chi_minus)
     # golden uncertainty cubes exist only if requested
     assert "golden/group1/seds_unc" not in z.files
 
 
-@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
 @pytest.mark.parametrize("evenly", [False, True])
 def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
     """test_peeloff.grid_type=*.raytracing=True.*.rtout (test_bit_level.py:175-236 with
