@@ -145,7 +145,9 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
         # all bins of the 4 peel-off goldens; the two views share those photons)
         assert np.abs(zI).max() < 5.0 and (zI ** 2).mean() < 4.0
         # total flux over all bins of the largest aperture, and summed images
-        assert gold[0][:, :, -1, :].sum() == pytest.approx(I.sum(), rel=0.06)
+        # (sph / evenly: the total of a 5e3-packet realisation scatters by 4.7 %; the golden sits 1.4 sigma up)
+        sig_tot = np.std([s[g]["seds"][0][:, :, -1, :].sum() for s in samples], ddof=1)
+        assert abs(gold[0][:, :, -1, :].sum() - I.sum()) < max(0.06 * I.sum(), 3.0 * sig_tot)
         gi = z["golden/group%d/images" % (g + 1)][0]
         assert gi.sum() == pytest.approx(big[g]["images"][0].sum(), rel=0.08)
         for ist in (1, 2):
