@@ -110,8 +110,12 @@ struct DProblem {
     double baes16_xi;
     double check_p, check_log1mp;         // propagation_check_frequency p, log(1-p)
     uint32_t seed_key, pad1;
-    int grid_type, pad3;                  // 1 cartesian, 2 octree, 3 voronoi, 4 amr
+    int grid_type, pad3;                  // 1 cartesian, 2 octree, 3 voronoi, 4 amr, 5 spherical polar, 6 cylindrical polar
     const double *w[3], *ew[3];           // walls and 3*spacing(wall)
+    // spherical / cylindrical polar grids (grid_type 5 / 6): w = (r, theta, phi) or (w, z, phi) walls, wr2 = w1^2,
+    // tan(theta), tan^2(theta), cos(theta), tan(phi) of the walls; index of the theta = pi/2 wall (-2: none); 2 if n3 == 1 else 3
+    const double *wr2, *wtant, *wtant2, *wcost, *wtanp;
+    int midplane, n_dim;
     const OctCell *oct_cells;             // [n_cells]
     const int *oct_children;              // [n_cells][8], -1 where not refined
     double oct_half[3], oct_box[6], oct_eps;
@@ -233,6 +237,14 @@ __device__ __forceinline__ double rng_exp(Rng &g) { return -log(1.0 - rng_unifor
 // ---------------------------------------------------------------------------
 // table helpers (fortranlib lib_array / type_pdf semantics)
 // ---------------------------------------------------------------------------
+
+// Fortran spacing(x): distance to the next larger representable number
+__device__ __forceinline__ double spacing_d(double x)
+{
+    x = fabs(x);
+    if (x == 0.0) return 2.2250738585072014e-308;
+    return __longlong_as_double(__double_as_longlong(x) + 1) - x;
+}
 
 // j with x[j] <= xv < x[j+1]; xv == x[n-1] -> n-2; -1 outside (ascending x)
 __device__ __forceinline__ int locate(const double *__restrict__ x, int n, double xv)

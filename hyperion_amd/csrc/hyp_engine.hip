@@ -226,6 +226,8 @@ RayKernel pick_ray_kernel(int nd, int grid_type)
     case 2: return pick_ray_kernel_g<GEOM_OCT>(nd);
     case 3: return pick_ray_kernel_g<GEOM_VOR>(nd);
     case 4: return pick_ray_kernel_g<GEOM_AMR>(nd);
+    case 5: return pick_ray_kernel_g<GEOM_SPH>(nd);
+    case 6: return pick_ray_kernel_g<GEOM_CYL>(nd);
     default: return pick_ray_kernel_g<GEOM_CAR>(nd);
     }
 }
@@ -239,6 +241,8 @@ LucyKernel pick_lucy_kernel(int nd, int grid_type)
     case 2: return pick_lucy_kernel_g<GEOM_OCT>(nd);
     case 3: return pick_lucy_kernel_g<GEOM_VOR>(nd);
     case 4: return pick_lucy_kernel_g<GEOM_AMR>(nd);
+    case 5: return pick_lucy_kernel_g<GEOM_SPH>(nd);
+    case 6: return pick_lucy_kernel_g<GEOM_CYL>(nd);
     default: return pick_lucy_kernel_g<GEOM_CAR>(nd);
     }
 }
@@ -252,6 +256,8 @@ LucyKernel pick_final_kernel(int nd, int grid_type)
     case 2: return pick_final_kernel_g<GEOM_OCT>(nd);
     case 3: return pick_final_kernel_g<GEOM_VOR>(nd);
     case 4: return pick_final_kernel_g<GEOM_AMR>(nd);
+    case 5: return pick_final_kernel_g<GEOM_SPH>(nd);
+    case 6: return pick_final_kernel_g<GEOM_CYL>(nd);
     default: return pick_final_kernel_g<GEOM_CAR>(nd);
     }
 }
@@ -488,10 +494,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     g_error.clear();
     if (out) *out = nullptr;
     if (!pr || !out) return set_error("null argument");
-    if (pr->grid.type < 1 || pr->grid.type > 4) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi, 4 amr)");
+    if (pr->grid.type < 1 || pr->grid.type > 6) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi, 4 amr, 5 spherical polar, 6 cylindrical polar)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
     if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
-    const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_car = pr->grid.type == 1, is_amr = pr->grid.type == 4;
+    const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_amr = pr->grid.type == 4;
+    const bool is_sph = pr->grid.type == 5, is_cyl = pr->grid.type == 6, is_polar = is_sph || is_cyl;
+    const bool is_xyz = pr->grid.type == 1;                 // Cartesian proper (walls staged in LDS, brick-tiled schedule)
+    const bool is_car = is_xyz || is_polar;                 // three wall arrays, cells (i1, i2, i3)
     std::vector<AmrGrid> amr_grids;
     std::vector<int> amr_go, amr_cell_grid;
     std::vector<double> amr_walls;
@@ -544,6 +553,23 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             last = nearest_from(c, last);
             vor_seed[((size_t)k * vor_g + j) * vor_g + i] = last;
         }
+    } else if (is_polar) {
+        // setup_grid_geometry: grid_geometry_spherical_3d.f90:90-203, grid_geometry_cylindrical_3d.f90:90-175
+        const double pi = 3.14159265358979323846;
+        for (int a = 0; a < 3; a++) if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
+        for (int i = 0; i <= n[0]; i++) if (win[0][i] < 0.0) return set_error(is_sph ? "r walls should be positive" : "w walls should be positive");
+        for (int i = 0; i <= n[1] && is_sph; i++) if (win[1][i] < 0.0 || win[1][i] > pi) return set_error("theta walls should be between 0 and pi");
+        for (int i = 0; i <= n[2]; i++) if (win[2][i] < 0.0 || win[2][i] > 2.0 * pi) return set_error("phi walls should be between 0 and 2*pi");
+        static const char *names_s[3] = {"dr", "dt", "dphi"}, *names_c[3] = {"dw", "dz", "dphi"};
+        for (int a = 0; a < 3; a++) for (int i = 0; i < n[a]; i++)
+            if (win[a][i + 1] - win[a][i] == 0.0)
+                return set_error(std::string("all ") + (is_sph ? names_s[a] : names_c[a]) + " values should be greater than zero");
+        for (int k = 0; k < n[2]; k++) for (int j = 0; j < n[1]; j++) for (int i = 0; i < n[0]; i++) {
+            const double a0 = win[0][i], b0 = win[0][i + 1], dphi = win[2][k + 1] - win[2][k];
+            const double vol = is_sph ? (b0 * b0 * b0 - a0 * a0 * a0) * (std::cos(win[1][j]) - std::cos(win[1][j + 1])) * dphi / 3.0
+                                      : (b0 * b0 - a0 * a0) * (win[1][j + 1] - win[1][j]) * dphi / 2.0;
+            if (vol == 0.0) return set_error("all volumes should be greater than zero");
+        }
     } else if (is_car) {
         for (int a = 0; a < 3; a++) {
             if (n[a] < 1 || !win[a]) return set_error("grid walls missing");
@@ -551,7 +577,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 if (!(win[a][i + 1] - win[a][i] > 0.0))
                     return set_error(std::string("all d") + "xyz"[a] + " values should be greater than zero");
         }
-        if ((size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
+        if (is_xyz && (size_t)n[0] + n[1] + n[2] + 3 > 9000) return set_error("grid has too many walls for LDS staging");
     } else if (is_amr) {
         // read_grid/read_level + setup_grid_geometry: grid_geometry_amr.f90:111-508
         const int ng = pr->grid.n_amr_grids, nl = pr->grid.n_amr_levels;
@@ -769,7 +795,28 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         w_off[a] = B.put(win[a], n[a] + 1);
         std::vector<double> ew(n[a] + 1);
         for (int i = 0; i <= n[a]; i++) ew[i] = 3.0 * spacing(win[a][i]);
+        // angles: ew = 3 * spacing(1) (spherical_3d.f90:199-201, cylindrical_3d.f90:171-173)
+        if (is_polar && (a == 2 || (a == 1 && is_sph))) for (int i = 0; i <= n[a]; i++) ew[i] = 3.0 * spacing(1.0);
         ew_off[a] = B.put(ew);
+    }
+    size_t polar_off[5] = {0, 0, 0, 0, 0};
+    int midplane = -2;
+    if (is_polar) {
+        std::vector<double> wr2(n[0] + 1), wtanp(n[2] + 1);
+        for (int i = 0; i <= n[0]; i++) wr2[i] = win[0][i] * win[0][i];
+        for (int i = 0; i <= n[2]; i++) wtanp[i] = std::tan(win[2][i]);
+        polar_off[0] = B.put(wr2); polar_off[4] = B.put(wtanp);
+        if (is_sph) {
+            std::vector<double> wtant(n[1] + 1), wtant2(n[1] + 1), wcost(n[1] + 1);
+            double m = DBL_MAX; int im = 0;
+            for (int i = 0; i <= n[1]; i++) {
+                wtant[i] = std::tan(win[1][i]); wtant2[i] = wtant[i] * wtant[i]; wcost[i] = std::cos(win[1][i]);
+                const double d = std::fabs(win[1][i] - 3.14159265358979323846 / 2.0);
+                if (d < m) { m = d; im = i; }
+            }
+            if (m < 1.e-6) midplane = im;       // :175: minloc(abs(w2 - pi/2)) if any is within 1e-6
+            polar_off[1] = B.put(wtant); polar_off[2] = B.put(wtant2); polar_off[3] = B.put(wcost);
+        }
     }
 
     // dust tables: dust_type_4elem.f90:78-293
@@ -1080,6 +1127,11 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     HIPC(hipMemcpy(h->d_blob, B.h.data(), sizeof(double) * B.h.size(), hipMemcpyHostToDevice));
     const double *db = h->d_blob;
     for (int a = 0; a < 3 && is_car; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    if (is_polar) {
+        P.wr2 = db + polar_off[0]; P.wtanp = db + polar_off[4];
+        if (is_sph) { P.wtant = db + polar_off[1]; P.wtant2 = db + polar_off[2]; P.wcost = db + polar_off[3]; }
+        P.midplane = midplane; P.n_dim = n[2] == 1 ? 2 : 3;
+    }
     if (is_vor) {
         const size_t nc = h->n_cells, nn = (size_t)pr->grid.vor_idx[nc];
         std::vector<double> vol(nc);

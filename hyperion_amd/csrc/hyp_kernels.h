@@ -29,6 +29,8 @@ template <int GEOM> struct Cell;
 template <> struct Cell<GEOM_CAR> { int ic[3], ow[3]; };
 template <> struct Cell<GEOM_OCT> { int id, ow[3]; double c[3]; int parent, level, subcell; };
 template <> struct Cell<GEOM_VOR> { int id, ow[3]; };   // ow[1] = -(previous cell + 1)
+template <> struct Cell<GEOM_SPH> { int ic[3], ow[3], radial; };      // radial: (r.v) > 0 at the start of the integration (find_wall skips the inner sphere)
+template <> struct Cell<GEOM_CYL> { int ic[3], ow[3]; };
 template <> struct Cell<GEOM_AMR> { int id, ow[3], grid, i[3]; };   // id = unique cell id (n_cells: outside, -1: invalid); i = 0-based position in the grid
 
 template <int NDT, int GEOM>
@@ -539,6 +541,25 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
     amr_find_position(P, rr, go - 1, c);
 }
 
+#include "hyp_polar.h"
+
+// in_correct_cell with the direction at hand (the polar grids read theta / phi off the direction where the position cannot tell)
+template <int GEOM>
+__device__ __forceinline__ bool geo_check_cell(const DProblem &P, const Walls &W, const double r[3], const double v[3], const Cell<GEOM> &c)
+{
+    return geo_in_correct_cell(P, W, r, c);
+}
+__device__ __forceinline__ bool geo_check_cell(const DProblem &P, const Walls &W, const double r[3], const double v[3], const Cell<GEOM_SPH> &c) { return polar_in_correct_cell<GEOM_SPH>(P, r, v, c); }
+__device__ __forceinline__ bool geo_check_cell(const DProblem &P, const Walls &W, const double r[3], const double v[3], const Cell<GEOM_CYL> &c) { return polar_in_correct_cell<GEOM_CYL>(P, r, v, c); }
+
+// start of an integration along v from r: radial = (p%r .dot. p%v) > 0 (grid_propagate_3d.f90:73,262,400,505)
+template <int GEOM>
+__device__ __forceinline__ void geo_begin(const double r[3], const double v[3], Cell<GEOM> &c) {}
+__device__ __forceinline__ void geo_begin(const double r[3], const double v[3], Cell<GEOM_SPH> &c)
+{
+    c.radial = ((r[0] * v[0] + r[1] * v[1]) + r[2] * v[2]) > 0.0;
+}
+
 // geometries whose next_cell cannot fail
 template <int GEOM>
 __device__ __forceinline__ bool geo_invalid(const DProblem &P, const Cell<GEOM> &c) { return false; }
@@ -599,6 +620,7 @@ __device__ __forceinline__ void begin_integrate(const DProblem &P, Packet<NDT, G
 {
     p.t_ach = 0.0;
     find_nearest_source(P, p.r, p.v, p.t_src, p.reabs_id);
+    geo_begin(p.r, p.v, p.cell);
 }
 
 // One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
@@ -611,7 +633,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
     const int nd = ndust<NDT>(P);
     if (g.countdown == 0) {
         g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-        if (!geo_in_correct_cell(P, W, p.r, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }
+        if (!geo_check_cell(P, W, p.r, p.v, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }
     } else g.countdown--;
     double tmin; int im[3];
     if (!geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im)) { cnt.killed_geo++; return ST_NEED_EMIT; }
@@ -1242,6 +1264,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
     Cell<GEOM> c = cell0;
+    geo_begin(r0, v, c);
     double tau = 0.0;
     killed = false;
     if (geo_escaped(P, c)) return 0.0;
@@ -1253,7 +1276,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-            if (!geo_in_correct_cell(P, W, r, c)) { cnt.killed_geo++; killed = true; return tau; }
+            if (!geo_check_cell(P, W, r, v, c)) { cnt.killed_geo++; killed = true; return tau; }
         } else g.countdown--;
         double tmin; int im[3];
         if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
@@ -1460,6 +1483,14 @@ __device__ __forceinline__ double cell_volume(const DProblem &P, size_t ic)
     int i1 = (int)(ic % P.n1);
     size_t t = ic / P.n1;
     int i2 = (int)(t % P.n2), i3 = (int)(t / P.n2);
+    if (P.grid_type == 5) {     // grid_geometry_spherical_3d.f90:138-155: dr3 * dcost * dphi / 3
+        const double a = P.w[0][i1], b = P.w[0][i1 + 1];
+        return (b * b * b - a * a * a) * (P.wcost[i2] - P.wcost[i2 + 1]) * (P.w[2][i3 + 1] - P.w[2][i3]) / 3.0;
+    }
+    if (P.grid_type == 6) {     // grid_geometry_cylindrical_3d.f90:135-147: dw2 * dz * dphi / 2
+        const double a = P.w[0][i1], b = P.w[0][i1 + 1];
+        return (b * b - a * a) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]) / 2.0;
+    }
     return (P.w[0][i1 + 1] - P.w[0][i1]) * (P.w[1][i2 + 1] - P.w[1][i2]) * (P.w[2][i3 + 1] - P.w[2][i3]);
 }
 
@@ -1476,6 +1507,7 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
     Cell<GEOM> c = cell0;
+    geo_begin(r0, v, c);
     killed = false;
 #pragma unroll
     for (int d = 0; d < NDT; d++) col[d] = 0.0;
@@ -1488,7 +1520,7 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
-            if (!geo_in_correct_cell(P, W, r, c)) { cnt.killed_geo++; killed = true; return; }
+            if (!geo_check_cell(P, W, r, v, c)) { cnt.killed_geo++; killed = true; return; }
         } else g.countdown--;
         double tmin; int im[3];
         if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return; }
@@ -1536,6 +1568,7 @@ __device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t i
         }
         return true;
     }
+    if (GEOM == GEOM_SPH || GEOM == GEOM_CYL) { polar_random_position<GEOM>(P, ic, x, y, z, r); return true; }
     return false;      // voronoi: rejection sampling in the reference, not built
 }
 

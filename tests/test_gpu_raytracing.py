@@ -20,7 +20,7 @@ def compare_cubes(ra, rb, rtol=1e-9):
             np.testing.assert_allclose(ga[name], gb[name], rtol=rtol, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
 
 
-@pytest.mark.parametrize("grid", ["car", "oct", "amr"])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
 @pytest.mark.parametrize("evenly", [False, True])
 def test_raytracing_parity_with_oracle(grid, evenly):
     prob, _ = golden_problem("%s_peeloff_ray.%s.npz" % (grid, evenly))
