@@ -59,7 +59,8 @@ class Config(C.Structure):
         ("forced_first_interaction", C.c_int32), ("forced_first_interaction_algorithm", C.c_int32),
         ("specific_energy_type", C.c_int32), ("raytracing", C.c_int32),
         ("baes16_xi", C.c_double), ("propagation_check_frequency", C.c_double),
-        ("n_inter_mrw_max", C.c_int64), ("mrw_gamma", C.c_double), ("mrw", C.c_int32), ("reserved1", C.c_int32),
+        ("n_inter_mrw_max", C.c_int64), ("mrw_gamma", C.c_double), ("mrw", C.c_int32), ("monochromatic", C.c_int32),
+        ("monochromatic_energy_threshold", C.c_double), ("frequencies", _dp), ("n_frequencies", C.c_int32), ("reserved2", C.c_int32),
     ]
 
 
@@ -72,7 +73,7 @@ class PeeledDesc(C.Structure):
         ("x_min", C.c_double), ("x_max", C.c_double), ("y_min", C.c_double), ("y_max", C.c_double),
         ("ap_min", C.c_double), ("ap_max", C.c_double), ("nu_min", C.c_double), ("nu_max", C.c_double),
         ("d_min", C.c_double), ("d_max", C.c_double), ("peeloff_origin", C.c_double * 3),
-        ("theta", _dp), ("phi", _dp),
+        ("theta", _dp), ("phi", _dp), ("inu_min", C.c_int32), ("inu_max", C.c_int32),
     ]
 
 
@@ -184,6 +185,11 @@ class MarshalledProblem:
         d.config.mrw_gamma = float(c.mrw_gamma)
         d.config.n_inter_mrw_max = int(c.n_inter_mrw_max)
         d.config.baes16_xi = float(c.baes16_xi)
+        d.config.monochromatic = int(bool(c.monochromatic))
+        d.config.monochromatic_energy_threshold = float(c.monochromatic_energy_threshold)
+        if c.monochromatic:
+            d.config.frequencies = arr(c.frequencies)
+            d.config.n_frequencies = int(np.asarray(c.frequencies).size)
         d.config.propagation_check_frequency = float(c.propagation_check_frequency)
 
         nd = prob.n_dust
@@ -268,6 +274,7 @@ class MarshalledProblem:
                 x.peeloff_origin[k] = float(p.peeloff_origin[k])
             x.theta = arr(p.theta)
             x.phi = arr(p.phi)
+            x.inu_min, x.inu_max = int(p.inu_min), int(p.inu_max)
         keep(pls)
         d.n_peeled = npl
         d.peeled = C.cast(pls, C.POINTER(PeeledDesc))

@@ -123,6 +123,9 @@ class PeeledImages:
     d_min: float = -np.inf
     d_max: float = np.inf
     peeloff_origin: tuple = (0.0, 0.0, 0.0)
+    # monochromatic mode: 1-based range of RunConfig.frequencies imaged by this group (image_type.f90:243-258)
+    inu_min: int = 0
+    inu_max: int = 0
 
     def __post_init__(self):
         self.theta = _f64(np.atleast_1d(self.theta))
@@ -172,7 +175,11 @@ class RunConfig:
     mrw_gamma: float = 1.0             # src/main/setup_rt.f90:106-113
     n_inter_mrw_max: int = 1000
     pda: bool = False
-    monochromatic: bool = False
+    monochromatic: bool = False        # src/main/setup_rt.f90:49-57,220-222: use_exact_nu with the /frequencies table
+    frequencies: Optional[np.ndarray] = None
+    monochromatic_energy_threshold: float = 1.0e-10
+    n_last_photons_sources: int = 0
+    n_last_photons_dust: int = 0
     raytracing: bool = False
 
 
@@ -248,6 +255,14 @@ class Problem:
             raise ValueError("Unexpected coordinate type: %s" % self.grid_type)
         if self.density.shape != want:
             raise ValueError("density array has wrong shape %r, expected %r" % (self.density.shape, want))
+        if self.config.monochromatic:
+            if self.config.frequencies is None or len(self.config.frequencies) < 1:
+                raise ValueError("monochromatic mode needs RunConfig.frequencies")
+            self.config.frequencies = _f64(self.config.frequencies)
+            for pl in self.peeled:
+                if pl.inu_min == 0 and pl.inu_max == 0:
+                    pl.inu_min, pl.inu_max = 1, self.config.frequencies.size
+                pl.n_wav = pl.inu_max - pl.inu_min + 1
         if self.specific_energy is not None:
             self.specific_energy = _f64(self.specific_energy)
             if self.specific_energy.shape != self.density.shape:
@@ -322,10 +337,12 @@ class Problem:
         library entry is stored as a reference to that sibling .npz file."""
         arrays = {}
         meta = {"grid_type": self.grid_type, "geometry_id": self.geometry_id,
-                "config": self.config.__dict__, "dust": [], "sources": [], "peeled": [],
+                "config": {k: v for k, v in self.config.__dict__.items() if k != "frequencies"}, "dust": [], "sources": [], "peeled": [],
                 "oct_center": list(self.oct_center), "oct_half": list(self.oct_half), "vor_box": list(self.vor_box)}
         for i, w in enumerate(self.walls):
             arrays["walls_%d" % (i + 1)] = w
+        if self.config.frequencies is not None:
+            arrays["config/frequencies"] = np.asarray(self.config.frequencies, dtype=float)
         if self.refined is not None:
             arrays["refined"] = self.refined
         for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds"):
@@ -409,6 +426,8 @@ class Problem:
                 kw["peeloff_origin"] = tuple(kw["peeloff_origin"])
             peeled.append(PeeledImages(**kw))
         cfg = RunConfig(**meta["config"])
+        if "config/frequencies" in z.files:
+            cfg.frequencies = z["config/frequencies"]
         walls = [z[k] for k in ("walls_1", "walls_2", "walls_3") if k in z.files]
         return cls(walls=walls, density=z["density"],
                    dust=dust, sources=sources, config=cfg, peeled=peeled,

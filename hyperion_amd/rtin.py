@@ -90,6 +90,12 @@ def read_rtin(path):
         cfg.pda = _b(a["pda"])
         cfg.monochromatic = _b(a["monochromatic"])
         cfg.raytracing = _b(a["raytracing"])
+        if cfg.monochromatic:       # src/main/setup_rt.f90:49-57,220-222; hyperion/model/model.py:133-137
+            cfg.frequencies = np.asarray(f["frequencies"][...]["nu"], dtype=float)
+            cfg.monochromatic_energy_threshold = float(a["monochromatic_energy_threshold"]) \
+                if "monochromatic_energy_threshold" in a else 1.0e-10
+            cfg.n_last_photons_sources = int(a["n_last_photons_sources"]) if "n_last_photons_sources" in a else 0
+            cfg.n_last_photons_dust = int(a["n_last_photons_dust"]) if "n_last_photons_dust" in a else 0
         cfg.n_last_photons = int(a["n_last_photons"]) if "n_last_photons" in a else 0
         if cfg.raytracing:
             cfg.n_ray_photons_sources = int(a["n_ray_photons_sources"]) if "n_ray_photons_sources" in a else 0
@@ -224,7 +230,10 @@ def read_rtin(path):
                 else:
                     p.peeloff_origin = tuple(float(pa["peeloff_" + k]) for k in "xyz")
                 p.n_wav = int(pa["n_wav"])
-                p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])
+                if cfg.monochromatic:       # image_type.f90:243-258
+                    p.inu_min, p.inu_max = int(pa["inu_min"]), int(pa["inu_max"])
+                else:
+                    p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])
                 p.compute_image = _b(pa["compute_image"])
                 if p.compute_image:
                     p.n_x, p.n_y = int(pa["n_x"]), int(pa["n_y"])

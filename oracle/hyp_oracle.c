@@ -438,6 +438,9 @@ struct orc_state {
     double mrw_x[100], mrw_y[100];              /* cumulative of Min et al. (2009) eq. 6 */
     size_t n_masked; uint32_t *mask_map;   /* valid cells (geo%mask_map of every geometry) */
     orc_config cfg;
+    double *frequencies;        /* copy of cfg.frequencies */
+    /* grid_monochromatic.f90: emission pdf over cells per dust at the current frequency */
+    int mono_inu; double *mono_cdf; double mono_mean_prob[ORC_MAX_DUST];
     double check_p, check_log1mp;
     int n_dust, n_sources, n_peeled;
     dust_t *dust;
@@ -1088,6 +1091,12 @@ int orc_create(const orc_problem *pr, orc_state **out)
     if (pr->n_dust < 0 || pr->n_dust > ORC_MAX_DUST) { snprintf(g_error, sizeof g_error, "n_dust out of range"); return 1; }
     orc_state *st = calloc(1, sizeof(*st));
     st->cfg = pr->config;
+    if (st->cfg.monochromatic) {
+        if (st->cfg.n_frequencies < 1 || !st->cfg.frequencies) { snprintf(g_error, sizeof g_error, "monochromatic mode needs a frequency table"); free(st); return 1; }
+        st->frequencies = dup(st->cfg.frequencies, st->cfg.n_frequencies);
+        st->cfg.frequencies = st->frequencies;
+    }
+    st->mono_inu = -1;
     st->grid_type = pr->grid.type;
     st->check_p = pr->config.propagation_check_frequency;
     st->check_log1mp = (st->check_p > 0.0 && st->check_p < 1.0) ? log1p(-st->check_p) : -1.0;
@@ -1250,6 +1259,7 @@ void orc_destroy(orc_state *st)
 {
     if (!st) return;
     for (int a = 0; a < 3; a++) { free(st->w[a]); free(st->ew[a]); }
+    free(st->frequencies); free(st->mono_cdf);
     free(st->volume); free(st->wr2); free(st->wtanp); free(st->wtant); free(st->wtant2); free(st->wcost);
     free(st->ox); free(st->oy); free(st->oz); free(st->odx); free(st->ody); free(st->odz);
     free(st->orefined); free(st->osubcell); free(st->oparent); free(st->ochildren);
@@ -1285,6 +1295,7 @@ typedef struct {
     int ic[3];          /* 0-based cell indices */
     int on_wall[3];     /* -1 lower wall, +1 upper wall, 0 none */
     int in_cell, killed;
+    int inu;            /* monochromatic: 0-based index into the frequency table */
     int radial;         /* (r.v) > 0 at the start of the current integration: grid_propagate_3d.f90:73 */
     double chi[ORC_MAX_DUST], albedo[ORC_MAX_DUST], kappa[ORC_MAX_DUST];
     int last, last_isotropic, scattered, reprocessed, n_scat, dust_id, source_id, face_id;
@@ -2115,7 +2126,8 @@ static void box_face_normal(int face, angle_t *a)
     a->cost = tab[face][0]; a->sint = tab[face][1]; a->cosp = tab[face][2]; a->sinp = tab[face][3];
 }
 
-static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy);
+static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy, int inu);
+static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy) { return emit_from_nu(st, p, g, acc, reemit_id, reemit_energy, -1); }
 static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc) { return emit_from(st, p, g, acc, -1, 0.0); }
 
 /* ran_mu_limb(a, b): source_type.f90:982-1086 -- mu from the pdf a mu^2 + b mu by the real root of the cubic */
@@ -2172,7 +2184,25 @@ static void find_nearest_source(const orc_state *st, const double r[3], const do
 }
 
 /* emit: source.f90:100-179; reemit_id >= 0 re-emits from that source with the given energy */
-static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy)
+/* interpolate_pdf(pdf, x, bounds_error=.false., fill_value=0) of a log pdf (fortranlib type_pdf): the
+ * normalised pdf interpolated in log-log */
+static double pdf_interp_log(const pdf_t *q, double xv)
+{
+    if (!(xv >= q->x[0]) || !(xv <= q->x[q->n - 1])) return 0.0;
+    return interp1d_loglog(q->x, q->pdf, q->n, xv);
+}
+
+/* normalized_B_nu: source_type.f90:1088-1096 */
+static double normalized_B_nu(double nu, double T)
+{
+    const double a = 2.0 * H_CGS / 29979245800.0 / 29979245800.0 / 5.67051e-5 * PI, b = H_CGS / K_CGS;
+    const double T4 = T * T * T * T;
+    return a * nu * nu * nu / (exp(b * nu / T) - 1.0) / T4;
+}
+
+/* inu >= 0: emit(p, inu=inu), the frequency is frequencies(inu) and the energy carries the
+ * probability of emission there (source_type.f90:440-468, source.f90:145-161) */
+static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy, int inu)
 {
     memset(p, 0, sizeof(*p));
     int is = 0;
@@ -2255,11 +2285,16 @@ static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int
     }
     p->s[0] = 1.0; p->s[1] = p->s[2] = p->s[3] = 0.0;
     p->energy = 1.0;
-    if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
+    p->inu = inu;
+    if (inu >= 0) {
+        p->nu = st->frequencies[inu];
+        p->energy = s->spectrum_type == 1 ? pdf_interp_log(&s->spectrum, p->nu) : normalized_B_nu(p->nu, s->temperature);
+    } else if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
     else p->nu = random_planck_frequency(g, s->temperature);
     angle_to_vector(&p->a, p->v);
     if (reemit_id >= 0) p->energy = reemit_energy;
     else {
+        if (inu >= 0) p->energy = p->energy * st->energy_total;
         if (st->cfg.sample_sources_evenly) p->energy = p->energy * st->lum_pdf[is] * st->n_sources;
         acc->energy_current += p->energy;
     }
@@ -2744,6 +2779,33 @@ static void raytracing_caches(const orc_state *st)
         p->dust_chi = calloc((size_t)(st->n_dust ? st->n_dust : 1) * nn, sizeof(double));
         p->nj_stride = nj_max;
     }
+    if (st->cfg.monochromatic) {
+        /* use_exact_nu: get_spectrum_interp (source_type.f90:1098-1116), get_j_nu_interp and get_chi_nu_interp
+         * (dust_type_4elem.f90:708-720, 780-791) at the group's frequencies */
+        for (int ig = 0; ig < st->n_peeled; ig++) {
+            peeled_t *p = &st->peeled[ig];
+            const int nn = p->d.n_nu;
+            const double *nu = st->frequencies + (p->d.inu_min - 1);
+            for (int is = 0; is < st->n_sources; is++) {
+                const source_t *src = &st->src[is];
+                for (int i = 0; i < nn; i++)
+                    p->src_spec[(size_t)is * nn + i] = src->spectrum_type == 1 ? pdf_interp_log(&src->spectrum, nu[i]) : normalized_B_nu(nu[i], src->temperature);
+            }
+            for (int d = 0; d < st->n_dust; d++) {
+                const dust_t *du = &st->dust[d];
+                for (int j = 0; j < du->n_jnu; j++)
+                    for (int i = 0; i < nn; i++)
+                        p->dust_log10_em[((size_t)d * nj_max + j) * nn + i] = log10(pdf_interp_log(&du->j_nu[j], nu[i]));
+                for (int i = 0; i < nn; i++) {
+                    double c = (nu[i] >= du->nu[0] && nu[i] <= du->nu[du->n_nu - 1]) ? interp1d_loglog(du->nu, du->chi, du->n_nu, nu[i]) : 0.0;
+                    p->dust_chi[(size_t)d * nn + i] = c;
+                }
+            }
+            free(lo[ig]); free(hi[ig]);
+        }
+        free(lo); free(hi);
+        return;
+    }
     /* blackbody tabulated on 100000 points per decade between 3e9 and 3e16 Hz (:1142-1154), once per source */
     const double l0 = log10(3.e9), l1 = log10(3.e16);
     const int nb = (int)ceil((l1 - l0) * 100000);
@@ -2801,6 +2863,11 @@ static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
         /* angle3d_deg(theta, phi) */
         double t = in->theta[i] * PI / 180.0, f = in->phi[i] * PI / 180.0;
         p->view[i].cost = cos(t); p->view[i].sint = sin(t); p->view[i].cosp = cos(f); p->view[i].sinp = sin(f);
+    }
+    if (st->cfg.monochromatic) {    /* image_type.f90:243-258 */
+        if (in->inu_min < 1 || in->inu_min > st->cfg.n_frequencies) { snprintf(g_error, sizeof g_error, "inu_min value is out of range"); return 1; }
+        if (in->inu_max < 1 || in->inu_max > st->cfg.n_frequencies) { snprintf(g_error, sizeof g_error, "inu_max value is out of range"); return 1; }
+        p->d.n_nu = in->inu_max - in->inu_min + 1;
     }
     p->n_stokes = in->compute_stokes ? 4 : 1;
     /* image_type.f90:283-300 */
@@ -2879,7 +2946,8 @@ static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_i
 {
     const peeled_t *pg = &st->peeled[ig];
     const orc_peeled_desc *d = &pg->d;
-    int inu = ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
+    int inu = st->cfg.monochromatic ? p->inu - (d->inu_min - 1)      /* image_type.f90:435-436 */
+                                    : ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
     if (inu < 0 || inu >= d->n_nu) return;
     if (p->energy != p->energy || p->s[0] != p->s[0]) return;   /* :421-429 NaN energy / flux ignored */
     int io = origin_slot(st, pg, p);
@@ -3376,6 +3444,205 @@ int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust,
         stats->killed_geo += b.killed_geo; stats->killed_int += b.killed_int; stats->crossings += b.crossings;
         stats->n_packets += b.n_packets;
     }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* do_final_mono: iter_final_mono.f90:58-343, grid_monochromatic.f90    */
+/* ------------------------------------------------------------------ */
+
+/* dust_sample_emit_probability: dust_type_4elem.f90:356-377 */
+static double dust_sample_emit_probability(const dust_t *d, int id, double frac, double nu)
+{
+    double p1 = pdf_interp_log(&d->j_nu[id], nu), p2 = pdf_interp_log(&d->j_nu[id + 1], nu);
+    if (p1 == 0.0 || p2 == 0.0) return 0.0;
+    double lp = log10(p1) + frac * (log10(p2) - log10(p1));
+    return pow(10.0, lp);
+}
+
+/* setup_monochromatic_grid_pdfs :51-117: per dust type a discrete pdf over ALL cells, weight =
+ * (emission probability at nu) x (energy emitted in the cell x n_cells / energy_abs_tot);
+ * mean_prob = mean of the weights.  Returns 1 if nothing emits at this frequency. */
+static int setup_monochromatic_grid_pdfs(orc_state *st, int inu)
+{
+    const double nu = st->frequencies[inu];
+    const size_t nc = st->n_cells;
+    if (!st->mono_cdf) st->mono_cdf = malloc(sizeof(double) * nc * (st->n_dust ? st->n_dust : 1));
+    double total = 0.0;
+    for (int d = 0; d < st->n_dust; d++) {
+        double *cdf = st->mono_cdf + (size_t)d * nc;
+        double sum = 0.0;
+        for (size_t ic = 0; ic < nc; ic++) {
+            size_t k = (size_t)d * nc + ic;
+            double energy = 0.0;
+            if (st->energy_abs_tot[d] > 0.0)
+                energy = st->specific_energy[k] * st->density[k] * st->volume[ic] * (double)nc / st->energy_abs_tot[d];
+            int valid = 1;
+            if (st->grid_type == GRID_OCT) valid = !st->orefined[ic];
+            else if (st->grid_type == GRID_AMR) valid = !amr_covered(st, ic);
+            else if (st->grid_type == GRID_VOR) valid = st->volume[ic] > 0.0;
+            if (!valid) energy = 0.0;
+            double prob = dust_sample_emit_probability(&st->dust[d], st->jnu_var_id[k], st->jnu_var_frac[k], nu);
+            sum += prob * energy;
+            cdf[ic] = sum;          /* running sum; normalised below (set_pdf of a discrete pdf) */
+        }
+        st->mono_mean_prob[d] = sum / (double)nc;
+        if (sum > 0.0) for (size_t ic = 0; ic < nc; ic++) cdf[ic] /= sum;
+        total += st->mono_mean_prob[d];
+    }
+    st->mono_inu = inu;
+    return total == 0.0;
+}
+
+/* propagate :232-341: like do_final's, with forced scattering (interact(force_scatter=.true.): the
+ * packet keeps its frequency and loses (1 - albedo) of its energy) and the energy threshold */
+static void mono_propagate(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc)
+{
+    const double energy_initial = p->energy;
+    for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
+        double tau;
+        if (inter == 1 && st->cfg.forced_first_interaction) {
+            int killed = 0;
+            double tau_escape = grid_escape_tau(st, p, DBL_MAX, g, acc, &killed);
+            if (tau_escape > 1e-10 && !killed) {
+                double weight, xi = rng_uniform(g);
+                if (st->cfg.forced_first_interaction_algorithm == 2)
+                    forced_interaction_baes16(tau_escape, st->cfg.baes16_xi, xi, &tau, &weight);
+                else
+                    forced_interaction_wr99(tau_escape, xi, &tau, &weight);
+                p->energy *= weight;
+            } else tau = rng_exp(g);
+        } else tau = rng_exp(g);
+        grid_integrate(st, p, tau, g, acc, NULL);
+        if (p->reabsorbed) {     /* :281-313 */
+            int64_t ia;
+            for (ia = 1; ia <= st->cfg.n_reabs_max; ia++) {
+                int rid = p->reabsorbed_id; double re = p->energy; int inu = p->inu;
+                if (emit_from_nu(st, p, g, acc, rid, re, inu)) return;
+                if (st->n_peeled) peeloff_photon(st, p, g, acc, 0);
+                tau = rng_exp(g);
+                grid_integrate(st, p, tau, g, acc, NULL);
+                if (!p->reabsorbed) break;
+            }
+            if (ia == st->cfg.n_reabs_max + 1) { acc->killed_int++; p->killed = 1; break; }
+        }
+        if (p->killed || escaped(st, p->ic)) break;
+        if (inter == st->cfg.n_inter_max + 1) { acc->killed_int++; p->killed = 1; break; }
+        /* interact(p, force_scatter=.true.): dust_interact.f90:22-79 with xi = 0 */
+        {
+            size_t ic = cell_index(st, p->ic);
+            int id = 0;
+            if (st->n_dust > 1) {
+                double cdf[ORC_MAX_DUST], c = 0.0;
+                for (int d = 0; d < st->n_dust; d++) { c += p->chi[d] * st->density[(size_t)d * st->n_cells + ic]; cdf[d] = c; }
+                for (int d = 0; d < st->n_dust; d++) cdf[d] /= c;
+                id = sample_discrete(cdf, st->n_dust, rng_uniform(g));
+            }
+            double albedo = p->albedo[id];
+            p->a_prev = p->a; memcpy(p->v_prev, p->v, sizeof p->v); memcpy(p->s_prev, p->s, sizeof p->s);
+            acc->interactions++;
+            if (0.0 > albedo) { p->killed = 1; break; }     /* cannot happen: albedo >= 0 */
+            dust_scatter(&st->dust[id], p->nu, &p->a, p->s, g);
+            p->scattered = 1; p->last_isotropic = 0; p->dust_id = id; p->last = LAST_DS; p->n_scat++;
+            angle_to_vector(&p->a, p->v);
+            p->energy = p->energy * albedo;
+        }
+        p->killed = (st->cfg.kill_on_scatter && p->scattered) || (p->energy < energy_initial * st->cfg.monochromatic_energy_threshold);
+        if (p->killed) break;
+        if (st->n_peeled) peeloff_photon(st, p, g, acc, 0);
+    }
+}
+
+typedef struct { uint64_t n_total; int inu; } mono_ctx;
+
+/* source part :84-133 */
+static void mono_source_packet(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx)
+{
+    const mono_ctx *c = ctx;
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, 0x40000u + (uint32_t)c->inu, id);
+    if (emit_from_nu(st, &p, &g, acc, -1, 0.0, c->inu)) return;
+    p.energy = p.energy / (double)c->n_total;
+    if (st->n_peeled && !st->cfg.raytracing) peeloff_photon(st, &p, &g, acc, 0);
+    mono_propagate(st, &p, &g, acc);
+}
+
+/* dust part :146-217 with emit_from_monochromatic_grid_pdf (grid_monochromatic.f90:119-174) */
+static void mono_dust_packet(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx)
+{
+    const mono_ctx *c = ctx;
+    rng_t g; photon_t p;
+    rng_init(&g, st->cfg.seed, 0x50000u + (uint32_t)c->inu, id);
+    memset(&p, 0, sizeof p);
+    p.nu = st->frequencies[c->inu]; p.inu = c->inu;
+    if (update_optconsts(st, &p, acc)) return;
+    double xi = rng_uniform(&g);
+    int d = (int)ceil(xi * (double)st->n_dust); if (d < 1) d = 1;
+    d -= 1;
+    if (st->mono_mean_prob[d] == 0.0) return;
+    /* grid_sample_pdf_map: sample_pdf of the discrete pdf = first cell whose cumulative exceeds xi */
+    const double *cdf = st->mono_cdf + (size_t)d * st->n_cells;
+    xi = rng_uniform(&g);
+    size_t lo = 0, hi = st->n_cells - 1;
+    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (xi < cdf[mid]) hi = mid; else lo = mid + 1; }
+    size_t ic = lo;
+    if (random_position_cell(st, ic, &p, &g)) {
+        if (!acc->fatal) { acc->fatal = 1; snprintf(acc->err, sizeof acc->err, "monochromatic dust emission is not available for this grid type"); }
+        return;
+    }
+    p.in_cell = 1;
+    random_sphere_angle(&g, &p.a);
+    angle_to_vector(&p.a, p.v);
+    p.s[0] = 1.0;
+    p.energy = st->mono_mean_prob[d];
+    p.scattered = 0; p.reprocessed = 1; p.last_isotropic = 1; p.dust_id = d; p.last = LAST_DE;
+    p.a_prev = p.a; memcpy(p.s_prev, p.s, sizeof p.s); memcpy(p.v_prev, p.v, sizeof p.v);
+    g.countdown = rng_check_gap(&g, st->check_p, st->check_log1mp);
+    if (p.energy > 0.0) {
+        p.energy = p.energy * st->energy_abs_tot[d] / (double)c->n_total * (double)st->n_dust;
+        if (st->n_peeled && !st->cfg.raytracing) peeloff_photon(st, &p, &g, acc, 0);
+        mono_propagate(st, &p, &g, acc);
+    }
+}
+
+int orc_mono_accumulate(orc_state *st, int which, int inu, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first,
+                        int n_threads, orc_iter_stats *stats)
+{
+    if (!st->cfg.monochromatic) { snprintf(st->err, sizeof st->err, "monochromatic mode was not requested in the configuration"); return 1; }
+    if (inu < 0 || inu >= st->cfg.n_frequencies) { snprintf(st->err, sizeof st->err, "incorrect inu"); return 1; }
+    orc_iter_stats a; memset(&a, 0, sizeof a);
+    if (zero_first)
+        for (int g = 0; g < st->n_peeled; g++) {
+            peeled_t *pg = &st->peeled[g];
+            if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
+            if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
+        }
+    mono_ctx c; c.n_total = n_total; c.inu = inu;
+    if (which == 1) {
+        if (st->n_dust == 0 || setup_monochromatic_grid_pdfs(st, inu)) { if (stats) *stats = a; return 0; }   /* "No emission at this frequency" */
+    }
+    if (n_local > 0 && n_total > 0)
+        if (image_run(st, n_local, n_threads, first_id, which == 0 ? mono_source_packet : mono_dust_packet, &c, 0, &a)) return 1;
+    if (stats) *stats = a;
+    return 0;
+}
+
+int orc_mono_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats)
+{
+    if (!st->cfg.monochromatic) { snprintf(st->err, sizeof st->err, "monochromatic mode was not requested in the configuration"); return 1; }
+    precompute_jnu_var(st);    /* iter_final_mono.f90:79 */
+    orc_iter_stats tot, a; memset(&tot, 0, sizeof tot);
+    int first = 1;
+    for (int which = 0; which < 2; which++) {
+        uint64_t n = which == 0 ? n_sources : n_dust;
+        for (int inu = 0; inu < st->cfg.n_frequencies; inu++) {
+            if (orc_mono_accumulate(st, which, inu, 0, n, n, first, n_threads, &a)) return 1;
+            first = 0;
+            tot.energy_current += a.energy_current; tot.killed_geo += a.killed_geo; tot.killed_int += a.killed_int;
+            tot.crossings += a.crossings; tot.interactions += a.interactions; tot.n_packets += a.n_packets;
+        }
+    }
+    if (stats) *stats = tot;
     return 0;
 }
 

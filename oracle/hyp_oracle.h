@@ -128,7 +128,11 @@ typedef struct orc_config {
     int64_t n_inter_mrw_max;
     double  mrw_gamma;
     int32_t mrw;
-    int32_t reserved1;
+    int32_t monochromatic;           /* root attribute `monochromatic` (use_exact_nu, src/main/setup_rt.f90:49-57) */
+    double  monochromatic_energy_threshold;   /* default 1e-10 */
+    const double *frequencies;       /* [n_frequencies] table /frequencies column nu (setup_rt.f90:220-222) */
+    int32_t n_frequencies;
+    int32_t reserved2;
 } orc_config;
 
 /* One peeled image group (reader: src/images/images_peeled.f90:272-380,
@@ -154,6 +158,7 @@ typedef struct orc_peeled_desc {
     double  peeloff_origin[3];
     const double *theta;     /* [n_view] degrees */
     const double *phi;       /* [n_view] degrees */
+    int32_t inu_min, inu_max; /* monochromatic: 1-based range of config.frequencies this group images (image_type.f90:243-258); n_nu = inu_max - inu_min + 1 */
 } orc_peeled_desc;
 
 typedef struct orc_problem {
@@ -212,6 +217,11 @@ const double *orc_density(const orc_state *st);
 /* do_raytracing (src/main/iter_raytracing.f90:30-143): adds the direct source and the thermal dust
  * emission to the (already scaled) cubes of the last orc_final_iteration. */
 int orc_raytracing_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats);
+/* do_final_mono (src/main/iter_final_mono.f90:58-230): all frequencies, source packets then dust packets; zeroes the cubes */
+int orc_mono_iteration(orc_state *st, uint64_t n_sources, uint64_t n_dust, int n_threads, orc_iter_stats *stats);
+/* one id range of one part (which = 0 sources, 1 dust) at frequency index inu (0-based) */
+int orc_mono_accumulate(orc_state *st, int which, int inu, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first,
+                        int n_threads, orc_iter_stats *stats);
 int orc_raytracing_accumulate(orc_state *st, int which, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first,
                               int n_threads, orc_iter_stats *stats);
 /* writable views of the cubes (tests emulate the all-reduce of the image block) */

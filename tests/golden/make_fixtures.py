@@ -284,9 +284,82 @@ def mrw_fixture():
     print("wrote", out, os.path.getsize(out))
 
 
+def pascucci_fixture(tmp):
+    """test_bit_level.py:341-427 (TestPascucciBenchmark.test_pascucci): flared disc on a 100 x 30 x 1
+    spherical polar grid around a 1 cm stellar sphere, isotropic silicate dust built by the
+    reference test's own setup_class, MONOCHROMATIC final iteration at 61 wavelengths with
+    raytracing, 5 x 1000 + 1000 + 1000 + 1000 + 1000 packets.  golden = Peeled/group_00001/seds of
+    hyperion/model/tests/data/test_pascucci.tau=*.rtout and the last specific energy."""
+    from hyperion.model import AnalyticalYSOModel
+    from hyperion.model.tests.test_bit_level import TestPascucciBenchmark as T
+    from hyperion.util.constants import au, msun, rsun, sigma
+    T.setup_class(T)
+    try:
+        for tau in (0.1, 1, 10, 100):
+            m = AnalyticalYSOModel()
+            m.star.radius = 1.
+            m.star.temperature = 5800.
+            m.star.luminosity = 4. * np.pi * rsun ** 2 * sigma * 5800. ** 4
+            disk = m.add_flared_disk()
+            disk.p = 0.125
+            disk.beta = 1.125
+            disk.mass = 1.113838e-6 * msun * tau
+            disk.rmin = 1. * au
+            disk.rmax = 1000. * au
+            disk.h_0 = 125 * au * np.sqrt(2. / np.pi)
+            disk.r_0 = 500 * au
+            disk.dust = T.dust_file
+            image = m.add_peeled_images()
+            image.set_viewing_angles(np.array([12.5, 42.5, 77.5]), np.array([30.0, 30.0, 30.0]))
+            image.set_image_size(1, 1)
+            image.set_image_limits(-1500. * au, 1500. * au, -1500. * au, 1500. * au)
+            image.set_aperture_radii(1, 1500. * au, 1500. * au)
+            image.set_wavelength_range(61, 1, 61)
+            image.set_stokes(True)
+            m.set_raytracing(True)
+            m.set_n_initial_iterations(5)
+            m.set_spherical_polar_grid_auto(100, 30, 1, rmax=1300. * au)
+            wavelengths = [0.12, 0.14, 0.16, 0.18, 0.2, 0.215, 0.22, 0.23, 0.25,
+                           0.274, 0.3, 0.344, 0.4, 0.44, 0.55, 0.7, 0.9, 1.1,
+                           1.4, 1.65, 2, 2.2, 2.6, 3, 3.2, 3.6, 4, 5, 6, 6.28,
+                           6.3, 6.32, 6.5, 8, 9.5, 10, 11.5, 11.515016,
+                           11.524977, 11.540016, 12, 14, 16, 18, 20, 24, 27.5,
+                           32.5, 37.5, 45, 55, 70, 90, 110, 135, 175, 250, 400,
+                           700, 1200, 2000]
+            m.set_monochromatic(True, wavelengths=wavelengths)
+            m.set_n_photons(initial=1000, imaging_sources=1000, imaging_dust=1000,
+                            raytracing_sources=1000, raytracing_dust=1000)
+            prob = write_and_read(m, tmp)
+            ref = os.path.join(DATA, "test_pascucci.tau=%s.rtout" % tau)
+            golden = {}
+            with h5py.File(ref, "r") as f:
+                grp = f["Peeled/group_00001"]
+                golden["seds"] = grp["seds"][...]
+                golden["frequencies"] = np.asarray(grp["frequencies"][...]["nu"], dtype=float)
+                n_it = int(f.attrs["iterations"])
+                golden["specific_energy_last"] = read_specific_energy(f["iteration_%05d" % n_it])
+            path = os.path.join(HERE, "pascucci.tau=%s.npz" % tau)
+            ptmp = path + ".problem.npz"
+            if tau == 0.1:      # the dust tables once, as a sibling file the four fixtures refer to
+                dl = prob.dust[0]
+                np.savez_compressed(os.path.join(HERE, "pascucci_dust.npz"), **{k: v for k, v in dl.__dict__.items() if isinstance(v, np.ndarray)})
+            prob.to_npz(ptmp, dust_library={"pascucci_dust.npz": dl})
+            z = dict(np.load(ptmp)); os.remove(ptmp)
+            for k, v in golden.items():
+                z["golden/" + k] = v
+            np.savez_compressed(path, **z)
+            print("wrote", path, os.path.getsize(path))
+    finally:
+        T.teardown_class(T)
+
+
 def main():
     if "mrw" in sys.argv[1:]:
         mrw_fixture()
+        return
+    if "pascucci" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            pascucci_fixture(tmp)
         return
     grids, denss = car_grid_and_densities()
     with tempfile.TemporaryDirectory() as tmp:

@@ -49,6 +49,8 @@ def lib():
         L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
+        L.orc_mono_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_mono_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
         L.orc_peeled_sed_rw.argtypes = [C.c_void_p, C.c_int]
         L.orc_peeled_sed_rw.restype = _dp
         L.orc_peeled_img_rw.argtypes = [C.c_void_p, C.c_int]
@@ -152,6 +154,22 @@ class Oracle:
         st = IterStats()
         rc = lib().orc_raytracing_accumulate(self.h, int(which), int(first_id), int(n_local), int(n_total), int(bool(zero_first)),
                                              n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return st.as_dict()
+
+    def mono_iteration(self, n_sources, n_dust, n_threads=0):
+        """do_final_mono: all frequencies, source then dust packets; returns the cubes."""
+        st = IterStats()
+        rc = lib().orc_mono_iteration(self.h, int(n_sources), int(n_dust), n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return self._peeled(), st.as_dict()
+
+    def mono_accumulate(self, which, inu, first_id, n_local, n_total, zero_first=False, n_threads=0):
+        st = IterStats()
+        rc = lib().orc_mono_accumulate(self.h, int(which), int(inu), int(first_id), int(n_local), int(n_total), int(bool(zero_first)),
+                                       n_threads, C.byref(st))
         if rc != 0:
             raise OracleError(self._err())
         return st.as_dict()

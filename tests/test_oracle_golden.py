@@ -203,3 +203,49 @@ def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
         assert abs(gi.sum() - itot.mean()) < 4.0 * itot.std(ddof=1)
         # raytraced flux is unpolarised: Q, U, V of the golden come from the scattered packets only
         assert np.all(gold[3] == 0)
+
+
+def _pascucci_run(prob, seed, scale=1):
+    """program main's sequence for the Pascucci model: 5 Lucy iterations, the monochromatic final
+    iteration (scattered light only, raytracing is on), the raytracing iteration."""
+    prob.config.seed = seed
+    o = Oracle(prob)
+    for it in range(1, 6):
+        o.lucy_iteration(1000 * scale, it)
+    o.mono_iteration(1000 * scale, 1000 * scale)
+    res, st = o.raytracing_iteration(1000 * scale, 1000 * scale)
+    o.close()
+    assert st["killed_geo"] == 0
+    return res[0]["sed"]
+
+
+@pytest.mark.parametrize("tau", ["0.1", "1", "10", "100"])
+def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
+    """test_pascucci.tau=*.rtout (test_bit_level.py:341-427): MONOCHROMATIC final iteration
+    (iter_final_mono.f90) at 61 wavelengths + raytracing on a 100 x 30 spherical polar grid around
+    a stellar sphere.  The golden is one realisation with 1000 packets per part; all wavelengths
+    share the raytraced packets, so its noise is coherent in wavelength (a sphere's peel-off weight
+    4 mu scatters by 4 % over 1000 packets): per (view, wavelength) z-scores against K oracle
+    realisations, and the write-time normalisation nu * F_nu of exact-frequency cubes
+    (image_type.f90:675-683)."""
+    prob, z = golden_problem("pascucci.tau=%s.npz" % tau)
+    assert prob.grid_type == "sph_pol" and prob.config.monochromatic and prob.config.raytracing
+    np.testing.assert_allclose(z["golden/frequencies"], prob.config.frequencies, rtol=1e-14)
+    gold = z["golden/seds"]
+    nu = prob.config.frequencies
+    K = 12
+    samples = np.array([_pascucci_run(prob, -(300 + k)) for k in range(K)]) * nu
+    mean = _pascucci_run(prob, -7, scale=12) * nu
+    assert gold.shape == mean.shape
+    sig = samples.std(axis=0, ddof=1)
+    I, g = mean[0, 0, :, 0, :], gold[0, 0, :, 0, :]
+    sel = (sig[0, 0, :, 0, :] > 0) & (I > 1e-3 * I.max())
+    zs = (g - I)[sel] / sig[0, 0, :, 0, :][sel]
+    assert sel.sum() > 120
+    assert np.abs(zs).max() < 6.0 and (zs ** 2).mean() < 3.0
+    # raytraced flux is unpolarised and the scattered part is small: |Q|, |U| << I; V = 0 (isotropic dust, P4 = 0)
+    assert np.all(gold[3] == 0) and np.all(mean[3] == 0)
+    # total over wavelengths of each view within the coherent noise
+    tot_s = samples[:, 0, 0, :, 0, :].sum(axis=2)
+    for iv in range(3):
+        assert abs(g[iv].sum() - I[iv].sum()) < 4.0 * tot_s[:, iv].std(ddof=1) + 0.02 * I[iv].sum()
