@@ -41,6 +41,9 @@ struct DDust {
     // modified random walk (grid_mrw_3d.f90): Planck mean opacities and the b_nu = j_nu / kappa_nu pdfs
     const double *mo_kappa_planck, *mo_chi_inv_planck;   // [n_e] or null
     const double *bnu_cdf, *bnu_bp1, *bnu_coarse;         // same layout as emiss_cdf / emiss_bp1 / emiss_coarse
+    // monochromatic mode: log10 of the normalised emissivity pdf of every row at the run's frequencies
+    // (interpolate_pdf in dust_sample_emit_probability, dust_type_4elem.f90:356-377); -inf where it is zero
+    const double *mono_log10_prob;           // [n_jnu][n_frequencies] or null
 };
 
 struct DSource {
@@ -71,7 +74,7 @@ struct DPeeled {
     const double *src_spec;       // [n_sources][n_nu]
     const double *dust_log10_em;  // [n_dust][nj_stride][n_nu]
     const double *dust_chi;       // [n_dust][n_nu]
-    int nj_stride, pad1;
+    int nj_stride, inu_min;       // inu_min: monochromatic, 1-based first frequency of this group (image_type.f90:243-258)
 };
 
 // Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
@@ -147,6 +150,14 @@ struct DProblem {
     const double *mrw_alpha, *mrw_diff;   // [n_cells] alpha_inv_planck, diff_coeff
     const double *mrw_kp;                 // [n_cells][n_dust] kappa_planck(specific_energy)
     const double *mrw_x, *mrw_y;          // [100]
+    // monochromatic final iteration (iter_final_mono.f90): the frequency table and, refreshed by the host before every
+    // launch, the part being run (0 = not a monochromatic launch, 1 = source packets, 2 = dust packets), the frequency
+    // and the cell emission pdfs of grid_monochromatic.f90
+    int mono_which, mono_inu, n_frequencies, pad6;
+    double mono_nu, mono_n_total, mono_threshold;
+    const double *mono_src_prob;          // [n_sources][n_frequencies] emission probability of each source at each frequency
+    const double *mono_cdf;               // [n_dust][n_cells] cumulative of prob x energy over cells, normalised
+    double mono_mean_prob[HYP_MAXD];
     const double *density;                // [n_cells][n_dust]   (cell-major)
     double *sum;                          // [n_copies][n_cells][n_dust] accumulators
     unsigned long long copy_stride;       // doubles between accumulator copies

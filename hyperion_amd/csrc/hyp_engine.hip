@@ -44,6 +44,33 @@ double seg_loglog(double x1, double x2, double y1, double y2)
     return y1 * (x2 * std::pow(x2 / x1, b) - x1) / (b + 1.0);
 }
 
+// interpolate_pdf(pdf, xv, bounds_error=.false., fill_value=0) of a log pdf set from (x, y[stride]): the normalised pdf
+// interpolated in log-log (linear where an ordinate is not positive), 0 outside the table
+double interp_log_pdf(const double *x, const double *y, size_t stride, int n, double xv)
+{
+    if (!(xv >= x[0]) || !(xv <= x[n - 1])) return 0.0;
+    double norm = 0.0;
+    for (int i = 0; i + 1 < n; i++) norm += seg_loglog(x[i], x[i + 1], y[(size_t)i * stride], y[(size_t)(i + 1) * stride]);
+    if (!(norm > 0.0)) return 0.0;
+    int j;
+    if (xv == x[n - 1]) j = n - 2;
+    else { int jl = 0, ju = n - 1; while (ju - jl > 1) { int jm = (ju + jl) >> 1; if (xv >= x[jm]) jl = jm; else ju = jm; } j = jl; }
+    const double y1 = y[(size_t)j * stride] / norm, y2 = y[(size_t)(j + 1) * stride] / norm;
+    if (y1 > 0.0 && y2 > 0.0) {
+        const double f = (std::log10(xv) - std::log10(x[j])) / (std::log10(x[j + 1]) - std::log10(x[j]));
+        return std::pow(10.0, std::log10(y1) + f * (std::log10(y2) - std::log10(y1)));
+    }
+    return y1 + (xv - x[j]) / (x[j + 1] - x[j]) * (y2 - y1);
+}
+
+// normalized_B_nu: source_type.f90:1088-1096
+double normalized_B_nu(double nu, double T)
+{
+    const double a = 2.0 * HYP_H_CGS / HYP_C_CGS / HYP_C_CGS / HYP_STEF_BOLTZ * HYP_PI, b = HYP_H_CGS / HYP_K_CGS;
+    const double T4 = T * T * T * T;
+    return a * nu * nu * nu / (std::exp(b * nu / T) - 1.0) / T4;
+}
+
 // type_pdf set_pdf(x, y, log=.true.): normalised pdf, cdf and per-bin power-law
 // index (+1) used by the device-side inversion.  Returns false if the integral
 // vanishes.
@@ -134,7 +161,7 @@ double spacing(double x)
 struct DustOffsets {
     size_t nu, log10_nu, chi, albedo, log10_chi, log10_albedo, mu, P1, P2, P3, P4, P1_cdf, P2_cdf;
     size_t emiss_x, emiss_cdf, emiss_bp1, emiss_coarse, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
-    size_t mo_kappa_planck, mo_chi_inv_planck, bnu_cdf, bnu_bp1, bnu_coarse;
+    size_t mo_kappa_planck, mo_chi_inv_planck, bnu_cdf, bnu_bp1, bnu_coarse, mono_prob;
     bool have_mo_e, have_mo_chi, have_mrw;
 };
 
@@ -204,6 +231,13 @@ struct hyp_engine {
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
+
+    // monochromatic final iteration
+    std::vector<double> frequencies;
+    double *d_mono_cdf = nullptr;       // [n_dust][n_cells]
+    double *d_mono_mean = nullptr;      // [HYP_MAXD]
+    bool mono_pending = false;
+    hyp_iter_stats mono_stats;
 
     int set_error(const std::string &m) { err = m; return 1; }
 };
@@ -463,6 +497,7 @@ void hyp_destroy(hyp_handle h)
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
+    free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
     free_dev(h->d_mask_map);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
@@ -497,6 +532,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     if (pr->grid.type < 1 || pr->grid.type > 6) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi, 4 amr, 5 spherical polar, 6 cylindrical polar)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
     if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
+    if (pr->config.monochromatic && (pr->config.n_frequencies < 1 || !pr->config.frequencies)) return set_error("monochromatic mode needs a frequency table");
     const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_amr = pr->grid.type == 4;
     const bool is_sph = pr->grid.type == 5, is_cyl = pr->grid.type == 6, is_polar = is_sph || is_cyl;
     const bool is_xyz = pr->grid.type == 1;                 // Cartesian proper (walls staged in LDS, brick-tiled schedule)
@@ -1023,6 +1059,12 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         G.n_view = in.n_view; G.ignore_optical_depth = in.ignore_optical_depth;
         G.compute_image = in.compute_image; G.compute_sed = in.compute_sed;
         G.n_x = in.n_x; G.n_y = in.n_y; G.n_ap = in.n_ap; G.n_nu = in.n_nu;
+        if (pr->config.monochromatic) {     // image_type.f90:243-258
+            if (in.inu_min < 1 || in.inu_min > pr->config.n_frequencies) FAIL("inu_min value is out of range");
+            if (in.inu_max < 1 || in.inu_max > pr->config.n_frequencies) FAIL("inu_max value is out of range");
+            G.n_nu = in.inu_max - in.inu_min + 1; G.inu_min = in.inu_min;
+            if (G.n_nu != in.n_nu) FAIL("n_nu of a monochromatic image group should be inu_max - inu_min + 1");
+        }
         G.track_origin = in.track_origin; G.track_n_scat = in.track_n_scat; G.uncertainties = in.uncertainties;
         G.n_stokes = in.compute_stokes ? 4 : 1;
         switch (in.track_origin) {
@@ -1061,7 +1103,41 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     // get_j_nu_binned and get_chi_nu_binned (dust_type_4elem.f90:722-750, 793-818).
     int nj_stride = 1;
     for (int d = 0; d < pr->n_dust; d++) nj_stride = std::max(nj_stride, pr->dust[d].n_jnu);
-    if (!ray_groups.empty()) {
+    if (!ray_groups.empty() && pr->config.monochromatic) {
+        // use_exact_nu: get_spectrum_interp (source_type.f90:1098-1116), get_j_nu_interp / get_chi_nu_interp
+        // (dust_type_4elem.f90:708-720, 780-791) at the group's own frequencies
+        for (int g : ray_groups) {
+            const int nn = h->h_peeled[g].n_nu;
+            const double *nu = pr->config.frequencies + (pr->peeled[g].inu_min - 1);
+            std::vector<double> spec((size_t)pr->n_sources * nn, 0.0), em((size_t)pr->n_dust * nj_stride * nn, 0.0), chi((size_t)pr->n_dust * nn, 0.0);
+            for (int is = 0; is < pr->n_sources; is++) {
+                const hyp_source_desc &src = pr->sources[is];
+                for (int i = 0; i < nn; i++)
+                    spec[(size_t)is * nn + i] = src.spectrum_type == 1 ? interp_log_pdf(src.spec_nu, src.spec_fnu, 1, src.n_spec, nu[i])
+                                                                         : normalized_B_nu(nu[i], src.temperature);
+            }
+            for (int d = 0; d < pr->n_dust; d++) {
+                const hyp_dust_desc &in = pr->dust[d];
+                for (int j = 0; j < in.n_jnu; j++)
+                    for (int i = 0; i < nn; i++)
+                        em[((size_t)d * nj_stride + j) * nn + i] = std::log10(interp_log_pdf(in.emiss_nu, in.emiss_jnu + j, in.n_jnu, in.n_enu, nu[i]));
+                for (int i = 0; i < nn; i++) {
+                    double c = 0.0;
+                    if (nu[i] >= in.nu[0] && nu[i] <= in.nu[in.n_nu - 1]) {
+                        int j = in.n_nu - 2;
+                        if (nu[i] != in.nu[in.n_nu - 1]) { int jl = 0, ju = in.n_nu - 1; while (ju - jl > 1) { int jm = (ju + jl) >> 1; if (nu[i] >= in.nu[jm]) jl = jm; else ju = jm; } j = jl; }
+                        const double y1 = in.chi[j], y2 = in.chi[j + 1];
+                        if (y1 > 0.0 && y2 > 0.0) {
+                            const double f = (std::log10(nu[i]) - std::log10(in.nu[j])) / (std::log10(in.nu[j + 1]) - std::log10(in.nu[j]));
+                            c = std::pow(10.0, std::log10(y1) + f * (std::log10(y2) - std::log10(y1)));
+                        } else c = y1 + (nu[i] - in.nu[j]) / (in.nu[j + 1] - in.nu[j]) * (y2 - y1);
+                    }
+                    chi[(size_t)d * nn + i] = c;
+                }
+            }
+            poff[g].src_spec = B.put(spec); poff[g].dust_em = B.put(em); poff[g].dust_chi = B.put(chi);
+        }
+    } else if (!ray_groups.empty()) {
         const double l0 = std::log10(3.e9), l1 = std::log10(3.e16);
         const int nb = (int)std::ceil((l1 - l0) * 100000);
         std::vector<double> bnu, bfnu;
@@ -1119,6 +1195,32 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         for (int g : ray_groups) { poff[g].src_spec = B.put(spec[g]); poff[g].dust_em = B.put(em[g]); poff[g].dust_chi = B.put(chi[g]); }
     }
 
+    // monochromatic mode: emission probability of every source and of every emissivity row at the run's frequencies
+    size_t mono_src_off = 0;
+    if (pr->config.monochromatic) {
+        const int nf = pr->config.n_frequencies;
+        const double *fr = pr->config.frequencies;
+        h->frequencies.assign(fr, fr + nf);
+        std::vector<double> sp((size_t)pr->n_sources * nf);
+        for (int is = 0; is < pr->n_sources; is++) {
+            const hyp_source_desc &src = pr->sources[is];
+            for (int i = 0; i < nf; i++)
+                sp[(size_t)is * nf + i] = src.spectrum_type == 1 ? interp_log_pdf(src.spec_nu, src.spec_fnu, 1, src.n_spec, fr[i])
+                                                                   : normalized_B_nu(fr[i], src.temperature);
+        }
+        mono_src_off = B.put(sp);
+        for (int d = 0; d < pr->n_dust; d++) {
+            const hyp_dust_desc &in = pr->dust[d];
+            std::vector<double> lp((size_t)in.n_jnu * nf);
+            for (int j = 0; j < in.n_jnu; j++)
+                for (int i = 0; i < nf; i++) {
+                    const double pv = interp_log_pdf(in.emiss_nu, in.emiss_jnu + j, in.n_jnu, in.n_enu, fr[i]);
+                    lp[(size_t)j * nf + i] = pv == 0.0 ? -INFINITY : std::log10(pv);
+                }
+            doff[d].mono_prob = B.put(lp);
+        }
+    }
+
     // ---- device allocations ----
     HIPC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPC(hipEventCreate(&h->ev0)); HIPC(hipEventCreate(&h->ev1));
@@ -1127,6 +1229,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     HIPC(hipMemcpy(h->d_blob, B.h.data(), sizeof(double) * B.h.size(), hipMemcpyHostToDevice));
     const double *db = h->d_blob;
     for (int a = 0; a < 3 && is_car; a++) { P.w[a] = db + w_off[a]; P.ew[a] = db + ew_off[a]; }
+    if (pr->config.monochromatic) {
+        P.n_frequencies = pr->config.n_frequencies; P.mono_threshold = pr->config.monochromatic_energy_threshold;
+        P.mono_src_prob = db + mono_src_off; P.mono_which = 0; P.mono_inu = 0;
+    }
     if (is_polar) {
         P.wr2 = db + polar_off[0]; P.wtanp = db + polar_off[4];
         if (is_sph) { P.wtant = db + polar_off[1]; P.wtant2 = db + polar_off[2]; P.wcost = db + polar_off[3]; }
@@ -1182,6 +1288,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         D.mo_chi_ross = O.have_mo_chi ? db + O.mo_chi_ross : nullptr;
         D.mo_kappa_planck = O.have_mrw ? db + O.mo_kappa_planck : nullptr;
         D.mo_chi_inv_planck = O.have_mrw ? db + O.mo_chi_inv_planck : nullptr;
+        D.mono_log10_prob = pr->config.monochromatic ? db + O.mono_prob : nullptr;
         D.bnu_cdf = O.have_mrw ? db + O.bnu_cdf : nullptr; D.bnu_bp1 = O.have_mrw ? db + O.bnu_bp1 : nullptr;
         D.bnu_coarse = O.have_mrw ? db + O.bnu_coarse : nullptr;
     }
@@ -1813,6 +1920,119 @@ int hyp_raytracing_iteration(hyp_handle h, uint64_t n_sources, uint64_t n_dust, 
     st.n_packets = n_sources + n_dust;
     if (stats) *stats = st;
     return 0;
+}
+
+// ---- monochromatic final iteration (iter_final_mono.f90) ---------------------------------------
+
+int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first)
+{
+    if (!h) return 1;
+    if (!h->cfg.monochromatic) return h->set_error("monochromatic mode was not requested in the configuration");
+    if (which < 0 || which > 1) return h->set_error("hyp_mono_launch: which must be 0 (sources) or 1 (dust)");
+    if (inu < 0 || inu >= (int)h->frequencies.size()) return h->set_error("incorrect inu");
+    if (!h->d_img_accum) return h->set_error("no peeled images set up");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    DProblem &P = h->hp;
+    double *tail = h->d_img_accum + (h->img_accum_n - TAIL_SIZE);
+    hipError_t e = hipSuccess;
+    if (zero_first) e = hipMemsetAsync(h->d_img_accum, 0, sizeof(double) * h->img_accum_n, h->stream);
+    else if (!h->mono_pending) e = hipMemsetAsync(tail, 0, sizeof(double) * TAIL_SIZE, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(images): ") + hipGetErrorString(e));
+    if (!h->mono_pending) std::memset(&h->mono_stats, 0, sizeof h->mono_stats);
+    h->mono_pending = true;
+    P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
+    P.mono_which = 0; P.mono_inu = inu; P.mono_nu = h->frequencies[inu]; P.mono_n_total = (double)n_total;
+    if (n_local == 0 || n_total == 0) return sync_problem(h);
+    if (which == 1) {
+        // setup_monochromatic_grid_pdfs: precompute_jnu_var ran in the last finish step (jnu_id / jnu_frac are current)
+        const size_t nc = h->n_cells;
+        if (!h->d_mono_cdf) {
+            if (hipMalloc(&h->d_mono_cdf, sizeof(double) * nc * h->n_dust) != hipSuccess ||
+                hipMalloc(&h->d_mono_mean, sizeof(double) * 2 * HYP_MAXD) != hipSuccess) return h->set_error("hipMalloc(monochromatic pdfs) failed");
+        }
+        P.mono_which = 2;       // dust_emit_probability reads mono_inu
+        if (sync_problem(h)) return 1;
+        mono_weight_kernel<<<dim3(1024), dim3(256), 0, h->stream>>>((const DProblem *)h->d_problem, h->d_mono_cdf);
+        mono_scan_kernel<<<dim3(h->n_dust), dim3(1024), 0, h->stream>>>(h->d_mono_cdf, nc, h->d_mono_mean);
+        double mean[2 * HYP_MAXD];
+        e = hipMemcpyAsync(mean, h->d_mono_mean, sizeof mean, hipMemcpyDeviceToHost, h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("monochromatic emission pdfs: ") + hipGetErrorString(e));
+        double tot = 0.0;
+        for (int d = 0; d < h->n_dust; d++) { P.mono_mean_prob[d] = mean[d]; tot += mean[d]; }
+        P.mono_cdf = h->d_mono_cdf;
+        if (tot == 0.0) { P.mono_which = 0; return sync_problem(h); }      // "No emission at this frequency"
+    }
+    P.mono_which = which + 1;
+    if (sync_problem(h)) return 1;
+    unsigned long long first = first_id;
+    e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type);
+    const size_t lds = lds_bytes(P);
+    long long blocks = (long long)h->n_cu * 2;
+    long long need_blocks = (long long)((n_local + 255) / 256);
+    if (need_blocks < 1) need_blocks = 1;
+    if (blocks > need_blocks) blocks = need_blocks;
+    LaunchParams L;
+    L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = (which == 0 ? 0x40000u : 0x50000u) + (uint32_t)inu;
+    unsigned long long c = n_local / ((unsigned long long)blocks * 32ull);
+    if (c < 64) c = 64;
+    if (c > 4096) c = 4096;
+    L.chunk = (int)c;
+    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    e = hipGetLastError();
+    if (e != hipSuccess) return h->set_error(std::string("final_kernel (monochromatic) launch: ") + hipGetErrorString(e));
+    // the launches share the id dispenser and the problem block: finish this one before the next changes them
+    e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) return h->set_error(std::string("monochromatic iteration failed: ") + hipGetErrorString(e));
+    P.mono_which = 0;
+    if (sync_problem(h)) return 1;
+    h->mono_stats.n_packets += n_local;
+    if (check_device_error(h)) { h->mono_pending = false; return 1; }
+    return 0;
+}
+
+int hyp_mono_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
+{
+    if (!h) return 1;
+    if (!h->mono_pending) return h->set_error("hyp_mono_accumulators called without a launched iteration");
+    if (device_ptr) *device_ptr = h->d_img_accum;
+    if (n_doubles) *n_doubles = h->img_accum_n;
+    return 0;
+}
+
+int hyp_mono_finish(hyp_handle h, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (!h->mono_pending) return h->set_error("hyp_mono_finish called without a launched iteration");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    h->mono_pending = false;
+    double tail[TAIL_SIZE];
+    hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    hyp_iter_stats st = h->mono_stats;
+    st.energy_current = tail[TAIL_ENERGY];
+    st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];
+    st.crossings = (uint64_t)tail[TAIL_CROSSINGS]; st.interactions = (uint64_t)tail[TAIL_INTERACTIONS];
+    if (stats) *stats = st;
+    return 0;
+}
+
+int hyp_mono_iteration(hyp_handle h, uint64_t n_sources, uint64_t n_dust, hyp_iter_stats *stats)
+{
+    if (!h) return 1;
+    if (!h->cfg.monochromatic) return h->set_error("monochromatic mode was not requested in the configuration");
+    bool first = true;
+    for (int which = 0; which < 2; which++) {
+        const uint64_t n = which == 0 ? n_sources : n_dust;
+        for (int inu = 0; inu < (int)h->frequencies.size(); inu++) {
+            if (hyp_mono_launch(h, which, inu, 0, n, n, first ? 1 : 0)) return 1;
+            first = false;
+        }
+    }
+    return hyp_mono_finish(h, stats);
 }
 
 int hyp_peeled_n_orig(hyp_handle h, int g) { return (h && g >= 0 && g < (int)h->h_peeled.size()) ? h->h_peeled[g].n_orig : -1; }

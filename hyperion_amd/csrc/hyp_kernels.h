@@ -792,11 +792,15 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     }
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
     p.energy = 1.0;
-    if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
+    if (P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
+        p.nu = P.mono_nu;
+        p.energy = P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
+    } else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     if (reemit_id >= 0) p.energy = reemit_energy;
     else {
+        if (P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
         if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
         cnt.energy_current += p.energy;
     }
@@ -880,7 +884,7 @@ __device__ __forceinline__ void dust_scatter(const DDust &D, double nu, Angle &a
 // Returns false on a fatal error.  `scattered`/`dust_id` report what happened.
 template <int NDT, int GEOM>
 __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt,
-                                         int &scattered, int &dust_id)
+                                         int &scattered, int &dust_id, bool force_scatter = false)
 {
     const int nd = ndust<NDT>(P);
     const size_t base = geo_index(P, p.cell) * (size_t)nd;
@@ -904,7 +908,7 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p
     }
     dust_id = id;
     cnt.interactions++;
-    double xi = rng_uniform(g);
+    double xi = force_scatter ? 0.0 : rng_uniform(g);      // interact(p, force_scatter): dust_interact.f90:49-53
     if (xi > albedo) {
         const DDust &D = P.dust[id];
         int jid = P.jnu_id[base + id];
@@ -919,6 +923,7 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p
         scattered = 1;
     }
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    if (force_scatter) p.energy = p.energy * albedo;       // :75-77
     return true;
 }
 
@@ -1350,7 +1355,8 @@ __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled 
                                                long long &k_img, long long &k_sed)
 {
     k_img = -1; k_sed = -1;
-    int inu = ipos0(G.log10_nu_min, G.log10_nu_max, log10(nu), G.n_nu);
+    int inu = P.mono_which ? P.mono_inu - (G.inu_min - 1)       // image_type.f90:435-436
+                           : ipos0(G.log10_nu_min, G.log10_nu_max, log10(nu), G.n_nu);
     if (inu < 0 || inu >= G.n_nu) return;
     if (energy != energy || s0 != s0) return;
     int o = f.scattered ? (f.reprocessed ? 4 : 3) : (f.reprocessed ? 2 : 1);
@@ -1751,6 +1757,46 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
     }
 }
 
+// dust_sample_emit_probability (dust_type_4elem.f90:356-377) from the per-row table of the run's frequencies
+__device__ __forceinline__ double dust_emit_probability(const DProblem &P, const DDust &D, int jid, double frac)
+{
+    const double l1 = D.mono_log10_prob[(size_t)jid * P.n_frequencies + P.mono_inu];
+    const double l2 = D.mono_log10_prob[(size_t)(jid + 1) * P.n_frequencies + P.mono_inu];
+    if (l1 == -HYP_INF || l2 == -HYP_INF) return 0.0;
+    return exp10(l1 + frac * (l2 - l1));
+}
+
+// emit_from_monochromatic_grid_pdf: grid_monochromatic.f90:119-174.  Returns false when the packet carries no
+// energy (nothing emits at this frequency in the chosen dust type) or on a fatal error.
+template <int NDT, int GEOM>
+__device__ __forceinline__ bool emit_mono_dust(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt, int &dust_id)
+{
+    const int nd = ndust<NDT>(P);
+    p.nu = P.mono_nu;
+    if (!update_optconsts<NDT, GEOM>(P, p)) return false;
+    int d = (int)ceil(rng_uniform(g) * (double)nd);
+    if (d < 1) d = 1;
+    d -= 1;
+    dust_id = d;
+    if (P.mono_mean_prob[d] == 0.0) return false;
+    // grid_sample_pdf_map: first cell whose cumulative exceeds xi
+    const double *cdf = P.mono_cdf + (size_t)d * P.n_cells;
+    const double xi = rng_uniform(g);
+    size_t lo = 0, hi = (size_t)P.n_cells - 1;
+    while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (xi < cdf[mid]) hi = mid; else lo = mid + 1; }
+    const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
+    if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
+    random_sphere_angle(g, p.a);
+    angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+    p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
+    g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+    geo_clear_wall(p.cell);
+    if (!geo_place(P, W, p.r, p.v, p.cell)) { cnt.killed_geo++; return false; }
+    p.inter = 1;
+    p.energy = P.mono_mean_prob[d] * P.energy_abs_tot[d] / P.mono_n_total * (double)nd;
+    return p.energy > 0.0;
+}
+
 // forced first interaction: forced_interaction.f90:23-133
 __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau_escape, double xi, double &tau, double &weight)
 {
@@ -1789,6 +1835,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
     p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
     long long mrw_k = 1;       // MRW steps of the current interaction (state ST_MRW)
+    double e_init = 0.0;       // monochromatic: energy at emission (the packet dies below mono_threshold of it)
 
     for (;;) {
         unsigned long long m_walk = __ballot(st == ST_WALK);
@@ -1853,11 +1900,13 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                 } else {
                     a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
                     int scattered, dust_id;
-                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id);
+                    // monochromatic: always scatter, the energy decreases by the albedo (iter_final_mono.f90:330-336)
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, P.mono_which != 0);
                     f.dust_id = dust_id;
                     if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
                     else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
-                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered && !P.mono_which);
+                    if (P.mono_which && p.energy < e_init * P.mono_threshold) killed = true;
                     if (killed) st = ST_NEED_EMIT;
                     else { p.inter++; peel = 2; }
                 }
@@ -1875,15 +1924,25 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
                     Angle src_normal;
+                    if (P.mono_which == 2) {
+                        // thermal packets of the monochromatic iteration: iter_final_mono.f90:176-196
+                        int dust_id = 0;
+                        bool ok = emit_mono_dust<NDT, GEOM>(P, W, p, g, cnt, dust_id);
+                        f.scattered = 0; f.reprocessed = 1; f.n_scat = 0; f.dust_id = dust_id; f.source_id = 0;
+                        if (!ok) st = ST_NEED_EMIT;
+                        else { peel = 1; last = LAST_DE; last_iso = true; st = ST_PLACED; p.reabs = 0; e_init = p.energy; }
+                    } else {
                     bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else {
+                        if (P.mono_which) { p.energy = p.energy / P.mono_n_total; e_init = p.energy; }     // iter_final_mono.f90:113-116
                         peel = 1; last = LAST_SR; st = ST_PLACED;   // placed, awaiting tau
                         p.reabs = 0;
                         last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8;
                         // external sources: a_prev carries the inward normal for emit_peeloff
                         if (!last_iso) a_prev = src_normal;
+                    }
                     }
                 }
             }
@@ -1924,7 +1983,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     st = ST_NEED_EMIT;
                 } else if (peel == 4) {
                     // stays in ST_MRW: the next pass decides on another step
-                } else if (peel == 2 && P.mrw) {
+                } else if (peel == 2 && P.mrw && !P.mono_which) {
                     st = ST_MRW; mrw_k = 1;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -1977,6 +2036,47 @@ __global__ void reduce_copies_kernel(double *__restrict__ sum, size_t n, size_t 
         for (int c = 1; c < n_copies; c++) s += sum[i + (size_t)c * stride];
         sum[i] = s;
     }
+}
+
+// setup_monochromatic_grid_pdfs (grid_monochromatic.f90:51-117), part 1: w[d][ic] = emission probability at the
+// frequency x energy emitted in the cell x n_cells / energy_abs_tot(d).  Masked cells carry no density.
+__global__ void mono_weight_kernel(const DProblem *__restrict__ Pp, double *__restrict__ w)
+{
+    const DProblem &P = *Pp;
+    const size_t nc = (size_t)P.n_cells, n = nc * (size_t)P.n_dust;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
+        const size_t ic = k / P.n_dust; const int d = (int)(k - ic * P.n_dust);
+        double energy = 0.0;
+        const double eat = P.energy_abs_tot[d];
+        if (eat > 0.0) energy = P.specific_energy[k] * P.density[k] * cell_volume(P, ic) * (double)nc / eat;
+        const double prob = dust_emit_probability(P, P.dust[d], P.jnu_id[k], P.jnu_frac[k]);
+        w[(size_t)d * nc + ic] = prob * energy;
+    }
+}
+
+// part 2: in-place cumulative sum over the cells of dust type blockIdx.x, normalised to 1 (set_pdf of a discrete
+// pdf); mean[d] = total / n_cells.  One 1024-thread block per dust type: each thread owns a contiguous chunk.
+__global__ __launch_bounds__(1024) void mono_scan_kernel(double *__restrict__ w, size_t nc, double *__restrict__ mean)
+{
+    __shared__ double part[1024];
+    double *a = w + (size_t)blockIdx.x * nc;
+    const size_t chunk = (nc + 1023) / 1024;
+    const size_t lo = (size_t)threadIdx.x * chunk, hi = lo + chunk < nc ? lo + chunk : nc;
+    double s = 0.0;
+    for (size_t i = lo; i < hi; i++) s += a[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int t = 0; t < 1024; t++) { const double v = part[t]; part[t] = run; run += v; }
+        mean[blockIdx.x] = run / (double)nc;
+        mean[HYP_MAXD + blockIdx.x] = run;
+    }
+    __syncthreads();
+    const double total = mean[HYP_MAXD + blockIdx.x];
+    double run = part[threadIdx.x];
+    for (size_t i = lo; i < hi; i++) { run += a[i]; a[i] = total > 0.0 ? run / total : 0.0; }
 }
 
 struct FinishParams {

@@ -86,3 +86,27 @@ def raytracing_iteration_sharded(engine, n_sources, n_dust, rank=0, world_size=1
     res, stats = engine.raytracing_finish()
     stats["n_packets"] = n_sources + n_dust
     return res, stats
+
+
+def mono_iteration_sharded(engine, n_sources, n_dust, n_frequencies, rank=0, world_size=1, all_reduce=None):
+    """do_final_mono (src/main/iter_final_mono.f90) sharded by packet id: every rank runs its id range of every
+    (part, frequency) launch into cubes it zeroed itself, then ONE all-reduce of the image block (cubes and
+    counters) as after the polychromatic final iteration."""
+    first_launch = True
+    for which, n_total in ((0, n_sources), (1, n_dust)):
+        first, n_local = shard_range(n_total, rank, world_size)
+        for inu in range(n_frequencies):
+            engine.mono_launch(which, inu, first, n_local, n_total, zero_first=first_launch)
+            first_launch = False
+    if world_size > 1:
+        acc = engine.mono_accumulators_tensor()
+        if all_reduce is None:
+            import torch
+            import torch.distributed as dist
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+            torch.cuda.synchronize()
+        else:
+            all_reduce(acc)
+    res, stats = engine.mono_finish()
+    stats["n_packets"] = (n_sources + n_dust) * n_frequencies
+    return res, stats

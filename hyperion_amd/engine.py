@@ -23,6 +23,7 @@ EXPORTS = [
     "hyp_get_specific_energy", "hyp_get_density", "hyp_set_specific_energy",
     "hyp_last_kernel_ms", "hyp_set_option", "hyp_get_option",
     "hyp_raytracing_iteration", "hyp_raytracing_launch", "hyp_raytracing_accumulators", "hyp_raytracing_finish",
+    "hyp_mono_iteration", "hyp_mono_launch", "hyp_mono_accumulators", "hyp_mono_finish",
 ]
 
 
@@ -94,6 +95,10 @@ def load_library(path=None):
     L.hyp_get_option.argtypes = [H, C.c_char_p, C.POINTER(C.c_int64)]
     L.hyp_raytracing_iteration.argtypes = [H, C.c_uint64, C.c_uint64, C.POINTER(IterStats)]
     L.hyp_raytracing_launch.argtypes = [H, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.hyp_mono_iteration.argtypes = [H, C.c_uint64, C.c_uint64, C.POINTER(IterStats)]
+    L.hyp_mono_launch.argtypes = [H, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.hyp_mono_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.hyp_mono_finish.argtypes = [H, C.POINTER(IterStats)]
     L.hyp_raytracing_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.hyp_raytracing_finish.argtypes = [H, C.POINTER(IterStats)]
     if path == LIB:
@@ -230,6 +235,28 @@ class Engine:
     def raytracing_finish(self):
         st = IterStats()
         self._check(self._lib.hyp_raytracing_finish(self._h, C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    # -- monochromatic final iteration (iter_final_mono.f90) ---------------------------
+    def mono_iteration(self, n_sources, n_dust):
+        """do_final_mono: every frequency, source packets then dust packets; zeroes the cubes first."""
+        st = IterStats()
+        self._check(self._lib.hyp_mono_iteration(self._h, int(n_sources), int(n_dust), C.byref(st)))
+        return self.peeled_results(), st.as_dict()
+
+    def mono_launch(self, which, inu, first_id, n_local, n_total, zero_first=False):
+        self._check(self._lib.hyp_mono_launch(self._h, int(which), int(inu), int(first_id), int(n_local), int(n_total), int(bool(zero_first))))
+
+    def mono_accumulators_tensor(self):
+        import torch
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self._lib.hyp_mono_accumulators(self._h, C.byref(p), C.byref(n)))
+        return torch.as_tensor(_DeviceBlock(p.value, n.value), device="cuda:%d" % self.device)
+
+    def mono_finish(self):
+        st = IterStats()
+        self._check(self._lib.hyp_mono_finish(self._h, C.byref(st)))
         return self.peeled_results(), st.as_dict()
 
     def peeled_results(self):

@@ -14,10 +14,23 @@ def dnunorm(peeled):
     return r ** (0.5 / n) - r ** (-0.5 / n)
 
 
-def finalize_peeled(peeled, raw):
+def finalize_peeled(peeled, raw, frequencies=None):
     """raw: {'sed','sed2','img','img2'} in the .rtout layout
     (n_stokes, n_orig, n_view, n_ap, n_nu) / (n_stokes, n_orig, n_view, n_y, n_x, n_nu)."""
     out = {}
+    if frequencies is not None:
+        # use_exact_nu (image_type.f90:675-683, 733-741): F_nu at the group's frequencies -> nu F_nu
+        nu = np.asarray(frequencies, dtype=float)[peeled.inu_min - 1:peeled.inu_max]
+        if "sed" in raw:
+            out["seds"] = np.cumsum(raw["sed"] * nu, axis=3)
+            if peeled.uncertainties:
+                unc = np.sqrt(raw["sed2"]) * nu
+                out["seds_unc"] = np.sqrt(np.cumsum(unc * unc, axis=3))
+        if "img" in raw:
+            out["images"] = raw["img"] * nu
+            if peeled.uncertainties:
+                out["images_unc"] = np.sqrt(raw["img2"]) * nu
+        return out
     norm = dnunorm(peeled)
     if "sed" in raw:
         sed = raw["sed"] / norm

@@ -20,7 +20,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .distributed import raytracing_iteration_sharded, final_iteration_sharded, lucy_iteration_sharded
+from .distributed import mono_iteration_sharded, raytracing_iteration_sharded, final_iteration_sharded, lucy_iteration_sharded
 from .engine import Engine, EngineError
 from .images import finalize_peeled
 from .problem import Problem
@@ -111,7 +111,7 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
     """The iteration sequence of ``program main`` (src/main/main.f90:167-344)."""
     log = log or (lambda *a: None)
     cfg = problem.config
-    for flag, name in ((cfg.pda, "PDA"), (cfg.monochromatic, "monochromatic mode")):
+    for flag, name in ((cfg.pda, "PDA"),):
         if flag:
             raise EngineError("%s is not supported by the MI355X engine yet" % name)
     date_started = _now()
@@ -147,7 +147,13 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
             break
     peeled, fstats = [], {"killed_geo": 0, "killed_int": 0}
     log(" [main] starting final iteration")
-    if cfg.n_last_photons > 0:
+    freq = cfg.frequencies if cfg.monochromatic else None
+    if cfg.monochromatic:
+        # main.f90:271-272: do_final_mono(n_last_photons_sources, n_last_photons_dust, ...)
+        if problem.peeled:
+            raw, fstats = mono_iteration_sharded(eng, cfg.n_last_photons_sources, cfg.n_last_photons_dust, len(freq), rank, world_size)
+            peeled = [finalize_peeled(p, r, freq) for p, r in zip(problem.peeled, raw)]
+    elif cfg.n_last_photons > 0:
         raw, fstats = final_iteration_sharded(eng, cfg.n_last_photons, rank, world_size)
         peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, raw)]
     else:
@@ -159,7 +165,7 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
         # main.f90:296-305: direct and thermal emission with the emitters' whole spectra
         log(" [main] starting raytracing iteration")
         raw, rstats = raytracing_iteration_sharded(eng, cfg.n_ray_photons_sources, cfg.n_ray_photons_dust, rank, world_size)
-        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, raw)]
+        peeled = [finalize_peeled(p, r, freq) for p, r in zip(problem.peeled, raw)]
         log(" [main] exiting raytracing iteration")
     eng.close()
     res = RunResult(records, converged, n_done, peeled, fstats, time.time() - t0, date_started, _now())
@@ -225,8 +231,9 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                     if name not in cubes:
                         continue
                     d = g.create_dataset(name, data=cubes[name], compression="gzip")
-                    d.attrs["numin"] = np.float64(pl.nu_min)
-                    d.attrs["numax"] = np.float64(pl.nu_max)
+                    if not problem.config.monochromatic:     # image_type.f90:701-706
+                        d.attrs["numin"] = np.float64(pl.nu_min)
+                        d.attrs["numax"] = np.float64(pl.nu_max)
                     for k, v in extra.items():
                         d.attrs[k] = np.float64(v)
                     d.attrs["track_origin"] = b(pl.track_origin)
@@ -237,6 +244,9 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                         d.attrs["track_n_scat"] = np.int32(pl.track_n_scat)
                     if name + "_unc" in cubes:
                         g.create_dataset(name + "_unc", data=cubes[name + "_unc"], compression="gzip")
+                if problem.config.monochromatic:     # image_type.f90:781-784
+                    nu = np.asarray(problem.config.frequencies, dtype=float)[pl.inu_min - 1:pl.inu_max]
+                    g.create_dataset("frequencies", data=np.array(list(zip(nu)), dtype=[("nu", "<f8")]))
         f.attrs["killed_photons_geo_final"] = np.int32(result.final_stats.get("killed_geo", 0))
         f.attrs["killed_photons_int_final"] = np.int32(result.final_stats.get("killed_int", 0))
         rst = getattr(result, "raytracing_stats", None) or {}

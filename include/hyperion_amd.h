@@ -130,7 +130,12 @@ typedef struct hyp_config {
     int64_t n_inter_mrw_max;
     double  mrw_gamma;
     int32_t mrw;
-    int32_t reserved1;
+    int32_t monochromatic;          /* root attr `monochromatic` (use_exact_nu): the final iteration is do_final_mono
+                                       (src/main/iter_final_mono.f90) at the frequencies below, src/main/setup_rt.f90:49-57 */
+    double  monochromatic_energy_threshold;   /* root attr, default 1e-10 */
+    const double *frequencies;      /* [n_frequencies] table /frequencies, column nu (setup_rt.f90:220-222) */
+    int32_t n_frequencies;
+    int32_t reserved2;
 } hyp_config;
 
 /* /Output/Peeled/group_NNNNN -- src/images/images_peeled.f90:272-380,
@@ -156,6 +161,8 @@ typedef struct hyp_peeled_desc {
     double  peeloff_origin[3];
     const double *theta;     /* [n_view] deg */
     const double *phi;       /* [n_view] deg */
+    int32_t inu_min, inu_max; /* monochromatic: attrs inu_min, inu_max (1-based range of config.frequencies, image_type.f90:243-258);
+                                 n_nu = inu_max - inu_min + 1 */
 } hyp_peeled_desc;
 
 typedef struct hyp_problem {
@@ -238,6 +245,20 @@ int  hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t 
 int  hyp_raytracing_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
 int  hyp_raytracing_finish(hyp_handle h, hyp_iter_stats *stats);
 int  hyp_peeled_n_orig(hyp_handle h, int group);
+
+/* do_final_mono (src/main/iter_final_mono.f90:58-343 with src/grid/grid_monochromatic.f90), only with
+ * config.monochromatic: for every frequency n_sources packets emitted by the sources at that frequency (their
+ * energy carries the emission probability, source_type.f90:440-468) and n_dust packets emitted by the dust from
+ * the cell pdf of that frequency; packets always scatter and lose (1 - albedo) of their energy until it drops
+ * below monochromatic_energy_threshold of the initial one; every emission / scattering is peeled off into the
+ * frequency's own image plane.  hyp_mono_iteration zeroes the cubes and runs all frequencies; the cubes are NOT
+ * rescaled afterwards (the energies are absolute).  Split form for sharding: launch(which = 0 sources / 1 dust,
+ * inu 0-based) runs ids [first_id, first_id + n_local) of n_total; the block of hyp_final_accumulators'
+ * layout is returned by hyp_mono_accumulators; finish reports the counters summed over the launches. */
+int  hyp_mono_iteration(hyp_handle h, uint64_t n_sources, uint64_t n_dust, hyp_iter_stats *stats);
+int  hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_t n_local, uint64_t n_total, int zero_first);
+int  hyp_mono_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
+int  hyp_mono_finish(hyp_handle h, hyp_iter_stats *stats);
 
 /* current state, reference layout [n_dust][n_cells] */
 int  hyp_get_specific_energy(hyp_handle h, double *out);

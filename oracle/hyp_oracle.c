@@ -3617,6 +3617,7 @@ int orc_mono_accumulate(orc_state *st, int which, int inu, uint64_t first_id, ui
             if (pg->sed) { memset(pg->sed, 0, sizeof(double) * pg->sed_size); memset(pg->sed2, 0, sizeof(double) * pg->sed_size); }
             if (pg->img) { memset(pg->img, 0, sizeof(double) * pg->img_size); memset(pg->img2, 0, sizeof(double) * pg->img_size); }
         }
+    if (inu == 0) precompute_jnu_var(st);    /* iter_final_mono.f90:79 (cheap; the sharded callers have no other hook) */
     mono_ctx c; c.n_total = n_total; c.inu = inu;
     if (which == 1) {
         if (st->n_dust == 0 || setup_monochromatic_grid_pdfs(st, inu)) { if (stats) *stats = a; return 0; }   /* "No emission at this frequency" */

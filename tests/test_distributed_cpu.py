@@ -53,6 +53,13 @@ class OracleAsEngine:
             off += v.size
         return self.o._peeled(), {"killed_geo": 0, "killed_int": 0}
 
+    # monochromatic final iteration: same image block
+    def mono_launch(self, which, inu, first, n_local, n_total, zero_first=False):
+        self.o.mono_accumulate(which, inu, first, n_local, n_total, zero_first, n_threads=2)
+
+    mono_accumulators_tensor = raytracing_accumulators_tensor
+    mono_finish = raytracing_finish
+
 
 def _free_port():
     s = socket.socket()
@@ -119,3 +126,32 @@ def test_two_rank_sharded_raytracing_equals_single_process(tmp_path):
     res, _ = o.raytracing_iteration(1501, 2001, n_threads=2)
     np.testing.assert_allclose(r0["sed"], res[1]["sed"], rtol=1e-12, atol=1e-14 * res[1]["sed"].max())
     np.testing.assert_allclose(r0["img"], res[0]["img"], rtol=1e-12, atol=1e-14 * res[0]["img"].max())
+
+
+def _mono_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperion_amd.distributed import mono_iteration_sharded
+    prob = golden_problem("pascucci.tau=1.npz")[0]
+    eng = OracleAsEngine(prob)
+    eng.o.lucy_iteration(2000, 1, n_threads=2)
+    nf = prob.config.frequencies.size
+    res, st = mono_iteration_sharded(eng, 301, 201, nf, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    np.savez(os.path.join(out_dir, "mono%d.npz" % rank), sed=res[0]["sed"])
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_monochromatic_iteration_equals_single_process(tmp_path):
+    """do_final_mono sharded by packet id over two gloo ranks: every (part, frequency) launch is split, one
+    all-reduce of the image block at the end (hyperion_amd.distributed.mono_iteration_sharded)."""
+    mp.spawn(_mono_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "mono0.npz"), np.load(tmp_path / "mono1.npz")
+    np.testing.assert_array_equal(r0["sed"], r1["sed"])
+    prob = golden_problem("pascucci.tau=1.npz")[0]
+    o = Oracle(prob)
+    o.lucy_iteration(2000, 1, n_threads=2)
+    res, _ = o.mono_iteration(301, 201, n_threads=2)
+    o.close()
+    assert res[0]["sed"].max() > 0
+    np.testing.assert_allclose(r0["sed"], res[0]["sed"], rtol=1e-12, atol=1e-14 * res[0]["sed"].max())
