@@ -233,9 +233,9 @@ def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
     np.testing.assert_allclose(z["golden/frequencies"], prob.config.frequencies, rtol=1e-14)
     gold = z["golden/seds"]
     nu = prob.config.frequencies
-    K = 12
+    K = 12 if tau != "100" else 8          # (the optically thick disc costs the oracle 4 x more per packet)
     samples = np.array([_pascucci_run(prob, -(300 + k)) for k in range(K)]) * nu
-    mean = _pascucci_run(prob, -7, scale=12) * nu
+    mean = _pascucci_run(prob, -7, scale=12 if tau != "100" else 5) * nu
     assert gold.shape == mean.shape
     sig = samples.std(axis=0, ddof=1)
     I, g = mean[0, 0, :, 0, :], gold[0, 0, :, 0, :]
