@@ -60,6 +60,9 @@ struct alignas(16) ColdRec {     // only touched at interactions / emission
 #ifndef HYP_TILE_DENS_LDS
 #define HYP_TILE_DENS_LDS 1      // 1: brick densities staged in LDS, 0: read through L1/L2
 #endif
+#ifndef HYP_TILE_SERVICE
+#define HYP_TILE_SERVICE 16      // lanes that must wait (visit finished / idle) before a wave runs its service phase
+#endif
 #ifndef HYP_TILE_STEPS
 #define HYP_TILE_STEPS 4         // cell steps between two scheduling decisions of a wave
 #endif
@@ -652,7 +655,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
         // generation in a full wave, instead of dragging a nearly empty wave along.
         const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
-        if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= 16 || !m_walk))) {
+        if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_TILE_SERVICE || !m_walk))) {
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
             if (st == LS_CHECK) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
