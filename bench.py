@@ -21,10 +21,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # L2<->fabric bytes per cell crossing from the committed rocprofv3 PMC passes of the 128^3
 # uniform benchmark (FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc runs):
 #  persistent lucy_kernel<1> (profiles/r01b_summary.md): 8.08522e7 / 1.08239e8 KiB per launch of 3.46321e9 crossings
-#  brick-tiled schedule, all tile_* kernels (profiles/r01c_summary.md): 4.30053e8 / 7.99293e8 KiB over 3 x 1.732e10 crossings
+#  brick-tiled schedule, all tile_* kernels (profiles/r01d_summary.md): 4.13481e8 / 8.0876e8 KiB over 3 x 1.7319e10 crossings
 PMC_B_PER_CROSSING = {
     0: (8.08522e7 + 1.08239e8) * 1024 / 3.46321e9,
-    1: (4.30053e8 + 7.99293e8) * 1024 / (3 * 1.73190e10),
+    1: (4.13481e8 + 8.0876e8) * 1024 / (3 * 1.73190e10),
 }
 
 
@@ -142,7 +142,7 @@ def main():
                                   "launch = the whole propagation of one iteration (all generations of tile_prepare/count/scan/scatter/walk on "
                                   "three streams), timed with HIP events on the engine's stream.  Density and accumulators of a 16^3 brick "
                                   "live in LDS, so the algorithmic bytes no longer go to memory: the dominant kernel tile_walk_kernel is "
-                                  "VALU-issue bound (profiles/r01c_summary.md), %.2f x the memory-side atomic rate that bounds the "
+                                  "VALU-issue bound (profiles/r01d_summary.md), %.2f x the memory-side atomic rate that bounds the "
                                   "persistent kernel (2.38e10 atomics/s, profiles/r01_atomic_rate_ubench.md)"
                                   % (crossings / world / (k_ms * 1e-3) / 2.38e10)) if tiled else
                                  ("24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "

@@ -83,6 +83,7 @@ class ProblemDesc(C.Structure):
         ("n_dust", C.c_int32), ("n_sources", C.c_int32), ("n_peeled", C.c_int32), ("reserved0", C.c_int32),
         ("dust", C.POINTER(DustDesc)), ("sources", C.POINTER(SourceDesc)), ("peeled", C.POINTER(PeeledDesc)),
         ("density", _dp), ("specific_energy", _dp),
+        ("binned", C.POINTER(PeeledDesc)), ("n_binned_theta", C.c_int32), ("n_binned_phi", C.c_int32),
     ]
 
 
@@ -253,8 +254,9 @@ class MarshalledProblem:
         d.sources = C.cast(srcs, C.POINTER(SourceDesc))
 
         npl = len(prob.peeled)
-        pls = (PeeledDesc * max(npl, 1))()
-        for i, p in enumerate(prob.peeled):
+        groups = list(prob.peeled) + ([prob.binned] if prob.binned is not None else [])
+        pls = (PeeledDesc * max(len(groups), 1))()
+        for i, p in enumerate(groups):
             x = pls[i]
             x.n_view = p.n_view
             x.inside_observer = int(p.inside_observer)
@@ -278,6 +280,9 @@ class MarshalledProblem:
         keep(pls)
         d.n_peeled = npl
         d.peeled = C.cast(pls, C.POINTER(PeeledDesc))
+        if prob.binned is not None:
+            d.binned = C.cast(C.byref(pls, npl * C.sizeof(PeeledDesc)), C.POINTER(PeeledDesc))
+            d.n_binned_theta, d.n_binned_phi = int(prob.n_binned_theta), int(prob.n_binned_phi)
 
         d.density = arr(prob.density)
         d.specific_energy = arr(prob.specific_energy) if prob.specific_energy is not None else None
@@ -286,8 +291,13 @@ class MarshalledProblem:
 
     def peeled_shapes(self, g, n_orig):
         """(sed_shape, img_shape) of group g in the .rtout layout."""
-        p = self.problem.peeled[g]
+        if g == len(self.problem.peeled):        # the binned group: n_theta x n_phi views
+            p = self.problem.binned
+            n_view = self.problem.n_binned_theta * self.problem.n_binned_phi
+        else:
+            p = self.problem.peeled[g]
+            n_view = p.n_view
         ns = 4 if p.compute_stokes else 1
-        sed = (ns, n_orig, p.n_view, p.n_ap, p.n_wav) if p.compute_sed else None
-        img = (ns, n_orig, p.n_view, p.n_y, p.n_x, p.n_wav) if p.compute_image else None
+        sed = (ns, n_orig, n_view, p.n_ap, p.n_wav) if p.compute_sed else None
+        img = (ns, n_orig, n_view, p.n_y, p.n_x, p.n_wav) if p.compute_image else None
         return sed, img

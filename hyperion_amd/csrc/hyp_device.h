@@ -141,6 +141,8 @@ struct DProblem {
     const double *energy_abs_tot;         // [n_dust]
     double energy_total;
     int peel_scattered_only;              // final iteration peels only scattered packets (raytracing on)
+    int binned, n_bin_theta, n_bin_phi;   // binned images (images_binned.f90): index of their group in `peeled` (-1: none), direction bins
+    int pad7;
     int any_intersect;                    // a source can re-absorb packets (spheres): source.f90:216
     long long n_reabs_max;
     // modified random walk: per-iteration tables of mrw_prepare_kernel and the cumulative of Min et al. (2009) eq. 6

@@ -1044,14 +1044,29 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     }
 
     // peeled image groups: images_peeled.f90:272-380, image_type.f90:153-335
-    h->h_peeled.resize(pr->n_peeled);
-    std::vector<PeeledOffsets> poff(pr->n_peeled);
+    // the binned image group (images_binned.f90:42-56), if any, is one more image group after the peeled ones:
+    // n_theta x n_phi "views", never peeled into (P.n_peeled stays the number of peeled groups)
+    const int n_groups = pr->n_peeled + (pr->binned ? 1 : 0);
+    std::vector<hyp_peeled_desc> pdesc(pr->peeled, pr->peeled + pr->n_peeled);
+    std::vector<double> binned_angles;
+    if (pr->binned) {
+        if (pr->config.monochromatic) FAIL("can't use binned images in exact wavelength mode");                       // setup_rt.f90:328
+        if (pr->config.forced_first_interaction) FAIL("can't use binned images with forced first interaction");      // :329
+        if (pr->n_binned_theta < 1 || pr->n_binned_phi < 1) FAIL("n_theta and n_phi should be positive");
+        hyp_peeled_desc bd = *pr->binned;
+        bd.n_view = pr->n_binned_theta * pr->n_binned_phi; bd.inside_observer = 0;
+        binned_angles.assign((size_t)bd.n_view, 0.0);
+        bd.theta = binned_angles.data(); bd.phi = binned_angles.data();
+        pdesc.push_back(bd);
+    }
+    h->h_peeled.resize(n_groups);
+    std::vector<PeeledOffsets> poff(n_groups);
     std::vector<int> ray_groups;
-    h->sed_off.assign(pr->n_peeled, 0); h->img_off.assign(pr->n_peeled, 0);
-    h->sed_n.assign(pr->n_peeled, 0); h->img_n.assign(pr->n_peeled, 0);
+    h->sed_off.assign(n_groups, 0); h->img_off.assign(n_groups, 0);
+    h->sed_n.assign(n_groups, 0); h->img_n.assign(n_groups, 0);
     size_t img_total = 0;
-    for (int g = 0; g < pr->n_peeled; g++) {
-        const hyp_peeled_desc &in = pr->peeled[g];
+    for (int g = 0; g < n_groups; g++) {
+        const hyp_peeled_desc &in = pdesc[g];
         DPeeled &G = h->h_peeled[g];
         std::memset(&G, 0, sizeof(G));
         if (in.inside_observer) FAIL("inside observers are not supported yet");
@@ -1087,7 +1102,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             view[4 * v + 2] = std::cos(f); view[4 * v + 3] = std::sin(f);
         }
         poff[g].view = B.put(view);
-        if (pr->config.raytracing) ray_groups.push_back(g);
+        if (pr->config.raytracing && g < pr->n_peeled) ray_groups.push_back(g);
         if (in.compute_sed) {
             h->sed_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_ap * in.n_nu;
             h->sed_off[g] = img_total; img_total += 2 * h->sed_n[g];
@@ -1108,7 +1123,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         // (dust_type_4elem.f90:708-720, 780-791) at the group's own frequencies
         for (int g : ray_groups) {
             const int nn = h->h_peeled[g].n_nu;
-            const double *nu = pr->config.frequencies + (pr->peeled[g].inu_min - 1);
+            const double *nu = pr->config.frequencies + (pdesc[g].inu_min - 1);
             std::vector<double> spec((size_t)pr->n_sources * nn, 0.0), em((size_t)pr->n_dust * nj_stride * nn, 0.0), chi((size_t)pr->n_dust * nn, 0.0);
             for (int is = 0; is < pr->n_sources; is++) {
                 const hyp_source_desc &src = pr->sources[is];
@@ -1141,7 +1156,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         const double l0 = std::log10(3.e9), l1 = std::log10(3.e16);
         const int nb = (int)std::ceil((l1 - l0) * 100000);
         std::vector<double> bnu, bfnu;
-        std::vector<std::vector<double>> lo(pr->n_peeled), hi(pr->n_peeled), spec(pr->n_peeled), em(pr->n_peeled), chi(pr->n_peeled);
+        std::vector<std::vector<double>> lo(n_groups), hi(n_groups), spec(n_groups), em(n_groups), chi(n_groups);
         for (int g : ray_groups) {
             const DPeeled &G = h->h_peeled[g];
             const int nn = G.n_nu;
@@ -1324,7 +1339,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMalloc(&h->d_img_accum, sizeof(double) * h->img_accum_n));
         HIPC(hipMemset(h->d_img_accum, 0, sizeof(double) * h->img_accum_n));
     }
-    for (int g = 0; g < pr->n_peeled; g++) {
+    for (int g = 0; g < n_groups; g++) {
         DPeeled &G = h->h_peeled[g];
         G.view = db + poff[g].view;
         if (pr->config.raytracing) {
@@ -1334,9 +1349,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         if (h->sed_n[g]) { G.sed = h->d_img_accum + h->sed_off[g]; G.sed2 = G.sed + h->sed_n[g]; }
         if (h->img_n[g]) { G.img = h->d_img_accum + h->img_off[g]; G.img2 = G.img + h->img_n[g]; }
     }
-    if (pr->n_peeled > 0) {
-        HIPC(hipMalloc(&h->d_peeled, sizeof(DPeeled) * pr->n_peeled));
-        HIPC(hipMemcpy(h->d_peeled, h->h_peeled.data(), sizeof(DPeeled) * pr->n_peeled, hipMemcpyHostToDevice));
+    P.binned = pr->binned ? pr->n_peeled : -1; P.n_bin_theta = pr->n_binned_theta; P.n_bin_phi = pr->n_binned_phi;
+    if (n_groups > 0) {
+        HIPC(hipMalloc(&h->d_peeled, sizeof(DPeeled) * n_groups));
+        HIPC(hipMemcpy(h->d_peeled, h->h_peeled.data(), sizeof(DPeeled) * n_groups, hipMemcpyHostToDevice));
     }
     P.peeled = h->d_peeled;
 
@@ -1818,8 +1834,10 @@ int hyp_final_finish(hyp_handle h, hyp_iter_stats *stats)
     if (st.energy_current > 0.0) {
         double scale = h->energy_total / st.energy_current;
         for (size_t g = 0; g < h->h_peeled.size(); g++) {
-            if (h->sed_n[g]) image_scale_kernel<<<256, 256, 0, h->stream>>>(h->d_img_accum + h->sed_off[g], h->sed_n[g], scale);
-            if (h->img_n[g]) image_scale_kernel<<<1024, 256, 0, h->stream>>>(h->d_img_accum + h->img_off[g], h->img_n[g], scale);
+            // binned_images_adjust_scale (images_binned.f90:34-38): x n_theta x n_phi
+            const double sc = (int)g == h->hp.binned ? scale * (double)h->hp.n_bin_theta * (double)h->hp.n_bin_phi : scale;
+            if (h->sed_n[g]) image_scale_kernel<<<256, 256, 0, h->stream>>>(h->d_img_accum + h->sed_off[g], h->sed_n[g], sc);
+            if (h->img_n[g]) image_scale_kernel<<<1024, 256, 0, h->stream>>>(h->d_img_accum + h->img_off[g], h->img_n[g], sc);
         }
         e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) return h->set_error(std::string("image scaling failed: ") + hipGetErrorString(e));

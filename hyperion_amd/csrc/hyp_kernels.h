@@ -13,7 +13,8 @@
 
 #include "hyp_device.h"
 
-enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5, ST_MRW = 6 };
+enum { ST_NEED_EMIT = 0, ST_WALK = 1, ST_NEED_INTERACT = 2, ST_DONE = 3, ST_PLACED = 4, ST_NEED_REEMIT = 5, ST_MRW = 6,
+       ST_ESCAPED = 7 };      // imaging iteration only: left the grid alive (binned images), then ST_NEED_EMIT
 enum { LAST_SR = 0, LAST_DS = 1, LAST_DE = 2 };
 
 #define GEOM_CAR 0
@@ -660,7 +661,8 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
         }
         geo_advance(P, p.r, p.cell, im);
         if (geo_invalid(P, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }     // amr: invalid_cell
-        return geo_escaped(P, p.cell) ? ST_NEED_EMIT : ST_WALK;
+        // the imaging iteration (no deposits) tells packets that left the grid from killed ones: iter_final.f90:127-129
+        return geo_escaped(P, p.cell) ? (DEPOSIT ? ST_NEED_EMIT : ST_ESCAPED) : ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
         if (P.any_intersect) { p.t_ach += tact; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // :184-188
@@ -1236,6 +1238,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 #pragma unroll 1
         for (int k = 0; k < HYP_WALK_STEPS; k++) {
             if (st == ST_WALK) st = walk_step<NDT, GEOM, kDeposit>(P, W, p, g, sum, cnt);
+                if (!kDeposit && st == ST_ESCAPED) st = ST_NEED_EMIT;      // HYP_NO_DEPOSIT probe builds
         }
     }
 
@@ -1797,6 +1800,34 @@ __device__ __forceinline__ bool emit_mono_dust(const DProblem &P, const Walls &W
     return p.energy > 0.0;
 }
 
+// binned_images_bin_photon: images_binned.f90:58-81.  Called by ALL lanes of the wave (`active` = this lane's packet
+// just left the grid); the deposit goes through the same wave-combined path as the peel-off.
+template <int NDT, int GEOM>
+__device__ __forceinline__ void bin_escaped(const DProblem &P, const Packet<NDT, GEOM> &p, bool active, const PeelFlags &f)
+{
+    const DPeeled &G = P.peeled[P.binned];
+    long long k_img = -1, k_sed = -1;
+    double val[4] = {0.0, 0.0, 0.0, 0.0};
+    if (active) {
+        double phi = atan2(p.a.sinp, p.a.cosp);
+        if (phi < 0.0) phi = phi + HYP_TWOPI;
+        const int it = ipos0(-1.0, 1.0, p.a.cost, P.n_bin_theta), ip = ipos0(0.0, HYP_TWOPI, phi, P.n_bin_phi);
+        if (it >= 0 && it < P.n_bin_theta && ip >= 0 && ip < P.n_bin_phi) {
+            const double x_image = p.r[1] * p.a.cosp - p.r[0] * p.a.sinp;
+            const double y_image = p.r[2] * p.a.sint - p.r[1] * p.a.cost * p.a.sinp - p.r[0] * p.a.cost * p.a.cosp;
+            image_bin_keys(P, G, p.nu, p.energy, p.s[0], f, x_image, y_image, P.n_bin_phi * it + ip, k_img, k_sed);
+#pragma unroll
+            for (int i = 0; i < 4; i++) val[i] = p.s[i] * p.energy;
+        }
+    }
+    if (G.compute_image)
+        wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img,
+                        (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, G.n_stokes, val);
+    if (G.compute_sed)
+        wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed,
+                        (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu, G.n_stokes, val);
+}
+
 // forced first interaction: forced_interaction.f90:23-133
 __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau_escape, double xi, double &tau, double &weight)
 {
@@ -1838,6 +1869,11 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     double e_init = 0.0;       // monochromatic: energy at emission (the packet dies below mono_threshold of it)
 
     for (;;) {
+        // packets that left the grid alive go into the binned images (iter_final.f90:127-129), then their lane is free
+        if (__ballot(st == ST_ESCAPED)) {
+            if (P.binned >= 0) bin_escaped<NDT, GEOM>(P, p, st == ST_ESCAPED, f);
+            if (st == ST_ESCAPED) st = ST_NEED_EMIT;
+        }
         unsigned long long m_walk = __ballot(st == ST_WALK);
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
@@ -1962,7 +1998,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
             if (peel != 0) {
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
-                    if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
+                    if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
                     else {
                         bool sampled = false;
                         if (P.forced_first) {
@@ -1980,7 +2016,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 } else if (peel == 3 && geo_escaped(P, p.cell)) {
-                    st = ST_NEED_EMIT;
+                    st = ST_ESCAPED;
                 } else if (peel == 4) {
                     // stays in ST_MRW: the next pass decides on another step
                 } else if (peel == 2 && P.mrw && !P.mono_which) {

@@ -716,7 +716,11 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                 if (j >= tk.len) exhausted = true;
                 else {
                     slot = order[tk.start + j];
+#ifdef HYP_TILE_ABLATE_REFILL      // timing experiment only (wrong results): records from a cache-hot window
+                    const HotRec<ND> &H = hot[slot & 1023];
+#else
                     const HotRec<ND> &H = hot[slot];
+#endif
                     v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {

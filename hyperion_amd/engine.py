@@ -261,7 +261,7 @@ class Engine:
 
     def peeled_results(self):
         out = []
-        for g in range(len(self.problem.peeled)):
+        for g in range(len(self.problem.peeled) + (1 if self.problem.binned is not None else 0)):
             n_orig = self._lib.hyp_peeled_n_orig(self._h, g)
             sed_shape, img_shape = self._m.peeled_shapes(g, n_orig)
             grp = {}

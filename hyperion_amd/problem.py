@@ -197,6 +197,11 @@ class Problem:
     config: RunConfig = field(default_factory=RunConfig)
     peeled: List[PeeledImages] = field(default_factory=list)
     specific_energy: Optional[np.ndarray] = None
+    # /Output/Binned/group_00001 (src/images/images_binned.f90): a PeeledImages carrying the image settings (its
+    # viewing angles are ignored) and the number of direction bins
+    binned: Optional[PeeledImages] = None
+    n_binned_theta: int = 0
+    n_binned_phi: int = 0
     grid_type: str = "car"
     geometry_id: str = ""
     refined: Optional[np.ndarray] = None
@@ -383,6 +388,9 @@ class Problem:
                 else:
                     m[k] = list(v) if isinstance(v, tuple) else v
             meta["peeled"].append(m)
+        if self.binned is not None:
+            meta["binned"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in self.binned.__dict__.items() if not isinstance(v, np.ndarray)}
+            meta["n_binned"] = [int(self.n_binned_theta), int(self.n_binned_phi)]
         arrays["meta_json"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
         np.savez_compressed(path, **arrays)
 
@@ -425,6 +433,14 @@ class Problem:
             if "peeloff_origin" in kw:
                 kw["peeloff_origin"] = tuple(kw["peeloff_origin"])
             peeled.append(PeeledImages(**kw))
+        binned, nb = None, (0, 0)
+        if "binned" in meta:
+            kw = dict(meta["binned"])
+            for k in ("d_min", "d_max"):
+                if kw.get(k) is None:
+                    kw.pop(k, None)
+            kw["peeloff_origin"] = tuple(kw.get("peeloff_origin", (0.0, 0.0, 0.0)))
+            binned, nb = PeeledImages(theta=[0.0], phi=[0.0], **kw), meta["n_binned"]
         cfg = RunConfig(**meta["config"])
         if "config/frequencies" in z.files:
             cfg.frequencies = z["config/frequencies"]
@@ -432,6 +448,7 @@ class Problem:
         return cls(walls=walls, density=z["density"],
                    dust=dust, sources=sources, config=cfg, peeled=peeled,
                    specific_energy=z["specific_energy"] if "specific_energy" in z.files else None,
+                   binned=binned, n_binned_theta=int(nb[0]), n_binned_phi=int(nb[1]),
                    grid_type=meta.get("grid_type", "car"), geometry_id=meta.get("geometry_id", ""),
                    refined=z["refined"] if "refined" in z.files else None,
                    oct_center=tuple(meta.get("oct_center", (0.0, 0.0, 0.0))),

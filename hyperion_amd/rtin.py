@@ -215,11 +215,13 @@ def read_rtin(path):
                 raise ValueError("Point source cannot have LTE spectrum")
             sources.append(s)
 
-        peeled = []
-        if "Peeled" in f["Output"]:
-            for n in sorted(f["Output/Peeled"].keys()):
-                g = f["Output/Peeled"][n]
-                pa = g.attrs
+        def image_group(g, binned=False):
+            """image_setup (src/images/image_type.f90:153-335); a peeled group also carries its viewing angles and
+            observer settings (images_peeled.f90:306-345), a binned one n_theta / n_phi (images_binned.f90:42-56)."""
+            pa = g.attrs
+            if binned:
+                p = PeeledImages(theta=[0.0], phi=[0.0])
+            else:
                 ang = g["angles"][...]
                 p = PeeledImages(theta=ang["theta"], phi=ang["phi"])
                 p.inside_observer = _b(pa["inside_observer"])
@@ -229,26 +231,39 @@ def read_rtin(path):
                     p.peeloff_origin = tuple(float(pa["observer_" + k]) for k in "xyz")
                 else:
                     p.peeloff_origin = tuple(float(pa["peeloff_" + k]) for k in "xyz")
-                p.n_wav = int(pa["n_wav"])
-                if cfg.monochromatic:       # image_type.f90:243-258
-                    p.inu_min, p.inu_max = int(pa["inu_min"]), int(pa["inu_max"])
-                else:
-                    p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])
-                p.compute_image = _b(pa["compute_image"])
-                if p.compute_image:
-                    p.n_x, p.n_y = int(pa["n_x"]), int(pa["n_y"])
-                    p.x_min, p.x_max = float(pa["x_min"]), float(pa["x_max"])
-                    p.y_min, p.y_max = float(pa["y_min"]), float(pa["y_max"])
-                p.compute_sed = _b(pa["compute_sed"])
-                if p.compute_sed:
-                    p.n_ap = int(pa["n_ap"])
-                    p.ap_min, p.ap_max = float(pa["ap_min"]), float(pa["ap_max"])
-                p.track_origin = _s(pa["track_origin"]).strip()
-                p.track_n_scat = int(pa["track_n_scat"]) if "track_n_scat" in pa else 0
-                p.uncertainties = _b(pa["uncertainties"])
-                p.compute_stokes = _b(pa["compute_stokes"]) if "compute_stokes" in pa else True
-                peeled.append(p)
+            p.n_wav = int(pa["n_wav"])
+            if cfg.monochromatic:       # image_type.f90:243-258
+                p.inu_min, p.inu_max = int(pa["inu_min"]), int(pa["inu_max"])
+            else:
+                p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])
+            p.compute_image = _b(pa["compute_image"])
+            if p.compute_image:
+                p.n_x, p.n_y = int(pa["n_x"]), int(pa["n_y"])
+                p.x_min, p.x_max = float(pa["x_min"]), float(pa["x_max"])
+                p.y_min, p.y_max = float(pa["y_min"]), float(pa["y_max"])
+            p.compute_sed = _b(pa["compute_sed"])
+            if p.compute_sed:
+                p.n_ap = int(pa["n_ap"])
+                p.ap_min, p.ap_max = float(pa["ap_min"]), float(pa["ap_max"])
+            p.track_origin = _s(pa["track_origin"]).strip()
+            p.track_n_scat = int(pa["track_n_scat"]) if "track_n_scat" in pa else 0
+            p.uncertainties = _b(pa["uncertainties"])
+            p.compute_stokes = _b(pa["compute_stokes"]) if "compute_stokes" in pa else True
+            return p
+
+        peeled = []
+        if "Peeled" in f["Output"]:
+            for n in sorted(f["Output/Peeled"].keys()):
+                peeled.append(image_group(f["Output/Peeled"][n]))
+        binned, nb = None, (0, 0)
+        if "Binned" in f["Output"] and len(f["Output/Binned"].keys()) > 0:
+            names = sorted(f["Output/Binned"].keys())
+            if len(names) > 1:
+                raise ValueError("can't have more than one binned image group")      # setup_rt.f90:324
+            g = f["Output/Binned"][names[0]]
+            binned, nb = image_group(g, binned=True), (int(g.attrs["n_theta"]), int(g.attrs["n_phi"]))
 
         return Problem(walls=walls, density=density, dust=dust, sources=sources, config=cfg,
                        peeled=peeled, specific_energy=spec, grid_type=grid_type,
+                       binned=binned, n_binned_theta=nb[0], n_binned_phi=nb[1],
                        geometry_id=_s(geo.attrs["geometry"]), **extra)

@@ -146,30 +146,36 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
             n_done = it
             break
     peeled, fstats = [], {"killed_geo": 0, "killed_int": 0}
+    groups = list(problem.peeled) + ([problem.binned] if problem.binned is not None else [])
     log(" [main] starting final iteration")
     freq = cfg.frequencies if cfg.monochromatic else None
     if cfg.monochromatic:
         # main.f90:271-272: do_final_mono(n_last_photons_sources, n_last_photons_dust, ...)
         if problem.peeled:
             raw, fstats = mono_iteration_sharded(eng, cfg.n_last_photons_sources, cfg.n_last_photons_dust, len(freq), rank, world_size)
-            peeled = [finalize_peeled(p, r, freq) for p, r in zip(problem.peeled, raw)]
+            peeled = [finalize_peeled(p, r, freq) for p, r in zip(groups, raw)]
     elif cfg.n_last_photons > 0:
         raw, fstats = final_iteration_sharded(eng, cfg.n_last_photons, rank, world_size)
-        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, raw)]
+        peeled = [finalize_peeled(p, r) for p, r in zip(groups, raw)]
     else:
         log("      ------------------ Skipping ------------------")
-        peeled = [finalize_peeled(p, r) for p, r in zip(problem.peeled, eng.peeled_results())]
+        peeled = [finalize_peeled(p, r) for p, r in zip(groups, eng.peeled_results())]
     log(" [main] exiting final iteration")
     rstats = {"killed_geo": 0, "killed_int": 0}
     if cfg.raytracing:
         # main.f90:296-305: direct and thermal emission with the emitters' whole spectra
         log(" [main] starting raytracing iteration")
         raw, rstats = raytracing_iteration_sharded(eng, cfg.n_ray_photons_sources, cfg.n_ray_photons_dust, rank, world_size)
-        peeled = [finalize_peeled(p, r, freq) for p, r in zip(problem.peeled, raw)]
+        peeled = [finalize_peeled(p, r, freq) for p, r in zip(groups, raw)]
         log(" [main] exiting raytracing iteration")
     eng.close()
+    binned = None
+    if problem.binned is not None:      # the engine returns the binned cubes as the group after the peeled ones
+        binned = peeled[len(problem.peeled)] if len(peeled) > len(problem.peeled) else None
+        peeled = peeled[:len(problem.peeled)]
     res = RunResult(records, converged, n_done, peeled, fstats, time.time() - t0, date_started, _now())
     res.raytracing_stats = rstats
+    res.binned = binned
     return res
 
 
@@ -247,6 +253,27 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                 if problem.config.monochromatic:     # image_type.f90:781-784
                     nu = np.asarray(problem.config.frequencies, dtype=float)[pl.inu_min - 1:pl.inu_max]
                     g.create_dataset("frequencies", data=np.array(list(zip(nu)), dtype=[("nu", "<f8")]))
+        if getattr(result, "binned", None) is not None:
+            # binned_images_write (images_binned.f90:89-93): image_write straight into /Binned
+            g = f.create_group("Binned")
+            pl = problem.binned
+            for name, extra in (("seds", {"apmin": pl.ap_min, "apmax": pl.ap_max}),
+                                ("images", {"xmin": pl.x_min, "xmax": pl.x_max, "ymin": pl.y_min, "ymax": pl.y_max})):
+                if name not in result.binned:
+                    continue
+                d = g.create_dataset(name, data=result.binned[name], compression="gzip")
+                d.attrs["numin"] = np.float64(pl.nu_min)
+                d.attrs["numax"] = np.float64(pl.nu_max)
+                for k, v in extra.items():
+                    d.attrs[k] = np.float64(v)
+                d.attrs["track_origin"] = b(pl.track_origin)
+                if pl.track_origin == "detailed":
+                    d.attrs["n_sources"] = np.int32(len(problem.sources))
+                    d.attrs["n_dust"] = np.int32(problem.n_dust)
+                elif pl.track_origin == "scatterings":
+                    d.attrs["track_n_scat"] = np.int32(pl.track_n_scat)
+                if name + "_unc" in result.binned:
+                    g.create_dataset(name + "_unc", data=result.binned[name + "_unc"], compression="gzip")
         f.attrs["killed_photons_geo_final"] = np.int32(result.final_stats.get("killed_geo", 0))
         f.attrs["killed_photons_int_final"] = np.int32(result.final_stats.get("killed_int", 0))
         rst = getattr(result, "raytracing_stats", None) or {}

@@ -177,6 +177,12 @@ typedef struct hyp_problem {
     const hyp_peeled_desc *peeled;
     const double *density;           /* [n_dust][n3][n2][n1] (cartesian) or [n_dust][n_cells] (octree, voronoi, amr), as in the .rtin */
     const double *specific_energy;   /* same shape, or NULL */
+    /* /Output/Binned/group_00001 (src/images/images_binned.f90:42-56): packets leaving the grid in the final iteration
+     * are binned by direction into n_binned_theta x n_binned_phi views (cos(theta) in [-1,1], phi in [0,2pi));
+     * `binned` describes the image like a peeled group (its n_view, theta, phi, inu_* are ignored); NULL = none.
+     * The cubes are returned as group index n_peeled. */
+    const hyp_peeled_desc *binned;
+    int32_t n_binned_theta, n_binned_phi;
 } hyp_problem;
 
 typedef struct hyp_iter_stats {

@@ -443,6 +443,7 @@ struct orc_state {
     int mono_inu; double *mono_cdf; double mono_mean_prob[ORC_MAX_DUST];
     double check_p, check_log1mp;
     int n_dust, n_sources, n_peeled;
+    int has_binned, n_theta, n_phi, n_groups;   /* binned images (images_binned.f90): group index n_peeled; n_groups = n_peeled + has_binned */
     dust_t *dust;
     source_t *src;
     double *lum_pdf, *lum_cdf;
@@ -1247,7 +1248,22 @@ int orc_create(const orc_problem *pr, orc_state **out)
     check_energy_abs(st);
 
     st->n_peeled = pr->n_peeled;
-    st->peeled = calloc(st->n_peeled ? st->n_peeled : 1, sizeof(peeled_t));
+    st->has_binned = pr->binned != NULL;
+    st->n_groups = st->n_peeled + st->has_binned;
+    st->peeled = calloc(st->n_groups ? st->n_groups : 1, sizeof(peeled_t));
+    if (st->has_binned) {   /* setup_rt.f90:327-331, binned_images_setup :42-56 */
+        if (st->cfg.monochromatic) { snprintf(g_error, sizeof g_error, "can't use binned images in exact wavelength mode"); orc_destroy(st); return 1; }
+        if (st->cfg.forced_first_interaction) { snprintf(g_error, sizeof g_error, "can't use binned images with forced first interaction"); orc_destroy(st); return 1; }
+        st->n_theta = pr->n_binned_theta; st->n_phi = pr->n_binned_phi;
+        if (st->n_theta < 1 || st->n_phi < 1) { snprintf(g_error, sizeof g_error, "n_theta and n_phi should be positive"); orc_destroy(st); return 1; }
+        orc_peeled_desc bd = *pr->binned;
+        bd.n_view = st->n_theta * st->n_phi;
+        double *zeros = calloc(bd.n_view, sizeof(double));
+        bd.theta = zeros; bd.phi = zeros; bd.inside_observer = 0;
+        int rc = peeled_setup(st, &st->peeled[st->n_peeled], &bd);
+        free(zeros);
+        if (rc) { orc_destroy(st); return 1; }
+    }
     for (int g = 0; g < st->n_peeled; g++)
         if (peeled_setup(st, &st->peeled[g], &pr->peeled[g])) { orc_destroy(st); return 1; }
     if (st->cfg.raytracing) raytracing_caches(st);
@@ -1274,7 +1290,7 @@ void orc_destroy(orc_state *st)
         }
         free(st->src);
     }
-    if (st->peeled) { for (int g = 0; g < st->n_peeled; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
+    if (st->peeled) { for (int g = 0; g < st->n_groups; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
     free(st->lum_pdf); free(st->lum_cdf);
     free(st->density); free(st->specific_energy); free(st->specific_energy_add);
     free(st->specific_energy_sum); free(st->jnu_var_id); free(st->jnu_var_frac);
@@ -3213,6 +3229,17 @@ static void final_packet(const orc_state *st, uint64_t id, acc_t *acc)
         if (p.killed) break;
         if (st->n_peeled && (p.scattered || !scattering_only)) peeloff_photon(st, &p, &g, acc, 0);
     }
+    /* iter_final.f90:127-129 + binned_images_bin_photon (images_binned.f90:58-81): packets that were not killed */
+    if (st->has_binned && !p.killed) {
+        double phi = atan2(p.a.sinp, p.a.cosp);
+        if (phi < 0.0) phi = phi + 2.0 * PI;
+        int it = ipos0(-1.0, 1.0, p.a.cost, st->n_theta), ip = ipos0(0.0, 2.0 * PI, phi, st->n_phi);
+        if (it >= 0 && it < st->n_theta && ip >= 0 && ip < st->n_phi) {
+            double x_image = p.r[1] * p.a.cosp - p.r[0] * p.a.sinp;
+            double y_image = p.r[2] * p.a.sint - p.r[1] * p.a.cost * p.a.sinp - p.r[0] * p.a.cost * p.a.cosp;
+            image_bin(st, st->n_peeled, &p, x_image, y_image, st->n_phi * it + ip, acc);
+        }
+    }
 }
 
 static uint64_t g_final_first_id = 0;   /* debugging aid: id offset of the next final iteration */
@@ -3229,7 +3256,7 @@ static int image_run(orc_state *st, uint64_t n_packets, int n_threads, uint64_t 
     if ((uint64_t)nt > n_packets && n_packets > 0) nt = (int)n_packets;
     if (nt < 1) nt = 1;
     acc_t *accs = calloc(nt, sizeof(acc_t));
-    int ng = st->n_peeled;
+    int ng = st->n_groups;
     for (int t = 0; t < nt; t++) {
         accs[t].sed = calloc(ng ? ng : 1, sizeof(double *)); accs[t].sed2 = calloc(ng ? ng : 1, sizeof(double *));
         accs[t].img = calloc(ng ? ng : 1, sizeof(double *)); accs[t].img2 = calloc(ng ? ng : 1, sizeof(double *));
@@ -3299,10 +3326,12 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
     /* peeled_images_adjust_scale(energy_total/energy_current): image_type.f90:136-151 */
     if (tot.energy_current > 0.0) {
         double scale = st->energy_total / tot.energy_current;
-        for (int g = 0; g < st->n_peeled; g++) {
+        for (int g = 0; g < st->n_groups; g++) {
             peeled_t *pg = &st->peeled[g];
-            if (pg->sed) for (size_t k = 0; k < pg->sed_size; k++) { pg->sed[k] *= scale; pg->sed2[k] *= scale * scale; }
-            if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] *= scale; pg->img2[k] *= scale * scale; }
+            /* binned_images_adjust_scale :34-38: x n_theta x n_phi (flux per bin -> 4 pi normalisation of the peeled images) */
+            const double sc = g == st->n_peeled ? scale * (double)st->n_theta * (double)st->n_phi : scale;
+            if (pg->sed) for (size_t k = 0; k < pg->sed_size; k++) { pg->sed[k] *= sc; pg->sed2[k] *= sc * sc; }
+            if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] *= sc; pg->img2[k] *= sc * sc; }
         }
     }
     if (stats) *stats = tot;

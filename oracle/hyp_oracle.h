@@ -173,6 +173,12 @@ typedef struct orc_problem {
     const orc_peeled_desc *peeled;   /* [n_peeled] */
     const double *density;           /* [n_dust][n_cells] (n_dust,nz,ny,nx) */
     const double *specific_energy;   /* [n_dust][n_cells] or NULL */
+    /* /Output/Binned/group_00001 (src/images/images_binned.f90:42-56): packets leaving the grid in the final iteration
+     * are binned by direction into n_binned_theta x n_binned_phi views (cos(theta) in [-1,1], phi in [0,2pi));
+     * `binned` describes the image like a peeled group (its n_view, theta, phi, inu_* are ignored); NULL = none.
+     * The cubes are returned as group index n_peeled. */
+    const orc_peeled_desc *binned;
+    int32_t n_binned_theta, n_binned_phi;
 } orc_problem;
 
 typedef struct orc_iter_stats {

@@ -177,7 +177,7 @@ class Oracle:
     def peeled_views(self):
         """Writable numpy views (sed, img) of every group's cubes."""
         out = []
-        for g in range(len(self.problem.peeled)):
+        for g in range(len(self.problem.peeled) + (1 if self.problem.binned is not None else 0)):
             n_orig = lib().orc_peeled_n_orig(self.h, g)
             sed_shape, img_shape = self.m.peeled_shapes(g, n_orig)
             v = {}
@@ -197,7 +197,7 @@ class Oracle:
 
     def _peeled(self):
         out = []
-        for g in range(len(self.problem.peeled)):
+        for g in range(len(self.problem.peeled) + (1 if self.problem.binned is not None else 0)):
             n_orig = lib().orc_peeled_n_orig(self.h, g)
             sed_shape, img_shape = self.m.peeled_shapes(g, n_orig)
             grp = {}
