@@ -134,3 +134,50 @@ def test_full_size_image_512():
     # the central pixel block holds the direct source light
     c = img[0, 0, 0, 254:258, 254:258, 0].sum()
     assert c > 0.1 * img[0].sum()
+
+
+def test_binned_images_parity_and_scaling():
+    """images_binned.f90 on the GPU: packets that leave the grid alive in the final iteration are binned by
+    direction; parity with the oracle on identical streams (cubes of the binned group = group index n_peeled),
+    together with a peeled group, origin tracking and uncertainties; a killed packet is not binned."""
+    from test_oracle_units import binned_problem
+    p = binned_problem()
+    p.binned.uncertainties = True
+    p.config.n_inter_max = 3                    # some packets are killed: they must not be binned
+    eng, orc = hyperion_amd.Engine(p), Oracle(p)
+    for it in (1, 2):
+        eng.lucy_iteration(20000, it); orc.lucy_iteration(20000, it)
+    ra, sa = eng.final_iteration(60000)
+    rb, sb = orc.final_iteration(60000)
+    eng.close(); orc.close()
+    for k in ("crossings", "interactions", "killed_geo", "killed_int"):
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["killed_int"] > 0
+    assert len(ra) == len(rb) == 2
+    for ga, gb in zip(ra, rb):
+        for name in gb:
+            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
+    assert ra[1]["sed"].shape == (4, 4, 12, 1, 5) and ra[1]["sed2"].max() > 0
+
+
+def test_binned_images_on_a_cartesian_grid_with_run():
+    """run(): the binned cubes come back separately (RunResult.binned) and every direction bin is filled."""
+    from hyperion_amd.problem import PeeledImages
+    from hyperion_amd.run import run_problem
+    p = imaging_problem(n=8, tau=0.5)
+    p.config.forced_first_interaction = False
+    p.config.n_initial_iter = 1
+    p.config.n_initial_photons = 20000
+    p.config.n_last_photons = 100000
+    p.binned = PeeledImages(theta=[0.0], phi=[0.0], n_wav=3, wav_min=0.1, wav_max=1000.0, compute_image=False,
+                            n_ap=1, ap_min=3 * PC, ap_max=3 * PC)
+    p.n_binned_theta, p.n_binned_phi = 3, 4
+    r = run_problem(p)
+    assert len(r.peeled) == 1 and r.binned is not None
+    s = r.binned["seds"]
+    assert s.shape == (4, 1, 12, 1, 3)
+    assert np.all(s[0].sum(axis=(0, 2, 3)) > 0)
+    # total over the bins / (n_theta n_phi) = the 4 pi average the peeled image approximates
+    tot = s[0, 0, :, 0, :].mean(axis=0).sum()
+    peel = r.peeled[0]["seds"][0, 0, 0, -1, :].sum()
+    assert tot == pytest.approx(peel, rel=0.1)

@@ -353,7 +353,8 @@ def binned_problem(n_theta=4, n_phi=3):
     from hyperion_amd.problem import PeeledImages
     p = _polar_problem("sph_pol", [np.linspace(0, PC, 9), np.linspace(0, np.pi, 5), np.linspace(0, 2 * np.pi, 4)], 1.0)
     p.config.forced_first_interaction = False       # setup_rt.f90:329: binned images exclude it
-    kw = dict(n_wav=5, wav_min=0.1, wav_max=1000.0, n_x=4, n_y=4, x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC,
+    # (odd pixel counts: unscattered packets of the central source project onto (0, 0) +- round-off, which must not be a pixel edge)
+    kw = dict(n_wav=5, wav_min=0.1, wav_max=1000.0, n_x=5, n_y=5, x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC,
               n_ap=1, ap_min=2 * PC, ap_max=2 * PC, track_origin="basic")
     p.peeled = [PeeledImages(theta=[60.0], phi=[20.0], **kw)]
     p.binned = PeeledImages(theta=[0.0], phi=[0.0], **kw)
