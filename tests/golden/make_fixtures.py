@@ -353,7 +353,86 @@ def pascucci_fixture(tmp):
         T.teardown_class(T)
 
 
+def pinte_fixture(tmp):
+    """test_bit_level.py:447-545 (TestPinteBenchmark.test_pinte_seds): Pinte et al. (2009) disc on a 100 x 30 x 1
+    CYLINDRICAL polar grid, stellar sphere, anisotropic polarising dust (pinte_dust_lite.hdf5), up to 10 Lucy
+    iterations with the convergence test, MRW (gamma = 2), monochromatic final iteration at 51 wavelengths with
+    energy threshold 1e-2, raytracing, at most 1000 interactions.  golden = seds, number of iterations and last
+    specific energy of hyperion/model/tests/data/test_pinte_seds.tau=*.rtout."""
+    from hyperion.model import AnalyticalYSOModel
+    from hyperion.dust import SphericalDust
+    from hyperion.util.constants import au, msun, rsun, sigma
+    dl = None
+    for tau in (1000, 10000, 100000):
+        m = AnalyticalYSOModel()
+        m.star.radius = 2. * rsun
+        m.star.temperature = 4000.
+        m.star.luminosity = 4. * np.pi * (2. * rsun) ** 2. * sigma * 4000. ** 4.
+        disk = m.add_flared_disk()
+        disk.p = -1.5
+        disk.beta = 1.125
+        disk.mass = 3.e-8 * msun * tau / 1.e3
+        disk.rmin = 0.1 * au
+        disk.rmax = 400 * au
+        disk.h_0 = 10 * au
+        disk.r_0 = 100. * au
+        disk.cylindrical_inner_rim = True
+        disk.cylindrical_outer_rim = True
+        disk.dust = SphericalDust(os.path.join(DATA, 'pinte_dust_lite.hdf5'))
+        theta = np.degrees(np.arccos(np.array([0.95, 0.25, 0.15, 0.05])))
+        image = m.add_peeled_images()
+        image.set_viewing_angles(theta, np.array([45., 45., 45., 45.]))
+        image.set_image_size(1, 1)
+        image.set_image_limits(-450. * au, 450. * au, -450. * au, 450. * au)
+        image.set_aperture_radii(1, 450. * au, 450. * au)
+        image.set_wavelength_range(2000, 0.01, 5000.)
+        image.set_stokes(True)
+        m.set_raytracing(True)
+        m.set_n_initial_iterations(10)
+        m.set_convergence(True, percentile=99., absolute=2., relative=1.02)
+        m.set_cylindrical_polar_grid_auto(100, 30, 1)
+        wavelengths = [0.110635, 0.135419, 0.165755, 0.202887, 0.248336,
+                       0.303967, 0.372060, 0.455408, 0.557426, 0.682297,
+                       0.835142, 1.02223, 1.25122, 1.53151, 1.87459,
+                       2.29453, 2.80854, 3.43769, 4.20779, 5.15039, 6.30416,
+                       7.71638, 9.44497, 11.5608, 14.1506, 17.3205, 21.2006,
+                       25.9498, 31.7629, 38.8783, 47.5876, 58.2480, 71.2964,
+                       87.2678, 106.817, 130.746, 160.035, 195.885, 239.766,
+                       293.477, 359.220, 439.691, 538.188, 658.751, 806.321,
+                       986.948, 1208.04, 1478.66, 1809.90, 2215.34, 2711.61]
+        m.set_monochromatic(True, wavelengths=wavelengths, energy_threshold=1e-2)
+        m.set_mrw(True, gamma=2.)
+        m.set_n_photons(initial=5000, imaging_sources=100, imaging_dust=200,
+                        raytracing_sources=1000, raytracing_dust=1000)
+        m.set_max_interactions(1000, warn=False)
+        prob = write_and_read(m, tmp)
+        ref = os.path.join(DATA, "test_pinte_seds.tau=%s.rtout" % tau)
+        golden = {}
+        with h5py.File(ref, "r") as f:
+            grp = f["Peeled/group_00001"]
+            golden["seds"] = grp["seds"][...]
+            n_it = int(f.attrs["iterations"])
+            golden["iterations"] = np.int32(n_it)
+            golden["converged"] = np.bool_(f.attrs["converged"].decode().strip() == "yes")
+            golden["specific_energy_last"] = read_specific_energy(f["iteration_%05d" % n_it])
+        path = os.path.join(HERE, "pinte_seds.tau=%s.npz" % tau)
+        ptmp = path + ".problem.npz"
+        if dl is None:
+            dl = prob.dust[0]
+            np.savez_compressed(os.path.join(HERE, "pinte_dust_lite.npz"), **{k: v for k, v in dl.__dict__.items() if isinstance(v, np.ndarray)})
+        prob.to_npz(ptmp, dust_library={"pinte_dust_lite.npz": dl})
+        z = dict(np.load(ptmp)); os.remove(ptmp)
+        for k, v in golden.items():
+            z["golden/" + k] = v
+        np.savez_compressed(path, **z)
+        print("wrote", path, os.path.getsize(path), "iterations", n_it)
+
+
 def main():
+    if "pinte" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            pinte_fixture(tmp)
+        return
     if "mrw" in sys.argv[1:]:
         mrw_fixture()
         return

@@ -249,3 +249,46 @@ def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
     tot_s = samples[:, 0, 0, :, 0, :].sum(axis=2)
     for iv in range(3):
         assert abs(g[iv].sum() - I[iv].sum()) < 4.0 * tot_s[:, iv].std(ddof=1) + 0.02 * I[iv].sum()
+
+
+def _pinte_run(prob, n_iter, seed):
+    prob.config.seed = seed
+    o = Oracle(prob)
+    for it in range(1, n_iter + 1):
+        o.lucy_iteration(5000, it)
+    o.mono_iteration(100, 200)
+    res, st = o.raytracing_iteration(1000, 1000)
+    o.close()
+    return res[0]["sed"]
+
+
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000"])
+def test_pinte_benchmark_seds_match_reference_golden(tau):
+    """test_pinte_seds.tau=*.rtout (test_bit_level.py:447-545): Pinte et al. (2009) disc on a 100 x 30 CYLINDRICAL
+    polar grid, stellar sphere, anisotropic polarising dust, 10 Lucy iterations of 5000 packets with the MODIFIED
+    RANDOM WALK (gamma = 2, at most 1000 interactions), MONOCHROMATIC final iteration at 51 wavelengths (100 + 200
+    packets, energy threshold 1e-2) and RAYTRACING: every piece of the path in one model.  The golden is one
+    realisation; z-scores of its Stokes I against K oracle realisations at the same packet numbers."""
+    prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
+    c = prob.config
+    assert prob.grid_type == "cyl_pol" and c.monochromatic and c.mrw and c.raytracing and c.n_inter_max == 1000
+    assert prob.sources[0].type == "sphere" and c.monochromatic_energy_threshold == 1e-2
+    n_iter = int(z["golden/iterations"])
+    gold = z["golden/seds"]
+    nu = c.frequencies
+    K = 12
+    S = np.array([_pinte_run(prob, n_iter, -(500 + k)) for k in range(K)]) * nu
+    assert S.shape[1:] == gold.shape == (4, 1, 4, 1, 51)
+    I, sg = S.mean(axis=0)[0, 0, :, 0, :], S.std(axis=0, ddof=1)[0, 0, :, 0, :]
+    g = gold[0, 0, :, 0, :]
+    sel = (sg > 0) & (I > 1e-3 * I.max())
+    zs = (g - I)[sel] / sg[sel]
+    assert sel.sum() > 80
+    # The optically thicker discs show the inclined views in scattered light only: a bin then holds a few of the
+    # golden's 100 + 200 monochromatic packets, its distribution is skewed (rare bright peel-offs, never far below
+    # the mean).  The normal-tail bound applies to the well-sampled bins, a one-sided bound to the rest.
+    well = sg[sel] < 0.3 * I[sel]
+    assert well.sum() > 20
+    assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
+    if (~well).any():
+        assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
