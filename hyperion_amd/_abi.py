@@ -34,7 +34,7 @@ class SourceDesc(C.Structure):
         ("luminosity", C.c_double), ("temperature", C.c_double),
         ("position", C.c_double * 3), ("radius", C.c_double), ("box", C.c_double * 6),
         ("spec_nu", _dp), ("spec_fnu", _dp),
-        ("direction", C.c_double * 2), ("points", _dp), ("point_lum", _dp),
+        ("direction", C.c_double * 2), ("points", _dp), ("point_lum", _dp), ("map", _dp),
     ]
 
 
@@ -101,7 +101,7 @@ class IterStats(C.Structure):
                 "n_packets": self.n_packets}
 
 
-SOURCE_TYPES = {"point": 1, "sphere": 2, "extern_sph": 5, "extern_box": 6, "plane_parallel": 7, "point_collection": 8}
+SOURCE_TYPES = {"point": 1, "sphere": 2, "map": 4, "extern_sph": 5, "extern_box": 6, "plane_parallel": 7, "point_collection": 8}
 
 
 def _ptr(a):
@@ -233,6 +233,10 @@ class MarshalledProblem:
                 x.n_points = pts.shape[0]
                 x.points = arr(pts)
                 x.point_lum = arr(s.point_luminosity)
+            if s.type == "map":
+                if s.map is None or np.size(s.map) != prob.n_cells:
+                    raise ValueError("map source needs a luminosity map with one value per cell")
+                x.map = arr(np.ascontiguousarray(s.map, dtype=np.float64).ravel())
             x.luminosity = float(s.luminosity)
             for k in range(3):
                 x.position[k] = float(s.position[k])
@@ -247,6 +251,8 @@ class MarshalledProblem:
             elif s.temperature is not None:
                 x.spectrum_type = 2
                 x.temperature = float(s.temperature)
+            elif s.lte and s.type == "map":
+                x.spectrum_type = 3
             else:
                 raise ValueError("source needs a spectrum or a temperature")
         keep(srcs)

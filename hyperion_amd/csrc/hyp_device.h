@@ -57,6 +57,7 @@ struct DSource {
     int n_points;             // point_collection
     double dir_cost, dir_sint, dir_cosp, dir_sinp;   // plane_parallel: beam direction angle3d_deg(theta, phi)
     const double *points, *point_cdf;   // point_collection: [n][3] positions, luminosity cdf
+    const double *map_cdf;              // map (type 4): [n_cells] cumulative of the luminosity map; spectrum_type 3 = 'lte'
     double radius, box[6], face_cdf[6];
 };
 

@@ -165,7 +165,7 @@ struct DustOffsets {
     bool have_mo_e, have_mo_chi, have_mrw;
 };
 
-struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; };
+struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; size_t map_cdf; bool have_map; };
 struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi; };
 
 }  // namespace
@@ -990,7 +990,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         src_lum[i] = s.luminosity;
         if (s.type == 8 && s.point_lum && s.n_points > 0) { src_lum[i] = 0.0; for (int k = 0; k < s.n_points; k++) src_lum[i] += s.point_lum[k]; }
         h->energy_total += src_lum[i];
-        soff[i].have_points = false;
+        soff[i].have_points = false; soff[i].have_map = false;
     }
     {
         double c = 0.0;
@@ -998,7 +998,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             const hyp_source_desc &s = pr->sources[i];
             DSource &S = hs[i];
             std::memset(&S, 0, sizeof(S));
-            if (s.type != 1 && s.type != 2 && s.type != 5 && s.type != 6 && s.type != 7 && s.type != 8) FAIL("unknown type in source list: " + std::to_string(s.type));
+            if (s.type != 1 && s.type != 2 && s.type != 4 && s.type != 5 && s.type != 6 && s.type != 7 && s.type != 8) FAIL("unknown type in source list: " + std::to_string(s.type));
             S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius; S.limb_darkening = s.limb_darkening;
             if (s.type == 2) P.any_intersect = 1;      // s%intersect = .true.: source_type.f90:148
             if (s.type == 7) {      // plane_parallel: source_type.f90:239-256
@@ -1016,6 +1016,17 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 S.n_points = s.n_points;
                 soff[i].points = B.put(s.points, 3 * (size_t)s.n_points); soff[i].point_cdf = B.put(cdf);
                 soff[i].have_points = true;
+            }
+            if (s.type == 4) {      // map: source_type.f90:190-199, set_pdf(luminosity_map, map) over all cells
+                if (!s.map) FAIL("map source needs a luminosity map");
+                const size_t nc = h->n_cells;
+                std::vector<double> cdf(nc);
+                double tot = 0.0, cc = 0.0;
+                for (size_t k = 0; k < nc; k++) tot += s.map[k];
+                if (!(tot > 0.0)) FAIL("luminosity map is zero everywhere");
+                for (size_t k = 0; k < nc; k++) { cc += s.map[k] / tot; cdf[k] = cc; }
+                for (size_t k = 0; k < nc; k++) cdf[k] /= cc;
+                soff[i].map_cdf = B.put(cdf); soff[i].have_map = true;
             }
             for (int k = 0; k < 6; k++) S.box[k] = s.box[k];
             if (s.type == 6) {   // face pdf ~ face areas: source_type.f90:233-237
@@ -1037,6 +1048,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 if (!build_log_pdf(s.spec_nu, s.spec_fnu, s.n_spec, 1, cdf, bp1)) FAIL("source spectrum has zero integral");
                 soff[i].x = B.put(s.spec_nu, s.n_spec); soff[i].cdf = B.put(cdf); soff[i].bp1 = B.put(bp1);
                 soff[i].have = true;
+            } else if (s.spectrum_type == 3 && s.type == 4) {
+                // 'lte': the emissivity of the dust in the emitting cell
             } else if (s.spectrum_type != 2)
                 FAIL(std::string(s.type == 5 ? "External spherical source" : s.type == 6 ? "External box source" : s.type == 2 ? "Spherical source" : s.type == 7 ? "Plane parallel" : s.type == 8 ? "Point source collection" : "Point source") + " cannot have LTE spectrum");
         }
@@ -1129,7 +1142,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 const hyp_source_desc &src = pr->sources[is];
                 for (int i = 0; i < nn; i++)
                     spec[(size_t)is * nn + i] = src.spectrum_type == 1 ? interp_log_pdf(src.spec_nu, src.spec_fnu, 1, src.n_spec, nu[i])
-                                                                         : normalized_B_nu(nu[i], src.temperature);
+                                              : src.spectrum_type == 2 ? normalized_B_nu(nu[i], src.temperature) : 0.0;     // lte: the packets carry the dust emissivity
             }
             for (int d = 0; d < pr->n_dust; d++) {
                 const hyp_dust_desc &in = pr->dust[d];
@@ -1172,6 +1185,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         for (int is = 0; is < pr->n_sources; is++) {
             const hyp_source_desc &src = pr->sources[is];
             const double *x, *y; int n;
+            if (src.spectrum_type == 3) continue;       // lte: the packets carry the dust emissivity
             if (src.spectrum_type == 1) { x = src.spec_nu; y = src.spec_fnu; n = src.n_spec; }
             else {
                 // blackbody on 100000 points per decade between 3e9 and 3e16 Hz, normalized_B_nu :1088-1096
@@ -1221,7 +1235,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             const hyp_source_desc &src = pr->sources[is];
             for (int i = 0; i < nf; i++)
                 sp[(size_t)is * nf + i] = src.spectrum_type == 1 ? interp_log_pdf(src.spec_nu, src.spec_fnu, 1, src.n_spec, fr[i])
-                                                                   : normalized_B_nu(fr[i], src.temperature);
+                                        : src.spectrum_type == 2 ? normalized_B_nu(fr[i], src.temperature) : 0.0;
         }
         mono_src_off = B.put(sp);
         for (int d = 0; d < pr->n_dust; d++) {
@@ -1314,6 +1328,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         if (soff[i].have) { hs[i].spec_x = db + soff[i].x; hs[i].spec_cdf = db + soff[i].cdf; hs[i].spec_bp1 = db + soff[i].bp1; }
     for (int i = 0; i < pr->n_sources; i++)
         if (soff[i].have_points) { hs[i].points = db + soff[i].points; hs[i].point_cdf = db + soff[i].point_cdf; }
+    for (int i = 0; i < pr->n_sources; i++)
+        if (soff[i].have_map) hs[i].map_cdf = db + soff[i].map_cdf;
     HIPC(hipMalloc(&h->d_sources, sizeof(DSource) * hs.size()));
     HIPC(hipMemcpy(h->d_sources, hs.data(), sizeof(DSource) * hs.size(), hipMemcpyHostToDevice));
     P.sources = h->d_sources;

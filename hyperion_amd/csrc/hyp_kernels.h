@@ -44,6 +44,7 @@ struct Packet {
     double chi[NDT], albedo[NDT], kappa[NDT];
     Cell<GEOM> cell;
     int inter;
+    int emiss_dust;             // 'lte' sources: dust type whose emissivity the packet was emitted with (-1: the source's own spectrum)
     // re-absorption by sources (grid_propagate_3d.f90:99-101,139-143): distance to the nearest
     // intersecting source along v, distance covered in this grid_integrate, that source, and the
     // number of successive re-emissions (iter_lucy.f90:155-185)
@@ -690,6 +691,11 @@ __device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
     return x * HYP_K_CGS * T / HYP_H_CGS;
 }
 
+template <int GEOM>
+__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3]);
+__device__ __forceinline__ double dust_sample_j_nu(const DDust &D, int jid, double frac, double xi);
+__device__ __forceinline__ double dust_emit_probability(const DProblem &P, const DDust &D, int jid, double frac);
+
 // emit: source.f90:100-179 + source_emit/emit_from_point source_type.f90:398-564.
 // Returns false on a fatal error (flag raised).
 template <int NDT, int GEOM>
@@ -708,6 +714,8 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (reemit_id >= 0) is = reemit_id;      // emit(reemit=.true., reemit_id=...): source.f90:135-141
     source_id = is;
     const DSource &S = P.sources[is];
+    size_t map_cell = 0;
+    p.emiss_dust = -1;
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
     if (S.type == 2) {
         // emit_from_sphere: source_type.f90:604-690
@@ -724,6 +732,15 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         angle_to_vector(a_coord, n0, n1, n2);
         p.r[0] = n0 * S.radius + S.pos[0]; p.r[1] = n1 * S.radius + S.pos[1]; p.r[2] = n2 * S.radius + S.pos[2];
         src_normal = a_coord;       // outward normal (p%source_a)
+    } else if (S.type == 4) {
+        // emit_from_map: source_type.f90:713-741 -- cell from the luminosity map, uniform position in it, isotropic direction
+        const double xi = rng_uniform(g);
+        size_t lo = 0, hi = (size_t)P.n_cells - 1;
+        while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (xi < S.map_cdf[mid]) hi = mid; else lo = mid + 1; }
+        map_cell = lo;
+        const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
+        if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
+        random_sphere_angle(g, p.a);
     } else if (S.type == 8) {
         // emit_from_point_collection: source_type.f90:570-598
         const double xi = rng_uniform(g);
@@ -794,10 +811,29 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     }
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
     p.energy = 1.0;
+    int lte_jid = 0; double lte_frac = 0.0;
+    if (S.spectrum_type == 3) {
+        // 'lte' (source_type.f90:455-459, 486-491): select_dust_specific_energy_rho (grid_physics_3d.f90:101-109) in the
+        // emitting cell, then the emissivity of that dust
+        const int nd = ndust<NDT>(P);
+        const size_t base = map_cell * (size_t)nd;
+        double c = 0.0;
+        for (int d = 0; d < nd; d++) c += P.specific_energy[base + d] * P.density[base + d];
+        const double xi = rng_uniform(g);
+        int id = nd - 1; double run = 0.0; bool found = false;
+        for (int d = 0; d < nd - 1; d++) {
+            run += P.specific_energy[base + d] * P.density[base + d];
+            if (!found && xi < run / c) { id = d; found = true; }
+        }
+        p.emiss_dust = id;
+        lte_jid = P.jnu_id[base + id]; lte_frac = P.jnu_frac[base + id];
+    }
     if (P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
         p.nu = P.mono_nu;
-        p.energy = P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
-    } else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
+        p.energy = S.spectrum_type == 3 ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)
+                                        : P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
+    } else if (S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
+    else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     if (reemit_id >= 0) p.energy = reemit_energy;
@@ -1722,7 +1758,13 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
                 int source_id = 0;
                 bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
                 f.source_id = source_id;
-                isotropic = P.sources[source_id].type == 1 || P.sources[source_id].type == 8;
+                isotropic = P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
+                if (ok && p.emiss_dust >= 0) {     // 'lte' source: the packet carries the emissivity of the dust of its cell
+                    emiss_dust = p.emiss_dust;
+                    const size_t k = geo_index(P, p.cell) * (size_t)ndust<NDT>(P) + (size_t)emiss_dust;
+                    var_id = P.jnu_id[k]; var_frac = P.jnu_frac[k];
+                    f.dust_id = 0;
+                }
                 r[0] = p.r[0]; r[1] = p.r[1]; r[2] = p.r[2];
                 energy = p.energy * P.energy_total / n_total;
                 active = ok;
@@ -1975,7 +2017,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                         if (P.mono_which) { p.energy = p.energy / P.mono_n_total; e_init = p.energy; }     // iter_final_mono.f90:113-116
                         peel = 1; last = LAST_SR; st = ST_PLACED;   // placed, awaiting tau
                         p.reabs = 0;
-                        last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8;
+                        last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
                         // external sources: a_prev carries the inward normal for emit_peeloff
                         if (!last_iso) a_prev = src_normal;
                     }

@@ -92,6 +92,8 @@ class Source:
     direction: tuple = (0.0, 0.0)                       # plane_parallel: theta, phi of the beam (deg)
     points: Optional[np.ndarray] = None                 # point_collection: (n, 3) positions
     point_luminosity: Optional[np.ndarray] = None       # point_collection: (n,) luminosities (luminosity = their sum)
+    map: Optional[np.ndarray] = None                    # map: luminosity per cell, shape of one density species ('Luminosity map')
+    lte: bool = False                                   # map sources only: spectrum = emissivity of the dust in the emitting cell
 
 
 @dataclass

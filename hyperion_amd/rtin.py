@@ -200,6 +200,11 @@ def read_rtin(path):
                 s.direction = (float(sa["theta"]), float(sa["phi"]))
             elif t == "point_collection":
                 pass
+            elif t == "map":       # source_type.f90:190-199; one dataset per AMR grid otherwise (grid_io_amr.f90)
+                if grid_type == "amr":
+                    s.map = np.concatenate([np.asarray(g[p_]["Luminosity map"][...], dtype=float).ravel() for p_ in paths])
+                else:
+                    s.map = np.asarray(g["Luminosity map"][...], dtype=float)
             elif t == "extern_box":
                 s.box = tuple(float(sa[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax"))
             else:
@@ -211,6 +216,8 @@ def read_rtin(path):
                 tab = g["spectrum"][...]
                 s.spectrum_nu = np.asarray(tab["nu"], dtype=float)
                 s.spectrum_fnu = np.asarray(tab["fnu"], dtype=float)
+            elif st == "lte" and t == "map":
+                s.lte = True
             else:
                 raise ValueError("Point source cannot have LTE spectrum")
             sources.append(s)

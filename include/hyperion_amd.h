@@ -63,7 +63,7 @@ typedef struct hyp_dust_desc {
 typedef struct hyp_source_desc {
     int32_t type;          /* 1 point, 2 sphere (position, radius, limb_darkening), 5 extern_sph (position, radius), 6 extern_box (box),
                               7 plane_parallel (position, radius, direction), 8 point_collection (points, point_lum) */
-    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
+    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature, 3 lte (map sources only) */
     int32_t peeloff;
     int32_t n_spec;
     int32_t limb_darkening; /* sphere: attr `limb` (source_type.f90:142) */
@@ -78,6 +78,9 @@ typedef struct hyp_source_desc {
     double  direction[2];     /* plane_parallel: attrs theta, phi (deg) of the beam (source_type.f90:239-256) */
     const double *points;     /* point_collection: [n_points][3] dataset `position` (source_type.f90:258-277) */
     const double *point_lum;  /* point_collection: [n_points] dataset `luminosity` */
+    const double *map;        /* map (type 4): [n_cells] dataset `Luminosity map`, cell order of the density (source_type.f90:190-199,
+                                 grid_load_pdf_map src/grid/grid_geometry_common_3d.f90:47-63); spectrum_type 3 = 'lte': the dust emissivity
+                                 of the emitting cell (select_dust_specific_energy_rho + dust_sample_j_nu, source_type.f90:486-491) */
 } hyp_source_desc;
 
 /* /Grid/Geometry -- src/grid/grid_geometry_cartesian_3d.f90:77-134 (type 1),

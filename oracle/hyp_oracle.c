@@ -374,6 +374,7 @@ typedef struct {
     double luminosity, temperature, position[3], radius, box[6], face_cdf[6];
     angle_t direction;          /* plane_parallel: angle3d_deg(theta, phi) */
     double *points, *point_cdf; /* point_collection: [n][3] positions, luminosity cdf */
+    double *map_cdf;            /* map: [n_cells] cumulative of the luminosity map */
     pdf_t spectrum;
 } source_t;
 
@@ -1163,9 +1164,18 @@ int orc_create(const orc_problem *pr, orc_state **out)
             for (int k = 0; k < s->n_points; k++) t->point_cdf[k] /= c;
             t->luminosity = tot;
         }
+        if (s->type == 4) {   /* map :190-199: set_pdf(luminosity_map, map) over all cells */
+            if (!s->map) { snprintf(g_error, sizeof g_error, "map source needs a luminosity map"); orc_destroy(st); return 1; }
+            t->map_cdf = malloc(sizeof(double) * st->n_cells);
+            double tot = 0.0, c = 0.0;
+            for (size_t k = 0; k < st->n_cells; k++) tot += s->map[k];
+            if (!(tot > 0.0)) { snprintf(g_error, sizeof g_error, "luminosity map is zero everywhere"); orc_destroy(st); return 1; }
+            for (size_t k = 0; k < st->n_cells; k++) { c += s->map[k] / tot; t->map_cdf[k] = c; }
+            for (size_t k = 0; k < st->n_cells; k++) t->map_cdf[k] /= c;
+        }
         t->luminosity = s->luminosity; t->temperature = s->temperature;
         memcpy(t->position, s->position, sizeof t->position);
-        if (s->type != 1 && s->type != 2 && s->type != 5 && s->type != 6 && s->type != 7 && s->type != 8) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
+        if (s->type != 1 && s->type != 2 && s->type != 4 && s->type != 5 && s->type != 6 && s->type != 7 && s->type != 8) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
         t->radius = s->radius; memcpy(t->box, s->box, sizeof t->box);
         if (s->type == 6) {   /* source_type.f90:233-237: face pdf ~ face areas */
             double dx = s->box[1] - s->box[0], dy = s->box[3] - s->box[2], dz = s->box[5] - s->box[4];
@@ -1183,6 +1193,8 @@ int orc_create(const orc_problem *pr, orc_state **out)
             if (pdf_set_log(&t->spectrum, s->spec_nu, s->spec_fnu, s->n_spec, 1)) {
                 snprintf(g_error, sizeof g_error, "source spectrum has zero integral"); orc_destroy(st); return 1;
             }
+        } else if (s->spectrum_type == 3 && s->type == 4) {
+            /* 'lte': the emissivity of the dust in the emitting cell */
         } else if (s->spectrum_type != 2) {
             snprintf(g_error, sizeof g_error, "%s cannot have LTE spectrum",
                      s->type == 5 ? "External spherical source" : s->type == 6 ? "External box source" : s->type == 2 ? "Spherical source" : s->type == 7 ? "Plane parallel" : s->type == 8 ? "Point source collection" : "Point source");
@@ -1286,7 +1298,7 @@ void orc_destroy(orc_state *st)
     if (st->src) {
         for (int i = 0; i < st->n_sources; i++) {
             if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
-            free(st->src[i].points); free(st->src[i].point_cdf);
+            free(st->src[i].points); free(st->src[i].point_cdf); free(st->src[i].map_cdf);
         }
         free(st->src);
     }
@@ -2142,6 +2154,9 @@ static void box_face_normal(int face, angle_t *a)
     a->cost = tab[face][0]; a->sint = tab[face][1]; a->cosp = tab[face][2]; a->sinp = tab[face][3];
 }
 
+static int random_position_cell(const orc_state *st, size_t ic, photon_t *p, rng_t *g);
+static double dust_sample_j_nu(const dust_t *d, int id, double frac, double xi);
+static double dust_sample_emit_probability(const dust_t *d, int id, double frac, double nu);
 static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy, int inu);
 static int emit_from(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy) { return emit_from_nu(st, p, g, acc, reemit_id, reemit_energy, -1); }
 static int emit(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc) { return emit_from(st, p, g, acc, -1, 0.0); }
@@ -2244,6 +2259,17 @@ static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, 
         for (int k = 0; k < 3; k++) p->r[k] = n[k] * s->radius + s->position[k];
         p->last_isotropic = 0;
         p->source_a = a_coord;
+    } else if (s->type == 4) {
+        /* emit_from_map :713-741: cell from the luminosity map, uniform position in it, isotropic direction */
+        const double xi = rng_uniform(g);
+        size_t lo = 0, hi = st->n_cells - 1;
+        while (lo < hi) { size_t mid = (lo + hi) >> 1; if (xi < s->map_cdf[mid]) hi = mid; else lo = mid + 1; }
+        if (random_position_cell(st, lo, p, g)) {
+            if (!acc->fatal) { acc->fatal = 1; snprintf(acc->err, sizeof acc->err, "map sources are not available for this grid type"); }
+            return -1;
+        }
+        random_sphere_angle(g, &p->a);
+        p->last_isotropic = 1;
     } else if (s->type == 8) {
         /* emit_from_point_collection :570-598 */
         int k = sample_discrete(s->point_cdf, s->n_points, rng_uniform(g));
@@ -2302,11 +2328,27 @@ static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, 
     p->s[0] = 1.0; p->s[1] = p->s[2] = p->s[3] = 0.0;
     p->energy = 1.0;
     p->inu = inu;
+    p->emiss_type = s->spectrum_type;
+    if (s->spectrum_type == 3) {
+        /* 'lte' (source_type.f90:455-459, 486-491): select_dust_specific_energy_rho (grid_physics_3d.f90:101-109) in the
+         * emitting cell, then the emissivity of that dust */
+        size_t ic = cell_index(st, p->ic);
+        int id = 0;
+        double cdf[ORC_MAX_DUST], c = 0.0;
+        for (int d = 0; d < st->n_dust; d++) { c += st->specific_energy[(size_t)d * st->n_cells + ic] * st->density[(size_t)d * st->n_cells + ic]; cdf[d] = c; }
+        for (int d = 0; d < st->n_dust; d++) cdf[d] /= c;
+        id = sample_discrete(cdf, st->n_dust, rng_uniform(g));
+        size_t k = (size_t)id * st->n_cells + ic;
+        p->dust_id = id; p->emiss_var_id = st->jnu_var_id[k]; p->emiss_var_frac = st->jnu_var_frac[k];
+    }
     if (inu >= 0) {
         p->nu = st->frequencies[inu];
-        p->energy = s->spectrum_type == 1 ? pdf_interp_log(&s->spectrum, p->nu) : normalized_B_nu(p->nu, s->temperature);
+        p->energy = s->spectrum_type == 1 ? pdf_interp_log(&s->spectrum, p->nu)
+                  : s->spectrum_type == 2 ? normalized_B_nu(p->nu, s->temperature)
+                  : dust_sample_emit_probability(&st->dust[p->dust_id], p->emiss_var_id, p->emiss_var_frac, p->nu);
     } else if (s->spectrum_type == 1) p->nu = pdf_sample_log(&s->spectrum, rng_uniform(g));
-    else p->nu = random_planck_frequency(g, s->temperature);
+    else if (s->spectrum_type == 2) p->nu = random_planck_frequency(g, s->temperature);
+    else p->nu = dust_sample_j_nu(&st->dust[p->dust_id], p->emiss_var_id, p->emiss_var_frac, rng_uniform(g));
     angle_to_vector(&p->a, p->v);
     if (reemit_id >= 0) p->energy = reemit_energy;
     else {
@@ -2805,7 +2847,8 @@ static void raytracing_caches(const orc_state *st)
             for (int is = 0; is < st->n_sources; is++) {
                 const source_t *src = &st->src[is];
                 for (int i = 0; i < nn; i++)
-                    p->src_spec[(size_t)is * nn + i] = src->spectrum_type == 1 ? pdf_interp_log(&src->spectrum, nu[i]) : normalized_B_nu(nu[i], src->temperature);
+                    p->src_spec[(size_t)is * nn + i] = src->spectrum_type == 1 ? pdf_interp_log(&src->spectrum, nu[i])
+                                                        : src->spectrum_type == 2 ? normalized_B_nu(nu[i], src->temperature) : 0.0;   /* lte: the packets carry the dust emissivity */
             }
             for (int d = 0; d < st->n_dust; d++) {
                 const dust_t *du = &st->dust[d];
@@ -2829,6 +2872,7 @@ static void raytracing_caches(const orc_state *st)
     for (int is = 0; is < st->n_sources; is++) {
         const source_t *src = &st->src[is];
         const double *x, *y; int n;
+        if (src->spectrum_type == 3) continue;      /* lte: get_spectrum_binned has no case for it; the packets carry the dust emissivity */
         if (src->spectrum_type == 1) { x = src->spectrum.x; y = src->spectrum.pdf; n = src->spectrum.n; }
         else {
             if (!bnu) {

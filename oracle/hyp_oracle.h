@@ -63,8 +63,8 @@ typedef struct orc_dust_desc {
 
 /* One source (reader: src/sources/source_type.f90:102-322). */
 typedef struct orc_source_desc {
-    int32_t type;          /* 1 point, 2 sphere, 5 extern_sph, 6 extern_box, 7 plane_parallel, 8 point_collection */
-    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature */
+    int32_t type;          /* 1 point, 2 sphere, 4 map, 5 extern_sph, 6 extern_box, 7 plane_parallel, 8 point_collection */
+    int32_t spectrum_type; /* 1 tabulated spectrum, 2 blackbody temperature, 3 lte (map sources only) */
     int32_t peeloff;
     int32_t n_spec;
     int32_t limb_darkening; /* sphere: attr `limb` (source_type.f90:142) */
@@ -79,6 +79,9 @@ typedef struct orc_source_desc {
     double  direction[2];     /* plane_parallel: attrs theta, phi (deg) of the beam (source_type.f90:239-256) */
     const double *points;     /* point_collection: [n_points][3] dataset `position` (source_type.f90:258-277) */
     const double *point_lum;  /* point_collection: [n_points] dataset `luminosity` */
+    const double *map;        /* map (type 4): [n_cells] dataset `Luminosity map`, cell order of the density (source_type.f90:190-199,
+                                 grid_load_pdf_map src/grid/grid_geometry_common_3d.f90:47-63); spectrum_type 3 = 'lte': the dust emissivity
+                                 of the emitting cell (select_dust_specific_energy_rho + dust_sample_j_nu, source_type.f90:486-491) */
 } orc_source_desc;
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */

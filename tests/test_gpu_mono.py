@@ -153,3 +153,15 @@ def test_not_monochromatic_is_refused():
     with pytest.raises(hyperion_amd.EngineError, match="monochromatic mode was not requested"):
         eng.mono_iteration(10, 10)
     eng.close()
+
+
+def test_lte_map_source_in_monochromatic_mode():
+    """A luminosity-map source with the 'lte' spectrum in the monochromatic iteration: its packets carry the emission
+    probability of the dust of their cell at the frequency (source_type.f90:455-459)."""
+    from test_oracle_units import map_source_problem
+    p, _ = map_source_problem(lte=True, n=5, tau=1.0)
+    p = mono_problem(p, [1.0, 10.0, 100.0, 500.0])
+    p.peeled = [PeeledImages(theta=[40.0], phi=[10.0], n_x=4, n_y=4, x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC,
+                             n_ap=1, ap_min=2 * PC, ap_max=2 * PC, track_origin="basic", n_wav=4, inu_min=1, inu_max=4)]
+    ra, st = run_mono_both(p, 20000, 10000, 10000)
+    assert ra[0]["sed"][0, 0].max() > 0 and ra[0]["sed"][0, 1].max() > 0

@@ -311,3 +311,41 @@ def test_auto_schedule_choice():
     eng.lucy_iteration(4000000, 1)
     assert eng.get_option("last_lucy_mode") == 0          # one brick: nothing to tile
     eng.close()
+
+
+@pytest.mark.parametrize("lte", [False, True])
+def test_map_source_parity(lte):
+    """Luminosity-map sources (emit_from_map, source_type.f90:713-741), with a blackbody or with the 'lte' spectrum
+    (the emissivity of the dust in the emitting cell): Lucy iterations on the persistent and the brick-tiled
+    schedule, the imaging iteration and the raytracing iteration against the oracle on identical streams."""
+    from test_oracle_units import map_source_problem
+    from hyperion_amd.problem import PeeledImages
+    p, _ = map_source_problem(lte=lte, n=6, tau=1.5)
+    p.config.raytracing = True
+    p.peeled = [PeeledImages(theta=[50.0], phi=[70.0], n_wav=4, wav_min=0.1, wav_max=1000.0, n_x=5, n_y=5,
+                             x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.3 * PC, ap_max=2 * PC,
+                             track_origin="basic")]
+    for mode in (0, 1):
+        eng, orc = hyperion_amd.Engine(p), Oracle(p)
+        eng.set_option("lucy_mode", mode)
+        if mode == 1:
+            eng.set_option("tile_slots", 8192); eng.set_option("tile_task", 512)
+        for it in (1, 2):
+            a, sa = eng.lucy_iteration(30000, it)
+            b, sb = orc.lucy_iteration(30000, it)
+            for k in INT_KEYS:
+                assert sa[k] == sb[k], (mode, k, sa, sb)
+            assert_parity(a, b)
+        if mode == 0:
+            ra, sa = eng.final_iteration(20000)
+            rb, sb = orc.final_iteration(20000)
+            for k in INT_KEYS:
+                assert sa[k] == sb[k], (k, sa, sb)
+            ra, sa = eng.raytracing_iteration(8000, 8000)
+            rb, sb = orc.raytracing_iteration(8000, 8000)
+            assert sa["crossings"] == sb["crossings"]
+            for ga, gb in zip(ra, rb):
+                for name in gb:
+                    np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
+            assert ra[0]["sed"][0, 0].max() > 0
+        eng.close(); orc.close()
