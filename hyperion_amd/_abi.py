@@ -27,6 +27,13 @@ class DustDesc(C.Structure):
     ]
 
 
+class SpotDesc(C.Structure):
+    _fields_ = [
+        ("longitude", C.c_double), ("latitude", C.c_double), ("radius", C.c_double), ("luminosity", C.c_double),
+        ("temperature", C.c_double), ("spectrum_type", C.c_int32), ("n_spec", C.c_int32), ("spec_nu", _dp), ("spec_fnu", _dp),
+    ]
+
+
 class SourceDesc(C.Structure):
     _fields_ = [
         ("type", C.c_int32), ("spectrum_type", C.c_int32), ("peeloff", C.c_int32), ("n_spec", C.c_int32),
@@ -35,6 +42,7 @@ class SourceDesc(C.Structure):
         ("position", C.c_double * 3), ("radius", C.c_double), ("box", C.c_double * 6),
         ("spec_nu", _dp), ("spec_fnu", _dp),
         ("direction", C.c_double * 2), ("points", _dp), ("point_lum", _dp), ("map", _dp),
+        ("n_spots", C.c_int32), ("reserved_spots", C.c_int32), ("spots", C.POINTER(SpotDesc)),
     ]
 
 
@@ -233,6 +241,23 @@ class MarshalledProblem:
                 x.n_points = pts.shape[0]
                 x.points = arr(pts)
                 x.point_lum = arr(s.point_luminosity)
+            if s.spots:
+                if s.type != "sphere":
+                    raise ValueError("only spherical sources can have spots")
+                sp = (SpotDesc * len(s.spots))()
+                for k, q in enumerate(s.spots):
+                    sp[k].longitude, sp[k].latitude, sp[k].radius = float(q.longitude), float(q.latitude), float(q.radius)
+                    sp[k].luminosity = float(q.luminosity)
+                    if q.spectrum_nu is not None:
+                        sp[k].spectrum_type, sp[k].n_spec = 1, int(np.size(q.spectrum_nu))
+                        sp[k].spec_nu, sp[k].spec_fnu = arr(q.spectrum_nu), arr(q.spectrum_fnu)
+                    elif q.temperature is not None:
+                        sp[k].spectrum_type, sp[k].temperature = 2, float(q.temperature)
+                    else:
+                        raise ValueError("Spot cannot have LTE spectrum")
+                keep(sp)
+                x.n_spots = len(s.spots)
+                x.spots = C.cast(sp, C.POINTER(SpotDesc))
             if s.type == "map":
                 if s.map is None or np.size(s.map) != prob.n_cells:
                     raise ValueError("map source needs a luminosity map with one value per cell")

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #define HYP_MAXD 8
+#define SPOT_STRIDE 11
 #define HYP_PI 3.14159265358979323846
 #define HYP_TWOPI 6.28318530717958647692
 #define HYP_H_CGS 6.6260755e-27
@@ -57,6 +58,11 @@ struct DSource {
     int n_points;             // point_collection
     double dir_cost, dir_sint, dir_cosp, dir_sinp;   // plane_parallel: beam direction angle3d_deg(theta, phi)
     const double *points, *point_cdf;   // point_collection: [n][3] positions, luminosity cdf
+    // spotted sphere (the reference's source type 3): spot_tab = [cdf over spots..., sphere (n_spots + 1)] then per spot
+    // SPOT_STRIDE doubles {nx, ny, nz, cos(radius), spectrum_type, temperature, n_spec, off_x, off_cdf, off_bp1, off_mono}
+    // with table offsets relative to spot_blob
+    int n_spots, pad_spots;
+    const double *spot_tab, *spot_blob;
     const double *map_cdf;              // map (type 4): [n_cells] cumulative of the luminosity map; spectrum_type 3 = 'lte'
     double radius, box[6], face_cdf[6];
 };

@@ -165,7 +165,7 @@ struct DustOffsets {
     bool have_mo_e, have_mo_chi, have_mrw;
 };
 
-struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; size_t map_cdf; bool have_map; };
+struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; size_t map_cdf; bool have_map; size_t spot_tab; bool have_spots; };
 struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi; };
 
 }  // namespace
@@ -990,7 +990,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         src_lum[i] = s.luminosity;
         if (s.type == 8 && s.point_lum && s.n_points > 0) { src_lum[i] = 0.0; for (int k = 0; k < s.n_points; k++) src_lum[i] += s.point_lum[k]; }
         h->energy_total += src_lum[i];
-        soff[i].have_points = false; soff[i].have_map = false;
+        soff[i].have_points = false; soff[i].have_map = false; soff[i].have_spots = false;
     }
     {
         double c = 0.0;
@@ -1016,6 +1016,38 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 S.n_points = s.n_points;
                 soff[i].points = B.put(s.points, 3 * (size_t)s.n_points); soff[i].point_cdf = B.put(cdf);
                 soff[i].have_points = true;
+            }
+            if (s.n_spots > 0) {    // spotted sphere: source_type.f90:150-188
+                if (s.type != 2 || !s.spots) FAIL("only spherical sources can have spots");
+                const int ns = s.n_spots;
+                std::vector<double> tab((size_t)(ns + 1) + (size_t)ns * SPOT_STRIDE, 0.0);
+                double tot = s.luminosity, cc = 0.0;
+                for (int k = 0; k < ns; k++) tot += s.spots[k].luminosity;
+                for (int k = 0; k <= ns; k++) { cc += (k < ns ? s.spots[k].luminosity : s.luminosity) / tot; tab[k] = cc; }
+                for (int k = 0; k <= ns; k++) tab[k] /= cc;
+                for (int k = 0; k < ns; k++) {
+                    const hyp_spot_desc &q = s.spots[k];
+                    double *t = tab.data() + (ns + 1) + (size_t)k * SPOT_STRIDE;
+                    // angle3d_deg(lon, lat) as the reference passes them (theta = lon, phi = lat), then angle3d_to_vector3d
+                    const double th = q.longitude * HYP_PI / 180.0, ph = q.latitude * HYP_PI / 180.0;
+                    t[0] = std::sin(th) * std::cos(ph); t[1] = std::sin(th) * std::sin(ph); t[2] = std::cos(th);
+                    t[3] = std::cos(q.radius * HYP_PI / 180.0);
+                    t[4] = q.spectrum_type; t[5] = q.temperature; t[6] = q.n_spec;
+                    if (q.spectrum_type == 1) {
+                        std::vector<double> cdf, bp1;
+                        if (!build_log_pdf(q.spec_nu, q.spec_fnu, q.n_spec, 1, cdf, bp1)) FAIL("source spectrum has zero integral");
+                        t[7] = (double)B.put(q.spec_nu, q.n_spec); t[8] = (double)B.put(cdf); t[9] = (double)B.put(bp1);
+                    } else if (q.spectrum_type != 2) FAIL("Spot cannot have LTE spectrum");
+                    if (pr->config.monochromatic) {
+                        std::vector<double> mp(pr->config.n_frequencies);
+                        for (int f = 0; f < pr->config.n_frequencies; f++)
+                            mp[f] = q.spectrum_type == 1 ? interp_log_pdf(q.spec_nu, q.spec_fnu, 1, q.n_spec, pr->config.frequencies[f])
+                                                         : normalized_B_nu(pr->config.frequencies[f], q.temperature);
+                        t[10] = (double)B.put(mp);
+                    }
+                }
+                S.n_spots = ns;
+                soff[i].spot_tab = B.put(tab); soff[i].have_spots = true;
             }
             if (s.type == 4) {      // map: source_type.f90:190-199, set_pdf(luminosity_map, map) over all cells
                 if (!s.map) FAIL("map source needs a luminosity map");
@@ -1330,6 +1362,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         if (soff[i].have_points) { hs[i].points = db + soff[i].points; hs[i].point_cdf = db + soff[i].point_cdf; }
     for (int i = 0; i < pr->n_sources; i++)
         if (soff[i].have_map) hs[i].map_cdf = db + soff[i].map_cdf;
+    for (int i = 0; i < pr->n_sources; i++)
+        if (soff[i].have_spots) { hs[i].spot_tab = db + soff[i].spot_tab; hs[i].spot_blob = db; }
     HIPC(hipMalloc(&h->d_sources, sizeof(DSource) * hs.size()));
     HIPC(hipMemcpy(h->d_sources, hs.data(), sizeof(DSource) * hs.size(), hipMemcpyHostToDevice));
     P.sources = h->d_sources;

@@ -715,12 +715,27 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     source_id = is;
     const DSource &S = P.sources[is];
     size_t map_cell = 0;
+    int ispot = -1;
     p.emiss_dust = -1;
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
     if (S.type == 2) {
         // emit_from_sphere: source_type.f90:604-690
         Angle a_coord, a_local;
-        random_sphere_angle(g, a_coord);
+        if (S.n_spots > 0) {        // source_emit case(3), source_type.f90:421-427: a spot or the rest of the sphere, by luminosity
+            const double xi = rng_uniform(g);
+            int k = S.n_spots;
+            for (int i = S.n_spots - 1; i >= 0; i--) if (xi < S.spot_tab[i]) k = i;
+            if (k < S.n_spots) ispot = k;
+        }
+        if (ispot >= 0) {           // emit_from_sphere(spot) :632-636: rejection until the position lies inside the spot
+            const double *q = S.spot_tab + (S.n_spots + 1) + (size_t)ispot * SPOT_STRIDE;
+            for (;;) {
+                random_sphere_angle(g, a_coord);
+                double n0, n1, n2;
+                angle_to_vector(a_coord, n0, n1, n2);
+                if ((n0 * q[0] + n1 * q[1]) + n2 * q[2] > q[3]) break;
+            }
+        } else random_sphere_angle(g, a_coord);
         double sp, cp;
         sincos(HYP_TWOPI * rng_uniform(g), &sp, &cp);
         a_local.cosp = cp; a_local.sinp = sp;
@@ -828,6 +843,15 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         p.emiss_dust = id;
         lte_jid = P.jnu_id[base + id]; lte_frac = P.jnu_frac[base + id];
     }
+    if (ispot >= 0) {       // the spot's own spectrum: source_type.f90:447-461, 480-492
+        const double *q = S.spot_tab + (S.n_spots + 1) + (size_t)ispot * SPOT_STRIDE;
+        if (P.mono_which) {
+            p.nu = P.mono_nu;
+            p.energy = S.spot_blob[(size_t)q[10] + P.mono_inu];
+        } else if (q[4] == 1.0)
+            p.nu = sample_log_pdf(S.spot_blob + (size_t)q[7], S.spot_blob + (size_t)q[8], S.spot_blob + (size_t)q[9], (int)q[6], rng_uniform(g));
+        else p.nu = random_planck_frequency(g, q[5]);
+    } else
     if (P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
         p.nu = P.mono_nu;
         p.energy = S.spectrum_type == 3 ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)

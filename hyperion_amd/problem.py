@@ -74,6 +74,19 @@ class Dust:
 
 
 @dataclass
+class Spot:
+    """A spot on a spherical source (``Spot N`` sub-group, ``src/sources/source_type.f90:150-188``): centre
+    (longitude, latitude) and angular radius in degrees, luminosity, own spectrum or temperature."""
+    longitude: float = 0.0
+    latitude: float = 0.0
+    radius: float = 0.0
+    luminosity: float = 0.0
+    temperature: Optional[float] = None
+    spectrum_nu: Optional[np.ndarray] = None
+    spectrum_fnu: Optional[np.ndarray] = None
+
+
+@dataclass
 class Source:
     """One ``/Sources/source_NNNNN`` group: 'point', 'sphere' (position, radius,
     limb_darkening; can re-absorb packets), 'extern_sph' (position +
@@ -93,6 +106,7 @@ class Source:
     points: Optional[np.ndarray] = None                 # point_collection: (n, 3) positions
     point_luminosity: Optional[np.ndarray] = None       # point_collection: (n,) luminosities (luminosity = their sum)
     map: Optional[np.ndarray] = None                    # map: luminosity per cell, shape of one density species ('Luminosity map')
+    spots: List[Spot] = field(default_factory=list)     # sphere: spots (the reference's source type 3)
     lte: bool = False                                   # map sources only: spectrum = emissivity of the dust in the emitting cell
 
 
@@ -377,7 +391,10 @@ class Problem:
         for i, s in enumerate(self.sources):
             m = {}
             for k, v in s.__dict__.items():
-                if isinstance(v, np.ndarray):
+                if k == "spots":
+                    if v:
+                        m["spots"] = [{kk: (vv.tolist() if isinstance(vv, np.ndarray) else vv) for kk, vv in q.__dict__.items()} for q in v]
+                elif isinstance(v, np.ndarray):
                     arrays["source%d/%s" % (i, k)] = v
                 elif v is not None:
                     m[k] = list(v) if isinstance(v, tuple) else v
@@ -424,6 +441,8 @@ class Problem:
                 kw["box"] = tuple(kw["box"])
             if "direction" in kw:
                 kw["direction"] = tuple(kw["direction"])
+            if "spots" in kw:
+                kw["spots"] = [Spot(**{kk: (np.asarray(vv, dtype=float) if isinstance(vv, list) else vv) for kk, vv in q.items()}) for q in kw["spots"]]
             sources.append(Source(**kw))
         peeled = []
         for i, m in enumerate(meta["peeled"]):

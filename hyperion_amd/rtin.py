@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .problem import Dust, PeeledImages, Problem, RunConfig, Source
+from .problem import Dust, PeeledImages, Problem, RunConfig, Source, Spot
 
 
 def _s(v):
@@ -186,8 +186,21 @@ def read_rtin(path):
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
             elif t == "sphere":
                 # spots are sub-groups of the source group (source_type.f90:150-188)
-                if any(isinstance(g[k], type(g)) for k in g.keys()):
-                    raise NotImplementedError("spots on spherical sources are not supported yet")
+                for k in sorted(g.keys()):
+                    if not isinstance(g[k], type(g)):
+                        continue
+                    qa = g[k].attrs
+                    q = Spot(longitude=float(qa["longitude"]), latitude=float(qa["latitude"]), radius=float(qa["radius"]),
+                             luminosity=float(qa["luminosity"]))
+                    qs = _s(qa["spectrum"]).strip()
+                    if qs == "temperature":
+                        q.temperature = float(qa["temperature"])
+                    elif qs == "spectrum":
+                        tab = g[k]["spectrum"][...]
+                        q.spectrum_nu, q.spectrum_fnu = np.asarray(tab["nu"], dtype=float), np.asarray(tab["fnu"], dtype=float)
+                    else:
+                        raise ValueError("Spot cannot have LTE spectrum")
+                    s.spots.append(q)
                 s.position = (float(sa["x"]), float(sa["y"]), float(sa["z"]))
                 s.radius = float(sa["r"])
                 s.limb_darkening = _b(sa["limb"])

@@ -375,6 +375,8 @@ typedef struct {
     angle_t direction;          /* plane_parallel: angle3d_deg(theta, phi) */
     double *points, *point_cdf; /* point_collection: [n][3] positions, luminosity cdf */
     double *map_cdf;            /* map: [n_cells] cumulative of the luminosity map */
+    /* spotted sphere (the reference's type 3): spot_cdf over [spots..., sphere] (source_type.f90:159-188) */
+    int n_spots; double *spot_cdf; angle_t *spot_a; double *spot_cost; int *spot_stype; double *spot_T; pdf_t *spot_spectrum;
     pdf_t spectrum;
 } source_t;
 
@@ -1173,6 +1175,28 @@ int orc_create(const orc_problem *pr, orc_state **out)
             for (size_t k = 0; k < st->n_cells; k++) { c += s->map[k] / tot; t->map_cdf[k] = c; }
             for (size_t k = 0; k < st->n_cells; k++) t->map_cdf[k] /= c;
         }
+        if (s->n_spots > 0) {   /* source_type.f90:150-188 */
+            if (s->type != 2 || !s->spots) { snprintf(g_error, sizeof g_error, "only spherical sources can have spots"); orc_destroy(st); return 1; }
+            const int ns = s->n_spots;
+            t->n_spots = ns;
+            t->spot_cdf = malloc(sizeof(double) * (ns + 1)); t->spot_a = malloc(sizeof(angle_t) * ns); t->spot_cost = malloc(sizeof(double) * ns);
+            t->spot_stype = malloc(sizeof(int) * ns); t->spot_T = malloc(sizeof(double) * ns); t->spot_spectrum = calloc(ns, sizeof(pdf_t));
+            double tot = s->luminosity, c = 0.0;
+            for (int k = 0; k < ns; k++) tot += s->spots[k].luminosity;
+            for (int k = 0; k <= ns; k++) { c += (k < ns ? s->spots[k].luminosity : s->luminosity) / tot; t->spot_cdf[k] = c; }
+            for (int k = 0; k <= ns; k++) t->spot_cdf[k] /= c;
+            for (int k = 0; k < ns; k++) {
+                const orc_spot_desc *q = &s->spots[k];
+                /* angle3d_deg(lon, lat): theta = lon, phi = lat as the reference passes them */
+                double th = q->longitude * PI / 180.0, ph = q->latitude * PI / 180.0;
+                t->spot_a[k].cost = cos(th); t->spot_a[k].sint = sin(th); t->spot_a[k].cosp = cos(ph); t->spot_a[k].sinp = sin(ph);
+                t->spot_cost[k] = cos(q->radius * PI / 180.0);
+                t->spot_stype[k] = q->spectrum_type; t->spot_T[k] = q->temperature;
+                if (q->spectrum_type == 1) {
+                    if (pdf_set_log(&t->spot_spectrum[k], q->spec_nu, q->spec_fnu, q->n_spec, 1)) { snprintf(g_error, sizeof g_error, "source spectrum has zero integral"); orc_destroy(st); return 1; }
+                } else if (q->spectrum_type != 2) { snprintf(g_error, sizeof g_error, "Spot cannot have LTE spectrum"); orc_destroy(st); return 1; }
+            }
+        }
         t->luminosity = s->luminosity; t->temperature = s->temperature;
         memcpy(t->position, s->position, sizeof t->position);
         if (s->type != 1 && s->type != 2 && s->type != 4 && s->type != 5 && s->type != 6 && s->type != 7 && s->type != 8) { snprintf(g_error, sizeof g_error, "unknown type in source list: %d", s->type); orc_destroy(st); return 1; }
@@ -1299,6 +1323,8 @@ void orc_destroy(orc_state *st)
         for (int i = 0; i < st->n_sources; i++) {
             if (st->src[i].spectrum_type == 1 && st->src[i].spectrum.x) pdf_free(&st->src[i].spectrum);
             free(st->src[i].points); free(st->src[i].point_cdf); free(st->src[i].map_cdf);
+            if (st->src[i].spot_spectrum) for (int k = 0; k < st->src[i].n_spots; k++) if (st->src[i].spot_stype[k] == 1) pdf_free(&st->src[i].spot_spectrum[k]);
+            free(st->src[i].spot_cdf); free(st->src[i].spot_a); free(st->src[i].spot_cost); free(st->src[i].spot_stype); free(st->src[i].spot_T); free(st->src[i].spot_spectrum);
         }
         free(st->src);
     }
@@ -2245,10 +2271,21 @@ static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, 
     if (reemit_id >= 0) is = reemit_id;
     p->source_id = is;
     const source_t *s = &st->src[is];
+    int ispot = -1;
     if (s->type == 2) {
         /* emit_from_sphere :604-690 */
         angle_t a_coord, a_local;
-        random_sphere_angle(g, &a_coord);
+        if (s->n_spots > 0) {   /* source_emit case(3) :421-427: a spot or the rest of the sphere, by luminosity */
+            int k = sample_discrete(s->spot_cdf, s->n_spots + 1, rng_uniform(g));
+            if (k < s->n_spots) ispot = k;
+        }
+        if (ispot >= 0) {       /* emit_from_sphere(spot) :632-636: rejection until the position falls inside the spot */
+            for (;;) {
+                random_sphere_angle(g, &a_coord);
+                double n1[3], n2[3]; angle_to_vector(&a_coord, n1); angle_to_vector(&s->spot_a[ispot], n2);
+                if ((n1[0] * n2[0] + n1[1] * n2[1]) + n1[2] * n2[2] > s->spot_cost[ispot]) break;
+            }
+        } else random_sphere_angle(g, &a_coord);
         double phi = TWOPI * rng_uniform(g);
         a_local.cosp = cos(phi); a_local.sinp = sin(phi);
         if (s->limb_darkening) a_local.cost = ran_mu_limb(1.5, 1.0, rng_uniform(g));
@@ -2341,6 +2378,14 @@ static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, 
         size_t k = (size_t)id * st->n_cells + ic;
         p->dust_id = id; p->emiss_var_id = st->jnu_var_id[k]; p->emiss_var_frac = st->jnu_var_frac[k];
     }
+    if (ispot >= 0) {      /* the spot's own spectrum: source_type.f90:447-461, 480-492 */
+        const int sty = s->spot_stype[ispot];
+        if (inu >= 0) {
+            p->nu = st->frequencies[inu];
+            p->energy = sty == 1 ? pdf_interp_log(&s->spot_spectrum[ispot], p->nu) : normalized_B_nu(p->nu, s->spot_T[ispot]);
+        } else if (sty == 1) p->nu = pdf_sample_log(&s->spot_spectrum[ispot], rng_uniform(g));
+        else p->nu = random_planck_frequency(g, s->spot_T[ispot]);
+    } else
     if (inu >= 0) {
         p->nu = st->frequencies[inu];
         p->energy = s->spectrum_type == 1 ? pdf_interp_log(&s->spectrum, p->nu)

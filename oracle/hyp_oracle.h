@@ -61,6 +61,18 @@ typedef struct orc_dust_desc {
     const double *mo_chi_inv_planck;  /* [n_e] or NULL; column chi_inv_planck (chi_rosseland in version-1 files, dust_type_4elem.f90:231-237) */
 } orc_dust_desc;
 
+/* One spot of a spherical source: sub-group `Spot N` of the source group (src/sources/source_type.f90:150-188;
+ * attrs longitude, latitude, radius [deg], luminosity, and its own spectrum / temperature). */
+typedef struct orc_spot_desc {
+    double  longitude, latitude, radius;   /* degrees: angle3d_deg(lon, lat), cos(radius) */
+    double  luminosity;
+    double  temperature;
+    int32_t spectrum_type;  /* 1 tabulated spectrum, 2 blackbody temperature */
+    int32_t n_spec;
+    const double *spec_nu;  /* [n_spec] */
+    const double *spec_fnu; /* [n_spec] */
+} orc_spot_desc;
+
 /* One source (reader: src/sources/source_type.f90:102-322). */
 typedef struct orc_source_desc {
     int32_t type;          /* 1 point, 2 sphere, 4 map, 5 extern_sph, 6 extern_box, 7 plane_parallel, 8 point_collection */
@@ -82,6 +94,9 @@ typedef struct orc_source_desc {
     const double *map;        /* map (type 4): [n_cells] dataset `Luminosity map`, cell order of the density (source_type.f90:190-199,
                                  grid_load_pdf_map src/grid/grid_geometry_common_3d.f90:47-63); spectrum_type 3 = 'lte': the dust emissivity
                                  of the emitting cell (select_dust_specific_energy_rho + dust_sample_j_nu, source_type.f90:486-491) */
+    int32_t n_spots;          /* sphere: number of spots (the source then is the reference's type 3, a spotted sphere) */
+    int32_t reserved_spots;
+    const orc_spot_desc *spots; /* [n_spots] */
 } orc_source_desc;
 
 /* Grid geometry (reader: src/grid/grid_geometry_cartesian_3d.f90:77-134). */

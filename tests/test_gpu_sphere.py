@@ -128,3 +128,41 @@ def test_plane_parallel_and_point_collection_sources():
     p.sources[0].peeloff = True
     with pytest.raises(hyperion_amd.EngineError, match="plane parallel sources cannot be peeled"):
         hyperion_amd.Engine(p)
+
+
+def test_spotted_star_parity_and_spectrum():
+    """Spots on a spherical source (source_type.f90:150-188, 421-427, 632-636): the reference's own regression
+    model (hyperion/model/tests/test_spot_source.py: sphere and spot with disjoint emission bands) through the
+    C ABI, parity with the oracle on identical streams, and a dusty model with a blackbody spot in the Lucy,
+    imaging and monochromatic iterations."""
+    from test_oracle_units import spotted_star_problem
+    from hyperion_amd.problem import PeeledImages, Spot
+    p = spotted_star_problem()
+    eng, orc = hyperion_amd.Engine(p), Oracle(p)
+    ra, sa = eng.final_iteration(100000)
+    rb, sb = orc.final_iteration(100000)
+    eng.close(); orc.close()
+    np.testing.assert_allclose(ra[0]["sed"], rb[0]["sed"], rtol=1e-9, atol=1e-12 * rb[0]["sed"].max())
+    sed = ra[0]["sed"][0, 0]
+    assert sed[1].sum() < sed[0].sum()              # the far side does not see the spot
+
+    q = make_benchmark_problem(10, tau=1.0)
+    q.sources = [Source(type="sphere", luminosity=LSUN, temperature=5000.0, position=(0.05 * PC, 0.0, -0.02 * PC), radius=0.03 * PC,
+                        limb_darkening=True,
+                        spots=[Spot(longitude=40.0, latitude=200.0, radius=30.0, luminosity=0.7 * LSUN, temperature=9000.0),
+                               Spot(longitude=130.0, latitude=20.0, radius=10.0, luminosity=0.2 * LSUN, temperature=3000.0)])]
+    q.peeled = [PeeledImages(theta=[40.0, 130.0], phi=[200.0, 30.0], n_wav=5, wav_min=0.1, wav_max=100.0, n_x=4, n_y=4,
+                             x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=1, ap_min=2 * PC, ap_max=2 * PC)]
+    eng, orc = hyperion_amd.Engine(q), Oracle(q)
+    for it in (1, 2):
+        a, sa = eng.lucy_iteration(30000, it)
+        b, sb = orc.lucy_iteration(30000, it)
+        for k in ("crossings", "interactions", "killed_geo", "killed_int"):
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert_parity(a, b)
+    ra, sa = eng.final_iteration(30000)
+    rb, sb = orc.final_iteration(30000)
+    eng.close(); orc.close()
+    assert sa["crossings"] == sb["crossings"] and sa["interactions"] == sb["interactions"]
+    for name in rb[0]:
+        np.testing.assert_allclose(ra[0][name], rb[0][name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(rb[0][name])), err_msg=name)

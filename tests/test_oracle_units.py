@@ -465,3 +465,46 @@ def test_lte_map_source_emits_the_dust_emissivity_of_its_cell():
     ratio = src[ok] / dust[ok]
     assert ratio.std() / ratio.mean() < 1e-6          # same spectral shape, frequency by frequency
     assert src.max() > 0 and np.all(sed[2:] < 1e-6 * src.max())      # optically thin: nothing scattered
+
+
+def spotted_star_problem(lum_spot=1.0):
+    """hyperion/model/tests/test_spot_source.py: a sphere and a spot with disjoint emission bands, no dust."""
+    from hyperion_amd.benchmark import load_test_dust
+    from hyperion_amd.problem import PeeledImages, Spot
+    x = np.array([-1e12, 1e12])
+    nu = np.logspace(np.log10(3e12), np.log10(1e15), 300)
+    fnu_sphere = np.where((nu > 1e13) & (nu < 2e13), 1.0, 0.0)      # ~15-30 micron
+    fnu_spot = np.where((nu > 3e14) & (nu < 6e14), 1.0, 0.0)        # ~0.5-1 micron
+    # the spot centre as the reference builds it: angle3d_deg(longitude, latitude) -> theta = longitude, phi = latitude
+    spot = Spot(longitude=60.0, latitude=30.0, radius=25.0, luminosity=lum_spot, spectrum_nu=nu, spectrum_fnu=fnu_spot)
+    src = Source(type="sphere", luminosity=1.0, position=(0.0, 0.0, 0.0), radius=1e11, spectrum_nu=nu, spectrum_fnu=fnu_sphere, spots=[spot])
+    cfg = RunConfig()
+    cfg.n_initial_iter = 0
+    # views: onto the spot, and from the opposite side
+    peel = [PeeledImages(theta=[60.0, 120.0], phi=[30.0, 210.0], n_wav=60, wav_min=0.1, wav_max=100.0, compute_image=False,
+                         n_ap=1, ap_min=1e12, ap_max=1e12)]
+    return Problem(walls=[x, x, x], density=np.zeros((1, 1, 1, 1)), dust=[load_test_dust()], sources=[src], config=cfg, peeled=peel)
+
+
+def test_spot_uses_its_own_spectrum_and_is_seen_from_its_side_only():
+    """The reference's regression test test_spot_source.py (spot photons carry the spot's spectrum, source_type.f90:
+    447-461, 480-492) plus the geometry of emit_from_sphere(spot) :632-636: the spot is visible from the hemisphere
+    it faces, with the flux of a Lambertian patch, and invisible from the opposite side."""
+    p = spotted_star_problem()
+    o = Oracle(p)
+    res, st = o.final_iteration(200000)
+    o.close()
+    sed = res[0]["sed"][0, 0, :, 0, :]              # (view, wavelength bin)
+    wav = np.logspace(np.log10(0.1), np.log10(100.0), 61)
+    wav_c = np.sqrt(wav[1:] * wav[:-1])[::-1]       # bins are in frequency order: long wavelengths first
+    sphere_band = (wav_c > 10.0) & (wav_c < 40.0)
+    spot_band = (wav_c > 0.4) & (wav_c < 1.2)
+    other = ~(sphere_band | spot_band)
+    assert np.all(sed[:, other] == 0)
+    f_sphere, f_spot = sed[:, sphere_band].sum(axis=1), sed[:, spot_band].sum(axis=1)
+    # half of the packets come from the spot (equal luminosities); energies are scaled to L_tot = L_sphere = 1
+    assert f_sphere[0] == pytest.approx(0.5, rel=0.03) and f_sphere[1] == pytest.approx(0.5, rel=0.03)
+    # a Lambertian cap of half-angle a seen along its axis: 4 <mu> x (1/2) with <mu> = (1 + cos a) / 2
+    ca = np.cos(np.radians(25.0))
+    assert f_spot[0] == pytest.approx(0.5 * 4.0 * 0.5 * (1.0 + ca), rel=0.03)
+    assert f_spot[1] == 0.0
