@@ -81,6 +81,7 @@ struct DPeeled {
     const double *src_spec;       // [n_sources][n_nu]
     const double *dust_log10_em;  // [n_dust][nj_stride][n_nu]
     const double *dust_chi;       // [n_dust][n_nu]
+    int inside_observer, pad_obs; // peel-off towards the point `origin` inside the grid (images_peeled.f90:158-205): lon / lat maps
     int nj_stride, inu_min;       // inu_min: monochromatic, 1-based first frequency of this group (image_type.f90:243-258)
 };
 

@@ -1114,7 +1114,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         const hyp_peeled_desc &in = pdesc[g];
         DPeeled &G = h->h_peeled[g];
         std::memset(&G, 0, sizeof(G));
-        if (in.inside_observer) FAIL("inside observers are not supported yet");
+        if (in.inside_observer) {       // images_peeled.f90:312-315, 356-363
+            if (in.compute_image && in.x_min < in.x_max) FAIL("longitudes should increase towards the left for inside observers");
+            if (in.compute_sed) FAIL("computing SEDs for inside observers is not supported");
+        }
         if (in.n_view < 1) FAIL("n_view should be a positive integer");
         G.n_view = in.n_view; G.ignore_optical_depth = in.ignore_optical_depth;
         G.compute_image = in.compute_image; G.compute_sed = in.compute_sed;
@@ -1139,6 +1142,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         G.log10_nu_min = std::log10(in.nu_min); G.log10_nu_max = std::log10(in.nu_max);
         if (in.compute_sed) { G.log10_ap_min = std::log10(in.ap_min); G.log10_ap_max = std::log10(in.ap_max); }
         G.d_min = in.d_min; G.d_max = in.d_max;
+        G.inside_observer = in.inside_observer ? 1 : 0;
+        if (in.inside_observer && G.d_min < 0.0) G.d_min = 0.0;
         for (int k = 0; k < 3; k++) G.origin[k] = in.peeloff_origin[k];
         std::vector<double> view((size_t)in.n_view * 4);
         for (int v = 0; v < in.n_view; v++) {

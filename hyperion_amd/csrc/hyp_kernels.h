@@ -1327,7 +1327,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 template <int NDT, int GEOM>
 __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
                                              const Cell<GEOM> &cell0,
-                                             const double chi[NDT], Rng &g, Counters &cnt, bool &killed)
+                                             const double chi[NDT], Rng &g, Counters &cnt, bool &killed, double tmax = HYP_DBL_MAX)
 {
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
@@ -1339,8 +1339,9 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     if (P.any_intersect) {      // a source in the way: grid_propagate_3d.f90:414-420 (tmax = huge for external observers)
         double t_source; int sid;
         find_nearest_source(P, r0, v, t_source, sid);
-        if (t_source < HYP_DBL_MAX) { killed = true; return 0.0; }
+        if (t_source < tmax) { killed = true; return 0.0; }
     }
+    double t_achieved = 0.0;       // inside observers stop at the observer: grid_propagate_3d.f90:446-452
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
@@ -1349,11 +1350,17 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
         double tmin; int im[3];
         if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
         const size_t base = geo_index(P, c) * (size_t)nd;
+        bool finished = false;
+        if (tmax < HYP_DBL_MAX) {
+            if (t_achieved + tmin > tmax) { tmin = tmax - t_achieved; finished = true; }
+            t_achieved += tmin;
+        }
 #pragma unroll
         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
         for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * P.density[base + d] * tmin;
         cnt.crossings++;
+        if (finished) return tau;
         geo_advance(P, r, c, im);
         if (geo_invalid(P, c)) { cnt.killed_geo++; killed = true; return tau; }     // amr: invalid_cell
         if (geo_escaped(P, c)) return tau;
@@ -1448,6 +1455,34 @@ __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled 
     }
 }
 
+// Inside observers (images_peeled.f90:158-205, 410-421): the peel-off direction is towards the observer's position
+// (vector3d_to_angle3d(r_peeloff - r)), d = distance to it.
+__device__ __forceinline__ void inside_direction(const DPeeled &G, const double r[3], Angle &a_req, double &d)
+{
+    const double w0 = G.origin[0] - r[0], w1 = G.origin[1] - r[1], w2 = G.origin[2] - r[2];
+    const double rxy = sqrt(w0 * w0 + w1 * w1);
+    d = sqrt((w0 * w0 + w1 * w1) + w2 * w2);
+    a_req.cost = w2 / d; a_req.sint = rxy / d;
+    if (rxy > 0.0) { a_req.cosp = w0 / rxy; a_req.sinp = w1 / rxy; } else { a_req.cosp = 1.0; a_req.sinp = 0.0; }
+}
+
+// sky position (longitude, latitude in degrees around the group's viewing direction) of a packet travelling along a_req
+__device__ __forceinline__ void inside_sky_position(const DPeeled &G, int iv, const Angle &a_req, double &x_image, double &y_image)
+{
+    const double vt = G.view[4 * iv + 0], vs = G.view[4 * iv + 1], vcp = G.view[4 * iv + 2], vsp = G.view[4 * iv + 3];
+    double va0, va1, va2;
+    angle_to_vector(a_req, va0, va1, va2);
+    const double sx = (va0 * vcp + va1 * vsp) * vs + va2 * vt;
+    const double sy = -va0 * vsp + va1 * vcp;
+    const double sz = -(va0 * vcp + va1 * vsp) * vt + va2 * vs;
+    const double rad2deg = 180.0 / HYP_PI;
+    x_image = atan2(sy, sx) * rad2deg;
+    y_image = atan2(sqrt(sx * sx + sy * sy), sz) * rad2deg - 90.0;
+    const double ax = x_image - G.x_max, ay = y_image - G.y_min;       // Fortran modulo(a, 360)
+    x_image = G.x_max + (ax - 360.0 * floor(ax / 360.0));
+    y_image = G.y_min + (ay - 360.0 * floor(ay / 360.0));
+}
+
 // peeloff_photon, external observers: images_peeled.f90:95-270.  Called by ALL
 // lanes of the wave (`active` = this lane has a packet to peel) so that the image
 // deposits can be combined across lanes.
@@ -1465,6 +1500,8 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 Angle a_req;
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                 a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+                double d_obs = 0.0;
+                if (G.inside_observer) inside_direction(G, p.r, a_req, d_obs);
                 double s[4];
                 if (last_isotropic) {
                     s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
@@ -1504,11 +1541,12 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 Cell<GEOM> c = p.cell;
                 bool ok = geo_place(P, W, p.r, v, c);
                 if (!ok) cnt.killed_geo++;
-                double d = -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
+                double d = G.inside_observer ? d_obs : -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
                 ok = ok && !(d < G.d_min || d > G.d_max);
                 double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
                 double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
                 double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                if (G.inside_observer) inside_sky_position(G, iv, a_req, x_image, y_image);
                 bool inside = false;
                 if (G.compute_image)
                     inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
@@ -1517,8 +1555,13 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 ok = ok && inside;
                 if (ok) {
                     double tau = 0.0; bool killed = false;
-                    if (!G.ignore_optical_depth) tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed);
+                    if (!G.ignore_optical_depth)
+                        tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed, G.inside_observer ? d_obs : HYP_DBL_MAX);
                     if (!killed) {
+                        if (G.inside_observer) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
+                            const double dil = 1.0 / (4.0 * HYP_PI * (d_obs * d_obs));
+                            s[0] = s[0] * dil; s[1] = s[1] * dil; s[2] = s[2] * dil; s[3] = s[3] * dil;
+                        }
                         double att = exp(-tau);
                         s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
                         image_bin_keys(P, G, p.nu, p.energy, s[0], f, x_image, y_image, iv, k_img, k_sed);
@@ -1571,7 +1614,7 @@ __device__ __forceinline__ double cell_volume(const DProblem &P, size_t ic)
 // grid_escape_column_density: grid_propagate_3d.f90:482-582
 template <int NDT, int GEOM>
 __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
-                                              const Cell<GEOM> &cell0, double col[NDT], Rng &g, Counters &cnt, bool &killed)
+                                              const Cell<GEOM> &cell0, double col[NDT], Rng &g, Counters &cnt, bool &killed, double tmax = HYP_DBL_MAX)
 {
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
@@ -1584,8 +1627,9 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
     if (P.any_intersect) {      // grid_propagate_3d.f90:516-523
         double t_source; int sid;
         find_nearest_source(P, r0, v, t_source, sid);
-        if (t_source < HYP_DBL_MAX) { killed = true; return; }
+        if (t_source < tmax) { killed = true; return; }
     }
+    double t_current = 0.0;
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
@@ -1594,11 +1638,17 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
         double tmin; int im[3];
         if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return; }
         const size_t base = geo_index(P, c) * (size_t)nd;
+        bool finished = false;
+        if (tmax < HYP_DBL_MAX) {       // inside observers: grid_propagate_3d.f90:551-557
+            if (t_current + tmin > tmax) { tmin = tmax - t_current; finished = true; }
+            t_current += tmin;
+        }
 #pragma unroll
         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
         for (int d = 0; d < NDT; d++) if (d < nd) col[d] += P.density[base + d] * tmin;
         cnt.crossings++;
+        if (finished) return;
         geo_advance(P, r, c, im);
         if (geo_invalid(P, c)) { cnt.killed_geo++; killed = true; return; }
         if (geo_escaped(P, c)) return;
@@ -1662,6 +1712,8 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                 Angle a_req;
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                 a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+                double d_obs = 0.0;
+                if (G.inside_observer) inside_direction(G, r, a_req, d_obs);
                 if (isotropic) s0 = 1.0;
                 else {      // source_emit_peeloff of the external sources: source_type.f90:512-533
                     double mu = 0.0;
@@ -1681,11 +1733,12 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                 geo_clear_wall(c);
                 bool ok = geo_place(P, W, r, v, c);
                 if (!ok) cnt.killed_geo++;
-                double d = -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
+                double d = G.inside_observer ? d_obs : -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
                 ok = ok && !(d < G.d_min || d > G.d_max);
                 double dr0 = r[0] - G.origin[0], dr1 = r[1] - G.origin[1], dr2 = r[2] - G.origin[2];
                 double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
                 double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                if (G.inside_observer) inside_sky_position(G, iv, a_req, x_image, y_image);
                 bool inside = false;
                 if (G.compute_image)
                     inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
@@ -1694,7 +1747,8 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                 ok = ok && inside;
                 if (ok) {
                     bool killed = false;
-                    if (!G.ignore_optical_depth) escape_column<NDT, GEOM>(P, W, r, v, c, col, g, cnt, killed);
+                    if (!G.ignore_optical_depth) escape_column<NDT, GEOM>(P, W, r, v, c, col, g, cnt, killed, G.inside_observer ? d_obs : HYP_DBL_MAX);
+                    if (G.inside_observer) s0 = s0 * (1.0 / (4.0 * HYP_PI * (d_obs * d_obs)));      // images_peeled.f90:236
                     if (!killed && energy == energy) {
                         // origin slot and pixel / aperture of the first frequency bin
                         int o = f.scattered ? (f.reprocessed ? 4 : 3) : (f.reprocessed ? 2 : 1);

@@ -2960,7 +2960,11 @@ static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
 {
     memset(p, 0, sizeof *p);
     p->d = *in;
-    if (in->inside_observer) { snprintf(g_error, sizeof g_error, "inside observers not supported by the oracle"); return 1; }
+    if (in->inside_observer) {      /* images_peeled.f90:312-315, 356-363 */
+        if (p->d.d_min < 0.0) p->d.d_min = 0.0;
+        if (in->compute_image && in->x_min < in->x_max) { snprintf(g_error, sizeof g_error, "longitudes should increase towards the left for inside observers"); return 1; }
+        if (in->compute_sed) { snprintf(g_error, sizeof g_error, "computing SEDs for inside observers is not supported"); return 1; }
+    }
     p->theta = dup(in->theta, in->n_view); p->phi = dup(in->phi, in->n_view);
     p->d.theta = p->theta; p->d.phi = p->phi;
     p->view = malloc(sizeof(angle_t) * in->n_view);
@@ -3177,6 +3181,13 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
             photon_t p = *p_orig;
             memcpy(p.s, p.s_prev, sizeof p.s); p.a = p.a_prev; memcpy(p.v, p.v_prev, sizeof p.v);
             angle_t a_req = pg->view[iv];
+            const int inside = pg->d.inside_observer;
+            if (inside) {   /* a_peeloff :410-421: vector3d_to_angle3d(r_peeloff - r) */
+                double w[3] = {pg->d.peeloff_origin[0] - p.r[0], pg->d.peeloff_origin[1] - p.r[1], pg->d.peeloff_origin[2] - p.r[2]};
+                double rxy = sqrt(w[0] * w[0] + w[1] * w[1]), rr = sqrt((w[0] * w[0] + w[1] * w[1]) + w[2] * w[2]);
+                a_req.cost = w[2] / rr; a_req.sint = rxy / rr;
+                if (rxy > 0.0) { a_req.cosp = w[0] / rxy; a_req.sinp = w[1] / rxy; } else { a_req.cosp = 1.0; a_req.sinp = 0.0; }
+            }
             double v_req[3]; angle_to_vector(&a_req, v_req);
             if (p.last_isotropic) {
                 p.s[0] = 1.0; p.s[1] = p.s[2] = p.s[3] = 0.0;
@@ -3207,18 +3218,39 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
             p.killed = 0;
             place_in_cell(st, &p, acc);
             if (p.killed) continue;
-            double dd = -(v_req[0] * p.r[0] + v_req[1] * p.r[1] + v_req[2] * p.r[2]);
-            if (dd < pg->d.d_min || dd > pg->d.d_max) continue;
             double dr[3] = {p.r[0] - pg->d.peeloff_origin[0], p.r[1] - pg->d.peeloff_origin[1], p.r[2] - pg->d.peeloff_origin[2]};
-            double x_image = dr[1] * p.a.cosp - dr[0] * p.a.sinp;
-            double y_image = dr[2] * p.a.sint - dr[1] * p.a.cost * p.a.sinp - dr[0] * p.a.cost * p.a.cosp;
+            double dd, tmax = DBL_MAX, x_image, y_image;
+            if (inside) { dd = sqrt((dr[0] * dr[0] + dr[1] * dr[1]) + dr[2] * dr[2]); tmax = dd; }       /* :158-165 */
+            else dd = -(v_req[0] * p.r[0] + v_req[1] * p.r[1] + v_req[2] * p.r[2]);
+            if (dd < pg->d.d_min || dd > pg->d.d_max) continue;
+            if (inside) {
+                /* sky position for an observer looking along the group's viewing angle: :169-205 */
+                const angle_t *av = &pg->view[iv];
+                double va[3]; angle_to_vector(&p.a, va);
+                double sx = (va[0] * av->cosp + va[1] * av->sinp) * av->sint + va[2] * av->cost;
+                double sy = -va[0] * av->sinp + va[1] * av->cosp;
+                double sz = -(va[0] * av->cosp + va[1] * av->sinp) * av->cost + va[2] * av->sint;
+                const double rad2deg = 180.0 / PI;
+                x_image = atan2(sy, sx) * rad2deg;
+                y_image = atan2(sqrt(sx * sx + sy * sy), sz) * rad2deg - 90.0;
+                /* Fortran modulo(a, 360) = a - 360 floor(a / 360) */
+                double ax = x_image - pg->d.x_max, ay = y_image - pg->d.y_min;
+                x_image = pg->d.x_max + (ax - 360.0 * floor(ax / 360.0));
+                y_image = pg->d.y_min + (ay - 360.0 * floor(ay / 360.0));
+            } else {
+                x_image = dr[1] * p.a.cosp - dr[0] * p.a.sinp;
+                y_image = dr[2] * p.a.sint - dr[1] * p.a.cost * p.a.sinp - dr[0] * p.a.cost * p.a.cosp;
+            }
             if (!in_image(pg, x_image, y_image)) continue;
+            /* the 1/d^2 flux dilution of inside observers (:236) is applied after the optical depth is known */
+            const double dilute = inside ? 1.0 / (4.0 * PI * pow(dd, 2.0)) : 1.0;
             if (polychromatic) {
                 /* images_peeled.f90:218-254: the packet carries the whole spectrum of its emitter */
                 double col[ORC_MAX_DUST]; int killed_c = 0;
                 for (int d = 0; d < st->n_dust; d++) col[d] = 0.0;
-                if (!pg->d.ignore_optical_depth) grid_escape_column_density(st, &p, DBL_MAX, col, g, acc, &killed_c);
+                if (!pg->d.ignore_optical_depth) grid_escape_column_density(st, &p, tmax, col, g, acc, &killed_c);
                 if (killed_c) continue;
+                if (inside) for (int k = 0; k < 4; k++) p.s[k] = p.s[k] * dilute;
                 const int nn = pg->d.n_nu;
                 double spec[nn];
                 if (p.emiss_type == 3) {      /* get_dust_emissivity :451-505 */
@@ -3240,8 +3272,9 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
                 continue;
             }
             double tau = 0.0; int killed = 0;
-            if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, DBL_MAX, g, acc, &killed);
+            if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, tmax, g, acc, &killed);
             if (killed) continue;
+            if (inside) for (int k = 0; k < 4; k++) p.s[k] = p.s[k] * dilute;
             double att = exp(-tau);
             for (int k = 0; k < 4; k++) p.s[k] *= att;
             image_bin(st, ig, &p, x_image, y_image, iv, acc);

@@ -181,3 +181,33 @@ def test_binned_images_on_a_cartesian_grid_with_run():
     tot = s[0, 0, :, 0, :].mean(axis=0).sum()
     peel = r.peeled[0]["seds"][0, 0, 0, -1, :].sum()
     assert tot == pytest.approx(peel, rel=0.1)
+
+
+@pytest.mark.parametrize("raytracing", [False, True])
+def test_inside_observer_parity(raytracing):
+    """Peel-off towards an observer INSIDE the grid (images_peeled.f90:158-205, 236): direction to the observer's
+    position, optical depth up to the observer (tmax = d), 1 / (4 pi d^2) dilution, longitude / latitude maps; in the
+    imaging iteration and (raytracing on) in the raytracing iteration, against the oracle on identical streams."""
+    from test_oracle_units import inside_observer_problem
+    p, d = inside_observer_problem(tau=1.0)
+    p.peeled[0].phi = np.array([250.0])
+    p.peeled[0].theta = np.array([80.0])
+    p.peeled[0].n_wav, p.peeled[0].wav_min, p.peeled[0].wav_max = 4, 0.1, 1000.0
+    p.peeled[0].track_origin = "basic"
+    p.config.raytracing = raytracing
+    eng, orc = hyperion_amd.Engine(p), Oracle(p)
+    for it in (1, 2):
+        eng.lucy_iteration(20000, it); orc.lucy_iteration(20000, it)
+    ra, sa = eng.final_iteration(40000)
+    rb, sb = orc.final_iteration(40000)
+    for k in ("crossings", "interactions", "killed_geo", "killed_int"):
+        assert sa[k] == sb[k], (k, sa, sb)
+    if raytracing:
+        ra, sa = eng.raytracing_iteration(20000, 20000)
+        rb, sb = orc.raytracing_iteration(20000, 20000)
+        assert sa["crossings"] == sb["crossings"]
+    eng.close(); orc.close()
+    for name in rb[0]:
+        np.testing.assert_allclose(ra[0][name], rb[0][name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(rb[0][name])), err_msg=name)
+    img = ra[0]["img"][0]
+    assert img.shape == (4, 1, 5, 9, 4) and img.sum() > 0

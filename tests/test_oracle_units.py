@@ -508,3 +508,44 @@ def test_spot_uses_its_own_spectrum_and_is_seen_from_its_side_only():
     ca = np.cos(np.radians(25.0))
     assert f_spot[0] == pytest.approx(0.5 * 4.0 * 0.5 * (1.0 + ca), rel=0.03)
     assert f_spot[1] == 0.0
+
+
+def inside_observer_problem(tau=0.2):
+    from hyperion_amd.problem import PeeledImages
+    p = make_benchmark_problem(8, tau=tau)
+    d = 0.6 * PC
+    # observer on the -y axis; the viewing angle is the direction the photons at the map centre TRAVEL in (as for external
+    # observers): (theta, phi) = (90, 270) = -y puts the central source at the map centre
+    # (slightly off the x = 0 and z = 0 wall planes of the grid: a line of sight that ends exactly on a cell wall is a knife edge)
+    p.peeled = [PeeledImages(theta=[90.0], phi=[270.0], inside_observer=True, peeloff_origin=(0.013 * PC, -d, 0.021 * PC), compute_sed=False,
+                             n_x=9, n_y=5, x_min=180.0, x_max=-180.0, y_min=-90.0, y_max=90.0, n_wav=1, wav_min=0.01, wav_max=1e5)]
+    return p, d
+
+
+def test_inside_observer_sees_the_source_diluted_by_distance():
+    """peeloff_photon for inside observers (images_peeled.f90:158-205, 236): peel-off towards the observer's position,
+    optical depth integrated up to the observer only, 1 / (4 pi d^2) dilution, sky position in degrees of
+    longitude / latitude around the viewing direction."""
+    from hyperion_amd.benchmark import LSUN
+    p, d = inside_observer_problem()
+    p.config.n_initial_iter = 0
+    o = Oracle(p)
+    res, st = o.final_iteration(200000)
+    o.close()
+    img = res[0]["img"][0, 0, 0, :, :, 0]           # (y = latitude, x = longitude)
+    iy, ix = np.unravel_index(img.argmax(), img.shape)
+    assert (iy, ix) == (2, 4)                        # the source sits at the map centre
+    # direct light: L / (4 pi d^2) exp(-tau_d) with tau_d = chi rho d; everything else is scattered / re-emitted light
+    d = np.sqrt(d * d + (0.013 * PC) ** 2 + (0.021 * PC) ** 2)
+    tau_d = 0.2 * d / PC
+    direct = LSUN / (4 * np.pi * d * d) * np.exp(-tau_d)
+    assert img[iy, ix] > direct and img[iy, ix] < 1.25 * direct
+    rest = img.sum() - img[iy, ix]
+    assert 0.0 < rest < 0.5 * direct
+    # the observer looks the other way: the source is at longitude 180 = the edge pixels
+    p.peeled[0].phi = np.array([90.0])
+    o = Oracle(p)
+    res2, _ = o.final_iteration(100000)
+    o.close()
+    img2 = res2[0]["img"][0, 0, 0, :, :, 0]
+    assert img2[2, 0] + img2[2, 8] > 0.8 * direct and img2[2, 4] < 0.05 * direct
