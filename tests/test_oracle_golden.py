@@ -179,7 +179,7 @@ def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
     aperture within the Monte Carlo noise of the golden's photon numbers; totals within 5 %."""
     prob, z = golden_problem("%s_peeloff_ray.%s.npz" % (grid, evenly))
     assert prob.config.raytracing and prob.config.n_ray_photons_sources == 2000 and prob.config.n_ray_photons_dust == 3000
-    K = 30
+    K = 20
     runs = [_peeloff_run(prob, -(100 + k), 1000, 5000) for k in range(K)]
     samples = [r[0] for r in runs]
     assert all(r[1]["killed_geo"] == 0 and r[1]["killed_int"] == 0 for r in runs)
