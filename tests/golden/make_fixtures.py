@@ -428,7 +428,68 @@ def pinte_fixture(tmp):
         print("wrote", path, os.path.getsize(path), "iterations", n_it)
 
 
+def pinte_images_fixture(tmp):
+    """test_bit_level.py:549-637 (TestPinteBenchmark.test_pinte_images): the same disc, 3 Lucy iterations of 10000
+    packets with the MRW, monochromatic final iteration at 1 micron (10000 + 10000 packets), raytracing (1e5 + 1e5),
+    two nearly edge-on views imaged on 51 x 51 pixels with Stokes.  golden = Peeled/group_00001/images."""
+    from hyperion.model import AnalyticalYSOModel
+    from hyperion.dust import SphericalDust
+    from hyperion.util.constants import au, msun, rsun, sigma
+    for tau in (1000, 10000, 100000):
+        m = AnalyticalYSOModel()
+        m.star.radius = 2. * rsun
+        m.star.temperature = 4000.
+        m.star.luminosity = 4. * np.pi * (2. * rsun) ** 2. * sigma * 4000. ** 4.
+        disk = m.add_flared_disk()
+        disk.p = -1.5
+        disk.beta = 1.125
+        disk.mass = 3.e-8 * msun * tau / 1.e3
+        disk.rmin = 0.1 * au
+        disk.rmax = 400 * au
+        disk.h_0 = 10 * au
+        disk.r_0 = 100. * au
+        disk.cylindrical_inner_rim = True
+        disk.cylindrical_outer_rim = True
+        disk.dust = SphericalDust(os.path.join(DATA, 'pinte_dust_lite.hdf5'))
+        image = m.add_peeled_images()
+        image.set_viewing_angles(np.array([69.5, 87.1]), np.array([45., 45.]))
+        image.set_image_size(51, 51)
+        image.set_image_limits(-450. * au, 450. * au, -450. * au, 450. * au)
+        image.set_aperture_radii(1, 450. * au, 450. * au)
+        image.set_wavelength_range(1, 0.9, 1.1)
+        image.set_stokes(True)
+        m.set_raytracing(True)
+        m.set_n_initial_iterations(3)
+        m.set_cylindrical_polar_grid_auto(100, 30, 1)
+        m.set_monochromatic(True, wavelengths=[1.], energy_threshold=1.e-2)
+        m.set_mrw(True, gamma=2.)
+        m.set_n_photons(initial=10000, imaging_sources=10000, imaging_dust=10000,
+                        raytracing_sources=100000, raytracing_dust=100000)
+        m.set_max_interactions(1000, warn=False)
+        prob = write_and_read(m, tmp)
+        ref = os.path.join(DATA, "test_pinte_images.tau=%s.rtout" % tau)
+        golden = {}
+        with h5py.File(ref, "r") as f:
+            golden["images"] = f["Peeled/group_00001/images"][...]
+            golden["seds"] = f["Peeled/group_00001/seds"][...]
+        path = os.path.join(HERE, "pinte_images.tau=%s.npz" % tau)
+        ptmp = path + ".problem.npz"
+        lib = dict(np.load(os.path.join(HERE, "pinte_dust_lite.npz")))
+        from hyperion_amd.problem import Dust
+        dl = prob.dust[0]
+        prob.to_npz(ptmp, dust_library={"pinte_dust_lite.npz": dl})
+        z = dict(np.load(ptmp)); os.remove(ptmp)
+        for k, v in golden.items():
+            z["golden/" + k] = v
+        np.savez_compressed(path, **z)
+        print("wrote", path, os.path.getsize(path))
+
+
 def main():
+    if "pinte_images" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            pinte_images_fixture(tmp)
+        return
     if "pinte" in sys.argv[1:]:
         with tempfile.TemporaryDirectory() as tmp:
             pinte_fixture(tmp)

@@ -292,3 +292,48 @@ def test_pinte_benchmark_seds_match_reference_golden(tau):
     assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
     if (~well).any():
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
+
+
+def _pinte_image_run(prob, seed):
+    prob.config.seed = seed
+    o = Oracle(prob)
+    for it in range(1, 4):
+        o.lucy_iteration(10000, it)
+    o.mono_iteration(10000, 10000)
+    res, st = o.raytracing_iteration(100000, 100000)
+    o.close()
+    return res[0]["img"] * prob.config.frequencies[0]
+
+
+@pytest.mark.parametrize("tau", ["1000", "100000"])
+def test_pinte_benchmark_images_match_reference_golden(tau):
+    """test_pinte_images.tau=*.rtout (test_bit_level.py:549-637): 51 x 51 Stokes images of the Pinte disc at 1 micron,
+    two nearly edge-on views -- cylindrical polar grid, stellar sphere, MRW, MONOCHROMATIC final iteration and
+    raytracing, imaged.  The golden's surface brightness in annuli around the star against K oracle realisations
+    at its own packet numbers, the peak pixel, and the total flux of each view."""
+    prob, z = golden_problem("pinte_images.tau=%s.npz" % tau)
+    assert prob.grid_type == "cyl_pol" and prob.config.monochromatic and prob.peeled[0].n_x == 51
+    gold = z["golden/images"]
+    K = 10
+    S = np.array([_pinte_image_run(prob, -(700 + k)) for k in range(K)])
+    assert S.shape[1:] == gold.shape == (4, 1, 2, 51, 51, 1)
+    yy, xx = np.mgrid[0:51, 0:51]
+    rad = np.hypot(yy - 25, xx - 25)
+    edges = [0.0, 0.5, 2.5, 6.0, 12.0, 40.0]
+    for iv in range(2):
+        g, s = gold[0, 0, iv, :, :, 0], S[:, 0, 0, iv, :, :, 0]
+        if tau == "1000":      # the star shines through the thin disc: brightest pixel in the golden and in every realisation
+            assert np.unravel_index(g.argmax(), g.shape) == (25, 25)
+            assert np.all([np.unravel_index(a.argmax(), a.shape) == (25, 25) for a in s])
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            sel = (rad >= lo) & (rad < hi)
+            gs, ss = g[sel].sum(), s[:, sel].sum(axis=1)
+            m, sd = ss.mean(), ss.std(ddof=1) * np.sqrt(1.0 + 1.0 / K)
+            if sd < 0.3 * m:
+                assert abs(gs - m) < 6.0 * sd, (iv, lo, hi, gs, m, sd)
+            else:       # a few scattered packets in the outer disc: skewed, bounded from below
+                assert gs > m - 6.0 * sd and gs < m + 30.0 * sd, (iv, lo, hi, gs, m, sd)
+        tot = s.sum(axis=(1, 2))
+        assert abs(g.sum() - tot.mean()) < 5.0 * tot.std(ddof=1) + 0.02 * tot.mean()
+    # the SED of the single aperture is the summed image
+    np.testing.assert_allclose(z["golden/seds"][0, 0, :, 0, 0], gold[0, 0].sum(axis=(1, 2, 3)), rtol=1e-6)
