@@ -2,8 +2,9 @@
  * hyp_oracle.h -- TEST INFRASTRUCTURE ONLY.
  *
  * CPU restatement (plain C, FP64) of the Hyperion Monte Carlo photon-packet
- * path: src/main/iter_lucy.f90, src/main/iter_final.f90 and what they call
- * under src/{core,grid,dust,sources,images} of the reference.  It is the
+ * path: src/main/iter_lucy.f90, iter_final.f90, iter_final_mono.f90, iter_raytracing.f90 and what they call
+ * under src/{core,grid,dust,sources,images} of the reference (six grid geometries, all source types,
+ * MRW, peeled and binned images, inside observers).  It is the
  * parity checker for the HIP product path and the `cpu_baseline` leg of
  * bench.py.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * may load this library; the product (hyperion_amd/) never does.
@@ -13,8 +14,14 @@
  * random-number stream and the fortranlib sampling/interpolation arithmetic are
  * restated from their published behaviour ("parity unpinned at source level").
  * The oracle IS pinned statistically against the reference's own golden
- * outputs hyperion/model/tests/data/test_specific_energy.grid_type=car.*.rtout
- * and test_peeloff.grid_type=car.*.rtout (see tests/test_oracle_golden.py).
+ * outputs under hyperion/model/tests/data/ (tests/test_oracle_golden.py, tests/test_oracle_mrw.py):
+ * test_specific_energy.grid_type={car,oct,amr,sph,cyl}.* (20 files), test_peeloff.grid_type={car,oct,amr,sph,cyl}.
+ * raytracing={False,True}.* (20), test_pascucci.tau=* (4: monochromatic + raytracing, spherical grid),
+ * test_pinte_seds.tau=* (3) and test_pinte_images.tau=* (2: cylindrical grid, MRW, monochromatic, raytracing),
+ * the 18-density temperature table of test_mrw.py and the models of test_mono.py / test_spot_source.py;
+ * test_pinte_specific_energy.* needs the PDA, which is not restated.  Features without a reference output
+ * (Voronoi walk, binned images, map sources, inside observers) are pinned by analytic results and by
+ * equivalence with golden-pinned features (tests/test_oracle_units.py).
  *
  * The descriptor structs below have the same memory layout as the product's
  * include/hyperion_amd.h so one ctypes builder serves both; the two
