@@ -100,7 +100,7 @@ struct OctCell {
 enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
        TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
 
-enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3, ERR_RAY_GRID = 4 };
+enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3, ERR_RAY_GRID = 4, ERR_INTERNAL = 5 };
 
 // One grid of an AMR level (type_grid_amr.f90:12-21).  Walls are linspace(lo, hi, n+1) as the
 // reference builds them (grid_geometry_amr.f90:124-137), stored once per grid.
@@ -207,8 +207,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        // one 32 x 32 -> 64 bit product per multiplier (v_mad_u64_u32) instead of separate high and low halves
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;

@@ -220,6 +220,9 @@ struct hyp_engine {
     int *d_slot_brick = nullptr, *d_order = nullptr;
     unsigned int *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr;
     TileTask *d_tasks = nullptr;
+    int *d_ilist = nullptr, *d_dlist = nullptr, *d_extra = nullptr;     // split schedule: per-task work lists
+    TileCount *d_tcount = nullptr;
+    int tile_split = 1;
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
@@ -336,6 +339,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
 {
     constexpr int TBX = TileShape<ND>::X, TBY = TileShape<ND>::Y, TBZ = TileShape<ND>::Z;
     const size_t lds_w = lds_bytes(h->hp);
+    const size_t lds_int = lds_w;
     const size_t lds_walk = lds_w + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)TBX * TBY * TBZ * ND;
     const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * h->tile_prep_blocks);
     const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
@@ -358,11 +362,30 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
             TileTask *tasks = h->d_tasks + pool * tasks_cap;
             unsigned *counts = h->d_counts + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
                      *cursor = h->d_cursor + pool * HYP_TILE_MAX_BRICKS;
-            tile_prepare_kernel<ND><<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
-            tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
+            int *ilist = h->d_ilist + (size_t)pool * T.n_slots, *dlist = h->d_dlist + (size_t)pool * T.n_slots;
+            int *extra = h->d_extra + (size_t)pool * 3 * HYP_TILE_EXTRA;
+            T.gen = gen;
+            TileCount *tcount = h->d_tcount + pool * tasks_cap;
+            if (T.split) {
+                // walk (previous generation) left per-task lists: interactions, then emission into the freed slots
+                if (gen == 0) tile_init_kernel<<<(T.n_slots + 255) / 256, 256, 0, st>>>(T, h->d_ctl, tasks, tcount, dlist);
+                else {
+                    void (*ik)(const DProblem *, TileGeom, TileCtl *, HotRec<ND> *, ColdRec<ND> *, int *, const TileTask *, const int *, int *, TileCount *,
+                               unsigned int *, int *) =
+                        h->hp.any_intersect ? (h->hp.mrw ? tile_interact_kernel<ND, true, true> : tile_interact_kernel<ND, true, false>)
+                                            : (h->hp.mrw ? tile_interact_kernel<ND, false, true> : tile_interact_kernel<ND, false, false>);
+                    ik<<<(grid_w + 1) * HYP_LIST_SPLIT, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist, tcount,
+                                                                           counts, extra);
+                }
+                tile_emit_kernel<ND><<<(grid_w + 1) * HYP_LIST_SPLIT, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra);
+            } else {
+                tile_prepare_kernel<ND><<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
+                tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
+            }
             tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
             tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
-            tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick);
+            tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick,
+                                                                                       ilist, dlist, tcount, counts);
         }
         if ((gen & 3) == 3 || gen > 200000) {
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
@@ -379,8 +402,10 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
                 }
                 TileGeom T = T0; T.n_slots = T0.n_slots * n_pools;
                 const int grid_d = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
-                tile_drain_kernel<ND><<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, (HotRec<ND> *)h->d_hot,
-                                                                         (ColdRec<ND> *)h->d_cold, h->d_slot_brick);
+                void (*dk)(const DProblem *, TileGeom, TileCtl *, HotRec<ND> *, ColdRec<ND> *, int *) =
+                    h->hp.any_intersect ? (h->hp.mrw ? tile_drain_kernel<ND, true, true> : tile_drain_kernel<ND, true, false>)
+                                        : (h->hp.mrw ? tile_drain_kernel<ND, false, true> : tile_drain_kernel<ND, false, false>);
+                dk<<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, (HotRec<ND> *)h->d_hot, (ColdRec<ND> *)h->d_cold, h->d_slot_brick);
                 e = hipStreamSynchronize(h->stream);
                 if (e != hipSuccess) return h->set_error(std::string("tiled drain failed: ") + hipGetErrorString(e));
                 break;
@@ -429,16 +454,20 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
     T.task_size = h->tile_task < 256 ? 256 : h->tile_task;
-    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park;
+    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = h->tile_split ? 1 : 0;
     const int nd = h->n_dust;
     size_t hot_sz = nd == 1 ? sizeof(HotRec<1>) : nd == 2 ? sizeof(HotRec<2>) : nd == 3 ? sizeof(HotRec<3>) : sizeof(HotRec<4>);
     size_t cold_sz = nd == 1 ? sizeof(ColdRec<1>) : nd == 2 ? sizeof(ColdRec<2>) : nd == 3 ? sizeof(ColdRec<3>) : sizeof(ColdRec<4>);
     if (all_slots > h->tile_slots_alloc || nd != h->tile_nd_alloc) {
         free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
+        free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
         const size_t n_tasks_max = HYP_TILE_MAX_POOLS * ((size_t)all_slots / 256 + HYP_TILE_MAX_BRICKS + 2);
         if (hipMalloc(&h->d_hot, hot_sz * all_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * all_slots) != hipSuccess ||
             hipMalloc(&h->d_slot_brick, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * all_slots) != hipSuccess ||
-            hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) != hipSuccess)
+            hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) != hipSuccess ||
+            hipMalloc(&h->d_ilist, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_dlist, sizeof(int) * all_slots) != hipSuccess ||
+            hipMalloc(&h->d_tcount, sizeof(TileCount) * n_tasks_max) != hipSuccess ||
+            hipMalloc(&h->d_extra, sizeof(int) * 3 * HYP_TILE_EXTRA * HYP_TILE_MAX_POOLS) != hipSuccess)
             return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
         h->tile_slots_alloc = all_slots; h->tile_nd_alloc = nd;
     }
@@ -508,6 +537,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_img_accum);
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
+    free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     for (int i = 1; i < 4; i++) if (h->pool_stream[i]) (void)hipStreamDestroy(h->pool_stream[i]);
     if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
@@ -1569,6 +1599,8 @@ static int check_device_error(hyp_handle h)
         std::snprintf(buf, sizeof buf, "negative t");
     } else if (code == ERR_RAY_GRID) {
         std::snprintf(buf, sizeof buf, "raytracing of dust emission is not available for this grid type");
+    } else if (code == ERR_INTERNAL) {
+        std::snprintf(buf, sizeof buf, "internal error: a work list of the tiled Lucy iteration overflowed (%g entries)", data[0]);
     } else std::snprintf(buf, sizeof buf, "device error %d", code);
     return h->set_error(buf);
 }
@@ -1766,6 +1798,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_slots") h->tile_slots = (int)value;
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
+    else if (n == "tile_split") h->tile_split = (int)value;
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = (int)value;
     else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
@@ -1786,6 +1819,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_slots") *value = h->tile_slots;
     else if (n == "tile_task") *value = h->tile_task;
     else if (n == "tile_pools") *value = h->tile_pools;
+    else if (n == "tile_split") *value = h->tile_split;
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;

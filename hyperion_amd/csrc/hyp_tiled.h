@@ -20,21 +20,25 @@ enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3, TS_REEMIT = 4 }; 
 #define HYP_TILE_MAX_BRICKS 8192
 
 template <int ND>
-struct alignas(16) HotRec {      // what the walk needs (128 B for ND = 1)
-    double r[3], v[3];
-    double tau_req, tau_ach, energy;
-    double chi[ND], kappa[ND];
-    unsigned long long id;
+struct alignas(64) HotRec {      // what the walk needs (128 B for ND = 1)
+    // first 64 bytes: what a brick visit changes -- tile_walk writes back one aligned half cache line
+    double r[3];
+    double tau_ach;
     int ic[3];
     int ow;                      // (ow0+1) | (ow1+1)<<2 | (ow2+1)<<4
     int countdown;
     unsigned int blk_b;
     int state;
     int pad;
+    // fixed between two interactions
+    double v[3];
+    double tau_req, energy;
+    unsigned long long id;
+    double chi[ND], kappa[ND];
 };
 
 template <int ND>
-struct alignas(16) ColdRec {     // only touched at interactions / emission
+struct alignas(64) ColdRec {     // only touched at interactions / emission
     Angle a;
     double s[4];
     double nu;
@@ -73,10 +77,17 @@ struct alignas(16) ColdRec {     // only touched at interactions / emission
 #define TILE_DEPOSIT(p, v) unsafeAtomicAdd(p, v)
 #endif
 
+#ifndef HYP_WALK_ATTR
+#define HYP_WALK_ATTR
+#endif
 #define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
     unsigned int n_tasks[HYP_TILE_MAX_POOLS];     // per slot pool
+    // split schedule: slots that need an interaction but sit in no task's list (a packet that drew a zero optical
+    // depth); two lists per pool, filled and emptied in alternate generations
+    unsigned int n_extra[HYP_TILE_MAX_POOLS][2];
+    unsigned int n_extra_dead[HYP_TILE_MAX_POOLS]; // ... and the slots freed while working through that list
     unsigned long long dbg[40];                   // debug builds only
 };
 
@@ -87,7 +98,14 @@ struct TileGeom {
     uint32_t iter_tag;
     int pool;                    // which slot pool (and stream) this launch belongs to
     int park;                    // tile_walk: park the last packets of a wave once this few lanes still walk
+    int gen;                     // generation number (split schedule: which of the two extra lists is read)
+    int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
 };
+
+// per task of the current generation: how many of its packets ended the visit waiting for an interaction
+// (or a re-emission by a source) and how many slots it left free
+struct TileCount { int n_int, n_dead; };
+#define HYP_TILE_EXTRA 8192       // capacity of each per-pool list behind TileCtl::n_extra; layout [list 0][list 1][freed slots]
 
 struct TileTask { int brick, start, len, pad; };
 
@@ -292,12 +310,392 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
 }
 
 // ---------------------------------------------------------------------------
+// Split schedule (T.split): tile_walk leaves, per task, a list of the slots whose packets wait
+// for an interaction (or for re-emission by a source that absorbed them) and a list of the slots
+// it freed, and adds the packets that move on to the brick histogram itself.  tile_interact and
+// tile_emit work through these lists with one workgroup per task -- full waves of one kind of
+// work, no scan over slot_brick[], and each kernel only carries the registers of its own phase --
+// and add the bricks of the packets they hand to the next walk to the histogram, so that the
+// counting pass of the sort is gone.
+// ---------------------------------------------------------------------------
+
+// The tallies of a workgroup go to the global tail through LDS: one set of (same-address) global atomics per
+// workgroup instead of one per wave.  red[] must be zero before the first call; every thread of the block calls.
+#define TILE_RED_N 6
+__device__ __forceinline__ void block_tally_flush(const DProblem &P, TileCtl *__restrict__ ctl, double *red, const Counters &cnt,
+                                                  unsigned int finished)
+{
+    const double e = wave_sum(cnt.energy_current);
+    const double c = wave_sum((double)cnt.crossings);
+    const double kg = wave_sum((double)cnt.killed_geo);
+    const double ki = wave_sum((double)cnt.killed_int);
+    const double ni = wave_sum((double)cnt.interactions);
+    const double nf = wave_sum((double)finished);
+    if (__lane_id() == 0) {
+        if (e != 0.0) atomicAdd(&red[0], e);
+        if (c != 0.0) atomicAdd(&red[1], c);
+        if (kg != 0.0) atomicAdd(&red[2], kg);
+        if (ki != 0.0) atomicAdd(&red[3], ki);
+        if (ni != 0.0) atomicAdd(&red[4], ni);
+        if (nf != 0.0) atomicAdd(&red[5], nf);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (red[0] != 0.0) unsafeAtomicAdd(&P.tail[TAIL_ENERGY], red[0]);
+        if (red[1] != 0.0) unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], red[1]);
+        if (red[2] != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], red[2]);
+        if (red[3] != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], red[3]);
+        if (red[4] != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], red[4]);
+        if (red[5] != 0.0) atomicAdd(&ctl->n_finished, (unsigned long long)red[5]);
+    }
+}
+
+// Brick histogram contributions of a workgroup, collected in a small LDS table first: the packets that one workgroup of
+// tile_interact / tile_emit hands to the next walk sit in one or two bricks (the task's own; the source's), and many
+// workgroups would otherwise hammer the same counts[] entries.  cache_b[] = brick or -1, cache_n[] = count.
+#define TILE_BCACHE 8
+__device__ __forceinline__ void count_bricks(unsigned int *__restrict__ counts, int *cache_b, unsigned int *cache_n, bool on, int brick)
+{
+    unsigned long long m = __ballot(on);
+    while (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        const int b = __shfl(brick, leader, 64);
+        const unsigned long long same = __ballot(on && brick == b) & m;
+        if ((int)__lane_id() == leader) {
+            const unsigned int n = (unsigned int)__popcll(same);
+            bool done = false;
+            for (int i = 0; i < TILE_BCACHE && !done; i++) {
+                const int old = atomicCAS(&cache_b[i], -1, b);
+                if (old == -1 || old == b) { atomicAdd(&cache_n[i], n); done = true; }
+            }
+            if (!done) atomicAdd(&counts[b], n);
+        }
+        m &= ~same;
+    }
+}
+__device__ __forceinline__ void flush_bricks(unsigned int *__restrict__ counts, const int *cache_b, const unsigned int *cache_n)
+{
+    if (threadIdx.x < TILE_BCACHE && cache_b[threadIdx.x] >= 0 && cache_n[threadIdx.x]) atomicAdd(&counts[cache_b[threadIdx.x]], cache_n[threadIdx.x]);
+}
+
+template <int ND>
+__device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, ColdRec<ND> &C, const Packet<ND, GEOM_CAR> &p, const Rng &g,
+                                              unsigned long long id, int state)
+{
+#pragma unroll
+    for (int a = 0; a < 3; a++) { H.r[a] = p.r[a]; H.v[a] = p.v[a]; H.ic[a] = p.cell.ic[a]; }
+    H.ow = pack_ow(p.cell.ow);
+    H.tau_req = p.tau_req; H.tau_ach = p.tau_ach; H.energy = p.energy;
+#pragma unroll
+    for (int d = 0; d < ND; d++) { H.chi[d] = p.chi[d]; H.kappa[d] = p.kappa[d]; C.albedo[d] = p.albedo[d]; }
+    H.id = id; H.countdown = g.countdown; H.blk_b = g.blk_b; H.state = state;
+    C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
+    C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
+    if (P.any_intersect) { C.t_src = p.t_src; C.t_ach = p.t_ach; C.reabs_id = p.reabs_id; C.reabs = p.reabs; }
+}
+
+// generation 0 of the split schedule: every slot is free; pseudo-tasks of task_size slots list them for tile_emit
+__global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileCtl *__restrict__ ctl, TileTask *__restrict__ tasks,
+                                                        TileCount *__restrict__ tcount, int *__restrict__ dlist)
+{
+    const int n_tasks = (T.n_slots + T.task_size - 1) / T.task_size;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T.n_slots) dlist[i] = i;
+    if (i < n_tasks) {
+        TileTask tk; tk.brick = -1; tk.start = i * T.task_size; tk.len = min(T.task_size, T.n_slots - tk.start); tk.pad = 0;
+        tasks[i] = tk;
+        TileCount c; c.n_int = 0; c.n_dead = tk.len; tcount[i] = c;
+    }
+    if (i == 0) { ctl->n_tasks[T.pool] = (unsigned int)n_tasks; ctl->n_extra[T.pool][0] = ctl->n_extra[T.pool][1] = 0; ctl->n_extra_dead[T.pool] = 0; }
+}
+
+#ifndef HYP_INTERACT_WAVES
+#define HYP_INTERACT_WAVES 2
+#endif
+#ifndef HYP_EMIT_WAVES
+#define HYP_EMIT_WAVES 2
+#endif
+#ifndef HYP_LIST_SPLIT
+#define HYP_LIST_SPLIT 1            // workgroups per task in tile_interact / tile_emit (chunks of the task's list round-robin)
+#endif
+#define HYP_INTERACT_CHUNK 1024     // list entries that tile_interact orders by kind at a time
+
+// REABS: the problem has sources that can absorb packets (P.any_intersect), so slots may wait for a re-emission;
+// MRW: the modified random walk is on (P.mrw).  Without them that code stays out of this kernel.
+template <int ND, bool REABS, bool MRW>
+__global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+        HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold, int *__restrict__ slot_brick,
+        const TileTask *__restrict__ tasks, const int *__restrict__ ilist, int *__restrict__ dlist, TileCount *__restrict__ tcount,
+        unsigned int *__restrict__ counts, int *__restrict__ extra)
+{
+    extern __shared__ double lds[];
+    constexpr int CH = HYP_INTERACT_CHUNK;
+    const DProblem &P = *Pp;
+    const unsigned int n_tasks = ctl->n_tasks[T.pool];
+    const unsigned int task = blockIdx.x / HYP_LIST_SPLIT;
+    const int part = (int)(blockIdx.x % HYP_LIST_SPLIT);
+    // the first workgroup after the last task takes the slots that are in no task's list (TileCtl::n_extra)
+    const bool is_extra = task == n_tasks;
+    if (task > n_tasks || (is_extra && part != 0)) return;
+    const int par = T.gen & 1;
+    int start = 0, n_int = 0;
+    if (is_extra) n_int = (int)min(ctl->n_extra[T.pool][par], (unsigned int)HYP_TILE_EXTRA);
+    else { start = tasks[task].start; n_int = tcount[task].n_int; }
+    if (n_int <= part * CH) {
+        if (is_extra && threadIdx.x == 0) ctl->n_extra_dead[T.pool] = 0;
+        return;
+    }
+    const int *list = is_extra ? extra + par * HYP_TILE_EXTRA : ilist + start;
+    int *extra_next = extra + (par ^ 1) * HYP_TILE_EXTRA;
+    Walls W;
+    stage_walls<GEOM_CAR>(P, lds, W);
+    __shared__ int sorted[CH];
+    __shared__ int n_dead_x, n_abs, n_oth;
+    __shared__ double red[TILE_RED_N];
+    __shared__ int cache_b[TILE_BCACHE];
+    __shared__ unsigned int cache_n[TILE_BCACHE];
+    if (threadIdx.x < TILE_RED_N) red[threadIdx.x] = 0.0;
+    if (threadIdx.x < TILE_BCACHE) { cache_b[threadIdx.x] = -1; cache_n[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) n_dead_x = 0;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    unsigned int finished = 0;
+    const int nd = ndust<ND>(P);
+    for (int c0 = part * CH; c0 < n_int; c0 += HYP_LIST_SPLIT * CH) {
+        // Absorption + re-emission and scattering are two long, different code paths (dust_interact.f90:49-70); which one
+        // a packet takes is decided by the first one or two numbers of its random stream.  Draw them ahead on a copy of
+        // the stream and order the chunk by the outcome, so that the waves below run one path each.
+        __syncthreads();
+        if (threadIdx.x == 0) { n_abs = 0; n_oth = 0; }
+        __syncthreads();
+        const int n_chunk = min(CH, n_int - c0);
+        for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) {
+            const int slot = list[c0 + k];
+            const HotRec<ND> &H = hot[slot];
+            const ColdRec<ND> &C = cold[slot];
+            bool absorb = false;
+            if (H.state == TS_INTERACT && (long long)C.inter != P.n_inter_max + 1) {
+                Rng g2;
+                const unsigned long long id = H.id;
+                g2.key0 = P.seed_key; g2.key1 = T.iter_tag; g2.id_lo = (uint32_t)id; g2.id_hi = (uint32_t)(id >> 32);
+                g2.blk_a = C.blk_a; g2.buf_a = C.buf_a; g2.have_a = C.have_a; g2.blk_b = 0; g2.countdown = 0;
+                double albedo = C.albedo[0];
+                if (ND > 1 && nd > 1) {        // select_dust_chi_rho, as in interact()
+                    const size_t base = (((size_t)H.ic[2] * P.n2 + H.ic[1]) * P.n1 + H.ic[0]) * (size_t)nd;
+                    double cdf[ND], c = 0.0;
+#pragma unroll
+                    for (int d = 0; d < ND; d++) { if (d < nd) c += H.chi[d] * P.density[base + d]; cdf[d] = c; }
+                    const double xi = rng_uniform(g2);
+                    int idd = nd - 1; bool found = false;
+#pragma unroll
+                    for (int d = 0; d < ND; d++) if (d < nd && !found && d < nd - 1 && xi < cdf[d] / c) { idd = d; found = true; }
+                    albedo = 0.0;
+#pragma unroll
+                    for (int d = 0; d < ND; d++) if (d == idd) albedo = C.albedo[d];
+                }
+                absorb = rng_uniform(g2) > albedo;
+            }
+            if (absorb) sorted[atomicAdd(&n_abs, 1)] = slot;
+            else sorted[CH - 1 - atomicAdd(&n_oth, 1)] = slot;
+        }
+        __syncthreads();
+        const int na = n_abs, oth0 = (na + 63) & ~63, nl = oth0 + n_oth;      // the other kind starts on a wave boundary
+    for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
+        const int k = k0 + (int)threadIdx.x;
+        const bool valid = k < na || (k >= oth0 && k < nl);
+        const int slot = !valid ? 0 : k < na ? sorted[k] : sorted[CH - 1 - (k - oth0)];
+        int state = TS_DONE;
+        Packet<ND, GEOM_CAR> p;
+        Rng g;
+        unsigned long long id = 0;
+        p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+        if (valid) {
+            const HotRec<ND> &H = hot[slot];
+            const ColdRec<ND> &C = cold[slot];
+            state = H.state;
+#pragma unroll
+            for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; p.cell.ic[a] = H.ic[a]; }
+            unpack_ow(H.ow, p.cell.ow);
+            p.a = C.a;
+            p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
+            p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
+#pragma unroll
+            for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
+            p.inter = C.inter;
+            id = H.id;
+            g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+            g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
+            if (REABS) { p.reabs = C.reabs; p.reabs_id = C.reabs_id; }
+        }
+        if (REABS && state == TS_REEMIT) {
+            // iter_lucy.f90:155-185: re-emission from the source that absorbed the packet
+            const int inter = p.inter, reabs = p.reabs, rid = p.reabs_id;
+            const double e = p.energy;
+            if ((long long)reabs == P.n_reabs_max) { cnt.killed_int++; state = TS_DEAD; finished++; }
+            else {
+                int source_id; Angle src_normal;
+                bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                p.inter = inter; p.reabs = reabs + 1;
+                if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
+                else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
+                }
+            }
+        } else if (state == TS_INTERACT) {
+            p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+            if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; state = TS_DEAD; finished++; }
+            else {
+                int scattered, dust_id;
+#ifdef HYP_ABLATE_INTERACT   // timing experiment (wrong results): the kernel without the physics
+                bool ok = true; scattered = 1; dust_id = 0; cnt.interactions++;
+#else
+                bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
+#endif
+                bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                if (killed) { state = TS_DEAD; finished++; }
+                else if (MRW && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
+                else {
+                    p.inter++;
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
+                }
+            }
+        }
+        int brick = 0;
+        if (valid) {
+            if (state == TS_WALK || state == TS_INTERACT) {
+                store_records<ND>(P, hot[slot], cold[slot], p, g, id, state);
+                if (state == TS_WALK) { brick = brick_of(T, p.cell.ic); slot_brick[slot] = brick; }
+                else {
+                    // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts again
+                    slot_brick[slot] = TILE_NEEDS_INTERACT;
+                    const unsigned int j = atomicAdd(&ctl->n_extra[T.pool][par ^ 1], 1u);
+                    if (j < HYP_TILE_EXTRA) extra_next[j] = slot; else raise_error(P, ERR_INTERNAL, (double)j, 0.0, 0.0);
+                }
+            } else {        // the packet ended here: the slot is free for tile_emit
+                hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
+                if (is_extra) extra[2 * HYP_TILE_EXTRA + atomicAdd(&n_dead_x, 1)] = slot;
+                else dlist[start + atomicAdd(&tcount[task].n_dead, 1)] = slot;
+            }
+        }
+        count_bricks(counts, cache_b, cache_n, valid && state == TS_WALK, brick);
+    }
+    }
+    __syncthreads();
+    if (is_extra && threadIdx.x == 0) { ctl->n_extra[T.pool][par] = 0; ctl->n_extra_dead[T.pool] = (unsigned int)n_dead_x; }
+    flush_bricks(counts, cache_b, cache_n);
+    block_tally_flush(P, ctl, red, cnt, finished);
+}
+
+template <int ND>
+__global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+        HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold, int *__restrict__ slot_brick,
+        const TileTask *__restrict__ tasks, const int *__restrict__ dlist, const TileCount *__restrict__ tcount,
+        unsigned int *__restrict__ counts, int *__restrict__ extra)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    const unsigned int n_tasks = ctl->n_tasks[T.pool];
+    const unsigned int task = blockIdx.x / HYP_LIST_SPLIT;
+    const int part = (int)(blockIdx.x % HYP_LIST_SPLIT);
+    const bool is_extra = task == n_tasks;        // slots freed by tile_interact's extra workgroup
+    if (task > n_tasks || (is_extra && part != 0)) return;
+    int start = 0, n_dead = 0;
+    if (is_extra) n_dead = (int)ctl->n_extra_dead[T.pool];
+    else { start = tasks[task].start; n_dead = tcount[task].n_dead; }
+    if (n_dead <= part * 256) return;
+    const int *list = is_extra ? extra + 2 * HYP_TILE_EXTRA : dlist + start;
+    const int par = T.gen & 1;
+    int *extra_next = extra + (par ^ 1) * HYP_TILE_EXTRA;
+    Walls W;
+    stage_walls<GEOM_CAR>(P, lds, W);
+    __shared__ double red[TILE_RED_N];
+    __shared__ int cache_b[TILE_BCACHE];
+    __shared__ unsigned int cache_n[TILE_BCACHE];
+    __shared__ unsigned long long id_base;
+    if (threadIdx.x < TILE_RED_N) red[threadIdx.x] = 0.0;
+    if (threadIdx.x < TILE_BCACHE) { cache_b[threadIdx.x] = -1; cache_n[threadIdx.x] = 0; }
+    // one trip to the packet-id dispenser for all the entries of this workgroup (it is one address for the whole
+    // chip); only packets that end at once (emitted outside the grid) go back to it, a wave at a time
+    if (threadIdx.x == 0) {
+        int mine = 0;
+        for (int c0 = part * 256; c0 < n_dead; c0 += HYP_LIST_SPLIT * 256) mine += min(256, n_dead - c0);
+        id_base = atomicAdd(&ctl->next_id, (unsigned long long)mine);
+    }
+    __syncthreads();
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    unsigned int finished = 0;
+    const unsigned long long end_id = ctl->end_id;
+    int done_before = 0;
+    for (int c0 = part * 256; c0 < n_dead; c0 += HYP_LIST_SPLIT * 256) {
+        const int k = c0 + (int)threadIdx.x;
+        const bool valid = k < n_dead;
+        const int slot = valid ? list[k] : 0;
+        int state = valid ? TS_DEAD : TS_DONE;
+        Packet<ND, GEOM_CAR> p;
+        Rng g;
+        unsigned long long id = 0;
+        p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+        // a packet that is emitted outside the grid (or leaves it at once) frees its slot again
+        for (int round = 0;; round++) {
+            const bool want = state == TS_DEAD;
+            const unsigned long long m = __ballot(want);
+            if (!m) break;
+            unsigned long long base = 0;
+            if (round > 0) {
+                const int leader = __ffsll((long long)m) - 1;
+                if ((int)__lane_id() == leader) base = atomicAdd(&ctl->next_id, (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, 64);
+            }
+            if (want) {
+                id = round == 0 ? id_base + (unsigned long long)(done_before + (int)threadIdx.x)
+                                : base + (unsigned long long)__popcll(m & ((1ull << __lane_id()) - 1ull));
+                if (id >= end_id) state = TS_DONE;
+                else {
+                    rng_init(g, P.seed_key, T.iter_tag, id);
+                    int source_id; Angle src_normal;
+                    bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal);
+                    if (!ok || geo_escaped(P, p.cell)) finished++;
+                    else {
+                        p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                        begin_integrate(P, p);
+                        state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
+                    }
+                }
+            }
+        }
+        done_before += min(256, n_dead - c0);
+        int brick = 0;
+        if (valid) {
+            if (state == TS_WALK || state == TS_INTERACT) {
+                store_records<ND>(P, hot[slot], cold[slot], p, g, id, state);
+                if (state == TS_WALK) { brick = brick_of(T, p.cell.ic); slot_brick[slot] = brick; }
+                else {
+                    // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts
+                    slot_brick[slot] = TILE_NEEDS_INTERACT;
+                    const unsigned int j = atomicAdd(&ctl->n_extra[T.pool][par ^ 1], 1u);
+                    if (j < HYP_TILE_EXTRA) extra_next[j] = slot; else raise_error(P, ERR_INTERNAL, (double)j, 0.0, 0.0);
+                }
+            } else { hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE; }      // no packet ids left: the slot retires
+        }
+        count_bricks(counts, cache_b, cache_n, valid && state == TS_WALK, brick);
+    }
+    __syncthreads();
+    flush_bricks(counts, cache_b, cache_n);
+    block_tally_flush(P, ctl, red, cnt, finished);
+}
+
+// ---------------------------------------------------------------------------
 // tile_drain: once the packet ids are used up and only a few packets are still in
 // flight, generations stop paying (every one of them rescans all slots for a handful of
 // steps).  This kernel takes every remaining packet to its end in one launch, one lane
 // per packet, with the persistent kernel's walk_step (global atomics).
 // ---------------------------------------------------------------------------
-template <int ND>
+template <int ND, bool REABS, bool MRW>
 __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                                        HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
                                                                        int *__restrict__ slot_brick)
@@ -351,8 +749,8 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                 g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                 g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
                 p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
-                if (P.any_intersect) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }
-                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : H.state == TS_REEMIT ? ST_NEED_REEMIT : ST_WALK;
+                if (REABS) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }
+                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : (REABS && H.state == TS_REEMIT) ? ST_NEED_REEMIT : ST_WALK;
             } else {
                 rng_init(g, P.seed_key, T.iter_tag, 0);
                 p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
@@ -361,9 +759,9 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
             for (;;) {
                 unsigned long long m_walk = __ballot(st == ST_WALK);
                 unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
-                unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+                unsigned long long m_re = REABS ? __ballot(st == ST_NEED_REEMIT) : 0ull;
                 if (!(m_walk | m_int | m_re)) break;
-                if (m_re && (__popcll(m_re) >= 16 || !m_walk)) {      // iter_lucy.f90:155-185
+                if (REABS && m_re && (__popcll(m_re) >= 16 || !m_walk)) {      // iter_lucy.f90:155-185
                     if (st == ST_NEED_REEMIT) {
                         if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_DONE; finished++; }
                         else {
@@ -392,7 +790,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                             bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
                             bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                             if (killed) { st = ST_DONE; finished++; }
-                            else if (P.mrw && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, sum, cnt)) { st = ST_DONE; finished++; }
+                            else if (MRW && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, sum, cnt)) { st = ST_DONE; finished++; }
                             else {
                                 p.inter++;
                                 p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -430,7 +828,11 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
 // ---------------------------------------------------------------------------
 // counting sort of the walking slots by brick
 // ---------------------------------------------------------------------------
-#define HYP_SORT_PER_THREAD 8
+// slots per thread of tile_scatter / tile_count.  Every workgroup makes one returning atomic per brick on cursor[], and
+// atomics on one address are served one after the other by the memory side: the fewer workgroups, the shorter that queue.
+#ifndef HYP_SORT_PER_THREAD
+#define HYP_SORT_PER_THREAD 32
+#endif
 
 __global__ __launch_bounds__(256) void tile_count_kernel(TileGeom T, const int *__restrict__ slot_brick, unsigned int *__restrict__ counts)
 {
@@ -578,10 +980,12 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
 enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6, LS_REABS = 7 };
 
 template <int ND, int BX, int BY, int BZ>
-__global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+__global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                       HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
                                                       const int *__restrict__ order,
-                                                      const TileTask *__restrict__ tasks, int *__restrict__ slot_brick)
+                                                      const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,
+                                                      int *__restrict__ ilist, int *__restrict__ dlist,
+                                                      TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
@@ -597,6 +1001,14 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
     double *accum = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
 #endif
     __shared__ int next_pkt;
+    // split schedule: this task's lists of waiting / free slots and the bricks its packets move to
+    // (index (dz+1)*9 + (dy+1)*3 + dx+1; 13 = packets parked in this brick)
+    __shared__ int n_int_l, n_dead_l;
+    __shared__ unsigned int nb_cnt[27];
+    __shared__ double red[TILE_RED_N];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + TILE_RED_N) red[threadIdx.x - 64] = 0.0;
+    if (threadIdx.x < 27) nb_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 32) { n_int_l = 0; n_dead_l = 0; }
     const int bi = tk.brick % T.nbx, bj = (tk.brick / T.nbx) % T.nby, bk = tk.brick / (T.nbx * T.nby);
     const int x0 = bi * BX, y0 = bj * BY, z0 = bk * BZ;
     const int x1 = min(x0 + BX, P.n1), y1 = min(y0 + BY, P.n2), z1 = min(z0 + BZ, P.n3);
@@ -697,6 +1109,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
             }
             if (st == LS_DEAD) {
                 hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
+                if (T.split) dlist[tk.start + atomicAdd(&n_dead_l, 1)] = slot;
                 finished++; st = LS_IDLE;
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[slot];
@@ -707,7 +1120,17 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
                 if (P.any_intersect) cold[slot].t_ach = t_ach;
                 if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
                 else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
-                else if (st == LS_LEFT) slot_brick[slot] = brick_of(T, cell.ic);     // H.state stays TS_WALK
+                else if (st == LS_LEFT) {                                             // H.state stays TS_WALK
+                    if (T.split) {
+                        // one cell step leaves the brick through a face, an edge or a corner
+                        const int dx = cell.ic[0] < x0 ? -1 : (cell.ic[0] >= x1 ? 1 : 0);
+                        const int dy = cell.ic[1] < y0 ? -1 : (cell.ic[1] >= y1 ? 1 : 0);
+                        const int dz = cell.ic[2] < z0 ? -1 : (cell.ic[2] >= z1 ? 1 : 0);
+                        slot_brick[slot] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
+                        atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
+                    } else slot_brick[slot] = brick_of(T, cell.ic);
+                } else if (T.split) atomicAdd(&nb_cnt[13], 1u);                      // parked: same brick again
+                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
                 st = LS_IDLE;
             }
             if (park) break;
@@ -801,6 +1224,13 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
         }
     }
     __syncthreads();
+    if (T.split) {
+        if (threadIdx.x < 27 && nb_cnt[threadIdx.x]) {
+            const int dx = (int)threadIdx.x % 3 - 1, dy = ((int)threadIdx.x / 3) % 3 - 1, dz = (int)threadIdx.x / 9 - 1;
+            atomicAdd(&counts[tk.brick + dx + T.nbx * (dy + T.nby * dz)], nb_cnt[threadIdx.x]);
+        }
+        if (threadIdx.x == 32) { TileCount c; c.n_int = n_int_l; c.n_dead = n_dead_l; tcount[blockIdx.x] = c; }
+    }
     // flush the brick's accumulators (replica chosen like in the persistent kernel)
     double *sum = P.sum;
     if (P.n_copies > 1) {
@@ -830,16 +1260,5 @@ __global__ __launch_bounds__(HYP_TILE_WG) void tile_walk_kernel(const DProblem *
         if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
     }
 #endif
-    double cr = wave_sum((double)cnt.crossings);
-    double kg = wave_sum((double)cnt.killed_geo);
-    double ki = wave_sum((double)cnt.killed_int);
-    double ni = wave_sum((double)cnt.interactions);
-    double nf = wave_sum((double)finished);
-    if (__lane_id() == 0) {
-        unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], cr);
-        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
-        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
-        if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
-        if (nf != 0.0) atomicAdd(&ctl->n_finished, (unsigned long long)nf);
-    }
+    block_tally_flush(P, ctl, red, cnt, finished);
 }
