@@ -1,7 +1,12 @@
 #!/usr/bin/env python
 """Benchmark of the hot path named by BASELINE.json: photon packets/s and Lucy-
-iteration wall time on the 128^3 Cartesian grid (configs[1]: one central point
-source, single grey dust species, 1e8 packets per Lucy iteration per GPU).
+iteration wall time on the 128^3 Cartesian grid.
+
+  N = 1: configs[1] -- one central point source, single grey dust species, 1e8
+         packets per Lucy iteration.
+  N > 1: configs[2] -- the same grid, 1e9 packets per Lucy iteration sharded by
+         packet id over the N GPUs (1e9 / N each), one RCCL all-reduce of the
+         accumulator block per iteration; total work is fixed: "strong" scaling.
 
 A "step" is one whole Lucy iteration (packet propagation kernel + accumulator
 all-reduce when N>1 + update_energy_abs epilogue) over synthetic inputs already
@@ -52,7 +57,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=128)
-    ap.add_argument("--photons", type=float, default=1e8, help="packets per Lucy iteration PER GPU")
+    ap.add_argument("--photons", type=float, default=None,
+                    help="packets per Lucy iteration PER GPU (default: 1e8 at --gpus 1 = configs[1]; 1e9 / N at --gpus N = configs[2])")
     ap.add_argument("--density", default="uniform")
     ap.add_argument("--cpu-sample", type=float, default=2e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -78,8 +84,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n_per_gpu = int(args.photons)
-    n_total = n_per_gpu * world
+    if args.photons is None:
+        n_total = 100000000 if world == 1 else 1000000000      # configs[1] / configs[2]
+        config_name, scaling = ("configs[1]", "weak") if world == 1 else ("configs[2]", "strong")
+    else:
+        n_total = int(args.photons) * world
+        config_name, scaling = "configs[1] shape", "weak"
+    n_per_gpu = n_total // world
     prob = make_benchmark_problem(args.grid, density=args.density, n_photons=n_total, n_iter=args.steps)
     eng = hyperion_amd.Engine(prob, device=local_rank)
     for o in args.option:
@@ -122,10 +133,10 @@ def main():
             "metric": "photon packets/sec, Lucy iteration, %d^3 Cartesian grid" % args.grid,
             "value": n_total * args.steps / dt, "unit": "packets/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d^3 Cartesian, central 6000 K point source, grey isotropic dust (tau=1 centre-to-face, albedo 0.5), %g packets per Lucy iteration per GPU, %s density"
-                                   % (args.grid, n_per_gpu, args.density),
+            "config": {"workload": "%s: %d^3 Cartesian, central 6000 K point source, grey isotropic dust (tau=1 centre-to-face, albedo 0.5), %g packets per Lucy iteration in total (%g per GPU), %s density"
+                                   % (config_name, args.grid, n_total, n_per_gpu, args.density),
                        "packets_per_iteration": n_total, "parallelism": "packets sharded by id range over %d GPU(s), one f64 all-reduce per iteration" % world,
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),

@@ -69,6 +69,8 @@ class Config(C.Structure):
         ("baes16_xi", C.c_double), ("propagation_check_frequency", C.c_double),
         ("n_inter_mrw_max", C.c_int64), ("mrw_gamma", C.c_double), ("mrw", C.c_int32), ("monochromatic", C.c_int32),
         ("monochromatic_energy_threshold", C.c_double), ("frequencies", _dp), ("n_frequencies", C.c_int32), ("reserved2", C.c_int32),
+        ("pda", C.c_int32), ("count_photons", C.c_int32), ("n_spectrum_bins", C.c_int32), ("reserved3", C.c_int32),
+        ("spectrum_bin_edges", _dp),
     ]
 
 
@@ -82,6 +84,8 @@ class PeeledDesc(C.Structure):
         ("ap_min", C.c_double), ("ap_max", C.c_double), ("nu_min", C.c_double), ("nu_max", C.c_double),
         ("d_min", C.c_double), ("d_max", C.c_double), ("peeloff_origin", C.c_double * 3),
         ("theta", _dp), ("phi", _dp), ("inu_min", C.c_int32), ("inu_max", C.c_int32),
+        ("use_filters", C.c_int32), ("reserved_f", C.c_int32),
+        ("filt_n", C.POINTER(C.c_int32)), ("filt_nu", _dp), ("filt_tr", _dp),
     ]
 
 
@@ -200,6 +204,17 @@ class MarshalledProblem:
             d.config.frequencies = arr(c.frequencies)
             d.config.n_frequencies = int(np.asarray(c.frequencies).size)
         d.config.propagation_check_frequency = float(c.propagation_check_frequency)
+        d.config.pda = int(bool(c.pda))
+        d.config.count_photons = int(bool(c.pda) or c.output_n_photons != "none")
+        if c.output_specific_energy_spectrum != "none":
+            if c.spectrum_bin_edges is None:
+                raise ValueError("specific_energy_spectrum_bin_edges should be present in the input when "
+                                 "output_specific_energy_spectrum is enabled")
+            edges = np.asarray(c.spectrum_bin_edges, dtype=np.float64)
+            if edges.size < 2 or np.any(edges[1:] <= edges[:-1]):
+                raise ValueError("specific_energy_spectrum_bin_edges should be strictly increasing")
+            d.config.n_spectrum_bins = edges.size - 1
+            d.config.spectrum_bin_edges = arr(edges)
 
         nd = prob.n_dust
         if nd > MAX_DUST:
@@ -308,6 +323,14 @@ class MarshalledProblem:
             x.theta = arr(p.theta)
             x.phi = arr(p.phi)
             x.inu_min, x.inu_max = int(p.inu_min), int(p.inu_max)
+            if p.filters:
+                x.use_filters = 1
+                fn = np.array([np.size(f[0]) for f in p.filters], dtype=np.int32)
+                keep(fn)
+                x.filt_n = fn.ctypes.data_as(C.POINTER(C.c_int32))
+                x.filt_nu = arr(np.concatenate([np.asarray(f[0], dtype=np.float64) for f in p.filters]))
+                x.filt_tr = arr(np.concatenate([np.asarray(f[1], dtype=np.float64) for f in p.filters]))
+                x.n_nu = len(p.filters)
         keep(pls)
         d.n_peeled = npl
         d.peeled = C.cast(pls, C.POINTER(PeeledDesc))

@@ -83,6 +83,10 @@ struct DPeeled {
     const double *dust_chi;       // [n_dust][n_nu]
     int inside_observer, pad_obs; // peel-off towards the point `origin` inside the grid (images_peeled.f90:158-205): lon / lat maps
     int nj_stride, inu_min;       // inu_min: monochromatic, 1-based first frequency of this group (image_type.f90:243-258)
+    // filter convolution (image_type.f90:173-181,285-291,467-475): n_nu transmission curves, filt_off[n_nu + 1] into filt_nu / filt_tr
+    int use_filters, pad_f;
+    const double *filt_off;       // integer-valued (the tables live in the constant blob of doubles)
+    const double *filt_nu, *filt_tr;
 };
 
 // Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
@@ -180,6 +184,17 @@ struct DProblem {
     double *err_data;                     // [0..2]
     const DSource *sources;
     const DPeeled *peeled;
+    // n_photons (grid_propagate_3d.f90:88-93,171-176): packets that entered each cell in this Lucy iteration [n_cells];
+    // last_id = tags of the last HYP_NPHOT_SLOTS packets counted in each cell [n_cells][HYP_NPHOT_SLOTS], see count_photon.
+    // count_photons = 0: arrays absent.
+    unsigned int *n_photons, *last_id;
+    int count_photons;
+    // frequency-resolved specific energy (grid_propagate_3d.f90:59-71,155-158,214-222): accumulators [n_bins][n_cells][n_dust],
+    // log10 of the bin edges [n_bins + 1], fraction of each emissivity row in each bin [n_dust][nj_max][n_bins] (MRW deposits)
+    int n_bins, nj_max, pad8;
+    const double *log_nu_edges;
+    double *sum_spec;
+    const double *jnu_bin_frac;
     DDust dust[HYP_MAXD];
 };
 

@@ -4,6 +4,7 @@
 #include "../../include/hyperion_amd.h"
 #include "hyp_kernels.h"
 #include "hyp_tiled.h"
+#include "hyp_epilogue.h"
 #include "hyp_pick.h"
 
 #include <array>
@@ -162,11 +163,11 @@ struct DustOffsets {
     size_t nu, log10_nu, chi, albedo, log10_chi, log10_albedo, mu, P1, P2, P3, P4, P1_cdf, P2_cdf;
     size_t emiss_x, emiss_cdf, emiss_bp1, emiss_coarse, jnu_var, log10_jnu_var, mo_e, mo_chi_ross;
     size_t mo_kappa_planck, mo_chi_inv_planck, bnu_cdf, bnu_bp1, bnu_coarse, mono_prob;
-    bool have_mo_e, have_mo_chi, have_mrw;
+    bool have_mo_e, have_mo_chi, have_mrw, have_pda;
 };
 
 struct SourceOffsets { size_t x, cdf, bp1; bool have; size_t points, point_cdf; bool have_points; size_t map_cdf; bool have_map; size_t spot_tab; bool have_spots; };
-struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi; };
+struct PeeledOffsets { size_t view, src_spec, dust_em, dust_chi, filt_off, filt_nu, filt_tr; };
 
 }  // namespace
 
@@ -241,6 +242,23 @@ struct hyp_engine {
     double *d_mono_mean = nullptr;      // [HYP_MAXD]
     bool mono_pending = false;
     hyp_iter_stats mono_stats;
+
+    // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
+    bool count_photons = false, pda = false;
+    int n_bins = 0, nj_max = 1;
+    unsigned int *d_nphot = nullptr, *d_last_id = nullptr;      // [n_cells]
+    size_t ext_nphot = 0, ext_spec = 0, block_doubles = 0;        // offsets (doubles) of the extensions in the accumulator block; its length
+    double *d_log_edges = nullptr, *d_bin_frac = nullptr, *d_spec = nullptr;
+    std::vector<double> spectrum_edges;
+    unsigned char *d_pda_mask = nullptr;
+    unsigned int *d_pda_cells = nullptr, *d_pda_hp = nullptr;    // hp: [count | offsets (+1) | cursor], n_hp + 1 entries each
+    double *d_pda_emean = nullptr, *d_pda_coef = nullptr;
+    size_t pda_coef_alloc = 0;
+    PdaCtl *d_pda_ctl = nullptr;
+    int pda_last_cells = 0, pda_last_outer = 0, pda_last_sweeps = 0;
+    double *d_prev_se = nullptr, *d_ratio = nullptr;
+    ConvCtl *d_conv_ctl = nullptr;
+    bool have_prev = false;
 
     int set_error(const std::string &m) { err = m; return 1; }
 };
@@ -538,6 +556,9 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
     free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
+    free_dev(h->d_nphot); free_dev(h->d_last_id); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
+    free_dev(h->d_pda_mask); free_dev(h->d_pda_cells); free_dev(h->d_pda_hp); free_dev(h->d_pda_emean); free_dev(h->d_pda_coef);
+    free_dev(h->d_pda_ctl); free_dev(h->d_prev_se); free_dev(h->d_ratio); free_dev(h->d_conv_ctl);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     for (int i = 1; i < 4; i++) if (h->pool_stream[i]) (void)hipStreamDestroy(h->pool_stream[i]);
     if (h->ev_pool) (void)hipEventDestroy(h->ev_pool);
@@ -550,6 +571,7 @@ void hyp_destroy(hyp_handle h)
 }
 
 static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref);
+static int solve_pda(hyp_handle h);
 static int sync_problem(hyp_handle h);
 static int check_device_error(hyp_handle h);
 static int mrw_prepare(hyp_handle h);
@@ -966,6 +988,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         }
         if (O.have_mo_chi) O.mo_chi_ross = B.put(in.mo_chi_rosseland, in.n_e);
         if (in.sublimation_mode == 2 && !O.have_mo_chi) FAIL("slow sublimation needs the Rosseland mean opacity table");
+        O.have_pda = false;
+        if (pr->config.pda) {       // setup_rt.f90:289-300; grid_pda_3d.f90 reads kappa_planck and chi_rosseland
+            if (in.version == 1)
+                FAIL("version 1 dust files can no longer be used when PDA is computed due to a bug - to fix this, re-generate the dust file using the latest version of Hyperion");
+            if (!(O.have_mo_chi && in.mo_kappa_planck)) FAIL("PDA needs the kappa_planck and chi_rosseland mean opacities of every dust type");
+            if (!pr->config.mrw) { O.mo_kappa_planck = B.put(in.mo_kappa_planck, in.n_e); O.have_pda = true; }
+        }
         // modified random walk: Planck means + b_nu = j_nu / kappa_nu pdfs (dust_type_4elem.f90:289-291)
         O.have_mrw = false;
         if (pr->config.mrw) {
@@ -1182,6 +1211,20 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             view[4 * v + 2] = std::cos(f); view[4 * v + 3] = std::sin(f);
         }
         poff[g].view = B.put(view);
+        if (in.use_filters) {       // image_type.f90:173-181,285-291; images_peeled.f90:349-351
+            if (pr->config.monochromatic) FAIL("cannot use filters in monochromatic mode");
+            if (pr->config.raytracing && g < pr->n_peeled) FAIL("filter convolution cannot be used with raytracing");
+            if (!in.filt_n || !in.filt_nu || !in.filt_tr) FAIL("filter tables are missing");
+            std::vector<double> off(in.n_nu + 1, 0.0);
+            for (int i = 0; i < in.n_nu; i++) {
+                if (in.filt_n[i] < 2) FAIL("a filter needs at least two points");
+                off[i + 1] = off[i] + in.filt_n[i];
+            }
+            poff[g].filt_off = B.put(off);
+            poff[g].filt_nu = B.put(in.filt_nu, (int)off[in.n_nu]);
+            poff[g].filt_tr = B.put(in.filt_tr, (int)off[in.n_nu]);
+            G.use_filters = 1;
+        }
         if (pr->config.raytracing && g < pr->n_peeled) ray_groups.push_back(g);
         if (in.compute_sed) {
             h->sed_n[g] = (size_t)G.n_stokes * G.n_orig * in.n_view * in.n_ap * in.n_nu;
@@ -1382,7 +1425,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         D.jnu_var = db + O.jnu_var; D.log10_jnu_var = db + O.log10_jnu_var;
         D.mo_e = O.have_mo_e ? db + O.mo_e : nullptr;
         D.mo_chi_ross = O.have_mo_chi ? db + O.mo_chi_ross : nullptr;
-        D.mo_kappa_planck = O.have_mrw ? db + O.mo_kappa_planck : nullptr;
+        D.mo_kappa_planck = (O.have_mrw || O.have_pda) ? db + O.mo_kappa_planck : nullptr;
         D.mo_chi_inv_planck = O.have_mrw ? db + O.mo_chi_inv_planck : nullptr;
         D.mono_log10_prob = pr->config.monochromatic ? db + O.mono_prob : nullptr;
         D.bnu_cdf = O.have_mrw ? db + O.bnu_cdf : nullptr; D.bnu_bp1 = O.have_mrw ? db + O.bnu_bp1 : nullptr;
@@ -1414,8 +1457,61 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     HIPC(hipMalloc(&h->d_err, sizeof(int)));
     HIPC(hipMalloc(&h->d_err_data, sizeof(double) * 4));
     HIPC(hipMemset(h->d_err, 0, sizeof(int)));
-    h->accum_stride = ((ne + TAIL_SIZE + 31) / 32) * 32;
-    h->accum_copies_alloc = 8;
+    // The accumulator block that the ranks all-reduce: [sums | tail | n_photons as doubles | spectrum sums]
+    h->count_photons = pr->config.count_photons || pr->config.pda;
+    h->pda = pr->config.pda != 0;
+    h->n_bins = pr->config.n_spectrum_bins > 0 ? pr->config.n_spectrum_bins : 0;
+    if (h->pda && !is_car) { /* grid_pda_disabled.f90: nothing to solve, but the counters are kept */ }
+    h->ext_nphot = ne + TAIL_SIZE;
+    h->ext_spec = h->ext_nphot + (h->count_photons ? h->n_cells : 0);
+    h->block_doubles = h->ext_spec + (size_t)h->n_bins * ne;
+    h->accum_stride = ((h->block_doubles + 31) / 32) * 32;
+    h->accum_copies_alloc = h->n_bins ? 1 : 8;
+    if (h->n_bins) h->accum_copies = 1;        // the spectrum planes are not replicated; their atomics dominate anyway
+    if (h->count_photons) {
+        HIPC(hipMalloc(&h->d_nphot, sizeof(unsigned int) * h->n_cells));
+        HIPC(hipMalloc(&h->d_last_id, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS));
+        HIPC(hipMemset(h->d_nphot, 0, sizeof(unsigned int) * h->n_cells));
+        HIPC(hipMemset(h->d_last_id, 0, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS));
+        P.n_photons = h->d_nphot; P.last_id = h->d_last_id; P.count_photons = 1;
+    }
+    if (h->n_bins) {     // grid_physics_3d.f90:124-143,269-282,326-348
+        const int nb = h->n_bins;
+        if (!pr->config.spectrum_bin_edges) FAIL("specific_energy_spectrum_bin_edges should be present in the input when output_specific_energy_spectrum is enabled");
+        h->spectrum_edges.assign(pr->config.spectrum_bin_edges, pr->config.spectrum_bin_edges + nb + 1);
+        std::vector<double> le(nb + 1);
+        for (int b = 0; b <= nb; b++) {
+            if (b && !(h->spectrum_edges[b] > h->spectrum_edges[b - 1])) FAIL("specific_energy_spectrum_bin_edges should be strictly increasing");
+            le[b] = std::log10(h->spectrum_edges[b]);
+        }
+        HIPC(hipMalloc(&h->d_log_edges, sizeof(double) * (nb + 1)));
+        HIPC(hipMemcpy(h->d_log_edges, le.data(), sizeof(double) * (nb + 1), hipMemcpyHostToDevice));
+        h->nj_max = 1;
+        for (int d = 0; d < pr->n_dust; d++) h->nj_max = std::max(h->nj_max, pr->dust[d].n_jnu);
+        // get_j_nu_bin_fractions (dust_type_4elem.f90:752-778): share of each emissivity row in each bin
+        std::vector<double> frac((size_t)pr->n_dust * h->nj_max * nb, 0.0);
+        for (int d = 0; d < pr->n_dust; d++) {
+            const hyp_dust_desc &in = pr->dust[d];
+            for (int iv = 0; iv < in.n_jnu; iv++) {
+                double *f = frac.data() + ((size_t)d * h->nj_max + iv) * nb;
+                for (int b = 0; b < nb; b++)
+                    f[b] = integral_loglog_range(in.emiss_nu, in.emiss_jnu + iv, in.n_jnu, in.n_enu, h->spectrum_edges[b], h->spectrum_edges[b + 1]);
+                const double norm = integral_loglog_all(in.emiss_nu, in.emiss_jnu + iv, in.n_jnu, in.n_enu);
+                if (norm > 0.0) for (int b = 0; b < nb; b++) f[b] /= norm;
+            }
+        }
+        HIPC(hipMalloc(&h->d_bin_frac, sizeof(double) * frac.size()));
+        HIPC(hipMemcpy(h->d_bin_frac, frac.data(), sizeof(double) * frac.size(), hipMemcpyHostToDevice));
+        // specific_energy_spectrum starts at the minimum specific energy unless an initial specific energy was given
+        // (then it starts at 0): grid_physics_3d.f90:143,215-253
+        std::vector<double> sp((size_t)nb * ne, 0.0);
+        if (!pr->specific_energy || pr->config.specific_energy_type == 1)
+            for (int b = 0; b < nb; b++) for (size_t ic = 0; ic < h->n_cells; ic++) for (int d = 0; d < pr->n_dust; d++)
+                sp[((size_t)b * h->n_cells + ic) * pr->n_dust + d] = pr->dust[d].minimum_specific_energy;
+        HIPC(hipMalloc(&h->d_spec, sizeof(double) * sp.size()));
+        HIPC(hipMemcpy(h->d_spec, sp.data(), sizeof(double) * sp.size(), hipMemcpyHostToDevice));
+        P.n_bins = nb; P.nj_max = h->nj_max; P.log_nu_edges = h->d_log_edges; P.jnu_bin_frac = h->d_bin_frac;
+    }
     HIPC(hipMalloc(&h->d_accum, sizeof(double) * h->accum_stride * h->accum_copies_alloc));
     HIPC(hipMemset(h->d_accum, 0, sizeof(double) * h->accum_stride * h->accum_copies_alloc));
 
@@ -1427,6 +1523,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     for (int g = 0; g < n_groups; g++) {
         DPeeled &G = h->h_peeled[g];
         G.view = db + poff[g].view;
+        if (G.use_filters) { G.filt_off = db + poff[g].filt_off; G.filt_nu = db + poff[g].filt_nu; G.filt_tr = db + poff[g].filt_tr; }
         if (pr->config.raytracing) {
             G.src_spec = db + poff[g].src_spec; G.dust_log10_em = db + poff[g].dust_em; G.dust_chi = db + poff[g].dust_chi;
             G.nj_stride = nj_stride;
@@ -1491,6 +1588,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     P.copy_stride = h->accum_stride;
     P.n_copies = 1;
     P.tail = h->d_accum + ne;
+    P.sum_spec = h->n_bins ? h->d_accum + h->ext_spec : nullptr;
     P.jnu_id = h->d_jnu_id; P.jnu_frac = h->d_jnu_frac;
     P.specific_energy = h->d_specific_energy; P.energy_abs_tot = h->d_energy_abs_tot;
     P.energy_total = h->energy_total; P.peel_scattered_only = pr->config.raytracing ? 1 : 0;
@@ -1548,7 +1646,8 @@ static int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out
     if ((size_t)blocks > need) blocks = (int)need;
     if (blocks < 1) blocks = 1;
     finish_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, F, mode, h->d_specific_energy, h->d_density,
-                                                 h->d_additional, h->d_jnu_id, h->d_jnu_frac, h->d_energy_abs_tot, d_out_ref);
+                                                 h->d_additional, h->d_jnu_id, h->d_jnu_frac, h->d_energy_abs_tot, d_out_ref,
+                                                 h->d_spec, h->n_bins);
     e = hipGetLastError();
     if (e != hipSuccess) return h->set_error(std::string("finish_kernel launch: ") + hipGetErrorString(e));
     return 0;
@@ -1605,6 +1704,152 @@ static int check_device_error(hyp_handle h)
     return h->set_error(buf);
 }
 
+// solve_pda (src/grid/grid_pda_3d.f90:84-172) on the device, after update_energy_abs.  The reference solves the
+// diffusion equation for the mean intensity in the cells that saw fewer than max(30, 0.5 % of the mean) packets:
+// with fewer than 10 000 such cells by Gaussian elimination, otherwise by Gauss-Seidel sweeps in cell order down to
+// a relative change of 1e-4 per sweep, and repeats with the updated Rosseland means until the specific energy moves
+// by less than 1e-5 / 1e-4.  Here both branches are Gauss-Seidel sweeps ordered by hyperplanes (pda_gs_kernel): the
+// iterative branch reproduces the reference's sweeps exactly; the Gauss pivot branch is iterated to 1e-12 instead,
+// which determines the solution of the same linear system far below the 1e-5 of the outer loop.
+static int solve_pda(hyp_handle h)
+{
+    h->pda_last_cells = 0; h->pda_last_outer = 0; h->pda_last_sweeps = 0;
+    const DProblem &P = h->hp;
+    if (!(P.grid_type == 1 || P.grid_type == 5 || P.grid_type == 6)) return 0;      // grid_pda_disabled.f90
+    const size_t nc = h->n_cells;
+    const int n_hp = P.n1 + P.n2 + P.n3 - 2;       // i1 + i2 + i3 = 0 .. n1 + n2 + n3 - 3
+    if (!h->d_pda_ctl) {
+        if (hipMalloc(&h->d_pda_ctl, sizeof(PdaCtl)) != hipSuccess || hipMalloc(&h->d_pda_mask, nc) != hipSuccess ||
+            hipMalloc(&h->d_pda_cells, sizeof(unsigned int) * nc) != hipSuccess ||
+            hipMalloc(&h->d_pda_hp, sizeof(unsigned int) * 3 * (n_hp + 1)) != hipSuccess ||
+            hipMalloc(&h->d_pda_emean, sizeof(double) * nc) != hipSuccess)
+            return h->set_error("cannot allocate the PDA work arrays");
+    }
+    unsigned int *hp_count = h->d_pda_hp, *hp_off = h->d_pda_hp + (n_hp + 1), *hp_cursor = h->d_pda_hp + 2 * (n_hp + 1);
+    const double *nphot = h->d_accum + h->ext_nphot;
+    const int blocks = h->n_cu * 4;
+    PdaCtl ctl;
+    (void)hipMemsetAsync(h->d_pda_ctl, 0, sizeof(PdaCtl), h->stream);
+    (void)hipMemsetAsync(h->d_pda_hp, 0, sizeof(unsigned int) * 3 * (n_hp + 1), h->stream);
+    pda_total_kernel<<<blocks, 256, 0, h->stream>>>(nphot, nc, h->d_pda_ctl);
+    if (hipMemcpyAsync(&ctl, h->d_pda_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return h->set_error("PDA: cannot read the packet total");
+    // mean_n_photons = sum(n_photons) / size(n_photons) is an INTEGER division (:99); threshold max(30, ceiling(0.005 mean))
+    const double mean_n = (double)((long long)ctl.total_photons / (long long)nc);
+    const double threshold = std::max(30.0, std::ceil(0.005 * mean_n));
+    pda_mask_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, nphot, threshold, h->d_specific_energy, h->d_density, h->d_pda_mask,
+                                                   h->d_pda_emean, hp_count, h->d_pda_ctl);
+    if (hipMemcpyAsync(&ctl, h->d_pda_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return h->set_error("PDA: cannot read the cell count");
+    const unsigned int n_pda = ctl.n_pda;
+    h->pda_last_cells = (int)n_pda;
+    if (n_pda == 0) return 0;        // " [pda] not necessary for this iteration"
+    pda_scan_kernel<<<1, 64, 0, h->stream>>>(hp_count, hp_off, hp_cursor, n_hp);
+    pda_list_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, h->d_pda_mask, hp_off, hp_cursor, h->d_pda_cells);
+    if ((size_t)n_pda * 6 > h->pda_coef_alloc) {
+        free_dev(h->d_pda_coef);
+        if (hipMalloc(&h->d_pda_coef, sizeof(double) * 6 * n_pda) != hipSuccess) return h->set_error("cannot allocate the PDA coefficients");
+        h->pda_coef_alloc = (size_t)n_pda * 6;
+    }
+    const bool exact = n_pda < 10000;
+    const double tolerance = exact ? 1.e-5 : 1.e-4, gs_tol = exact ? 1.e-12 : 1.e-4;
+    const int cb = (int)std::min<size_t>((n_pda + 255) / 256, (size_t)h->n_cu * 4);
+    for (int outer = 1; outer <= 10000; outer++) {
+        h->pda_last_outer = outer;
+        pda_coef_kernel<<<cb, 256, 0, h->stream>>>(h->d_problem, h->d_pda_cells, n_pda, h->d_specific_energy, h->d_density, h->d_pda_emean,
+                                                  h->d_pda_coef, exact ? 1 : 0);
+        pda_gs_kernel<<<1, 1024, 0, h->stream>>>(h->d_problem, h->d_pda_cells, hp_off, n_hp, h->d_pda_coef, h->d_pda_emean, gs_tol,
+                                                 20000000, h->d_pda_ctl);
+        (void)hipMemsetAsync(&h->d_pda_ctl->maxdiff_bits, 0, sizeof(unsigned long long), h->stream);
+        pda_update_kernel<<<cb, 256, 0, h->stream>>>(h->d_problem, h->d_pda_cells, n_pda, h->d_pda_emean, h->d_specific_energy, h->d_spec,
+                                                    h->n_bins, h->d_pda_ctl);
+        if (hipMemcpyAsync(&ctl, h->d_pda_ctl, sizeof ctl, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) return h->set_error(std::string("PDA solve failed: ") + hipGetErrorString(hipGetLastError()));
+        h->pda_last_sweeps += ctl.sweeps;
+        double maxdiff;
+        std::memcpy(&maxdiff, &ctl.maxdiff_bits, sizeof maxdiff);
+        if (maxdiff < tolerance) return 0;      // " [pda] converged"
+    }
+    return h->set_error("PDA did not converge");
+}
+
+int hyp_get_n_photons(hyp_handle h, double *out)
+{
+    if (!h || !out) return 1;
+    if (!h->count_photons) return h->set_error("n_photons array is not allocated");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    // after hyp_lucy_accumulators (and the all-reduce) the block holds the whole-job counts
+    hipError_t e = hipMemcpy(out, h->d_accum + h->ext_nphot, sizeof(double) * h->n_cells, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(n_photons): ") + hipGetErrorString(e));
+    return 0;
+}
+
+int hyp_get_specific_energy_spectrum(hyp_handle h, double *out, double *bin_edges_out)
+{
+    if (!h) return 1;
+    if (!h->n_bins) return h->set_error("specific_energy_spectrum array is not allocated");
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    if (bin_edges_out) std::memcpy(bin_edges_out, h->spectrum_edges.data(), sizeof(double) * (h->n_bins + 1));
+    if (!out) return 0;
+    double *tmp = nullptr;
+    const size_t n = (size_t)h->n_bins * h->n_elem;
+    if (hipMalloc(&tmp, sizeof(double) * n) != hipSuccess) return h->set_error("cannot allocate the spectrum staging buffer");
+    spectrum_to_ref_kernel<<<h->n_cu * 8, 256, 0, h->stream>>>(h->d_spec, tmp, h->n_cells, h->n_dust, h->n_bins);
+    hipError_t e = hipMemcpyAsync(out, tmp, sizeof(double) * n, hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return h->set_error(std::string("copy out failed: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// specific_energy_converged (grid_physics_3d.f90:637-689): the `percentile` quantile of max(a/b, b/a) between the
+// specific energy at the previous call and now.  status 0: value computed; 1: nothing changed (value 0); 2: could not
+// check (only cells that were or became zero changed); 3: first call (no previous state).  fortranlib's quantile
+// (source absent) is restated as the element of rank nint(percentile / 100 * (n - 1)) of the sorted sample; it is
+// found by a search over the bit patterns of the (positive) ratios: 63 counting passes, no sort.
+int hyp_convergence_value(hyp_handle h, double percentile, double *value, int *status)
+{
+    if (!h || !value || !status) return 1;
+    if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
+    const size_t n = h->n_elem;
+    if (!h->d_prev_se) {
+        if (hipMalloc(&h->d_prev_se, sizeof(double) * n) != hipSuccess || hipMalloc(&h->d_ratio, sizeof(double) * n) != hipSuccess ||
+            hipMalloc(&h->d_conv_ctl, sizeof(ConvCtl)) != hipSuccess) return h->set_error("cannot allocate the convergence work arrays");
+    }
+    *value = 0.0;
+    if (!h->have_prev) {
+        (void)hipMemcpyAsync(h->d_prev_se, h->d_specific_energy, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream);
+        (void)hipStreamSynchronize(h->stream);
+        h->have_prev = true; *status = 3;
+        return 0;
+    }
+    const int blocks = h->n_cu * 8;
+    ConvCtl c;
+    (void)hipMemsetAsync(h->d_conv_ctl, 0, sizeof(ConvCtl), h->stream);
+    conv_ratio_kernel<<<blocks, 256, 0, h->stream>>>(h->d_prev_se, h->d_specific_energy, n, h->d_ratio, h->d_conv_ctl);
+    (void)hipMemcpyAsync(h->d_prev_se, h->d_specific_energy, sizeof(double) * n, hipMemcpyDeviceToDevice, h->stream);
+    if (hipMemcpyAsync(&c, h->d_conv_ctl, sizeof c, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+        hipStreamSynchronize(h->stream) != hipSuccess) return h->set_error("convergence check failed");
+    if (c.n_changed == 0) { *status = 1; return 0; }
+    if (c.n_changed_nonzero == 0 || c.n_valid == 0) { *status = 2; return 0; }
+    long long rank = (long long)std::floor(percentile / 100.0 * (double)(c.n_valid - 1) + 0.5);
+    if (rank < 0) rank = 0;
+    if ((unsigned long long)rank > c.n_valid - 1) rank = (long long)(c.n_valid - 1);
+    // largest bit pattern v with #(ratios < v) <= rank is the ratio of that rank
+    unsigned long long prefix = 0;
+    for (int bit = 62; bit >= 0; bit--) {
+        const unsigned long long cand = prefix | (1ull << bit);
+        (void)hipMemsetAsync(&h->d_conv_ctl->count, 0, sizeof(unsigned long long), h->stream);
+        conv_count_kernel<<<blocks, 256, 0, h->stream>>>(h->d_ratio, n, cand, h->d_conv_ctl);
+        if (hipMemcpyAsync(&c.count, &h->d_conv_ctl->count, sizeof c.count, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+            hipStreamSynchronize(h->stream) != hipSuccess) return h->set_error("convergence check failed");
+        if (c.count <= (unsigned long long)rank) prefix = cand;
+    }
+    std::memcpy(value, &prefix, sizeof(double));
+    *status = 0;
+    return 0;
+}
+
 int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration)
 {
     if (!h) return 1;
@@ -1622,6 +1867,11 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         h->d_accum = nb; h->accum_copies_alloc = copies;
     }
     P.sum = h->d_accum; P.tail = h->d_accum + h->n_elem; P.n_copies = copies; P.copy_stride = h->accum_stride;
+    P.sum_spec = h->n_bins ? h->d_accum + h->ext_spec : nullptr;
+    if (h->count_photons) {      // grid_reset_energy: grid_generic.f90:21-27
+        (void)hipMemsetAsync(h->d_nphot, 0, sizeof(unsigned int) * h->n_cells, h->stream);
+        (void)hipMemsetAsync(h->d_last_id, 0, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS, h->stream);
+    }
     if (mrw_prepare(h)) return 1;
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
@@ -1632,7 +1882,9 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
 
     // The brick-tiled iteration pays off once the grid has many bricks and the
     // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
-    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS;
+    // (the per-cell packet counter and the spectrum planes live in global memory: those runs use the persistent kernel)
+    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS &&
+                         !h->count_photons && !h->n_bins;
     const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
     if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
         if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;
@@ -1685,12 +1937,13 @@ int hyp_lucy_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
         int blocks = h->n_cu * 8;
         reduce_copies_kernel<<<blocks, 256, 0, h->stream>>>(h->d_accum, h->n_elem + TAIL_SIZE, h->accum_stride, h->hp.n_copies);
     }
+    if (h->count_photons) nphot_to_block_kernel<<<h->n_cu * 4, 256, 0, h->stream>>>(h->d_nphot, h->d_accum + h->ext_nphot, h->n_cells);
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
     (void)hipEventElapsedTime(&h->last_propagate_ms, h->ev0, h->ev1);
     if (check_device_error(h)) { h->lucy_pending = false; return 1; }
     if (device_ptr) *device_ptr = h->d_accum;
-    if (n_doubles) *n_doubles = h->n_elem + TAIL_SIZE;
+    if (n_doubles) *n_doubles = h->block_doubles;
     return 0;
 }
 
@@ -1713,7 +1966,17 @@ int hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *s
     // update_energy_abs(energy_total/energy_current): iter_lucy.f90:224
     (void)hipEventRecord(h->ev2, h->stream);
     double *d_out = (specific_energy_out && h->n_dust > 1) ? h->d_scratch : nullptr;
-    if (run_finish_kernel(h, 0, h->energy_total / st.energy_current, d_out)) return 1;
+    const double scale = h->energy_total / st.energy_current;
+    if (h->n_bins) {
+        spectrum_update_kernel<<<h->n_cu * 8, 256, 0, h->stream>>>(h->d_problem, h->d_accum + h->ext_spec, h->d_spec, scale, h->n_bins);
+        if (hipGetLastError() != hipSuccess) return h->set_error("spectrum_update_kernel launch failed");
+    }
+    if (h->pda) {
+        // update_energy_abs, then solve_pda, then sublimate_dust: iter_lucy.f90:224-235
+        if (run_finish_kernel(h, 2, scale, nullptr)) return 1;
+        if (solve_pda(h)) return 1;
+        if (run_finish_kernel(h, 3, scale, d_out)) return 1;
+    } else if (run_finish_kernel(h, 0, scale, d_out)) return 1;
     (void)hipEventRecord(h->ev3, h->stream);
     double tot[HYP_MAXD];
     e = hipMemcpyAsync(tot, h->d_energy_abs_tot, sizeof(tot), hipMemcpyDeviceToHost, h->stream);
@@ -1820,6 +2083,9 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_task") *value = h->tile_task;
     else if (n == "tile_pools") *value = h->tile_pools;
     else if (n == "tile_split") *value = h->tile_split;
+    else if (n == "pda_last_cells") *value = h->pda_last_cells;
+    else if (n == "pda_last_outer") *value = h->pda_last_outer;
+    else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;

@@ -50,6 +50,7 @@ struct Packet {
     // number of successive re-emissions (iter_lucy.f90:155-185)
     double t_src, t_ach;
     int reabs_id, reabs;
+    int spec_idx;               // frequency bin of the specific-energy spectrum during this grid_integrate (-1: none)
 };
 
 // extra state carried only by the imaging (final) iteration
@@ -625,6 +626,40 @@ __device__ __forceinline__ void begin_integrate(const DProblem &P, Packet<NDT, G
     geo_begin(p.r, p.v, p.cell);
 }
 
+// n_photons(ic) += 1 unless this packet has been counted in the cell before (grid_propagate_3d.f90:90-95,175-180).  The
+// reference runs its packets one after the other, so its "the last packet here was not this one" IS "this packet has not
+// been here before": n_photons = number of distinct packets per cell.  Here packets interleave, so every cell remembers the
+// last HYP_NPHOT_SLOTS packets it counted (one 128-byte line per cell): the count is exact in every cell that at most that
+// many packets visit -- which covers the decision the count exists for, the PDA threshold of 30 packets -- and an upper
+// bound elsewhere (a packet that returns after 32 others were counted in between is counted again).
+#define HYP_NPHOT_SLOTS 32
+__device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsigned int tag)
+{
+    const uint4 *slots = (const uint4 *)(P.last_id + ic * HYP_NPHOT_SLOTS);
+    bool seen = false;
+#pragma unroll
+    for (int k = 0; k < HYP_NPHOT_SLOTS / 4; k++) {
+        const uint4 q = slots[k];
+        seen = seen | (q.x == tag) | (q.y == tag) | (q.z == tag) | (q.w == tag);
+    }
+    if (!seen) {
+        const unsigned int old = atomicAdd(&P.n_photons[ic], 1u);
+        P.last_id[ic * HYP_NPHOT_SLOTS + (old % HYP_NPHOT_SLOTS)] = tag;
+    }
+}
+__device__ __forceinline__ unsigned int photon_tag(const Rng &g) { return g.id_lo + 1u; }
+
+// start of a grid_integrate call of the Lucy iteration: also the frequency bin of the packet (:59-71) and the
+// count of the starting cell (:90-95)
+template <int NDT, int GEOM>
+__device__ __forceinline__ void begin_integrate_lucy(const DProblem &P, Packet<NDT, GEOM> &p, const Rng &g)
+{
+    begin_integrate(P, p);
+    p.spec_idx = -1;
+    if (P.n_bins) p.spec_idx = locate(P.log_nu_edges, P.n_bins + 1, log10(p.nu));
+    if (P.count_photons && !geo_escaped(P, p.cell)) count_photon(P, geo_index(P, p.cell), photon_tag(g));
+}
+
 // One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
 // / grid_integrate_noenergy (:237-375).  Returns the lane's next phase;
 // ST_NEED_EMIT means the packet left the grid or was killed.
@@ -658,12 +693,18 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
         if (DEPOSIT) {
 #pragma unroll
             for (int d = 0; d < NDT; d++)
-                if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
+                if (d < nd && rho[d] > 0.0) {
+                    unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
+                    if (P.n_bins && p.spec_idx >= 0)
+                        unsafeAtomicAdd(&P.sum_spec[(size_t)p.spec_idx * P.n_cells * nd + base + d], tmin * p.kappa[d] * p.energy);
+                }
         }
         geo_advance(P, p.r, p.cell, im);
         if (geo_invalid(P, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }     // amr: invalid_cell
         // the imaging iteration (no deposits) tells packets that left the grid from killed ones: iter_final.f90:127-129
-        return geo_escaped(P, p.cell) ? (DEPOSIT ? ST_NEED_EMIT : ST_ESCAPED) : ST_WALK;
+        if (geo_escaped(P, p.cell)) return DEPOSIT ? ST_NEED_EMIT : ST_ESCAPED;
+        if (DEPOSIT && P.count_photons) count_photon(P, geo_index(P, p.cell), photon_tag(g));
+        return ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
         if (P.any_intersect) { p.t_ach += tact; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // :184-188
@@ -674,7 +715,11 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
         if (DEPOSIT) {
 #pragma unroll
             for (int d = 0; d < NDT; d++)
-                if (d < nd && rho[d] > 0.0) unsafeAtomicAdd(&sum[base + d], tact * p.kappa[d] * p.energy);
+                if (d < nd && rho[d] > 0.0) {
+                    unsafeAtomicAdd(&sum[base + d], tact * p.kappa[d] * p.energy);
+                    if (P.n_bins && p.spec_idx >= 0)
+                        unsafeAtomicAdd(&P.sum_spec[(size_t)p.spec_idx * P.n_cells * nd + base + d], tact * p.kappa[d] * p.energy);
+                }
         }
         return ST_NEED_INTERACT;
     }
@@ -1064,7 +1109,16 @@ __device__ __forceinline__ int mrw_step(const DProblem &P, const Walls &W, Packe
         const double ct = -log(y) / P.mrw_diff[ic] * (q * q);
 #pragma unroll
         for (int d = 0; d < NDT; d++)
-            if (d < nd && P.density[base + d] > 0.0) unsafeAtomicAdd(&sum[base + d], p.energy * ct * P.mrw_kp[base + d]);
+            if (d < nd && P.density[base + d] > 0.0) {
+                const double e = p.energy * ct * P.mrw_kp[base + d];
+                unsafeAtomicAdd(&sum[base + d], e);
+                if (P.n_bins) {      // deposit_specific_energy_spectrum: grid_physics_3d.f90:367-395
+                    const int iv = P.jnu_id[base + d]; const double fr = P.jnu_frac[base + d];
+                    const double *f0 = P.jnu_bin_frac + ((size_t)d * P.nj_max + iv) * P.n_bins, *f1 = f0 + P.n_bins;
+                    for (int b = 0; b < P.n_bins; b++)
+                        unsafeAtomicAdd(&P.sum_spec[(size_t)b * P.n_cells * nd + base + d], e * ((1.0 - fr) * f0[b] + fr * f1[b]));
+                }
+            }
     }
     Angle ar;
     random_sphere_angle(g, ar);
@@ -1233,7 +1287,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     if (!ok || geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                        begin_integrate(P, p);
+                        begin_integrate_lucy(P, p, g);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 }
@@ -1258,7 +1312,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     else {
                         p.inter++;
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                        begin_integrate(P, p);
+                        begin_integrate_lucy(P, p, g);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 }
@@ -1283,7 +1337,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
                     else if (geo_escaped(P, p.cell)) st = ST_NEED_EMIT;
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                        begin_integrate(P, p);
+                        begin_integrate_lucy(P, p, g);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
                 }
@@ -1422,10 +1476,11 @@ __device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, doubl
 // Stokes-I entry in the image and SED cubes (-1 = not binned)
 __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled &G, double nu, double energy, double s0,
                                                const PeelFlags &f, double x_image, double y_image, int iv,
-                                               long long &k_img, long long &k_sed)
+                                               long long &k_img, long long &k_sed, int inu_filter = -1)
 {
     k_img = -1; k_sed = -1;
-    int inu = P.mono_which ? P.mono_inu - (G.inu_min - 1)       // image_type.f90:435-436
+    int inu = inu_filter >= 0 ? inu_filter
+            : P.mono_which ? P.mono_inu - (G.inu_min - 1)       // image_type.f90:435-436
                            : ipos0(G.log10_nu_min, G.log10_nu_max, log10(nu), G.n_nu);
     if (inu < 0 || inu >= G.n_nu) return;
     if (energy != energy || s0 != s0) return;
@@ -1452,6 +1507,38 @@ __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled 
         else ir = ipos0(G.log10_ap_min, G.log10_ap_max, lr, G.n_ap - 1) + 1;
         if (ir >= 0 && ir < G.n_ap)
             k_sed = (long long)(((((size_t)0 * G.n_orig + io) * G.n_view + iv) * G.n_ap + ir) * G.n_nu + inu);
+    }
+}
+
+// image_bin (image_type.f90:408-476) for all lanes of the wave: `live` lanes bin their packet (Stokes vector s already
+// attenuated, energy, frequency nu) at (x_image, y_image) of view iv.  With filters the packet goes into every filter
+// whose transmission at nu (linear interpolation, 0 outside the curve) is positive, with that weight (:467-475).
+// Must be called by all 64 lanes.
+__device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled &G, bool live, double nu, double energy, const double s[4],
+                                               const PeelFlags &f, double x_image, double y_image, int iv)
+{
+    const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
+    const int n_pass = G.use_filters ? G.n_nu : 1;
+    for (int pass = 0; pass < n_pass; pass++) {
+        long long k_img = -1, k_sed = -1;
+        double val[4] = {0.0, 0.0, 0.0, 0.0};
+        if (live) {
+            double tr = 1.0;
+            if (G.use_filters) {
+                const int o0 = (int)G.filt_off[pass], o1 = (int)G.filt_off[pass + 1];
+                const double *fx = G.filt_nu + o0, *ft = G.filt_tr + o0;
+                const int j = locate(fx, o1 - o0, nu);
+                tr = j < 0 ? 0.0 : ft[j] + (nu - fx[j]) / (fx[j + 1] - fx[j]) * (ft[j + 1] - ft[j]);
+            }
+            if (tr > 0.0) {
+                image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed, G.use_filters ? pass : -1);
+                val[0] = s[0] * energy; val[1] = s[1] * energy; val[2] = s[2] * energy; val[3] = s[3] * energy;
+                if (G.use_filters) { val[0] *= tr; val[1] *= tr; val[2] *= tr; val[3] *= tr; }
+            }
+        }
+        // wave-uniform from here: combine lanes that hit the same pixel / SED bin
+        if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img, stride_img, G.n_stokes, val);
+        if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed, stride_sed, G.n_stokes, val);
     }
 }
 
@@ -1494,8 +1581,8 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
     for (int ig = 0; ig < P.n_peeled; ig++) {
         const DPeeled &G = P.peeled[ig];
         for (int iv = 0; iv < G.n_view; iv++) {
-            long long k_img = -1, k_sed = -1;
-            double val[4] = {0.0, 0.0, 0.0, 0.0};
+            bool live = false;
+            double s_out[4] = {0.0, 0.0, 0.0, 0.0}, x_out = 0.0, y_out = 0.0;
             if (active) {
                 Angle a_req;
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
@@ -1564,18 +1651,11 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                         }
                         double att = exp(-tau);
                         s[0] *= att; s[1] *= att; s[2] *= att; s[3] *= att;
-                        image_bin_keys(P, G, p.nu, p.energy, s[0], f, x_image, y_image, iv, k_img, k_sed);
-                        val[0] = s[0] * p.energy; val[1] = s[1] * p.energy; val[2] = s[2] * p.energy; val[3] = s[3] * p.energy;
+                        live = true; s_out[0] = s[0]; s_out[1] = s[1]; s_out[2] = s[2]; s_out[3] = s[3]; x_out = x_image; y_out = y_image;
                     }
                 }
             }
-            // wave-uniform from here: combine lanes that hit the same pixel / SED bin
-            if (G.compute_image)
-                wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img,
-                                (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, G.n_stokes, val);
-            if (G.compute_sed)
-                wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed,
-                                (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu, G.n_stokes, val);
+            deposit_images(P, G, live, p.nu, p.energy, s_out, f, x_out, y_out, iv);
         }
     }
 }
@@ -1926,26 +2006,21 @@ template <int NDT, int GEOM>
 __device__ __forceinline__ void bin_escaped(const DProblem &P, const Packet<NDT, GEOM> &p, bool active, const PeelFlags &f)
 {
     const DPeeled &G = P.peeled[P.binned];
-    long long k_img = -1, k_sed = -1;
-    double val[4] = {0.0, 0.0, 0.0, 0.0};
+    bool live = false;
+    double x_image = 0.0, y_image = 0.0;
+    int iv = 0;
     if (active) {
         double phi = atan2(p.a.sinp, p.a.cosp);
         if (phi < 0.0) phi = phi + HYP_TWOPI;
         const int it = ipos0(-1.0, 1.0, p.a.cost, P.n_bin_theta), ip = ipos0(0.0, HYP_TWOPI, phi, P.n_bin_phi);
         if (it >= 0 && it < P.n_bin_theta && ip >= 0 && ip < P.n_bin_phi) {
-            const double x_image = p.r[1] * p.a.cosp - p.r[0] * p.a.sinp;
-            const double y_image = p.r[2] * p.a.sint - p.r[1] * p.a.cost * p.a.sinp - p.r[0] * p.a.cost * p.a.cosp;
-            image_bin_keys(P, G, p.nu, p.energy, p.s[0], f, x_image, y_image, P.n_bin_phi * it + ip, k_img, k_sed);
-#pragma unroll
-            for (int i = 0; i < 4; i++) val[i] = p.s[i] * p.energy;
+            x_image = p.r[1] * p.a.cosp - p.r[0] * p.a.sinp;
+            y_image = p.r[2] * p.a.sint - p.r[1] * p.a.cost * p.a.sinp - p.r[0] * p.a.cost * p.a.cosp;
+            iv = P.n_bin_phi * it + ip;
+            live = true;
         }
     }
-    if (G.compute_image)
-        wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img,
-                        (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, G.n_stokes, val);
-    if (G.compute_sed)
-        wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed,
-                        (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu, G.n_stokes, val);
+    deposit_images(P, G, live, p.nu, p.energy, p.s, f, x_image, y_image, iv);
 }
 
 // forced first interaction: forced_interaction.f90:23-133
@@ -2317,13 +2392,17 @@ __global__ void mrw_prepare_kernel(const DProblem *__restrict__ Pp, const double
 // update_energy_abs + check_energy_abs + sublimate_dust + update_energy_abs_tot
 // + precompute_jnu_var fused (grid_physics_3d.f90:420-629).  One thread per
 // (cell, dust) element of the cell-major arrays.  mode 0: full update from the
-// accumulators; mode 1: only clamp + jnu_var + totals (used at create time).
+// accumulators; mode 1: only clamp + jnu_var + totals (used at create time);
+// mode 2: update_energy_abs only (no sublimation: solve_pda comes in between, iter_lucy.f90:224-235);
+// mode 3: sublimate_dust from the current specific energy.  `spec` = the frequency-resolved specific
+// energy [n_bins][n_cells][n_dust], rescaled or reset where dust sublimates (:441-447,463-464,479-480).
 __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, int mode,
                               double *__restrict__ specific_energy, double *__restrict__ density,
                               const double *__restrict__ additional, int *__restrict__ jnu_id,
                               double *__restrict__ jnu_frac, double *__restrict__ energy_abs_tot,
-                              double *__restrict__ out_ref_layout)
+                              double *__restrict__ out_ref_layout, double *__restrict__ spec, int n_bins)
 {
+    const bool from_sum = mode == 0 || mode == 2, sublimate = mode == 0 || mode == 3;
     const DProblem &P = *Pp;
     const int nd = P.n_dust;
     const size_t n = (size_t)P.n_cells * nd;
@@ -2337,7 +2416,7 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
         const double vol = cell_volume(P, ic);
         const DDust &D = P.dust[d];
         double e;
-        if (mode == 0) {
+        if (from_sum) {
             e = P.sum[k] * F.scale / vol;
             if (vol == 0.0) e = 0.0;
             if (F.additional) e += additional[k];
@@ -2346,9 +2425,15 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
         }
         e = clamp_energy(D, e, F.enforce_energy_range);
         double rho = density[k];
-        if (mode == 0 && D.sublimation_mode != 0) {
+        if (sublimate && D.sublimation_mode != 0) {
             double es = D.sublimation_specific_energy;
             if (e > es) {
+                if (n_bins) {
+                    for (int b = 0; b < n_bins; b++) {
+                        double &q = spec[(size_t)b * n + k];
+                        q = D.sublimation_mode == 1 ? D.minimum_specific_energy : q * (es / e);
+                    }
+                }
                 if (D.sublimation_mode == 1) { rho = 0.0; e = D.minimum_specific_energy; }
                 else if (D.sublimation_mode == 2) {
                     double r = chi_rosseland(D, e) / chi_rosseland(D, es);

@@ -7,6 +7,13 @@ per-packet Philox streams are keyed by the global packet id, the result does not
 depend on the number of ranks (up to FP64 summation order), and because every
 rank applies ``update_energy_abs`` to the same reduced block no broadcast is
 needed.
+
+Error agreement: a device error (frequency outside the dust table, packet emitted
+outside the grid, negative t in find_wall) can hit one rank only, because it
+depends on that rank's packet ids.  The reference stops every rank through
+``error()``; here the ranks agree on a flag (one MAX all-reduce of a single int)
+before the data collective, so that nobody waits in ``all_reduce`` for a rank
+that has raised.
 """
 from __future__ import annotations
 
@@ -18,95 +25,104 @@ def shard_range(n_total, rank, world_size):
     return first, last - first
 
 
+def _try(fn, *args, **kw):
+    """Run a launch; return the exception instead of raising so that the ranks can agree on it."""
+    try:
+        fn(*args, **kw)
+    except Exception as e:
+        return e
+    return None
+
+
+def _collective(acc_getter, world_size, all_reduce, force, error=None, agree=None):
+    """Sum the accumulator block over the ranks.  `acc_getter()` returns the tensor alias of the
+    device block, or raises the engine's error; `error` is an exception the launch already raised on
+    this rank.  `agree(flag) -> max over ranks` (default: a MAX all-reduce through torch.distributed)."""
+    if world_size == 1 and all_reduce is None and not force:
+        if error is not None:
+            raise error
+        return False
+    err = error
+    acc = None
+    if err is None:
+        try:
+            acc = acc_getter()
+        except Exception as e:        # EngineError of this rank: tell the others before raising
+            err = e
+    if all_reduce is None:
+        import torch
+        import torch.distributed as dist
+        flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise err if err is not None else RuntimeError("another rank reported an engine error")
+        dist.all_reduce(acc, op=dist.ReduceOp.SUM)
+        # the engine reads the block on its own HIP stream: wait for RCCL's stream
+        torch.cuda.synchronize()
+    else:
+        if agree is not None:
+            if agree(1 if err is not None else 0):
+                raise err if err is not None else RuntimeError("another rank reported an engine error")
+        elif err is not None:
+            raise err
+        all_reduce(acc)
+    return True
+
+
 def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all_reduce=None, want_output=True,
-                           force_collective=False):
+                           force_collective=False, agree=None):
     """One Lucy iteration of `n_total` packets over `world_size` ranks.
 
     `engine` provides lucy_launch / lucy_accumulators_tensor / lucy_finish
     (hyperion_amd.Engine); `all_reduce(tensor)` sums in place across ranks
-    (``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
+    (default ``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
     first, n_local = shard_range(n_total, rank, world_size)
-    engine.lucy_launch(first, n_local, iteration)
-    if world_size == 1 and all_reduce is None and not force_collective:
+    err = _try(engine.lucy_launch, first, n_local, iteration)
+    if not _collective(engine.lucy_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree):
         engine.lucy_accumulators()           # no collective: no torch needed
-        acc = None
-    else:
-        acc = engine.lucy_accumulators_tensor()
-    if world_size > 1 or force_collective:
-        if all_reduce is None:
-            import torch
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            # the engine reads the block on its own HIP stream: wait for RCCL's stream
-            torch.cuda.synchronize()
-        else:
-            all_reduce(acc)
     out, stats = engine.lucy_finish(want_output=want_output)
     stats["n_packets"] = n_total
     return out, stats
 
 
-def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=None):
+def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=None, force_collective=False, agree=None):
     first, n_local = shard_range(n_total, rank, world_size)
-    engine.final_launch(first, n_local)
-    if world_size == 1 and all_reduce is None:
+    err = _try(engine.final_launch, first, n_local)
+    if not _collective(engine.final_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree):
         engine.final_accumulators()
-        acc = None
-    else:
-        acc = engine.final_accumulators_tensor()
-    if world_size > 1:
-        if all_reduce is None:
-            import torch
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-        else:
-            all_reduce(acc)
     res, stats = engine.final_finish()
     stats["n_packets"] = n_total
     return res, stats
 
 
-def raytracing_iteration_sharded(engine, n_sources, n_dust, rank=0, world_size=1, all_reduce=None):
+def raytracing_iteration_sharded(engine, n_sources, n_dust, rank=0, world_size=1, all_reduce=None, force_collective=False, agree=None):
     """do_raytracing (src/main/iter_raytracing.f90) sharded by packet id over the ranks.  Rank 0
     keeps the cubes of the final iteration, the others start from zero, so that ONE all-reduce of
     the image block yields final + raytraced flux on every rank."""
+    err = None
     for which, n_total in ((0, n_sources), (1, n_dust)):
         first, n_local = shard_range(n_total, rank, world_size)
-        engine.raytracing_launch(which, first, n_local, n_total, zero_first=(which == 0 and rank > 0))
-    if world_size > 1:
-        acc = engine.raytracing_accumulators_tensor()
-        if all_reduce is None:
-            import torch
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-        else:
-            all_reduce(acc)
+        err = err or _try(engine.raytracing_launch, which, first, n_local, n_total, zero_first=(which == 0 and rank > 0))
+    _collective(engine.raytracing_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree)
     res, stats = engine.raytracing_finish()
     stats["n_packets"] = n_sources + n_dust
     return res, stats
 
 
-def mono_iteration_sharded(engine, n_sources, n_dust, n_frequencies, rank=0, world_size=1, all_reduce=None):
+def mono_iteration_sharded(engine, n_sources, n_dust, n_frequencies, rank=0, world_size=1, all_reduce=None, force_collective=False,
+                           agree=None):
     """do_final_mono (src/main/iter_final_mono.f90) sharded by packet id: every rank runs its id range of every
     (part, frequency) launch into cubes it zeroed itself, then ONE all-reduce of the image block (cubes and
     counters) as after the polychromatic final iteration."""
     first_launch = True
+    err = None
     for which, n_total in ((0, n_sources), (1, n_dust)):
         first, n_local = shard_range(n_total, rank, world_size)
         for inu in range(n_frequencies):
-            engine.mono_launch(which, inu, first, n_local, n_total, zero_first=first_launch)
+            if err is None:
+                err = _try(engine.mono_launch, which, inu, first, n_local, n_total, zero_first=first_launch)
             first_launch = False
-    if world_size > 1:
-        acc = engine.mono_accumulators_tensor()
-        if all_reduce is None:
-            import torch
-            import torch.distributed as dist
-            dist.all_reduce(acc, op=dist.ReduceOp.SUM)
-            torch.cuda.synchronize()
-        else:
-            all_reduce(acc)
+    _collective(engine.mono_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree)
     res, stats = engine.mono_finish()
     stats["n_packets"] = (n_sources + n_dust) * n_frequencies
     return res, stats

@@ -24,6 +24,7 @@ EXPORTS = [
     "hyp_last_kernel_ms", "hyp_set_option", "hyp_get_option",
     "hyp_raytracing_iteration", "hyp_raytracing_launch", "hyp_raytracing_accumulators", "hyp_raytracing_finish",
     "hyp_mono_iteration", "hyp_mono_launch", "hyp_mono_accumulators", "hyp_mono_finish",
+    "hyp_get_n_photons", "hyp_get_specific_energy_spectrum", "hyp_convergence_value",
 ]
 
 
@@ -101,6 +102,9 @@ def load_library(path=None):
     L.hyp_mono_finish.argtypes = [H, C.POINTER(IterStats)]
     L.hyp_raytracing_accumulators.argtypes = [H, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.hyp_raytracing_finish.argtypes = [H, C.POINTER(IterStats)]
+    L.hyp_get_n_photons.argtypes = [H, _dp]
+    L.hyp_get_specific_energy_spectrum.argtypes = [H, _dp, _dp]
+    L.hyp_convergence_value.argtypes = [H, C.c_double, _dp, C.POINTER(C.c_int)]
     if path == LIB:
         _lib = L
     return L
@@ -258,6 +262,27 @@ class Engine:
         st = IterStats()
         self._check(self._lib.hyp_mono_finish(self._h, C.byref(st)))
         return self.peeled_results(), st.as_dict()
+
+    # -- n_photons, frequency-resolved specific energy, convergence (grid_generic.f90:40-93, grid_physics_3d.f90:637-689) --
+    def n_photons(self):
+        """n_photons of the last Lucy iteration (whole job once the block has been all-reduced), shape of one species."""
+        out = np.empty(self.shape[1:], dtype=np.float64)
+        self._check(self._lib.hyp_get_n_photons(self._h, out.ctypes.data_as(_dp)))
+        return np.rint(out).astype(np.int64)
+
+    def specific_energy_spectrum(self):
+        """(spectrum [n_bins, n_dust, cells...], bin_edges [n_bins + 1])."""
+        nb = int(self._m.desc.config.n_spectrum_bins)
+        out = np.empty((nb,) + tuple(self.shape), dtype=np.float64)
+        edges = np.empty(nb + 1, dtype=np.float64)
+        self._check(self._lib.hyp_get_specific_energy_spectrum(self._h, out.ctypes.data_as(_dp), edges.ctypes.data_as(_dp)))
+        return out, edges
+
+    def convergence_value(self, percentile):
+        """(status, value): the quantity specific_energy_converged tests, against the specific energy at the previous call."""
+        v, st = C.c_double(), C.c_int()
+        self._check(self._lib.hyp_convergence_value(self._h, float(percentile), C.byref(v), C.byref(st)))
+        return int(st.value), float(v.value)
 
     def peeled_results(self):
         out = []

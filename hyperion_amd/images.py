@@ -31,7 +31,8 @@ def finalize_peeled(peeled, raw, frequencies=None):
             if peeled.uncertainties:
                 out["images_unc"] = np.sqrt(raw["img2"]) * nu
         return out
-    norm = dnunorm(peeled)
+    # with filters the flux stays F_nu dnu: the filter already carries the normalisation (image_type.f90:644-651)
+    norm = 1.0 if getattr(peeled, "filters", None) else dnunorm(peeled)
     if "sed" in raw:
         sed = raw["sed"] / norm
         out["seds"] = np.cumsum(sed, axis=3)

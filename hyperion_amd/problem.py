@@ -142,6 +142,9 @@ class PeeledImages:
     # monochromatic mode: 1-based range of RunConfig.frequencies imaged by this group (image_type.f90:243-258)
     inu_min: int = 0
     inu_max: int = 0
+    # filter convolution (image_type.f90:173-181,285-291): list of (nu[], transmission[], nu0), replaces the n_wav bins
+    filters: Optional[list] = None
+    io_bytes: int = 8          # attr io_bytes: precision of the cubes in the .rtout (image_type.f90:325-333)
 
     def __post_init__(self):
         self.theta = _f64(np.atleast_1d(self.theta))
@@ -187,6 +190,12 @@ class RunConfig:
     convergence_percentile: float = 100.0
     output_specific_energy: str = "last"
     output_density: str = "none"
+    output_density_diff: str = "none"                  # src/grid/grid_generic.f90:114-130
+    output_n_photons: str = "none"                     # src/grid/grid_generic.f90:40-46
+    output_specific_energy_spectrum: str = "none"      # src/main/setup_rt.f90:77-104, src/grid/grid_generic.f90:71-93
+    spectrum_bin_edges: Optional[np.ndarray] = None    # table /specific_energy_spectrum_bin_edges, column nu (Hz)
+    physics_io_bytes: int = 8                          # root attr: precision of the grid datasets of the .rtout
+    copy_input: bool = False                           # root attr: copy the input into /Input instead of linking it (main.f90:133-150)
     mrw: bool = False
     mrw_gamma: float = 1.0             # src/main/setup_rt.f90:106-113
     n_inter_mrw_max: int = 1000
@@ -358,12 +367,14 @@ class Problem:
         library entry is stored as a reference to that sibling .npz file."""
         arrays = {}
         meta = {"grid_type": self.grid_type, "geometry_id": self.geometry_id,
-                "config": {k: v for k, v in self.config.__dict__.items() if k != "frequencies"}, "dust": [], "sources": [], "peeled": [],
+                "config": {k: v for k, v in self.config.__dict__.items() if k not in ("frequencies", "spectrum_bin_edges")}, "dust": [], "sources": [], "peeled": [],
                 "oct_center": list(self.oct_center), "oct_half": list(self.oct_half), "vor_box": list(self.vor_box)}
         for i, w in enumerate(self.walls):
             arrays["walls_%d" % (i + 1)] = w
         if self.config.frequencies is not None:
             arrays["config/frequencies"] = np.asarray(self.config.frequencies, dtype=float)
+        if self.config.spectrum_bin_edges is not None:
+            arrays["config/spectrum_bin_edges"] = np.asarray(self.config.spectrum_bin_edges, dtype=float)
         if self.refined is not None:
             arrays["refined"] = self.refined
         for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds"):
@@ -402,7 +413,14 @@ class Problem:
         for i, p in enumerate(self.peeled):
             m = {}
             for k, v in p.__dict__.items():
-                if isinstance(v, np.ndarray):
+                if k == "filters":
+                    if v:
+                        m["n_filters"] = len(v)
+                        for j, f in enumerate(v):
+                            arrays["peeled%d/filter%d_nu" % (i, j)] = np.asarray(f[0], dtype=float)
+                            arrays["peeled%d/filter%d_tr" % (i, j)] = np.asarray(f[1], dtype=float)
+                        m["filter_nu0"] = [float(f[2]) for f in v]
+                elif isinstance(v, np.ndarray):
                     arrays["peeled%d/%s" % (i, k)] = v
                 else:
                     m[k] = list(v) if isinstance(v, tuple) else v
@@ -448,6 +466,9 @@ class Problem:
         for i, m in enumerate(meta["peeled"]):
             kw = dict(m)
             kw.update(sub("peeled%d/" % i))
+            nf, nu0 = kw.pop("n_filters", 0), kw.pop("filter_nu0", [])
+            if nf:
+                kw["filters"] = [(kw.pop("filter%d_nu" % j), kw.pop("filter%d_tr" % j), nu0[j]) for j in range(nf)]
             for k in ("d_min", "d_max"):
                 if kw.get(k) is None:
                     kw.pop(k, None)
@@ -465,6 +486,8 @@ class Problem:
         cfg = RunConfig(**meta["config"])
         if "config/frequencies" in z.files:
             cfg.frequencies = z["config/frequencies"]
+        if "config/spectrum_bin_edges" in z.files:
+            cfg.spectrum_bin_edges = z["config/spectrum_bin_edges"]
         walls = [z[k] for k in ("walls_1", "walls_2", "walls_3") if k in z.files]
         return cls(walls=walls, density=z["density"],
                    dust=dust, sources=sources, config=cfg, peeled=peeled,

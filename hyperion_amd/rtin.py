@@ -18,6 +18,16 @@ def _s(v):
     return str(v)
 
 
+def _version_tuple(v):
+    out = []
+    for part in v.strip().split("."):
+        digits = "".join(ch for ch in part if ch.isdigit())
+        if digits == "" or not part[0].isdigit():
+            break
+        out.append(int(digits))
+    return tuple(out)
+
+
 def _b(v):
     s = _s(v).strip().lower()
     if s in ("yes", "y", "true"):
@@ -64,6 +74,9 @@ def read_rtin(path):
     with h5py.File(path, "r") as f:
         a = f.attrs
         cfg = RunConfig()
+        # src/main/setup_rt.f90:38-45
+        if "python_version" not in a or _version_tuple(_s(a["python_version"])) < (0, 8, 7):
+            raise ValueError("cannot read files made with the Python module before version 0.8.7")
         cfg.seed = int(a["seed"]) if "seed" in a else -124902
         cfg.n_inter_max = int(a["n_inter_max"])
         cfg.n_reabs_max = int(a["n_reabs_max"])
@@ -106,9 +119,27 @@ def read_rtin(path):
                 cfg.convergence_absolute = float(a["convergence_absolute"])
                 cfg.convergence_relative = float(a["convergence_relative"])
                 cfg.convergence_percentile = float(a["convergence_percentile"])
+        # src/main/setup_rt.f90:77-104,247-283: every /Output switch is one of all / last / none
         out = f["Output"].attrs
-        cfg.output_specific_energy = _s(out["output_specific_energy"]).strip()
-        cfg.output_density = _s(out["output_density"]).strip()
+        for key in ("output_density", "output_density_diff", "output_specific_energy", "output_n_photons"):
+            v = _s(out[key]).strip()
+            if v not in ("all", "last", "none"):
+                raise ValueError("%s should be one of all/last/none" % key)
+            setattr(cfg, key, v)
+        if "output_specific_energy_spectrum" in out:
+            cfg.output_specific_energy_spectrum = _s(out["output_specific_energy_spectrum"]).strip()
+            if cfg.output_specific_energy_spectrum not in ("all", "last", "none"):
+                raise ValueError("output_specific_energy_spectrum should be one of all/last/none")
+        if cfg.output_specific_energy_spectrum != "none":
+            if "specific_energy_spectrum_bin_edges" not in f:
+                raise ValueError("specific_energy_spectrum_bin_edges should be present in the input when "
+                                 "output_specific_energy_spectrum is enabled")
+            cfg.spectrum_bin_edges = np.asarray(f["specific_energy_spectrum_bin_edges"][...]["nu"], dtype=float)
+        # src/main/setup_rt.f90:207-215, src/main/main.f90:133-150
+        cfg.physics_io_bytes = int(a["physics_io_bytes"]) if "physics_io_bytes" in a else 8
+        if cfg.physics_io_bytes not in (4, 8):
+            raise ValueError("unexpected value of physics_io_bytes (should be 4 or 8)")
+        cfg.copy_input = _b(a["copy_input"]) if "copy_input" in a else False
 
         geo = f["Grid/Geometry"]
         grid_type = _s(geo.attrs["grid_type"]).strip()
@@ -159,6 +190,11 @@ def read_rtin(path):
         else:
             density = q["density"][...]
             spec = q["specific_energy"][...] if "specific_energy" in q else None
+            # read_grid_4d (src/grid/grid_io.f90:78-81): the dataset must belong to this geometry
+            for name in ("density", "specific_energy"):
+                if name in q and "geometry" in q[name].attrs and "geometry" in geo.attrs \
+                        and _s(q[name].attrs["geometry"]).strip() != _s(geo.attrs["geometry"]).strip():
+                    raise ValueError("geometry IDs do not match for %s" % name)
         n_dust = density.shape[0]
         mse = np.zeros(n_dust)
         if "minimum_specific_energy" in q.attrs:
@@ -251,8 +287,28 @@ def read_rtin(path):
                     p.peeloff_origin = tuple(float(pa["observer_" + k]) for k in "xyz")
                 else:
                     p.peeloff_origin = tuple(float(pa["peeloff_" + k]) for k in "xyz")
-            p.n_wav = int(pa["n_wav"])
-            if cfg.monochromatic:       # image_type.f90:243-258
+            use_filters = _b(pa["use_filters"]) if "use_filters" in pa else False
+            if use_filters:             # image_type.f90:173-181,285-291
+                if cfg.monochromatic:
+                    raise ValueError("cannot use filters in monochromatic mode")
+                if cfg.raytracing and not binned:      # images_peeled.f90:349-351
+                    raise ValueError("filter convolution cannot be used with raytracing")
+                p.filters = []
+                for i in range(1, int(pa["n_filt"]) + 1):
+                    fg = g["filter_%05d" % i]
+                    tab = fg[...]
+                    p.filters.append((np.asarray(tab["nu"], dtype=float), np.asarray(tab["tn"], dtype=float), float(fg.attrs["nu0"])))
+                p.n_wav = len(p.filters)
+            else:
+                p.n_wav = int(pa["n_wav"])
+            if p.n_wav < 1:
+                raise ValueError("n_nu should be >= 1")
+            p.io_bytes = int(pa["io_bytes"]) if "io_bytes" in pa else 8
+            if p.io_bytes not in (4, 8):
+                raise ValueError("unexpected value of io_bytes (should be 4 or 8)")
+            if use_filters:
+                pass
+            elif cfg.monochromatic:       # image_type.f90:243-258
                 p.inu_min, p.inu_max = int(pa["inu_min"]), int(pa["inu_max"])
             else:
                 p.wav_min, p.wav_max = float(pa["wav_min"]), float(pa["wav_max"])

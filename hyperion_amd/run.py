@@ -28,40 +28,25 @@ from .problem import Problem
 FORTRAN_VERSION = "1.0.0"      # src/main/main.f90 `fortran_version`
 
 
-def quantile(values, percent):
-    """fortranlib lib_statistics `quantile` (source absent): nearest-rank element
-    of the sorted sample at fraction percent/100."""
-    v = np.sort(np.asarray(values, dtype=np.float64).ravel())
-    if v.size == 0:
-        return 0.0
-    ipos = int(round(percent / 100.0 * (v.size - 1)))
-    return float(v[min(max(ipos, 0), v.size - 1)])
-
-
 class ConvergenceCheck:
-    """specific_energy_converged: src/grid/grid_physics_3d.f90:637-689."""
+    """specific_energy_converged: src/grid/grid_physics_3d.f90:637-689.  The tested value -- the `percentile`
+    quantile of max(a/b, b/a) between two iterations -- is computed on the device (``hyp_convergence_value``;
+    fortranlib's ``quantile`` restated as the element of rank nint(percentile/100 (n-1)) of the sorted sample);
+    this class only keeps the history and applies the two thresholds."""
 
     def __init__(self, absolute, relative, percentile, log=None):
         self.absolute, self.relative, self.percentile = absolute, relative, percentile
-        self.prev = None
         self.value_prev = np.inf
         self.log = log or (lambda *a: None)
         self.value = None
 
-    def __call__(self, se):
-        if self.prev is None:
-            self.prev = se.copy()
+    def __call__(self, engine):
+        status, value = engine.convergence_value(self.percentile)
+        if status == 3:          # first iteration: nothing to compare with
             return False
-        prev = self.prev
-        if np.all(prev == se):
-            value = 0.0
-        elif np.all((prev == se) | (prev == 0) | (se == 0)):
+        if status == 2:
             self.log(" [specific_energy_converged] could not check for convergence, as the only cells that changed had zero value before or after")
             return False
-        else:
-            m = (prev > 0) & (se > 0) & (prev != se)
-            a, b = prev[m], se[m]
-            value = quantile(np.maximum(a / b, b / a), self.percentile)
         self.value = value
         if self.value_prev < np.inf:
             if value == 0.0:
@@ -71,7 +56,6 @@ class ConvergenceCheck:
                 converged = value < self.absolute and abs(ratio) < self.relative
         else:
             converged = False
-        self.prev = se.copy()
         self.value_prev = value
         return converged
 
@@ -83,6 +67,10 @@ class IterationRecord:
     killed_int: int
     specific_energy: Optional[np.ndarray] = None
     density: Optional[np.ndarray] = None
+    density_diff: Optional[np.ndarray] = None
+    n_photons: Optional[np.ndarray] = None
+    specific_energy_spectrum: Optional[np.ndarray] = None
+    spectrum_bin_edges: Optional[np.ndarray] = None
     stats: dict = field(default_factory=dict)
     seconds: float = 0.0
 
@@ -111,9 +99,6 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
     """The iteration sequence of ``program main`` (src/main/main.f90:167-344)."""
     log = log or (lambda *a: None)
     cfg = problem.config
-    for flag, name in ((cfg.pda, "PDA"),):
-        if flag:
-            raise EngineError("%s is not supported by the MI355X engine yet" % name)
     date_started = _now()
     t0 = time.time()
     eng = Engine(problem, device=device)
@@ -132,15 +117,22 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
         se, st = lucy_iteration_sharded(eng, cfg.n_initial_photons, it, rank, world_size)
         log(" [main] exiting Lucy iteration")
         if check is not None:
-            converged = check(se)
+            converged = check(eng)
             if converged:
                 log("      ------ Specific energy calculation converged -----")
         last = it if (check is not None and converged) else n_iter
         rec = IterationRecord(it, st["killed_geo"], st["killed_int"], stats=st, seconds=time.time() - ti)
         if _want(cfg.output_specific_energy, it, last):
             rec.specific_energy = se
+        # output_grid: src/grid/grid_generic.f90:29-130
         if _want(cfg.output_density, it, last):
             rec.density = eng.density()
+        if _want(cfg.output_density_diff, it, last):
+            rec.density_diff = eng.density() - np.asarray(problem.density, dtype=np.float64).reshape(eng.shape)
+        if _want(cfg.output_n_photons, it, last):
+            rec.n_photons = eng.n_photons()
+        if _want(cfg.output_specific_energy_spectrum, it, last):
+            rec.specific_energy_spectrum, rec.spectrum_bin_edges = eng.specific_energy_spectrum()
         records.append(rec)
         if check is not None and converged:
             n_done = it
@@ -201,24 +193,41 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
             else:
                 f["Input"] = h5py.ExternalLink(os.path.abspath(input_path), "/")
         geo = b(problem.geometry_id)
+        # physics_io_type (setup_rt.f90:207-215): precision of the grid datasets; n_photons stays integer
+        ptype = np.float32 if problem.config.physics_io_bytes == 4 else np.float64
         for rec in result.iterations:
             g = f.create_group("iteration_%05d" % rec.index)
             g.attrs["killed_photons_geo"] = np.int32(rec.killed_geo)
             g.attrs["killed_photons_int"] = np.int32(rec.killed_int)
-            for name in ("specific_energy", "density"):
+            if rec.specific_energy_spectrum is not None:       # grid_generic.f90:71-93
+                g.create_dataset("specific_energy_spectrum_bin_edges", data=np.asarray(rec.spectrum_bin_edges, dtype=np.float64))
+            for name in ("n_photons", "specific_energy", "specific_energy_spectrum", "density", "density_diff"):
                 a = getattr(rec, name)
                 if a is None:
+                    continue
+                if name == "n_photons":
+                    a = np.asarray(a, dtype=np.int64)[None]          # one plane, written like a species axis of length 1
+                else:
+                    a = np.asarray(a).astype(ptype)
+                if name == "specific_energy_spectrum" and problem.grid_type != "amr":
+                    d = g.create_dataset(name, data=a, compression="gzip")     # (n_bins, n_dust, cells...)
+                    d.attrs["geometry"] = geo
+                    continue
+                if name == "n_photons" and problem.grid_type != "amr":
+                    d = g.create_dataset(name, data=a[0], compression="gzip")  # write_grid_3d: (cells...)
+                    d.attrs["geometry"] = geo
                     continue
                 if problem.grid_type == "amr":
                     # write_grid_4d for AMR (src/grid/grid_io_amr_template.f90): one (n_dust, n3, n2, n1)
                     # dataset per level_NNNNN/grid_NNNNN group
-                    a = np.asarray(a).reshape(problem.n_dust, -1)
+                    lead = a.shape[:-1] if name != "n_photons" else ()
+                    a = np.asarray(a).reshape(-1, a.shape[-1])
                     start, count = 0, {}
                     for lev, n in zip(problem.amr_level, problem.amr_n):
                         count[int(lev)] = count.get(int(lev), 0) + 1
                         nc = int(n[0]) * int(n[1]) * int(n[2])
                         gg = g.require_group("level_%05d/grid_%05d" % (int(lev), count[int(lev)]))
-                        gg.create_dataset(name, data=a[:, start:start + nc].reshape(problem.n_dust, n[2], n[1], n[0]), compression="gzip")
+                        gg.create_dataset(name, data=a[:, start:start + nc].reshape(tuple(lead) + (n[2], n[1], n[0])), compression="gzip")
                         start += nc
                 else:
                     d = g.create_dataset(name, data=a, compression="gzip")
@@ -236,8 +245,9 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                                     ("images", {"xmin": pl.x_min, "xmax": pl.x_max, "ymin": pl.y_min, "ymax": pl.y_max})):
                     if name not in cubes:
                         continue
-                    d = g.create_dataset(name, data=cubes[name], compression="gzip")
-                    if not problem.config.monochromatic:     # image_type.f90:701-706
+                    itype = np.float32 if pl.io_bytes == 4 else np.float64      # image_type.f90:690-700
+                    d = g.create_dataset(name, data=np.asarray(cubes[name]).astype(itype), compression="gzip")
+                    if not problem.config.monochromatic and not pl.filters:     # image_type.f90:701-706
                         d.attrs["numin"] = np.float64(pl.nu_min)
                         d.attrs["numax"] = np.float64(pl.nu_max)
                     for k, v in extra.items():
@@ -249,7 +259,11 @@ def write_rtout(path, problem: Problem, result: RunResult, input_path=None, copy
                     elif pl.track_origin == "scatterings":
                         d.attrs["track_n_scat"] = np.int32(pl.track_n_scat)
                     if name + "_unc" in cubes:
-                        g.create_dataset(name + "_unc", data=cubes[name + "_unc"], compression="gzip")
+                        g.create_dataset(name + "_unc", data=np.asarray(cubes[name + "_unc"]).astype(itype), compression="gzip")
+                if pl.filters:      # image_type.f90:773-777
+                    g.attrs["use_filters"] = b("yes")
+                    g.attrs["n_filt"] = np.int32(len(pl.filters))
+                    g.create_dataset("filt_nu0", data=np.array([f_[2] for f_ in pl.filters], dtype=np.float64))
                 if problem.config.monochromatic:     # image_type.f90:781-784
                     nu = np.asarray(problem.config.frequencies, dtype=float)[pl.inu_min - 1:pl.inu_max]
                     g.create_dataset("frequencies", data=np.array(list(zip(nu)), dtype=[("nu", "<f8")]))
@@ -301,22 +315,29 @@ def write_npz_output(path, problem, result):
 
 def run(input_file, output_file=None, overwrite=False, logfile=None, device=None, engine_options=None):
     """``Model.run()`` counterpart: ``.rtin`` (or a Problem ``.npz``) in,
-    ``.rtout`` (or ``.npz``) out.  Returns the output path."""
+    ``.rtout`` (or ``.npz``) out.  Returns the output path.
+
+    Under ``torch.distributed.run`` every rank computes its share of the packets; only rank 0 touches the output
+    file and the log (the reference's ``main_process()``), the others wait at a barrier until it is written, and
+    all ranks leave with rank 0's status."""
     if output_file is None:
         output_file = input_file.replace(".rtin", ".rtout") if ".rtin" in input_file else input_file + ".rtout"
-    if os.path.exists(output_file):
-        if not overwrite:
-            raise SystemExit("Output file %s already exists (use -f / overwrite=True)" % output_file)
-        os.remove(output_file)
-    flog = open(logfile, "w") if logfile else None
-
-    def log(*a):
-        print(*a, file=flog or sys.stdout, flush=True)
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    main_process = rank == 0
+    if main_process and os.path.exists(output_file):
+        if not overwrite:
+            raise SystemExit("Output file %s already exists (use -f / overwrite=True)" % output_file)
+        os.remove(output_file)
+    flog = open(logfile, "w") if (logfile and main_process) else None
+
+    def log(*a):
+        if main_process:
+            print(*a, file=flog or sys.stdout, flush=True)
+
     dist = None
+    failed = None
     try:
         if world > 1:
             import torch
@@ -324,32 +345,44 @@ def run(input_file, output_file=None, overwrite=False, logfile=None, device=None
             torch.cuda.set_device(local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", rank=rank, world_size=world)
-        if input_file.endswith(".npz"):
-            problem = Problem.from_npz(input_file)
-        else:
-            from .rtin import read_rtin
-            problem = read_rtin(input_file)
-        log(" " + "-" * 60)
-        log(" Hyperion-AMD (C-ABI v1) on device %d, rank %d of %d" % (local_rank if device is None else device, rank, world))
-        log(" Input:  %s" % input_file)
-        log(" Output: %s" % output_file)
-        log(" " + "-" * 60)
-        result = run_problem(problem, device=local_rank if device is None else device, rank=rank, world_size=world,
-                             log=log, engine_options=engine_options)
-        if rank == 0:
-            if output_file.endswith(".npz"):
-                write_npz_output(output_file, problem, result)
+        try:
+            if input_file.endswith(".npz"):
+                problem = Problem.from_npz(input_file)
             else:
-                write_rtout(output_file, problem, result, input_path=None if input_file.endswith(".npz") else input_file)
-        log(" Total CPU time elapsed: %16.2f" % result.cpu_time)
-    except (EngineError, NotImplementedError, ValueError) as e:
-        print(" ERROR: %s" % e, file=flog or sys.stderr, flush=True)
-        raise SystemExit("An error occurred, and the run did not complete")
+                from .rtin import read_rtin
+                problem = read_rtin(input_file)
+            log(" " + "-" * 60)
+            log(" Hyperion-AMD (C-ABI v2) on device %d, rank %d of %d" % (local_rank if device is None else device, rank, world))
+            log(" Input:  %s" % input_file)
+            log(" Output: %s" % output_file)
+            log(" " + "-" * 60)
+            result = run_problem(problem, device=local_rank if device is None else device, rank=rank, world_size=world,
+                                 log=log, engine_options=engine_options)
+            if main_process:
+                if output_file.endswith(".npz"):
+                    write_npz_output(output_file, problem, result)
+                else:
+                    write_rtout(output_file, problem, result, input_path=None if input_file.endswith(".npz") else input_file,
+                                copy_input=problem.config.copy_input)
+            log(" Total CPU time elapsed: %16.2f" % result.cpu_time)
+        except (EngineError, NotImplementedError, ValueError, KeyError, OSError, RuntimeError) as e:
+            # the reference's error(): message to the log, no date_ended in the output
+            failed = e
+            print(" ERROR: %s" % e, file=flog or sys.stderr, flush=True)
+        if dist is not None:
+            # nobody leaves before rank 0 has written the file; everybody leaves with the worst status
+            import torch
+            flag = torch.tensor([1 if failed is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()) and failed is None:
+                failed = RuntimeError("another rank failed")
     finally:
         if dist is not None and dist.is_initialized():
             dist.destroy_process_group()
         if flog:
             flog.close()
+    if failed is not None:
+        raise SystemExit("An error occurred, and the run did not complete")
     return output_file
 
 
@@ -374,8 +407,8 @@ def main(argv=None):
         except SystemExit as e:
             print(e, file=sys.stderr)
             rc = 1
-    # scripts/hyperion:98-104: success == the output carries date_ended
-    if rc == 0 and not a.output.endswith(".npz"):
+    # scripts/hyperion:98-104: success == the output carries date_ended (checked by the process that wrote it)
+    if rc == 0 and not a.output.endswith(".npz") and int(os.environ.get("RANK", "0")) == 0:
         try:
             import h5py
             with h5py.File(a.output, "r") as f:

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define HYP_MAX_DUST 8
-#define HYP_ABI_VERSION 1
+#define HYP_ABI_VERSION 2
 
 /* /Dust/dust_NNN of the .rtin -- src/dust/dust_type_4elem.f90:78-293 */
 typedef struct hyp_dust_desc {
@@ -154,6 +154,19 @@ typedef struct hyp_config {
     const double *frequencies;      /* [n_frequencies] table /frequencies, column nu (setup_rt.f90:220-222) */
     int32_t n_frequencies;
     int32_t reserved2;
+    /* partial diffusion approximation (root attr `pda`): solve_pda after update_energy_abs, src/grid/grid_pda_3d.f90:84-172;
+     * Cartesian, spherical and cylindrical grids (the others are built with grid_pda_disabled.f90: nothing to do) */
+    int32_t pda;
+    /* keep n_photons(cell), the number of packets that entered each cell in a Lucy iteration
+     * (src/grid/grid_propagate_3d.f90:88-93,171-176): allocated with pda or /Output output_n_photons != 'none'
+     * (src/grid/grid_physics_3d.f90:307-318) */
+    int32_t count_photons;
+    /* frequency-resolved specific energy (/Output output_specific_energy_spectrum != 'none', src/main/setup_rt.f90:77-104):
+     * n_spectrum_bins bins with edges spectrum_bin_edges[n_spectrum_bins + 1] (Hz, strictly increasing; table
+     * /specific_energy_spectrum_bin_edges column nu); 0 = off */
+    int32_t n_spectrum_bins;
+    int32_t reserved3;
+    const double *spectrum_bin_edges;
 } hyp_config;
 
 /* /Output/Peeled/group_NNNNN -- src/images/images_peeled.f90:272-380,
@@ -181,6 +194,15 @@ typedef struct hyp_peeled_desc {
     const double *phi;       /* [n_view] deg */
     int32_t inu_min, inu_max; /* monochromatic: attrs inu_min, inu_max (1-based range of config.frequencies, image_type.f90:243-258);
                                  n_nu = inu_max - inu_min + 1 */
+    /* filter convolution (attrs use_filters, n_filt and groups filter_NNNNN with tables nu, tn and attr nu0,
+     * src/images/image_type.f90:173-181,285-291): n_nu = n_filt planes, a packet is binned into every filter whose
+     * transmission at its frequency is positive with that weight (image_bin :467-475); not with raytracing or
+     * monochromatic mode */
+    int32_t use_filters;
+    int32_t reserved_f;
+    const int32_t *filt_n;   /* [n_nu] points of each filter curve */
+    const double *filt_nu;   /* concatenated, increasing within a filter */
+    const double *filt_tr;   /* concatenated transmissions (column tn) */
 } hyp_peeled_desc;
 
 typedef struct hyp_problem {
@@ -288,6 +310,18 @@ int  hyp_mono_finish(hyp_handle h, hyp_iter_stats *stats);
 int  hyp_get_specific_energy(hyp_handle h, double *out);
 int  hyp_get_density(hyp_handle h, double *out);
 int  hyp_set_specific_energy(hyp_handle h, const double *in);
+
+/* n_photons of the last Lucy iteration (src/grid/grid_physics_3d.f90:38, output_grid src/grid/grid_generic.f90:40-46):
+ * [n_cells] as doubles, whole-job counts once the accumulator block has been all-reduced; needs config.count_photons
+ * or config.pda.  Call after hyp_lucy_accumulators / hyp_lucy_finish. */
+int  hyp_get_n_photons(hyp_handle h, double *out);
+/* frequency-resolved specific energy (src/grid/grid_generic.f90:71-93): out [n_bins][n_dust][n_cells] (may be NULL),
+ * bin_edges_out [n_bins + 1] (may be NULL); needs config.n_spectrum_bins > 0 */
+int  hyp_get_specific_energy_spectrum(hyp_handle h, double *out, double *bin_edges_out);
+/* specific_energy_converged (src/grid/grid_physics_3d.f90:637-689): the `percentile` quantile of max(a/b, b/a)
+ * between the specific energy at the previous call and the current one, computed on the device.  status: 0 value
+ * computed, 1 nothing changed (value 0), 2 "could not check for convergence" (only zero cells changed), 3 first call */
+int  hyp_convergence_value(hyp_handle h, double percentile, double *value, int *status);
 
 /* measurement hooks for bench.py: duration (ms, HIP events on the engine's
  * stream) of the last propagation kernel and of the last finish step. */

@@ -385,6 +385,8 @@ typedef struct {
     double *theta, *phi;
     angle_t *view;          /* [n_view] */
     int n_orig, n_stokes;
+    int *filt_off;          /* filters: offsets into d.filt_nu / d.filt_tr, [n_nu + 1] */
+    double *filt_nu, *filt_tr;
     double log10_nu_min, log10_nu_max, log10_ap_min, log10_ap_max;
     double *sed, *sed2, *img, *img2;
     size_t sed_size, img_size;
@@ -459,6 +461,15 @@ struct orc_state {
     int32_t *jnu_var_id;        /* [n_dust][n_cells] */
     double *jnu_var_frac;
     double energy_abs_tot[ORC_MAX_DUST];
+    /* n_photons (grid_physics_3d.f90:307-318): packets that entered each cell in the current Lucy iteration */
+    int64_t *n_photons;
+    /* frequency-resolved specific energy (grid_physics_3d.f90:41-56,111-282): [n_bins][n_dust][n_cells] */
+    int n_bins;
+    double *nu_edges, *log_nu_edges;
+    double *spec, *spec_sum, *spec_add;
+    double *jnu_bin_frac;       /* [n_dust][nj_max][n_bins] setup_j_nu_bin_fractions :326-348 */
+    int nj_max;
+    int pda_last_cells, pda_last_outer;   /* diagnostics of the last solve_pda */
     /* pending accumulate totals */
     orc_iter_stats pending;
     int fatal;                  /* set by update_optconsts range error */
@@ -632,6 +643,13 @@ static double chi_rosseland(const dust_t *d, double e)
     return interp1d_loglog(d->mo_e, d->mo_chi_ross, d->n_e, e);
 }
 
+/* scale_specific_energy_spectrum: grid_physics_3d.f90:350-365 */
+static void scale_spectrum(orc_state *st, size_t ic, int d, double factor)
+{
+    if (!st->n_bins) return;
+    for (int b = 0; b < st->n_bins; b++) st->spec[((size_t)b * st->n_dust + d) * st->n_cells + ic] *= factor;
+}
+
 static void sublimate_dust(orc_state *st)
 {
     for (int d = 0; d < st->n_dust; d++) {
@@ -642,18 +660,22 @@ static void sublimate_dust(orc_state *st)
         switch (du->sublimation_mode) {
         case 1:
             for (size_t ic = 0; ic < st->n_cells; ic++)
-                if (e[ic] > es) { rho[ic] = 0.0; e[ic] = du->minimum_specific_energy; }
+                if (e[ic] > es) {
+                    rho[ic] = 0.0; e[ic] = du->minimum_specific_energy;
+                    for (int b = 0; b < st->n_bins; b++) st->spec[((size_t)b * st->n_dust + d) * st->n_cells + ic] = du->minimum_specific_energy;   /* :441-447 */
+                }
             break;
         case 2:
             for (size_t ic = 0; ic < st->n_cells; ic++)
                 if (e[ic] > es) {
                     double r = chi_rosseland(du, e[ic]) / chi_rosseland(du, es);
                     rho[ic] = rho[ic] * es / e[ic] * r * r;
+                    scale_spectrum(st, ic, d, es / e[ic]);      /* :463-464 */
                     e[ic] = es;
                 }
             break;
         case 3:
-            for (size_t ic = 0; ic < st->n_cells; ic++) if (e[ic] > es) e[ic] = es;
+            for (size_t ic = 0; ic < st->n_cells; ic++) if (e[ic] > es) { scale_spectrum(st, ic, d, es / e[ic]); e[ic] = es; }
             break;
         default: break;
         }
@@ -672,12 +694,252 @@ static void update_energy_abs(orc_state *st, double scale)
             if (st->volume[ic] == 0.0) e[ic] = 0.0;
         }
     }
+    if (st->n_bins) {        /* :517-524 */
+        for (int b = 0; b < st->n_bins; b++)
+            for (int d = 0; d < st->n_dust; d++)
+                for (size_t ic = 0; ic < st->n_cells; ic++) {
+                    size_t k = ((size_t)b * st->n_dust + d) * st->n_cells + ic;
+                    st->spec[k] = st->spec_sum[k] * scale / st->volume[ic];
+                    if (st->volume[ic] == 0.0) st->spec[k] = 0.0;
+                }
+    }
     if (st->cfg.specific_energy_type == 1 && st->specific_energy_add) {
         size_t n = (size_t)st->n_dust * st->n_cells;
         for (size_t k = 0; k < n; k++) st->specific_energy[k] += st->specific_energy_add[k];
+        if (st->n_bins && st->spec_add)      /* :543-545 */
+            for (size_t k = 0; k < n * st->n_bins; k++) st->spec[k] += st->spec_add[k];
     }
     update_energy_abs_tot(st);
     check_energy_abs(st);
+}
+
+/* ------------------------------------------------------------------ */
+/* Partial diffusion approximation: src/grid/grid_pda_3d.f90 with       */
+/* grid_pda_{cartesian,spherical,cylindrical}_3d.f90                    */
+/* ------------------------------------------------------------------ */
+
+static double kappa_planck(const dust_t *d, double e) { return interp1d_loglog(d->mo_e, d->mo_kappa_planck, d->n_e, e); }
+static inline size_t cell_index(const orc_state *st, const int ic[3]);
+
+/* cell_width: grid_geometry_cartesian_3d.f90:49-61, _spherical_3d.f90:60-72, _cylindrical_3d.f90:60-72 */
+static double pda_cell_width(const orc_state *st, const int i[3], int dir)
+{
+    const double *w1 = st->w[0], *w2 = st->w[1], *w3 = st->w[2];
+    if (st->grid_type == GRID_CAR) return st->w[dir][i[dir] + 1] - st->w[dir][i[dir]];
+    /* cell centre in the first coordinate: half the outer wall if the inner one is 0, geometric mean otherwise */
+    const double rc = w1[i[0]] == 0.0 ? w1[i[0] + 1] / 2.0 : pow(10.0, (log10(w1[i[0]]) + log10(w1[i[0] + 1])) / 2.0);
+    if (st->grid_type == GRID_SPH) {
+        if (dir == 0) return w1[i[0] + 1] - w1[i[0]];
+        if (dir == 1) return rc * (w2[i[1] + 1] - w2[i[1]]);
+        return rc * sin((w2[i[1]] + w2[i[1] + 1]) / 2.0) * (w3[i[2] + 1] - w3[i[2]]);
+    }
+    if (dir == 0) return w1[i[0] + 1] - w1[i[0]];
+    if (dir == 1) return w2[i[1] + 1] - w2[i[1]];
+    return rc * (w3[i[2] + 1] - w3[i[2]]);
+}
+
+/* geometrical_factor: grid_pda_*_3d.f90 (wall = 0..5: lower / upper wall of directions 1, 2, 3) */
+static double pda_geom_factor(const orc_state *st, int wall, const int i[3])
+{
+    const double *w1 = st->w[0], *w2 = st->w[1];
+    if (st->grid_type == GRID_CYL) {
+        if (wall == 0) return 2.0 * w1[i[0]] / (w1[i[0]] + w1[i[0] + 1]);
+        if (wall == 1) return 2.0 * w1[i[0] + 1] / (w1[i[0]] + w1[i[0] + 1]);
+    } else if (st->grid_type == GRID_SPH) {
+        const double sw = w1[i[0]] + w1[i[0] + 1];
+        if (wall == 0) return 4.0 * (w1[i[0]] * w1[i[0]]) / (sw * sw);
+        if (wall == 1) return 4.0 * (w1[i[0] + 1] * w1[i[0] + 1]) / (sw * sw);
+        if (wall == 2) return 2.0 * sin(w2[i[1]]) / (sin(w2[i[1]]) + sin(w2[i[1] + 1]));
+        if (wall == 3) return 2.0 * sin(w2[i[1] + 1]) / (sin(w2[i[1]]) + sin(w2[i[1] + 1]));
+    }
+    return 1.0;
+}
+
+static void pda_neighbour(const orc_state *st, const int i[3], int wall, int j[3])      /* next_cell_int */
+{
+    j[0] = i[0]; j[1] = i[1]; j[2] = i[2];
+    const int dir = wall >> 1;
+    j[dir] += (wall & 1) ? 1 : -1;
+    if (dir == 2 && st->grid_type != GRID_CAR) { if (j[2] < 0) j[2] = st->n3 - 1; if (j[2] >= st->n3) j[2] = 0; }   /* phi is periodic */
+}
+
+static double pda_dtau_rosseland(const orc_state *st, const int i[3], int dir)
+{
+    const size_t ic = cell_index(st, i);
+    double t = 0.0;
+    for (int d = 0; d < st->n_dust; d++) {
+        const size_t k = (size_t)d * st->n_cells + ic;
+        t += st->density[k] * chi_rosseland(&st->dust[d], st->specific_energy[k]) * pda_cell_width(st, i, dir);
+    }
+    return t;
+}
+
+static double pda_e_mean(const orc_state *st, size_t ic)       /* update_e_mean :72-82 */
+{
+    double sr = 0.0, e = 0.0;
+    for (int d = 0; d < st->n_dust; d++) sr += st->density[(size_t)d * st->n_cells + ic];
+    if (!(sr > 0.0)) return 0.0;
+    for (int d = 0; d < st->n_dust; d++) {
+        const size_t k = (size_t)d * st->n_cells + ic;
+        e += st->density[k] * st->specific_energy[k] / kappa_planck(&st->dust[d], st->specific_energy[k]);
+    }
+    return e / sr;
+}
+
+static void pda_update_specific_energy(orc_state *st, size_t ic, double e_mean)    /* update_specific_energy :36-70 */
+{
+    for (int d = 0; d < st->n_dust; d++) {
+        const dust_t *du = &st->dust[d];
+        const size_t k = (size_t)d * st->n_cells + ic;
+        double s = st->specific_energy[k];
+        const double s_old = s, smin = du->mo_e[0], smax = du->mo_e[du->n_e - 1];
+        if (e_mean < smin / kappa_planck(du, smin)) s = smin;
+        else if (e_mean > smax / kappa_planck(du, smax)) s = smax;
+        else {
+            for (;;) {
+                const double s_prev = s;
+                s = e_mean * kappa_planck(du, s);
+                const double a = s / s_prev, b = s_prev / s;
+                if ((a > b ? a : b) - 1.0 < 1.e-5) break;
+                if (s != s) break;          /* NaN guard: the reference would loop for ever */
+            }
+        }
+        st->specific_energy[k] = s;
+        if (s_old > 0.0) scale_spectrum(st, ic, d, s / s_old);
+    }
+}
+
+/* solve_pda :84-172.  The Gauss pivot branch (< 10 000 cells, lineq_gausselim of fortranlib, source absent) solves the
+ * linear system  sum_walls c_w (e_next - e_curr) = 0  of the PDA cells exactly; it is restated as Gaussian elimination
+ * with partial pivoting on the matrix with one ROW per cell's equation (the reference stores a(id_next, id_curr), i.e.
+ * the equation of id_curr in COLUMN id_curr of a column-major array: its solver works on that transposed storage). */
+static int solve_pda(orc_state *st)
+{
+    st->pda_last_cells = 0; st->pda_last_outer = 0;
+    if (!GRID_IS_3IDX(st->grid_type)) return 0;          /* grid_pda_disabled.f90: do_pda = .false. */
+    if (!st->n_photons) return 0;
+    const size_t nc = st->n_cells;
+    int64_t tot = 0;
+    for (size_t ic = 0; ic < nc; ic++) tot += st->n_photons[ic];
+    const double mean_n = (double)(tot / (int64_t)nc);    /* integer division, :99 */
+    double thr_d = ceil(0.005 * mean_n); if (thr_d < 30.0) thr_d = 30.0;
+    const int64_t thr = (int64_t)thr_d;
+    uint8_t *do_pda = calloc(nc, 1);
+    for (size_t ic = 0; ic < nc; ic++) {
+        double sr = 0.0;
+        for (int d = 0; d < st->n_dust; d++) sr += st->density[(size_t)d * nc + ic];
+        do_pda[ic] = st->n_photons[ic] < thr && sr > 0.0;
+    }
+    /* check_allowed_pda: no cells on the outer faces (directions 1, 2; also 3 for Cartesian grids) */
+    size_t n_pda = 0;
+    for (int i3 = 0; i3 < st->n3; i3++) for (int i2 = 0; i2 < st->n2; i2++) for (int i1 = 0; i1 < st->n1; i1++) {
+        const size_t ic = ((size_t)i3 * st->n2 + i2) * st->n1 + i1;
+        if (i1 == 0 || i1 == st->n1 - 1 || i2 == 0 || i2 == st->n2 - 1) do_pda[ic] = 0;
+        if (st->grid_type == GRID_CAR && (i3 == 0 || i3 == st->n3 - 1)) do_pda[ic] = 0;
+        n_pda += do_pda[ic];
+    }
+    if (!n_pda) { free(do_pda); return 0; }
+    st->pda_last_cells = (int)n_pda;
+    const int exact = n_pda < 10000;
+    const double tolerance = exact ? 1.e-5 : 1.e-4;
+    double *e_mean = malloc(sizeof(double) * nc);
+    for (size_t ic = 0; ic < nc; ic++) e_mean[ic] = pda_e_mean(st, ic);
+    int32_t *cells = malloc(sizeof(int32_t) * 3 * n_pda);
+    int64_t *id_pda = malloc(sizeof(int64_t) * nc);
+    size_t np = 0;
+    for (int i3 = 0; i3 < st->n3; i3++) for (int i2 = 0; i2 < st->n2; i2++) for (int i1 = 0; i1 < st->n1; i1++) {
+        const size_t ic = ((size_t)i3 * st->n2 + i2) * st->n1 + i1;
+        id_pda[ic] = -1;
+        if (do_pda[ic]) { cells[3 * np] = i1; cells[3 * np + 1] = i2; cells[3 * np + 2] = i3; id_pda[ic] = (int64_t)np; np++; }
+    }
+    const int n_walls = st->grid_type == GRID_CAR ? 6 : st->n_dim * 2;      /* geo%n_dim * 2 */
+    const size_t ntot = (size_t)st->n_dust * nc;
+    double *prev = malloc(sizeof(double) * ntot);
+    double *coef = malloc(sizeof(double) * 6 * n_pda);
+    for (int outer = 1; outer < 100000; outer++) {
+        st->pda_last_outer = outer;
+        memcpy(prev, st->specific_energy, sizeof(double) * ntot);
+        for (size_t q = 0; q < n_pda; q++) { const int *i = &cells[3 * q]; e_mean[cell_index(st, i)] = pda_e_mean(st, cell_index(st, i)); }
+        /* the coefficients depend on the specific energy, which is only updated after the solve */
+        for (size_t q = 0; q < n_pda; q++) {
+            const int *i = &cells[3 * q];
+            for (int wall = 0; wall < n_walls; wall++) {
+                const int dir = wall >> 1; int j[3];
+                pda_neighbour(st, i, wall, j);
+                double dsum = pda_dtau_rosseland(st, i, dir) + pda_dtau_rosseland(st, j, dir);
+                double c;
+                if (exact) { if (dsum < 1e-100) dsum = 1e-100; c = 1. / dsum / pda_cell_width(st, i, dir); }
+                else c = 1. / dsum / pda_cell_width(st, i, dir);
+                coef[6 * q + wall] = c * pda_geom_factor(st, wall, i);
+            }
+        }
+        if (exact) {      /* solve_pda_indiv_exact :185-256 */
+            const size_t n = n_pda;
+            double *a = calloc(n * n, sizeof(double)), *b = calloc(n, sizeof(double));
+            for (size_t q = 0; q < n; q++) {
+                const int *i = &cells[3 * q];
+                for (int wall = 0; wall < n_walls; wall++) {
+                    int j[3]; pda_neighbour(st, i, wall, j);
+                    const double c = coef[6 * q + wall];
+                    a[q * n + q] -= c;
+                    const int64_t qn = id_pda[cell_index(st, j)];
+                    if (qn >= 0) a[q * n + (size_t)qn] += c;
+                    else b[q] -= c * e_mean[cell_index(st, j)];
+                }
+            }
+            for (size_t k = 0; k < n; k++) {        /* Gaussian elimination, partial pivoting */
+                size_t piv = k; double big = fabs(a[k * n + k]);
+                for (size_t r = k + 1; r < n; r++) if (fabs(a[r * n + k]) > big) { big = fabs(a[r * n + k]); piv = r; }
+                if (piv != k) {
+                    for (size_t c2 = k; c2 < n; c2++) { double t = a[k * n + c2]; a[k * n + c2] = a[piv * n + c2]; a[piv * n + c2] = t; }
+                    double t = b[k]; b[k] = b[piv]; b[piv] = t;
+                }
+                for (size_t r = k + 1; r < n; r++) {
+                    const double f = a[r * n + k] / a[k * n + k];
+                    if (f == 0.0) continue;
+                    for (size_t c2 = k; c2 < n; c2++) a[r * n + c2] -= f * a[k * n + c2];
+                    b[r] -= f * b[k];
+                }
+            }
+            for (size_t kk = n; kk-- > 0;) {
+                double t = b[kk];
+                for (size_t c2 = kk + 1; c2 < n; c2++) t -= a[kk * n + c2] * b[c2];
+                b[kk] = t / a[kk * n + kk];
+            }
+            for (size_t q = 0; q < n; q++) { const size_t ic = cell_index(st, &cells[3 * q]); e_mean[ic] = b[q]; pda_update_specific_energy(st, ic, e_mean[ic]); }
+            free(a); free(b);
+        } else {          /* solve_pda_indiv_iterative :258-325: Gauss-Seidel in cell order */
+            for (;;) {
+                double max_diff = 0.0;
+                for (size_t q = 0; q < n_pda; q++) {
+                    const int *i = &cells[3 * q];
+                    double a = 0.0, b = 0.0;
+                    for (int wall = 0; wall < n_walls; wall++) {
+                        int j[3]; pda_neighbour(st, i, wall, j);
+                        const double c = coef[6 * q + wall];
+                        a = a - c;
+                        b = b - c * e_mean[cell_index(st, j)];
+                    }
+                    const size_t ic = cell_index(st, i);
+                    const double e_new = b / a, diff = fabs(e_new - e_mean[ic]) / e_mean[ic];
+                    if (diff > max_diff) max_diff = diff;
+                    e_mean[ic] = e_new;
+                }
+                if (max_diff < 1.e-4) break;
+            }
+            for (size_t q = 0; q < n_pda; q++) { const size_t ic = cell_index(st, &cells[3 * q]); pda_update_specific_energy(st, ic, e_mean[ic]); }
+        }
+        double maxdiff = 0.0;
+        for (size_t k = 0; k < ntot; k++) {
+            const double dv = fabs(st->specific_energy[k] - prev[k]) / prev[k];
+            if (dv > maxdiff) maxdiff = dv;          /* NaN (0/0) compares false and is skipped, like maxval */
+        }
+        if (maxdiff < tolerance) break;
+    }
+    free(do_pda); free(e_mean); free(cells); free(id_pda); free(prev); free(coef);
+    update_energy_abs_tot(st);
+    check_energy_abs(st);
+    return 0;
 }
 
 /* ------------------------------------------------------------------ */
@@ -1282,6 +1544,41 @@ int orc_create(const orc_problem *pr, orc_state **out)
                 st->specific_energy[(size_t)d * st->n_cells + ic] = st->dust[d].minimum_specific_energy;
     }
     check_energy_abs(st);
+    if (st->cfg.count_photons || st->cfg.pda) st->n_photons = calloc(st->n_cells ? st->n_cells : 1, sizeof(int64_t));
+    if (st->cfg.pda)      /* setup_rt.f90:289-300 */
+        for (int d = 0; d < st->n_dust; d++)
+            if (st->dust[d].version == 1) {
+                snprintf(g_error, sizeof g_error, "version 1 dust files can no longer be used when PDA is computed due to a bug - to fix this, re-generate the dust file using the latest version of Hyperion");
+                orc_destroy(st); return 1;
+            }
+    st->n_bins = st->cfg.n_spectrum_bins > 0 ? st->cfg.n_spectrum_bins : 0;
+    if (st->n_bins) {     /* grid_physics_3d.f90:124-143,215-282 */
+        const int nb = st->n_bins;
+        st->nu_edges = dup(st->cfg.spectrum_bin_edges, nb + 1);
+        st->cfg.spectrum_bin_edges = st->nu_edges;
+        for (int b = 0; b < nb; b++)
+            if (!(st->nu_edges[b + 1] > st->nu_edges[b])) { snprintf(g_error, sizeof g_error, "specific_energy_spectrum_bin_edges should be strictly increasing"); orc_destroy(st); return 1; }
+        st->log_nu_edges = malloc(sizeof(double) * (nb + 1));
+        for (int b = 0; b <= nb; b++) st->log_nu_edges[b] = log10(st->nu_edges[b]);
+        const size_t ns = (size_t)nb * (ntot ? ntot : 1);
+        st->spec = calloc(ns, sizeof(double)); st->spec_sum = calloc(ns, sizeof(double));
+        if (pr->specific_energy && st->cfg.specific_energy_type == 1) st->spec_add = calloc(ns, sizeof(double));   /* copy of the zeros */
+        if (!pr->specific_energy || st->cfg.specific_energy_type == 1)
+            for (int b = 0; b < nb; b++) for (int d = 0; d < st->n_dust; d++) for (size_t ic = 0; ic < st->n_cells; ic++)
+                st->spec[((size_t)b * st->n_dust + d) * st->n_cells + ic] = st->dust[d].minimum_specific_energy;
+        /* setup_j_nu_bin_fractions :326-348 with get_j_nu_bin_fractions dust_type_4elem.f90:752-778 */
+        st->nj_max = 1;
+        for (int d = 0; d < st->n_dust; d++) if (st->dust[d].n_jnu > st->nj_max) st->nj_max = st->dust[d].n_jnu;
+        st->jnu_bin_frac = calloc((size_t)st->n_dust * st->nj_max * nb, sizeof(double));
+        for (int d = 0; d < st->n_dust; d++)
+            for (int iv = 0; iv < st->dust[d].n_jnu; iv++) {
+                const pdf_t *q = &st->dust[d].j_nu[iv];
+                double *f = st->jnu_bin_frac + ((size_t)d * st->nj_max + iv) * nb;
+                for (int b = 0; b < nb; b++) f[b] = integral_loglog_range(q->x, q->pdf, q->n, st->nu_edges[b], st->nu_edges[b + 1]);
+                const double norm = integral_loglog_all(q->x, q->pdf, q->n);
+                if (norm > 0.0) for (int b = 0; b < nb; b++) f[b] /= norm;
+            }
+    }
 
     st->n_peeled = pr->n_peeled;
     st->has_binned = pr->binned != NULL;
@@ -1331,6 +1628,7 @@ void orc_destroy(orc_state *st)
     if (st->peeled) { for (int g = 0; g < st->n_groups; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
     free(st->lum_pdf); free(st->lum_cdf);
     free(st->density); free(st->specific_energy); free(st->specific_energy_add);
+    free(st->n_photons); free(st->nu_edges); free(st->log_nu_edges); free(st->spec); free(st->spec_sum); free(st->spec_add); free(st->jnu_bin_frac);
     free(st->specific_energy_sum); free(st->jnu_var_id); free(st->jnu_var_frac);
     free(st);
 }
@@ -1361,6 +1659,10 @@ typedef struct {
 
 typedef struct {
     double *sum;        /* thread-local specific_energy_sum or NULL (noenergy) */
+    int64_t *nphot;     /* thread-local n_photons or NULL */
+    uint64_t *last_id;  /* thread-local last_photon_id (packet id + 1; 0 = none) */
+    uint64_t cur_id;    /* id + 1 of the packet being propagated */
+    double *sum_spec;   /* thread-local specific_energy_sum_spectrum or NULL */
     uint64_t killed_geo, killed_int, crossings, interactions;
     double energy_current;
     int fatal; char err[256];
@@ -2069,7 +2371,14 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
     double tau_achieved = 0.0;
     p->reabsorbed = 0;
     p->radial = ((p->r[0] * p->v[0] + p->r[1] * p->v[1]) + p->r[2] * p->v[2]) > 0.0;   /* :73 */
+    /* frequency bin of the packet, found once per call (:59-71): locate() - 1-based in the reference, -1 outside */
+    int idx = -1;
+    if (deposit && acc->sum_spec) idx = locate(st->log_nu_edges, st->n_bins + 1, log10(p->nu));
     if (escaped(st, p->ic)) return;
+    if (deposit && acc->nphot) {      /* :90-95 */
+        size_t c0 = cell_index(st, p->ic);
+        if (acc->last_id[c0] != acc->cur_id) { acc->nphot[c0]++; acc->last_id[c0] = acc->cur_id; }
+    }
     if (tau_required == 0.0) return;
     /* distance to the nearest source that can re-absorb the packet: grid_propagate_3d.f90:99-101 */
     double t_source, t_achieved = 0.0; int source_id;
@@ -2096,11 +2405,17 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
             tau_achieved += tau_cell;
             if (deposit)
                 for (int d = 0; d < st->n_dust; d++)
-                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
+                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0) {
                         deposit[(size_t)d * st->n_cells + ic] += tmin * p->kappa[d] * p->energy;
+                        if (idx >= 0) acc->sum_spec[((size_t)idx * st->n_dust + d) * st->n_cells + ic] += tmin * p->kappa[d] * p->energy;   /* :155-158 */
+                    }
             advance_cell(st, p, id_min);
             if (st->grid_type == GRID_AMR && p->ic[0] < 0) { acc->killed_geo++; p->killed = 1; return; }   /* invalid_cell */
             if (escaped(st, p->ic)) return;
+            if (deposit && acc->nphot) {      /* :175-180 */
+                size_t c1 = cell_index(st, p->ic);
+                if (acc->last_id[c1] != acc->cur_id) { acc->nphot[c1]++; acc->last_id[c1] = acc->cur_id; }
+            }
         } else {
             double tact = tmin * (tau_needed / tau_cell);
             t_achieved += tact;
@@ -2110,8 +2425,10 @@ static void grid_integrate(const orc_state *st, photon_t *p, double tau_required
             p->on_wall[0] = p->on_wall[1] = p->on_wall[2] = 0;
             if (deposit)
                 for (int d = 0; d < st->n_dust; d++)
-                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0)
+                    if (st->density[(size_t)d * st->n_cells + ic] > 0.0) {
                         deposit[(size_t)d * st->n_cells + ic] += tact * p->kappa[d] * p->energy;
+                        if (idx >= 0) acc->sum_spec[((size_t)idx * st->n_dust + d) * st->n_cells + ic] += tact * p->kappa[d] * p->energy;   /* :214-222 */
+                    }
             return;
         }
     }
@@ -2662,7 +2979,7 @@ static double distance_to_closest_wall(const orc_state *st, const photon_t *p)
 }
 
 /* grid_do_mrw :55-107 (deposit != NULL) and grid_do_mrw_noenergy :109-148 */
-static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *deposit)
+static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *deposit, double *sum_spec)
 {
     size_t ic = cell_index(st, p->ic);
     double R0 = distance_to_closest_wall(st, p);
@@ -2679,6 +2996,12 @@ static void grid_do_mrw(const orc_state *st, photon_t *p, rng_t *g, double *depo
                 const dust_t *du = &st->dust[d];
                 double e = p->energy * ct * interp1d_loglog(du->mo_e, du->mo_kappa_planck, du->n_e, st->specific_energy[k]);
                 deposit[k] += e;
+                if (sum_spec) {     /* deposit_specific_energy_spectrum: grid_physics_3d.f90:367-395 */
+                    const int iv = st->jnu_var_id[k]; const double fr = st->jnu_var_frac[k];
+                    const double *f0 = st->jnu_bin_frac + ((size_t)d * st->nj_max + iv) * st->n_bins, *f1 = f0 + st->n_bins;
+                    for (int b = 0; b < st->n_bins; b++)
+                        sum_spec[((size_t)b * st->n_dust + d) * st->n_cells + ic] += e * ((1.0 - fr) * f0[b] + fr * f1[b]);
+                }
             }
         }
     }
@@ -2715,7 +3038,7 @@ static int mrw_steps(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, dou
     for (k = 1; k <= st->cfg.n_inter_mrw_max; k++) {
         size_t ic = cell_index(st, p->ic);
         if (st->alpha_inv_planck[ic] * distance_to_closest_wall(st, p) > st->cfg.mrw_gamma) {
-            grid_do_mrw(st, p, g, deposit);
+            grid_do_mrw(st, p, g, deposit, deposit ? acc->sum_spec : NULL);
             if (peel) peeloff_photon(st, p, g, acc, 0);
         } else break;
     }
@@ -2731,6 +3054,7 @@ static void lucy_packet(const orc_state *st, uint64_t id, int iter, acc_t *acc)
 {
     rng_t g; photon_t p;
     rng_init(&g, st->cfg.seed, (uint32_t)iter, id);
+    acc->cur_id = id + 1;
     if (emit(st, &p, &g, acc)) return;
     for (int64_t inter = 1; inter <= st->cfg.n_inter_max + 1; inter++) {
         if (st->cfg.mrw && inter > 1 && mrw_steps(st, &p, &g, acc, acc->sum, 0)) break;
@@ -2777,7 +3101,15 @@ int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int 
     precompute_jnu_var(st);                                      /* iter_lucy.f90:107 */
     if (st->cfg.mrw && prepare_mrw(st)) return 1;                /* iter_lucy.f90:109-112 */
     acc_t *accs = calloc(nt, sizeof(acc_t));
-    for (int t = 0; t < nt; t++) accs[t].sum = (t == 0) ? st->specific_energy_sum : calloc(ntot ? ntot : 1, sizeof(double));
+    const size_t nspec = (size_t)st->n_bins * ntot;
+    if (st->n_photons) memset(st->n_photons, 0, sizeof(int64_t) * st->n_cells);
+    if (nspec) memset(st->spec_sum, 0, sizeof(double) * nspec);
+    for (int t = 0; t < nt; t++) {
+        accs[t].sum = (t == 0) ? st->specific_energy_sum : calloc(ntot ? ntot : 1, sizeof(double));
+        /* every thread keeps its own n_photons / last_photon_id like an MPI rank does (mpi_routines.f90:303-310 sums them) */
+        if (st->n_photons) { accs[t].nphot = calloc(st->n_cells, sizeof(int64_t)); accs[t].last_id = calloc(st->n_cells, sizeof(uint64_t)); }
+        if (nspec) accs[t].sum_spec = (t == 0) ? st->spec_sum : calloc(nspec, sizeof(double));
+    }
 #ifdef _OPENMP
 #pragma omp parallel num_threads(nt)
 #endif
@@ -2802,6 +3134,11 @@ int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int 
         if (t > 0) {
             for (size_t k = 0; k < ntot; k++) st->specific_energy_sum[k] += accs[t].sum[k];
             free(accs[t].sum);
+            if (nspec) { for (size_t k = 0; k < nspec; k++) st->spec_sum[k] += accs[t].sum_spec[k]; free(accs[t].sum_spec); }
+        }
+        if (st->n_photons) {
+            for (size_t k = 0; k < st->n_cells; k++) st->n_photons[k] += accs[t].nphot[k];
+            free(accs[t].nphot); free(accs[t].last_id);
         }
         st->pending.energy_current += accs[t].energy_current;
         st->pending.killed_geo += accs[t].killed_geo;
@@ -2820,6 +3157,7 @@ int orc_lucy_finish(orc_state *st, double *specific_energy_out, orc_iter_stats *
 {
     if (!(st->pending.energy_current > 0.0)) { snprintf(st->err, sizeof st->err, "no energy emitted"); return 1; }
     update_energy_abs(st, st->energy_total / st->pending.energy_current); /* iter_lucy.f90:224 */
+    if (st->cfg.pda && solve_pda(st)) return 1;                            /* :227 */
     sublimate_dust(st);                                                    /* :235 */
     for (int d = 0; d < st->n_dust; d++) st->pending.energy_abs_tot[d] = st->energy_abs_tot[d];
     if (specific_energy_out) memcpy(specific_energy_out, st->specific_energy, sizeof(double) * st->n_dust * st->n_cells);
@@ -2839,6 +3177,52 @@ int orc_set_accumulators(orc_state *st, const double *block)
     st->pending.killed_int = (uint64_t)block[ntot + 2];
     st->pending.crossings = (uint64_t)block[ntot + 3];
     st->pending.interactions = (uint64_t)block[ntot + 4];
+    /* optional extensions of the block: [8 tail doubles][n_photons as doubles (n_cells)][spectrum sums (n_bins*n_dust*n_cells)] */
+    const double *q = block + ntot + 8;
+    if (st->n_photons) { for (size_t k = 0; k < st->n_cells; k++) st->n_photons[k] = (int64_t)q[k]; q += st->n_cells; }
+    if (st->n_bins) memcpy(st->spec_sum, q, sizeof(double) * st->n_bins * ntot);
+    return 0;
+}
+
+const int64_t *orc_n_photons(const orc_state *st) { return st->n_photons; }
+const double *orc_specific_energy_spectrum(const orc_state *st) { return st->spec; }
+const double *orc_specific_energy_sum_spectrum(const orc_state *st) { return st->spec_sum; }
+int orc_pda_last_cells(const orc_state *st) { return st->pda_last_cells; }
+
+/* fortranlib `quantile` (lib_statistics; source absent): element of the sorted sample at rank
+ * nint(percent / 100 * (n - 1)) + 1 -- nint rounds half away from zero. */
+static int cmp_double(const void *a, const void *b) { double x = *(const double *)a, y = *(const double *)b; return (x > y) - (x < y); }
+static double quantile(double *v, size_t n, double percent)
+{
+    if (!n) return 0.0;
+    qsort(v, n, sizeof(double), cmp_double);
+    long ipos = (long)floor(percent / 100.0 * (double)(n - 1) + 0.5);
+    if (ipos < 0) ipos = 0;
+    if ((size_t)ipos > n - 1) ipos = (long)(n - 1);
+    return v[ipos];
+}
+
+/* specific_energy_converged: src/grid/grid_physics_3d.f90:637-689 -- the value whose evolution is tested: the
+ * `percentile` quantile of max(a/b, b/a) over the (cell, dust) pairs that changed and are positive before and after.
+ * status: 0 value computed, 1 nothing changed (value 0), 2 could not check (only zero cells changed). */
+int orc_convergence_value(const orc_state *st, const double *prev, double percentile, double *value)
+{
+    const size_t n = (size_t)st->n_dust * st->n_cells;
+    const double *cur = st->specific_energy;
+    int all_same = 1, only_zero = 1;
+    size_t m = 0;
+    for (size_t k = 0; k < n; k++) {
+        if (prev[k] != cur[k]) { all_same = 0; if (prev[k] != 0.0 && cur[k] != 0.0) only_zero = 0; }
+        if (prev[k] > 0.0 && cur[k] > 0.0 && prev[k] != cur[k]) m++;
+    }
+    if (all_same) { *value = 0.0; return 1; }
+    if (only_zero) { *value = 0.0; return 2; }
+    double *v = malloc(sizeof(double) * (m ? m : 1));
+    size_t j = 0;
+    for (size_t k = 0; k < n; k++)
+        if (prev[k] > 0.0 && cur[k] > 0.0 && prev[k] != cur[k]) { double a = prev[k] / cur[k], b = cur[k] / prev[k]; v[j++] = a > b ? a : b; }
+    *value = quantile(v, m, percentile);
+    free(v);
     return 0;
 }
 
@@ -2978,6 +3362,14 @@ static int peeled_setup(orc_state *st, peeled_t *p, const orc_peeled_desc *in)
         if (in->inu_max < 1 || in->inu_max > st->cfg.n_frequencies) { snprintf(g_error, sizeof g_error, "inu_max value is out of range"); return 1; }
         p->d.n_nu = in->inu_max - in->inu_min + 1;
     }
+    if (in->use_filters) {        /* image_type.f90:173-181,285-291; images_peeled.f90:349 */
+        if (st->cfg.monochromatic) { snprintf(g_error, sizeof g_error, "cannot use filters in monochromatic mode"); return 1; }
+        if (st->cfg.raytracing) { snprintf(g_error, sizeof g_error, "filter convolution cannot be used with raytracing"); return 1; }
+        p->filt_off = malloc(sizeof(int) * (in->n_nu + 1));
+        p->filt_off[0] = 0;
+        for (int i = 0; i < in->n_nu; i++) p->filt_off[i + 1] = p->filt_off[i] + in->filt_n[i];
+        p->filt_nu = dup(in->filt_nu, p->filt_off[in->n_nu]); p->filt_tr = dup(in->filt_tr, p->filt_off[in->n_nu]);
+    }
     p->n_stokes = in->compute_stokes ? 4 : 1;
     /* image_type.f90:283-300 */
     switch (in->track_origin) {
@@ -3004,6 +3396,7 @@ static void peeled_free(peeled_t *p)
 {
     free(p->theta); free(p->phi); free(p->view); free(p->sed); free(p->sed2); free(p->img); free(p->img2);
     free(p->src_spec); free(p->dust_log10_em); free(p->dust_chi);
+    free(p->filt_off); free(p->filt_nu); free(p->filt_tr);
 }
 
 int orc_peeled_n_orig(const orc_state *st, int g) { return st->peeled[g].n_orig; }
@@ -3049,17 +3442,41 @@ static int origin_slot(const orc_state *st, const peeled_t *pg, const photon_t *
     return 0;
 }
 
-/* image_bin :408-524 */
+/* image_bin_single :478-522 */
+static void image_bin_single(const orc_state *st, int ig, const photon_t *p, double x_image, double y_image,
+                             int iv, acc_t *acc, int inu, int io, double transmission);
+
+/* image_bin :408-476 */
 static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_image, double y_image,
                       int iv, acc_t *acc)
 {
     const peeled_t *pg = &st->peeled[ig];
     const orc_peeled_desc *d = &pg->d;
-    int inu = st->cfg.monochromatic ? p->inu - (d->inu_min - 1)      /* image_type.f90:435-436 */
-                                    : ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
-    if (inu < 0 || inu >= d->n_nu) return;
     if (p->energy != p->energy || p->s[0] != p->s[0]) return;   /* :421-429 NaN energy / flux ignored */
     int io = origin_slot(st, pg, p);
+    if (d->use_filters) {      /* :467-475: interp1d (linear) of the transmission curve, 0 outside it */
+        for (int f = 0; f < d->n_nu; f++) {
+            const double *fx = pg->filt_nu + pg->filt_off[f], *ft = pg->filt_tr + pg->filt_off[f];
+            const int n = pg->filt_off[f + 1] - pg->filt_off[f];
+            const int j = locate(fx, n, p->nu);
+            if (j < 0) continue;
+            const double tr = ft[j] + (p->nu - fx[j]) / (fx[j + 1] - fx[j]) * (ft[j + 1] - ft[j]);
+            if (tr > 0.0) image_bin_single(st, ig, p, x_image, y_image, iv, acc, f, io, tr);
+        }
+        return;
+    }
+    int inu = st->cfg.monochromatic ? p->inu - (d->inu_min - 1)      /* image_type.f90:435-436 */
+                                    : ipos0(pg->log10_nu_min, pg->log10_nu_max, log10(p->nu), d->n_nu);
+    image_bin_single(st, ig, p, x_image, y_image, iv, acc, inu, io, 1.0);
+}
+
+static void image_bin_single(const orc_state *st, int ig, const photon_t *p, double x_image, double y_image,
+                             int iv, acc_t *acc, int inu, int io, double transmission)
+{
+    const peeled_t *pg = &st->peeled[ig];
+    const orc_peeled_desc *d = &pg->d;
+    (void)st;
+    if (inu < 0 || inu >= d->n_nu) return;
     int ns = pg->n_stokes;
     if (d->compute_image) {
         int ix = ipos0(d->x_min, d->x_max, x_image, d->n_x);
@@ -3067,7 +3484,7 @@ static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_i
         if (ix >= 0 && ix < d->n_x && iy >= 0 && iy < d->n_y) {
             for (int is = 0; is < ns; is++) {
                 size_t k = (((((size_t)is * pg->n_orig + io) * d->n_view + iv) * d->n_y + iy) * d->n_x + ix) * d->n_nu + inu;
-                double val = p->s[is] * p->energy;
+                double val = p->s[is] * p->energy * transmission;
                 acc->img[ig][k] += val;
                 if (d->uncertainties) acc->img2[ig][k] += val * val;
             }
@@ -3082,7 +3499,7 @@ static void image_bin(const orc_state *st, int ig, const photon_t *p, double x_i
         if (ir >= 0 && ir < d->n_ap) {
             for (int is = 0; is < ns; is++) {
                 size_t k = ((((size_t)is * pg->n_orig + io) * d->n_view + iv) * d->n_ap + ir) * d->n_nu + inu;
-                double val = p->s[is] * p->energy;
+                double val = p->s[is] * p->energy * transmission;
                 acc->sed[ig][k] += val;
                 if (d->uncertainties) acc->sed2[ig][k] += val * val;
             }

@@ -19,7 +19,7 @@
  * raytracing={False,True}.* (20), test_pascucci.tau=* (4: monochromatic + raytracing, spherical grid),
  * test_pinte_seds.tau=* (3) and test_pinte_images.tau=* (2: cylindrical grid, MRW, monochromatic, raytracing),
  * the 18-density temperature table of test_mrw.py and the models of test_mono.py / test_spot_source.py;
- * test_pinte_specific_energy.* needs the PDA, which is not restated.  Features without a reference output
+ * test_pinte_specific_energy.* (4: the same disc with the PDA).  Features without a reference output
  * (Voronoi walk, binned images, map sources, inside observers) are pinned by analytic results and by
  * equivalence with golden-pinned features (tests/test_oracle_units.py).
  *
@@ -158,6 +158,19 @@ typedef struct orc_config {
     const double *frequencies;       /* [n_frequencies] table /frequencies column nu (setup_rt.f90:220-222) */
     int32_t n_frequencies;
     int32_t reserved2;
+    /* partial diffusion approximation (root attr `pda`): solve_pda after update_energy_abs, src/grid/grid_pda_3d.f90:84-172;
+     * Cartesian, spherical and cylindrical grids (the others are built with grid_pda_disabled.f90: nothing to do) */
+    int32_t pda;
+    /* keep n_photons(cell), the number of packets that entered each cell in a Lucy iteration
+     * (src/grid/grid_propagate_3d.f90:88-93,171-176): allocated with pda or /Output output_n_photons != 'none'
+     * (src/grid/grid_physics_3d.f90:307-318) */
+    int32_t count_photons;
+    /* frequency-resolved specific energy (/Output output_specific_energy_spectrum != 'none', src/main/setup_rt.f90:77-104):
+     * n_spectrum_bins bins with edges spectrum_bin_edges[n_spectrum_bins + 1] (Hz, strictly increasing; table
+     * /specific_energy_spectrum_bin_edges column nu); 0 = off */
+    int32_t n_spectrum_bins;
+    int32_t reserved3;
+    const double *spectrum_bin_edges;
 } orc_config;
 
 /* One peeled image group (reader: src/images/images_peeled.f90:272-380,
@@ -184,6 +197,15 @@ typedef struct orc_peeled_desc {
     const double *theta;     /* [n_view] degrees */
     const double *phi;       /* [n_view] degrees */
     int32_t inu_min, inu_max; /* monochromatic: 1-based range of config.frequencies this group images (image_type.f90:243-258); n_nu = inu_max - inu_min + 1 */
+    /* filter convolution (attrs use_filters, n_filt and groups filter_NNNNN with tables nu, tn and attr nu0,
+     * src/images/image_type.f90:173-181,285-291): n_nu = n_filt planes, a packet is binned into every filter whose
+     * transmission at its frequency is positive with that weight (image_bin :467-475); not with raytracing or
+     * monochromatic mode */
+    int32_t use_filters;
+    int32_t reserved_f;
+    const int32_t *filt_n;   /* [n_nu] points of each filter curve */
+    const double *filt_nu;   /* concatenated, increasing within a filter */
+    const double *filt_tr;   /* concatenated transmissions (column tn) */
 } orc_peeled_desc;
 
 typedef struct orc_problem {
@@ -240,6 +262,14 @@ int orc_set_accumulators(orc_state *st, const double *block);
 const double *orc_specific_energy_sum(const orc_state *st);
 const double *orc_specific_energy(const orc_state *st);
 const double *orc_density(const orc_state *st);
+/* n_photons of the last Lucy iteration ([n_cells], NULL unless config.count_photons / pda); frequency-resolved specific
+ * energy [n_bins][n_dust][n_cells] (NULL unless config.n_spectrum_bins) and its raw sums; number of cells the last
+ * solve_pda treated; the value tested by specific_energy_converged (grid_physics_3d.f90:637-689) against `prev` */
+const int64_t *orc_n_photons(const orc_state *st);
+const double *orc_specific_energy_spectrum(const orc_state *st);
+const double *orc_specific_energy_sum_spectrum(const orc_state *st);
+int orc_pda_last_cells(const orc_state *st);
+int orc_convergence_value(const orc_state *st, const double *prev, double percentile, double *value);
 
 /* Final (imaging) iteration with peel-off (src/main/iter_final.f90:60-273).
  * Image/SED cubes are returned scaled (image_scale) but not dnu-normalised;

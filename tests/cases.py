@@ -67,3 +67,20 @@ def imaging_problem(n=12, tau=1.0, n_x=16, n_y=16, **peeled_kw):
     kw.update(peeled_kw)
     p.peeled = [PeeledImages(**kw)]
     return p
+
+
+def pda_block_problem(n=14, tau_cell=100.0, n_photons=30000, pda=True, grid="car"):
+    """A thin medium with an opaque block in it, lit from the side: packets are absorbed and re-emitted in the skin of
+    the block and hardly ever reach its inner cells -- the situation the partial diffusion approximation is for
+    (src/grid/grid_pda_3d.f90: cells with fewer than max(30, 0.5 % of the mean) packets)."""
+    prob = make_benchmark_problem(n, n_photons=n_photons, n_iter=1)
+    w = prob.walls[0]
+    dx = w[1] - w[0]
+    rho = np.full(prob.density.shape, 0.05 / (w[-1] - w[0]))
+    lo, hi = n // 2 - 3, n // 2 + 3
+    rho[0, lo:hi, lo:hi, lo:hi] = tau_cell / dx
+    prob.density = rho
+    prob.sources[0].position = (0.8 * w[0] + 0.0, 0.13 * dx, -0.21 * dx)
+    prob.config.pda = pda
+    prob.config.output_n_photons = "last"
+    return prob

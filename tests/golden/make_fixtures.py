@@ -485,7 +485,57 @@ def pinte_images_fixture(tmp):
         print("wrote", path, os.path.getsize(path))
 
 
+def pinte_specific_energy_fixture(tmp):
+    """test_bit_level.py:638-697 (TestPinteBenchmark.test_pinte_specific_energy): the Pinte disc on a 50 x 30 x 1
+    cylindrical polar grid, 3 Lucy iterations of 50000 packets with the MRW (gamma = 2) AND the partial diffusion
+    approximation (set_pda(True)), no imaging.  golden = iteration_00003/specific_energy of
+    hyperion/model/tests/data/test_pinte_specific_energy.tau=*.rtout (the only shipped outputs that exercise
+    src/grid/grid_pda_3d.f90)."""
+    from hyperion.model import AnalyticalYSOModel
+    from hyperion.dust import SphericalDust
+    from hyperion.util.constants import au, msun, rsun, sigma
+    for tau in (1000, 10000, 100000, 1000000):
+        m = AnalyticalYSOModel()
+        m.star.radius = 2. * rsun
+        m.star.temperature = 4000.
+        m.star.luminosity = 4. * np.pi * (2. * rsun) ** 2. * sigma * 4000. ** 4.
+        disk = m.add_flared_disk()
+        disk.p = -1.5
+        disk.beta = 1.125
+        disk.mass = 3.e-8 * msun * tau / 1.e3
+        disk.rmin = 0.1 * au
+        disk.rmax = 400 * au
+        disk.h_0 = 10 * au
+        disk.r_0 = 100. * au
+        disk.cylindrical_inner_rim = True
+        disk.cylindrical_outer_rim = True
+        disk.dust = SphericalDust(os.path.join(DATA, 'pinte_dust_lite.hdf5'))
+        m.set_n_initial_iterations(3)
+        m.set_cylindrical_polar_grid_auto(50, 30, 1)
+        m.set_mrw(True, gamma=2.)
+        m.set_pda(True)
+        m.set_n_photons(initial=50000, imaging=0)
+        m.set_max_interactions(1000, warn=False)
+        prob = write_and_read(m, tmp)
+        ref = os.path.join(DATA, "test_pinte_specific_energy.tau=%s.rtout" % tau)
+        golden = {}
+        with h5py.File(ref, "r") as f:
+            golden["specific_energy_3"] = read_specific_energy(f["iteration_00003"])      # output_specific_energy = 'last'
+        path = os.path.join(HERE, "pinte_specific_energy.tau=%s.npz" % tau)
+        ptmp = path + ".problem.npz"
+        prob.to_npz(ptmp, dust_library={"pinte_dust_lite.npz": prob.dust[0]})
+        z = dict(np.load(ptmp)); os.remove(ptmp)
+        for k, v in golden.items():
+            z["golden/" + k] = v
+        np.savez_compressed(path, **z)
+        print("wrote", path, os.path.getsize(path))
+
+
 def main():
+    if "pinte_specific_energy" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            pinte_specific_energy_fixture(tmp)
+        return
     if "pinte_images" in sys.argv[1:]:
         with tempfile.TemporaryDirectory() as tmp:
             pinte_images_fixture(tmp)

@@ -46,6 +46,13 @@ def lib():
         for f in ("orc_specific_energy_sum", "orc_specific_energy", "orc_density"):
             getattr(L, f).argtypes = [C.c_void_p]
             getattr(L, f).restype = _dp
+        L.orc_n_photons.argtypes = [C.c_void_p]
+        L.orc_n_photons.restype = C.POINTER(C.c_int64)
+        for f in ("orc_specific_energy_spectrum", "orc_specific_energy_sum_spectrum"):
+            getattr(L, f).argtypes = [C.c_void_p]
+            getattr(L, f).restype = _dp
+        L.orc_pda_last_cells.argtypes = [C.c_void_p]
+        L.orc_convergence_value.argtypes = [C.c_void_p, _dp, C.c_double, _dp]
         L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
@@ -141,6 +148,37 @@ class Oracle:
     def specific_energy(self):
         n = int(np.prod(self.shape))
         return np.ctypeslib.as_array(lib().orc_specific_energy(self.h), shape=(n,)).reshape(self.shape).copy()
+
+    def density(self):
+        n = int(np.prod(self.shape))
+        return np.ctypeslib.as_array(lib().orc_density(self.h), shape=(n,)).reshape(self.shape).copy()
+
+    def n_photons(self):
+        """n_photons of the last Lucy iteration, shape of one species of the density."""
+        p = lib().orc_n_photons(self.h)
+        if not p:
+            return None
+        n = int(np.prod(self.shape[1:]))
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(self.shape[1:]).copy()
+
+    def specific_energy_spectrum(self, sums=False):
+        """(n_bins, n_dust, cells...) frequency-resolved specific energy (or its raw sums)."""
+        nb = int(self.m.desc.config.n_spectrum_bins)
+        if nb == 0:
+            return None
+        fn = lib().orc_specific_energy_sum_spectrum if sums else lib().orc_specific_energy_spectrum
+        n = int(np.prod(self.shape)) * nb
+        return np.ctypeslib.as_array(fn(self.h), shape=(n,)).reshape((nb,) + tuple(self.shape)).copy()
+
+    def pda_last_cells(self):
+        return int(lib().orc_pda_last_cells(self.h))
+
+    def convergence_value(self, prev, percentile):
+        """(status, value) of specific_energy_converged's tested quantity against the previous specific energy."""
+        prev = np.ascontiguousarray(prev, dtype=np.float64)
+        v = C.c_double()
+        rc = lib().orc_convergence_value(self.h, prev.ctypes.data_as(_dp), float(percentile), C.byref(v))
+        return int(rc), v.value
 
     def raytracing_iteration(self, n_sources, n_dust, n_threads=0):
         """do_raytracing: adds to the cubes of the last final_iteration; returns them."""

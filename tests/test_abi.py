@@ -30,7 +30,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "missing export %s" % n
     assert sorted(hyperion_amd.engine.EXPORTS) == names
-    assert hyperion_amd.load_library().hyp_abi_version() == 1
+    assert hyperion_amd.load_library().hyp_abi_version() == 2
 
 
 def test_ctypes_layout_matches_the_header(tmp_path):

@@ -1,0 +1,182 @@
+"""GPU <-> oracle parity of the round-2 features through the C-ABI: n_photons, frequency-resolved specific energy, the
+partial diffusion approximation, image filters and the convergence quantile (all on identical Philox streams)."""
+import numpy as np
+import pytest
+
+import hyperion_amd
+from cases import golden_problem, pda_block_problem
+from hyperion_amd.benchmark import make_benchmark_problem
+from hyperion_amd.problem import PeeledImages
+from oracle_lib import Oracle
+
+pytestmark = pytest.mark.gpu
+KEYS = ("killed_geo", "killed_int", "crossings", "interactions")
+
+
+def both(prob, n, iters=1, **opts):
+    eng = hyperion_amd.Engine(prob)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    orc = Oracle(prob)
+    out = []
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        b, sb = orc.lucy_iteration(n, it)
+        assert all(sa[k] == sb[k] for k in KEYS), (sa, sb)
+        out.append((a, b))
+    return eng, orc, out
+
+
+def test_n_photons_parity():
+    """The reference counts distinct packets per cell (it runs them one after the other and remembers the last one).  The
+    device remembers the last 32 packets counted in each cell: exact wherever at most 32 packets pass -- the PDA threshold
+    is 30 -- and never fewer than the reference anywhere."""
+    prob = make_benchmark_problem(12, n_photons=20000, n_iter=1)
+    prob.config.output_n_photons = "last"
+    eng, orc, _ = both(prob, 20000)
+    g, c = eng.n_photons(), orc.n_photons()
+    eng.close(); orc.close()
+    assert g.shape == c.shape and g.dtype == np.int64
+    assert np.all(g >= c) and g.sum() <= 1.2 * c.sum()
+    low = c <= 32
+    assert low.any()
+    np.testing.assert_array_equal(g[low], c[low])
+    # an opaque block: its heart is starved, a few packets wander about in its skin for hundreds of interactions
+    prob = pda_block_problem(pda=False)
+    eng, orc, _ = both(prob, 30000)
+    g, c = eng.n_photons(), orc.n_photons()
+    eng.close(); orc.close()
+    low = c <= 32
+    assert low.sum() > 500 and np.all(g >= c)
+    np.testing.assert_array_equal(g[low], c[low])
+    np.testing.assert_array_equal(g < 30, c < 30)           # the PDA decision is the reference's
+
+
+@pytest.mark.parametrize("mrw", [False, True])
+def test_specific_energy_spectrum_parity(mrw):
+    if mrw:
+        # optically thick cells with the realistic dust: the random walk deposits through the emissivity bin fractions
+        # (deposit_specific_energy_spectrum, grid_physics_3d.f90:367-395)
+        from test_gpu_mrw import thicken
+        prob = thicken(make_benchmark_problem(8, n_photons=8000, n_iter=2), tau_cell=4.0)
+        edges = np.logspace(np.log10(prob.dust[0].nu[0]), np.log10(prob.dust[0].nu[-1]), 9)
+        edges[0] *= 0.999; edges[-1] *= 1.001
+        n = 8000
+    else:
+        prob = make_benchmark_problem(10, n_photons=20000, n_iter=2, tau=2.0)
+        edges = np.logspace(9.0, 17.0, 9)          # covers the whole dust table (3e9 .. 3e16 Hz)
+        n = 20000
+    prob.config.output_specific_energy_spectrum = "last"
+    prob.config.spectrum_bin_edges = edges
+    eng, orc, res = both(prob, n, iters=2)
+    gs, e_out = eng.specific_energy_spectrum()
+    cs = orc.specific_energy_spectrum()
+    eng.close(); orc.close()
+    np.testing.assert_array_equal(e_out, prob.config.spectrum_bin_edges)
+    assert gs.shape == cs.shape == (8,) + prob.density.shape and (cs > 0).sum(axis=0).max() > 2
+    np.testing.assert_allclose(gs, cs, rtol=1e-8, atol=1e-11 * cs.max())
+    a, _ = res[-1]
+    if not mrw:
+        np.testing.assert_allclose(gs.sum(axis=0), a, rtol=1e-6)      # the reference's own identity
+
+
+def test_spectrum_with_sublimation_and_several_species():
+    prob, _ = golden_problem("car_specific_energy.False.True.npz")          # three species
+    for d, mode in zip(prob.dust, ("fast", "slow", "cap")):
+        d.sublimation_mode = mode
+        d.sublimation_specific_energy = 3.0e4
+    prob.config.output_specific_energy_spectrum = "all"
+    prob.config.spectrum_bin_edges = np.logspace(10.0, 16.0, 5)
+    eng, orc, res = both(prob, 20000, iters=2)
+    gs, _ = eng.specific_energy_spectrum()
+    cs = orc.specific_energy_spectrum()
+    np.testing.assert_allclose(eng.density(), orc.density(), rtol=1e-9)
+    eng.close(); orc.close()
+    np.testing.assert_allclose(gs, cs, rtol=1e-8, atol=1e-12 * cs.max())
+
+
+def test_pda_parity_exact_branch():
+    """Fewer than 10 000 PDA cells: the reference eliminates, the device iterates the same system to 1e-12; the outer loop
+    stops at 1e-5 on both sides."""
+    prob = pda_block_problem()
+    eng, orc, res = both(prob, 30000)
+    a, b = res[0]
+    n_dev, n_orc = eng.get_option("pda_last_cells"), orc.pda_last_cells()
+    g, c = eng.n_photons(), orc.n_photons()
+    eng.close(); orc.close()
+    assert n_orc > 64 and n_dev == n_orc
+    np.testing.assert_array_equal(g < 30, c < 30)
+    pda = (c < 30)
+    np.testing.assert_allclose(a[0][~pda], b[0][~pda], rtol=1e-9)
+    np.testing.assert_allclose(a[0][pda], b[0][pda], rtol=1e-4)
+
+
+def test_pda_iterative_branch_follows_the_reference_sweeps():
+    """More than 10 000 PDA cells: Gauss-Seidel in cell order down to 1e-4 per sweep; the hyperplane-ordered sweeps of the
+    device give each cell the operands of the sequential loop, so the two agree far below that tolerance."""
+    prob = make_benchmark_problem(26, n_photons=20, n_iter=1, tau=30.0)      # 20 packets: every interior cell is starved
+    prob.config.pda = True
+    eng, orc, res = both(prob, 20)
+    a, b = res[0]
+    assert orc.pda_last_cells() == 24 ** 3 and eng.get_option("pda_last_cells") == 24 ** 3
+    eng.close(); orc.close()
+    np.testing.assert_allclose(a, b, rtol=1e-9)
+
+
+def test_pda_on_a_cylindrical_grid_runs_the_reference_model():
+    """The reference's own PDA model (test_pinte_specific_energy, tau = 1e4): device and oracle on the same streams."""
+    prob, gold = golden_problem("pinte_specific_energy.tau=10000.npz")
+    prob.config.n_inter_max = 100             # cut trajectories (MRW: chaotic in the last bit), PDA unaffected
+    eng, orc, res = both(prob, 20000)
+    a, b = res[0]
+    assert orc.pda_last_cells() > 300
+    g, c = eng.n_photons(), orc.n_photons()
+    eng.close(); orc.close()
+    np.testing.assert_array_equal(g < 30, c < 30)
+    ok = (c >= 300)
+    np.testing.assert_allclose(a[0][ok], b[0][ok], rtol=1e-8)
+    pda = (c < 30) & (prob.density[0] > 0)
+    lr = np.log10(a[0][pda] / b[0][pda])
+    assert np.abs(np.median(lr)) < 1e-3 and (np.abs(lr) < 0.05).mean() > 0.9
+
+
+def test_filters_parity():
+    prob, _ = golden_problem("car_peeloff.False.npz")
+    base = prob.peeled[0]
+    nu = np.logspace(np.log10(base.nu_min), np.log10(base.nu_max), 12)
+    bell = np.exp(-0.5 * ((np.log10(nu) - np.log10(nu[6])) / 0.3) ** 2)
+    flt = PeeledImages(theta=base.theta, phi=base.phi, n_wav=2, compute_image=True, n_x=6, n_y=5, x_min=base.x_min, x_max=base.x_max,
+                       y_min=base.y_min, y_max=base.y_max, compute_sed=True, n_ap=3, ap_min=base.ap_max / 10, ap_max=base.ap_max,
+                       uncertainties=True, track_origin="basic",
+                       filters=[(nu, bell, nu[6]), (nu[:5], np.array([0.0, 0.3, 1.0, 0.3, 0.0]), nu[2])])
+    prob.peeled = [base, flt]
+    eng = hyperion_amd.Engine(prob); orc = Oracle(prob)
+    eng.lucy_iteration(5000, 1); orc.lucy_iteration(5000, 1)
+    rg, sg = eng.final_iteration(20000)
+    rc, sc = orc.final_iteration(20000)
+    eng.close(); orc.close()
+    assert all(sg[k] == sc[k] for k in KEYS)
+    assert rc[1]["sed"].sum() > 0 and rc[1]["img"].sum() > 0
+    for x, y in zip(rg, rc):
+        for k in y:
+            np.testing.assert_allclose(x[k], y[k], rtol=1e-9, atol=1e-14 * np.abs(y[k]).max())
+
+
+def test_convergence_value_on_the_device():
+    prob = make_benchmark_problem(8, n_photons=5000, n_iter=3)
+    eng = hyperion_amd.Engine(prob); orc = Oracle(prob)
+    prev = None
+    for it in (1, 2, 3):
+        eng.lucy_iteration(5000, it)
+        b, _ = orc.lucy_iteration(5000, it)
+        st, v = eng.convergence_value(99.0)
+        if prev is None:
+            assert st == 3
+        else:
+            so, vo = orc.convergence_value(prev, 99.0)
+            assert st == 0 and so == 0
+            assert abs(v - vo) <= 1e-9 * vo
+        prev = b
+    st, v = eng.convergence_value(50.0)          # nothing changed since the last call
+    assert st == 1 and v == 0.0
+    eng.close(); orc.close()
