@@ -173,12 +173,21 @@ class Oracle:
     def pda_last_cells(self):
         return int(lib().orc_pda_last_cells(self.h))
 
-    def convergence_value(self, prev, percentile):
-        """(status, value) of specific_energy_converged's tested quantity against the previous specific energy."""
+    def convergence_value_against(self, prev, percentile):
+        """(status, value) of specific_energy_converged's tested quantity against the given previous specific energy."""
         prev = np.ascontiguousarray(prev, dtype=np.float64)
         v = C.c_double()
         rc = lib().orc_convergence_value(self.h, prev.ctypes.data_as(_dp), float(percentile), C.byref(v))
         return int(rc), v.value
+
+    def convergence_value(self, percentile):
+        """Same call as Engine.convergence_value: against the specific energy at the previous call (status 3 the first time)."""
+        cur = self.specific_energy()
+        prev = getattr(self, "_prev_se", None)
+        self._prev_se = cur
+        if prev is None:
+            return 3, 0.0
+        return self.convergence_value_against(prev, percentile)
 
     def raytracing_iteration(self, n_sources, n_dust, n_threads=0):
         """do_raytracing: adds to the cubes of the last final_iteration; returns them."""

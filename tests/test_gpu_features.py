@@ -173,7 +173,7 @@ def test_convergence_value_on_the_device():
         if prev is None:
             assert st == 3
         else:
-            so, vo = orc.convergence_value(prev, 99.0)
+            so, vo = orc.convergence_value_against(prev, 99.0)
             assert st == 0 and so == 0
             assert abs(v - vo) <= 1e-9 * vo
         prev = b

@@ -193,11 +193,11 @@ def test_convergence_value_is_the_nint_quantile():
     a, _ = o.lucy_iteration(2000, 1)
     b, _ = o.lucy_iteration(2000, 2)
     for pct in (50.0, 99.0, 100.0, 12.5):
-        st, v = o.convergence_value(a, pct)
+        st, v = o.convergence_value_against(a, pct)
         m = (a > 0) & (b > 0) & (a != b)
         r = np.sort(np.maximum(a[m] / b[m], b[m] / a[m]))
         k = int(np.floor(pct / 100.0 * (r.size - 1) + 0.5))
         assert st == 0 and v == r[k]
-    st, v = o.convergence_value(b, 99.0)
+    st, v = o.convergence_value_against(b, 99.0)
     assert st == 1 and v == 0.0
     o.close()

@@ -47,7 +47,7 @@ def converge(engine, n_packets=1000, n_iter=30):
     chk = ConvergenceCheck(2.0, 1.02, 99.0)
     for it in range(1, n_iter + 1):
         e, st = engine.lucy_iteration(n_packets, it)
-        if chk(e):
+        if chk(engine):
             break
     return e, st
 

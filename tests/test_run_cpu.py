@@ -10,34 +10,61 @@ import numpy as np
 import pytest
 
 from cases import GOLDEN, golden_problem
-from hyperion_amd.run import ConvergenceCheck, IterationRecord, RunResult, quantile
+from hyperion_amd.run import ConvergenceCheck, IterationRecord, RunResult
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONDA = "/opt/conda/bin/python3.9"
 needs_h5py = pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")
 
 
-def test_quantile_nearest_rank():
-    assert quantile(np.arange(101), 99.0) == 99.0
-    assert quantile([3.0, 1.0, 2.0], 100.0) == 3.0 and quantile([3.0, 1.0, 2.0], 0.0) == 1.0
-    assert quantile([], 50.0) == 0.0
+class _ValueSource:
+    """Stands in for Engine.convergence_value (hyp_convergence_value, computed on the device): same status codes, the
+    quantile as restated in the oracle (element of rank nint(p / 100 (n - 1)) of the sorted ratios; tests/test_oracle_features.py
+    checks the C implementation, tests/test_gpu_features.py the device one)."""
+
+    def __init__(self):
+        self.prev, self.cur = None, None
+
+    def set(self, a):
+        self.cur = np.asarray(a, dtype=float)
+
+    def convergence_value(self, percentile):
+        prev, cur = self.prev, self.cur
+        self.prev = cur.copy()
+        if prev is None:
+            return 3, 0.0
+        if np.all(prev == cur):
+            return 1, 0.0
+        if np.all((prev == cur) | (prev == 0) | (cur == 0)):
+            return 2, 0.0
+        m = (prev > 0) & (cur > 0) & (prev != cur)
+        r = np.sort(np.maximum(prev[m] / cur[m], cur[m] / prev[m]))
+        return 0, float(r[int(np.floor(percentile / 100.0 * (r.size - 1) + 0.5))])
 
 
 def test_convergence_follows_reference_rules():
     """grid_physics_3d.f90:637-689"""
+    src = _ValueSource()
+
+    def step(c, a):
+        src.set(a)
+        return c(src)
+
     c = ConvergenceCheck(absolute=2.0, relative=1.5, percentile=99.0)
     a = np.ones((1, 2, 2, 2))
-    assert c(a) is False                       # first call only stores the state
-    assert c(a * 1.5) is False                 # no previous value yet
-    assert c(a * 1.5 * 1.2) is True            # 1.2 < 2 and 1.5/1.2 < 1.5
-    assert c(a * 1.5 * 1.2) is True            # unchanged -> exact convergence
+    assert step(c, a) is False                       # first call only stores the state
+    assert step(c, a * 1.5) is False                 # no previous value yet
+    assert step(c, a * 1.5 * 1.2) is True            # 1.2 < 2 and 1.5/1.2 < 1.5
+    assert step(c, a * 1.5 * 1.2) is True            # unchanged -> exact convergence
+    src = _ValueSource()
     c = ConvergenceCheck(absolute=1.1, relative=1.5, percentile=99.0)
-    c(a); c(a * 1.5)
-    assert c(a * 1.5 * 1.2) is False           # value 1.2 above the absolute threshold
+    step(c, a); step(c, a * 1.5)
+    assert step(c, a * 1.5 * 1.2) is False           # value 1.2 above the absolute threshold
+    src = _ValueSource()
     c = ConvergenceCheck(absolute=2.0, relative=1.5, percentile=99.0)
     z = np.zeros_like(a)
-    c(z)
-    assert c(a) is False                       # only zero -> non-zero changes: cannot check
+    step(c, z)
+    assert step(c, a) is False                       # only zero -> non-zero changes: cannot check
 
 
 @needs_h5py
