@@ -531,7 +531,98 @@ def pinte_specific_energy_fixture(tmp):
         print("wrote", path, os.path.getsize(path))
 
 
+def filters_fixture(tmp):
+    """hyperion/model/tests/test_filters.py:18-66 (TestFilters): one-cell Cartesian grid, the grey test dust, two 6000 K point
+    sources, one peeled group (3 views, 10 x 20 pixels, SED) convolved with two filters, no Lucy iterations.  golden = the
+    known answers of test_image_values (:96-100): sum of the image in MJy/sr at distance 1 per filter (rtol 0.1 there, with
+    1000 packets), plus the filter frequencies of test_image_wav.  Also writes car_options.rtin: the reference's Cartesian
+    peel-off model with every output switch of the boundary turned on (filters and 4-byte cubes in one image group,
+    n_photons / density_diff / specific_energy_spectrum datasets, 4-byte grid datasets, copy_input) for the file-level test."""
+    from astropy import units as u
+    m = Model()
+    m.set_cartesian_grid([-1., 1.], [-1., 1.], [-1., 1.])
+    dust = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
+    dust.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)        # get_test_dust(), test_helpers.py:14-18
+    dust_file = os.path.join(tmp, "test_dust.hdf5")
+    dust.write(dust_file)
+    m.add_density_grid(np.array([[[1.]]]), dust_file)
+    for name in ('first', 'second'):
+        s = m.add_point_source()
+        s.name = name
+        s.luminosity = 1.
+        s.temperature = 6000.
+    i = m.add_peeled_images(sed=True, image=True)
+    i.set_viewing_angles([1., 2., 3.], [1., 2., 3.])
+    i.set_image_limits(-1., 1., -1., 1.)
+    i.set_image_size(10, 20)
+    f1 = i.add_filter()
+    f1.name = 'F1'
+    f1.spectral_coord = [1, 1.1, 1.2, 1.3] * u.micron
+    f1.transmission = [0., 100., 50, 0.] * u.percent
+    f1.detector_type = 'photons'
+    f1.alpha = 0.
+    f1.central_spectral_coord = 1.15 * u.micron
+    f2 = i.add_filter()
+    f2.name = 'F2'
+    f2.spectral_coord = [2, 2.1, 2.2, 2.3, 2.4] * u.micron
+    f2.transmission = [0., 50, 100, 60, 0.] * u.percent
+    f2.detector_type = 'energy'
+    f2.alpha = 1.
+    f2.central_spectral_coord = 2.15 * u.micron
+    m.set_n_initial_iterations(0)
+    m.set_n_photons(imaging=1000)
+    prob = write_and_read(m, tmp)
+    save(os.path.join(HERE, "car_filters.npz"), prob,
+         {"image_sum_MJy_sr": np.array([3438.059082285024, 2396.4803378036186]), "filter_nu0": np.array([2.60689094e+14, 1.39438353e+14])})
+
+    # every output switch of the boundary on one reference-written input
+    grids, denss = car_grid_and_densities()
+    m = build_model(grids["car"], denss["car"], False)
+    m.set_n_initial_iterations(2)
+    m.set_n_photons(initial=5000, imaging=5000)
+    i_p = m.add_peeled_images()
+    i_p.set_viewing_angles([33.4, 110.], [65.4, 103.2])
+    i_p.set_image_size(4, 5)
+    i_p.set_image_limits(-0.8 * pc, 0.8 * pc, -pc, pc)
+    i_p.set_aperture_radii(3, 0.1 * pc, pc)
+    i_p.set_output_bytes(4)
+    f1 = i_p.add_filter()
+    f1.name = 'A'
+    f1.spectral_coord = [1, 1.5, 2.5, 3.0] * u.micron
+    f1.transmission = [0., 80., 100., 0.] * u.percent
+    f1.detector_type = 'energy'
+    f1.alpha = 1.
+    f1.central_spectral_coord = 2.0 * u.micron
+    i_p = m.add_peeled_images()
+    i_p.set_wavelength_range(4, 0.05, 200.)
+    i_p.set_viewing_angles([22.1], [203.2])
+    i_p.set_image_size(6, 6)
+    i_p.set_image_limits(-pc, pc, -pc, pc)
+    i_p.set_aperture_radii(2, 0.5 * pc, pc)
+    m.conf.output.output_density = 'last'
+    m.conf.output.output_density_diff = 'last'
+    m.conf.output.output_n_photons = 'all'
+    m.conf.output.output_specific_energy = 'all'
+    m.conf.output.output_specific_energy_spectrum = 'last'
+    m.set_specific_energy_spectrum_bins(np.logspace(10., 16., 7))
+    m.set_output_bytes(4)
+    path = os.path.join(tmp, "options.rtin")
+    m.set_copy_input(True)
+    m.write(path, copy=True, absolute_paths=False)
+    keep = os.path.join(HERE, "car_options.rtin")
+    with h5py.File(path, "r") as fi, h5py.File(keep, "w") as fo:
+        for k, v in fi.attrs.items():
+            fo.attrs[k] = v
+        for k in fi:
+            fi.copy(k, fo, expand_external=True, expand_soft=True)
+    print("wrote", keep, os.path.getsize(keep))
+
+
 def main():
+    if "filters" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            filters_fixture(tmp)
+        return
     if "pinte_specific_energy" in sys.argv[1:]:
         with tempfile.TemporaryDirectory() as tmp:
             pinte_specific_energy_fixture(tmp)

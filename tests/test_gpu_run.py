@@ -87,10 +87,11 @@ def test_npz_round_trip_and_failure_convention(tmp_path):
         run(src, out, overwrite=True, logfile=str(tmp_path / "log2.txt"))
     assert "photon was not emitted inside a cell" in open(tmp_path / "log2.txt").read()
     assert not os.path.exists(out)
-    # unsupported modes are refused, not silently ignored
-    p = make_benchmark_problem(8, n_photons=1000, n_iter=1)
+    # a mode the input asks for and the engine cannot honour is refused, never ignored: PDA with a version-1 dust file
+    # (setup_rt.f90:289-300)
+    p, _ = golden_problem("car_specific_energy.False.False.npz")
     p.config.pda = True
-    with pytest.raises(hyperion_amd.EngineError, match="PDA is not supported"):
+    with pytest.raises(hyperion_amd.EngineError, match="version 1 dust files can no longer be used when PDA is computed"):
         run_problem(p)
 
 
@@ -153,3 +154,51 @@ def test_monochromatic_run_matches_the_pascucci_golden(tau, tmp_path):
         grp = f["Peeled/group_00001"]
         np.testing.assert_allclose(grp["frequencies"][...]["nu"], prob.config.frequencies, rtol=1e-15)
         assert "numin" not in grp["seds"].attrs and "apmin" in grp["seds"].attrs
+
+
+def test_filters_run_reproduces_the_reference_known_answer():
+    """hyperion/model/tests/test_filters.py through run_problem (n_initial_iter = 0: only the final iteration)."""
+    from test_oracle_features import check_filter_known_answers
+    prob, z = golden_problem("car_filters.npz")
+    prob.config.n_last_photons = 200000
+    r = run_problem(prob)
+    assert r.n_iterations == 0 and r.peeled[0]["images"].shape == (1, 1, 3, 20, 10, 2) and r.peeled[0]["seds"].shape == (1, 1, 3, 1, 2)
+    check_filter_known_answers(prob, z, r.peeled[0]["images"])
+    # the SED aperture takes in the whole sky, the image only its frame: SED >= image summed over the pixels, and close to it
+    sed, img = r.peeled[0]["seds"][0, 0, :, 0, :], r.peeled[0]["images"][0, 0].sum(axis=(1, 2))
+    assert np.all(sed >= img * (1 - 1e-12)) and np.all(sed <= img * 1.02)
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")
+def test_every_output_switch_of_the_boundary_is_honoured(tmp_path):
+    """A reference-written .rtin (tests/golden/car_options.rtin, made by make_fixtures.py filters) that turns on what
+    src/main/setup_rt.f90:247-283, src/grid/grid_generic.f90:29-130, src/images/image_type.f90:173-181,690-777 and
+    src/main/main.f90:133-150 read: filters + 4-byte cubes in one image group, n_photons / density / density_diff /
+    specific_energy_spectrum datasets, 4-byte grid datasets, copy_input."""
+    out = str(tmp_path / "options.rtout")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    rc = subprocess.call([CONDA, "-W", "ignore", "-m", "hyperion_amd", "-f", os.path.join(GOLDEN, "car_options.rtin"), out], env=env, cwd=ROOT)
+    assert rc == 0
+    code = ("import h5py, numpy as np\n"
+            "f = h5py.File(%r, 'r')\n"
+            "assert f.attrs['date_ended'] and f.attrs['iterations'] == 2\n"
+            "assert isinstance(f.get('Input', getlink=True), h5py.HardLink) and 'Grid' in f['Input'] and f['Input'].attrs['copy_input'] == b'yes'\n"
+            "g1, g2 = f['iteration_00001'], f['iteration_00002']\n"
+            "assert sorted(g1) == ['n_photons', 'specific_energy'], sorted(g1)\n"
+            "assert sorted(g2) == ['density', 'density_diff', 'n_photons', 'specific_energy', 'specific_energy_spectrum', 'specific_energy_spectrum_bin_edges'], sorted(g2)\n"
+            "assert g2['specific_energy'].dtype == np.float32 and g2['density'].dtype == np.float32 and g2['specific_energy'].shape == (1, 3, 5, 7)\n"
+            "assert g2['n_photons'].shape == (3, 5, 7) and g2['n_photons'].dtype.kind == 'i' and g2['n_photons'][...].max() > 100\n"
+            "assert not g2['density_diff'][...].any()\n"
+            "sp = g2['specific_energy_spectrum'][...]; assert sp.shape == (6, 1, 3, 5, 7) and sp.dtype == np.float32\n"
+            "np.testing.assert_allclose(g2['specific_energy_spectrum_bin_edges'][...], np.logspace(10., 16., 7), rtol=1e-12)\n"
+            "se = g2['specific_energy'][...]; ok = sp.sum(axis=0) > 0\n"
+            "assert ok.mean() > 0.9 and np.all(sp.sum(axis=0)[ok] <= se[ok] * 1.0001)\n"
+            "p1, p2 = f['Peeled/group_00001'], f['Peeled/group_00002']\n"
+            "assert p1.attrs['use_filters'] == b'yes' and p1.attrs['n_filt'] == 1 and p1['filt_nu0'].shape == (1,)\n"
+            "assert p1['images'].dtype == np.float32 and p1['images'].shape == (1, 1, 2, 5, 4, 1) and 'numin' not in p1['images'].attrs\n"
+            "assert p2['images'].dtype == np.float64 and 'numin' in p2['images'].attrs and p2['seds'].shape == (1, 1, 1, 2, 4)\n"
+            "assert float(p1['images'][...].sum()) > 0 and float(p2['seds'][...].sum()) > 0\n") % out
+    subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+    keep = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(keep):
+        shutil.copy(out, os.path.join(keep, "car_options.gpu.rtout"))

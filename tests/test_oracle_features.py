@@ -201,3 +201,49 @@ def test_convergence_value_is_the_nint_quantile():
     st, v = o.convergence_value_against(b, 99.0)
     assert st == 1 and v == 0.0
     o.close()
+
+
+def filter_image_sums_MJy_sr(prob, images):
+    """Sum over views and pixels of the image in MJy/sr at distance 1, per filter: the conversion of the reference's
+    ModelOutput.get_image(units='MJy/sr', distance=1) (hyperion/model/model_output.py:753-804) applied to the .rtout cube."""
+    g = prob.peeled[0]
+    nu0 = np.array([f[2] for f in g.filters])
+    pix = (abs(np.arctan(g.x_max) - np.arctan(g.x_min)) / g.n_x) * (abs(np.arctan(g.y_max) - np.arctan(g.y_min)) / g.n_y)
+    return images[0, 0].sum(axis=(0, 1, 2)) * 1.e17 / nu0 / pix / (4.0 * np.pi)
+
+
+def blackbody_filter_ratio(prob, T=6000.0):
+    """(int b_nu tn_2 dnu / nu0_2) / (int b_nu tn_1 dnu / nu0_1) for a blackbody: what the two filter planes must be to each
+    other when the same extinction applies to both (grey dust)."""
+    h, k = 6.6260755e-27, 1.380658e-16
+    out = []
+    for nu, tr, nu0 in prob.peeled[0].filters:
+        x = np.linspace(nu[0], nu[-1], 20001)
+        b = x ** 3 / np.expm1(h * x / (k * T))
+        out.append(np.sum(0.5 * (b[1:] * np.interp(x[1:], nu, tr) + b[:-1] * np.interp(x[:-1], nu, tr)) * np.diff(x)) / nu0)
+    return out[1] / out[0]
+
+
+def check_filter_known_answers(prob, z, images):
+    got = filter_image_sums_MJy_sr(prob, images)
+    assert got[0] == pytest.approx(z["golden/image_sum_MJy_sr"][0], rel=0.1)
+    assert got[1] / got[0] == pytest.approx(blackbody_filter_ratio(prob), rel=0.03)
+
+
+def test_filters_known_answer_of_the_reference():
+    """hyperion/model/tests/test_filters.py:96-100 (test_image_values): the reference's own number for the first filter of its
+    two-filter model, 3438.06 MJy/sr summed over the image (rtol 0.1 there, with 1000 packets).  Its number for the second
+    filter (2396.48) is NOT reproduced: the ratio of the two planes must be the ratio of the blackbody folded with the two
+    normalised transmission curves of the input (grey dust: same extinction), 0.475 with the curves the reference front-end
+    writes today, and the stored pair has 0.697 -- that number predates the current filter normalisation of
+    hyperion/filter/filter.py:103-114.  The second plane is therefore pinned on the analytic ratio."""
+    from hyperion_amd.images import finalize_peeled
+    prob, z = golden_problem("car_filters.npz")
+    assert len(prob.peeled[0].filters) == 2 and prob.config.n_initial_iter == 0
+    np.testing.assert_allclose([f[2] for f in prob.peeled[0].filters], z["golden/filter_nu0"], rtol=1e-8)
+    o = Oracle(prob)
+    raw, _ = o.final_iteration(40000)
+    o.close()
+    cubes = finalize_peeled(prob.peeled[0], raw[0])
+    assert cubes["images"].shape == (1, 1, 3, 20, 10, 2)          # compute_stokes is off by default
+    check_filter_known_answers(prob, z, cubes["images"])
