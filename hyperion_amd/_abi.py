@@ -56,6 +56,7 @@ class GridDesc(C.Structure):
         ("vor_idx", C.POINTER(C.c_int32)), ("vor_neighs", C.POINTER(C.c_int32)), ("vor_box", C.c_double * 6),
         ("n_amr_levels", C.c_int32), ("n_amr_grids", C.c_int32),
         ("amr_level", C.POINTER(C.c_int32)), ("amr_n", C.POINTER(C.c_int32)), ("amr_bounds", _dp),
+        ("vor_bb", _dp),
     ]
 
 
@@ -161,6 +162,8 @@ class MarshalledProblem:
             d.grid.vor_neighs = nei.ctypes.data_as(C.POINTER(C.c_int32))
             for k in range(6):
                 d.grid.vor_box[k] = float(prob.vor_box[k])
+            if prob.vor_bb is not None:
+                d.grid.vor_bb = arr(np.asarray(prob.vor_bb, dtype=np.float64).reshape(-1, 6))
         elif prob.grid_type == "amr":
             d.grid.type = 4
             lev = np.ascontiguousarray(prob.amr_level, dtype=np.int32)

@@ -138,6 +138,7 @@ struct DProblem {
     const int *vor_idx, *vor_neigh;       // CSR neighbour lists (ids >= 0, walls -1..-6)
     const int *vor_seed;                  // [vor_g^3] start site of the nearest-site walk
     const double *vor_volume;             // [n_cells]
+    const double *vor_bb;                 // [n_cells][6] bb_min, bb_max of the cells (random_position_cell) or null
     double vor_box[6];
     int vor_g, pad4;
     const AmrGrid *amr_grids;             // amr: [n_amr_grids], level by level

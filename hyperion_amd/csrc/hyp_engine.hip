@@ -183,7 +183,7 @@ struct hyp_engine {
     double *d_blob = nullptr;
     OctCell *d_oct_cells = nullptr;
     int *d_oct_children = nullptr;
-    double *d_vor_sites = nullptr, *d_vor_volume = nullptr;
+    double *d_vor_sites = nullptr, *d_vor_volume = nullptr, *d_vor_bb = nullptr;
     unsigned int *d_mask_map = nullptr;
     bool ray_pending = false;
     AmrGrid *d_amr_grids = nullptr; int *d_amr_go = nullptr, *d_amr_cell_grid = nullptr; double *d_amr_walls = nullptr;
@@ -254,6 +254,9 @@ struct hyp_engine {
     unsigned int *d_pda_cells = nullptr, *d_pda_hp = nullptr;    // hp: [count | offsets (+1) | cursor], n_hp + 1 entries each
     double *d_pda_emean = nullptr, *d_pda_coef = nullptr;
     size_t pda_coef_alloc = 0;
+    unsigned int *d_pda_id = nullptr;                            // [n_cells] index of a cell in the PDA list (0xffffffff: not one)
+    double *d_pda_a = nullptr, *d_pda_b = nullptr, *d_pda_f = nullptr;   // dense system of the Gauss pivot branch
+    size_t pda_dense_alloc = 0;
     PdaCtl *d_pda_ctl = nullptr;
     int pda_last_cells = 0, pda_last_outer = 0, pda_last_sweeps = 0;
     double *d_prev_se = nullptr, *d_ratio = nullptr;
@@ -545,6 +548,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
     free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
+    free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
     free_dev(h->d_mask_map);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
@@ -558,6 +562,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
     free_dev(h->d_nphot); free_dev(h->d_last_id); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
     free_dev(h->d_pda_mask); free_dev(h->d_pda_cells); free_dev(h->d_pda_hp); free_dev(h->d_pda_emean); free_dev(h->d_pda_coef);
+    free_dev(h->d_pda_id); free_dev(h->d_pda_a); free_dev(h->d_pda_b); free_dev(h->d_pda_f);
     free_dev(h->d_pda_ctl); free_dev(h->d_prev_se); free_dev(h->d_ratio); free_dev(h->d_conv_ctl);
     if (h->h_ctl) (void)hipHostFree(h->h_ctl);
     for (int i = 1; i < 4; i++) if (h->pool_stream[i]) (void)hipStreamDestroy(h->pool_stream[i]);
@@ -1391,6 +1396,11 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMemcpy(h->d_vor_neigh, pr->grid.vor_neighs, sizeof(int) * nn, hipMemcpyHostToDevice));
         HIPC(hipMalloc(&h->d_vor_seed, sizeof(int) * vor_seed.size()));
         HIPC(hipMemcpy(h->d_vor_seed, vor_seed.data(), sizeof(int) * vor_seed.size(), hipMemcpyHostToDevice));
+        if (pr->grid.vor_bb) {
+            HIPC(hipMalloc(&h->d_vor_bb, sizeof(double) * 6 * nc));
+            HIPC(hipMemcpy(h->d_vor_bb, pr->grid.vor_bb, sizeof(double) * 6 * nc, hipMemcpyHostToDevice));
+        }
+        P.vor_bb = h->d_vor_bb;
         P.vor_sites = h->d_vor_sites; P.vor_volume = h->d_vor_volume; P.vor_idx = h->d_vor_idx;
         P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g;
         for (int k = 0; k < 6; k++) P.vor_box[k] = pr->grid.vor_box[k];
@@ -1708,9 +1718,9 @@ static int check_device_error(hyp_handle h)
 // diffusion equation for the mean intensity in the cells that saw fewer than max(30, 0.5 % of the mean) packets:
 // with fewer than 10 000 such cells by Gaussian elimination, otherwise by Gauss-Seidel sweeps in cell order down to
 // a relative change of 1e-4 per sweep, and repeats with the updated Rosseland means until the specific energy moves
-// by less than 1e-5 / 1e-4.  Here both branches are Gauss-Seidel sweeps ordered by hyperplanes (pda_gs_kernel): the
-// iterative branch reproduces the reference's sweeps exactly; the Gauss pivot branch is iterated to 1e-12 instead,
-// which determines the solution of the same linear system far below the 1e-5 of the outer loop.
+// by less than 1e-5 / 1e-4.  Here: the Gauss pivot branch is a dense elimination on the device (pda_dense_* kernels;
+// rows are diagonally dominant, no pivoting, zero rows skipped), the iterative branch Gauss-Seidel sweeps ordered by
+// hyperplanes (pda_gs_kernel), which reproduce the reference's sequential sweeps exactly.
 static int solve_pda(hyp_handle h)
 {
     h->pda_last_cells = 0; h->pda_last_outer = 0; h->pda_last_sweeps = 0;
@@ -1752,14 +1762,37 @@ static int solve_pda(hyp_handle h)
         h->pda_coef_alloc = (size_t)n_pda * 6;
     }
     const bool exact = n_pda < 10000;
-    const double tolerance = exact ? 1.e-5 : 1.e-4, gs_tol = exact ? 1.e-12 : 1.e-4;
+    const double tolerance = exact ? 1.e-5 : 1.e-4, gs_tol = 1.e-4;
     const int cb = (int)std::min<size_t>((n_pda + 255) / 256, (size_t)h->n_cu * 4);
+    if (exact) {
+        if (!h->d_pda_id && hipMalloc(&h->d_pda_id, sizeof(unsigned int) * nc) != hipSuccess) return h->set_error("cannot allocate the PDA index");
+        if ((size_t)n_pda > h->pda_dense_alloc) {
+            free_dev(h->d_pda_a); free_dev(h->d_pda_b); free_dev(h->d_pda_f);
+            if (hipMalloc(&h->d_pda_a, sizeof(double) * (size_t)n_pda * n_pda) != hipSuccess || hipMalloc(&h->d_pda_b, sizeof(double) * n_pda) != hipSuccess ||
+                hipMalloc(&h->d_pda_f, sizeof(double) * n_pda) != hipSuccess) return h->set_error("cannot allocate the dense PDA system");
+            h->pda_dense_alloc = n_pda;
+        }
+        (void)hipMemsetAsync(h->d_pda_id, 0xff, sizeof(unsigned int) * nc, h->stream);
+        pda_id_kernel<<<cb, 256, 0, h->stream>>>(h->d_pda_cells, n_pda, h->d_pda_id);
+    }
     for (int outer = 1; outer <= 10000; outer++) {
         h->pda_last_outer = outer;
         pda_coef_kernel<<<cb, 256, 0, h->stream>>>(h->d_problem, h->d_pda_cells, n_pda, h->d_specific_energy, h->d_density, h->d_pda_emean,
                                                   h->d_pda_coef, exact ? 1 : 0);
-        pda_gs_kernel<<<1, 1024, 0, h->stream>>>(h->d_problem, h->d_pda_cells, hp_off, n_hp, h->d_pda_coef, h->d_pda_emean, gs_tol,
-                                                 20000000, h->d_pda_ctl);
+        if (exact) {
+            (void)hipMemsetAsync(h->d_pda_a, 0, sizeof(double) * (size_t)n_pda * n_pda, h->stream);
+            pda_dense_build_kernel<<<cb, 256, 0, h->stream>>>(h->d_problem, h->d_pda_cells, n_pda, h->d_pda_id, h->d_pda_coef, h->d_pda_emean,
+                                                             h->d_pda_a, h->d_pda_b);
+            for (unsigned int k = 0; k + 1 < n_pda; k++) {
+                const unsigned int rows = n_pda - k - 1;
+                pda_elim_factor_kernel<<<(rows + 255) / 256, 256, 0, h->stream>>>(h->d_pda_a, n_pda, k, h->d_pda_f);
+                pda_elim_update_kernel<<<dim3(std::min(8u, (rows + 255) / 256), rows), 256, 0, h->stream>>>(h->d_pda_a, h->d_pda_b, n_pda, k, h->d_pda_f);
+            }
+            pda_backsub_kernel<<<1, 1024, 0, h->stream>>>(h->d_pda_a, h->d_pda_b, n_pda);
+            pda_scatter_solution_kernel<<<cb, 256, 0, h->stream>>>(h->d_pda_cells, n_pda, h->d_pda_b, h->d_pda_emean);
+        } else
+            pda_gs_kernel<<<1, 1024, 0, h->stream>>>(h->d_problem, h->d_pda_cells, hp_off, n_hp, h->d_pda_coef, h->d_pda_emean, gs_tol,
+                                                     20000000, h->d_pda_ctl);
         (void)hipMemsetAsync(&h->d_pda_ctl->maxdiff_bits, 0, sizeof(unsigned long long), h->stream);
         pda_update_kernel<<<cb, 256, 0, h->stream>>>(h->d_problem, h->d_pda_cells, n_pda, h->d_pda_emean, h->d_specific_energy, h->d_spec,
                                                     h->n_bins, h->d_pda_ctl);

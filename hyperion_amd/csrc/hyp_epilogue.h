@@ -274,6 +274,90 @@ __global__ __launch_bounds__(1024) void pda_gs_kernel(const DProblem *__restrict
     if (threadIdx.x == 0) ctl->sweeps = sweep;
 }
 
+// solve_pda_indiv_exact :185-256 -- fewer than 10 000 PDA cells: the dense system  a x = b  with one row per cell's
+// equation  sum_walls c (e_next - e_curr) = 0  (unknown neighbours on the left, Monte Carlo neighbours on the right),
+// solved by Gaussian elimination.  Every row is diagonally dominant (|a_qq| = sum of its coefficients >= the sum of
+// its off-diagonal entries), so the elimination needs no pivoting.  The matrix is sparse (7-point stencil); rows whose
+// entry in the pivot column is zero are skipped, so the work follows the fill-in, not n^3.
+__global__ void pda_dense_build_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
+                                       const unsigned int *__restrict__ id_of_cell, const double *__restrict__ coef,
+                                       const double *__restrict__ e_mean, double *__restrict__ a, double *__restrict__ b)
+{
+    const DProblem &P = *Pp;
+    const int n_walls = P.grid_type == 1 ? 6 : P.n_dim * 2;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pda; q += step) {
+        const size_t ic = cells[q];
+        int i[3];
+        pda_cell_coords(P, ic, i);
+        double diag = 0.0, rhs = 0.0;
+        for (int wall = 0; wall < n_walls; wall++) {
+            int j[3];
+            const size_t jc = pda_neighbour(P, i, wall, j);
+            const double c = coef[6 * q + wall];
+            diag -= c;
+            const unsigned int qn = id_of_cell[jc];
+            if (qn != 0xffffffffu) a[q * n_pda + qn] += c;       // (two walls can lead to the same cell across a 2-cell phi seam)
+            else rhs -= c * e_mean[jc];
+        }
+        a[q * n_pda + q] += diag;
+        b[q] = rhs;
+    }
+}
+
+__global__ void pda_id_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, unsigned int *__restrict__ id_of_cell)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pda; q += step) id_of_cell[cells[q]] = (unsigned int)q;
+}
+
+// elimination step k: factors f[r] = a[r][k] / a[k][k] for the rows below the pivot ...
+__global__ void pda_elim_factor_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, double *__restrict__ f)
+{
+    const unsigned int r = k + 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) f[r] = a[(size_t)r * n + k] / a[(size_t)k * n + k];
+}
+// ... and row r -= f[r] * row k (one workgroup row of the grid per matrix row; rows with a zero factor return at once)
+__global__ void pda_elim_update_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const double *__restrict__ f)
+{
+    const unsigned int r = k + 1 + blockIdx.y;
+    const double fr = f[r];
+    if (fr == 0.0) return;
+    const double *pk = a + (size_t)k * n;
+    double *pr = a + (size_t)r * n;
+    for (unsigned int c = k + 1 + blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+        const double v = pk[c];
+        if (v != 0.0) pr[c] -= fr * v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { b[r] -= fr * b[k]; pr[k] = 0.0; }
+}
+// back substitution, one workgroup: x overwrites b
+__global__ __launch_bounds__(1024) void pda_backsub_kernel(const double *__restrict__ a, double *__restrict__ b, unsigned int n)
+{
+    __shared__ double red[16];
+    for (unsigned int kk = n; kk-- > 0;) {
+        const double *row = a + (size_t)kk * n;
+        double s = 0.0;
+        for (unsigned int c = kk + 1 + threadIdx.x; c < n; c += blockDim.x) { const double v = row[c]; if (v != 0.0) s += v * b[c]; }
+        s = wave_sum(s);
+        if (__lane_id() == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (unsigned int w = 0; w < blockDim.x / 64; w++) t += red[w];
+            b[kk] = (b[kk] - t) / row[kk];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+__global__ void pda_scatter_solution_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, const double *__restrict__ x,
+                                            double *__restrict__ e_mean)
+{
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pda; q += step) e_mean[cells[q]] = x[q];
+}
+
 // update_specific_energy :36-70 for the PDA cells + the rescaling of their spectrum; the largest relative change
 __global__ void pda_update_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
                                   const double *__restrict__ e_mean, double *__restrict__ se, double *__restrict__ spec, int n_bins,

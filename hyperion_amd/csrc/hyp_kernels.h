@@ -737,7 +737,7 @@ __device__ __forceinline__ double random_planck_frequency(Rng &g, double T)
 }
 
 template <int GEOM>
-__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3]);
+__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3], Rng &g);
 __device__ __forceinline__ double dust_sample_j_nu(const DDust &D, int jid, double frac, double xi);
 __device__ __forceinline__ double dust_emit_probability(const DProblem &P, const DDust &D, int jid, double frac);
 
@@ -799,7 +799,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (xi < S.map_cdf[mid]) hi = mid; else lo = mid + 1; }
         map_cell = lo;
         const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
-        if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
+        if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r, g)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
         random_sphere_angle(g, p.a);
     } else if (S.type == 8) {
         // emit_from_point_collection: source_type.f90:570-598
@@ -1735,9 +1735,10 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
     }
 }
 
-// random_position_cell: cartesian_3d.f90:383-394, octree.f90:397-408, amr.f90:728-741
+// random_position_cell: cartesian_3d.f90:383-394, octree.f90:397-408, amr.f90:728-741, voronoi.f90:285-310.
+// (x, y, z) are three uniforms already drawn by the caller; only the Voronoi rejection loop draws more from g.
 template <int GEOM>
-__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3])
+__device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t ic, double x, double y, double z, double r[3], Rng &g)
 {
     if (GEOM == GEOM_CAR) {
         int i1 = (int)(ic % P.n1);
@@ -1768,7 +1769,28 @@ __device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t i
         return true;
     }
     if (GEOM == GEOM_SPH || GEOM == GEOM_CYL) { polar_random_position<GEOM>(P, ic, x, y, z, r); return true; }
-    return false;      // voronoi: rejection sampling in the reference, not built
+    if (GEOM == GEOM_VOR && P.vor_bb) {
+        // positions uniform in the cell's bounding box until one lies in the cell (the reference asks its kd-tree for the
+        // nearest site; a point is in cell ic iff none of the cell's neighbours has its site closer)
+        const double *bb = P.vor_bb + 6 * ic;
+        const double s0 = P.vor_sites[3 * ic], s1 = P.vor_sites[3 * ic + 1], s2 = P.vor_sites[3 * ic + 2];
+        for (int trial = 0; trial < 1000000; trial++) {
+            if (trial) { x = rng_uniform(g); y = rng_uniform(g); z = rng_uniform(g); }
+            r[0] = bb[0] + x * (bb[3] - bb[0]); r[1] = bb[1] + y * (bb[4] - bb[1]); r[2] = bb[2] + z * (bb[5] - bb[2]);
+            const double a0 = r[0] - s0, a1 = r[1] - s1, a2 = r[2] - s2;
+            const double d0 = (a0 * a0 + a1 * a1) + a2 * a2;
+            bool inside = true;
+            for (int k = P.vor_idx[ic]; k < P.vor_idx[ic + 1] && inside; k++) {
+                const int j = P.vor_neigh[k];
+                if (j < 0) continue;
+                const double b0 = r[0] - P.vor_sites[3 * j], b1 = r[1] - P.vor_sites[3 * j + 1], b2 = r[2] - P.vor_sites[3 * j + 2];
+                if ((b0 * b0 + b1 * b1) + b2 * b2 < d0) inside = false;
+            }
+            if (inside) return true;
+        }
+        return false;      // "too many samples"
+    }
+    return false;      // voronoi without bounding boxes
 }
 
 // Polychromatic peel-off of a freshly emitted packet: the whole binned spectrum of its emitter,
@@ -1935,7 +1957,7 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
                 long long im = (long long)ceil(xi * (double)P.n_masked); if (im < 1) im = 1;
                 const size_t ic = P.mask_map[im - 1];
                 const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
-                if (!random_position_cell<GEOM>(P, ic, x, y, z, r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); active = false; }
+                if (!random_position_cell<GEOM>(P, ic, x, y, z, r, g)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); active = false; }
                 Angle a; random_sphere_angle(g, a);         // drawn like the reference, not used by the peel-off
                 const size_t k = ic * (size_t)nd + (size_t)(d - 1);
                 const double eat = P.energy_abs_tot[d - 1];
@@ -1988,7 +2010,7 @@ __device__ __forceinline__ bool emit_mono_dust(const DProblem &P, const Walls &W
     size_t lo = 0, hi = (size_t)P.n_cells - 1;
     while (lo < hi) { const size_t mid = (lo + hi) >> 1; if (xi < cdf[mid]) hi = mid; else lo = mid + 1; }
     const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
-    if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
+    if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r, g)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
     random_sphere_angle(g, p.a);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;

@@ -239,6 +239,7 @@ class Problem:
     vor_idx: Optional[np.ndarray] = None
     vor_neighs: Optional[np.ndarray] = None
     vor_box: tuple = (0.0, 1.0, 0.0, 1.0, 0.0, 1.0)
+    vor_bb: Optional[np.ndarray] = None     # (n, 6) bb_min, bb_max of the cells (table `cells`): random_position_cell
     # grid_type 'amr' (src/grid/grid_geometry_amr.f90:111-180): the grids of all levels, level by
     # level: amr_level (g,) 1-based, amr_n (g,3) = n1,n2,n3, amr_bounds (g,6) = xmin,xmax,...;
     # density (n_dust, n_cells) with the cells of grid after grid, x fastest
@@ -377,7 +378,7 @@ class Problem:
             arrays["config/spectrum_bin_edges"] = np.asarray(self.config.spectrum_bin_edges, dtype=float)
         if self.refined is not None:
             arrays["refined"] = self.refined
-        for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds"):
+        for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "vor_bb", "amr_level", "amr_n", "amr_bounds"):
             if getattr(self, k) is not None:
                 arrays[k] = getattr(self, k)
         arrays["density"] = self.density
@@ -498,4 +499,4 @@ class Problem:
                    oct_center=tuple(meta.get("oct_center", (0.0, 0.0, 0.0))),
                    oct_half=tuple(meta.get("oct_half", (1.0, 1.0, 1.0))),
                    vor_box=tuple(meta.get("vor_box", (0.0, 1.0, 0.0, 1.0, 0.0, 1.0))),
-                   **{k: z[k] for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "amr_level", "amr_n", "amr_bounds") if k in z.files})
+                   **{k: z[k] for k in ("vor_sites", "vor_volume", "vor_idx", "vor_neighs", "vor_bb", "amr_level", "amr_n", "amr_bounds") if k in z.files})

@@ -162,6 +162,8 @@ def read_rtin(path):
             cells = geo["cells"][...]
             extra = dict(vor_sites=np.asarray(cells["coordinates"], dtype=float),
                          vor_volume=np.asarray(cells["volume"], dtype=float),
+                         vor_bb=np.concatenate([np.asarray(cells["bb_min"], dtype=float), np.asarray(cells["bb_max"], dtype=float)], axis=1)
+                         if "bb_min" in cells.dtype.names else None,
                          vor_idx=np.asarray(geo["sparse_idx"][...]).astype(np.int32),
                          vor_neighs=np.asarray(geo["sparse_neighs"][...]).astype(np.int32),
                          vor_box=tuple(float(ga[k]) for k in ("xmin", "xmax", "ymin", "ymax", "zmin", "zmax")))

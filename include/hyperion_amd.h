@@ -125,6 +125,10 @@ typedef struct hyp_grid_desc {
     const int32_t *amr_level;   /* [n_amr_grids] 1-based level of each grid, non-decreasing */
     const int32_t *amr_n;       /* [n_amr_grids][3] attrs n1,n2,n3 */
     const double *amr_bounds;   /* [n_amr_grids][6] attrs xmin,xmax,ymin,ymax,zmin,zmax */
+    /* voronoi: bounding boxes of the cells, [n_cells][6] = bb_min[3], bb_max[3] of table `cells`, or NULL.  Needed by
+     * random_position_cell (src/grid/grid_geometry_voronoi.f90:285-310: rejection sampling in the box) -- map sources,
+     * raytraced / monochromatic dust emission */
+    const double *vor_bb;
 } hyp_grid_desc;
 
 /* root attributes -- src/main/setup_rt.f90:38-302 */

@@ -423,6 +423,7 @@ struct orc_state {
     double *vsite;              /* [n][3] */
     int32_t *vidx, *vneigh;
     double vbox[6];
+    double *vbb;                /* [n][6] bb_min, bb_max of the cells (table `cells`), or NULL */
     int vg;                     /* seed grid for the nearest-site search: vg^3 cells */
     int32_t *vseed;
     /* amr: grid_geometry_amr.f90 */
@@ -1010,6 +1011,7 @@ static int voronoi_setup(orc_state *st, const orc_grid_desc *gd)
     }
     st->n_cells = n;
     st->vsite = dup(gd->vor_sites, 3 * n);
+    st->vbb = gd->vor_bb ? dup(gd->vor_bb, 6 * n) : NULL;
     st->vidx = malloc(sizeof(int32_t) * (n + 1)); memcpy(st->vidx, gd->vor_idx, sizeof(int32_t) * (n + 1));
     size_t nn = (size_t)st->vidx[n];
     st->vneigh = malloc(sizeof(int32_t) * (nn ? nn : 1)); memcpy(st->vneigh, gd->vor_neighs, sizeof(int32_t) * nn);
@@ -1628,6 +1630,7 @@ void orc_destroy(orc_state *st)
     if (st->peeled) { for (int g = 0; g < st->n_groups; g++) peeled_free(&st->peeled[g]); free(st->peeled); }
     free(st->lum_pdf); free(st->lum_cdf);
     free(st->density); free(st->specific_energy); free(st->specific_energy_add);
+    free(st->vbb);
     free(st->n_photons); free(st->nu_edges); free(st->log_nu_edges); free(st->spec); free(st->spec_sum); free(st->spec_add); free(st->jnu_bin_frac);
     free(st->specific_energy_sum); free(st->jnu_var_id); free(st->jnu_var_frac);
     free(st);
@@ -3941,7 +3944,22 @@ static int random_position_cell(const orc_state *st, size_t ic, photon_t *p, rng
         for (int a = 0; a < 3; a++) p->r[a] = u[a] * (gr->w[a][ci[a] + 1] - gr->w[a][ci[a]]) + gr->w[a][ci[a]];
         return 0;
     }
-    return -1;   /* voronoi: rejection sampling in the reference, not restated */
+    if (st->grid_type == GRID_VOR && st->vbb) {
+        /* grid_geometry_voronoi.f90:285-310: positions uniform in the cell's bounding box until one lies in the cell.  The
+         * reference asks its kd-tree for the nearest site; a point is in cell ic iff no neighbour's site is closer. */
+        const double *bb = st->vbb + 6 * ic;
+        for (int trial = 0; trial < 1000000; trial++) {
+            if (trial) { x = rng_uniform(g); y = rng_uniform(g); z = rng_uniform(g); }
+            p->r[0] = bb[0] + x * (bb[3] - bb[0]); p->r[1] = bb[1] + y * (bb[4] - bb[1]); p->r[2] = bb[2] + z * (bb[5] - bb[2]);   /* random_uni */
+            const double d0 = vdist2(st, (int32_t)ic, p->r);
+            int inside = 1;
+            for (int32_t k = st->vidx[ic]; k < st->vidx[ic + 1] && inside; k++)
+                if (st->vneigh[k] >= 0 && vdist2(st, st->vneigh[k], p->r) < d0) inside = 0;
+            if (inside) return 0;
+        }
+        return -1;   /* "too many samples" */
+    }
+    return -1;   /* voronoi without bounding boxes */
 }
 
 /* thermal part :96-126 with emit_from_grid (grid_physics_3d.f90:691-753) */

@@ -84,3 +84,20 @@ def pda_block_problem(n=14, tau_cell=100.0, n_photons=30000, pda=True, grid="car
     prob.config.pda = pda
     prob.config.output_n_photons = "last"
     return prob
+
+
+def voronoi_big_problem(n_photons=10_000_000, n_iter=1, two_species=True):
+    """BASELINE configs[4] on a REAL tessellation: the voro++ cells of 100 000 random sites in a 2 pc box
+    (tests/golden/vor_big.npz, computed by the reference front-end; ~15.5 neighbours per cell), two anisotropically
+    scattering polarising dust species, a point source and an external box source."""
+    from hyperion_amd.benchmark import make_voronoi_lattice_problem
+    z = np.load(os.path.join(GOLDEN, "vor_big.npz"), allow_pickle=False)
+    tpl = make_voronoi_lattice_problem(n=2, n_photons=n_photons, n_iter=n_iter, two_species=two_species)     # dust, sources, config
+    n = z["sites"].shape[0]
+    tau = 1.0
+    rho = np.full((1, n), tau / PC)
+    if two_species:
+        rho = np.vstack([rho * 0.6, rho * 0.8])
+    return Problem(walls=[], density=rho, dust=tpl.dust, sources=tpl.sources, config=tpl.config, grid_type="vor",
+                   vor_sites=z["sites"], vor_volume=z["volume"], vor_idx=z["idx"], vor_neighs=z["neighs"],
+                   vor_box=tuple(z["box"]), vor_bb=np.concatenate([z["bb_lo"].astype(np.float64), z["bb_hi"].astype(np.float64)], axis=1))

@@ -618,7 +618,100 @@ def filters_fixture(tmp):
     print("wrote", keep, os.path.getsize(keep))
 
 
+def voronoi_fixtures(tmp, big=True):
+    """Voronoi INPUTS (the reference ships no Voronoi regression output): tessellations computed by the reference
+    front-end (voro++ through hyperion.grid.VoronoiGrid), written and read back through the .rtin contract, including the
+    cells' bounding boxes (random_position_cell).  vor_big.npz: 100 000 random sites (BASELINE config 5 at a size where
+    the walk is measured), geometry only -- the test builds the model around it."""
+    # --- Voronoi inputs (BASELINE config 5, small) ----------------------------------
+    np.random.seed(141412)
+    n = 400
+    x, y, z = [np.random.uniform(-pc, pc, n) for _ in range(3)]
+    g = VoronoiGrid(x, y, z, xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
+    nu = [3.e7, 1.e10, 2.e11, 2.e12, 2.e13, 2.e14, 2.e15, 2.e16, 2.e17]
+    chi = [1.e-11, 2.e-6, 2.e-3, 0.2, 13., 90., 1000., 700., 700.]
+    alb = [0., 0., 0., 0., 0.1, 0.5, 0.4, 0.4, 0.4]
+    m = Model()
+    m.set_grid(g)
+    for gg, pl, scale in ((0.6, 0.5, 1.0), (0.3, 0.2, 0.5)):
+        d = HenyeyGreensteinDust(nu, alb, np.array(chi) * scale, np.repeat(gg, 9), np.repeat(pl, 9))
+        d.set_lte_emissivities(n_temp=20, temp_min=0.1, temp_max=10000.)
+        m.add_density_grid(np.random.random(g.shape) * 2.e-21, d)
+    s = m.add_point_source()
+    s.luminosity = lsun
+    s.temperature = 6000.
+    s.position = (0.1 * pc, -0.05 * pc, 0.2 * pc)
+    e = m.add_external_box_source()
+    e.luminosity = 2 * lsun
+    e.temperature = 3000.
+    e.bounds = [[-pc, pc], [-pc, pc], [-pc, pc]]
+    m.set_n_photons(initial=10000, imaging=10000)
+    i_p = m.add_peeled_images()
+    i_p.set_wavelength_range(4, 0.1, 1000.)
+    i_p.set_viewing_angles([40., 120.], [30., 250.])
+    i_p.set_image_size(8, 8)
+    i_p.set_image_limits(-1.5 * pc, 1.5 * pc, -1.5 * pc, 1.5 * pc)
+    i_p.set_aperture_radii(3, 0.3 * pc, 2 * pc)
+    i_p.set_track_origin('basic')
+    i_p.set_stokes(True)
+    path = os.path.join(tmp, "vor5.rtin")
+    m.write(path, copy=True)
+    read_rtin(path).to_npz(os.path.join(HERE, "vor_config5.npz"))
+    print("wrote", os.path.join(HERE, "vor_config5.npz"))
+
+    k = 6
+    c = (np.arange(k) + 0.5) / k * 2 - 1
+    zz, yy, xx = np.meshgrid(c, c, c, indexing="ij")
+    jit = np.random.uniform(-1e-3, 1e-3, (3, k ** 3))
+    g = VoronoiGrid((xx.ravel() + jit[0]) * pc, (yy.ravel() + jit[1]) * pc, (zz.ravel() + jit[2]) * pc,
+                    xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
+    d = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
+    d.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)
+    m = Model()
+    m.set_grid(g)
+    m.add_density_grid(np.ones(g.shape) / pc, d)
+    s = m.add_point_source()
+    s.luminosity = lsun
+    s.temperature = 6000.
+    s.position = (0.03 * pc, 0.02 * pc, 0.01 * pc)
+    m.set_n_photons(initial=10000, imaging=0)
+    path = os.path.join(tmp, "vorl.rtin")
+    m.write(path, copy=True)
+    read_rtin(path).to_npz(os.path.join(HERE, "vor_lattice.npz"))
+    print("wrote", os.path.join(HERE, "vor_lattice.npz"))
+
+    if big:
+        np.random.seed(20240917)
+        n = 100000
+        x, y, z = [np.random.uniform(-pc, pc, n) for _ in range(3)]
+        g = VoronoiGrid(x, y, z, xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
+        d = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
+        d.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)
+        m = Model()
+        m.set_grid(g)
+        m.add_density_grid(np.ones(g.shape) / pc, d)
+        s = m.add_point_source()
+        s.luminosity = lsun
+        s.temperature = 6000.
+        s.position = (0.03 * pc, 0.02 * pc, 0.01 * pc)
+        m.set_n_photons(initial=10000, imaging=0)
+        path = os.path.join(tmp, "vorb.rtin")
+        m.write(path, copy=True)
+        prob = read_rtin(path)
+        # geometry only; the sites are stored as float64, the boxes as float32 rounded outwards (they only have to contain the
+        # cells), volumes as float64 -- about 9 MB
+        bb = prob.vor_bb
+        lo = np.nextafter(bb[:, :3].astype(np.float32), np.float32(-np.inf)); hi = np.nextafter(bb[:, 3:].astype(np.float32), np.float32(np.inf))
+        np.savez_compressed(os.path.join(HERE, "vor_big.npz"), sites=prob.vor_sites, volume=prob.vor_volume, idx=prob.vor_idx.astype(np.int32),
+                            neighs=prob.vor_neighs.astype(np.int32), bb_lo=lo, bb_hi=hi, box=np.array(prob.vor_box))
+        print("wrote", os.path.join(HERE, "vor_big.npz"), os.path.getsize(os.path.join(HERE, "vor_big.npz")))
+
+
 def main():
+    if "vor" in sys.argv[1:]:
+        with tempfile.TemporaryDirectory() as tmp:
+            voronoi_fixtures(tmp, big=True)
+        return
     if "filters" in sys.argv[1:]:
         with tempfile.TemporaryDirectory() as tmp:
             filters_fixture(tmp)
@@ -656,62 +749,7 @@ def main():
         if ONLY or RAY_ONLY:
             return
 
-        # --- Voronoi inputs (BASELINE config 5, small) ----------------------------------
-        np.random.seed(141412)
-        n = 400
-        x, y, z = [np.random.uniform(-pc, pc, n) for _ in range(3)]
-        g = VoronoiGrid(x, y, z, xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
-        nu = [3.e7, 1.e10, 2.e11, 2.e12, 2.e13, 2.e14, 2.e15, 2.e16, 2.e17]
-        chi = [1.e-11, 2.e-6, 2.e-3, 0.2, 13., 90., 1000., 700., 700.]
-        alb = [0., 0., 0., 0., 0.1, 0.5, 0.4, 0.4, 0.4]
-        m = Model()
-        m.set_grid(g)
-        for gg, pl, scale in ((0.6, 0.5, 1.0), (0.3, 0.2, 0.5)):
-            d = HenyeyGreensteinDust(nu, alb, np.array(chi) * scale, np.repeat(gg, 9), np.repeat(pl, 9))
-            d.set_lte_emissivities(n_temp=20, temp_min=0.1, temp_max=10000.)
-            m.add_density_grid(np.random.random(g.shape) * 2.e-21, d)
-        s = m.add_point_source()
-        s.luminosity = lsun
-        s.temperature = 6000.
-        s.position = (0.1 * pc, -0.05 * pc, 0.2 * pc)
-        e = m.add_external_box_source()
-        e.luminosity = 2 * lsun
-        e.temperature = 3000.
-        e.bounds = [[-pc, pc], [-pc, pc], [-pc, pc]]
-        m.set_n_photons(initial=10000, imaging=10000)
-        i_p = m.add_peeled_images()
-        i_p.set_wavelength_range(4, 0.1, 1000.)
-        i_p.set_viewing_angles([40., 120.], [30., 250.])
-        i_p.set_image_size(8, 8)
-        i_p.set_image_limits(-1.5 * pc, 1.5 * pc, -1.5 * pc, 1.5 * pc)
-        i_p.set_aperture_radii(3, 0.3 * pc, 2 * pc)
-        i_p.set_track_origin('basic')
-        i_p.set_stokes(True)
-        path = os.path.join(tmp, "vor5.rtin")
-        m.write(path, copy=True)
-        read_rtin(path).to_npz(os.path.join(HERE, "vor_config5.npz"))
-        print("wrote", os.path.join(HERE, "vor_config5.npz"))
-
-        k = 6
-        c = (np.arange(k) + 0.5) / k * 2 - 1
-        zz, yy, xx = np.meshgrid(c, c, c, indexing="ij")
-        jit = np.random.uniform(-1e-3, 1e-3, (3, k ** 3))
-        g = VoronoiGrid((xx.ravel() + jit[0]) * pc, (yy.ravel() + jit[1]) * pc, (zz.ravel() + jit[2]) * pc,
-                        xmin=-pc, xmax=pc, ymin=-pc, ymax=pc, zmin=-pc, zmax=pc)
-        d = IsotropicDust([3.e9, 3.e16], [0.5, 0.5], [1., 1.])
-        d.set_lte_emissivities(n_temp=10, temp_min=0.1, temp_max=1600.)
-        m = Model()
-        m.set_grid(g)
-        m.add_density_grid(np.ones(g.shape) / pc, d)
-        s = m.add_point_source()
-        s.luminosity = lsun
-        s.temperature = 6000.
-        s.position = (0.03 * pc, 0.02 * pc, 0.01 * pc)
-        m.set_n_photons(initial=10000, imaging=0)
-        path = os.path.join(tmp, "vorl.rtin")
-        m.write(path, copy=True)
-        read_rtin(path).to_npz(os.path.join(HERE, "vor_lattice.npz"))
-        print("wrote", os.path.join(HERE, "vor_lattice.npz"))
+        voronoi_fixtures(tmp, big=False)
 
         # --- layout of the golden .rtout (names, shapes, attribute types) ------
         import json

@@ -70,3 +70,54 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     e_gpu = (r.iterations[-1].specific_energy * w).sum()
     # (the absorbed luminosity of a 5000-packet iteration of this model scatters by ~10 %: 5.8e33 .. 7.4e33 over seeds and iterations)
     assert (z["golden/specific_energy_last"] * w).sum() == pytest.approx(e_gpu, rel=0.35)
+
+
+class _EngineRunner:
+    def __init__(self, prob):
+        self.e = hyperion_amd.Engine(prob)
+
+    def __call__(self, n, it):
+        return self.e.lucy_iteration(n, it)[0]
+
+    def close(self):
+        self.e.close()
+
+
+def test_pooled_bias_over_all_specific_energy_goldens():
+    """The HIP engine against all 20 specific-energy goldens x 5 iterations of the reference (Cartesian, octree, AMR,
+    spherical, cylindrical), pooled: the weighted mean ratio within 1 %, each grid type within 2.5 %."""
+    from test_oracle_golden import pooled_specific_energy_bias
+    mean, n, per = pooled_specific_energy_bias(_EngineRunner, n_packets=1000000)
+    assert n == 100
+    assert abs(mean - 1.0) < 0.01, (mean, per)
+    for grid, r in per.items():
+        assert abs(r - 1.0) < 0.025, (grid, r, per)
+
+
+@pytest.mark.parametrize("tau", [1000, 1000000])
+def test_pda_golden_pinte_specific_energy(tau):
+    """The reference's PDA outputs (test_pinte_specific_energy.tau=*) against K realisations of the whole run on the GPU:
+    same statistic as tests/test_oracle_features.py::test_pda_golden_pinte_specific_energy."""
+    from hyperion_amd.run import run_problem
+    prob, gold = golden_problem("pinte_specific_energy.tau=%d.npz" % tau)
+    prob.config.output_n_photons = "last"
+    K = 8
+    logs, nph = [], []
+    for seed in range(K):
+        prob.config.seed = -5000 - seed
+        r = run_problem(prob)
+        assert r.n_iterations == 3
+        logs.append(np.log10(r.iterations[-1].specific_energy[0, 0])); nph.append(r.iterations[-1].n_photons[0])
+    logs, nph = np.array(logs), np.array(nph).mean(axis=0)
+    g = np.log10(gold["golden/specific_energy_3"][0, 0])
+    rho = prob.density[0, 0]
+    mu, sd = logs.mean(axis=0), logs.std(axis=0, ddof=1)
+    z = (g - mu) / np.sqrt(sd ** 2 * (1 + 1.0 / K) + 1e-6)
+    interior = np.zeros(rho.shape, dtype=bool)
+    interior[1:-1, 1:-1] = True
+    pda_like = (nph < 30) & (rho > 0) & interior
+    sampled = (nph >= 300) & (rho > 0)
+    assert pda_like.sum() > 300 and sampled.sum() > 100
+    zc = np.clip(z, -6.0, 6.0)
+    assert abs(np.median(z[pda_like])) < 0.6 and (zc[pda_like] ** 2).mean() < 5.0 and (np.abs(z[pda_like]) > 6).mean() < 0.08
+    assert abs(np.median(z[sampled])) < 0.6 and (zc[sampled] ** 2).mean() < 3.0

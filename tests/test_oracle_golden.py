@@ -337,3 +337,48 @@ def test_pinte_benchmark_images_match_reference_golden(tau):
         assert abs(g.sum() - tot.mean()) < 5.0 * tot.std(ddof=1) + 0.02 * tot.mean()
     # the SED of the single aperture is the summed image
     np.testing.assert_allclose(z["golden/seds"][0, 0, :, 0, 0], gold[0, 0].sum(axis=(1, 2, 3)), rtol=1e-6)
+
+
+def pooled_specific_energy_bias(make_runner, n_packets=200000):
+    """Weighted-mean ratio golden / computed of the absorbed energy sum(E rho V) over ALL specific-energy goldens of the
+    reference (5 grid types x 4 variants x 5 iterations = 100 Fortran-produced numbers of 1e4 packets each).  One such
+    ratio carries ~1 % noise; pooled, a systematic error of half a percent shows.  Returns (weighted mean, n, per-grid means)."""
+    num, den, per = 0.0, 0.0, {}
+    n = 0
+    for grid in ("car", "oct", "amr", "sph", "cyl"):
+        r_grid = []
+        for name in ("False.False", "True.False", "False.True", "True.True"):
+            prob, z = golden_problem("%s_specific_energy.%s.npz" % (grid, name))
+            gold = z["golden/specific_energy"]
+            w = prob.density * prob.volumes
+            prob.config.seed = -4242
+            run = make_runner(prob)
+            for it in range(1, 6):
+                se = run(n_packets, it)
+                g, c = float((gold[it - 1] * w).sum()), float((se * w).sum())
+                num += g; den += c; n += 1
+                r_grid.append(g / c)
+            run.close()
+        per[grid] = float(np.mean(r_grid))
+    return num / den, n, per
+
+
+class _OracleRunner:
+    def __init__(self, prob):
+        self.o = Oracle(prob)
+
+    def __call__(self, n, it):
+        return self.o.lucy_iteration(n, it)[0]
+
+    def close(self):
+        self.o.close()
+
+
+def test_pooled_bias_over_all_specific_energy_goldens():
+    """one pooled estimate over the 20 goldens x 5 iterations; bound 1 % on the pooled ratio, 2.5 % per
+    grid type (20 numbers each)."""
+    mean, n, per = pooled_specific_energy_bias(_OracleRunner)
+    assert n == 100
+    assert abs(mean - 1.0) < 0.01, (mean, per)
+    for grid, r in per.items():
+        assert abs(r - 1.0) < 0.025, (grid, r, per)
