@@ -23,14 +23,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-# L2<->fabric bytes per cell crossing from the committed rocprofv3 PMC passes of the 128^3
-# uniform benchmark (FETCH_SIZE / WRITE_SIZE in KiB, separate --pmc runs):
-#  persistent lucy_kernel<1> (profiles/r01b_summary.md): 8.08522e7 / 1.08239e8 KiB per launch of 3.46321e9 crossings
-#  brick-tiled schedule, all tile_* kernels (profiles/r01d_summary.md): 4.13481e8 / 8.0876e8 KiB over 3 x 1.7319e10 crossings
-PMC_B_PER_CROSSING = {
-    0: (8.08522e7 + 1.08239e8) * 1024 / 3.46321e9,
-    1: (4.13481e8 + 8.0876e8) * 1024 / (3 * 1.73190e10),
-}
+PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock; one wave64 VALU instruction issues in 4 cycles
+
+
+def committed_pmc(tiled):
+    """Per-crossing PMC totals of the committed rocprofv3 passes of THIS bench command (profiles/r02_pmc.json, written by
+    tools/r02_profile.sh + tools/summarize_tiled.py on the GPU box).  Counters cannot be read inside the timed run, so the
+    bench line carries them with their source; None when the file is not there or does not apply."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    if not tiled or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
 
 
 def cpu_baseline(prob, n_sample):
@@ -51,6 +56,59 @@ def cpu_baseline(prob, n_sample):
             "crossings_per_s": st["crossings"] / dt}
 
 
+def extras(n):
+    """The other single-GPU configurations of BASELINE.json, after the timed region, as extra entries of the same JSON line
+    (not `value`): configs[3] = adaptive octree + peel-off imaging to a 512 x 512 Stokes image, configs[4] = the real
+    100 000-site voro++ tessellation with two anisotropic polarising species and an external source.  One warm-up and one
+    timed pass each; unit of work = cell crossing (24 B x n_dust algorithmic)."""
+    import hyperion_amd
+    from hyperion_amd.benchmark import make_octree_problem
+    res = []
+
+    def timed(fn):
+        fn()
+        t0 = time.perf_counter()
+        st = fn()
+        return st, time.perf_counter() - t0
+
+    p = make_octree_problem(max_level=7, n_photons=n, n_iter=1)
+    e = hyperion_amd.Engine(p)
+    state = {"it": 0}
+
+    def lucy():
+        state["it"] += 1
+        return e.lucy_iteration(n, state["it"], want_output=False)[1]
+    st, dt = timed(lucy)
+    k_ms = e.last_kernel_ms()[0]
+    res.append({"config": "configs[3] Lucy iteration: octree depth 7 (%d cells), central source" % p.n_cells, "packets": n,
+                "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
+                "hbm_frac": 24.0 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+    st, dt = timed(lambda: e.final_iteration(n)[1])
+    res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view", "packets": n,
+                "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS})
+    e.close()
+    try:
+        from cases import voronoi_big_problem
+        p = voronoi_big_problem(n_photons=n)
+    except Exception as ex:           # the tessellation fixture travels with tests/golden
+        res.append({"config": "configs[4]", "error": str(ex)})
+        return res
+    e = hyperion_amd.Engine(p)
+    state["it"] = 0
+
+    def lucy4():
+        state["it"] += 1
+        return e.lucy_iteration(n, state["it"], want_output=False)[1]
+    st, dt = timed(lucy4)
+    k_ms = e.last_kernel_ms()[0]
+    res.append({"config": "configs[4] Lucy iteration: voro++ tessellation of 100000 random sites (15.2 neighbours / cell), 2 HG-like polarising "
+                          "species, point + external box source", "packets": n, "packets_per_s": n / dt,
+                "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
+                "hbm_frac": 24.0 * 2 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+    e.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +120,8 @@ def main():
     ap.add_argument("--density", default="uniform")
     ap.add_argument("--cpu-sample", type=float, default=2e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] lines (N = 1 only)")
+    ap.add_argument("--extra-photons", type=float, default=2e7, help="packets per iteration of the extra configurations")
     ap.add_argument("--option", action="append", default=[], help="engine option name=value")
     args = ap.parse_args()
 
@@ -140,31 +200,62 @@ def main():
                        "packets_per_iteration": n_total, "parallelism": "packets sharded by id range over %d GPU(s), one f64 all-reduce per iteration" % world,
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),
-            "lucy_schedule": "brick-tiled (tile_prepare/sort/tile_walk generations)" if tiled else "persistent kernel, global atomics",
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0,
-                         # L2<->fabric bytes per launch from the committed PMC passes of this schedule/config
-                         # (KiB units x1024, separate --pmc runs; the x2 wide-load correction of the guide does
-                         # not apply to 8-byte scattered loads, one 64-B request each = TCC_EA0_RDREQ x 64).
-                         "traffic": PMC_B_PER_CROSSING[1 if tiled else 0] * crossings / world / 1e9
-                                    if args.grid == 128 and args.density == "uniform" else None,
-                         "traffic_unit": "GB per launch (L2<->fabric; Infinity-Cache hits included, not HBM-only)",
-                         "note": ("24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
-                                  "launch = the whole propagation of one iteration (all generations of tile_prepare/count/scan/scatter/walk on "
-                                  "three streams), timed with HIP events on the engine's stream.  Density and accumulators of a 16^3 brick "
-                                  "live in LDS, so the algorithmic bytes no longer go to memory: the dominant kernel tile_walk_kernel is "
-                                  "VALU-issue bound (profiles/r01d_summary.md), %.2f x the memory-side atomic rate that bounds the "
-                                  "persistent kernel (2.38e10 atomics/s, profiles/r01_atomic_rate_ubench.md)"
-                                  % (crossings / world / (k_ms * 1e-3) / 2.38e10)) if tiled else
-                                 ("24 B x n_dust per cell crossing (8 B density load + 16 B accumulator RMW), crossings counted in-kernel; "
-                                  "the kernel is bound by the memory-side scattered-atomic rate (2.38e10/s measured, profiles/r01_atomic_rate_ubench.md): "
-                                  "atomic-rate fraction %.2f" % (crossings / world / (k_ms * 1e-3) / 2.38e10))},
+            "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_scan / tile_scatter / tile_walk on %d slot pools (streams)"
+                              % eng.get_option("tile_pools")) if tiled else "persistent kernel, global atomics",
         }
+        std_case = args.grid == 128 and args.density == "uniform"
+        pmc = committed_pmc(tiled) if std_case else None
+        per = pmc["per_crossing"] if pmc else {}
+        xs = crossings / world                      # crossings of one launch on this GPU
+        roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                "kernel": "whole propagation of one Lucy iteration (all generations), HIP events on the engine's stream",
+                "algorithmic_bytes_per_unit": "24 B x n_dust per cell crossing (8 B density load + 16 B accumulator read-modify-write, "
+                                              "src/grid/grid_propagate_3d.f90:131-160); crossings counted in-kernel"}
+        if per:
+            # FETCH_SIZE / WRITE_SIZE are in KiB; L2 <-> fabric requests, Infinity-Cache hits included.  The guide's x2
+            # correction for wide streaming reads applies to the 16 B/lane record loads of tile_walk / tile_interact, so
+            # the read half is a lower bound: both are given.
+            rd, wr = per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0
+            roof["traffic"] = (rd + wr) * xs / 1e9
+            roof["traffic_unit"] = "GB per launch, L2<->fabric (FETCH_SIZE + WRITE_SIZE as reported)"
+            roof["traffic_reads_x2"] = (2 * rd + wr) * xs / 1e9
+            roof["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc passes of this command, tools/r02_profile.sh); not measured in this run"
+        else:
+            roof["traffic"] = None
+        if tiled:
+            walk_ms = eng.get_option("last_walk_us") / 1e3
+            n_walk = eng.get_option("last_walk_launches")
+            roof["dominant_kernel"] = {
+                "name": "tile_walk_kernel", "launches_per_iteration": n_walk, "sum_ms_per_iteration": walk_ms,
+                "avg_launch_us": walk_ms * 1e3 / max(n_walk, 1),
+                "achieved_GBs_over_its_own_time": alg_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
+                "note": "HIP events around every tile_walk launch on its pool's stream (last timed step); with several pools the "
+                        "launches overlap other kernels and stretch -- profiles/r02_serial_summary.md has the one-pool trace"}
+            roof["note"] = ("density and accumulators of a 16^3 brick live in LDS, so the 24 B per crossing never go to memory: the HBM "
+                            "fraction says how far the path is from a streaming bound it does not have; what limits it is VALU issue "
+                            "(see issue_roofline) and, for tile_interact, random 128-byte record traffic")
+        else:
+            roof["note"] = ("bound by the memory-side scattered-atomic rate (2.38e10/s, profiles/r01_atomic_rate_ubench.md): fraction %.2f"
+                            % (xs / (k_ms * 1e-3) / 2.38e10))
+        out["roofline"] = roof
+        if per:
+            # second ceiling: VALU issue.  wave-instructions x 4 cycles / (SIMDs x clock) is the time the chip needs to issue
+            # the vector instructions of one launch if every SIMD issued one every cycle it could.
+            t_issue = per["SQ_INSTS_VALU"] * xs * 4.0 / (N_SIMD * CLOCK_HZ)
+            out["issue_roofline"] = {"bound": "valu_issue", "valu_wave_instructions_per_crossing": per["SQ_INSTS_VALU"],
+                                     "ideal_issue_ms": t_issue * 1e3, "measured_ms": k_ms, "frac": t_issue / (k_ms * 1e-3),
+                                     "peak": "%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (N_SIMD, CLOCK_HZ / 1e9),
+                                     "source": "profiles/r02_pmc.json (SQ_INSTS_VALU summed over all tile_* kernels)"}
         if world == 1 and not args.no_cpu_baseline:
             sample_prob = make_benchmark_problem(args.grid, density=args.density, n_photons=int(args.cpu_sample), n_iter=1)
             out["cpu_baseline"] = cpu_baseline(sample_prob, int(args.cpu_sample))
+        eng.close()
+        eng = None
+        if world == 1 and std_case and not args.no_extras:
+            out["extra"] = extras(int(args.extra_photons))
         print(json.dumps(out), flush=True)
-    eng.close()
+    if eng is not None:
+        eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

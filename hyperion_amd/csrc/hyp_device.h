@@ -84,7 +84,7 @@ struct DPeeled {
     int inside_observer, pad_obs; // peel-off towards the point `origin` inside the grid (images_peeled.f90:158-205): lon / lat maps
     int nj_stride, inu_min;       // inu_min: monochromatic, 1-based first frequency of this group (image_type.f90:243-258)
     // filter convolution (image_type.f90:173-181,285-291,467-475): n_nu transmission curves, filt_off[n_nu + 1] into filt_nu / filt_tr
-    int use_filters, pad_f;
+    int use_filters, view_base;           // view_base: global number of this group's first view
     const double *filt_off;       // integer-valued (the tables live in the constant blob of doubles)
     const double *filt_nu, *filt_tr;
 };
@@ -185,6 +185,7 @@ struct DProblem {
     double *err_data;                     // [0..2]
     const DSource *sources;
     const DPeeled *peeled;
+    int n_views_total, pad9;              // peeled views numbered through all groups (DPeeled::view_base)
     // n_photons (grid_propagate_3d.f90:88-93,171-176): packets that entered each cell in this Lucy iteration [n_cells];
     // last_id = tags of the last HYP_NPHOT_SLOTS packets counted in each cell [n_cells][HYP_NPHOT_SLOTS], see count_photon.
     // count_photons = 0: arrays absent.
@@ -259,12 +260,13 @@ __device__ __forceinline__ double rng_uniform(Rng &g)
 // with probability p (grid_propagate_3d.f90:108).  The same Bernoulli process is
 // generated from its gap distribution: steps until the next check
 // = floor(log(1-u)/log(1-p)), one stream-B draw per check instead of per step.
-__device__ __forceinline__ int rng_check_gap(Rng &g, double p, double log1mp)
+// stream 1: the packet's own propagation checks; stream 2: those of a peel-off walk (its own block range, see peel_rng)
+__device__ __forceinline__ int rng_check_gap(Rng &g, double p, double log1mp, uint32_t stream = 1u)
 {
     if (p >= 1.0) return 0;
     if (!(p > 0.0)) return 2147483647;
     uint32_t o[4];
-    philox4x32_10(g.id_lo, g.id_hi, g.blk_b, 1u, g.key0, g.key1, o);
+    philox4x32_10(g.id_lo, g.id_hi, g.blk_b, stream, g.key0, g.key1, o);
     g.blk_b++;
     double gap = floor(log(1.0 - u64_to_unit(o[0], o[1])) / log1mp);
     return gap >= 2147483647.0 ? 2147483647 : (int)gap;

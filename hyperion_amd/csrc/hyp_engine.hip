@@ -224,6 +224,11 @@ struct hyp_engine {
     int *d_ilist = nullptr, *d_dlist = nullptr, *d_extra = nullptr;     // split schedule: per-task work lists
     TileCount *d_tcount = nullptr;
     int tile_split = 1;
+    // live timing of the dominant kernel (bench.py's roofline): HIP events around every tile_walk launch, on its own stream
+    int tile_time_walk = 1;
+    std::vector<hipEvent_t> walk_events;
+    double last_walk_ms = 0.0;
+    int last_walk_launches = 0;
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
@@ -244,6 +249,7 @@ struct hyp_engine {
     hyp_iter_stats mono_stats;
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
+    bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool count_photons = false, pda = false;
     int n_bins = 0, nj_max = 1;
     unsigned int *d_nphot = nullptr, *d_last_id = nullptr;      // [n_cells]
@@ -305,18 +311,18 @@ LucyKernel pick_lucy_kernel(int nd, int grid_type)
     }
 }
 
-LucyKernel pick_final_kernel(int nd, int grid_type)
+LucyKernel pick_final_kernel(int nd, int grid_type, bool plain)
 {
 #ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
-    return pick_final_kernel_g<GEOM_CAR>(nd);
+    return pick_final_kernel_g<GEOM_CAR>(nd, plain);
 #endif
     switch (grid_type) {
-    case 2: return pick_final_kernel_g<GEOM_OCT>(nd);
-    case 3: return pick_final_kernel_g<GEOM_VOR>(nd);
-    case 4: return pick_final_kernel_g<GEOM_AMR>(nd);
-    case 5: return pick_final_kernel_g<GEOM_SPH>(nd);
-    case 6: return pick_final_kernel_g<GEOM_CYL>(nd);
-    default: return pick_final_kernel_g<GEOM_CAR>(nd);
+    case 2: return pick_final_kernel_g<GEOM_OCT>(nd, plain);
+    case 3: return pick_final_kernel_g<GEOM_VOR>(nd, plain);
+    case 4: return pick_final_kernel_g<GEOM_AMR>(nd, plain);
+    case 5: return pick_final_kernel_g<GEOM_SPH>(nd, plain);
+    case 6: return pick_final_kernel_g<GEOM_CYL>(nd, plain);
+    default: return pick_final_kernel_g<GEOM_CAR>(nd, plain);
     }
 }
 
@@ -372,6 +378,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
     // packet-id dispenser, the finished counter and the (atomic) accumulators.
     const size_t tasks_cap = (size_t)T0.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2;
     int gen = 0;
+    size_t n_timed = 0;
     for (;; gen++) {
         for (int pool = 0; pool < n_pools; pool++) {
             TileGeom T = T0; T.pool = pool;
@@ -405,8 +412,18 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
             }
             tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
             tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
+            const bool timed = h->tile_time_walk && n_timed + 2 <= 16384;
+            if (timed) {
+                while (h->walk_events.size() < n_timed + 2) {
+                    hipEvent_t e = nullptr;
+                    if (hipEventCreate(&e) != hipSuccess) return h->set_error("cannot create a timing event");
+                    h->walk_events.push_back(e);
+                }
+                (void)hipEventRecord(h->walk_events[n_timed], st);
+            }
             tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick,
                                                                                        ilist, dlist, tcount, counts);
+            if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
         if ((gen & 3) == 3 || gen > 200000) {
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
@@ -437,6 +454,14 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
         }
     }
     h->last_generations = gen + 1;
+    h->last_walk_ms = 0.0; h->last_walk_launches = 0;
+    if (n_timed) {
+        (void)hipDeviceSynchronize();
+        for (size_t i = 0; i + 1 < n_timed; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->walk_events[i], h->walk_events[i + 1]) == hipSuccess) { h->last_walk_ms += ms; h->last_walk_launches++; }
+        }
+    }
 #ifdef HYP_PREP_STATS
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
@@ -560,6 +585,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
     free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
+    for (hipEvent_t e : h->walk_events) (void)hipEventDestroy(e);
     free_dev(h->d_nphot); free_dev(h->d_last_id); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
     free_dev(h->d_pda_mask); free_dev(h->d_pda_cells); free_dev(h->d_pda_hp); free_dev(h->d_pda_emean); free_dev(h->d_pda_coef);
     free_dev(h->d_pda_id); free_dev(h->d_pda_a); free_dev(h->d_pda_b); free_dev(h->d_pda_f);
@@ -1174,10 +1200,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     h->sed_off.assign(n_groups, 0); h->img_off.assign(n_groups, 0);
     h->sed_n.assign(n_groups, 0); h->img_n.assign(n_groups, 0);
     size_t img_total = 0;
+    int views_total = 0;
     for (int g = 0; g < n_groups; g++) {
         const hyp_peeled_desc &in = pdesc[g];
         DPeeled &G = h->h_peeled[g];
         std::memset(&G, 0, sizeof(G));
+        G.view_base = views_total;
+        if (g < pr->n_peeled && in.n_view > 0) views_total += in.n_view;
         if (in.inside_observer) {       // images_peeled.f90:312-315, 356-363
             if (in.compute_image && in.x_min < in.x_max) FAIL("longitudes should increase towards the left for inside observers");
             if (in.compute_sed) FAIL("computing SEDs for inside observers is not supported");
@@ -1541,6 +1570,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         if (h->sed_n[g]) { G.sed = h->d_img_accum + h->sed_off[g]; G.sed2 = G.sed + h->sed_n[g]; }
         if (h->img_n[g]) { G.img = h->d_img_accum + h->img_off[g]; G.img2 = G.img + h->img_n[g]; }
     }
+    {
+        bool plain = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
+        for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
+        for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer && !pr->peeled[g].use_filters;
+        h->plain_imaging = plain;
+    }
+    P.n_views_total = views_total;
     P.binned = pr->binned ? pr->n_peeled : -1; P.n_bin_theta = pr->n_binned_theta; P.n_bin_phi = pr->n_binned_phi;
     if (n_groups > 0) {
         HIPC(hipMalloc(&h->d_peeled, sizeof(DPeeled) * n_groups));
@@ -2095,6 +2131,8 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
     else if (n == "tile_split") h->tile_split = (int)value;
+    else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
+    else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = (int)value;
     else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
@@ -2116,6 +2154,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_task") *value = h->tile_task;
     else if (n == "tile_pools") *value = h->tile_pools;
     else if (n == "tile_split") *value = h->tile_split;
+    else if (n == "last_walk_us") *value = (int64_t)(h->last_walk_ms * 1000.0);
+    else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
     else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
@@ -2151,7 +2191,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     unsigned long long first = first_id;
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->hp.mono_which);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {
@@ -2374,7 +2414,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     unsigned long long first = first_id;
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, false);
     const size_t lds = lds_bytes(P);
     long long blocks = (long long)h->n_cu * 2;
     long long need_blocks = (long long)((n_local + 255) / 256);

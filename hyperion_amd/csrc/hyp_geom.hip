@@ -25,18 +25,18 @@ LucyKernel pick_lucy_kernel_g(int nd)
 }
 
 template <int GEOM>
-LucyKernel pick_final_kernel_g(int nd)
+LucyKernel pick_final_kernel_g(int nd, bool plain)
 {
 #ifdef HYP_ONLY_ND1
     (void)nd;
-    return final_kernel<1, GEOM>;
+    return plain ? final_kernel<1, GEOM, true> : final_kernel<1, GEOM, false>;
 #else
     switch (nd) {
-    case 1: return final_kernel<1, GEOM>;
-    case 2: return final_kernel<2, GEOM>;
-    case 3: return final_kernel<3, GEOM>;
-    case 4: return final_kernel<4, GEOM>;
-    default: return final_kernel<HYP_MAXD, GEOM>;
+    case 1: return plain ? final_kernel<1, GEOM, true> : final_kernel<1, GEOM, false>;
+    case 2: return plain ? final_kernel<2, GEOM, true> : final_kernel<2, GEOM, false>;
+    case 3: return plain ? final_kernel<3, GEOM, true> : final_kernel<3, GEOM, false>;
+    case 4: return plain ? final_kernel<4, GEOM, true> : final_kernel<4, GEOM, false>;
+    default: return plain ? final_kernel<HYP_MAXD, GEOM, true> : final_kernel<HYP_MAXD, GEOM, false>;
     }
 #endif
 }
@@ -59,5 +59,5 @@ RayKernel pick_ray_kernel_g(int nd)
 }
 
 template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
-template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int);
+template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, bool);
 template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);

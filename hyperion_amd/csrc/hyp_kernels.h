@@ -51,6 +51,7 @@ struct Packet {
     double t_src, t_ach;
     int reabs_id, reabs;
     int spec_idx;               // frequency bin of the specific-energy spectrum during this grid_integrate (-1: none)
+    unsigned int peel_seq;      // peel-off events of this packet so far (keys the check stream of the peel-off walks)
 };
 
 // extra state carried only by the imaging (final) iteration
@@ -743,7 +744,9 @@ __device__ __forceinline__ double dust_emit_probability(const DProblem &P, const
 
 // emit: source.f90:100-179 + source_emit/emit_from_point source_type.f90:398-564.
 // Returns false on a fatal error (flag raised).
-template <int NDT, int GEOM>
+// SIMPLE: every source is a point source with a tabulated or blackbody spectrum and the launch is not monochromatic
+// (checked by the host): the other emitters stay out of the kernel.
+template <int NDT, int GEOM, bool SIMPLE = false>
 __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
                                             Counters &cnt, int &source_id, Angle &src_normal, int reemit_id = -1, double reemit_energy = 0.0)
 {
@@ -763,7 +766,10 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     int ispot = -1;
     p.emiss_dust = -1;
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
-    if (S.type == 2) {
+    if (SIMPLE) {
+        p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+        random_sphere_angle(g, p.a);
+    } else if (S.type == 2) {
         // emit_from_sphere: source_type.f90:604-690
         Angle a_coord, a_local;
         if (S.n_spots > 0) {        // source_emit case(3), source_type.f90:421-427: a spot or the rest of the sphere, by luminosity
@@ -872,7 +878,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
     p.energy = 1.0;
     int lte_jid = 0; double lte_frac = 0.0;
-    if (S.spectrum_type == 3) {
+    if (!SIMPLE && S.spectrum_type == 3) {
         // 'lte' (source_type.f90:455-459, 486-491): select_dust_specific_energy_rho (grid_physics_3d.f90:101-109) in the
         // emitting cell, then the emissivity of that dust
         const int nd = ndust<NDT>(P);
@@ -888,7 +894,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         p.emiss_dust = id;
         lte_jid = P.jnu_id[base + id]; lte_frac = P.jnu_frac[base + id];
     }
-    if (ispot >= 0) {       // the spot's own spectrum: source_type.f90:447-461, 480-492
+    if (!SIMPLE && ispot >= 0) {       // the spot's own spectrum: source_type.f90:447-461, 480-492
         const double *q = S.spot_tab + (S.n_spots + 1) + (size_t)ispot * SPOT_STRIDE;
         if (P.mono_which) {
             p.nu = P.mono_nu;
@@ -897,17 +903,17 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
             p.nu = sample_log_pdf(S.spot_blob + (size_t)q[7], S.spot_blob + (size_t)q[8], S.spot_blob + (size_t)q[9], (int)q[6], rng_uniform(g));
         else p.nu = random_planck_frequency(g, q[5]);
     } else
-    if (P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
+    if (!SIMPLE && P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
         p.nu = P.mono_nu;
         p.energy = S.spectrum_type == 3 ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)
                                         : P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
-    } else if (S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
+    } else if (!SIMPLE && S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
     else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     if (reemit_id >= 0) p.energy = reemit_energy;
     else {
-        if (P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
+        if (!SIMPLE && P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
         if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
         cnt.energy_current += p.energy;
     }
@@ -920,6 +926,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         return false;
     }
     p.inter = 1;
+    if (reemit_id < 0) p.peel_seq = 0;      // a re-emitted packet is still the same packet
     return true;
 }
 
@@ -1381,7 +1388,8 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 template <int NDT, int GEOM>
 __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, const double r0[3], const double v[3],
                                              const Cell<GEOM> &cell0,
-                                             const double chi[NDT], Rng &g, Counters &cnt, bool &killed, double tmax = HYP_DBL_MAX)
+                                             const double chi[NDT], Rng &g, Counters &cnt, bool &killed, double tmax = HYP_DBL_MAX,
+                                             uint32_t stream = 1u)
 {
     const int nd = ndust<NDT>(P);
     double r[3] = {r0[0], r0[1], r0[2]};
@@ -1398,7 +1406,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     double t_achieved = 0.0;       // inside observers stop at the observer: grid_propagate_3d.f90:446-452
     for (;;) {
         if (g.countdown == 0) {
-            g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+            g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp, stream);
             if (!geo_check_cell(P, W, r, v, c)) { cnt.killed_geo++; killed = true; return tau; }
         } else g.countdown--;
         double tmin; int im[3];
@@ -1514,26 +1522,28 @@ __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled 
 // attenuated, energy, frequency nu) at (x_image, y_image) of view iv.  With filters the packet goes into every filter
 // whose transmission at nu (linear interpolation, 0 outside the curve) is positive, with that weight (:467-475).
 // Must be called by all 64 lanes.
+template <bool PLAIN = false>
 __device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled &G, bool live, double nu, double energy, const double s[4],
                                                const PeelFlags &f, double x_image, double y_image, int iv)
 {
     const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
-    const int n_pass = G.use_filters ? G.n_nu : 1;
+    const bool use_filters = !PLAIN && G.use_filters;
+    const int n_pass = use_filters ? G.n_nu : 1;
     for (int pass = 0; pass < n_pass; pass++) {
         long long k_img = -1, k_sed = -1;
         double val[4] = {0.0, 0.0, 0.0, 0.0};
         if (live) {
             double tr = 1.0;
-            if (G.use_filters) {
+            if (use_filters) {
                 const int o0 = (int)G.filt_off[pass], o1 = (int)G.filt_off[pass + 1];
                 const double *fx = G.filt_nu + o0, *ft = G.filt_tr + o0;
                 const int j = locate(fx, o1 - o0, nu);
                 tr = j < 0 ? 0.0 : ft[j] + (nu - fx[j]) / (fx[j + 1] - fx[j]) * (ft[j + 1] - ft[j]);
             }
             if (tr > 0.0) {
-                image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed, G.use_filters ? pass : -1);
+                image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed, use_filters ? pass : -1);
                 val[0] = s[0] * energy; val[1] = s[1] * energy; val[2] = s[2] * energy; val[3] = s[3] * energy;
-                if (G.use_filters) { val[0] *= tr; val[1] *= tr; val[2] *= tr; val[3] *= tr; }
+                if (use_filters) { val[0] *= tr; val[1] *= tr; val[2] *= tr; val[3] *= tr; }
             }
         }
         // wave-uniform from here: combine lanes that hit the same pixel / SED bin
@@ -1570,10 +1580,22 @@ __device__ __forceinline__ void inside_sky_position(const DPeeled &G, int iv, co
     y_image = G.y_min + (ay - 360.0 * floor(ay / 360.0));
 }
 
+// The propagation checks of a peel-off walk draw from their own stream, keyed by (packet, peel-off event, view), not from
+// the packet's: the walk then is a function of the event alone and can be done by any lane, in any order, in another kernel.
+// 16 blocks per walk (one check every ~1 / propagation_check_frequency steps).
+__device__ __forceinline__ void peel_rng(const DProblem &P, Rng &gp, uint32_t key0, uint32_t key1, unsigned long long id, unsigned int peel_seq,
+                                         int view_global)
+{
+    gp.key0 = key0; gp.key1 = key1; gp.id_lo = (uint32_t)id; gp.id_hi = (uint32_t)(id >> 32);
+    gp.blk_a = 0; gp.have_a = 0; gp.buf_a = 0.0;
+    gp.blk_b = (peel_seq * (unsigned int)P.n_views_total + (unsigned int)view_global) * 16u;
+    gp.countdown = rng_check_gap(gp, P.check_p, P.check_log1mp, 2u);
+}
+
 // peeloff_photon, external observers: images_peeled.f90:95-270.  Called by ALL
 // lanes of the wave (`active` = this lane has a packet to peel) so that the image
 // deposits can be combined across lanes.
-template <int NDT, int GEOM>
+template <int NDT, int GEOM, bool PLAIN = false>
 __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, bool active,
                                         const Angle &a_prev, const double s_prev[4], int last, bool last_isotropic,
                                         const PeelFlags &f, Rng &g, Counters &cnt)
@@ -1588,7 +1610,7 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                 a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
                 double d_obs = 0.0;
-                if (G.inside_observer) inside_direction(G, p.r, a_req, d_obs);
+                if ((!PLAIN && G.inside_observer)) inside_direction(G, p.r, a_req, d_obs);
                 double s[4];
                 if (last_isotropic) {
                     s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
@@ -1628,12 +1650,12 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 Cell<GEOM> c = p.cell;
                 bool ok = geo_place(P, W, p.r, v, c);
                 if (!ok) cnt.killed_geo++;
-                double d = G.inside_observer ? d_obs : -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
+                double d = (!PLAIN && G.inside_observer) ? d_obs : -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
                 ok = ok && !(d < G.d_min || d > G.d_max);
                 double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
                 double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
                 double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
-                if (G.inside_observer) inside_sky_position(G, iv, a_req, x_image, y_image);
+                if ((!PLAIN && G.inside_observer)) inside_sky_position(G, iv, a_req, x_image, y_image);
                 bool inside = false;
                 if (G.compute_image)
                     inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
@@ -1642,10 +1664,12 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 ok = ok && inside;
                 if (ok) {
                     double tau = 0.0; bool killed = false;
+                    Rng gp;
+                    peel_rng(P, gp, g.key0, g.key1, ((unsigned long long)g.id_hi << 32) | g.id_lo, p.peel_seq, G.view_base + iv);
                     if (!G.ignore_optical_depth)
-                        tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, g, cnt, killed, G.inside_observer ? d_obs : HYP_DBL_MAX);
+                        tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, gp, cnt, killed, (!PLAIN && G.inside_observer) ? d_obs : HYP_DBL_MAX, 2u);
                     if (!killed) {
-                        if (G.inside_observer) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
+                        if ((!PLAIN && G.inside_observer)) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
                             const double dil = 1.0 / (4.0 * HYP_PI * (d_obs * d_obs));
                             s[0] = s[0] * dil; s[1] = s[1] * dil; s[2] = s[2] * dil; s[3] = s[3] * dil;
                         }
@@ -1655,7 +1679,7 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                     }
                 }
             }
-            deposit_images(P, G, live, p.nu, p.energy, s_out, f, x_out, y_out, iv);
+            deposit_images<PLAIN>(P, G, live, p.nu, p.energy, s_out, f, x_out, y_out, iv);
         }
     }
 }
@@ -2017,7 +2041,7 @@ __device__ __forceinline__ bool emit_mono_dust(const DProblem &P, const Walls &W
     g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
     geo_clear_wall(p.cell);
     if (!geo_place(P, W, p.r, p.v, p.cell)) { cnt.killed_geo++; return false; }
-    p.inter = 1;
+    p.inter = 1; p.peel_seq = 0;
     p.energy = P.mono_mean_prob[d] * P.energy_abs_tot[d] / P.mono_n_total * (double)nd;
     return p.energy > 0.0;
 }
@@ -2064,7 +2088,10 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
     }
 }
 
-template <int NDT, int GEOM>
+// PLAIN: the polychromatic peel-off iteration without anything optional -- point sources only, no monochromatic launch,
+// no modified random walk, no re-absorbing sources, no binned images, no inside observers, no filters (the host checks).
+// Those paths cost registers even where a problem never takes them; this is the imaging kernel of BASELINE configs[3].
+template <int NDT, int GEOM, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
@@ -2073,6 +2100,8 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     stage_walls<GEOM>(P, lds, W);
     Packet<NDT, GEOM> p;
     Rng g;
+    const bool has_mrw = !PLAIN && P.mrw, has_reabs = !PLAIN && P.any_intersect;
+    const int mono = PLAIN ? 0 : P.mono_which;
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     Dispenser dsp; dsp.next = 0; dsp.end = 0;
@@ -2088,14 +2117,14 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     for (;;) {
         // packets that left the grid alive go into the binned images (iter_final.f90:127-129), then their lane is free
         if (__ballot(st == ST_ESCAPED)) {
-            if (P.binned >= 0) bin_escaped<NDT, GEOM>(P, p, st == ST_ESCAPED, f);
+            if (!PLAIN && P.binned >= 0) bin_escaped<NDT, GEOM>(P, p, st == ST_ESCAPED, f);
             if (st == ST_ESCAPED) st = ST_NEED_EMIT;
         }
         unsigned long long m_walk = __ballot(st == ST_WALK);
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        unsigned long long m_re = P.any_intersect ? __ballot(st == ST_NEED_REEMIT) : 0ull;
-        const unsigned long long m_mrw = P.mrw ? __ballot(st == ST_MRW) : 0ull;
+        unsigned long long m_re = has_reabs ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+        const unsigned long long m_mrw = has_mrw ? __ballot(st == ST_MRW) : 0ull;
         if (!(m_walk | m_int | m_emit | m_re | m_mrw)) break;
 
         // peel: 0 none, 1 after emission, 2 after interaction, 3 after re-emission by a source
@@ -2105,7 +2134,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
         int last = LAST_SR; bool last_iso = true;
 
         // ---- packets re-absorbed by a source are re-emitted from it: iter_final.f90:213-243 ----
-        if (m_re && (__popcll(m_re) >= L.emit_threshold || !m_walk)) {
+        if (!PLAIN && m_re && (__popcll(m_re) >= L.emit_threshold || !m_walk)) {
             if (st == ST_NEED_REEMIT) {
                 if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_NEED_EMIT; }
                 else {
@@ -2126,7 +2155,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
 
         // ---- modified random walk, one step per pass, each peeled off as isotropic emission:
         //      iter_final.f90:165-183 ----
-        if (m_mrw) {
+        if (!PLAIN && m_mrw) {
             if (st == ST_MRW) {
                 if (mrw_k == P.n_inter_mrw_max + 1) { cnt.killed_int++; st = ST_NEED_EMIT; }
                 else if (mrw_wanted(P, W, p)) {
@@ -2154,12 +2183,12 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
                     int scattered, dust_id;
                     // monochromatic: always scatter, the energy decreases by the albedo (iter_final_mono.f90:330-336)
-                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, P.mono_which != 0);
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, mono != 0);
                     f.dust_id = dust_id;
                     if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
                     else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
-                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered && !P.mono_which);
-                    if (P.mono_which && p.energy < e_init * P.mono_threshold) killed = true;
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered && !mono);
+                    if (mono && p.energy < e_init * P.mono_threshold) killed = true;
                     if (killed) st = ST_NEED_EMIT;
                     else { p.inter++; peel = 2; }
                 }
@@ -2177,7 +2206,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
                     Angle src_normal;
-                    if (P.mono_which == 2) {
+                    if (mono == 2) {
                         // thermal packets of the monochromatic iteration: iter_final_mono.f90:176-196
                         int dust_id = 0;
                         bool ok = emit_mono_dust<NDT, GEOM>(P, W, p, g, cnt, dust_id);
@@ -2185,14 +2214,14 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                         if (!ok) st = ST_NEED_EMIT;
                         else { peel = 1; last = LAST_DE; last_iso = true; st = ST_PLACED; p.reabs = 0; e_init = p.energy; }
                     } else {
-                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal);
+                    bool ok = emit_packet<NDT, GEOM, PLAIN>(P, W, p, g, cnt, source_id, src_normal);
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else {
-                        if (P.mono_which) { p.energy = p.energy / P.mono_n_total; e_init = p.energy; }     // iter_final_mono.f90:113-116
+                        if (mono) { p.energy = p.energy / P.mono_n_total; e_init = p.energy; }     // iter_final_mono.f90:113-116
                         peel = 1; last = LAST_SR; st = ST_PLACED;   // placed, awaiting tau
                         p.reabs = 0;
-                        last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
+                        last_iso = PLAIN || P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
                         // external sources: a_prev carries the inward normal for emit_peeloff
                         if (!last_iso) a_prev = src_normal;
                     }
@@ -2211,7 +2240,10 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
             // and thermal emission come from the raytracing iteration
             // (a re-emission by a source is peeled in any case: "a kind of scattering", :226-227)
             const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);   // peel 4 (MRW): :171-173
-            if (P.n_peeled > 0 && __ballot(do_peel)) peeloff<NDT, GEOM>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
+            if (P.n_peeled > 0 && __ballot(do_peel)) {
+                peeloff<NDT, GEOM, PLAIN>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
+                if (do_peel) p.peel_seq++;
+            }
             if (peel != 0) {
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
@@ -2236,7 +2268,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
                     st = ST_ESCAPED;
                 } else if (peel == 4) {
                     // stays in ST_MRW: the next pass decides on another step
-                } else if (peel == 2 && P.mrw && !P.mono_which) {
+                } else if (peel == 2 && has_mrw && !mono) {
                     st = ST_MRW; mrw_k = 1;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;

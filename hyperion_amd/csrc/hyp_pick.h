@@ -8,5 +8,5 @@ using LucyKernel = void (*)(const DProblem *, LaunchParams);
 using RayKernel = void (*)(const DProblem *, LaunchParams, int, double);
 
 template <int GEOM> LucyKernel pick_lucy_kernel_g(int nd);    // lucy_kernel<nd, GEOM>
-template <int GEOM> LucyKernel pick_final_kernel_g(int nd);   // final_kernel<nd, GEOM>
+template <int GEOM> LucyKernel pick_final_kernel_g(int nd, bool plain);   // final_kernel<nd, GEOM, plain>
 template <int GEOM> RayKernel pick_ray_kernel_g(int nd);      // ray_kernel<nd, GEOM>

@@ -60,6 +60,7 @@ typedef struct {
     uint32_t key[2];
     uint64_t id;
     uint32_t blk_a, blk_b;
+    uint32_t stream_b;      /* 1: the packet's own propagation checks; 2: those of a peel-off walk (own block range) */
     int have_a;
     int32_t countdown;      /* cell steps left until the next propagation check */
     double buf_a;
@@ -74,7 +75,7 @@ static uint32_t seed_key(int64_t seed)
 static void rng_init(rng_t *g, int64_t seed, uint32_t iter_tag, uint64_t id)
 {
     g->key[0] = seed_key(seed); g->key[1] = iter_tag;
-    g->id = id; g->blk_a = 0; g->blk_b = 0; g->have_a = 0; g->countdown = 0;
+    g->id = id; g->blk_a = 0; g->blk_b = 0; g->stream_b = 1u; g->have_a = 0; g->countdown = 0;
 }
 
 static inline double u64_to_unit(uint32_t hi, uint32_t lo)
@@ -99,7 +100,7 @@ static int32_t rng_check_gap(rng_t *g, double p, double log1mp)
 {
     if (p >= 1.0) return 0;
     if (!(p > 0.0)) return INT32_MAX;
-    uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_b++, 1u}, o[4];
+    uint32_t ctr[4] = {(uint32_t)g->id, (uint32_t)(g->id >> 32), g->blk_b++, g->stream_b}, o[4];
     orc_philox4x32_10(ctr, g->key, o);
     double gap = floor(log(1.0 - u64_to_unit(o[0], o[1])) / log1mp);
     return gap >= 2147483647.0 ? INT32_MAX : (int32_t)gap;
@@ -449,6 +450,7 @@ struct orc_state {
     int mono_inu; double *mono_cdf; double mono_mean_prob[ORC_MAX_DUST];
     double check_p, check_log1mp;
     int n_dust, n_sources, n_peeled;
+    int n_views_total, view_base[64];   /* peeled views numbered through all groups */
     int has_binned, n_theta, n_phi, n_groups;   /* binned images (images_binned.f90): group index n_peeled; n_groups = n_peeled + has_binned */
     dust_t *dust;
     source_t *src;
@@ -1583,6 +1585,9 @@ int orc_create(const orc_problem *pr, orc_state **out)
     }
 
     st->n_peeled = pr->n_peeled;
+    if (st->n_peeled > 64) { snprintf(g_error, sizeof g_error, "at most 64 peeled image groups"); orc_destroy(st); return 1; }
+    st->n_views_total = 0;
+    for (int ig = 0; ig < st->n_peeled; ig++) { st->view_base[ig] = st->n_views_total; st->n_views_total += pr->peeled[ig].n_view; }
     st->has_binned = pr->binned != NULL;
     st->n_groups = st->n_peeled + st->has_binned;
     st->peeled = calloc(st->n_groups ? st->n_groups : 1, sizeof(peeled_t));
@@ -1658,6 +1663,7 @@ typedef struct {
     angle_t source_a;   /* inward normal at the emission point of an external source */
     int reabsorbed, reabsorbed_id;
     int emiss_type, emiss_var_id; double emiss_var_frac;   /* raytracing: 1/2 source spectrum, 3 dust emissivity */
+    uint32_t peel_seq;  /* peel-off events of this packet so far (keys the check stream of the peel-off walks) */
 } photon_t;
 
 typedef struct {
@@ -2581,7 +2587,9 @@ static double normalized_B_nu(double nu, double T)
  * probability of emission there (source_type.f90:440-468, source.f90:145-161) */
 static int emit_from_nu(const orc_state *st, photon_t *p, rng_t *g, acc_t *acc, int reemit_id, double reemit_energy, int inu)
 {
+    const uint32_t keep_seq = reemit_id >= 0 ? p->peel_seq : 0u;      /* a re-emitted packet is still the same packet */
     memset(p, 0, sizeof(*p));
+    p->peel_seq = keep_seq;
     int is = 0;
     if (st->n_sources > 1) {
         double xi = rng_uniform(g);
@@ -3692,7 +3700,13 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
                 continue;
             }
             double tau = 0.0; int killed = 0;
-            if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, tmax, g, acc, &killed);
+            /* The propagation checks of a peel-off walk draw from their own stream, keyed by (packet, peel-off event,
+             * view), not from the packet's: the walk then is a function of the event alone and can be done anywhere, in any
+             * order (the device defers it to a separate kernel).  16 blocks per walk: one check per ~1/p steps. */
+            rng_t gp = *g;
+            gp.stream_b = 2u; gp.blk_b = (p_orig->peel_seq * (uint32_t)st->n_views_total + (uint32_t)(st->view_base[ig] + iv)) * 16u;
+            gp.countdown = rng_check_gap(&gp, st->check_p, st->check_log1mp);
+            if (!pg->d.ignore_optical_depth) tau = grid_escape_tau(st, &p, tmax, &gp, acc, &killed);
             if (killed) continue;
             if (inside) for (int k = 0; k < 4; k++) p.s[k] = p.s[k] * dilute;
             double att = exp(-tau);
@@ -3700,6 +3714,7 @@ static void peeloff_photon(const orc_state *st, const photon_t *p_orig, rng_t *g
             image_bin(st, ig, &p, x_image, y_image, iv, acc);
         }
     }
+    if (!polychromatic) ((photon_t *)p_orig)->peel_seq++;
 }
 
 /* forced_interaction_wr99: forced_interaction.f90:23-58 */

@@ -18,3 +18,7 @@ res, st = eng.final_iteration(n)
 ms = eng.last_kernel_ms()[0]
 print("final n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet (incl. peel-off walks), %.3e crossings/s"
       % (n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3))
+eng.set_option("plain_imaging", 0)          # the general imaging kernel, for comparison
+res, st = eng.final_iteration(n)
+ms = eng.last_kernel_ms()[0]
+print("final (general kernel) n=%d kernel %.1f ms -> %.3e packets/s" % (n, ms, n / ms * 1e3))

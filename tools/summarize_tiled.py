@@ -24,8 +24,8 @@ def short(n):
 
 for db in glob.glob(os.path.join(src, "trace", "*.db")):
     c = sqlite3.connect(db)
-    L += ["## kernel stats (`rocprofv3 --kernel-trace --stats`, view `top_kernels`; durations in ns)", "",
-          "| kernel | calls | total ns | average ns | % |", "|---|---|---|---|---|"]
+    L += ["## kernel stats (`rocprofv3 --kernel-trace --stats`, view `top_kernels`; durations in microseconds)", "",
+          "| kernel | calls | total us | average us | % |", "|---|---|---|---|---|"]
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         L.append("| `%s` | %d | %d | %.0f | %.2f |" % (short(r[0]), r[1], r[2], r[3], r[4]))
     rows = list(c.execute("select name,start,end,vgpr_count,lds_size,workgroup_x from kernels order by start"))
@@ -41,8 +41,8 @@ for db in glob.glob(os.path.join(src, "trace", "*.db")):
             x = d.setdefault(short(n), [0, 0.0, vg, lds, wg]); x[0] += 1; x[1] += (e - s) / 1e6
         span = (sg[-1][2] - sg[0][1]) / 1e6
         if not any(k.startswith("tile_walk") for k in d): continue
-        L.append("- iteration %d: span %.1f ms, sum of kernel durations %.1f ms (pools overlap on %d streams)" %
-                 (i, span, sum(v[1] for v in d.values()), 3))
+        L.append("- iteration %d: span %.1f ms, sum of kernel durations %.1f ms (%s)" %
+                 (i, span, sum(v[1] for v in d.values()), os.environ.get("POOLS_NOTE", "pools overlap on 3 streams")))
         for k, v in d.items():
             if v[1] > 0.05:
                 L.append("  - `%s`: %d launches, %.1f ms, wg %d, LDS %d B" % (k, v[0], v[1], v[4], v[3]))
@@ -67,6 +67,9 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
 L += ["", "totals over the tile_* kernels, per crossing:", ""]
 for name, v in sorted(tot.items()):
     L.append("- %s: %.6g  (%.4g per crossing)" % (name, v, v / (n_iter * crossings_iter)))
+pmc_json = {"tag": tag, "crossings_per_iteration": crossings_iter, "iterations": n_iter,
+            "per_crossing": {k: v / (n_iter * crossings_iter) for k, v in tot.items()}}
+json.dump(pmc_json, open(os.path.join(os.environ.get("SUMMARY_DIR", os.path.join(root, "profiles")), tag + "_pmc.json"), "w"), indent=1)
 out = os.path.join(os.environ.get("SUMMARY_DIR", os.path.join(root, "profiles")), tag + "_summary.md")
 open(out, "w").write("\n".join(L) + "\n")
 print("\n".join(L))
