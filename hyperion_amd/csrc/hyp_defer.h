@@ -1,0 +1,448 @@
+// hyp_defer.h -- the imaging iteration with DEFERRED peel-off (do_final / propagate, iter_final.f90:60-273, with
+// peeloff_photon, images_peeled.f90:95-270), for the problems final_kernel<.., PLAIN> covers.
+//
+// In final_kernel a lane that has just emitted or scattered walks to the edge of the grid once per viewing angle while the
+// other lanes of its wave wait: with ~3.5 such walks per packet, each ~40 cells long on BASELINE configs[3], the wave runs
+// at 15-20 % lane occupancy.  Here the propagation kernel only WRITES an event (position, cell, frequency, energy, incoming
+// direction and Stokes vector, origin flags: one PeelEvent) per emission / interaction, and a second kernel walks all
+// (event, view) pairs to the observer, one lane each, lanes taking the next pair as soon as theirs has left the grid.
+// The walk of a pair depends on the event alone -- its propagation checks draw from Philox stream 2 keyed by (packet,
+// event number, view), see peel_rng -- so the images are the same sums as the inline kernel's, in a different order.
+//
+// Rounds.  The event buffer is finite and the number of events per packet is not bounded (a packet in an optically thick
+// envelope is re-emitted thousands of times), so the host runs rounds of {propagate, peel}.  A wave of the propagation
+// kernel reserves event slots HYP_PEEL_CHUNK at a time; when a reservation fails the wave stops emitting, returns the
+// packet ids it had been handed but not used (DeferBuf::ret) and sets aside every packet that reaches its next
+// interaction (DeferBuf::susp: packet, RNG state, origin flags).  The next round starts from those.  No event is ever
+// dropped and no packet is emitted twice.
+#pragma once
+#include "hyp_kernels.h"
+
+#ifndef HYP_PAIR_CHUNK
+#define HYP_PAIR_CHUNK 256      // (event, view) pairs a wave of the peel kernel reserves at a time
+#endif
+#ifndef HYP_PEEL_REFILL
+#define HYP_PEEL_REFILL 16      // idle lanes that trigger a refill in the peel kernel
+#endif
+#ifndef HYP_PEEL_OCC
+#define HYP_PEEL_OCC 3        // workgroups of the peel kernel per CU the register budget is set for
+#endif
+#ifndef HYP_PEEL_STEPS
+#define HYP_PEEL_STEPS 8        // cell crossings between two refill / deposit checks
+#endif
+
+template <int NDT, int GEOM>
+struct alignas(16) PeelEvent {
+    double r[3], nu, energy;
+    Angle a_prev;                       // direction before the scattering
+    double s_prev[4];                   // Stokes vector before the scattering
+    double chi[NDT];
+    unsigned long long id;
+    unsigned int peel_seq;
+    int code;                           // 0: empty slot, else 1 | last << 1 | last_isotropic << 3
+    PeelFlags f;
+    Cell<GEOM> cell;
+};
+
+template <int NDT, int GEOM>
+struct alignas(16) SuspRec {
+    Packet<NDT, GEOM> p;
+    Rng g;
+    PeelFlags f;
+};
+
+template <int GEOM>
+__global__ void defer_reset_kernel(PeelCtl *ctl, int cur, int first)
+{
+    ctl->reserved = 0; ctl->pair_cursor = 0; ctl->written = 0;
+    ctl->n_susp[cur] = 0; ctl->n_ret[cur] = 0;
+    if (first) { ctl->n_susp[cur ^ 1] = 0; ctl->n_ret[cur ^ 1] = 0; }
+}
+
+// The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
+    Packet<NDT, GEOM> p;
+    Rng g;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    Dispenser dsp; dsp.next = 0; dsp.end = 0;
+    PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
+    int st = ST_NEED_EMIT;
+    bool pool_empty = false, full = false;
+    unsigned long long w_pos = 0, w_end = 0;        // the wave's reserved event slots
+    unsigned int n_written = 0;
+    PeelEvent<NDT, GEOM> *__restrict__ ev = (PeelEvent<NDT, GEOM> *)B.events;
+    const unsigned int lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    rng_init(g, P.seed_key, L.iter_tag, 0);
+    p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0; p.peel_seq = 0;
+    {
+        // what the previous round set aside: lane i resumes packet i, wave w takes back id range w (the grid is the same in
+        // every round and a lane sets aside at most one packet, a wave returns at most one range per round)
+        const unsigned int gl = blockIdx.x * 256u + threadIdx.x;
+        if (gl < B.ctl->n_susp[B.cur ^ 1]) {
+            const SuspRec<NDT, GEOM> &R = ((const SuspRec<NDT, GEOM> *)B.susp[B.cur ^ 1])[gl];
+            p = R.p; g = R.g; f = R.f;
+            st = ST_NEED_INTERACT;
+        }
+        const unsigned int wv = gl >> 6;
+        if (wv < B.ctl->n_ret[B.cur ^ 1]) { dsp.next = B.ret[B.cur ^ 1][2 * (size_t)wv]; dsp.end = B.ret[B.cur ^ 1][2 * (size_t)wv + 1]; }
+    }
+
+    for (;;) {
+        if (st == ST_ESCAPED) st = ST_NEED_EMIT;
+        unsigned long long m_walk = __ballot(st == ST_WALK);
+        unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
+        unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
+        if (!(m_walk | m_int | m_emit)) break;
+
+        // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
+        // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
+        // set aside by the round before (with a buffer of fewer chunks than waves they would otherwise never get one).
+        if (!full && w_end - w_pos < 64ull &&
+            (m_int || (m_emit && !pool_empty && (dsp.next < dsp.end || *((volatile unsigned long long *)P.counter) < L.end_id)))) {
+            unsigned long long b = 0;
+            if (lane == 0) b = atomicAdd(&B.ctl->reserved, (unsigned long long)HYP_PEEL_CHUNK);
+            b = __shfl(b, 0, 64);
+            if (b + HYP_PEEL_CHUNK <= B.cap) {
+                if (w_pos + lane < w_end) ev[w_pos + lane].code = 0;       // the < 64 slots left of the old chunk stay empty
+                w_pos = b; w_end = b + HYP_PEEL_CHUNK;
+            } else full = true;
+        }
+        if (full) {
+            // this round's buffer is full: set aside what would peel off next, return the unused ids, walk the rest out
+            const unsigned long long m = m_int;
+            if (m) {
+                unsigned int base = 0;
+                if (lane == (unsigned int)(__ffsll((long long)m) - 1)) base = atomicAdd(&B.ctl->n_susp[B.cur], (unsigned int)__popcll(m));
+                base = __shfl(base, __ffsll((long long)m) - 1, 64);
+                if (st == ST_NEED_INTERACT) {
+                    SuspRec<NDT, GEOM> &R = ((SuspRec<NDT, GEOM> *)B.susp[B.cur])[base + __popcll(m & lt)];
+                    R.p = p; R.g = g; R.f = f;
+                    st = ST_DONE;
+                }
+            }
+            if (st == ST_NEED_EMIT) st = ST_DONE;
+            if (dsp.next < dsp.end) {
+                if (lane == 0) {
+                    const unsigned int i = atomicAdd(&B.ctl->n_ret[B.cur], 1u);
+                    B.ret[B.cur][2 * (size_t)i] = dsp.next; B.ret[B.cur][2 * (size_t)i + 1] = dsp.end;
+                }
+                dsp.next = dsp.end;
+            }
+            pool_empty = true;
+            m_int = 0; m_emit = 0;
+            if (!m_walk) break;
+        }
+
+        // peel: 0 none, 1 after emission, 2 after interaction
+        int peel = 0;
+        Angle a_prev = p.a;
+        double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
+        int last = LAST_SR; bool last_iso = true;
+
+        if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
+            if (st == ST_NEED_INTERACT) {
+                if ((long long)p.inter == P.n_inter_max + 1) {
+                    cnt.killed_int++; st = ST_NEED_EMIT;
+                } else {
+                    int scattered, dust_id;
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, false);
+                    f.dust_id = dust_id;
+                    if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
+                    else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                    if (killed) st = ST_NEED_EMIT;
+                    else { p.inter++; peel = 2; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
+        if (m_emit && !pool_empty && (__popcll(m_emit) >= L.emit_threshold || !m_walk)) {
+            const bool need = st == ST_NEED_EMIT;
+            unsigned long long id = 0;
+            bool got = take_id(P, L, dsp, need, id);
+            if (need) {
+                if (!got) st = ST_DONE;
+                else {
+                    rng_init(g, P.seed_key, L.iter_tag, id);
+                    int source_id = 0;
+                    Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM, true>(P, W, p, g, cnt, source_id, src_normal);
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    if (!ok) st = ST_NEED_EMIT;
+                    else { peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true; }
+                }
+            }
+            if (__ballot(st == ST_DONE)) pool_empty = true;
+            if (*((volatile int *)P.err) != 0) { if (st == ST_NEED_EMIT) st = ST_DONE; pool_empty = true; }
+        } else if (m_emit && pool_empty) {
+            if (st == ST_NEED_EMIT) st = ST_DONE;
+        }
+
+        if (__ballot(peel != 0)) {
+            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS));
+            const unsigned long long m = __ballot(do_peel);
+            if (m) {
+                if (do_peel) {
+                    PeelEvent<NDT, GEOM> &E = ev[w_pos + __popcll(m & lt)];
+                    E.r[0] = p.r[0]; E.r[1] = p.r[1]; E.r[2] = p.r[2]; E.nu = p.nu; E.energy = p.energy;
+                    E.a_prev = a_prev;
+                    E.s_prev[0] = s_prev[0]; E.s_prev[1] = s_prev[1]; E.s_prev[2] = s_prev[2]; E.s_prev[3] = s_prev[3];
+#pragma unroll
+                    for (int d = 0; d < NDT; d++) E.chi[d] = p.chi[d];
+                    E.id = ((unsigned long long)g.id_hi << 32) | g.id_lo;
+                    E.peel_seq = p.peel_seq;
+                    E.code = 1 | (last << 1) | ((last_iso ? 1 : 0) << 3);
+                    E.f = f;
+                    E.cell = p.cell;
+                    p.peel_seq++;
+                }
+                w_pos += __popcll(m); n_written += __popcll(m);
+            }
+            if (peel != 0) {
+                if (peel == 1) {
+                    // first propagation after emission: iter_final.f90:191-209
+                    if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
+                    else {
+                        bool sampled = false;
+                        if (P.forced_first) {
+                            bool killed = false;
+                            double tau_escape = escape_tau<NDT, GEOM>(P, W, p.r, p.v, p.cell, p.chi, g, cnt, killed);
+                            if (tau_escape > 1e-10 && !killed) {
+                                double weight, tau;
+                                forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                                p.tau_req = tau; p.energy *= weight; sampled = true;
+                            }
+                        }
+                        if (!sampled) p.tau_req = rng_exp(g);
+                        p.tau_ach = 0.0;
+                        begin_integrate(P, p);
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    }
+                } else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                }
+            }
+        }
+
+#pragma unroll 1
+        for (int k = 0; k < HYP_WALK_STEPS; k++) {
+            if (st == ST_WALK) st = walk_step<NDT, GEOM, false>(P, W, p, g, nullptr, cnt);
+        }
+    }
+
+    for (unsigned long long q = w_pos + lane; q < w_end; q += 64ull) ev[q].code = 0;      // reserved, never written
+
+    double e = wave_sum(cnt.energy_current);
+    double c = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    double ki = wave_sum((double)cnt.killed_int);
+    double ni = wave_sum((double)cnt.interactions);
+    if (lane == 0) {
+        if (n_written) atomicAdd(&B.ctl->written, (unsigned long long)n_written);
+        if (e != 0.0) unsafeAtomicAdd(&P.tail[TAIL_ENERGY], e);
+        if (c != 0.0) unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], c);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
+        if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
+    }
+}
+
+// The peel-off half: one lane per (event, view), peeloff<.., PLAIN> up to the walk, grid_escape_tau
+// (grid_propagate_3d.f90:377-480) a few cells at a time, image_bin at the end.
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem *__restrict__ Pp, DeferBuf B, uint32_t iter_tag)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
+    __shared__ unsigned long long img_keys[HYP_IMG_CACHE];
+    __shared__ double img_vals[HYP_IMG_CACHE];
+    ImgCache ic;
+    img_cache_init(ic, img_keys, img_vals);
+    const int nd = ndust<NDT>(P);
+    const PeelEvent<NDT, GEOM> *__restrict__ ev = (const PeelEvent<NDT, GEOM> *)B.events;
+    unsigned long long n_slots = B.ctl->reserved;
+    if (n_slots > B.cap) n_slots = B.cap;
+    const unsigned long long n_views = (unsigned long long)P.n_views_total;
+    const unsigned long long n_pairs = n_slots * n_views;
+    const unsigned int lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    Counters cnt;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+
+    // lane state: 0 idle, 1 walking, 2 out of the grid (to be binned)
+    int st = 0, ig = 0;
+    double r[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 1.0}, tau = 0.0, chi[NDT];
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, energy = 0.0;
+    long long k_img = -1, k_sed = -1;
+    Cell<GEOM> c;
+    Rng gp;
+#pragma unroll
+    for (int d = 0; d < NDT; d++) chi[d] = 0.0;
+    gp.countdown = 0; gp.blk_b = 0;
+    unsigned long long q_next = 0, q_end = 0;       // the wave's reserved pairs
+    bool exhausted = n_pairs == 0;
+
+    for (;;) {
+        const unsigned long long m_idle = __ballot(st == 0);
+        const unsigned long long m_walk = __ballot(st == 1);
+        if (!exhausted && (__popcll(m_idle) >= HYP_PEEL_REFILL || !m_walk)) {
+            // hand pairs to the idle lanes
+            unsigned long long mask = m_idle, pair = 0;
+            bool got = false;
+            while (mask) {
+                if (q_next >= q_end) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(&B.ctl->pair_cursor, (unsigned long long)HYP_PAIR_CHUNK);
+                    b = __shfl(b, 0, 64);
+                    if (b >= n_pairs) { exhausted = true; break; }
+                    q_next = b; q_end = b + HYP_PAIR_CHUNK < n_pairs ? b + HYP_PAIR_CHUNK : n_pairs;
+                }
+                const unsigned long long avail = q_end - q_next;
+                const unsigned int rank = __popcll(mask & lt);
+                const bool mine = ((mask >> lane) & 1ull) && rank < avail;
+                if (mine) { pair = q_next + rank; got = true; }
+                const unsigned long long taken = __ballot(mine);
+                q_next += __popcll(taken);
+                mask &= ~taken;
+            }
+            if (got) {
+                const PeelEvent<NDT, GEOM> &E = ev[pair / n_views];
+                const int code = E.code;
+                if (code != 0) {
+                    int vg = (int)(pair % n_views), g_i = 0;
+                    while (g_i + 1 < P.n_peeled && vg >= P.peeled[g_i + 1].view_base) g_i++;
+                    const DPeeled &G = P.peeled[g_i];
+                    const int iv = vg - G.view_base;
+                    const int last = (code >> 1) & 3;
+                    const bool last_iso = (code >> 3) & 1;
+                    const PeelFlags f = E.f;
+                    Angle a_req;
+                    a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
+                    a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+                    const double nu = E.nu;
+                    if (last_iso) {
+                        s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+                    } else {
+                        // dust_scatter_peeloff: dust_type_4elem.f90:421-444 (PLAIN: the sources are isotropic points)
+                        const DDust &D = P.dust[f.dust_id];
+                        s[0] = E.s_prev[0]; s[1] = E.s_prev[1]; s[2] = E.s_prev[2]; s[3] = E.s_prev[3];
+                        if (last == LAST_DS) {
+                            const Angle a_prev = E.a_prev;
+                            Angle a_scat;
+                            difference_angle(a_prev, a_req, a_scat);
+                            if (a_scat.cost < D.mu_min || a_scat.cost > D.mu_max) { s[0] = s[1] = s[2] = s[3] = 0.0; }
+                            else {
+                                double P1, P2, P3, P4;
+                                interp_P(D, a_scat.cost, nu, P1, P2, P3, P4);
+                                scatter_stokes(s, a_prev, a_scat, a_req, P1, P2, P3, P4);
+                            }
+                        }
+                    }
+                    r[0] = E.r[0]; r[1] = E.r[1]; r[2] = E.r[2];
+                    angle_to_vector(a_req, v[0], v[1], v[2]);
+                    c = E.cell;
+                    bool ok = geo_place(P, W, r, v, c);
+                    if (!ok) cnt.killed_geo++;
+                    const double d = -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
+                    ok = ok && !(d < G.d_min || d > G.d_max);
+                    const double dr0 = r[0] - G.origin[0], dr1 = r[1] - G.origin[1], dr2 = r[2] - G.origin[2];
+                    const double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
+                    const double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                    bool inside = false;
+                    if (G.compute_image)
+                        inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
+                                 ((y_image >= G.y_min && y_image <= G.y_max) || (y_image <= G.y_min && y_image >= G.y_max));
+                    if (!inside && G.compute_sed) inside = x_image * x_image + y_image * y_image <= G.ap_max * G.ap_max;
+                    ok = ok && inside;
+                    if (ok) {
+                        energy = E.energy;
+                        // the bins do not depend on the attenuation (image_bin: image_type.f90:408-476); a NaN Stokes I
+                        // after it is checked again when the lane deposits
+                        image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed);
+                        ig = g_i; tau = 0.0;
+#pragma unroll
+                        for (int dd = 0; dd < NDT; dd++) chi[dd] = E.chi[dd];
+                        peel_rng(P, gp, P.seed_key, iter_tag, E.id, E.peel_seq, vg);
+                        st = 1;
+                        if (G.ignore_optical_depth) st = 2;
+                        else {
+                            geo_begin(r, v, c);
+                            if (geo_escaped(P, c)) st = 2;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__ballot(st != 0)) { if (exhausted) break; else continue; }
+
+#pragma unroll 1
+        for (int k = 0; k < HYP_PEEL_STEPS; k++) {
+            if (st == 1) {
+                bool check_ok = true;
+                if (gp.countdown == 0) {
+                    gp.countdown = rng_check_gap(gp, P.check_p, P.check_log1mp, 2u);
+                    check_ok = geo_check_cell(P, W, r, v, c);
+                } else gp.countdown--;
+                double tmin = 0.0; int im[3];
+                if (!check_ok || !geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; st = 0; }
+                else {
+                    const size_t base = geo_index(P, c) * (size_t)nd;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+#pragma unroll
+                    for (int dd = 0; dd < NDT; dd++) if (dd < nd) tau += chi[dd] * P.density[base + dd] * tmin;
+                    cnt.crossings++;
+                    geo_advance(P, r, c, im);
+                    if (geo_invalid(P, c)) { cnt.killed_geo++; st = 0; }
+                    else if (geo_escaped(P, c)) st = 2;
+                }
+            }
+        }
+
+#ifdef HYP_PEEL_NO_DEPOSIT      // tuning builds: what the image atomics cost
+        if (st == 2) st = 0;
+#endif
+        if (__ballot(st == 2)) {
+            double sa[4] = {0.0, 0.0, 0.0, 0.0};
+            bool live = false;
+            if (st == 2) {
+                const double att = exp(-tau);
+                sa[0] = s[0] * att; sa[1] = s[1] * att; sa[2] = s[2] * att; sa[3] = s[3] * att;
+                live = sa[0] == sa[0];
+            }
+            for (int g_i = 0; g_i < P.n_peeled; g_i++) {
+                const bool mine = live && ig == g_i;
+                if (!__ballot(mine)) continue;
+                const DPeeled &G = P.peeled[g_i];
+                const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
+                double val[4] = {sa[0] * energy, sa[1] * energy, sa[2] * energy, sa[3] * energy};
+                if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, mine ? k_img : -1, stride_img, G.n_stokes, val, &ic);
+                if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, mine ? k_sed : -1, stride_sed, G.n_stokes, val, &ic);
+            }
+            if (st == 2) st = 0;
+        }
+    }
+
+    img_cache_flush(ic);
+    double cr = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    if (lane == 0) {
+        if (cr != 0.0) unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], cr);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
+    }
+}

@@ -133,6 +133,7 @@ struct DProblem {
     int midplane, n_dim;
     const OctCell *oct_cells;             // [n_cells]
     const int *oct_children;              // [n_cells][8], -1 where not refined
+    const int *oct_neigh;                 // [n_cells][6] (axis * 2 + up): see geo_advance; n_cells = outside the grid
     double oct_half[3], oct_box[6], oct_eps;
     const double *vor_sites;              // voronoi: [n_cells][3]
     const int *vor_idx, *vor_neigh;       // CSR neighbour lists (ids >= 0, walls -1..-6)
@@ -205,6 +206,26 @@ struct LaunchParams {
     uint32_t iter_tag;
     int chunk;
     int interact_threshold, emit_threshold;
+};
+
+// Deferred peel-off (hyp_defer.h): control block and buffers of one {propagate, peel} round
+#ifndef HYP_PEEL_CHUNK
+#define HYP_PEEL_CHUNK 512      // event slots a wave reserves at a time (one same-address atomic per chunk)
+#endif
+struct PeelCtl {
+    unsigned long long reserved;        // event slots reserved in this round (failed reservations count: may exceed the capacity)
+    unsigned long long pair_cursor;     // (event, view) pairs handed out by the peel kernel
+    unsigned long long written;         // events written in this round
+    unsigned int n_susp[2], n_ret[2];   // packets set aside / id ranges returned, by round parity
+};
+
+struct DeferBuf {
+    void *events;                       // PeelEvent<NDT, GEOM>[cap] (hyp_defer.h)
+    unsigned long long cap;             // a multiple of HYP_PEEL_CHUNK
+    PeelCtl *ctl;
+    void *susp[2];                      // SuspRec<NDT, GEOM>[one per lane of the propagation grid], by round parity
+    unsigned long long *ret[2];         // (next, end) pairs, one per wave of the propagation grid
+    int cur;                            // parity of this round
 };
 
 // ---------------------------------------------------------------------------

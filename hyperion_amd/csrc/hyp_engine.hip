@@ -182,7 +182,8 @@ struct hyp_engine {
     DProblem *d_problem = nullptr;
     double *d_blob = nullptr;
     OctCell *d_oct_cells = nullptr;
-    int *d_oct_children = nullptr;
+    int *d_oct_children = nullptr, *d_oct_neigh = nullptr;
+    int oct_neighbours = 1;         // option: 0 = geo_advance climbs and descends as the reference does (for comparison)
     double *d_vor_sites = nullptr, *d_vor_volume = nullptr, *d_vor_bb = nullptr;
     unsigned int *d_mask_map = nullptr;
     bool ray_pending = false;
@@ -250,6 +251,16 @@ struct hyp_engine {
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
+    // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
+    int defer_peel = 1;             // option: 1 = use it where plain_imaging holds, 0 = peel off inline
+    long long peel_events = 16ll << 20;     // option: capacity of the event buffer, in events
+    void *d_peel_events = nullptr, *d_peel_susp[2] = {nullptr, nullptr};
+    unsigned long long *d_peel_ret[2] = {nullptr, nullptr};
+    PeelCtl *d_peel_ctl = nullptr, *h_peel_ctl = nullptr;
+    unsigned long long *h_peel_counter = nullptr;
+    size_t peel_cap = 0, peel_event_bytes = 0, peel_lanes = 0;
+    int last_defer_rounds = 0;
+    unsigned long long last_defer_events = 0;
     bool count_photons = false, pda = false;
     int n_bins = 0, nj_max = 1;
     unsigned int *d_nphot = nullptr, *d_last_id = nullptr;      // [n_cells]
@@ -283,8 +294,8 @@ size_t lds_bytes(const DProblem &P) { return P.grid_type != 1 ? 0 : sizeof(doubl
 
 RayKernel pick_ray_kernel(int nd, int grid_type)
 {
-#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
-    return pick_ray_kernel_g<GEOM_CAR>(nd);
+#ifdef HYP_VARIANT_GEOM   // tuning builds (tools/variants.py) link one geometry unit only
+    return pick_ray_kernel_g<HYP_VARIANT_GEOM>(nd);
 #endif
     switch (grid_type) {
     case 2: return pick_ray_kernel_g<GEOM_OCT>(nd);
@@ -298,8 +309,8 @@ RayKernel pick_ray_kernel(int nd, int grid_type)
 
 LucyKernel pick_lucy_kernel(int nd, int grid_type)
 {
-#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
-    return pick_lucy_kernel_g<GEOM_CAR>(nd);
+#ifdef HYP_VARIANT_GEOM   // tuning builds (tools/variants.py) link one geometry unit only
+    return pick_lucy_kernel_g<HYP_VARIANT_GEOM>(nd);
 #endif
     switch (grid_type) {
     case 2: return pick_lucy_kernel_g<GEOM_OCT>(nd);
@@ -311,10 +322,25 @@ LucyKernel pick_lucy_kernel(int nd, int grid_type)
     }
 }
 
+DeferKernels pick_defer_kernels(int nd, int grid_type)
+{
+#ifdef HYP_VARIANT_GEOM
+    return pick_defer_kernels_g<HYP_VARIANT_GEOM>(nd);
+#endif
+    switch (grid_type) {
+    case 2: return pick_defer_kernels_g<GEOM_OCT>(nd);
+    case 3: return pick_defer_kernels_g<GEOM_VOR>(nd);
+    case 4: return pick_defer_kernels_g<GEOM_AMR>(nd);
+    case 5: return pick_defer_kernels_g<GEOM_SPH>(nd);
+    case 6: return pick_defer_kernels_g<GEOM_CYL>(nd);
+    default: return pick_defer_kernels_g<GEOM_CAR>(nd);
+    }
+}
+
 LucyKernel pick_final_kernel(int nd, int grid_type, bool plain)
 {
-#ifdef HYP_VARIANT_CAR_ONLY   // tuning builds (tools/variants.py) link the Cartesian unit only
-    return pick_final_kernel_g<GEOM_CAR>(nd, plain);
+#ifdef HYP_VARIANT_GEOM   // tuning builds (tools/variants.py) link one geometry unit only
+    return pick_final_kernel_g<HYP_VARIANT_GEOM>(nd, plain);
 #endif
     switch (grid_type) {
     case 2: return pick_final_kernel_g<GEOM_OCT>(nd, plain);
@@ -571,7 +597,7 @@ void hyp_destroy(hyp_handle h)
     if (!h) return;
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
-    free_dev(h->d_oct_cells); free_dev(h->d_oct_children);
+    free_dev(h->d_oct_cells); free_dev(h->d_oct_children); free_dev(h->d_oct_neigh);
     free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
     free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
@@ -581,6 +607,10 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_mrw_alpha); free_dev(h->d_mrw_diff); free_dev(h->d_mrw_kp);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
+    free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
+    free_dev(h->d_peel_ctl);
+    if (h->h_peel_ctl) (void)hipHostFree(h->h_peel_ctl);
+    if (h->h_peel_counter) (void)hipHostFree(h->h_peel_counter);
     free_dev(h->d_img_accum);
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
@@ -631,7 +661,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     int vor_g = 1;
     const double *win[3] = {pr->grid.w1, pr->grid.w2, pr->grid.w3};
     std::vector<OctCell> oct_cells;
-    std::vector<int> oct_children;
+    std::vector<int> oct_children, oct_neigh;
     if (is_vor) {
         // setup_grid_geometry: grid_geometry_voronoi.f90:96-188
         const int64_t nc = pr->grid.n_cells;
@@ -859,6 +889,29 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             if (cc.refined) stack.push_back({c, 0});
         }
         if (filled != nc) return set_error("refined array is not self-consistent");
+        // neighbour across each face, no finer than the cell itself: what next_cell_int (:328-347) finds when its descent is
+        // stopped at the cell's own level (geo_advance goes on from there)
+        oct_neigh.assign((size_t)nc * 6, (int)nc);
+        std::vector<int> subs(256);
+        for (int64_t id = 1; id < nc; id++)
+            for (int axis = 0; axis < 3; axis++)
+                for (int up = 0; up < 2; up++) {
+                    int cur = (int)id, depth = 0, n = (int)nc;
+                    while (cur != 0) {
+                        const int sub = oct_cells[cur].subcell, par = oct_cells[cur].parent;
+                        if (((sub >> axis) & 1) != up) {
+                            int S = oct_children[(size_t)par * 8 + (up ? (sub | (1 << axis)) : (sub & ~(1 << axis)))];
+                            while (oct_cells[S].refined && depth > 0) {
+                                const int sc = subs[--depth];
+                                S = oct_children[(size_t)S * 8 + ((sc & ~(1 << axis)) | ((up ? 0 : 1) << axis))];
+                            }
+                            n = S;
+                            break;
+                        }
+                        subs[depth++] = sub; cur = par;
+                    }
+                    oct_neigh[(size_t)id * 6 + 2 * axis + up] = n;
+                }
     }
 
     int ndev = 0;
@@ -1451,7 +1504,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMemcpy(h->d_oct_cells, oct_cells.data(), sizeof(OctCell) * oct_cells.size(), hipMemcpyHostToDevice));
         HIPC(hipMalloc(&h->d_oct_children, sizeof(int) * oct_children.size()));
         HIPC(hipMemcpy(h->d_oct_children, oct_children.data(), sizeof(int) * oct_children.size(), hipMemcpyHostToDevice));
-        P.oct_cells = h->d_oct_cells; P.oct_children = h->d_oct_children;
+        HIPC(hipMalloc(&h->d_oct_neigh, sizeof(int) * oct_neigh.size()));
+        HIPC(hipMemcpy(h->d_oct_neigh, oct_neigh.data(), sizeof(int) * oct_neigh.size(), hipMemcpyHostToDevice));
+        P.oct_cells = h->d_oct_cells; P.oct_children = h->d_oct_children; P.oct_neigh = h->d_oct_neigh;
     }
     for (int d = 0; d < pr->n_dust; d++) {
         DDust &D = P.dust[d]; const DustOffsets &O = doff[d];
@@ -2133,6 +2188,16 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_split") h->tile_split = (int)value;
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
+    else if (n == "defer_peel") h->defer_peel = value != 0;
+    else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
+    else if (n == "peel_events") {
+        if (value < 1) return h->set_error("peel_events must be positive");
+        if (h->peel_events != value) {      // the buffers are allocated by the next imaging iteration
+            free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
+            h->peel_cap = 0;
+        }
+        h->peel_events = value;
+    }
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = (int)value;
     else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
@@ -2157,6 +2222,11 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_us") *value = (int64_t)(h->last_walk_ms * 1000.0);
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
+    else if (n == "defer_peel") *value = h->defer_peel;
+    else if (n == "peel_events") *value = h->peel_events;
+    else if (n == "plain_imaging") *value = h->plain_imaging ? 1 : 0;
+    else if (n == "last_defer_rounds") *value = h->last_defer_rounds;
+    else if (n == "last_defer_events") *value = (int64_t)h->last_defer_events;
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
     else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
     else if (n == "tile_drain") *value = h->tile_drain;
@@ -2169,6 +2239,66 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
 }
 
 // ---- imaging iteration -------------------------------------------------------
+
+// Buffers of the deferred peel-off, sized for `lanes` lanes of the propagation grid.  Returns nonzero when they cannot be had
+// (the caller then peels off inline).
+static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes)
+{
+    const size_t waves = lanes / 64;
+    size_t cap = (size_t)h->peel_events;
+    cap = (cap + HYP_PEEL_CHUNK - 1) / HYP_PEEL_CHUNK * HYP_PEEL_CHUNK;
+    if (h->d_peel_events && h->peel_cap == cap && h->peel_event_bytes == dk.event_bytes && h->peel_lanes >= lanes) return 0;
+    free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
+    h->peel_cap = 0;
+    bool ok = hipMalloc(&h->d_peel_events, cap * dk.event_bytes) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+        ok = hipMalloc(&h->d_peel_susp[i], lanes * dk.susp_bytes) == hipSuccess &&
+             hipMalloc((void **)&h->d_peel_ret[i], waves * 2 * sizeof(unsigned long long)) == hipSuccess;
+    if (ok && !h->d_peel_ctl)
+        ok = hipMalloc((void **)&h->d_peel_ctl, sizeof(PeelCtl)) == hipSuccess && hipHostMalloc((void **)&h->h_peel_ctl, sizeof(PeelCtl)) == hipSuccess &&
+             hipHostMalloc((void **)&h->h_peel_counter, sizeof(unsigned long long)) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
+        return 1;
+    }
+    h->peel_cap = cap; h->peel_event_bytes = dk.event_bytes; h->peel_lanes = lanes;
+    return 0;
+}
+
+// Rounds of {propagate, peel} until every packet id has been used and no packet is left set aside (hyp_defer.h).
+static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, unsigned blocks, size_t lds)
+{
+    DeferBuf B;
+    B.events = h->d_peel_events; B.cap = h->peel_cap; B.ctl = h->d_peel_ctl;
+    B.susp[0] = h->d_peel_susp[0]; B.susp[1] = h->d_peel_susp[1]; B.ret[0] = h->d_peel_ret[0]; B.ret[1] = h->d_peel_ret[1];
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.peel, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+    const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
+    int idle_rounds = 0;
+    for (int round = 0;; round++) {
+        B.cur = round & 1;
+        hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, B.cur, round == 0 ? 1 : 0);
+        hipLaunchKernelGGL(dk.propagate, dim3(blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
+        hipLaunchKernelGGL(dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return h->set_error(std::string("deferred imaging launch: ") + hipGetErrorString(e));
+        (void)hipMemcpyAsync(h->h_peel_ctl, h->d_peel_ctl, sizeof(PeelCtl), hipMemcpyDeviceToHost, h->stream);
+        (void)hipMemcpyAsync(h->h_peel_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
+        e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
+        const PeelCtl &C = *h->h_peel_ctl;
+        h->last_defer_rounds = round + 1;
+        h->last_defer_events += C.written;
+        if (C.n_susp[B.cur] == 0 && C.n_ret[B.cur] == 0 && *h->h_peel_counter >= L.end_id) break;
+        // a round without a single event can happen (all packets in flight left the grid), a long run of them cannot
+        idle_rounds = C.written == 0 ? idle_rounds + 1 : 0;
+        if (idle_rounds > 64) return h->set_error("deferred peel-off makes no progress (event buffer too small?)");
+        int err = 0;
+        if (hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess || err != 0) break;     // reported by hyp_final_accumulators
+    }
+    return 0;
+}
 
 int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
 {
@@ -2192,14 +2322,20 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
     LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->hp.mono_which);
+    // deferred peel-off where the plain kernel applies and there is something to peel into (hyp_defer.h)
+    bool deferred = h->plain_imaging && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    DeferKernels dk;
+    std::memset(&dk, 0, sizeof dk);
+    if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {
         int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, deferred ? (const void *)dk.propagate : (const void *)k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
         bpc = occ;
     }
     long long blocks = (long long)h->n_cu * bpc;
+    if (deferred && defer_buffers(h, dk, (size_t)blocks * 256)) deferred = false;      // no memory for the buffers: peel off inline
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
@@ -2214,6 +2350,15 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     }
     L.chunk = chunk;
     L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    h->last_defer_rounds = 0; h->last_defer_events = 0;
+    if (deferred) {
+        (void)hipEventRecord(h->ev0, h->stream);
+        if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds)) return 1;
+        (void)hipEventRecord(h->ev1, h->stream);
+        h->final_pending = true;
+        h->pending_packets = n_local;
+        return 0;
+    }
     (void)hipEventRecord(h->ev0, h->stream);
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();

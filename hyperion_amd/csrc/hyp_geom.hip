@@ -5,6 +5,7 @@
 #define HYP_GEOM_TU 0   // GEOM_CAR
 #endif
 #include "hyp_kernels.h"
+#include "hyp_defer.h"
 #include "hyp_pick.h"
 
 template <int GEOM>
@@ -58,6 +59,33 @@ RayKernel pick_ray_kernel_g(int nd)
 #endif
 }
 
+template <int NDT, int GEOM>
+static DeferKernels defer_kernels()
+{
+    DeferKernels k;
+    k.propagate = final_defer_kernel<NDT, GEOM>; k.peel = peel_kernel<NDT, GEOM>; k.reset = defer_reset_kernel<GEOM>;
+    k.event_bytes = sizeof(PeelEvent<NDT, GEOM>); k.susp_bytes = sizeof(SuspRec<NDT, GEOM>);
+    return k;
+}
+
+template <int GEOM>
+DeferKernels pick_defer_kernels_g(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return defer_kernels<1, GEOM>();
+#else
+    switch (nd) {
+    case 1: return defer_kernels<1, GEOM>();
+    case 2: return defer_kernels<2, GEOM>();
+    case 3: return defer_kernels<3, GEOM>();
+    case 4: return defer_kernels<4, GEOM>();
+    default: return defer_kernels<HYP_MAXD, GEOM>();
+    }
+#endif
+}
+
 template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
 template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, bool);
 template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);
+template DeferKernels pick_defer_kernels_g<HYP_GEOM_TU>(int);

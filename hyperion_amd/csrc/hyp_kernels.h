@@ -236,6 +236,21 @@ __device__ __forceinline__ int oct_locate(const DProblem &P, const double r[3], 
     }
 }
 
+// locate_cell from `id` + the record of the leaf, one 32-B record per level
+__device__ __forceinline__ void oct_descend(const DProblem &P, const double r[3], int id, Cell<GEOM_OCT> &c)
+{
+    for (;;) {
+        const OctCell o = P.oct_cells[id];
+        if (!o.refined) {
+            c.id = id; c.c[0] = o.x; c.c[1] = o.y; c.c[2] = o.z;
+            c.parent = o.parent; c.level = o.level; c.subcell = o.subcell;
+            return;
+        }
+        int sub = (r[0] < o.x ? 0 : 1) | (r[1] < o.y ? 0 : 2) | (r[2] < o.z ? 0 : 4);
+        id = P.oct_children[8 * (size_t)id + sub];
+    }
+}
+
 __device__ __forceinline__ bool geo_escaped(const DProblem &P, const Cell<GEOM_OCT> &c) { return (unsigned long long)c.id == P.n_cells; }
 __device__ __forceinline__ size_t geo_index(const DProblem &P, const Cell<GEOM_OCT> &c) { return (size_t)c.id; }
 
@@ -244,7 +259,7 @@ __device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, con
 {
     if (r[0] < P.oct_box[0] || r[0] > P.oct_box[1] || r[1] < P.oct_box[2] || r[1] > P.oct_box[3] ||
         r[2] < P.oct_box[4] || r[2] > P.oct_box[5]) return false;
-    oct_load(P, oct_locate(P, r, 0), c);
+    oct_descend(P, r, 0, c);
     return true;
 }
 
@@ -301,13 +316,32 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
     const int axis = im[0] ? 0 : im[1] ? 1 : 2;
     const int up = (im[0] + im[1] + im[2]) > 0 ? 1 : 0;
     c.ow[0] = -im[0]; c.ow[1] = -im[1]; c.ow[2] = -im[2];
+    // The climb and the descent are chains of dependent loads whose length differs from lane to lane (the wave waits
+    // for the longest: up to 2 x depth L2 round trips per crossing).  oct_neigh holds, for every cell and face, where that
+    // climb-and-descend ends when it is stopped at the cell's own level (or at a leaf above it): the descent from there
+    // makes the same comparisons as the one from the sibling as long as r lies inside the cell's extent on the two
+    // other axes.  Within 1e-6 of an edge (round-off may have put r in the neighbour's column) take the reference's route.
+    if (P.oct_neigh) {
+        bool fast = true;
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const double h = ldexp(P.oct_half[b], -c.level), d = fabs(r[b] - c.c[b]);
+            if (b != axis && !(d < h * (1.0 - 1e-6) && h * 1e-6 > 1e-14 * (fabs(c.c[b]) + h))) fast = false;
+        }
+        if (fast) {
+            const int n = P.oct_neigh[6 * (size_t)c.id + 2 * axis + up];
+            if ((unsigned long long)n == P.n_cells) { c.id = n; return; }
+            oct_descend(P, r, n, c);
+            return;
+        }
+    }
     int id = c.id, parent = c.parent, sub = c.subcell;
     for (;;) {
         if (id == 0) { c.id = (int)P.n_cells; return; }
         int bit = (sub >> axis) & 1;
         if (bit != up) {
             int sib = up ? (sub | (1 << axis)) : (sub & ~(1 << axis));
-            oct_load(P, oct_locate(P, r, P.oct_children[8 * (size_t)parent + sib]), c);
+            oct_descend(P, r, P.oct_children[8 * (size_t)parent + sib], c);
             return;
         }
         id = parent;
@@ -1441,6 +1475,43 @@ __device__ __forceinline__ int ipos0(double xmin, double xmax, double x, int n)
 
 struct PeelFlags { int scattered, reprocessed, n_scat, dust_id, source_id; };
 
+// The direct light of a point source lands on ONE pixel per view and frequency bin, once per packet: atomics on one
+// address serialise in L2 (~35 ns each; 85 of 146 ms of the configs[3] imaging iteration before this cache).  Each
+// workgroup therefore keeps partial sums of the addresses its waves hit together in a small LDS table (open hashing
+// without probing: an address that finds its slot taken goes to HBM directly) and adds them to the cube once, when the
+// workgroup ends.
+#define HYP_IMG_CACHE 256       // entries (4 KB of LDS)
+struct ImgCache { unsigned long long *keys; double *vals; };
+
+__device__ __forceinline__ void img_cache_init(ImgCache &ic, unsigned long long *keys, double *vals)
+{
+    ic.keys = keys; ic.vals = vals;
+    for (int i = threadIdx.x; i < HYP_IMG_CACHE; i += blockDim.x) { keys[i] = 0ull; vals[i] = 0.0; }
+    __syncthreads();
+}
+
+// all waves of the workgroup, after their last deposit
+__device__ __forceinline__ void img_cache_flush(const ImgCache &ic)
+{
+    __syncthreads();
+    for (int i = threadIdx.x; i < HYP_IMG_CACHE; i += blockDim.x)
+        if (ic.keys[i]) unsafeAtomicAdd((double *)ic.keys[i], ic.vals[i]);
+}
+
+// *addr += v; `claim`: the address may take a free slot of the table (it was hit by several lanes at once)
+__device__ __forceinline__ void img_add(const ImgCache *ic, double *addr, double v, bool claim)
+{
+    if (v == 0.0) return;       // Q, U, V of unpolarised light
+    if (ic) {
+        const unsigned long long key = (unsigned long long)addr;
+        const unsigned int slot = ((unsigned int)(key >> 3) * 2654435761u) >> 24;
+        unsigned long long cur = ic->keys[slot];
+        if (cur == 0ull && claim) { cur = atomicCAS(&ic->keys[slot], 0ull, key); if (cur == 0ull) cur = key; }
+        if (cur == key) { atomicAdd(&ic->vals[slot], v); return; }
+    }
+    unsafeAtomicAdd(addr, v);
+}
+
 // Wave-cooperative accumulation of one value per lane into cube[key + i*stride],
 // i = 0..n-1 (the Stokes components).  Lanes that hit the same element are summed
 // in registers first (up to three distinct keys per call; the direct light of a
@@ -1448,7 +1519,7 @@ struct PeelFlags { int scattered, reprocessed, n_scat, dust_id, source_id; };
 // serialise as same-address atomics), the rest falls back to one atomic per lane.
 // Must be called with all 64 lanes active; `key < 0` = nothing to add.
 __device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, double *__restrict__ cube2, long long key,
-                                                size_t stride, int n, const double val[4])
+                                                size_t stride, int n, const double val[4], const ImgCache *ic = nullptr)
 {
     unsigned long long todo = __ballot(key >= 0);
     for (int round = 0; round < 3 && todo; round++) {
@@ -1462,8 +1533,8 @@ __device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, doubl
                 double t = wave_sum(v);
                 double t2 = cube2 ? wave_sum(v * v) : 0.0;
                 if ((int)__lane_id() == leader) {
-                    unsafeAtomicAdd(&cube[k0 + (long long)i * (long long)stride], t);
-                    if (cube2) unsafeAtomicAdd(&cube2[k0 + (long long)i * (long long)stride], t2);
+                    img_add(ic, &cube[k0 + (long long)i * (long long)stride], t, true);
+                    if (cube2) img_add(ic, &cube2[k0 + (long long)i * (long long)stride], t2, true);
                 }
             }
             if (same) key = -1;
@@ -1474,8 +1545,8 @@ __device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, doubl
     }
     if (key >= 0) {
         for (int i = 0; i < n; i++) {
-            unsafeAtomicAdd(&cube[key + (long long)i * (long long)stride], val[i]);
-            if (cube2) unsafeAtomicAdd(&cube2[key + (long long)i * (long long)stride], val[i] * val[i]);
+            img_add(ic, &cube[key + (long long)i * (long long)stride], val[i], false);
+            if (cube2) img_add(ic, &cube2[key + (long long)i * (long long)stride], val[i] * val[i], false);
         }
     }
 }
@@ -1524,7 +1595,7 @@ __device__ __forceinline__ void image_bin_keys(const DProblem &P, const DPeeled 
 // Must be called by all 64 lanes.
 template <bool PLAIN = false>
 __device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled &G, bool live, double nu, double energy, const double s[4],
-                                               const PeelFlags &f, double x_image, double y_image, int iv)
+                                               const PeelFlags &f, double x_image, double y_image, int iv, const ImgCache *ic = nullptr)
 {
     const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
     const bool use_filters = !PLAIN && G.use_filters;
@@ -1547,8 +1618,8 @@ __device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled 
             }
         }
         // wave-uniform from here: combine lanes that hit the same pixel / SED bin
-        if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img, stride_img, G.n_stokes, val);
-        if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed, stride_sed, G.n_stokes, val);
+        if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img, stride_img, G.n_stokes, val, ic);
+        if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed, stride_sed, G.n_stokes, val, ic);
     }
 }
 
@@ -1598,7 +1669,7 @@ __device__ __forceinline__ void peel_rng(const DProblem &P, Rng &gp, uint32_t ke
 template <int NDT, int GEOM, bool PLAIN = false>
 __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, bool active,
                                         const Angle &a_prev, const double s_prev[4], int last, bool last_isotropic,
-                                        const PeelFlags &f, Rng &g, Counters &cnt)
+                                        const PeelFlags &f, Rng &g, Counters &cnt, const ImgCache *ic = nullptr)
 {
     for (int ig = 0; ig < P.n_peeled; ig++) {
         const DPeeled &G = P.peeled[ig];
@@ -1679,7 +1750,7 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                     }
                 }
             }
-            deposit_images<PLAIN>(P, G, live, p.nu, p.energy, s_out, f, x_out, y_out, iv);
+            deposit_images<PLAIN>(P, G, live, p.nu, p.energy, s_out, f, x_out, y_out, iv, ic);
         }
     }
 }
@@ -2098,6 +2169,10 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
     const DProblem &P = *Pp;
     Walls W;
     stage_walls<GEOM>(P, lds, W);
+    __shared__ unsigned long long img_keys[HYP_IMG_CACHE];
+    __shared__ double img_vals[HYP_IMG_CACHE];
+    ImgCache ic;
+    img_cache_init(ic, img_keys, img_vals);
     Packet<NDT, GEOM> p;
     Rng g;
     const bool has_mrw = !PLAIN && P.mrw, has_reabs = !PLAIN && P.any_intersect;
@@ -2241,7 +2316,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
             // (a re-emission by a source is peeled in any case: "a kind of scattering", :226-227)
             const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);   // peel 4 (MRW): :171-173
             if (P.n_peeled > 0 && __ballot(do_peel)) {
-                peeloff<NDT, GEOM, PLAIN>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt);
+                peeloff<NDT, GEOM, PLAIN>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt, &ic);
                 if (do_peel) p.peel_seq++;
             }
             if (peel != 0) {
@@ -2284,6 +2359,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
         }
     }
 
+    img_cache_flush(ic);
     double e = wave_sum(cnt.energy_current);
     double c = wave_sum((double)cnt.crossings);
     double kg = wave_sum((double)cnt.killed_geo);

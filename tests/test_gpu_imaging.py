@@ -211,3 +211,37 @@ def test_inside_observer_parity(raytracing):
         np.testing.assert_allclose(ra[0][name], rb[0][name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(rb[0][name])), err_msg=name)
     img = ra[0]["img"][0]
     assert img.shape == (4, 1, 5, 9, 4) and img.sum() > 0
+
+
+def _images_equal(ra, rb, rtol=1e-9):
+    for ga, gb in zip(ra, rb):
+        assert set(ga) == set(gb)
+        for name in gb:
+            scale = np.nanmax(np.abs(gb[name]))
+            np.testing.assert_allclose(ga[name], gb[name], rtol=rtol, atol=1e-11 * scale, err_msg=name)
+
+
+@pytest.mark.parametrize("kw", [{}, {"uncertainties": True, "track_origin": "detailed", "theta": [10.0, 80.0, 150.0], "phi": [0.0, 120.0, 300.0]}])
+@pytest.mark.parametrize("peel_events", [0, 4096])
+def test_deferred_peeloff_equals_inline(kw, peel_events):
+    """hyp_defer.h: the events written by the propagation kernel and walked by the peel kernel give the images of the
+    inline peel-off (the same sums in another order), also when the event buffer is so small that the iteration takes
+    many rounds, with packets set aside and id ranges returned between them."""
+    prob = imaging_problem(tau=3.0, **kw)
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(20000, 1, want_output=False)
+    assert eng.get_option("plain_imaging") == 1 and eng.get_option("defer_peel") == 1
+    if peel_events:
+        eng.set_option("peel_events", peel_events)
+    ra, sa = eng.final_iteration(30000)
+    rounds = eng.get_option("last_defer_rounds")
+    assert rounds >= (3 if peel_events else 1)
+    assert eng.get_option("last_defer_events") >= 30000
+    eng.set_option("defer_peel", 0)
+    rb, sb = eng.final_iteration(30000)
+    assert eng.get_option("last_defer_rounds") == 0
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+    _images_equal(ra, rb)
+    eng.close()

@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/$TAG; rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
 cd $REPO
 for TESTS in "${TESTS:-}" "${TESTS2:-}"; do if [ -n "$TESTS" ]; then
-  echo "== tests: $TESTS"; timeout 1500 python -m pytest $TESTS -x -q -m gpu >> $OUT/tests.log 2>&1; echo rc $?; tail -5 $OUT/tests.log
+  echo "== tests: $TESTS"; timeout 1500 python -m pytest $TESTS -x -q -m gpu --timeout=300 --timeout_method=thread >> $OUT/tests.log 2>&1; echo rc $?; tail -5 $OUT/tests.log
 fi; done
 i=0
 for opts in "$@"; do

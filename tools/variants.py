@@ -10,7 +10,7 @@ VDIR = os.path.join(ROOT, "build", "variants")
 
 
 def build(specs):
-    """Each variant: hyp_engine.hip (tiled kernels, one species) + the Cartesian geometry unit."""
+    """Each variant: hyp_engine.hip (tiled kernels, one species) + one geometry unit (env GEOM, default Cartesian)."""
     from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc
     os.makedirs(VDIR, exist_ok=True)
     procs = []
@@ -18,7 +18,8 @@ def build(specs):
         name, _, flags = spec.partition(":")
         out = os.path.join(VDIR, name + ".so")
         objs = []
-        for unit, src, defs in (("engine", "hyp_engine.hip", ["-DHYP_VARIANT_CAR_ONLY"]), ("car", "hyp_geom.hip", ["-DHYP_GEOM_TU=0"])):
+        geom = int(os.environ.get("GEOM", "0"))      # GEOM_* of the one geometry unit linked (0 Cartesian, 1 octree, ...)
+        for unit, src, defs in (("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom]), ("geom", "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom])):
             obj = os.path.join(VDIR, "%s_%s.o" % (name, unit))
             cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-DHYP_ONLY_ND1", "-c", src, "-o", obj,
                                                                     "-Rpass-analysis=kernel-resource-usage"]
