@@ -84,8 +84,12 @@ def extras(n):
                 "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
                 "hbm_frac": 24.0 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
     st, dt = timed(lambda: e.final_iteration(n)[1])
-    res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view", "packets": n,
-                "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS})
+    rounds = e.get_option("last_defer_rounds")
+    res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction", "packets": n,
+                "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet" % (rounds, e.get_option("last_defer_events") / n))
+                            if rounds else "inline peel-off",
+                "packets_per_s": n / dt, "kernel_ms": e.last_kernel_ms()[0],
+                "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS})
     e.close()
     try:
         from cases import voronoi_big_problem

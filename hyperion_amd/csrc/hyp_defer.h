@@ -59,6 +59,56 @@ __global__ void defer_reset_kernel(PeelCtl *ctl, int cur, int first)
     if (first) { ctl->n_susp[cur ^ 1] = 0; ctl->n_ret[cur ^ 1] = 0; }
 }
 
+// Forced first interaction (iter_final.f90:191-209) needs the optical depth from the source to the edge of the grid along
+// the packet's direction before the packet takes its first step: in final_kernel that is a grid_escape_tau walk of the
+// lanes that have just emitted, with the rest of the wave waiting.  Here it is a state of the lane like any other walk:
+// ST_FF lanes cross cells in the same loop as the ST_WALK lanes (defer_step), summing the optical depth the way
+// grid_escape_tau does and never interacting; once out they go back to the source (a point: PLAIN) and sample tau.
+enum { ST_FF = 8, ST_FF_DONE = 9, ST_FF_KILLED = 10 };
+
+// walk_step<NDT, GEOM, false> without re-absorbing sources (PLAIN), plus the `ff` mode = one pass of the loop of
+// escape_tau (same order of operations, same association of the optical-depth sum, same use of the check stream)
+template <int NDT, int GEOM>
+__device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt, bool ff)
+{
+    const int nd = ndust<NDT>(P);
+    if (g.countdown == 0) {
+        g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
+        if (!geo_check_cell(P, W, p.r, p.v, p.cell)) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
+    } else g.countdown--;
+    double tmin; int im[3];
+    if (!geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im)) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
+    const size_t base = geo_index(P, p.cell) * (size_t)nd;
+    double rho[NDT];
+    double chi_rho = 0.0;
+#pragma unroll
+    for (int d = 0; d < NDT; d++) {
+        rho[d] = 0.0;
+        if (d < nd) { rho[d] = P.density[base + d]; chi_rho += p.chi[d] * rho[d]; }
+    }
+    const double tau_cell = chi_rho * tmin;
+    const double tau_needed = p.tau_req - p.tau_ach;
+    cnt.crossings++;
+    if (ff || tau_cell < tau_needed) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
+        if (ff) {
+#pragma unroll
+            for (int d = 0; d < NDT; d++) if (d < nd) p.tau_ach += p.chi[d] * rho[d] * tmin;
+        } else p.tau_ach += tau_cell;
+        geo_advance(P, p.r, p.cell, im);
+        if (geo_invalid(P, p.cell)) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
+        if (geo_escaped(P, p.cell)) return ff ? ST_FF_DONE : ST_ESCAPED;
+        return ff ? ST_FF : ST_WALK;
+    }
+    const double tact = tmin * (tau_needed / tau_cell);
+#pragma unroll
+    for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tact * p.v[a];
+    p.tau_ach += tau_needed;
+    geo_clear_wall(p.cell);
+    return ST_NEED_INTERACT;
+}
+
 // The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.
 template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
@@ -98,10 +148,33 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
 
     for (;;) {
         if (st == ST_ESCAPED) st = ST_NEED_EMIT;
-        unsigned long long m_walk = __ballot(st == ST_WALK);
+        unsigned long long m_walk = __ballot(st == ST_WALK || st == ST_FF);
+        const unsigned long long m_ffd = __ballot(st == ST_FF_DONE || st == ST_FF_KILLED);
+        if (m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
+            // the optical depth to the edge is known: back to the source, first optical depth (iter_final.f90:195-209)
+            if (st == ST_FF_DONE || st == ST_FF_KILLED) {
+                const double tau_escape = p.tau_ach;
+                const bool killed = st == ST_FF_KILLED;
+                const DSource &S = P.sources[f.source_id];
+                p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+                geo_clear_wall(p.cell);
+                (void)geo_place(P, W, p.r, p.v, p.cell);        // it did succeed when the packet was emitted
+                bool sampled = false;
+                if (tau_escape > 1e-10 && !killed) {
+                    double weight, tau;
+                    forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                    p.tau_req = tau; p.energy *= weight; sampled = true;
+                }
+                if (!sampled) p.tau_req = rng_exp(g);
+                p.tau_ach = 0.0;
+                begin_integrate(P, p);
+                st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+            }
+            m_walk = __ballot(st == ST_WALK || st == ST_FF);
+        }
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit)) break;
+        if (!(m_walk | m_int | m_emit | __ballot(st == ST_FF_DONE || st == ST_FF_KILLED))) break;
 
         // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
         // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
@@ -139,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
             }
             pool_empty = true;
             m_int = 0; m_emit = 0;
-            if (!m_walk) break;
+            if (!(m_walk | __ballot(st == ST_FF_DONE || st == ST_FF_KILLED))) break;
         }
 
         // peel: 0 none, 1 after emission, 2 after interaction
@@ -163,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
                     else { p.inter++; peel = 2; }
                 }
             }
-            m_walk = __ballot(st == ST_WALK);
+            m_walk = __ballot(st == ST_WALK || st == ST_FF);
             m_emit = __ballot(st == ST_NEED_EMIT);
         }
 
@@ -193,7 +266,12 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
             const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS));
             const unsigned long long m = __ballot(do_peel);
             if (m) {
+#ifdef HYP_DEFER_NO_WRITE       // tuning builds: what writing the events costs (the images are wrong)
+                if (do_peel) p.peel_seq++;
+                if (false) {
+#else
                 if (do_peel) {
+#endif
                     PeelEvent<NDT, GEOM> &E = ev[w_pos + __popcll(m & lt)];
                     E.r[0] = p.r[0]; E.r[1] = p.r[1]; E.r[2] = p.r[2]; E.nu = p.nu; E.energy = p.energy;
                     E.a_prev = a_prev;
@@ -213,18 +291,12 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
-                    else {
-                        bool sampled = false;
-                        if (P.forced_first) {
-                            bool killed = false;
-                            double tau_escape = escape_tau<NDT, GEOM>(P, W, p.r, p.v, p.cell, p.chi, g, cnt, killed);
-                            if (tau_escape > 1e-10 && !killed) {
-                                double weight, tau;
-                                forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
-                                p.tau_req = tau; p.energy *= weight; sampled = true;
-                            }
-                        }
-                        if (!sampled) p.tau_req = rng_exp(g);
+                    else if (P.forced_first) {
+                        p.tau_ach = 0.0; p.tau_req = 0.0;
+                        geo_begin(p.r, p.v, p.cell);
+                        st = ST_FF;
+                    } else {
+                        p.tau_req = rng_exp(g);
                         p.tau_ach = 0.0;
                         begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
@@ -238,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__r
         }
 
 #pragma unroll 1
-        for (int k = 0; k < HYP_WALK_STEPS; k++) {
-            if (st == ST_WALK) st = walk_step<NDT, GEOM, false>(P, W, p, g, nullptr, cnt);
+        for (int k = 0; k < walk_steps<GEOM>(); k++) {
+            if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF);
         }
     }
 

@@ -91,6 +91,9 @@ struct DPeeled {
 
 // Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
 // Half-widths are root half-width * 2^-level.
+// one entry of a Voronoi cell's wall list: the neighbour (or -1..-6: a face of the box) and the neighbour's site
+struct alignas(32) VorWall { double x, y, z; int nb, pad; };
+
 struct OctCell {
     double x, y, z;
     int parent;              // -1 for the root
@@ -137,6 +140,7 @@ struct DProblem {
     double oct_half[3], oct_box[6], oct_eps;
     const double *vor_sites;              // voronoi: [n_cells][3]
     const int *vor_idx, *vor_neigh;       // CSR neighbour lists (ids >= 0, walls -1..-6)
+    const VorWall *vor_walls;             // per CSR entry: the neighbour and its site (geo_find_wall)
     const int *vor_seed;                  // [vor_g^3] start site of the nearest-site walk
     const double *vor_volume;             // [n_cells]
     const double *vor_bb;                 // [n_cells][6] bb_min, bb_max of the cells (random_position_cell) or null

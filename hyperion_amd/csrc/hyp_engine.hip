@@ -189,6 +189,7 @@ struct hyp_engine {
     bool ray_pending = false;
     AmrGrid *d_amr_grids = nullptr; int *d_amr_go = nullptr, *d_amr_cell_grid = nullptr; double *d_amr_walls = nullptr;
     int *d_vor_idx = nullptr, *d_vor_neigh = nullptr, *d_vor_seed = nullptr;
+    VorWall *d_vor_walls = nullptr;
     DSource *d_sources = nullptr;
     DPeeled *d_peeled = nullptr;
     double *d_density = nullptr, *d_specific_energy = nullptr, *d_additional = nullptr;
@@ -600,7 +601,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children); free_dev(h->d_oct_neigh);
     free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
     free_dev(h->d_vor_bb);
-    free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed);
+    free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed); free_dev(h->d_vor_walls);
     free_dev(h->d_mask_map);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
@@ -1476,6 +1477,17 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMemcpy(h->d_vor_idx, pr->grid.vor_idx, sizeof(int) * (nc + 1), hipMemcpyHostToDevice));
         HIPC(hipMalloc(&h->d_vor_neigh, sizeof(int) * (nn ? nn : 1)));
         HIPC(hipMemcpy(h->d_vor_neigh, pr->grid.vor_neighs, sizeof(int) * nn, hipMemcpyHostToDevice));
+        {
+            std::vector<VorWall> walls(nn ? nn : 1);
+            for (size_t k = 0; k < nn; k++) {
+                const int nb = pr->grid.vor_neighs[k];
+                VorWall &w = walls[k];
+                w.nb = nb; w.pad = 0; w.x = w.y = w.z = 0.0;
+                if (nb >= 0) { w.x = pr->grid.vor_sites[3 * (size_t)nb]; w.y = pr->grid.vor_sites[3 * (size_t)nb + 1]; w.z = pr->grid.vor_sites[3 * (size_t)nb + 2]; }
+            }
+            HIPC(hipMalloc(&h->d_vor_walls, sizeof(VorWall) * walls.size()));
+            HIPC(hipMemcpy(h->d_vor_walls, walls.data(), sizeof(VorWall) * walls.size(), hipMemcpyHostToDevice));
+        }
         HIPC(hipMalloc(&h->d_vor_seed, sizeof(int) * vor_seed.size()));
         HIPC(hipMemcpy(h->d_vor_seed, vor_seed.data(), sizeof(int) * vor_seed.size(), hipMemcpyHostToDevice));
         if (pr->grid.vor_bb) {
@@ -1484,7 +1496,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         }
         P.vor_bb = h->d_vor_bb;
         P.vor_sites = h->d_vor_sites; P.vor_volume = h->d_vor_volume; P.vor_idx = h->d_vor_idx;
-        P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g;
+        P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g; P.vor_walls = h->d_vor_walls;
         for (int k = 0; k < 6; k++) P.vor_box[k] = pr->grid.vor_box[k];
     }
     if (is_amr) {

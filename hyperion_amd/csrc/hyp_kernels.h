@@ -427,24 +427,30 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
     const double s0 = si[0], s1 = si[1], s2 = si[2];
     const int prev = -c.ow[1] - 1;
     double tmin = HYP_DBL_MAX; int imin = -1; bool found = false;
-    for (int k = P.vor_idx[ic]; k < P.vor_idx[ic + 1]; k++) {
-        int nb = P.vor_neigh[k];
-        double t;
+    // vor_walls holds, per CSR entry, the neighbour's id AND its site (gathered at set-up): one 32-B record at an address
+    // that depends on k only, instead of the id and then the site it points to -- the loop is a stream of independent
+    // loads, not ~15 chains of two dependent ones.
+    const int k0 = P.vor_idx[ic], k1 = P.vor_idx[ic + 1];
+#pragma unroll 4
+    for (int k = k0; k < k1; k++) {
+        const VorWall w = P.vor_walls[k];
+        const int nb = w.nb;
+        double t; int cand; bool ahead;
         if (nb < 0) {
-            int w = -nb - 1, a = w >> 1, up = w & 1;
-            double va = a == 0 ? v[0] : a == 1 ? v[1] : v[2];
-            double ra = a == 0 ? r[0] : a == 1 ? r[1] : r[2];
-            if (up ? !(va > 0.0) : !(va < 0.0)) continue;
-            t = (P.vor_box[w] - ra) / va;
-            if (t > 0.0 && t < tmin) { tmin = t; imin = (int)P.n_cells; found = true; }
-            continue;
+            const int iw = -nb - 1, a = iw >> 1, up = iw & 1;
+            const double va = a == 0 ? v[0] : a == 1 ? v[1] : v[2];
+            const double ra = a == 0 ? r[0] : a == 1 ? r[1] : r[2];
+            ahead = up ? (va > 0.0) : (va < 0.0);
+            t = (P.vor_box[iw] - ra) / va;
+            cand = (int)P.n_cells;
+        } else {
+            const double n0 = w.x - s0, n1 = w.y - s1, n2 = w.z - s2;
+            const double m0 = 0.5 * (w.x + s0), m1 = 0.5 * (w.y + s1), m2 = 0.5 * (w.z + s2);
+            t = (n0 * (m0 - r[0]) + n1 * (m1 - r[1]) + n2 * (m2 - r[2])) / (n0 * v[0] + n1 * v[1] + n2 * v[2]);
+            ahead = nb != prev;
+            cand = nb;
         }
-        if (nb == prev) continue;
-        const double *so = P.vor_sites + 3 * (size_t)nb;
-        double n0 = so[0] - s0, n1 = so[1] - s1, n2 = so[2] - s2;
-        double m0 = 0.5 * (so[0] + s0), m1 = 0.5 * (so[1] + s1), m2 = 0.5 * (so[2] + s2);
-        t = (n0 * (m0 - r[0]) + n1 * (m1 - r[1]) + n2 * (m2 - r[2])) / (n0 * v[0] + n1 * v[1] + n2 * v[2]);
-        if (t > 0.0 && t < tmin) { tmin = t; imin = nb; found = true; }
+        if (ahead && t > 0.0 && t < tmin) { tmin = t; imin = cand; found = true; }
     }
     tnear = tmin;
     im[0] = found ? imin + 1 : 0; im[1] = ic + 1; im[2] = 0;
@@ -1274,8 +1280,12 @@ __device__ __forceinline__ void stage_walls(const DProblem &P, double *lds, Wall
 #define HYP_LUCY_WAVES 2
 #endif
 #ifndef HYP_WALK_STEPS
-#define HYP_WALK_STEPS 4
+#define HYP_WALK_STEPS 4        // cell crossings between two looks at the lanes' states, Cartesian grid
 #endif
+#ifndef HYP_WALK_STEPS_TREE
+#define HYP_WALK_STEPS_TREE 8   // the other geometries: a crossing is several dependent loads, fewer state checks pay
+#endif
+template <int GEOM> constexpr int walk_steps() { return GEOM == GEOM_CAR ? HYP_WALK_STEPS : HYP_WALK_STEPS_TREE; }
 template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
@@ -1391,7 +1401,7 @@ __global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProble
 
         // ---- walk phase: a few cell crossings per outer iteration ----
 #pragma unroll 1
-        for (int k = 0; k < HYP_WALK_STEPS; k++) {
+        for (int k = 0; k < walk_steps<GEOM>(); k++) {
             if (st == ST_WALK) st = walk_step<NDT, GEOM, kDeposit>(P, W, p, g, sum, cnt);
                 if (!kDeposit && st == ST_ESCAPED) st = ST_NEED_EMIT;      // HYP_NO_DEPOSIT probe builds
         }
@@ -2354,7 +2364,7 @@ __global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restric
         }
 
 #pragma unroll 1
-        for (int k = 0; k < HYP_WALK_STEPS; k++) {
+        for (int k = 0; k < walk_steps<GEOM>(); k++) {
             if (st == ST_WALK) st = walk_step<NDT, GEOM, false>(P, W, p, g, nullptr, cnt);
         }
     }

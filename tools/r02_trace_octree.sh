@@ -11,6 +11,6 @@ import sqlite3, glob
 for db in glob.glob("$OUT/trace/**/*.db", recursive=True):
     c = sqlite3.connect(db)
     for r in c.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
-        print("%-60s %6d %10.1f ms %9.1f us %6.2f" % (r[0].split("(")[0][:60], r[1], r[2]/1e6, r[3]/1e3, r[4]))
+        print("%-60s %6d %10.1f ms %9.1f us %6.2f" % (r[0].split("(")[0][:60], r[1], r[2]/1e3, r[3], r[4]))
 PY
 rm -rf $OUT/trace
