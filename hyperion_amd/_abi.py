@@ -10,6 +10,8 @@ import numpy as np
 
 from .problem import Problem, SUBLIMATION_MODES, TRACK_ORIGIN
 
+ABI_VERSION = 2      # HYP_ABI_VERSION of include/hyperion_amd.h these mirrors follow
+
 MAX_DUST = 8
 _dp = C.POINTER(C.c_double)
 

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from ._abi import IterStats, MarshalledProblem, ProblemDesc
+from ._abi import ABI_VERSION, IterStats, MarshalledProblem, ProblemDesc
 from .build import LIB
 
 _dp = C.POINTER(C.c_double)
@@ -105,6 +105,9 @@ def load_library(path=None):
     L.hyp_get_n_photons.argtypes = [H, _dp]
     L.hyp_get_specific_energy_spectrum.argtypes = [H, _dp, _dp]
     L.hyp_convergence_value.argtypes = [H, C.c_double, _dp, C.POINTER(C.c_int)]
+    if L.hyp_abi_version() != ABI_VERSION:      # the struct mirrors of _abi.py are for one version of include/hyperion_amd.h
+        raise EngineError("%s has ABI version %d, this binding was written for %d: rebuild the extension"
+                          % (path, L.hyp_abi_version(), ABI_VERSION))
     if path == LIB:
         _lib = L
     return L

@@ -13,7 +13,7 @@ for name in ("octree", "voronoi"):
         for n, vg, lds in c.execute("select name, vgpr_count, lds_size from kernels"):
             reg[n] = (vg, lds)
         L += ["| kernel | calls | total us | average us | vgpr | lds |", "|---|---|---|---|---|---|"]
-        for r in c.execute("select name,total_calls,total_duration,average from top_kernels limit 6"):
+        for r in c.execute("select name,total_calls,total_duration,average from top_kernels limit 8"):
             vg, lds = reg.get(r[0], ("?", "?"))
             L.append("| `%s` | %d | %d | %.0f | %s | %s |" % (r[0].split("(")[0][:70], r[1], r[2], r[3], vg, lds))
     L += ["", "| counter | kernel | sum over dispatches |", "|---|---|---|"]
@@ -23,7 +23,7 @@ for name in ("octree", "voronoi"):
             try:
                 for cn, kn, v in c.execute("select counter_name, kernel_name, sum(value) from counters_collection group by counter_name, kernel_name"):
                     k = kn.split("(")[0]
-                    if "lucy_kernel" in k or "final_kernel" in k:
+                    if any(t in k for t in ("lucy_kernel", "final_kernel", "final_defer_kernel", "peel_kernel")):
                         L.append("| %s | `%s` | %.6g |" % (cn, k[:60], v))
             except Exception as e:
                 L.append("| (%s) | | |" % e)
