@@ -7,6 +7,7 @@
 #include "hyp_epilogue.h"
 #include "hyp_pick.h"
 
+#include <algorithm>
 #include <array>
 #include <cfloat>
 #include <cmath>
@@ -255,6 +256,7 @@ struct hyp_engine {
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
     int defer_peel = 1;             // option: 1 = use it where plain_imaging holds, 0 = peel off inline
     long long peel_events = 16ll << 20;     // option: capacity of the event buffer, in events
+    bool peel_events_exact = false;         // set by the option: use exactly that many (tests force many rounds with it)
     void *d_peel_events = nullptr, *d_peel_susp[2] = {nullptr, nullptr};
     unsigned long long *d_peel_ret[2] = {nullptr, nullptr};
     PeelCtl *d_peel_ctl = nullptr, *h_peel_ctl = nullptr;
@@ -2208,7 +2210,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
             free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
             h->peel_cap = 0;
         }
-        h->peel_events = value;
+        h->peel_events = value; h->peel_events_exact = true;
     }
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = (int)value;
@@ -2254,12 +2256,17 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
 
 // Buffers of the deferred peel-off, sized for `lanes` lanes of the propagation grid.  Returns nonzero when they cannot be had
 // (the caller then peels off inline).
-static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes)
+static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes, uint64_t n_local)
 {
     const size_t waves = lanes / 64;
+    // `peel_events` is the ceiling; a small iteration does not need it (8 events per packet in one round, more rounds
+    // beyond that) and the buffer only grows
     size_t cap = (size_t)h->peel_events;
+    const size_t want = n_local > (1ull << 40) ? cap : std::max<size_t>((size_t)n_local * 8, (size_t)1 << 16);
+    if (want < cap && !h->peel_events_exact) cap = want;
     cap = (cap + HYP_PEEL_CHUNK - 1) / HYP_PEEL_CHUNK * HYP_PEEL_CHUNK;
-    if (h->d_peel_events && h->peel_cap == cap && h->peel_event_bytes == dk.event_bytes && h->peel_lanes >= lanes) return 0;
+    if (h->d_peel_events && h->peel_event_bytes == dk.event_bytes && h->peel_lanes >= lanes &&
+        (h->peel_events_exact ? h->peel_cap == cap : h->peel_cap >= cap)) return 0;
     free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
     h->peel_cap = 0;
     bool ok = hipMalloc(&h->d_peel_events, cap * dk.event_bytes) == hipSuccess;
@@ -2347,7 +2354,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         bpc = occ;
     }
     long long blocks = (long long)h->n_cu * bpc;
-    if (deferred && defer_buffers(h, dk, (size_t)blocks * 256)) deferred = false;      // no memory for the buffers: peel off inline
+    if (deferred && defer_buffers(h, dk, (size_t)blocks * 256, n_local)) deferred = false;      // no memory for the buffers: peel off inline
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;

@@ -1905,7 +1905,7 @@ __device__ __forceinline__ bool random_position_cell(const DProblem &P, size_t i
 template <int NDT, int GEOM>
 __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, const double r[3], bool active, double energy,
                                              bool isotropic, const Angle &src_normal, int emiss_dust, int var_id, double var_frac,
-                                             const PeelFlags &f, Rng &g, Counters &cnt)
+                                             const PeelFlags &f, Rng &g, Counters &cnt, const ImgCache *ic = nullptr)
 {
     const int nd = ndust<NDT>(P);
     for (int ig = 0; ig < P.n_peeled; ig++) {
@@ -2004,9 +2004,9 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                     val[0] = sp;
                 }
                 if (G.compute_image)
-                    wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img >= 0 ? k_img + iw : -1, 0, 1, val);
+                    wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img >= 0 ? k_img + iw : -1, 0, 1, val, ic);
                 if (G.compute_sed)
-                    wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed >= 0 ? k_sed + iw : -1, 0, 1, val);
+                    wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed >= 0 ? k_sed + iw : -1, 0, 1, val, ic);
             }
         }
     }
@@ -2021,6 +2021,11 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
     const DProblem &P = *Pp;
     Walls W;
     stage_walls<GEOM>(P, lds, W);
+    // every source packet of a point source puts its whole spectrum on one pixel: all frequency bins of it are hot
+    __shared__ unsigned long long img_keys[HYP_IMG_CACHE];
+    __shared__ double img_vals[HYP_IMG_CACHE];
+    ImgCache ic;
+    img_cache_init(ic, img_keys, img_vals);
     Rng g;
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
@@ -2076,9 +2081,10 @@ __global__ __launch_bounds__(256, 2) void ray_kernel(const DProblem *__restrict_
                 else active = false;
             }
         }
-        peeloff_poly<NDT, GEOM>(P, W, r, active, energy, isotropic, src_normal, emiss_dust, var_id, var_frac, f, g, cnt);
+        peeloff_poly<NDT, GEOM>(P, W, r, active, energy, isotropic, src_normal, emiss_dust, var_id, var_frac, f, g, cnt, &ic);
         if (*((volatile int *)P.err) != 0) break;
     }
+    img_cache_flush(ic);
     double c = wave_sum((double)cnt.crossings);
     double kg = wave_sum((double)cnt.killed_geo);
     if (__lane_id() == 0) {

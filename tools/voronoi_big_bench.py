@@ -3,9 +3,12 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hyperion_amd
+if os.environ.get("HYP_LIB"):        # a tuning variant built by tools/variants.py
+    import hyperion_amd.engine as E
+    E._lib = E.load_library(os.environ["HYP_LIB"])
 from cases import voronoi_big_problem
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
-p = voronoi_big_problem(n_photons=n)
+p = voronoi_big_problem(n_photons=n, two_species="one" not in sys.argv[2:])      # `one`: single species (tuning variants are built for one)
 eng = hyperion_amd.Engine(p)
 eng.lucy_iteration(n // 10, 1, want_output=False)
 for it in (2, 3):
