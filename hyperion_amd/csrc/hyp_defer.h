@@ -111,7 +111,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
 
 // The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.
 template <int NDT, int GEOM>
-__global__ __launch_bounds__(256, 2) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
+__global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;

@@ -1276,9 +1276,22 @@ __device__ __forceinline__ void stage_walls(const DProblem &P, double *lds, Wall
 // ---------------------------------------------------------------------------
 // Lucy iteration: do_lucy packet loop, iter_lucy.f90:119-209
 // ---------------------------------------------------------------------------
+// Workgroups per CU the register budget of the persistent kernels is set for (x 4 waves / 4 SIMDs = waves per SIMD).
+// The Cartesian walk is atomic-bound and keeps everything in registers at 2; the Voronoi walk waits on memory (a stream
+// of wall records per crossing) and gains from more waves even though they spill (measured: 167 / 141 / 138 ms at 2 / 3 / 4).
 #ifndef HYP_LUCY_WAVES
 #define HYP_LUCY_WAVES 2
 #endif
+#ifndef HYP_LUCY_WAVES_VOR
+#define HYP_LUCY_WAVES_VOR 4
+#endif
+#ifndef HYP_LUCY_WAVES_OCT
+#define HYP_LUCY_WAVES_OCT 2
+#endif
+#ifndef HYP_FINAL_WAVES
+#define HYP_FINAL_WAVES 2
+#endif
+template <int GEOM> constexpr int lucy_waves() { return GEOM == GEOM_VOR ? HYP_LUCY_WAVES_VOR : GEOM == GEOM_OCT ? HYP_LUCY_WAVES_OCT : HYP_LUCY_WAVES; }
 #ifndef HYP_WALK_STEPS
 #define HYP_WALK_STEPS 4        // cell crossings between two looks at the lanes' states, Cartesian grid
 #endif
@@ -1287,7 +1300,7 @@ __device__ __forceinline__ void stage_walls(const DProblem &P, double *lds, Wall
 #endif
 template <int GEOM> constexpr int walk_steps() { return GEOM == GEOM_CAR ? HYP_WALK_STEPS : HYP_WALK_STEPS_TREE; }
 template <int NDT, int GEOM>
-__global__ __launch_bounds__(256, HYP_LUCY_WAVES) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+__global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
@@ -2179,7 +2192,7 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
 // no modified random walk, no re-absorbing sources, no binned images, no inside observers, no filters (the host checks).
 // Those paths cost registers even where a problem never takes them; this is the imaging kernel of BASELINE configs[3].
 template <int NDT, int GEOM, bool PLAIN>
-__global__ __launch_bounds__(256, 2) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
+__global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
