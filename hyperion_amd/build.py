@@ -64,5 +64,51 @@ def build_extension(force=False, verbose=False):
     return compile_units(LIB, verbose=verbose)
 
 
+# ---- the native .rtin -> .rtout driver (hyp_run.cpp): `hyperion_car`-style executables over the C ABI -------------------
+BIN = os.path.join(HERE, "bin")
+DRIVER = os.path.join(BIN, "hyperion_amd_run")
+GRID_SUFFIXES = ("car", "sph", "cyl", "oct", "amr", "vor")      # scripts/hyperion:44-58 calls hyperion_<suffix>
+
+
+def hdf5_prefix():
+    """Where a C libhdf5 lives (headers + shared library), or None: this image ships one with /opt/conda."""
+    for prefix in (os.environ.get("HDF5_DIR"), "/opt/conda", "/usr", "/usr/local"):
+        if prefix and os.path.exists(os.path.join(prefix, "include", "hdf5.h")) and os.path.exists(os.path.join(prefix, "lib", "libhdf5.so")):
+            return prefix
+    return None
+
+
+def build_native_driver(force=False, verbose=False):
+    """g++ hyp_run.cpp against libhdf5 and libhyperion_amd.so -> hyperion_amd/bin/hyperion_amd_run plus the names the
+    reference's launcher looks for (hyperion_car, hyperion_sph, ...).  Returns the path, or None where there is no libhdf5
+    to link (the Python adapter `python -m hyperion_amd` is the file seam then)."""
+    prefix = hdf5_prefix()
+    if prefix is None:
+        return None
+    src = os.path.join(CSRC, "hyp_run.cpp")
+    hdr = os.path.join(os.path.dirname(HERE), "include", "hyperion_amd.h")
+    if not force and os.path.exists(DRIVER) and os.path.getmtime(DRIVER) > max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB)):
+        return DRIVER
+    os.makedirs(BIN, exist_ok=True)
+    # libstdc++ is linked statically and the system directories are searched first at link time: the prefix that has
+    # libhdf5 (conda) may carry an older libstdc++ than the HIP runtime needs; at run time RUNPATH only serves the
+    # executable's own two dependencies
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(prefix, "include"), src, "-o", DRIVER + ".tmp",
+           "-L" + CSRC, "-lhyperion_amd", os.path.join(prefix, "lib", "libhdf5.so"), "-static-libstdc++", "-static-libgcc",
+           "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--enable-new-dtags",
+           "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(prefix, "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    os.replace(DRIVER + ".tmp", DRIVER)
+    for suffix in GRID_SUFFIXES:
+        link = os.path.join(BIN, "hyperion_" + suffix)
+        if os.path.lexists(link):
+            os.remove(link)
+        os.symlink("hyperion_amd_run", link)
+    return DRIVER
+
+
 if __name__ == "__main__":
     print(build_extension(force=True, verbose=True))
+    print(build_native_driver(force=True, verbose=True))
