@@ -192,9 +192,11 @@ struct DProblem {
     const DPeeled *peeled;
     int n_views_total, pad9;              // peeled views numbered through all groups (DPeeled::view_base)
     // n_photons (grid_propagate_3d.f90:88-93,171-176): packets that entered each cell in this Lucy iteration [n_cells];
-    // last_id = tags of the last HYP_NPHOT_SLOTS packets counted in each cell [n_cells][HYP_NPHOT_SLOTS], see count_photon.
+    // visit_tab = per-lane set of the cells the lane's current packet has been counted in, see count_photon.
     // count_photons = 0: arrays absent.
-    unsigned int *n_photons, *last_id;
+    unsigned int *n_photons;
+    unsigned long long *visit_tab;        // [lanes of the launch][HYP_VISIT_SLOTS]: see count_photon
+    int *nphot_inexact;                   // set when a packet overflowed its table
     int count_photons;
     // frequency-resolved specific energy (grid_propagate_3d.f90:59-71,155-158,214-222): accumulators [n_bins][n_cells][n_dust],
     // log10 of the bin edges [n_bins + 1], fraction of each emissivity row in each bin [n_dust][nj_max][n_bins] (MRW deposits)

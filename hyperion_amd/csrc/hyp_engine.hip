@@ -266,7 +266,11 @@ struct hyp_engine {
     unsigned long long last_defer_events = 0;
     bool count_photons = false, pda = false;
     int n_bins = 0, nj_max = 1;
-    unsigned int *d_nphot = nullptr, *d_last_id = nullptr;      // [n_cells]
+    unsigned int *d_nphot = nullptr;      // [n_cells]
+    unsigned long long *d_visit = nullptr;      // per-lane visited sets of count_photon, [visit_lanes][HYP_VISIT_SLOTS]
+    size_t visit_lanes = 0;
+    int *d_nphot_inexact = nullptr;
+    int nphot_inexact = 0;          // a packet overflowed its visited set in the last counting iteration
     size_t ext_nphot = 0, ext_spec = 0, block_doubles = 0;        // offsets (doubles) of the extensions in the accumulator block; its length
     double *d_log_edges = nullptr, *d_bin_frac = nullptr, *d_spec = nullptr;
     std::vector<double> spectrum_edges;
@@ -619,7 +623,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
     free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
     for (hipEvent_t e : h->walk_events) (void)hipEventDestroy(e);
-    free_dev(h->d_nphot); free_dev(h->d_last_id); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
+    free_dev(h->d_nphot); free_dev(h->d_visit); free_dev(h->d_nphot_inexact); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
     free_dev(h->d_pda_mask); free_dev(h->d_pda_cells); free_dev(h->d_pda_hp); free_dev(h->d_pda_emean); free_dev(h->d_pda_coef);
     free_dev(h->d_pda_id); free_dev(h->d_pda_a); free_dev(h->d_pda_b); free_dev(h->d_pda_f);
     free_dev(h->d_pda_ctl); free_dev(h->d_prev_se); free_dev(h->d_ratio); free_dev(h->d_conv_ctl);
@@ -1578,10 +1582,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     if (h->n_bins) h->accum_copies = 1;        // the spectrum planes are not replicated; their atomics dominate anyway
     if (h->count_photons) {
         HIPC(hipMalloc(&h->d_nphot, sizeof(unsigned int) * h->n_cells));
-        HIPC(hipMalloc(&h->d_last_id, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS));
+        HIPC(hipMalloc(&h->d_nphot_inexact, sizeof(int)));
         HIPC(hipMemset(h->d_nphot, 0, sizeof(unsigned int) * h->n_cells));
-        HIPC(hipMemset(h->d_last_id, 0, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS));
-        P.n_photons = h->d_nphot; P.last_id = h->d_last_id; P.count_photons = 1;
+        HIPC(hipMemset(h->d_nphot_inexact, 0, sizeof(int)));
+        P.n_photons = h->d_nphot; P.visit_tab = nullptr; P.nphot_inexact = h->d_nphot_inexact; P.count_photons = 1;
     }
     if (h->n_bins) {     // grid_physics_3d.f90:124-143,269-282,326-348
         const int nb = h->n_bins;
@@ -2008,7 +2012,20 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     P.sum_spec = h->n_bins ? h->d_accum + h->ext_spec : nullptr;
     if (h->count_photons) {      // grid_reset_energy: grid_generic.f90:21-27
         (void)hipMemsetAsync(h->d_nphot, 0, sizeof(unsigned int) * h->n_cells, h->stream);
-        (void)hipMemsetAsync(h->d_last_id, 0, sizeof(unsigned int) * h->n_cells * HYP_NPHOT_SLOTS, h->stream);
+        (void)hipMemsetAsync(h->d_nphot_inexact, 0, sizeof(int), h->stream);
+        // the visited sets: one per lane of the largest launch this device can hold (the persistent kernel's grid)
+        const size_t lanes = (size_t)h->n_cu * 8 * 256;
+        if (h->visit_lanes < lanes) {
+            free_dev(h->d_visit);
+            h->visit_lanes = 0;
+            if (hipMalloc((void **)&h->d_visit, lanes * HYP_VISIT_SLOTS * sizeof(unsigned long long)) != hipSuccess) {
+                (void)hipGetLastError();
+                return h->set_error("no memory for the per-lane visited sets of the n_photons counter");
+            }
+            h->visit_lanes = lanes;
+        }
+        (void)hipMemsetAsync(h->d_visit, 0, h->visit_lanes * HYP_VISIT_SLOTS * sizeof(unsigned long long), h->stream);
+        P.visit_tab = h->d_visit;
     }
     if (mrw_prepare(h)) return 1;
     if (sync_problem(h)) return 1;
@@ -2040,6 +2057,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
         bpc = occ;
     }
+    if (h->count_photons && bpc > 8) bpc = 8;        // the visited sets are sized for 8 workgroups per CU
     long long blocks = (long long)h->n_cu * bpc;
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
@@ -2079,6 +2097,7 @@ int hyp_lucy_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles)
     hipError_t e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
     (void)hipEventElapsedTime(&h->last_propagate_ms, h->ev0, h->ev1);
+    if (h->count_photons) (void)hipMemcpy(&h->nphot_inexact, h->d_nphot_inexact, sizeof(int), hipMemcpyDeviceToHost);
     if (check_device_error(h)) { h->lucy_pending = false; return 1; }
     if (device_ptr) *device_ptr = h->d_accum;
     if (n_doubles) *n_doubles = h->block_doubles;
@@ -2237,6 +2256,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
+    else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
     else if (n == "plain_imaging") *value = h->plain_imaging ? 1 : 0;
     else if (n == "last_defer_rounds") *value = h->last_defer_rounds;

@@ -52,6 +52,7 @@ struct Packet {
     int reabs_id, reabs;
     int spec_idx;               // frequency bin of the specific-energy spectrum during this grid_integrate (-1: none)
     unsigned int peel_seq;      // peel-off events of this packet so far (keys the check stream of the peel-off walks)
+    int n_visited;              // cells this packet has been counted in (count_photon)
 };
 
 // extra state carried only by the imaging (final) iteration
@@ -669,23 +670,28 @@ __device__ __forceinline__ void begin_integrate(const DProblem &P, Packet<NDT, G
 
 // n_photons(ic) += 1 unless this packet has been counted in the cell before (grid_propagate_3d.f90:90-95,175-180).  The
 // reference runs its packets one after the other, so its "the last packet here was not this one" IS "this packet has not
-// been here before": n_photons = number of distinct packets per cell.  Here packets interleave, so every cell remembers the
-// last HYP_NPHOT_SLOTS packets it counted (one 128-byte line per cell): the count is exact in every cell that at most that
-// many packets visit -- which covers the decision the count exists for, the PDA threshold of 30 packets -- and an upper
-// bound elsewhere (a packet that returns after 32 others were counted in between is counted again).
-#define HYP_NPHOT_SLOTS 32
-__device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsigned int tag)
+// been here before": n_photons = number of distinct packets per cell.  Here packets interleave, so every LANE keeps the set
+// of cells its current packet has been counted in: an open-addressing table of HYP_VISIT_SLOTS (tag, cell) words in HBM
+// (32 KB per lane, 4.3 GB for the 131 072 lanes of a launch, cleared per iteration), entries of earlier packets
+// recognised by their tag and overwritten.  Exact and independent of the order packets run in; a packet that visits
+// more than 3/4 HYP_VISIT_SLOTS distinct cells (never seen) is counted on every entry from then on and raises
+// DProblem::nphot_inexact.
+#define HYP_VISIT_SLOTS 4096
+__device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsigned int tag, int &n_visited)
 {
-    const uint4 *slots = (const uint4 *)(P.last_id + ic * HYP_NPHOT_SLOTS);
-    bool seen = false;
-#pragma unroll
-    for (int k = 0; k < HYP_NPHOT_SLOTS / 4; k++) {
-        const uint4 q = slots[k];
-        seen = seen | (q.x == tag) | (q.y == tag) | (q.z == tag) | (q.w == tag);
-    }
-    if (!seen) {
-        const unsigned int old = atomicAdd(&P.n_photons[ic], 1u);
-        P.last_id[ic * HYP_NPHOT_SLOTS + (old % HYP_NPHOT_SLOTS)] = tag;
+    unsigned long long *tab = P.visit_tab + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * HYP_VISIT_SLOTS;
+    const unsigned long long key = ((unsigned long long)tag << 32) | (unsigned long long)(unsigned int)ic;
+    if (n_visited >= HYP_VISIT_SLOTS * 3 / 4) { atomicAdd(&P.n_photons[ic], 1u); *P.nphot_inexact = 1; return; }
+    unsigned int h = ((unsigned int)ic * 2654435761u) >> 20;       // 12 bits
+    for (;;) {
+        const unsigned long long e = tab[h];
+        if (e == key) return;
+        if ((unsigned int)(e >> 32) != tag) {       // empty, or left by an earlier packet of this lane
+            tab[h] = key; n_visited++;
+            atomicAdd(&P.n_photons[ic], 1u);
+            return;
+        }
+        h = (h + 1u) & (HYP_VISIT_SLOTS - 1u);
     }
 }
 __device__ __forceinline__ unsigned int photon_tag(const Rng &g) { return g.id_lo + 1u; }
@@ -698,7 +704,7 @@ __device__ __forceinline__ void begin_integrate_lucy(const DProblem &P, Packet<N
     begin_integrate(P, p);
     p.spec_idx = -1;
     if (P.n_bins) p.spec_idx = locate(P.log_nu_edges, P.n_bins + 1, log10(p.nu));
-    if (P.count_photons && !geo_escaped(P, p.cell)) count_photon(P, geo_index(P, p.cell), photon_tag(g));
+    if (P.count_photons && !geo_escaped(P, p.cell)) count_photon(P, geo_index(P, p.cell), photon_tag(g), p.n_visited);
 }
 
 // One iteration of the big loop of grid_integrate (grid_propagate_3d.f90:106-232)
@@ -744,7 +750,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
         if (geo_invalid(P, p.cell)) { cnt.killed_geo++; return ST_NEED_EMIT; }     // amr: invalid_cell
         // the imaging iteration (no deposits) tells packets that left the grid from killed ones: iter_final.f90:127-129
         if (geo_escaped(P, p.cell)) return DEPOSIT ? ST_NEED_EMIT : ST_ESCAPED;
-        if (DEPOSIT && P.count_photons) count_photon(P, geo_index(P, p.cell), photon_tag(g));
+        if (DEPOSIT && P.count_photons) count_photon(P, geo_index(P, p.cell), photon_tag(g), p.n_visited);
         return ST_WALK;
     } else {
         double tact = tmin * (tau_needed / tau_cell);
@@ -966,7 +972,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         return false;
     }
     p.inter = 1;
-    if (reemit_id < 0) p.peel_seq = 0;      // a re-emitted packet is still the same packet
+    if (reemit_id < 0) { p.peel_seq = 0; p.n_visited = 0; }      // a re-emitted packet is still the same packet
     return true;
 }
 
