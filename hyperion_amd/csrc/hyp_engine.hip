@@ -651,7 +651,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     if (!pr || !out) return set_error("null argument");
     if (pr->grid.type < 1 || pr->grid.type > 6) return set_error("Unexpected coordinate type (grid types: 1 cartesian, 2 octree, 3 voronoi, 4 amr, 5 spherical polar, 6 cylindrical polar)");
     if (pr->n_dust < 1 || pr->n_dust > HYP_MAX_DUST) return set_error("n_dust must be between 1 and 8");
-    if (pr->n_sources < 1) return set_error("no sources set up - need sources for initial iteration(s)");
+    // no sources is a valid set-up for dust-only raytracing / monochromatic runs (setup_rt.f90:228-239): the iterations that
+    // need sources refuse to start instead (hyp_lucy_launch, hyp_final_launch)
+    if (pr->n_sources < 0 || (pr->n_sources > 0 && !pr->sources)) return set_error("invalid source list");
     if (pr->config.monochromatic && (pr->config.n_frequencies < 1 || !pr->config.frequencies)) return set_error("monochromatic mode needs a frequency table");
     const bool is_oct = pr->grid.type == 2, is_vor = pr->grid.type == 3, is_amr = pr->grid.type == 4;
     const bool is_sph = pr->grid.type == 5, is_cyl = pr->grid.type == 6, is_polar = is_sph || is_cyl;
@@ -1997,6 +1999,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     if (!h) return 1;
     if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
     DProblem &P = h->hp;
+    if (P.n_sources == 0) return h->set_error("no sources set up - need sources for initial iteration(s)");      // setup_rt.f90:230
     int copies = h->accum_copies;
     if (copies < 1) copies = 1;
     if (copies > 256) copies = 256;
@@ -2344,6 +2347,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     if (!h) return 1;
     if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
     DProblem &P = h->hp;
+    if (P.n_sources == 0 && n_local > 0) return h->set_error("no sources set up - need sources for last iteration");      // setup_rt.f90:236
     double *tail;
     if (h->d_img_accum) {
         hipError_t e = hipMemsetAsync(h->d_img_accum, 0, sizeof(double) * h->img_accum_n, h->stream);
@@ -2487,6 +2491,7 @@ int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n
     P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
     if (sync_problem(h)) return 1;
     h->ray_pending = true;
+    if (which == 0 && P.n_sources == 0) n_local = 0;       // n_raytracing_photons_sources = 0: setup_rt.f90:238
     if (n_local == 0 || n_total == 0) return 0;
     unsigned long long first = first_id;
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
@@ -2572,6 +2577,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     h->mono_pending = true;
     P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
     P.mono_which = 0; P.mono_inu = inu; P.mono_nu = h->frequencies[inu]; P.mono_n_total = (double)n_total;
+    if (which == 0 && h->hp.n_sources == 0) n_local = 0;       // n_last_photons_sources = 0: setup_rt.f90:232
     if (n_local == 0 || n_total == 0) return sync_problem(h);
     if (which == 1) {
         // setup_monochromatic_grid_pdfs: precompute_jnu_var ran in the last finish step (jnu_id / jnu_frac are current)

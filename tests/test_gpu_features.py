@@ -176,3 +176,32 @@ def test_convergence_value_on_the_device():
     st, v = eng.convergence_value(50.0)          # nothing changed since the last call
     assert st == 1 and v == 0.0
     eng.close(); orc.close()
+
+
+def test_no_sources_is_a_valid_setup_for_dust_only_raytracing():
+    """setup_rt.f90:228-239: without sources the run is refused only if an iteration that needs them is asked for; the
+    raytracing iteration then images the thermal emission alone -- the same cubes as the dust part of a run with the
+    source (same packet ids, same specific energy)."""
+    import copy
+    from cases import imaging_problem
+    prob = imaging_problem(tau=1.0)
+    prob.config.raytracing = True
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(20000, 1, want_output=False)
+    se = eng.specific_energy()
+    a, sa = eng.raytracing_iteration(0, 4000)
+    eng.close()
+    assert float(np.nansum(a[0]["img"][0])) > 0
+    p2 = copy.deepcopy(prob)
+    p2.sources = []
+    p2.specific_energy = se
+    eng = hyperion_amd.Engine(p2)
+    b, sb = eng.raytracing_iteration(9999, 4000)          # the source packets are dropped: n_raytracing_photons_sources = 0
+    assert sa["crossings"] == sb["crossings"]
+    for name in a[0]:
+        np.testing.assert_allclose(b[0][name], a[0][name], rtol=1e-9, atol=1e-12 * np.nanmax(np.abs(a[0][name])), err_msg=name)
+    with pytest.raises(hyperion_amd.EngineError, match=r"no sources set up - need sources for initial iteration\(s\)"):
+        eng.lucy_iteration(100, 1)
+    with pytest.raises(hyperion_amd.EngineError, match="no sources set up - need sources for last iteration"):
+        eng.final_iteration(100)
+    eng.close()
