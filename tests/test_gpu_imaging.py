@@ -245,3 +245,26 @@ def test_deferred_peeloff_equals_inline(kw, peel_events):
     assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
     _images_equal(ra, rb)
     eng.close()
+
+
+def test_sharded_imaging_iteration_equals_the_whole_one():
+    """hyp_final_launch(first_id, n_local) on two id ranges (what two ranks do), blocks summed like the all-reduce does,
+    then hyp_final_finish: the cubes of the whole iteration -- also through the deferred schedule with an event buffer
+    small enough to need several rounds per shard."""
+    import torch
+    prob = imaging_problem(tau=2.0, uncertainties=True)
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(20000, 1, want_output=False)
+    eng.set_option("peel_events", 8192)
+    whole, sw = eng.final_iteration(24000)
+    assert eng.get_option("last_defer_rounds") > 2
+    eng.final_launch(0, 10000)
+    a = eng.final_accumulators_tensor().clone()
+    eng.final_launch(10000, 14000)
+    b = eng.final_accumulators_tensor()
+    b += a                                              # the all-reduce of two ranks
+    parts, sp = eng.final_finish()
+    for k in INT_KEYS:
+        assert sp[k] == sw[k], (k, sp, sw)
+    _images_equal(parts, whole)
+    eng.close()
