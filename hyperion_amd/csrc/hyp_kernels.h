@@ -434,7 +434,13 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
     const int k0 = P.vor_idx[ic], k1 = P.vor_idx[ic + 1];
 #pragma unroll 4
     for (int k = k0; k < k1; k++) {
+#ifdef HYP_VOR_NO_GATHER        // tuning builds: the neighbour's id, then its site from the (L2-resident) site table
+        VorWall w;
+        w.nb = P.vor_neigh[k];
+        { const double *so = P.vor_sites + 3 * (size_t)(w.nb < 0 ? ic : w.nb); w.x = so[0]; w.y = so[1]; w.z = so[2]; }
+#else
         const VorWall w = P.vor_walls[k];
+#endif
         const int nb = w.nb;
         double t; int cand; bool ahead;
         if (nb < 0) {
