@@ -240,6 +240,7 @@ struct hyp_engine {
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
     int last_generations = 0;
+    int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
@@ -458,7 +459,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
                                                                                        ilist, dlist, tcount, counts);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
-        if ((gen & 3) == 3 || gen > 200000) {
+        if ((gen + 1) % h->tile_poll == 0 || gen > 200000) {
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return h->set_error(std::string("tiled generation failed: ") + hipGetErrorString(e));
@@ -2219,6 +2220,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "chunk") h->chunk = (int)value;
     else if (n == "lucy_mode") h->lucy_mode = (int)value;       // -1 auto, 0 persistent atomics kernel, 1 brick-tiled
     else if (n == "tile_slots") h->tile_slots = (int)value;
+    else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
     else if (n == "tile_split") h->tile_split = (int)value;
