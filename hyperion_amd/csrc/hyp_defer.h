@@ -22,13 +22,13 @@
 #define HYP_PAIR_CHUNK 256      // (event, view) pairs a wave of the peel kernel reserves at a time
 #endif
 #ifndef HYP_PEEL_REFILL
-#define HYP_PEEL_REFILL 16      // idle lanes that trigger a refill in the peel kernel
+#define HYP_PEEL_REFILL 32      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
 #endif
 #ifndef HYP_PEEL_OCC
 #define HYP_PEEL_OCC 3        // workgroups of the peel kernel per CU the register budget is set for
 #endif
 #ifndef HYP_PEEL_STEPS
-#define HYP_PEEL_STEPS 8        // cell crossings between two refill / deposit checks
+#define HYP_PEEL_STEPS 16       // cell crossings between two refill / deposit checks
 #endif
 
 template <int NDT, int GEOM>
