@@ -244,6 +244,11 @@ struct hyp_engine {
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
+    // the imaging iteration batches harder: the lanes that have just emitted walk to the observer (and, forced first
+    // interaction, to the edge) together, so an emission of 48 lanes keeps 3 x the lanes busy in those walks than one of 16
+    // (configs[3]: inline 76 -> 52 ms, deferred 60 -> 52 ms; profiles/r02_tiled_log.md).  -1 = measured optimum: interactions 16
+    // deferred / 32 inline; emissions 48, except 16 for the deferred schedule on a Cartesian grid (its walks are cheap).
+    int final_interact_threshold = -1, final_emit_threshold = -1;
 
     // monochromatic final iteration
     std::vector<double> frequencies;
@@ -2215,6 +2220,8 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     std::string n(name);
     if (n == "interact_threshold") h->interact_threshold = (int)value;
     else if (n == "emit_threshold") h->emit_threshold = (int)value;
+    else if (n == "final_interact_threshold") h->final_interact_threshold = (int)value;
+    else if (n == "final_emit_threshold") h->final_emit_threshold = (int)value;
     else if (n == "accum_copies") h->accum_copies = (int)value;
     else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
     else if (n == "chunk") h->chunk = (int)value;
@@ -2249,6 +2256,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     std::string n(name);
     if (n == "interact_threshold") *value = h->interact_threshold;
     else if (n == "emit_threshold") *value = h->emit_threshold;
+    else if (n == "final_interact_threshold") *value = h->final_interact_threshold;
+    else if (n == "final_emit_threshold") *value = h->final_emit_threshold;
     else if (n == "accum_copies") *value = h->accum_copies;
     else if (n == "blocks_per_cu") *value = h->blocks_per_cu;
     else if (n == "chunk") *value = h->chunk;
@@ -2394,7 +2403,8 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         chunk = (int)c;
     }
     L.chunk = chunk;
-    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : (deferred ? 16 : 32);
+    L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : (deferred && h->hp.grid_type == 1 ? 16 : 48);
     h->last_defer_rounds = 0; h->last_defer_events = 0;
     if (deferred) {
         (void)hipEventRecord(h->ev0, h->stream);

@@ -10,6 +10,9 @@ from cases import voronoi_big_problem
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 p = voronoi_big_problem(n_photons=n, two_species="one" not in sys.argv[2:])      # `one`: single species (tuning variants are built for one)
 eng = hyperion_amd.Engine(p)
+for a in sys.argv[2:]:
+    if "=" in a:
+        eng.set_option(a.split("=")[0], int(a.split("=")[1]))
 eng.lucy_iteration(n // 10, 1, want_output=False)
 for it in (2, 3):
     _, st = eng.lucy_iteration(n, it, want_output=False)
