@@ -2628,7 +2628,9 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     if (c < 64) c = 64;
     if (c > 4096) c = 4096;
     L.chunk = (int)c;
-    L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    // the monochromatic iteration is final_kernel with inline peel-off: the imaging iteration's batch sizes
+    L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : 32;
+    L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : 48;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
     if (e != hipSuccess) return h->set_error(std::string("final_kernel (monochromatic) launch: ") + hipGetErrorString(e));
