@@ -333,7 +333,8 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
 /* tuning knobs (environment-independent): name in {"interact_threshold",
  * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
  * (-1 auto, 0 persistent kernel with global atomics, 1 brick-tiled),
- * "tile_slots", "tile_task", "tile_pools", "tile_drain", "tile_split", "defer_peel" (1: deferred peel-off where the plain
+ * "tile_slots", "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "final_interact_threshold" /
+ * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
  * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer), "oct_neighbours" (0: the
  * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (can only be
  * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "last_defer_rounds",
