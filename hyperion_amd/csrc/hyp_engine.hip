@@ -247,7 +247,7 @@ struct hyp_engine {
     // the imaging iteration batches harder: the lanes that have just emitted walk to the observer (and, forced first
     // interaction, to the edge) together, so an emission of 48 lanes keeps 3 x the lanes busy in those walks than one of 16
     // (configs[3]: inline 76 -> 52 ms, deferred 60 -> 52 ms; profiles/r02_tiled_log.md).  -1 = measured optimum: interactions 16
-    // deferred / 32 inline; emissions 48, except 16 for the deferred schedule on a Cartesian grid (its walks are cheap).
+    // deferred / 32 inline; emissions 48 deferred (16 on a Cartesian grid: its walks are cheap) / 32 inline.
     int final_interact_threshold = -1, final_emit_threshold = -1;
 
     // monochromatic final iteration
@@ -2404,7 +2404,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     }
     L.chunk = chunk;
     L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : (deferred ? 16 : 32);
-    L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : (deferred && h->hp.grid_type == 1 ? 16 : 48);
+    L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : (!deferred ? 32 : h->hp.grid_type == 1 ? 16 : 48);
     h->last_defer_rounds = 0; h->last_defer_events = 0;
     if (deferred) {
         (void)hipEventRecord(h->ev0, h->stream);

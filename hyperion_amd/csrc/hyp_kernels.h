@@ -1308,9 +1308,15 @@ template <int GEOM> constexpr int lucy_waves() { return GEOM == GEOM_VOR ? HYP_L
 #define HYP_WALK_STEPS 4        // cell crossings between two looks at the lanes' states, Cartesian grid
 #endif
 #ifndef HYP_WALK_STEPS_TREE
-#define HYP_WALK_STEPS_TREE 8   // the other geometries: a crossing is several dependent loads, fewer state checks pay
+#define HYP_WALK_STEPS_TREE 16  // octree, Voronoi: a crossing is several dependent loads, fewer state checks pay (configs[3]
+#endif                          // imaging 52.7 -> 50 ms; the Lucy kernels do not care)
+#ifndef HYP_WALK_STEPS_OTHER
+#define HYP_WALK_STEPS_OTHER 8  // AMR, polar grids
 #endif
-template <int GEOM> constexpr int walk_steps() { return GEOM == GEOM_CAR ? HYP_WALK_STEPS : HYP_WALK_STEPS_TREE; }
+template <int GEOM> constexpr int walk_steps()
+{
+    return GEOM == GEOM_CAR ? HYP_WALK_STEPS : (GEOM == GEOM_OCT || GEOM == GEOM_VOR) ? HYP_WALK_STEPS_TREE : HYP_WALK_STEPS_OTHER;
+}
 template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
