@@ -271,7 +271,9 @@ int  hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *
 
 /* do_final + peeloff_photon (src/main/iter_final.f90:60-273,
  * src/images/images_peeled.f90:95-270).  Same split as above; the accumulator
- * block is [all sed/img cubes | energy_current | killed counters ...]. */
+ * block is [all sed/img cubes | energy_current | killed counters ...].  With the deferred peel-off schedule (option
+ * "defer_peel", the default where it applies) hyp_final_launch runs its rounds of {propagate, peel} to the end before it
+ * returns; the split stays valid, only the overlap with host work is gone. */
 int  hyp_final_iteration(hyp_handle h, uint64_t n_packets, hyp_iter_stats *stats);
 int  hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local);
 int  hyp_final_accumulators(hyp_handle h, void **device_ptr, uint64_t *n_doubles);
