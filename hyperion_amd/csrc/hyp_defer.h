@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
 
 #pragma unroll 1
-        for (int k = 0; k < walk_steps<GEOM>(); k++) {
+        for (int k = 0; k < final_walk_steps<GEOM>(); k++) {
             if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF);
         }
     }
