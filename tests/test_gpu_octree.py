@@ -121,3 +121,27 @@ def test_full_size_config4_properties():
     assert img.shape == (4, 1, 1, 512, 512, 1)
     assert img[0].sum() == pytest.approx(sed[0].sum(), rel=1e-9)
     assert 0.05 * LSUN < sed[0].sum() < 1.2 * LSUN
+
+
+def test_neighbour_table_walk_is_the_reference_walk_at_full_size():
+    """geo_advance through oct_neigh (one load + a short descent) against the reference's climb-and-descend on BASELINE
+    configs[3] itself -- depth 7, 30 217 cells, the source ON a vertex of the tree, where the edge fallback of the table
+    path is exercised -- with 2e6 packets: the same integers (crossings, interactions, packets killed by the propagation
+    check), the same energies to summation order, in the Lucy and in the imaging iteration (peel-off walks included)."""
+    prob = make_octree_problem(max_level=7)
+    eng = hyperion_amd.Engine(prob)
+    out = {}
+    for table in (1, 0):
+        eng.set_option("oct_neighbours", table)
+        se, st = eng.lucy_iteration(2_000_000, 1)
+        img, si = eng.final_iteration(1_000_000)
+        out[table] = (se, st, img, si)
+    eng.close()
+    (a, sa, ia, fa), (b, sb, ib, fb) = out[1], out[0]
+    assert sa["killed_geo"] > 100            # the vertex source does send packets along tree edges
+    for k in INT_KEYS:
+        assert sa[k] == sb[k] and fa[k] == fb[k], (k, sa, sb, fa, fb)
+    np.testing.assert_allclose(a, b, rtol=1e-10, atol=1e-13 * b.max())
+    for ga, gb in zip(ia, ib):
+        for name in gb:
+            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
