@@ -61,7 +61,8 @@ struct DSource {
     // spotted sphere (the reference's source type 3): spot_tab = [cdf over spots..., sphere (n_spots + 1)] then per spot
     // SPOT_STRIDE doubles {nx, ny, nz, cos(radius), spectrum_type, temperature, n_spec, off_x, off_cdf, off_bp1, off_mono}
     // with table offsets relative to spot_blob
-    int n_spots, pad_spots;
+    int n_spots;
+    int vor_cell1;            // Voronoi grid, point source: cell of the source position + 1 (0: not set)
     const double *spot_tab, *spot_blob;
     const double *map_cdf;              // map (type 4): [n_cells] cumulative of the luminosity map; spectrum_type 3 = 'lte'
     double radius, box[6], face_cdf[6];
@@ -92,7 +93,13 @@ struct DPeeled {
 // Octree cell record (32 B): grid_geometry_octree.f90 / type_grid_octree.f90:14-22.
 // Half-widths are root half-width * 2^-level.
 // one entry of a Voronoi cell's wall list: the neighbour (or -1..-6: a face of the box) and the neighbour's site
-struct alignas(32) VorWall { double x, y, z; int nb, pad; };
+// (`loc` is used by the cluster-tiled schedule, hyp_vtile.h: index of the neighbour inside the cluster whose copy of the record this
+// is, -1 for a face of the box, <= -2 where the neighbour belongs to another cluster: -(slot in the cluster's adjacency list) - 2)
+struct alignas(32) VorWall { double x, y, z; int nb, loc; };
+// cluster-tiled Voronoi schedule: one cell of a cluster = its site and its range in the cluster's wall records
+struct alignas(32) VtHdr { double x, y, z; int k0, k1; };
+#define VT_MAX_ADJ 64           // adjacent clusters listed per cluster (walls to further ones: VT_FAR)
+#define VT_FAR (-(VT_MAX_ADJ) - 2)
 
 struct OctCell {
     double x, y, z;
@@ -146,6 +153,13 @@ struct DProblem {
     const double *vor_bb;                 // [n_cells][6] bb_min, bb_max of the cells (random_position_cell) or null
     double vor_box[6];
     int vor_g, pad4;
+    // cluster-tiled schedule (hyp_vtile.h): cells grouped into spatially compact clusters whose wall records fit in LDS
+    const int *vt_cluster;                // [n_cells] cluster << 8 | index of the cell in its cluster
+    const int *vt_cell_off, *vt_wall_off; // [n_clusters + 1] first cell / wall record of each cluster
+    const int *vt_members;                // [n_cells] cell ids, cluster by cluster
+    const VtHdr *vt_hdr;                  // [n_cells] cluster by cluster
+    const VorWall *vt_walls;              // wall records, cluster by cluster, `loc` filled in
+    const int *vt_adj;                    // [n_clusters][VT_MAX_ADJ] adjacent clusters (-1: unused)
     const AmrGrid *amr_grids;             // amr: [n_amr_grids], level by level
     const int *amr_go;                    // goto tables of all grids
     const double *amr_walls;              // wall arrays of all grids

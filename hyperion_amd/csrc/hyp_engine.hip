@@ -241,6 +241,13 @@ struct hyp_engine {
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
     int last_generations = 0;
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
+    // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
+    int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
+    int vt_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB (78: two workgroups per CU)
+    int vt_clusters = 0, vt_max_cells = 0, vt_max_walls = 0, vt_built_for = -1;
+    int *d_vt_cluster = nullptr, *d_vt_cell_off = nullptr, *d_vt_wall_off = nullptr, *d_vt_members = nullptr, *d_vt_adj = nullptr;
+    VtHdr *d_vt_hdr = nullptr; VorWall *d_vt_walls = nullptr;
+    std::vector<double> h_vor_sites; std::vector<int> h_vor_idx, h_vor_neigh;     // host copies for the cluster builder
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
@@ -259,6 +266,7 @@ struct hyp_engine {
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
+    bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
     int defer_peel = 1;             // option: 1 = use it where plain_imaging holds, 0 = peel off inline
     long long peel_events = 16ll << 20;     // option: capacity of the event buffer, in events
@@ -368,20 +376,20 @@ LucyKernel pick_final_kernel(int nd, int grid_type, bool plain)
 }  // namespace
 
 
-// ---- brick-tiled Lucy iteration (Cartesian grids): host-driven generations ----
+// ---- brick- / cluster-tiled Lucy iteration (Cartesian and Voronoi grids): host-driven generations ----
 namespace {
 
-// brick shape per number of species: density + accumulators (16 B per cell and
-// species) must leave room for two workgroups per CU in the 160 KB LDS
-#ifndef HYP_TILE_BX
-#define HYP_TILE_BX 16
-#define HYP_TILE_BY 16
-#define HYP_TILE_BZ 16
+TileKernels pick_tile_kernels(int nd, int grid_type)
+{
+#ifdef HYP_VARIANT_GEOM
+    return pick_tile_kernels_g<HYP_VARIANT_GEOM>(nd);
 #endif
-template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 64 KB
-template <> struct TileShape<2> { static constexpr int X = 16, Y = 16, Z = 8; };         // 64 KB
-template <> struct TileShape<3> { static constexpr int X = 16, Y = 8, Z = 8; };          // 48 KB
-template <> struct TileShape<4> { static constexpr int X = 16, Y = 8, Z = 8; };          // 64 KB
+    switch (grid_type) {
+    case 1: return pick_tile_kernels_g<GEOM_CAR>(nd);
+    case 3: return pick_tile_kernels_g<GEOM_VOR>(nd);
+    default: { TileKernels k; memset(&k, 0, sizeof k); return k; }
+    }
+}
 
 void tile_shape(int nd, int &x, int &y, int &z)
 {
@@ -400,18 +408,30 @@ int tile_bricks(const DProblem &P, int nd)
     return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
 }
 
-template <int ND>
-int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, int n_pools)
+// LDS of one walk workgroup
+size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T)
 {
-    constexpr int TBX = TileShape<ND>::X, TBY = TileShape<ND>::Y, TBZ = TileShape<ND>::Z;
+    if (h->hp.grid_type == 3)       // cluster: cell headers + wall records + densities + accumulators
+        return sizeof(VtHdr) * (size_t)T.bx + sizeof(VorWall) * (size_t)T.by + sizeof(double) * 2 * (size_t)T.bx * K.nd;
+    return lds_bytes(h->hp) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd;
+}
+
+int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0, uint64_t n_local, int n_pools)
+{
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_int = lds_w;
-    const size_t lds_walk = lds_w + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)TBX * TBY * TBZ * ND;
+    const size_t lds_walk = tile_walk_lds(h, K, T0);
     const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * h->tile_prep_blocks);
     const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
     const int grid_w = T0.n_slots / T0.task_size + T0.n_bricks + 1;
-    if (hipFuncSetAttribute((const void *)tile_walk_kernel<ND, TBX, TBY, TBZ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
+    // tile_interact: one workgroup per HYP_INTERACT_CHUNK entries of the pool's list (+ one for the extra list); tile_emit:
+    // one per 256 free slots.  Workgroups beyond the lists' lengths (known on the device only) leave at once.
+    const int grid_i = (T0.n_slots + HYP_INTERACT_CHUNK - 1) / HYP_INTERACT_CHUNK + 1;
+    const int grid_e = (T0.n_slots + 255) / 256;
+    if (hipFuncSetAttribute((const void *)K.walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
         return h->set_error("cannot reserve LDS for the tiled walk kernel");
+    const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
+    const int ri = h->hp.any_intersect ? 1 : 0, mi = h->hp.mrw ? 1 : 0;
     // Each pool of slots runs its own prepare -> sort -> walk sequence on its own stream, so the
     // latency-bound prepare of one pool overlaps the walk of the other.  The pools share only the
     // packet-id dispenser, the finished counter and the (atomic) accumulators.
@@ -422,31 +442,26 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
         for (int pool = 0; pool < n_pools; pool++) {
             TileGeom T = T0; T.pool = pool;
             hipStream_t st = pool == 0 ? h->stream : h->pool_stream[pool];
-            HotRec<ND> *hot = (HotRec<ND> *)h->d_hot + (size_t)pool * T.n_slots;
-            ColdRec<ND> *cold = (ColdRec<ND> *)h->d_cold + (size_t)pool * T.n_slots;
+            void *hot = (char *)h->d_hot + hot_sz * (size_t)pool * T.n_slots;
+            void *cold = (char *)h->d_cold + cold_sz * (size_t)pool * T.n_slots;
             int *slot_brick = h->d_slot_brick + (size_t)pool * T.n_slots;
             int *order = h->d_order + (size_t)pool * T.n_slots;
             TileTask *tasks = h->d_tasks + pool * tasks_cap;
             unsigned *counts = h->d_counts + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
                      *cursor = h->d_cursor + pool * HYP_TILE_MAX_BRICKS;
-            int *ilist = h->d_ilist + (size_t)pool * T.n_slots, *dlist = h->d_dlist + (size_t)pool * T.n_slots;
+            int *ilist = h->d_ilist + (size_t)pool * 2 * T.n_slots, *dlist = h->d_dlist + (size_t)pool * 2 * T.n_slots;      // [staging | pool-wide list]
             int *extra = h->d_extra + (size_t)pool * 3 * HYP_TILE_EXTRA;
             T.gen = gen;
             TileCount *tcount = h->d_tcount + pool * tasks_cap;
             if (T.split) {
                 // walk (previous generation) left per-task lists: interactions, then emission into the freed slots
                 if (gen == 0) tile_init_kernel<<<(T.n_slots + 255) / 256, 256, 0, st>>>(T, h->d_ctl, tasks, tcount, dlist);
-                else {
-                    void (*ik)(const DProblem *, TileGeom, TileCtl *, HotRec<ND> *, ColdRec<ND> *, int *, const TileTask *, const int *, int *, TileCount *,
-                               unsigned int *, int *) =
-                        h->hp.any_intersect ? (h->hp.mrw ? tile_interact_kernel<ND, true, true> : tile_interact_kernel<ND, true, false>)
-                                            : (h->hp.mrw ? tile_interact_kernel<ND, false, true> : tile_interact_kernel<ND, false, false>);
-                    ik<<<(grid_w + 1) * HYP_LIST_SPLIT, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist, tcount,
-                                                                           counts, extra);
-                }
-                tile_emit_kernel<ND><<<(grid_w + 1) * HYP_LIST_SPLIT, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra);
+                else
+                    K.interact[ri][mi]<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
+                                                                                         tcount, counts, extra);
+                (h->simple_sources && K.emit_simple ? K.emit_simple : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra);
             } else {
-                tile_prepare_kernel<ND><<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
+                K.prepare<<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
                 tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
             }
             tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
@@ -460,8 +475,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
                 }
                 (void)hipEventRecord(h->walk_events[n_timed], st);
             }
-            tile_walk_kernel<ND, TBX, TBY, TBZ><<<grid_w, HYP_TILE_WG, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick,
-                                                                                       ilist, dlist, tcount, counts);
+            K.walk<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
         if ((gen + 1) % h->tile_poll == 0 || gen > 200000) {
@@ -479,10 +493,7 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
                 }
                 TileGeom T = T0; T.n_slots = T0.n_slots * n_pools;
                 const int grid_d = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
-                void (*dk)(const DProblem *, TileGeom, TileCtl *, HotRec<ND> *, ColdRec<ND> *, int *) =
-                    h->hp.any_intersect ? (h->hp.mrw ? tile_drain_kernel<ND, true, true> : tile_drain_kernel<ND, true, false>)
-                                        : (h->hp.mrw ? tile_drain_kernel<ND, false, true> : tile_drain_kernel<ND, false, false>);
-                dk<<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, (HotRec<ND> *)h->d_hot, (ColdRec<ND> *)h->d_cold, h->d_slot_brick);
+                K.drain[ri][mi]<<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, h->d_hot, h->d_cold, h->d_slot_brick);
                 e = hipStreamSynchronize(h->stream);
                 if (e != hipSuccess) return h->set_error(std::string("tiled drain failed: ") + hipGetErrorString(e));
                 break;
@@ -528,10 +539,19 @@ int run_tiled_generations(hyp_handle h, const TileGeom &T0, uint64_t n_local, in
 int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration)
 {
     const DProblem &P = h->hp;
+    const int nd = h->n_dust;
+    const TileKernels K = pick_tile_kernels(nd, P.grid_type);
+    if (!K.walk) return h->set_error("no tiled schedule for this grid geometry");
     TileGeom T;
-    tile_shape(h->n_dust, T.bx, T.by, T.bz);
-    T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
-    T.n_bricks = T.nbx * T.nby * T.nbz;
+    memset(&T, 0, sizeof T);
+    if (P.grid_type == 3) {
+        T.bx = h->vt_max_cells; T.by = h->vt_max_walls; T.bz = 1;
+        T.nbx = T.n_bricks = h->vt_clusters; T.nby = T.nbz = 1;
+    } else {
+        tile_shape(nd, T.bx, T.by, T.bz);
+        T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
+        T.n_bricks = T.nbx * T.nby * T.nbz;
+    }
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
     long long slots = std::min<long long>(h->tile_slots, (long long)n_local);
     if (slots < 65536) n_pools = 1;
@@ -539,18 +559,16 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
     T.task_size = h->tile_task < 256 ? 256 : h->tile_task;
-    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = h->tile_split ? 1 : 0;
-    const int nd = h->n_dust;
-    size_t hot_sz = nd == 1 ? sizeof(HotRec<1>) : nd == 2 ? sizeof(HotRec<2>) : nd == 3 ? sizeof(HotRec<3>) : sizeof(HotRec<4>);
-    size_t cold_sz = nd == 1 ? sizeof(ColdRec<1>) : nd == 2 ? sizeof(ColdRec<2>) : nd == 3 ? sizeof(ColdRec<3>) : sizeof(ColdRec<4>);
-    if (all_slots > h->tile_slots_alloc || nd != h->tile_nd_alloc) {
+    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare) ? 1 : 0;
+    const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
+    if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
         free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
         free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
         const size_t n_tasks_max = HYP_TILE_MAX_POOLS * ((size_t)all_slots / 256 + HYP_TILE_MAX_BRICKS + 2);
         if (hipMalloc(&h->d_hot, hot_sz * all_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * all_slots) != hipSuccess ||
             hipMalloc(&h->d_slot_brick, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * all_slots) != hipSuccess ||
             hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) != hipSuccess ||
-            hipMalloc(&h->d_ilist, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_dlist, sizeof(int) * all_slots) != hipSuccess ||
+            hipMalloc(&h->d_ilist, sizeof(int) * 2 * all_slots) != hipSuccess || hipMalloc(&h->d_dlist, sizeof(int) * 2 * all_slots) != hipSuccess ||
             hipMalloc(&h->d_tcount, sizeof(TileCount) * n_tasks_max) != hipSuccess ||
             hipMalloc(&h->d_extra, sizeof(int) * 3 * HYP_TILE_EXTRA * HYP_TILE_MAX_POOLS) != hipSuccess)
             return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
@@ -575,20 +593,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
     (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
     (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
-    int rc;
-#ifdef HYP_ONLY_ND1
-    if (nd != 1) return h->set_error("tuning build: one dust species only");
-#endif
-    switch (nd) {
-    case 1: rc = run_tiled_generations<1>(h, T, n_local, n_pools); break;
-#ifndef HYP_ONLY_ND1
-    case 2: rc = run_tiled_generations<2>(h, T, n_local, n_pools); break;
-    case 3: rc = run_tiled_generations<3>(h, T, n_local, n_pools); break;
-    default: rc = run_tiled_generations<4>(h, T, n_local, n_pools); break;
-#else
-    default: rc = 1; break;
-#endif
-    }
+    const int rc = run_tiled_generations(h, K, T, n_local, n_pools);
     for (int pool = 1; pool < n_pools; pool++) {      // join the other pools into the engine's stream
         (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
         (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
@@ -615,6 +620,8 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed); free_dev(h->d_vor_walls);
     free_dev(h->d_mask_map);
+    free_dev(h->d_vt_cluster); free_dev(h->d_vt_cell_off); free_dev(h->d_vt_wall_off); free_dev(h->d_vt_members); free_dev(h->d_vt_adj);
+    free_dev(h->d_vt_hdr); free_dev(h->d_vt_walls);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
@@ -649,6 +656,7 @@ static int solve_pda(hyp_handle h);
 static int sync_problem(hyp_handle h);
 static int check_device_error(hyp_handle h);
 static int mrw_prepare(hyp_handle h);
+static int build_vor_clusters(hyp_handle h);
 
 int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 {
@@ -706,7 +714,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                 cur = best; dcur = dbest;
             }
         };
-        vor_g = (int)std::ceil(std::cbrt((double)nc / 4.0));
+        // about two seed cells per site: the walk from the seed to the nearest site is 0-1 hops for most positions (emission
+        // from extended sources places every packet this way); the result does not depend on the seed
+        vor_g = (int)std::ceil(std::cbrt((double)nc * 2.0));
         if (vor_g < 1) vor_g = 1;
         if (vor_g > 256) vor_g = 256;
         vor_seed.resize((size_t)vor_g * vor_g * vor_g);
@@ -1158,6 +1168,34 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             std::memset(&S, 0, sizeof(S));
             if (s.type != 1 && s.type != 2 && s.type != 4 && s.type != 5 && s.type != 6 && s.type != 7 && s.type != 8) FAIL("unknown type in source list: " + std::to_string(s.type));
             S.type = s.type; S.peeloff = s.peeloff; S.radius = s.radius; S.limb_darkening = s.limb_darkening;
+            if (is_vor && s.type == 1) {
+                // every packet of a point source starts in the same cell: find_cell (grid_geometry_voronoi.f90:196-229) once, here
+                const double *Sx = pr->grid.vor_sites, *Bx = pr->grid.vor_box;
+                const double r[3] = {s.position[0], s.position[1], s.position[2]};
+                if (!(r[0] < Bx[0] || r[0] > Bx[1] || r[1] < Bx[2] || r[1] > Bx[3] || r[2] < Bx[4] || r[2] > Bx[5])) {
+                    int id[3];
+                    for (int a = 0; a < 3; a++) {
+                        const double f = (r[a] - Bx[2 * a]) / (Bx[2 * a + 1] - Bx[2 * a]);
+                        const int q = (int)(f * vor_g);
+                        id[a] = q < 0 ? 0 : (q >= vor_g ? vor_g - 1 : q);
+                    }
+                    auto d2 = [&](int c) { const double dx = Sx[3 * (size_t)c] - r[0], dy = Sx[3 * (size_t)c + 1] - r[1], dz = Sx[3 * (size_t)c + 2] - r[2]; return dx * dx + dy * dy + dz * dz; };
+                    int cur = vor_seed[((size_t)id[2] * vor_g + id[1]) * vor_g + id[0]];
+                    double dcur = d2(cur);
+                    for (;;) {
+                        int best = cur; double dbest = dcur;
+                        for (int k = pr->grid.vor_idx[cur]; k < pr->grid.vor_idx[cur + 1]; k++) {
+                            const int nb = pr->grid.vor_neighs[k];
+                            if (nb < 0) continue;
+                            const double d = d2(nb);
+                            if (d < dbest) { dbest = d; best = nb; }
+                        }
+                        if (best == cur) break;
+                        cur = best; dcur = dbest;
+                    }
+                    S.vor_cell1 = cur + 1;
+                }
+            }
             if (s.type == 2) P.any_intersect = 1;      // s%intersect = .true.: source_type.f90:148
             if (s.type == 7) {      // plane_parallel: source_type.f90:239-256
                 const double th = s.direction[0] * HYP_PI / 180.0, ph = s.direction[1] * HYP_PI / 180.0;
@@ -1496,7 +1534,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (size_t k = 0; k < nn; k++) {
                 const int nb = pr->grid.vor_neighs[k];
                 VorWall &w = walls[k];
-                w.nb = nb; w.pad = 0; w.x = w.y = w.z = 0.0;
+                w.nb = nb; w.loc = 0; w.x = w.y = w.z = 0.0;
                 if (nb >= 0) { w.x = pr->grid.vor_sites[3 * (size_t)nb]; w.y = pr->grid.vor_sites[3 * (size_t)nb + 1]; w.z = pr->grid.vor_sites[3 * (size_t)nb + 2]; }
             }
             HIPC(hipMalloc(&h->d_vor_walls, sizeof(VorWall) * walls.size()));
@@ -1508,6 +1546,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             HIPC(hipMalloc(&h->d_vor_bb, sizeof(double) * 6 * nc));
             HIPC(hipMemcpy(h->d_vor_bb, pr->grid.vor_bb, sizeof(double) * 6 * nc, hipMemcpyHostToDevice));
         }
+        h->h_vor_sites.assign(pr->grid.vor_sites, pr->grid.vor_sites + 3 * nc);
+        h->h_vor_idx.assign(pr->grid.vor_idx, pr->grid.vor_idx + nc + 1);
+        h->h_vor_neigh.assign(pr->grid.vor_neighs, pr->grid.vor_neighs + nn);
         P.vor_bb = h->d_vor_bb;
         P.vor_sites = h->d_vor_sites; P.vor_volume = h->d_vor_volume; P.vor_idx = h->d_vor_idx;
         P.vor_neigh = h->d_vor_neigh; P.vor_seed = h->d_vor_seed; P.vor_g = vor_g; P.vor_walls = h->d_vor_walls;
@@ -1656,6 +1697,9 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
         for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer && !pr->peeled[g].use_filters;
         h->plain_imaging = plain;
+        bool simple = pr->n_sources > 0;
+        for (int i = 0; i < pr->n_sources; i++) simple = simple && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
+        h->simple_sources = simple;
     }
     P.n_views_total = views_total;
     P.binned = pr->binned ? pr->n_peeled : -1; P.n_bin_theta = pr->n_binned_theta; P.n_bin_phi = pr->n_binned_phi;
@@ -1751,6 +1795,115 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 #undef FAIL
 #undef HIPC
     *out = h;
+    return 0;
+}
+
+// Clusters of Voronoi cells for the tiled schedule (hyp_vtile.h): recursive coordinate bisection of the sites into groups
+// of equal cell count whose wall records, headers, densities and accumulators fit the LDS share of one workgroup (two
+// workgroups per CU); per cluster the gathered wall records with the neighbour's index inside the cluster, or the slot of
+// the neighbour's cluster in the adjacency list.
+static int build_vor_clusters(hyp_handle h)
+{
+    const int nd = h->n_dust;
+    if (h->vt_built_for == nd && h->d_vt_cluster) return 0;
+    const size_t nc = h->n_cells;
+    const double *S = h->h_vor_sites.data();
+    const int *idx = h->h_vor_idx.data(), *nei = h->h_vor_neigh.data();
+    if (h->h_vor_sites.size() != 3 * nc) return h->set_error("voronoi tables missing for the cluster builder");
+    const size_t budget = (size_t)h->vt_lds_kb * 1024;
+    std::vector<int> perm(nc), cl_of(nc), cell_off, wall_off;
+    int n_cl = 0, max_cells = 0, max_walls = 0;
+    double target = h->vt_cells > 0 ? (double)h->vt_cells : 250.0;
+    for (int attempt = 0;; attempt++) {
+        n_cl = (int)std::max<double>(1.0, std::ceil((double)nc / target));
+        if (n_cl > HYP_TILE_MAX_BRICKS) return h->set_error("voronoi grid has too many cells for the cluster-tiled schedule");
+        for (size_t i = 0; i < nc; i++) perm[i] = (int)i;
+        cell_off.assign(n_cl + 1, 0);
+        // iterative bisection: (first cell, number of cells, first cluster, number of clusters)
+        struct Part { size_t lo, n; int c0, k; };
+        std::vector<Part> stack{{0, nc, 0, n_cl}};
+        while (!stack.empty()) {
+            const Part p = stack.back(); stack.pop_back();
+            if (p.k == 1) { cell_off[p.c0 + 1] = (int)p.n; for (size_t i = p.lo; i < p.lo + p.n; i++) cl_of[perm[i]] = p.c0; continue; }
+            double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+            for (size_t i = p.lo; i < p.lo + p.n; i++)
+                for (int a = 0; a < 3; a++) { const double x = S[3 * (size_t)perm[i] + a]; lo[a] = std::min(lo[a], x); hi[a] = std::max(hi[a], x); }
+            int ax = 0;
+            for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a;
+            const int k1 = p.k / 2;
+            const size_t n1 = (size_t)((double)p.n * k1 / p.k + 0.5);
+            std::nth_element(perm.begin() + p.lo, perm.begin() + p.lo + n1, perm.begin() + p.lo + p.n,
+                             [&](int a, int b) { const double xa = S[3 * (size_t)a + ax], xb = S[3 * (size_t)b + ax]; return xa < xb || (xa == xb && a < b); });
+            stack.push_back({p.lo, n1, p.c0, k1});
+            stack.push_back({p.lo + n1, p.n - n1, p.c0 + k1, p.k - k1});
+        }
+        for (int c = 0; c < n_cl; c++) cell_off[c + 1] += cell_off[c];
+        wall_off.assign(n_cl + 1, 0);
+        for (size_t i = 0; i < nc; i++) wall_off[cl_of[i] + 1] += idx[i + 1] - idx[i];
+        max_cells = max_walls = 0;
+        for (int c = 0; c < n_cl; c++) {
+            max_cells = std::max(max_cells, cell_off[c + 1] - cell_off[c]);
+            max_walls = std::max(max_walls, wall_off[c + 1]);
+            wall_off[c + 1] += wall_off[c];
+        }
+        const size_t lds = sizeof(VtHdr) * (size_t)max_cells + sizeof(VorWall) * (size_t)max_walls + sizeof(double) * 2 * (size_t)max_cells * nd;
+        if (max_cells <= 256 && lds <= budget) break;
+        if (h->vt_cells > 0 && max_cells <= 256 && lds <= 2 * budget) break;       // a forced size may take a whole CU's LDS
+        if (h->vt_cells > 0 || attempt > 40) return h->set_error("voronoi clusters do not fit in LDS");
+        target *= 0.9;
+    }
+    // members of each cluster in ascending cell order
+    std::vector<int> members(nc), cursor(cell_off.begin(), cell_off.end() - 1), packed(nc);
+    for (size_t i = 0; i < nc; i++) {
+        const int c = cl_of[i], l = cursor[c]++ - cell_off[c];
+        members[cell_off[c] + l] = (int)i;
+        packed[i] = (c << 8) | l;
+    }
+    std::vector<VtHdr> hdr(nc);
+    std::vector<VorWall> walls((size_t)wall_off[n_cl] ? (size_t)wall_off[n_cl] : 1);
+    std::vector<int> adj((size_t)n_cl * VT_MAX_ADJ, -1);
+    size_t n_far = 0;
+    for (int c = 0; c < n_cl; c++) {
+        int kw = 0;
+        int *ad = adj.data() + (size_t)c * VT_MAX_ADJ;
+        for (int j = cell_off[c]; j < cell_off[c + 1]; j++) {
+            const int cell = members[j];
+            VtHdr &H = hdr[j];
+            H.x = S[3 * (size_t)cell]; H.y = S[3 * (size_t)cell + 1]; H.z = S[3 * (size_t)cell + 2];
+            H.k0 = kw;
+            for (int k = idx[cell]; k < idx[cell + 1]; k++) {
+                VorWall &w = walls[(size_t)wall_off[c] + kw++];
+                const int nb = nei[k];
+                w.nb = nb; w.x = w.y = w.z = 0.0; w.loc = -1;
+                if (nb < 0) continue;
+                w.x = S[3 * (size_t)nb]; w.y = S[3 * (size_t)nb + 1]; w.z = S[3 * (size_t)nb + 2];
+                const int cn = cl_of[nb];
+                if (cn == c) { w.loc = packed[nb] & 255; continue; }
+                int s = 0;
+                while (s < VT_MAX_ADJ && ad[s] != cn && ad[s] != -1) s++;
+                if (s < VT_MAX_ADJ) { ad[s] = cn; w.loc = -s - 2; }
+                else { w.loc = VT_FAR; n_far++; }
+            }
+            H.k1 = kw;
+        }
+    }
+    // unused adjacency slots point at the cluster itself (the walk adds a zero count there)
+    for (int c = 0; c < n_cl; c++) for (int s = 0; s < VT_MAX_ADJ; s++) if (adj[(size_t)c * VT_MAX_ADJ + s] < 0) adj[(size_t)c * VT_MAX_ADJ + s] = c;
+    free_dev(h->d_vt_cluster); free_dev(h->d_vt_cell_off); free_dev(h->d_vt_wall_off); free_dev(h->d_vt_members); free_dev(h->d_vt_adj);
+    free_dev(h->d_vt_hdr); free_dev(h->d_vt_walls);
+    auto up = [&](auto *&dst, const auto &v) {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (hipMalloc((void **)&dst, sizeof(T) * v.size()) != hipSuccess) return 1;
+        return hipMemcpy(dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
+    };
+    if (up(h->d_vt_cluster, packed) || up(h->d_vt_cell_off, cell_off) || up(h->d_vt_wall_off, wall_off) || up(h->d_vt_members, members) ||
+        up(h->d_vt_adj, adj) || up(h->d_vt_hdr, hdr) || up(h->d_vt_walls, walls))
+        return h->set_error("cannot allocate the cluster tables of the tiled Voronoi schedule");
+    DProblem &P = h->hp;
+    P.vt_cluster = h->d_vt_cluster; P.vt_cell_off = h->d_vt_cell_off; P.vt_wall_off = h->d_vt_wall_off; P.vt_members = h->d_vt_members;
+    P.vt_adj = h->d_vt_adj; P.vt_hdr = h->d_vt_hdr; P.vt_walls = h->d_vt_walls;
+    h->vt_clusters = n_cl; h->vt_max_cells = max_cells; h->vt_max_walls = max_walls; h->vt_built_for = nd;
+    (void)n_far;
     return 0;
 }
 
@@ -2022,21 +2175,23 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     if (h->count_photons) {      // grid_reset_energy: grid_generic.f90:21-27
         (void)hipMemsetAsync(h->d_nphot, 0, sizeof(unsigned int) * h->n_cells, h->stream);
         (void)hipMemsetAsync(h->d_nphot_inexact, 0, sizeof(int), h->stream);
-        // the visited sets: one per lane of the largest launch this device can hold (the persistent kernel's grid)
-        const size_t lanes = (size_t)h->n_cu * 8 * 256;
-        if (h->visit_lanes < lanes) {
-            free_dev(h->d_visit);
-            h->visit_lanes = 0;
-            if (hipMalloc((void **)&h->d_visit, lanes * HYP_VISIT_SLOTS * sizeof(unsigned long long)) != hipSuccess) {
-                (void)hipGetLastError();
-                return h->set_error("no memory for the per-lane visited sets of the n_photons counter");
-            }
-            h->visit_lanes = lanes;
-        }
-        (void)hipMemsetAsync(h->d_visit, 0, h->visit_lanes * HYP_VISIT_SLOTS * sizeof(unsigned long long), h->stream);
-        P.visit_tab = h->d_visit;
+        // the visited sets are sized by hyp_lucy_launch below, once the grid of the persistent kernel is known
     }
     if (mrw_prepare(h)) return 1;
+    // The brick-tiled iteration pays off once the grid has many bricks and the
+    // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
+    // (the per-cell packet counter and the spectrum planes live in global memory: those runs use the persistent kernel)
+    bool tile_ok = false, tile_auto = false;
+    if (P.grid_type == 1) {
+        tile_ok = h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
+        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
+    } else if (P.grid_type == 3) {
+        // Voronoi: clusters of cells in LDS (hyp_vtile.h); the modified random walk does not exist on these grids
+        tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && !P.mrw;
+        tile_auto = tile_ok && h->n_cells >= 8192 && n_local >= 2000000ull;
+    }
+    const bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto));
+    if (tiled && P.grid_type == 3 && build_vor_clusters(h)) return 1;
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(accum): ") + hipGetErrorString(e));
@@ -2044,13 +2199,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
 
-    // The brick-tiled iteration pays off once the grid has many bricks and the
-    // iteration is long enough to amortise its generations (measured: profiles/r01c_*).
-    // (the per-cell packet counter and the spectrum planes live in global memory: those runs use the persistent kernel)
-    const bool tile_ok = P.grid_type == 1 && h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS &&
-                         !h->count_photons && !h->n_bins;
-    const bool tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
-    if (tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto))) {
+    if (tiled) {
         if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;
         h->last_lucy_mode = 1;
         h->lucy_pending = true;
@@ -2066,11 +2215,26 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k, 256, lds) != hipSuccess || occ <= 0) occ = 2;
         bpc = occ;
     }
-    if (h->count_photons && bpc > 8) bpc = 8;        // the visited sets are sized for 8 workgroups per CU
     long long blocks = (long long)h->n_cu * bpc;
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
+    if (h->count_photons) {
+        // one visited set per lane of THIS launch (HYP_VISIT_SLOTS words each); with less memory than that, fewer workgroups
+        for (;;) {
+            const size_t lanes = (size_t)blocks * 256;
+            if (h->visit_lanes >= lanes) break;
+            free_dev(h->d_visit);
+            h->visit_lanes = 0;
+            if (hipMalloc((void **)&h->d_visit, lanes * HYP_VISIT_SLOTS * sizeof(unsigned long long)) == hipSuccess) { h->visit_lanes = lanes; break; }
+            (void)hipGetLastError();
+            h->d_visit = nullptr;
+            if (blocks <= 1) return h->set_error("no memory for the per-lane visited sets of the n_photons counter");
+            blocks = (blocks + 1) / 2;
+        }
+        (void)hipMemsetAsync(h->d_visit, 0, (size_t)blocks * 256 * HYP_VISIT_SLOTS * sizeof(unsigned long long), h->stream);
+        if (P.visit_tab != h->d_visit) { P.visit_tab = h->d_visit; if (sync_problem(h)) return 1; }
+    }
     LaunchParams L;
     L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = (uint32_t)iteration;
     int chunk = h->chunk;
@@ -2244,6 +2408,8 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
         h->peel_events = value; h->peel_events_exact = true;
     }
     else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; }
+    else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; }      // cells per Voronoi cluster (0: fill the LDS budget)
     else if (n == "tile_park") h->tile_park = (int)value;
     else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
     else return h->set_error("unknown option: " + n);
@@ -2278,6 +2444,10 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
     else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
     else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "vt_cells") *value = h->vt_cells;
+    else if (n == "vt_clusters") *value = h->vt_clusters;
+    else if (n == "vt_max_cells") *value = h->vt_max_cells;
+    else if (n == "vt_max_walls") *value = h->vt_max_walls;
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with

@@ -6,7 +6,9 @@
 #endif
 #include "hyp_kernels.h"
 #include "hyp_defer.h"
+#include "hyp_vtile.h"
 #include "hyp_pick.h"
+#include <cstring>
 
 template <int GEOM>
 LucyKernel pick_lucy_kernel_g(int nd)
@@ -85,7 +87,52 @@ DeferKernels pick_defer_kernels_g(int nd)
 #endif
 }
 
+template <int NDT, int GEOM>
+static TileKernels tile_kernels()
+{
+    TileKernels k;
+    memset(&k, 0, sizeof k);
+    k.nd = NDT;
+    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR) {
+        k.interact[0][0] = tile_interact_kernel<NDT, false, false, GEOM>; k.interact[1][0] = tile_interact_kernel<NDT, true, false, GEOM>;
+        k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
+        k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
+        k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
+    }
+    if constexpr (GEOM == GEOM_CAR) {
+        k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
+        k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
+        k.prepare = tile_prepare_kernel<NDT>;
+        k.walk = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z>;
+        k.walk_threads = HYP_TILE_WG;
+        k.bx = TileShape<NDT>::X; k.by = TileShape<NDT>::Y; k.bz = TileShape<NDT>::Z;
+    }
+    if constexpr (GEOM == GEOM_VOR) {      // the modified random walk is not defined on Voronoi grids (the engine refuses it)
+        k.walk = vtile_walk_kernel<NDT>;
+        k.walk_threads = HYP_VTILE_WG;
+    }
+    return k;
+}
+
+template <int GEOM>
+TileKernels pick_tile_kernels_g(int nd)
+{
+#ifdef HYP_ONLY_ND1
+    (void)nd;
+    return tile_kernels<1, GEOM>();
+#else
+    switch (nd) {
+    case 1: return tile_kernels<1, GEOM>();
+    case 2: return tile_kernels<2, GEOM>();
+    case 3: return tile_kernels<3, GEOM>();
+    case 4: return tile_kernels<4, GEOM>();
+    default: { TileKernels k; memset(&k, 0, sizeof k); return k; }
+    }
+#endif
+}
+
 template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
+template TileKernels pick_tile_kernels_g<HYP_GEOM_TU>(int);
 template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, bool);
 template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);
 template DeferKernels pick_defer_kernels_g<HYP_GEOM_TU>(int);

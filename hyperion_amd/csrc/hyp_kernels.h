@@ -369,11 +369,15 @@ __device__ __forceinline__ int vor_nearest_from(const DProblem &P, const double 
     double dcur = vor_dist2(P, cur, r);
     for (;;) {
         int best = cur; double dbest = dcur;
-        for (int k = P.vor_idx[cur]; k < P.vor_idx[cur + 1]; k++) {
-            int nb = P.vor_neigh[k];
-            if (nb < 0) continue;
-            double d = vor_dist2(P, nb, r);
-            if (d < dbest) { dbest = d; best = nb; }
+        // the gathered wall records hold the neighbour AND its site: one stream of independent 32-byte loads per hop
+        const int k0 = P.vor_idx[cur], k1 = P.vor_idx[cur + 1];
+#pragma unroll 4
+        for (int k = k0; k < k1; k++) {
+            const VorWall w = P.vor_walls[k];
+            if (w.nb < 0) continue;
+            const double dx = w.x - r[0], dy = w.y - r[1], dz = w.z - r[2];
+            const double d = dx * dx + dy * dy + dz * dz;
+            if (d < dbest) { dbest = d; best = w.nb; }
         }
         if (best == cur) return cur;
         cur = best; dcur = dbest;
@@ -689,7 +693,7 @@ __device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsig
     const unsigned long long key = ((unsigned long long)tag << 32) | (unsigned long long)(unsigned int)ic;
     if (n_visited >= HYP_VISIT_SLOTS * 3 / 4) { atomicAdd(&P.n_photons[ic], 1u); *P.nphot_inexact = 1; return; }
     unsigned int h = ((unsigned int)ic * 2654435761u) >> 20;       // 12 bits
-    for (;;) {
+    for (int probe = 0; probe < HYP_VISIT_SLOTS; probe++) {
         const unsigned long long e = tab[h];
         if (e == key) return;
         if ((unsigned int)(e >> 32) != tag) {       // empty, or left by an earlier packet of this lane
@@ -699,8 +703,10 @@ __device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsig
         }
         h = (h + 1u) & (HYP_VISIT_SLOTS - 1u);
     }
+    atomicAdd(&P.n_photons[ic], 1u); *P.nphot_inexact = 1;       // table full of this packet's own entries: cannot happen below 3/4 load
 }
-__device__ __forceinline__ unsigned int photon_tag(const Rng &g) { return g.id_lo + 1u; }
+// never 0 (the cleared-table marker): id 2^32 - 1 (mod 2^32) shares the tag of an id 2^31 away
+__device__ __forceinline__ unsigned int photon_tag(const Rng &g) { const unsigned int t = g.id_lo + 1u; return t ? t : 0x80000000u; }
 
 // start of a grid_integrate call of the Lucy iteration: also the frequency bin of the packet (:59-71) and the
 // count of the starting cell (:90-95)
@@ -972,7 +978,11 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (!update_optconsts<NDT, GEOM>(P, p)) return false;
     g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
     geo_clear_wall(p.cell);
-    if (!geo_place(P, W, p.r, p.v, p.cell)) {
+    bool placed = false;
+    if constexpr (GEOM == GEOM_VOR) {       // a point source sits in one cell, found at set-up (same search, same answer)
+        if (S.type == 1 && S.vor_cell1 > 0) { p.cell.id = S.vor_cell1 - 1; placed = true; }
+    }
+    if (!placed && !geo_place(P, W, p.r, p.v, p.cell)) {
         cnt.killed_geo++;
         raise_error(P, ERR_NOT_IN_CELL, p.r[0], p.r[1], p.r[2]);
         return false;

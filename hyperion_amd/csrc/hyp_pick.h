@@ -16,3 +16,26 @@ using DeferKernel = void (*)(const DProblem *, LaunchParams, DeferBuf);
 using PeelKernel = void (*)(const DProblem *, DeferBuf, uint32_t);
 struct DeferKernels { DeferKernel propagate; PeelKernel peel; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes; };
 template <int GEOM> DeferKernels pick_defer_kernels_g(int nd);
+
+// brick- / cluster-tiled Lucy iteration (hyp_tiled.h, hyp_vtile.h): the kernels of one geometry and species count.
+// Slot records travel as void * (HotRec<nd> / ColdRec<nd>).
+struct TileGeom; struct TileCtl; struct TileTask; struct TileCount;
+using TileInteractK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, const TileTask *, const int *, int *, TileCount *,
+                               unsigned int *, int *);
+using TileEmitK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, const TileTask *, const int *, const TileCount *,
+                           unsigned int *, int *);
+using TileDrainK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *);
+using TileWalkK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, const int *, const TileTask *, int *, int *, int *, TileCount *,
+                           unsigned int *);
+struct TileKernels {
+    TileInteractK interact[2][2];       // [sources can re-absorb][modified random walk]
+    TileEmitK emit, emit_simple;        // emit_simple: point sources with tabulated / blackbody spectra only
+    TileDrainK drain[2][2];
+    TileDrainK prepare;                 // unsplit schedule (Cartesian only), else null
+    TileWalkK walk;
+    size_t hot_bytes, cold_bytes;
+    int walk_threads;
+    int bx, by, bz;                     // Cartesian: brick shape; LDS of the walk = walls + 2 x 8 B x bx by bz nd
+    int nd;
+};
+template <int GEOM> TileKernels pick_tile_kernels_g(int nd);      // .walk == nullptr: no tiled schedule for this geometry

@@ -260,7 +260,8 @@ hid_t put_dataset(hid_t loc, const char *name, const std::vector<hsize_t> &dims,
         // one chunk per slowest index keeps chunks below HDF5's 4 GiB limit for any grid this engine can hold
         std::vector<hsize_t> ch(dims);
         size_t bytes = n * 8;
-        for (size_t k = 0; k < ch.size() && bytes > (1u << 30); k++) { bytes /= (size_t)ch[k]; ch[k] = 1; }
+        // (a few MB at most: a deflated chunk larger than HDF5's chunk cache is compressed and written in one piece)
+        for (size_t k = 0; k < ch.size() && bytes > (4u << 20); k++) { bytes /= (size_t)ch[k]; ch[k] = 1; }
         H5Pset_chunk(pl, (int)ch.size(), ch.data());
         H5Pset_deflate(pl, 4);
     }
@@ -953,10 +954,15 @@ int run(const char *input, const char *output, bool overwrite)
     if (access(input, R_OK) != 0) throw Fail(fmt("File does not exist: %s", input));
     if (access(output, F_OK) == 0) {
         if (!overwrite) throw Fail(fmt("Output file %s already exists (use -f)", output));
-        unlink(output);
+        char *ai = realpath(input, nullptr), *ao = realpath(output, nullptr);
+        const bool same = ai && ao && strcmp(ai, ao) == 0;
+        free(ai); free(ao);
+        if (same) throw Fail("input and output are the same file");
     }
+    // the input is read and validated BEFORE an existing output is removed: a bad .rtin must not cost the previous result
     Input in;
     read_rtin(input, in);
+    if (access(output, F_OK) == 0) unlink(output);
     const hyp_config &cfg = in.P.config;
 
     // the output exists from the start, date_ended is written last: its presence marks success (main.f90:130-136,338-344)
@@ -982,7 +988,13 @@ int run(const char *input, const char *output, bool overwrite)
     H5Fflush(fo, H5F_SCOPE_GLOBAL);
 
     hyp_handle h = nullptr;
-    if (hyp_create(&in.P, 0, &h) != 0) { const char *m = hyp_last_error(nullptr); throw Fail(m && *m ? m : "hyp_create failed"); }
+    // one process per GPU: HYP_DEVICE, else the launcher's local rank (torchrun / Open MPI / Slurm), else device 0
+    int device = 0;
+    for (const char *name : {"HYP_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}) {
+        const char *v = getenv(name);
+        if (v && *v) { device = atoi(v); break; }
+    }
+    if (hyp_create(&in.P, device, &h) != 0) { const char *m = hyp_last_error(nullptr); throw Fail(m && *m ? m : "hyp_create failed"); }
     printf(" [main] using random seed = %lld\n", (long long)cfg.seed);
     const size_t plane = (size_t)in.P.n_dust * in.n_cells;
     const int pkind = in.physics_io_bytes == 4 ? 4 : 8;
@@ -998,6 +1010,11 @@ int run(const char *input, const char *output, bool overwrite)
         std::vector<double> se(plane);
         hyp_iter_stats st;
         check(hyp_lucy_iteration(h, (uint64_t)in.n_initial_photons, (int)it, se.data(), &st), h);
+        if (cfg.count_photons) {
+            int64_t inexact = 0;
+            if (hyp_get_option(h, "n_photons_inexact", &inexact) == 0 && inexact)
+                printf(" [main] WARNING: n_photons of iteration %lld is an upper bound (a packet overflowed its visited-cell set)\n", it);
+        }
         printf(" [main] exiting Lucy iteration\n");
         rec.killed_geo = st.killed_geo; rec.killed_int = st.killed_int;
         if (in.check_convergence) {     // specific_energy_converged: grid_physics_3d.f90:637-689

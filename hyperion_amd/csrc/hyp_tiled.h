@@ -87,7 +87,9 @@ struct TileCtl {
     // split schedule: slots that need an interaction but sit in no task's list (a packet that drew a zero optical
     // depth); two lists per pool, filled and emptied in alternate generations
     unsigned int n_extra[HYP_TILE_MAX_POOLS][2];
-    unsigned int n_extra_dead[HYP_TILE_MAX_POOLS]; // ... and the slots freed while working through that list
+    // slots that wait for an interaction / are free, listed by the walk of the previous generation (and by tile_interact for
+    // the packets it ends): counters by generation parity, see tile_walk_publish_lists
+    unsigned int n_gil[HYP_TILE_MAX_POOLS][2], n_gdl[HYP_TILE_MAX_POOLS][2];
     unsigned long long dbg[40];                   // debug builds only
 };
 
@@ -105,7 +107,7 @@ struct TileGeom {
 // per task of the current generation: how many of its packets ended the visit waiting for an interaction
 // (or a re-emission by a source) and how many slots it left free
 struct TileCount { int n_int, n_dead; };
-#define HYP_TILE_EXTRA 8192       // capacity of each per-pool list behind TileCtl::n_extra; layout [list 0][list 1][freed slots]
+#define HYP_TILE_EXTRA 1024       // capacity of each per-pool list behind TileCtl::n_extra; layout [list 0][list 1][freed slots]
 
 struct TileTask { int brick, start, len, pad; };
 
@@ -116,6 +118,37 @@ __device__ __forceinline__ int brick_of(const TileGeom &T, const int ic[3])
 {
     return ((ic[2] / T.bz) * T.nby + (ic[1] / T.by)) * T.nbx + (ic[0] / T.bx);
 }
+
+// How a packet's cell is kept in its slot record, and which brick (Cartesian) or cluster of cells (Voronoi, hyp_vtile.h)
+// it belongs to.  The interaction / emission / drain kernels below are shared by the geometries through this.
+template <int GEOM> struct TileCellIO;
+template <> struct TileCellIO<GEOM_CAR> {
+    template <int ND> static __device__ __forceinline__ void load(const HotRec<ND> &H, Cell<GEOM_CAR> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) c.ic[a] = H.ic[a];
+        unpack_ow(H.ow, c.ow);
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_CAR> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) H.ic[a] = c.ic[a];
+        H.ow = pack_ow(c.ow);
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_CAR> &c) { return brick_of(T, c.ic); }
+};
+// Voronoi: ic = (cell, the cell the packet came from or -1, cluster << 8 | index of the cell in its cluster)
+template <> struct TileCellIO<GEOM_VOR> {
+    template <int ND> static __device__ __forceinline__ void load(const HotRec<ND> &H, Cell<GEOM_VOR> &c)
+    {
+        c.id = H.ic[0]; c.ow[0] = 0; c.ow[1] = -(H.ic[1] + 1); c.ow[2] = 0;
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_VOR> &c)
+    {
+        H.ic[0] = c.id; H.ic[1] = -c.ow[1] - 1; H.ic[2] = P.vt_cluster[c.id]; H.ow = 0;
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 8; }
+};
 
 // ---------------------------------------------------------------------------
 // tile_prepare: interactions and (re-)emission, one lane per slot; writes the
@@ -131,10 +164,12 @@ __device__ __forceinline__ int brick_of(const TileGeom &T, const int ic[3])
 #endif
 template <int ND>
 __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-                                                         HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
+                                                         void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                          int *__restrict__ slot_brick)
 {
     extern __shared__ double lds[];
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
     Walls W;
     stage_walls<GEOM_CAR>(P, lds, W);
@@ -310,13 +345,20 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const
 }
 
 // ---------------------------------------------------------------------------
-// Split schedule (T.split): tile_walk leaves, per task, a list of the slots whose packets wait
-// for an interaction (or for re-emission by a source that absorbed them) and a list of the slots
-// it freed, and adds the packets that move on to the brick histogram itself.  tile_interact and
-// tile_emit work through these lists with one workgroup per task -- full waves of one kind of
-// work, no scan over slot_brick[], and each kernel only carries the registers of its own phase --
-// and add the bricks of the packets they hand to the next walk to the histogram, so that the
-// counting pass of the sort is gone.
+// Split schedule (T.split): every task of tile_walk collects the slots whose packets wait for an
+// interaction (or for re-emission by a source that absorbed them) and the slots it freed, appends
+// both to the pool's two lists with ONE reservation per task (tile_walk_publish_lists), and adds the
+// packets that move on to the brick histogram itself.  tile_interact and tile_emit work through the
+// lists in full chunks -- full waves of one kind of work, no scan over slot_brick[], no nearly
+// empty per-task workgroups, and each kernel only carries the registers of its own phase -- and
+// add the bricks of the packets they hand to the next walk to the histogram, so that the counting
+// pass of the sort is gone.
+//
+// Lists: ilist / dlist hold n_slots staging entries (a task's own range [start, start + len)) followed
+// by n_slots entries of the pool-wide list.  Counters TileCtl::n_gil / n_gdl by parity: the walk of
+// generation g adds to [g & 1]; tile_interact / tile_emit of generation g + 1 read [g & 1] (and
+// tile_interact appends the slots of the packets it ends to the free list it is about to hand to
+// tile_emit); tile_scan of generation g, which runs between them and the walk, clears [g & 1].
 // ---------------------------------------------------------------------------
 
 // The tallies of a workgroup go to the global tail through LDS: one set of (same-address) global atomics per
@@ -378,13 +420,13 @@ __device__ __forceinline__ void flush_bricks(unsigned int *__restrict__ counts, 
     if (threadIdx.x < TILE_BCACHE && cache_b[threadIdx.x] >= 0 && cache_n[threadIdx.x]) atomicAdd(&counts[cache_b[threadIdx.x]], cache_n[threadIdx.x]);
 }
 
-template <int ND>
-__device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, ColdRec<ND> &C, const Packet<ND, GEOM_CAR> &p, const Rng &g,
+template <int ND, int GEOM>
+__device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, ColdRec<ND> &C, const Packet<ND, GEOM> &p, const Rng &g,
                                               unsigned long long id, int state)
 {
 #pragma unroll
-    for (int a = 0; a < 3; a++) { H.r[a] = p.r[a]; H.v[a] = p.v[a]; H.ic[a] = p.cell.ic[a]; }
-    H.ow = pack_ow(p.cell.ow);
+    for (int a = 0; a < 3; a++) { H.r[a] = p.r[a]; H.v[a] = p.v[a]; }
+    TileCellIO<GEOM>::store(P, H, p.cell);
     H.tau_req = p.tau_req; H.tau_ach = p.tau_ach; H.energy = p.energy;
 #pragma unroll
     for (int d = 0; d < ND; d++) { H.chi[d] = p.chi[d]; H.kappa[d] = p.kappa[d]; C.albedo[d] = p.albedo[d]; }
@@ -394,19 +436,17 @@ __device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, 
     if (P.any_intersect) { C.t_src = p.t_src; C.t_ach = p.t_ach; C.reabs_id = p.reabs_id; C.reabs = p.reabs; }
 }
 
-// generation 0 of the split schedule: every slot is free; pseudo-tasks of task_size slots list them for tile_emit
-__global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileCtl *__restrict__ ctl, TileTask *__restrict__ tasks,
+// generation 0 of the split schedule: every slot is free and listed for tile_emit
+static __global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileCtl *__restrict__ ctl, TileTask *__restrict__ tasks,
                                                         TileCount *__restrict__ tcount, int *__restrict__ dlist)
 {
-    const int n_tasks = (T.n_slots + T.task_size - 1) / T.task_size;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T.n_slots) dlist[i] = i;
-    if (i < n_tasks) {
-        TileTask tk; tk.brick = -1; tk.start = i * T.task_size; tk.len = min(T.task_size, T.n_slots - tk.start); tk.pad = 0;
-        tasks[i] = tk;
-        TileCount c; c.n_int = 0; c.n_dead = tk.len; tcount[i] = c;
+    if (i < T.n_slots) dlist[T.n_slots + i] = i;
+    if (i == 0) {
+        ctl->n_tasks[T.pool] = 0; ctl->n_extra[T.pool][0] = ctl->n_extra[T.pool][1] = 0;
+        ctl->n_gil[T.pool][0] = ctl->n_gil[T.pool][1] = 0;
+        ctl->n_gdl[T.pool][0] = 0; ctl->n_gdl[T.pool][1] = (unsigned int)T.n_slots;      // read by the emission of generation 0
     }
-    if (i == 0) { ctl->n_tasks[T.pool] = (unsigned int)n_tasks; ctl->n_extra[T.pool][0] = ctl->n_extra[T.pool][1] = 0; ctl->n_extra_dead[T.pool] = 0; }
 }
 
 #ifndef HYP_INTERACT_WAVES
@@ -415,42 +455,49 @@ __global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileCtl *__r
 #ifndef HYP_EMIT_WAVES
 #define HYP_EMIT_WAVES 2
 #endif
-#ifndef HYP_LIST_SPLIT
-#define HYP_LIST_SPLIT 1            // workgroups per task in tile_interact / tile_emit (chunks of the task's list round-robin)
+#ifndef HYP_EMIT_WAVES_SIMPLE
+#define HYP_EMIT_WAVES_SIMPLE 4
 #endif
+// end of a walk task: its two lists (staged in the task's own range) go to the pool-wide lists, one reservation each
+__device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileCtl *__restrict__ ctl, const TileTask &tk, int *__restrict__ ilist,
+                                                        int *__restrict__ dlist, int n_int, int n_dead, int *base /* 2 ints of LDS */)
+{
+    if (threadIdx.x == 0) base[0] = n_int ? (int)atomicAdd(&ctl->n_gil[T.pool][T.gen & 1], (unsigned int)n_int) : 0;
+    if (threadIdx.x == 64) base[1] = n_dead ? (int)atomicAdd(&ctl->n_gdl[T.pool][T.gen & 1], (unsigned int)n_dead) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_int; i += blockDim.x) ilist[T.n_slots + base[0] + i] = ilist[tk.start + i];
+    for (int i = threadIdx.x; i < n_dead; i += blockDim.x) dlist[T.n_slots + base[1] + i] = dlist[tk.start + i];
+}
 #define HYP_INTERACT_CHUNK 1024     // list entries that tile_interact orders by kind at a time
 
 // REABS: the problem has sources that can absorb packets (P.any_intersect), so slots may wait for a re-emission;
 // MRW: the modified random walk is on (P.mrw).  Without them that code stays out of this kernel.
-template <int ND, bool REABS, bool MRW>
+template <int ND, bool REABS, bool MRW, int GEOM>
 __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-        HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold, int *__restrict__ slot_brick,
+        void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick,
         const TileTask *__restrict__ tasks, const int *__restrict__ ilist, int *__restrict__ dlist, TileCount *__restrict__ tcount,
         unsigned int *__restrict__ counts, int *__restrict__ extra)
 {
     extern __shared__ double lds[];
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     constexpr int CH = HYP_INTERACT_CHUNK;
     const DProblem &P = *Pp;
-    const unsigned int n_tasks = ctl->n_tasks[T.pool];
-    const unsigned int task = blockIdx.x / HYP_LIST_SPLIT;
-    const int part = (int)(blockIdx.x % HYP_LIST_SPLIT);
-    // the first workgroup after the last task takes the slots that are in no task's list (TileCtl::n_extra)
-    const bool is_extra = task == n_tasks;
-    if (task > n_tasks || (is_extra && part != 0)) return;
-    const int par = T.gen & 1;
-    int start = 0, n_int = 0;
+    // the last workgroup takes the slots that are in neither list (TileCtl::n_extra); the others one chunk of the list each
+    const bool is_extra = blockIdx.x == gridDim.x - 1;
+    const int par = T.gen & 1, rp = (T.gen + 1) & 1;
+    int n_int = 0;
     if (is_extra) n_int = (int)min(ctl->n_extra[T.pool][par], (unsigned int)HYP_TILE_EXTRA);
-    else { start = tasks[task].start; n_int = tcount[task].n_int; }
-    if (n_int <= part * CH) {
-        if (is_extra && threadIdx.x == 0) ctl->n_extra_dead[T.pool] = 0;
-        return;
-    }
-    const int *list = is_extra ? extra + par * HYP_TILE_EXTRA : ilist + start;
+    else n_int = (int)ctl->n_gil[T.pool][rp] - (int)blockIdx.x * CH;
+    if (n_int <= 0) return;
+    if (n_int > CH) n_int = CH;
+    const int *list = is_extra ? extra + par * HYP_TILE_EXTRA : ilist + T.n_slots + (size_t)blockIdx.x * CH;
     int *extra_next = extra + (par ^ 1) * HYP_TILE_EXTRA;
     Walls W;
-    stage_walls<GEOM_CAR>(P, lds, W);
+    stage_walls<GEOM>(P, lds, W);
     __shared__ int sorted[CH];
-    __shared__ int n_dead_x, n_abs, n_oth;
+    __shared__ int n_dead_x, n_abs, n_oth, dead_base;
+    __shared__ int dead_l[CH];
     __shared__ double red[TILE_RED_N];
     __shared__ int cache_b[TILE_BCACHE];
     __shared__ unsigned int cache_n[TILE_BCACHE];
@@ -461,7 +508,8 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
     const int nd = ndust<ND>(P);
-    for (int c0 = part * CH; c0 < n_int; c0 += HYP_LIST_SPLIT * CH) {
+    {
+        const int c0 = 0;
         // Absorption + re-emission and scattering are two long, different code paths (dust_interact.f90:49-70); which one
         // a packet takes is decided by the first one or two numbers of its random stream.  Draw them ahead on a copy of
         // the stream and order the chunk by the outcome, so that the waves below run one path each.
@@ -481,7 +529,8 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
                 g2.blk_a = C.blk_a; g2.buf_a = C.buf_a; g2.have_a = C.have_a; g2.blk_b = 0; g2.countdown = 0;
                 double albedo = C.albedo[0];
                 if (ND > 1 && nd > 1) {        // select_dust_chi_rho, as in interact()
-                    const size_t base = (((size_t)H.ic[2] * P.n2 + H.ic[1]) * P.n1 + H.ic[0]) * (size_t)nd;
+                    Cell<GEOM> hc; TileCellIO<GEOM>::load(H, hc);
+                    const size_t base = geo_index(P, hc) * (size_t)nd;
                     double cdf[ND], c = 0.0;
 #pragma unroll
                     for (int d = 0; d < ND; d++) { if (d < nd) c += H.chi[d] * P.density[base + d]; cdf[d] = c; }
@@ -505,7 +554,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         const bool valid = k < na || (k >= oth0 && k < nl);
         const int slot = !valid ? 0 : k < na ? sorted[k] : sorted[CH - 1 - (k - oth0)];
         int state = TS_DONE;
-        Packet<ND, GEOM_CAR> p;
+        Packet<ND, GEOM> p;
         Rng g;
         unsigned long long id = 0;
         p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
@@ -514,8 +563,8 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             const ColdRec<ND> &C = cold[slot];
             state = H.state;
 #pragma unroll
-            for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; p.cell.ic[a] = H.ic[a]; }
-            unpack_ow(H.ow, p.cell.ow);
+            for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
+            TileCellIO<GEOM>::load(H, p.cell);
             p.a = C.a;
             p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
             p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
@@ -534,7 +583,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if ((long long)reabs == P.n_reabs_max) { cnt.killed_int++; state = TS_DEAD; finished++; }
             else {
                 int source_id; Angle src_normal;
-                bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                bool ok = emit_packet<ND, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
                 p.inter = inter; p.reabs = reabs + 1;
                 if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
                 else {
@@ -551,11 +600,11 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
 #ifdef HYP_ABLATE_INTERACT   // timing experiment (wrong results): the kernel without the physics
                 bool ok = true; scattered = 1; dust_id = 0; cnt.interactions++;
 #else
-                bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
+                bool ok = interact<ND, GEOM>(P, p, g, cnt, scattered, dust_id);
 #endif
                 bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                 if (killed) { state = TS_DEAD; finished++; }
-                else if (MRW && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
+                else if (MRW && mrw_loop_lucy<ND, GEOM>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
                 else {
                     p.inter++;
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -567,8 +616,8 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         int brick = 0;
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
-                store_records<ND>(P, hot[slot], cold[slot], p, g, id, state);
-                if (state == TS_WALK) { brick = brick_of(T, p.cell.ic); slot_brick[slot] = brick; }
+                store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
+                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts again
                     slot_brick[slot] = TILE_NEEDS_INTERACT;
@@ -577,41 +626,44 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
                 }
             } else {        // the packet ended here: the slot is free for tile_emit
                 hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
-                if (is_extra) extra[2 * HYP_TILE_EXTRA + atomicAdd(&n_dead_x, 1)] = slot;
-                else dlist[start + atomicAdd(&tcount[task].n_dead, 1)] = slot;
+                dead_l[atomicAdd(&n_dead_x, 1)] = slot;
             }
         }
         count_bricks(counts, cache_b, cache_n, valid && state == TS_WALK, brick);
     }
     }
     __syncthreads();
-    if (is_extra && threadIdx.x == 0) { ctl->n_extra[T.pool][par] = 0; ctl->n_extra_dead[T.pool] = (unsigned int)n_dead_x; }
+    if (is_extra && threadIdx.x == 0) ctl->n_extra[T.pool][par] = 0;
+    // the slots of the packets that ended here join the free list tile_emit is about to work through
+    if (threadIdx.x == 0) dead_base = n_dead_x ? (int)atomicAdd(&ctl->n_gdl[T.pool][rp], (unsigned int)n_dead_x) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_dead_x; i += (int)blockDim.x) dlist[T.n_slots + dead_base + i] = dead_l[i];
     flush_bricks(counts, cache_b, cache_n);
     block_tally_flush(P, ctl, red, cnt, finished);
 }
 
-template <int ND>
-__global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-        HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold, int *__restrict__ slot_brick,
+// SIMPLE: every source is a point source with a tabulated or blackbody spectrum (emit_packet<.., SIMPLE>): the other
+// emitters stay out of the kernel and its register budget allows twice the waves
+template <int ND, int GEOM, bool SIMPLE>
+__global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVES) void tile_emit_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+        void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick,
         const TileTask *__restrict__ tasks, const int *__restrict__ dlist, const TileCount *__restrict__ tcount,
         unsigned int *__restrict__ counts, int *__restrict__ extra)
 {
     extern __shared__ double lds[];
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
-    const unsigned int n_tasks = ctl->n_tasks[T.pool];
-    const unsigned int task = blockIdx.x / HYP_LIST_SPLIT;
-    const int part = (int)(blockIdx.x % HYP_LIST_SPLIT);
-    const bool is_extra = task == n_tasks;        // slots freed by tile_interact's extra workgroup
-    if (task > n_tasks || (is_extra && part != 0)) return;
-    int start = 0, n_dead = 0;
-    if (is_extra) n_dead = (int)ctl->n_extra_dead[T.pool];
-    else { start = tasks[task].start; n_dead = tcount[task].n_dead; }
-    if (n_dead <= part * 256) return;
-    const int *list = is_extra ? extra + 2 * HYP_TILE_EXTRA : dlist + start;
-    const int par = T.gen & 1;
+    // one chunk of 256 entries of the pool's free list per workgroup
+    const int par = T.gen & 1, rp = (T.gen + 1) & 1;
+    const int part = 0;
+    int n_dead = (int)ctl->n_gdl[T.pool][rp] - (int)blockIdx.x * 256;
+    if (n_dead <= 0) return;
+    if (n_dead > 256) n_dead = 256;
+    const int *list = dlist + T.n_slots + (size_t)blockIdx.x * 256;
     int *extra_next = extra + (par ^ 1) * HYP_TILE_EXTRA;
     Walls W;
-    stage_walls<GEOM_CAR>(P, lds, W);
+    stage_walls<GEOM>(P, lds, W);
     __shared__ double red[TILE_RED_N];
     __shared__ int cache_b[TILE_BCACHE];
     __shared__ unsigned int cache_n[TILE_BCACHE];
@@ -622,7 +674,7 @@ __global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DP
     // chip); only packets that end at once (emitted outside the grid) go back to it, a wave at a time
     if (threadIdx.x == 0) {
         int mine = 0;
-        for (int c0 = part * 256; c0 < n_dead; c0 += HYP_LIST_SPLIT * 256) mine += min(256, n_dead - c0);
+        for (int c0 = part * 256; c0 < n_dead; c0 += 256) mine += min(256, n_dead - c0);
         id_base = atomicAdd(&ctl->next_id, (unsigned long long)mine);
     }
     __syncthreads();
@@ -631,12 +683,12 @@ __global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DP
     unsigned int finished = 0;
     const unsigned long long end_id = ctl->end_id;
     int done_before = 0;
-    for (int c0 = part * 256; c0 < n_dead; c0 += HYP_LIST_SPLIT * 256) {
+    for (int c0 = part * 256; c0 < n_dead; c0 += 256) {
         const int k = c0 + (int)threadIdx.x;
         const bool valid = k < n_dead;
         const int slot = valid ? list[k] : 0;
         int state = valid ? TS_DEAD : TS_DONE;
-        Packet<ND, GEOM_CAR> p;
+        Packet<ND, GEOM> p;
         Rng g;
         unsigned long long id = 0;
         p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
@@ -658,7 +710,7 @@ __global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DP
                 else {
                     rng_init(g, P.seed_key, T.iter_tag, id);
                     int source_id; Angle src_normal;
-                    bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal);
+                    bool ok = emit_packet<ND, GEOM, SIMPLE>(P, W, p, g, cnt, source_id, src_normal);
                     if (!ok || geo_escaped(P, p.cell)) finished++;
                     else {
                         p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -672,8 +724,8 @@ __global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DP
         int brick = 0;
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
-                store_records<ND>(P, hot[slot], cold[slot], p, g, id, state);
-                if (state == TS_WALK) { brick = brick_of(T, p.cell.ic); slot_brick[slot] = brick; }
+                store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
+                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts
                     slot_brick[slot] = TILE_NEEDS_INTERACT;
@@ -695,15 +747,17 @@ __global__ __launch_bounds__(256, HYP_EMIT_WAVES) void tile_emit_kernel(const DP
 // steps).  This kernel takes every remaining packet to its end in one launch, one lane
 // per packet, with the persistent kernel's walk_step (global atomics).
 // ---------------------------------------------------------------------------
-template <int ND, bool REABS, bool MRW>
+template <int ND, bool REABS, bool MRW, int GEOM>
 __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-                                                                       HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
+                                                                       void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                                        int *__restrict__ slot_brick)
 {
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
     Walls W;
-    stage_walls<GEOM_CAR>(P, lds, W);
+    stage_walls<GEOM>(P, lds, W);
     double *sum = P.sum;
     if (P.n_copies > 1) {
         unsigned c = xcc_id();
@@ -730,15 +784,15 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
         for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
             const int k = k0 + (int)threadIdx.x;
             int st = ST_DONE, slot = 0;
-            Packet<ND, GEOM_CAR> p;
+            Packet<ND, GEOM> p;
             Rng g;
             if (k < nl) {
                 slot = list[k];
                 const HotRec<ND> &H = hot[slot];
                 const ColdRec<ND> &C = cold[slot];
 #pragma unroll
-                for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; p.cell.ic[a] = H.ic[a]; }
-                unpack_ow(H.ow, p.cell.ow);
+                for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
+                TileCellIO<GEOM>::load(H, p.cell);
                 p.a = C.a;
                 p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
                 p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
@@ -768,7 +822,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                             const int inter = p.inter, reabs = p.reabs + 1, rid = p.reabs_id;
                             const double e = p.energy;
                             int source_id; Angle src_normal;
-                            bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                            bool ok = emit_packet<ND, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
                             p.inter = inter; p.reabs = reabs;
                             if (!ok || geo_escaped(P, p.cell)) { st = ST_DONE; finished++; }
                             else {
@@ -787,10 +841,10 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                         if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; st = ST_DONE; finished++; }
                         else {
                             int scattered, dust_id;
-                            bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
+                            bool ok = interact<ND, GEOM>(P, p, g, cnt, scattered, dust_id);
                             bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                             if (killed) { st = ST_DONE; finished++; }
-                            else if (MRW && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, sum, cnt)) { st = ST_DONE; finished++; }
+                            else if (MRW && mrw_loop_lucy<ND, GEOM>(P, W, p, g, sum, cnt)) { st = ST_DONE; finished++; }
                             else {
                                 p.inter++;
                                 p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -803,7 +857,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
 #pragma unroll 1
                 for (int q = 0; q < 4; q++) {
                     if (st == ST_WALK) {
-                        st = walk_step<ND, GEOM_CAR, true>(P, W, p, g, sum, cnt);
+                        st = walk_step<ND, GEOM, true>(P, W, p, g, sum, cnt);
                         if (st == ST_NEED_EMIT) { st = ST_DONE; finished++; }
                     }
                 }
@@ -834,7 +888,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
 #define HYP_SORT_PER_THREAD 32
 #endif
 
-__global__ __launch_bounds__(256) void tile_count_kernel(TileGeom T, const int *__restrict__ slot_brick, unsigned int *__restrict__ counts)
+static __global__ __launch_bounds__(256) void tile_count_kernel(TileGeom T, const int *__restrict__ slot_brick, unsigned int *__restrict__ counts)
 {
     __shared__ unsigned int hist[HYP_TILE_MAX_BRICKS];
     for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x) hist[b] = 0;
@@ -849,7 +903,7 @@ __global__ __launch_bounds__(256) void tile_count_kernel(TileGeom T, const int *
 }
 
 // exclusive scan of the brick counts, task list, reset of the cursors
-__global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned int *__restrict__ counts, unsigned int *__restrict__ offsets,
+static __global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned int *__restrict__ counts, unsigned int *__restrict__ offsets,
                                                         unsigned int *__restrict__ cursor, TileTask *__restrict__ tasks,
                                                         TileCtl *__restrict__ ctl)
 {
@@ -864,6 +918,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned in
         unsigned int ac = 0, at = 0;
         for (int i = 0; i < 1024; i++) { unsigned int c = part_c[i], t = part_t[i]; part_c[i] = ac; part_t[i] = at; ac += c; at += t; }
         ctl->n_tasks[T.pool] = at;
+        ctl->n_gil[T.pool][T.gen & 1] = 0; ctl->n_gdl[T.pool][T.gen & 1] = 0;      // the walk of this generation fills them
     }
     __syncthreads();
     unsigned int oc = part_c[threadIdx.x], ot = part_t[threadIdx.x];
@@ -879,7 +934,7 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned in
     }
 }
 
-__global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int *__restrict__ slot_brick, const unsigned int *__restrict__ offsets,
+static __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int *__restrict__ slot_brick, const unsigned int *__restrict__ offsets,
                                                           unsigned int *__restrict__ cursor, int *__restrict__ order)
 {
     __shared__ unsigned int hist[HYP_TILE_MAX_BRICKS];
@@ -903,6 +958,18 @@ __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int
         if (br[k] >= 0) order[offsets[br[k]] + hist[br[k]] + rank[k]] = slot;
     }
 }
+
+// brick shape per number of species: density + accumulators (16 B per cell and
+// species) must leave room for two workgroups per CU in the 160 KB LDS
+#ifndef HYP_TILE_BX
+#define HYP_TILE_BX 16
+#define HYP_TILE_BY 16
+#define HYP_TILE_BZ 16
+#endif
+template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 64 KB
+template <> struct TileShape<2> { static constexpr int X = 16, Y = 16, Z = 8; };         // 64 KB
+template <> struct TileShape<3> { static constexpr int X = 16, Y = 8, Z = 8; };          // 48 KB
+template <> struct TileShape<4> { static constexpr int X = 16, Y = 8, Z = 8; };          // 64 KB
 
 // ---------------------------------------------------------------------------
 // tile_walk: one workgroup per task; density and accumulators of the brick in LDS
@@ -981,13 +1048,15 @@ enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK 
 
 template <int ND, int BX, int BY, int BZ>
 __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-                                                      HotRec<ND> *__restrict__ hot, ColdRec<ND> *__restrict__ cold,
+                                                      void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                       const int *__restrict__ order,
                                                       const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,
                                                       int *__restrict__ ilist, int *__restrict__ dlist,
                                                       TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
     extern __shared__ double lds[];
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
     if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
@@ -1003,7 +1072,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
     __shared__ int next_pkt;
     // split schedule: this task's lists of waiting / free slots and the bricks its packets move to
     // (index (dz+1)*9 + (dy+1)*3 + dx+1; 13 = packets parked in this brick)
-    __shared__ int n_int_l, n_dead_l;
+    __shared__ int n_int_l, n_dead_l, pub_base[2];
     __shared__ unsigned int nb_cnt[27];
     __shared__ double red[TILE_RED_N];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + TILE_RED_N) red[threadIdx.x - 64] = 0.0;
@@ -1229,7 +1298,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
             const int dx = (int)threadIdx.x % 3 - 1, dy = ((int)threadIdx.x / 3) % 3 - 1, dz = (int)threadIdx.x / 9 - 1;
             atomicAdd(&counts[tk.brick + dx + T.nbx * (dy + T.nby * dz)], nb_cnt[threadIdx.x]);
         }
-        if (threadIdx.x == 32) { TileCount c; c.n_int = n_int_l; c.n_dead = n_dead_l; tcount[blockIdx.x] = c; }
+        tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);
     }
     // flush the brick's accumulators (replica chosen like in the persistent kernel)
     double *sum = P.sum;

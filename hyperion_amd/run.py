@@ -129,6 +129,9 @@ def run_problem(problem: Problem, device=0, rank=0, world_size=1, log=None, engi
             rec.density = eng.density()
         if _want(cfg.output_density_diff, it, last):
             rec.density_diff = eng.density() - np.asarray(problem.density, dtype=np.float64).reshape(eng.shape)
+        if (cfg.pda or cfg.output_n_photons != "none") and eng.get_option("n_photons_inexact"):
+            # a packet visited more distinct cells than its visited set holds: from then on it was counted on every entry
+            log(" [main] WARNING: n_photons of iteration %d is an upper bound (a packet overflowed its visited-cell set)" % it)
         if _want(cfg.output_n_photons, it, last):
             rec.n_photons = eng.n_photons()
         if _want(cfg.output_specific_energy_spectrum, it, last):
@@ -326,10 +329,16 @@ def run(input_file, output_file=None, overwrite=False, logfile=None, device=None
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     main_process = rank == 0
+    # A refusal must reach every rank: rank 0 looks at the file, but nobody raises before the process group exists and the
+    # ranks have agreed (a rank 0 that left here would leave the others waiting in the rendezvous).
+    exists_msg = None
     if main_process and os.path.exists(output_file):
         if not overwrite:
-            raise SystemExit("Output file %s already exists (use -f / overwrite=True)" % output_file)
-        os.remove(output_file)
+            exists_msg = "Output file %s already exists (use -f / overwrite=True)" % output_file
+        elif world == 1:
+            os.remove(output_file)
+    if exists_msg is not None and world == 1:
+        raise SystemExit(exists_msg)
     flog = open(logfile, "w") if (logfile and main_process) else None
 
     def log(*a):
@@ -345,6 +354,12 @@ def run(input_file, output_file=None, overwrite=False, logfile=None, device=None
             torch.cuda.set_device(local_rank)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group("nccl", rank=rank, world_size=world)
+            refuse = torch.tensor([1 if exists_msg is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(refuse, op=dist.ReduceOp.MAX)
+            if int(refuse.item()):
+                raise SystemExit(exists_msg or "Output file %s already exists (use -f / overwrite=True)" % output_file)
+            if main_process and os.path.exists(output_file):
+                os.remove(output_file)
         try:
             if input_file.endswith(".npz"):
                 problem = Problem.from_npz(input_file)

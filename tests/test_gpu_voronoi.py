@@ -175,3 +175,72 @@ def test_full_size_voronoi_config5_properties():
     wc = car.density * car.volumes
     assert (se * wv).sum() == pytest.approx((sc * wc).sum(), rel=5e-3)
     assert st["crossings"] / n > 30
+
+
+# --- cluster-tiled Lucy iteration (hyp_vtile.h, lucy_mode=1): same packets, same answer ---------------------
+
+def run_tiled(prob, n, iters=1, **opts):
+    eng = hyperion_amd.Engine(prob)
+    eng.set_option("lucy_mode", 1)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    orc = Oracle(prob)
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        assert eng.get_option("last_lucy_mode") == 1
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+        assert_parity(a, b)
+        np.testing.assert_array_equal(a == 0, b == 0)
+    n_cl = eng.get_option("vt_clusters")
+    eng.close(); orc.close()
+    return a, sa, n_cl
+
+
+def test_vtile_config5_small_many_clusters():
+    """configs[4] in small (400 cells, two polarising species, point + external box source) through the cluster-tiled
+    schedule with clusters of 16 cells: packets change cluster every few crossings; slot pools far smaller than the
+    packet count, generations all the way down (no drain launch), one pool and three."""
+    prob, _ = golden_problem("vor_config5.npz")
+    a, st, n_cl = run_tiled(prob, 60000, iters=2, vt_cells=16, tile_slots=8192, tile_task=512, tile_drain=0, tile_poll=1)
+    assert n_cl == 25 and st["killed_geo"] == 0
+    run_tiled(prob, 60000, vt_cells=40, tile_slots=24576, tile_pools=3, tile_task=256, tile_drain=0)
+    run_tiled(prob, 60000, vt_cells=7, tile_slots=16384, tile_pools=2, tile_drain=500)
+    run_tiled(prob, 60000)          # default cluster size: the whole grid is two clusters
+
+
+def test_vtile_lattice_ties():
+    """A (jittered) lattice tessellation: packets from the central source run along cell edges and through vertices,
+    where several bisector planes are hit at once -- the guard band of the division-free wall search hands those steps
+    to the reference's loop."""
+    pv, _ = golden_problem("vor_lattice.npz")
+    run_tiled(pv, 200000, vt_cells=12, tile_slots=32768, tile_drain=0)
+
+
+def test_vtile_spherical_source_reabsorption():
+    """Packets re-absorbed by a stellar sphere (LS_REABS) on the tiled Voronoi schedule."""
+    prob, _ = golden_problem("vor_config5.npz")
+    prob.sources = [Source(type="sphere", luminosity=LSUN, temperature=5000.0, position=(0.05 * PC, -0.02 * PC, 0.03 * PC), radius=0.08 * PC)]
+    run_tiled(prob, 40000, vt_cells=16, tile_slots=8192, tile_drain=100)
+
+
+def test_vtile_matches_persistent_at_scale():
+    """The real 100 000-site tessellation at 2e6 packets: both GPU schedules walk the same packets; integer tallies
+    equal, sums equal to rounding; the tiled one is what lucy_mode -1 picks at this size."""
+    from cases import voronoi_big_problem
+    prob = voronoi_big_problem(n_photons=2_000_000)
+    res = []
+    for mode in (0, -1):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("lucy_mode", mode)
+        res.append(eng.lucy_iteration(2_000_000, 1))
+        assert eng.get_option("last_lucy_mode") == (0 if mode == 0 else 1)
+        if mode:
+            assert eng.get_option("vt_clusters") > 500 and eng.get_option("vt_max_cells") <= 256
+        eng.close()
+    (a, sa), (b, sb) = res
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert_parity(a, b)
