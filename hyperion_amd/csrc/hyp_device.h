@@ -101,7 +101,7 @@ struct alignas(32) VtHdr { double x, y, z; int k0, k1; };
 #define VT_MAX_ADJ 64           // adjacent clusters listed per cluster (walls to further ones: VT_FAR)
 #define VT_FAR (-(VT_MAX_ADJ) - 2)
 
-struct OctCell {
+struct alignas(16) OctCell {
     double x, y, z;
     int parent;              // -1 for the root
     signed char subcell;     // position inside the parent, bit0 = x, bit1 = y, bit2 = z
@@ -160,6 +160,13 @@ struct DProblem {
     const VtHdr *vt_hdr;                  // [n_cells] cluster by cluster
     const VorWall *vt_walls;              // wall records, cluster by cluster, `loc` filled in
     const int *vt_adj;                    // [n_clusters][VT_MAX_ADJ] adjacent clusters (-1: unused)
+    // cluster-tiled octree schedule (hyp_otile.h): clusters = runs of sibling subtrees (contiguous cell ids) whose records fit in LDS
+    const int *ot_cluster;                // [n_cells] cluster of the cell (-1: a cell above the clusters, never a leaf)
+    const int *ot_c0, *ot_nc;             // [n_clusters] first cell id and number of cells
+    const int *ot_kid_off;                // [n_clusters + 1] first row of the cluster in ot_kid
+    const OctCell *ot_rec;                // [n_cells] oct_cells with `parent` replaced by the cell's row in its cluster's ot_kid slice (refined cells)
+    const short *ot_kid;                  // [rows][8] children of the refined cells of a cluster as indices inside the cluster
+    const short *ot_nb;                   // [n_cells][6] oct_neigh as an index inside the cell's cluster; -1: outside the grid, -2: in another cluster
     const AmrGrid *amr_grids;             // amr: [n_amr_grids], level by level
     const int *amr_go;                    // goto tables of all grids
     const double *amr_walls;              // wall arrays of all grids

@@ -227,6 +227,8 @@ struct hyp_engine {
     int *d_ilist = nullptr, *d_dlist = nullptr, *d_extra = nullptr;     // split schedule: per-task work lists
     TileCount *d_tcount = nullptr;
     int tile_split = 1;
+    int tile_ring = 0;              // option: walk workgroups take their packets from an LDS ring fed by a loader wave (RecRing; tuning builds only)
+    int last_tile_ring = 0;
     // live timing of the dominant kernel (bench.py's roofline): HIP events around every tile_walk launch, on its own stream
     int tile_time_walk = 1;
     std::vector<hipEvent_t> walk_events;
@@ -248,6 +250,13 @@ struct hyp_engine {
     int *d_vt_cluster = nullptr, *d_vt_cell_off = nullptr, *d_vt_wall_off = nullptr, *d_vt_members = nullptr, *d_vt_adj = nullptr;
     VtHdr *d_vt_hdr = nullptr; VorWall *d_vt_walls = nullptr;
     std::vector<double> h_vor_sites; std::vector<int> h_vor_idx, h_vor_neigh;     // host copies for the cluster builder
+    // cluster-tiled octree schedule (hyp_otile.h): tables built by build_oct_clusters()
+    int ot_cells = 0;               // option: most cells per cluster (0: as many as the LDS budget allows)
+    int ot_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB (78: two workgroups per CU)
+    int ot_clusters = 0, ot_max_cells = 0, ot_max_kids = 0, ot_built_for = -1;
+    int *d_ot_cluster = nullptr, *d_ot_c0 = nullptr, *d_ot_nc = nullptr, *d_ot_kid_off = nullptr;
+    OctCell *d_ot_rec = nullptr; short *d_ot_kid = nullptr, *d_ot_nb = nullptr;
+    std::vector<OctCell> h_oct_cells; std::vector<int> h_oct_children, h_oct_neigh;      // host copies for the cluster builder
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
@@ -386,6 +395,7 @@ TileKernels pick_tile_kernels(int nd, int grid_type)
 #endif
     switch (grid_type) {
     case 1: return pick_tile_kernels_g<GEOM_CAR>(nd);
+    case 2: return pick_tile_kernels_g<GEOM_OCT>(nd);
     case 3: return pick_tile_kernels_g<GEOM_VOR>(nd);
     default: { TileKernels k; memset(&k, 0, sizeof k); return k; }
     }
@@ -408,11 +418,18 @@ int tile_bricks(const DProblem &P, int nd)
     return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
 }
 
+// LDS of one octree cluster (hyp_otile.h): n cells of which k are refined
+size_t oct_cluster_lds(size_t n, size_t k, int nd) { return (sizeof(OctCell) + sizeof(double) * 2 * nd + sizeof(short) * 6) * n + sizeof(short) * 8 * k + 16; }
+
 // LDS of one walk workgroup
-size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T)
+size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool ring)
 {
     if (h->hp.grid_type == 3)       // cluster: cell headers + wall records + densities + accumulators
         return sizeof(VtHdr) * (size_t)T.bx + sizeof(VorWall) * (size_t)T.by + sizeof(double) * 2 * (size_t)T.bx * K.nd;
+    if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
+        return oct_cluster_lds((size_t)T.bx, (size_t)T.by, K.nd);
+    if (ring)                       // the brick's own walls + brick + record ring (hyp_tiled.h: RecRing)
+        return sizeof(double) * (2 * ((size_t)K.bx + K.by + K.bz + 3) + 6) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd + HYP_RING_BYTES;
     return lds_bytes(h->hp) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd;
 }
 
@@ -420,7 +437,11 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
 {
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_int = lds_w;
-    const size_t lds_walk = tile_walk_lds(h, K, T0);
+    // record ring (one loader wave per walk workgroup) where the kernel has that form and two workgroups still fit a CU
+    const bool ring = h->tile_ring && K.walk_ring && tile_walk_lds(h, K, T0, true) <= 80 * 1024;
+    const TileWalkK walk_k = ring ? K.walk_ring : K.walk;
+    const size_t lds_walk = tile_walk_lds(h, K, T0, ring);
+    h->last_tile_ring = ring ? 1 : 0;
     const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * h->tile_prep_blocks);
     const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
     const int grid_w = T0.n_slots / T0.task_size + T0.n_bricks + 1;
@@ -428,7 +449,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
     // one per 256 free slots.  Workgroups beyond the lists' lengths (known on the device only) leave at once.
     const int grid_i = (T0.n_slots + HYP_INTERACT_CHUNK - 1) / HYP_INTERACT_CHUNK + 1;
     const int grid_e = (T0.n_slots + 255) / 256;
-    if (hipFuncSetAttribute((const void *)K.walk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
+    if (hipFuncSetAttribute((const void *)walk_k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_walk) != hipSuccess)
         return h->set_error("cannot reserve LDS for the tiled walk kernel");
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     const int ri = h->hp.any_intersect ? 1 : 0, mi = h->hp.mrw ? 1 : 0;
@@ -475,7 +496,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 }
                 (void)hipEventRecord(h->walk_events[n_timed], st);
             }
-            K.walk<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts);
+            walk_k<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
         if ((gen + 1) % h->tile_poll == 0 || gen > 200000) {
@@ -531,6 +552,8 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
         fprintf(stderr, "tile stats: generations %d, outer loops %llu, wave-steps %llu, lane-steps %llu (lane utilisation %.3f), waves %llu, "
                         "tasks %llu (mean %.0f packets), steps per outer loop %.2f\n", gen + 1, d[0], d[1], d[2], (double)d[2] / (64.0 * d[1]),
                 d[3], d[4], (double)d[5] / d[4], (double)d[1] / d[0]);
+        fprintf(stderr, "tile stats: service phases %llu (%.2f per outer loop), wave clocks in the service phase %.3f of the loop's (%.0f clocks per service phase, %.0f per outer loop)\n",
+                d[7], (double)d[7] / d[0], (double)d[6] / d[8], (double)d[6] / d[7], (double)d[8] / d[0]);
     }
 #endif
     return 0;
@@ -547,6 +570,9 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     if (P.grid_type == 3) {
         T.bx = h->vt_max_cells; T.by = h->vt_max_walls; T.bz = 1;
         T.nbx = T.n_bricks = h->vt_clusters; T.nby = T.nbz = 1;
+    } else if (P.grid_type == 2) {
+        T.bx = h->ot_max_cells; T.by = h->ot_max_kids; T.bz = 1;
+        T.nbx = T.n_bricks = h->ot_clusters; T.nby = T.nbz = 1;
     } else {
         tile_shape(nd, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
@@ -616,6 +642,7 @@ void hyp_destroy(hyp_handle h)
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children); free_dev(h->d_oct_neigh);
+    free_dev(h->d_ot_cluster); free_dev(h->d_ot_c0); free_dev(h->d_ot_nc); free_dev(h->d_ot_kid_off); free_dev(h->d_ot_rec); free_dev(h->d_ot_kid); free_dev(h->d_ot_nb);
     free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
     free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed); free_dev(h->d_vor_walls);
@@ -657,6 +684,7 @@ static int sync_problem(hyp_handle h);
 static int check_device_error(hyp_handle h);
 static int mrw_prepare(hyp_handle h);
 static int build_vor_clusters(hyp_handle h);
+static int build_oct_clusters(hyp_handle h);
 
 int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 {
@@ -1574,6 +1602,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMalloc(&h->d_oct_neigh, sizeof(int) * oct_neigh.size()));
         HIPC(hipMemcpy(h->d_oct_neigh, oct_neigh.data(), sizeof(int) * oct_neigh.size(), hipMemcpyHostToDevice));
         P.oct_cells = h->d_oct_cells; P.oct_children = h->d_oct_children; P.oct_neigh = h->d_oct_neigh;
+        h->h_oct_cells = oct_cells; h->h_oct_children = oct_children; h->h_oct_neigh = oct_neigh;
     }
     for (int d = 0; d < pr->n_dust; d++) {
         DDust &D = P.dust[d]; const DustOffsets &O = doff[d];
@@ -1907,6 +1936,91 @@ static int build_vor_clusters(hyp_handle h)
     return 0;
 }
 
+// Clusters of octree cells for the tiled schedule (hyp_otile.h).  Cells are numbered depth first
+// (grid_geometry_octree.f90:206-246), so a subtree is a contiguous range of ids and so is a run of consecutive siblings.
+// Top down: a subtree that fits the LDS budget is a unit; the children of one that does not are grouped, in order, into
+// runs that fit; the cells above the units belong to no cluster (they are refined, a packet is never in one of them).
+static int build_oct_clusters(hyp_handle h)
+{
+    const int nd = h->n_dust;
+    if (h->ot_built_for == nd && h->d_ot_cluster) return 0;
+    const size_t nc = h->n_cells;
+    const std::vector<OctCell> &C = h->h_oct_cells;
+    const std::vector<int> &CH = h->h_oct_children, &NB = h->h_oct_neigh;
+    if (C.size() != nc || NB.size() != 6 * nc) return h->set_error("octree tables missing for the cluster builder");
+    // subtree sizes (cells, refined cells): children have larger ids than their parent
+    std::vector<int> size(nc, 1), nref(nc, 0);
+    for (size_t i = nc; i-- > 0;) {
+        if (C[i].refined) nref[i] += 1;
+        if (i > 0) { size[C[i].parent] += size[i]; nref[C[i].parent] += nref[i]; }
+    }
+    const size_t budget = (size_t)h->ot_lds_kb * 1024;
+    const int cap = h->ot_cells > 0 ? h->ot_cells : 32767;
+    auto fits = [&](long long n, long long k) { return n <= cap && n <= 32767 && oct_cluster_lds((size_t)n, (size_t)k, nd) <= budget; };
+    std::vector<int> cl_of(nc, -1), c0v, ncv, kid_off{0};
+    auto emit = [&](int first, int n, int k) {
+        const int c = (int)c0v.size();
+        c0v.push_back(first); ncv.push_back(n); kid_off.push_back(kid_off.back() + k);
+        for (int i = first; i < first + n; i++) cl_of[i] = c;
+    };
+    std::vector<int> stack{0};
+    if (fits(size[0], nref[0])) { emit(0, size[0], nref[0]); stack.clear(); }
+    while (!stack.empty()) {
+        const int p = stack.back(); stack.pop_back();      // a refined cell whose subtree does not fit
+        int first = -1, n = 0, k = 0;
+        std::vector<int> deeper;
+        for (int s = 0; s < 8; s++) {
+            const int c = CH[(size_t)p * 8 + s];
+            if (!fits(size[c], nref[c])) {
+                if (!C[c].refined) return h->set_error("octree cluster budget too small for a single cell");
+                if (n) emit(first, n, k);
+                n = 0; k = 0; deeper.push_back(c);
+                continue;
+            }
+            if (n && !fits(n + size[c], k + nref[c])) { emit(first, n, k); n = 0; k = 0; }
+            if (!n) first = c;
+            n += size[c]; k += nref[c];
+        }
+        if (n) emit(first, n, k);
+        for (size_t i = deeper.size(); i-- > 0;) stack.push_back(deeper[i]);
+    }
+    const int n_cl = (int)c0v.size();
+    if (n_cl > HYP_TILE_MAX_BRICKS) return h->set_error("octree has too many cells for the cluster-tiled schedule");
+    int max_cells = 0, max_kids = 0;
+    for (int c = 0; c < n_cl; c++) { max_cells = std::max(max_cells, ncv[c]); max_kids = std::max(max_kids, kid_off[c + 1] - kid_off[c]); }
+    // per-cluster images: records with the row of a refined cell's children in `parent`, children and neighbours as local indices
+    std::vector<OctCell> rec(C);
+    std::vector<short> kid((size_t)std::max(1, kid_off[n_cl]) * 8, (short)-1), nb(6 * nc, (short)-2);
+    for (int c = 0; c < n_cl; c++) {
+        int row = 0;
+        for (int i = c0v[c]; i < c0v[c] + ncv[c]; i++) {
+            if (C[i].refined) {
+                rec[i].parent = row;
+                for (int s = 0; s < 8; s++) kid[((size_t)kid_off[c] + row) * 8 + s] = (short)(CH[(size_t)i * 8 + s] - c0v[c]);
+                row++;
+            }
+            for (int f = 0; f < 6; f++) {
+                const int n = NB[(size_t)i * 6 + f];
+                nb[(size_t)i * 6 + f] = (size_t)n == nc ? (short)-1 : (cl_of[n] == c ? (short)(n - c0v[c]) : (short)-2);
+            }
+        }
+    }
+    free_dev(h->d_ot_cluster); free_dev(h->d_ot_c0); free_dev(h->d_ot_nc); free_dev(h->d_ot_kid_off); free_dev(h->d_ot_rec); free_dev(h->d_ot_kid); free_dev(h->d_ot_nb);
+    auto up = [&](auto *&dst, const auto &v) {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (hipMalloc((void **)&dst, sizeof(T) * v.size()) != hipSuccess) return 1;
+        return hipMemcpy(dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
+    };
+    if (up(h->d_ot_cluster, cl_of) || up(h->d_ot_c0, c0v) || up(h->d_ot_nc, ncv) || up(h->d_ot_kid_off, kid_off) || up(h->d_ot_rec, rec) ||
+        up(h->d_ot_kid, kid) || up(h->d_ot_nb, nb))
+        return h->set_error("cannot allocate the cluster tables of the tiled octree schedule");
+    DProblem &P = h->hp;
+    P.ot_cluster = h->d_ot_cluster; P.ot_c0 = h->d_ot_c0; P.ot_nc = h->d_ot_nc; P.ot_kid_off = h->d_ot_kid_off;
+    P.ot_rec = h->d_ot_rec; P.ot_kid = h->d_ot_kid; P.ot_nb = h->d_ot_nb;
+    h->ot_clusters = n_cl; h->ot_max_cells = max_cells; h->ot_max_kids = max_kids; h->ot_built_for = nd;
+    return 0;
+}
+
 static int sync_problem(hyp_handle h)
 {
     hipError_t e = hipMemcpyAsync(h->d_problem, &h->hp, sizeof(DProblem), hipMemcpyHostToDevice, h->stream);
@@ -2190,8 +2304,14 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && !P.mrw;
         tile_auto = tile_ok && h->n_cells >= 8192 && n_local >= 2000000ull;
     }
+    else if (P.grid_type == 2) {
+        // octree: clusters of sibling subtrees in LDS (hyp_otile.h)
+        tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && h->oct_neighbours;
+        tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 2000000ull;
+    }
     const bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto));
     if (tiled && P.grid_type == 3 && build_vor_clusters(h)) return 1;
+    if (tiled && P.grid_type == 2 && build_oct_clusters(h)) return 1;
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(accum): ") + hipGetErrorString(e));
@@ -2395,6 +2515,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
     else if (n == "tile_split") h->tile_split = (int)value;
+    else if (n == "tile_ring") h->tile_ring = (int)value;
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value != 0;
@@ -2408,6 +2529,8 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
         h->peel_events = value; h->peel_events_exact = true;
     }
     else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; }
+    else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; }
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; }      // cells per Voronoi cluster (0: fill the LDS budget)
     else if (n == "tile_park") h->tile_park = (int)value;
@@ -2432,6 +2555,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_task") *value = h->tile_task;
     else if (n == "tile_pools") *value = h->tile_pools;
     else if (n == "tile_split") *value = h->tile_split;
+    else if (n == "tile_ring") *value = h->tile_ring;
+    else if (n == "last_tile_ring") *value = h->last_tile_ring;
     else if (n == "last_walk_us") *value = (int64_t)(h->last_walk_ms * 1000.0);
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
@@ -2444,6 +2569,9 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
     else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
     else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "ot_cells") *value = h->ot_cells;
+    else if (n == "ot_clusters") *value = h->ot_clusters;
+    else if (n == "ot_max_cells") *value = h->ot_max_cells;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;
     else if (n == "vt_max_cells") *value = h->vt_max_cells;

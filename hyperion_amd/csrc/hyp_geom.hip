@@ -7,6 +7,7 @@
 #include "hyp_kernels.h"
 #include "hyp_defer.h"
 #include "hyp_vtile.h"
+#include "hyp_otile.h"
 #include "hyp_pick.h"
 #include <cstring>
 
@@ -93,17 +94,26 @@ static TileKernels tile_kernels()
     TileKernels k;
     memset(&k, 0, sizeof k);
     k.nd = NDT;
-    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR) {
+    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR || GEOM == GEOM_OCT) {
         k.interact[0][0] = tile_interact_kernel<NDT, false, false, GEOM>; k.interact[1][0] = tile_interact_kernel<NDT, true, false, GEOM>;
         k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
         k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
     }
+    if constexpr (GEOM == GEOM_OCT) {
+        k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
+        k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
+        k.walk = otile_walk_kernel<NDT>;
+        k.walk_threads = HYP_OTILE_WG;
+    }
     if constexpr (GEOM == GEOM_CAR) {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
         k.prepare = tile_prepare_kernel<NDT>;
-        k.walk = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z>;
+        k.walk = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z, false>;
+#ifdef HYP_TILE_RING_BUILD   // the record-ring form of the walk (hyp_tiled.h: RecRing) measured slower: only tuning builds carry it
+        k.walk_ring = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z, true>;
+#endif
         k.walk_threads = HYP_TILE_WG;
         k.bx = TileShape<NDT>::X; k.by = TileShape<NDT>::Y; k.bz = TileShape<NDT>::Z;
     }

@@ -123,7 +123,7 @@ __device__ __forceinline__ int brick_of(const TileGeom &T, const int ic[3])
 // it belongs to.  The interaction / emission / drain kernels below are shared by the geometries through this.
 template <int GEOM> struct TileCellIO;
 template <> struct TileCellIO<GEOM_CAR> {
-    template <int ND> static __device__ __forceinline__ void load(const HotRec<ND> &H, Cell<GEOM_CAR> &c)
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_CAR> &c)
     {
 #pragma unroll
         for (int a = 0; a < 3; a++) c.ic[a] = H.ic[a];
@@ -139,7 +139,7 @@ template <> struct TileCellIO<GEOM_CAR> {
 };
 // Voronoi: ic = (cell, the cell the packet came from or -1, cluster << 8 | index of the cell in its cluster)
 template <> struct TileCellIO<GEOM_VOR> {
-    template <int ND> static __device__ __forceinline__ void load(const HotRec<ND> &H, Cell<GEOM_VOR> &c)
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_VOR> &c)
     {
         c.id = H.ic[0]; c.ow[0] = 0; c.ow[1] = -(H.ic[1] + 1); c.ow[2] = 0;
     }
@@ -148,6 +148,20 @@ template <> struct TileCellIO<GEOM_VOR> {
         H.ic[0] = c.id; H.ic[1] = -c.ow[1] - 1; H.ic[2] = P.vt_cluster[c.id]; H.ow = 0;
     }
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 8; }
+};
+// Octree (hyp_otile.h): ic = (leaf cell, -, cluster of the leaf), ow as on Cartesian grids; the rest of the cell record
+// (centre, level, parent, sub-cell) is read back from the cell table
+template <> struct TileCellIO<GEOM_OCT> {
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_OCT> &c)
+    {
+        oct_load(P, H.ic[0], c);
+        unpack_ow(H.ow, c.ow);
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_OCT> &c)
+    {
+        H.ic[0] = c.id; H.ic[1] = 0; H.ic[2] = P.ot_cluster[c.id]; H.ow = pack_ow(c.ow);
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_OCT> &c) { return P.ot_cluster[c.id]; }
 };
 
 // ---------------------------------------------------------------------------
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
                 g2.blk_a = C.blk_a; g2.buf_a = C.buf_a; g2.have_a = C.have_a; g2.blk_b = 0; g2.countdown = 0;
                 double albedo = C.albedo[0];
                 if (ND > 1 && nd > 1) {        // select_dust_chi_rho, as in interact()
-                    Cell<GEOM> hc; TileCellIO<GEOM>::load(H, hc);
+                    Cell<GEOM> hc; TileCellIO<GEOM>::load(P, H, hc);
                     const size_t base = geo_index(P, hc) * (size_t)nd;
                     double cdf[ND], c = 0.0;
 #pragma unroll
@@ -564,7 +578,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             state = H.state;
 #pragma unroll
             for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
-            TileCellIO<GEOM>::load(H, p.cell);
+            TileCellIO<GEOM>::load(P, H, p.cell);
             p.a = C.a;
             p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
             p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
@@ -792,7 +806,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                 const ColdRec<ND> &C = cold[slot];
 #pragma unroll
                 for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
-                TileCellIO<GEOM>::load(H, p.cell);
+                TileCellIO<GEOM>::load(P, H, p.cell);
                 p.a = C.a;
                 p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
                 p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
@@ -959,6 +973,108 @@ static __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, co
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Record ring (EXPERIMENT, off: built only with -DHYP_TILE_RING_BUILD, option tile_ring).  The LAST wave of a walk
+// workgroup does not walk: it streams the slot records of the task's packets, in queue order, into a ring of LDS batches
+// with global_load_lds (DMA: no registers, 1 KB = 64 lanes x 16 B per instruction, each record read from wherever its slot
+// lies), several batches in flight, and publishes how many records have landed; the walking waves take their next packet
+// from the ring (ds_read) instead of following order[] -> HotRec through global memory.  Motive: a wave spends 46 % of its
+// clocks in the service phase (-DHYP_TILE_STATS), much of it waiting for those two dependent loads with its walking
+// lanes idle.  Measured (profiles/r03_tiled_log.md): parity green, but with the 13 KB that a 16^3 brick leaves of a CU's
+// LDS at two workgroups per CU the ring holds ~100 records, less than a loader needs in flight plus what the walkers
+// have claimed and not yet picked up: walk kernels 367 ms against 205 ms (one pool).  Kept for bricks that leave room.
+// Batch = the records one DMA instruction moves: 8 of 128 B (one species) or 5 of 192 B.
+// ---------------------------------------------------------------------------
+#ifndef HYP_RING_BATCHES
+#define HYP_RING_BATCHES 13      // ring size in batches of 1 KB
+#endif
+#ifndef HYP_RING_FLY
+#define HYP_RING_FLY 8           // DMAs the loader keeps in flight (at most 8: the switch in load_task)
+#endif
+#define HYP_RING_BYTES (HYP_RING_BATCHES * 1024 + HYP_RING_BATCHES * 8 * 4 + HYP_RING_BATCHES * 4 + 16)
+
+template <int ND>
+struct RecRing {
+    static constexpr int RS = (int)sizeof(HotRec<ND>), LPR = RS / 16, RPB = 64 / LPR;
+    char *data; int *slot; int *cons; int *tail;
+    __device__ __forceinline__ void carve(char *base)
+    {
+        data = base; slot = (int *)(base + HYP_RING_BATCHES * 1024); cons = slot + HYP_RING_BATCHES * 8; tail = cons + HYP_RING_BATCHES;
+    }
+    __device__ __forceinline__ void reset()      // by the whole workgroup, before the barrier that starts the task
+    {
+        if (threadIdx.x < HYP_RING_BATCHES) cons[threadIdx.x] = 0;
+        if (threadIdx.x == 64) *tail = 0;
+    }
+    // the loader wave's whole life: a DMA per batch as soon as its place in the ring is free, up to HYP_RING_FLY of them in
+    // flight, the oldest retired (and published) with a counted s_waitcnt.  The slot indices come through the scalar cache
+    // (the batch's 8 consecutive entries of order[] are wave-uniform), so the vector-memory counter holds the DMAs only.
+    __device__ __forceinline__ void load_task(const void *__restrict__ hot, const int *__restrict__ order, const TileTask &tk) const
+    {
+        constexpr int NB = HYP_RING_BATCHES, FLY = HYP_RING_FLY;
+        const int lane = (int)__lane_id();
+        const int rib = lane / LPR, part = lane % LPR;
+        const int n_batches = (tk.len + RPB - 1) / RPB;
+        const int *__restrict__ ord = order + tk.start;
+        int issued = 0, landed = 0;
+#ifdef HYP_RING_PRIO
+        __builtin_amdgcn_s_setprio(HYP_RING_PRIO);
+#endif
+        while (landed < n_batches) {
+            // issue while there is room in the ring and in the queue
+            while (issued < n_batches && issued - landed < FLY) {
+                const int rs = issued % NB;
+                if (issued >= NB) {      // the batch that lived here (always a full one) must have been taken entirely
+                    if (__hip_atomic_load(&cons[rs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RPB) break;
+                    if (lane == 0) __hip_atomic_store(&cons[rs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                const int j0 = issued * RPB;
+                int mine = -1;
+#pragma unroll
+                for (int c = 0; c < RPB; c++) {
+#ifdef HYP_RING_ABLATE_IDX      // timing experiment only (wrong results): no order[] indirection
+                    const int sc = j0 + c < tk.len ? ((tk.start + j0 + c) & 0xfffff) : -1;
+#else
+                    const int sc = j0 + c < tk.len ? ord[j0 + c] : -1;      // uniform address: s_load
+#endif
+                    if (rib == c) mine = sc;
+                }
+                if (mine >= 0) {
+                    const char *src = (const char *)hot + (size_t)mine * RS + part * 16;
+                    // global_load_lds_dwordx4: LDS address = M0 + 16 x lane.  In asm so that hipcc neither counts it nor orders the
+                    // LDS traffic of this loop behind it (/opt/skills/guides/cdna_hip_programming.md, "LDS-DMA recipe")
+                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(data + rs * 1024));
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+                    if (part == 0) slot[rs * 8 + rib] = mine;
+                }
+                issued++;
+            }
+            if (issued == landed) { __builtin_amdgcn_s_sleep(2); continue; }      // ring full of untaken records
+            // retire the oldest batch in flight: all but the (issued - landed - 1) youngest DMAs have landed
+            switch (issued - landed - 1) {
+            case 0: __builtin_amdgcn_s_waitcnt(0x0070 | 0); break;       // vmcnt(0) lgkmcnt(0) (the slot indices too)
+            case 1: __builtin_amdgcn_s_waitcnt(0x0070 | 1); break;
+            case 2: __builtin_amdgcn_s_waitcnt(0x0070 | 2); break;
+            case 3: __builtin_amdgcn_s_waitcnt(0x0070 | 3); break;
+            case 4: __builtin_amdgcn_s_waitcnt(0x0070 | 4); break;
+            case 5: __builtin_amdgcn_s_waitcnt(0x0070 | 5); break;
+            case 6: __builtin_amdgcn_s_waitcnt(0x0070 | 6); break;
+            default: __builtin_amdgcn_s_waitcnt(0x0070 | 7); break;
+            }
+            landed++;
+            if (lane == 0) __hip_atomic_store(tail, min(landed * RPB, tk.len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    // a walking lane with claim j (0 <= j < tk.len): has its record landed?  Then where it is.
+    __device__ __forceinline__ bool ready(int j) const { return j < __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ const HotRec<ND> &record(int j) const { return *(const HotRec<ND> *)(data + ((j / RPB) % HYP_RING_BATCHES) * 1024 + (j % RPB) * RS); }
+    __device__ __forceinline__ int slot_of(int j) const { return slot[((j / RPB) % HYP_RING_BATCHES) * 8 + j % RPB]; }
+    __device__ __forceinline__ void taken(int j) const { atomicAdd(&cons[(j / RPB) % HYP_RING_BATCHES], 1); }
+};
+
 // brick shape per number of species: density + accumulators (16 B per cell and
 // species) must leave room for two workgroups per CU in the 160 KB LDS
 #ifndef HYP_TILE_BX
@@ -1041,20 +1157,63 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
     return simple;
 }
 
+// geo_in_correct_cell (grid_geometry_cartesian_3d.f90:330-381) for a packet whose cell lies in the brick [x0, x1) when only the
+// brick's own walls are at hand (W indexed by grid position, valid on [x0, x1] per axis) plus the grid's outer walls gb =
+// {lo0, hi0, lo1, hi1, lo2, hi2}.  locate() over the whole wall array and the search over the brick's walls name the same cell
+// whenever the position lies inside the brick's extent; outside it the cell found cannot be the packet's.
+__device__ __forceinline__ bool in_correct_cell_brick(const Walls &W, const double *gb, const int x0[3], const int x1[3],
+                                                      const double r[3], const Cell<GEOM_CAR> &c)
+{
+    int act[3];
+    bool found = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double lo = gb[2 * a], hi = gb[2 * a + 1];
+        const bool in_grid = (r[a] >= lo) && (r[a] <= hi);
+        found = found && in_grid;
+        int j = -2;
+        if (r[a] == hi) j = W.n[a] - 1;
+        else if (r[a] >= W.w[a][x0[a]] && r[a] < W.w[a][x1[a]]) {
+            int jl = x0[a], ju = x1[a];
+            while (ju - jl > 1) {
+                const int jm = (ju + jl) >> 1;
+                if (r[a] >= W.w[a][jm]) jl = jm; else ju = jm;
+            }
+            j = jl;
+        }
+        act[a] = j;
+    }
+    const double thr = 1e-3;
+    if (c.ow[0] | c.ow[1] | c.ow[2]) {
+        bool ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int i = c.ic[a];
+            const double wl = W.w[a][i], wu = W.w[a][i + 1];
+            if (c.ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
+            else if (c.ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
+            else ok = ok && found && act[a] == i;
+        }
+        return ok;
+    }
+    return found && act[0] == c.ic[0] && act[1] == c.ic[1] && act[2] == c.ic[2];
+}
+
 // lane states of tile_walk_kernel
 // LS_CHECK: the propagation check is due; LS_SLOW: geo_find_wall is needed for this step
 // LS_REABS: the step would run into a source (grid_propagate_3d.f90:139-143)
 enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6, LS_REABS = 7 };
 
-template <int ND, int BX, int BY, int BZ>
-__global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+template <int ND, int BX, int BY, int BZ, bool RING>
+__global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_WG / 128) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                       void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                       const int *__restrict__ order,
                                                       const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,
                                                       int *__restrict__ ilist, int *__restrict__ dlist,
                                                       TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
-    extern __shared__ double lds[];
+    extern __shared__ float4 lds16[];        // 16-byte aligned base (the record ring is read with ds_read_b128)
+    double *lds = (double *)lds16;
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
     ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
@@ -1062,13 +1221,38 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
     const TileTask tk = tasks[blockIdx.x];
     constexpr int NC = BX * BY * BZ;
     Walls W;
-    stage_walls<GEOM_CAR>(P, lds, W);
+    RecRing<ND> ring;
+    double *after_walls;
+    const double *grid_bounds = nullptr;
+    if (RING) {
+        // only the brick's own walls (BX + 1, BY + 1, BZ + 1 of them, and their epsilons) are staged: the ring needs the room.
+        // W.w[a] is offset so that it is still indexed by the cell's position in the grid.
+        const int bi = tk.brick % T.nbx, bj = (tk.brick / T.nbx) % T.nby, bk = tk.brick / (T.nbx * T.nby);
+        const int o[3] = {bi * BX, bj * BY, bk * BZ}, m[3] = {BX + 1, BY + 1, BZ + 1}, n[3] = {P.n1, P.n2, P.n3};
+        double *q = lds;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            for (int i = threadIdx.x; i < m[a]; i += blockDim.x) {
+                const int gi = min(o[a] + i, n[a]);
+                q[i] = P.w[a][gi]; q[m[a] + i] = P.ew[a][gi];
+            }
+            W.w[a] = q - o[a]; W.ew[a] = q + m[a] - o[a]; W.n[a] = n[a];
+            q += 2 * m[a];
+        }
+        if (threadIdx.x < 6) q[threadIdx.x] = P.w[threadIdx.x >> 1][(threadIdx.x & 1) ? n[threadIdx.x >> 1] : 0];      // the grid's outer walls
+        grid_bounds = q;
+        after_walls = lds + 2 * (BX + BY + BZ + 3) + 6;
+    } else {
+        stage_walls<GEOM_CAR>(P, lds, W);
+        after_walls = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
+    }
 #if HYP_TILE_DENS_LDS
-    double *dens = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
+    double *dens = after_walls;
     double *accum = dens + (size_t)NC * ND;
 #else
-    double *accum = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
+    double *accum = after_walls;
 #endif
+    if (RING) { ring.carve((char *)(accum + (size_t)NC * ND)); ring.reset(); }
     __shared__ int next_pkt;
     // split schedule: this task's lists of waiting / free slots and the bricks its packets move to
     // (index (dz+1)*9 + (dy+1)*3 + dx+1; 13 = packets parked in this brick)
@@ -1101,6 +1285,10 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
+    // the last wave feeds the record ring and takes no packets
+    const bool loader = RING && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1;
+    if (loader) ring.load_task(hot_v, order, tk);
+    int claim = -1;                           // RING: index in the task's queue of the packet this lane waits for
     // lane state: the walking part of a packet (the rest stays in its ColdRec)
     double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
     double sgn[3];                            // sign of v per axis (+1, -1, 0) and iu = 1 where v > 0: fixed during a visit
@@ -1115,7 +1303,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
     int slot = -1;
     int st = LS_IDLE;
-    bool exhausted = false, pre = false;
+    bool exhausted = loader, pre = false;
 #pragma unroll
     for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; inv[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; sgn[a] = 1.0; iu[a] = 1; }
 #pragma unroll
@@ -1123,25 +1311,38 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
 
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
 #ifdef HYP_TILE_STATS
-    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0;
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0;
+    const long long dbg_t0 = clock64();
 #endif
     for (;;) {
-        if (queue_empty && st == LS_IDLE) exhausted = true;
+        if (queue_empty && st == LS_IDLE && claim < 0) exhausted = true;
+        // RING: records [0, tail_now) of the task's queue have landed; a lane whose claimed record has not waits without
+        // asking for a service phase
+        const int tail_now = RING ? __hip_atomic_load(ring.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        // landed records nobody has claimed yet: an idle lane asks for a packet only when there is one to be had
+        const int next_now = RING ? __hip_atomic_load(&next_pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
+        const bool can_take = !RING || next_now < tail_now || next_now >= tk.len;
         const unsigned long long m_walk = __ballot(st == LS_WALK);
         const unsigned long long m_out = __ballot(st >= LS_LEFT);      // anything the service phase must look at
-        const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted);
-        if (!(m_walk | m_out | m_idle)) break;
+        const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted && (!RING || (claim >= 0 ? claim < tail_now : can_take)));
+        const unsigned long long m_wait = RING ? __ballot(st == LS_IDLE && !exhausted && (claim >= 0 ? claim >= tail_now : !can_take)) : 0ull;
+        if (!(m_walk | m_out | m_idle | m_wait)) break;
+        if (RING && !(m_walk | m_out | m_idle)) __builtin_amdgcn_s_sleep(8);      // everybody waits for the loader (nothing below runs)
         // Tail of a task: the queue is empty and only a few lanes of this wave still walk.  Their
         // packets go back to their slots as they are (same brick) and continue in the next
         // generation in a full wave, instead of dragging a nearly empty wave along.
-        const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
+        const bool park = !(m_idle | m_wait) && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_TILE_SERVICE || !m_walk))) {
+#ifdef HYP_TILE_STATS
+            const long long dbg_ts = clock64();
+#endif
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
             if (st == LS_CHECK) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
-                if (geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
+                const int bx0[3] = {x0, y0, z0}, bx1[3] = {x1, y1, z1};
+                if (RING ? in_correct_cell_brick(W, grid_bounds, bx0, bx1, r, cell) : geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
                 else { cnt.killed_geo++; st = LS_DEAD; }
             }
             // packets that round-off left outside their cell: the general wall search, handed to the
@@ -1204,15 +1405,29 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
             }
             if (park) break;
             if (st == LS_IDLE && !exhausted) {
-                int j = atomicAdd(&next_pkt, 1);
-                if (j >= tk.len) exhausted = true;
+                int j = RING ? claim : -1;
+                if (RING && j < 0) {
+                    // the lanes that want a packet share the landed, unclaimed records between them (rank order); the others
+                    // keep waiting.  Another wave may get in between the look and the reservation: a lane that ends up
+                    // with a record still in flight holds on to the claim.
+                    const unsigned long long want = __ballot(true);
+                    const int rank = __popcll(want & ((1ull << __lane_id()) - 1ull)), first = __ffsll((long long)want) - 1;
+                    int take = 0, base = 0;
+                    if (rank == 0) {
+                        const int cur = __hip_atomic_load(&next_pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        take = cur >= tk.len ? __popcll(want) : min(__popcll(want), max(tail_now - cur, 0));
+                        if (take > 0) base = atomicAdd(&next_pkt, take);
+                    }
+                    take = __shfl(take, first, 64); base = __shfl(base, first, 64);
+                    j = rank < take ? base + rank : -2;
+                } else if (j < 0) j = atomicAdd(&next_pkt, 1);
+                if (j == -2) { }                                   // RING: nothing landed for this lane yet
+                else if (j >= tk.len) exhausted = true;
+                else if (RING && j >= tail_now) claim = j;        // not landed yet: the lane waits (m_wait)
                 else {
-                    slot = order[tk.start + j];
-#ifdef HYP_TILE_ABLATE_REFILL      // timing experiment only (wrong results): records from a cache-hot window
-                    const HotRec<ND> &H = hot[slot & 1023];
-#else
-                    const HotRec<ND> &H = hot[slot];
-#endif
+                    if (RING) slot = ring.slot_of(j); else slot = order[tk.start + j];
+                    const HotRec<ND> &H = RING ? ring.record(j) : hot[slot];
+                    claim = -1;
                     v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
@@ -1229,10 +1444,15 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
+                    if (RING) ring.taken(j);
                     st = LS_WALK; pre = false;
                 }
             }
-            if (__ballot(exhausted)) queue_empty = true;
+            if (__ballot(exhausted && !loader)) queue_empty = true;
+#ifdef HYP_TILE_STATS
+            __builtin_amdgcn_s_waitcnt(0);      // charge the loads of the refill to the service phase
+            dbg_service += (unsigned long long)(clock64() - dbg_ts); dbg_nservice++;
+#endif
         }
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #ifdef HYP_TILE_STATS
@@ -1326,6 +1546,7 @@ __global__ __launch_bounds__(HYP_TILE_WG) HYP_WALK_ATTR void tile_walk_kernel(co
     if (__lane_id() == 0) {
         atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps);
         atomicAdd(&ctl->dbg[3], 1ull);
+        atomicAdd(&ctl->dbg[6], dbg_service); atomicAdd(&ctl->dbg[7], dbg_nservice); atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
         if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
     }
 #endif

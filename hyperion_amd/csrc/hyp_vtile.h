@@ -117,7 +117,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                                                                   int *__restrict__ ilist, int *__restrict__ dlist,
                                                                   TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
-    extern __shared__ double lds[];
+    extern __shared__ float4 lds16[];        // 16-byte aligned base: headers and wall records are read with ds_read_b128
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
     ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
     const int cl = tk.brick;
     const int c0 = P.vt_cell_off[cl], nc = P.vt_cell_off[cl + 1] - c0;
     const int w0 = P.vt_wall_off[cl], nw = P.vt_wall_off[cl + 1] - w0;
-    VtHdr *hdr = (VtHdr *)lds;
+    VtHdr *hdr = (VtHdr *)lds16;
     VorWall *walls = (VorWall *)(hdr + T.bx);
     double *dens = (double *)(walls + T.by);
     double *accum = dens + (size_t)T.bx * ND;

@@ -145,3 +145,75 @@ def test_neighbour_table_walk_is_the_reference_walk_at_full_size():
     for ga, gb in zip(ia, ib):
         for name in gb:
             np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
+
+
+# --- cluster-tiled Lucy iteration (hyp_otile.h, lucy_mode=1): same packets, same answer ---------------------
+
+def run_tiled(prob, n, iters=1, **opts):
+    eng = hyperion_amd.Engine(prob)
+    eng.set_option("lucy_mode", 1)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    orc = Oracle(prob)
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        assert eng.get_option("last_lucy_mode") == 1
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+        assert_parity(a, b)
+    n_cl = eng.get_option("ot_clusters")
+    eng.close(); orc.close()
+    return a, sa, n_cl
+
+
+def test_otile_reference_model_one_cluster_and_many():
+    """The reference's 25-cell octree (three refined cells): the whole tree as one cluster, and clusters of at most 9
+    cells (one per refined level-1 cell and runs of leaves) with packets changing cluster nearly every crossing."""
+    prob, _ = golden_problem("oct_specific_energy.False.False.npz")
+    a, st, n_cl = run_tiled(prob, 30000, iters=2)
+    assert n_cl == 1
+    a, st, n_cl = run_tiled(prob, 30000, iters=2, ot_cells=9, tile_slots=4096, tile_task=256, tile_drain=0, tile_poll=1)
+    assert n_cl > 2
+
+
+def test_otile_adaptive_octree_small_clusters():
+    """Adaptive octree of depth 5 (BASELINE configs[3] in small, source on a vertex of the tree: edge-running packets take
+    the reference's climb, LS_OSLOW) with clusters of <= 80 and <= 600 cells, slot pools far smaller than the packet count,
+    generations all the way down (no drain launch), one pool and three; then the default cluster size and the drain."""
+    p = make_octree_problem(max_level=5, imaging=False)
+    a, st, n_cl = run_tiled(p, 60000, iters=2, ot_cells=80, tile_slots=8192, tile_task=512, tile_drain=0, tile_poll=1)
+    assert n_cl > 20 and st["killed_int"] == 0
+    run_tiled(p, 60000, ot_cells=600, tile_slots=24576, tile_pools=3, tile_task=256, tile_drain=0)
+    run_tiled(p, 60000, tile_slots=16384, tile_pools=2, tile_drain=500)
+
+
+def test_otile_offcentre_source_and_two_species():
+    """Off-centre source (no vertex degeneracy, nobody killed) and two dust species (LDS layout with ND = 2)."""
+    p = make_octree_problem(max_level=4, imaging=False)
+    p.sources[0].position = (0.123 * PC, -0.217 * PC, 0.05 * PC)
+    a, st, _ = run_tiled(p, 50000, ot_cells=100, tile_slots=8192, tile_drain=0)
+    assert st["killed_geo"] == 0
+    p.density = np.vstack([p.density * 0.6, p.density * 0.8])
+    p.dust = [p.dust[0], p.dust[0]]
+    run_tiled(p, 50000, ot_cells=100, tile_slots=8192, tile_drain=100)
+
+
+def test_otile_matches_persistent_at_scale():
+    """BASELINE configs[3] (depth 7, 30 217 cells) at 4e6 packets: both GPU schedules walk the same packets; integer
+    tallies equal, sums equal to rounding; the tiled one is what lucy_mode -1 picks at this size."""
+    prob = make_octree_problem(max_level=7, imaging=False)
+    res = []
+    for mode in (0, -1):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("lucy_mode", mode)
+        res.append(eng.lucy_iteration(4_000_000, 1))
+        assert eng.get_option("last_lucy_mode") == (0 if mode == 0 else 1)
+        if mode:
+            assert eng.get_option("ot_clusters") > 8
+        eng.close()
+    (a, sa), (b, sb) = res
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert_parity(a, b)

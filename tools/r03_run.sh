@@ -19,7 +19,7 @@ if [ -n "${VORV:-}" ]; then
     for o in "${SETS[@]}"; do echo "== variant $(basename $f) $o"; HYP_LIB=$f timeout 600 python tools/voronoi_big_bench.py $o 2>&1 | tail -1 | tee -a $OUT/vorv.log; done
   done
 fi
-if [ -n "${OCT:-}" ]; then echo "== octree"; timeout 600 python tools/octree_bench.py $OCT 2>&1 | tail -4 | tee -a $OUT/oct.log; fi
+if [ -n "${OCT:-}" ]; then echo "== octree"; timeout 600 python tools/octree_bench.py $OCT 2>&1 | tail -12 | tee -a $OUT/oct.log; fi
 if [ -n "${CAR:-}" ]; then
   IFS=';' read -ra SETS <<< "$CAR"
   i=0
