@@ -24,18 +24,49 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock; one wave64 VALU instruction issues in 4 cycles
+N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock
+# SIMD cycles per wave64 instruction at 4 waves per SIMD, measured with tools/ubench/valu_issue.hip (profiles/r03_tiled_log.md):
+# FP64 add / mul / fma / compare / ldexp and 64-bit integer 4.2-4.9 -> 4.3; 32-bit 2.2-2.6 -> 2.4; v_rcp_f64 16
+CYC_F64, CYC_32, CYC_TRANS_F64 = 4.3, 2.4, 16.0
+PMC_FILE = "profiles/r03_pmc.json"
 
 
-def committed_pmc(tiled):
-    """Per-crossing PMC totals of the committed rocprofv3 passes of THIS bench command (profiles/r02_pmc.json, written by
-    tools/r02_profile.sh + tools/summarize_tiled.py on the GPU box).  Counters cannot be read inside the timed run, so the
-    bench line carries them with their source; None when the file is not there or does not apply."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    if not tiled or not os.path.exists(path):
+def committed_pmc(workload):
+    """Counter sums of the committed rocprofv3 passes of one workload (profiles/r03_pmc.json, written on the GPU box by
+    tools/r03_profile.sh + tools/summarize_r03.py: `car` = THIS bench command, `oct_lucy` / `oct_img` / `vor` = the extra
+    configurations at 1e8 packets).  Counters cannot be read inside the timed run, so the bench line carries them with
+    their source; None when the file is not there."""
+    path = os.path.join(ROOT, PMC_FILE)
+    if not os.path.exists(path):
         return None
     with open(path) as f:
-        return json.load(f)
+        return json.load(f).get(workload)
+
+
+def host_cpu():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("model name"):
+                    return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def traffic_fields(pmc):
+    """bytes per crossing (L2 <-> fabric, FETCH_SIZE / WRITE_SIZE in KiB as reported; reads also with the guide's x2 for wide
+    streaming loads) and their ratio to the algorithmic 24 B x n_dust, from a workload entry of profiles/r03_pmc.json."""
+    if not pmc or "bytes_per_crossing" not in pmc:
+        return {"bytes_per_crossing": None}
+    b = pmc["bytes_per_crossing"]
+    out = {"bytes_per_crossing": {"fetched": b["fetched"], "fetched_reads_x2": b["fetched_x2"], "written": b["written"], "algorithmic": b["algorithmic"]},
+           "traffic_over_algorithmic": b["traffic_over_algorithmic"], "traffic_over_algorithmic_reads_x2": b["traffic_over_algorithmic_reads_x2"],
+           "pmc_source": PMC_FILE}
+    per = pmc.get("per_crossing", {})
+    if "TCC_EA0_ATOMIC_sum" in per:
+        out["memory_side_atomics_per_crossing"] = per["TCC_EA0_ATOMIC_sum"]
+    return out
 
 
 def cpu_baseline(prob, n_sample):
@@ -51,7 +82,7 @@ def cpu_baseline(prob, n_sample):
     _, st = orc.lucy_iteration(n_sample, 1, n_threads=threads)
     dt = time.time() - t0
     orc.close()
-    return {"value": n_sample / dt, "unit": "packets/s", "cores": threads, "kind": "port",
+    return {"value": n_sample / dt, "unit": "packets/s", "cores": threads, "kind": "port", "host_cpu": host_cpu(), "host_logical_cpus": cores,
             "sample": "%d packets of the same 128^3 workload, 1 Lucy iteration, %d OpenMP threads (%.1f s)" % (n_sample, threads, dt),
             "crossings_per_s": st["crossings"] / dt}
 
@@ -82,14 +113,15 @@ def extras(n):
     k_ms = e.last_kernel_ms()[0]
     res.append({"config": "configs[3] Lucy iteration: octree depth 7 (%d cells), central source" % p.n_cells, "packets": n,
                 "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
-                "hbm_frac": 24.0 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                "schedule": "cluster-tiled (hyp_otile.h), %d clusters" % e.get_option("ot_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
+                "hbm_frac": 24.0 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("oct_lucy"))})
     st, dt = timed(lambda: e.final_iteration(n)[1])
     rounds = e.get_option("last_defer_rounds")
     res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction", "packets": n,
                 "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet" % (rounds, e.get_option("last_defer_events") / n))
                             if rounds else "inline peel-off",
                 "packets_per_s": n / dt, "kernel_ms": e.last_kernel_ms()[0],
-                "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS})
+                "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("oct_img"))})
     e.close()
     try:
         from cases import voronoi_big_problem
@@ -108,7 +140,8 @@ def extras(n):
     res.append({"config": "configs[4] Lucy iteration: voro++ tessellation of 100000 random sites (15.2 neighbours / cell), 2 HG-like polarising "
                           "species, point + external box source", "packets": n, "packets_per_s": n / dt,
                 "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
-                "hbm_frac": 24.0 * 2 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
+                "schedule": "cluster-tiled (hyp_vtile.h), %d clusters" % e.get_option("vt_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
+                "hbm_frac": 24.0 * 2 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("vor"))})
     e.close()
     return res
 
@@ -125,7 +158,7 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=2e7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the configs[3] / configs[4] lines (N = 1 only)")
-    ap.add_argument("--extra-photons", type=float, default=2e7, help="packets per iteration of the extra configurations")
+    ap.add_argument("--extra-photons", type=float, default=1e8, help="packets per iteration of the extra configurations (BASELINE: 1e8)")
     ap.add_argument("--option", action="append", default=[], help="engine option name=value")
     args = ap.parse_args()
 
@@ -173,20 +206,40 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms, crossings, finish_ms = [], 0, []
+    parts = {"t_launch_s": 0.0, "t_kernel_s": 0.0, "t_collective_s": 0.0, "t_finish_s": 0.0}      # this rank's host clock, summed over the steps
     for _ in range(args.steps):
         it += 1
         _, st = lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False, force_collective=dist is not None)
         a, b = eng.last_kernel_ms()
         kernel_ms.append(a)
         finish_ms.append(b)
+        for k in parts:
+            parts[k] += st.get(k, 0.0)
         crossings = st["crossings"]          # whole-job crossings of the last step
     barrier()
     dt = time.perf_counter() - t0
     tiled = eng.get_option("last_lucy_mode") == 1
+    if tiled:
+        # the dominant kernel's launch durations, live: one more step (outside the timed region) with HIP events around every
+        # tile_walk launch -- the instrumentation is an option of the engine, off in the product path and in the timed steps
+        eng.set_option("tile_time_walk", 1)
+        it += 1
+        lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False, force_collective=dist is not None)
+        eng.set_option("tile_time_walk", 0)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # where each rank's time went (ms per step): launches (host side of the generations, which includes most of the
+    # propagation: the tiled schedule polls the device), waiting for the kernels, the all-reduce, the epilogue; device
+    # time of the propagation from HIP events.  Gathered after the timed region.
+    mine = torch.tensor([parts["t_launch_s"], parts["t_kernel_s"], parts["t_collective_s"], parts["t_finish_s"],
+                         sum(kernel_ms) * 1e-3, sum(finish_ms) * 1e-3], dtype=torch.float64, device="cuda") * (1e3 / args.steps)
+    per_rank = [mine]
+    if dist is not None and world > 1:
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+    per_rank = torch.stack(per_rank).cpu().numpy()
 
     if rank == 0:
         n_dust = prob.n_dust
@@ -207,15 +260,24 @@ def main():
             "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_scan / tile_scatter / tile_walk on %d slot pools (streams)"
                               % eng.get_option("tile_pools")) if tiled else "persistent kernel, global atomics",
         }
+        if world > 1:
+            out["ms_per_step_note"] = "max over ranks of the barrier-to-barrier time of the timed steps / steps"
+        names = ("launch_ms", "kernel_wait_ms", "allreduce_ms", "finish_ms", "device_propagate_ms", "device_finish_ms")
+        out["per_rank_ms_per_step"] = {n: {"min": float(per_rank[:, i].min()), "max": float(per_rank[:, i].max()),
+                                           "ranks": [float(x) for x in per_rank[:, i]]} for i, n in enumerate(names)}
+        out["per_rank_ms_per_step"]["note"] = ("host clock of each rank per step: launch = enqueueing the generations (the tiled schedule polls the device, so "
+                                               "most of the propagation is spent here), kernel_wait = waiting for the remaining kernels + replica reduction, allreduce = "
+                                               "RCCL all-reduce of the accumulator block (the error flag rides in its tail: one collective) + stream sync, finish = "
+                                               "update_energy_abs epilogue; device_* = HIP events on the engine's stream")
         std_case = args.grid == 128 and args.density == "uniform"
-        pmc = committed_pmc(tiled) if std_case else None
-        per = pmc["per_crossing"] if pmc else {}
+        pmc = committed_pmc("car") if (std_case and tiled) else None
+        per = pmc.get("per_crossing", {}) if pmc else {}
         xs = crossings / world                      # crossings of one launch on this GPU
         roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                 "kernel": "whole propagation of one Lucy iteration (all generations), HIP events on the engine's stream",
                 "algorithmic_bytes_per_unit": "24 B x n_dust per cell crossing (8 B density load + 16 B accumulator read-modify-write, "
                                               "src/grid/grid_propagate_3d.f90:131-160); crossings counted in-kernel"}
-        if per:
+        if per and "FETCH_SIZE" in per:
             # FETCH_SIZE / WRITE_SIZE are in KiB; L2 <-> fabric requests, Infinity-Cache hits included.  The guide's x2
             # correction for wide streaming reads applies to the 16 B/lane record loads of tile_walk / tile_interact, so
             # the read half is a lower bound: both are given.
@@ -223,33 +285,48 @@ def main():
             roof["traffic"] = (rd + wr) * xs / 1e9
             roof["traffic_unit"] = "GB per launch, L2<->fabric (FETCH_SIZE + WRITE_SIZE as reported)"
             roof["traffic_reads_x2"] = (2 * rd + wr) * xs / 1e9
-            roof["traffic_source"] = "profiles/r02_pmc.json (rocprofv3 --pmc passes of this command, tools/r02_profile.sh); not measured in this run"
+            roof["traffic_over_algorithmic"] = (rd + wr) / (24.0 * n_dust)
+            roof["traffic_source"] = PMC_FILE + " (rocprofv3 --pmc passes of this command, tools/r03_profile.sh); not measured in this run"
         else:
             roof["traffic"] = None
         if tiled:
             walk_ms = eng.get_option("last_walk_us") / 1e3
             n_walk = eng.get_option("last_walk_launches")
-            roof["dominant_kernel"] = {
-                "name": "tile_walk_kernel", "launches_per_iteration": n_walk, "sum_ms_per_iteration": walk_ms,
-                "avg_launch_us": walk_ms * 1e3 / max(n_walk, 1),
-                "achieved_GBs_over_its_own_time": alg_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
-                "note": "HIP events around every tile_walk launch on its pool's stream (last timed step); with several pools the "
-                        "launches overlap other kernels and stretch -- profiles/r02_serial_summary.md has the one-pool trace"}
-            roof["note"] = ("density and accumulators of a 16^3 brick live in LDS, so the 24 B per crossing never go to memory: the HBM "
-                            "fraction says how far the path is from a streaming bound it does not have; what limits it is VALU issue "
-                            "(see issue_roofline) and, for tile_interact, random 128-byte record traffic")
+            if n_walk:
+                roof["dominant_kernel"] = {
+                    "name": "tile_walk_kernel", "launches_per_iteration": n_walk, "sum_ms_per_iteration": walk_ms,
+                    "avg_launch_us": walk_ms * 1e3 / max(n_walk, 1),
+                    "achieved_GBs_over_its_own_time": alg_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
+                    "note": "HIP events around every tile_walk launch on its pool's stream, in one extra step after the timed region (option tile_time_walk, off in the timed steps); with several "
+                            "pools the launches overlap other kernels and stretch -- profiles/r03_car1_summary.md has the one-pool trace"}
+            roof["limiter"] = "valu_issue + service-phase latency"
+            roof["note"] = ("density and accumulators of a 16^3 brick live in LDS, so the 24 B per crossing never go to memory: `bound` names the "
+                            "nominal roofline of the path (HBM), the fraction says how far it is from a streaming bound it does not have; the counters "
+                            "name the limiter: VALU issue (issue_roofline) and the service phase of tile_walk, 46 % of a wave's clocks "
+                            "(profiles/r03_tiled_log.md)")
         else:
+            roof["limiter"] = "memory-side atomics"
             roof["note"] = ("bound by the memory-side scattered-atomic rate (2.38e10/s, profiles/r01_atomic_rate_ubench.md): fraction %.2f"
                             % (xs / (k_ms * 1e-3) / 2.38e10))
         out["roofline"] = roof
-        if per:
-            # second ceiling: VALU issue.  wave-instructions x 4 cycles / (SIMDs x clock) is the time the chip needs to issue
-            # the vector instructions of one launch if every SIMD issued one every cycle it could.
-            t_issue = per["SQ_INSTS_VALU"] * xs * 4.0 / (N_SIMD * CLOCK_HZ)
+        if per and "SQ_INSTS_VALU" in per:
+            # second ceiling: VALU issue, priced per instruction class with the measured issue costs (tools/ubench/valu_issue.hip):
+            # the dynamic FP64 / 64-bit-integer / transcendental-FP64 counts of the PMC passes at 4.3 / 4.3 / 16 cycles, the
+            # rest of SQ_INSTS_VALU at 2.4; SALU instructions issue from the scalar unit beside them and are reported, not priced.
+            f64 = sum(per.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_INT64"))
+            trans = per.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+            rest = max(per["SQ_INSTS_VALU"] - f64 - trans, 0.0)
+            cyc = f64 * CYC_F64 + trans * CYC_TRANS_F64 + rest * CYC_32
+            t_issue = cyc * xs / (N_SIMD * CLOCK_HZ)
             out["issue_roofline"] = {"bound": "valu_issue", "valu_wave_instructions_per_crossing": per["SQ_INSTS_VALU"],
+                                     "fp64_and_int64_per_crossing": f64, "trans_f64_per_crossing": trans, "other_valu_per_crossing": rest,
+                                     "salu_per_crossing": per.get("SQ_INSTS_SALU"),
+                                     "cycles_per_instruction": {"fp64_int64": CYC_F64, "trans_f64": CYC_TRANS_F64, "other": CYC_32,
+                                                                "source": "tools/ubench/valu_issue.hip at 4 waves per SIMD, profiles/r03_tiled_log.md"},
+                                     "measured_avg_cycles_per_valu_instruction": (4.0 * per["SQ_ACTIVE_INST_VALU"] / per["SQ_INSTS_VALU"]) if "SQ_ACTIVE_INST_VALU" in per else None,
                                      "ideal_issue_ms": t_issue * 1e3, "measured_ms": k_ms, "frac": t_issue / (k_ms * 1e-3),
-                                     "peak": "%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction" % (N_SIMD, CLOCK_HZ / 1e9),
-                                     "source": "profiles/r02_pmc.json (SQ_INSTS_VALU summed over all tile_* kernels)"}
+                                     "peak": "%d SIMDs x %.1f GHz" % (N_SIMD, CLOCK_HZ / 1e9),
+                                     "source": PMC_FILE + " (dynamic counts summed over all tile_* kernels of this command)"}
         if world == 1 and not args.no_cpu_baseline:
             sample_prob = make_benchmark_problem(args.grid, density=args.density, n_photons=int(args.cpu_sample), n_iter=1)
             out["cpu_baseline"] = cpu_baseline(sample_prob, int(args.cpu_sample))

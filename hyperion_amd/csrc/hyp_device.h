@@ -111,8 +111,10 @@ struct alignas(16) OctCell {
 };
 
 // Slots of the scalar tail that follows the per-cell accumulators.
+// TAIL_RANK_ERROR: never written on the device; a rank of a sharded run that failed adds 1 there before the all-reduce
+// (hyperion_amd/distributed.py, hyp_run.cpp), so the sum tells every rank.
 enum { TAIL_ENERGY = 0, TAIL_KILLED_GEO = 1, TAIL_KILLED_INT = 2, TAIL_CROSSINGS = 3,
-       TAIL_INTERACTIONS = 4, TAIL_SIZE = 8 };
+       TAIL_INTERACTIONS = 4, TAIL_RANK_ERROR = 5, TAIL_SIZE = 8 };
 
 enum { ERR_NONE = 0, ERR_NU_RANGE = 1, ERR_NOT_IN_CELL = 2, ERR_NEGATIVE_T = 3, ERR_RAY_GRID = 4, ERR_INTERNAL = 5 };
 

@@ -229,15 +229,16 @@ struct hyp_engine {
     int tile_split = 1;
     int tile_ring = 0;              // option: walk workgroups take their packets from an LDS ring fed by a loader wave (RecRing; tuning builds only)
     int last_tile_ring = 0;
-    // live timing of the dominant kernel (bench.py's roofline): HIP events around every tile_walk launch, on its own stream
-    int tile_time_walk = 1;
+    // option (off): live timing of the dominant kernel for bench.py's roofline -- HIP events around every tile_walk launch on its
+    // own stream and a device synchronisation at the end of the iteration; bench.py switches it on for one extra step
+    int tile_time_walk = 0;
     std::vector<hipEvent_t> walk_events;
     double last_walk_ms = 0.0;
     int last_walk_launches = 0;
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 3 << 21, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -579,7 +580,8 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
         T.n_bricks = T.nbx * T.nby * T.nbz;
     }
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
-    long long slots = std::min<long long>(h->tile_slots, (long long)n_local);
+    const long long want_slots = h->tile_slots > 0 ? h->tile_slots : (P.grid_type == 2 ? 3ll << 22 : 3ll << 21);
+    long long slots = std::min<long long>(want_slots, (long long)n_local);
     if (slots < 65536) n_pools = 1;
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
@@ -2406,6 +2408,7 @@ int hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *s
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->d_accum + h->n_elem, sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    if (tail[TAIL_RANK_ERROR] != 0.0) return h->set_error("another rank reported an engine error");
     hyp_iter_stats st;
     std::memset(&st, 0, sizeof st);
     st.energy_current = tail[TAIL_ENERGY];
@@ -2554,6 +2557,10 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_slots") *value = h->tile_slots;
     else if (n == "tile_task") *value = h->tile_task;
     else if (n == "tile_pools") *value = h->tile_pools;
+    else if (n == "lucy_block_doubles") *value = (int64_t)h->block_doubles;
+    else if (n == "lucy_flag_index") *value = (int64_t)(h->n_elem + TAIL_RANK_ERROR);
+    else if (n == "image_block_doubles") *value = (int64_t)(h->d_img_accum ? h->img_accum_n : (size_t)TAIL_SIZE);
+    else if (n == "image_flag_index") *value = (int64_t)((h->d_img_accum ? h->img_accum_n - TAIL_SIZE : (size_t)0) + TAIL_RANK_ERROR);
     else if (n == "tile_split") *value = h->tile_split;
     else if (n == "tile_ring") *value = h->tile_ring;
     else if (n == "last_tile_ring") *value = h->last_tile_ring;
@@ -2750,6 +2757,7 @@ int hyp_final_finish(hyp_handle h, hyp_iter_stats *stats)
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->hp.tail, sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    if (tail[TAIL_RANK_ERROR] != 0.0) return h->set_error("another rank reported an engine error");
     hyp_iter_stats st;
     std::memset(&st, 0, sizeof st);
     st.energy_current = tail[TAIL_ENERGY];
@@ -2847,6 +2855,7 @@ int hyp_raytracing_finish(hyp_handle h, hyp_iter_stats *stats)
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    if (tail[TAIL_RANK_ERROR] != 0.0) return h->set_error("another rank reported an engine error");
     hyp_iter_stats st;
     std::memset(&st, 0, sizeof st);
     st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];
@@ -2960,6 +2969,7 @@ int hyp_mono_finish(hyp_handle h, hyp_iter_stats *stats)
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
+    if (tail[TAIL_RANK_ERROR] != 0.0) return h->set_error("another rank reported an engine error");
     hyp_iter_stats st = h->mono_stats;
     st.energy_current = tail[TAIL_ENERGY];
     st.killed_geo = (uint64_t)tail[TAIL_KILLED_GEO]; st.killed_int = (uint64_t)tail[TAIL_KILLED_INT];

@@ -26,10 +26,10 @@
 #define HYP_OTILE_OCC 4          // waves per SIMD the register budget is set for (two 512-thread workgroups per CU)
 #endif
 #ifndef HYP_OTILE_SERVICE
-#define HYP_OTILE_SERVICE 16      // lanes that must wait before a wave runs its service phase
+#define HYP_OTILE_SERVICE 24      // lanes that must wait before a wave runs its service phase (8 / 16 / 24 / 32: 118.9 / 119.1 / 114.2 / - ms at 4 steps)
 #endif
 #ifndef HYP_OTILE_STEPS
-#define HYP_OTILE_STEPS 4         // cell steps between two scheduling decisions of a wave
+#define HYP_OTILE_STEPS 8         // cell steps between two scheduling decisions of a wave (2 / 4 / 8: 125.5 / 119.1 / 108.9 ms; 8 with 24 lanes: 103.2)
 #endif
 #define OT_HIST 256               // clusters whose packet counts a task collects in LDS (the others: global atomics)
 

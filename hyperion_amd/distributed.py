@@ -11,9 +11,10 @@ needed.
 Error agreement: a device error (frequency outside the dust table, packet emitted
 outside the grid, negative t in find_wall) can hit one rank only, because it
 depends on that rank's packet ids.  The reference stops every rank through
-``error()``; here the ranks agree on a flag (one MAX all-reduce of a single int)
-before the data collective, so that nobody waits in ``all_reduce`` for a rank
-that has raised.
+``error()``; here the flag travels IN the data collective: a spare slot of the
+block's scalar tail (``TAIL_RANK_ERROR``) is 1 on a rank in error, the sum is
+non-zero on every rank, and ``finish`` raises everywhere -- nobody waits in
+``all_reduce`` for a rank that has raised, and there is no second collective.
 """
 from __future__ import annotations
 
@@ -34,38 +35,63 @@ def _try(fn, *args, **kw):
     return None
 
 
-def _collective(acc_getter, world_size, all_reduce, force, error=None, agree=None):
-    """Sum the accumulator block over the ranks.  `acc_getter()` returns the tensor alias of the
-    device block, or raises the engine's error; `error` is an exception the launch already raised on
-    this rank.  `agree(flag) -> max over ranks` (default: a MAX all-reduce through torch.distributed)."""
+def _collective(engine, name, world_size, all_reduce, force, error=None, agree=None, timing=None):
+    """Sum the accumulator block of iteration kind `name` ('lucy', 'final', 'raytracing', 'mono') over the ranks.
+    `engine.<name>_accumulators_tensor()` returns the tensor alias of the device block (it waits for the kernels), or
+    raises the engine's error; `error` is an exception the launch already raised on this rank.
+
+    ONE collective: where the engine names a spare slot in the block's scalar tail
+    (`engine.flag_index(name)`), a rank in error adds 1 there (to a zero block of the same length if it has none) and
+    raises after the sum; the `finish` call of the other ranks finds the slot non-zero and raises too.  Adapters without
+    that slot agree through `agree(flag) -> max over ranks` first.  `timing` (dict) receives seconds spent waiting for the
+    kernels and in the collective."""
+    import time
     if world_size == 1 and all_reduce is None and not force:
         if error is not None:
             raise error
         return False
+    t0 = time.perf_counter()
     err = error
     acc = None
     if err is None:
         try:
-            acc = acc_getter()
+            acc = getattr(engine, name + "_accumulators_tensor")()
         except Exception as e:        # EngineError of this rank: tell the others before raising
             err = e
-    if all_reduce is None:
+    t1 = time.perf_counter()
+    flag_index = engine.flag_index(name) if hasattr(engine, "flag_index") else None
+    if flag_index is not None:
+        if acc is None:
+            acc = engine.zero_block(name)
+        if err is not None:
+            acc[flag_index] += 1.0
+    elif all_reduce is not None:
+        if agree is not None:
+            if agree(1 if err is not None else 0):
+                raise err if err is not None else RuntimeError("another rank reported an engine error")
+        elif err is not None:
+            raise err       # no way to tell the other ranks: they wait in all_reduce (pass `agree`)
+    else:
         import torch
         import torch.distributed as dist
         flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cuda")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         if int(flag.item()):
             raise err if err is not None else RuntimeError("another rank reported an engine error")
+    if all_reduce is None:
+        import torch
+        import torch.distributed as dist
         dist.all_reduce(acc, op=dist.ReduceOp.SUM)
         # the engine reads the block on its own HIP stream: wait for RCCL's stream
-        torch.cuda.synchronize()
+        if acc.is_cuda:
+            torch.cuda.synchronize()
     else:
-        if agree is not None:
-            if agree(1 if err is not None else 0):
-                raise err if err is not None else RuntimeError("another rank reported an engine error")
-        elif err is not None:
-            raise err
         all_reduce(acc)
+    if timing is not None:
+        timing["t_kernel_s"] = t1 - t0
+        timing["t_collective_s"] = time.perf_counter() - t1
+    if err is not None:
+        raise err
     return True
 
 
@@ -75,20 +101,31 @@ def lucy_iteration_sharded(engine, n_total, iteration, rank=0, world_size=1, all
 
     `engine` provides lucy_launch / lucy_accumulators_tensor / lucy_finish
     (hyperion_amd.Engine); `all_reduce(tensor)` sums in place across ranks
-    (default ``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI)."""
+    (default ``torch.distributed.all_reduce``; backend "nccl" is RCCL over xGMI).
+    The returned stats carry where this rank's time went: t_launch_s (host side of the launches), t_kernel_s (waiting
+    for the propagation), t_collective_s, t_finish_s."""
+    import time
     first, n_local = shard_range(n_total, rank, world_size)
+    t0 = time.perf_counter()
     err = _try(engine.lucy_launch, first, n_local, iteration)
-    if not _collective(engine.lucy_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree):
+    t1 = time.perf_counter()
+    timing = {}
+    if not _collective(engine, "lucy", world_size, all_reduce, force_collective, error=err, agree=agree, timing=timing):
         engine.lucy_accumulators()           # no collective: no torch needed
+        timing = {"t_kernel_s": time.perf_counter() - t1, "t_collective_s": 0.0}
+    t2 = time.perf_counter()
     out, stats = engine.lucy_finish(want_output=want_output)
     stats["n_packets"] = n_total
+    stats["t_launch_s"] = t1 - t0
+    stats.update(timing)
+    stats["t_finish_s"] = time.perf_counter() - t2
     return out, stats
 
 
 def final_iteration_sharded(engine, n_total, rank=0, world_size=1, all_reduce=None, force_collective=False, agree=None):
     first, n_local = shard_range(n_total, rank, world_size)
     err = _try(engine.final_launch, first, n_local)
-    if not _collective(engine.final_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree):
+    if not _collective(engine, "final", world_size, all_reduce, force_collective, error=err, agree=agree):
         engine.final_accumulators()
     res, stats = engine.final_finish()
     stats["n_packets"] = n_total
@@ -103,7 +140,7 @@ def raytracing_iteration_sharded(engine, n_sources, n_dust, rank=0, world_size=1
     for which, n_total in ((0, n_sources), (1, n_dust)):
         first, n_local = shard_range(n_total, rank, world_size)
         err = err or _try(engine.raytracing_launch, which, first, n_local, n_total, zero_first=(which == 0 and rank > 0))
-    _collective(engine.raytracing_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree)
+    _collective(engine, "raytracing", world_size, all_reduce, force_collective, error=err, agree=agree)
     res, stats = engine.raytracing_finish()
     stats["n_packets"] = n_sources + n_dust
     return res, stats
@@ -122,7 +159,7 @@ def mono_iteration_sharded(engine, n_sources, n_dust, n_frequencies, rank=0, wor
             if err is None:
                 err = _try(engine.mono_launch, which, inu, first, n_local, n_total, zero_first=first_launch)
             first_launch = False
-    _collective(engine.mono_accumulators_tensor, world_size, all_reduce, force_collective, error=err, agree=agree)
+    _collective(engine, "mono", world_size, all_reduce, force_collective, error=err, agree=agree)
     res, stats = engine.mono_finish()
     stats["n_packets"] = (n_sources + n_dust) * n_frequencies
     return res, stats

@@ -191,6 +191,17 @@ class Engine:
         ptr, n = self.lucy_accumulators()
         return torch.as_tensor(_DeviceBlock(ptr, n), device="cuda:%d" % self.device)
 
+    # -- sharded iterations: the error flag of a rank rides in the block's scalar tail (hyperion_amd.distributed) --------
+    def flag_index(self, name):
+        """Index (in doubles) of the TAIL_RANK_ERROR slot in the accumulator block of iteration kind `name`."""
+        return self.get_option("lucy_flag_index" if name == "lucy" else "image_flag_index")
+
+    def zero_block(self, name):
+        """What a rank without results contributes to the collective: zeros of the block's length."""
+        import torch
+        n = self.get_option("lucy_block_doubles" if name == "lucy" else "image_block_doubles")
+        return torch.zeros(n, dtype=torch.float64, device="cuda:%d" % self.device)
+
     def lucy_finish(self, want_output=True):
         out = np.empty(self.shape, dtype=np.float64) if want_output else None
         st = IterStats()

@@ -155,3 +155,61 @@ def test_two_rank_sharded_monochromatic_iteration_equals_single_process(tmp_path
     o.close()
     assert res[0]["sed"].max() > 0
     np.testing.assert_allclose(r0["sed"], res[0]["sed"], rtol=1e-12, atol=1e-14 * res[0]["sed"].max())
+
+
+# --- error agreement inside the ONE collective: the flag rides in the tail of the block ------------------------------------
+
+class FlaggedEngine(OracleAsEngine):
+    """OracleAsEngine + the engine's spare tail slot for a rank's error (Engine.flag_index / zero_block) and, like
+    hyp_lucy_finish, a finish that refuses when the summed slot is non-zero.  `fail` makes this rank's launch raise."""
+
+    def __init__(self, prob, fail):
+        super().__init__(prob)
+        self.fail = fail
+        self.n_collectives = 0
+
+    def lucy_launch(self, first, n_local, iteration):
+        if self.fail:
+            raise RuntimeError("photon frequency is outside the range defined for the dust optical properties")
+        super().lucy_launch(first, n_local, iteration)
+
+    def flag_index(self, name):
+        return self.n + 5            # TAIL_RANK_ERROR
+
+    def zero_block(self, name):
+        self.t = torch.zeros(self.n + 8, dtype=torch.float64)
+        return self.t
+
+    def lucy_finish(self, want_output=True):
+        if self.t[self.n + 5] != 0:
+            raise RuntimeError("another rank reported an engine error")
+        return super().lucy_finish(want_output)
+
+
+def _flag_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = FlaggedEngine(ragged_grid_problem(), fail=(rank == 1))
+
+    def all_reduce(t):
+        eng.n_collectives += 1
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    msg = "no error"
+    try:
+        lucy_iteration_sharded(eng, 4001, 1, rank, world, all_reduce=all_reduce)
+    except RuntimeError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, "flag%d.txt" % rank), "w") as f:
+        f.write("%d|%s" % (eng.n_collectives, msg))
+    dist.destroy_process_group()
+
+
+def test_error_on_one_rank_reaches_every_rank_through_the_one_collective(tmp_path):
+    """Rank 1 fails in its launch: it still takes part in the all-reduce (a zero block with the flag slot set), raises its own
+    error afterwards, and rank 0 -- whose launch was fine -- is told by the summed flag in finish.  One collective each."""
+    mp.spawn(_flag_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = (tmp_path / "flag0.txt").read_text().split("|")
+    r1 = (tmp_path / "flag1.txt").read_text().split("|")
+    assert r0 == ["1", "another rank reported an engine error"]
+    assert r1[0] == "1" and "outside the range defined" in r1[1]

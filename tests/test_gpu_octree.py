@@ -217,3 +217,42 @@ def test_otile_matches_persistent_at_scale():
     for k in INT_KEYS:
         assert sa[k] == sb[k], (k, sa, sb)
     assert_parity(a, b)
+
+
+def test_config4_at_baseline_packet_count():
+    """BASELINE configs[3] as BASELINE.json states it: depth-7 octree, 512 x 512 Stokes detector, 1e8 packets in the Lucy
+    iteration and 1e8 in the imaging iteration (deferred peel-off: ~2.3e8 events through a 16 Mi-slot buffer, >= 10 rounds
+    with packets set aside and id ranges returned between them).  Size-independent properties: every packet accounted for,
+    absorbed energy = what the cells hold, image sum = SED sum; and the many-round deferred schedule equals the inline
+    peel-off on a 1e6-packet subsample forced through as many rounds."""
+    n = 100_000_000
+    p = make_octree_problem(max_level=7)
+    eng = hyperion_amd.Engine(p)
+    se, st = eng.lucy_iteration(n, 1)
+    assert eng.get_option("last_lucy_mode") == 1            # the cluster-tiled schedule
+    assert st["n_packets"] == n and st["energy_current"] == pytest.approx(n, rel=1e-12)      # unit-energy packets, none lost
+    w = p.density * p.volumes
+    assert (se * w).sum() == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
+    assert st["killed_geo"] / n < 5e-3 and st["killed_int"] == 0
+    assert 35 < st["crossings"] / n < 50
+    res, sf = eng.final_iteration(n)
+    rounds, events = eng.get_option("last_defer_rounds"), eng.get_option("last_defer_events")
+    assert rounds >= 10 and events > 2 * n, (rounds, events)
+    assert sf["n_packets"] == n and sf["energy_current"] == pytest.approx(n, rel=1e-12)
+    img, sed = res[0]["img"], res[0]["sed"]
+    assert img.shape == (4, 1, 1, 512, 512, 1)
+    assert img[0].sum() == pytest.approx(sed[0].sum(), rel=1e-9)
+    assert 0.05 * LSUN < sed[0].sum() < 1.2 * LSUN
+    # the same schedule, as many rounds, against the inline peel-off on 1e6 packets
+    m = 1_000_000
+    eng.set_option("peel_events", 160 * 1024)
+    ra, sa = eng.final_iteration(m)
+    assert eng.get_option("last_defer_rounds") >= 10
+    eng.set_option("defer_peel", 0)
+    rb, sb = eng.final_iteration(m)
+    eng.close()
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    for ga, gb in zip(ra, rb):
+        for name in gb:
+            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)

@@ -244,3 +244,24 @@ def test_vtile_matches_persistent_at_scale():
     for k in INT_KEYS:
         assert sa[k] == sb[k], (k, sa, sb)
     assert_parity(a, b)
+
+
+def test_config5_at_baseline_packet_count():
+    """BASELINE configs[4] as BASELINE.json states it: the 100 000-site tessellation, two anisotropic polarising species,
+    point + external source, 1e8 packets (cluster-tiled schedule, ~280 generations).  Nothing killed, every packet accounted
+    for, absorbed energy = what the cells hold, and the interaction count per packet of the same medium at 1e7 packets
+    (uniform density: it does not depend on the packet count beyond noise)."""
+    from cases import voronoi_big_problem
+    n = 100_000_000
+    prob = voronoi_big_problem(n_photons=n)
+    eng = hyperion_amd.Engine(prob)
+    se, st = eng.lucy_iteration(n, 1)
+    assert eng.get_option("last_lucy_mode") == 1 and eng.get_option("last_generations") > 50
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0 and st["n_packets"] == n
+    w = prob.density * prob.vor_volume[None]
+    tot = np.array(st["energy_abs_tot"][:prob.n_dust])
+    np.testing.assert_allclose((se * w).sum(axis=1), tot, rtol=1e-10)
+    _, s7 = eng.lucy_iteration(10_000_000, 2)
+    eng.close()
+    assert st["interactions"] / n == pytest.approx(s7["interactions"] / 1e7, rel=2e-3)
+    assert st["crossings"] / n == pytest.approx(s7["crossings"] / 1e7, rel=2e-3)

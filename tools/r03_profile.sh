@@ -1,0 +1,35 @@
+#!/bin/bash
+# Round-3 rocprofv3 capture on the GPU box: for each workload one kernel-trace pass and one --pmc pass per counter set
+# (counters only alongside --kernel-trace), condensed on the box by tools/summarize_r03.py into
+# gpurun_out/r03prof/<workload>_summary.md and r03_pmc.json (copy both into profiles/).
+#   usage: bash tools/r03_profile.sh [workload ...]      workloads: car car1 oct_lucy oct_img vor
+set -u
+REPO=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$REPO/gpurun_out/r03prof; mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+WL=${@:-car car1 oct_lucy oct_img vor}
+SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
+      "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
+      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_THREAD_CYCLES_VALU"
+      "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
+for w in $WL; do
+  case $w in
+    car)  CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" ;;
+    car1) CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --option tile_pools=1" ;;
+    *)    CMD="python $REPO/tools/r03_workload.py $w ${PACKETS:-1e8}" ;;
+  esac
+  D=$OUT/raw_$w; rm -rf $D; mkdir -p $D
+  echo "== $w: kernel trace"
+  timeout 900 rocprofv3 --kernel-trace --stats -d $D/trace -o t -- $CMD > $D/trace.log 2>&1
+  grep -h "PROFILE_TOTALS\|^{" $D/trace.log | tail -1 | cut -c1-300
+  if [ "$w" != "car1" ]; then
+    i=0
+    for set in "${SETS[@]}"; do
+      i=$((i+1))
+      timeout 900 rocprofv3 --pmc $set --kernel-trace -d $D/pmc_$i -o pmc -- $CMD > $D/pmc_$i.log 2>&1 || echo "pmc pass '$set' failed"
+    done
+  fi
+  python $REPO/tools/summarize_r03.py $w $D $OUT && rm -rf $D/trace $D/pmc_*/
+done
+ls -la $OUT
