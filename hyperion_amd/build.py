@@ -93,19 +93,24 @@ def build_native_driver(force=False, verbose=False):
     # libstdc++ is linked statically and the system directories are searched first at link time: the prefix that has
     # libhdf5 (conda) may carry an older libstdc++ than the HIP runtime needs; at run time RUNPATH only serves the
     # executable's own two dependencies
-    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(prefix, "include"), src, "-o", DRIVER + ".tmp",
-           "-L" + CSRC, "-lhyperion_amd", os.path.join(prefix, "lib", "libhdf5.so"), "-static-libstdc++", "-static-libgcc",
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-I" + os.path.join(prefix, "include"), "-isystem", os.path.join(rocm, "include"), src, "-o", DRIVER + ".tmp",
+           "-L" + CSRC, "-lhyperion_amd", os.path.join(prefix, "lib", "libhdf5.so"),
+           "-L" + os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-static-libstdc++", "-static-libgcc",
            "-Wl,-rpath-link,/usr/lib/x86_64-linux-gnu", "-Wl,-rpath-link,/opt/rocm/lib", "-Wl,--enable-new-dtags",
            "-Wl,-rpath,$ORIGIN/../csrc", "-Wl,-rpath," + os.path.join(prefix, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
     os.replace(DRIVER + ".tmp", DRIVER)
+    # scripts/hyperion:44-92 starts hyperion_<grid> or, with -m N, `mpirun -n N hyperion_<grid>_mpi`: the same executable
+    # (it is a rank of N when the launcher's environment says so)
     for suffix in GRID_SUFFIXES:
-        link = os.path.join(BIN, "hyperion_" + suffix)
-        if os.path.lexists(link):
-            os.remove(link)
-        os.symlink("hyperion_amd_run", link)
+        for name in ("hyperion_" + suffix, "hyperion_" + suffix + "_mpi"):
+            link = os.path.join(BIN, name)
+            if os.path.lexists(link):
+                os.remove(link)
+            os.symlink("hyperion_amd_run", link)
     return DRIVER
 
 

@@ -148,11 +148,23 @@ __device__ __forceinline__ bool geo_place(const DProblem &P, const Walls &W, con
     return true;
 }
 
-// grid_geometry_cartesian_3d.f90:330-381
+// grid_geometry_cartesian_3d.f90:330-381.  The reference locates the position in the three wall arrays (find_cell) and
+// compares the cell it finds with the packet's; only "is it the packet's cell" is used, so the three binary searches
+// (7 dependent reads each at 128 cells) are replaced by the two walls of the packet's own cell: locate() returns i exactly
+// when w[i] <= r < w[i + 1], or r sits on the last wall and i is the last cell; `found` = inside the grid on every axis
+// (find_cell stops at the first axis outside: the result is then false whatever the other axes say, as here).
 __device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Walls &W, const double r[3], const Cell<GEOM_CAR> &c)
 {
-    int act[3] = {0, 0, 0};
-    bool found = find_cell_car(W, r, act);
+    bool found = true, same[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int i = c.ic[a], n = W.n[a];
+        const double lo = W.w[a][0], hi = W.w[a][n];
+        found = found && (r[a] >= lo) && (r[a] <= hi);
+        const bool inside = i >= 0 && i < n;          // a packet that has left the grid is not asked
+        const double wl = W.w[a][inside ? i : 0], wu = W.w[a][inside ? i + 1 : 1];
+        same[a] = inside && ((r[a] >= wl && r[a] < wu) || (r[a] == hi && i == n - 1));
+    }
     const double thr = 1e-3;
     if (c.ow[0] | c.ow[1] | c.ow[2]) {
         bool ok = true;
@@ -162,11 +174,11 @@ __device__ __forceinline__ bool geo_in_correct_cell(const DProblem &P, const Wal
             double wl = W.w[a][i], wu = W.w[a][i + 1];
             if (c.ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
             else if (c.ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
-            else ok = ok && found && act[a] == i;
+            else ok = ok && found && same[a];
         }
         return ok;
     }
-    return found && act[0] == c.ic[0] && act[1] == c.ic[1] && act[2] == c.ic[2];
+    return found && same[0] && same[1] && same[2];
 }
 
 // find_wall + insert_t, grid_geometry_cartesian_3d.f90:424-521.  The six

@@ -6,7 +6,11 @@
 // sequence of `program main` (src/main/main.f90:74-344) on the HIP engine through the C ABI of
 // include/hyperion_amd.h, and writes the .rtout the reference's ModelOutput reads.  No Python, no h5py: libhdf5 (C API)
 // and libhyperion_amd.so only, so the reference's unmodified scripts/hyperion:92 finds a drop-in on PATH.
-// One process, one GPU (the reference's `_mpi` variants: use `python -m hyperion_amd -m N`).
+// Under the `_mpi` names (hyperion_car_mpi, ...: what scripts/hyperion:62-92 starts with `mpirun -n N`) or whenever the
+// launcher's environment names a rank (RANK / OMPI_COMM_WORLD_RANK / PMI_RANK / SLURM_PROCID), the process is one rank of
+// N, one GPU each: packets are split by id range, ONE ncclAllReduce (RCCL over xGMI, rccl.h) of the accumulator block per
+// iteration replaces mp_collect_physical_arrays / mp_collect_images (src/mpi/mpi_routines.f90:272-361), every rank runs the
+// epilogue, rank 0 alone writes the output.  `--ranks N` starts the N ranks itself (no MPI installation needed).
 //
 // What is read, and the defaults, follow src/main/setup_rt.f90:38-302 (root attributes, /Output),
 // src/grid/grid_geometry_*.f90 (geometry), src/dust/dust_type_4elem.f90:78-293 (dust), src/sources/source_type.f90:102-322
@@ -14,6 +18,11 @@
 // what is written follows main.f90:130-344, src/grid/grid_generic.f90:29-130 and image_type.f90:608-788.
 // Failure convention of the reference: message on stderr, the output lacks `date_ended`, non-zero exit status.
 #include <hdf5.h>
+#define __HIP_PLATFORM_AMD__ 1
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 
 #include <algorithm>
 #include <cmath>
@@ -807,6 +816,179 @@ void check(int rc, hyp_handle h)
     if (rc != 0) { const char *m = hyp_last_error(h); throw Fail(m && *m ? m : "engine error"); }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Ranks: one process per GPU, RCCL for the one collective of each iteration (src/mpi/mpi_routines.f90:272-361)
+// ---------------------------------------------------------------------------------------------------------------
+struct Comm {
+    int rank = 0, size = 1, local_rank = -1;
+    bool on = false;                 // a launcher named a rank (also at size 1: the collective is then executed all the same)
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    double *zero = nullptr; size_t zero_n = 0;
+    std::string id_file;
+
+    static bool env_int(std::initializer_list<const char *> names, int &out)
+    {
+        for (const char *n : names) { const char *v = getenv(n); if (v && *v) { out = atoi(v); return true; } }
+        return false;
+    }
+    void from_env()
+    {
+        on = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, rank);
+        if (on && !env_int({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, size)) size = 1;
+        env_int({"HYP_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, local_rank);
+        if (!on) { rank = 0; size = 1; }
+        if (rank < 0 || rank >= size) throw Fail(fmt("rank %d of %d: inconsistent launcher environment", rank, size));
+    }
+    bool main_process() const { return rank == 0; }
+
+    // The ncclUniqueId travels through a file next to the output (the ranks of one node share it): rank 0 writes
+    // {magic, parent pid, id} to a temporary name and renames it; the others wait for a file whose parent pid is theirs
+    // (a stale file of another run is ignored).  `abort_msg`: rank 0 could not start -- the others leave with it.
+    struct IdFile { char magic[8]; long long ppid; int aborted; char msg[256]; ncclUniqueId id; };
+    // what the ranks of one launch have in common: the launcher's pid (--ranks sets HYP_LAUNCHER_PID; mpirun / torchrun: the parent)
+    static long long launch_id() { const char *v = getenv("HYP_LAUNCHER_PID"); return v && *v ? atoll(v) : (long long)getppid(); }
+    void publish(const IdFile &f) const
+    {
+        const std::string tmp = id_file + ".tmp";
+        FILE *fp = fopen(tmp.c_str(), "wb");
+        if (!fp || fwrite(&f, sizeof f, 1, fp) != 1) { if (fp) fclose(fp); throw Fail("cannot write " + tmp); }
+        fclose(fp);
+        if (rename(tmp.c_str(), id_file.c_str()) != 0) throw Fail("cannot publish " + id_file);
+    }
+    void abort_others(const std::string &why) const
+    {
+        if (!on || size == 1 || rank != 0 || comm) return;
+        IdFile f; std::memset(&f, 0, sizeof f);
+        std::memcpy(f.magic, "HYPNCCL", 8); f.ppid = launch_id(); f.aborted = 1;
+        snprintf(f.msg, sizeof f.msg, "%s", why.c_str());
+        try { publish(f); } catch (...) { }
+    }
+    void init(const std::string &output, int device)
+    {
+        if (!on) return;
+        if (hipSetDevice(device) != hipSuccess) throw Fail("hipSetDevice failed");
+        const char *e = getenv("HYP_NCCL_ID_FILE");
+        id_file = e && *e ? e : output + ".ncclid";
+        IdFile f; std::memset(&f, 0, sizeof f);
+        if (rank == 0) {
+            std::memcpy(f.magic, "HYPNCCL", 8); f.ppid = launch_id();
+            if (ncclGetUniqueId(&f.id) != ncclSuccess) throw Fail("ncclGetUniqueId failed");
+            if (size > 1) publish(f);
+        } else {
+            const double t_end = (double)time(nullptr) + 300.0;
+            for (;;) {
+                FILE *fp = fopen(id_file.c_str(), "rb");
+                bool ok = false;
+                if (fp) { ok = fread(&f, sizeof f, 1, fp) == 1 && !std::memcmp(f.magic, "HYPNCCL", 8) && f.ppid == launch_id(); fclose(fp); }
+                if (ok) break;
+                if ((double)time(nullptr) > t_end) throw Fail("rank 0 did not publish " + id_file + " (ranks must share a launcher and a file system)");
+                usleep(20000);
+            }
+            if (f.aborted) throw Fail(f.msg);
+        }
+        if (ncclCommInitRank(&comm, size, f.id, rank) != ncclSuccess) throw Fail("ncclCommInitRank failed");
+        if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) throw Fail("cannot create the collective's stream");
+        // everybody has read the id once this first collective returns: rank 0 removes the file
+        double *one = nullptr;
+        if (hipMalloc((void **)&one, sizeof(double)) != hipSuccess) throw Fail("hipMalloc failed");
+        (void)hipMemset(one, 0, sizeof(double));
+        sum(one, 1);
+        (void)hipFree(one);
+        if (rank == 0 && size > 1) unlink(id_file.c_str());
+    }
+    void sum(void *ptr, size_t n)
+    {
+        if (ncclAllReduce(ptr, ptr, n, ncclDouble, ncclSum, comm, stream) != ncclSuccess) throw Fail("ncclAllReduce failed");
+        if (hipStreamSynchronize(stream) != hipSuccess) throw Fail("the all-reduce failed");
+    }
+    // [first, first + n) of this rank: static id ranges (hyperion_amd/distributed.py: shard_range)
+    void range(uint64_t n_total, uint64_t &first, uint64_t &n) const
+    {
+        first = n_total * (uint64_t)rank / (uint64_t)size;
+        n = n_total * (uint64_t)(rank + 1) / (uint64_t)size - first;
+    }
+    // Sum the block of the iteration just launched over the ranks.  rc / err: what the launches of this rank returned.  A rank
+    // in error contributes zeros with 1 in the TAIL_RANK_ERROR slot of the block's tail (`flag_opt` / `len_opt` name the
+    // engine options that hold its index and the block's length), raises after the sum; the others are told by `finish`.
+    void collect(hyp_handle h, int rc, int (*accumulators)(hyp_handle, void **, uint64_t *), const char *flag_opt, const char *len_opt)
+    {
+        std::string err;
+        if (rc) { const char *m = hyp_last_error(h); err = m && *m ? m : "engine error"; }
+        void *ptr = nullptr; uint64_t n = 0;
+        if (!rc && accumulators(h, &ptr, &n) != 0) { const char *m = hyp_last_error(h); err = m && *m ? m : "engine error"; rc = 1; }
+        if (!on) { if (rc) throw Fail(err); return; }
+        if (rc) {
+            int64_t len = 0, flag = 0;
+            if (hyp_get_option(h, len_opt, &len) || hyp_get_option(h, flag_opt, &flag)) throw Fail(err);
+            if (zero_n < (size_t)len) { if (zero) (void)hipFree(zero); zero = nullptr; if (hipMalloc((void **)&zero, sizeof(double) * (size_t)len) != hipSuccess) throw Fail(err); zero_n = (size_t)len; }
+            (void)hipMemset(zero, 0, sizeof(double) * (size_t)len);
+            const double one = 1.0;
+            (void)hipMemcpy(zero + flag, &one, sizeof one, hipMemcpyHostToDevice);
+            ptr = zero; n = (uint64_t)len;
+        }
+        sum(ptr, (size_t)n);
+        if (rc) throw Fail(err);
+    }
+    void finalize()
+    {
+        if (zero) (void)hipFree(zero);
+        if (comm) ncclCommDestroy(comm);
+        if (stream) (void)hipStreamDestroy(stream);
+        comm = nullptr; stream = nullptr; zero = nullptr;
+    }
+};
+
+// the iterations through their split entry points (launch on this rank's id range / one all-reduce / finish everywhere)
+void lucy_iteration(hyp_handle h, Comm &c, uint64_t n_total, int it, double *se_out, hyp_iter_stats *st)
+{
+    if (!c.on) { check(hyp_lucy_iteration(h, n_total, it, se_out, st), h); return; }
+    if (n_total == 0) return;
+    uint64_t first, n; c.range(n_total, first, n);
+    c.collect(h, hyp_lucy_launch(h, first, n, it), hyp_lucy_accumulators, "lucy_flag_index", "lucy_block_doubles");
+    check(hyp_lucy_finish(h, se_out, st), h);
+    st->n_packets = n_total;
+}
+
+void final_iteration(hyp_handle h, Comm &c, uint64_t n_total, hyp_iter_stats *st)
+{
+    if (!c.on) { check(hyp_final_iteration(h, n_total, st), h); return; }
+    uint64_t first, n; c.range(n_total, first, n);
+    c.collect(h, hyp_final_launch(h, first, n), hyp_final_accumulators, "image_flag_index", "image_block_doubles");
+    check(hyp_final_finish(h, st), h);
+}
+
+void raytracing_iteration(hyp_handle h, Comm &c, uint64_t n_src, uint64_t n_dust, hyp_iter_stats *st)
+{
+    if (!c.on) { check(hyp_raytracing_iteration(h, n_src, n_dust, st), h); return; }
+    // rank 0 keeps the cubes of the final iteration, the others start from zero: one sum gives final + raytraced flux
+    int rc = 0;
+    const uint64_t tot[2] = {n_src, n_dust};
+    for (int which = 0; which < 2 && !rc; which++) {
+        uint64_t first, n; c.range(tot[which], first, n);
+        rc = hyp_raytracing_launch(h, which, first, n, tot[which], which == 0 && c.rank > 0);
+    }
+    c.collect(h, rc, hyp_raytracing_accumulators, "image_flag_index", "image_block_doubles");
+    check(hyp_raytracing_finish(h, st), h);
+}
+
+void mono_iteration(hyp_handle h, Comm &c, uint64_t n_src, uint64_t n_dust, int n_freq, hyp_iter_stats *st)
+{
+    if (!c.on) { check(hyp_mono_iteration(h, n_src, n_dust, st), h); return; }
+    int rc = 0; bool first_launch = true;
+    const uint64_t tot[2] = {n_src, n_dust};
+    for (int which = 0; which < 2; which++) {
+        uint64_t first, n; c.range(tot[which], first, n);
+        for (int inu = 0; inu < n_freq; inu++) {
+            if (!rc) rc = hyp_mono_launch(h, which, inu, first, n, tot[which], first_launch);
+            first_launch = false;
+        }
+    }
+    c.collect(h, rc, hyp_mono_accumulators, "image_flag_index", "image_block_doubles");
+    check(hyp_mono_finish(h, st), h);
+}
+
 struct Iteration {
     long long index = 0;
     uint64_t killed_geo = 0, killed_int = 0;
@@ -944,7 +1126,7 @@ void write_quantity(hid_t g, const Input &in, const char *name, const std::vecto
     }
 }
 
-int run(const char *input, const char *output, bool overwrite)
+int run(const char *input, const char *output, bool overwrite, Comm &comm)
 {
     const std::string date_started = now_string();
     const double t0 = (double)clock() / CLOCKS_PER_SEC;
@@ -952,7 +1134,7 @@ int run(const char *input, const char *output, bool overwrite)
     printf(" %s\n Hyperion-AMD native driver (C ABI v%d)\n Started on %s\n Input:  %s\n Output: %s\n %s\n", std::string(60, '-').c_str(),
            hyp_abi_version(), date_started.c_str(), input, output, std::string(60, '-').c_str());
     if (access(input, R_OK) != 0) throw Fail(fmt("File does not exist: %s", input));
-    if (access(output, F_OK) == 0) {
+    if (comm.main_process() && access(output, F_OK) == 0) {
         if (!overwrite) throw Fail(fmt("Output file %s already exists (use -f)", output));
         char *ai = realpath(input, nullptr), *ao = realpath(output, nullptr);
         const bool same = ai && ao && strcmp(ai, ao) == 0;
@@ -962,11 +1144,14 @@ int run(const char *input, const char *output, bool overwrite)
     // the input is read and validated BEFORE an existing output is removed: a bad .rtin must not cost the previous result
     Input in;
     read_rtin(input, in);
-    if (access(output, F_OK) == 0) unlink(output);
+    if (comm.main_process() && access(output, F_OK) == 0) unlink(output);
     const hyp_config &cfg = in.P.config;
 
-    // the output exists from the start, date_ended is written last: its presence marks success (main.f90:130-136,338-344)
-    Hid fo(H5Fcreate(output, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT), 0);
+    // the output exists from the start, date_ended is written last: its presence marks success (main.f90:130-136,338-344).
+    // Only rank 0 has a file: the other ranks write the same groups into memory (HDF5 core driver, no backing store).
+    Hid fapl(H5Pcreate(H5P_FILE_ACCESS), 6);
+    if (!comm.main_process()) H5Pset_fapl_core(fapl, (size_t)1 << 24, 0);
+    Hid fo(H5Fcreate(comm.main_process() ? output : fmt("hyperion_amd_rank%d.mem", comm.rank).c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, fapl), 0);
     if (fo < 0) throw Fail(fmt("cannot create output file %s", output));
     Hid root(H5Gopen2(fo, "/", H5P_DEFAULT), 1);
     put_attr_str(root, "date_started", date_started);
@@ -988,12 +1173,15 @@ int run(const char *input, const char *output, bool overwrite)
     H5Fflush(fo, H5F_SCOPE_GLOBAL);
 
     hyp_handle h = nullptr;
-    // one process per GPU: HYP_DEVICE, else the launcher's local rank (torchrun / Open MPI / Slurm), else device 0
-    int device = 0;
-    for (const char *name : {"HYP_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}) {
-        const char *v = getenv(name);
-        if (v && *v) { device = atoi(v); break; }
+    // one process per GPU: HYP_DEVICE, else the launcher's local rank (torchrun / Open MPI / Slurm), else the rank modulo the
+    // devices of the node, else device 0
+    int device = comm.local_rank >= 0 ? comm.local_rank : 0;
+    if (comm.local_rank < 0 && comm.on) {
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) == hipSuccess && nd > 0) device = comm.rank % nd;
     }
+    comm.init(output, device);
+    if (comm.on) printf(" [mpi] rank %d of %d on device %d, RCCL all-reduce of the accumulator block per iteration\n", comm.rank, comm.size, device);
     if (hyp_create(&in.P, device, &h) != 0) { const char *m = hyp_last_error(nullptr); throw Fail(m && *m ? m : "hyp_create failed"); }
     printf(" [main] using random seed = %lld\n", (long long)cfg.seed);
     const size_t plane = (size_t)in.P.n_dust * in.n_cells;
@@ -1009,7 +1197,7 @@ int run(const char *input, const char *output, bool overwrite)
         rec.index = it;
         std::vector<double> se(plane);
         hyp_iter_stats st;
-        check(hyp_lucy_iteration(h, (uint64_t)in.n_initial_photons, (int)it, se.data(), &st), h);
+        lucy_iteration(h, comm, (uint64_t)in.n_initial_photons, (int)it, se.data(), &st);
         if (cfg.count_photons) {
             int64_t inexact = 0;
             if (hyp_get_option(h, "n_photons_inexact", &inexact) == 0 && inexact)
@@ -1072,13 +1260,13 @@ int run(const char *input, const char *output, bool overwrite)
     std::vector<double> freq;
     if (cfg.monochromatic) freq.assign(cfg.frequencies, cfg.frequencies + cfg.n_frequencies);
     printf(" [main] starting final iteration\n");
-    if (cfg.monochromatic) { if (in.P.n_peeled > 0) check(hyp_mono_iteration(h, (uint64_t)in.n_last_photons_sources, (uint64_t)in.n_last_photons_dust, &fst), h); }
-    else if (in.n_last_photons > 0) check(hyp_final_iteration(h, (uint64_t)in.n_last_photons, &fst), h);
+    if (cfg.monochromatic) { if (in.P.n_peeled > 0) mono_iteration(h, comm, (uint64_t)in.n_last_photons_sources, (uint64_t)in.n_last_photons_dust, cfg.n_frequencies, &fst); }
+    else if (in.n_last_photons > 0) final_iteration(h, comm, (uint64_t)in.n_last_photons, &fst);
     else printf("      ------------------ Skipping ------------------\n");
     printf(" [main] exiting final iteration\n");
     if (cfg.raytracing) {
         printf(" [main] starting raytracing iteration\n");
-        check(hyp_raytracing_iteration(h, (uint64_t)in.n_ray_photons_sources, (uint64_t)in.n_ray_photons_dust, &rst), h);
+        raytracing_iteration(h, comm, (uint64_t)in.n_ray_photons_sources, (uint64_t)in.n_ray_photons_dust, &rst);
         printf(" [main] exiting raytracing iteration\n");
     }
     const bool have_cubes = !(cfg.monochromatic && in.P.n_peeled == 0);
@@ -1116,6 +1304,7 @@ int run(const char *input, const char *output, bool overwrite)
         write_image_datasets(g, in, G, in.groups_desc[ig], C, true);
     }
     hyp_destroy(h);
+    comm.finalize();
     put_attr_i32(root, "killed_photons_geo_final", (int32_t)fst.killed_geo);
     put_attr_i32(root, "killed_photons_int_final", (int32_t)fst.killed_int);
     put_attr_i32(root, "killed_photons_geo_raytracing", (int32_t)rst.killed_geo);
@@ -1135,15 +1324,33 @@ int main(int argc, char **argv)
 {
     // main.f90:74-106: [-f] input_file output_file; --check-input parses the input and stops (no GPU needed)
     bool overwrite = false, check_only = false;
+    int n_ranks = 0;
     std::vector<const char *> pos;
     for (int i = 1; i < argc; i++) {
         if (!std::strcmp(argv[i], "-f")) overwrite = true;
         else if (!std::strcmp(argv[i], "--check-input")) check_only = true;
+        else if (!std::strcmp(argv[i], "--ranks") && i + 1 < argc) n_ranks = atoi(argv[++i]);
         else pos.push_back(argv[i]);
     }
-    if ((check_only && pos.size() != 1) || (!check_only && pos.size() != 2)) {
-        fprintf(stderr, "Usage: %s [-f] input_file output_file\n", argv[0]);
+    if ((check_only && pos.size() != 1) || (!check_only && pos.size() != 2) || n_ranks < 0) {
+        fprintf(stderr, "Usage: %s [-f] [--ranks N] input_file output_file\n", argv[0]);
         return 2;
+    }
+    // --ranks N: be the launcher -- N ranks of this executable on this node, one GPU each (what `mpirun -n N hyperion_car_mpi`
+    // is to the reference, scripts/hyperion:62-92), started before anything touches HIP or HDF5
+    std::vector<pid_t> children;
+    if (n_ranks > 0 && !check_only) {
+        setenv("WORLD_SIZE", std::to_string(n_ranks).c_str(), 1);
+        setenv("HYP_LAUNCHER_PID", std::to_string((long long)getpid()).c_str(), 1);
+        int my_rank = 0;
+        for (int r = 1; r < n_ranks; r++) {
+            pid_t pid = fork();
+            if (pid < 0) { fprintf(stderr, " ERROR: cannot start rank %d\n", r); return 1; }
+            if (pid == 0) { my_rank = r; children.clear(); break; }
+            children.push_back(pid);
+        }
+        setenv("RANK", std::to_string(my_rank).c_str(), 1);
+        setenv("LOCAL_RANK", std::to_string(my_rank).c_str(), 1);
     }
     H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);      // errors are reported through Fail, not HDF5's stack dump
     try {
@@ -1167,11 +1374,25 @@ int main(int argc, char **argv)
                        in.groups_desc[i].uncertainties, in.groups_desc[i].compute_stokes, in.groups_desc[i].use_filters, in.groups[i].io_bytes);
             return 0;
         }
-        return run(pos[0], pos[1], overwrite);
     } catch (const std::exception &e) {
-        // the reference's error(): message on stderr, the output (if any) has no date_ended
         fprintf(stderr, " ERROR: %s\n", e.what());
-        fprintf(stderr, "An error occurred, and the run did not complete\n");
         return 1;
     }
+    Comm comm;
+    int rc = 0;
+    try {
+        comm.from_env();
+        rc = run(pos[0], pos[1], overwrite, comm);
+    } catch (const std::exception &e) {
+        // the reference's error(): message on stderr, the output (if any) has no date_ended
+        comm.abort_others(e.what());
+        fprintf(stderr, " ERROR: %s\n", e.what());
+        fprintf(stderr, "An error occurred, and the run did not complete\n");
+        rc = 1;
+    }
+    for (pid_t pid : children) {        // --ranks: the launcher's status is the worst of its ranks
+        int st = 0;
+        if (waitpid(pid, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = rc ? rc : 1;
+    }
+    return rc;
 }

@@ -334,14 +334,24 @@ int  hyp_convergence_value(hyp_handle h, double percentile, double *value, int *
 int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
 /* tuning knobs (environment-independent): name in {"interact_threshold",
  * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
- * (-1 auto, 0 persistent kernel with global atomics, 1 brick-tiled),
- * "tile_slots", "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "final_interact_threshold" /
+ * (-1 auto, 0 persistent kernel with global atomics, 1 tiled: bricks of a Cartesian grid, hyp_tiled.h; clusters of Voronoi
+ * cells, hyp_vtile.h; runs of sibling subtrees of an octree, hyp_otile.h),
+ * "tile_slots" (0: 3 << 21, octree 3 << 22), "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "tile_park",
+ * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb" (most cells per Voronoi / octree cluster; LDS budget of a walk workgroup),
+ * "tile_time_walk" (1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches"; off by
+ * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only),
+ * "final_interact_threshold" /
  * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
  * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer), "oct_neighbours" (0: the
  * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (can only be
- * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "last_defer_rounds",
- * "last_defer_events", "last_walk_us", "pda_last_cells / _outer / _sweeps" and "n_photons_inexact" (a packet visited more
- * cells than its visited set holds: the n_photons of the last iteration are an upper bound). */
+ * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
+ * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more
+ * cells than its visited set holds: the n_photons of the last iteration are an upper bound) and, for sharded runs, the
+ * geometry of the blocks that hyp_*_accumulators hand out: "lucy_block_doubles" / "image_block_doubles" (their lengths) and
+ * "lucy_flag_index" / "image_flag_index" -- the index of a spare slot of the block's scalar tail that is never written on
+ * the device: a rank whose launch failed adds 1 there before the all-reduce (to a zero block of the same length), and
+ * hyp_*_finish on every rank returns "another rank reported an engine error" when the summed slot is not zero.  That is
+ * mp_join's role (src/mpi/mpi_routines.f90) without a second collective. */
 int  hyp_set_option(hyp_handle h, const char *name, int64_t value);
 int  hyp_get_option(hyp_handle h, const char *name, int64_t *value);
 

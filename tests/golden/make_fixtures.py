@@ -363,7 +363,7 @@ def pinte_fixture(tmp):
     from hyperion.dust import SphericalDust
     from hyperion.util.constants import au, msun, rsun, sigma
     dl = None
-    for tau in (1000, 10000, 100000):
+    for tau in (1000, 10000, 100000, 1000000):
         m = AnalyticalYSOModel()
         m.star.radius = 2. * rsun
         m.star.temperature = 4000.
@@ -435,7 +435,7 @@ def pinte_images_fixture(tmp):
     from hyperion.model import AnalyticalYSOModel
     from hyperion.dust import SphericalDust
     from hyperion.util.constants import au, msun, rsun, sigma
-    for tau in (1000, 10000, 100000):
+    for tau in (1000, 10000, 100000, 1000000):
         m = AnalyticalYSOModel()
         m.star.radius = 2. * rsun
         m.star.temperature = 4000.

@@ -36,7 +36,7 @@ def test_all_five_iterations_match_reference_golden(name):
     assert (gold * w).sum() == pytest.approx((big * w).sum(), rel=0.02)
 
 
-@pytest.mark.parametrize("tau", ["1000", "100000"])
+@pytest.mark.parametrize("tau", ["1000", "100000", "1000000"])
 def test_pinte_benchmark_run_matches_reference_golden(tau):
     """The whole run() sequence on the GPU for the reference's Pinte benchmark model (cylindrical polar grid,
     stellar sphere, polarising dust, Lucy iterations with the convergence test and the modified random walk,
@@ -62,7 +62,7 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     sel = (sg > 0) & (I > 1e-3 * I.max())
     zs = (g - I)[sel] / sg[sel]
     well = sg[sel] < 0.3 * I[sel]
-    assert well.sum() > 20
+    assert well.sum() > (10 if tau == "1000000" else 20)      # the thickest disc: only the face-on view is well sampled
     assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
     if (~well).any():
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1

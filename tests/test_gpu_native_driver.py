@@ -109,3 +109,36 @@ def test_reference_model_output_reads_the_native_rtout(tmp_path):
             "assert g['seds_unc'].shape == s.shape and g['images'].shape == (4, 6, 2, 6, 6, 4) and g['images'].attrs['track_origin'] == b'detailed'\n"
             "assert np.all(np.diff(s[0].sum(axis=(0, 1, 3))) >= 0)\n") % native
     subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+
+
+def test_mpi_name_runs_as_a_rank_and_equals_the_single_process_run(tmp_path):
+    """`hyperion_car_mpi` as rank 0 of 1 (what a 1-GPU box can execute of `mpirun -n N hyperion_car_mpi`): the communicator is
+    created from the launcher's environment, every iteration goes launch -> ncclAllReduce of the accumulator block -> finish,
+    and the .rtout equals the one of the plain executable (a sum over one rank changes nothing).  Lucy + imaging + raytracing
+    on the Cartesian peel-off model, monochromatic + raytracing on the spherical one."""
+    for suffix, name in (("car", "car_peeloff.False.rtin"), ("sph", "native_sph.rtin")):
+        src = os.path.join(GOLDEN, name)
+        plain, ranked = str(tmp_path / (suffix + ".plain.rtout")), str(tmp_path / (suffix + ".rank.rtout"))
+        r = subprocess.run([os.path.join(BIN, "hyperion_" + suffix), "-f", src, plain], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr + r.stdout
+        env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        r = subprocess.run([os.path.join(BIN, "hyperion_" + suffix + "_mpi"), "-f", src, ranked], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr + r.stdout
+        assert "[mpi] rank 0 of 1" in r.stdout and "RCCL all-reduce" in r.stdout
+        script = str(tmp_path / "compare.py")
+        open(script, "w").write(COMPARE)
+        out = subprocess.run([CONDA, "-W", "ignore", script, ranked, plain], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-3000:]
+    # the launcher form: --ranks 1 forks nothing and sets the same environment
+    r = subprocess.run([os.path.join(BIN, "hyperion_car_mpi"), "-f", "--ranks", "1", os.path.join(GOLDEN, "car_peeloff.False.rtin"), str(tmp_path / "l.rtout")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "[mpi] rank 0 of 1" in r.stdout, r.stderr + r.stdout
+
+
+def test_mpi_rank_refusing_to_start_tells_the_launcher(tmp_path):
+    """An existing output without -f: rank 0 refuses before the rendezvous, with the reference's failure convention."""
+    out = str(tmp_path / "exists.rtout")
+    open(out, "w").write("x")
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([os.path.join(BIN, "hyperion_car_mpi"), os.path.join(GOLDEN, "car_peeloff.False.rtin"), out], capture_output=True, text=True, env=env)
+    assert r.returncode == 1 and "already exists" in r.stderr and "did not complete" in r.stderr

@@ -341,6 +341,9 @@ def test_map_source_parity(lte):
             rb, sb = orc.final_iteration(20000)
             for k in INT_KEYS:
                 assert sa[k] == sb[k], (k, sa, sb)
+            for ga, gb in zip(ra, rb):          # the cubes of the imaging iteration itself (scattered light only: raytracing is on)
+                for name in gb:
+                    np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg="final " + name)
             ra, sa = eng.raytracing_iteration(8000, 8000)
             rb, sb = orc.raytracing_iteration(8000, 8000)
             assert sa["crossings"] == sb["crossings"]

@@ -36,12 +36,20 @@ def check_input(name):
 
 
 def test_the_launcher_names_of_the_reference_exist():
-    """scripts/hyperion:44-92 runs `hyperion_<suffix> [-f] input output`"""
+    """scripts/hyperion:44-92 runs `hyperion_<suffix> [-f] input output`, or `mpirun -n N hyperion_<suffix>_mpi ...` with -m N"""
     for suffix in ("car", "sph", "cyl", "oct", "amr", "vor"):
-        p = os.path.join(BIN, "hyperion_" + suffix)
-        assert os.path.exists(p) and os.access(p, os.X_OK), p
+        for name in ("hyperion_" + suffix, "hyperion_" + suffix + "_mpi"):
+            p = os.path.join(BIN, name)
+            assert os.path.exists(p) and os.access(p, os.X_OK), p
     r = subprocess.run([DRIVER], capture_output=True, text=True)
-    assert r.returncode == 2 and "Usage:" in r.stderr and "[-f] input_file output_file" in r.stderr
+    assert r.returncode == 2 and "Usage:" in r.stderr and "[-f] [--ranks N] input_file output_file" in r.stderr
+
+
+def test_the_driver_links_rccl_for_its_one_collective():
+    """The N > 1 path of the native driver is rccl.h directly (ncclAllReduce over xGMI), not torch: the executable depends on
+    librccl and the HIP runtime, and on nothing of the oracle."""
+    out = subprocess.run(["ldd", DRIVER], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libamdhip64" in out and "libhyperion_amd" in out and "oracle" not in out
 
 
 @pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")

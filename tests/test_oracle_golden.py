@@ -262,7 +262,7 @@ def _pinte_run(prob, n_iter, seed):
     return res[0]["sed"]
 
 
-@pytest.mark.parametrize("tau", ["1000", "10000", "100000"])
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
 def test_pinte_benchmark_seds_match_reference_golden(tau):
     """test_pinte_seds.tau=*.rtout (test_bit_level.py:447-545): Pinte et al. (2009) disc on a 100 x 30 CYLINDRICAL
     polar grid, stellar sphere, anisotropic polarising dust, 10 Lucy iterations of 5000 packets with the MODIFIED
@@ -288,7 +288,7 @@ def test_pinte_benchmark_seds_match_reference_golden(tau):
     # golden's 100 + 200 monochromatic packets, its distribution is skewed (rare bright peel-offs, never far below
     # the mean).  The normal-tail bound applies to the well-sampled bins, a one-sided bound to the rest.
     well = sg[sel] < 0.3 * I[sel]
-    assert well.sum() > 20
+    assert well.sum() > (10 if tau == "1000000" else 20)      # the thickest disc: only the face-on view is well sampled
     assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
     if (~well).any():
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
@@ -305,7 +305,7 @@ def _pinte_image_run(prob, seed):
     return res[0]["img"] * prob.config.frequencies[0]
 
 
-@pytest.mark.parametrize("tau", ["1000", "100000"])
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
 def test_pinte_benchmark_images_match_reference_golden(tau):
     """test_pinte_images.tau=*.rtout (test_bit_level.py:549-637): 51 x 51 Stokes images of the Pinte disc at 1 micron,
     two nearly edge-on views -- cylindrical polar grid, stellar sphere, MRW, MONOCHROMATIC final iteration and

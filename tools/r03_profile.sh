@@ -6,6 +6,8 @@
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03prof; mkdir -p $OUT
+# the box starts without gpurun_out/: continue from the committed summary so that a partial re-run keeps the other workloads
+[ -f $OUT/r03_pmc.json ] || cp $REPO/profiles/r03_pmc.json $OUT/r03_pmc.json 2>/dev/null
 export TMPDIR=/tmp
 cd /tmp
 WL=${@:-car car1 oct_lucy oct_img vor}

@@ -18,7 +18,7 @@ for l in log.splitlines():
         tot = json.loads(l[len("PROFILE_TOTALS "):])
     elif l.startswith("{") and '"metric"' in l:
         b = json.loads(l)
-        n_it = b["steps"] + b["warmup"]
+        n_it = b.get("iterations_in_process", b["steps"] + b["warmup"])
         tot = {"workload": w, "packets": b["config"]["packets_per_iteration"] * n_it,
                "crossings": b["config"]["crossings_per_packet"] * b["config"]["packets_per_iteration"] * n_it, "n_dust": 1,
                "timed_ms": [b["lucy_kernel_ms"]], "ms_per_step": b["ms_per_step"], "bench_line": b}
