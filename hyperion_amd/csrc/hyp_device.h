@@ -128,6 +128,10 @@ struct AmrGrid {
     unsigned int start;      // unique id of the first cell
 };
 
+// brick-tiled AMR schedule (hyp_atile.h): cells [o, o + n) per axis of grid `grid`; go_off = its slice of the goto table
+// in DProblem::at_go, (n0 + 2)(n1 + 2)(n2 + 2) 16-bit entries (ghost layer included)
+struct AtSlab { int grid, o[3], n[3], go_off; };
+
 struct DProblem {
     int n1, n2, n3, n_dust;
     int n_sources, n_peeled, sample_sources_evenly, kill_on_absorb;
@@ -169,6 +173,11 @@ struct DProblem {
     const OctCell *ot_rec;                // [n_cells] oct_cells with `parent` replaced by the cell's row in its cluster's ot_kid slice (refined cells)
     const short *ot_kid;                  // [rows][8] children of the refined cells of a cluster as indices inside the cluster
     const short *ot_nb;                   // [n_cells][6] oct_neigh as an index inside the cell's cluster; -1: outside the grid, -2: in another cluster
+    // brick-tiled AMR schedule (hyp_atile.h): every grid is cut into bricks of at most at_b[0] x at_b[1] x at_b[2] cells
+    const AtSlab *at_slabs;               // [n_bricks]
+    const short *at_go;                   // goto-table slices of the bricks, ghost layer included
+    const int *at_grid_c0, *at_grid_nb;   // [n_amr_grids] first brick of a grid; [n_amr_grids][2] bricks along x and y:
+    int at_b[3], pad_at;                  //   brick of a cell = c0 + ((i3 / b2) nb1 + i2 / b1) nb0 + i1 / b0
     const AmrGrid *amr_grids;             // amr: [n_amr_grids], level by level
     const int *amr_go;                    // goto tables of all grids
     const double *amr_walls;              // wall arrays of all grids

@@ -258,6 +258,12 @@ struct hyp_engine {
     int *d_ot_cluster = nullptr, *d_ot_c0 = nullptr, *d_ot_nc = nullptr, *d_ot_kid_off = nullptr;
     OctCell *d_ot_rec = nullptr; short *d_ot_kid = nullptr, *d_ot_nb = nullptr;
     std::vector<OctCell> h_oct_cells; std::vector<int> h_oct_children, h_oct_neigh;      // host copies for the cluster builder
+    // slab-tiled AMR schedule (hyp_atile.h): tables built by build_amr_slabs()
+    int at_cells = 0;               // option: most cells per slab (0: as many as the LDS budget allows)
+    int at_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB
+    int at_slabs_n = 0, at_max_cells = 0, at_max_go = 0, at_max_walls = 0, at_built_for = -1;
+    AtSlab *d_at_slabs = nullptr; short *d_at_go = nullptr; int *d_at_grid_c0 = nullptr, *d_at_grid_nz = nullptr;      // (d_at_grid_nz: bricks along x, y per grid)
+    std::vector<AmrGrid> h_amr_grids; std::vector<int> h_amr_go;
 
     // options
     int interact_threshold = 24, emit_threshold = 16, accum_copies = 16, blocks_per_cu = 0, chunk = 0;
@@ -397,6 +403,7 @@ TileKernels pick_tile_kernels(int nd, int grid_type)
     switch (grid_type) {
     case 1: return pick_tile_kernels_g<GEOM_CAR>(nd);
     case 2: return pick_tile_kernels_g<GEOM_OCT>(nd);
+    case 4: return pick_tile_kernels_g<GEOM_AMR>(nd);
     case 3: return pick_tile_kernels_g<GEOM_VOR>(nd);
     default: { TileKernels k; memset(&k, 0, sizeof k); return k; }
     }
@@ -419,6 +426,9 @@ int tile_bricks(const DProblem &P, int nd)
     return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
 }
 
+// LDS of one AMR brick (hyp_atile.h): n cells, g goto entries (16 bits), w walls
+size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd) { return sizeof(double) * (2 * n * nd + w) + sizeof(short) * g + 16; }
+
 // LDS of one octree cluster (hyp_otile.h): n cells of which k are refined
 size_t oct_cluster_lds(size_t n, size_t k, int nd) { return (sizeof(OctCell) + sizeof(double) * 2 * nd + sizeof(short) * 6) * n + sizeof(short) * 8 * k + 16; }
 
@@ -427,6 +437,8 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool
 {
     if (h->hp.grid_type == 3)       // cluster: cell headers + wall records + densities + accumulators
         return sizeof(VtHdr) * (size_t)T.bx + sizeof(VorWall) * (size_t)T.by + sizeof(double) * 2 * (size_t)T.bx * K.nd;
+    if (h->hp.grid_type == 4)       // slab: densities + accumulators + walls + goto slice
+        return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
         return oct_cluster_lds((size_t)T.bx, (size_t)T.by, K.nd);
     if (ring)                       // the brick's own walls + brick + record ring (hyp_tiled.h: RecRing)
@@ -571,6 +583,9 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     if (P.grid_type == 3) {
         T.bx = h->vt_max_cells; T.by = h->vt_max_walls; T.bz = 1;
         T.nbx = T.n_bricks = h->vt_clusters; T.nby = T.nbz = 1;
+    } else if (P.grid_type == 4) {
+        T.bx = h->at_max_cells; T.by = h->at_max_go; T.bz = h->at_max_walls;
+        T.nbx = T.n_bricks = h->at_slabs_n; T.nby = T.nbz = 1;
     } else if (P.grid_type == 2) {
         T.bx = h->ot_max_cells; T.by = h->ot_max_kids; T.bz = 1;
         T.nbx = T.n_bricks = h->ot_clusters; T.nby = T.nbz = 1;
@@ -644,6 +659,7 @@ void hyp_destroy(hyp_handle h)
     (void)hipSetDevice(h->device);
     free_dev(h->d_problem); free_dev(h->d_blob); free_dev(h->d_sources); free_dev(h->d_peeled);
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children); free_dev(h->d_oct_neigh);
+    free_dev(h->d_at_slabs); free_dev(h->d_at_go); free_dev(h->d_at_grid_c0); free_dev(h->d_at_grid_nz);
     free_dev(h->d_ot_cluster); free_dev(h->d_ot_c0); free_dev(h->d_ot_nc); free_dev(h->d_ot_kid_off); free_dev(h->d_ot_rec); free_dev(h->d_ot_kid); free_dev(h->d_ot_nb);
     free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
     free_dev(h->d_vor_bb);
@@ -687,6 +703,7 @@ static int check_device_error(hyp_handle h);
 static int mrw_prepare(hyp_handle h);
 static int build_vor_clusters(hyp_handle h);
 static int build_oct_clusters(hyp_handle h);
+static int build_amr_slabs(hyp_handle h);
 
 int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 {
@@ -1595,6 +1612,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         HIPC(hipMemcpy(h->d_amr_cell_grid, amr_cell_grid.data(), sizeof(int) * amr_cell_grid.size(), hipMemcpyHostToDevice));
         P.amr_grids = h->d_amr_grids; P.amr_go = h->d_amr_go; P.amr_walls = h->d_amr_walls; P.amr_cell_grid = h->d_amr_cell_grid;
         P.amr_eps = amr_eps; P.n_amr_grids = (int)amr_grids.size(); P.n_amr_level1 = amr_level1;
+        h->h_amr_grids = amr_grids; h->h_amr_go = amr_go;
     }
     if (is_oct) {
         HIPC(hipMalloc(&h->d_oct_cells, sizeof(OctCell) * oct_cells.size()));
@@ -1935,6 +1953,71 @@ static int build_vor_clusters(hyp_handle h)
     P.vt_adj = h->d_vt_adj; P.vt_hdr = h->d_vt_hdr; P.vt_walls = h->d_vt_walls;
     h->vt_clusters = n_cl; h->vt_max_cells = max_cells; h->vt_max_walls = max_walls; h->vt_built_for = nd;
     (void)n_far;
+    return 0;
+}
+
+// Bricks of AMR grids for the tiled schedule (hyp_atile.h): every grid is cut into bricks of at most b0 x b1 x b2 cells, the
+// shape of the Cartesian schedule for the number of species (16^3 for one), shrunk along z until densities + accumulators,
+// walls and the brick's slice of the goto table (ghost layer included, 16 bits per entry) fit the LDS budget.
+static int build_amr_slabs(hyp_handle h)
+{
+    const int nd = h->n_dust;
+    if (h->at_built_for == nd && h->d_at_slabs) return 0;
+    const std::vector<AmrGrid> &G = h->h_amr_grids;
+    const std::vector<int> &GO = h->h_amr_go;
+    if (G.empty()) return h->set_error("amr tables missing for the brick builder");
+    if (G.size() >= 32767) return h->set_error("too many amr grids for the 16-bit goto slices of the tiled schedule");
+    const size_t budget = (size_t)h->at_lds_kb * 1024;
+    int b[3];
+    tile_shape(nd, b[0], b[1], b[2]);
+    if (h->at_cells > 0)         // option: smaller bricks (tests)
+        while ((long long)b[0] * b[1] * b[2] > h->at_cells && (b[0] > 1 || b[1] > 1 || b[2] > 1)) {
+            int a = b[2] >= b[1] && b[2] >= b[0] ? 2 : (b[1] >= b[0] ? 1 : 0);
+            b[a] = (b[a] + 1) / 2;
+        }
+    auto lds_of = [&](const int n[3]) { return amr_slab_lds((size_t)n[0] * n[1] * n[2], (size_t)(n[0] + 2) * (n[1] + 2) * (n[2] + 2), (size_t)n[0] + n[1] + n[2] + 3, nd); };
+    while (lds_of(b) > budget && (b[0] > 1 || b[1] > 1 || b[2] > 1)) {
+        int a = b[2] >= b[1] && b[2] >= b[0] ? 2 : (b[1] >= b[0] ? 1 : 0);
+        b[a]--;
+    }
+    if (lds_of(b) > budget) return h->set_error("the LDS budget of the tiled amr schedule is too small");
+    std::vector<AtSlab> bricks;
+    std::vector<short> go;
+    std::vector<int> c0(G.size()), gnb(2 * G.size());
+    int max_cells = 0, max_go = 0, max_walls = 0;
+    for (size_t k = 0; k < G.size(); k++) {
+        const AmrGrid &g = G[k];
+        const int nb[3] = {(g.n[0] + b[0] - 1) / b[0], (g.n[1] + b[1] - 1) / b[1], (g.n[2] + b[2] - 1) / b[2]};
+        c0[k] = (int)bricks.size(); gnb[2 * k] = nb[0]; gnb[2 * k + 1] = nb[1];
+        for (int kz = 0; kz < nb[2]; kz++) for (int ky = 0; ky < nb[1]; ky++) for (int kx = 0; kx < nb[0]; kx++) {
+            AtSlab s; std::memset(&s, 0, sizeof s);
+            s.grid = (int)k;
+            s.o[0] = kx * b[0]; s.o[1] = ky * b[1]; s.o[2] = kz * b[2];
+            for (int a = 0; a < 3; a++) s.n[a] = std::min(b[a], g.n[a] - s.o[a]);
+            s.go_off = (int)go.size();
+            // goto entries of the brick's cells and one layer around them: 1-based positions o .. o + n + 1 of the grid's table
+            for (int z = 0; z < s.n[2] + 2; z++) for (int y = 0; y < s.n[1] + 2; y++) for (int x = 0; x < s.n[0] + 2; x++)
+                go.push_back((short)GO[(size_t)g.go_off + ((size_t)(s.o[2] + z) * (g.n[1] + 2) + (s.o[1] + y)) * (g.n[0] + 2) + (s.o[0] + x)]);
+            bricks.push_back(s);
+            max_cells = std::max(max_cells, s.n[0] * s.n[1] * s.n[2]);
+            max_go = std::max(max_go, (s.n[0] + 2) * (s.n[1] + 2) * (s.n[2] + 2));
+            max_walls = std::max(max_walls, s.n[0] + s.n[1] + s.n[2] + 3);
+        }
+    }
+    if (bricks.size() > HYP_TILE_MAX_BRICKS) return h->set_error("amr grid has too many cells for the brick-tiled schedule");
+    if (go.size() > 2000000000ull) return h->set_error("amr goto slices too large");
+    free_dev(h->d_at_slabs); free_dev(h->d_at_go); free_dev(h->d_at_grid_c0); free_dev(h->d_at_grid_nz);
+    auto up = [&](auto *&dst, const auto &v) {
+        using T = typename std::remove_reference<decltype(v)>::type::value_type;
+        if (hipMalloc((void **)&dst, sizeof(T) * std::max<size_t>(v.size(), 1)) != hipSuccess) return 1;
+        return hipMemcpy(dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
+    };
+    if (up(h->d_at_slabs, bricks) || up(h->d_at_go, go) || up(h->d_at_grid_c0, c0) || up(h->d_at_grid_nz, gnb))
+        return h->set_error("cannot allocate the brick tables of the tiled AMR schedule");
+    DProblem &P = h->hp;
+    P.at_slabs = h->d_at_slabs; P.at_go = h->d_at_go; P.at_grid_c0 = h->d_at_grid_c0; P.at_grid_nb = h->d_at_grid_nz;
+    for (int a = 0; a < 3; a++) P.at_b[a] = b[a];
+    h->at_slabs_n = (int)bricks.size(); h->at_max_cells = max_cells; h->at_max_go = max_go; h->at_max_walls = max_walls; h->at_built_for = nd;
     return 0;
 }
 
@@ -2311,7 +2394,13 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && h->oct_neighbours;
         tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 2000000ull;
     }
+    else if (P.grid_type == 4) {
+        // AMR: bricks of the grids in LDS (hyp_atile.h)
+        tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins;
+        tile_auto = tile_ok && h->n_cells >= 32768 && n_local >= 2000000ull;
+    }
     const bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto));
+    if (tiled && P.grid_type == 4 && build_amr_slabs(h)) return 1;
     if (tiled && P.grid_type == 3 && build_vor_clusters(h)) return 1;
     if (tiled && P.grid_type == 2 && build_oct_clusters(h)) return 1;
     if (sync_problem(h)) return 1;
@@ -2532,6 +2621,8 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
         h->peel_events = value; h->peel_events_exact = true;
     }
     else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "at_cells") { h->at_cells = (int)value; h->at_built_for = -1; }
+    else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; }
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; }
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; }
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; }
@@ -2576,6 +2667,9 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
     else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
     else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "at_cells") *value = h->at_cells;
+    else if (n == "at_slabs") *value = h->at_slabs_n;
+    else if (n == "at_max_cells") *value = h->at_max_cells;
     else if (n == "ot_cells") *value = h->ot_cells;
     else if (n == "ot_clusters") *value = h->ot_clusters;
     else if (n == "ot_max_cells") *value = h->ot_max_cells;

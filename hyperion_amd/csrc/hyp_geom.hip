@@ -8,6 +8,7 @@
 #include "hyp_defer.h"
 #include "hyp_vtile.h"
 #include "hyp_otile.h"
+#include "hyp_atile.h"
 #include "hyp_pick.h"
 #include <cstring>
 
@@ -94,11 +95,17 @@ static TileKernels tile_kernels()
     TileKernels k;
     memset(&k, 0, sizeof k);
     k.nd = NDT;
-    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR || GEOM == GEOM_OCT) {
+    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR || GEOM == GEOM_OCT || GEOM == GEOM_AMR) {
         k.interact[0][0] = tile_interact_kernel<NDT, false, false, GEOM>; k.interact[1][0] = tile_interact_kernel<NDT, true, false, GEOM>;
         k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
         k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
+    }
+    if constexpr (GEOM == GEOM_AMR) {
+        k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
+        k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
+        k.walk = atile_walk_kernel<NDT>;
+        k.walk_threads = HYP_ATILE_WG;
     }
     if constexpr (GEOM == GEOM_OCT) {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;

@@ -61,6 +61,9 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
 #ifndef HYP_TILE_WG
 #define HYP_TILE_WG 512          // threads per workgroup (one workgroup per task)
 #endif
+#ifndef HYP_TILE_OCC
+#define HYP_TILE_OCC (HYP_TILE_WG / 128)      // waves per SIMD the walk kernel's registers are budgeted for (4: two 512-thread workgroups per CU)
+#endif
 #ifndef HYP_TILE_DENS_LDS
 #define HYP_TILE_DENS_LDS 1      // 1: brick densities staged in LDS, 0: read through L1/L2
 #endif
@@ -148,6 +151,26 @@ template <> struct TileCellIO<GEOM_VOR> {
         H.ic[0] = c.id; H.ic[1] = -c.ow[1] - 1; H.ic[2] = P.vt_cluster[c.id]; H.ow = 0;
     }
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 8; }
+};
+// AMR (hyp_atile.h): ic = (cell, grid, brick); the position in the grid follows from the cell id
+__device__ __forceinline__ int amr_brick_of(const DProblem &P, int grid, const int i[3])
+{
+    return P.at_grid_c0[grid] + ((i[2] / P.at_b[2]) * P.at_grid_nb[2 * grid + 1] + i[1] / P.at_b[1]) * P.at_grid_nb[2 * grid] + i[0] / P.at_b[0];
+}
+template <> struct TileCellIO<GEOM_AMR> {
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_AMR> &c)
+    {
+        c.id = H.ic[0]; c.grid = H.ic[1];
+        const AmrGrid &g = P.amr_grids[c.grid];
+        const int local = c.id - (int)g.start;
+        c.i[0] = local % g.n[0]; c.i[1] = (local / g.n[0]) % g.n[1]; c.i[2] = local / (g.n[0] * g.n[1]);
+        unpack_ow(H.ow, c.ow);
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_AMR> &c)
+    {
+        H.ic[0] = c.id; H.ic[1] = c.grid; H.ic[2] = amr_brick_of(P, c.grid, c.i); H.ow = pack_ow(c.ow);
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_AMR> &c) { return amr_brick_of(P, c.grid, c.i); }
 };
 // Octree (hyp_otile.h): ic = (leaf cell, -, cluster of the leaf), ow as on Cartesian grids; the rest of the cell record
 // (centre, level, parent, sub-cell) is read back from the cell table
@@ -1205,7 +1228,7 @@ __device__ __forceinline__ bool in_correct_cell_brick(const Walls &W, const doub
 enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6, LS_REABS = 7 };
 
 template <int ND, int BX, int BY, int BZ, bool RING>
-__global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_WG / 128) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+__global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                       void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                       const int *__restrict__ order,
                                                       const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,

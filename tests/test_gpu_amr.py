@@ -109,3 +109,69 @@ def test_golden_amr_statistical():
     eng.close()
     w = prob.density * prob.volumes
     assert (gold * w).sum() == pytest.approx((big * w).sum(), rel=0.04)
+
+
+# --- brick-tiled Lucy iteration (hyp_atile.h, lucy_mode=1): same packets, same answer -----------------------
+
+def run_tiled(prob, n, iters=1, **opts):
+    eng = hyperion_amd.Engine(prob)
+    eng.set_option("lucy_mode", 1)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    orc = Oracle(prob)
+    for it in range(1, iters + 1):
+        a, sa = eng.lucy_iteration(n, it)
+        assert eng.get_option("last_lucy_mode") == 1
+        b, sb = orc.lucy_iteration(n, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+        assert_parity(a, b)
+    n_sl = eng.get_option("at_slabs")
+    eng.close(); orc.close()
+    return a, sa, n_sl
+
+
+@pytest.mark.parametrize("name", ["False.False", "True.True"])
+def test_atile_reference_amr_model(name):
+    """The reference's AMR regression model (two levels, refinement 1 x 2 x 10) through the brick-tiled schedule: every grid one
+    brick, then bricks of a single cell each (a packet changes brick at every crossing)."""
+    prob, _ = golden_problem("amr_specific_energy.%s.npz" % name)
+    a, st, n_sl = run_tiled(prob, 30000, iters=2)
+    assert prob.amr_n.shape[0] <= n_sl <= 2 * prob.amr_n.shape[0]       # bricks of up to 16^3 cells: one or two per grid here
+    a, st, n_sl = run_tiled(prob, 30000, at_cells=1, tile_slots=4096, tile_task=256, tile_drain=0, tile_poll=1)
+    assert n_sl == int(np.prod(prob.amr_n, axis=1).sum())
+
+
+def test_atile_nested_grids_side_by_side():
+    """Three levels with two level-2 grids side by side and a level-3 grid straddling their boundary: steps between grids of
+    one level, down and up the hierarchy (find_position_in_grid through the goto tables), bricks of 4 x 4 x 4 cells, small pools,
+    generations all the way down; then the default brick size with the drain launch."""
+    p = nested_amr_problem()
+    a, st, n_sl = run_tiled(p, 60000, iters=2, at_cells=64, tile_slots=8192, tile_task=512, tile_drain=0, tile_poll=1)
+    assert n_sl > 8 and st["killed_geo"] == 0
+    run_tiled(p, 60000, tile_slots=16384, tile_pools=2, tile_drain=500)
+
+
+def test_atile_two_species():
+    p = nested_amr_problem()
+    p.density = np.vstack([p.density * 0.6, p.density * 0.8])
+    p.dust = [p.dust[0], p.dust[0]]
+    run_tiled(p, 40000, at_cells=100, tile_slots=8192, tile_drain=100)
+
+
+def test_atile_matches_persistent_at_scale():
+    """Three nested 32^3 grids, 2e6 packets: both GPU schedules walk the same packets; integer tallies equal, sums to rounding."""
+    from hyperion_amd.benchmark import make_amr_problem
+    prob = make_amr_problem(n=32, levels=3)
+    res = []
+    for mode in (0, -1):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("lucy_mode", mode)
+        res.append(eng.lucy_iteration(2_000_000, 1))
+        assert eng.get_option("last_lucy_mode") == (0 if mode == 0 else 1)
+        eng.close()
+    (a, sa), (b, sb) = res
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert_parity(a, b)
