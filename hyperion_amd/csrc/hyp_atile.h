@@ -24,10 +24,10 @@
 #define HYP_ATILE_OCC 4          // waves per SIMD the register budget is set for (two 512-thread workgroups per CU)
 #endif
 #ifndef HYP_ATILE_SERVICE
-#define HYP_ATILE_SERVICE 16      // lanes that must wait before a wave runs its service phase
+#define HYP_ATILE_SERVICE 24      // lanes that must wait before a wave runs its service phase (16 with 4 steps: 235.5 ms, 24 with 8: 224.2)
 #endif
 #ifndef HYP_ATILE_STEPS
-#define HYP_ATILE_STEPS 4         // cell steps between two scheduling decisions of a wave
+#define HYP_ATILE_STEPS 8         // cell steps between two scheduling decisions of a wave
 #endif
 #define AT_HIST 256               // slabs whose packet counts a task collects in LDS (the others: global atomics)
 

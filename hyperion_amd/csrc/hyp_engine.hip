@@ -238,7 +238,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -595,7 +595,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
         T.n_bricks = T.nbx * T.nby * T.nbz;
     }
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
-    const long long want_slots = h->tile_slots > 0 ? h->tile_slots : (P.grid_type == 2 ? 3ll << 22 : 3ll << 21);
+    const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
     long long slots = std::min<long long>(want_slots, (long long)n_local);
     if (slots < 65536) n_pools = 1;
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
