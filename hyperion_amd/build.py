@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libhyperion_amd.so")
-SOURCES = ["hyp_engine.hip", "hyp_geom.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h", "hyp_pick.h", "hyp_polar.h", "hyp_epilogue.h", "hyp_defer.h", "hyp_vtile.h", "hyp_otile.h", "hyp_atile.h"]
+SOURCES = ["hyp_engine.hip", "hyp_geom.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h", "hyp_pick.h", "hyp_polar.h", "hyp_epilogue.h", "hyp_defer.h", "hyp_vtile.h", "hyp_otile.h", "hyp_atile.h", "hyp_stage.h"]
 # one translation unit per grid geometry (lucy / final / ray kernels x species counts) + the host side
 GEOMS = {"car": 0, "oct": 1, "vor": 2, "amr": 3, "sph": 4, "cyl": 5}
 # -ffp-contract=off: the cell-walk arithmetic must round like the reference formulation (see find_wall)

@@ -69,7 +69,8 @@ enum { ST_FF = 8, ST_FF_DONE = 9, ST_FF_KILLED = 10 };
 // walk_step<NDT, GEOM, false> without re-absorbing sources (PLAIN), plus the `ff` mode = one pass of the loop of
 // escape_tau (same order of operations, same association of the optical-depth sum, same use of the check stream)
 template <int NDT, int GEOM>
-__device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt, bool ff)
+__device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt, bool ff,
+                                          const double inv[3], bool v_ok)
 {
     const int nd = ndust<NDT>(P);
     if (g.countdown == 0) {
@@ -77,7 +78,10 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
         if (!geo_check_cell(P, W, p.r, p.v, p.cell)) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
     } else g.countdown--;
     double tmin; int im[3];
-    if (!geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im)) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
+    bool found;
+    if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
+    else found = geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
+    if (!found) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
     const size_t base = geo_index(P, p.cell) * (size_t)nd;
     double rho[NDT];
     double chi_rho = 0.0;
@@ -124,6 +128,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
     Dispenser dsp; dsp.next = 0; dsp.end = 0;
     PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
     int st = ST_NEED_EMIT;
+    double inv[3] = {1.0, 1.0, 1.0};          // octree: RN(1 / v) of the packet's direction since its last emission / interaction
+    bool v_ok = false;                        //   (oct_find_wall_inv); false: geo_find_wall
     bool pool_empty = false, full = false;
     unsigned long long w_pos = 0, w_end = 0;        // the wave's reserved event slots
     unsigned int n_written = 0;
@@ -288,6 +294,11 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 w_pos += __popcll(m); n_written += __popcll(m);
             }
             if (peel != 0) {
+                if (GEOM == GEOM_OCT) {         // the direction is new
+                    v_ok = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                }
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 
 #pragma unroll 1
         for (int k = 0; k < final_walk_steps<GEOM>(); k++) {
-            if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF);
+            if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok);
         }
     }
 
@@ -359,6 +370,8 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
     // lane state: 0 idle, 1 walking, 2 out of the grid (to be binned)
     int st = 0, ig = 0;
     double r[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 1.0}, tau = 0.0, chi[NDT];
+    double inv[3] = {1.0, 1.0, 1.0};          // octree: RN(1 / v) of the walk's direction, see oct_find_wall_inv
+    bool v_ok = true;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, energy = 0.0;
     long long k_img = -1, k_sed = -1;
     Cell<GEOM> c;
@@ -427,6 +440,11 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                     }
                     r[0] = E.r[0]; r[1] = E.r[1]; r[2] = E.r[2];
                     angle_to_vector(a_req, v[0], v[1], v[2]);
+                    if (GEOM == GEOM_OCT) {
+                        v_ok = true;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400); }
+                    }
                     c = E.cell;
                     bool ok = geo_place(P, W, r, v, c);
                     if (!ok) cnt.killed_geo++;
@@ -471,7 +489,10 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                     check_ok = geo_check_cell(P, W, r, v, c);
                 } else gp.countdown--;
                 double tmin = 0.0; int im[3];
-                if (!check_ok || !geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; st = 0; }
+                bool found;
+                if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                else found = geo_find_wall(P, W, r, v, c, tmin, im);
+                if (!check_ok || !found) { cnt.killed_geo++; st = 0; }
                 else {
                     const size_t base = geo_index(P, c) * (size_t)nd;
 #pragma unroll

@@ -6,6 +6,7 @@
 #endif
 #include "hyp_kernels.h"
 #include "hyp_defer.h"
+#include "hyp_stage.h"
 #include "hyp_vtile.h"
 #include "hyp_otile.h"
 #include "hyp_atile.h"
@@ -69,6 +70,8 @@ static DeferKernels defer_kernels()
     DeferKernels k;
     k.propagate = final_defer_kernel<NDT, GEOM>; k.peel = peel_kernel<NDT, GEOM>; k.reset = defer_reset_kernel<GEOM>;
     k.event_bytes = sizeof(PeelEvent<NDT, GEOM>); k.susp_bytes = sizeof(SuspRec<NDT, GEOM>);
+    k.stage_event = stage_event_kernel<NDT, GEOM>; k.stage_walk = stage_walk_kernel<NDT, GEOM>; k.stage_init = stage_init_kernel<NDT, GEOM>;
+    k.hot_bytes = sizeof(StageHot<NDT, GEOM>);
     return k;
 }
 
