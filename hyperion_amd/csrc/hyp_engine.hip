@@ -655,6 +655,124 @@ extern "C" {
 
 int hyp_abi_version(void) { return HYP_ABI_VERSION; }
 
+namespace {
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } }
+    void i64(int64_t v) { bytes(&v, sizeof v); }
+    void f64(double v) { if (v == 0.0) v = 0.0; bytes(&v, sizeof v); }      // -0.0 and 0.0 alike
+    void arr(const double *p, size_t n) { i64(p ? (int64_t)n : -1); if (p) for (size_t i = 0; i < n; i++) f64(p[i]); }
+    void arr32(const int32_t *p, size_t n) { i64(p ? (int64_t)n : -1); if (p) bytes(p, n * sizeof(int32_t)); }
+};
+void digest_peeled(Fnv &f, const hyp_peeled_desc &d, bool binned)
+{
+    for (int64_t v : {(int64_t)(binned ? 0 : d.n_view), (int64_t)d.inside_observer, (int64_t)d.ignore_optical_depth, (int64_t)d.compute_image, (int64_t)d.compute_sed,
+                      (int64_t)d.n_x, (int64_t)d.n_y, (int64_t)d.n_ap, (int64_t)d.n_nu, (int64_t)d.track_origin, (int64_t)d.track_n_scat, (int64_t)d.uncertainties,
+                      (int64_t)d.compute_stokes, (int64_t)d.use_filters}) f.i64(v);
+    if (d.compute_image) for (double v : {d.x_min, d.x_max, d.y_min, d.y_max}) f.f64(v);
+    if (d.compute_sed) for (double v : {d.ap_min, d.ap_max}) f.f64(v);
+    for (double v : {d.nu_min, d.nu_max, d.d_min, d.d_max}) f.f64(v);
+    if (d.inside_observer) for (double v : d.peeloff_origin) f.f64(v);
+    if (!binned) { f.arr(d.theta, (size_t)d.n_view); f.arr(d.phi, (size_t)d.n_view); }
+    if (d.use_filters) {
+        f.arr32(d.filt_n, (size_t)d.n_nu);
+        size_t tot = 0;
+        for (int i = 0; i < d.n_nu && d.filt_n; i++) tot += (size_t)d.filt_n[i];
+        f.arr(d.filt_nu, tot); f.arr(d.filt_tr, tot);
+    }
+}
+}  // namespace
+
+int hyp_problem_digest(const hyp_problem *pr, uint64_t out[4])
+{
+    if (!pr || !out) return 1;
+    const hyp_grid_desc &g = pr->grid;
+    if (pr->n_dust < 0 || pr->n_sources < 0 || pr->n_peeled < 0 || g.n_cells < 0) return 1;
+    size_t nc = (size_t)g.n_cells;
+    Fnv a;
+    a.i64(g.type);
+    if (g.type == 1 || g.type == 5 || g.type == 6) {
+        nc = (size_t)g.n1 * g.n2 * g.n3;
+        a.i64(g.n1); a.i64(g.n2); a.i64(g.n3);
+        a.arr(g.w1, (size_t)g.n1 + 1); a.arr(g.w2, (size_t)g.n2 + 1); a.arr(g.w3, (size_t)g.n3 + 1);
+    } else if (g.type == 2) {
+        a.arr32(g.refined, nc);
+        for (double v : g.oct_center) a.f64(v);
+        for (double v : g.oct_half) a.f64(v);
+    } else if (g.type == 3) {
+        a.arr(g.vor_sites, 3 * nc); a.arr(g.vor_volume, nc); a.arr32(g.vor_idx, nc + 1);
+        a.arr32(g.vor_neighs, g.vor_idx ? (size_t)g.vor_idx[nc] : 0);
+        for (double v : g.vor_box) a.f64(v);
+        a.arr(g.vor_bb, 6 * nc);
+    } else if (g.type == 4) {
+        a.i64(g.n_amr_levels); a.i64(g.n_amr_grids);
+        a.arr32(g.amr_level, (size_t)g.n_amr_grids); a.arr32(g.amr_n, 3 * (size_t)g.n_amr_grids); a.arr(g.amr_bounds, 6 * (size_t)g.n_amr_grids);
+        nc = 0;
+        for (int k = 0; k < g.n_amr_grids && g.amr_n; k++) nc += (size_t)g.amr_n[3 * k] * g.amr_n[3 * k + 1] * g.amr_n[3 * k + 2];
+    } else return 1;
+    a.arr(pr->density, nc * (size_t)pr->n_dust);
+    a.arr(pr->specific_energy, nc * (size_t)pr->n_dust);
+    out[0] = a.h;
+    Fnv d;
+    d.i64(pr->n_dust);
+    for (int i = 0; i < pr->n_dust; i++) {
+        const hyp_dust_desc &D = pr->dust[i];
+        for (int64_t v : {(int64_t)D.n_nu, (int64_t)D.n_mu, (int64_t)D.n_jnu, (int64_t)D.n_enu, (int64_t)D.n_e, (int64_t)D.sublimation_mode, (int64_t)D.version, (int64_t)D.is_lte}) d.i64(v);
+        d.f64(D.sublimation_mode ? D.sublimation_specific_energy : 0.0); d.f64(D.minimum_specific_energy);
+        d.arr(D.nu, (size_t)D.n_nu); d.arr(D.albedo, (size_t)D.n_nu); d.arr(D.chi, (size_t)D.n_nu); d.arr(D.mu, (size_t)D.n_mu);
+        const size_t np = (size_t)D.n_nu * D.n_mu;
+        d.arr(D.P1, np); d.arr(D.P2, np); d.arr(D.P3, np); d.arr(D.P4, np);
+        d.arr(D.emiss_nu, (size_t)D.n_enu); d.arr(D.emiss_jnu, (size_t)D.n_enu * D.n_jnu); d.arr(D.emiss_var, (size_t)D.n_jnu);
+        d.arr(D.mo_specific_energy, (size_t)D.n_e); d.arr(D.mo_chi_rosseland, (size_t)D.n_e); d.arr(D.mo_kappa_planck, (size_t)D.n_e);
+        d.arr(D.mo_chi_inv_planck, (size_t)D.n_e);
+    }
+    out[1] = d.h;
+    Fnv s;
+    s.i64(pr->n_sources);
+    for (int i = 0; i < pr->n_sources; i++) {
+        const hyp_source_desc &S = pr->sources[i];
+        for (int64_t v : {(int64_t)S.type, (int64_t)S.spectrum_type, (int64_t)S.peeloff}) s.i64(v);
+        s.f64(S.luminosity);
+        if (S.spectrum_type == 1) { s.arr(S.spec_nu, (size_t)S.n_spec); s.arr(S.spec_fnu, (size_t)S.n_spec); }
+        else if (S.spectrum_type == 2) s.f64(S.temperature);
+        if (S.type == 1 || S.type == 2 || S.type == 5 || S.type == 7) for (double v : S.position) s.f64(v);
+        if (S.type == 2 || S.type == 5 || S.type == 7) s.f64(S.radius);
+        if (S.type == 2) s.i64(S.limb_darkening);
+        if (S.type == 6) for (double v : S.box) s.f64(v);
+        if (S.type == 7) for (double v : S.direction) s.f64(v);
+        if (S.type == 8) { s.arr(S.points, 3 * (size_t)S.n_points); s.arr(S.point_lum, (size_t)S.n_points); }
+        if (S.type == 4) s.arr(S.map, nc);
+        s.i64(S.type == 2 ? S.n_spots : 0);
+        for (int k = 0; k < S.n_spots && S.type == 2 && S.spots; k++) {
+            const hyp_spot_desc &T = S.spots[k];
+            for (double v : {T.longitude, T.latitude, T.radius, T.luminosity}) s.f64(v);
+            s.i64(T.spectrum_type);
+            if (T.spectrum_type == 1) { s.arr(T.spec_nu, (size_t)T.n_spec); s.arr(T.spec_fnu, (size_t)T.n_spec); } else s.f64(T.temperature);
+        }
+    }
+    out[2] = s.h;
+    Fnv c;
+    const hyp_config &K = pr->config;
+    for (int64_t v : {K.seed, K.n_inter_max, K.n_reabs_max, (int64_t)K.kill_on_absorb, (int64_t)K.kill_on_scatter, (int64_t)K.sample_sources_evenly,
+                      (int64_t)K.enforce_energy_range, (int64_t)K.forced_first_interaction, (int64_t)(K.forced_first_interaction ? K.forced_first_interaction_algorithm : 0),
+                      (int64_t)K.specific_energy_type, (int64_t)K.raytracing, (int64_t)K.mrw, (int64_t)K.monochromatic, (int64_t)K.pda, (int64_t)K.count_photons,
+                      (int64_t)K.n_spectrum_bins}) c.i64(v);
+    if (K.forced_first_interaction && K.forced_first_interaction_algorithm == 2) c.f64(K.baes16_xi);
+    c.f64(K.propagation_check_frequency);
+    if (K.mrw) { c.i64(K.n_inter_mrw_max); c.f64(K.mrw_gamma); }
+    if (K.monochromatic) { c.f64(K.monochromatic_energy_threshold); c.arr(K.frequencies, (size_t)K.n_frequencies); }
+    if (K.n_spectrum_bins) c.arr(K.spectrum_bin_edges, (size_t)K.n_spectrum_bins + 1);
+    c.i64(pr->n_peeled);
+    for (int i = 0; i < pr->n_peeled; i++) {
+        digest_peeled(c, pr->peeled[i], false);
+        if (K.monochromatic) { c.i64(pr->peeled[i].inu_min); c.i64(pr->peeled[i].inu_max); }
+    }
+    c.i64(pr->binned ? 1 : 0);
+    if (pr->binned) { digest_peeled(c, *pr->binned, true); c.i64(pr->n_binned_theta); c.i64(pr->n_binned_phi); }
+    out[3] = c.h;
+    return 0;
+}
+
 const char *hyp_last_error(hyp_handle h) { return h ? h->err.c_str() : g_error.c_str(); }
 
 void hyp_destroy(hyp_handle h)

@@ -1368,6 +1368,9 @@ int main(int argc, char **argv)
             for (size_t i = 0; i < in.dust.size(); i++)
                 printf("dust %zu n_nu %d n_mu %d n_jnu %d n_enu %d n_e %d sublimation %d chi0 %.17g\n", i, in.dust[i].n_nu, in.dust[i].n_mu, in.dust[i].n_jnu,
                        in.dust[i].n_enu, in.dust[i].n_e, in.dust[i].sublimation_mode, in.dust[i].chi[0]);
+            uint64_t dg[4];
+            if (hyp_problem_digest(&in.P, dg) == 0)
+                printf("digest %016llx %016llx %016llx %016llx\n", (unsigned long long)dg[0], (unsigned long long)dg[1], (unsigned long long)dg[2], (unsigned long long)dg[3]);
             for (size_t i = 0; i < in.groups.size(); i++)
                 printf("group %zu n_view %d n_nu %d n_x %d n_y %d n_ap %d track_origin %d uncertainties %d stokes %d filters %d io_bytes %d\n", i, in.groups_desc[i].n_view,
                        in.groups_desc[i].n_nu, in.groups_desc[i].n_x, in.groups_desc[i].n_y, in.groups_desc[i].n_ap, in.groups_desc[i].track_origin,

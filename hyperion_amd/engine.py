@@ -16,7 +16,7 @@ from .build import LIB
 _dp = C.POINTER(C.c_double)
 
 EXPORTS = [
-    "hyp_abi_version", "hyp_create", "hyp_destroy", "hyp_last_error",
+    "hyp_abi_version", "hyp_problem_digest", "hyp_create", "hyp_destroy", "hyp_last_error",
     "hyp_lucy_iteration", "hyp_lucy_launch", "hyp_lucy_accumulators", "hyp_lucy_finish",
     "hyp_final_iteration", "hyp_final_launch", "hyp_final_accumulators", "hyp_final_finish",
     "hyp_peeled_get", "hyp_peeled_n_orig",
@@ -73,6 +73,7 @@ def load_library(path=None):
     L = C.CDLL(path)
     H = C.c_void_p
     L.hyp_abi_version.restype = C.c_int
+    L.hyp_problem_digest.argtypes = [C.POINTER(ProblemDesc), C.POINTER(C.c_uint64 * 4)]
     L.hyp_create.argtypes = [C.POINTER(ProblemDesc), C.c_int, C.POINTER(H)]
     L.hyp_destroy.argtypes = [H]
     L.hyp_destroy.restype = None

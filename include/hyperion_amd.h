@@ -248,6 +248,13 @@ int  hyp_create(const hyp_problem *problem, int device, hyp_handle *out);
 void hyp_destroy(hyp_handle h);
 const char *hyp_last_error(hyp_handle h);
 int  hyp_abi_version(void);
+/* Digest of everything a hyp_problem points to, in a canonical order (FNV-1a 64 over scalars and arrays with their
+ * lengths; needs no GPU): out[0] grid + density + specific energy, out[1] dust, out[2] sources, out[3] run configuration +
+ * image groups.  Two marshallers that read the same .rtin (hyperion_amd/_abi.py from the Python reader, hyp_run.cpp's own
+ * HDF5 reader) must produce the same four words: tests/test_native_driver_cpu.py compares them, which is how the marshalling
+ * that feeds both the engine and the test oracle is checked independently of itself.  Returns non-zero on a malformed
+ * problem (negative sizes). */
+int  hyp_problem_digest(const hyp_problem *problem, uint64_t out[4]);
 
 /* do_lucy (src/main/iter_lucy.f90:66-237): one whole temperature iteration on
  * one GPU.  `iteration` is the 1-based Lucy iteration (part of the RNG key).

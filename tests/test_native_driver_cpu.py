@@ -108,3 +108,25 @@ def test_failures_look_like_the_reference_binarys(tmp_path):
     if os.path.exists(CONDA):
         code = "import h5py; f = h5py.File(%r, 'r'); assert 'date_started' in f.attrs and 'date_ended' not in f.attrs" % out
         subprocess.check_call([CONDA, "-W", "ignore", "-c", code])
+
+
+@pytest.mark.skipif(not os.path.exists(CONDA), reason="no python with h5py in this image")
+@pytest.mark.parametrize("name", FIXTURES)
+def test_two_independent_marshallers_hand_over_the_same_problem(name):
+    """hyp_problem_digest (a digest, in a canonical order, of every scalar and array a hyp_problem points to) of the SAME
+    reference-written .rtin marshalled twice, by two pieces of code that share nothing: hyp_run.cpp's HDF5 reader in C++, and
+    hyperion_amd.rtin.read_rtin + hyperion_amd._abi.MarshalledProblem in Python -- the marshalling that feeds both the engine
+    and, in tests/oracle_lib.py, the oracle.  A field one side mis-marshals (order, dtype, units, layout) changes its word:
+    [0] grid + density, [1] dust tables, [2] sources, [3] run configuration + image groups."""
+    out = subprocess.check_output([DRIVER, "--check-input", os.path.join(GOLDEN, name)], text=True)
+    native = [l.split()[1:] for l in out.splitlines() if l.startswith("digest ")][0]
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\n"
+            "from hyperion_amd.rtin import read_rtin\n"
+            "from hyperion_amd._abi import MarshalledProblem\n"
+            "from hyperion_amd.engine import load_library\n"
+            "m = MarshalledProblem(read_rtin(%r))\n"
+            "out = (C.c_uint64 * 4)()\n"
+            "assert load_library().hyp_problem_digest(C.byref(m.desc), C.byref(out)) == 0\n"
+            "print(' '.join('%%016x' %% v for v in out))\n") % (ROOT, os.path.join(GOLDEN, name))
+    py = subprocess.check_output([CONDA, "-W", "ignore", "-c", code], text=True).split()
+    assert py == native, dict(zip(("grid", "dust", "sources", "config+images"), zip(py, native)))
