@@ -2,7 +2,7 @@
 # Round-3 rocprofv3 capture on the GPU box: for each workload one kernel-trace pass and one --pmc pass per counter set
 # (counters only alongside --kernel-trace), condensed on the box by tools/summarize_r03.py into
 # gpurun_out/r03prof/<workload>_summary.md and r03_pmc.json (copy both into profiles/).
-#   usage: bash tools/r03_profile.sh [workload ...]      workloads: car car1 oct_lucy oct_img vor
+#   usage: bash tools/r03_profile.sh [workload ...]      workloads: car car1 oct_lucy oct_img vor amr
 set -u
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/r03prof; mkdir -p $OUT
@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/r03prof; mkdir -p $OUT
 [ -f $OUT/r03_pmc.json ] || cp $REPO/profiles/r03_pmc.json $OUT/r03_pmc.json 2>/dev/null
 export TMPDIR=/tmp
 cd /tmp
-WL=${@:-car car1 oct_lucy oct_img vor}
+WL=${@:-car car1 oct_lucy oct_img vor amr}
 SETS=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY"
       "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_INT32 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY"
       "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES SQ_THREAD_CYCLES_VALU"

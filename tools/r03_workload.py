@@ -1,5 +1,5 @@
 """The single-GPU workloads of BASELINE.json that are profiled besides the bench command (tools/r03_profile.sh):
-   python tools/r03_workload.py oct_lucy|oct_img|vor [packets] [opt=value ...]
+   python tools/r03_workload.py oct_lucy|oct_img|vor|amr [packets] [opt=value ...]
 Runs one warm-up (a tenth of the packets) and two timed iterations; prints the timings and one line
 `PROFILE_TOTALS {json}` with the crossings / packets of ALL iterations of the process (what a rocprofv3 pass sees)."""
 import json, os, sys
@@ -10,7 +10,11 @@ from hyperion_amd.benchmark import make_octree_problem
 
 which = sys.argv[1]
 n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
-if which == "vor":
+if which == "amr":
+    from hyperion_amd.benchmark import make_amr_problem
+    p = make_amr_problem(n=64, levels=3)
+    n_dust = 1
+elif which == "vor":
     from cases import voronoi_big_problem
     p = voronoi_big_problem(n_photons=n)
     n_dust = 2
