@@ -301,7 +301,7 @@ def main():
                     "note": "HIP events around every tile_walk launch on its pool's stream, in one extra step after the timed region (option tile_time_walk, off in the timed steps); with several "
                             "pools the launches overlap other kernels and stretch -- profiles/r03_car1_summary.md has the one-pool trace"}
             roof["limiter"] = "valu_issue + service-phase latency"
-            roof["note"] = ("density and accumulators of a 16^3 brick live in LDS, so the 24 B per crossing never go to memory: `bound` names the "
+            roof["note"] = ("density and accumulators of a 32 x 16 x 16 brick live in LDS, so the 24 B per crossing never go to memory: `bound` names the "
                             "nominal roofline of the path (HBM), the fraction says how far it is from a streaming bound it does not have; the counters "
                             "name the limiter: VALU issue (issue_roofline) and the service phase of tile_walk, 46 % of a wave's clocks "
                             "(profiles/r03_tiled_log.md)")

@@ -238,7 +238,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 4096, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 4096 packets per task, 8192 on Cartesian grids */, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -605,7 +605,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
-    T.task_size = h->tile_task < 256 ? 256 : h->tile_task;
+    T.task_size = h->tile_task <= 0 ? (P.grid_type == 1 ? 8192 : 4096) : h->tile_task < 256 ? 256 : h->tile_task;
     T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare) ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
@@ -2092,8 +2092,7 @@ static int build_amr_slabs(hyp_handle h)
     if (G.empty()) return h->set_error("amr tables missing for the brick builder");
     if (G.size() >= 32767) return h->set_error("too many amr grids for the 16-bit goto slices of the tiled schedule");
     const size_t budget = (size_t)h->at_lds_kb * 1024;
-    int b[3];
-    tile_shape(nd, b[0], b[1], b[2]);
+    int b[3] = {16, nd <= 2 ? 16 : 8, nd == 1 ? 16 : 8};      // two 512-thread workgroups per CU
     if (h->at_cells > 0)         // option: smaller bricks (tests)
         while ((long long)b[0] * b[1] * b[2] > h->at_cells && (b[0] > 1 || b[1] > 1 || b[2] > 1)) {
             int a = b[2] >= b[1] && b[2] >= b[0] ? 2 : (b[1] >= b[0] ? 1 : 0);
@@ -2507,7 +2506,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     bool tile_ok = false, tile_auto = false;
     if (P.grid_type == 1) {
         tile_ok = h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
-        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 64 && n_local >= 4000000ull;
+        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 32 && n_local >= 4000000ull;
     } else if (P.grid_type == 3) {
         // Voronoi: clusters of cells in LDS (hyp_vtile.h); the modified random walk does not exist on these grids
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && !P.mrw;

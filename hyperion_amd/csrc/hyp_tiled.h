@@ -59,10 +59,10 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
 #define HYP_PREP_CHUNK 2048
 // build-time shape of tile_walk_kernel (tools/variants.py sweeps these)
 #ifndef HYP_TILE_WG
-#define HYP_TILE_WG 512          // threads per workgroup (one workgroup per task)
+#define HYP_TILE_WG 1024         // threads per workgroup (one workgroup per task; with 32 x 16 x 16 bricks one workgroup per CU)
 #endif
 #ifndef HYP_TILE_OCC
-#define HYP_TILE_OCC (HYP_TILE_WG / 128)      // waves per SIMD the walk kernel's registers are budgeted for (4: two 512-thread workgroups per CU)
+#define HYP_TILE_OCC 4           // waves per SIMD the walk kernel's registers are budgeted for (16 waves per CU)
 #endif
 #ifndef HYP_TILE_DENS_LDS
 #define HYP_TILE_DENS_LDS 1      // 1: brick densities staged in LDS, 0: read through L1/L2
@@ -1100,15 +1100,19 @@ struct RecRing {
 
 // brick shape per number of species: density + accumulators (16 B per cell and
 // species) must leave room for two workgroups per CU in the 160 KB LDS
+// Round 3: 32 x 16 x 16 bricks walked by ONE 1024-thread workgroup per CU instead of two 512-thread workgroups on 16^3 bricks:
+// the mean chord grows from 10.7 to 12.8 cells, a fifth fewer visits (record traffic, sort, service phases); with the
+// interaction / emission work in kernels of their own a CU that drains a task's tail alone costs less than it did in
+// round 1 (311 against 298 ms then; now 255-259 against 268-277 at tasks of 8192 packets, profiles/r03_tiled_log.md).
 #ifndef HYP_TILE_BX
-#define HYP_TILE_BX 16
+#define HYP_TILE_BX 32
 #define HYP_TILE_BY 16
 #define HYP_TILE_BZ 16
 #endif
-template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 64 KB
-template <> struct TileShape<2> { static constexpr int X = 16, Y = 16, Z = 8; };         // 64 KB
-template <> struct TileShape<3> { static constexpr int X = 16, Y = 8, Z = 8; };          // 48 KB
-template <> struct TileShape<4> { static constexpr int X = 16, Y = 8, Z = 8; };          // 64 KB
+template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 128 KB
+template <> struct TileShape<2> { static constexpr int X = 32, Y = 16, Z = 8; };         // 128 KB
+template <> struct TileShape<3> { static constexpr int X = 32, Y = 8, Z = 8; };          // 96 KB
+template <> struct TileShape<4> { static constexpr int X = 32, Y = 8, Z = 8; };          // 128 KB
 
 // ---------------------------------------------------------------------------
 // tile_walk: one workgroup per task; density and accumulators of the brick in LDS
