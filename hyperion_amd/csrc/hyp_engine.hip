@@ -238,7 +238,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 4096 packets per task, 8192 on Cartesian grids */, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -253,14 +253,14 @@ struct hyp_engine {
     std::vector<double> h_vor_sites; std::vector<int> h_vor_idx, h_vor_neigh;     // host copies for the cluster builder
     // cluster-tiled octree schedule (hyp_otile.h): tables built by build_oct_clusters()
     int ot_cells = 0;               // option: most cells per cluster (0: as many as the LDS budget allows)
-    int ot_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB (78: two workgroups per CU)
+    int ot_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU)
     int ot_clusters = 0, ot_max_cells = 0, ot_max_kids = 0, ot_built_for = -1;
     int *d_ot_cluster = nullptr, *d_ot_c0 = nullptr, *d_ot_nc = nullptr, *d_ot_kid_off = nullptr;
     OctCell *d_ot_rec = nullptr; short *d_ot_kid = nullptr, *d_ot_nb = nullptr;
     std::vector<OctCell> h_oct_cells; std::vector<int> h_oct_children, h_oct_neigh;      // host copies for the cluster builder
     // slab-tiled AMR schedule (hyp_atile.h): tables built by build_amr_slabs()
     int at_cells = 0;               // option: most cells per slab (0: as many as the LDS budget allows)
-    int at_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB
+    int at_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU)
     int at_slabs_n = 0, at_max_cells = 0, at_max_go = 0, at_max_walls = 0, at_built_for = -1;
     AtSlab *d_at_slabs = nullptr; short *d_at_go = nullptr; int *d_at_grid_c0 = nullptr, *d_at_grid_nz = nullptr;      // (d_at_grid_nz: bricks along x, y per grid)
     std::vector<AmrGrid> h_amr_grids; std::vector<int> h_amr_go;
@@ -605,7 +605,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
-    T.task_size = h->tile_task <= 0 ? (P.grid_type == 1 ? 8192 : 4096) : h->tile_task < 256 ? 256 : h->tile_task;
+    T.task_size = h->tile_task <= 0 ? (P.grid_type == 3 ? 4096 : 8192) : h->tile_task < 256 ? 256 : h->tile_task;
     T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare) ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
@@ -2021,7 +2021,7 @@ static int build_vor_clusters(hyp_handle h)
         }
         const size_t lds = sizeof(VtHdr) * (size_t)max_cells + sizeof(VorWall) * (size_t)max_walls + sizeof(double) * 2 * (size_t)max_cells * nd;
         if (max_cells <= 256 && lds <= budget) break;
-        if (h->vt_cells > 0 && max_cells <= 256 && lds <= 2 * budget) break;       // a forced size may take a whole CU's LDS
+        if (h->vt_cells > 0 && max_cells <= 256 && lds <= std::min(2 * budget, (size_t)156 * 1024)) break;       // a forced size may take a whole CU's LDS
         if (h->vt_cells > 0 || attempt > 40) return h->set_error("voronoi clusters do not fit in LDS");
         target *= 0.9;
     }
@@ -2092,7 +2092,7 @@ static int build_amr_slabs(hyp_handle h)
     if (G.empty()) return h->set_error("amr tables missing for the brick builder");
     if (G.size() >= 32767) return h->set_error("too many amr grids for the 16-bit goto slices of the tiled schedule");
     const size_t budget = (size_t)h->at_lds_kb * 1024;
-    int b[3] = {16, nd <= 2 ? 16 : 8, nd == 1 ? 16 : 8};      // two 512-thread workgroups per CU
+    int b[3] = {h->at_lds_kb > 100 ? 32 : 16, nd <= 2 ? 16 : 8, nd == 1 ? 16 : 8};      // one 1024-thread workgroup per CU (option at_lds_kb <= 100: 16-cell bricks, two fit a CU)
     if (h->at_cells > 0)         // option: smaller bricks (tests)
         while ((long long)b[0] * b[1] * b[2] > h->at_cells && (b[0] > 1 || b[1] > 1 || b[2] > 1)) {
             int a = b[2] >= b[1] && b[2] >= b[0] ? 2 : (b[1] >= b[0] ? 1 : 0);

@@ -20,10 +20,10 @@
 #include "hyp_tiled.h"
 
 #ifndef HYP_OTILE_WG
-#define HYP_OTILE_WG 512          // threads per workgroup (one workgroup per task)
+#define HYP_OTILE_WG 1024         // threads per workgroup (one workgroup per task; one per CU with clusters of up to 156 KB: 104.5 -> 97.3 ms on configs[3] against two 512-thread workgroups on 78 KB clusters)
 #endif
 #ifndef HYP_OTILE_OCC
-#define HYP_OTILE_OCC 4          // waves per SIMD the register budget is set for (two 512-thread workgroups per CU)
+#define HYP_OTILE_OCC 4          // waves per SIMD the register budget is set for (16 waves per CU)
 #endif
 #ifndef HYP_OTILE_SERVICE
 #define HYP_OTILE_SERVICE 24      // lanes that must wait before a wave runs its service phase (8 / 16 / 24 / 32: 118.9 / 119.1 / 114.2 / - ms at 4 steps)

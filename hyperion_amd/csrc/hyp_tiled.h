@@ -83,6 +83,9 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
 #ifndef HYP_WALK_ATTR
 #define HYP_WALK_ATTR
 #endif
+#ifndef HYP_TILE_PREFETCH
+#define HYP_TILE_PREFETCH 0      // look-ahead of tile_walk's record prefetch, in packets of the task's queue (0: none; measured: no gain, profiles/r03_tiled_log.md)
+#endif
 #define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
@@ -1226,6 +1229,14 @@ __device__ __forceinline__ bool in_correct_cell_brick(const Walls &W, const doub
     return found && act[0] == c.ic[0] && act[1] == c.ic[1] && act[2] == c.ic[2];
 }
 
+// fire-and-forget load of one dword into a junk LDS word per lane (LDS address = M0 + 4 x lane): pulls the line towards the CU
+__device__ __forceinline__ void tile_prefetch(const void *src, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
 // lane states of tile_walk_kernel
 // LS_CHECK: the propagation check is due; LS_SLOW: geo_find_wall is needed for this step
 // LS_REABS: the step would run into a source (grid_propagate_3d.f90:139-143)
@@ -1307,6 +1318,21 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
         }
     }
     if (threadIdx.x == 0) next_pkt = 0;
+    // Record prefetch: the packets of a task are taken in queue order, so the record a lane will need HYP_TILE_PREFETCH claims
+    // from now can be pulled towards the CU while the packets at hand walk; the claim's own loads of order[] and hot[] then hit
+    // L2 instead of waiting for HBM in the service phase.  The prefetch is a global_load_lds_dword into a junk word per lane:
+    // no destination register, and -- being inline asm -- no s_waitcnt of the compiler's is attributed to it.  vmcnt counts in
+    // order, so it is issued after every load of the claim has been waited for (tile_prefetch_fence) and nothing waits on it
+    // before the next service phase.
+    __shared__ int pf_junk[64];
+    const unsigned pf_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_junk);
+    if (HYP_TILE_PREFETCH > 0 && !RING) {
+        for (int j = threadIdx.x; j < 2 * HYP_TILE_PREFETCH && j < tk.len; j += blockDim.x) {
+            const int sp = order[tk.start + j];
+            if (j < HYP_TILE_PREFETCH) tile_prefetch(&hot[sp], pf_lds);
+            else asm volatile("" :: "v"(sp));
+        }
+    }
     __syncthreads();
 
     Counters cnt;
@@ -1453,6 +1479,8 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 else if (RING && j >= tail_now) claim = j;        // not landed yet: the lane waits (m_wait)
                 else {
                     if (RING) slot = ring.slot_of(j); else slot = order[tk.start + j];
+                    int slot_ahead = 0;
+                    if (HYP_TILE_PREFETCH > 0 && !RING && j + HYP_TILE_PREFETCH < tk.len) slot_ahead = order[tk.start + j + HYP_TILE_PREFETCH];
                     const HotRec<ND> &H = RING ? ring.record(j) : hot[slot];
                     claim = -1;
                     v_ok = true;
@@ -1472,6 +1500,17 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     if (RING) ring.taken(j);
+                    if (HYP_TILE_PREFETCH > 0 && !RING) {
+                        // every value loaded above is "used" here: the compiler waits for them now and has nothing in flight
+                        // when the prefetches go out
+                        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(tau_req), "v"(tau_ach), "v"(energy),
+                                     "v"(g.id_lo), "v"(g.id_hi), "v"(g.countdown), "v"(g.blk_b), "v"(cell.ic[0]), "v"(cell.ic[1]), "v"(cell.ic[2]),
+                                     "v"(cell.ow[0]), "v"(cell.ow[1]), "v"(cell.ow[2]), "v"(t_src), "v"(t_ach), "v"(slot_ahead));
+#pragma unroll
+                        for (int d = 0; d < ND; d++) asm volatile("" :: "v"(chi[d]), "v"(kappa[d]));
+                        if (j + HYP_TILE_PREFETCH < tk.len) tile_prefetch(&hot[slot_ahead], pf_lds);
+                        if (j + 2 * HYP_TILE_PREFETCH < tk.len) tile_prefetch(&order[tk.start + j + 2 * HYP_TILE_PREFETCH], pf_lds);
+                    }
                     st = LS_WALK; pre = false;
                 }
             }
@@ -1539,6 +1578,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             }
         }
     }
+    if (HYP_TILE_PREFETCH > 0 && !RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetches still in flight
     __syncthreads();
     if (T.split) {
         if (threadIdx.x < 27 && nb_cnt[threadIdx.x]) {
