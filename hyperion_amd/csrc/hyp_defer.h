@@ -343,6 +343,98 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Sorted peel-off.  The events of a round are written in the order the propagation waves reach them: neighbouring lanes of
+// a peel wave then walk through unrelated parts of the grid, and every load of the walk (next cell, its record, its
+// density) is 64 different cache lines -- the imaging kernels are bound by exactly that, the L1's look-ups per scattered
+// load, not by the latency of the chain (profiles/r03_tiled_log.md).  Ordered by the cell they happened in, the events of
+// a wave start in the same few cells and, for one view, walk the same way out: the lanes touch the same lines (the
+// direct light of a point source, one event per packet, is 64 times the same walk) and finish together.  The order is a
+// counting sort of the event slots by key = cell index scaled to <= 4096 bins (indices follow the tree / the grid's
+// rows, so a bin is a compact region): histogram + keys, scan, scatter; the peel kernel takes pair p as view p / n,
+// event order[p % n].  Which pair a lane walks changes nothing about the walk (peel_rng is keyed by packet, event, view).
+// ---------------------------------------------------------------------------------------------------------------------
+
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256) void peel_sort_hist_kernel(const DProblem *__restrict__ Pp, DeferBuf B)
+{
+    __shared__ unsigned int hist[HYP_SORT_MAX_BINS];
+    const DProblem &P = *Pp;
+    const PeelEvent<NDT, GEOM> *__restrict__ ev = (const PeelEvent<NDT, GEOM> *)B.events;
+    unsigned long long n_slots = B.ctl->reserved;
+    if (n_slots > B.cap) n_slots = B.cap;
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * HYP_SORT_PER_WG;
+    if (i0 >= n_slots) return;
+    for (unsigned int b = threadIdx.x; b < B.n_bins; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const unsigned long long i1 = i0 + HYP_SORT_PER_WG < n_slots ? i0 + HYP_SORT_PER_WG : n_slots;
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        unsigned int key = HYP_SORT_EMPTY;
+        if (ev[i].code != 0) {
+            const unsigned long long idx = (unsigned long long)geo_index(P, ev[i].cell);
+            key = idx >= P.n_cells ? B.n_bins - 1u : (unsigned int)((idx * (unsigned long long)B.n_bins) / P.n_cells);
+            atomicAdd(&hist[key], 1u);
+        }
+        B.keys[i] = key;
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < B.n_bins; b += blockDim.x) if (hist[b]) atomicAdd(&B.bins[b], hist[b]);
+}
+
+// one workgroup: offsets = exclusive scan of the counts, the counts become the cursors of the scatter, n_sorted = their sum
+static __global__ __launch_bounds__(1024) void peel_sort_scan_kernel(DeferBuf B)
+{
+    __shared__ unsigned int part[1024];
+    const unsigned int per = (B.n_bins + 1023u) / 1024u, b0 = threadIdx.x * per;
+    unsigned int sum = 0;
+    for (unsigned int b = b0; b < b0 + per && b < B.n_bins; b++) sum += B.bins[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (unsigned int d = 1; d < 1024u; d <<= 1) {
+        const unsigned int v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned int run = part[threadIdx.x] - sum;
+    for (unsigned int b = b0; b < b0 + per && b < B.n_bins; b++) {
+        const unsigned int c = B.bins[b];
+        B.bins[B.n_bins + b] = run; B.bins[b] = 0;
+        run += c;
+    }
+    if (threadIdx.x == 1023) B.ctl->n_sorted = part[1023];
+}
+
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256) void peel_sort_scatter_kernel(const DProblem *__restrict__ Pp, DeferBuf B)
+{
+    // per workgroup: count its slots per bin, reserve that many places of the bin with ONE atomic, hand them out locally
+    __shared__ unsigned int hist[HYP_SORT_MAX_BINS];
+    __shared__ unsigned int base[HYP_SORT_MAX_BINS];
+    unsigned long long n_slots = B.ctl->reserved;
+    if (n_slots > B.cap) n_slots = B.cap;
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * HYP_SORT_PER_WG;
+    if (i0 >= n_slots) return;
+    for (unsigned int b = threadIdx.x; b < B.n_bins; b += blockDim.x) hist[b] = 0;
+    __syncthreads();
+    const unsigned long long i1 = i0 + HYP_SORT_PER_WG < n_slots ? i0 + HYP_SORT_PER_WG : n_slots;
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const unsigned int key = B.keys[i];
+        if (key != HYP_SORT_EMPTY) atomicAdd(&hist[key], 1u);
+    }
+    __syncthreads();
+    for (unsigned int b = threadIdx.x; b < B.n_bins; b += blockDim.x) {
+        const unsigned int c = hist[b];
+        base[b] = c ? B.bins[B.n_bins + b] + atomicAdd(&B.bins[b], c) : 0u;
+        hist[b] = 0;
+    }
+    __syncthreads();
+    for (unsigned long long i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        const unsigned int key = B.keys[i];
+        if (key != HYP_SORT_EMPTY) B.order[base[key] + atomicAdd(&hist[key], 1u)] = (unsigned int)i;
+    }
+}
+
 // The peel-off half: one lane per (event, view), peeloff<.., PLAIN> up to the walk, grid_escape_tau
 // (grid_propagate_3d.f90:377-480) a few cells at a time, image_bin at the end.
 template <int NDT, int GEOM>
@@ -361,6 +453,8 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
     unsigned long long n_slots = B.ctl->reserved;
     if (n_slots > B.cap) n_slots = B.cap;
     const unsigned long long n_views = (unsigned long long)P.n_views_total;
+    const bool sorted = B.order != nullptr;
+    if (sorted) n_slots = B.ctl->n_sorted;       // only written slots are listed
     const unsigned long long n_pairs = n_slots * n_views;
     const unsigned int lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -406,10 +500,11 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 mask &= ~taken;
             }
             if (got) {
-                const PeelEvent<NDT, GEOM> &E = ev[pair / n_views];
+                // sorted: view-major, so that neighbouring lanes hold neighbouring events of ONE view
+                const PeelEvent<NDT, GEOM> &E = ev[sorted ? (unsigned long long)B.order[pair % n_slots] : pair / n_views];
                 const int code = E.code;
                 if (code != 0) {
-                    int vg = (int)(pair % n_views), g_i = 0;
+                    int vg = sorted ? (int)(pair / n_slots) : (int)(pair % n_views), g_i = 0;
                     while (g_i + 1 < P.n_peeled && vg >= P.peeled[g_i + 1].view_base) g_i++;
                     const DPeeled &G = P.peeled[g_i];
                     const int iv = vg - G.view_base;

@@ -255,6 +255,7 @@ struct PeelCtl {
     unsigned long long pair_cursor;     // (event, view) pairs handed out by the peel kernel
     unsigned long long written;         // events written in this round
     unsigned int n_susp[2], n_ret[2];   // packets set aside / id ranges returned, by round parity
+    unsigned long long n_sorted;        // events of this round in DeferBuf::order (sorted peel-off)
 };
 
 struct DeferBuf {
@@ -264,7 +265,16 @@ struct DeferBuf {
     void *susp[2];                      // SuspRec<NDT, GEOM>[one per lane of the propagation grid], by round parity
     unsigned long long *ret[2];         // (next, end) pairs, one per wave of the propagation grid
     int cur;                            // parity of this round
+    // sorted peel-off (hyp_defer.h: peel_sort_*): the round's events ordered by the cell they happened in, so that the lanes
+    // of a peel wave walk side by side; null = the events are taken in the order they were written
+    unsigned int *order;                // [cap] event slots by ascending key
+    unsigned int *keys;                 // [cap] key of every event slot (HYP_SORT_EMPTY: nothing written there)
+    unsigned int *bins;                 // [2 * n_bins]: counts (then cursors) | offsets
+    unsigned int n_bins;
 };
+#define HYP_SORT_EMPTY 0xffffffffu
+#define HYP_SORT_MAX_BINS 4096
+#define HYP_SORT_PER_WG 8192      // event slots per workgroup of the sort kernels
 
 // Staged imaging iteration (hyp_stage.h): slot records, one event per slot and round
 struct StageCtl {

@@ -290,6 +290,9 @@ struct hyp_engine {
     StageCtl *d_stage_ctl = nullptr, *h_stage_ctl = nullptr;
     size_t stage_alloc = 0, stage_hot_bytes = 0, stage_cold_bytes = 0;
     long long peel_events = 16ll << 20;     // option: capacity of the event buffer, in events
+    int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
+    unsigned int *d_peel_order = nullptr, *d_peel_keys = nullptr, *d_peel_bins = nullptr;
+    size_t peel_sort_cap = 0;
     bool peel_events_exact = false;         // set by the option: use exactly that many (tests force many rounds with it)
     void *d_peel_events = nullptr, *d_peel_susp[2] = {nullptr, nullptr};
     unsigned long long *d_peel_ret[2] = {nullptr, nullptr};
@@ -797,6 +800,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_stage_hot); free_dev(h->d_stage_cold); free_dev(h->d_stage_ctl);
     if (h->h_stage_ctl) { (void)hipHostFree(h->h_stage_ctl); h->h_stage_ctl = nullptr; }
     free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
+    free_dev(h->d_peel_order); free_dev(h->d_peel_keys); free_dev(h->d_peel_bins);
     free_dev(h->d_peel_ctl);
     if (h->h_peel_ctl) (void)hipHostFree(h->h_peel_ctl);
     if (h->h_peel_counter) (void)hipHostFree(h->h_peel_counter);
@@ -2734,6 +2738,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "stage_slots") { if (value < 256) return h->set_error("stage_slots must be at least 256"); h->stage_slots = value; }
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
     else if (n == "peel_events") {
@@ -2783,6 +2788,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
+    else if (n == "peel_sort") *value = h->peel_sort;
     else if (n == "stage_slots") *value = h->stage_slots;
     else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
@@ -2849,6 +2855,23 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
     DeferBuf B;
     B.events = h->d_peel_events; B.cap = h->peel_cap; B.ctl = h->d_peel_ctl;
     B.susp[0] = h->d_peel_susp[0]; B.susp[1] = h->d_peel_susp[1]; B.ret[0] = h->d_peel_ret[0]; B.ret[1] = h->d_peel_ret[1];
+    B.order = nullptr; B.keys = nullptr; B.bins = nullptr; B.n_bins = 0;
+    if (h->peel_sort && dk.sort_hist && h->peel_cap < 0xffffffffull) {
+        // sorted peel-off: order + keys per event slot, counts | offsets per bin; without the memory the events are taken as written
+        if (h->peel_sort_cap < h->peel_cap) {
+            free_dev(h->d_peel_order); free_dev(h->d_peel_keys);
+            h->peel_sort_cap = 0;
+            if (hipMalloc((void **)&h->d_peel_order, sizeof(unsigned int) * h->peel_cap) == hipSuccess &&
+                hipMalloc((void **)&h->d_peel_keys, sizeof(unsigned int) * h->peel_cap) == hipSuccess) h->peel_sort_cap = h->peel_cap;
+            else { (void)hipGetLastError(); free_dev(h->d_peel_order); free_dev(h->d_peel_keys); }
+        }
+        if (!h->d_peel_bins && hipMalloc((void **)&h->d_peel_bins, sizeof(unsigned int) * 2 * HYP_SORT_MAX_BINS) != hipSuccess) { (void)hipGetLastError(); h->d_peel_bins = nullptr; }
+        if (h->peel_sort_cap >= h->peel_cap && h->d_peel_bins) {
+            B.order = h->d_peel_order; B.keys = h->d_peel_keys; B.bins = h->d_peel_bins;
+            B.n_bins = (unsigned int)std::max<unsigned long long>(1ull, std::min<unsigned long long>(HYP_SORT_MAX_BINS, h->hp.n_cells));
+        }
+    }
+    const unsigned sort_blocks = (unsigned)((h->peel_cap + HYP_SORT_PER_WG - 1) / HYP_SORT_PER_WG);
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.peel, 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
@@ -2857,6 +2880,12 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
         B.cur = round & 1;
         hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, B.cur, round == 0 ? 1 : 0);
         hipLaunchKernelGGL(dk.propagate, dim3(blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
+        if (B.order) {
+            (void)hipMemsetAsync(B.bins, 0, sizeof(unsigned int) * B.n_bins, h->stream);
+            hipLaunchKernelGGL(dk.sort_hist, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
+            hipLaunchKernelGGL(dk.sort_scan, dim3(1), dim3(1024), 0, h->stream, B);
+            hipLaunchKernelGGL(dk.sort_scatter, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
+        }
         hipLaunchKernelGGL(dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return h->set_error(std::string("deferred imaging launch: ") + hipGetErrorString(e));

@@ -14,11 +14,13 @@ template <int GEOM> RayKernel pick_ray_kernel_g(int nd);      // ray_kernel<nd, 
 // deferred peel-off (hyp_defer.h): final_defer_kernel<nd, GEOM> / peel_kernel<nd, GEOM> and their record sizes
 using DeferKernel = void (*)(const DProblem *, LaunchParams, DeferBuf);
 using PeelKernel = void (*)(const DProblem *, DeferBuf, uint32_t);
+using PeelSortK = void (*)(const DProblem *, DeferBuf);
 using StageEventK = void (*)(const DProblem *, LaunchParams, StageBuf);
 using StageWalkK = void (*)(const DProblem *, StageBuf, uint32_t);
 using StageInitK = void (*)(StageBuf);
 struct DeferKernels {
     DeferKernel propagate; PeelKernel peel; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes;
+    PeelSortK sort_hist, sort_scatter; void (*sort_scan)(DeferBuf);  // sorted peel-off: keys + histogram, scatter (peel_sort_scan_kernel between them)
     // staged schedule (hyp_stage.h): slot records StageHot (hot_bytes) + SuspRec (susp_bytes), one PeelEvent per slot
     StageEventK stage_event; StageWalkK stage_walk; StageInitK stage_init; size_t hot_bytes;
 };

@@ -6,6 +6,9 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hyperion_amd
+if os.environ.get("HYP_LIB"):        # a tuning variant built by tools/variants.py (one geometry, one species)
+    import hyperion_amd.engine as E
+    E._lib = E.load_library(os.environ["HYP_LIB"])
 from hyperion_amd.benchmark import make_octree_problem
 
 which = sys.argv[1]
