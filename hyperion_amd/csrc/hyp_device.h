@@ -273,7 +273,9 @@ struct DeferBuf {
     unsigned int n_bins;
 };
 #define HYP_SORT_EMPTY 0xffffffffu
+#ifndef HYP_SORT_MAX_BINS
 #define HYP_SORT_MAX_BINS 4096
+#endif
 #define HYP_SORT_PER_WG 8192      // event slots per workgroup of the sort kernels
 
 // Staged imaging iteration (hyp_stage.h): slot records, one event per slot and round

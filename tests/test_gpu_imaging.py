@@ -237,6 +237,13 @@ def test_deferred_peeloff_equals_inline(kw, peel_events):
     rounds = eng.get_option("last_defer_rounds")
     assert rounds >= (3 if peel_events else 1)
     assert eng.get_option("last_defer_events") >= 30000
+    # the peel kernel took the events ordered by cell (peel_sort, the default); as written they give the same images
+    assert eng.get_option("peel_sort") == 1
+    eng.set_option("peel_sort", 0)
+    rc, sc = eng.final_iteration(30000)
+    for k in INT_KEYS:
+        assert sa[k] == sc[k], (k, sa, sc)
+    _images_equal(ra, rc)
     eng.set_option("defer_peel", 0)
     rb, sb = eng.final_iteration(30000)
     assert eng.get_option("last_defer_rounds") == 0
