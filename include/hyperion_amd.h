@@ -344,12 +344,14 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * (-1 auto, 0 persistent kernel with global atomics, 1 tiled: bricks of a Cartesian grid, hyp_tiled.h; clusters of Voronoi
  * cells, hyp_vtile.h; runs of sibling subtrees of an octree, hyp_otile.h),
  * "tile_slots" (0: 3 << 21, octree 3 << 22), "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "tile_park",
- * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb" (most cells per Voronoi / octree cluster; LDS budget of a walk workgroup),
+ * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb", "at_cells" / "at_lds_kb" (most cells per Voronoi / octree cluster / AMR brick; LDS
+ * budget of a walk workgroup in KB: 156 = one 1024-thread workgroup per CU on octree and AMR grids, 78 = two 512-thread ones on Voronoi),
  * "tile_time_walk" (1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches"; off by
  * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only),
  * "final_interact_threshold" /
  * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
- * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer), "oct_neighbours" (0: the
+ * imaging kernel applies, hyp_defer.h; 2: the staged schedule, hyp_stage.h; 0: inline), "peel_events" (capacity of its event buffer),
+ * "peel_sort" (1, the default: the peel kernel takes a round's events ordered by the cell they happened in), "oct_neighbours" (0: the
  * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (can only be
  * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
  * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more
