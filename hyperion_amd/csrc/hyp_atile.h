@@ -330,7 +330,7 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
 #pragma unroll
         for (int d = 0; d < ND; d++) {
             const double val = accum[c * ND + d];
-            if (val != 0.0) unsafeAtomicAdd(&sum[gid * ND + d], val);
+            if (val != 0.0) hyp_atomic_add_g(&sum[gid * ND + d], val);
         }
     }
     block_tally_flush(P, ctl, red, cnt, finished);

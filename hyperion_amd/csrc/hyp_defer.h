@@ -88,7 +88,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
 #pragma unroll
     for (int d = 0; d < NDT; d++) {
         rho[d] = 0.0;
-        if (d < nd) { rho[d] = P.density[base + d]; chi_rho += p.chi[d] * rho[d]; }
+        if (d < nd) { rho[d] = hyp_ldg(P.density + base + d); chi_rho += p.chi[d] * rho[d]; }
     }
     const double tau_cell = chi_rho * tmin;
     const double tau_needed = p.tau_req - p.tau_ach;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
 #pragma unroll
                     for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
-                    for (int dd = 0; dd < NDT; dd++) if (dd < nd) tau += chi[dd] * P.density[base + dd] * tmin;
+                    for (int dd = 0; dd < NDT; dd++) if (dd < nd) tau += chi[dd] * hyp_ldg(P.density + base + dd) * tmin;
                     cnt.crossings++;
                     geo_advance(P, r, c, im);
                     if (geo_invalid(P, c)) { cnt.killed_geo++; st = 0; }

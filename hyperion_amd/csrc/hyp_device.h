@@ -110,6 +110,51 @@ struct alignas(16) OctCell {
     unsigned char pad;
 };
 
+// A pointer that comes out of a DProblem in memory is "flat" to the compiler (it cannot know that it does not point into LDS or
+// scratch; neither an address-space cast pair nor an assumption changes that with this hipcc), and a flat load is issued to the
+// LDS and the vector-memory path both, counts on lgkmcnt and vmcnt, and is not merged with its neighbours: an OctCell arrives as
+// dwordx4 + dwordx2 + dword + ubyte.  The tables of the walks live in global memory: these loaders say so with address-space-1
+// pointers to builtin types (hyp_ldg: one scalar; oct_cell_ldg: the 32-byte record as two global_load_dwordx4).  Measured
+// (profiles/r03_tiled_log.md): configs[3] imaging 427 -> 390 ms; the lookup tables of the interaction / emission kernels neutral;
+// the Voronoi wall records of the persistent kernel and of place_in_cell's site search are left as they were (two dwordx4 per
+// record instead of dwordx4 + dwordx2 + dword read 32 bytes for 28 and cost 2.5 % of a configs[4] iteration).
+#if defined(__HIPCC__)
+#define HYP_AS1 __attribute__((address_space(1)))
+typedef float hyp_v4f __attribute__((ext_vector_type(4)));
+template <class T> __device__ __forceinline__ T hyp_ldg(const T *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const HYP_AS1 T *)p;
+#else
+    return *p;
+#endif
+}
+// unsafeAtomicAdd on an address in global memory: global_atomic_add_f64 instead of the flat form
+__device__ __forceinline__ void hyp_atomic_add_g(double *p, double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)__hip_atomic_fetch_add((HYP_AS1 double *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p += v;
+#endif
+}
+__device__ __forceinline__ OctCell oct_cell_ldg(const OctCell *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const HYP_AS1 hyp_v4f *q = (const HYP_AS1 hyp_v4f *)p;
+    const hyp_v4f u = q[0], w = q[1];
+    OctCell o;
+    o.x = __hiloint2double(__float_as_int(u.y), __float_as_int(u.x)); o.y = __hiloint2double(__float_as_int(u.w), __float_as_int(u.z));
+    o.z = __hiloint2double(__float_as_int(w.y), __float_as_int(w.x)); o.parent = __float_as_int(w.z);
+    const unsigned int m = (unsigned int)__float_as_int(w.w);
+    o.subcell = (signed char)(m & 0xffu); o.level = (unsigned char)((m >> 8) & 0xffu); o.refined = (unsigned char)((m >> 16) & 0xffu); o.pad = 0;
+    return o;
+#else
+    return *p;
+#endif
+}
+#endif
+
 // Slots of the scalar tail that follows the per-cell accumulators.
 // TAIL_RANK_ERROR: never written on the device; a rank of a sharded run that failed adds 1 there before the all-reduce
 // (hyperion_amd/distributed.py, hyp_run.cpp), so the sum tells every rank.
@@ -384,25 +429,41 @@ __device__ __forceinline__ int locate(const double *__restrict__ x, int n, doubl
     return jl;
 }
 
+// locate() on a table in global memory (dust, source and run tables: everything but the walls staged in LDS): global loads
+__device__ __forceinline__ int locate_g(const double *__restrict__ x, int n, double xv)
+{
+    const double x0 = hyp_ldg(x), xn = hyp_ldg(x + n - 1);
+    if (!(xv >= x0) || !(xv <= xn)) return -1;
+    if (xv == xn) return n - 2;
+    int jl = 0, ju = n - 1;
+    while (ju - jl > 1) {
+        int jm = (ju + jl) >> 1;
+        if (xv >= hyp_ldg(x + jm)) jl = jm; else ju = jm;
+    }
+    return jl;
+}
+
 // log-log interpolation with precomputed log10 tables; linear where an
 // ordinate is not positive.  j = bracketing bin, lxv = log10(xv).
 __device__ __forceinline__ double interp_loglog_at(const double *__restrict__ x, const double *__restrict__ lx,
                                                    const double *__restrict__ y, const double *__restrict__ ly,
                                                    int j, double xv, double lxv)
 {
-    double y1 = y[j], y2 = y[j + 1];
+    double y1 = hyp_ldg(y + j), y2 = hyp_ldg(y + j + 1);
     if (y1 > 0.0 && y2 > 0.0) {
-        double f = (lxv - lx[j]) / (lx[j + 1] - lx[j]);
-        return exp10(ly[j] + f * (ly[j + 1] - ly[j]));
+        const double lx1 = hyp_ldg(lx + j), ly1 = hyp_ldg(ly + j);
+        double f = (lxv - lx1) / (hyp_ldg(lx + j + 1) - lx1);
+        return exp10(ly1 + f * (hyp_ldg(ly + j + 1) - ly1));
     }
-    return y1 + (xv - x[j]) / (x[j + 1] - x[j]) * (y2 - y1);
+    const double x1 = hyp_ldg(x + j);
+    return y1 + (xv - x1) / (hyp_ldg(x + j + 1) - x1) * (y2 - y1);
 }
 
 // bilinear, a[iy][ix]
 __device__ __forceinline__ double bilinear(const double *__restrict__ a, int nx, int i, int j, double fx, double fy)
 {
     const double *r0 = a + (size_t)j * nx + i, *r1 = r0 + nx;
-    double a00 = r0[0], a10 = r0[1], a01 = r1[0], a11 = r1[1];
+    double a00 = hyp_ldg(r0), a10 = hyp_ldg(r0 + 1), a01 = hyp_ldg(r1), a11 = hyp_ldg(r1 + 1);
     return a00 * (1 - fx) * (1 - fy) + a10 * fx * (1 - fy) + a01 * (1 - fx) * fy + a11 * fx * fy;
 }
 
@@ -410,11 +471,11 @@ __device__ __forceinline__ double bilinear(const double *__restrict__ a, int nx,
 __device__ __forceinline__ double sample_log_pdf(const double *__restrict__ x, const double *__restrict__ cdf,
                                                  const double *__restrict__ bp1, int n, double xi)
 {
-    int j = locate(cdf, n, xi);
+    int j = locate_g(cdf, n, xi);
     if (j < 0) j = 0;
-    double c1 = cdf[j], c2 = cdf[j + 1];
+    double c1 = hyp_ldg(cdf + j), c2 = hyp_ldg(cdf + j + 1);
     double f = (c2 > c1) ? (xi - c1) / (c2 - c1) : 0.0;
-    double x1 = x[j], x2 = x[j + 1], b = bp1[j];
+    double x1 = hyp_ldg(x + j), x2 = hyp_ldg(x + j + 1), b = hyp_ldg(bp1 + j);
     if (b != b) return x1 + f * (x2 - x1);
     if (fabs(b) < 1e-10) return x1 * pow(x2 / x1, f);
     return x1 * pow(1.0 + f * (pow(x2 / x1, b) - 1.0), 1.0 / b);
@@ -432,12 +493,12 @@ __device__ __forceinline__ void sample_log_pdf_pair(const double *__restrict__ x
                                                     const double *__restrict__ co_a, const double *__restrict__ co_b, int n, int nc, double xi,
                                                     double &xa, double &xb)
 {
-    const bool in_a = (xi >= cdf_a[0]) && (xi <= cdf_a[n - 1]);
-    const bool in_b = (xi >= cdf_b[0]) && (xi <= cdf_b[n - 1]);
+    const bool in_a = (xi >= hyp_ldg(cdf_a)) && (xi <= hyp_ldg(cdf_a + n - 1));
+    const bool in_b = (xi >= hyp_ldg(cdf_b)) && (xi <= hyp_ldg(cdf_b + n - 1));
     int lo_a = 0, hi_a = nc, lo_b = 0, hi_b = nc;
     while (hi_a - lo_a > 1 || hi_b - lo_b > 1) {
         const int ma = (lo_a + hi_a) >> 1, mb = (lo_b + hi_b) >> 1;
-        const double va = co_a[ma], vb = co_b[mb];
+        const double va = hyp_ldg(co_a + ma), vb = hyp_ldg(co_b + mb);
         if (hi_a - lo_a > 1) { if (xi >= va) lo_a = ma; else hi_a = ma; }
         if (hi_b - lo_b > 1) { if (xi >= vb) lo_b = mb; else hi_b = mb; }
     }
@@ -445,8 +506,8 @@ __device__ __forceinline__ void sample_log_pdf_pair(const double *__restrict__ x
     double wa[HYP_COARSE + 1], wb[HYP_COARSE + 1];
 #pragma unroll
     for (int k = 0; k <= HYP_COARSE; k++) {      // the window and the entry after it, all loads independent
-        wa[k] = cdf_a[min(base_a + k, n - 1)];
-        wb[k] = cdf_b[min(base_b + k, n - 1)];
+        wa[k] = hyp_ldg(cdf_a + min(base_a + k, n - 1));
+        wb[k] = hyp_ldg(cdf_b + min(base_b + k, n - 1));
     }
     int ca = 0, cb = 0;
 #pragma unroll
@@ -460,10 +521,10 @@ __device__ __forceinline__ void sample_log_pdf_pair(const double *__restrict__ x
     if (!in_a) ja = 0;           // locate() = -1, sample_log_pdf then uses bin 0
     if (!in_b) jb = 0;
     // c1 = cdf[j], c2 = cdf[j+1]: from the window where possible
-    double c1a = cdf_a[ja], c2a = cdf_a[ja + 1], c1b = cdf_b[jb], c2b = cdf_b[jb + 1];
+    double c1a = hyp_ldg(cdf_a + ja), c2a = hyp_ldg(cdf_a + ja + 1), c1b = hyp_ldg(cdf_b + jb), c2b = hyp_ldg(cdf_b + jb + 1);
     (void)wa; (void)wb;
-    const double x1a = x[ja], x2a = x[ja + 1], ba = bp1_a[ja];
-    const double x1b = x[jb], x2b = x[jb + 1], bb = bp1_b[jb];
+    const double x1a = hyp_ldg(x + ja), x2a = hyp_ldg(x + ja + 1), ba = hyp_ldg(bp1_a + ja);
+    const double x1b = hyp_ldg(x + jb), x2b = hyp_ldg(x + jb + 1), bb = hyp_ldg(bp1_b + jb);
     const double fa = (c2a > c1a) ? (xi - c1a) / (c2a - c1a) : 0.0;
     const double fb = (c2b > c1b) ? (xi - c1b) / (c2b - c1b) : 0.0;
     if (ba != ba) xa = x1a + fa * (x2a - x1a);

@@ -90,7 +90,7 @@ __device__ __forceinline__ bool update_optconsts(const DProblem &P, Packet<NDT, 
                 raise_error(P, ERR_NU_RANGE, p.nu, D.nu_min, D.nu_max);
                 return false;
             }
-            int j = locate(D.nu, D.n_nu, p.nu);
+            int j = locate_g(D.nu, D.n_nu, p.nu);
             double chi = interp_loglog_at(D.nu, D.log10_nu, D.chi, D.log10_chi, j, p.nu, lnu);
             double alb = interp_loglog_at(D.nu, D.log10_nu, D.albedo, D.log10_albedo, j, p.nu, lnu);
             p.chi[d] = chi; p.albedo[d] = alb; p.kappa[d] = chi * (1.0 - alb);
@@ -253,14 +253,14 @@ __device__ __forceinline__ int oct_locate(const DProblem &P, const double r[3], 
 __device__ __forceinline__ void oct_descend(const DProblem &P, const double r[3], int id, Cell<GEOM_OCT> &c)
 {
     for (;;) {
-        const OctCell o = P.oct_cells[id];
+        const OctCell o = oct_cell_ldg(P.oct_cells + id);
         if (!o.refined) {
             c.id = id; c.c[0] = o.x; c.c[1] = o.y; c.c[2] = o.z;
             c.parent = o.parent; c.level = o.level; c.subcell = o.subcell;
             return;
         }
         int sub = (r[0] < o.x ? 0 : 1) | (r[1] < o.y ? 0 : 2) | (r[2] < o.z ? 0 : 4);
-        id = P.oct_children[8 * (size_t)id + sub];
+        id = hyp_ldg(P.oct_children + 8 * (size_t)id + sub);
     }
 }
 
@@ -376,7 +376,7 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
             if (b != axis && !(d < h * (1.0 - 1e-6) && h * 1e-6 > 1e-14 * (fabs(c.c[b]) + h))) fast = false;
         }
         if (fast) {
-            const int n = P.oct_neigh[6 * (size_t)c.id + 2 * axis + up];
+            const int n = hyp_ldg(P.oct_neigh + 6 * (size_t)c.id + 2 * axis + up);
             if ((unsigned long long)n == P.n_cells) { c.id = n; return; }
             oct_descend(P, r, n, c);
             return;
@@ -761,7 +761,7 @@ __device__ __forceinline__ void begin_integrate_lucy(const DProblem &P, Packet<N
 {
     begin_integrate(P, p);
     p.spec_idx = -1;
-    if (P.n_bins) p.spec_idx = locate(P.log_nu_edges, P.n_bins + 1, log10(p.nu));
+    if (P.n_bins) p.spec_idx = locate_g(P.log_nu_edges, P.n_bins + 1, log10(p.nu));
     if (P.count_photons && !geo_escaped(P, p.cell)) count_photon(P, geo_index(P, p.cell), photon_tag(g), p.n_visited);
 }
 
@@ -785,7 +785,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
 #pragma unroll
     for (int d = 0; d < NDT; d++) {
         rho[d] = 0.0;
-        if (d < nd) { rho[d] = P.density[base + d]; chi_rho += p.chi[d] * rho[d]; }
+        if (d < nd) { rho[d] = hyp_ldg(P.density + base + d); chi_rho += p.chi[d] * rho[d]; }
     }
     double tau_cell = chi_rho * tmin;
     double tau_needed = p.tau_req - p.tau_ach;
@@ -799,7 +799,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
 #pragma unroll
             for (int d = 0; d < NDT; d++)
                 if (d < nd && rho[d] > 0.0) {
-                    unsafeAtomicAdd(&sum[base + d], tmin * p.kappa[d] * p.energy);
+                    hyp_atomic_add_g(&sum[base + d], tmin * p.kappa[d] * p.energy);
                     if (P.n_bins && p.spec_idx >= 0)
                         unsafeAtomicAdd(&P.sum_spec[(size_t)p.spec_idx * P.n_cells * nd + base + d], tmin * p.kappa[d] * p.energy);
                 }
@@ -821,7 +821,7 @@ __device__ __forceinline__ int walk_step(const DProblem &P, const Walls &W, Pack
 #pragma unroll
             for (int d = 0; d < NDT; d++)
                 if (d < nd && rho[d] > 0.0) {
-                    unsafeAtomicAdd(&sum[base + d], tact * p.kappa[d] * p.energy);
+                    hyp_atomic_add_g(&sum[base + d], tact * p.kappa[d] * p.energy);
                     if (P.n_bins && p.spec_idx >= 0)
                         unsafeAtomicAdd(&P.sum_spec[(size_t)p.spec_idx * P.n_cells * nd + base + d], tact * p.kappa[d] * p.energy);
                 }
@@ -988,11 +988,11 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         const int nd = ndust<NDT>(P);
         const size_t base = map_cell * (size_t)nd;
         double c = 0.0;
-        for (int d = 0; d < nd; d++) c += P.specific_energy[base + d] * P.density[base + d];
+        for (int d = 0; d < nd; d++) c += P.specific_energy[base + d] * hyp_ldg(P.density + base + d);
         const double xi = rng_uniform(g);
         int id = nd - 1; double run = 0.0; bool found = false;
         for (int d = 0; d < nd - 1; d++) {
-            run += P.specific_energy[base + d] * P.density[base + d];
+            run += P.specific_energy[base + d] * hyp_ldg(P.density + base + d);
             if (!found && xi < run / c) { id = d; found = true; }
         }
         p.emiss_dust = id;
@@ -1052,7 +1052,7 @@ __device__ __forceinline__ double dust_sample_j_nu(const DDust &D, int jid, doub
 
 __device__ __forceinline__ void interp_P(const DDust &D, double mu, double nu, double &P1, double &P2, double &P3, double &P4)
 {
-    int i = locate(D.mu, D.n_mu, mu), j = locate(D.nu, D.n_nu, nu);
+    int i = locate_g(D.mu, D.n_mu, mu), j = locate_g(D.nu, D.n_nu, nu);
     if (i < 0 || j < 0) { P1 = P2 = P3 = P4 = __builtin_nan(""); return; }
     double fx = (mu - D.mu[i]) / (D.mu[i + 1] - D.mu[i]);
     double fy = (nu - D.nu[j]) / (D.nu[j + 1] - D.nu[j]);
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void dust_scatter(const DDust &D, double nu, Angle &a
     double ctot = c1 + c2;
     c1 /= ctot; c2 /= ctot;
     const int nm = D.n_mu;
-    int inu = locate(D.nu, D.n_nu, nu);
+    int inu = locate_g(D.nu, D.n_nu, nu);
     double P1, P2, P3, P4;
     if (inu == -1) {
         P1 = 1.0; P2 = 0.0; P3 = 1.0; P4 = 0.0;
@@ -1115,7 +1115,7 @@ __device__ __forceinline__ bool interact(const DProblem &P, Packet<NDT, GEOM> &p
     if (NDT > 1 && nd > 1) {
         double cdf[NDT], c = 0.0;
 #pragma unroll
-        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * P.density[base + d]; cdf[d] = c; }
+        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * hyp_ldg(P.density + base + d); cdf[d] = c; }
         double xi = rng_uniform(g);
         id = nd - 1; albedo = 0.0;
         bool found = false;
@@ -1217,16 +1217,16 @@ __device__ __forceinline__ int mrw_step(const DProblem &P, const Walls &W, Packe
     if (DEPOSIT) {
         // sample_cumulative :197-202: interp1d(ycdf, xcdf, xi)
         const double xi = rng_uniform(g);
-        const int j = locate(P.mrw_y, 100, xi);
+        const int j = locate_g(P.mrw_y, 100, xi);
         const double y = (j < 0) ? __builtin_nan("")
                                  : P.mrw_x[j] + (xi - P.mrw_y[j]) / (P.mrw_y[j + 1] - P.mrw_y[j]) * (P.mrw_x[j + 1] - P.mrw_x[j]);
         const double q = R0 / HYP_PI;
         const double ct = -log(y) / P.mrw_diff[ic] * (q * q);
 #pragma unroll
         for (int d = 0; d < NDT; d++)
-            if (d < nd && P.density[base + d] > 0.0) {
+            if (d < nd && hyp_ldg(P.density + base + d) > 0.0) {
                 const double e = p.energy * ct * P.mrw_kp[base + d];
-                unsafeAtomicAdd(&sum[base + d], e);
+                hyp_atomic_add_g(&sum[base + d], e);
                 if (P.n_bins) {      // deposit_specific_energy_spectrum: grid_physics_3d.f90:367-395
                     const int iv = P.jnu_id[base + d]; const double fr = P.jnu_frac[base + d];
                     const double *f0 = P.jnu_bin_frac + ((size_t)d * P.nj_max + iv) * P.n_bins, *f1 = f0 + P.n_bins;
@@ -1246,7 +1246,7 @@ __device__ __forceinline__ int mrw_step(const DProblem &P, const Walls &W, Packe
     if (NDT > 1 && nd > 1) {       // select_dust_chi_rho: grid_physics_3d.f90:87-99
         double cdf[NDT], c = 0.0;
 #pragma unroll
-        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * P.density[base + d]; cdf[d] = c; }
+        for (int d = 0; d < NDT; d++) { if (d < nd) c += p.chi[d] * hyp_ldg(P.density + base + d); cdf[d] = c; }
         const double xi = rng_uniform(g);
         id = nd - 1;
         bool found = false;
@@ -1557,7 +1557,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
 #pragma unroll
         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
-        for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * P.density[base + d] * tmin;
+        for (int d = 0; d < NDT; d++) if (d < nd) tau += chi[d] * hyp_ldg(P.density + base + d) * tmin;
         cnt.crossings++;
         if (finished) return tau;
         geo_advance(P, r, c, im);
@@ -1924,7 +1924,7 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
 #pragma unroll
         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
-        for (int d = 0; d < NDT; d++) if (d < nd) col[d] += P.density[base + d] * tmin;
+        for (int d = 0; d < NDT; d++) if (d < nd) col[d] += hyp_ldg(P.density + base + d) * tmin;
         cnt.crossings++;
         if (finished) return;
         geo_advance(P, r, c, im);
@@ -2561,7 +2561,7 @@ __device__ __forceinline__ void jnu_var_pos_frac(const DDust &D, double e, int &
     if (e < D.jnu_var[0]) { id = 0; frac = 0.0; }
     else if (e > D.jnu_var[n - 1]) { id = n - 2; frac = 1.0; }
     else {
-        int j = locate(D.jnu_var, n, e);
+        int j = locate_g(D.jnu_var, n, e);
         id = j;
         frac = (log10(e) - D.log10_jnu_var[j]) / (D.log10_jnu_var[j + 1] - D.log10_jnu_var[j]);
     }
@@ -2579,7 +2579,7 @@ __device__ __forceinline__ double clamp_energy(const DDust &D, double e, int enf
 
 __device__ __forceinline__ double chi_rosseland(const DDust &D, double e)
 {
-    int j = locate(D.mo_e, D.n_e, e);
+    int j = locate_g(D.mo_e, D.n_e, e);
     if (j < 0) return __builtin_nan("");
     double y1 = D.mo_chi_ross[j], y2 = D.mo_chi_ross[j + 1];
     if (y1 > 0.0 && y2 > 0.0) {
@@ -2592,7 +2592,7 @@ __device__ __forceinline__ double chi_rosseland(const DDust &D, double e)
 // interp1d_loglog on a mean-opacity table (dust.f90:81-100)
 __device__ __forceinline__ double mean_opacity(const DDust &D, const double *__restrict__ y, double e)
 {
-    int j = locate(D.mo_e, D.n_e, e);
+    int j = locate_g(D.mo_e, D.n_e, e);
     if (j < 0) return __builtin_nan("");
     double y1 = y[j], y2 = y[j + 1];
     if (y1 > 0.0 && y2 > 0.0) {

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
     }
     for (int i = threadIdx.x; i < nc * ND; i += blockDim.x) {
         const double val = accum[i];
-        if (val != 0.0) unsafeAtomicAdd(&sum[(size_t)c0 * ND + i], val);
+        if (val != 0.0) hyp_atomic_add_g(&sum[(size_t)c0 * ND + i], val);
     }
     block_tally_flush(P, ctl, red, cnt, finished);
 }

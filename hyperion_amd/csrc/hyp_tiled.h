@@ -1602,7 +1602,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             for (int d = 0; d < ND; d++) {
                 double val = accum[c * ND + d];
 #ifndef HYP_TILE_ABLATE_FLUSH
-                if (val != 0.0) unsafeAtomicAdd(&sum[gidx * ND + d], val);
+                if (val != 0.0) hyp_atomic_add_g(&sum[gidx * ND + d], val);
 #else
                 (void)val; (void)sum;
 #endif

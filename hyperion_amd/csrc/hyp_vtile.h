@@ -311,7 +311,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
     }
     for (int i = threadIdx.x; i < nc * ND; i += blockDim.x) {
         const double val = accum[i];
-        if (val != 0.0) unsafeAtomicAdd(&sum[(size_t)P.vt_members[c0 + i / ND] * ND + i % ND], val);
+        if (val != 0.0) hyp_atomic_add_g(&sum[(size_t)P.vt_members[c0 + i / ND] * ND + i % ND], val);
     }
     block_tally_flush(P, ctl, red, cnt, finished);
 }
