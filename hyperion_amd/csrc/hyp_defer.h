@@ -27,6 +27,11 @@
 #ifndef HYP_PEEL_OCC
 #define HYP_PEEL_OCC 3        // workgroups of the peel kernel per CU the register budget is set for
 #endif
+#ifndef HYP_DEFER_STEPS
+// cell crossings of the propagation kernel between two state checks: with the escape walks of the forced first interaction made
+// ahead a packet is at an event every ~12 crossings (configs[3], 1e8 packets: 4 / 8 / 16 / 32 steps 362 / 353 / 359 / 407 ms)
+#define HYP_DEFER_STEPS (GEOM == GEOM_OCT ? 8 : final_walk_steps<GEOM>())
+#endif
 #ifndef HYP_PEEL_STEPS
 #define HYP_PEEL_STEPS 16       // cell crossings between two refill / deposit checks
 #endif
@@ -113,8 +118,9 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
     return ST_NEED_INTERACT;
 }
 
-// The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.
-template <int NDT, int GEOM>
+// The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.  FFIN = false: every escape
+// walk of the forced first interaction was made ahead of the rounds (ff_walk_kernel, B.ff), the ST_FF state is compiled out.
+template <int NDT, int GEOM, bool FFIN>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
 {
     extern __shared__ double lds[];
@@ -154,7 +160,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 
     for (;;) {
         if (st == ST_ESCAPED) st = ST_NEED_EMIT;
-        unsigned long long m_walk = __ballot(st == ST_WALK || st == ST_FF);
+        unsigned long long m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
         const unsigned long long m_ffd = __ballot(st == ST_FF_DONE || st == ST_FF_KILLED);
         if (m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
             // the optical depth to the edge is known: back to the source, first optical depth (iter_final.f90:195-209)
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 begin_integrate(P, p);
                 st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
             }
-            m_walk = __ballot(st == ST_WALK || st == ST_FF);
+            m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
         }
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     else { p.inter++; peel = 2; }
                 }
             }
-            m_walk = __ballot(st == ST_WALK || st == ST_FF);
+            m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
             m_emit = __ballot(st == ST_NEED_EMIT);
         }
 
@@ -304,8 +310,27 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
                     else if (P.forced_first) {
                         p.tau_ach = 0.0; p.tau_req = 0.0;
-                        geo_begin(p.r, p.v, p.cell);
-                        st = ST_FF;
+                        int walked = 0;
+                        if (B.ff) {
+                            // the escape walk was made ahead of the rounds (ff_walk_kernel): its optical depth and what it left of
+                            // the packet's random stream
+                            const FFRec R = B.ff[(((unsigned long long)g.id_hi << 32) | g.id_lo) - L.first_id];
+                            walked = R.code >> 1;
+                            if (walked) {
+                                p.tau_ach = R.tau;
+                                g.buf_a = R.buf_a; g.blk_a = R.blk_a; g.blk_b = R.blk_b; g.have_a = R.code & 1; g.countdown = R.countdown;
+                                st = walked == 2 ? ST_FF_KILLED : ST_FF_DONE;
+                            }
+                        }
+                        if (!walked) {
+                            if (FFIN) {
+                                geo_begin(p.r, p.v, p.cell);
+                                st = ST_FF;
+                            } else {        // cannot happen: the pre-pass emits the same packet and leaves a record when it walks
+                                raise_error(P, ERR_INTERNAL, p.r[0], p.r[1], p.r[2]);
+                                st = ST_NEED_EMIT;
+                            }
+                        }
                     } else {
                         p.tau_req = rng_exp(g);
                         p.tau_ach = 0.0;
@@ -321,8 +346,9 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
 
 #pragma unroll 1
-        for (int k = 0; k < final_walk_steps<GEOM>(); k++) {
-            if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok);
+        for (int k = 0; k < HYP_DEFER_STEPS; k++) {
+            if (FFIN) { if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok); }
+            else if (st == ST_WALK) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, false, inv, v_ok);
         }
     }
 
@@ -340,6 +366,116 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
         if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
         if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Forced first interaction ahead of the rounds.  The escape walk of a packet (iter_final.f90:191-209: grid_escape_tau from the
+// source along the direction it was emitted in) depends on nothing but the packet's id: emission and the walk's propagation
+// checks draw from the packet's own stream.  In final_defer_kernel those walks are half of the crossings, made by lanes that
+// carry a whole packet (256 VGPRs + spills, two waves per SIMD) next to emission and interaction code.  Here they are made
+// first, by a kernel that holds a position, a direction and an optical depth per lane (the peel kernel's budget): lane takes
+// an id, emits the packet again (same stream, same packet: nothing of it is kept or counted), walks, and leaves FFRec[id] =
+// optical depth + the stream's state after the walk.  The propagation kernel then finds a packet it emits already at the
+// edge (ST_FF_DONE / ST_FF_KILLED) and goes on from there; ids without a record (emission failed, source outside the grid)
+// never ask.  Crossings and packets killed by the walk are counted here, once.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef HYP_FF_OCC
+#define HYP_FF_OCC 3
+#endif
+#ifndef HYP_FF_REFILL
+#define HYP_FF_REFILL 32
+#endif
+
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
+    const unsigned long long n_ids = L.end_id - L.first_id;
+    const unsigned int lane = __lane_id();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    Counters cnt, cnt_emit;
+    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
+    Packet<NDT, GEOM> p;
+    Rng g;
+    p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0; p.peel_seq = 0;
+    rng_init(g, P.seed_key, L.iter_tag, 0);
+    int st = 0;                                 // 0 idle, ST_FF walking
+    double inv[3] = {1.0, 1.0, 1.0};
+    bool v_ok = false;
+    unsigned long long mine_id = 0, q_next = 0, q_end = 0;
+    bool exhausted = n_ids == 0;
+
+    for (;;) {
+        const unsigned long long m_idle = __ballot(st == 0);
+        const unsigned long long m_walk = __ballot(st != 0);
+        if (!exhausted && (__popcll(m_idle) >= HYP_FF_REFILL || !m_walk)) {
+            unsigned long long mask = m_idle, q = 0;
+            bool got = false;
+            while (mask) {
+                if (q_next >= q_end) {
+                    unsigned long long b = 0;
+                    if (lane == 0) b = atomicAdd(&B.ctl->ff_cursor, (unsigned long long)HYP_PAIR_CHUNK);
+                    b = __shfl(b, 0, 64);
+                    if (b >= n_ids) { exhausted = true; break; }
+                    q_next = b; q_end = b + HYP_PAIR_CHUNK < n_ids ? b + HYP_PAIR_CHUNK : n_ids;
+                }
+                const unsigned long long avail = q_end - q_next;
+                const unsigned int rank = __popcll(mask & lt);
+                const bool take = ((mask >> lane) & 1ull) && rank < avail;
+                if (take) { q = q_next + rank; got = true; }
+                const unsigned long long taken = __ballot(take);
+                q_next += __popcll(taken);
+                mask &= ~taken;
+            }
+            if (got) {
+                mine_id = q;
+                rng_init(g, P.seed_key, L.iter_tag, L.first_id + q);
+                int source_id = 0;
+                Angle src_normal;
+                cnt_emit.energy_current = 0.0; cnt_emit.crossings = 0; cnt_emit.killed_geo = 0; cnt_emit.killed_int = 0; cnt_emit.interactions = 0;
+                const bool ok = emit_packet<NDT, GEOM, true>(P, W, p, g, cnt_emit, source_id, src_normal);
+                if (ok && !geo_escaped(P, p.cell)) {
+                    if (GEOM == GEOM_OCT) {
+                        v_ok = true;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                    }
+                    p.tau_ach = 0.0; p.tau_req = 0.0;
+                    geo_begin(p.r, p.v, p.cell);
+                    st = ST_FF;
+                } else {
+                    FFRec R; R.tau = 0.0; R.buf_a = 0.0; R.blk_a = 0; R.blk_b = 0; R.code = 0; R.countdown = 0;
+                    B.ff[q] = R;
+                }
+            }
+        }
+        if (!__ballot(st != 0)) { if (exhausted) break; else continue; }
+
+#pragma unroll 1
+        for (int k = 0; k < HYP_PEEL_STEPS; k++) {
+            if (st == ST_FF) {
+                const int s2 = defer_step<NDT, GEOM>(P, W, p, g, cnt, true, inv, v_ok);
+                if (s2 != ST_FF) {
+                    FFRec R;
+                    R.tau = p.tau_ach; R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b;
+                    R.code = (g.have_a & 1) | ((s2 == ST_FF_KILLED ? 2 : 1) << 1); R.countdown = g.countdown;
+                    B.ff[mine_id] = R;
+                    st = 0;
+                }
+            }
+        }
+    }
+
+    double cr = wave_sum((double)cnt.crossings);
+    double kg = wave_sum((double)cnt.killed_geo);
+    if (lane == 0) {
+        if (cr != 0.0) unsafeAtomicAdd(&P.tail[TAIL_CROSSINGS], cr);
+        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
     }
 }
 

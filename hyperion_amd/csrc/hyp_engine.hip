@@ -289,10 +289,15 @@ struct hyp_engine {
     void *d_stage_hot = nullptr, *d_stage_cold = nullptr;
     StageCtl *d_stage_ctl = nullptr, *h_stage_ctl = nullptr;
     size_t stage_alloc = 0, stage_hot_bytes = 0, stage_cold_bytes = 0;
-    long long peel_events = 16ll << 20;     // option: capacity of the event buffer, in events
+    long long peel_events = 128ll << 20;    // option: capacity of the event buffer, in events (the ceiling: 8 per packet are asked for, and half as many
+                                            // again and again while the allocation fails; 16 Mi until round 3: 1e8 packets then took 15 rounds)
     int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
     unsigned int *d_peel_order = nullptr, *d_peel_keys = nullptr, *d_peel_bins = nullptr;
     size_t peel_sort_cap = 0;
+    int ff_prepass = 1;             // option: 1 = the escape walks of the forced first interaction are made ahead of the rounds (hyp_defer.h: ff_walk_kernel)
+    int last_ff_prepass = 0;        // whether the last imaging iteration did so
+    FFRec *d_ff = nullptr;          // one record per packet id of the launch
+    size_t ff_cap = 0;
     bool peel_events_exact = false;         // set by the option: use exactly that many (tests force many rounds with it)
     void *d_peel_events = nullptr, *d_peel_susp[2] = {nullptr, nullptr};
     unsigned long long *d_peel_ret[2] = {nullptr, nullptr};
@@ -800,7 +805,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_stage_hot); free_dev(h->d_stage_cold); free_dev(h->d_stage_ctl);
     if (h->h_stage_ctl) { (void)hipHostFree(h->h_stage_ctl); h->h_stage_ctl = nullptr; }
     free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
-    free_dev(h->d_peel_order); free_dev(h->d_peel_keys); free_dev(h->d_peel_bins);
+    free_dev(h->d_peel_order); free_dev(h->d_peel_keys); free_dev(h->d_peel_bins); free_dev(h->d_ff);
     free_dev(h->d_peel_ctl);
     if (h->h_peel_ctl) (void)hipHostFree(h->h_peel_ctl);
     if (h->h_peel_counter) (void)hipHostFree(h->h_peel_counter);
@@ -2739,6 +2744,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (n == "peel_sort") h->peel_sort = value != 0;
+    else if (n == "ff_prepass") h->ff_prepass = value != 0;
     else if (n == "stage_slots") { if (value < 256) return h->set_error("stage_slots must be at least 256"); h->stage_slots = value; }
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
     else if (n == "peel_events") {
@@ -2789,6 +2795,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
     else if (n == "peel_sort") *value = h->peel_sort;
+    else if (n == "ff_prepass") *value = h->ff_prepass;
+    else if (n == "last_ff_prepass") *value = h->last_ff_prepass;
     else if (n == "stage_slots") *value = h->stage_slots;
     else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
@@ -2834,6 +2842,11 @@ static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes, uin
     free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
     h->peel_cap = 0;
     bool ok = hipMalloc(&h->d_peel_events, cap * dk.event_bytes) == hipSuccess;
+    while (!ok && !h->peel_events_exact && cap > ((size_t)1 << 20)) {        // a smaller buffer means more rounds, not another schedule
+        (void)hipGetLastError();
+        cap = (cap / 2 + HYP_PEEL_CHUNK - 1) / HYP_PEEL_CHUNK * HYP_PEEL_CHUNK;
+        ok = hipMalloc(&h->d_peel_events, cap * dk.event_bytes) == hipSuccess;
+    }
     for (int i = 0; i < 2 && ok; i++)
         ok = hipMalloc(&h->d_peel_susp[i], lanes * dk.susp_bytes) == hipSuccess &&
              hipMalloc((void **)&h->d_peel_ret[i], waves * 2 * sizeof(unsigned long long)) == hipSuccess;
@@ -2873,13 +2886,37 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
     }
     const unsigned sort_blocks = (unsigned)((h->peel_cap + HYP_SORT_PER_WG - 1) / HYP_SORT_PER_WG);
     int occ = 0;
+    // forced first interaction: every packet's escape walk ahead of the rounds, one record per id (32 bytes; without the memory the
+    // propagation kernel walks them itself)
+    B.ff = nullptr;
+    h->last_ff_prepass = 0;
+    const unsigned long long n_ids = L.end_id - L.first_id;
+    if (h->ff_prepass && h->hp.forced_first && dk.ff_walk && n_ids > 0) {
+        if (h->ff_cap < n_ids) {
+            free_dev(h->d_ff);
+            h->ff_cap = 0;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_ids * sizeof(FFRec) < free_b / 2 &&
+                hipMalloc((void **)&h->d_ff, n_ids * sizeof(FFRec)) == hipSuccess) h->ff_cap = n_ids;
+            else { (void)hipGetLastError(); h->d_ff = nullptr; }
+        }
+        if (h->ff_cap >= n_ids) {
+            B.ff = h->d_ff;
+            (void)hipMemsetAsync(&h->d_peel_ctl->ff_cursor, 0, sizeof(unsigned long long), h->stream);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.ff_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+            const unsigned long long need = (n_ids + 255) / 256;
+            const unsigned ff_blocks = (unsigned)std::min<unsigned long long>((unsigned long long)h->n_cu * occ, need);
+            hipLaunchKernelGGL(dk.ff_walk, dim3(ff_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
+            h->last_ff_prepass = 1;
+        }
+    }
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.peel, 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
     int idle_rounds = 0;
     for (int round = 0;; round++) {
         B.cur = round & 1;
         hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, B.cur, round == 0 ? 1 : 0);
-        hipLaunchKernelGGL(dk.propagate, dim3(blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
+        hipLaunchKernelGGL(B.ff ? dk.propagate_pre : dk.propagate, dim3(blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
         if (B.order) {
             (void)hipMemsetAsync(B.bins, 0, sizeof(unsigned int) * B.n_bins, h->stream);
             hipLaunchKernelGGL(dk.sort_hist, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);

@@ -254,6 +254,58 @@ def test_deferred_peeloff_equals_inline(kw, peel_events):
     eng.close()
 
 
+def _ff_problem(grid):
+    if grid == "car":
+        return imaging_problem(tau=2.0, uncertainties=True)
+    if grid == "oct":
+        from hyperion_amd.benchmark import make_octree_problem
+        return make_octree_problem(max_level=5, n_pix=32)
+    prob, _ = golden_problem("%s_peeloff.False.npz" % grid)       # test_bit_level.py:175-236 on that grid
+    prob.config.forced_first_interaction = True
+    return prob
+
+
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph"])
+@pytest.mark.parametrize("peel_events", [0, 4096])
+def test_forced_first_prepass_equals_the_walk_inside_the_propagation_kernel(grid, peel_events):
+    """hyp_defer.h: ff_walk_kernel makes every packet's escape walk (iter_final.f90:191-209) ahead of the rounds and leaves the
+    optical depth and the state of the packet's stream; final_defer_kernel<.., false> picks them up.  Same packets, same
+    draws: the tallies are equal and the images are the same sums -- also over many rounds (id ranges returned, packets set
+    aside) and against the inline schedule."""
+    prob = _ff_problem(grid)
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(20000, 1, want_output=False)
+    assert eng.get_option("plain_imaging") == 1 and eng.get_option("ff_prepass") == 1
+    if peel_events:
+        eng.set_option("peel_events", peel_events)
+    ra, sa = eng.final_iteration(30000)
+    assert eng.get_option("last_ff_prepass") == 1
+    assert eng.get_option("last_defer_rounds") >= (3 if peel_events else 1)
+    eng.set_option("ff_prepass", 0)
+    rb, sb = eng.final_iteration(30000)
+    assert eng.get_option("last_ff_prepass") == 0
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["energy_current"] == sb["energy_current"]
+    _images_equal(ra, rb)
+    eng.set_option("defer_peel", 0)
+    rc, sc = eng.final_iteration(30000)
+    for k in INT_KEYS:
+        assert sa[k] == sc[k], (k, sa, sc)
+    _images_equal(ra, rc)
+    eng.close()
+
+
+def test_forced_first_prepass_is_skipped_without_forced_first_interaction():
+    p = imaging_problem(tau=0.3)
+    p.config.forced_first_interaction = False
+    eng = hyperion_amd.Engine(p)
+    eng.lucy_iteration(10000, 1, want_output=False)
+    eng.final_iteration(10000)
+    assert eng.get_option("last_defer_rounds") >= 1 and eng.get_option("last_ff_prepass") == 0
+    eng.close()
+
+
 def test_sharded_imaging_iteration_equals_the_whole_one():
     """hyp_final_launch(first_id, n_local) on two id ranges (what two ranks do), blocks summed like the all-reduce does,
     then hyp_final_finish: the cubes of the whole iteration -- also through the deferred schedule with an event buffer

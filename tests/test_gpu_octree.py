@@ -235,9 +235,11 @@ def test_config4_at_baseline_packet_count():
     assert (se * w).sum() == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
     assert st["killed_geo"] / n < 5e-3 and st["killed_int"] == 0
     assert 35 < st["crossings"] / n < 50
+    eng.set_option("peel_events", 16 << 20)         # the default (128 Mi slots) finishes in two rounds: this is the many-round path at full size
     res, sf = eng.final_iteration(n)
     rounds, events = eng.get_option("last_defer_rounds"), eng.get_option("last_defer_events")
     assert rounds >= 10 and events > 2 * n, (rounds, events)
+    assert eng.get_option("last_ff_prepass") == 1     # forced first interaction: the escape walks were made ahead (ff_walk_kernel)
     assert sf["n_packets"] == n and sf["energy_current"] == pytest.approx(n, rel=1e-12)
     img, sed = res[0]["img"], res[0]["sed"]
     assert img.shape == (4, 1, 1, 512, 512, 1)

@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hyperion_amd
+if os.environ.get("HYP_LIB"):        # a tuning variant built by tools/variants.py (GEOM=1: only the octree lines run)
+    import hyperion_amd.engine as E
+    E._lib = E.load_library(os.environ["HYP_LIB"])
 from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem, make_octree_problem
 from hyperion_amd.problem import PeeledImages, Source
 
@@ -38,6 +41,8 @@ _, st = e.lucy_iteration(n, 2, want_output=False); line("configs[3] octree with 
 e.final_iteration(n // 10)
 _, st = e.final_iteration(n); line("... imaging iteration, general kernel (plain_imaging %d)" % e.get_option("plain_imaging"), n, e.last_kernel_ms()[0], st)
 e.close()
+if os.environ.get("HYP_LIB"):
+    sys.exit(0)
 # (c) monochromatic final iteration on a 64^3 Cartesian grid, 5 wavelengths, one 256^2 image
 p = make_benchmark_problem(64, tau=1.0)
 p.config.monochromatic = True

@@ -4,7 +4,7 @@ bench line).  Writes <out>/<workload>_summary.md and merges <out>/r03_pmc.json.
 usage: python tools/summarize_r03.py <workload> <raw dir> <out dir>"""
 import glob, json, os, re, sqlite3, sys
 w, raw, out = sys.argv[1:4]
-KEEP = ("tile_", "vtile_", "otile_", "lucy_kernel", "final_kernel", "final_defer_kernel", "peel_kernel", "reduce_copies", "finish_kernel")
+KEEP = ("tile_", "vtile_", "otile_", "atile_", "lucy_kernel", "final_kernel", "final_defer_kernel", "ff_walk_kernel", "peel_kernel", "reduce_copies", "finish_kernel")
 
 
 def short(n):
