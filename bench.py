@@ -118,7 +118,8 @@ def extras(n):
     st, dt = timed(lambda: e.final_iteration(n)[1])
     rounds = e.get_option("last_defer_rounds")
     res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction", "packets": n,
-                "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet" % (rounds, e.get_option("last_defer_events") / n))
+                "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet%s" % (rounds, e.get_option("last_defer_events") / n,
+                             ", emission + forced first interaction ahead of the rounds (ff_walk_kernel)" if e.get_option("last_ff_prepass") else ""))
                             if rounds else "inline peel-off",
                 "packets_per_s": n / dt, "kernel_ms": e.last_kernel_ms()[0],
                 "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("oct_img"))})

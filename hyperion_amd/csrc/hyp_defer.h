@@ -28,9 +28,9 @@
 #define HYP_PEEL_OCC 3        // workgroups of the peel kernel per CU the register budget is set for
 #endif
 #ifndef HYP_DEFER_STEPS
-// cell crossings of the propagation kernel between two state checks: with the escape walks of the forced first interaction made
-// ahead a packet is at an event every ~12 crossings (configs[3], 1e8 packets: 4 / 8 / 16 / 32 steps 362 / 353 / 359 / 407 ms)
-#define HYP_DEFER_STEPS (GEOM == GEOM_OCT ? 8 : final_walk_steps<GEOM>())
+// cell crossings of the propagation kernel between two state checks (configs[3], 1e8 packets, emission and forced first interaction made
+// ahead of the rounds: 8 / 12 / 16 crossings 331.8 / 325.4 / 326.0 ms)
+#define HYP_DEFER_STEPS (GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>())
 #endif
 #ifndef HYP_PEEL_STEPS
 #define HYP_PEEL_STEPS 16       // cell crossings between two refill / deposit checks
@@ -47,6 +47,20 @@ struct alignas(16) PeelEvent {
     int code;                           // 0: empty slot, else 1 | last << 1 | last_isotropic << 3
     PeelFlags f;
     Cell<GEOM> cell;
+};
+
+// What ff_walk_kernel leaves of a packet it emitted and walked to the edge of the grid ahead of the rounds
+template <int NDT>
+struct alignas(16) EmitRec {
+    Angle a;                            // direction of emission
+    double nu, energy0, energy;         // energy0: as emitted (the emission's peel-off event, energy_current); energy: with the weight of
+    double tau_req;                     //   the forced first interaction; tau_req: the first optical depth (iter_final.f90:195-209)
+    double chi[NDT], albedo[NDT], kappa[NDT];
+    double buf_a;                       // Rng::buf_a, blk_a, blk_b, have_a, countdown after all of that
+    uint32_t blk_a, blk_b;
+    int code;                           // have_a | status << 1: 0 emission failed (error raised), 1 emitted outside the grid, 2 walked
+    int countdown;
+    int source_id, pad;
 };
 
 template <int NDT, int GEOM>
@@ -161,8 +175,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
     for (;;) {
         if (st == ST_ESCAPED) st = ST_NEED_EMIT;
         unsigned long long m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
-        const unsigned long long m_ffd = __ballot(st == ST_FF_DONE || st == ST_FF_KILLED);
-        if (m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
+        const unsigned long long m_ffd = FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull;
+        if (FFIN && m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
             // the optical depth to the edge is known: back to the source, first optical depth (iter_final.f90:195-209)
             if (st == ST_FF_DONE || st == ST_FF_KILLED) {
                 const double tau_escape = p.tau_ach;
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit | __ballot(st == ST_FF_DONE || st == ST_FF_KILLED))) break;
+        if (!(m_walk | m_int | m_emit | (FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
 
         // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
         // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
@@ -224,11 +238,12 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
             }
             pool_empty = true;
             m_int = 0; m_emit = 0;
-            if (!(m_walk | __ballot(st == ST_FF_DONE || st == ST_FF_KILLED))) break;
+            if (!(m_walk | (FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
         }
 
         // peel: 0 none, 1 after emission, 2 after interaction
         int peel = 0;
+        int ff_status = 0; double ff_tau_req = 0.0, ff_energy = 0.0;       // FFIN = false: from the packet's EmitRec
         Angle a_prev = p.a;
         double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
         int last = LAST_SR; bool last_iso = true;
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
             bool got = take_id(P, L, dsp, need, id);
             if (need) {
                 if (!got) st = ST_DONE;
-                else {
+                else if constexpr (FFIN) {
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
                     Angle src_normal;
@@ -266,6 +281,36 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else { peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true; }
+                } else {
+                    // the packet was emitted ahead of the rounds (ff_walk_kernel): what emit_packet<.., SIMPLE> leaves in a packet,
+                    // from the record; a packet whose emission failed raised its error there (the launch stops below)
+                    const EmitRec<NDT> &R = ((const EmitRec<NDT> *)B.ff)[id - L.first_id];
+                    ff_status = R.code >> 1;
+                    if (ff_status != 0) {
+                        rng_init(g, P.seed_key, L.iter_tag, id);
+                        g.buf_a = R.buf_a; g.blk_a = R.blk_a; g.blk_b = R.blk_b; g.have_a = R.code & 1; g.countdown = R.countdown;
+                        const int source_id = R.source_id;
+                        const DSource &S = P.sources[source_id];
+                        p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+                        p.a = R.a;
+                        angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+                        p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
+                        p.nu = R.nu; p.energy = R.energy0;
+                        cnt.energy_current += R.energy0;
+                        ff_tau_req = R.tau_req; ff_energy = R.energy;
+#pragma unroll
+                        for (int d = 0; d < NDT; d++) { p.chi[d] = R.chi[d]; p.albedo[d] = R.albedo[d]; p.kappa[d] = R.kappa[d]; }
+                        p.emiss_dust = -1;
+                        geo_clear_wall(p.cell);
+                        bool placed = false;
+                        if constexpr (GEOM == GEOM_VOR) {
+                            if (S.type == 1 && S.vor_cell1 > 0) { p.cell.id = S.vor_cell1 - 1; placed = true; }
+                        }
+                        if (!placed) (void)geo_place(P, W, p.r, p.v, p.cell);       // it did succeed ahead of the rounds
+                        p.inter = 1; p.peel_seq = 0; p.n_visited = 0;
+                        f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                        peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true;
+                    }
                 }
             }
             if (__ballot(st == ST_DONE)) pool_empty = true;
@@ -308,29 +353,17 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
-                    else if (P.forced_first) {
+                    else if (!FFIN) {
+                        // escape walk and first optical depth (iter_final.f90:195-209) were made ahead of the rounds; the packet
+                        // has not moved
+                        p.tau_req = ff_tau_req; p.energy = ff_energy;
+                        p.tau_ach = 0.0;
+                        begin_integrate(P, p);
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    } else if (P.forced_first) {
                         p.tau_ach = 0.0; p.tau_req = 0.0;
-                        int walked = 0;
-                        if (B.ff) {
-                            // the escape walk was made ahead of the rounds (ff_walk_kernel): its optical depth and what it left of
-                            // the packet's random stream
-                            const FFRec R = B.ff[(((unsigned long long)g.id_hi << 32) | g.id_lo) - L.first_id];
-                            walked = R.code >> 1;
-                            if (walked) {
-                                p.tau_ach = R.tau;
-                                g.buf_a = R.buf_a; g.blk_a = R.blk_a; g.blk_b = R.blk_b; g.have_a = R.code & 1; g.countdown = R.countdown;
-                                st = walked == 2 ? ST_FF_KILLED : ST_FF_DONE;
-                            }
-                        }
-                        if (!walked) {
-                            if (FFIN) {
-                                geo_begin(p.r, p.v, p.cell);
-                                st = ST_FF;
-                            } else {        // cannot happen: the pre-pass emits the same packet and leaves a record when it walks
-                                raise_error(P, ERR_INTERNAL, p.r[0], p.r[1], p.r[2]);
-                                st = ST_NEED_EMIT;
-                            }
-                        }
+                        geo_begin(p.r, p.v, p.cell);
+                        st = ST_FF;
                     } else {
                         p.tau_req = rng_exp(g);
                         p.tau_ach = 0.0;
@@ -370,15 +403,16 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Forced first interaction ahead of the rounds.  The escape walk of a packet (iter_final.f90:191-209: grid_escape_tau from the
-// source along the direction it was emitted in) depends on nothing but the packet's id: emission and the walk's propagation
-// checks draw from the packet's own stream.  In final_defer_kernel those walks are half of the crossings, made by lanes that
-// carry a whole packet (256 VGPRs + spills, two waves per SIMD) next to emission and interaction code.  Here they are made
-// first, by a kernel that holds a position, a direction and an optical depth per lane (the peel kernel's budget): lane takes
-// an id, emits the packet again (same stream, same packet: nothing of it is kept or counted), walks, and leaves FFRec[id] =
-// optical depth + the stream's state after the walk.  The propagation kernel then finds a packet it emits already at the
-// edge (ST_FF_DONE / ST_FF_KILLED) and goes on from there; ids without a record (emission failed, source outside the grid)
-// never ask.  Crossings and packets killed by the walk are counted here, once.
+// Emission and forced first interaction ahead of the rounds.  What happens to a packet between its emission and its first
+// optical depth (iter_final.f90:191-209: emit, grid_escape_tau from the source along the direction it was emitted in, the
+// forced first interaction's optical depth and weight) depends on nothing but the packet's id: emission, the walk's
+// propagation checks and the sampling draw from the packet's own stream.  In final_defer_kernel<.., true> those walks are
+// half of the crossings, made by lanes that carry a whole packet (256 VGPRs + spills, two waves per SIMD), and emission runs
+// once 48 lanes of a wave wait for it.  Here all of it is done first, by a kernel of the peel kernel's budget: a lane takes
+// an id, emits, walks, samples, and leaves EmitRec[id] -- direction, frequency, opacities, energy before and after the
+// weight, first optical depth, and the state of the packet's stream.  final_defer_kernel<.., false> has neither emission
+// code nor the ST_FF state: a lane that takes an id loads the record, writes the emission's peel-off event and walks.
+// Crossings and packets killed by the escape walk are counted here, once; energy_current by the propagation kernel.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef HYP_FF_OCC
 #define HYP_FF_OCC 3
@@ -395,6 +429,7 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
     Walls W;
     stage_walls<GEOM>(P, lds, W);
     const unsigned long long n_ids = L.end_id - L.first_id;
+    EmitRec<NDT> *__restrict__ out = (EmitRec<NDT> *)B.ff;
     const unsigned int lane = __lane_id();
     const unsigned long long lt = (1ull << lane) - 1ull;
     Counters cnt, cnt_emit;
@@ -404,16 +439,33 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
     p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
     p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0; p.peel_seq = 0;
     rng_init(g, P.seed_key, L.iter_tag, 0);
-    int st = 0;                                 // 0 idle, ST_FF walking
+    int st = 0;                                 // 0 idle, ST_FF walking, ST_FF_DONE / ST_FF_KILLED out of the grid (record to be finished)
     double inv[3] = {1.0, 1.0, 1.0};
     bool v_ok = false;
     unsigned long long mine_id = 0, q_next = 0, q_end = 0;
     bool exhausted = n_ids == 0;
 
     for (;;) {
-        const unsigned long long m_idle = __ballot(st == 0);
-        const unsigned long long m_walk = __ballot(st != 0);
-        if (!exhausted && (__popcll(m_idle) >= HYP_FF_REFILL || !m_walk)) {
+        const unsigned long long m_idle = __ballot(st != ST_FF);
+        const unsigned long long m_walk = __ballot(st == ST_FF);
+        const bool service = __popcll(m_idle) >= HYP_FF_REFILL || !m_walk;
+        if (service && (st == ST_FF_DONE || st == ST_FF_KILLED)) {
+            // the optical depth to the edge is known: first optical depth (iter_final.f90:195-209)
+            const double tau_escape = p.tau_ach;
+            double energy = p.energy, tau_req = 0.0;
+            bool sampled = false;
+            if (tau_escape > 1e-10 && st != ST_FF_KILLED) {
+                double weight, tau;
+                forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                tau_req = tau; energy *= weight; sampled = true;
+            }
+            if (!sampled) tau_req = rng_exp(g);
+            EmitRec<NDT> &R = out[mine_id];
+            R.energy = energy; R.tau_req = tau_req;
+            R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b; R.code = (g.have_a & 1) | (2 << 1); R.countdown = g.countdown;
+            st = 0;
+        }
+        if (service && !exhausted) {
             unsigned long long mask = m_idle, q = 0;
             bool got = false;
             while (mask) {
@@ -439,18 +491,25 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
                 Angle src_normal;
                 cnt_emit.energy_current = 0.0; cnt_emit.crossings = 0; cnt_emit.killed_geo = 0; cnt_emit.killed_int = 0; cnt_emit.interactions = 0;
                 const bool ok = emit_packet<NDT, GEOM, true>(P, W, p, g, cnt_emit, source_id, src_normal);
-                if (ok && !geo_escaped(P, p.cell)) {
-                    if (GEOM == GEOM_OCT) {
-                        v_ok = true;
+                EmitRec<NDT> &R = out[q];
+                if (!ok) R.code = 0;
+                else {
+                    R.a = p.a; R.nu = p.nu; R.energy0 = p.energy; R.source_id = source_id; R.pad = 0;
 #pragma unroll
-                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                    for (int d = 0; d < NDT; d++) { R.chi[d] = p.chi[d]; R.albedo[d] = p.albedo[d]; R.kappa[d] = p.kappa[d]; }
+                    if (geo_escaped(P, p.cell)) {
+                        R.energy = p.energy; R.tau_req = 0.0;
+                        R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b; R.code = (g.have_a & 1) | (1 << 1); R.countdown = g.countdown;
+                    } else {
+                        if (GEOM == GEOM_OCT) {
+                            v_ok = true;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                        }
+                        p.tau_ach = 0.0; p.tau_req = 0.0;
+                        geo_begin(p.r, p.v, p.cell);
+                        st = ST_FF;
                     }
-                    p.tau_ach = 0.0; p.tau_req = 0.0;
-                    geo_begin(p.r, p.v, p.cell);
-                    st = ST_FF;
-                } else {
-                    FFRec R; R.tau = 0.0; R.buf_a = 0.0; R.blk_a = 0; R.blk_b = 0; R.code = 0; R.countdown = 0;
-                    B.ff[q] = R;
                 }
             }
         }
@@ -458,16 +517,7 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
 
 #pragma unroll 1
         for (int k = 0; k < HYP_PEEL_STEPS; k++) {
-            if (st == ST_FF) {
-                const int s2 = defer_step<NDT, GEOM>(P, W, p, g, cnt, true, inv, v_ok);
-                if (s2 != ST_FF) {
-                    FFRec R;
-                    R.tau = p.tau_ach; R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b;
-                    R.code = (g.have_a & 1) | ((s2 == ST_FF_KILLED ? 2 : 1) << 1); R.countdown = g.countdown;
-                    B.ff[mine_id] = R;
-                    st = 0;
-                }
-            }
+            if (st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, true, inv, v_ok);
         }
     }
 

@@ -304,16 +304,6 @@ struct PeelCtl {
     unsigned long long ff_cursor;       // packet ids handed out by the forced-first-interaction pre-pass (ff_walk_kernel)
 };
 
-// Forced first interaction, walked ahead of the rounds (hyp_defer.h: ff_walk_kernel): what the escape walk of a packet leaves
-// behind -- the optical depth to the edge of the grid and the state of the packet's random stream after the walk's propagation checks
-struct alignas(16) FFRec {
-    double tau;                         // grid_escape_tau from the source along the packet's direction
-    double buf_a;                       // Rng::buf_a
-    uint32_t blk_a, blk_b;              // Rng::blk_a, blk_b
-    int code;                           // Rng::have_a | status << 1 (0: no walk recorded, 1: left the grid, 2: killed on the way)
-    int countdown;                      // Rng::countdown
-};
-
 struct DeferBuf {
     void *events;                       // PeelEvent<NDT, GEOM>[cap] (hyp_defer.h)
     unsigned long long cap;             // a multiple of HYP_PEEL_CHUNK
@@ -327,9 +317,9 @@ struct DeferBuf {
     unsigned int *keys;                 // [cap] key of every event slot (HYP_SORT_EMPTY: nothing written there)
     unsigned int *bins;                 // [2 * n_bins]: counts (then cursors) | offsets
     unsigned int n_bins;
-    // forced first interaction walked ahead (ff_walk_kernel): one record per packet id of the launch, null = the propagation
-    // kernel walks to the edge itself (ST_FF lanes)
-    FFRec *ff;
+    // emission and forced first interaction made ahead of the rounds (hyp_defer.h: ff_walk_kernel): EmitRec<NDT>[packet ids of the
+    // launch]; null = the propagation kernel emits and walks to the edge itself (ST_FF lanes)
+    void *ff;
 };
 #define HYP_SORT_EMPTY 0xffffffffu
 #ifndef HYP_SORT_MAX_BINS

@@ -294,10 +294,10 @@ struct hyp_engine {
     int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
     unsigned int *d_peel_order = nullptr, *d_peel_keys = nullptr, *d_peel_bins = nullptr;
     size_t peel_sort_cap = 0;
-    int ff_prepass = 1;             // option: 1 = the escape walks of the forced first interaction are made ahead of the rounds (hyp_defer.h: ff_walk_kernel)
+    int ff_prepass = 1;             // option: 1 = emission and the forced first interaction are made ahead of the rounds (hyp_defer.h: ff_walk_kernel)
     int last_ff_prepass = 0;        // whether the last imaging iteration did so
-    FFRec *d_ff = nullptr;          // one record per packet id of the launch
-    size_t ff_cap = 0;
+    void *d_ff = nullptr;           // EmitRec<n_dust>: one record per packet id of the launch
+    size_t ff_cap = 0;              // bytes
     bool peel_events_exact = false;         // set by the option: use exactly that many (tests force many rounds with it)
     void *d_peel_events = nullptr, *d_peel_susp[2] = {nullptr, nullptr};
     unsigned long long *d_peel_ret[2] = {nullptr, nullptr};
@@ -2886,21 +2886,21 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
     }
     const unsigned sort_blocks = (unsigned)((h->peel_cap + HYP_SORT_PER_WG - 1) / HYP_SORT_PER_WG);
     int occ = 0;
-    // forced first interaction: every packet's escape walk ahead of the rounds, one record per id (32 bytes; without the memory the
-    // propagation kernel walks them itself)
+    // forced first interaction: every packet's emission, escape walk and first optical depth ahead of the rounds, one record per id
+    // (128 bytes at one dust species; without the memory the propagation kernel does it all itself)
     B.ff = nullptr;
     h->last_ff_prepass = 0;
     const unsigned long long n_ids = L.end_id - L.first_id;
     if (h->ff_prepass && h->hp.forced_first && dk.ff_walk && n_ids > 0) {
-        if (h->ff_cap < n_ids) {
+        const size_t want = (size_t)n_ids * dk.ff_bytes;
+        if (h->ff_cap < want) {
             free_dev(h->d_ff);
             h->ff_cap = 0;
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && n_ids * sizeof(FFRec) < free_b / 2 &&
-                hipMalloc((void **)&h->d_ff, n_ids * sizeof(FFRec)) == hipSuccess) h->ff_cap = n_ids;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want < free_b / 2 && hipMalloc(&h->d_ff, want) == hipSuccess) h->ff_cap = want;
             else { (void)hipGetLastError(); h->d_ff = nullptr; }
         }
-        if (h->ff_cap >= n_ids) {
+        if (h->ff_cap >= want) {
             B.ff = h->d_ff;
             (void)hipMemsetAsync(&h->d_peel_ctl->ff_cursor, 0, sizeof(unsigned long long), h->stream);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.ff_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;

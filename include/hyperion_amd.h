@@ -353,8 +353,9 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * imaging kernel applies, hyp_defer.h; 2: the staged schedule, hyp_stage.h; 0: inline), "peel_events" (capacity of its event buffer: at most
  * 128 Mi events by default, fewer if the memory is not there),
  * "peel_sort" (1, the default: the peel kernel takes a round's events ordered by the cell they happened in), "ff_prepass" (1, the
- * default: the escape walks of the forced first interaction are made ahead of the rounds by a kernel of their own, 32 bytes per packet id
- * of the launch; "last_ff_prepass" reports whether the last imaging iteration did so), "oct_neighbours" (0: the
+ * default: with forced first interaction on, every packet's emission, escape walk and first optical depth are made ahead of the rounds by a
+ * kernel of their own, one record of 96 + 24 n_dust bytes (rounded up to 16) per packet id of the launch; "last_ff_prepass" reports whether the last imaging
+ * iteration did so), "oct_neighbours" (0: the
  * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (can only be
  * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
  * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more

@@ -268,10 +268,10 @@ def _ff_problem(grid):
 @pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph"])
 @pytest.mark.parametrize("peel_events", [0, 4096])
 def test_forced_first_prepass_equals_the_walk_inside_the_propagation_kernel(grid, peel_events):
-    """hyp_defer.h: ff_walk_kernel makes every packet's escape walk (iter_final.f90:191-209) ahead of the rounds and leaves the
-    optical depth and the state of the packet's stream; final_defer_kernel<.., false> picks them up.  Same packets, same
-    draws: the tallies are equal and the images are the same sums -- also over many rounds (id ranges returned, packets set
-    aside) and against the inline schedule."""
+    """hyp_defer.h: ff_walk_kernel emits every packet, makes its escape walk and samples the forced first interaction
+    (iter_final.f90:191-209) ahead of the rounds and leaves an EmitRec per id; final_defer_kernel<.., false> has no emission
+    code and starts its packets from the records.  Same packets, same draws: the tallies are equal and the images are the
+    same sums -- also over many rounds (id ranges returned, packets set aside) and against the inline schedule."""
     prob = _ff_problem(grid)
     eng = hyperion_amd.Engine(prob)
     eng.lucy_iteration(20000, 1, want_output=False)

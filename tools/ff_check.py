@@ -1,5 +1,5 @@
-"""Forced-first-interaction pre-pass (hyp_defer.h: ff_walk_kernel) against the propagation kernel's own escape walks: same tallies,
-same images (sums in another order), on configs[3]'s octree.   python tools/ff_check.py [packets]      (HYP_LIB: a tools/variants.py build)"""
+"""Emission + forced first interaction ahead of the rounds (hyp_defer.h: ff_walk_kernel, EmitRec) against the propagation kernel doing
+both itself: same tallies, same images (sums in another order), on configs[3]'s octree.   python tools/ff_check.py [packets]      (HYP_LIB: a tools/variants.py build)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
