@@ -18,10 +18,11 @@
 #include "hyp_tiled.h"
 
 #ifndef HYP_ATILE_WG
-#define HYP_ATILE_WG 1024         // threads per workgroup (one workgroup per task; one per CU with bricks of 32 x 16 x 16 cells: 216.1 -> 200.9 ms on the three-level nest)
+#define HYP_ATILE_WG 768          // threads per workgroup (one workgroup per task; one per CU with bricks of 32 x 16 x 16 cells: two of 512 threads ->
+                                  // one of 1024: 216.1 -> 200.9 ms on the three-level nest; 768 threads at 167 VGPRs, nothing spilled: 204.0 -> 177.9 ms)
 #endif
 #ifndef HYP_ATILE_OCC
-#define HYP_ATILE_OCC 4          // waves per SIMD the register budget is set for (16 waves per CU)
+#define HYP_ATILE_OCC 3          // waves per SIMD the register budget is set for (12 waves per CU; at 4 the walk spilled 40 VGPRs in the step loop)
 #endif
 #ifndef HYP_ATILE_SERVICE
 #define HYP_ATILE_SERVICE 24      // lanes that must wait before a wave runs its service phase (16 with 4 steps: 235.5 ms, 24 with 8: 224.2)

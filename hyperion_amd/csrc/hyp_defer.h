@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
     double r[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 1.0}, tau = 0.0, chi[NDT];
     double inv[3] = {1.0, 1.0, 1.0};          // octree: RN(1 / v) of the walk's direction, see oct_find_wall_inv
     bool v_ok = true;
-    double s[4] = {0.0, 0.0, 0.0, 0.0}, energy = 0.0;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, energy = 0.0, nu_l = 0.0;
     long long k_img = -1, k_sed = -1;
     Cell<GEOM> c;
     Rng gp;
@@ -744,7 +744,10 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         energy = E.energy;
                         // the bins do not depend on the attenuation (image_bin: image_type.f90:408-476); a NaN Stokes I
                         // after it is checked again when the lane deposits
-                        image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed);
+                        // (filters, image_type.f90:467-475: the packet goes into every filter with a positive transmission at nu --
+                        // the keys of filter 0 here, the filter index is the fastest one of the cubes)
+                        image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed, G.use_filters ? 0 : -1);
+                        nu_l = nu;
                         ig = g_i; tau = 0.0;
 #pragma unroll
                         for (int dd = 0; dd < NDT; dd++) chi[dd] = E.chi[dd];
@@ -804,9 +807,24 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 if (!__ballot(mine)) continue;
                 const DPeeled &G = P.peeled[g_i];
                 const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
-                double val[4] = {sa[0] * energy, sa[1] * energy, sa[2] * energy, sa[3] * energy};
-                if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, mine ? k_img : -1, stride_img, G.n_stokes, val, &ic);
-                if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, mine ? k_sed : -1, stride_sed, G.n_stokes, val, &ic);
+                const int n_pass = G.use_filters ? G.n_nu : 1;
+                for (int pass = 0; pass < n_pass; pass++) {
+                    double val[4] = {sa[0] * energy, sa[1] * energy, sa[2] * energy, sa[3] * energy};
+                    bool on = mine;
+                    if (G.use_filters) {        // deposit_images: transmission of filter `pass` at nu, linear in the curve, 0 outside
+                        double tr = 0.0;
+                        if (mine) {
+                            const int o0 = (int)G.filt_off[pass], o1 = (int)G.filt_off[pass + 1];
+                            const double *fx = G.filt_nu + o0, *ft = G.filt_tr + o0;
+                            const int j = locate(fx, o1 - o0, nu_l);
+                            tr = j < 0 ? 0.0 : ft[j] + (nu_l - fx[j]) / (fx[j + 1] - fx[j]) * (ft[j + 1] - ft[j]);
+                        }
+                        on = mine && tr > 0.0;
+                        val[0] *= tr; val[1] *= tr; val[2] *= tr; val[3] *= tr;
+                    }
+                    if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, on && k_img >= 0 ? k_img + pass : -1, stride_img, G.n_stokes, val, &ic);
+                    if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, on && k_sed >= 0 ? k_sed + pass : -1, stride_sed, G.n_stokes, val, &ic);
+                }
             }
             if (st == 2) st = 0;
         }

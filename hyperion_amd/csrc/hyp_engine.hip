@@ -1877,7 +1877,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     {
         bool plain = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
-        for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer && !pr->peeled[g].use_filters;
+        for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer;     // (filters are the peel kernel's / deposit_images' business)
         h->plain_imaging = plain;
         bool simple = pr->n_sources > 0;
         for (int i = 0; i < pr->n_sources; i++) simple = simple && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);

@@ -1701,7 +1701,7 @@ __device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled 
                                                const PeelFlags &f, double x_image, double y_image, int iv, const ImgCache *ic = nullptr)
 {
     const size_t stride_img = (size_t)G.n_orig * G.n_view * G.n_y * G.n_x * G.n_nu, stride_sed = (size_t)G.n_orig * G.n_view * G.n_ap * G.n_nu;
-    const bool use_filters = !PLAIN && G.use_filters;
+    const bool use_filters = G.use_filters;
     const int n_pass = use_filters ? G.n_nu : 1;
     for (int pass = 0; pass < n_pass; pass++) {
         long long k_img = -1, k_sed = -1;
@@ -2269,7 +2269,7 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
 }
 
 // PLAIN: the polychromatic peel-off iteration without anything optional -- point sources only, no monochromatic launch,
-// no modified random walk, no re-absorbing sources, no binned images, no inside observers, no filters (the host checks).
+// no modified random walk, no re-absorbing sources, no binned images, no inside observers (the host checks; filters only change the deposit).
 // Those paths cost registers even where a problem never takes them; this is the imaging kernel of BASELINE configs[3].
 template <int NDT, int GEOM, bool PLAIN>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)

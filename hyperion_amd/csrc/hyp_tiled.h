@@ -496,7 +496,7 @@ static __global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileC
 #define HYP_EMIT_WAVES 2
 #endif
 #ifndef HYP_EMIT_WAVES_SIMPLE
-#define HYP_EMIT_WAVES_SIMPLE 4
+#define HYP_EMIT_WAVES_SIMPLE 3     // 167 VGPRs, nothing spilled (4: 128 + 74 spilled; configs[1] 254.0-254.2 -> 251.5-252.5 ms; 2: 254.0)
 #endif
 // end of a walk task: its two lists (staged in the task's own range) go to the pool-wide lists, one reservation each
 __device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileCtl *__restrict__ ctl, const TileTask &tk, int *__restrict__ ilist,

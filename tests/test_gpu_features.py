@@ -149,13 +149,22 @@ def test_filters_parity():
     eng = hyperion_amd.Engine(prob); orc = Oracle(prob)
     eng.lucy_iteration(5000, 1); orc.lucy_iteration(5000, 1)
     rg, sg = eng.final_iteration(20000)
+    # filters only change the deposit: the problem runs on the deferred schedule (hyp_defer.h: the peel kernel spreads a packet
+    # over the filters), on the inline plain kernel and on the general kernel alike
+    assert eng.get_option("plain_imaging") == 1 and eng.get_option("last_defer_rounds") >= 1
+    eng.set_option("defer_peel", 0)
+    ri, si = eng.final_iteration(20000)
+    assert eng.get_option("last_defer_rounds") == 0
+    eng.set_option("plain_imaging", 0)
+    rn, sn = eng.final_iteration(20000)
     rc, sc = orc.final_iteration(20000)
     eng.close(); orc.close()
-    assert all(sg[k] == sc[k] for k in KEYS)
     assert rc[1]["sed"].sum() > 0 and rc[1]["img"].sum() > 0
-    for x, y in zip(rg, rc):
-        for k in y:
-            np.testing.assert_allclose(x[k], y[k], rtol=1e-9, atol=1e-14 * np.abs(y[k]).max())
+    for res, st in ((rg, sg), (ri, si), (rn, sn)):
+        assert all(st[k] == sc[k] for k in KEYS)
+        for x, y in zip(res, rc):
+            for k in y:
+                np.testing.assert_allclose(x[k], y[k], rtol=1e-9, atol=1e-14 * np.abs(y[k]).max())
 
 
 def test_convergence_value_on_the_device():
