@@ -216,7 +216,7 @@ struct hyp_engine {
     double energy_total = 0.0;
     bool lucy_pending = false, final_pending = false;
     uint64_t pending_packets = 0;
-    float last_propagate_ms = 0.f, last_finish_ms = 0.f;
+    float last_propagate_ms = 0.f, last_finish_ms = 0.f, ray_ms = 0.f;
     hyp_iter_stats last_stats{};
 
     // brick-tiled Lucy iteration (hyp_tiled.h)
@@ -282,6 +282,7 @@ struct hyp_engine {
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
+    bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
     int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h), 2 = the staged schedule (hyp_stage.h), 0 = inline
@@ -386,18 +387,18 @@ DeferKernels pick_defer_kernels(int nd, int grid_type)
     }
 }
 
-LucyKernel pick_final_kernel(int nd, int grid_type, bool plain)
+LucyKernel pick_final_kernel(int nd, int grid_type, int mode)
 {
 #ifdef HYP_VARIANT_GEOM   // tuning builds (tools/variants.py) link one geometry unit only
-    return pick_final_kernel_g<HYP_VARIANT_GEOM>(nd, plain);
+    return pick_final_kernel_g<HYP_VARIANT_GEOM>(nd, mode);
 #endif
     switch (grid_type) {
-    case 2: return pick_final_kernel_g<GEOM_OCT>(nd, plain);
-    case 3: return pick_final_kernel_g<GEOM_VOR>(nd, plain);
-    case 4: return pick_final_kernel_g<GEOM_AMR>(nd, plain);
-    case 5: return pick_final_kernel_g<GEOM_SPH>(nd, plain);
-    case 6: return pick_final_kernel_g<GEOM_CYL>(nd, plain);
-    default: return pick_final_kernel_g<GEOM_CAR>(nd, plain);
+    case 2: return pick_final_kernel_g<GEOM_OCT>(nd, mode);
+    case 3: return pick_final_kernel_g<GEOM_VOR>(nd, mode);
+    case 4: return pick_final_kernel_g<GEOM_AMR>(nd, mode);
+    case 5: return pick_final_kernel_g<GEOM_SPH>(nd, mode);
+    case 6: return pick_final_kernel_g<GEOM_CYL>(nd, mode);
+    default: return pick_final_kernel_g<GEOM_CAR>(nd, mode);
     }
 }
 
@@ -1879,6 +1880,11 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
         for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer;     // (filters are the peel kernel's / deposit_images' business)
         h->plain_imaging = plain;
+        {
+            bool lean = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
+            for (int g = 0; g < pr->n_peeled; g++) lean = lean && !pr->peeled[g].inside_observer;
+            h->lean_imaging = lean;
+        }
         bool simple = pr->n_sources > 0;
         for (int i = 0; i < pr->n_sources; i++) simple = simple && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
         h->simple_sources = simple;
@@ -2742,6 +2748,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_ring") h->tile_ring = (int)value;
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
+    else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 2 ? 2 : (int)value;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
@@ -2801,6 +2808,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
     else if (n == "plain_imaging") *value = h->plain_imaging ? 1 : 0;
+    else if (n == "lean_imaging") *value = h->lean_imaging ? 1 : 0;
     else if (n == "last_defer_rounds") *value = h->last_defer_rounds;
     else if (n == "last_defer_events") *value = (int64_t)h->last_defer_events;
     else if (n == "pda_last_outer") *value = h->pda_last_outer;
@@ -3029,7 +3037,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     unsigned long long first = first_id;
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->hp.mono_which);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->hp.mono_which ? 1 : h->lean_imaging && !h->hp.mono_which ? 2 : 0);
     // deferred peel-off where the plain kernel applies and there is something to peel into (hyp_defer.h)
     bool deferred = h->plain_imaging && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
     DeferKernels dk;
@@ -3165,6 +3173,7 @@ int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(images): ") + hipGetErrorString(e));
     P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
     if (sync_problem(h)) return 1;
+    if (!h->ray_pending) h->ray_ms = 0.f;        // hyp_last_kernel_ms after hyp_raytracing_finish: the launches of this iteration
     h->ray_pending = true;
     if (which == 0 && P.n_sources == 0) n_local = 0;       // n_raytracing_photons_sources = 0: setup_rt.f90:238
     if (n_local == 0 || n_total == 0) return 0;
@@ -3184,12 +3193,15 @@ int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n
     if (c > 4096) c = 4096;
     L.chunk = (int)c;
     L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
+    (void)hipEventRecord(h->ev0, h->stream);
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, which, (double)n_total);
     e = hipGetLastError();
+    (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("ray_kernel launch: ") + hipGetErrorString(e));
     // the two parts share the id dispenser: finish this launch before the next one resets it
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return h->set_error(std::string("raytracing failed: ") + hipGetErrorString(e));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ray_ms += ms; }
     if (check_device_error(h)) { h->ray_pending = false; return 1; }
     return 0;
 }
@@ -3209,6 +3221,7 @@ int hyp_raytracing_finish(hyp_handle h, hyp_iter_stats *stats)
     if (!h->ray_pending) return h->set_error("hyp_raytracing_finish called without a launched iteration");
     if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
     h->ray_pending = false;
+    h->last_propagate_ms = h->ray_ms; h->last_finish_ms = 0.f;
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));
@@ -3249,7 +3262,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     if (zero_first) e = hipMemsetAsync(h->d_img_accum, 0, sizeof(double) * h->img_accum_n, h->stream);
     else if (!h->mono_pending) e = hipMemsetAsync(tail, 0, sizeof(double) * TAIL_SIZE, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(images): ") + hipGetErrorString(e));
-    if (!h->mono_pending) std::memset(&h->mono_stats, 0, sizeof h->mono_stats);
+    if (!h->mono_pending) { std::memset(&h->mono_stats, 0, sizeof h->mono_stats); h->ray_ms = 0.f; }
     h->mono_pending = true;
     P.tail = tail; P.sum = h->d_accum; P.n_copies = 1;
     P.mono_which = 0; P.mono_inu = inu; P.mono_nu = h->frequencies[inu]; P.mono_n_total = (double)n_total;
@@ -3280,7 +3293,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     unsigned long long first = first_id;
     e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, false);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, 0);
     const size_t lds = lds_bytes(P);
     long long blocks = (long long)h->n_cu * 2;
     long long need_blocks = (long long)((n_local + 255) / 256);
@@ -3295,12 +3308,15 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     // the monochromatic iteration is final_kernel with inline peel-off: the imaging iteration's batch sizes
     L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : 32;
     L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : 48;
+    (void)hipEventRecord(h->ev0, h->stream);
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
+    (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("final_kernel (monochromatic) launch: ") + hipGetErrorString(e));
     // the launches share the id dispenser and the problem block: finish this one before the next changes them
     e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) return h->set_error(std::string("monochromatic iteration failed: ") + hipGetErrorString(e));
+    { float ms = 0.f; if (hipEventElapsedTime(&ms, h->ev0, h->ev1) == hipSuccess) h->ray_ms += ms; }
     P.mono_which = 0;
     if (sync_problem(h)) return 1;
     h->mono_stats.n_packets += n_local;
@@ -3323,6 +3339,7 @@ int hyp_mono_finish(hyp_handle h, hyp_iter_stats *stats)
     if (!h->mono_pending) return h->set_error("hyp_mono_finish called without a launched iteration");
     if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
     h->mono_pending = false;
+    h->last_propagate_ms = h->ray_ms; h->last_finish_ms = 0.f;       // hyp_last_kernel_ms: the propagation kernels of all launches of this iteration
     double tail[TAIL_SIZE];
     hipError_t e = hipMemcpy(tail, h->d_img_accum + (h->img_accum_n - TAIL_SIZE), sizeof(tail), hipMemcpyDeviceToHost);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpy(tail): ") + hipGetErrorString(e));

@@ -31,20 +31,22 @@ LucyKernel pick_lucy_kernel_g(int nd)
 }
 
 template <int GEOM>
-LucyKernel pick_final_kernel_g(int nd, bool plain)
+LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plain, 2 lean (final_kernel<.., false, true>)
 {
+#define HYP_FINAL_PICK(N) (mode == 1 ? final_kernel<N, GEOM, true> : mode == 2 ? final_kernel<N, GEOM, false, true> : final_kernel<N, GEOM, false>)
 #ifdef HYP_ONLY_ND1
     (void)nd;
-    return plain ? final_kernel<1, GEOM, true> : final_kernel<1, GEOM, false>;
+    return HYP_FINAL_PICK(1);
 #else
     switch (nd) {
-    case 1: return plain ? final_kernel<1, GEOM, true> : final_kernel<1, GEOM, false>;
-    case 2: return plain ? final_kernel<2, GEOM, true> : final_kernel<2, GEOM, false>;
-    case 3: return plain ? final_kernel<3, GEOM, true> : final_kernel<3, GEOM, false>;
-    case 4: return plain ? final_kernel<4, GEOM, true> : final_kernel<4, GEOM, false>;
-    default: return plain ? final_kernel<HYP_MAXD, GEOM, true> : final_kernel<HYP_MAXD, GEOM, false>;
+    case 1: return HYP_FINAL_PICK(1);
+    case 2: return HYP_FINAL_PICK(2);
+    case 3: return HYP_FINAL_PICK(3);
+    case 4: return HYP_FINAL_PICK(4);
+    default: return HYP_FINAL_PICK(HYP_MAXD);
     }
 #endif
+#undef HYP_FINAL_PICK
 }
 
 template <int GEOM>
@@ -154,6 +156,6 @@ TileKernels pick_tile_kernels_g(int nd)
 
 template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
 template TileKernels pick_tile_kernels_g<HYP_GEOM_TU>(int);
-template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, bool);
+template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, int);
 template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);
 template DeferKernels pick_defer_kernels_g<HYP_GEOM_TU>(int);

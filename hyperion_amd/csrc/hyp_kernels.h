@@ -1769,7 +1769,7 @@ __device__ __forceinline__ void peel_rng(const DProblem &P, Rng &gp, uint32_t ke
 // peeloff_photon, external observers: images_peeled.f90:95-270.  Called by ALL
 // lanes of the wave (`active` = this lane has a packet to peel) so that the image
 // deposits can be combined across lanes.
-template <int NDT, int GEOM, bool PLAIN = false>
+template <int NDT, int GEOM, bool PLAIN = false, bool LEAN = false>
 __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const Packet<NDT, GEOM> &p, bool active,
                                         const Angle &a_prev, const double s_prev[4], int last, bool last_isotropic,
                                         const PeelFlags &f, Rng &g, Counters &cnt, const ImgCache *ic = nullptr)
@@ -1784,7 +1784,7 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                 a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
                 double d_obs = 0.0;
-                if ((!PLAIN && G.inside_observer)) inside_direction(G, p.r, a_req, d_obs);
+                if ((!PLAIN && !LEAN && G.inside_observer)) inside_direction(G, p.r, a_req, d_obs);
                 double s[4];
                 if (last_isotropic) {
                     s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
@@ -1824,12 +1824,12 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                 Cell<GEOM> c = p.cell;
                 bool ok = geo_place(P, W, p.r, v, c);
                 if (!ok) cnt.killed_geo++;
-                double d = (!PLAIN && G.inside_observer) ? d_obs : -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
+                double d = (!PLAIN && !LEAN && G.inside_observer) ? d_obs : -(v[0] * p.r[0] + v[1] * p.r[1] + v[2] * p.r[2]);
                 ok = ok && !(d < G.d_min || d > G.d_max);
                 double dr0 = p.r[0] - G.origin[0], dr1 = p.r[1] - G.origin[1], dr2 = p.r[2] - G.origin[2];
                 double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
                 double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
-                if ((!PLAIN && G.inside_observer)) inside_sky_position(G, iv, a_req, x_image, y_image);
+                if ((!PLAIN && !LEAN && G.inside_observer)) inside_sky_position(G, iv, a_req, x_image, y_image);
                 bool inside = false;
                 if (G.compute_image)
                     inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
@@ -1841,9 +1841,9 @@ __device__ __forceinline__ void peeloff(const DProblem &P, const Walls &W, const
                     Rng gp;
                     peel_rng(P, gp, g.key0, g.key1, ((unsigned long long)g.id_hi << 32) | g.id_lo, p.peel_seq, G.view_base + iv);
                     if (!G.ignore_optical_depth)
-                        tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, gp, cnt, killed, (!PLAIN && G.inside_observer) ? d_obs : HYP_DBL_MAX, 2u);
+                        tau = escape_tau<NDT, GEOM>(P, W, p.r, v, c, p.chi, gp, cnt, killed, (!PLAIN && !LEAN && G.inside_observer) ? d_obs : HYP_DBL_MAX, 2u);
                     if (!killed) {
-                        if ((!PLAIN && G.inside_observer)) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
+                        if ((!PLAIN && !LEAN && G.inside_observer)) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
                             const double dil = 1.0 / (4.0 * HYP_PI * (d_obs * d_obs));
                             s[0] = s[0] * dil; s[1] = s[1] * dil; s[2] = s[2] * dil; s[3] = s[3] * dil;
                         }
@@ -2271,7 +2271,10 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
 // PLAIN: the polychromatic peel-off iteration without anything optional -- point sources only, no monochromatic launch,
 // no modified random walk, no re-absorbing sources, no binned images, no inside observers (the host checks; filters only change the deposit).
 // Those paths cost registers even where a problem never takes them; this is the imaging kernel of BASELINE configs[3].
-template <int NDT, int GEOM, bool PLAIN>
+// LEAN (with PLAIN = false): any sources (spheres with limb darkening / spots / re-absorption, maps, external and plane-parallel ones),
+// but no modified random walk, no monochromatic launch, no binned images and no inside observers (the host checks) -- what a model
+// lit by a star with a radius needs.  Those four paths are what the general kernel spills for: 350 -> 125 spilled VGPRs on octrees.
+template <int NDT, int GEOM, bool PLAIN, bool LEAN = false>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
 {
     extern __shared__ double lds[];
@@ -2284,8 +2287,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProb
     img_cache_init(ic, img_keys, img_vals);
     Packet<NDT, GEOM> p;
     Rng g;
-    const bool has_mrw = !PLAIN && P.mrw, has_reabs = !PLAIN && P.any_intersect;
-    const int mono = PLAIN ? 0 : P.mono_which;
+    const bool has_mrw = !PLAIN && !LEAN && P.mrw, has_reabs = !PLAIN && P.any_intersect;
+    const int mono = (PLAIN || LEAN) ? 0 : P.mono_which;
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     Dispenser dsp; dsp.next = 0; dsp.end = 0;
@@ -2301,7 +2304,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProb
     for (;;) {
         // packets that left the grid alive go into the binned images (iter_final.f90:127-129), then their lane is free
         if (__ballot(st == ST_ESCAPED)) {
-            if (!PLAIN && P.binned >= 0) bin_escaped<NDT, GEOM>(P, p, st == ST_ESCAPED, f);
+            if (!PLAIN && !LEAN && P.binned >= 0) bin_escaped<NDT, GEOM>(P, p, st == ST_ESCAPED, f);
             if (st == ST_ESCAPED) st = ST_NEED_EMIT;
         }
         unsigned long long m_walk = __ballot(st == ST_WALK);
@@ -2339,7 +2342,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProb
 
         // ---- modified random walk, one step per pass, each peeled off as isotropic emission:
         //      iter_final.f90:165-183 ----
-        if (!PLAIN && m_mrw) {
+        if (!PLAIN && !LEAN && m_mrw) {
             if (st == ST_MRW) {
                 if (mrw_k == P.n_inter_mrw_max + 1) { cnt.killed_int++; st = ST_NEED_EMIT; }
                 else if (mrw_wanted(P, W, p)) {
@@ -2425,7 +2428,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProb
             // (a re-emission by a source is peeled in any case: "a kind of scattering", :226-227)
             const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);   // peel 4 (MRW): :171-173
             if (P.n_peeled > 0 && __ballot(do_peel)) {
-                peeloff<NDT, GEOM, PLAIN>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt, &ic);
+                peeloff<NDT, GEOM, PLAIN, LEAN>(P, W, p, do_peel, a_prev, s_prev, last, last_iso, f, g, cnt, &ic);
                 if (do_peel) p.peel_seq++;
             }
             if (peel != 0) {

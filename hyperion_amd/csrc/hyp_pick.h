@@ -8,7 +8,7 @@ using LucyKernel = void (*)(const DProblem *, LaunchParams);
 using RayKernel = void (*)(const DProblem *, LaunchParams, int, double);
 
 template <int GEOM> LucyKernel pick_lucy_kernel_g(int nd);    // lucy_kernel<nd, GEOM>
-template <int GEOM> LucyKernel pick_final_kernel_g(int nd, bool plain);   // final_kernel<nd, GEOM, plain>
+template <int GEOM> LucyKernel pick_final_kernel_g(int nd, int mode);     // final_kernel<nd, GEOM, ..>: 0 general, 1 plain, 2 lean
 template <int GEOM> RayKernel pick_ray_kernel_g(int nd);      // ray_kernel<nd, GEOM>
 
 // deferred peel-off (hyp_defer.h): final_defer_kernel<nd, GEOM> / peel_kernel<nd, GEOM> and their record sizes

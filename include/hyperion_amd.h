@@ -337,7 +337,8 @@ int  hyp_get_specific_energy_spectrum(hyp_handle h, double *out, double *bin_edg
 int  hyp_convergence_value(hyp_handle h, double percentile, double *value, int *status);
 
 /* measurement hooks for bench.py: duration (ms, HIP events on the engine's
- * stream) of the last propagation kernel and of the last finish step. */
+ * stream) of the last propagation kernel and of the last finish step.  After a raytracing or monochromatic
+ * iteration: the sum over the propagation kernels of all its launches (sources + dust, every wavelength), finish 0. */
 int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
 /* tuning knobs (environment-independent): name in {"interact_threshold",
  * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
@@ -356,8 +357,9 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * default: with forced first interaction on, every packet's emission, escape walk and first optical depth are made ahead of the rounds by a
  * kernel of their own, one record of 96 + 24 n_dust bytes (rounded up to 16) per packet id of the launch; "last_ff_prepass" reports whether the last imaging
  * iteration did so), "oct_neighbours" (0: the
- * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (can only be
- * switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
+ * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" / "lean_imaging" (the
+ * specialisations of the imaging kernel the problem qualifies for -- point sources only / any sources, both without MRW, monochromatic launch,
+ * binned images and inside observers; can only be switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
  * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more
  * cells than its visited set holds: the n_photons of the last iteration are an upper bound) and, for sharded runs, the
  * geometry of the blocks that hyp_*_accumulators hand out: "lucy_block_doubles" / "image_block_doubles" (their lengths) and
