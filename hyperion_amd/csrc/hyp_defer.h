@@ -623,7 +623,9 @@ __global__ __launch_bounds__(256) void peel_sort_scatter_kernel(const DProblem *
 
 // The peel-off half: one lane per (event, view), peeloff<.., PLAIN> up to the walk, grid_escape_tau
 // (grid_propagate_3d.f90:377-480) a few cells at a time, image_bin at the end.
-template <int NDT, int GEOM>
+// INSIDE: some peeled group has an inside observer (the walk towards the observer's position, ended at the observer: 18 spilled VGPRs
+// at this budget, which the problems without one do not pay)
+template <int NDT, int GEOM, bool INSIDE>
 __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem *__restrict__ Pp, DeferBuf B, uint32_t iter_tag)
 {
     extern __shared__ double lds[];
@@ -653,6 +655,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
     double inv[3] = {1.0, 1.0, 1.0};          // octree: RN(1 / v) of the walk's direction, see oct_find_wall_inv
     bool v_ok = true;
     double s[4] = {0.0, 0.0, 0.0, 0.0}, energy = 0.0, nu_l = 0.0;
+    double t_max = HYP_DBL_MAX, t_ach = 0.0;         // inside observers (images_peeled.f90:158-205): the walk ends at the observer
     long long k_img = -1, k_sed = -1;
     Cell<GEOM> c;
     Rng gp;
@@ -701,6 +704,9 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                     a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
                     a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
                     const double nu = E.nu;
+                    r[0] = E.r[0]; r[1] = E.r[1]; r[2] = E.r[2];
+                    double d_obs = 0.0;
+                    if ((INSIDE && G.inside_observer)) inside_direction(G, r, a_req, d_obs);      // towards the observer's position, d_obs away
                     if (last_iso) {
                         s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
                     } else {
@@ -719,7 +725,6 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                             }
                         }
                     }
-                    r[0] = E.r[0]; r[1] = E.r[1]; r[2] = E.r[2];
                     angle_to_vector(a_req, v[0], v[1], v[2]);
                     if (GEOM == GEOM_OCT) {
                         v_ok = true;
@@ -729,11 +734,12 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                     c = E.cell;
                     bool ok = geo_place(P, W, r, v, c);
                     if (!ok) cnt.killed_geo++;
-                    const double d = -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
+                    const double d = (INSIDE && G.inside_observer) ? d_obs : -(v[0] * r[0] + v[1] * r[1] + v[2] * r[2]);
                     ok = ok && !(d < G.d_min || d > G.d_max);
                     const double dr0 = r[0] - G.origin[0], dr1 = r[1] - G.origin[1], dr2 = r[2] - G.origin[2];
-                    const double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
-                    const double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                    double x_image = dr1 * a_req.cosp - dr0 * a_req.sinp;
+                    double y_image = dr2 * a_req.sint - dr1 * a_req.cost * a_req.sinp - dr0 * a_req.cost * a_req.cosp;
+                    if ((INSIDE && G.inside_observer)) inside_sky_position(G, iv, a_req, x_image, y_image);
                     bool inside = false;
                     if (G.compute_image)
                         inside = ((x_image >= G.x_min && x_image <= G.x_max) || (x_image <= G.x_min && x_image >= G.x_max)) &&
@@ -749,6 +755,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         image_bin_keys(P, G, nu, energy, s[0], f, x_image, y_image, iv, k_img, k_sed, G.use_filters ? 0 : -1);
                         nu_l = nu;
                         ig = g_i; tau = 0.0;
+                        t_max = (INSIDE && G.inside_observer) ? d_obs : HYP_DBL_MAX; t_ach = 0.0;
 #pragma unroll
                         for (int dd = 0; dd < NDT; dd++) chi[dd] = E.chi[dd];
                         peel_rng(P, gp, P.seed_key, iter_tag, E.id, E.peel_seq, vg);
@@ -779,14 +786,22 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 if (!check_ok || !found) { cnt.killed_geo++; st = 0; }
                 else {
                     const size_t base = geo_index(P, c) * (size_t)nd;
+                    bool finished = false;          // grid_propagate_3d.f90:446-452
+                    if (INSIDE && t_max < HYP_DBL_MAX) {
+                        if (t_ach + tmin > t_max) { tmin = t_max - t_ach; finished = true; }
+                        t_ach += tmin;
+                    }
 #pragma unroll
                     for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
 #pragma unroll
                     for (int dd = 0; dd < NDT; dd++) if (dd < nd) tau += chi[dd] * hyp_ldg(P.density + base + dd) * tmin;
                     cnt.crossings++;
-                    geo_advance(P, r, c, im);
-                    if (geo_invalid(P, c)) { cnt.killed_geo++; st = 0; }
-                    else if (geo_escaped(P, c)) st = 2;
+                    if (finished) st = 2;
+                    else {
+                        geo_advance(P, r, c, im);
+                        if (geo_invalid(P, c)) { cnt.killed_geo++; st = 0; }
+                        else if (geo_escaped(P, c)) st = 2;
+                    }
                 }
             }
         }
@@ -798,6 +813,10 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
             double sa[4] = {0.0, 0.0, 0.0, 0.0};
             bool live = false;
             if (st == 2) {
+                if (INSIDE && t_max < HYP_DBL_MAX) {        // 1 / (4 pi d^2) flux dilution: images_peeled.f90:236
+                    const double dil = 1.0 / (4.0 * HYP_PI * (t_max * t_max));
+                    s[0] = s[0] * dil; s[1] = s[1] * dil; s[2] = s[2] * dil; s[3] = s[3] * dil;
+                }
                 const double att = exp(-tau);
                 sa[0] = s[0] * att; sa[1] = s[1] * att; sa[2] = s[2] * att; sa[3] = s[3] * att;
                 live = sa[0] == sa[0];

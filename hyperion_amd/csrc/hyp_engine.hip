@@ -282,6 +282,7 @@ struct hyp_engine {
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
+    bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
@@ -1878,8 +1879,10 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     {
         bool plain = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
-        for (int g = 0; g < pr->n_peeled; g++) plain = plain && !pr->peeled[g].inside_observer;     // (filters are the peel kernel's / deposit_images' business)
+        // (filters are the peel kernel's / deposit_images' business; inside observers are the peel kernel's, not the inline plain kernel's)
         h->plain_imaging = plain;
+        h->inside_observers = false;
+        for (int g = 0; g < pr->n_peeled; g++) h->inside_observers = h->inside_observers || pr->peeled[g].inside_observer;
         {
             bool lean = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
             for (int g = 0; g < pr->n_peeled; g++) lean = lean && !pr->peeled[g].inside_observer;
@@ -2918,7 +2921,7 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
             h->last_ff_prepass = 1;
         }
     }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.peel, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
     int idle_rounds = 0;
     for (int round = 0;; round++) {
@@ -2931,7 +2934,7 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
             hipLaunchKernelGGL(dk.sort_scan, dim3(1), dim3(1024), 0, h->stream, B);
             hipLaunchKernelGGL(dk.sort_scatter, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
         }
-        hipLaunchKernelGGL(dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
+        hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return h->set_error(std::string("deferred imaging launch: ") + hipGetErrorString(e));
         (void)hipMemcpyAsync(h->h_peel_ctl, h->d_peel_ctl, sizeof(PeelCtl), hipMemcpyDeviceToHost, h->stream);
@@ -2988,7 +2991,7 @@ static int run_staged_rounds(hyp_handle h, const DeferKernels &dk, const LaunchP
     std::memset(&B, 0, sizeof B);
     B.events = h->d_peel_events; B.cap = n_slots; B.ctl = h->d_peel_ctl;
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.peel, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.stage_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned walk_blocks = (unsigned)std::min<size_t>((size_t)h->n_cu * occ, n_slots / 256);
@@ -2999,7 +3002,7 @@ static int run_staged_rounds(hyp_handle h, const DeferKernels &dk, const LaunchP
         hipLaunchKernelGGL(dk.stage_event, dim3(slot_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, S);
         (void)hipMemcpyAsync(h->h_stage_ctl, h->d_stage_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, h->stream);
         (void)hipMemcpyAsync(h->h_peel_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
-        hipLaunchKernelGGL(dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
+        hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
         hipLaunchKernelGGL(dk.stage_walk, dim3(walk_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, S, L.iter_tag);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return h->set_error(std::string("staged imaging launch: ") + hipGetErrorString(e));
@@ -3037,7 +3040,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     unsigned long long first = first_id;
     hipError_t e = hipMemcpyAsync(h->d_counter, &first, sizeof(first), hipMemcpyHostToDevice, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
-    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->hp.mono_which ? 1 : h->lean_imaging && !h->hp.mono_which ? 2 : 0);
+    LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->inside_observers && !h->hp.mono_which ? 1 : h->lean_imaging && !h->hp.mono_which ? 2 : 0);
     // deferred peel-off where the plain kernel applies and there is something to peel into (hyp_defer.h)
     bool deferred = h->plain_imaging && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
     DeferKernels dk;

@@ -2269,7 +2269,8 @@ __device__ __forceinline__ void forced_interaction(const DProblem &P, double tau
 }
 
 // PLAIN: the polychromatic peel-off iteration without anything optional -- point sources only, no monochromatic launch,
-// no modified random walk, no re-absorbing sources, no binned images, no inside observers (the host checks; filters only change the deposit).
+// no modified random walk, no re-absorbing sources, no binned images, no inside observers (the host checks; filters only change the deposit;
+// with an inside observer the problem still qualifies for the deferred schedule, whose peel kernel handles it, but not for this kernel).
 // Those paths cost registers even where a problem never takes them; this is the imaging kernel of BASELINE configs[3].
 // LEAN (with PLAIN = false): any sources (spheres with limb darkening / spots / re-absorption, maps, external and plane-parallel ones),
 // but no modified random walk, no monochromatic launch, no binned images and no inside observers (the host checks) -- what a model

@@ -20,7 +20,7 @@ using StageWalkK = void (*)(const DProblem *, StageBuf, uint32_t);
 using StageInitK = void (*)(StageBuf);
 struct DeferKernels {
     DeferKernel propagate, propagate_pre, ff_walk;       // propagate_pre: with the forced-first walks made ahead (ff_walk)
-    PeelKernel peel; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
+    PeelKernel peel, peel_inside; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
     PeelSortK sort_hist, sort_scatter; void (*sort_scan)(DeferBuf);  // sorted peel-off: keys + histogram, scatter (peel_sort_scan_kernel between them)
     // staged schedule (hyp_stage.h): slot records StageHot (hot_bytes) + SuspRec (susp_bytes), one PeelEvent per slot
     StageEventK stage_event; StageWalkK stage_walk; StageInitK stage_init; size_t hot_bytes;
