@@ -71,8 +71,8 @@ def traffic_fields(pmc):
 
 def cpu_baseline(prob, n_sample):
     """Oracle (CPU restatement) timed on this host's cores on a bounded sample
-    of the same workload.  Test infrastructure used as the reported baseline,
-    never as the product."""
+    of the same workload, on all the threads it can use and on ONE core.  Test
+    infrastructure used as the reported baseline, never as the product."""
     from oracle_lib import Oracle
     cores = os.cpu_count() or 1
     threads = min(cores, 64)         # per-thread accumulators: 64 x 16 MiB at 128^3
@@ -81,49 +81,86 @@ def cpu_baseline(prob, n_sample):
     t0 = time.time()
     _, st = orc.lucy_iteration(n_sample, 1, n_threads=threads)
     dt = time.time() - t0
+    n_one = max(min(n_sample // 80, 250000), 1000)
+    t1 = time.time()
+    _, s1 = orc.lucy_iteration(n_one, 1, n_threads=1)
+    d1 = time.time() - t1
     orc.close()
     return {"value": n_sample / dt, "unit": "packets/s", "cores": threads, "kind": "port", "host_cpu": host_cpu(), "host_logical_cpus": cores,
             "sample": "%d packets of the same 128^3 workload, 1 Lucy iteration, %d OpenMP threads (%.1f s)" % (n_sample, threads, dt),
-            "crossings_per_s": st["crossings"] / dt}
+            "crossings_per_s": st["crossings"] / dt,
+            "one_core": {"value": n_one / d1, "unit": "packets/s", "cores": 1, "crossings_per_s": s1["crossings"] / d1,
+                         "sample": "%d packets of the same workload on one thread (%.1f s)" % (n_one, d1)},
+            "note": "the CPU restatement (oracle/hyp_oracle.c), not the Fortran: the reference needs its absent fortranlib submodule to build "
+                    "(DESIGN.md section 6 has the survey's probe of the reference's own geometry loop for calibration)"}
 
 
-def extras(n):
+def extras(n, passes=3):
     """The other single-GPU configurations of BASELINE.json, after the timed region, as extra entries of the same JSON line
     (not `value`): configs[3] = adaptive octree + peel-off imaging to a 512 x 512 Stokes image, configs[4] = the real
-    100 000-site voro++ tessellation with two anisotropic polarising species and an external source.  One warm-up and one
-    timed pass each; unit of work = cell crossing (24 B x n_dust algorithmic)."""
+    100 000-site voro++ tessellation with two anisotropic polarising species and an external source.  One warm-up and
+    `passes` timed passes each (mean, and every pass listed).  Unit of work = cell crossing.  Algorithmic bytes (SURVEY
+    section 8d): a Lucy iteration moves 24 B x n_dust per crossing; an imaging iteration deposits nothing on its crossings --
+    8 B x n_dust per crossing (density read of grid_integrate_noenergy / grid_escape_tau) + 16 B x n_stokes per binned
+    peel-off event (event x view)."""
     import hyperion_amd
     from hyperion_amd.benchmark import make_octree_problem
     res = []
 
     def timed(fn):
         fn()
-        t0 = time.perf_counter()
-        st = fn()
-        return st, time.perf_counter() - t0
+        dts, st = [], None
+        for _ in range(passes):
+            t0 = time.perf_counter()
+            st = fn()
+            dts.append(time.perf_counter() - t0)
+        return st, sum(dts) / len(dts), dts
 
-    p = make_octree_problem(max_level=7, n_photons=n, n_iter=1)
-    e = hyperion_amd.Engine(p)
-    state = {"it": 0}
+    def common(st, n, dt, dts, k_ms, alg_bytes):
+        return {"packets": n, "passes": len(dts), "packets_per_s": n / dt, "pass_ms": [x * 1e3 for x in dts], "kernel_ms": k_ms,
+                "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "crossings_per_packet": st["crossings"] / n,
+                "killed_geo": int(st["killed_geo"]), "killed_int": int(st["killed_int"]),
+                "algorithmic_GB": alg_bytes / 1e9, "hbm_frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
 
-    def lucy():
-        state["it"] += 1
-        return e.lucy_iteration(n, state["it"], want_output=False)[1]
-    st, dt = timed(lucy)
-    k_ms = e.last_kernel_ms()[0]
-    res.append({"config": "configs[3] Lucy iteration: octree depth 7 (%d cells), central source" % p.n_cells, "packets": n,
-                "packets_per_s": n / dt, "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
-                "schedule": "cluster-tiled (hyp_otile.h), %d clusters" % e.get_option("ot_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
-                "hbm_frac": 24.0 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("oct_lucy"))})
-    st, dt = timed(lambda: e.final_iteration(n)[1])
-    rounds = e.get_option("last_defer_rounds")
-    res.append({"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction", "packets": n,
-                "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet%s" % (rounds, e.get_option("last_defer_events") / n,
-                             ", emission + forced first interaction ahead of the rounds (ff_walk_kernel)" if e.get_option("last_ff_prepass") else ""))
-                            if rounds else "inline peel-off",
-                "packets_per_s": n / dt, "kernel_ms": e.last_kernel_ms()[0],
-                "crossings_per_s": st["crossings"] / dt, "hbm_frac": 24.0 * st["crossings"] / dt / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("oct_img"))})
-    e.close()
+    def pmc_fields(name, alg_per_crossing):
+        f = traffic_fields(committed_pmc(name))
+        b = f.get("bytes_per_crossing")
+        if b:       # the committed counters are per crossing: restate their ratio against THIS entry's algorithmic bytes
+            b["algorithmic"] = alg_per_crossing
+            f["traffic_over_algorithmic"] = (b["fetched"] + b["written"]) / alg_per_crossing
+            f["traffic_over_algorithmic_reads_x2"] = (b["fetched_reads_x2"] + b["written"]) / alg_per_crossing
+        return f
+
+    for label, pos in (("central source on a vertex of the tree (BASELINE's config)", (0.0, 0.0, 0.0)),
+                       ("the same tree, source moved off the vertex to (0.013, 0.007, -0.011) pc", (0.013 * 3.08568025e18, 0.007 * 3.08568025e18, -0.011 * 3.08568025e18))):
+        p = make_octree_problem(max_level=7, n_photons=n, n_iter=1, source_position=pos)
+        e = hyperion_amd.Engine(p)
+        state = {"it": 0}
+
+        def lucy():
+            state["it"] += 1
+            return e.lucy_iteration(n, state["it"], want_output=False)[1]
+        st, dt, dts = timed(lucy)
+        k_ms = e.last_kernel_ms()[0]
+        res.append({"config": "configs[3] Lucy iteration: octree depth 7 (%d cells), %s" % (p.n_cells, label),
+                    "schedule": "cluster-tiled (hyp_otile.h), %d clusters" % e.get_option("ot_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
+                    **common(st, n, dt, dts, k_ms, 24.0 * st["crossings"]), **pmc_fields("oct_lucy", 24.0)})
+        st, dt, dts = timed(lambda: e.final_iteration(n)[1])
+        rounds = e.get_option("last_defer_rounds")
+        k_ms = e.last_kernel_ms()[0]
+        events = e.get_option("last_defer_events") if rounds else 0
+        n_view, n_stokes = 1, 4
+        alg = 8.0 * st["crossings"] + 16.0 * n_stokes * events * n_view
+        ent = {"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction; %s" % label,
+               "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet%s" % (rounds, events / n,
+                            ", emission + forced first interaction ahead of the rounds (ff_walk_kernel)" if e.get_option("last_ff_prepass") else ""))
+                           if rounds else "inline peel-off",
+               **common(st, n, dt, dts, k_ms, alg),
+               "algorithmic_bytes": "8 B x n_dust per crossing (no deposit in the imaging iteration) + 16 B x 4 Stokes x %d binned events (events x views)" % (events * n_view)}
+        if st["crossings"]:
+            ent.update(pmc_fields("oct_img", alg / st["crossings"]))
+        res.append(ent)
+        e.close()
     try:
         from cases import voronoi_big_problem
         p = voronoi_big_problem(n_photons=n)
@@ -131,18 +168,17 @@ def extras(n):
         res.append({"config": "configs[4]", "error": str(ex)})
         return res
     e = hyperion_amd.Engine(p)
-    state["it"] = 0
+    state = {"it": 0}
 
     def lucy4():
         state["it"] += 1
         return e.lucy_iteration(n, state["it"], want_output=False)[1]
-    st, dt = timed(lucy4)
+    st, dt, dts = timed(lucy4)
     k_ms = e.last_kernel_ms()[0]
     res.append({"config": "configs[4] Lucy iteration: voro++ tessellation of 100000 random sites (15.2 neighbours / cell), 2 HG-like polarising "
-                          "species, point + external box source", "packets": n, "packets_per_s": n / dt,
-                "crossings_per_s": st["crossings"] / (k_ms * 1e-3), "kernel_ms": k_ms,
+                          "species, point + external box source",
                 "schedule": "cluster-tiled (hyp_vtile.h), %d clusters" % e.get_option("vt_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
-                "hbm_frac": 24.0 * 2 * st["crossings"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, **traffic_fields(committed_pmc("vor"))})
+                **common(st, n, dt, dts, k_ms, 24.0 * 2 * st["crossings"]), **pmc_fields("vor", 48.0)})
     e.close()
     return res
 

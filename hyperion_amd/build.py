@@ -10,8 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libhyperion_amd.so")
-SOURCES = ["hyp_engine.hip", "hyp_geom.hip", "hyp_kernels.h", "hyp_device.h", "hyp_tiled.h", "hyp_pick.h", "hyp_polar.h", "hyp_epilogue.h", "hyp_defer.h", "hyp_vtile.h", "hyp_otile.h", "hyp_atile.h", "hyp_stage.h"]
-# one translation unit per grid geometry (lucy / final / ray kernels x species counts) + the host side
+# one translation unit per (grid geometry, kernel family) + the host side: see units()
 GEOMS = {"car": 0, "oct": 1, "vor": 2, "amr": 3, "sph": 4, "cyl": 5}
 # -ffp-contract=off: the cell-walk arithmetic must round like the reference formulation (see find_wall)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-ffp-contract=off", "-fPIC"]
@@ -25,31 +24,107 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
-def is_stale():
+PARTS = {"lucy": 0, "tile": 1, "final": 2, "defer": 3, "ray": 4}
+# heaviest first: the pool starts them first so that the long poles do not land at the end
+_COST = {"final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
+
+
+def units():
+    """(name, source, defines): the host side + one unit per (geometry, kernel family) -- hyp_geom.hip's header."""
+    u = [("engine", "hyp_engine.hip", [])]
+    for part in sorted(PARTS, key=lambda k: -_COST[k]):
+        for g, k in GEOMS.items():
+            u.append(("%s_%s" % (part, g), "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % k, "-DHYP_PART=%d" % PARTS[part]]))
+    return u
+
+
+def _deps_of(depfile):
+    """Prerequisites listed in a make-style dependency file written by `hipcc -MD -MF`."""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace("\\\n", " ")
+    return [t for t in text.split(":", 1)[1].split() if t] if ":" in text else None
+
+
+def unit_is_stale(obj, cmd, cwd=CSRC):
+    """An object is rebuilt when it is missing, when its command line changed, or when a file it was compiled from is newer."""
+    if not os.path.exists(obj):
+        return True
+    try:
+        if open(obj + ".cmd").read() != " ".join(cmd):
+            return True
+    except OSError:
+        return True
+    deps = _deps_of(obj + ".d")
+    if deps is None:
+        return True
+    t = os.path.getmtime(obj)
+    for d in deps:
+        path = d if os.path.isabs(d) else os.path.join(cwd, d)
+        if not os.path.exists(path) or os.path.getmtime(path) > t:
+            return True
+    return False
+
+
+def _unit_cmd(src, defs, obj, extra_flags):
+    return [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + defs + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj]
+
+
+def is_stale(objdir=OBJDIR):
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "hyperion_amd.h"))
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
-
-
-def compile_units(out, extra_flags=(), objdir=OBJDIR, verbose=False):
-    """hipcc -c every translation unit in parallel, then link them into `out`."""
-    os.makedirs(objdir, exist_ok=True)
-    units = [("engine", "hyp_engine.hip", [])] + [("geom_" + g, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % k]) for g, k in GEOMS.items()]
-    procs = []
-    for name, src, defs in units:
+    for name, src, defs in units():
         obj = os.path.join(objdir, name + ".o")
-        cmd = [_hipcc()] + HIPCC_FLAGS + list(extra_flags) + defs + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
-    objs = []
-    for cmd, obj, p in procs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+        if unit_is_stale(obj, _unit_cmd(src, defs, obj, ())) or os.path.getmtime(obj) > t:
+            return True
+    return False
+
+
+def compile_units(out, extra_flags=(), objdir=OBJDIR, verbose=False, force=False, jobs=None, select=None):
+    """hipcc -c every stale translation unit, at most `jobs` at a time, then link all of them into `out`.
+    `select`: only units whose name contains one of these strings are (re)compiled -- tuning builds."""
+    os.makedirs(objdir, exist_ok=True)
+    jobs = jobs or max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("HYP_BUILD_JOBS", "64"))))
+    todo, objs = [], []
+    for name, src, defs in units():
+        obj = os.path.join(objdir, name + ".o")
         objs.append(obj)
+        if select is not None and not any(x in name for x in select):
+            continue
+        cmd = _unit_cmd(src, defs, obj, extra_flags)
+        if force or unit_is_stale(obj, cmd):
+            todo.append((cmd, obj))
+    import time
+    running, failed = [], None
+    while (todo or running) and failed is None:
+        while todo and len(running) < jobs:
+            cmd, obj = todo.pop(0)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            for stale in (obj + ".cmd", obj):
+                if os.path.exists(stale):
+                    os.remove(stale)
+            running.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+        still = []
+        for cmd, obj, p in running:
+            rc = p.poll()
+            if rc is None:
+                still.append((cmd, obj, p))
+            elif rc != 0:
+                failed = failed or (rc, cmd)
+            else:
+                with open(obj + ".cmd", "w") as f:
+                    f.write(" ".join(cmd))
+        running = still
+        if running and failed is None:
+            time.sleep(0.2)
+    for _, _, p in running:
+        p.wait()
+    if failed:
+        raise subprocess.CalledProcessError(*failed)
     cmd = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out + ".tmp"]
     if verbose:
         print(" ".join(cmd))
@@ -61,7 +136,7 @@ def compile_units(out, extra_flags=(), objdir=OBJDIR, verbose=False):
 def build_extension(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
-    return compile_units(LIB, verbose=verbose)
+    return compile_units(LIB, verbose=verbose, force=force)
 
 
 # ---- the native .rtin -> .rtout driver (hyp_run.cpp): `hyperion_car`-style executables over the C ABI -------------------

@@ -281,6 +281,7 @@ struct hyp_engine {
     hyp_iter_stats mono_stats;
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
+    bool tile_unbuildable = false;  // the grid is beyond the limits of its tiled Lucy schedule's tables: auto mode stays on the persistent kernel
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
@@ -1880,13 +1881,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         bool plain = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
         // (filters are the peel kernel's / deposit_images' business; inside observers are the peel kernel's, not the inline plain kernel's)
-        h->plain_imaging = plain;
+        h->plain_imaging = plain && h->n_dust <= 4;      // five to eight species: the general kernel only (hyp_geom.hip)
         h->inside_observers = false;
         for (int g = 0; g < pr->n_peeled; g++) h->inside_observers = h->inside_observers || pr->peeled[g].inside_observer;
         {
             bool lean = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
             for (int g = 0; g < pr->n_peeled; g++) lean = lean && !pr->peeled[g].inside_observer;
-            h->lean_imaging = lean;
+            h->lean_imaging = lean && h->n_dust <= 4;
         }
         bool simple = pr->n_sources > 0;
         for (int i = 0; i < pr->n_sources; i++) simple = simple && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
@@ -2540,10 +2541,18 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins;
         tile_auto = tile_ok && h->n_cells >= 32768 && n_local >= 2000000ull;
     }
-    const bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto));
-    if (tiled && P.grid_type == 4 && build_amr_slabs(h)) return 1;
-    if (tiled && P.grid_type == 3 && build_vor_clusters(h)) return 1;
-    if (tiled && P.grid_type == 2 && build_oct_clusters(h)) return 1;
+    bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto && !h->tile_unbuildable));
+    if (tiled && P.grid_type != 1) {
+        // the builders have limits of their own (HYP_TILE_MAX_BRICKS clusters / bricks, the LDS budget, 16-bit grid numbers):
+        // a grid beyond them runs on the persistent kernel as before; only a FORCED tiled iteration (lucy_mode = 1) reports the limit
+        const int rc = P.grid_type == 4 ? build_amr_slabs(h) : P.grid_type == 3 ? build_vor_clusters(h) : build_oct_clusters(h);
+        if (rc) {
+            if (h->lucy_mode == 1) return 1;
+            h->tile_unbuildable = true;
+            h->err.clear();
+            tiled = false;
+        }
+    }
     if (sync_problem(h)) return 1;
     hipError_t e = hipMemsetAsync(h->d_accum, 0, sizeof(double) * h->accum_stride * copies, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("hipMemsetAsync(accum): ") + hipGetErrorString(e));
@@ -3046,6 +3055,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
+    if (deferred && !dk.propagate) deferred = false;
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {

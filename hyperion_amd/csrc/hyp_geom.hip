@@ -1,18 +1,37 @@
-// hyp_geom.hip -- instantiates lucy_kernel / final_kernel / ray_kernel for ONE grid geometry
-// (-DHYP_GEOM_TU=GEOM_xxx; hyperion_amd/build.py compiles this file once per geometry, in
-// parallel, and links the objects with hyp_engine.hip into libhyperion_amd.so).
+// hyp_geom.hip -- instantiates the propagation kernels of ONE grid geometry and ONE family of kernels
+// (-DHYP_GEOM_TU=GEOM_xxx -DHYP_PART=n; hyperion_amd/build.py compiles this file once per pair, in
+// parallel, and links the objects with hyp_engine.hip into libhyperion_amd.so).  Every unit includes only the
+// headers of its family, so that an edit of one schedule recompiles the units that carry it and nothing else.
+//   HYP_PART 0: lucy_kernel      1: the tiled Lucy schedules (hyp_tiled.h + hyp_vtile.h / hyp_otile.h / hyp_atile.h)
+//            2: final_kernel     3: deferred / staged imaging (hyp_defer.h, hyp_stage.h)      4: ray_kernel
+// Species counts: 1-4 are compile-time (registers hold the per-species state); 5-8 run on the HYP_MAXD instances that
+// read the count from the problem -- only the persistent Lucy kernel, the general imaging kernel and the raytracing
+// kernel exist in that form (the engine does not pick a plain / lean / deferred / tiled schedule above four species).
 #ifndef HYP_GEOM_TU
 #define HYP_GEOM_TU 0   // GEOM_CAR
 #endif
+#ifndef HYP_PART
+#error "compile with -DHYP_PART=0..4 (hyperion_amd/build.py)"
+#endif
 #include "hyp_kernels.h"
+#if HYP_PART == 1
+#include "hyp_tiled.h"
+#if HYP_GEOM_TU == 2
+#include "hyp_vtile.h"
+#elif HYP_GEOM_TU == 1
+#include "hyp_otile.h"
+#elif HYP_GEOM_TU == 3
+#include "hyp_atile.h"
+#endif
+#endif
+#if HYP_PART == 3
 #include "hyp_defer.h"
 #include "hyp_stage.h"
-#include "hyp_vtile.h"
-#include "hyp_otile.h"
-#include "hyp_atile.h"
+#endif
 #include "hyp_pick.h"
 #include <cstring>
 
+#if HYP_PART == 0
 template <int GEOM>
 LucyKernel pick_lucy_kernel_g(int nd)
 {
@@ -30,6 +49,9 @@ LucyKernel pick_lucy_kernel_g(int nd)
 #endif
 }
 
+#endif
+
+#if HYP_PART == 2
 template <int GEOM>
 LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plain, 2 lean (final_kernel<.., false, true>)
 {
@@ -43,12 +65,15 @@ LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plai
     case 2: return HYP_FINAL_PICK(2);
     case 3: return HYP_FINAL_PICK(3);
     case 4: return HYP_FINAL_PICK(4);
-    default: return HYP_FINAL_PICK(HYP_MAXD);
+    default: return final_kernel<HYP_MAXD, GEOM, false>;      // five to eight species: the general kernel only
     }
 #endif
 #undef HYP_FINAL_PICK
 }
 
+#endif
+
+#if HYP_PART == 4
 template <int GEOM>
 RayKernel pick_ray_kernel_g(int nd)
 {
@@ -66,6 +91,9 @@ RayKernel pick_ray_kernel_g(int nd)
 #endif
 }
 
+#endif
+
+#if HYP_PART == 3
 template <int NDT, int GEOM>
 static DeferKernels defer_kernels()
 {
@@ -90,11 +118,14 @@ DeferKernels pick_defer_kernels_g(int nd)
     case 2: return defer_kernels<2, GEOM>();
     case 3: return defer_kernels<3, GEOM>();
     case 4: return defer_kernels<4, GEOM>();
-    default: return defer_kernels<HYP_MAXD, GEOM>();
+    default: { DeferKernels k; memset(&k, 0, sizeof k); return k; }      // five to eight species: inline peel-off (the engine checks .propagate)
     }
 #endif
 }
 
+#endif
+
+#if HYP_PART == 1
 template <int NDT, int GEOM>
 static TileKernels tile_kernels()
 {
@@ -107,19 +138,22 @@ static TileKernels tile_kernels()
         k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
     }
-    if constexpr (GEOM == GEOM_AMR) {
+#if HYP_GEOM_TU == 3
+    {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
         k.walk = atile_walk_kernel<NDT>;
         k.walk_threads = HYP_ATILE_WG;
     }
-    if constexpr (GEOM == GEOM_OCT) {
+#elif HYP_GEOM_TU == 1
+    {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
         k.walk = otile_walk_kernel<NDT>;
         k.walk_threads = HYP_OTILE_WG;
     }
-    if constexpr (GEOM == GEOM_CAR) {
+#elif HYP_GEOM_TU == 0
+    {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
         k.prepare = tile_prepare_kernel<NDT>;
@@ -130,10 +164,12 @@ static TileKernels tile_kernels()
         k.walk_threads = HYP_TILE_WG;
         k.bx = TileShape<NDT>::X; k.by = TileShape<NDT>::Y; k.bz = TileShape<NDT>::Z;
     }
-    if constexpr (GEOM == GEOM_VOR) {      // the modified random walk is not defined on Voronoi grids (the engine refuses it)
+#elif HYP_GEOM_TU == 2
+    {      // the modified random walk is not defined on Voronoi grids (the engine refuses it)
         k.walk = vtile_walk_kernel<NDT>;
         k.walk_threads = HYP_VTILE_WG;
     }
+#endif
     return k;
 }
 
@@ -154,8 +190,16 @@ TileKernels pick_tile_kernels_g(int nd)
 #endif
 }
 
+#endif
+
+#if HYP_PART == 0
 template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
+#elif HYP_PART == 1
 template TileKernels pick_tile_kernels_g<HYP_GEOM_TU>(int);
+#elif HYP_PART == 2
 template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, int);
-template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);
+#elif HYP_PART == 3
 template DeferKernels pick_defer_kernels_g<HYP_GEOM_TU>(int);
+#else
+template RayKernel pick_ray_kernel_g<HYP_GEOM_TU>(int);
+#endif

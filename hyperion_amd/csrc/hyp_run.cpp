@@ -36,6 +36,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 
@@ -270,7 +271,18 @@ hid_t put_dataset(hid_t loc, const char *name, const std::vector<hsize_t> &dims,
         std::vector<hsize_t> ch(dims);
         size_t bytes = n * 8;
         // (a few MB at most: a deflated chunk larger than HDF5's chunk cache is compressed and written in one piece)
-        for (size_t k = 0; k < ch.size() && bytes > (4u << 20); k++) { bytes /= (size_t)ch[k]; ch[k] = 1; }
+        // leading dimensions collapse to 1 while the chunk is too large; the dimension that is left over is SPLIT, never
+        // reduced to single elements: (n_dust, n_cells) of a large octree / Voronoi grid gives chunks of (1, 524288)
+        const size_t limit = 4u << 20;
+        for (size_t k = 0; k < ch.size() && bytes > limit; k++) {
+            const size_t inner = bytes / (size_t)ch[k];       // bytes of one index of dimension k
+            if (inner <= limit || k + 1 == ch.size()) {
+                ch[k] = (hsize_t)std::max<size_t>(1, limit / std::max<size_t>(inner, 1));
+                bytes = inner * (size_t)ch[k];
+                break;
+            }
+            bytes = inner; ch[k] = 1;
+        }
         H5Pset_chunk(pl, (int)ch.size(), ch.data());
         H5Pset_deflate(pl, 4);
     }
@@ -826,26 +838,40 @@ struct Comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double *zero = nullptr; size_t zero_n = 0;
-    std::string id_file;
+    std::string id_file, abort_file;
+    volatile bool leaving = false;   // this rank wrote the abort file itself (or finished): its watcher stands down
 
     static bool env_int(std::initializer_list<const char *> names, int &out)
     {
         for (const char *n : names) { const char *v = getenv(n); if (v && *v) { out = atoi(v); return true; } }
         return false;
     }
-    void from_env()
+    // `mpi_name`: started under one of the reference's hyperion_<grid>_mpi names (scripts/hyperion:62-92).  An explicit RANK /
+    // WORLD_SIZE (torchrun, --ranks) always counts; the variables a batch system sets for ANY process of a job (Open MPI, PMI,
+    // Slurm) make this process a rank only under the _mpi names -- `hyperion_car` inside an sbatch script with --ntasks=N is one
+    // plain process, not rank 0 of N waiting for peers that do not exist.
+    void from_env(const std::string &output, bool mpi_name)
     {
-        on = env_int({"RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, rank);
-        if (on && !env_int({"WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, size)) size = 1;
+        on = env_int({"RANK"}, rank);
+        if (on) { if (!env_int({"WORLD_SIZE"}, size)) size = 1; }
+        else if (mpi_name) {
+            on = env_int({"OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"}, rank);
+            if (on && !env_int({"OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "SLURM_NTASKS"}, size)) size = 1;
+        }
         env_int({"HYP_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", "SLURM_LOCALID"}, local_rank);
         if (!on) { rank = 0; size = 1; }
         if (rank < 0 || rank >= size) throw Fail(fmt("rank %d of %d: inconsistent launcher environment", rank, size));
+        // the files the ranks of ONE launch talk through before (and beside) the communicator carry the launcher's id in their
+        // names: a file a crashed run left behind belongs to another launch and is never read
+        const char *e = getenv("HYP_NCCL_ID_FILE");
+        id_file = (e && *e ? std::string(e) : output + ".ncclid") + "." + std::to_string(launch_id());
+        abort_file = output + ".abort." + std::to_string(launch_id());
+        if (on && size > 1) std::thread([this] { watch(); }).detach();
     }
     bool main_process() const { return rank == 0; }
 
     // The ncclUniqueId travels through a file next to the output (the ranks of one node share it): rank 0 writes
-    // {magic, parent pid, id} to a temporary name and renames it; the others wait for a file whose parent pid is theirs
-    // (a stale file of another run is ignored).  `abort_msg`: rank 0 could not start -- the others leave with it.
+    // {magic, launch id, id} to a temporary name and renames it; the others wait for it.
     struct IdFile { char magic[8]; long long ppid; int aborted; char msg[256]; ncclUniqueId id; };
     // what the ranks of one launch have in common: the launcher's pid (--ranks sets HYP_LAUNCHER_PID; mpirun / torchrun: the parent)
     static long long launch_id() { const char *v = getenv("HYP_LAUNCHER_PID"); return v && *v ? atoll(v) : (long long)getppid(); }
@@ -857,20 +883,43 @@ struct Comm {
         fclose(fp);
         if (rename(tmp.c_str(), id_file.c_str()) != 0) throw Fail("cannot publish " + id_file);
     }
-    void abort_others(const std::string &why) const
+    // error() / mp_stop of the reference (src/mpi/mpi_core.f90): a rank in error takes every rank down.  A rank that fails
+    // OUTSIDE a collective it can still take part in (before the communicator exists, while reading the input, in hyp_create)
+    // leaves `abort_file` with its message; every rank runs a watcher thread that finds it within a tenth of a second, repeats
+    // the message and leaves with status 1 -- also out of ncclCommInitRank or an all-reduce that would never return.  The rank
+    // that wrote the file removes it again after a grace period (and the unique-id file with it).
+    void abort_others(const std::string &why)
     {
-        if (!on || size == 1 || rank != 0 || comm) return;
-        IdFile f; std::memset(&f, 0, sizeof f);
-        std::memcpy(f.magic, "HYPNCCL", 8); f.ppid = launch_id(); f.aborted = 1;
-        snprintf(f.msg, sizeof f.msg, "%s", why.c_str());
-        try { publish(f); } catch (...) { }
+        if (!on || size == 1 || abort_file.empty()) return;
+        const std::string tmp = abort_file + fmt(".%d.tmp", rank);
+        FILE *fp = fopen(tmp.c_str(), "w");
+        if (fp) { fprintf(fp, "rank %d: %s\n", rank, why.c_str()); fclose(fp); (void)rename(tmp.c_str(), abort_file.c_str()); }
+        leaving = true;
+        usleep(1500000);
+        unlink(abort_file.c_str());
+        if (rank == 0) unlink(id_file.c_str());
+    }
+    void watch() const
+    {
+        for (;;) {
+            usleep(100000);
+            if (leaving) return;
+            FILE *fp = fopen(abort_file.c_str(), "r");
+            if (!fp) continue;
+            char msg[512] = "";
+            if (!fgets(msg, sizeof msg, fp)) msg[0] = 0;
+            fclose(fp);
+            if (leaving) return;
+            fprintf(stderr, " ERROR: another rank stopped the run: %sAn error occurred, and the run did not complete\n", msg);
+            if (rank == 0) unlink(id_file.c_str());
+            _exit(1);
+        }
     }
     void init(const std::string &output, int device)
     {
         if (!on) return;
-        if (hipSetDevice(device) != hipSuccess) throw Fail("hipSetDevice failed");
-        const char *e = getenv("HYP_NCCL_ID_FILE");
-        id_file = e && *e ? e : output + ".ncclid";
+        (void)output;
+        if (hipSetDevice(device) != hipSuccess) throw Fail(fmt("hipSetDevice(%d) failed", device));
         IdFile f; std::memset(&f, 0, sizeof f);
         if (rank == 0) {
             std::memcpy(f.magic, "HYPNCCL", 8); f.ppid = launch_id();
@@ -886,7 +935,6 @@ struct Comm {
                 if ((double)time(nullptr) > t_end) throw Fail("rank 0 did not publish " + id_file + " (ranks must share a launcher and a file system)");
                 usleep(20000);
             }
-            if (f.aborted) throw Fail(f.msg);
         }
         if (ncclCommInitRank(&comm, size, f.id, rank) != ncclSuccess) throw Fail("ncclCommInitRank failed");
         if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) throw Fail("cannot create the collective's stream");
@@ -933,6 +981,7 @@ struct Comm {
     }
     void finalize()
     {
+        leaving = true;
         if (zero) (void)hipFree(zero);
         if (comm) ncclCommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
@@ -944,7 +993,7 @@ struct Comm {
 void lucy_iteration(hyp_handle h, Comm &c, uint64_t n_total, int it, double *se_out, hyp_iter_stats *st)
 {
     if (!c.on) { check(hyp_lucy_iteration(h, n_total, it, se_out, st), h); return; }
-    if (n_total == 0) return;
+    if (n_total == 0) { *st = hyp_iter_stats{}; return; }
     uint64_t first, n; c.range(n_total, first, n);
     c.collect(h, hyp_lucy_launch(h, first, n, it), hyp_lucy_accumulators, "lucy_flag_index", "lucy_block_doubles");
     check(hyp_lucy_finish(h, se_out, st), h);
@@ -957,6 +1006,7 @@ void final_iteration(hyp_handle h, Comm &c, uint64_t n_total, hyp_iter_stats *st
     uint64_t first, n; c.range(n_total, first, n);
     c.collect(h, hyp_final_launch(h, first, n), hyp_final_accumulators, "image_flag_index", "image_block_doubles");
     check(hyp_final_finish(h, st), h);
+    st->n_packets = n_total;
 }
 
 void raytracing_iteration(hyp_handle h, Comm &c, uint64_t n_src, uint64_t n_dust, hyp_iter_stats *st)
@@ -1196,7 +1246,7 @@ int run(const char *input, const char *output, bool overwrite, Comm &comm)
         Iteration rec;
         rec.index = it;
         std::vector<double> se(plane);
-        hyp_iter_stats st;
+        hyp_iter_stats st{};
         lucy_iteration(h, comm, (uint64_t)in.n_initial_photons, (int)it, se.data(), &st);
         if (cfg.count_photons) {
             int64_t inexact = 0;
@@ -1384,7 +1434,8 @@ int main(int argc, char **argv)
     Comm comm;
     int rc = 0;
     try {
-        comm.from_env();
+        const std::string exe = argv[0];
+        comm.from_env(pos[1], exe.size() >= 4 && exe.compare(exe.size() - 4, 4, "_mpi") == 0);
         rc = run(pos[0], pos[1], overwrite, comm);
     } catch (const std::exception &e) {
         // the reference's error(): message on stderr, the output (if any) has no date_ended

@@ -50,6 +50,13 @@ def _collective(engine, name, world_size, all_reduce, force, error=None, agree=N
         if error is not None:
             raise error
         return False
+    flag_index = engine.flag_index(name) if hasattr(engine, "flag_index") else None
+    if all_reduce is not None and flag_index is None and agree is None and world_size > 1:
+        # an adapter with its own all_reduce, no spare slot in the block and no `agree`: a rank in error could only raise
+        # locally and leave its peers in all_reduce.  Refused on EVERY rank, before anybody enters the collective (the
+        # configuration is the same everywhere, so all ranks raise this together)
+        raise ValueError("sharded %s iteration over %d ranks: an engine adapter without flag_index() needs `agree` "
+                         "(max of an int over the ranks) so that the ranks can agree on an error" % (name, world_size))
     t0 = time.perf_counter()
     err = error
     acc = None
@@ -59,7 +66,6 @@ def _collective(engine, name, world_size, all_reduce, force, error=None, agree=N
         except Exception as e:        # EngineError of this rank: tell the others before raising
             err = e
     t1 = time.perf_counter()
-    flag_index = engine.flag_index(name) if hasattr(engine, "flag_index") else None
     if flag_index is not None:
         if acc is None:
             acc = engine.zero_block(name)
@@ -70,7 +76,7 @@ def _collective(engine, name, world_size, all_reduce, force, error=None, agree=N
             if agree(1 if err is not None else 0):
                 raise err if err is not None else RuntimeError("another rank reported an engine error")
         elif err is not None:
-            raise err       # no way to tell the other ranks: they wait in all_reduce (pass `agree`)
+            raise err       # world size 1 (refused above otherwise): nobody else is waiting
     else:
         import torch
         import torch.distributed as dist

@@ -3874,15 +3874,24 @@ static int image_run(orc_state *st, uint64_t n_packets, int n_threads, uint64_t 
 
 static void final_packet_fn(const orc_state *st, uint64_t id, acc_t *acc, const void *ctx) { (void)ctx; final_packet(st, id, acc); }
 
-int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
+/* The final iteration in two halves, for the sharded runs of tests/test_distributed_cpu.py (mp_collect_images,
+ * src/mpi/mpi_routines.f90:381-459): raw flux sums of the packet ids [first_id, first_id + n_local) into zeroed cubes, then --
+ * after the cubes and the emitted energy have been summed over the ranks -- the scaling of image_type.f90:136-151. */
+int orc_final_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int n_threads, orc_iter_stats *stats)
 {
     precompute_jnu_var(st); /* iter_final.f90:99 */
     if (st->cfg.mrw && prepare_mrw(st)) return 1;   /* iter_final.f90:93-96 */
     orc_iter_stats tot;
-    if (image_run(st, n_packets, n_threads, g_final_first_id, final_packet_fn, NULL, 1, &tot)) return 1;
+    if (image_run(st, n_local, n_threads, first_id, final_packet_fn, NULL, 1, &tot)) return 1;
+    if (stats) *stats = tot;
+    return 0;
+}
+
+int orc_final_scale(orc_state *st, double energy_current)
+{
     /* peeled_images_adjust_scale(energy_total/energy_current): image_type.f90:136-151 */
-    if (tot.energy_current > 0.0) {
-        double scale = st->energy_total / tot.energy_current;
+    if (energy_current > 0.0) {
+        double scale = st->energy_total / energy_current;
         for (int g = 0; g < st->n_groups; g++) {
             peeled_t *pg = &st->peeled[g];
             /* binned_images_adjust_scale :34-38: x n_theta x n_phi (flux per bin -> 4 pi normalisation of the peeled images) */
@@ -3891,6 +3900,14 @@ int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_it
             if (pg->img) for (size_t k = 0; k < pg->img_size; k++) { pg->img[k] *= sc; pg->img2[k] *= sc * sc; }
         }
     }
+    return 0;
+}
+
+int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads, orc_iter_stats *stats)
+{
+    orc_iter_stats tot;
+    if (orc_final_accumulate(st, g_final_first_id, n_packets, n_threads, &tot)) return 1;
+    orc_final_scale(st, tot.energy_current);
     if (stats) *stats = tot;
     return 0;
 }

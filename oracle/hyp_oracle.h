@@ -292,6 +292,10 @@ int orc_raytracing_accumulate(orc_state *st, int which, uint64_t first_id, uint6
 /* writable views of the cubes (tests emulate the all-reduce of the image block) */
 double *orc_peeled_sed_rw(orc_state *st, int g);
 double *orc_peeled_img_rw(orc_state *st, int g);
+/* the two halves of orc_final_iteration for sharded runs: unscaled sums of an id range into zeroed cubes; the scaling
+ * energy_total / energy_current (image_type.f90:136-151) once cubes and emitted energy have been summed over the ranks */
+int orc_final_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int n_threads, orc_iter_stats *stats);
+int orc_final_scale(orc_state *st, double energy_current);
 int orc_final_iteration(orc_state *st, uint64_t n_packets, int n_threads,
                         orc_iter_stats *stats);
 int orc_peeled_n_orig(const orc_state *st, int group);

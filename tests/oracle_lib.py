@@ -54,6 +54,8 @@ def lib():
         L.orc_pda_last_cells.argtypes = [C.c_void_p]
         L.orc_convergence_value.argtypes = [C.c_void_p, _dp, C.c_double, _dp]
         L.orc_final_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_final_accumulate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
+        L.orc_final_scale.argtypes = [C.c_void_p, C.c_double]
         L.orc_raytracing_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
         L.orc_raytracing_accumulate.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(IterStats)]
         L.orc_mono_iteration.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(IterStats)]
@@ -241,6 +243,17 @@ class Oracle:
         if rc != 0:
             raise OracleError(self._err())
         return self._peeled(), st.as_dict()
+
+    def final_accumulate(self, first_id, n_local, n_threads=0):
+        """Unscaled flux sums of the packet ids [first_id, first_id + n_local) into zeroed cubes (see peeled_views)."""
+        st = IterStats()
+        rc = lib().orc_final_accumulate(self.h, int(first_id), int(n_local), n_threads, C.byref(st))
+        if rc != 0:
+            raise OracleError(self._err())
+        return st.as_dict()
+
+    def final_scale(self, energy_current):
+        lib().orc_final_scale(self.h, float(energy_current))
 
     def _peeled(self):
         out = []

@@ -53,12 +53,48 @@ class OracleAsEngine:
             off += v.size
         return self.o._peeled(), {"killed_geo": 0, "killed_int": 0}
 
+    # polychromatic final iteration (mp_collect_images, mpi_routines.f90:381-459): unscaled cubes + sums of squares + the tail
+    def final_launch(self, first, n_local):
+        self.fst = self.o.final_accumulate(first, n_local, n_threads=2)
+
+    def final_accumulators_tensor(self):
+        from oracle_lib import lib
+        import ctypes as C
+        self.views = []
+        for g, v in enumerate(self.o.peeled_views()):
+            for k, fn2 in (("sed", lib().orc_peeled_sed2), ("img", lib().orc_peeled_img2)):
+                if k in v:
+                    self.views += [v[k], np.ctypeslib.as_array(fn2(self.o.h, g), shape=(v[k].size,))]
+        tail = np.array([self.fst[k] for k in ("energy_current", "killed_geo", "killed_int", "crossings", "interactions")], dtype=np.float64)
+        self.blk = torch.from_numpy(np.concatenate(self.views + [tail, np.zeros(3)]))
+        return self.blk
+
+    def final_finish(self):
+        blk = self.blk.numpy()
+        off = 0
+        for v in self.views:
+            v[:] = blk[off:off + v.size]
+            off += v.size
+        tail = blk[off:off + 8]
+        if tail[5] != 0:
+            raise RuntimeError("another rank reported an engine error")
+        self.o.final_scale(tail[0])
+        return self.o._peeled(), {"energy_current": float(tail[0]), "killed_geo": int(tail[1]), "killed_int": int(tail[2]),
+                                  "crossings": int(tail[3]), "interactions": int(tail[4])}
+
     # monochromatic final iteration: same image block
     def mono_launch(self, which, inu, first, n_local, n_total, zero_first=False):
         self.o.mono_accumulate(which, inu, first, n_local, n_total, zero_first, n_threads=2)
 
     mono_accumulators_tensor = raytracing_accumulators_tensor
     mono_finish = raytracing_finish
+
+
+def _agree(flag):
+    """max of an int over the ranks: how an adapter without a spare slot in its block lets the ranks agree on an error"""
+    t = torch.tensor([int(flag)], dtype=torch.int32)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
 
 
 def _free_port():
@@ -77,7 +113,7 @@ def _worker(rank, world, port, which, n_total, out_dir):
     eng = OracleAsEngine(prob)
     res = []
     for it in (1, 2):
-        se, st = lucy_iteration_sharded(eng, n_total, it, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        se, st = lucy_iteration_sharded(eng, n_total, it, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), agree=_agree)
         res.append(se)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), se=np.array(res), crossings=st["crossings"], energy=st["energy_current"],
              n=st["n_packets"])
@@ -110,7 +146,7 @@ def _ray_worker(rank, world, port, out_dir):
     eng = OracleAsEngine(prob)
     eng.o.lucy_iteration(3000, 1, n_threads=2)
     eng.o.final_iteration(2000, n_threads=2)          # every rank holds the same final cubes; rank 0's are kept
-    res, st = raytracing_iteration_sharded(eng, 1501, 2001, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    res, st = raytracing_iteration_sharded(eng, 1501, 2001, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), agree=_agree)
     np.savez(os.path.join(out_dir, "ray%d.npz" % rank), sed=res[1]["sed"], img=res[0]["img"])
     dist.destroy_process_group()
 
@@ -137,7 +173,7 @@ def _mono_worker(rank, world, port, out_dir):
     eng = OracleAsEngine(prob)
     eng.o.lucy_iteration(2000, 1, n_threads=2)
     nf = prob.config.frequencies.size
-    res, st = mono_iteration_sharded(eng, 301, 201, nf, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+    res, st = mono_iteration_sharded(eng, 301, 201, nf, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM), agree=_agree)
     np.savez(os.path.join(out_dir, "mono%d.npz" % rank), sed=res[0]["sed"])
     dist.destroy_process_group()
 
@@ -213,3 +249,88 @@ def test_error_on_one_rank_reaches_every_rank_through_the_one_collective(tmp_pat
     r1 = (tmp_path / "flag1.txt").read_text().split("|")
     assert r0 == ["1", "another rank reported an engine error"]
     assert r1[0] == "1" and "outside the range defined" in r1[1]
+
+
+# --- the polychromatic imaging iteration over two ranks ----------------------------------------------------------------------
+
+class FlaggedImagingEngine(OracleAsEngine):
+    """the image block with the engine's spare tail slot; `fail` makes this rank's launch raise"""
+
+    def __init__(self, prob, fail):
+        super().__init__(prob)
+        self.fail = fail
+
+    def final_launch(self, first, n_local):
+        if self.fail:
+            raise RuntimeError("photon was not emitted inside a cell")
+        super().final_launch(first, n_local)
+
+    def flag_index(self, name):
+        return self._n_block() - 3
+
+    def zero_block(self, name):
+        self.views = []
+        self.blk = torch.zeros(self._n_block(), dtype=torch.float64)
+        return self.blk
+
+    def _n_block(self):
+        return 2 * sum(v[k].size for v in self.o.peeled_views() for k in ("sed", "img") if k in v) + 8
+
+
+def _final_worker(rank, world, port, out_dir, fail_rank):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hyperion_amd.distributed import final_iteration_sharded
+    prob = golden_problem("car_peeloff.False.npz")[0]
+    eng = FlaggedImagingEngine(prob, fail=(rank == fail_rank))
+    eng.o.lucy_iteration(3000, 1, n_threads=2)
+    msg = "no error"
+    try:
+        res, st = final_iteration_sharded(eng, 4001, rank, world, all_reduce=lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        np.savez(os.path.join(out_dir, "final%d.npz" % rank), sed=res[1]["sed"], sed2=res[1]["sed2"], img=res[0]["img"], crossings=st["crossings"],
+                 energy=st["energy_current"], n=st["n_packets"])
+    except RuntimeError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, "final%d.txt" % rank), "w") as f:
+        f.write(msg)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_imaging_iteration_equals_single_process(tmp_path):
+    """do_final over two gloo ranks (hyperion_amd.distributed.final_iteration_sharded): odd packet count, ONE all-reduce of
+    [cubes | sums of squares | tail], scaling by the summed emitted energy on every rank."""
+    mp.spawn(_final_worker, args=(2, _free_port(), str(tmp_path), -1), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "final0.npz"), np.load(tmp_path / "final1.npz")
+    for k in ("sed", "sed2", "img"):
+        np.testing.assert_array_equal(r0[k], r1[k])
+    assert int(r0["n"]) == 4001
+    prob = golden_problem("car_peeloff.False.npz")[0]
+    o = Oracle(prob)
+    o.lucy_iteration(3000, 1, n_threads=2)
+    res, st = o.final_iteration(4001, n_threads=2)
+    o.close()
+    assert res[1]["sed"].max() > 0 and res[0]["img"].max() > 0
+    np.testing.assert_allclose(r0["sed"], res[1]["sed"], rtol=1e-12, atol=1e-14 * res[1]["sed"].max())
+    np.testing.assert_allclose(r0["sed2"], res[1]["sed2"], rtol=1e-12, atol=1e-14 * res[1]["sed2"].max())
+    np.testing.assert_allclose(r0["img"], res[0]["img"], rtol=1e-12, atol=1e-14 * res[0]["img"].max())
+    assert int(r0["crossings"]) == st["crossings"]
+    assert float(r0["energy"]) == pytest.approx(st["energy_current"], rel=1e-13)
+
+
+def test_error_in_the_imaging_iteration_of_one_rank_reaches_every_rank(tmp_path):
+    mp.spawn(_final_worker, args=(2, _free_port(), str(tmp_path), 0), nprocs=2, join=True)
+    assert "not emitted inside a cell" in (tmp_path / "final0.txt").read_text()
+    assert (tmp_path / "final1.txt").read_text() == "another rank reported an engine error"
+
+
+def test_an_adapter_that_cannot_report_errors_is_refused_at_world_size_two():
+    """all_reduce given, no flag_index, no agree: every rank raises before anybody enters the collective"""
+    from hyperion_amd.distributed import lucy_iteration_sharded as lis
+
+    class Bare:
+        def lucy_launch(self, *a):
+            pass
+
+    with pytest.raises(ValueError, match="agree"):
+        lis(Bare(), 100, 1, rank=0, world_size=2, all_reduce=lambda t: None)

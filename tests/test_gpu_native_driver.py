@@ -142,3 +142,31 @@ def test_mpi_rank_refusing_to_start_tells_the_launcher(tmp_path):
     env = dict(os.environ, RANK="0", WORLD_SIZE="1")
     r = subprocess.run([os.path.join(BIN, "hyperion_car_mpi"), os.path.join(GOLDEN, "car_peeloff.False.rtin"), out], capture_output=True, text=True, env=env)
     assert r.returncode == 1 and "already exists" in r.stderr and "did not complete" in r.stderr
+
+
+def test_a_rank_that_cannot_start_stops_its_peers_instead_of_leaving_them_in_the_rendezvous(tmp_path):
+    """--ranks 2 on a box with ONE GPU: rank 1's hipSetDevice(1) fails before any communicator exists while rank 0 already
+    waits in ncclCommInitRank for it.  Rank 1 leaves the launch's abort file, rank 0's watcher finds it and leaves with the
+    reference's failure convention: status 1 within seconds instead of a hang, and no id / abort file stays behind."""
+    import time
+    code = "import torch, sys; sys.exit(0 if torch.cuda.device_count() == 1 else 3)"
+    if subprocess.run(["python", "-c", code]).returncode != 0:
+        pytest.skip("needs exactly one visible GPU")
+    out = str(tmp_path / "two.rtout")
+    t0 = time.time()
+    r = subprocess.run([os.path.join(BIN, "hyperion_car_mpi"), "-f", "--ranks", "2", os.path.join(GOLDEN, "car_peeloff.False.rtin"), out],
+                       capture_output=True, text=True, timeout=280, cwd=str(tmp_path))
+    assert r.returncode == 1, r.stdout + r.stderr
+    assert "hipSetDevice(1) failed" in r.stderr and "did not complete" in r.stderr
+    assert time.time() - t0 < 120
+    time.sleep(2.0)
+    assert [f for f in os.listdir(tmp_path) if "ncclid" in f or "abort" in f or f.endswith(".tmp")] == []
+
+
+def test_batch_system_variables_do_not_make_a_plain_executable_a_rank(tmp_path):
+    """`hyperion_oct` inside an sbatch allocation with --ntasks=4 is one plain process: it runs to the end alone."""
+    env = dict(os.environ, SLURM_PROCID="0", SLURM_NTASKS="4", SLURM_LOCALID="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = str(tmp_path / "slurm.rtout")
+    r = subprocess.run([os.path.join(BIN, "hyperion_oct"), "-f", os.path.join(GOLDEN, "native_oct.rtin"), out], capture_output=True, text=True, timeout=280, env=env)
+    assert r.returncode == 0 and "[mpi]" not in r.stdout, r.stdout + r.stderr

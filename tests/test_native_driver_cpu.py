@@ -130,3 +130,32 @@ def test_two_independent_marshallers_hand_over_the_same_problem(name):
             "print(' '.join('%%016x' %% v for v in out))\n") % (ROOT, os.path.join(GOLDEN, name))
     py = subprocess.check_output([CONDA, "-W", "ignore", "-c", code], text=True).split()
     assert py == native, dict(zip(("grid", "dust", "sources", "config+images"), zip(py, native)))
+
+
+def test_a_rank_that_fails_early_takes_the_launch_down_and_leaves_no_files(tmp_path):
+    """error() / mp_stop of the reference: with --ranks 2 rank 0 refuses an existing output before any communicator exists.
+    Its peer must not be left waiting for the unique-id file (it is told through the launch's abort file, or fails on its own
+    without a GPU), the launcher's status is 1, and neither the abort file, the id file nor a stray '.tmp' survives."""
+    import time
+    out = str(tmp_path / "x.rtout")
+    open(out, "w").write("precious")
+    t0 = time.time()
+    r = subprocess.run([DRIVER, "--ranks", "2", os.path.join(GOLDEN, "native_oct.rtin"), out], capture_output=True, text=True, timeout=120, cwd=str(tmp_path))
+    assert r.returncode == 1 and "already exists" in r.stderr
+    assert time.time() - t0 < 60
+    assert open(out).read() == "precious"
+    time.sleep(2.0)          # the rank that wrote the abort file removes it after its grace period
+    left = sorted(os.listdir(tmp_path))
+    assert left == ["x.rtout"], left
+
+
+def test_batch_system_variables_do_not_make_a_plain_executable_a_rank(tmp_path):
+    """`hyperion_oct` inside an sbatch allocation (SLURM_PROCID / SLURM_NTASKS set for every process of the job) is ONE
+    process: it must not wait for peers.  Without a GPU it stops at hyp_create like any single run, at once."""
+    if _gpu():
+        pytest.skip("the GPU suite runs the same check to completion (tests/test_gpu_native_driver.py)")
+    env = dict(os.environ, SLURM_PROCID="0", SLURM_NTASKS="4", SLURM_LOCALID="0")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = str(tmp_path / "y.rtout")
+    r = subprocess.run([os.path.join(BIN, "hyperion_oct"), os.path.join(GOLDEN, "native_oct.rtin"), out], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 1 and "no HIP device available" in r.stderr and "[mpi]" not in r.stdout

@@ -10,7 +10,7 @@ VDIR = os.path.join(ROOT, "build", "variants")
 
 
 def build(specs):
-    """Each variant: hyp_engine.hip (tiled kernels, one species) + one geometry unit (env GEOM, default Cartesian)."""
+    """Each variant: hyp_engine.hip + the units of ONE geometry (env GEOM, default Cartesian) for ONE species (env ND, default 1)."""
     from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc
     os.makedirs(VDIR, exist_ok=True)
     procs = []
@@ -19,9 +19,11 @@ def build(specs):
         out = os.path.join(VDIR, name + ".so")
         objs = []
         geom = int(os.environ.get("GEOM", "0"))      # GEOM_* of the one geometry unit linked (0 Cartesian, 1 octree, ...)
-        for unit, src, defs in (("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom]), ("geom", "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom])):
+        from hyperion_amd.build import PARTS
+        geom_units = [(part, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom, "-DHYP_PART=%d" % k]) for part, k in PARTS.items()]
+        for unit, src, defs in [("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom])] + geom_units:
             obj = os.path.join(VDIR, "%s_%s.o" % (name, unit))
-            cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-DHYP_ONLY_ND1", "-c", src, "-o", obj,
+            cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-DHYP_ONLY_ND1" if os.environ.get("ND", "1") == "1" else "-DHYP_ONLY_ND=" + os.environ["ND"], "-c", src, "-o", obj,
                                                                     "-Rpass-analysis=kernel-resource-usage"]
             procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
             objs.append(obj)
