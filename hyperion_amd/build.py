@@ -76,6 +76,11 @@ def is_stale(objdir=OBJDIR):
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
+    if not os.path.isdir(objdir) or not any(f.endswith(".o") for f in os.listdir(objdir)):
+        # a snapshot without the objects (build/obj does not travel to the GPU box): the library against its sources
+        deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hip"))]
+        deps.append(os.path.join(os.path.dirname(HERE), "include", "hyperion_amd.h"))
+        return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
     for name, src, defs in units():
         obj = os.path.join(objdir, name + ".o")
         if unit_is_stale(obj, _unit_cmd(src, defs, obj, ())) or os.path.getmtime(obj) > t:

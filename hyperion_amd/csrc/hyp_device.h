@@ -96,10 +96,34 @@ struct DPeeled {
 // (`loc` is used by the cluster-tiled schedule, hyp_vtile.h: index of the neighbour inside the cluster whose copy of the record this
 // is, -1 for a face of the box, <= -2 where the neighbour belongs to another cluster: -(slot in the cluster's adjacency list) - 2)
 struct alignas(32) VorWall { double x, y, z; int nb, loc; };
-// cluster-tiled Voronoi schedule: one cell of a cluster = its site and its range in the cluster's wall records
-struct alignas(32) VtHdr { double x, y, z; int k0, k1; };
-#define VT_MAX_ADJ 64           // adjacent clusters listed per cluster (walls to further ones: VT_FAR)
-#define VT_FAR (-(VT_MAX_ADJ) - 2)
+// Cluster-tiled Voronoi schedule (hyp_vtile.h).  A cluster's tables are one contiguous blob that a walk workgroup copies
+// into LDS with 16-byte loads; sections, each padded to 16 bytes, in this order:
+//   sx, sy, sz   [n_site] double   sites of the cluster's own cells (index < n_own) and of the cells of OTHER clusters that
+//                                  share a wall with one of them ("ghosts", index >= n_own): the exact wall test needs them
+//   wrec         [n_wall] float4   per wall of an own cell, in the cell's CSR order: (n.x, n.y, n.z, +-|n|) x scale in FP32,
+//                                  n = neighbour's site - own site (a face of the box: the site's mirror image in it, and
+//                                  the sign bit of the fourth component set) --
+//                                  the FP32 filter of the wall search
+//   wlink        [n_wall] uint32   neighbour's index in the site table (bits 0-15) | position of THIS cell in the neighbour's
+//                                  CSR list (bits 16-23; 255: none) | 1 + face for a face of the box (bits 24-27)
+//   hdr          [n_own]  uint32   first wall record of the cell (bits 0-19) | number of walls (bits 20-27) | VT_HDR_EXACT
+//   members      [n_own]  int      cell ids of the own cells
+//   gcell, gpacked, gadj [n_site - n_own] int   per ghost: cell id, its vt_cluster word, slot of its cluster in vt_adj (VT_MAX_ADJ: none)
+struct VtInfo {
+    int blob16;              // offset of the blob in units of 16 bytes
+    int n_own, n_site, n_wall;
+    int cell0;               // first entry of the cluster in vt_members
+    int ghost0;              // first entry of the cluster in vt_ghost
+    float scale;             // power of two that brings the cluster's wall normals to order one (FP32 filter only)
+    float abs_eps;           // 2^-49 x largest |coordinate| of the cluster x scale: the reference's own rounding of m - r
+};
+#define VT_HDR_EXACT 0x10000000u    // a neighbour listed twice, or more than 64 walls: this cell's search skips the filter
+#define VT_LINK_LOC(l) ((int)((l) & 0xffffu))
+#define VT_LINK_BACK(l) ((int)(((l) >> 16) & 0xffu))
+#define VT_LINK_BOX(l) ((int)(((l) >> 24) & 0xfu))       // 0: a neighbouring cell; 1 + face otherwise
+#define VT_NO_BACK 255
+struct VtGhost { int cell, adj; };   // a ghost's cell id and the slot of its cluster in this cluster's adjacency list (VT_MAX_ADJ: none)
+#define VT_MAX_ADJ 64           // adjacent clusters listed per cluster (packets handed to further ones are counted in global memory)
 
 struct alignas(16) OctCell {
     double x, y, z;
@@ -204,13 +228,13 @@ struct DProblem {
     const double *vor_bb;                 // [n_cells][6] bb_min, bb_max of the cells (random_position_cell) or null
     double vor_box[6];
     int vor_g, pad4;
-    // cluster-tiled schedule (hyp_vtile.h): cells grouped into spatially compact clusters whose wall records fit in LDS
-    const int *vt_cluster;                // [n_cells] cluster << 8 | index of the cell in its cluster
-    const int *vt_cell_off, *vt_wall_off; // [n_clusters + 1] first cell / wall record of each cluster
+    // cluster-tiled schedule (hyp_vtile.h): cells grouped into spatially compact clusters whose tables fit in LDS
+    const int *vt_cluster;                // [n_cells] cluster << 16 | index of the cell in its cluster
+    const VtInfo *vt_info;                // [n_clusters]
+    const float4 *vt_blob;                // the clusters' tables (VtInfo)
     const int *vt_members;                // [n_cells] cell ids, cluster by cluster
-    const VtHdr *vt_hdr;                  // [n_cells] cluster by cluster
-    const VorWall *vt_walls;              // wall records, cluster by cluster, `loc` filled in
-    const int *vt_adj;                    // [n_clusters][VT_MAX_ADJ] adjacent clusters (-1: unused)
+    const VtGhost *vt_ghost;              // ghosts of every cluster (VtInfo::ghost0)
+    const int *vt_adj;                    // [n_clusters][VT_MAX_ADJ] adjacent clusters (unused slots: the cluster itself)
     // cluster-tiled octree schedule (hyp_otile.h): clusters = runs of sibling subtrees (contiguous cell ids) whose records fit in LDS
     const int *ot_cluster;                // [n_cells] cluster of the cell (-1: a cell above the clusters, never a leaf)
     const int *ot_c0, *ot_nc;             // [n_clusters] first cell id and number of cells

@@ -246,10 +246,11 @@ struct hyp_engine {
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
-    int vt_lds_kb = 78;             // option: LDS budget of one walk workgroup in KB (78: two workgroups per CU)
-    int vt_clusters = 0, vt_max_cells = 0, vt_max_walls = 0, vt_built_for = -1;
-    int *d_vt_cluster = nullptr, *d_vt_cell_off = nullptr, *d_vt_wall_off = nullptr, *d_vt_members = nullptr, *d_vt_adj = nullptr;
-    VtHdr *d_vt_hdr = nullptr; VorWall *d_vt_walls = nullptr;
+    int vt_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU; 78: room for two of 512 threads)
+    int vt_clusters = 0, vt_max_cells = 0, vt_built_for = -1;
+    size_t vt_max_lds = 0;          // LDS of the largest cluster: tables + densities + accumulators
+    int *d_vt_cluster = nullptr, *d_vt_members = nullptr, *d_vt_adj = nullptr;
+    VtInfo *d_vt_info = nullptr; float4 *d_vt_blob = nullptr; VtGhost *d_vt_ghost = nullptr;
     std::vector<double> h_vor_sites; std::vector<int> h_vor_idx, h_vor_neigh;     // host copies for the cluster builder
     // cluster-tiled octree schedule (hyp_otile.h): tables built by build_oct_clusters()
     int ot_cells = 0;               // option: most cells per cluster (0: as many as the LDS budget allows)
@@ -450,8 +451,8 @@ size_t oct_cluster_lds(size_t n, size_t k, int nd) { return (sizeof(OctCell) + s
 // LDS of one walk workgroup
 size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool ring)
 {
-    if (h->hp.grid_type == 3)       // cluster: cell headers + wall records + densities + accumulators
-        return sizeof(VtHdr) * (size_t)T.bx + sizeof(VorWall) * (size_t)T.by + sizeof(double) * 2 * (size_t)T.bx * K.nd;
+    if (h->hp.grid_type == 3)       // cluster: its tables (VtInfo) + densities + accumulators
+        return h->vt_max_lds;
     if (h->hp.grid_type == 4)       // slab: densities + accumulators + walls + goto slice
         return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
@@ -582,6 +583,9 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 d[3], d[4], (double)d[5] / d[4], (double)d[1] / d[0]);
         fprintf(stderr, "tile stats: service phases %llu (%.2f per outer loop), wave clocks in the service phase %.3f of the loop's (%.0f clocks per service phase, %.0f per outer loop)\n",
                 d[7], (double)d[7] / d[0], (double)d[6] / d[8], (double)d[6] / d[7], (double)d[8] / d[0]);
+        if (d[10]) fprintf(stderr, "tile stats: service phase = check + write-back %.3f (%.1f lanes), claim %.3f (%.1f lanes) of its clocks\n", (double)d[10] / d[6], (double)d[12] / d[7],
+                           (double)d[11] / d[6], (double)d[13] / d[7]);
+        fprintf(stderr, "tile stats: wave clocks waiting at the end of the task for the workgroup's last wave %.3f of the loop's\n", (double)d[9] / d[8]);
     }
 #endif
     return 0;
@@ -596,7 +600,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     TileGeom T;
     memset(&T, 0, sizeof T);
     if (P.grid_type == 3) {
-        T.bx = h->vt_max_cells; T.by = h->vt_max_walls; T.bz = 1;
+        T.bx = h->vt_max_cells; T.by = 1; T.bz = 1;
         T.nbx = T.n_bricks = h->vt_clusters; T.nby = T.nbz = 1;
     } else if (P.grid_type == 4) {
         T.bx = h->at_max_cells; T.by = h->at_max_go; T.bz = h->at_max_walls;
@@ -616,7 +620,7 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
-    T.task_size = h->tile_task <= 0 ? (P.grid_type == 3 ? 4096 : 8192) : h->tile_task < 256 ? 256 : h->tile_task;
+    T.task_size = h->tile_task <= 0 ? 8192 : h->tile_task < 256 ? 256 : h->tile_task;
     T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare) ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
@@ -798,8 +802,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed); free_dev(h->d_vor_walls);
     free_dev(h->d_mask_map);
-    free_dev(h->d_vt_cluster); free_dev(h->d_vt_cell_off); free_dev(h->d_vt_wall_off); free_dev(h->d_vt_members); free_dev(h->d_vt_adj);
-    free_dev(h->d_vt_hdr); free_dev(h->d_vt_walls);
+    free_dev(h->d_vt_cluster); free_dev(h->d_vt_info); free_dev(h->d_vt_blob); free_dev(h->d_vt_members); free_dev(h->d_vt_adj); free_dev(h->d_vt_ghost);
     free_dev(h->d_amr_grids); free_dev(h->d_amr_go); free_dev(h->d_amr_walls); free_dev(h->d_amr_cell_grid);
     free_dev(h->d_density); free_dev(h->d_specific_energy); free_dev(h->d_additional);
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
@@ -1991,9 +1994,14 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 }
 
 // Clusters of Voronoi cells for the tiled schedule (hyp_vtile.h): recursive coordinate bisection of the sites into groups
-// of equal cell count whose wall records, headers, densities and accumulators fit the LDS share of one workgroup (two
-// workgroups per CU); per cluster the gathered wall records with the neighbour's index inside the cluster, or the slot of
-// the neighbour's cluster in the adjacency list.
+// of equal cell count whose tables (VtInfo in hyp_device.h: sites of the cluster's cells and of the cells across its
+// boundary, one FP32 record and one link word per wall, one header word per cell), densities and accumulators fit the LDS
+// budget of one walk workgroup.
+static size_t vt_blob16(size_t n_own, size_t n_site, size_t n_wall)
+{
+    return 3 * ((n_site + 1) / 2) + n_wall + (n_wall + 3) / 4 + 2 * ((n_own + 3) / 4) + 3 * ((n_site - n_own + 3) / 4);
+}
+
 static int build_vor_clusters(hyp_handle h)
 {
     const int nd = h->n_dust;
@@ -2002,10 +2010,16 @@ static int build_vor_clusters(hyp_handle h)
     const double *S = h->h_vor_sites.data();
     const int *idx = h->h_vor_idx.data(), *nei = h->h_vor_neigh.data();
     if (h->h_vor_sites.size() != 3 * nc) return h->set_error("voronoi tables missing for the cluster builder");
+    for (size_t i = 0; i < nc; i++) if (idx[i + 1] - idx[i] > 255) return h->set_error("a voronoi cell has more than 255 walls: no cluster-tiled schedule");
     const size_t budget = (size_t)h->vt_lds_kb * 1024;
-    std::vector<int> perm(nc), cl_of(nc), cell_off, wall_off;
-    int n_cl = 0, max_cells = 0, max_walls = 0;
-    double target = h->vt_cells > 0 ? (double)h->vt_cells : 250.0;
+    std::vector<int> perm(nc), cl_of(nc), cell_off;
+    std::vector<int> local(nc, -1);          // index of a cell in the site table of the cluster being laid out (-1: not in it)
+    struct Layout { std::vector<int> ghosts; size_t n_wall = 0; };
+    std::vector<Layout> lay;
+    int n_cl = 0;
+    size_t max_lds = 0;
+    // sites + per wall 20 bytes + header, densities, accumulators, and about as many ghost sites as own cells at these sizes
+    double target = h->vt_cells > 0 ? (double)h->vt_cells : std::max(8.0, (double)budget / (24.0 * 2 + 20.0 * 16.5 + 4 + 16.0 * nd));
     for (int attempt = 0;; attempt++) {
         n_cl = (int)std::max<double>(1.0, std::ceil((double)nc / target));
         if (n_cl > HYP_TILE_MAX_BRICKS) return h->set_error("voronoi grid has too many cells for the cluster-tiled schedule");
@@ -2030,72 +2044,147 @@ static int build_vor_clusters(hyp_handle h)
             stack.push_back({p.lo + n1, p.n - n1, p.c0 + k1, p.k - k1});
         }
         for (int c = 0; c < n_cl; c++) cell_off[c + 1] += cell_off[c];
-        wall_off.assign(n_cl + 1, 0);
-        for (size_t i = 0; i < nc; i++) wall_off[cl_of[i] + 1] += idx[i + 1] - idx[i];
-        max_cells = max_walls = 0;
-        for (int c = 0; c < n_cl; c++) {
-            max_cells = std::max(max_cells, cell_off[c + 1] - cell_off[c]);
-            max_walls = std::max(max_walls, wall_off[c + 1]);
-            wall_off[c + 1] += wall_off[c];
+        // ghosts (cells of other clusters across a wall, each once, in the order met) and the LDS each cluster needs
+        lay.assign(n_cl, Layout());
+        std::vector<int> seen(nc, -1);
+        for (size_t i = 0; i < nc; i++) {
+            Layout &Lc = lay[cl_of[i]];
+            Lc.n_wall += (size_t)(idx[i + 1] - idx[i]);
+            for (int k = idx[i]; k < idx[i + 1]; k++) {
+                const int nb = nei[k];
+                if (nb >= 0 && cl_of[nb] != cl_of[i] && seen[nb] != cl_of[i]) { seen[nb] = cl_of[i]; Lc.ghosts.push_back(nb); }
+            }
         }
-        const size_t lds = sizeof(VtHdr) * (size_t)max_cells + sizeof(VorWall) * (size_t)max_walls + sizeof(double) * 2 * (size_t)max_cells * nd;
-        if (max_cells <= 256 && lds <= budget) break;
-        if (h->vt_cells > 0 && max_cells <= 256 && lds <= std::min(2 * budget, (size_t)156 * 1024)) break;       // a forced size may take a whole CU's LDS
-        if (h->vt_cells > 0 || attempt > 40) return h->set_error("voronoi clusters do not fit in LDS");
-        target *= 0.9;
+        max_lds = 0;
+        bool fits = true;
+        for (int c = 0; c < n_cl; c++) {
+            const size_t n_own = (size_t)(cell_off[c + 1] - cell_off[c]), n_site = n_own + lay[c].ghosts.size();
+            const size_t lds = 16 * vt_blob16(n_own, n_site, lay[c].n_wall) + sizeof(double) * 2 * n_own * nd;
+            max_lds = std::max(max_lds, lds);
+            if (n_site > 65535 || lay[c].n_wall >= (1u << 20)) fits = false;
+        }
+        if (fits && max_lds <= budget) break;
+        if (fits && h->vt_cells > 0 && max_lds <= (size_t)156 * 1024) break;       // a forced size may take a whole CU's LDS
+        if (h->vt_cells > 0 || attempt > 60) return h->set_error("voronoi clusters do not fit in LDS");
+        target *= std::min(0.95, 0.98 * (double)budget / (double)max_lds);
+        if (target < 1.0) target = 1.0;
     }
     // members of each cluster in ascending cell order
     std::vector<int> members(nc), cursor(cell_off.begin(), cell_off.end() - 1), packed(nc);
     for (size_t i = 0; i < nc; i++) {
         const int c = cl_of[i], l = cursor[c]++ - cell_off[c];
         members[cell_off[c] + l] = (int)i;
-        packed[i] = (c << 8) | l;
+        packed[i] = (c << 16) | l;
     }
-    std::vector<VtHdr> hdr(nc);
-    std::vector<VorWall> walls((size_t)wall_off[n_cl] ? (size_t)wall_off[n_cl] : 1);
+    std::vector<VtInfo> info(n_cl);
+    std::vector<VtGhost> ghosts;
     std::vector<int> adj((size_t)n_cl * VT_MAX_ADJ, -1);
-    size_t n_far = 0;
+    size_t total16 = 0;
     for (int c = 0; c < n_cl; c++) {
-        int kw = 0;
+        VtInfo &I = info[c];
+        I.n_own = cell_off[c + 1] - cell_off[c]; I.n_site = I.n_own + (int)lay[c].ghosts.size(); I.n_wall = (int)lay[c].n_wall;
+        I.cell0 = cell_off[c]; I.ghost0 = (int)ghosts.size();
+        if (total16 > 0x7fffffffull) return h->set_error("voronoi cluster tables too large");
+        I.blob16 = (int)total16;
+        total16 += vt_blob16((size_t)I.n_own, (size_t)I.n_site, (size_t)I.n_wall);
         int *ad = adj.data() + (size_t)c * VT_MAX_ADJ;
-        for (int j = cell_off[c]; j < cell_off[c + 1]; j++) {
-            const int cell = members[j];
-            VtHdr &H = hdr[j];
-            H.x = S[3 * (size_t)cell]; H.y = S[3 * (size_t)cell + 1]; H.z = S[3 * (size_t)cell + 2];
-            H.k0 = kw;
-            for (int k = idx[cell]; k < idx[cell + 1]; k++) {
-                VorWall &w = walls[(size_t)wall_off[c] + kw++];
-                const int nb = nei[k];
-                w.nb = nb; w.x = w.y = w.z = 0.0; w.loc = -1;
-                if (nb < 0) continue;
-                w.x = S[3 * (size_t)nb]; w.y = S[3 * (size_t)nb + 1]; w.z = S[3 * (size_t)nb + 2];
-                const int cn = cl_of[nb];
-                if (cn == c) { w.loc = packed[nb] & 255; continue; }
-                int s = 0;
-                while (s < VT_MAX_ADJ && ad[s] != cn && ad[s] != -1) s++;
-                if (s < VT_MAX_ADJ) { ad[s] = cn; w.loc = -s - 2; }
-                else { w.loc = VT_FAR; n_far++; }
-            }
-            H.k1 = kw;
+        for (int nb : lay[c].ghosts) {
+            const int cn = cl_of[nb];
+            int s = 0;
+            while (s < VT_MAX_ADJ && ad[s] != cn && ad[s] != -1) s++;
+            if (s < VT_MAX_ADJ) ad[s] = cn;
+            ghosts.push_back(VtGhost{nb, s});
         }
+    }
+    std::vector<float4> blob(total16 ? total16 : 1, make_float4(0.f, 0.f, 0.f, 0.f));
+    const double *B = h->hp.vor_box;
+    for (int c = 0; c < n_cl; c++) {
+        VtInfo &I = info[c];
+        for (int j = 0; j < I.n_own; j++) local[members[I.cell0 + j]] = j;
+        for (int gI = 0; gI < I.n_site - I.n_own; gI++) local[lay[c].ghosts[gI]] = I.n_own + gI;
+        const int ns = (I.n_site + 1) & ~1;
+        double *sx = (double *)(blob.data() + I.blob16), *sy = sx + ns, *sz = sy + ns;
+        float4 *wrec = (float4 *)(sz + ns);
+        uint32_t *wlink = (uint32_t *)(wrec + I.n_wall), *hdr = wlink + ((I.n_wall + 3) & ~3);
+        const int ng = I.n_site - I.n_own, ngp = (ng + 3) & ~3;
+        int *mem = (int *)(hdr + ((I.n_own + 3) & ~3)), *gcell = mem + ((I.n_own + 3) & ~3), *gpacked = gcell + ngp, *gadj = gpacked + ngp;
+        for (int j = 0; j < I.n_own; j++) mem[j] = members[I.cell0 + j];
+        for (int gI = 0; gI < ng; gI++) {
+            const VtGhost &gh = ghosts[(size_t)I.ghost0 + gI];
+            gcell[gI] = gh.cell; gpacked[gI] = packed[gh.cell]; gadj[gI] = gh.adj;
+        }
+        double rmax = 0.0, len_sum = 0.0; size_t len_n = 0;
+        for (int j = 0; j < I.n_site; j++) {
+            const int cell = j < I.n_own ? members[I.cell0 + j] : lay[c].ghosts[j - I.n_own];
+            sx[j] = S[3 * (size_t)cell]; sy[j] = S[3 * (size_t)cell + 1]; sz[j] = S[3 * (size_t)cell + 2];
+            for (int a = 0; a < 3; a++) rmax = std::max(rmax, std::fabs(S[3 * (size_t)cell + a]));
+        }
+        for (int a = 0; a < 6; a++) rmax = std::max(rmax, std::fabs(B[a]));
+        // first pass: the scale (a power of two that brings the mean |n| to order one)
+        for (int j = 0; j < I.n_own; j++) {
+            const int cell = members[I.cell0 + j];
+            for (int k = idx[cell]; k < idx[cell + 1]; k++) {
+                const int nb = nei[k];
+                double n[3];
+                if (nb >= 0) for (int a = 0; a < 3; a++) n[a] = S[3 * (size_t)nb + a] - S[3 * (size_t)cell + a];
+                else { const int iw = -nb - 1, ax = iw >> 1; n[0] = n[1] = n[2] = 0.0; n[ax] = 2.0 * (B[iw] - S[3 * (size_t)cell + ax]); }
+                const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+                if (len > 0.0 && std::isfinite(len)) { len_sum += len; len_n++; }
+            }
+        }
+        int e2 = 0;
+        if (len_n) (void)std::frexp(len_sum / (double)len_n, &e2);
+        const double scale = std::ldexp(1.0, -e2);
+        I.scale = (float)scale;
+        I.abs_eps = (float)(std::ldexp(1.0, -49) * rmax * scale * (1.0 + 1e-6));
+        int kw = 0;
+        for (int j = 0; j < I.n_own; j++) {
+            const int cell = members[I.cell0 + j];
+            const int k0 = kw;
+            bool exact = false;
+            for (int k = idx[cell]; k < idx[cell + 1]; k++, kw++) {
+                const int nb = nei[k];
+                double n[3];
+                uint32_t link;
+                if (nb >= 0) {
+                    for (int a = 0; a < 3; a++) n[a] = S[3 * (size_t)nb + a] - S[3 * (size_t)cell + a];
+                    int back = VT_NO_BACK;
+                    for (int q = idx[nb]; q < idx[nb + 1]; q++) if (nei[q] == cell) { if (q - idx[nb] < VT_FIND_BACK) back = q - idx[nb]; break; }
+                    link = (uint32_t)local[nb] | ((uint32_t)back << 16);
+                    for (int q = idx[cell]; q < k; q++) if (nei[q] == nb) exact = true;      // a neighbour listed twice
+                } else {
+                    // a face of the box: the bisector plane with the site's mirror image in it (FP32 filter only)
+                    const int iw = -nb - 1, ax = iw >> 1;
+                    n[0] = n[1] = n[2] = 0.0; n[ax] = 2.0 * (B[iw] - S[3 * (size_t)cell + ax]);
+                    link = 0xffffu | ((uint32_t)VT_NO_BACK << 16) | ((uint32_t)(iw + 1) << 24);
+                }
+                const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) * scale * (1.0 + 4.0 * 5.9604645e-8);
+                wrec[kw] = make_float4((float)(n[0] * scale), (float)(n[1] * scale), (float)(n[2] * scale), nb >= 0 ? (float)len : -(float)len);
+                wlink[kw] = link;
+            }
+            hdr[j] = (uint32_t)k0 | ((uint32_t)(kw - k0) << 20) | (exact ? VT_HDR_EXACT : 0u);
+        }
+        for (int j = 0; j < I.n_own; j++) local[members[I.cell0 + j]] = -1;
+        for (int gI = 0; gI < I.n_site - I.n_own; gI++) local[lay[c].ghosts[gI]] = -1;
     }
     // unused adjacency slots point at the cluster itself (the walk adds a zero count there)
     for (int c = 0; c < n_cl; c++) for (int s = 0; s < VT_MAX_ADJ; s++) if (adj[(size_t)c * VT_MAX_ADJ + s] < 0) adj[(size_t)c * VT_MAX_ADJ + s] = c;
-    free_dev(h->d_vt_cluster); free_dev(h->d_vt_cell_off); free_dev(h->d_vt_wall_off); free_dev(h->d_vt_members); free_dev(h->d_vt_adj);
-    free_dev(h->d_vt_hdr); free_dev(h->d_vt_walls);
+    if (ghosts.empty()) ghosts.push_back(VtGhost{0, VT_MAX_ADJ});
+    free_dev(h->d_vt_cluster); free_dev(h->d_vt_info); free_dev(h->d_vt_blob); free_dev(h->d_vt_members); free_dev(h->d_vt_adj); free_dev(h->d_vt_ghost);
     auto up = [&](auto *&dst, const auto &v) {
         using T = typename std::remove_reference<decltype(v)>::type::value_type;
         if (hipMalloc((void **)&dst, sizeof(T) * v.size()) != hipSuccess) return 1;
         return hipMemcpy(dst, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess ? 1 : 0;
     };
-    if (up(h->d_vt_cluster, packed) || up(h->d_vt_cell_off, cell_off) || up(h->d_vt_wall_off, wall_off) || up(h->d_vt_members, members) ||
-        up(h->d_vt_adj, adj) || up(h->d_vt_hdr, hdr) || up(h->d_vt_walls, walls))
+    if (up(h->d_vt_cluster, packed) || up(h->d_vt_info, info) || up(h->d_vt_blob, blob) || up(h->d_vt_members, members) ||
+        up(h->d_vt_adj, adj) || up(h->d_vt_ghost, ghosts))
         return h->set_error("cannot allocate the cluster tables of the tiled Voronoi schedule");
     DProblem &P = h->hp;
-    P.vt_cluster = h->d_vt_cluster; P.vt_cell_off = h->d_vt_cell_off; P.vt_wall_off = h->d_vt_wall_off; P.vt_members = h->d_vt_members;
-    P.vt_adj = h->d_vt_adj; P.vt_hdr = h->d_vt_hdr; P.vt_walls = h->d_vt_walls;
-    h->vt_clusters = n_cl; h->vt_max_cells = max_cells; h->vt_max_walls = max_walls; h->vt_built_for = nd;
-    (void)n_far;
+    P.vt_cluster = h->d_vt_cluster; P.vt_info = h->d_vt_info; P.vt_blob = h->d_vt_blob; P.vt_members = h->d_vt_members;
+    P.vt_adj = h->d_vt_adj; P.vt_ghost = h->d_vt_ghost;
+    int max_cells = 0;
+    for (int c = 0; c < n_cl; c++) max_cells = std::max(max_cells, info[c].n_own);
+    h->vt_clusters = n_cl; h->vt_max_cells = max_cells; h->vt_max_lds = max_lds; h->vt_built_for = nd;
     return 0;
 }
 
@@ -2835,7 +2924,9 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;
     else if (n == "vt_max_cells") *value = h->vt_max_cells;
-    else if (n == "vt_max_walls") *value = h->vt_max_walls;
+    else if (n == "vt_max_lds") *value = (int64_t)h->vt_max_lds;
+    else if (n == "last_vt_exact_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;      // steps of the Voronoi walk that ran the reference's loop
+    else if (n == "last_vt_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;         // -DHYP_VTILE_VERIFY builds: filter and loop disagreed
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with

@@ -10,6 +10,9 @@
 #ifndef HYP_GEOM_TU
 #define HYP_GEOM_TU 0   // GEOM_CAR
 #endif
+#ifdef HYP_ONLY_ND1
+#define HYP_ONLY_ND 1
+#endif
 #ifndef HYP_PART
 #error "compile with -DHYP_PART=0..4 (hyperion_amd/build.py)"
 #endif
@@ -35,9 +38,9 @@
 template <int GEOM>
 LucyKernel pick_lucy_kernel_g(int nd)
 {
-#ifdef HYP_ONLY_ND1   // tuning builds (tools/variants.py) instantiate one species only
+#ifdef HYP_ONLY_ND   // tuning builds (tools/variants.py) instantiate one species count only
     (void)nd;
-    return lucy_kernel<1, GEOM>;
+    return lucy_kernel<HYP_ONLY_ND, GEOM>;
 #else
     switch (nd) {
     case 1: return lucy_kernel<1, GEOM>;
@@ -56,9 +59,9 @@ template <int GEOM>
 LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plain, 2 lean (final_kernel<.., false, true>)
 {
 #define HYP_FINAL_PICK(N) (mode == 1 ? final_kernel<N, GEOM, true> : mode == 2 ? final_kernel<N, GEOM, false, true> : final_kernel<N, GEOM, false>)
-#ifdef HYP_ONLY_ND1
+#ifdef HYP_ONLY_ND
     (void)nd;
-    return HYP_FINAL_PICK(1);
+    return HYP_FINAL_PICK(HYP_ONLY_ND);
 #else
     switch (nd) {
     case 1: return HYP_FINAL_PICK(1);
@@ -77,9 +80,9 @@ LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plai
 template <int GEOM>
 RayKernel pick_ray_kernel_g(int nd)
 {
-#ifdef HYP_ONLY_ND1
+#ifdef HYP_ONLY_ND
     (void)nd;
-    return ray_kernel<1, GEOM>;
+    return ray_kernel<HYP_ONLY_ND, GEOM>;
 #else
     switch (nd) {
     case 1: return ray_kernel<1, GEOM>;
@@ -109,9 +112,9 @@ static DeferKernels defer_kernels()
 template <int GEOM>
 DeferKernels pick_defer_kernels_g(int nd)
 {
-#ifdef HYP_ONLY_ND1
+#ifdef HYP_ONLY_ND
     (void)nd;
-    return defer_kernels<1, GEOM>();
+    return defer_kernels<HYP_ONLY_ND, GEOM>();
 #else
     switch (nd) {
     case 1: return defer_kernels<1, GEOM>();
@@ -176,9 +179,9 @@ static TileKernels tile_kernels()
 template <int GEOM>
 TileKernels pick_tile_kernels_g(int nd)
 {
-#ifdef HYP_ONLY_ND1
+#ifdef HYP_ONLY_ND
     (void)nd;
-    return tile_kernels<1, GEOM>();
+    return tile_kernels<HYP_ONLY_ND, GEOM>();
 #else
     switch (nd) {
     case 1: return tile_kernels<1, GEOM>();

@@ -143,7 +143,9 @@ template <> struct TileCellIO<GEOM_CAR> {
     }
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_CAR> &c) { return brick_of(T, c.ic); }
 };
-// Voronoi: ic = (cell, the cell the packet came from or -1, cluster << 8 | index of the cell in its cluster)
+// Voronoi: ic = (cell, the cell the packet came from or -1, cluster << 16 | index of the cell in its cluster); ow = position of the
+// wall the packet came through in the cell's wall list (VT_NO_BACK: none; VT_FIND_BACK: to be looked up from ic[1])
+#define VT_FIND_BACK 254
 template <> struct TileCellIO<GEOM_VOR> {
     template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_VOR> &c)
     {
@@ -151,9 +153,10 @@ template <> struct TileCellIO<GEOM_VOR> {
     }
     template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_VOR> &c)
     {
-        H.ic[0] = c.id; H.ic[1] = -c.ow[1] - 1; H.ic[2] = P.vt_cluster[c.id]; H.ow = 0;
+        const int prev = -c.ow[1] - 1;
+        H.ic[0] = c.id; H.ic[1] = prev; H.ic[2] = P.vt_cluster[c.id]; H.ow = prev < 0 ? VT_NO_BACK : VT_FIND_BACK;
     }
-    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 8; }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 16; }
 };
 // AMR (hyp_atile.h): ic = (cell, grid, brick); the position in the grid follows from the cell id
 __device__ __forceinline__ int amr_brick_of(const DProblem &P, int grid, const int i[3])

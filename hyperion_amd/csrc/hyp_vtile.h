@@ -3,112 +3,207 @@
 // The persistent kernel reads, per cell crossing, one 32-byte wall record per neighbour (~15) from wherever it lives in
 // the memory hierarchy (49 MB at 100 000 sites: L2 misses, ~500 B of L2<->fabric traffic per crossing) and makes one
 // memory-side atomic per species.  Here the cells are grouped at set-up into spatially compact CLUSTERS (recursive
-// coordinate bisection of the sites, ~100 cells each) whose wall records, sites, densities and accumulators fit in LDS.
-// The slot-pool schedule of hyp_tiled.h does the rest with "brick" = cluster: packets wait in slot records, are sorted by
-// cluster every generation, and one workgroup per task walks the packets of one cluster from LDS (ds_read_b128 for the
-// records, ds_add_f64 for the deposits) until they leave the cluster, interact or die.
+// coordinate bisection of the sites) whose tables, densities and accumulators fit in LDS.  The slot-pool schedule of
+// hyp_tiled.h does the rest with "brick" = cluster: packets wait in slot records, are sorted by cluster every generation,
+// and one workgroup per task walks the packets of one cluster from LDS (ds_add_f64 deposits) until they leave the
+// cluster, interact or die.
 //
-// The wall search is grid_geometry_voronoi.f90:322-402 (geo_find_wall<GEOM_VOR>): the nearest bisector plane ahead,
-// t = n.(m - r) / n.v per neighbour, one IEEE division per neighbour like the reference.  A division-free variant is kept
-// behind -DHYP_VTILE_CROSSMUL: numerator and denominator of every candidate formed with the reference's operations, the
-// minimum found by cross-multiplication with a guard band of 2^-48, ONE quotient (the winner's) per step, and the
-// reference's loop for any step with a second candidate inside the guard band (bit-identical results, tested).  It is
-// SLOWER (1e8 packets, one species: 627 ms against 564 ms): the kernel waits on LDS (56 % of its wave cycles are
-// s_waitcnt, two thirds of the LDS cycles are bank conflicts of the scattered 32-byte record reads), not on VALU issue,
-// and the extra state of the cross-multiplication costs 16 spilled VGPRs at 4 waves per SIMD.
+// The wall search is grid_geometry_voronoi.f90:322-402: the nearest bisector plane ahead, t = n.(m - r) / n.v over the
+// neighbours, one IEEE division each -- ~45 FP64 instructions and 32 bytes of LDS per wall, ~16 walls per crossing, which
+// is what bound round 3's kernel (VALU issue 62 % and the LDS pipe 75 % busy).  Round 4 keeps the reference's arithmetic
+// for the wall that WINS and finds that wall in FP32:
+//
+//   * per wall one 16-byte record (n.x, n.y, n.z, |n|) x scale, n = neighbour's site - own site.  With q = r - site (formed
+//     in FP64, then rounded) num = |n|^2 / 2 - n.q and den = n.v are seven FP32 operations; t32 = num / den with v_rcp_f32.
+//   * every t32 carries a rigorous bound eps on its distance from the reference's FP64 quotient (vt_filter below: rounding
+//     of the inputs, of the seven operations, of the reciprocal, and the reference's own rounding of m - r at the cluster's
+//     coordinate magnitude), so each wall has an interval [lo, hi] that contains its true t.
+//   * U = the smallest hi among walls that are certainly ahead (lo > 0).  A wall can be the reference's minimum only if it
+//     may be ahead (hi > 0) and lo <= U.  The loop tracks the two smallest lo of such walls: when the second one is above
+//     U the first is the ONLY candidate and the step evaluates the reference's expression for that wall alone -- the
+//     same t, bit for bit, and the same wall.  Anything else -- two candidates (ties on lattices, a corner clipped within
+//     1e-6 of a cell width), a wall nearly parallel to the flight, non-finite FP32 values at absurd scales, a cell whose
+//     list names a neighbour twice -- runs the reference's loop over all walls in FP64 (vt_find_wall_exact).
+//
+// So results are those of the reference's loop whatever the filter does (tests/test_gpu_voronoi.py: tallies equal to the
+// oracle's and to the persistent kernel's; -DHYP_VTILE_VERIFY runs both searches on every step and counts disagreements),
+// and a crossing costs ~20 FP32 instructions and 16 bytes of LDS per wall plus ONE FP64 evaluation.  Sites are stored once
+// per cell (own cells + the "ghost" cells across the cluster's boundary) instead of once per wall, which makes the tables of a
+// cell ~400 bytes instead of ~580: clusters of ~380 cells on a whole CU's LDS (16-bit cell indices), longer visits.
 #pragma once
 
 #include "hyp_tiled.h"
 
 #ifndef HYP_VTILE_WG
-#define HYP_VTILE_WG 512         // threads per workgroup (one workgroup per task)
+#define HYP_VTILE_WG 1024        // threads per workgroup (one workgroup per task, one per CU with vt_lds_kb = 156)
 #endif
 #ifndef HYP_VTILE_OCC
-#define HYP_VTILE_OCC 4         // waves per SIMD the register budget is set for (two 512-thread workgroups per CU)
+#define HYP_VTILE_OCC 4          // waves per SIMD the register budget is set for (128 VGPRs, nothing spilled at one and two species)
 #endif
 #ifndef HYP_VTILE_SERVICE
 #define HYP_VTILE_SERVICE 16     // lanes that must wait before a wave runs its service phase
 #endif
 #ifndef HYP_VTILE_UNROLL
-#define HYP_VTILE_UNROLL 1       // unrolling of the wall loop (more LDS reads in flight per lane, more registers)
+#define HYP_VTILE_UNROLL 2       // unrolling of the filter loop (more LDS reads in flight per lane)
 #endif
 #ifndef HYP_VTILE_STEPS
-#define HYP_VTILE_STEPS 1        // cell steps between two scheduling decisions of a wave (measured: 1 beats 2 and 4)
+#define HYP_VTILE_STEPS 2        // cell steps between two scheduling decisions of a wave
 #endif
 
-// grid_geometry_voronoi.f90:357-393 over the cluster's copy of the wall records; kmin = index of the nearest wall ahead
-__device__ __forceinline__ bool vt_find_wall_exact(const DProblem &P, const VorWall *walls, int k0, int k1, double s0, double s1, double s2,
-                                                   const double r[3], const double v[3], int prev, double &tnear, int &kmin)
+// the cluster's tables in LDS (layout of the blob: hyp_device.h, VtInfo)
+struct VtLds {
+    const double *sx, *sy, *sz;
+    const float4 *wrec;
+    const uint32_t *wlink, *hdr;
+    const int *members;                      // cell ids of the own cells
+    const int *gcell, *gpacked, *gadj;       // per ghost: cell id, its vt_cluster word, slot of its cluster in the adjacency list
+    int blob16;                              // size of all of it in units of 16 bytes
+};
+
+__device__ __forceinline__ void vt_lds_view(const VtInfo &I, const float4 *base, VtLds &L)
 {
+    const int ns = (I.n_site + 1) & ~1;
+    L.sx = (const double *)base; L.sy = L.sx + ns; L.sz = L.sy + ns;
+    L.wrec = (const float4 *)(L.sz + ns);
+    L.wlink = (const uint32_t *)(L.wrec + I.n_wall);
+    L.hdr = L.wlink + ((I.n_wall + 3) & ~3);
+    const int ng = I.n_site - I.n_own, ngp = (ng + 3) & ~3;
+    L.members = (const int *)(L.hdr + ((I.n_own + 3) & ~3));
+    L.gcell = L.members + ((I.n_own + 3) & ~3); L.gpacked = L.gcell + ngp; L.gadj = L.gpacked + ngp;
+    L.blob16 = (int)(((const char *)(L.gadj + ngp) - (const char *)base) >> 4);
+}
+
+// the reference's expression for ONE wall (grid_geometry_voronoi.f90:357-393); returns `ahead` for a face of the box
+// (:362-371), true for a bisector plane (the caller excludes the wall the packet came through)
+__device__ __forceinline__ bool vt_exact_t(const DProblem &P, const VtLds &L, uint32_t link, double s0, double s1, double s2,
+                                           double r0, double r1, double r2, double v0, double v1, double v2, double &t)
+{
+    const int box = VT_LINK_BOX(link);
+    if (box) {
+        // (position and direction are scalars, selected by comparisons: an indexed array would live in scratch memory)
+        const int iw = box - 1, up = iw & 1;
+        const double va = iw < 2 ? v0 : iw < 4 ? v1 : v2;
+        const double ra = iw < 2 ? r0 : iw < 4 ? r1 : r2;
+        const double wall = iw < 2 ? (up ? P.vor_box[1] : P.vor_box[0]) : iw < 4 ? (up ? P.vor_box[3] : P.vor_box[2]) : (up ? P.vor_box[5] : P.vor_box[4]);
+        t = (wall - ra) / va;
+        return up ? (va > 0.0) : (va < 0.0);
+    }
+    const int j = VT_LINK_LOC(link);
+    const double wx = L.sx[j], wy = L.sy[j], wz = L.sz[j];
+    const double n0 = wx - s0, n1 = wy - s1, n2 = wz - s2;
+    const double m0 = 0.5 * (wx + s0), m1 = 0.5 * (wy + s1), m2 = 0.5 * (wz + s2);
+    t = (n0 * (m0 - r0) + n1 * (m1 - r1) + n2 * (m2 - r2)) / (n0 * v0 + n1 * v1 + n2 * v2);
+    return true;
+}
+
+// grid_geometry_voronoi.f90:357-393 over the cluster's tables: the reference's loop, wall by wall in FP64
+__device__ __forceinline__ bool vt_find_wall_exact(const DProblem &P, const VtLds &L, int k0, int nk, int prev_k, double s0, double s1, double s2,
+                                                   double r0, double r1, double r2, double v0, double v1, double v2, double &tnear, int &kmin)
+{
+    // `ahead = neighbour /= previous cell`: compared through the neighbours' places in the site table (one per cell id)
+    const int prev_site = prev_k < nk ? VT_LINK_LOC(L.wlink[k0 + prev_k]) : -1;
     double tmin = HYP_DBL_MAX; int imin = -1;
-#pragma unroll HYP_VTILE_UNROLL
-    for (int k = k0; k < k1; k++) {
-        const VorWall w = walls[k];
-        double t; bool ahead;
-        if (w.nb < 0) {
-            const int iw = -w.nb - 1, a = iw >> 1, up = iw & 1;
-            const double va = a == 0 ? v[0] : a == 1 ? v[1] : v[2];
-            const double ra = a == 0 ? r[0] : a == 1 ? r[1] : r[2];
-            ahead = up ? (va > 0.0) : (va < 0.0);
-            t = (P.vor_box[iw] - ra) / va;
-        } else {
-            const double n0 = w.x - s0, n1 = w.y - s1, n2 = w.z - s2;
-            const double m0 = 0.5 * (w.x + s0), m1 = 0.5 * (w.y + s1), m2 = 0.5 * (w.z + s2);
-            t = (n0 * (m0 - r[0]) + n1 * (m1 - r[1]) + n2 * (m2 - r[2])) / (n0 * v[0] + n1 * v[1] + n2 * v[2]);
-            ahead = w.nb != prev;
-        }
+    for (int k = 0; k < nk; k++) {
+        const uint32_t link = L.wlink[k0 + k];
+        double t;
+        bool ahead = vt_exact_t(P, L, link, s0, s1, s2, r0, r1, r2, v0, v1, v2, t);
+        if (!VT_LINK_BOX(link)) ahead = VT_LINK_LOC(link) != prev_site;
         if (ahead && t > 0.0 && t < tmin) { tmin = t; imin = k; }
     }
     tnear = tmin; kmin = imin;
     return imin >= 0;
 }
 
-__device__ __forceinline__ bool vt_find_wall(const DProblem &P, const VorWall *walls, int k0, int k1, double s0, double s1, double s2,
-                                             const double r[3], const double v[3], int prev, double &tnear, int &kmin)
+// The FP32 filter.  Inputs: q = (r - site) x scale and v rounded to FP32, Q >= |q|.  With u = 2^-24 and a wall record
+// (n, len) -- n within u of N x scale componentwise, len in [|N|, |N| (1 + 8u)] x scale -- the computed quantities obey
+//   |num32 - num| <= len (8u len + 7u Q + abs_eps)        (three fma for n.q: 5.5u len Q; len^2 / 2: 7u len^2; the subtraction)
+//   |den32 - den| <= 5.5u len                             (three fma for n.v, |v| = 1)
+// where num / den is the real-number quotient and the reference's FP64 value lies within abs_eps len of num (its m - r is
+// formed from absolute coordinates).  For |den32| > 4 dd:  |num32 / den32 - num / den| <= 2 (dn + |t| dd) / |den32|, and
+// v_rcp_f32 (1 ulp) times one multiplication adds 4u |t|.  The constants below are those with a margin of 1.4 - 2.
+// Returns the index of the only wall that can be the reference's minimum, or -1 when there is more than one or none.
+#define VT_U 5.9604645e-8f
+__device__ __forceinline__ int vt_filter(const VtLds &L, int k0, int nk, int prev_k, float q0, float q1, float q2, float Q, float abs_eps,
+                                         float v0, float v1, float v2)
 {
-#ifndef HYP_VTILE_CROSSMUL       // default: the reference's loop, one division per wall (measured faster, see the header comment)
-    return vt_find_wall_exact(P, walls, k0, k1, s0, s1, s2, r, v, prev, tnear, kmin);
-#else
-    double bn = 0.0, bd = 1.0; int bk = -1; bool amb = false;
-    for (int k = k0; k < k1; k++) {
-        const VorWall w = walls[k];
-        double num, den; bool ahead;
-        if (w.nb < 0) {
-            const int iw = -w.nb - 1, a = iw >> 1, up = iw & 1;
-            const double va = a == 0 ? v[0] : a == 1 ? v[1] : v[2];
-            const double ra = a == 0 ? r[0] : a == 1 ? r[1] : r[2];
-            ahead = up ? (va > 0.0) : (va < 0.0);
-            num = P.vor_box[iw] - ra; den = va;
-        } else {
-            const double n0 = w.x - s0, n1 = w.y - s1, n2 = w.z - s2;
-            const double m0 = 0.5 * (w.x + s0), m1 = 0.5 * (w.y + s1), m2 = 0.5 * (w.z + s2);
-            num = n0 * (m0 - r[0]) + n1 * (m1 - r[1]) + n2 * (m2 - r[2]);
-            den = n0 * v[0] + n1 * v[1] + n2 * v[2];
-            ahead = w.nb != prev;
-        }
-        // the quotient is positive exactly when both have the same sign (and neither is zero or NaN)
-        const bool pos = (num > 0.0 && den > 0.0) || (num < 0.0 && den < 0.0);
-        if (ahead && pos) {
-            const double an = fabs(num), ad = fabs(den);
-            if (bk < 0) { bn = an; bd = ad; bk = k; }
-            else {
-                // an / ad < bn / bd  <=>  an bd < bn ad; within 2^-48 of equality (or not finite) the reference's loop decides
-                const double lhs = an * bd, rhs = bn * ad;
-                if (lhs < rhs * (1.0 - 0x1p-48)) { bn = an; bd = ad; bk = k; }
-                else if (!(lhs > rhs * (1.0 + 0x1p-48))) amb = true;
-            }
-        }
+    const float cq = fmaf(10.0f * VT_U, Q, abs_eps);
+    const float inf = __builtin_inff();
+    float lo1 = inf, lo2 = inf, U = inf;
+    int k1 = -1;
+    bool unc = false;
+    // written without branches: a wave's lanes are in different cells, every `if` here would be a pair of exec-mask updates
+#pragma unroll HYP_VTILE_UNROLL
+    for (int k = 0; k < nk; k++) {
+        const float4 w = L.wrec[k0 + k];
+        const float len = fabsf(w.w);        // (the sign bit marks a face of the box)
+        const float dq = fmaf(w.z, q2, fmaf(w.y, q1, w.x * q0));
+        const float num = 0.5f * len * len - dq;
+        const float den = fmaf(w.z, v2, fmaf(w.y, v1, w.x * v0));
+        const float dn = len * fmaf(12.0f * VT_U, len, cq);
+        const float dd = 8.0f * VT_U * len;
+        const float rcp = __builtin_amdgcn_rcpf(den);
+        const float t = num * rcp, at = fabsf(t);
+        const float eps = fmaf(2.5f * fmaf(at, dd, dn), fabsf(rcp), 16.0f * VT_U * at);
+        const float lo = t - eps, hi = t + eps;
+        // a face of the box is ahead when the packet moves towards it (:362-371: the sign of one component of v, which the
+        // single product of its record's den keeps): a packet emitted ON a face by an external source is not held up by it
+        const bool valid = (k != prev_k) & !((w.w < 0.0f) & (den < 0.0f));
+        const bool good = (fabsf(den) > 4.0f * dd) & (eps < inf);        // false for NaN
+        unc |= valid & !good;
+        const bool cand = valid & good & (hi > 0.0f), sure = valid & good & (lo > 0.0f);
+        U = sure ? fminf(U, hi) : U;
+        const bool lt1 = cand & (lo < lo1), lt2 = cand & (lo < lo2);
+        lo2 = lt1 ? lo1 : lt2 ? lo : lo2;
+        lo1 = lt1 ? lo : lo1;
+        k1 = lt1 ? k : k1;
     }
-    if (bk < 0) { tnear = HYP_DBL_MAX; kmin = -1; return false; }
-    const double t = bn / bd;       // |num| / |den| rounds like num / den
-    if (amb || !(t > 0.0 && t < HYP_DBL_MAX)) return vt_find_wall_exact(P, walls, k0, k1, s0, s1, s2, r, v, prev, tnear, kmin);
-    tnear = t; kmin = bk;
-    return true;
-#endif
+    return (!unc && k1 >= 0 && lo2 > U) ? k1 : -1;
 }
 
-// TileGeom for this schedule: n_bricks = number of clusters; bx = most cells, by = most wall records of a cluster (LDS
-// layout); the other brick fields are unused.
+// the search of one step: filter, then the reference's expression for the wall it names, or the reference's loop
+__device__ __forceinline__ bool vt_find_wall(const DProblem &P, const VtLds &L, const VtInfo &I, int loc, int k0, int nk, bool exact_only, int prev_k,
+                                             double r0, double r1, double r2, double v0, double v1, double v2, double &tnear, int &kmin,
+                                             unsigned int &n_exact)
+{
+    const double s0 = L.sx[loc], s1 = L.sy[loc], s2 = L.sz[loc];       // the cell's site (three ds_read_b64 per step: registers are scarcer)
+    int k1 = -1;
+    if (!exact_only) {
+        const float q0 = (float)((r0 - s0) * (double)I.scale), q1 = (float)((r1 - s1) * (double)I.scale), q2 = (float)((r2 - s2) * (double)I.scale);
+        const float Q = sqrtf(fmaf(q2, q2, fmaf(q1, q1, q0 * q0))) * 1.000001f;
+        k1 = vt_filter(L, k0, nk, prev_k, q0, q1, q2, Q, I.abs_eps, (float)v0, (float)v1, (float)v2);
+    }
+    bool ok = false;
+    if (k1 >= 0) {
+        double t;
+        const bool ahead = vt_exact_t(P, L, L.wlink[k0 + k1], s0, s1, s2, r0, r1, r2, v0, v1, v2, t);
+        if (ahead && t > 0.0 && t < HYP_DBL_MAX) { tnear = t; kmin = k1; ok = true; }
+    }
+#ifdef HYP_VTILE_VERIFY     // both searches on every step: a disagreement is counted in TileCtl::dbg[39] (tests/test_gpu_voronoi.py)
+    {
+        double te; int ke;
+        const bool fe = vt_find_wall_exact(P, L, k0, nk, prev_k, s0, s1, s2, r0, r1, r2, v0, v1, v2, te, ke);
+        if (ok && (!fe || ke != kmin || te != tnear)) n_exact |= 0x80000000u;
+        if (!ok) n_exact++;
+        tnear = te; kmin = ke;
+        return fe;
+    }
+#endif
+    if (ok) return true;
+    n_exact++;
+    return vt_find_wall_exact(P, L, k0, nk, prev_k, s0, s1, s2, r0, r1, r2, v0, v1, v2, tnear, kmin);
+}
+
+// the propagation check's in_correct_cell (grid_geometry_voronoi.f90:274-283) walks the neighbour graph in global memory: a
+// real call, once per ~1000 steps, so that its registers are not the walk's (inlined it cost the kernel 66 spilled VGPRs)
+__device__ __attribute__((noinline)) bool vt_in_correct_cell(const DProblem *Pp, double r0, double r1, double r2, int cell)
+{
+    const Walls W = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}};
+    const double r[3] = {r0, r1, r2};
+    Cell<GEOM_VOR> c; c.id = cell; c.ow[0] = 0; c.ow[1] = 0; c.ow[2] = 0;      // (only the cell is looked at)
+    return geo_in_correct_cell(*Pp, W, r, c);
+}
+
+// TileGeom for this schedule: n_bricks = number of clusters; the LDS of the launch holds the largest cluster
 template <int ND>
 __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                                   void *__restrict__ hot_v, void *__restrict__ cold_v,
@@ -117,32 +212,30 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                                                                   int *__restrict__ ilist, int *__restrict__ dlist,
                                                                   TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
-    extern __shared__ float4 lds16[];        // 16-byte aligned base: headers and wall records are read with ds_read_b128
+    extern __shared__ float4 lds16[];        // 16-byte aligned base: the wall records are read with ds_read_b128
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
     ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
     if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
     const int cl = tk.brick;
-    const int c0 = P.vt_cell_off[cl], nc = P.vt_cell_off[cl + 1] - c0;
-    const int w0 = P.vt_wall_off[cl], nw = P.vt_wall_off[cl + 1] - w0;
-    VtHdr *hdr = (VtHdr *)lds16;
-    VorWall *walls = (VorWall *)(hdr + T.bx);
-    double *dens = (double *)(walls + T.by);
-    double *accum = dens + (size_t)T.bx * ND;
+    const VtInfo I = P.vt_info[cl];
+    const int nc = I.n_own;
+    VtLds L;
+    vt_lds_view(I, lds16, L);
+    const int blob16 = L.blob16;
+    double *dens = (double *)(lds16 + blob16);
+    double *accum = dens + (size_t)nc * ND;
     __shared__ int next_pkt, n_int_l, n_dead_l, pub_base[2];
     __shared__ unsigned int nb_cnt[VT_MAX_ADJ + 1];      // packets that move on to each adjacent cluster; [VT_MAX_ADJ]: parked here
     __shared__ int adj[VT_MAX_ADJ];
     __shared__ double red[TILE_RED_N];
     {
-        const float4 *src = (const float4 *)(P.vt_hdr + c0);
-        float4 *dst = (float4 *)hdr;
-        for (int i = threadIdx.x; i < nc * 2; i += blockDim.x) dst[i] = src[i];
-        src = (const float4 *)(P.vt_walls + w0); dst = (float4 *)walls;
-        for (int i = threadIdx.x; i < nw * 2; i += blockDim.x) dst[i] = src[i];
+        const float4 *src = P.vt_blob + I.blob16;
+        for (int i = threadIdx.x; i < blob16; i += blockDim.x) lds16[i] = src[i];
     }
     for (int i = threadIdx.x; i < nc * ND; i += blockDim.x) {
-        const int cell = P.vt_members[c0 + i / ND];
+        const int cell = P.vt_members[I.cell0 + i / ND];       // (the LDS copy is still on its way)
         dens[i] = P.density[(size_t)cell * ND + i % ND];
         accum[i] = 0.0;
     }
@@ -154,13 +247,17 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
 
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
-    unsigned int finished = 0;
+    unsigned int finished = 0, n_exact = 0;
     // lane state: the walking part of a packet (the rest stays in its ColdRec)
-    double r[3] = {0.0, 0.0, 0.0}, v[3] = {1.0, 0.0, 0.0}, tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, v0 = 1.0, v1 = 0.0, v2 = 0.0, tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
     double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
-    double hs0 = 0.0, hs1 = 0.0, hs2 = 0.0;  // site of the current cell and its wall records [hk0, hk1)
-    int hk0 = 0, hk1 = 0;
-    int cell = 0, prev = -1, loc = 0, left_adj = 0;
+    int hk0 = 0, hnk = 0;                    // its wall records [hk0, hk0 + hnk)
+    bool hexact = false;                     // VT_HDR_EXACT
+    int loc = 0;                             // the current cell's index in the cluster
+    int prev_k = VT_NO_BACK;                 // position, in the current cell's list, of the wall the packet came through
+    int prev_loc = -2;                       // the cell it came from, if that happened in this visit (else prev_g, the record's ic[1])
+    int prev_g = -1;
+    int left_ghost = 0;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
     int slot = -1;
@@ -168,8 +265,11 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
     bool exhausted = false;
 #pragma unroll
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
-    const Walls W = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}};
 
+#ifdef HYP_TILE_STATS
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_visits = 0, dbg_wb = 0, dbg_claim = 0, dbg_nclaim = 0, dbg_nwb = 0;
+    const long long dbg_t0 = clock64();
+#endif
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
     for (;;) {
         if (queue_empty && st == LS_IDLE) exhausted = true;
@@ -181,12 +281,29 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
         const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_VTILE_SERVICE || !m_walk))) {
+#ifdef HYP_TILE_STATS
+            const long long dbg_ts = clock64();
+#endif
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
             if (st == LS_CHECK) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
-                Cell<GEOM_VOR> c; c.id = cell; c.ow[0] = 0; c.ow[1] = -(prev + 1); c.ow[2] = 0;
-                if (geo_in_correct_cell(P, W, r, c)) st = LS_WALK;
+                // in_correct_cell (:274-283) first asks whether the nearest-site walk from the packet's cell stays there, i.e. whether
+                // no neighbour's site is closer than the cell's own: answered from the cluster's tables with vor_dist2's operations;
+                // only a packet that fails this goes through the reference's whole test on the global tables
+                bool stays = true;
+                {
+                    const double ox = L.sx[loc] - r0, oy = L.sy[loc] - r1, oz = L.sz[loc] - r2;
+                    const double d_own = ox * ox + oy * oy + oz * oz;
+                    for (int k = 0; k < hnk; k++) {
+                        const uint32_t link = L.wlink[hk0 + k];
+                        if (VT_LINK_BOX(link)) continue;
+                        const int j2 = VT_LINK_LOC(link);
+                        const double dx = L.sx[j2] - r0, dy = L.sy[j2] - r1, dz = L.sz[j2] - r2;
+                        if (dx * dx + dy * dy + dz * dz < d_own) stays = false;
+                    }
+                }
+                if (stays || vt_in_correct_cell(Pp, r0, r1, r2, L.members[loc])) st = LS_WALK;
                 else { cnt.killed_geo++; st = LS_DEAD; }
             }
             if (st == LS_DEAD) {
@@ -195,26 +312,40 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                 finished++; st = LS_IDLE;
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[slot];
-#pragma unroll
-                for (int a = 0; a < 3; a++) H.r[a] = r[a];
-                H.ic[0] = cell; H.ic[1] = prev;
-                H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
                 if (P.any_intersect) cold[slot].t_ach = t_ach;
-                if (st == LS_LEFT) {                                                  // H.state stays TS_WALK
-                    const int packed = P.vt_cluster[cell];
-                    H.ic[2] = packed;
-                    slot_brick[slot] = packed >> 8;
-                    if (left_adj < VT_MAX_ADJ) atomicAdd(&nb_cnt[left_adj], 1u);
-                    else atomicAdd(&counts[packed >> 8], 1u);
+                const int here = L.members[loc];
+                // the 64-byte line a visit changes goes out as four 16-byte stores (r | r, tau_ach | ic, ow | countdown, blk_b,
+                // state, pad): a store instruction per field was a third of the service phase
+                int c0, c1, c2, c3, state = TS_WALK;
+                if (st == LS_LEFT) {
+                    const int packed = L.gpacked[left_ghost], ga = L.gadj[left_ghost];
+                    c0 = L.gcell[left_ghost]; c1 = here; c2 = packed; c3 = prev_k;
+                    slot_brick[slot] = packed >> 16;
+                    if (ga < VT_MAX_ADJ) atomicAdd(&nb_cnt[ga], 1u);
+                    else atomicAdd(&counts[packed >> 16], 1u);
                 } else {
-                    H.ic[2] = (cl << 8) | loc;
-                    if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
-                    else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
+                    c0 = here; c2 = (cl << 16) | loc;
+                    if (st == LS_HIT) { c1 = -1; c3 = VT_NO_BACK; }                    // geo_clear_wall
+                    else { c1 = prev_loc >= 0 ? L.members[prev_loc] : prev_g; c3 = prev_k; }
+                    if (st == LS_REABS) { state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
+                    else if (st == LS_HIT) { state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                     else atomicAdd(&nb_cnt[VT_MAX_ADJ], 1u);                          // parked: same cluster again
                     if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
                 }
+                static_assert(offsetof(HotRec<ND>, tau_ach) == 24 && offsetof(HotRec<ND>, ic) == 32 && offsetof(HotRec<ND>, ow) == 44 &&
+                              offsetof(HotRec<ND>, countdown) == 48 && offsetof(HotRec<ND>, blk_b) == 52 && offsetof(HotRec<ND>, state) == 56, "HotRec layout");
+                double2 *line = (double2 *)&H;
+                line[0] = make_double2(r0, r1);
+                line[1] = make_double2(r2, tau_ach);
+                ((int4 *)line)[2] = make_int4(c0, c1, c2, c3);
+                ((int4 *)line)[3] = make_int4(g.countdown, (int)g.blk_b, state, 0);
                 st = LS_IDLE;
             }
+#ifdef HYP_TILE_STATS
+            const long long dbg_tw = clock64();
+            dbg_wb += (unsigned long long)(dbg_tw - dbg_ts); dbg_nwb += __popcll(m_out);
+            dbg_nclaim += __popcll(__ballot(st == LS_IDLE && !exhausted));
+#endif
             if (park) break;
             if (st == LS_IDLE && !exhausted) {
                 const int j = atomicAdd(&next_pkt, 1);
@@ -222,9 +353,8 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                 else {
                     slot = order[tk.start + j];
                     const HotRec<ND> &H = hot[slot];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { r[a] = H.r[a]; v[a] = H.v[a]; }
-                    cell = H.ic[0]; prev = H.ic[1]; loc = H.ic[2] & 255;
+                    r0 = H.r[0]; r1 = H.r[1]; r2 = H.r[2]; v0 = H.v[0]; v1 = H.v[1]; v2 = H.v[2];
+                    loc = H.ic[2] & 0xffff; prev_k = H.ow & 255; prev_loc = -2; prev_g = H.ic[1];
                     tau_req = H.tau_req; tau_ach = H.tau_ach; energy = H.energy;
 #pragma unroll
                     for (int d = 0; d < ND; d++) { chi[d] = H.chi[d]; kappa[d] = H.kappa[d]; }
@@ -232,13 +362,32 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
-                    const VtHdr hh = hdr[loc];
-                    hs0 = hh.x; hs1 = hh.y; hs2 = hh.z; hk0 = hh.k0; hk1 = hh.k1;
+                    const uint32_t hh = L.hdr[loc];
+                    hk0 = (int)(hh & 0xfffffu); hnk = (int)((hh >> 20) & 0xffu); hexact = (hh & VT_HDR_EXACT) != 0;
+                    if (prev_k == VT_FIND_BACK) {        // a record written without the wall's position: look the previous cell up
+                        const int want = prev_g;
+                        prev_k = VT_NO_BACK;
+                        for (int k = 0; k < hnk; k++) {
+                            const uint32_t link = L.wlink[hk0 + k];
+                            if (VT_LINK_BOX(link)) continue;
+                            const int j2 = VT_LINK_LOC(link);
+                            const int idn = j2 < nc ? L.members[j2] : L.gcell[j2 - nc];
+                            if (idn == want && prev_k == VT_NO_BACK) prev_k = k;
+                        }
+                    }
                     st = LS_WALK;
                 }
             }
             if (__ballot(exhausted)) queue_empty = true;
+#ifdef HYP_TILE_STATS
+            dbg_service += (unsigned long long)(clock64() - dbg_ts); dbg_nservice++; dbg_claim += (unsigned long long)(clock64() - dbg_tw);
+            dbg_visits += __popcll(__ballot(st == LS_WALK)) ;
+#endif
         }
+#ifdef HYP_TILE_STATS
+        dbg_outer++;
+        { unsigned long long mw = __ballot(st == LS_WALK); if (mw) { dbg_wsteps++; dbg_lsteps += __popcll(mw); } }
+#endif
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #pragma unroll 1
         for (int q = 0; q < HYP_VTILE_STEPS; q++) {
@@ -247,7 +396,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                 else {
                     g.countdown--;
                     double tmin; int kmin;
-                    if (!vt_find_wall(P, walls, hk0, hk1, hs0, hs1, hs2, r, v, prev, tmin, kmin)) { cnt.killed_geo++; st = LS_DEAD; }
+                    if (!vt_find_wall(P, L, I, loc, hk0, hnk, hexact, prev_k, r0, r1, r2, v0, v1, v2, tmin, kmin, n_exact)) { cnt.killed_geo++; st = LS_DEAD; }
                     else {
                         double rho[ND], chi_rho = 0.0;
 #pragma unroll
@@ -260,21 +409,20 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                             if (P.any_intersect) { t_ach += tmin; reabs = t_ach > t_src; }      // :139-143
                             if (reabs) st = LS_REABS;
                             else {
-#pragma unroll
-                                for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+                                r0 = r0 + tmin * v0; r1 = r1 + tmin * v1; r2 = r2 + tmin * v2;
                                 tau_ach += tau_cell;
 #pragma unroll
                                 for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[loc * ND + d], tmin * kappa[d] * energy);
-                                const int nb = walls[kmin].nb, nloc = walls[kmin].loc;
-                                prev = cell;
-                                if (nb < 0) { cell = (int)P.n_cells; st = LS_DEAD; }      // left the grid: the packet ends here
+                                const uint32_t link = L.wlink[hk0 + kmin];
+                                if (VT_LINK_BOX(link)) st = LS_DEAD;      // left the grid: the packet ends here
                                 else {
-                                    cell = nb;
-                                    if (nloc >= 0) {
-                                        loc = nloc;
-                                        const VtHdr hh = hdr[loc];
-                                        hs0 = hh.x; hs1 = hh.y; hs2 = hh.z; hk0 = hh.k0; hk1 = hh.k1;
-                                    } else { left_adj = -nloc - 2; st = LS_LEFT; }
+                                    const int nloc = VT_LINK_LOC(link);
+                                    prev_k = VT_LINK_BACK(link);
+                                    if (nloc < nc) {
+                                        prev_loc = loc; loc = nloc;
+                                        const uint32_t hh = L.hdr[loc];
+                                        hk0 = (int)(hh & 0xfffffu); hnk = (int)((hh >> 20) & 0xffu); hexact = (hh & VT_HDR_EXACT) != 0;
+                                                        } else { left_ghost = nloc - nc; st = LS_LEFT; }
                                 }
                             }
                         } else {
@@ -284,10 +432,8 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                             if (P.any_intersect) { t_ach += tact; reabs = t_ach > t_src; }      // :184-188
                             if (reabs) st = LS_REABS;
                             else {
-#pragma unroll
-                                for (int a = 0; a < 3; a++) r[a] = r[a] + tact * v[a];
+                                r0 = r0 + tact * v0; r1 = r1 + tact * v1; r2 = r2 + tact * v2;
                                 tau_ach += tau_needed;
-                                prev = -1;       // geo_clear_wall
 #pragma unroll
                                 for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[loc * ND + d], tact * kappa[d] * energy);
                                 st = LS_HIT;
@@ -298,7 +444,19 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
             }
         }
     }
+#ifdef HYP_TILE_STATS
+    if (__lane_id() == 0) {
+        atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps);
+        atomicAdd(&ctl->dbg[3], 1ull); atomicAdd(&ctl->dbg[10], dbg_wb); atomicAdd(&ctl->dbg[11], dbg_claim); atomicAdd(&ctl->dbg[12], dbg_nwb); atomicAdd(&ctl->dbg[13], dbg_nclaim);
+        atomicAdd(&ctl->dbg[6], dbg_service); atomicAdd(&ctl->dbg[7], dbg_nservice); atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
+        if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
+    }
+    const long long dbg_te = clock64();
+#endif
     __syncthreads();
+#ifdef HYP_TILE_STATS
+    if (__lane_id() == 0) atomicAdd(&ctl->dbg[9], (unsigned long long)(clock64() - dbg_te));      // waiting for the workgroup's last wave
+#endif
     if (threadIdx.x < VT_MAX_ADJ && nb_cnt[threadIdx.x]) atomicAdd(&counts[adj[threadIdx.x]], nb_cnt[threadIdx.x]);
     if (threadIdx.x == VT_MAX_ADJ && nb_cnt[VT_MAX_ADJ]) atomicAdd(&counts[cl], nb_cnt[VT_MAX_ADJ]);
     tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);
@@ -311,7 +469,16 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
     }
     for (int i = threadIdx.x; i < nc * ND; i += blockDim.x) {
         const double val = accum[i];
-        if (val != 0.0) hyp_atomic_add_g(&sum[(size_t)P.vt_members[c0 + i / ND] * ND + i % ND], val);
+        if (val != 0.0) hyp_atomic_add_g(&sum[(size_t)L.members[i / ND] * ND + i % ND], val);
+    }
+    // how often the search ran the reference's loop (option last_vt_exact_steps); bit 31: the two searches disagreed (-DHYP_VTILE_VERIFY)
+    {
+        const unsigned long long bad = __ballot((n_exact & 0x80000000u) != 0);
+        const double ne = wave_sum((double)(n_exact & 0x7fffffffu));
+        if (__lane_id() == 0) {
+            if (ne != 0.0) atomicAdd(&ctl->dbg[38], (unsigned long long)ne);
+            if (bad) atomicAdd(&ctl->dbg[39], (unsigned long long)__popcll(bad));
+        }
     }
     block_tally_flush(P, ctl, red, cnt, finished);
 }

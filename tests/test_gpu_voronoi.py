@@ -238,7 +238,9 @@ def test_vtile_matches_persistent_at_scale():
         res.append(eng.lucy_iteration(2_000_000, 1))
         assert eng.get_option("last_lucy_mode") == (0 if mode == 0 else 1)
         if mode:
-            assert eng.get_option("vt_clusters") > 500 and eng.get_option("vt_max_cells") <= 256
+            assert eng.get_option("vt_clusters") > 100 and eng.get_option("vt_max_cells") > 256      # 16-bit cell indices: a whole CU's LDS per cluster
+            # the FP32 filter names the winning wall on all but a handful of the ~1e8 steps (the rest run the reference's loop)
+            assert eng.get_option("last_vt_exact_steps") < 1e-3 * res[-1][1]["crossings"]
         eng.close()
     (a, sa), (b, sb) = res
     for k in INT_KEYS:

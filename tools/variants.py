@@ -10,39 +10,49 @@ VDIR = os.path.join(ROOT, "build", "variants")
 
 
 def build(specs):
-    """Each variant: hyp_engine.hip + the units of ONE geometry (env GEOM, default Cartesian) for ONE species (env ND, default 1)."""
-    from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc
+    """Each variant: hyp_engine.hip + the units of ONE geometry (env GEOM, default Cartesian).  The kernel families named by env
+    PARTS (default "tile") are compiled with the variant's flags for ONE species count (env ND, default 1); the others are taken
+    from the default build (build/obj), so a variant costs two compilations.  At most 8 compilers run at a time."""
+    from hyperion_amd.build import CSRC, HIPCC_FLAGS, _hipcc, PARTS, GEOMS, OBJDIR
     os.makedirs(VDIR, exist_ok=True)
-    procs = []
+    geom = int(os.environ.get("GEOM", "0"))      # GEOM_* of the one geometry linked (0 Cartesian, 1 octree, ...)
+    gname = [g for g, k in GEOMS.items() if k == geom][0]
+    nd = os.environ.get("ND", "1")
+    mine = os.environ.get("PARTS", "tile").split(",")
+    jobs, links = [], []
     for spec in specs:
         name, _, flags = spec.partition(":")
         out = os.path.join(VDIR, name + ".so")
         objs = []
-        geom = int(os.environ.get("GEOM", "0"))      # GEOM_* of the one geometry unit linked (0 Cartesian, 1 octree, ...)
-        from hyperion_amd.build import PARTS
-        geom_units = [(part, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom, "-DHYP_PART=%d" % k]) for part, k in PARTS.items()]
-        for unit, src, defs in [("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom])] + geom_units:
+        units = [("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom])]
+        for part, k in PARTS.items():
+            if part in mine:
+                units.append((part, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom, "-DHYP_PART=%d" % k, "-DHYP_ONLY_ND=" + nd]))
+            else:
+                objs.append(os.path.join(OBJDIR, "%s_%s.o" % (part, gname)))
+        for unit, src, defs in units:
             obj = os.path.join(VDIR, "%s_%s.o" % (name, unit))
-            cmd = [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-DHYP_ONLY_ND1" if os.environ.get("ND", "1") == "1" else "-DHYP_ONLY_ND=" + os.environ["ND"], "-c", src, "-o", obj,
-                                                                    "-Rpass-analysis=kernel-resource-usage"]
-            procs.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
+            jobs.append((name, [_hipcc()] + HIPCC_FLAGS + flags.split() + defs + ["-c", src, "-o", obj, "-Rpass-analysis=kernel-resource-usage"]))
             objs.append(obj)
-        procs.append((name, [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out]))
-    pending_link = []
-    for name, p in procs:
-        if isinstance(p, list):
-            pending_link.append((name, p))
-            continue
+        links.append((name, [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", out]))
+    running = []
+
+    def reap(p_name, p):
         err = p.communicate()[1]
-        blocks = err.split("Function Name: ")
-        for b in blocks:
+        for b in err.split("Function Name: "):
             if b.startswith(os.environ.get("KERNEL", "_Z11lucy_kernelILi1E")):
                 info = [l.split("remark:")[1].strip() for l in b.split("\n") if "remark:" in l and
                         any(k in l for k in (" VGPRs:", "AGPRs:", "ScratchSize", "Occupancy", "VGPRs Spill"))]
-                print(name, "|", "; ".join(info))
+                print(p_name, "|", "; ".join(info), flush=True)
         if p.returncode:
-            print(name, "rc", p.returncode, err[-2000:])
-    for name, cmd in pending_link:
+            print(p_name, "rc", p.returncode, err[-2000:])
+    while jobs or running:
+        while jobs and len(running) < 8:
+            name, cmd = jobs.pop(0)
+            running.append((name, subprocess.Popen(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)))
+        name, p = running.pop(0)
+        reap(name, p)
+    for name, cmd in links:
         print(name, "link rc", subprocess.call(cmd, cwd=CSRC))
 
 
