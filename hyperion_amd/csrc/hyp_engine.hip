@@ -2485,6 +2485,8 @@ static int solve_pda(hyp_handle h)
                                                              h->d_pda_a, h->d_pda_b);
             for (unsigned int k = 0; k + 1 < n_pda; k++) {
                 const unsigned int rows = n_pda - k - 1;
+                pda_pivot_kernel<<<1, 1024, 0, h->stream>>>(h->d_pda_a, n_pda, k, (unsigned int *)h->d_pda_f);       // f[0 .. k] is free: the pivot row's index lives in f[0]
+                pda_swap_kernel<<<std::min(64u, (rows + 256) / 256), 256, 0, h->stream>>>(h->d_pda_a, h->d_pda_b, n_pda, k, (const unsigned int *)h->d_pda_f);
                 pda_elim_factor_kernel<<<(rows + 255) / 256, 256, 0, h->stream>>>(h->d_pda_a, n_pda, k, h->d_pda_f);
                 pda_elim_update_kernel<<<dim3(std::min(8u, (rows + 255) / 256), rows), 256, 0, h->stream>>>(h->d_pda_a, h->d_pda_b, n_pda, k, h->d_pda_f);
             }

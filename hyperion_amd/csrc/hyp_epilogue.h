@@ -276,9 +276,10 @@ __global__ __launch_bounds__(1024) void pda_gs_kernel(const DProblem *__restrict
 
 // solve_pda_indiv_exact :185-256 -- fewer than 10 000 PDA cells: the dense system  a x = b  with one row per cell's
 // equation  sum_walls c (e_next - e_curr) = 0  (unknown neighbours on the left, Monte Carlo neighbours on the right),
-// solved by Gaussian elimination.  Every row is diagonally dominant (|a_qq| = sum of its coefficients >= the sum of
-// its off-diagonal entries), so the elimination needs no pivoting.  The matrix is sparse (7-point stencil); rows whose
-// entry in the pivot column is zero are skipped, so the work follows the fill-in, not n^3.
+// solved by Gaussian elimination with partial pivoting.  Every row is diagonally dominant (|a_qq| = sum of its coefficients
+// >= the sum of its off-diagonal entries), so the pivot search normally confirms the diagonal; it matters where the 1e-100
+// clamp of pda_coef leaves rows of wildly different scale.  The matrix is sparse (7-point stencil); rows whose entry in the
+// pivot column is zero are skipped, so the work follows the fill-in, not n^3.
 __global__ void pda_dense_build_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
                                        const unsigned int *__restrict__ id_of_cell, const double *__restrict__ coef,
                                        const double *__restrict__ e_mean, double *__restrict__ a, double *__restrict__ b)
@@ -311,7 +312,39 @@ __global__ void pda_id_kernel(const unsigned int *__restrict__ cells, unsigned i
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pda; q += step) id_of_cell[cells[q]] = (unsigned int)q;
 }
 
-// elimination step k: factors f[r] = a[r][k] / a[k][k] for the rows below the pivot ...
+// elimination step k, partial pivoting (the reference calls fortranlib's lineq_gausselim, grid_pda_3d.f90:246): the row at or
+// below k with the largest |a[r][k]| -- the first of them, like the oracle's search -- is found by one workgroup ...
+__global__ __launch_bounds__(1024) void pda_pivot_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, unsigned int *__restrict__ piv)
+{
+    __shared__ double big_s[16];
+    __shared__ unsigned int row_s[16];
+    double big = -1.0; unsigned int row = k;
+    for (unsigned int r = k + threadIdx.x; r < n; r += blockDim.x) {        // ascending r per thread: a strict > keeps the first maximum
+        const double v = fabs(a[(size_t)r * n + k]);
+        if (v > big) { big = v; row = r; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(big, off, 64);
+        const unsigned int orow = __shfl_xor(row, off, 64);
+        if (ob > big || (ob == big && orow < row)) { big = ob; row = orow; }
+    }
+    if (__lane_id() == 0) { big_s[threadIdx.x >> 6] = big; row_s[threadIdx.x >> 6] = row; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (unsigned int w = 1; w < blockDim.x / 64; w++) if (big_s[w] > big || (big_s[w] == big && row_s[w] < row)) { big = big_s[w]; row = row_s[w]; }
+        *piv = row;
+    }
+}
+// ... and exchanged with row k (columns >= k: the others are already zero in both; and the right-hand side)
+__global__ void pda_swap_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const unsigned int *__restrict__ piv)
+{
+    const unsigned int p = *piv;
+    if (p == k) return;
+    double *rk = a + (size_t)k * n, *rp = a + (size_t)p * n;
+    for (unsigned int c = k + blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) { const double t = rk[c]; rk[c] = rp[c]; rp[c] = t; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = b[k]; b[k] = b[p]; b[p] = t; }
+}
+// then the factors f[r] = a[r][k] / a[k][k] for the rows below the pivot ...
 __global__ void pda_elim_factor_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, double *__restrict__ f)
 {
     const unsigned int r = k + 1 + blockIdx.x * blockDim.x + threadIdx.x;

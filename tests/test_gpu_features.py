@@ -107,6 +107,28 @@ def test_pda_parity_exact_branch():
     np.testing.assert_allclose(a[0][pda], b[0][pda], rtol=1e-4)
 
 
+def test_pda_exact_branch_with_an_empty_pocket_pivots_like_the_oracle():
+    """A hollow of eight empty cells inside the opaque block: two empty PDA cells side by side have no Rosseland depth between
+    them, solve_pda_indiv_exact clamps the sum at 1e-100 (grid_pda_3d.f90:222) and the row of such a cell carries coefficients
+    of 1e100 next to rows of order one -- the system lineq_gausselim is given, solved here with partial pivoting on the
+    device and by the oracle's own pivoting elimination."""
+    prob = pda_block_problem()
+    n = prob.density.shape[1]
+    prob.density[0, n // 2 - 1:n // 2 + 1, n // 2 - 1:n // 2 + 1, n // 2 - 1:n // 2 + 1] = 0.0
+    eng, orc, res = both(prob, 30000)
+    a, b = res[0]
+    n_dev, n_orc = eng.get_option("pda_last_cells"), orc.pda_last_cells()
+    c = orc.n_photons()
+    eng.close(); orc.close()
+    assert n_orc > 64 and n_dev == n_orc
+    assert np.all(np.isfinite(a)) and np.all(np.isfinite(b))
+    pda = (c < 30)
+    filled = prob.density[0] > 0
+    assert (pda & ~filled).sum() == 8          # the pocket is solved for, not sampled
+    np.testing.assert_allclose(a[0][~pda], b[0][~pda], rtol=1e-9)
+    np.testing.assert_allclose(a[0][pda & filled], b[0][pda & filled], rtol=1e-4)
+
+
 def test_pda_iterative_branch_follows_the_reference_sweeps():
     """More than 10 000 PDA cells: Gauss-Seidel in cell order down to 1e-4 per sweep; the hyperplane-ordered sweeps of the
     device give each cell the operands of the sequential loop, so the two agree far below that tolerance."""
