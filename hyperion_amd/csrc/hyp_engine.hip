@@ -246,6 +246,7 @@ struct hyp_engine {
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
+    int pt_lds_kb = 128;            // option: LDS of the densities and accumulators of one polar-grid brick in KB (hyp_ptile.h)
     int vt_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU; 78: room for two of 512 threads)
     int vt_clusters = 0, vt_max_cells = 0, vt_built_for = -1;
     size_t vt_max_lds = 0;          // LDS of the largest cluster: tables + densities + accumulators
@@ -421,6 +422,8 @@ TileKernels pick_tile_kernels(int nd, int grid_type)
     case 2: return pick_tile_kernels_g<GEOM_OCT>(nd);
     case 4: return pick_tile_kernels_g<GEOM_AMR>(nd);
     case 3: return pick_tile_kernels_g<GEOM_VOR>(nd);
+    case 5: return pick_tile_kernels_g<GEOM_SPH>(nd);
+    case 6: return pick_tile_kernels_g<GEOM_CYL>(nd);
     default: { TileKernels k; memset(&k, 0, sizeof k); return k; }
     }
 }
@@ -442,6 +445,19 @@ int tile_bricks(const DProblem &P, int nd)
     return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
 }
 
+// Bricks of a polar grid (hyp_ptile.h): boxes of (r, theta, phi) / (w, z, phi) indices whose densities and accumulators fit `cells`
+// cells of LDS.  Packets move mostly along r, so the brick is long in the first index: at most 8 cells in phi, 32 in theta / z,
+// and what is left of the budget in r; theta / z shrink before r falls below 16 cells.
+void polar_tile_shape(const DProblem &P, int nd, int lds_kb, int &x, int &y, int &z)
+{
+    const long long cells = std::max<long long>(64, (long long)lds_kb * 1024 / (16ll * nd));
+    z = (int)std::min<long long>(P.n3, 8);
+    y = (int)std::min<long long>(P.n2, 32);
+    while ((long long)y * z * 16 > cells && y > 1) y = (y + 1) / 2;
+    while ((long long)y * z * 16 > cells && z > 1) z = (z + 1) / 2;
+    x = (int)std::max<long long>(1, std::min<long long>(P.n1, cells / ((long long)y * z)));
+}
+
 // LDS of one AMR brick (hyp_atile.h): n cells, g goto entries (16 bits), w walls
 size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd) { return sizeof(double) * (2 * n * nd + w) + sizeof(short) * g + 16; }
 
@@ -453,6 +469,8 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool
 {
     if (h->hp.grid_type == 3)       // cluster: its tables (VtInfo) + densities + accumulators
         return h->vt_max_lds;
+    if (h->hp.grid_type == 5 || h->hp.grid_type == 6)      // polar brick: densities + accumulators
+        return sizeof(double) * 2 * (size_t)T.bx * T.by * T.bz * K.nd;
     if (h->hp.grid_type == 4)       // slab: densities + accumulators + walls + goto slice
         return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
@@ -608,6 +626,10 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     } else if (P.grid_type == 2) {
         T.bx = h->ot_max_cells; T.by = h->ot_max_kids; T.bz = 1;
         T.nbx = T.n_bricks = h->ot_clusters; T.nby = T.nbz = 1;
+    } else if (P.grid_type == 5 || P.grid_type == 6) {
+        polar_tile_shape(P, nd, h->pt_lds_kb, T.bx, T.by, T.bz);
+        T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
+        T.n_bricks = T.nbx * T.nby * T.nbz;
     } else {
         tile_shape(nd, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
@@ -2627,13 +2649,21 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && h->oct_neighbours;
         tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 2000000ull;
     }
+    else if (P.grid_type == 5 || P.grid_type == 6) {
+        // spherical / cylindrical polar grids: index bricks in LDS (hyp_ptile.h)
+        int bx, by, bz;
+        polar_tile_shape(P, h->n_dust, h->pt_lds_kb, bx, by, bz);
+        const long long nb = (long long)((P.n1 + bx - 1) / bx) * ((P.n2 + by - 1) / by) * ((P.n3 + bz - 1) / bz);
+        tile_ok = h->n_dust <= 4 && nb <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
+        tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 2000000ull;
+    }
     else if (P.grid_type == 4) {
         // AMR: bricks of the grids in LDS (hyp_atile.h)
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins;
         tile_auto = tile_ok && h->n_cells >= 32768 && n_local >= 2000000ull;
     }
     bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto && !h->tile_unbuildable));
-    if (tiled && P.grid_type != 1) {
+    if (tiled && (P.grid_type == 2 || P.grid_type == 3 || P.grid_type == 4)) {
         // the builders have limits of their own (HYP_TILE_MAX_BRICKS clusters / bricks, the LDS budget, 16-bit grid numbers):
         // a grid beyond them runs on the persistent kernel as before; only a FORCED tiled iteration (lucy_mode = 1) reports the limit
         const int rc = P.grid_type == 4 ? build_amr_slabs(h) : P.grid_type == 3 ? build_vor_clusters(h) : build_oct_clusters(h);
@@ -2870,6 +2900,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; }
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; }
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; }
+    else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; }      // cells per Voronoi cluster (0: fill the LDS budget)
     else if (n == "tile_park") h->tile_park = (int)value;
@@ -2923,6 +2954,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "ot_cells") *value = h->ot_cells;
     else if (n == "ot_clusters") *value = h->ot_clusters;
     else if (n == "ot_max_cells") *value = h->ot_max_cells;
+    else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;
     else if (n == "vt_max_cells") *value = h->vt_max_cells;

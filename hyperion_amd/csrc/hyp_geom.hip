@@ -25,6 +25,8 @@
 #include "hyp_otile.h"
 #elif HYP_GEOM_TU == 3
 #include "hyp_atile.h"
+#elif HYP_GEOM_TU == 4 || HYP_GEOM_TU == 5
+#include "hyp_ptile.h"
 #endif
 #endif
 #if HYP_PART == 3
@@ -135,7 +137,7 @@ static TileKernels tile_kernels()
     TileKernels k;
     memset(&k, 0, sizeof k);
     k.nd = NDT;
-    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_VOR || GEOM == GEOM_OCT || GEOM == GEOM_AMR) {
+    {
         k.interact[0][0] = tile_interact_kernel<NDT, false, false, GEOM>; k.interact[1][0] = tile_interact_kernel<NDT, true, false, GEOM>;
         k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
         k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
@@ -166,6 +168,13 @@ static TileKernels tile_kernels()
 #endif
         k.walk_threads = HYP_TILE_WG;
         k.bx = TileShape<NDT>::X; k.by = TileShape<NDT>::Y; k.bz = TileShape<NDT>::Z;
+    }
+#elif HYP_GEOM_TU == 4 || HYP_GEOM_TU == 5
+    {
+        k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
+        k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
+        k.walk = ptile_walk_kernel<NDT, GEOM>;
+        k.walk_threads = HYP_PTILE_WG;
     }
 #elif HYP_GEOM_TU == 2
     {      // the modified random walk is not defined on Voronoi grids (the engine refuses it)

@@ -158,6 +158,39 @@ template <> struct TileCellIO<GEOM_VOR> {
     }
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 16; }
 };
+// Polar grids (hyp_ptile.h): cells are numbered (i1, i2, i3) like on Cartesian grids; the spherical grid's `radial` (the sign of
+// r.v at the start of the integration, Cell<GEOM_SPH>) rides in bit 6 of ow
+template <> struct TileCellIO<GEOM_SPH> {
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_SPH> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) c.ic[a] = H.ic[a];
+        unpack_ow(H.ow & 63, c.ow);
+        c.radial = (H.ow >> 6) & 1;
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_SPH> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) H.ic[a] = c.ic[a];
+        H.ow = pack_ow(c.ow) | ((c.radial ? 1 : 0) << 6);
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_SPH> &c) { return brick_of(T, c.ic); }
+};
+template <> struct TileCellIO<GEOM_CYL> {
+    template <int ND> static __device__ __forceinline__ void load(const DProblem &P, const HotRec<ND> &H, Cell<GEOM_CYL> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) c.ic[a] = H.ic[a];
+        unpack_ow(H.ow, c.ow);
+    }
+    template <int ND> static __device__ __forceinline__ void store(const DProblem &P, HotRec<ND> &H, const Cell<GEOM_CYL> &c)
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++) H.ic[a] = c.ic[a];
+        H.ow = pack_ow(c.ow);
+    }
+    static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_CYL> &c) { return brick_of(T, c.ic); }
+};
 // AMR (hyp_atile.h): ic = (cell, grid, brick); the position in the grid follows from the cell id
 __device__ __forceinline__ int amr_brick_of(const DProblem &P, int grid, const int i[3])
 {

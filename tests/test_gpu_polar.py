@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 INT_KEYS = ("crossings", "interactions", "killed_geo", "killed_int")
 
 
-def run_both(prob, n, iters=1, n_img=0, rtol=1e-9):
+def run_both(prob, n, iters=1, n_img=0, rtol=1e-9, **options):
     eng = hyperion_amd.Engine(prob)
+    for k, v in options.items():
+        eng.set_option(k, v)
     orc = Oracle(prob)
     for it in range(1, iters + 1):
         a, sa = eng.lucy_iteration(n, it)
@@ -36,6 +38,8 @@ def run_both(prob, n, iters=1, n_img=0, rtol=1e-9):
             for name in gb:
                 np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)
         res = ra
+    if options.get("lucy_mode") == 1:
+        assert eng.get_option("last_lucy_mode") == 1
     eng.close(); orc.close()
     return a, sa, res
 
@@ -113,6 +117,62 @@ def test_cylindrical_disc_with_images():
                 grid_type="cyl_pol")
     a, st, _ = run_both(p, 40000, iters=2, n_img=40000)
     assert st["killed_geo"] == 0
+
+
+# --- the brick-tiled Lucy schedule on polar grids (hyp_ptile.h): bricks of (r, theta, phi) / (w, z, phi) indices in LDS --------
+# small bricks (pt_lds_kb = 1: 64 cells), small slot pools and tasks, so that packets change brick, wait and refill all the time
+PT = dict(lucy_mode=1, pt_lds_kb=1, tile_slots=8192, tile_task=256, tile_drain=200)
+
+
+@pytest.mark.parametrize("grid", ["sph", "cyl"])
+def test_ptile_reference_models(grid):
+    """the reference's regression model (7 x 5 x 3 cells, five sources, three species in the True.True variant) on the tiled schedule"""
+    for name in ("False.False", "True.True"):
+        prob, _ = golden_problem("%s_specific_energy.%s.npz" % (grid, name))
+        a, st, _ = run_both(prob, 30000, iters=2, **PT)
+        assert st["killed_geo"] == 0
+
+
+def test_ptile_config0_and_periodic_phi():
+    """configs[0]'s shape (source on the origin), then twelve phi cells with logarithmic r walls and a cavity: bricks of 16 x 4 x 1
+    and 8 x 4 x 2 cells, packets crossing the phi = 0 seam between the first and the last brick"""
+    a, st, _ = run_both(config0_problem(), 100000, **PT)
+    assert st["killed_geo"] == 0 and st["killed_int"] == 0
+    a, st, _ = run_both(config0_problem(n_r=40, n_t=24, n_p=12, log_r=True), 60000, iters=2, **PT)
+    assert st["killed_geo"] == 0
+    # one brick holds the whole grid (the default budget): visits end only with interactions
+    a, st, _ = run_both(config0_problem(n_r=40, n_t=24, n_p=12, log_r=True), 60000, lucy_mode=1, tile_slots=16384, tile_task=512)
+    assert st["killed_geo"] == 0
+
+
+def test_ptile_cylindrical_disc_with_a_reabsorbing_sphere():
+    w = np.hstack([0.0, np.logspace(np.log10(0.02 * PC), np.log10(PC), 30)])
+    z = np.linspace(-0.5 * PC, 0.5 * PC, 21)
+    ph = np.linspace(0.0, 2 * np.pi, 9)
+    wc = 0.5 * (w[1:] + w[:-1]); zc = 0.5 * (z[1:] + z[:-1])
+    dens = (3.0 / PC) * np.exp(-0.5 * (zc[None, :, None] / (0.15 * PC)) ** 2) * np.ones((8, 1, 1)) * (wc[None, None, :] > 0.03 * PC)
+    src = [Source(type="point", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0)),
+           Source(type="sphere", luminosity=0.3 * LSUN, temperature=4000.0, position=(0.3 * PC, 0.1 * PC, 0.05 * PC), radius=0.01 * PC)]
+    p = Problem(walls=[w, z, ph], density=dens[None], dust=[load_test_dust()], sources=src, config=RunConfig(), grid_type="cyl_pol")
+    a, st, _ = run_both(p, 60000, iters=2, **PT)
+    assert st["killed_geo"] == 0
+
+
+def test_ptile_matches_persistent_at_scale():
+    """400 x 200 cells (the benchmark row of tools/r03_other.py) at 3e6 packets: auto mode picks the tiled schedule, integer tallies
+    equal to the persistent kernel's, sums to rounding"""
+    prob = config0_problem(n_r=400, n_t=200, tau=3.0)
+    res = []
+    for mode in (0, -1):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("lucy_mode", mode)
+        res.append(eng.lucy_iteration(3_000_000, 1))
+        assert eng.get_option("last_lucy_mode") == (0 if mode == 0 else 1)
+        eng.close()
+    (a, sa), (b, sb) = res
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert_parity(a, b)
 
 
 @pytest.mark.parametrize("grid", ["sph_pol", "cyl_pol"])

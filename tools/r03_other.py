@@ -57,7 +57,11 @@ e.close()
 # (d) spherical polar grid: configs[0]'s shape at 400 x 200 x 1 cells
 from test_gpu_polar import config0_problem
 p = config0_problem(n_r=400, n_t=200, tau=3.0)
-e = hyperion_amd.Engine(p)
-e.lucy_iteration(n // 10, 1, want_output=False)
-_, st = e.lucy_iteration(n, 2, want_output=False); line("spherical polar 400 x 200 (configs[0]'s shape), Lucy iteration, persistent kernel", n, e.last_kernel_ms()[0], st)
-e.close()
+for mode in (0, -1):
+    e = hyperion_amd.Engine(p)
+    e.set_option("lucy_mode", mode)
+    e.lucy_iteration(n // 10 if mode == 0 else n, 1, want_output=False)
+    _, st = e.lucy_iteration(n, 2, want_output=False)
+    line("spherical polar 400 x 200 (configs[0]'s shape), Lucy iteration, %s" % ("brick-tiled (hyp_ptile.h)" if e.get_option("last_lucy_mode") == 1 else "persistent kernel"),
+         n, e.last_kernel_ms()[0], st)
+    e.close()

@@ -1,5 +1,5 @@
 """The single-GPU workloads of BASELINE.json that are profiled besides the bench command (tools/r03_profile.sh):
-   python tools/r03_workload.py oct_lucy|oct_img|vor|amr [packets] [opt=value ...]
+   python tools/r03_workload.py oct_lucy|oct_img|vor|amr|sph [packets] [opt=value ...]
 Runs one warm-up (a tenth of the packets) and two timed iterations; prints the timings and one line
 `PROFILE_TOTALS {json}` with the crossings / packets of ALL iterations of the process (what a rocprofv3 pass sees)."""
 import json, os, sys
@@ -16,6 +16,11 @@ n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 100_000_000
 if which == "amr":
     from hyperion_amd.benchmark import make_amr_problem
     p = make_amr_problem(n=64, levels=3)
+    n_dust = 1
+elif which == "sph":
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_polar import config0_problem
+    p = config0_problem(n_r=400, n_t=200, tau=3.0)
     n_dust = 1
 elif which == "vor":
     from cases import voronoi_big_problem
