@@ -24,9 +24,9 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
-PARTS = {"lucy": 0, "tile": 1, "final": 2, "defer": 3, "ray": 4}
+PARTS = {"lucy": 0, "tile": 1, "final": 2, "defer": 3, "ray": 4, "finalp": 5}
 # heaviest first: the pool starts them first so that the long poles do not land at the end
-_COST = {"final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
+_COST = {"finalp": 6, "final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
 
 
 def units():

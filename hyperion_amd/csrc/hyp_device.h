@@ -351,20 +351,6 @@ struct DeferBuf {
 #endif
 #define HYP_SORT_PER_WG 8192      // event slots per workgroup of the sort kernels
 
-// Staged imaging iteration (hyp_stage.h): slot records, one event per slot and round
-struct StageCtl {
-    unsigned long long n_live;          // packets in flight after the round's event kernel
-    unsigned long long walk_cursor;     // slots handed out by the round's walk kernel
-    unsigned long long n_events;        // events written in the round
-    unsigned long long pad;
-};
-
-struct StageBuf {
-    void *hot, *cold, *events;          // StageHot[n_slots], SuspRec[n_slots], PeelEvent[n_slots]
-    StageCtl *ctl;
-    unsigned long long n_slots;
-};
-
 // ---------------------------------------------------------------------------
 // Philox4x32-10, one stream pair per packet (counter = packet id, block, stream)
 // ---------------------------------------------------------------------------

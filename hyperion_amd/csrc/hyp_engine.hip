@@ -289,11 +289,7 @@ struct hyp_engine {
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
-    int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h), 2 = the staged schedule (hyp_stage.h), 0 = inline
-    long long stage_slots = 8ll << 20;      // option: slot records of the staged schedule
-    void *d_stage_hot = nullptr, *d_stage_cold = nullptr;
-    StageCtl *d_stage_ctl = nullptr, *h_stage_ctl = nullptr;
-    size_t stage_alloc = 0, stage_hot_bytes = 0, stage_cold_bytes = 0;
+    int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h), 0 = inline
     long long peel_events = 128ll << 20;    // option: capacity of the event buffer, in events (the ceiling: 8 per packet are asked for, and half as many
                                             // again and again while the allocation fails; 16 Mi until round 3: 1e8 packets then took 15 rounds)
     int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
@@ -393,17 +389,19 @@ DeferKernels pick_defer_kernels(int nd, int grid_type)
 
 LucyKernel pick_final_kernel(int nd, int grid_type, int mode)
 {
-#ifdef HYP_VARIANT_GEOM   // tuning builds (tools/variants.py) link one geometry unit only
-    return pick_final_kernel_g<HYP_VARIANT_GEOM>(nd, mode);
+#define HYP_PICK_FINAL(G) (mode == 0 || nd > 4 ? pick_final_kernel_g<G>(nd) : pick_final_special_g<G>(nd, mode))
+#ifdef HYP_VARIANT_GEOM
+    return HYP_PICK_FINAL(HYP_VARIANT_GEOM);
 #endif
     switch (grid_type) {
-    case 2: return pick_final_kernel_g<GEOM_OCT>(nd, mode);
-    case 3: return pick_final_kernel_g<GEOM_VOR>(nd, mode);
-    case 4: return pick_final_kernel_g<GEOM_AMR>(nd, mode);
-    case 5: return pick_final_kernel_g<GEOM_SPH>(nd, mode);
-    case 6: return pick_final_kernel_g<GEOM_CYL>(nd, mode);
-    default: return pick_final_kernel_g<GEOM_CAR>(nd, mode);
+    case 2: return HYP_PICK_FINAL(GEOM_OCT);
+    case 3: return HYP_PICK_FINAL(GEOM_VOR);
+    case 4: return HYP_PICK_FINAL(GEOM_AMR);
+    case 5: return HYP_PICK_FINAL(GEOM_SPH);
+    case 6: return HYP_PICK_FINAL(GEOM_CYL);
+    default: return HYP_PICK_FINAL(GEOM_CAR);
     }
+#undef HYP_PICK_FINAL
 }
 
 }  // namespace
@@ -830,8 +828,6 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_accum); free_dev(h->d_jnu_id); free_dev(h->d_jnu_frac); free_dev(h->d_energy_abs_tot);
     free_dev(h->d_mrw_alpha); free_dev(h->d_mrw_diff); free_dev(h->d_mrw_kp);
     free_dev(h->d_scratch); free_dev(h->d_counter); free_dev(h->d_err); free_dev(h->d_err_data);
-    free_dev(h->d_stage_hot); free_dev(h->d_stage_cold); free_dev(h->d_stage_ctl);
-    if (h->h_stage_ctl) { (void)hipHostFree(h->h_stage_ctl); h->h_stage_ctl = nullptr; }
     free_dev(h->d_peel_events); free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
     free_dev(h->d_peel_order); free_dev(h->d_peel_keys); free_dev(h->d_peel_bins); free_dev(h->d_ff);
     free_dev(h->d_peel_ctl);
@@ -2882,10 +2878,9 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
-    else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 2 ? 2 : (int)value;
+    else if (n == "defer_peel") h->defer_peel = value != 0 ? 1 : 0;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
-    else if (n == "stage_slots") { if (value < 256) return h->set_error("stage_slots must be at least 256"); h->stage_slots = value; }
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
     else if (n == "peel_events") {
         if (value < 1) return h->set_error("peel_events must be positive");
@@ -2938,7 +2933,6 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "peel_sort") *value = h->peel_sort;
     else if (n == "ff_prepass") *value = h->ff_prepass;
     else if (n == "last_ff_prepass") *value = h->last_ff_prepass;
-    else if (n == "stage_slots") *value = h->stage_slots;
     else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
     else if (n == "plain_imaging") *value = h->plain_imaging ? 1 : 0;
@@ -3088,70 +3082,6 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
     return 0;
 }
 
-// start of a round of the staged imaging iteration (hyp_stage.h): counters to zero; the peel kernel looks at every slot's event
-static __global__ void stage_reset_kernel(StageCtl *ctl, PeelCtl *pctl, unsigned long long n_slots)
-{
-    ctl->n_live = 0; ctl->walk_cursor = 0; ctl->n_events = 0;
-    pctl->reserved = n_slots; pctl->pair_cursor = 0; pctl->written = 0;
-}
-
-// Rounds of {event, peel, walk} over a pool of slot records until the packet ids are used up and no slot is live (hyp_stage.h).
-static int run_staged_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, size_t lds, uint64_t n_local)
-{
-    size_t n_slots = (size_t)std::min<unsigned long long>((unsigned long long)h->stage_slots, std::max<unsigned long long>(n_local, 256ull));
-    n_slots = (n_slots + 255) / 256 * 256;
-    if (h->stage_alloc < n_slots || h->stage_hot_bytes != dk.hot_bytes || h->stage_cold_bytes != dk.susp_bytes || h->peel_event_bytes != dk.event_bytes || h->peel_cap < n_slots) {
-        free_dev(h->d_stage_hot); free_dev(h->d_stage_cold); free_dev(h->d_peel_events);
-        h->stage_alloc = 0; h->peel_cap = 0;
-        if (hipMalloc(&h->d_stage_hot, n_slots * dk.hot_bytes) != hipSuccess || hipMalloc(&h->d_stage_cold, n_slots * dk.susp_bytes) != hipSuccess ||
-            hipMalloc(&h->d_peel_events, n_slots * dk.event_bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            free_dev(h->d_stage_hot); free_dev(h->d_stage_cold); free_dev(h->d_peel_events);
-            return h->set_error("cannot allocate the slot records of the staged imaging iteration");
-        }
-        h->stage_alloc = n_slots; h->stage_hot_bytes = dk.hot_bytes; h->stage_cold_bytes = dk.susp_bytes;
-        h->peel_cap = n_slots; h->peel_event_bytes = dk.event_bytes;
-        free_dev(h->d_peel_susp[0]); free_dev(h->d_peel_susp[1]); free_dev(h->d_peel_ret[0]); free_dev(h->d_peel_ret[1]);
-        h->peel_lanes = 0;      // the deferred schedule re-allocates its buffers if it runs after this one
-    }
-    if (!h->d_stage_ctl && (hipMalloc((void **)&h->d_stage_ctl, sizeof(StageCtl)) != hipSuccess || hipHostMalloc((void **)&h->h_stage_ctl, sizeof(StageCtl)) != hipSuccess))
-        return h->set_error("cannot allocate the control block of the staged imaging iteration");
-    if (!h->d_peel_ctl && (hipMalloc((void **)&h->d_peel_ctl, sizeof(PeelCtl)) != hipSuccess || hipHostMalloc((void **)&h->h_peel_ctl, sizeof(PeelCtl)) != hipSuccess ||
-                           hipHostMalloc((void **)&h->h_peel_counter, sizeof(unsigned long long)) != hipSuccess))
-        return h->set_error("cannot allocate the control block of the peel kernel");
-    StageBuf S;
-    S.hot = h->d_stage_hot; S.cold = h->d_stage_cold; S.events = h->d_peel_events; S.ctl = h->d_stage_ctl; S.n_slots = n_slots;
-    DeferBuf B;
-    std::memset(&B, 0, sizeof B);
-    B.events = h->d_peel_events; B.cap = n_slots; B.ctl = h->d_peel_ctl;
-    int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
-    const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.stage_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;
-    const unsigned walk_blocks = (unsigned)std::min<size_t>((size_t)h->n_cu * occ, n_slots / 256);
-    const unsigned slot_blocks = (unsigned)(n_slots / 256);
-    hipLaunchKernelGGL(dk.stage_init, dim3(slot_blocks), dim3(256), 0, h->stream, S);
-    for (int round = 0;; round++) {
-        hipLaunchKernelGGL(stage_reset_kernel, dim3(1), dim3(1), 0, h->stream, h->d_stage_ctl, h->d_peel_ctl, (unsigned long long)n_slots);
-        hipLaunchKernelGGL(dk.stage_event, dim3(slot_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, S);
-        (void)hipMemcpyAsync(h->h_stage_ctl, h->d_stage_ctl, sizeof(StageCtl), hipMemcpyDeviceToHost, h->stream);
-        (void)hipMemcpyAsync(h->h_peel_counter, h->d_counter, sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream);
-        hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
-        hipLaunchKernelGGL(dk.stage_walk, dim3(walk_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, S, L.iter_tag);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return h->set_error(std::string("staged imaging launch: ") + hipGetErrorString(e));
-        e = hipStreamSynchronize(h->stream);
-        if (e != hipSuccess) return h->set_error(std::string("propagation failed: ") + hipGetErrorString(e));
-        h->last_defer_rounds = round + 1;
-        h->last_defer_events += h->h_stage_ctl->n_events;
-        if (h->h_stage_ctl->n_live == 0 && *h->h_peel_counter >= L.end_id) break;
-        if (round > 10000000) return h->set_error("staged imaging iteration did not terminate");
-        int err = 0;
-        if (hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess || err != 0) break;     // reported by hyp_final_accumulators
-    }
-    return 0;
-}
-
 int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
 {
     if (!h) return 1;
@@ -3189,7 +3119,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         bpc = occ;
     }
     long long blocks = (long long)h->n_cu * bpc;
-    if (deferred && h->defer_peel != 2 && defer_buffers(h, dk, (size_t)blocks * 256, n_local)) deferred = false;      // no memory for the buffers: peel off inline
+    if (deferred && defer_buffers(h, dk, (size_t)blocks * 256, n_local)) deferred = false;      // no memory for the buffers: peel off inline
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
@@ -3206,14 +3136,6 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : (deferred ? 16 : 32);
     L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : (!deferred ? 32 : h->hp.grid_type == 1 ? 16 : 48);
     h->last_defer_rounds = 0; h->last_defer_events = 0;
-    if (deferred && h->defer_peel == 2 && dk.stage_event) {
-        (void)hipEventRecord(h->ev0, h->stream);
-        if (run_staged_rounds(h, dk, L, lds, n_local)) return 1;
-        (void)hipEventRecord(h->ev1, h->stream);
-        h->final_pending = true;
-        h->pending_packets = n_local;
-        return 0;
-    }
     if (deferred) {
         (void)hipEventRecord(h->ev0, h->stream);
         if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds)) return 1;

@@ -3,7 +3,7 @@
 // parallel, and links the objects with hyp_engine.hip into libhyperion_amd.so).  Every unit includes only the
 // headers of its family, so that an edit of one schedule recompiles the units that carry it and nothing else.
 //   HYP_PART 0: lucy_kernel      1: the tiled Lucy schedules (hyp_tiled.h + hyp_vtile.h / hyp_otile.h / hyp_atile.h)
-//            2: final_kernel     3: deferred / staged imaging (hyp_defer.h, hyp_stage.h)      4: ray_kernel
+//            2: final_kernel, general     5: final_kernel, plain and lean     3: deferred imaging (hyp_defer.h)     4: ray_kernel
 // Species counts: 1-4 are compile-time (registers hold the per-species state); 5-8 run on the HYP_MAXD instances that
 // read the count from the problem -- only the persistent Lucy kernel, the general imaging kernel and the raytracing
 // kernel exist in that form (the engine does not pick a plain / lean / deferred / tiled schedule above four species).
@@ -14,7 +14,7 @@
 #define HYP_ONLY_ND 1
 #endif
 #ifndef HYP_PART
-#error "compile with -DHYP_PART=0..4 (hyperion_amd/build.py)"
+#error "compile with -DHYP_PART=0..5 (hyperion_amd/build.py)"
 #endif
 #include "hyp_kernels.h"
 #if HYP_PART == 1
@@ -31,7 +31,6 @@
 #endif
 #if HYP_PART == 3
 #include "hyp_defer.h"
-#include "hyp_stage.h"
 #endif
 #include "hyp_pick.h"
 #include <cstring>
@@ -58,9 +57,28 @@ LucyKernel pick_lucy_kernel_g(int nd)
 
 #if HYP_PART == 2
 template <int GEOM>
-LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plain, 2 lean (final_kernel<.., false, true>)
+LucyKernel pick_final_kernel_g(int nd)      // the general imaging kernel final_kernel<nd, GEOM, false>
 {
-#define HYP_FINAL_PICK(N) (mode == 1 ? final_kernel<N, GEOM, true> : mode == 2 ? final_kernel<N, GEOM, false, true> : final_kernel<N, GEOM, false>)
+#ifdef HYP_ONLY_ND
+    (void)nd;
+    return final_kernel<HYP_ONLY_ND, GEOM, false>;
+#else
+    switch (nd) {
+    case 1: return final_kernel<1, GEOM, false>;
+    case 2: return final_kernel<2, GEOM, false>;
+    case 3: return final_kernel<3, GEOM, false>;
+    case 4: return final_kernel<4, GEOM, false>;
+    default: return final_kernel<HYP_MAXD, GEOM, false>;      // five to eight species: the general kernel only
+    }
+#endif
+}
+#endif
+
+#if HYP_PART == 5
+template <int GEOM>
+LucyKernel pick_final_special_g(int nd, int mode)      // mode 1: plain (final_kernel<.., true>), 2: lean (final_kernel<.., false, true>); one to four species
+{
+#define HYP_FINAL_PICK(N) (mode == 1 ? final_kernel<N, GEOM, true> : final_kernel<N, GEOM, false, true>)
 #ifdef HYP_ONLY_ND
     (void)nd;
     return HYP_FINAL_PICK(HYP_ONLY_ND);
@@ -69,13 +87,11 @@ LucyKernel pick_final_kernel_g(int nd, int mode)      // mode: 0 general, 1 plai
     case 1: return HYP_FINAL_PICK(1);
     case 2: return HYP_FINAL_PICK(2);
     case 3: return HYP_FINAL_PICK(3);
-    case 4: return HYP_FINAL_PICK(4);
-    default: return final_kernel<HYP_MAXD, GEOM, false>;      // five to eight species: the general kernel only
+    default: return HYP_FINAL_PICK(4);
     }
 #endif
 #undef HYP_FINAL_PICK
 }
-
 #endif
 
 #if HYP_PART == 4
@@ -106,8 +122,6 @@ static DeferKernels defer_kernels()
     k.propagate = final_defer_kernel<NDT, GEOM, true>; k.propagate_pre = final_defer_kernel<NDT, GEOM, false>; k.ff_walk = ff_walk_kernel<NDT, GEOM>; k.peel = peel_kernel<NDT, GEOM, false>; k.peel_inside = peel_kernel<NDT, GEOM, true>; k.reset = defer_reset_kernel<GEOM>;
     k.event_bytes = sizeof(PeelEvent<NDT, GEOM>); k.susp_bytes = sizeof(SuspRec<NDT, GEOM>); k.ff_bytes = sizeof(EmitRec<NDT>);
     k.sort_hist = peel_sort_hist_kernel<NDT, GEOM>; k.sort_scatter = peel_sort_scatter_kernel<NDT, GEOM>; k.sort_scan = peel_sort_scan_kernel;
-    k.stage_event = stage_event_kernel<NDT, GEOM>; k.stage_walk = stage_walk_kernel<NDT, GEOM>; k.stage_init = stage_init_kernel<NDT, GEOM>;
-    k.hot_bytes = sizeof(StageHot<NDT, GEOM>);
     return k;
 }
 
@@ -209,7 +223,9 @@ template LucyKernel pick_lucy_kernel_g<HYP_GEOM_TU>(int);
 #elif HYP_PART == 1
 template TileKernels pick_tile_kernels_g<HYP_GEOM_TU>(int);
 #elif HYP_PART == 2
-template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int, int);
+template LucyKernel pick_final_kernel_g<HYP_GEOM_TU>(int);
+#elif HYP_PART == 5
+template LucyKernel pick_final_special_g<HYP_GEOM_TU>(int, int);
 #elif HYP_PART == 3
 template DeferKernels pick_defer_kernels_g<HYP_GEOM_TU>(int);
 #else

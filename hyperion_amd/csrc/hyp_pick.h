@@ -8,22 +8,18 @@ using LucyKernel = void (*)(const DProblem *, LaunchParams);
 using RayKernel = void (*)(const DProblem *, LaunchParams, int, double);
 
 template <int GEOM> LucyKernel pick_lucy_kernel_g(int nd);    // lucy_kernel<nd, GEOM>
-template <int GEOM> LucyKernel pick_final_kernel_g(int nd, int mode);     // final_kernel<nd, GEOM, ..>: 0 general, 1 plain, 2 lean
+template <int GEOM> LucyKernel pick_final_kernel_g(int nd);               // final_kernel<nd, GEOM, false>: the general imaging kernel
+template <int GEOM> LucyKernel pick_final_special_g(int nd, int mode);    // its specialisations, one to four species: 1 plain, 2 lean
 template <int GEOM> RayKernel pick_ray_kernel_g(int nd);      // ray_kernel<nd, GEOM>
 
 // deferred peel-off (hyp_defer.h): final_defer_kernel<nd, GEOM> / peel_kernel<nd, GEOM> and their record sizes
 using DeferKernel = void (*)(const DProblem *, LaunchParams, DeferBuf);
 using PeelKernel = void (*)(const DProblem *, DeferBuf, uint32_t);
 using PeelSortK = void (*)(const DProblem *, DeferBuf);
-using StageEventK = void (*)(const DProblem *, LaunchParams, StageBuf);
-using StageWalkK = void (*)(const DProblem *, StageBuf, uint32_t);
-using StageInitK = void (*)(StageBuf);
 struct DeferKernels {
     DeferKernel propagate, propagate_pre, ff_walk;       // propagate_pre: with the forced-first walks made ahead (ff_walk)
     PeelKernel peel, peel_inside; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
     PeelSortK sort_hist, sort_scatter; void (*sort_scan)(DeferBuf);  // sorted peel-off: keys + histogram, scatter (peel_sort_scan_kernel between them)
-    // staged schedule (hyp_stage.h): slot records StageHot (hot_bytes) + SuspRec (susp_bytes), one PeelEvent per slot
-    StageEventK stage_event; StageWalkK stage_walk; StageInitK stage_init; size_t hot_bytes;
 };
 template <int GEOM> DeferKernels pick_defer_kernels_g(int nd);
 

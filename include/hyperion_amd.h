@@ -343,15 +343,16 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
 /* tuning knobs (environment-independent): name in {"interact_threshold",
  * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
  * (-1 auto, 0 persistent kernel with global atomics, 1 tiled: bricks of a Cartesian grid, hyp_tiled.h; clusters of Voronoi
- * cells, hyp_vtile.h; runs of sibling subtrees of an octree, hyp_otile.h),
+ * cells, hyp_vtile.h; runs of sibling subtrees of an octree, hyp_otile.h; bricks of an AMR hierarchy's grids, hyp_atile.h; index bricks of a
+ * spherical / cylindrical polar grid, hyp_ptile.h),
  * "tile_slots" (0: 3 << 21, octree 3 << 22), "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "tile_park",
  * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb", "at_cells" / "at_lds_kb" (most cells per Voronoi / octree cluster / AMR brick; LDS
- * budget of a walk workgroup in KB: 156 = one 1024-thread workgroup per CU on octree and AMR grids, 78 = two 512-thread ones on Voronoi),
+ * budget of a walk workgroup in KB: 156 = one workgroup per CU), "pt_lds_kb" (LDS of a polar-grid brick's densities and accumulators),
  * "tile_time_walk" (1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches"; off by
  * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only),
  * "final_interact_threshold" /
  * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
- * imaging kernel applies, hyp_defer.h; 2: the staged schedule, hyp_stage.h; 0: inline), "peel_events" (capacity of its event buffer: at most
+ * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer: at most
  * 128 Mi events by default, fewer if the memory is not there),
  * "peel_sort" (1, the default: the peel kernel takes a round's events ordered by the cell they happened in), "ff_prepass" (1, the
  * default: with forced first interaction on, every packet's emission, escape walk and first optical depth are made ahead of the rounds by a

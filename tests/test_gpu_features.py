@@ -115,6 +115,10 @@ def test_pda_exact_branch_with_an_empty_pocket_pivots_like_the_oracle():
     prob = pda_block_problem()
     n = prob.density.shape[1]
     prob.density[0, n // 2 - 1:n // 2 + 1, n // 2 - 1:n // 2 + 1, n // 2 - 1:n // 2 + 1] = 0.0
+    # (a packet that gets into the pocket bounces between its opaque walls for hundreds of interactions, and trajectories that long
+    # are not the same on the device and on the host -- one ulp of libm per interaction, DESIGN.md section 2 --: cut them like the
+    # MRW parity tests do)
+    prob.config.n_inter_max = 60
     eng, orc, res = both(prob, 30000)
     a, b = res[0]
     n_dev, n_orc = eng.get_option("pda_last_cells"), orc.pda_last_cells()

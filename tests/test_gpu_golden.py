@@ -46,13 +46,14 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
     gold = z["golden/seds"]
     K = 12
-    S, n_it, e_last = [], [], []
+    S, n_it, e_last, se_last = [], [], [], []
     w = prob.density * prob.volumes
     for k in range(K):
         prob.config.seed = -(900 + k)
         r = run_problem(prob)
         S.append(r.peeled[0]["seds"]); n_it.append(r.n_iterations)
         e_last.append((r.iterations[-1].specific_energy * w).sum())
+        se_last.append(r.iterations[-1].specific_energy[0])
         assert r.final_stats["killed_geo"] == 0
     # the golden ran all 10 iterations without converging (99th percentile rule at 5000 packets); so does the GPU
     assert int(z["golden/iterations"]) == 10 and not bool(z["golden/converged"])
@@ -68,6 +69,17 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
     if (~well).any():
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
+    # the specific energy of the last iteration, cell by cell: over the cells the realisations agree on (scatter below 30 %) the
+    # golden is neither above nor below -- the median of log10(golden / mean) is zero to a few per cent (the oracle: -0.0001 at
+    # tau = 1e6 over 329 cells).  This is the unbiased statistic; the TOTAL below is not: at tau = 1e6 five mid-plane cells hold two
+    # thirds of it, their energies still grow from iteration to iteration (1.4e33 -> 1e36 over the ten) and differ by factors of
+    # 0.2 - 1.3 between the golden and the mean, in the oracle's realisations exactly as in the device's
+    se = np.array(se_last)
+    m, sd = se.mean(axis=0), se.std(axis=0, ddof=1)
+    gold_se = z["golden/specific_energy_last"][0]
+    okc = (m > 0) & (gold_se > 0) & (sd < 0.3 * m) & (w[0] > 0)
+    assert okc.sum() > 100
+    assert abs(np.median(np.log10(gold_se[okc] / m[okc]))) < 0.05
     e_gold = (z["golden/specific_energy_last"] * w).sum()
     if tau == "1000000":
         # the mid-plane cells of the thickest disc hold almost all the mass and are reached by a handful of the 5000 packets:

@@ -24,12 +24,6 @@ for rep in range(2):
     ms = eng.last_kernel_ms()[0]
     print("final (deferred peel-off, %d rounds, %.2f events/packet) n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet (incl. peel-off walks), %.3e crossings/s"
           % (eng.get_option("last_defer_rounds"), eng.get_option("last_defer_events") / n, n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3))
-eng.set_option("defer_peel", 2)
-for rep in range(2):
-    res, st = eng.final_iteration(n)
-    ms = eng.last_kernel_ms()[0]
-    print("final (staged: event / peel / walk rounds, %d rounds, %.2f events/packet) n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet, %.3e crossings/s"
-          % (eng.get_option("last_defer_rounds"), eng.get_option("last_defer_events") / n, n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3))
 eng.set_option("defer_peel", 0)
 res, st = eng.final_iteration(n)
 ms = eng.last_kernel_ms()[0]
