@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -289,7 +290,9 @@ struct hyp_engine {
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
-    int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h), 0 = inline
+    int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h; large launches: propagation on the tiled schedule),
+                                    //   2 = always on the tiled schedule where there is one, 3 = never, 0 = inline peel-off
+    int last_tiled_imaging = 0;
     long long peel_events = 128ll << 20;    // option: capacity of the event buffer, in events (the ceiling: 8 per packet are asked for, and half as many
                                             // again and again while the allocation fails; 16 Mi until round 3: 1e8 packets then took 15 rounds)
     int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
@@ -478,8 +481,13 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool
     return lds_bytes(h->hp) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd;
 }
 
-int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0, uint64_t n_local, int n_pools)
+// `img`: the imaging iteration on the tiled schedule -- the event buffer the IMG kernels append to; `flush` empties it (sort +
+// peel_kernel) and is called with every pool's stream idle, when the buffer could overflow before the next look and at the end
+int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0, uint64_t n_local, int n_pools, const DeferBuf *img = nullptr,
+                          const std::function<int()> &flush = std::function<int()>())
 {
+    DeferBuf no_events;
+    std::memset(&no_events, 0, sizeof no_events);
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_int = lds_w;
     // record ring (one loader wave per walk workgroup) where the kernel has that form and two workgroups still fit a CU
@@ -502,8 +510,11 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
     // latency-bound prepare of one pool overlaps the walk of the other.  The pools share only the
     // packet-id dispenser, the finished counter and the (atomic) accumulators.
     const size_t tasks_cap = (size_t)T0.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2;
-    int gen = 0;
+    int gen = 0, next_check = h->tile_poll;
     size_t n_timed = 0;
+    // imaging: every generation can add at most one event per slot (plus the padding of the interaction chunks)
+    const unsigned long long ev_per_gen = (unsigned long long)n_pools * ((unsigned long long)T0.n_slots + 64ull * (unsigned long long)grid_i);
+    if (img) next_check = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)h->tile_poll, img->cap / ev_per_gen));
     for (;; gen++) {
         for (int pool = 0; pool < n_pools; pool++) {
             TileGeom T = T0; T.pool = pool;
@@ -523,9 +534,9 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 // walk (previous generation) left per-task lists: interactions, then emission into the freed slots
                 if (gen == 0) tile_init_kernel<<<(T.n_slots + 255) / 256, 256, 0, st>>>(T, h->d_ctl, tasks, tcount, dlist);
                 else
-                    K.interact[ri][mi]<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
-                                                                                         tcount, counts, extra);
-                (h->simple_sources && K.emit_simple ? K.emit_simple : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra);
+                    (img ? K.interact_img : K.interact[ri][mi])<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
+                                                                                         tcount, counts, extra, img ? *img : no_events);
+                (img ? K.emit_img : h->simple_sources && K.emit_simple ? K.emit_simple : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra, img ? *img : no_events);
             } else {
                 K.prepare<<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
                 tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
@@ -544,15 +555,31 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             walk_k<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
-        if ((gen + 1) % h->tile_poll == 0 || gen > 200000) {
+        if (gen + 1 >= next_check || gen > 200000) {
+            next_check = gen + 1 + h->tile_poll;
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e != hipSuccess) return h->set_error(std::string("tiled generation failed: ") + hipGetErrorString(e));
+            if (img) {
+                // how many more generations are sure to fit the event buffer decides when to look again; with fewer than two (or at
+                // the end) the buffer is emptied: sort + peel, every pool's stream idle
+                for (int pool = 1; pool < n_pools; pool++)
+                    if (hipStreamSynchronize(h->pool_stream[pool]) != hipSuccess) return h->set_error("tiled imaging generation failed");
+                unsigned long long reserved = 0;
+                (void)hipMemcpy(&reserved, &img->ctl->reserved, sizeof reserved, hipMemcpyDeviceToHost);
+                if (reserved > img->cap) return h->set_error("tiled imaging: the event buffer overflowed");
+                unsigned long long room = (img->cap - reserved) / ev_per_gen;
+                if (h->h_ctl->n_finished >= n_local || room < 2) {
+                    if (flush()) return 1;
+                    room = img->cap / ev_per_gen;
+                }
+                next_check = gen + 1 + (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)h->tile_poll, room));
+            }
             if (h->h_ctl->n_finished >= n_local) break;
             if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
             // few packets left and no ids to hand out: finish them in one launch
             const uint64_t in_flight = n_local - h->h_ctl->n_finished;
-            if (h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= (uint64_t)h->tile_drain) {
+            if (!img && h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= (uint64_t)h->tile_drain) {      // (the drain kernel deposits: Lucy only)
                 for (int pool = 1; pool < n_pools; pool++) {
                     (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
                     (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
@@ -607,7 +634,10 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
     return 0;
 }
 
-int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int iteration)
+// One iteration on the slot-pool schedule: the Lucy iteration (img == nullptr; `iter_tag` = the iteration number), or the imaging
+// iteration's propagation half with its events appended to *img (run_tiled_imaging below)
+int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t iter_tag, const DeferBuf *img = nullptr,
+                 const std::function<int()> &flush = std::function<int()>())
 {
     const DProblem &P = h->hp;
     const int nd = h->n_dust;
@@ -641,7 +671,8 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
     T.task_size = h->tile_task <= 0 ? 8192 : h->tile_task < 256 ? 256 : h->tile_task;
-    T.iter_tag = (uint32_t)iteration; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare) ? 1 : 0;
+    T.iter_tag = iter_tag; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare || img) ? 1 : 0;
+    T.imaging = img ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
         free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
@@ -668,14 +699,14 @@ int lucy_launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, int ite
         if (!h->pool_stream[pool] && hipStreamCreateWithFlags(&h->pool_stream[pool], hipStreamNonBlocking) != hipSuccess)
             return h->set_error("cannot create a stream for the tiled Lucy iteration");
     TileCtl c0; memset(&c0, 0, sizeof(c0));
-    c0.next_id = first_id; c0.end_id = first_id + n_local;
-    (void)hipEventRecord(h->ev0, h->stream);
+    c0.next_id = first_id; c0.end_id = first_id + n_local; c0.first_id = first_id;
+    if (!img) (void)hipEventRecord(h->ev0, h->stream);        // (the imaging iteration's clock starts before its pre-pass)
     (void)hipMemsetAsync(h->d_hot, 0, hot_sz * all_slots, h->stream);          // state 0 = TS_DEAD
     (void)hipMemsetD32Async((hipDeviceptr_t)h->d_slot_brick, TILE_NEEDS_PREPARE, all_slots, h->stream);   // every slot is free
     (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
     (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
     (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
-    const int rc = run_tiled_generations(h, K, T, n_local, n_pools);
+    const int rc = run_tiled_generations(h, K, T, n_local, n_pools, img, flush);
     for (int pool = 1; pool < n_pools; pool++) {      // join the other pools into the engine's stream
         (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
         (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
@@ -2678,7 +2709,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
 
     if (tiled) {
-        if (lucy_launch_tiled(h, first_id, n_local, iteration)) return 1;
+        if (launch_tiled(h, first_id, n_local, (uint32_t)iteration)) return 1;
         h->last_lucy_mode = 1;
         h->lucy_pending = true;
         h->pending_packets = n_local;
@@ -2878,7 +2909,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
-    else if (n == "defer_peel") h->defer_peel = value != 0 ? 1 : 0;
+    else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 3 ? 3 : (int)value;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
@@ -2891,13 +2922,13 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
         h->peel_events = value; h->peel_events_exact = true;
     }
     else if (n == "tile_drain") h->tile_drain = (int)value;
-    else if (n == "at_cells") { h->at_cells = (int)value; h->at_built_for = -1; }
-    else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; }
-    else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; }
-    else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; }
+    else if (n == "at_cells") { h->at_cells = (int)value; h->at_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
-    else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; }
-    else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; }      // cells per Voronoi cluster (0: fill the LDS budget)
+    else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
     else if (n == "tile_park") h->tile_park = (int)value;
     else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
     else return h->set_error("unknown option: " + n);
@@ -2930,6 +2961,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
+    else if (n == "last_tiled_imaging") *value = h->last_tiled_imaging;
     else if (n == "peel_sort") *value = h->peel_sort;
     else if (n == "ff_prepass") *value = h->ff_prepass;
     else if (n == "last_ff_prepass") *value = h->last_ff_prepass;
@@ -3002,12 +3034,12 @@ static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes, uin
 }
 
 // Rounds of {propagate, peel} until every packet id has been used and no packet is left set aside (hyp_defer.h).
-static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, unsigned blocks, size_t lds)
+// the event buffer and, where the memory is there, the tables of the sorted peel-off
+static void defer_setup_buffers(hyp_handle h, const DeferKernels &dk, DeferBuf &B)
 {
-    DeferBuf B;
     B.events = h->d_peel_events; B.cap = h->peel_cap; B.ctl = h->d_peel_ctl;
     B.susp[0] = h->d_peel_susp[0]; B.susp[1] = h->d_peel_susp[1]; B.ret[0] = h->d_peel_ret[0]; B.ret[1] = h->d_peel_ret[1];
-    B.order = nullptr; B.keys = nullptr; B.bins = nullptr; B.n_bins = 0;
+    B.order = nullptr; B.keys = nullptr; B.bins = nullptr; B.n_bins = 0; B.ff = nullptr; B.cur = 0;
     if (h->peel_sort && dk.sort_hist && h->peel_cap < 0xffffffffull) {
         // sorted peel-off: order + keys per event slot, counts | offsets per bin; without the memory the events are taken as written
         if (h->peel_sort_cap < h->peel_cap) {
@@ -3023,32 +3055,54 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
             B.n_bins = (unsigned int)std::max<unsigned long long>(1ull, std::min<unsigned long long>(HYP_SORT_MAX_BINS, h->hp.n_cells));
         }
     }
-    const unsigned sort_blocks = (unsigned)((h->peel_cap + HYP_SORT_PER_WG - 1) / HYP_SORT_PER_WG);
-    int occ = 0;
-    // forced first interaction: every packet's emission, escape walk and first optical depth ahead of the rounds, one record per id
-    // (128 bytes at one dust species; without the memory the propagation kernel does it all itself)
+}
+
+// forced first interaction: every packet's emission, escape walk and first optical depth ahead of the rounds, one record per id
+// (128 bytes at one dust species; without the memory the propagation kernel does it all itself).  Sets B.ff where it ran.
+static void defer_ff_prepass(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, DeferBuf &B, size_t lds)
+{
     B.ff = nullptr;
     h->last_ff_prepass = 0;
     const unsigned long long n_ids = L.end_id - L.first_id;
-    if (h->ff_prepass && h->hp.forced_first && dk.ff_walk && n_ids > 0) {
-        const size_t want = (size_t)n_ids * dk.ff_bytes;
-        if (h->ff_cap < want) {
-            free_dev(h->d_ff);
-            h->ff_cap = 0;
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want < free_b / 2 && hipMalloc(&h->d_ff, want) == hipSuccess) h->ff_cap = want;
-            else { (void)hipGetLastError(); h->d_ff = nullptr; }
-        }
-        if (h->ff_cap >= want) {
-            B.ff = h->d_ff;
-            (void)hipMemsetAsync(&h->d_peel_ctl->ff_cursor, 0, sizeof(unsigned long long), h->stream);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.ff_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;
-            const unsigned long long need = (n_ids + 255) / 256;
-            const unsigned ff_blocks = (unsigned)std::min<unsigned long long>((unsigned long long)h->n_cu * occ, need);
-            hipLaunchKernelGGL(dk.ff_walk, dim3(ff_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
-            h->last_ff_prepass = 1;
-        }
+    if (!(h->ff_prepass && h->hp.forced_first && dk.ff_walk && n_ids > 0)) return;
+    const size_t want = (size_t)n_ids * dk.ff_bytes;
+    if (h->ff_cap < want) {
+        free_dev(h->d_ff);
+        h->ff_cap = 0;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want < free_b / 2 && hipMalloc(&h->d_ff, want) == hipSuccess) h->ff_cap = want;
+        else { (void)hipGetLastError(); h->d_ff = nullptr; }
     }
+    if (h->ff_cap < want) return;
+    B.ff = h->d_ff;
+    (void)hipMemsetAsync(&h->d_peel_ctl->ff_cursor, 0, sizeof(unsigned long long), h->stream);
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.ff_walk, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+    const unsigned long long need = (n_ids + 255) / 256;
+    const unsigned ff_blocks = (unsigned)std::min<unsigned long long>((unsigned long long)h->n_cu * occ, need);
+    hipLaunchKernelGGL(dk.ff_walk, dim3(ff_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
+    h->last_ff_prepass = 1;
+}
+
+// the events in the buffer: ordered by cell (where the tables are there), then every (event, view) pair walked to the observer
+static void defer_peel_events(hyp_handle h, const DeferKernels &dk, const DeferBuf &B, unsigned peel_blocks, size_t lds, uint32_t iter_tag)
+{
+    if (B.order) {
+        const unsigned sort_blocks = (unsigned)((h->peel_cap + HYP_SORT_PER_WG - 1) / HYP_SORT_PER_WG);
+        (void)hipMemsetAsync(B.bins, 0, sizeof(unsigned int) * B.n_bins, h->stream);
+        hipLaunchKernelGGL(dk.sort_hist, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
+        hipLaunchKernelGGL(dk.sort_scan, dim3(1), dim3(1024), 0, h->stream, B);
+        hipLaunchKernelGGL(dk.sort_scatter, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
+    }
+    hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, iter_tag);
+}
+
+static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, unsigned blocks, size_t lds)
+{
+    DeferBuf B;
+    defer_setup_buffers(h, dk, B);
+    defer_ff_prepass(h, dk, L, B, lds);
+    int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
     int idle_rounds = 0;
@@ -3056,13 +3110,7 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
         B.cur = round & 1;
         hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, B.cur, round == 0 ? 1 : 0);
         hipLaunchKernelGGL(B.ff ? dk.propagate_pre : dk.propagate, dim3(blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, B);
-        if (B.order) {
-            (void)hipMemsetAsync(B.bins, 0, sizeof(unsigned int) * B.n_bins, h->stream);
-            hipLaunchKernelGGL(dk.sort_hist, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
-            hipLaunchKernelGGL(dk.sort_scan, dim3(1), dim3(1024), 0, h->stream, B);
-            hipLaunchKernelGGL(dk.sort_scatter, dim3(sort_blocks), dim3(256), 0, h->stream, (const DProblem *)h->d_problem, B);
-        }
-        hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, L.iter_tag);
+        defer_peel_events(h, dk, B, peel_blocks, lds, L.iter_tag);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return h->set_error(std::string("deferred imaging launch: ") + hipGetErrorString(e));
         (void)hipMemcpyAsync(h->h_peel_ctl, h->d_peel_ctl, sizeof(PeelCtl), hipMemcpyDeviceToHost, h->stream);
@@ -3080,6 +3128,55 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
         if (hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess || err != 0) break;     // reported by hyp_final_accumulators
     }
     return 0;
+}
+
+// The imaging iteration with its propagation half on the slot-pool schedule of the Lucy iteration (hyp_tiled.h: IMG kernels):
+// emission and the forced first interaction ahead of everything (ff_walk_kernel), then generations of interact / emit / sort /
+// WALK FROM LDS -- the packets' own walks start at interaction points in random directions, which is what made them slow in
+// final_defer_kernel (scattered loads) --, events appended to the buffer and peeled (sorted) when it could overflow and at the
+// end.  Returns 0 done, 1 error, 2 not applicable (no tiled schedule for the grid, tables too large, forced first interaction
+// without room for its records): the caller runs the rounds of hyp_defer.h instead.
+static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, size_t lds, uint64_t n_local)
+{
+    const DProblem &P = h->hp;
+    const TileKernels K = pick_tile_kernels(h->n_dust, P.grid_type);
+    if (!K.walk || !K.interact_img || !K.emit_img || K.event_bytes != dk.event_bytes) return 2;
+    if (P.grid_type == 1 && tile_bricks(P, h->n_dust) > HYP_TILE_MAX_BRICKS) return 2;
+    if (P.grid_type == 2 && !h->oct_neighbours) return 2;
+    if (P.grid_type == 2 || P.grid_type == 3 || P.grid_type == 4) {
+        const int rc = P.grid_type == 4 ? build_amr_slabs(h) : P.grid_type == 3 ? build_vor_clusters(h) : build_oct_clusters(h);
+        if (rc) { h->err.clear(); return 2; }
+        if (sync_problem(h)) return 1;
+    }
+    DeferBuf B;
+    defer_setup_buffers(h, dk, B);
+    defer_ff_prepass(h, dk, L, B, lds);
+    if (P.forced_first && !B.ff) return 2;
+    {
+        // the event buffer must hold a few generations' worth of events (one per slot and generation at most)
+        const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
+        const unsigned long long slots = (unsigned long long)std::min<long long>(want_slots, (long long)n_local) + 4096ull;
+        if (B.cap < 3ull * (slots + slots / 8)) return 2;
+    }
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
+    const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
+    hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, 0, 1);
+    const uint32_t iter_tag = L.iter_tag;
+    auto flush = [&]() -> int {
+        // (every pool's stream is idle here)
+        defer_peel_events(h, dk, B, peel_blocks, lds, iter_tag);
+        (void)hipMemcpyAsync(h->h_peel_ctl, h->d_peel_ctl, sizeof(PeelCtl), hipMemcpyDeviceToHost, h->stream);
+        hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, 0, 0);
+        const hipError_t e = hipStreamSynchronize(h->stream);
+        if (e != hipSuccess) return h->set_error(std::string("tiled imaging: peel-off failed: ") + hipGetErrorString(e));
+        h->last_defer_rounds++;
+        h->last_defer_events += B.order ? h->h_peel_ctl->n_sorted : h->h_peel_ctl->reserved;
+        return 0;
+    };
+    const int rc = launch_tiled(h, L.first_id, n_local, iter_tag, &B, flush);
+    h->last_tiled_imaging = rc == 0 ? 1 : 0;
+    return rc ? 1 : 0;
 }
 
 int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
@@ -3136,8 +3233,19 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : (deferred ? 16 : 32);
     L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : (!deferred ? 32 : h->hp.grid_type == 1 ? 16 : 48);
     h->last_defer_rounds = 0; h->last_defer_events = 0;
+    h->last_tiled_imaging = 0;
     if (deferred) {
         (void)hipEventRecord(h->ev0, h->stream);
+        // large launches of problems whose grid has a tiled schedule: the propagation half on it (defer_peel = 2 forces, 3 forbids)
+        int rc = 2;
+        if (!h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || n_local >= 4000000ull)) rc = run_tiled_imaging(h, dk, L, lds, n_local);
+        if (rc == 1) return 1;
+        if (rc == 0) {
+            (void)hipEventRecord(h->ev1, h->stream);
+            h->final_pending = true;
+            h->pending_packets = n_local;
+            return 0;
+        }
         if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds)) return 1;
         (void)hipEventRecord(h->ev1, h->stream);
         h->final_pending = true;

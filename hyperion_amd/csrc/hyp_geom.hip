@@ -156,6 +156,8 @@ static TileKernels tile_kernels()
         k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
         k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
+        k.interact_img = tile_interact_kernel<NDT, false, false, GEOM, true>; k.emit_img = tile_emit_kernel<NDT, GEOM, true, true>;
+        k.event_bytes = sizeof(PeelEvent<NDT, GEOM>);
     }
 #if HYP_GEOM_TU == 3
     {

@@ -27,15 +27,17 @@ template <int GEOM> DeferKernels pick_defer_kernels_g(int nd);
 // Slot records travel as void * (HotRec<nd> / ColdRec<nd>).
 struct TileGeom; struct TileCtl; struct TileTask; struct TileCount;
 using TileInteractK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, const TileTask *, const int *, int *, TileCount *,
-                               unsigned int *, int *);
+                               unsigned int *, int *, DeferBuf);
 using TileEmitK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, const TileTask *, const int *, const TileCount *,
-                           unsigned int *, int *);
+                           unsigned int *, int *, DeferBuf);
 using TileDrainK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *);
 using TileWalkK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, const int *, const TileTask *, int *, int *, int *, TileCount *,
                            unsigned int *);
 struct TileKernels {
     TileInteractK interact[2][2];       // [sources can re-absorb][modified random walk]
     TileEmitK emit, emit_simple;        // emit_simple: point sources with tabulated / blackbody spectra only
+    TileInteractK interact_img; TileEmitK emit_img;      // the imaging iteration on this schedule (IMG kernels of hyp_tiled.h); event_bytes = sizeof(PeelEvent)
+    size_t event_bytes;
     TileDrainK drain[2][2];
     TileDrainK prepare;                 // unsplit schedule (Cartesian only), else null
     TileWalkK walk;

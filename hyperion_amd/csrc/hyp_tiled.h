@@ -14,6 +14,7 @@
 #pragma once
 
 #include "hyp_kernels.h"
+#include "hyp_defer.h"      // PeelEvent, EmitRec: the imaging iteration on this schedule (IMG kernels below)
 
 enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3, TS_REEMIT = 4 };   // TS_REEMIT: re-absorbed by a source
 
@@ -51,6 +52,38 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
     int reabs_id, reabs;
 };
 
+// Imaging iteration (IMG kernels): the origin flags of peeloff_photon and the packet's event counter ride in fields the
+// plain problems it runs on never use -- the re-absorption block (no source has a radius) and the pad word.
+template <int ND>
+__device__ __forceinline__ void cold_flags_store(ColdRec<ND> &C, const PeelFlags &f, unsigned int peel_seq)
+{
+    int *q = (int *)&C.t_src;
+    q[0] = f.scattered; q[1] = f.reprocessed; q[2] = f.n_scat; q[3] = f.dust_id; q[4] = f.source_id;
+    C.pad = (int)peel_seq;
+}
+template <int ND>
+__device__ __forceinline__ void cold_flags_load(const ColdRec<ND> &C, PeelFlags &f, unsigned int &peel_seq)
+{
+    const int *q = (const int *)&C.t_src;
+    f.scattered = q[0]; f.reprocessed = q[1]; f.n_scat = q[2]; f.dust_id = q[3]; f.source_id = q[4];
+    peel_seq = (unsigned int)C.pad;
+}
+template <int ND, int GEOM>
+__device__ __forceinline__ void write_peel_event(PeelEvent<ND, GEOM> &E, const Packet<ND, GEOM> &p, const Rng &g, const Angle &a_prev, const double s_prev[4],
+                                                 const PeelFlags &f, unsigned int peel_seq, int last, bool last_iso)
+{
+    E.r[0] = p.r[0]; E.r[1] = p.r[1]; E.r[2] = p.r[2]; E.nu = p.nu; E.energy = p.energy;
+    E.a_prev = a_prev;
+    E.s_prev[0] = s_prev[0]; E.s_prev[1] = s_prev[1]; E.s_prev[2] = s_prev[2]; E.s_prev[3] = s_prev[3];
+#pragma unroll
+    for (int d = 0; d < ND; d++) E.chi[d] = p.chi[d];
+    E.id = ((unsigned long long)g.id_hi << 32) | g.id_lo;
+    E.peel_seq = peel_seq;
+    E.code = 1 | (last << 1) | ((last_iso ? 1 : 0) << 3);
+    E.f = f;
+    E.cell = p.cell;
+}
+
 // slot_brick[] values besides a brick index
 #define TILE_IDLE (-1)            // slot retired (no packet ids left)
 #define TILE_NEEDS_PREPARE (-2)   // the slot is free for a new packet
@@ -77,7 +110,7 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
 #ifdef HYP_TILE_ABLATE_DEPOSIT
 #define TILE_DEPOSIT(p, v) ((void)(p), (void)(v))
 #else
-#define TILE_DEPOSIT(p, v) unsafeAtomicAdd(p, v)
+#define TILE_DEPOSIT(p, v) do { if (!T.imaging) unsafeAtomicAdd(p, v); } while (0)      // (T: the walk kernel's TileGeom)
 #endif
 
 #ifndef HYP_WALK_ATTR
@@ -89,6 +122,7 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
 #define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
+    unsigned long long first_id;                  // first packet id of the launch (imaging: index of a packet's EmitRec)
     unsigned int n_tasks[HYP_TILE_MAX_POOLS];     // per slot pool
     // split schedule: slots that need an interaction but sit in no task's list (a packet that drew a zero optical
     // depth); two lists per pool, filled and emptied in alternate generations
@@ -108,6 +142,7 @@ struct TileGeom {
     int park;                    // tile_walk: park the last packets of a wave once this few lanes still walk
     int gen;                     // generation number (split schedule: which of the two extra lists is read)
     int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
+    int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
 };
 
 // per task of the current generation: how many of its packets ended the visit waiting for an interaction
@@ -548,11 +583,14 @@ __device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileC
 
 // REABS: the problem has sources that can absorb packets (P.any_intersect), so slots may wait for a re-emission;
 // MRW: the modified random walk is on (P.mrw).  Without them that code stays out of this kernel.
-template <int ND, bool REABS, bool MRW, int GEOM>
+// IMG: the imaging iteration (do_final) on this schedule -- the interaction deposits nothing and leaves one PeelEvent in the
+// event buffer B (peeloff_photon is made later by peel_kernel, hyp_defer.h); a workgroup reserves one event slot per entry of
+// its chunk with ONE atomic and marks the slots of entries that peel nothing as empty.
+template <int ND, bool REABS, bool MRW, int GEOM, bool IMG = false>
 __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
         void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick,
         const TileTask *__restrict__ tasks, const int *__restrict__ ilist, int *__restrict__ dlist, TileCount *__restrict__ tcount,
-        unsigned int *__restrict__ counts, int *__restrict__ extra)
+        unsigned int *__restrict__ counts, int *__restrict__ extra, DeferBuf B)
 {
     extern __shared__ double lds[];
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
@@ -573,6 +611,12 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
     stage_walls<GEOM>(P, lds, W);
     __shared__ int sorted[CH];
     __shared__ int n_dead_x, n_abs, n_oth, dead_base;
+    __shared__ unsigned long long ev_base;
+    if (IMG && threadIdx.x == 0) {
+        ev_base = atomicAdd(&B.ctl->reserved, (unsigned long long)(n_int + 64));      // (+ 64: the two kinds start on wave boundaries)
+        if (ev_base + (unsigned long long)(n_int + 64) > B.cap) { raise_error(P, ERR_INTERNAL, (double)ev_base, (double)B.cap, 1.0); ev_base = ~0ull; }
+    }
+    PeelEvent<ND, GEOM> *__restrict__ ev = (PeelEvent<ND, GEOM> *)B.events;
     __shared__ int dead_l[CH];
     __shared__ double red[TILE_RED_N];
     __shared__ int cache_b[TILE_BCACHE];
@@ -633,6 +677,8 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         Packet<ND, GEOM> p;
         Rng g;
         unsigned long long id = 0;
+        PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
+        unsigned int peel_seq = 0;
         p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
         if (valid) {
             const HotRec<ND> &H = hot[slot];
@@ -651,7 +697,11 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
             g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
             if (REABS) { p.reabs = C.reabs; p.reabs_id = C.reabs_id; }
+            if (IMG) cold_flags_load(C, f, peel_seq);
         }
+        const Angle a_prev = p.a;
+        const double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
+        int last = LAST_SR; bool last_iso = true, do_peel = false;
         if (REABS && state == TS_REEMIT) {
             // iter_lucy.f90:155-185: re-emission from the source that absorbed the packet
             const int inter = p.inter, reabs = p.reabs, rid = p.reabs_id;
@@ -679,10 +729,17 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
                 bool ok = interact<ND, GEOM>(P, p, g, cnt, scattered, dust_id);
 #endif
                 bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                if (IMG) {          // iter_final.f90:245-268: the origin flags of the peel-off
+                    f.dust_id = dust_id;
+                    if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
+                    else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
+                }
                 if (killed) { state = TS_DEAD; finished++; }
                 else if (MRW && mrw_loop_lucy<ND, GEOM>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
                 else {
                     p.inter++;
+                    if (IMG) do_peel = !P.peel_scattered_only || last == LAST_DS;
+                    if (IMG && do_peel) { if (ev_base != ~0ull) write_peel_event<ND, GEOM>(ev[ev_base + (unsigned long long)k], p, g, a_prev, s_prev, f, peel_seq, last, last_iso); peel_seq++; }
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
                     begin_integrate(P, p);
                     state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
@@ -690,9 +747,11 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             }
         }
         int brick = 0;
+        if (IMG && !do_peel && k < n_int + 64 && ev_base != ~0ull) ev[ev_base + (unsigned long long)k].code = 0;       // nothing peeled here: an empty slot
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
+                if (IMG) cold_flags_store(cold[slot], f, peel_seq);
                 if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts again
@@ -707,6 +766,9 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         }
         count_bricks(counts, cache_b, cache_n, valid && state == TS_WALK, brick);
     }
+        if (IMG && ev_base != ~0ull)        // reserved slots beyond the last pass of the loop
+            for (int k = ((nl + (int)blockDim.x - 1) / (int)blockDim.x) * (int)blockDim.x + (int)threadIdx.x; k < n_int + 64; k += (int)blockDim.x)
+                ev[ev_base + (unsigned long long)k].code = 0;
     }
     __syncthreads();
     if (is_extra && threadIdx.x == 0) ctl->n_extra[T.pool][par] = 0;
@@ -720,11 +782,14 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
 
 // SIMPLE: every source is a point source with a tabulated or blackbody spectrum (emit_packet<.., SIMPLE>): the other
 // emitters stay out of the kernel and its register budget allows twice the waves
-template <int ND, int GEOM, bool SIMPLE>
+// IMG: the imaging iteration -- a packet's emission, the escape walk of the forced first interaction and its first optical depth
+// come from the record ff_walk_kernel left (B.ff, hyp_defer.h) when forced first interaction is on, and the emission leaves a
+// PeelEvent (one slot per free-list entry reserved by the workgroup; the rare second emission into a slot reserves its own).
+template <int ND, int GEOM, bool SIMPLE, bool IMG = false>
 __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVES) void tile_emit_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
         void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick,
         const TileTask *__restrict__ tasks, const int *__restrict__ dlist, const TileCount *__restrict__ tcount,
-        unsigned int *__restrict__ counts, int *__restrict__ extra)
+        unsigned int *__restrict__ counts, int *__restrict__ extra, DeferBuf B)
 {
     extern __shared__ double lds[];
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
@@ -743,7 +808,12 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
     __shared__ double red[TILE_RED_N];
     __shared__ int cache_b[TILE_BCACHE];
     __shared__ unsigned int cache_n[TILE_BCACHE];
-    __shared__ unsigned long long id_base;
+    __shared__ unsigned long long id_base, ev_base;
+    PeelEvent<ND, GEOM> *__restrict__ ev = (PeelEvent<ND, GEOM> *)B.events;
+    if (IMG && threadIdx.x == 64) {
+        ev_base = atomicAdd(&B.ctl->reserved, (unsigned long long)n_dead);
+        if (ev_base + (unsigned long long)n_dead > B.cap) { raise_error(P, ERR_INTERNAL, (double)ev_base, (double)B.cap, 2.0); ev_base = ~0ull; }
+    }
     if (threadIdx.x < TILE_RED_N) red[threadIdx.x] = 0.0;
     if (threadIdx.x < TILE_BCACHE) { cache_b[threadIdx.x] = -1; cache_n[threadIdx.x] = 0; }
     // one trip to the packet-id dispenser for all the entries of this workgroup (it is one address for the whole
@@ -768,6 +838,9 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
         Rng g;
         unsigned long long id = 0;
         p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+        PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
+        unsigned int peel_seq = 0;
+        bool wrote = false;        // IMG: this entry's reserved event slot holds an event
         // a packet that is emitted outside the grid (or leaves it at once) frees its slot again
         for (int round = 0;; round++) {
             const bool want = state == TS_DEAD;
@@ -783,7 +856,7 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
                 id = round == 0 ? id_base + (unsigned long long)(done_before + (int)threadIdx.x)
                                 : base + (unsigned long long)__popcll(m & ((1ull << __lane_id()) - 1ull));
                 if (id >= end_id) state = TS_DONE;
-                else {
+                else if constexpr (!IMG) {
                     rng_init(g, P.seed_key, T.iter_tag, id);
                     int source_id; Angle src_normal;
                     bool ok = emit_packet<ND, GEOM, SIMPLE>(P, W, p, g, cnt, source_id, src_normal);
@@ -793,14 +866,72 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
                         begin_integrate(P, p);
                         state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
                     }
+                } else {
+                    // iter_final.f90:160-209: emission, its peel-off event, the first optical depth (forced first interaction or not)
+                    rng_init(g, P.seed_key, T.iter_tag, id);
+                    bool ok = true;
+                    double tau_first = 0.0, energy_after = 0.0;
+                    int source_id = 0;
+                    if (B.ff) {
+                        const EmitRec<ND> &R = ((const EmitRec<ND> *)B.ff)[id - ctl->first_id];
+                        ok = (R.code >> 1) != 0;          // 0: the emission failed ahead of the rounds (its error is raised: the launch stops)
+                        if (ok) {
+                            g.buf_a = R.buf_a; g.blk_a = R.blk_a; g.blk_b = R.blk_b; g.have_a = R.code & 1; g.countdown = R.countdown;
+                            source_id = R.source_id;
+                            const DSource &S = P.sources[source_id];
+                            p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
+                            p.a = R.a;
+                            angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
+                            p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
+                            p.nu = R.nu; p.energy = R.energy0;
+                            cnt.energy_current += R.energy0;
+                            tau_first = R.tau_req; energy_after = R.energy;
+#pragma unroll
+                            for (int d = 0; d < ND; d++) { p.chi[d] = R.chi[d]; p.albedo[d] = R.albedo[d]; p.kappa[d] = R.kappa[d]; }
+                            p.emiss_dust = -1;
+                            geo_clear_wall(p.cell);
+                            bool placed = false;
+                            if constexpr (GEOM == GEOM_VOR) {
+                                if (S.type == 1 && S.vor_cell1 > 0) { p.cell.id = S.vor_cell1 - 1; placed = true; }
+                            }
+                            if (!placed) (void)geo_place(P, W, p.r, p.v, p.cell);       // it did succeed ahead of the rounds
+                            p.inter = 1; p.n_visited = 0;
+                        }
+                    } else {
+                        Angle src_normal;
+                        ok = emit_packet<ND, GEOM, true>(P, W, p, g, cnt, source_id, src_normal);
+                    }
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    peel_seq = 0; p.reabs = 0;
+                    if (!ok) finished++;
+                    else {
+                        if (!P.peel_scattered_only) {
+                            // the emission's event: this entry's reserved slot, or one more for a second emission into the same slot
+                            unsigned long long e_idx = ev_base == ~0ull ? ~0ull : ev_base + (unsigned long long)k;
+                            if (wrote) { e_idx = atomicAdd(&B.ctl->reserved, 1ull); if (e_idx >= B.cap) { raise_error(P, ERR_INTERNAL, (double)e_idx, (double)B.cap, 3.0); e_idx = ~0ull; } }
+                            const double s0[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
+                            if (e_idx != ~0ull) write_peel_event<ND, GEOM>(ev[e_idx], p, g, p.a, s0, f, peel_seq, LAST_SR, true);
+                            peel_seq++; wrote = true;
+                        }
+                        if (geo_escaped(P, p.cell)) finished++;
+                        else {
+                            if (B.ff) { p.tau_req = tau_first; p.energy = energy_after; }
+                            else p.tau_req = rng_exp(g);
+                            p.tau_ach = 0.0;
+                            begin_integrate(P, p);
+                            state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
+                        }
+                    }
                 }
             }
         }
+        if (IMG && valid && !wrote && ev_base != ~0ull) ev[ev_base + (unsigned long long)k].code = 0;       // nothing emitted into this entry: an empty slot
         done_before += min(256, n_dead - c0);
         int brick = 0;
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
+                if (IMG) cold_flags_store(cold[slot], f, peel_seq);
                 if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts

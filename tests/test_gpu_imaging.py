@@ -396,3 +396,59 @@ def test_deferred_imaging_on_the_tree_and_polar_grids():
     prob.peeled = [PeeledImages(theta=[45.0, 100.0], phi=[45.0, 250.0], n_wav=3, wav_min=0.1, wav_max=1000.0, n_x=8, n_y=8, x_min=-1.5 * PC, x_max=1.5 * PC,
                                 y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.2 * PC, ap_max=2.0 * PC, compute_stokes=True)]
     _deferred_vs_inline(prob, 5000, 20000)
+
+
+# --- the imaging iteration's propagation half on the tiled schedule (IMG kernels of hyp_tiled.h; defer_peel = 2 forces it) ----------
+
+def _tiled_vs_inline(prob, n_lucy, n_img, oracle=False, **opts):
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(n_lucy, 1, want_output=False)
+    assert eng.get_option("plain_imaging") == 1
+    eng.set_option("defer_peel", 2)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    ra, sa = eng.final_iteration(n_img)
+    assert eng.get_option("last_tiled_imaging") == 1, "the tiled imaging schedule did not run"
+    flushes, events = eng.get_option("last_defer_rounds"), eng.get_option("last_defer_events")
+    assert flushes >= 1 and events >= (0 if prob.config.raytracing else n_img)
+    eng.set_option("defer_peel", 0)
+    rb, sb = eng.final_iteration(n_img)
+    assert eng.get_option("last_defer_rounds") == 0 and eng.get_option("last_tiled_imaging") == 0
+    eng.close()
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+    _images_equal(ra, rb)
+    return flushes, ra
+
+
+@pytest.mark.parametrize("kw", [{}, {"uncertainties": True, "track_origin": "detailed", "theta": [10.0, 80.0, 150.0], "phi": [0.0, 120.0, 300.0]}])
+def test_tiled_imaging_equals_inline_cartesian(kw):
+    """Optically thick Cartesian model with forced first interaction: emission and the forced first interaction ahead (ff_walk_kernel),
+    interactions and emissions leave events from the slot-pool kernels, walks from LDS bricks; one pool and three, small tasks,
+    an event buffer that has to be emptied several times on the way"""
+    _tiled_vs_inline(imaging_problem(tau=3.0, **kw), 20000, 30000, tile_slots=8192, tile_task=256, tile_pools=1)
+    flushes, _ = _tiled_vs_inline(imaging_problem(tau=3.0, **kw), 20000, 90000, tile_slots=12288, tile_task=512, tile_pools=3, peel_events=65536)
+    assert flushes >= 3
+
+
+def test_tiled_imaging_without_forced_first_interaction_and_scattered_only():
+    p = imaging_problem(tau=2.0)
+    p.config.forced_first_interaction = False
+    _tiled_vs_inline(p, 20000, 30000, tile_slots=8192, tile_task=256)
+    p.config.raytracing = True          # the final iteration then peels scattered packets only
+    _tiled_vs_inline(p, 20000, 30000, tile_slots=8192, tile_task=256)
+
+
+def test_tiled_imaging_on_the_tree_voronoi_and_polar_grids():
+    from cases import golden_problem
+    from hyperion_amd.benchmark import make_octree_problem
+    _tiled_vs_inline(make_octree_problem(max_level=5, n_pix=32), 20000, 40000, tile_slots=8192, tile_task=256, ot_cells=9)
+    for name in ("amr_peeloff.False.npz", "sph_peeloff.False.npz", "oct_peeloff.True.npz"):
+        prob, _ = golden_problem(name)
+        _tiled_vs_inline(prob, 5000, 20000, tile_slots=4096, tile_task=256)
+    from hyperion_amd.problem import PeeledImages
+    prob, _ = golden_problem("vor_lattice.npz")
+    prob.peeled = [PeeledImages(theta=[45.0, 100.0], phi=[45.0, 250.0], n_wav=3, wav_min=0.1, wav_max=1000.0, n_x=8, n_y=8, x_min=-1.5 * PC, x_max=1.5 * PC,
+                                y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.2 * PC, ap_max=2.0 * PC, compute_stokes=True)]
+    _tiled_vs_inline(prob, 5000, 20000, tile_slots=4096, tile_task=256, vt_cells=12)

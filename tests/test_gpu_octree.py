@@ -115,7 +115,14 @@ def test_full_size_config4_properties():
     se, st = eng.lucy_iteration(5_000_000, 1)
     w = p.density * p.volumes
     assert (se * w).sum() == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
-    assert st["killed_geo"] / 5e6 < 5e-3            # vertex source: the reference octree kills ~1e-3
+    # the source sits on a vertex of the tree: packets emitted along a cell face or edge die in find_wall's negative-t branch
+    # (grid_geometry_octree.f90:527-535), 1.5e-3 of them in the oracle (586 of 4e5) and on the device -- DESIGN.md section 2
+    assert 1.0e-3 < st["killed_geo"] / 5e6 < 2.0e-3
+    # ... and none of them with the source moved off the vertex
+    eng2 = hyperion_amd.Engine(make_octree_problem(max_level=7, source_position=(0.013 * 3.08568025e18, 0.007 * 3.08568025e18, -0.011 * 3.08568025e18)))
+    _, st2 = eng2.lucy_iteration(5_000_000, 1, want_output=False)
+    eng2.close()
+    assert st2["killed_geo"] == 0 and st2["killed_int"] == 0
     res, sf = eng.final_iteration(5_000_000)
     img, sed = res[0]["img"], res[0]["sed"]
     assert img.shape == (4, 1, 1, 512, 512, 1)
@@ -233,7 +240,7 @@ def test_config4_at_baseline_packet_count():
     assert st["n_packets"] == n and st["energy_current"] == pytest.approx(n, rel=1e-12)      # unit-energy packets, none lost
     w = p.density * p.volumes
     assert (se * w).sum() == pytest.approx(st["energy_abs_tot"][0], rel=1e-10)
-    assert st["killed_geo"] / n < 5e-3 and st["killed_int"] == 0
+    assert 1.2e-3 < st["killed_geo"] / n < 1.8e-3 and st["killed_int"] == 0      # the vertex source's kills (see test_full_size_config4_properties)
     assert 35 < st["crossings"] / n < 50
     eng.set_option("peel_events", 16 << 20)         # the default (128 Mi slots) finishes in two rounds: this is the many-round path at full size
     res, sf = eng.final_iteration(n)

@@ -267,3 +267,26 @@ def test_config5_at_baseline_packet_count():
     eng.close()
     assert st["interactions"] / n == pytest.approx(s7["interactions"] / 1e7, rel=2e-3)
     assert st["crossings"] / n == pytest.approx(s7["crossings"] / 1e7, rel=2e-3)
+
+
+def test_a_grid_beyond_the_tile_builder_runs_on_the_persistent_kernel_in_auto_mode():
+    """More clusters than the tiled schedule's tables hold (vt_cells = 1: one cluster per cell, 100 000 > HYP_TILE_MAX_BRICKS): auto
+    mode falls back to the persistent kernel -- as large AMR hierarchies and deep octrees did before the tiled schedules existed --
+    and only a FORCED tiled iteration reports the limit."""
+    from cases import voronoi_big_problem
+    from hyperion_amd.engine import EngineError
+    prob = voronoi_big_problem(n_photons=2_000_000)
+    eng = hyperion_amd.Engine(prob)
+    eng.set_option("vt_cells", 1)
+    a, sa = eng.lucy_iteration(2_000_000, 1)
+    assert eng.get_option("last_lucy_mode") == 0 and sa["killed_geo"] == 0
+    eng.set_option("lucy_mode", 1)
+    with pytest.raises(EngineError, match="too many cells"):
+        eng.lucy_iteration(2_000_000, 2)
+    eng.set_option("lucy_mode", -1)
+    eng.set_option("vt_cells", 0)          # the default clusters fit: the tiled schedule again, same packets as the persistent kernel
+    b, sb = eng.lucy_iteration(2_000_000, 1)
+    assert eng.get_option("last_lucy_mode") == 1
+    eng.close()
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
