@@ -3150,14 +3150,15 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
     }
     DeferBuf B;
     defer_setup_buffers(h, dk, B);
-    defer_ff_prepass(h, dk, L, B, lds);
-    if (P.forced_first && !B.ff) return 2;
     {
-        // the event buffer must hold a few generations' worth of events (one per slot and generation at most)
+        // the event buffer must hold a few generations' worth of events (one per slot and generation at most); decided BEFORE the
+        // pre-pass runs: it counts its crossings and kills, and the caller's fall-back runs it again
         const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
         const unsigned long long slots = (unsigned long long)std::min<long long>(want_slots, (long long)n_local) + 4096ull;
         if (B.cap < 3ull * (slots + slots / 8)) return 2;
     }
+    defer_ff_prepass(h, dk, L, B, lds);
+    if (P.forced_first && !B.ff) return 2;          // (no room for the records: the pre-pass did not run)
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
