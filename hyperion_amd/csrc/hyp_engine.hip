@@ -287,6 +287,7 @@ struct hyp_engine {
     bool tile_unbuildable = false;  // the grid is beyond the limits of its tiled Lucy schedule's tables: auto mode stays on the persistent kernel
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
+    bool ext_sources = false;       // point and external (box / sphere) sources with tabulated or blackbody spectra only: tile_emit_kernel<.., 2>
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
@@ -536,7 +537,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 else
                     (img ? K.interact_img : K.interact[ri][mi])<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
                                                                                          tcount, counts, extra, img ? *img : no_events);
-                (img ? K.emit_img : h->simple_sources && K.emit_simple ? K.emit_simple : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra, img ? *img : no_events);
+                (img ? K.emit_img : h->simple_sources && K.emit_simple ? K.emit_simple : h->ext_sources && K.emit_ext ? K.emit_ext : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra, img ? *img : no_events);
             } else {
                 K.prepare<<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
                 tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
@@ -1941,9 +1942,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (int g = 0; g < pr->n_peeled; g++) lean = lean && !pr->peeled[g].inside_observer;
             h->lean_imaging = lean && h->n_dust <= 4;
         }
-        bool simple = pr->n_sources > 0;
-        for (int i = 0; i < pr->n_sources; i++) simple = simple && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
-        h->simple_sources = simple;
+        bool simple = pr->n_sources > 0, ext = pr->n_sources > 0;
+        for (int i = 0; i < pr->n_sources; i++) {
+            const bool spec = pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2;
+            simple = simple && pr->sources[i].type == 1 && spec;
+            ext = ext && (pr->sources[i].type == 1 || pr->sources[i].type == 5 || pr->sources[i].type == 6) && spec;
+        }
+        h->simple_sources = simple; h->ext_sources = ext;
     }
     P.n_views_total = views_total;
     P.binned = pr->binned ? pr->n_peeled : -1; P.n_bin_theta = pr->n_binned_theta; P.n_bin_phi = pr->n_binned_phi;

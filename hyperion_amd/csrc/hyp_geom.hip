@@ -154,9 +154,9 @@ static TileKernels tile_kernels()
     {
         k.interact[0][0] = tile_interact_kernel<NDT, false, false, GEOM>; k.interact[1][0] = tile_interact_kernel<NDT, true, false, GEOM>;
         k.drain[0][0] = tile_drain_kernel<NDT, false, false, GEOM>; k.drain[1][0] = tile_drain_kernel<NDT, true, false, GEOM>;
-        k.emit = tile_emit_kernel<NDT, GEOM, false>; k.emit_simple = tile_emit_kernel<NDT, GEOM, true>;
+        k.emit = tile_emit_kernel<NDT, GEOM, 0>; k.emit_simple = tile_emit_kernel<NDT, GEOM, 1>; k.emit_ext = tile_emit_kernel<NDT, GEOM, 2>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
-        k.interact_img = tile_interact_kernel<NDT, false, false, GEOM, true>; k.emit_img = tile_emit_kernel<NDT, GEOM, true, true>;
+        k.interact_img = tile_interact_kernel<NDT, false, false, GEOM, true>; k.emit_img = tile_emit_kernel<NDT, GEOM, 1, true>;
         k.event_bytes = sizeof(PeelEvent<NDT, GEOM>);
     }
 #if HYP_GEOM_TU == 3

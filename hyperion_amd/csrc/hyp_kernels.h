@@ -848,9 +848,10 @@ __device__ __forceinline__ double dust_emit_probability(const DProblem &P, const
 
 // emit: source.f90:100-179 + source_emit/emit_from_point source_type.f90:398-564.
 // Returns false on a fatal error (flag raised).
-// SIMPLE: every source is a point source with a tabulated or blackbody spectrum and the launch is not monochromatic
-// (checked by the host): the other emitters stay out of the kernel.
-template <int NDT, int GEOM, bool SIMPLE = false>
+// CLASS (checked by the host): 0 any source; 1 ("simple") every source is a point source with a tabulated or blackbody spectrum and
+// the launch is not monochromatic; 2 the same plus external spherical / box sources (configs[4]'s point + extern_box): the other
+// emitters stay out of the kernel, whose registers then allow another wave per SIMD.
+template <int NDT, int GEOM, int CLASS = 0>
 __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g,
                                             Counters &cnt, int &source_id, Angle &src_normal, int reemit_id = -1, double reemit_energy = 0.0)
 {
@@ -870,10 +871,12 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     int ispot = -1;
     p.emiss_dust = -1;
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
+    constexpr bool SIMPLE = CLASS == 1;
+    constexpr bool FEW = CLASS != 0;          // no sphere / spot / map / point-collection / plane-parallel emitters, no 'lte' spectrum, not monochromatic
     if (SIMPLE) {
         p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
         random_sphere_angle(g, p.a);
-    } else if (S.type == 2) {
+    } else if (!FEW && S.type == 2) {
         // emit_from_sphere: source_type.f90:604-690
         Angle a_coord, a_local;
         if (S.n_spots > 0) {        // source_emit case(3), source_type.f90:421-427: a spot or the rest of the sphere, by luminosity
@@ -902,7 +905,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         angle_to_vector(a_coord, n0, n1, n2);
         p.r[0] = n0 * S.radius + S.pos[0]; p.r[1] = n1 * S.radius + S.pos[1]; p.r[2] = n2 * S.radius + S.pos[2];
         src_normal = a_coord;       // outward normal (p%source_a)
-    } else if (S.type == 4) {
+    } else if (!FEW && S.type == 4) {
         // emit_from_map: source_type.f90:713-741 -- cell from the luminosity map, uniform position in it, isotropic direction
         const double xi = rng_uniform(g);
         size_t lo = 0, hi = (size_t)P.n_cells - 1;
@@ -911,14 +914,14 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         const double x = rng_uniform(g), y = rng_uniform(g), z = rng_uniform(g);
         if (!random_position_cell<GEOM>(P, lo, x, y, z, p.r, g)) { raise_error(P, ERR_RAY_GRID, 0.0, 0.0, 0.0); return false; }
         random_sphere_angle(g, p.a);
-    } else if (S.type == 8) {
+    } else if (!FEW && S.type == 8) {
         // emit_from_point_collection: source_type.f90:570-598
         const double xi = rng_uniform(g);
         int k = S.n_points - 1;
         for (int i = 0; i < S.n_points - 1; i++) if (xi < S.point_cdf[i]) { k = i; break; }
         p.r[0] = S.points[3 * k]; p.r[1] = S.points[3 * k + 1]; p.r[2] = S.points[3 * k + 2];
         random_sphere_angle(g, p.a);
-    } else if (S.type == 7) {
+    } else if (!FEW && S.type == 7) {
         // emit_from_plane_parallel: source_type.f90:935-975 (not peeled: source_emit_peeloff has no case for it)
         const double rr = pow(rng_uniform(g), 0.5) * S.radius;
         const double phi = 360.0 * rng_uniform(g) * HYP_PI / 180.0;
@@ -982,7 +985,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     p.s[0] = 1.0; p.s[1] = 0.0; p.s[2] = 0.0; p.s[3] = 0.0;
     p.energy = 1.0;
     int lte_jid = 0; double lte_frac = 0.0;
-    if (!SIMPLE && S.spectrum_type == 3) {
+    if (!FEW && S.spectrum_type == 3) {
         // 'lte' (source_type.f90:455-459, 486-491): select_dust_specific_energy_rho (grid_physics_3d.f90:101-109) in the
         // emitting cell, then the emissivity of that dust
         const int nd = ndust<NDT>(P);
@@ -998,7 +1001,7 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
         p.emiss_dust = id;
         lte_jid = P.jnu_id[base + id]; lte_frac = P.jnu_frac[base + id];
     }
-    if (!SIMPLE && ispot >= 0) {       // the spot's own spectrum: source_type.f90:447-461, 480-492
+    if (!FEW && ispot >= 0) {       // the spot's own spectrum: source_type.f90:447-461, 480-492
         const double *q = S.spot_tab + (S.n_spots + 1) + (size_t)ispot * SPOT_STRIDE;
         if (P.mono_which) {
             p.nu = P.mono_nu;
@@ -1007,17 +1010,17 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
             p.nu = sample_log_pdf(S.spot_blob + (size_t)q[7], S.spot_blob + (size_t)q[8], S.spot_blob + (size_t)q[9], (int)q[6], rng_uniform(g));
         else p.nu = random_planck_frequency(g, q[5]);
     } else
-    if (!SIMPLE && P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
+    if (!FEW && P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
         p.nu = P.mono_nu;
         p.energy = S.spectrum_type == 3 ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)
                                         : P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
-    } else if (!SIMPLE && S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
+    } else if (!FEW && S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
     else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     if (reemit_id >= 0) p.energy = reemit_energy;
     else {
-        if (!SIMPLE && P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
+        if (!FEW && P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
         if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
         cnt.energy_current += p.energy;
     }

@@ -35,7 +35,7 @@ using TileWalkK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *
                            unsigned int *);
 struct TileKernels {
     TileInteractK interact[2][2];       // [sources can re-absorb][modified random walk]
-    TileEmitK emit, emit_simple;        // emit_simple: point sources with tabulated / blackbody spectra only
+    TileEmitK emit, emit_simple, emit_ext;      // emit_simple: point sources with tabulated / blackbody spectra only; emit_ext: those + external sources
     TileInteractK interact_img; TileEmitK emit_img;      // the imaging iteration on this schedule (IMG kernels of hyp_tiled.h); event_bytes = sizeof(PeelEvent)
     size_t event_bytes;
     TileDrainK drain[2][2];

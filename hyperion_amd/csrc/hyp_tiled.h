@@ -785,7 +785,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
 // IMG: the imaging iteration -- a packet's emission, the escape walk of the forced first interaction and its first optical depth
 // come from the record ff_walk_kernel left (B.ff, hyp_defer.h) when forced first interaction is on, and the emission leaves a
 // PeelEvent (one slot per free-list entry reserved by the workgroup; the rare second emission into a slot reserves its own).
-template <int ND, int GEOM, bool SIMPLE, bool IMG = false>
+template <int ND, int GEOM, int SIMPLE /* emit_packet's CLASS */, bool IMG = false>
 __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVES) void tile_emit_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
         void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick,
         const TileTask *__restrict__ tasks, const int *__restrict__ dlist, const TileCount *__restrict__ tcount,

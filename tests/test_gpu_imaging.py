@@ -452,3 +452,22 @@ def test_tiled_imaging_on_the_tree_voronoi_and_polar_grids():
     prob.peeled = [PeeledImages(theta=[45.0, 100.0], phi=[45.0, 250.0], n_wav=3, wav_min=0.1, wav_max=1000.0, n_x=8, n_y=8, x_min=-1.5 * PC, x_max=1.5 * PC,
                                 y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.2 * PC, ap_max=2.0 * PC, compute_stokes=True)]
     _tiled_vs_inline(prob, 5000, 20000, tile_slots=4096, tile_task=256, vt_cells=12)
+
+
+def test_tiled_imaging_falls_back_to_the_deferred_rounds_and_counts_once():
+    """An event buffer that does not hold a few generations' worth of events: the tiled schedule declines BEFORE the forced-first
+    pre-pass has run (the pre-pass counts its crossings and kills; the deferred rounds run it themselves) -- tallies and images of
+    the inline kernel"""
+    prob = imaging_problem(tau=3.0)
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(20000, 1, want_output=False)
+    eng.set_option("defer_peel", 2)
+    eng.set_option("peel_events", 4096)
+    ra, sa = eng.final_iteration(30000)
+    assert eng.get_option("last_tiled_imaging") == 0 and eng.get_option("last_defer_rounds") >= 5
+    eng.set_option("defer_peel", 0)
+    rb, sb = eng.final_iteration(30000)
+    eng.close()
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    _images_equal(ra, rb)
