@@ -225,7 +225,7 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
                     for (int a = 0; a < 3; a++) {
                         r[a] = H.r[a]; v[a] = H.v[a];
                         inv[a] = 1.0 / v[a];
-                        v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400);
+                        v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400));      // no short circuit: its branches split the record's loads into batches with a wait each
                     }
                     const int local = H.ic[0] - (int)G.start;    // index inside the grid
                     i0 = local % n0; i1 = (local / n0) % n1; i2 = local / (n0 * n1);

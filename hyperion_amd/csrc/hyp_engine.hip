@@ -629,6 +629,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 d[7], (double)d[7] / d[0], (double)d[6] / d[8], (double)d[6] / d[7], (double)d[8] / d[0]);
         if (d[10]) fprintf(stderr, "tile stats: service phase = check + write-back %.3f (%.1f lanes), claim %.3f (%.1f lanes) of its clocks\n", (double)d[10] / d[6], (double)d[12] / d[7],
                            (double)d[11] / d[6], (double)d[13] / d[7]);
+        if (d[15]) fprintf(stderr, "tile stats: propagation check / general wall search ran in %.3f of the service phases and took %.3f of their clocks\n", (double)d[14] / d[7], (double)d[15] / d[6]);
         fprintf(stderr, "tile stats: wave clocks waiting at the end of the task for the workgroup's last wave %.3f of the loop's\n", (double)d[9] / d[8]);
     }
 #endif

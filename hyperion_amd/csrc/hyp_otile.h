@@ -220,7 +220,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                     for (int a = 0; a < 3; a++) {
                         r[a] = H.r[a]; v[a] = H.v[a];
                         inv[a] = 1.0 / v[a];
-                        v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400);
+                        v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400));      // no short circuit: its branches split the record's loads into batches with a wait each
                     }
                     loc = H.ic[0] - c0;
                     int ow[3]; unpack_ow(H.ow, ow);

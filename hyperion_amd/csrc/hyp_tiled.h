@@ -119,6 +119,15 @@ __device__ __forceinline__ void write_peel_event(PeelEvent<ND, GEOM> &E, const P
 #ifndef HYP_TILE_PREFETCH
 #define HYP_TILE_PREFETCH 0      // look-ahead of tile_walk's record prefetch, in packets of the task's queue (0: none; measured: no gain, profiles/r03_tiled_log.md)
 #endif
+#ifndef HYP_TILE_WCLAIM
+#define HYP_TILE_WCLAIM 0        // 1: a wave takes the task's queue in blocks of 64 entries (one LDS atomic and one coalesced load of order[] per block, the
+#endif                           //    records of the block prefetched), its lanes are served from the block by rank; 0: one atomic + one load of order[] per lane
+#ifndef HYP_TILE_LDS_FRONT
+#define HYP_TILE_LDS_FRONT 0     // find_wall_ahead: the step's nine wall reads issued together
+#endif
+#ifndef HYP_TILE_BULK_LOAD
+#define HYP_TILE_BULK_LOAD 0     // tile_walk takes a packet's record with one batch of 16-byte loads (0: field by field)
+#endif
 #define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
@@ -1323,10 +1332,22 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
     double tmin = HYP_DBL_MAX, emin = 0.0;
     int m0 = 0, m1 = 0, m2 = 0;
     bool simple = true;
+#if HYP_TILE_LDS_FRONT
+    // all nine LDS reads of the step before the arithmetic (one wait instead of five)
+    double wa_[3], wb_[3], ea_[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { wa_[a] = W.w[a][c.ic[a] + iu[a]]; wb_[a] = W.w[a][c.ic[a] + 1 - iu[a]]; ea_[a] = W.ew[a][c.ic[a] + iu[a]]; }
+    asm volatile("" : "+v"(wa_[0]), "+v"(wa_[1]), "+v"(wa_[2]), "+v"(wb_[0]), "+v"(wb_[1]), "+v"(wb_[2]), "+v"(ea_[0]), "+v"(ea_[1]), "+v"(ea_[2]));
+#endif
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const int ia = c.ic[a] + iu[a], ib = c.ic[a] + 1 - iu[a];
+#if HYP_TILE_LDS_FRONT
+        const double d = wa_[a] - r[a], db = wb_[a] - r[a];
+        (void)ib;
+#else
         const double d = W.w[a][ia] - r[a], db = W.w[a][ib] - r[a];
+#endif
         const int dir = 2 * iu[a] - 1, ow = c.ow[a];
         // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
         const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
@@ -1338,7 +1359,11 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
         const double q0 = d * inv[a];
         const double t = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
 #endif
+#if HYP_TILE_LDS_FRONT
+        const double emax = fmax(ea_[a], emin);
+#else
         const double emax = fmax(W.ew[a][ia], emin);
+#endif
         const bool lt = cand & (t < tmin - emax);
         const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
         tmin = lt ? t : tmin;
@@ -1424,6 +1449,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
     const DProblem &P = *Pp;
     if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
+    const bool any_intersect = P.any_intersect != 0;      // read once: inside the loops it would be a scalar load and a wait per cell step
     constexpr int NC = BX * BY * BZ;
     Walls W;
     RecRing<ND> ring;
@@ -1530,8 +1556,11 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
 
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
+    int wl_slots = -1, wl_pos = 0, wl_n = 0;      // HYP_TILE_WCLAIM: the wave's block of the queue (wl_pos, wl_n, wl_end wave-uniform)
+    bool wl_end = false;
+    static_assert(!(HYP_TILE_WCLAIM && HYP_TILE_PREFETCH > 0), "the per-lane record prefetch belongs to the per-lane claim");
 #ifdef HYP_TILE_STATS
-    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0;
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_wb = 0, dbg_claim = 0, dbg_nclaim = 0, dbg_nwb = 0, dbg_ncheck = 0, dbg_chk = 0;
     const long long dbg_t0 = clock64();
 #endif
     for (;;) {
@@ -1556,6 +1585,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_TILE_SERVICE || !m_walk))) {
 #ifdef HYP_TILE_STATS
             const long long dbg_ts = clock64();
+            dbg_nwb += __popcll(m_out); if (__ballot(st == LS_CHECK || st == LS_SLOW)) dbg_ncheck++;
 #endif
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
             if (st == LS_CHECK) {
@@ -1574,7 +1604,12 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     pre = true; st = LS_WALK;
                 } else { cnt.killed_geo++; st = LS_DEAD; }
             }
-            if (st == LS_HIT && P.any_intersect) {
+#ifdef HYP_TILE_STATS
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long dbg_tc = clock64();
+            dbg_chk += (unsigned long long)(dbg_tc - dbg_ts);
+#endif
+            if (st == LS_HIT && any_intersect) {
                 const double tact0 = hit_t * ((tau_req - tau_ach) / hit_tau);
                 t_ach += tact0;
                 if (t_ach > t_src) st = LS_REABS;       // grid_propagate_3d.f90:184-188
@@ -1607,7 +1642,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
                 H.ow = pack_ow(cell.ow);
                 H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
-                if (P.any_intersect) cold[slot].t_ach = t_ach;
+                if (any_intersect) cold[slot].t_ach = t_ach;
                 if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
                 else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                 else if (st == LS_LEFT) {                                             // H.state stays TS_WALK
@@ -1624,8 +1659,37 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 st = LS_IDLE;
             }
             if (park) break;
+#ifdef HYP_TILE_STATS
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long dbg_tw = clock64();
+            dbg_wb += (unsigned long long)(dbg_tw - dbg_tc); dbg_nclaim += __popcll(__ballot(st == LS_IDLE && !exhausted));
+#endif
+            // the wave's block of the task's queue: lane i holds the slot of entry wl_base + i; entries [wl_pos, wl_n) are still to be had
+            int wslot = -1;
+            if (HYP_TILE_WCLAIM && !RING) {
+                const bool wants = st == LS_IDLE && !exhausted;
+                const unsigned long long want = __ballot(wants);
+                if (want) {
+                    if (wl_pos == wl_n && !wl_end) {
+                        int base = 0;
+                        if (__lane_id() == 0) base = atomicAdd(&next_pkt, 64);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        wl_n = max(0, min(64, tk.len - base)); wl_pos = 0;
+                        wl_end = wl_n == 0;
+                        wl_slots = (int)__lane_id() < wl_n ? order[tk.start + base + (int)__lane_id()] : -1;
+                        if (HYP_TILE_WCLAIM > 1 && wl_slots >= 0) tile_prefetch(&hot[wl_slots], pf_lds);
+                    }
+                    const int rank = __popcll(want & ((1ull << __lane_id()) - 1ull));
+                    const int avail = wl_n - wl_pos;
+                    const int s_of = __shfl(wl_slots, (wl_pos + rank) & 63, 64);
+                    if (wants && rank < avail) wslot = s_of;
+                    wl_pos += min(avail, (int)__popcll(want));
+                }
+            }
             if (st == LS_IDLE && !exhausted) {
                 int j = RING ? claim : -1;
+                if (HYP_TILE_WCLAIM && !RING) j = wslot >= 0 ? 0 : (wl_end ? tk.len : -2);      // -2: the block ran out, served in the next service phase
+                else
                 if (RING && j < 0) {
                     // the lanes that want a packet share the landed, unclaimed records between them (rank order); the others
                     // keep waiting.  Another wave may get in between the look and the reservation: a lane that ends up
@@ -1645,10 +1709,28 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 else if (j >= tk.len) exhausted = true;
                 else if (RING && j >= tail_now) claim = j;        // not landed yet: the lane waits (m_wait)
                 else {
-                    if (RING) slot = ring.slot_of(j); else slot = order[tk.start + j];
+                    if (RING) slot = ring.slot_of(j); else if (HYP_TILE_WCLAIM) slot = wslot; else slot = order[tk.start + j];
                     int slot_ahead = 0;
                     if (HYP_TILE_PREFETCH > 0 && !RING && j + HYP_TILE_PREFETCH < tk.len) slot_ahead = order[tk.start + j + HYP_TILE_PREFETCH];
+#if HYP_TILE_BULK_LOAD
+                    // the whole record in one batch of 16-byte loads and ONE wait: read field by field, the compiler issues the loads
+                    // where the fields are first used -- three batches with a wait each, behind the branches of the v_ok test
+                    // (profiles/r04_tiled_log.md: the claim was 60 % of a service phase's clocks)
+                    union RecWords { uint4 q[sizeof(HotRec<ND>) / 16]; HotRec<ND> h; };
+                    RecWords U;
+                    if (!RING) {
+                        const uint4 *__restrict__ src = (const uint4 *)&hot[slot];
+#pragma unroll
+                        for (int i = 0; i < (int)(sizeof(HotRec<ND>) / 16); i++) U.q[i] = src[i];
+#pragma unroll
+                        for (int i = 0; i < (int)(sizeof(HotRec<ND>) / 16); i += 2)
+                            asm volatile("" : "+v"(U.q[i].x), "+v"(U.q[i].y), "+v"(U.q[i].z), "+v"(U.q[i].w),
+                                              "+v"(U.q[i + 1].x), "+v"(U.q[i + 1].y), "+v"(U.q[i + 1].z), "+v"(U.q[i + 1].w));
+                    }
+                    const HotRec<ND> &H = RING ? ring.record(j) : U.h;
+#else
                     const HotRec<ND> &H = RING ? ring.record(j) : hot[slot];
+#endif
                     claim = -1;
                     v_ok = true;
 #pragma unroll
@@ -1656,7 +1738,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                         r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a];
                         iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0);
                         inv[a] = 1.0 / v[a];
-                        v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400);
+                        v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400));
                     }
                     unpack_ow(H.ow, cell.ow);
                     tau_req = H.tau_req; tau_ach = H.tau_ach; energy = H.energy;
@@ -1665,7 +1747,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-                    if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
+                    if (any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     if (RING) ring.taken(j);
                     if (HYP_TILE_PREFETCH > 0 && !RING) {
                         // every value loaded above is "used" here: the compiler waits for them now and has nothing in flight
@@ -1684,7 +1766,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             if (__ballot(exhausted && !loader)) queue_empty = true;
 #ifdef HYP_TILE_STATS
             __builtin_amdgcn_s_waitcnt(0);      // charge the loads of the refill to the service phase
-            dbg_service += (unsigned long long)(clock64() - dbg_ts); dbg_nservice++;
+            dbg_service += (unsigned long long)(clock64() - dbg_ts); dbg_nservice++; dbg_claim += (unsigned long long)(clock64() - dbg_tw);
 #endif
         }
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
@@ -1725,7 +1807,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     const double tau_cell = chi_rho * tmin;
                     cnt.crossings++;
                     bool reabs = false;
-                    if (P.any_intersect && tau_cell < tau_req - tau_ach) { t_ach += tmin; reabs = t_ach > t_src; }
+                    if (any_intersect && tau_cell < tau_req - tau_ach) { t_ach += tmin; reabs = t_ach > t_src; }
                     if (reabs) st = LS_REABS;
                     else if (tau_cell < tau_req - tau_ach) {
 #pragma unroll
@@ -1745,7 +1827,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             }
         }
     }
-    if (HYP_TILE_PREFETCH > 0 && !RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetches still in flight
+    if ((HYP_TILE_PREFETCH > 0 || HYP_TILE_WCLAIM > 1) && !RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetches still in flight
     __syncthreads();
     if (T.split) {
         if (threadIdx.x < 27 && nb_cnt[threadIdx.x]) {
@@ -1781,6 +1863,8 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
         atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps);
         atomicAdd(&ctl->dbg[3], 1ull);
         atomicAdd(&ctl->dbg[6], dbg_service); atomicAdd(&ctl->dbg[7], dbg_nservice); atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
+        atomicAdd(&ctl->dbg[10], dbg_wb); atomicAdd(&ctl->dbg[11], dbg_claim); atomicAdd(&ctl->dbg[12], dbg_nwb); atomicAdd(&ctl->dbg[13], dbg_nclaim);
+        atomicAdd(&ctl->dbg[14], dbg_ncheck); atomicAdd(&ctl->dbg[15], dbg_chk);
         if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
     }
 #endif
