@@ -32,6 +32,9 @@
 // ahead of the rounds: 8 / 12 / 16 crossings 331.8 / 325.4 / 326.0 ms)
 #define HYP_DEFER_STEPS (GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>())
 #endif
+#ifndef HYP_CAR_INV
+#define HYP_CAR_INV 1           // Cartesian grids: the walks of the deferred schedule search the wall with one reciprocal per direction (car_find_wall_inv)
+#endif
 #ifndef HYP_PEEL_STEPS
 #define HYP_PEEL_STEPS 16       // cell crossings between two refill / deposit checks
 #endif
@@ -99,6 +102,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
     double tmin; int im[3];
     bool found;
     if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
+    else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
     else found = geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
     if (!found) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
     const size_t base = geo_index(P, p.cell) * (size_t)nd;
@@ -134,11 +138,17 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
 
 // The propagation half: final_kernel<NDT, GEOM, true> with the peel-off replaced by an event record.  FFIN = false: every escape
 // walk of the forced first interaction was made ahead of the rounds (ff_walk_kernel, B.ff), the ST_FF state is compiled out.
-template <int NDT, int GEOM, bool FFIN>
+// MONO: one launch of the monochromatic final iteration (iter_final_mono.f90:58-343; P.mono_which = 1 source packets, 2 thermal
+// packets from the grid pdf) of a problem that is plain otherwise: every interaction is a scattering weighted by the albedo, the
+// packet ends below mono_threshold of the energy it was emitted with (Packet::e_init, set aside with the packet between rounds),
+// and the peel kernel bins every event into the launch's frequency plane (image_bin_keys reads P.mono_inu).
+template <int NDT, int GEOM, bool FFIN, bool MONO = false>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
+    static_assert(!MONO || FFIN, "the monochromatic launches emit in the kernel");
+    constexpr bool FFS = FFIN && !MONO;       // the escape walk of the forced first interaction as a lane state (MONO: inline, see below)
     Walls W;
     stage_walls<GEOM>(P, lds, W);
     Packet<NDT, GEOM> p;
@@ -174,9 +184,9 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 
     for (;;) {
         if (st == ST_ESCAPED) st = ST_NEED_EMIT;
-        unsigned long long m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
-        const unsigned long long m_ffd = FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull;
-        if (FFIN && m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
+        unsigned long long m_walk = __ballot(st == ST_WALK || (FFS && st == ST_FF));
+        const unsigned long long m_ffd = FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull;
+        if (FFS && m_ffd && (__popcll(m_ffd) >= L.interact_threshold || !m_walk)) {
             // the optical depth to the edge is known: back to the source, first optical depth (iter_final.f90:195-209)
             if (st == ST_FF_DONE || st == ST_FF_KILLED) {
                 const double tau_escape = p.tau_ach;
@@ -196,11 +206,11 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 begin_integrate(P, p);
                 st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
             }
-            m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
+            m_walk = __ballot(st == ST_WALK || (FFS && st == ST_FF));
         }
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit | (FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
+        if (!(m_walk | m_int | m_emit | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
 
         // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
         // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
             }
             pool_empty = true;
             m_int = 0; m_emit = 0;
-            if (!(m_walk | (FFIN ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
+            if (!(m_walk | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
         }
 
         // peel: 0 none, 1 after emission, 2 after interaction
@@ -254,16 +264,18 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     cnt.killed_int++; st = ST_NEED_EMIT;
                 } else {
                     int scattered, dust_id;
-                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, false);
+                    // MONO: always scatter, the energy decreases by the albedo (iter_final_mono.f90:330-336)
+                    bool ok = interact<NDT, GEOM>(P, p, g, cnt, scattered, dust_id, MONO);
                     f.dust_id = dust_id;
                     if (scattered) { f.scattered = 1; f.n_scat++; last = LAST_DS; last_iso = false; }
                     else { f.scattered = 0; f.reprocessed = 1; last = LAST_DE; last_iso = true; }
-                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
+                    bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered && !MONO);
+                    if (MONO && p.energy < p.e_init * P.mono_threshold) killed = true;
                     if (killed) st = ST_NEED_EMIT;
                     else { p.inter++; peel = 2; }
                 }
             }
-            m_walk = __ballot(st == ST_WALK || (FFIN && st == ST_FF));
+            m_walk = __ballot(st == ST_WALK || (FFS && st == ST_FF));
             m_emit = __ballot(st == ST_NEED_EMIT);
         }
 
@@ -277,10 +289,24 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     rng_init(g, P.seed_key, L.iter_tag, id);
                     int source_id = 0;
                     Angle src_normal;
-                    bool ok = emit_packet<NDT, GEOM, true>(P, W, p, g, cnt, source_id, src_normal);
-                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
-                    if (!ok) st = ST_NEED_EMIT;
-                    else { peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true; }
+                    if (MONO && P.mono_which == 2) {
+                        // thermal packets of the monochromatic iteration: iter_final_mono.f90:176-196
+                        int dust_id = 0;
+                        bool ok = emit_mono_dust<NDT, GEOM>(P, W, p, g, cnt, dust_id);
+                        f.scattered = 0; f.reprocessed = 1; f.n_scat = 0; f.dust_id = dust_id; f.source_id = 0;
+                        if (!ok) st = ST_NEED_EMIT;
+                        else { peel = 1; last = LAST_DE; st = ST_PLACED; p.reabs = 0; last_iso = true; p.e_init = p.energy; }
+                    } else {
+                        // (MONO: the general emitter -- the energy carries the source's emission probability at the launch's frequency;
+                        // the sources are isotropic points, the host checks)
+                        bool ok = emit_packet<NDT, GEOM, !MONO>(P, W, p, g, cnt, source_id, src_normal);
+                        f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                        if (!ok) st = ST_NEED_EMIT;
+                        else {
+                            if (MONO) { p.energy = p.energy / P.mono_n_total; p.e_init = p.energy; }     // iter_final_mono.f90:113-116
+                            peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true;
+                        }
+                    }
                 } else {
                     // the packet was emitted ahead of the rounds (ff_walk_kernel): what emit_packet<.., SIMPLE> leaves in a packet,
                     // from the record; a packet whose emission failed raised its error there (the launch stops below)
@@ -345,22 +371,39 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 w_pos += __popcll(m); n_written += __popcll(m);
             }
             if (peel != 0) {
-                if (GEOM == GEOM_OCT) {         // the direction is new
+                if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {         // the direction is new
                     v_ok = true;
 #pragma unroll
-                    for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                    for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
                 }
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
-                    else if (!FFIN) {
+                    else if (MONO) {
+                        // a thermal packet starts anywhere in the grid: the escape walk is made here, from where the packet is, the
+                        // way final_kernel makes it (once per packet, against ~30 forced scatterings)
+                        bool sampled = false;
+                        if (P.forced_first) {
+                            bool killed = false;
+                            const double tau_escape = escape_tau<NDT, GEOM>(P, W, p.r, p.v, p.cell, p.chi, g, cnt, killed);
+                            if (tau_escape > 1e-10 && !killed) {
+                                double weight, tau;
+                                forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                                p.tau_req = tau; p.energy *= weight; sampled = true;
+                            }
+                        }
+                        if (!sampled) p.tau_req = rng_exp(g);
+                        p.tau_ach = 0.0;
+                        begin_integrate(P, p);
+                        st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
+                    } else if (!FFIN) {
                         // escape walk and first optical depth (iter_final.f90:195-209) were made ahead of the rounds; the packet
                         // has not moved
                         p.tau_req = ff_tau_req; p.energy = ff_energy;
                         p.tau_ach = 0.0;
                         begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
-                    } else if (P.forced_first) {
+                    } else if (FFS && P.forced_first) {
                         p.tau_ach = 0.0; p.tau_req = 0.0;
                         geo_begin(p.r, p.v, p.cell);
                         st = ST_FF;
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 
 #pragma unroll 1
         for (int k = 0; k < HYP_DEFER_STEPS; k++) {
-            if (FFIN) { if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok); }
+            if (FFS) { if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok); }
             else if (st == ST_WALK) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, false, inv, v_ok);
         }
     }
@@ -501,10 +544,10 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
                         R.energy = p.energy; R.tau_req = 0.0;
                         R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b; R.code = (g.have_a & 1) | (1 << 1); R.countdown = g.countdown;
                     } else {
-                        if (GEOM == GEOM_OCT) {
+                        if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
                             v_ok = true;
 #pragma unroll
-                            for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok && (p.v[a] == 0.0 || fabs(p.v[a]) >= 0x1p-400); }
+                            for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
                         }
                         p.tau_ach = 0.0; p.tau_req = 0.0;
                         geo_begin(p.r, p.v, p.cell);
@@ -726,10 +769,10 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         }
                     }
                     angle_to_vector(a_req, v[0], v[1], v[2]);
-                    if (GEOM == GEOM_OCT) {
+                    if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
                         v_ok = true;
 #pragma unroll
-                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok && (v[a] == 0.0 || fabs(v[a]) >= 0x1p-400); }
+                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
                     }
                     c = E.cell;
                     bool ok = geo_place(P, W, r, v, c);
@@ -782,6 +825,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 double tmin = 0.0; int im[3];
                 bool found;
                 if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
                 else found = geo_find_wall(P, W, r, v, c, tmin, im);
                 if (!check_ok || !found) { cnt.killed_geo++; st = 0; }
                 else {

@@ -281,6 +281,8 @@ struct hyp_engine {
     double *d_mono_cdf = nullptr;       // [n_dust][n_cells]
     double *d_mono_mean = nullptr;      // [HYP_MAXD]
     bool mono_pending = false;
+    int mono_defer_opt = 1;             // option mono_defer: 1 = monochromatic launches of plain problems on the deferred schedule, 0 = the general kernel
+    int last_mono_deferred = 0;
     hyp_iter_stats mono_stats;
 
     // n_photons / frequency-resolved specific energy / PDA / convergence (hyp_epilogue.h)
@@ -288,6 +290,7 @@ struct hyp_engine {
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool ext_sources = false;       // point and external (box / sphere) sources with tabulated or blackbody spectra only: tile_emit_kernel<.., 2>
+    bool mono_defer = false;        // a monochromatic run of a problem that is plain otherwise: its launches run on the deferred schedule (final_defer_kernel<.., true, true>)
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
     // deferred peel-off (hyp_defer.h): event buffer, control block, packets / id ranges carried between rounds
@@ -1936,6 +1939,11 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         for (int i = 0; i < pr->n_sources; i++) plain = plain && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
         // (filters are the peel kernel's / deposit_images' business; inside observers are the peel kernel's, not the inline plain kernel's)
         h->plain_imaging = plain && h->n_dust <= 4;      // five to eight species: the general kernel only (hyp_geom.hip)
+        {
+            bool md = pr->config.monochromatic && !pr->config.mrw && !pr->binned && h->n_dust <= 4;
+            for (int i = 0; i < pr->n_sources; i++) md = md && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
+            h->mono_defer = md;
+        }
         h->inside_observers = false;
         for (int g = 0; g < pr->n_peeled; g++) h->inside_observers = h->inside_observers || pr->peeled[g].inside_observer;
         {
@@ -2916,6 +2924,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 3 ? 3 : (int)value;
+    else if (n == "mono_defer") h->mono_defer_opt = value ? 1 : 0;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
@@ -2967,6 +2976,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
+    else if (n == "mono_defer") *value = h->mono_defer_opt;
+    else if (n == "last_mono_deferred") *value = h->last_mono_deferred;
     else if (n == "last_tiled_imaging") *value = h->last_tiled_imaging;
     else if (n == "peel_sort") *value = h->peel_sort;
     else if (n == "ff_prepass") *value = h->ff_prepass;
@@ -3103,11 +3114,12 @@ static void defer_peel_events(hyp_handle h, const DeferKernels &dk, const DeferB
     hipLaunchKernelGGL(h->inside_observers ? dk.peel_inside : dk.peel, dim3(peel_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, B, iter_tag);
 }
 
-static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, unsigned blocks, size_t lds)
+static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, unsigned blocks, size_t lds, bool ff_ahead = true)
 {
     DeferBuf B;
     defer_setup_buffers(h, dk, B);
-    defer_ff_prepass(h, dk, L, B, lds);
+    if (ff_ahead) defer_ff_prepass(h, dk, L, B, lds);
+    else h->last_ff_prepass = 0;
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
@@ -3470,7 +3482,20 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
     LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, 0);
     const size_t lds = lds_bytes(P);
+    // problems that are plain apart from being monochromatic: the launch on the deferred schedule (hyp_defer.h: the propagation
+    // kernel writes events, the peel kernel walks them sorted by cell into the launch's frequency plane); option mono_defer = 0: inline
+    bool deferred = h->mono_defer && h->mono_defer_opt && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    DeferKernels dk;
+    std::memset(&dk, 0, sizeof dk);
+    if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
+    if (deferred && !dk.propagate_mono) deferred = false;
     long long blocks = (long long)h->n_cu * 2;
+    if (deferred) {
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)dk.propagate_mono, 256, lds) != hipSuccess || occ <= 0) occ = 2;
+        blocks = (long long)h->n_cu * occ;
+        if (defer_buffers(h, dk, (size_t)blocks * 256, n_local * 4)) deferred = false;      // (a packet leaves tens of events: fewer rounds)
+    }
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
@@ -3483,8 +3508,15 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     // the monochromatic iteration is final_kernel with inline peel-off: the imaging iteration's batch sizes
     L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : 32;
     L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : 48;
+    h->last_mono_deferred = deferred ? 1 : 0;
     (void)hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    if (deferred) {
+        L.interact_threshold = h->final_interact_threshold >= 0 ? h->final_interact_threshold : 16;
+        L.emit_threshold = h->final_emit_threshold >= 0 ? h->final_emit_threshold : 48;
+        dk.propagate = dk.propagate_mono;
+        if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds, false)) { P.mono_which = 0; h->mono_pending = false; return 1; }
+    } else
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
     (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("final_kernel (monochromatic) launch: ") + hipGetErrorString(e));

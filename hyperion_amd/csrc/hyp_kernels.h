@@ -53,6 +53,7 @@ struct Packet {
     int spec_idx;               // frequency bin of the specific-energy spectrum during this grid_integrate (-1: none)
     unsigned int peel_seq;      // peel-off events of this packet so far (keys the check stream of the peel-off walks)
     int n_visited;              // cells this packet has been counted in (count_photon)
+    double e_init;              // monochromatic launches on the deferred schedule: energy at emission (iter_final_mono.f90:247)
 };
 
 // extra state carried only by the imaging (final) iteration
@@ -226,6 +227,100 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
 {
 #pragma unroll
     for (int a = 0; a < 3; a++) { c.ic[a] += im[a]; c.ow[a] = -im[a]; }
+}
+
+#ifndef HYP_TILE_LDS_FRONT
+#define HYP_TILE_LDS_FRONT 0     // find_wall_ahead: the step's nine wall reads issued together (measured neutral)
+#endif
+// find_wall for the common case that, on every axis, the wall *behind* the packet is not a
+// candidate of geo_find_wall (it is one only if round-off left the packet outside its cell on
+// an axis where it is not flagged as sitting on that wall).  Then at most the wall ahead is a
+// candidate on each axis, with exactly geo_find_wall's condition, and the candidates are merged
+// in the same order with the same epsilon rules.  Written without control flow: the wall ahead
+// is picked by index arithmetic (iu = 1 where v > 0) and the sign tests are products with
+// sgn = +-1 or 0 (exact), so that the three IEEE divisions can be scheduled together and no
+// lane-divergent branch is left in the step.  Returns false when the precondition fails; the
+// caller then uses geo_find_wall.
+//
+// The three quotients d / v are formed with the reciprocals inv = RN(1 / v) that the lane
+// computed (with a true IEEE division) when it took the packet -- the direction is fixed during
+// a visit: q0 = RN(d inv), rem = d - q0 v (exact in one FMA), t = RN(q0 + rem inv).  By
+// Markstein's theorem (IBM J. Res. Dev. 34, 1990; Muller et al., Handbook of Floating-Point
+// Arithmetic, 2nd ed., Thm 4.8) t is then the correctly rounded quotient RN(d / v), i.e.
+// bit-for-bit the IEEE division of the reference formulation, for 3 instructions instead of
+// the ~14 of a division (div_scale x2, rcp, 8 FMA steps, div_fmas, div_fixup).  The theorem
+// needs no underflow/overflow in q0, rem and inv: the caller enables this path (v_ok) only when
+// every non-zero direction component is at least 2^-400 in magnitude, the distances d are
+// differences of wall and position coordinates (zero or >= one ulp of a coordinate), and an axis
+// with v = 0 is never a candidate, so its inf/NaN quotient is not looked at.
+// tools/ubench/markstein_check.c compares the sequence with the division on 4e8 operand pairs
+// including all-ones / near-power-of-two / short mantissas: no mismatch.
+__device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const double inv[3],
+                                                const int iu[3], const double sgn[3],
+                                                const Cell<GEOM_CAR> &c, double &tnear, int im[3], bool &found)
+{
+    double tmin = HYP_DBL_MAX, emin = 0.0;
+    int m0 = 0, m1 = 0, m2 = 0;
+    bool simple = true;
+#if HYP_TILE_LDS_FRONT
+    // all nine LDS reads of the step before the arithmetic (one wait instead of five)
+    double wa_[3], wb_[3], ea_[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { wa_[a] = W.w[a][c.ic[a] + iu[a]]; wb_[a] = W.w[a][c.ic[a] + 1 - iu[a]]; ea_[a] = W.ew[a][c.ic[a] + iu[a]]; }
+    asm volatile("" : "+v"(wa_[0]), "+v"(wa_[1]), "+v"(wa_[2]), "+v"(wb_[0]), "+v"(wb_[1]), "+v"(wb_[2]), "+v"(ea_[0]), "+v"(ea_[1]), "+v"(ea_[2]));
+#endif
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int ia = c.ic[a] + iu[a], ib = c.ic[a] + 1 - iu[a];
+#if HYP_TILE_LDS_FRONT
+        const double d = wa_[a] - r[a], db = wb_[a] - r[a];
+        (void)ib;
+#else
+        const double d = W.w[a][ia] - r[a], db = W.w[a][ib] - r[a];
+#endif
+        const int dir = 2 * iu[a] - 1, ow = c.ow[a];
+        // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
+        const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
+        // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
+        simple = simple & !((ow != -dir) & (db * sgn[a] > 0.0));
+#ifdef HYP_TILE_TRUE_DIV
+        const double t = d / v[a];
+#else
+        const double q0 = d * inv[a];
+        const double t = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
+#endif
+#if HYP_TILE_LDS_FRONT
+        const double emax = fmax(ea_[a], emin);
+#else
+        const double emax = fmax(W.ew[a][ia], emin);
+#endif
+        const bool lt = cand & (t < tmin - emax);
+        const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
+        tmin = lt ? t : tmin;
+        emin = any ? emax : emin;
+        const int mine = any ? dir : 0;
+        if (a == 0) m0 = mine;
+        if (a == 1) { m0 = lt ? 0 : m0; m1 = mine; }
+        if (a == 2) { m0 = lt ? 0 : m0; m1 = lt ? 0 : m1; m2 = mine; }
+    }
+    tnear = tmin;
+    im[0] = m0; im[1] = m1; im[2] = m2;
+    found = (m0 | m1 | m2) != 0;
+    return simple;
+}
+
+// geo_find_wall for a direction that stays fixed over many steps (a peel-off walk, a packet between two interactions), inv =
+// RN(1 / v) per axis computed once (the caller checks v_ok: every non-zero component at least 2^-400 in magnitude): the branch-free
+// search above where it applies, geo_find_wall otherwise -- the same wall, the same t, bit for bit.
+__device__ __forceinline__ bool car_find_wall_inv(const DProblem &P, const Walls &W, const double r[3], const double v[3], const double inv[3],
+                                                  const Cell<GEOM_CAR> &c, double &tnear, int im[3])
+{
+    int iu[3]; double sgn[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) { iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0); }
+    bool found;
+    if (find_wall_ahead(W, r, v, inv, iu, sgn, c, tnear, im, found)) return found;
+    return geo_find_wall(P, W, r, v, c, tnear, im);
 }
 
 // ------------------------------- octree -------------------------------------

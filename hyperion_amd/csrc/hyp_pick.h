@@ -18,6 +18,7 @@ using PeelKernel = void (*)(const DProblem *, DeferBuf, uint32_t);
 using PeelSortK = void (*)(const DProblem *, DeferBuf);
 struct DeferKernels {
     DeferKernel propagate, propagate_pre, ff_walk;       // propagate_pre: with the forced-first walks made ahead (ff_walk)
+    DeferKernel propagate_mono;                          // a launch of the monochromatic iteration (final_defer_kernel<.., true, true>)
     PeelKernel peel, peel_inside; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
     PeelSortK sort_hist, sort_scatter; void (*sort_scan)(DeferBuf);  // sorted peel-off: keys + histogram, scatter (peel_sort_scan_kernel between them)
 };

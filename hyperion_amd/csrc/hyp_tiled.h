@@ -588,6 +588,9 @@ __device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileC
     for (int i = threadIdx.x; i < n_int; i += blockDim.x) ilist[T.n_slots + base[0] + i] = ilist[tk.start + i];
     for (int i = threadIdx.x; i < n_dead; i += blockDim.x) dlist[T.n_slots + base[1] + i] = dlist[tk.start + i];
 }
+#ifndef HYP_INTERACT_SORT
+#define HYP_INTERACT_SORT 1          // 1: a chunk's entries ordered by kind (absorption / scattering) on a peek at their random streams; 0: taken as listed
+#endif
 #define HYP_INTERACT_CHUNK 1024     // list entries that tile_interact orders by kind at a time
 
 // REABS: the problem has sources that can absorb packets (P.any_intersect), so slots may wait for a re-emission;
@@ -646,6 +649,10 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         if (threadIdx.x == 0) { n_abs = 0; n_oth = 0; }
         __syncthreads();
         const int n_chunk = min(CH, n_int - c0);
+#if !HYP_INTERACT_SORT
+        for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) sorted[k] = list[c0 + k];
+        if (threadIdx.x == 0) n_abs = n_chunk;
+#else
         for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) {
             const int slot = list[c0 + k];
             const HotRec<ND> &H = hot[slot];
@@ -676,6 +683,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if (absorb) sorted[atomicAdd(&n_abs, 1)] = slot;
             else sorted[CH - 1 - atomicAdd(&n_oth, 1)] = slot;
         }
+#endif
         __syncthreads();
         const int na = n_abs, oth0 = (na + 63) & ~63, nl = oth0 + n_oth;      // the other kind starts on a wave boundary
     for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
@@ -1302,82 +1310,7 @@ template <> struct TileShape<4> { static constexpr int X = 32, Y = 8, Z = 8; }; 
 // "service" phase that runs when at least 16 lanes of the wave wait for it.
 // ---------------------------------------------------------------------------
 
-// find_wall for the common case that, on every axis, the wall *behind* the packet is not a
-// candidate of geo_find_wall (it is one only if round-off left the packet outside its cell on
-// an axis where it is not flagged as sitting on that wall).  Then at most the wall ahead is a
-// candidate on each axis, with exactly geo_find_wall's condition, and the candidates are merged
-// in the same order with the same epsilon rules.  Written without control flow: the wall ahead
-// is picked by index arithmetic (iu = 1 where v > 0) and the sign tests are products with
-// sgn = +-1 or 0 (exact), so that the three IEEE divisions can be scheduled together and no
-// lane-divergent branch is left in the step.  Returns false when the precondition fails; the
-// caller then uses geo_find_wall.
-//
-// The three quotients d / v are formed with the reciprocals inv = RN(1 / v) that the lane
-// computed (with a true IEEE division) when it took the packet -- the direction is fixed during
-// a visit: q0 = RN(d inv), rem = d - q0 v (exact in one FMA), t = RN(q0 + rem inv).  By
-// Markstein's theorem (IBM J. Res. Dev. 34, 1990; Muller et al., Handbook of Floating-Point
-// Arithmetic, 2nd ed., Thm 4.8) t is then the correctly rounded quotient RN(d / v), i.e.
-// bit-for-bit the IEEE division of the reference formulation, for 3 instructions instead of
-// the ~14 of a division (div_scale x2, rcp, 8 FMA steps, div_fmas, div_fixup).  The theorem
-// needs no underflow/overflow in q0, rem and inv: the caller enables this path (v_ok) only when
-// every non-zero direction component is at least 2^-400 in magnitude, the distances d are
-// differences of wall and position coordinates (zero or >= one ulp of a coordinate), and an axis
-// with v = 0 is never a candidate, so its inf/NaN quotient is not looked at.
-// tools/ubench/markstein_check.c compares the sequence with the division on 4e8 operand pairs
-// including all-ones / near-power-of-two / short mantissas: no mismatch.
-__device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const double inv[3],
-                                                const int iu[3], const double sgn[3],
-                                                const Cell<GEOM_CAR> &c, double &tnear, int im[3], bool &found)
-{
-    double tmin = HYP_DBL_MAX, emin = 0.0;
-    int m0 = 0, m1 = 0, m2 = 0;
-    bool simple = true;
-#if HYP_TILE_LDS_FRONT
-    // all nine LDS reads of the step before the arithmetic (one wait instead of five)
-    double wa_[3], wb_[3], ea_[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { wa_[a] = W.w[a][c.ic[a] + iu[a]]; wb_[a] = W.w[a][c.ic[a] + 1 - iu[a]]; ea_[a] = W.ew[a][c.ic[a] + iu[a]]; }
-    asm volatile("" : "+v"(wa_[0]), "+v"(wa_[1]), "+v"(wa_[2]), "+v"(wb_[0]), "+v"(wb_[1]), "+v"(wb_[2]), "+v"(ea_[0]), "+v"(ea_[1]), "+v"(ea_[2]));
-#endif
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const int ia = c.ic[a] + iu[a], ib = c.ic[a] + 1 - iu[a];
-#if HYP_TILE_LDS_FRONT
-        const double d = wa_[a] - r[a], db = wb_[a] - r[a];
-        (void)ib;
-#else
-        const double d = W.w[a][ia] - r[a], db = W.w[a][ib] - r[a];
-#endif
-        const int dir = 2 * iu[a] - 1, ow = c.ow[a];
-        // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
-        const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
-        // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
-        simple = simple & !((ow != -dir) & (db * sgn[a] > 0.0));
-#ifdef HYP_TILE_TRUE_DIV
-        const double t = d / v[a];
-#else
-        const double q0 = d * inv[a];
-        const double t = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
-#endif
-#if HYP_TILE_LDS_FRONT
-        const double emax = fmax(ea_[a], emin);
-#else
-        const double emax = fmax(W.ew[a][ia], emin);
-#endif
-        const bool lt = cand & (t < tmin - emax);
-        const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
-        tmin = lt ? t : tmin;
-        emin = any ? emax : emin;
-        const int mine = any ? dir : 0;
-        if (a == 0) m0 = mine;
-        if (a == 1) { m0 = lt ? 0 : m0; m1 = mine; }
-        if (a == 2) { m0 = lt ? 0 : m0; m1 = lt ? 0 : m1; m2 = mine; }
-    }
-    tnear = tmin;
-    im[0] = m0; im[1] = m1; im[2] = m2;
-    found = (m0 | m1 | m2) != 0;
-    return simple;
-}
+// (find_wall_ahead, the branch-free wall search of the step, lives in hyp_kernels.h: the deferred imaging kernels use it too)
 
 // geo_in_correct_cell (grid_geometry_cartesian_3d.f90:330-381) for a packet whose cell lies in the brick [x0, x1) when only the
 // brick's own walls are at hand (W indexed by grid position, valid on [x0, x1] per axis) plus the grid's outer walls gb =

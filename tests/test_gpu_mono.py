@@ -165,3 +165,79 @@ def test_lte_map_source_in_monochromatic_mode():
                              n_ap=1, ap_min=2 * PC, ap_max=2 * PC, track_origin="basic", n_wav=4, inu_min=1, inu_max=4)]
     ra, st = run_mono_both(p, 20000, 10000, 10000)
     assert ra[0]["sed"][0, 0].max() > 0 and ra[0]["sed"][0, 1].max() > 0
+
+
+# ---- round 4: the launches of a plain problem's monochromatic iteration on the deferred schedule (hyp_defer.h:
+# final_defer_kernel<.., true, true> writes events, peel_kernel walks them sorted by cell into the launch's frequency plane) ----
+
+def _mono_deferred_vs_inline(prob, n_lucy, n_src, n_dust, peel_events=0, oracle=True):
+    """The same iteration on the deferred schedule (default), on the general kernel with inline peel-off (mono_defer = 0)
+    and on the CPU oracle: integer tallies equal, cubes to 1e-9."""
+    out = []
+    for defer in (1, 0):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("mono_defer", defer)
+        if peel_events and defer:
+            eng.set_option("peel_events", peel_events)
+        eng.lucy_iteration(n_lucy, 1)
+        res, st = eng.mono_iteration(n_src, n_dust)
+        assert eng.get_option("last_mono_deferred") == defer
+        rounds = eng.get_option("last_defer_rounds") if defer else 0
+        eng.close()
+        out.append((res, st, rounds))
+    (ra, sa, rounds), (rb, sb, _) = out
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    compare_cubes(ra, rb)
+    if oracle:
+        orc = Oracle(prob)
+        orc.lucy_iteration(n_lucy, 1)
+        ro, so = orc.mono_iteration(n_src, n_dust)
+        orc.close()
+        for k in INT_KEYS:
+            assert sa[k] == so[k], (k, sa, so)
+        compare_cubes(ra, ro)
+    return ra, sa, rounds
+
+
+@pytest.mark.parametrize("forced_first", [True, False])
+def test_mono_deferred_equals_inline_cartesian(forced_first):
+    p = mono_problem(imaging_problem(n=10, tau=2.0, track_origin="basic"), [0.5, 2.0, 20.0, 300.0])
+    p.config.forced_first_interaction = forced_first
+    ra, st, _ = _mono_deferred_vs_inline(p, 20000, 20000, 20000)
+    assert st["interactions"] > 20000 and np.nansum(ra[0]["img"]) > 0
+
+
+def test_mono_deferred_many_rounds_small_event_buffer():
+    """An event buffer of 4096 slots: packets are set aside between rounds with the energy they were emitted with
+    (Packet::e_init), which the energy threshold of the forced scatterings needs."""
+    p = mono_problem(imaging_problem(n=8, tau=4.0), [1.0, 30.0])
+    p.config.monochromatic_energy_threshold = 1e-6
+    _, st, rounds = _mono_deferred_vs_inline(p, 10000, 6000, 6000, peel_events=4096)
+    assert rounds >= 3
+
+
+def test_mono_deferred_two_species_and_raytracing_peels_scattered_light_only():
+    p = imaging_problem(n=8, tau=2.0, track_origin="detailed")
+    p.dust = [p.dust[0], load_test_dust()]
+    p.density = np.concatenate([0.7 * p.density, 0.3 * p.density], axis=0)
+    p = mono_problem(p, [0.4, 4.0, 40.0])
+    p.config.raytracing = True
+    _mono_deferred_vs_inline(p, 20000, 15000, 15000)
+
+
+def test_mono_deferred_octree():
+    from hyperion_amd.benchmark import make_octree_problem
+    p = mono_problem(make_octree_problem(max_level=4, n_pix=16), [1.0, 10.0, 100.0])
+    _mono_deferred_vs_inline(p, 20000, 10000, 10000)
+
+
+def test_mono_with_a_stellar_sphere_stays_on_the_general_kernel():
+    """Sources with a radius (limb darkening, re-absorption) are not what the deferred kernels cover."""
+    p = mono_problem(imaging_problem(n=6, tau=1.0), [1.0, 10.0])
+    p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.01 * PC)]
+    eng = hyperion_amd.Engine(p)
+    eng.lucy_iteration(5000, 1)
+    eng.mono_iteration(2000, 2000)
+    assert eng.get_option("last_mono_deferred") == 0
+    eng.close()
