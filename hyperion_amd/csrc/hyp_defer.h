@@ -297,9 +297,9 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                         if (!ok) st = ST_NEED_EMIT;
                         else { peel = 1; last = LAST_DE; st = ST_PLACED; p.reabs = 0; last_iso = true; p.e_init = p.energy; }
                     } else {
-                        // (MONO: the general emitter -- the energy carries the source's emission probability at the launch's frequency;
-                        // the sources are isotropic points, the host checks)
-                        bool ok = emit_packet<NDT, GEOM, !MONO>(P, W, p, g, cnt, source_id, src_normal);
+                        // (MONO: the energy carries the source's emission probability at the launch's frequency; the sources are
+                        // isotropic points with tabulated or blackbody spectra, the host checks)
+                        bool ok = emit_packet<NDT, GEOM, MONO ? 3 : 1>(P, W, p, g, cnt, source_id, src_normal);
                         f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                         if (!ok) st = ST_NEED_EMIT;
                         else {
@@ -664,6 +664,78 @@ __global__ __launch_bounds__(256) void peel_sort_scatter_kernel(const DProblem *
     }
 }
 
+// Direct light of the point sources: one lane per (source, view) makes the walk every emission event of that source makes
+// towards that view in peel_kernel -- same placement, same wall search, same order of the checks -- and leaves the column density
+// per species, the crossings and how the walk ends (DirectCol).  No propagation check is made here: a real walk draws the step
+// of its first check when it is set up (peel_rng), and the peel kernel takes the recorded walk only for the pairs whose first check
+// would fall behind the walk's last crossing (about 96 % of them at the default frequency of 1e-3 and ~40 crossings); the others are
+// walked as before, check included.
+template <int NDT, int GEOM>
+__global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__restrict__ Pp, DirectCol *__restrict__ out)
+{
+    extern __shared__ double lds[];
+    const DProblem &P = *Pp;
+    Walls W;
+    stage_walls<GEOM>(P, lds, W);
+    const int nd = ndust<NDT>(P);
+    const int n_views = P.n_views_total, n = P.n_sources * n_views;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int is = k / n_views, vg = k % n_views;
+        DirectCol dc;
+        dc.col[0] = dc.col[1] = dc.col[2] = dc.col[3] = 0.0; dc.crossings = 0; dc.status = 0;
+        int g_i = 0;
+        while (g_i + 1 < P.n_peeled && vg >= P.peeled[g_i + 1].view_base) g_i++;
+        const DPeeled &G = P.peeled[g_i];
+        const int iv = vg - G.view_base;
+        const DSource &S = P.sources[is];
+        if (S.type == 1 && !G.inside_observer && !G.ignore_optical_depth && NDT <= 4) {
+            Angle a_req;
+            a_req.cost = G.view[4 * iv + 0]; a_req.sint = G.view[4 * iv + 1];
+            a_req.cosp = G.view[4 * iv + 2]; a_req.sinp = G.view[4 * iv + 3];
+            double r[3] = {S.pos[0], S.pos[1], S.pos[2]}, v[3];
+            angle_to_vector(a_req, v[0], v[1], v[2]);
+            double inv[3] = {1.0, 1.0, 1.0};
+            bool v_ok = true;
+            if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
+#pragma unroll
+                for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
+            }
+            Cell<GEOM> c;
+            memset(&c, 0, sizeof c);
+            if (geo_place(P, W, r, v, c)) {        // (not placed: the peel kernel counts a killed packet per event and does not walk)
+                geo_begin(r, v, c);
+                int status = 1;
+                unsigned int crossings = 0;
+                double col[NDT];
+#pragma unroll
+                for (int d = 0; d < NDT; d++) col[d] = 0.0;
+                if (!geo_escaped(P, c)) for (;;) {
+                    double tmin = 0.0; int im[3];
+                    bool found;
+                    if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                    else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                    else found = geo_find_wall(P, W, r, v, c, tmin, im);
+                    if (!found) { status = 2; break; }
+                    const size_t base = geo_index(P, c) * (size_t)nd;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
+#pragma unroll
+                    for (int d = 0; d < NDT; d++) if (d < nd) col[d] += hyp_ldg(P.density + base + d) * tmin;
+                    crossings++;
+                    geo_advance(P, r, c, im);
+                    if (geo_invalid(P, c)) { status = 2; break; }
+                    if (geo_escaped(P, c)) break;
+                    if (crossings > (1u << 26)) { status = 0; break; }
+                }
+                dc.status = status; dc.crossings = crossings;
+#pragma unroll
+                for (int d = 0; d < NDT; d++) if (d < 4) dc.col[d] = col[d];
+            }
+        }
+        out[k] = dc;
+    }
+}
+
 // The peel-off half: one lane per (event, view), peeloff<.., PLAIN> up to the walk, grid_escape_tau
 // (grid_propagate_3d.f90:377-480) a few cells at a time, image_bin at the end.
 // INSIDE: some peeled group has an inside observer (the walk towards the observer's position, ended at the observer: 18 spilled VGPRs
@@ -807,6 +879,18 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         else {
                             geo_begin(r, v, c);
                             if (geo_escaped(P, c)) st = 2;
+                            else if (B.direct && last == LAST_SR && NDT <= 4) {
+                                // the direct light of a point source: the walk every packet of that source makes towards this view
+                                const DirectCol dc = B.direct[(size_t)f.source_id * (size_t)n_views + (size_t)vg];
+                                // (its first propagation check falls on step gp.countdown: behind the walk's crossings, or on the step that
+                                // ends a status-2 walk anyway)
+                                if (dc.status && (unsigned int)gp.countdown >= dc.crossings) {
+#pragma unroll
+                                    for (int dd = 0; dd < NDT; dd++) if (dd < nd && dd < 4) tau += chi[dd] * dc.col[dd];
+                                    cnt.crossings += dc.crossings;
+                                    if (dc.status == 2) { cnt.killed_geo++; st = 0; } else st = 2;
+                                }
+                            }
                         }
                     }
                 }

@@ -328,6 +328,14 @@ struct PeelCtl {
     unsigned long long ff_cursor;       // packet ids handed out by the forced-first-interaction pre-pass (ff_walk_kernel)
 };
 
+// The direct light of a point source towards one view is the same walk for every packet (same start, same direction): its
+// column density per dust species, crossings and fate, computed once per (source, view) by direct_column_kernel (hyp_defer.h);
+// the peel kernel then gives an emission's (event, view) pair tau = sum_d chi_d(nu) x col[d] instead of walking it again.
+struct DirectCol {
+    double col[4];                      // sum of rho_d x t over the cells of the walk
+    unsigned int crossings;             // cells crossed (what every such walk adds to the crossing tally)
+    int status;                         // 0: walk it (inside observer, not a point source, ...);
+};                                      // 1: leaves the grid; 2: ends in a failed wall search / an invalid cell (one killed packet per event)
 struct DeferBuf {
     void *events;                       // PeelEvent<NDT, GEOM>[cap] (hyp_defer.h)
     unsigned long long cap;             // a multiple of HYP_PEEL_CHUNK
@@ -344,6 +352,7 @@ struct DeferBuf {
     // emission and forced first interaction made ahead of the rounds (hyp_defer.h: ff_walk_kernel): EmitRec<NDT>[packet ids of the
     // launch]; null = the propagation kernel emits and walks to the edge itself (ST_FF lanes)
     void *ff;
+    const DirectCol *direct;            // [n_sources x n_views_total] or null (option direct_memo = 0, memory)
 };
 #define HYP_SORT_EMPTY 0xffffffffu
 #ifndef HYP_SORT_MAX_BINS

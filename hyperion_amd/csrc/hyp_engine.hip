@@ -280,6 +280,8 @@ struct hyp_engine {
     std::vector<double> frequencies;
     double *d_mono_cdf = nullptr;       // [n_dust][n_cells]
     double *d_mono_mean = nullptr;      // [HYP_MAXD]
+    DirectCol *d_direct = nullptr; size_t direct_cap = 0;       // direct light of the point sources, per (source, view): hyp_defer.h
+    int direct_memo = 1, last_direct_memo = 0;                   // option direct_memo
     bool mono_pending = false;
     int mono_defer_opt = 1;             // option mono_defer: 1 = monochromatic launches of plain problems on the deferred schedule, 0 = the general kernel
     int last_mono_deferred = 0;
@@ -854,7 +856,7 @@ void hyp_destroy(hyp_handle h)
     free_dev(h->d_oct_cells); free_dev(h->d_oct_children); free_dev(h->d_oct_neigh);
     free_dev(h->d_at_slabs); free_dev(h->d_at_go); free_dev(h->d_at_grid_c0); free_dev(h->d_at_grid_nz);
     free_dev(h->d_ot_cluster); free_dev(h->d_ot_c0); free_dev(h->d_ot_nc); free_dev(h->d_ot_kid_off); free_dev(h->d_ot_rec); free_dev(h->d_ot_kid); free_dev(h->d_ot_nb);
-    free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean);
+    free_dev(h->d_mono_cdf); free_dev(h->d_mono_mean); free_dev(h->d_direct);
     free_dev(h->d_vor_bb);
     free_dev(h->d_vor_sites); free_dev(h->d_vor_volume); free_dev(h->d_vor_idx); free_dev(h->d_vor_neigh); free_dev(h->d_vor_seed); free_dev(h->d_vor_walls);
     free_dev(h->d_mask_map);
@@ -2925,6 +2927,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 3 ? 3 : (int)value;
     else if (n == "mono_defer") h->mono_defer_opt = value ? 1 : 0;
+    else if (n == "direct_memo") h->direct_memo = value ? 1 : 0;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
     else if (n == "oct_neighbours") { h->oct_neighbours = value != 0; h->hp.oct_neigh = h->oct_neighbours ? h->d_oct_neigh : nullptr; }
@@ -2977,6 +2980,8 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
     else if (n == "mono_defer") *value = h->mono_defer_opt;
+    else if (n == "direct_memo") *value = h->direct_memo;
+    else if (n == "last_direct_memo") *value = h->last_direct_memo;
     else if (n == "last_mono_deferred") *value = h->last_mono_deferred;
     else if (n == "last_tiled_imaging") *value = h->last_tiled_imaging;
     else if (n == "peel_sort") *value = h->peel_sort;
@@ -3056,7 +3061,23 @@ static void defer_setup_buffers(hyp_handle h, const DeferKernels &dk, DeferBuf &
 {
     B.events = h->d_peel_events; B.cap = h->peel_cap; B.ctl = h->d_peel_ctl;
     B.susp[0] = h->d_peel_susp[0]; B.susp[1] = h->d_peel_susp[1]; B.ret[0] = h->d_peel_ret[0]; B.ret[1] = h->d_peel_ret[1];
-    B.order = nullptr; B.keys = nullptr; B.bins = nullptr; B.n_bins = 0; B.ff = nullptr; B.cur = 0;
+    B.order = nullptr; B.keys = nullptr; B.bins = nullptr; B.n_bins = 0; B.ff = nullptr; B.cur = 0; B.direct = nullptr;
+    h->last_direct_memo = 0;
+    if (h->direct_memo && dk.direct && h->hp.n_sources > 0 && h->hp.n_views_total > 0 && !h->hp.peel_scattered_only) {
+        // direct light of the point sources: one walk per (source, view) instead of one per packet (hyp_defer.h: direct_column_kernel)
+        const size_t n = (size_t)h->hp.n_sources * (size_t)h->hp.n_views_total;
+        if (h->direct_cap < n) {
+            free_dev(h->d_direct);
+            h->direct_cap = 0;
+            if (hipMalloc((void **)&h->d_direct, n * sizeof(DirectCol)) == hipSuccess) h->direct_cap = n;
+            else { (void)hipGetLastError(); h->d_direct = nullptr; }
+        }
+        if (h->direct_cap >= n) {
+            hipLaunchKernelGGL(dk.direct, dim3((unsigned)std::min<size_t>((n + 63) / 64, 1024)), dim3(64), lds_bytes(h->hp), h->stream, (const DProblem *)h->d_problem, h->d_direct);
+            B.direct = h->d_direct;
+            h->last_direct_memo = 1;
+        }
+    }
     if (h->peel_sort && dk.sort_hist && h->peel_cap < 0xffffffffull) {
         // sorted peel-off: order + keys per event slot, counts | offsets per bin; without the memory the events are taken as written
         if (h->peel_sort_cap < h->peel_cap) {

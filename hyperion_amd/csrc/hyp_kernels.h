@@ -966,8 +966,9 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     int ispot = -1;
     p.emiss_dust = -1;
     src_normal.cost = 1.0; src_normal.sint = 0.0; src_normal.cosp = 1.0; src_normal.sinp = 0.0;
-    constexpr bool SIMPLE = CLASS == 1;
+    constexpr bool SIMPLE = CLASS == 1 || CLASS == 3;
     constexpr bool FEW = CLASS != 0;          // no sphere / spot / map / point-collection / plane-parallel emitters, no 'lte' spectrum, not monochromatic
+    constexpr bool MONO_OK = CLASS == 0 || CLASS == 3;      // CLASS 3: the SIMPLE emitter in a monochromatic launch (final_defer_kernel<.., true, true>)
     if (SIMPLE) {
         p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
         random_sphere_angle(g, p.a);
@@ -1105,17 +1106,17 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
             p.nu = sample_log_pdf(S.spot_blob + (size_t)q[7], S.spot_blob + (size_t)q[8], S.spot_blob + (size_t)q[9], (int)q[6], rng_uniform(g));
         else p.nu = random_planck_frequency(g, q[5]);
     } else
-    if (!FEW && P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
+    if (MONO_OK && P.mono_which) {     // emit(p, inu=inu): source_type.f90:440-468, the energy carries the emission probability at nu
         p.nu = P.mono_nu;
-        p.energy = S.spectrum_type == 3 ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)
-                                        : P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
+        p.energy = (!FEW && S.spectrum_type == 3) ? dust_emit_probability(P, P.dust[p.emiss_dust], lte_jid, lte_frac)
+                                                  : P.mono_src_prob[(size_t)is * P.n_frequencies + P.mono_inu];
     } else if (!FEW && S.spectrum_type == 3) p.nu = dust_sample_j_nu(P.dust[p.emiss_dust], lte_jid, lte_frac, rng_uniform(g));
     else if (S.spectrum_type == 1) p.nu = sample_log_pdf(S.spec_x, S.spec_cdf, S.spec_bp1, S.n_spec, rng_uniform(g));
     else p.nu = random_planck_frequency(g, S.temperature);
     angle_to_vector(p.a, p.v[0], p.v[1], p.v[2]);
     if (reemit_id >= 0) p.energy = reemit_energy;
     else {
-        if (!FEW && P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
+        if (MONO_OK && P.mono_which) p.energy = p.energy * P.energy_total;      // source.f90:161
         if (P.sample_sources_evenly) p.energy = p.energy * S.lum_pdf * P.n_sources;
         cnt.energy_current += p.energy;
     }

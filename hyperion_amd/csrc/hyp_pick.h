@@ -20,6 +20,7 @@ struct DeferKernels {
     DeferKernel propagate, propagate_pre, ff_walk;       // propagate_pre: with the forced-first walks made ahead (ff_walk)
     DeferKernel propagate_mono;                          // a launch of the monochromatic iteration (final_defer_kernel<.., true, true>)
     PeelKernel peel, peel_inside; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
+    void (*direct)(const DProblem *, DirectCol *);       // direct_column_kernel<nd, GEOM>
     PeelSortK sort_hist, sort_scatter; void (*sort_scan)(DeferBuf);  // sorted peel-off: keys + histogram, scatter (peel_sort_scan_kernel between them)
 };
 template <int GEOM> DeferKernels pick_defer_kernels_g(int nd);

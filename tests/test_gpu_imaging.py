@@ -471,3 +471,50 @@ def test_tiled_imaging_falls_back_to_the_deferred_rounds_and_counts_once():
     for k in INT_KEYS:
         assert sa[k] == sb[k], (k, sa, sb)
     _images_equal(ra, rb)
+
+
+# ---- round 4: the direct light of a point source towards a view walked once (hyp_defer.h: direct_column_kernel) ----
+
+def _memo_vs_walked(prob, n_lucy, n_img):
+    """The deferred schedule with the recorded walk of the direct light (default) and with every event walked
+    (direct_memo = 0): identical integer tallies -- the recorded walk is only taken for pairs whose first propagation check
+    falls behind its last crossing -- and the same images up to the association of the optical-depth sum."""
+    out = []
+    for memo in (1, 0):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("direct_memo", memo)
+        eng.set_option("defer_peel", 1)
+        eng.lucy_iteration(n_lucy, 1, want_output=False)
+        res, st = eng.final_iteration(n_img)
+        assert eng.get_option("last_defer_rounds") >= 1 and eng.get_option("last_direct_memo") == memo
+        eng.close()
+        out.append((res, st))
+    (ra, sa), (rb, sb) = out
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    _images_equal(ra, rb)
+    return ra, sa
+
+
+def test_direct_light_memo_cartesian_several_sources_and_views():
+    from hyperion_amd.problem import Source
+    p = imaging_problem(tau=2.0, theta=[20.0, 90.0, 160.0], phi=[10.0, 200.0, 330.0], track_origin="detailed")
+    p.sources = [Source(type="point", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0)),
+                 Source(type="point", luminosity=0.5 * LSUN, temperature=4000.0, position=(0.31 * PC, -0.2 * PC, 0.44 * PC))]
+    _memo_vs_walked(p, 20000, 40000)
+
+
+def test_direct_light_memo_with_frequent_propagation_checks():
+    """A check every ~5 steps: most direct walks meet a check before their last crossing and are walked; the tallies
+    stay those of the walked schedule."""
+    p = imaging_problem(tau=1.0)
+    p.config.propagation_check_frequency = 0.2
+    _memo_vs_walked(p, 10000, 30000)
+
+
+def test_direct_light_memo_octree_source_on_a_vertex():
+    """BASELINE configs[3]'s situation: the source sits on a vertex of the tree (packets are killed in find_wall's
+    negative-t branch there, SURVEY / DESIGN section 2); same kills, same crossings with and without the recorded walk."""
+    from hyperion_amd.benchmark import make_octree_problem
+    _, st = _memo_vs_walked(make_octree_problem(max_level=5, n_pix=32), 20000, 60000)
+    assert st["crossings"] > 0
