@@ -477,7 +477,7 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool
     if (h->hp.grid_type == 3)       // cluster: its tables (VtInfo) + densities + accumulators
         return h->vt_max_lds;
     if (h->hp.grid_type == 5 || h->hp.grid_type == 6)      // polar brick: densities + accumulators
-        return sizeof(double) * 2 * (size_t)T.bx * T.by * T.bz * K.nd;
+        return sizeof(double) * 2 * (size_t)T.bx * T.by * T.bz * K.nd + sizeof(float) * (size_t)(T.bx + 2 * T.by + 8);      // + the FP32 wall tables of sph_fast_wall
     if (h->hp.grid_type == 4)       // slab: densities + accumulators + walls + goto slice
         return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
@@ -3008,6 +3008,10 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "vt_max_cells") *value = h->vt_max_cells;
     else if (n == "vt_max_lds") *value = (int64_t)h->vt_max_lds;
     else if (n == "last_vt_exact_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;      // steps of the Voronoi walk that ran the reference's loop
+    else if (n.rfind("last_walk_why", 0) == 0 && n.size() == 14 && n[13] >= '0' && n[13] <= '7') *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[30 + (n[13] - '0')] : 0;
+    else if (n == "last_walk_fast_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[37] : 0;     // -DHYP_PTILE_VERIFY builds: steps answered by sph_fast_wall,
+    else if (n == "last_walk_slow_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;     //   by the reference's search,
+    else if (n == "last_walk_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;       //   and disagreements of the two
     else if (n == "last_vt_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;         // -DHYP_VTILE_VERIFY builds: filter and loop disagreed
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;

@@ -290,6 +290,35 @@ __device__ __forceinline__ void sph_wall_cone(const DProblem &P, const double r[
     }
 }
 
+// A cone wall that cannot matter, told without solving its quadratic (round 4; the two cones are half of the walk kernel's time,
+// profiles/r04_tiled_log.md).  When the cones come up in find_wall the spheres have left ws.tmin: a root of the cone changes
+// anything only if insert_t sees 0 < t < ws.tmin + max(e, ws.emin) =: T.  The roots quad_full computes are exact roots of a
+// quadratic whose coefficients differ from (pA, pB, pC) by a few units of round-off (the formula is backward stable), so there is
+// none in [0, T] when the parabola keeps its sign there by more than that: both ends of the same sign, and the smaller of
+// |p(0)|, |p(T)| above the bulge |pA| T^2 / 4 of the parabola over its chord plus 64 eps (|pA| T^2 + |pB| T + |pC|).  A packet that
+// flies radially -- every packet until its first interaction, 60 % of the steps -- has pA, pB / 2 rho, pC / rho^2 all equal and the
+// (meaningless) roots at the apex: p(0) and p(T) agree in sign by five orders of magnitude more than needed.  Not applied to the
+// wall the packet sits on (insert_pair and the extension rule look at both roots) nor to the mid-plane (a plane, one division).
+#ifndef HYP_POLAR_REACH
+#define HYP_POLAR_REACH 0      // measured: 528 against 493 ms on the 400 x 200 grid -- a wave mixes radial and scattered packets, so both cones are
+#endif                         // solved for some lane in almost every wave-step and the test comes on top (profiles/r04_tiled_log.md)
+__device__ __forceinline__ bool sph_cone_out_of_reach(const DProblem &P, const Cell<GEOM_SPH> &c, int side, double v2_xy, double v2_z, double rv_xy, double rv_z,
+                                                      double r2_xy, double r2_z, const WallSel &ws)
+{
+    if (!HYP_POLAR_REACH) return false;
+    const int iw = c.ic[1] + side, dir = side ? +1 : -1;
+    if (c.ow[1] == dir || iw == P.midplane) return false;
+    const double tt2 = P.wtant2[iw];
+    const double pA = v2_xy - v2_z * tt2;
+    double pB = rv_xy - rv_z * tt2; pB = pB + pB;
+    const double pC = r2_xy - r2_z * tt2;
+    const double T = ws.tmin + fmax(P.ew[1][iw], ws.emin);
+    const double aT2 = fabs(pA) * T * T, pT = (pA * T + pB) * T + pC;
+    const double lim = 0.25 * aT2 + 0x1p-46 * (aT2 + fabs(pB) * T + fabs(pC));
+    // (a NaN or an infinity anywhere -- no sphere ahead, ws.tmin = huge -- fails the comparisons: the wall is solved)
+    return ((pC > 0.0) == (pT > 0.0)) && fabs(pC) > lim && fabs(pT) > lim;
+}
+
 // find_wall: spherical_3d.f90:741-1073
 __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
                                               const Cell<GEOM_SPH> &c, double &tnear, int im[3])
@@ -309,8 +338,12 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
     }
     quad_reduced(pB, pC - P.wr2[i1 + 1], t1, t2);
     insert_pair(ws, t1, t2, c.ow[0] == +1, 0, +1, P.ew[0][i1 + 1]);
-    if (c.ic[1] > 0) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
-    if (c.ic[1] < P.n2 - 1) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+#ifdef HYP_POLAR_ABLATE      // timing experiment (wrong results): what the cone walls cost
+    if (HYP_POLAR_ABLATE == 1 && c.ic[1] > 0) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+#else
+    if (c.ic[1] > 0 && !sph_cone_out_of_reach(P, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws)) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+    if (c.ic[1] < P.n2 - 1 && !sph_cone_out_of_reach(P, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws)) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+#endif
     polar_wall_phi<GEOM_SPH>(P, r, v, c, r2_xy, ws);
     tnear = ws.tmin;
 #pragma unroll

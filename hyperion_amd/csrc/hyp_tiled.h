@@ -658,12 +658,17 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             const HotRec<ND> &H = hot[slot];
             const ColdRec<ND> &C = cold[slot];
             bool absorb = false;
-            if (H.state == TS_INTERACT && (long long)C.inter != P.n_inter_max + 1) {
+            // everything the peek needs in ONE batch of loads: behind the short circuit of the test below they came as four
+            // dependent batches (state; inter; stream state; id), a memory round trip each
+            int h_state = H.state, c_inter = C.inter, c_have_a = C.have_a;
+            unsigned int c_blk_a = C.blk_a;
+            unsigned long long id = H.id;
+            double c_buf_a = C.buf_a, albedo = C.albedo[0];
+            asm volatile("" : "+v"(h_state), "+v"(c_inter), "+v"(c_have_a), "+v"(c_blk_a), "+v"(id), "+v"(c_buf_a), "+v"(albedo));
+            if ((h_state == TS_INTERACT) & ((long long)c_inter != P.n_inter_max + 1)) {
                 Rng g2;
-                const unsigned long long id = H.id;
                 g2.key0 = P.seed_key; g2.key1 = T.iter_tag; g2.id_lo = (uint32_t)id; g2.id_hi = (uint32_t)(id >> 32);
-                g2.blk_a = C.blk_a; g2.buf_a = C.buf_a; g2.have_a = C.have_a; g2.blk_b = 0; g2.countdown = 0;
-                double albedo = C.albedo[0];
+                g2.blk_a = c_blk_a; g2.buf_a = c_buf_a; g2.have_a = c_have_a; g2.blk_b = 0; g2.countdown = 0;
                 if (ND > 1 && nd > 1) {        // select_dust_chi_rho, as in interact()
                     Cell<GEOM> hc; TileCellIO<GEOM>::load(P, H, hc);
                     const size_t base = geo_index(P, hc) * (size_t)nd;
