@@ -153,7 +153,9 @@ def extras(n, passes=3):
         alg = 8.0 * st["crossings"] + 16.0 * n_stokes * events * n_view
         ent = {"config": "configs[3] imaging iteration: peel-off to a 512x512 Stokes image, 1 view, forced first interaction; %s" % label,
                "schedule": ("deferred peel-off (hyp_defer.h), %d rounds, %.2f events/packet%s" % (rounds, events / n,
-                            ", emission + forced first interaction ahead of the rounds (ff_walk_kernel)" if e.get_option("last_ff_prepass") else ""))
+                            ", emission + forced first interaction ahead of the rounds (ff_walk_kernel)" if e.get_option("last_ff_prepass") else "")
+                            + (", propagation half on the slot-pool schedule (tile_interact / tile_emit <IMG>, LDS walk)" if e.get_option("last_tiled_imaging") else "")
+                            + (", direct light of the point source walked once per view (direct_column_kernel)" if e.get_option("last_direct_memo") else ""))
                            if rounds else "inline peel-off",
                **common(st, n, dt, dts, k_ms, alg),
                "algorithmic_bytes": "8 B x n_dust per crossing (no deposit in the imaging iteration) + 16 B x 4 Stokes x %d binned events (events x views)" % (events * n_view)}
