@@ -247,6 +247,7 @@ struct hyp_engine {
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
+    int pt_vsplit = 1;              // option: spherical grids, 1 = two sort entries per brick (not yet interacted / the others)
     int pt_lds_kb = 128;            // option: LDS of the densities and accumulators of one polar-grid brick in KB (hyp_ptile.h)
     int vt_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU; 78: room for two of 512 threads)
     int vt_clusters = 0, vt_max_cells = 0, vt_built_for = -1;
@@ -665,6 +666,9 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         polar_tile_shape(P, nd, h->pt_lds_kb, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
         T.n_bricks = T.nbx * T.nby * T.nbz;
+        // spherical grids: packets that have not interacted yet (radial for a central source: no cone wall is ever in reach, hyp_polar.h:
+        // sph_cone_out_of_reach) sorted apart from the others, so that their waves skip the cone quadratics
+        if (P.grid_type == 5 && h->pt_vsplit && 2 * T.n_bricks <= HYP_TILE_MAX_BRICKS) { T.vsplit = 2; T.n_bricks *= 2; }
     } else {
         tile_shape(nd, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
@@ -2944,6 +2948,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "pt_vsplit") h->pt_vsplit = value ? 1 : 0;
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
@@ -3002,6 +3007,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "ot_cells") *value = h->ot_cells;
     else if (n == "ot_clusters") *value = h->ot_clusters;
     else if (n == "ot_max_cells") *value = h->ot_max_cells;
+    else if (n == "pt_vsplit") *value = h->pt_vsplit;
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;

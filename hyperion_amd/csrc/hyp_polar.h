@@ -300,12 +300,12 @@ __device__ __forceinline__ void sph_wall_cone(const DProblem &P, const double r[
 // (meaningless) roots at the apex: p(0) and p(T) agree in sign by five orders of magnitude more than needed.  Not applied to the
 // wall the packet sits on (insert_pair and the extension rule look at both roots) nor to the mid-plane (a plane, one division).
 #ifndef HYP_POLAR_REACH
-#define HYP_POLAR_REACH 0      // measured: 528 against 493 ms on the 400 x 200 grid -- a wave mixes radial and scattered packets, so both cones are
-#endif                         // solved for some lane in almost every wave-step and the test comes on top (profiles/r04_tiled_log.md)
+#define HYP_POLAR_REACH 0      // 1: the test in EVERY find_wall.  Measured: 528 against 493 ms on the 400 x 200 grid -- a wave mixes radial and scattered
+#endif                         // packets, so both cones are solved for some lane in almost every wave-step and the test comes on top (profiles/r04_tiled_log.md);
+                               // the tiled walk applies it to the tasks of packets that have not interacted yet (TileGeom::vsplit, hyp_ptile.h)
 __device__ __forceinline__ bool sph_cone_out_of_reach(const DProblem &P, const Cell<GEOM_SPH> &c, int side, double v2_xy, double v2_z, double rv_xy, double rv_z,
                                                       double r2_xy, double r2_z, const WallSel &ws)
 {
-    if (!HYP_POLAR_REACH) return false;
     const int iw = c.ic[1] + side, dir = side ? +1 : -1;
     if (c.ow[1] == dir || iw == P.midplane) return false;
     const double tt2 = P.wtant2[iw];
@@ -319,9 +319,10 @@ __device__ __forceinline__ bool sph_cone_out_of_reach(const DProblem &P, const C
     return ((pC > 0.0) == (pT > 0.0)) && fabs(pC) > lim && fabs(pT) > lim;
 }
 
-// find_wall: spherical_3d.f90:741-1073
-__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
-                                              const Cell<GEOM_SPH> &c, double &tnear, int im[3])
+// find_wall: spherical_3d.f90:741-1073.  reach: try to dismiss each cone wall with sph_cone_out_of_reach before solving it (the same
+// answer either way; worth it where a whole wave's packets fly radially, hyp_ptile.h)
+__device__ __forceinline__ bool sph_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_SPH> &c, double &tnear, int im[3], bool reach)
 {
     WallSel ws; ws.tmin = HYP_DBL_MAX; ws.emin = 0.0;
     ws.imin[0] = ws.imin[1] = ws.imin[2] = 0; ws.iext[0] = ws.iext[1] = ws.iext[2] = 0;
@@ -341,14 +342,20 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
 #ifdef HYP_POLAR_ABLATE      // timing experiment (wrong results): what the cone walls cost
     if (HYP_POLAR_ABLATE == 1 && c.ic[1] > 0) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
 #else
-    if (c.ic[1] > 0 && !sph_cone_out_of_reach(P, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws)) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
-    if (c.ic[1] < P.n2 - 1 && !sph_cone_out_of_reach(P, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws)) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+    if (c.ic[1] > 0 && !(reach && sph_cone_out_of_reach(P, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
+    if (c.ic[1] < P.n2 - 1 && !(reach && sph_cone_out_of_reach(P, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws);
 #endif
     polar_wall_phi<GEOM_SPH>(P, r, v, c, r2_xy, ws);
     tnear = ws.tmin;
 #pragma unroll
     for (int a = 0; a < 3; a++) im[a] = ws.imin[a] + ws.iext[a];      // find_next_wall :1114-1121
     return (im[0] | im[1] | im[2]) != 0;
+}
+
+__device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
+                                              const Cell<GEOM_SPH> &c, double &tnear, int im[3])
+{
+    return sph_find_wall(P, W, r, v, c, tnear, im, HYP_POLAR_REACH != 0);
 }
 
 // find_wall: cylindrical_3d.f90:593-771

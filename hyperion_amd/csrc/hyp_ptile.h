@@ -231,7 +231,9 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
     const DProblem &P = *Pp;
     if (blockIdx.x >= ctl->n_tasks[T.pool]) return;
     const TileTask tk = tasks[blockIdx.x];
-    const int cl = tk.brick;
+    const int vs = T.vsplit > 1 ? T.vsplit : 1;
+    const bool reach_task = vs > 1 && tk.brick % vs == 0;      // packets that have not interacted yet: cone walls dismissed without solving where the test allows
+    const int cl = tk.brick / vs;       // (vsplit: the task's packets are all of one kind, tk.brick % vs)
     const int x0 = (cl % T.nbx) * T.bx, y0 = ((cl / T.nbx) % T.nby) * T.by, z0 = (cl / (T.nbx * T.nby)) * T.bz;
     const int x1 = min(x0 + T.bx, P.n1), y1 = min(y0 + T.by, P.n2), z1 = min(z0 + T.bz, P.n3);
     const int bx = x1 - x0, by = y1 - y0, bz = z1 - z0, nc = bx * by * bz;
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                 if (st == LS_REABS) { state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
                 else if (st == LS_HIT) { state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                 else {
-                    const int nb = st == LS_LEFT ? brick_of(T, cell.ic) : cl;           // parked: same brick again
+                    const int nb = st == LS_LEFT ? brick_of(T, cell.ic) * vs + tk.brick % vs : tk.brick;           // parked: same brick again
                     if (st == LS_LEFT) slot_brick[slot] = nb;
                     if (nb < PT_HIST) atomicAdd(&nb_cnt[nb], 1u); else atomicAdd(&counts[nb], 1u);
                 }
@@ -391,7 +393,8 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
 #else
                         if (!found) found = geo_find_wall(P, W, r, v, cell, tmin, im);
 #endif
-                    } else found = geo_find_wall(P, W, r, v, cell, tmin, im);
+                    } else if constexpr (GEOM == GEOM_SPH) found = sph_find_wall(P, W, r, v, cell, tmin, im, reach_task);
+                    else found = geo_find_wall(P, W, r, v, cell, tmin, im);
                     if (!found) { cnt.killed_geo++; st = LS_DEAD; }
                     else {
                         const int loc = ((cell.ic[2] - z0) * by + (cell.ic[1] - y0)) * bx + (cell.ic[0] - x0);

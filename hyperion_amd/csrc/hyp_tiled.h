@@ -152,7 +152,8 @@ struct TileGeom {
     int gen;                     // generation number (split schedule: which of the two extra lists is read)
     int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
     int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
-};
+    int vsplit;                  // 2: every brick is two entries of the sort -- 2 b for packets that have not interacted yet, 2 b + 1 for the others
+};                               //    (spherical grids: waves of one kind, hyp_ptile.h); 0 / 1: one entry per brick
 
 // per task of the current generation: how many of its packets ended the visit waiting for an interaction
 // (or a re-emission by a source) and how many slots it left free
@@ -774,7 +775,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
                 if (IMG) cold_flags_store(cold[slot], f, peel_seq);
-                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
+                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) brick = brick * T.vsplit + 1; slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts again
                     slot_brick[slot] = TILE_NEEDS_INTERACT;
@@ -954,7 +955,7 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
                 if (IMG) cold_flags_store(cold[slot], f, peel_seq);
-                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); slot_brick[slot] = brick; }
+                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) brick = brick * T.vsplit; slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts
                     slot_brick[slot] = TILE_NEEDS_INTERACT;

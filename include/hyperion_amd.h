@@ -357,7 +357,11 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * "peel_sort" (1, the default: the peel kernel takes a round's events ordered by the cell they happened in), "ff_prepass" (1, the
  * default: with forced first interaction on, every packet's emission, escape walk and first optical depth are made ahead of the rounds by a
  * kernel of their own, one record of 96 + 24 n_dust bytes (rounded up to 16) per packet id of the launch; "last_ff_prepass" reports whether the last imaging
- * iteration did so), "oct_neighbours" (0: the
+ * iteration did so), "direct_memo" (1, the default: the peel-off walk of a point source's direct light is made once per (source, view) and
+ * reused for every emission event whose first propagation check falls behind it, hyp_defer.h: direct_column_kernel; "last_direct_memo"),
+ * "mono_defer" (1, the default: the launches of a monochromatic run whose problem is plain otherwise -- point sources, no MRW, no binned
+ * images -- run on the deferred schedule; 0: the general kernel with inline peel-off; "last_mono_deferred" reports which one the last
+ * hyp_mono_launch took), "oct_neighbours" (0: the
  * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" / "lean_imaging" (the
  * specialisations of the imaging kernel the problem qualifies for -- point sources only / any sources, both without MRW, monochromatic launch,
  * binned images and inside observers; can only be switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
