@@ -247,6 +247,7 @@ struct hyp_engine {
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
+    int tile_fused_sort = 1;        // option: 1 = tile_scan + tile_scatter in one launch (tile_sort_kernel)
     int pt_vsplit = 1;              // option: spherical grids, 1 = two sort entries per brick (not yet interacted / the others)
     int pt_lds_kb = 128;            // option: LDS of the densities and accumulators of one polar-grid brick in KB (hyp_ptile.h)
     int vt_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU; 78: room for two of 512 threads)
@@ -531,8 +532,12 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             int *slot_brick = h->d_slot_brick + (size_t)pool * T.n_slots;
             int *order = h->d_order + (size_t)pool * T.n_slots;
             TileTask *tasks = h->d_tasks + pool * tasks_cap;
-            unsigned *counts = h->d_counts + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
-                     *cursor = h->d_cursor + pool * HYP_TILE_MAX_BRICKS;
+            // split schedule: counts and cursors by generation parity (tile_sort_kernel); `counts` = what this generation's sort reads
+            const size_t par_off = (size_t)HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
+            const int gp = T0.split && h->tile_fused_sort ? (gen & 1) : 0, gn = T0.split && h->tile_fused_sort ? ((gen + 1) & 1) : 0;
+            unsigned *counts = h->d_counts + gp * par_off + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
+                     *cursor = h->d_cursor + gp * par_off + pool * HYP_TILE_MAX_BRICKS;
+            unsigned *counts_next = h->d_counts + gn * par_off + pool * HYP_TILE_MAX_BRICKS, *cursor_next = h->d_cursor + gn * par_off + pool * HYP_TILE_MAX_BRICKS;
             int *ilist = h->d_ilist + (size_t)pool * 2 * T.n_slots, *dlist = h->d_dlist + (size_t)pool * 2 * T.n_slots;      // [staging | pool-wide list]
             int *extra = h->d_extra + (size_t)pool * 3 * HYP_TILE_EXTRA;
             T.gen = gen;
@@ -548,8 +553,12 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 K.prepare<<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
                 tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
             }
-            tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
-            tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
+            if (T.split && h->tile_fused_sort)
+                tile_sort_kernel<<<grid_s, 256, sizeof(unsigned) * (2 * (size_t)T.n_bricks + 512), st>>>(T, slot_brick, counts, counts_next, cursor, cursor_next, order, tasks, h->d_ctl);
+            else {
+                tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
+                tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
+            }
             const bool timed = h->tile_time_walk && n_timed + 2 <= 16384;
             if (timed) {
                 while (h->walk_events.size() < n_timed + 2) {
@@ -559,7 +568,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 }
                 (void)hipEventRecord(h->walk_events[n_timed], st);
             }
-            walk_k<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts);
+            walk_k<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts_next);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
         if (gen + 1 >= next_check || gen > 200000) {
@@ -700,7 +709,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     }
     if (!h->d_counts) {
         const size_t nb = sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
-        if (hipMalloc(&h->d_counts, nb) != hipSuccess || hipMalloc(&h->d_offsets, nb) != hipSuccess || hipMalloc(&h->d_cursor, nb) != hipSuccess ||
+        if (hipMalloc(&h->d_counts, 2 * nb) != hipSuccess || hipMalloc(&h->d_offsets, nb) != hipSuccess || hipMalloc(&h->d_cursor, 2 * nb) != hipSuccess ||
             hipMalloc(&h->d_ctl, sizeof(TileCtl)) != hipSuccess || hipHostMalloc(&h->h_ctl, sizeof(TileCtl)) != hipSuccess)
             return h->set_error("cannot allocate the control blocks of the tiled Lucy iteration");
         if (hipEventCreateWithFlags(&h->ev_pool, hipEventDisableTiming) != hipSuccess)
@@ -709,12 +718,17 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     for (int pool = 1; pool < n_pools; pool++)
         if (!h->pool_stream[pool] && hipStreamCreateWithFlags(&h->pool_stream[pool], hipStreamNonBlocking) != hipSuccess)
             return h->set_error("cannot create a stream for the tiled Lucy iteration");
+    {
+        static bool sort_attr = false;       // (n_bricks near HYP_TILE_MAX_BRICKS: more than the default 64 KB of dynamic LDS)
+        if (!sort_attr) { (void)hipFuncSetAttribute((const void *)tile_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(unsigned) * (2 * HYP_TILE_MAX_BRICKS + 512))); sort_attr = true; }
+    }
     TileCtl c0; memset(&c0, 0, sizeof(c0));
     c0.next_id = first_id; c0.end_id = first_id + n_local; c0.first_id = first_id;
     if (!img) (void)hipEventRecord(h->ev0, h->stream);        // (the imaging iteration's clock starts before its pre-pass)
     (void)hipMemsetAsync(h->d_hot, 0, hot_sz * all_slots, h->stream);          // state 0 = TS_DEAD
     (void)hipMemsetD32Async((hipDeviceptr_t)h->d_slot_brick, TILE_NEEDS_PREPARE, all_slots, h->stream);   // every slot is free
-    (void)hipMemsetAsync(h->d_counts, 0, sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
+    (void)hipMemsetAsync(h->d_counts, 0, 2 * sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
+    (void)hipMemsetAsync(h->d_cursor, 0, 2 * sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
     (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
     (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
     const int rc = run_tiled_generations(h, K, T, n_local, n_pools, img, flush);
@@ -2949,6 +2963,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "pt_vsplit") h->pt_vsplit = value ? 1 : 0;
+    else if (n == "tile_fused_sort") h->tile_fused_sort = value ? 1 : 0;
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
@@ -3008,6 +3023,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "ot_clusters") *value = h->ot_clusters;
     else if (n == "ot_max_cells") *value = h->ot_max_cells;
     else if (n == "pt_vsplit") *value = h->pt_vsplit;
+    else if (n == "tile_fused_sort") *value = h->tile_fused_sort;
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;

@@ -1189,6 +1189,80 @@ static __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, co
     }
 }
 
+// tile_scan + tile_scatter in one launch (round 4: one launch less on every pool's chain of five per generation).  Every workgroup
+// scans the brick counts itself (a few hundred values; the offsets stay in LDS), workgroup 0 also writes the task list and resets
+// what the next generation accumulates into.  The counts and the scatter cursors are kept twice, by generation parity: this
+// generation's (`counts`, read by every workgroup for as long as the launch runs) and the next one's (`counts_next`: what the walk
+// of this generation and the interaction / emission kernels of the next add to; it held generation g - 1's counts and is cleared
+// here, after that generation's sort and before this generation's walk).
+// dynamic LDS: 2 x n_bricks unsigned (histogram | offsets) + 512 unsigned
+static __global__ __launch_bounds__(256) void tile_sort_kernel(TileGeom T, const int *__restrict__ slot_brick, const unsigned int *__restrict__ counts,
+                                                       unsigned int *__restrict__ counts_next, unsigned int *__restrict__ cursor,
+                                                       unsigned int *__restrict__ cursor_next, int *__restrict__ order,
+                                                       TileTask *__restrict__ tasks, TileCtl *__restrict__ ctl)
+{
+    extern __shared__ unsigned int sort_lds[];
+    unsigned int *hist = sort_lds, *offs = sort_lds + T.n_bricks, *part_c = offs + T.n_bricks, *part_t = part_c + 256;
+    const int per = (T.n_bricks + 255) / 256;
+    const int b0 = min((int)threadIdx.x * per, T.n_bricks), b1 = min(b0 + per, T.n_bricks);
+    unsigned int sc = 0, stt = 0;
+    for (int b = b0; b < b1; b++) { const unsigned int c = counts[b]; hist[b] = 0; sc += c; stt += (c + T.task_size - 1) / T.task_size; }
+    part_c[threadIdx.x] = sc; part_t[threadIdx.x] = stt;
+    __syncthreads();
+    if (threadIdx.x < 64) {        // exclusive scan of the 256 partial sums by one wave (four per lane)
+        unsigned int c4[4], t4[4], lc = 0, lt = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c4[k] = part_c[4 * threadIdx.x + k]; t4[k] = part_t[4 * threadIdx.x + k]; lc += c4[k]; lt += t4[k]; }
+        unsigned int ic = lc, it = lt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int uc = __shfl_up(ic, d, 64), ut = __shfl_up(it, d, 64);
+            if ((int)threadIdx.x >= d) { ic += uc; it += ut; }
+        }
+        unsigned int ec = ic - lc, et = it - lt;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { part_c[4 * threadIdx.x + k] = ec; part_t[4 * threadIdx.x + k] = et; ec += c4[k]; et += t4[k]; }
+        if (blockIdx.x == 0 && threadIdx.x == 63) {
+            ctl->n_tasks[T.pool] = it;
+            ctl->n_gil[T.pool][T.gen & 1] = 0; ctl->n_gdl[T.pool][T.gen & 1] = 0;      // the walk of this generation fills them
+        }
+    }
+    __syncthreads();
+    {
+        unsigned int oc = part_c[threadIdx.x], ot = part_t[threadIdx.x];
+        for (int b = b0; b < b1; b++) {
+            const unsigned int c = counts[b];
+            offs[b] = oc;
+            if (blockIdx.x == 0) {
+                for (unsigned int q = 0; q < c; q += T.task_size) {
+                    TileTask tk; tk.brick = b; tk.start = (int)(oc + q); tk.len = (int)min((unsigned int)T.task_size, c - q); tk.pad = 0;
+                    tasks[ot++] = tk;
+                }
+                counts_next[b] = 0; cursor_next[b] = 0;
+            }
+            oc += c;
+        }
+    }
+    __syncthreads();
+    const int base = blockIdx.x * blockDim.x * HYP_SORT_PER_THREAD;
+    int br[HYP_SORT_PER_THREAD]; unsigned int rank[HYP_SORT_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < HYP_SORT_PER_THREAD; k++) {
+        int slot = base + k * blockDim.x + threadIdx.x;
+        br[k] = slot < T.n_slots ? slot_brick[slot] : -1;
+        rank[k] = br[k] >= 0 ? atomicAdd(&hist[br[k]], 1u) : 0u;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x)
+        if (hist[b]) hist[b] = atomicAdd(&cursor[b], hist[b]);      // hist[] now holds this workgroup's base
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HYP_SORT_PER_THREAD; k++) {
+        int slot = base + k * blockDim.x + threadIdx.x;
+        if (br[k] >= 0) order[offs[br[k]] + hist[br[k]] + rank[k]] = slot;
+    }
+}
+
 
 // ---------------------------------------------------------------------------
 // Record ring (EXPERIMENT, off: built only with -DHYP_TILE_RING_BUILD, option tile_ring).  The LAST wave of a walk
