@@ -90,7 +90,7 @@ enum { ST_FF = 8, ST_FF_DONE = 9, ST_FF_KILLED = 10 };
 
 // walk_step<NDT, GEOM, false> without re-absorbing sources (PLAIN), plus the `ff` mode = one pass of the loop of
 // escape_tau (same order of operations, same association of the optical-depth sum, same use of the check stream)
-template <int NDT, int GEOM>
+template <int NDT, int GEOM, bool REABS = false>
 __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Packet<NDT, GEOM> &p, Rng &g, Counters &cnt, bool ff,
                                           const double inv[3], bool v_ok)
 {
@@ -117,6 +117,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
     const double tau_needed = p.tau_req - p.tau_ach;
     cnt.crossings++;
     if (ff || tau_cell < tau_needed) {
+        if (REABS && P.any_intersect) { p.t_ach += tmin; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // re-absorbed by a source: grid_propagate_3d.f90:139-143
 #pragma unroll
         for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tmin * p.v[a];
         if (ff) {
@@ -129,6 +130,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
         return ff ? ST_FF : ST_WALK;
     }
     const double tact = tmin * (tau_needed / tau_cell);
+    if (REABS && P.any_intersect) { p.t_ach += tact; if (p.t_ach > p.t_src) return ST_NEED_REEMIT; }     // :184-188
 #pragma unroll
     for (int a = 0; a < 3; a++) p.r[a] = p.r[a] + tact * p.v[a];
     p.tau_ach += tau_needed;
@@ -142,13 +144,14 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
 // packets from the grid pdf) of a problem that is plain otherwise: every interaction is a scattering weighted by the albedo, the
 // packet ends below mono_threshold of the energy it was emitted with (Packet::e_init, set aside with the packet between rounds),
 // and the peel kernel bins every event into the launch's frequency plane (image_bin_keys reads P.mono_inu).
-template <int NDT, int GEOM, bool FFIN, bool MONO = false>
+template <int NDT, int GEOM, bool FFIN, bool MONO = false, bool GEN = false>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
-    static_assert(!MONO || FFIN, "the monochromatic launches emit in the kernel");
-    constexpr bool FFS = FFIN && !MONO;       // the escape walk of the forced first interaction as a lane state (MONO: inline, see below)
+    static_assert(!(MONO || GEN) || FFIN, "the monochromatic launches and the ones with general sources emit in the kernel");
+    static_assert(!(MONO && GEN), "monochromatic launches with general sources run on final_kernel");
+    constexpr bool FFS = FFIN && !MONO && !GEN;       // the escape walk of the forced first interaction as a lane state (MONO / GEN: inline, see below)
     Walls W;
     stage_walls<GEOM>(P, lds, W);
     Packet<NDT, GEOM> p;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         if (gl < B.ctl->n_susp[B.cur ^ 1]) {
             const SuspRec<NDT, GEOM> &R = ((const SuspRec<NDT, GEOM> *)B.susp[B.cur ^ 1])[gl];
             p = R.p; g = R.g; f = R.f;
-            st = ST_NEED_INTERACT;
+            st = (GEN && p.spec_idx == 1) ? ST_NEED_REEMIT : ST_NEED_INTERACT;       // (spec_idx: unused by the imaging iteration, marks a packet set aside before its re-emission)
         }
         const unsigned int wv = gl >> 6;
         if (wv < B.ctl->n_ret[B.cur ^ 1]) { dsp.next = B.ret[B.cur ^ 1][2 * (size_t)wv]; dsp.end = B.ret[B.cur ^ 1][2 * (size_t)wv + 1]; }
@@ -210,13 +213,14 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
-        if (!(m_walk | m_int | m_emit | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
+        unsigned long long m_re = GEN ? __ballot(st == ST_NEED_REEMIT) : 0ull;       // re-absorbed by a source with a radius: iter_final.f90:213-243
+        if (!(m_walk | m_int | m_emit | m_re | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
 
         // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
         // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
         // set aside by the round before (with a buffer of fewer chunks than waves they would otherwise never get one).
         if (!full && w_end - w_pos < 64ull &&
-            (m_int || (m_emit && !pool_empty && (dsp.next < dsp.end || *((volatile unsigned long long *)P.counter) < L.end_id)))) {
+            (m_int || m_re || (m_emit && !pool_empty && (dsp.next < dsp.end || *((volatile unsigned long long *)P.counter) < L.end_id)))) {
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&B.ctl->reserved, (unsigned long long)HYP_PEEL_CHUNK);
             b = __shfl(b, 0, 64);
@@ -227,13 +231,14 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
         if (full) {
             // this round's buffer is full: set aside what would peel off next, return the unused ids, walk the rest out
-            const unsigned long long m = m_int;
+            const unsigned long long m = m_int | m_re;
             if (m) {
                 unsigned int base = 0;
                 if (lane == (unsigned int)(__ffsll((long long)m) - 1)) base = atomicAdd(&B.ctl->n_susp[B.cur], (unsigned int)__popcll(m));
                 base = __shfl(base, __ffsll((long long)m) - 1, 64);
-                if (st == ST_NEED_INTERACT) {
+                if (st == ST_NEED_INTERACT || (GEN && st == ST_NEED_REEMIT)) {
                     SuspRec<NDT, GEOM> &R = ((SuspRec<NDT, GEOM> *)B.susp[B.cur])[base + __popcll(m & lt)];
+                    if (GEN) p.spec_idx = st == ST_NEED_REEMIT ? 1 : 0;
                     R.p = p; R.g = g; R.f = f;
                     st = ST_DONE;
                 }
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 dsp.next = dsp.end;
             }
             pool_empty = true;
-            m_int = 0; m_emit = 0;
+            m_int = 0; m_emit = 0; m_re = 0;
             if (!(m_walk | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
         }
 
@@ -258,8 +263,30 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
         int last = LAST_SR; bool last_iso = true;
 
+        if (GEN && m_re && (__popcll(m_re) >= L.emit_threshold || !m_walk)) {
+            // packets re-absorbed by a source are re-emitted from it, and that is peeled off like a scattering: iter_final.f90:213-243
+            if (st == ST_NEED_REEMIT) {
+                if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_NEED_EMIT; }
+                else {
+                    const int inter = p.inter, reabs = p.reabs + 1, rid = p.reabs_id;
+                    const unsigned int seq = p.peel_seq;
+                    const double e = p.energy;
+                    int source_id = 0; Angle src_normal;
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                    p.inter = inter; p.reabs = reabs; p.peel_seq = seq;
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    if (!ok) st = ST_NEED_EMIT;
+                    else { peel = 3; last = LAST_SR; st = ST_PLACED; last_iso = false; a_prev = src_normal; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_int = __ballot(st == ST_NEED_INTERACT);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
         if (m_int && (__popcll(m_int) >= L.interact_threshold || !m_walk)) {
             if (st == ST_NEED_INTERACT) {
+                if (GEN) { p.reabs = 0; a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3]; }
                 if ((long long)p.inter == P.n_inter_max + 1) {
                     cnt.killed_int++; st = ST_NEED_EMIT;
                 } else {
@@ -299,12 +326,16 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     } else {
                         // (MONO: the energy carries the source's emission probability at the launch's frequency; the sources are
                         // isotropic points with tabulated or blackbody spectra, the host checks)
-                        bool ok = emit_packet<NDT, GEOM, MONO ? 3 : 1>(P, W, p, g, cnt, source_id, src_normal);
+                        bool ok = emit_packet<NDT, GEOM, GEN ? 0 : (MONO ? 3 : 1)>(P, W, p, g, cnt, source_id, src_normal);
                         f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                         if (!ok) st = ST_NEED_EMIT;
                         else {
                             if (MONO) { p.energy = p.energy / P.mono_n_total; p.e_init = p.energy; }     // iter_final_mono.f90:113-116
                             peel = 1; last = LAST_SR; st = ST_PLACED; p.reabs = 0; last_iso = true;
+                            if (GEN) {      // sources with a surface: the emission's peel-off weighs with the angle to the normal (a_prev carries it)
+                                last_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
+                                if (!last_iso) a_prev = src_normal;
+                            }
                         }
                     }
                 } else {
@@ -346,7 +377,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
 
         if (__ballot(peel != 0)) {
-            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS));
+            const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);       // (a re-emission is peeled in any case: "a kind of scattering", iter_final.f90:226-227)
             const unsigned long long m = __ballot(do_peel);
             if (m) {
 #ifdef HYP_DEFER_NO_WRITE       // tuning builds: what writing the events costs (the images are wrong)
@@ -379,8 +410,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
-                    else if (MONO) {
-                        // a thermal packet starts anywhere in the grid: the escape walk is made here, from where the packet is, the
+                    else if (MONO || GEN) {
+                        // (GEN: the packet starts on the surface of its source.)  MONO: a thermal packet starts anywhere in the grid: the escape walk is made here, from where the packet is, the
                         // way final_kernel makes it (once per packet, against ~30 forced scatterings)
                         bool sampled = false;
                         if (P.forced_first) {
@@ -413,6 +444,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                         begin_integrate(P, p);
                         st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                     }
+                } else if (GEN && peel == 3 && geo_escaped(P, p.cell)) {
+                    st = ST_ESCAPED;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
                     begin_integrate(P, p);
@@ -424,7 +457,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 #pragma unroll 1
         for (int k = 0; k < HYP_DEFER_STEPS; k++) {
             if (FFS) { if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok); }
-            else if (st == ST_WALK) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, false, inv, v_ok);
+            else if (st == ST_WALK) st = defer_step<NDT, GEOM, GEN>(P, W, p, g, cnt, false, inv, v_ok);
         }
     }
 
@@ -740,7 +773,10 @@ __global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__res
 // (grid_propagate_3d.f90:377-480) a few cells at a time, image_bin at the end.
 // INSIDE: some peeled group has an inside observer (the walk towards the observer's position, ended at the observer: 18 spilled VGPRs
 // at this budget, which the problems without one do not pay)
-template <int NDT, int GEOM, bool INSIDE>
+// GEN: the problem has sources with a surface (final_defer_kernel<.., GEN>): their emission / re-emission events weigh with the angle
+// between the view and the surface normal (source_emit_peeloff, source_type.f90:512-533, 692-707), and a walk that meets a source
+// ends without a deposit (grid_propagate_3d.f90:414-420)
+template <int NDT, int GEOM, bool INSIDE, bool GEN = false>
 __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem *__restrict__ Pp, DeferBuf B, uint32_t iter_tag)
 {
     extern __shared__ double lds[];
@@ -824,6 +860,19 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                     if ((INSIDE && G.inside_observer)) inside_direction(G, r, a_req, d_obs);      // towards the observer's position, d_obs away
                     if (last_iso) {
                         s[0] = 1.0; s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
+                    } else if (GEN && last == LAST_SR) {
+                        // (a_prev holds the surface normal at the emission point)
+                        double mu = 0.0;
+                        const DSource &S = P.sources[f.source_id];
+                        if (S.peeloff) {
+                            double n0, n1, n2, q0, q1, q2;
+                            angle_to_vector(E.a_prev, n0, n1, n2);
+                            angle_to_vector(a_req, q0, q1, q2);
+                            mu = q0 * n0 + q1 * n1 + q2 * n2;
+                            if (mu < 0.0) mu = 0.0;
+                        }
+                        s[0] = (S.type == 2 && S.limb_darkening) ? 2.0 * (1.5 * mu * mu + mu) : 4.0 * mu;
+                        s[1] = 0.0; s[2] = 0.0; s[3] = 0.0;
                     } else {
                         // dust_scatter_peeloff: dust_type_4elem.f90:421-444 (PLAIN: the sources are isotropic points)
                         const DDust &D = P.dust[f.dust_id];
@@ -879,7 +928,11 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         else {
                             geo_begin(r, v, c);
                             if (geo_escaped(P, c)) st = 2;
-                            else if (B.direct && last == LAST_SR && NDT <= 4) {
+                            else if (GEN && P.any_intersect) {
+                                double t_source; int sid;
+                                find_nearest_source(P, r, v, t_source, sid);
+                                if (t_source < t_max) st = 0;          // a source in the way: nothing reaches the observer
+                            } else if (B.direct && last == LAST_SR && NDT <= 4) {
                                 // the direct light of a point source: the walk every packet of that source makes towards this view
                                 const DirectCol dc = B.direct[(size_t)f.source_id * (size_t)n_views + (size_t)vg];
                                 // (its first propagation check falls on step gp.countdown: behind the walk's crossings, or on the step that

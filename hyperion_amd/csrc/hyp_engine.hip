@@ -285,6 +285,7 @@ struct hyp_engine {
     DirectCol *d_direct = nullptr; size_t direct_cap = 0;       // direct light of the point sources, per (source, view): hyp_defer.h
     int direct_memo = 1, last_direct_memo = 0;                   // option direct_memo
     bool mono_pending = false;
+    int gen_defer_opt = 1;              // option gen_defer: 1 = problems with spherical sources image on the deferred schedule, 0 = the general kernel
     int mono_defer_opt = 1;             // option mono_defer: 1 = monochromatic launches of plain problems on the deferred schedule, 0 = the general kernel
     int last_mono_deferred = 0;
     hyp_iter_stats mono_stats;
@@ -294,6 +295,7 @@ struct hyp_engine {
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool ext_sources = false;       // point and external (box / sphere) sources with tabulated or blackbody spectra only: tile_emit_kernel<.., 2>
+    bool gen_defer = false;         // sources with a surface: the imaging iteration on the deferred schedule (final_defer_kernel<.., GEN>, peel_kernel<.., GEN>)
     bool mono_defer = false;        // a monochromatic run of a problem that is plain otherwise: its launches run on the deferred schedule (final_defer_kernel<.., true, true>)
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
     bool simple_sources = false;    // every source is a point source with a tabulated / blackbody spectrum (tile_emit_kernel<.., SIMPLE>)
@@ -1964,6 +1966,16 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (int i = 0; i < pr->n_sources; i++) md = md && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
             h->mono_defer = md;
         }
+        {
+            // sources with a surface (spheres, limb darkening and re-absorption included; no spots) next to points: the imaging iteration
+            // on the deferred schedule with the GEN kernels (hyp_defer.h) instead of the general kernel with inline peel-off
+            bool gd = !plain && !pr->config.mrw && !pr->config.monochromatic && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
+            for (int i = 0; i < pr->n_sources; i++)
+                gd = gd && (pr->sources[i].type == 1 || (pr->sources[i].type == 2 && pr->sources[i].n_spots == 0)) &&
+                     (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
+            for (int g = 0; g < pr->n_peeled; g++) gd = gd && !pr->peeled[g].inside_observer;
+            h->gen_defer = gd;
+        }
         h->inside_observers = false;
         for (int g = 0; g < pr->n_peeled; g++) h->inside_observers = h->inside_observers || pr->peeled[g].inside_observer;
         {
@@ -2945,6 +2957,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 3 ? 3 : (int)value;
     else if (n == "mono_defer") h->mono_defer_opt = value ? 1 : 0;
+    else if (n == "gen_defer") h->gen_defer_opt = value ? 1 : 0;
     else if (n == "direct_memo") h->direct_memo = value ? 1 : 0;
     else if (n == "peel_sort") h->peel_sort = value != 0;
     else if (n == "ff_prepass") h->ff_prepass = value != 0;
@@ -3000,6 +3013,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
     else if (n == "defer_peel") *value = h->defer_peel;
     else if (n == "mono_defer") *value = h->mono_defer_opt;
+    else if (n == "gen_defer") *value = h->gen_defer_opt && h->gen_defer ? 1 : 0;
     else if (n == "direct_memo") *value = h->direct_memo;
     else if (n == "last_direct_memo") *value = h->last_direct_memo;
     else if (n == "last_mono_deferred") *value = h->last_mono_deferred;
@@ -3269,11 +3283,13 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     if (e != hipSuccess) return h->set_error(std::string("hipMemcpyAsync(counter): ") + hipGetErrorString(e));
     LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->inside_observers && !h->hp.mono_which ? 1 : h->lean_imaging && !h->hp.mono_which ? 2 : 0);
     // deferred peel-off where the plain kernel applies and there is something to peel into (hyp_defer.h)
-    bool deferred = h->plain_imaging && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    const bool gen = !h->plain_imaging && h->gen_defer && h->gen_defer_opt;
+    bool deferred = (h->plain_imaging || gen) && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
-    if (deferred && !dk.propagate) deferred = false;
+    if (deferred && gen) { dk.propagate = dk.propagate_gen; dk.peel = dk.peel_gen; dk.direct = nullptr; }      // (a source may stand in the way of another's direct light)
+    if (deferred && (!dk.propagate || !dk.peel)) deferred = false;
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;
     if (bpc <= 0) {
@@ -3304,7 +3320,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         (void)hipEventRecord(h->ev0, h->stream);
         // large launches of problems whose grid has a tiled schedule: the propagation half on it (defer_peel = 2 forces, 3 forbids)
         int rc = 2;
-        if (!h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || n_local >= 4000000ull)) rc = run_tiled_imaging(h, dk, L, lds, n_local);
+        if (!gen && !h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || n_local >= 4000000ull)) rc = run_tiled_imaging(h, dk, L, lds, n_local);
         if (rc == 1) return 1;
         if (rc == 0) {
             (void)hipEventRecord(h->ev1, h->stream);
@@ -3312,7 +3328,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
             h->pending_packets = n_local;
             return 0;
         }
-        if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds)) return 1;
+        if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds, !gen)) return 1;
         (void)hipEventRecord(h->ev1, h->stream);
         h->final_pending = true;
         h->pending_packets = n_local;

@@ -518,3 +518,71 @@ def test_direct_light_memo_octree_source_on_a_vertex():
     from hyperion_amd.benchmark import make_octree_problem
     _, st = _memo_vs_walked(make_octree_problem(max_level=5, n_pix=32), 20000, 60000)
     assert st["crossings"] > 0
+
+
+# ---- round 4: sources with a surface on the deferred schedule (final_defer_kernel<.., GEN>, peel_kernel<.., GEN>) ----
+
+def _sphere_problem(base, radius, limb=False, extra_point=False):
+    from hyperion_amd.problem import Source
+    base.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=radius, limb_darkening=limb)]
+    if extra_point:
+        base.sources.append(Source(type="point", luminosity=0.3 * LSUN, temperature=4000.0, position=(0.4 * PC, 0.1 * PC, -0.3 * PC)))
+    return base
+
+
+def _gen_deferred_vs_general(prob, n_lucy, n_img, peel_events=0, oracle=True):
+    """Spherical sources (emission from the surface, limb darkening, re-absorption and re-emission, walks blocked by a source):
+    the imaging iteration on the deferred schedule (default), on the general kernel with inline peel-off (gen_defer = 0) and on
+    the CPU oracle -- integer tallies equal, cubes to 1e-9."""
+    out = []
+    for defer in (1, 0):
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("gen_defer", defer)
+        if peel_events and defer:
+            eng.set_option("peel_events", peel_events)
+        assert eng.get_option("plain_imaging") == 0 and eng.get_option("gen_defer") == defer
+        eng.lucy_iteration(n_lucy, 1, want_output=False)
+        res, st = eng.final_iteration(n_img)
+        rounds = eng.get_option("last_defer_rounds")
+        assert (rounds >= 1) == bool(defer)
+        eng.close()
+        out.append((res, st, rounds))
+    (ra, sa, rounds), (rb, sb, _) = out
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
+    _images_equal(ra, rb)
+    if oracle:
+        orc = Oracle(prob)
+        orc.lucy_iteration(n_lucy, 1)
+        ro, so = orc.final_iteration(n_img)
+        orc.close()
+        for k in INT_KEYS:
+            assert sa[k] == so[k], (k, sa, so)
+        _images_equal(ra, ro)
+    return ra, sa, rounds
+
+
+@pytest.mark.parametrize("limb", [False, True])
+def test_sphere_source_deferred_equals_general_cartesian(limb):
+    p = _sphere_problem(imaging_problem(n=10, tau=2.0, theta=[30.0, 100.0], phi=[20.0, 250.0], track_origin="basic"), 0.12 * PC, limb=limb)
+    ra, st, _ = _gen_deferred_vs_general(p, 20000, 30000)
+    assert st["interactions"] > 0 and np.nansum(ra[0]["sed"]) > 0
+
+
+def test_sphere_and_point_sources_many_rounds():
+    """A big star (many re-absorptions) next to a point source whose light it blocks for some views; an event buffer of
+    4096 slots: packets are set aside before interactions AND before re-emissions."""
+    p = _sphere_problem(imaging_problem(n=8, tau=3.0, theta=[60.0, 120.0], phi=[15.0, 195.0]), 0.25 * PC, extra_point=True)
+    _, st, rounds = _gen_deferred_vs_general(p, 10000, 20000, peel_events=4096)
+    assert rounds >= 3
+
+
+def test_sphere_source_deferred_spherical_grid_and_octree():
+    import sys, os
+    from test_gpu_polar import config0_problem
+    p = _sphere_problem(config0_problem(n_r=40, n_t=24, tau=2.0, log_r=True, peeled=True), 0.004 * PC)
+    _gen_deferred_vs_general(p, 20000, 20000)
+    from hyperion_amd.benchmark import make_octree_problem
+    q = _sphere_problem(make_octree_problem(max_level=4, n_pix=16), 0.03 * PC)
+    _gen_deferred_vs_general(q, 20000, 20000)
