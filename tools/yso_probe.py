@@ -5,6 +5,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import hyperion_amd
+if os.environ.get("HYP_LIB"):
+    import hyperion_amd.engine as E
+    E._lib = E.load_library(os.environ["HYP_LIB"])
 from hyperion_amd.benchmark import LSUN, PC
 from hyperion_amd.problem import Source
 from test_gpu_polar import config0_problem
