@@ -150,7 +150,6 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
     static_assert(!(MONO || GEN) || FFIN, "the monochromatic launches and the ones with general sources emit in the kernel");
-    static_assert(!(MONO && GEN), "monochromatic launches with general sources run on final_kernel");
     constexpr bool FFS = FFIN && !MONO && !GEN;       // the escape walk of the forced first interaction as a lane state (MONO / GEN: inline, see below)
     Walls W;
     stage_walls<GEOM>(P, lds, W);

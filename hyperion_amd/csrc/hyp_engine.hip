@@ -295,6 +295,7 @@ struct hyp_engine {
     bool plain_imaging = false;     // final_kernel<.., PLAIN>: see hyp_kernels.h
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool ext_sources = false;       // point and external (box / sphere) sources with tabulated or blackbody spectra only: tile_emit_kernel<.., 2>
+    bool mono_gen_defer = false;    // ... in a monochromatic run (final_defer_kernel<.., true, true, true>)
     bool gen_defer = false;         // sources with a surface: the imaging iteration on the deferred schedule (final_defer_kernel<.., GEN>, peel_kernel<.., GEN>)
     bool mono_defer = false;        // a monochromatic run of a problem that is plain otherwise: its launches run on the deferred schedule (final_defer_kernel<.., true, true>)
     bool lean_imaging = false;      // final_kernel<.., false, LEAN>: any sources, but no MRW / monochromatic / binned images / inside observers
@@ -1975,6 +1976,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
                      (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
             for (int g = 0; g < pr->n_peeled; g++) gd = gd && !pr->peeled[g].inside_observer;
             h->gen_defer = gd;
+            // ... and the same sources in a monochromatic run (the Pascucci / Pinte benchmark models: a stellar sphere)
+            bool mg = pr->config.monochromatic && !h->mono_defer && !pr->config.mrw && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
+            for (int i = 0; i < pr->n_sources; i++)
+                mg = mg && (pr->sources[i].type == 1 || (pr->sources[i].type == 2 && pr->sources[i].n_spots == 0)) &&
+                     (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
+            for (int g = 0; g < pr->n_peeled; g++) mg = mg && !pr->peeled[g].inside_observer;
+            h->mono_gen_defer = mg;
         }
         h->inside_observers = false;
         for (int g = 0; g < pr->n_peeled; g++) h->inside_observers = h->inside_observers || pr->peeled[g].inside_observer;
@@ -3547,11 +3555,13 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     const size_t lds = lds_bytes(P);
     // problems that are plain apart from being monochromatic: the launch on the deferred schedule (hyp_defer.h: the propagation
     // kernel writes events, the peel kernel walks them sorted by cell into the launch's frequency plane); option mono_defer = 0: inline
-    bool deferred = h->mono_defer && h->mono_defer_opt && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    const bool mgen = h->mono_gen_defer && h->gen_defer_opt;
+    bool deferred = (h->mono_defer || mgen) && h->mono_defer_opt && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
-    if (deferred && !dk.propagate_mono) deferred = false;
+    if (deferred && mgen) { dk.propagate_mono = dk.propagate_mono_gen; dk.peel = dk.peel_gen; dk.direct = nullptr; }
+    if (deferred && (!dk.propagate_mono || !dk.peel)) deferred = false;
     long long blocks = (long long)h->n_cu * 2;
     if (deferred) {
         int occ = 0;

@@ -232,12 +232,19 @@ def test_mono_deferred_octree():
     _mono_deferred_vs_inline(p, 20000, 10000, 10000)
 
 
-def test_mono_with_a_stellar_sphere_stays_on_the_general_kernel():
-    """Sources with a radius (limb darkening, re-absorption) are not what the deferred kernels cover."""
-    p = mono_problem(imaging_problem(n=6, tau=1.0), [1.0, 10.0])
-    p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.01 * PC)]
-    eng = hyperion_amd.Engine(p)
-    eng.lucy_iteration(5000, 1)
-    eng.mono_iteration(2000, 2000)
-    assert eng.get_option("last_mono_deferred") == 0
+def test_mono_with_a_stellar_sphere_on_the_deferred_schedule():
+    """A star with a radius (the Pascucci / Pinte benchmark models): re-absorption, re-emission at the launch's frequency and the
+    4 mu / limb-darkened peel-off on the deferred schedule (final_defer_kernel<.., true, true, true>) = the general kernel = the oracle."""
+    p = mono_problem(imaging_problem(n=8, tau=2.0, theta=[40.0, 110.0], phi=[10.0, 220.0]), [1.0, 10.0, 100.0])
+    p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.2 * PC, limb_darkening=True)]
+    _, st, _ = _mono_deferred_vs_inline(p, 10000, 10000, 10000)
+    assert st["interactions"] > 0
+
+
+def test_pascucci_model_runs_deferred():
+    prob, _ = golden_problem("pascucci.tau=1.npz")
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(2000, 1)
+    eng.mono_iteration(500, 500)
+    assert eng.get_option("last_mono_deferred") == 1
     eng.close()
