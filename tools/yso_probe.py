@@ -30,3 +30,24 @@ for kind in ("point", "sphere"):
     print("%s source: imaging %.1f ms (%.3g packets/s, %.0f crossings/packet, deferred rounds %d, plain %d, lean %d)"
           % (kind, ms, n / ms * 1e3, st["crossings"] / n, e.get_option("last_defer_rounds"), e.get_option("plain_imaging"), e.get_option("lean_imaging")), flush=True)
     e.close()
+# the same with raytracing on (the usual choice for SEDs): the imaging iteration peels scattered light only, the raytracing iteration adds
+# the sources' and the dust's own emission
+for kind in ("point", "sphere"):
+    p = config0_problem(n_r=400, n_t=200, tau=3.0, log_r=True, peeled=True)
+    p.config.raytracing = True
+    if kind == "sphere":
+        p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.002 * PC)]
+    e = hyperion_amd.Engine(p)
+    for a in args:
+        e.set_option(a.split("=")[0], int(a.split("=")[1]))
+    e.lucy_iteration(n, 1, want_output=False)
+    e.final_iteration(n // 10)
+    _, st = e.final_iteration(n)
+    ms = e.last_kernel_ms()[0]
+    print("%s source, raytracing on: imaging %.1f ms (%.3g packets/s, %.0f crossings/packet, deferred rounds %d)"
+          % (kind, ms, n / ms * 1e3, st["crossings"] / n, e.get_option("last_defer_rounds")), flush=True)
+    e.raytracing_iteration(n // 10, n // 10)
+    _, st = e.raytracing_iteration(n, n)
+    ms = e.last_kernel_ms()[0]
+    print("%s source, raytracing iteration: %.1f ms (%.3g packets/s, %.0f crossings/packet)" % (kind, ms, 2 * n / ms * 1e3, st["crossings"] / (2 * n)), flush=True)
+    e.close()
