@@ -39,7 +39,7 @@ e.lucy_iteration(n, 1, want_output=False)
 mode = e.get_option("last_lucy_mode")
 _, st = e.lucy_iteration(n, 2, want_output=False); line("configs[3] octree with a stellar sphere, Lucy iteration (lucy_mode %d)" % mode, n, e.last_kernel_ms()[0], st)
 e.final_iteration(n // 10)
-_, st = e.final_iteration(n); line("... imaging iteration, general kernel (plain_imaging %d)" % e.get_option("plain_imaging"), n, e.last_kernel_ms()[0], st)
+_, st = e.final_iteration(n); line("... imaging iteration (plain_imaging %d, deferred rounds %d)" % (e.get_option("plain_imaging"), e.get_option("last_defer_rounds")), n, e.last_kernel_ms()[0], st)
 e.close()
 if os.environ.get("HYP_LIB"):
     sys.exit(0)
