@@ -239,7 +239,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = 1000000, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 400 000 packets in flight on Cartesian and Voronoi grids, 1 000 000 elsewhere (profiles/r04_tiled_log.md) */, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -598,7 +598,8 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
             // few packets left and no ids to hand out: finish them in one launch
             const uint64_t in_flight = n_local - h->h_ctl->n_finished;
-            if (!img && h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= (uint64_t)h->tile_drain) {      // (the drain kernel deposits: Lucy only)
+            const uint64_t drain_at = h->tile_drain >= 0 ? (uint64_t)h->tile_drain : (h->hp.grid_type == 1 || h->hp.grid_type == 3) ? 400000ull : 1000000ull;
+            if (!img && h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= drain_at) {      // (the drain kernel deposits: Lucy only)
                 for (int pool = 1; pool < n_pools; pool++) {
                     (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
                     (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
