@@ -1619,6 +1619,28 @@ __global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DPr
 // peeloff_photon (images_peeled.f90:95-270)
 // ---------------------------------------------------------------------------
 
+// One walk along a fixed direction (grid_escape_tau, grid_escape_column_density): on Cartesian grids and octrees the wall search with one
+// reciprocal per direction (car_find_wall_inv / oct_find_wall_inv: the same wall, the same t bit for bit, three operations per quotient
+// instead of an IEEE division); inv = RN(1 / v), v_ok = every non-zero component at least 2^-400 in magnitude.
+template <int GEOM>
+__device__ __forceinline__ void walk_reciprocals(const double v[3], double inv[3], bool &v_ok)
+{
+    v_ok = false;
+    if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_OCT) {
+        v_ok = true;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
+    }
+}
+template <int GEOM>
+__device__ __forceinline__ bool find_wall_fixed_dir(const DProblem &P, const Walls &W, const double r[3], const double v[3], const double inv[3], bool v_ok,
+                                                    const Cell<GEOM> &c, double &tmin, int im[3])
+{
+    if constexpr (GEOM == GEOM_OCT) return v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+    else if constexpr (GEOM == GEOM_CAR) return v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+    else return geo_find_wall(P, W, r, v, c, tmin, im);
+}
+
 // grid_escape_tau: grid_propagate_3d.f90:377-480 -- optical depth from (r, ic, ow)
 // along v to the edge of the grid (external observers: tmax = huge).
 template <int NDT, int GEOM>
@@ -1640,13 +1662,15 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
         if (t_source < tmax) { killed = true; return 0.0; }
     }
     double t_achieved = 0.0;       // inside observers stop at the observer: grid_propagate_3d.f90:446-452
+    double inv[3] = {1.0, 1.0, 1.0}; bool v_ok;
+    walk_reciprocals<GEOM>(v, inv, v_ok);
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp, stream);
             if (!geo_check_cell(P, W, r, v, c)) { cnt.killed_geo++; killed = true; return tau; }
         } else g.countdown--;
         double tmin; int im[3];
-        if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
+        if (!find_wall_fixed_dir<GEOM>(P, W, r, v, inv, v_ok, c, tmin, im)) { cnt.killed_geo++; killed = true; return tau; }
         const size_t base = geo_index(P, c) * (size_t)nd;
         bool finished = false;
         if (tmax < HYP_DBL_MAX) {
@@ -2007,13 +2031,15 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
         if (t_source < tmax) { killed = true; return; }
     }
     double t_current = 0.0;
+    double inv[3] = {1.0, 1.0, 1.0}; bool v_ok;
+    walk_reciprocals<GEOM>(v, inv, v_ok);
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);
             if (!geo_check_cell(P, W, r, v, c)) { cnt.killed_geo++; killed = true; return; }
         } else g.countdown--;
         double tmin; int im[3];
-        if (!geo_find_wall(P, W, r, v, c, tmin, im)) { cnt.killed_geo++; killed = true; return; }
+        if (!find_wall_fixed_dir<GEOM>(P, W, r, v, inv, v_ok, c, tmin, im)) { cnt.killed_geo++; killed = true; return; }
         const size_t base = geo_index(P, c) * (size_t)nd;
         bool finished = false;
         if (tmax < HYP_DBL_MAX) {       // inside observers: grid_propagate_3d.f90:551-557
