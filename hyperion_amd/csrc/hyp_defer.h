@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     const unsigned int seq = p.peel_seq;
                     const double e = p.energy;
                     int source_id = 0; Angle src_normal;
-                    bool ok = emit_packet<NDT, GEOM, MONO ? 0 : 4>(P, W, p, g, cnt, source_id, src_normal, rid, e);
+                    bool ok = emit_packet<NDT, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
                     p.inter = inter; p.reabs = reabs; p.peel_seq = seq;
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     } else {
                         // (MONO: the energy carries the source's emission probability at the launch's frequency; the sources are
                         // isotropic points with tabulated or blackbody spectra, the host checks)
-                        bool ok = emit_packet<NDT, GEOM, GEN ? (MONO ? 0 : 4) : (MONO ? 3 : 1)>(P, W, p, g, cnt, source_id, src_normal);
+                        bool ok = emit_packet<NDT, GEOM, GEN ? 0 : (MONO ? 3 : 1)>(P, W, p, g, cnt, source_id, src_normal);
                         f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                         if (!ok) st = ST_NEED_EMIT;
                         else {

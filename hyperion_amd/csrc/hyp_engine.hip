@@ -1971,17 +1971,13 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         {
             // sources with a surface (spheres, limb darkening and re-absorption included; no spots) next to points: the imaging iteration
             // on the deferred schedule with the GEN kernels (hyp_defer.h) instead of the general kernel with inline peel-off
+            // (any sources: the GEN kernels emit with the general emitter; what stays on final_kernel is MRW, binned images, inside
+            // observers together with such sources, and more than four species)
             bool gd = !plain && !pr->config.mrw && !pr->config.monochromatic && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
-            for (int i = 0; i < pr->n_sources; i++)
-                gd = gd && (pr->sources[i].type == 1 || (pr->sources[i].type == 2 && pr->sources[i].n_spots == 0)) &&
-                     (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
             for (int g = 0; g < pr->n_peeled; g++) gd = gd && !pr->peeled[g].inside_observer;
             h->gen_defer = gd;
             // ... and the same sources in a monochromatic run (the Pascucci / Pinte benchmark models: a stellar sphere)
             bool mg = pr->config.monochromatic && !h->mono_defer && !pr->config.mrw && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
-            for (int i = 0; i < pr->n_sources; i++)
-                mg = mg && (pr->sources[i].type == 1 || (pr->sources[i].type == 2 && pr->sources[i].n_spots == 0)) &&
-                     (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
             for (int g = 0; g < pr->n_peeled; g++) mg = mg && !pr->peeled[g].inside_observer;
             h->mono_gen_defer = mg;
         }

@@ -972,10 +972,10 @@ __device__ __forceinline__ bool emit_packet(const DProblem &P, const Walls &W, P
     if (SIMPLE) {
         p.r[0] = S.pos[0]; p.r[1] = S.pos[1]; p.r[2] = S.pos[2];
         random_sphere_angle(g, p.a);
-    } else if ((!FEW || CLASS == 4) && S.type == 2) {       // CLASS 4: points and spheres without spots (the GEN instances of hyp_defer.h)
+    } else if (!FEW && S.type == 2) {
         // emit_from_sphere: source_type.f90:604-690
         Angle a_coord, a_local;
-        if (CLASS != 4 && S.n_spots > 0) {        // source_emit case(3), source_type.f90:421-427: a spot or the rest of the sphere, by luminosity
+        if (S.n_spots > 0) {        // source_emit case(3), source_type.f90:421-427: a spot or the rest of the sphere, by luminosity
             const double xi = rng_uniform(g);
             int k = S.n_spots;
             for (int i = S.n_spots - 1; i >= 0; i--) if (xi < S.spot_tab[i]) k = i;

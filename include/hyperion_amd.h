@@ -359,7 +359,7 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * kernel of their own, one record of 96 + 24 n_dust bytes (rounded up to 16) per packet id of the launch; "last_ff_prepass" reports whether the last imaging
  * iteration did so), "direct_memo" (1, the default: the peel-off walk of a point source's direct light is made once per (source, view) and
  * reused for every emission event whose first propagation check falls behind it, hyp_defer.h: direct_column_kernel; "last_direct_memo"),
- * "gen_defer" (1, the default: a problem lit by spheres (no spots) and points, without MRW / monochromatic launches / binned images / inside
+ * "gen_defer" (1, the default: a problem with sources other than isotropic points, without MRW / binned images / inside
  * observers, images on the deferred schedule -- re-absorption, re-emission and the limb-darkened peel-off included; 0: the general kernel
  * with inline peel-off; reads back 1 only where the problem qualifies),
  * "mono_defer" (1, the default: the launches of a monochromatic run whose problem is plain otherwise -- point sources, no MRW, no binned

@@ -586,3 +586,25 @@ def test_sphere_source_deferred_spherical_grid_and_octree():
     from hyperion_amd.benchmark import make_octree_problem
     q = _sphere_problem(make_octree_problem(max_level=4, n_pix=16), 0.03 * PC)
     _gen_deferred_vs_general(q, 20000, 20000)
+
+
+def test_external_box_and_point_on_a_voronoi_lattice_deferred():
+    """BASELINE configs[4]'s sources (a point + an external box, inward normals in the emission events, no peel-off of the box's
+    light) and two species on a Voronoi lattice: GEN kernels = general kernel = oracle."""
+    from hyperion_amd.benchmark import make_voronoi_lattice_problem
+    from hyperion_amd.problem import PeeledImages
+    p = make_voronoi_lattice_problem(n=6, tau=1.5, n_photons=20000, n_iter=1)
+    p.peeled = [PeeledImages(theta=[35.0, 120.0], phi=[25.0, 260.0], n_wav=3, wav_min=0.1, wav_max=1000.0, n_x=8, n_y=8,
+                             x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.3 * PC, ap_max=2.0 * PC, compute_stokes=True)]
+    _gen_deferred_vs_general(p, 20000, 20000)
+
+
+def test_spotted_star_deferred():
+    from test_oracle_units import spotted_star_problem
+    p = spotted_star_problem()
+    eng = hyperion_amd.Engine(p)
+    if eng.get_option("gen_defer") != 1:
+        eng.close()
+        pytest.skip("the spotted-star model has no peeled group the deferred schedule applies to")
+    eng.close()
+    _gen_deferred_vs_general(p, 5000, 20000)
