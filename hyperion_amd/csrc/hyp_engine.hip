@@ -2716,7 +2716,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     bool tile_ok = false, tile_auto = false;
     if (P.grid_type == 1) {
         tile_ok = h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
-        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 32 && n_local >= 4000000ull;
+        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 32 && n_local >= 1500000ull;      // (128^3: 14.2 against 18.0 ms at 2e6 packets, even at 1e6; tools/small_probe.py)
     } else if (P.grid_type == 3) {
         // Voronoi: clusters of cells in LDS (hyp_vtile.h); the modified random walk does not exist on these grids
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && !P.mrw;
@@ -2733,7 +2733,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         polar_tile_shape(P, h->n_dust, h->pt_lds_kb, bx, by, bz);
         const long long nb = (long long)((P.n1 + bx - 1) / bx) * ((P.n2 + by - 1) / by) * ((P.n3 + bz - 1) / bz);
         tile_ok = h->n_dust <= 4 && nb <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
-        tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 2000000ull;
+        tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 3000000ull;      // (400 x 200: 91 against 81 ms at 2e6 packets, 140 against 150 at 4e6)
     }
     else if (P.grid_type == 4) {
         // AMR: bricks of the grids in LDS (hyp_atile.h)
