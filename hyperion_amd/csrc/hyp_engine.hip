@@ -1964,7 +1964,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         // (filters are the peel kernel's / deposit_images' business; inside observers are the peel kernel's, not the inline plain kernel's)
         h->plain_imaging = plain && h->n_dust <= 4;      // five to eight species: the general kernel only (hyp_geom.hip)
         {
-            bool md = pr->config.monochromatic && !pr->config.mrw && !pr->binned && h->n_dust <= 4;
+            bool md = pr->config.monochromatic && !pr->binned && h->n_dust <= 4;      // (the modified random walk is not made in monochromatic launches: iter_final_mono.f90 has none)
             for (int i = 0; i < pr->n_sources; i++) md = md && pr->sources[i].type == 1 && (pr->sources[i].spectrum_type == 1 || pr->sources[i].spectrum_type == 2);
             h->mono_defer = md;
         }
@@ -1977,7 +1977,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             for (int g = 0; g < pr->n_peeled; g++) gd = gd && !pr->peeled[g].inside_observer;
             h->gen_defer = gd;
             // ... and the same sources in a monochromatic run (the Pascucci / Pinte benchmark models: a stellar sphere)
-            bool mg = pr->config.monochromatic && !h->mono_defer && !pr->config.mrw && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
+            bool mg = pr->config.monochromatic && !h->mono_defer && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
             for (int g = 0; g < pr->n_peeled; g++) mg = mg && !pr->peeled[g].inside_observer;
             h->mono_gen_defer = mg;
         }

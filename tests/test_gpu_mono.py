@@ -248,3 +248,18 @@ def test_pascucci_model_runs_deferred():
     eng.mono_iteration(500, 500)
     assert eng.get_option("last_mono_deferred") == 1
     eng.close()
+
+
+def test_mono_deferred_with_the_modified_random_walk_switched_on():
+    """The modified random walk belongs to the polychromatic iterations (iter_final_mono.f90 has none): a run that has it on
+    still takes the deferred schedule for its monochromatic launches (the Pinte benchmark set-up)."""
+    from test_oracle_mrw import realistic_dust
+    p = mono_problem(imaging_problem(n=8, tau=20.0, theta=[40.0], phi=[10.0]), [1.0, 100.0])
+    p.dust = [realistic_dust()]
+    p.density = p.density * (1.0 / float(p.dust[0].mo_chi_inv_planck[0]))
+    p.config.mrw = True
+    p.config.mrw_gamma = 2.0
+    p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.05 * PC)]
+    p.config.monochromatic_energy_threshold = 1e-4
+    _, st, _ = _mono_deferred_vs_inline(p, 5000, 4000, 4000)
+    assert st["interactions"] > 0
