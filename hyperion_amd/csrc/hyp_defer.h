@@ -144,12 +144,13 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
 // packets from the grid pdf) of a problem that is plain otherwise: every interaction is a scattering weighted by the albedo, the
 // packet ends below mono_threshold of the energy it was emitted with (Packet::e_init, set aside with the packet between rounds),
 // and the peel kernel bins every event into the launch's frequency plane (image_bin_keys reads P.mono_inu).
-template <int NDT, int GEOM, bool FFIN, bool MONO = false, bool GEN = false>
+template <int NDT, int GEOM, bool FFIN, bool MONO = false, bool GEN = false, bool MRWF = false>
 __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
 {
     extern __shared__ double lds[];
     const DProblem &P = *Pp;
     static_assert(!(MONO || GEN) || FFIN, "the monochromatic launches and the ones with general sources emit in the kernel");
+    static_assert(!MRWF || (GEN && !MONO), "the modified random walk: polychromatic launches, GEN instances");
     constexpr bool FFS = FFIN && !MONO && !GEN;       // the escape walk of the forced first interaction as a lane state (MONO / GEN: inline, see below)
     Walls W;
     stage_walls<GEOM>(P, lds, W);
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
     Dispenser dsp; dsp.next = 0; dsp.end = 0;
     PeelFlags f; f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = 0;
     int st = ST_NEED_EMIT;
+    int mrw_k = 1;                            // MRWF: steps of the modified random walk since the last interaction (state ST_MRW; iter_final.f90:165-183)
     double inv[3] = {1.0, 1.0, 1.0};          // octree: RN(1 / v) of the packet's direction since its last emission / interaction
     bool v_ok = false;                        //   (oct_find_wall_inv); false: geo_find_wall
     bool pool_empty = false, full = false;
@@ -178,7 +180,10 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         if (gl < B.ctl->n_susp[B.cur ^ 1]) {
             const SuspRec<NDT, GEOM> &R = ((const SuspRec<NDT, GEOM> *)B.susp[B.cur ^ 1])[gl];
             p = R.p; g = R.g; f = R.f;
-            st = (GEN && p.spec_idx == 1) ? ST_NEED_REEMIT : ST_NEED_INTERACT;       // (spec_idx: unused by the imaging iteration, marks a packet set aside before its re-emission)
+            // (spec_idx, unused by the imaging iteration, says what the packet was set aside before: 0 an interaction, 1 its re-emission
+            // by a source, 2 + k the k-th step of its modified random walk)
+            st = (GEN && p.spec_idx == 1) ? ST_NEED_REEMIT : (MRWF && p.spec_idx >= 2) ? ST_MRW : ST_NEED_INTERACT;
+            if (MRWF && p.spec_idx >= 2) mrw_k = p.spec_idx - 2;
         }
         const unsigned int wv = gl >> 6;
         if (wv < B.ctl->n_ret[B.cur ^ 1]) { dsp.next = B.ret[B.cur ^ 1][2 * (size_t)wv]; dsp.end = B.ret[B.cur ^ 1][2 * (size_t)wv + 1]; }
@@ -213,13 +218,14 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
         unsigned long long m_emit = __ballot(st == ST_NEED_EMIT);
         unsigned long long m_re = GEN ? __ballot(st == ST_NEED_REEMIT) : 0ull;       // re-absorbed by a source with a radius: iter_final.f90:213-243
-        if (!(m_walk | m_int | m_emit | m_re | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
+        unsigned long long m_mrw = MRWF ? __ballot(st == ST_MRW) : 0ull;
+        if (!(m_walk | m_int | m_emit | m_re | m_mrw | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
 
         // One event slot per lane must be there before anything that peels off is started.  A wave that only wants to emit
         // does not ask while there is no packet id left to emit with: the slots then go to the waves that hold the packets
         // set aside by the round before (with a buffer of fewer chunks than waves they would otherwise never get one).
         if (!full && w_end - w_pos < 64ull &&
-            (m_int || m_re || (m_emit && !pool_empty && (dsp.next < dsp.end || *((volatile unsigned long long *)P.counter) < L.end_id)))) {
+            (m_int || m_re || m_mrw || (m_emit && !pool_empty && (dsp.next < dsp.end || *((volatile unsigned long long *)P.counter) < L.end_id)))) {
             unsigned long long b = 0;
             if (lane == 0) b = atomicAdd(&B.ctl->reserved, (unsigned long long)HYP_PEEL_CHUNK);
             b = __shfl(b, 0, 64);
@@ -230,14 +236,14 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
         if (full) {
             // this round's buffer is full: set aside what would peel off next, return the unused ids, walk the rest out
-            const unsigned long long m = m_int | m_re;
+            const unsigned long long m = m_int | m_re | m_mrw;
             if (m) {
                 unsigned int base = 0;
                 if (lane == (unsigned int)(__ffsll((long long)m) - 1)) base = atomicAdd(&B.ctl->n_susp[B.cur], (unsigned int)__popcll(m));
                 base = __shfl(base, __ffsll((long long)m) - 1, 64);
-                if (st == ST_NEED_INTERACT || (GEN && st == ST_NEED_REEMIT)) {
+                if (st == ST_NEED_INTERACT || (GEN && st == ST_NEED_REEMIT) || (MRWF && st == ST_MRW)) {
                     SuspRec<NDT, GEOM> &R = ((SuspRec<NDT, GEOM> *)B.susp[B.cur])[base + __popcll(m & lt)];
-                    if (GEN) p.spec_idx = st == ST_NEED_REEMIT ? 1 : 0;
+                    if (GEN) p.spec_idx = st == ST_NEED_REEMIT ? 1 : (MRWF && st == ST_MRW) ? 2 + mrw_k : 0;
                     R.p = p; R.g = g; R.f = f;
                     st = ST_DONE;
                 }
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 dsp.next = dsp.end;
             }
             pool_empty = true;
-            m_int = 0; m_emit = 0; m_re = 0;
+            m_int = 0; m_emit = 0; m_re = 0; m_mrw = 0;
             if (!(m_walk | (FFS ? __ballot(st == ST_FF_DONE || st == ST_FF_KILLED) : 0ull))) break;
         }
 
@@ -276,6 +282,26 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     if (!ok) st = ST_NEED_EMIT;
                     else { peel = 3; last = LAST_SR; st = ST_PLACED; last_iso = false; a_prev = src_normal; }
+                }
+            }
+            m_walk = __ballot(st == ST_WALK);
+            m_int = __ballot(st == ST_NEED_INTERACT);
+            m_emit = __ballot(st == ST_NEED_EMIT);
+        }
+
+        if (MRWF && m_mrw) {
+            // modified random walk, one step per pass, each peeled off as isotropic emission: iter_final.f90:165-183
+            if (st == ST_MRW) {
+                if ((long long)mrw_k == P.n_inter_mrw_max + 1) { cnt.killed_int++; st = ST_NEED_EMIT; }
+                else if (mrw_wanted(P, W, p)) {
+                    a_prev = p.a; s_prev[0] = p.s[0]; s_prev[1] = p.s[1]; s_prev[2] = p.s[2]; s_prev[3] = p.s[3];
+                    f.dust_id = mrw_step<NDT, GEOM, false>(P, W, p, g, nullptr);
+                    mrw_k++;
+                    peel = 4; last = LAST_DE; last_iso = true;
+                } else {
+                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
+                    begin_integrate(P, p);
+                    st = (p.tau_req == 0.0) ? ST_NEED_INTERACT : ST_WALK;
                 }
             }
             m_walk = __ballot(st == ST_WALK);
@@ -445,6 +471,10 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                     }
                 } else if (GEN && peel == 3 && geo_escaped(P, p.cell)) {
                     st = ST_ESCAPED;
+                } else if (MRWF && peel == 4) {
+                    // stays in ST_MRW: the next pass decides on another step
+                } else if (MRWF && peel == 2) {
+                    st = ST_MRW; mrw_k = 1;
                 } else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
                     begin_integrate(P, p);

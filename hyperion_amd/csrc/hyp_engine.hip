@@ -1973,7 +1973,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
             // on the deferred schedule with the GEN kernels (hyp_defer.h) instead of the general kernel with inline peel-off
             // (any sources: the GEN kernels emit with the general emitter; what stays on final_kernel is MRW, binned images, inside
             // observers together with such sources, and more than four species)
-            bool gd = !plain && !pr->config.mrw && !pr->config.monochromatic && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;
+            bool gd = !plain && !pr->config.monochromatic && !pr->binned && h->n_dust <= 4 && pr->n_sources > 0;      // (with the modified random walk: the MRWF instance)
             for (int g = 0; g < pr->n_peeled; g++) gd = gd && !pr->peeled[g].inside_observer;
             h->gen_defer = gd;
             // ... and the same sources in a monochromatic run (the Pascucci / Pinte benchmark models: a stellar sphere)
@@ -3293,7 +3293,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
-    if (deferred && gen) { dk.propagate = dk.propagate_gen; dk.peel = dk.peel_gen; dk.direct = nullptr; }      // (a source may stand in the way of another's direct light)
+    if (deferred && gen) { dk.propagate = h->cfg.mrw ? dk.propagate_gen_mrw : dk.propagate_gen; dk.peel = dk.peel_gen; dk.direct = nullptr; }      // (a source may stand in the way of another's direct light)
     if (deferred && (!dk.propagate || !dk.peel)) deferred = false;
     const size_t lds = lds_bytes(P);
     int bpc = h->blocks_per_cu;

@@ -119,7 +119,7 @@ template <int NDT, int GEOM>
 static DeferKernels defer_kernels()
 {
     DeferKernels k;
-    k.propagate = final_defer_kernel<NDT, GEOM, true>; k.propagate_mono = final_defer_kernel<NDT, GEOM, true, true>; k.propagate_gen = final_defer_kernel<NDT, GEOM, true, false, true>; k.propagate_mono_gen = final_defer_kernel<NDT, GEOM, true, true, true>; k.peel_gen = peel_kernel<NDT, GEOM, false, true>; k.propagate_pre = final_defer_kernel<NDT, GEOM, false>; k.ff_walk = ff_walk_kernel<NDT, GEOM>; k.peel = peel_kernel<NDT, GEOM, false>; k.peel_inside = peel_kernel<NDT, GEOM, true>; k.reset = defer_reset_kernel<GEOM>;
+    k.propagate = final_defer_kernel<NDT, GEOM, true>; k.propagate_mono = final_defer_kernel<NDT, GEOM, true, true>; k.propagate_gen = final_defer_kernel<NDT, GEOM, true, false, true>; k.propagate_mono_gen = final_defer_kernel<NDT, GEOM, true, true, true>; k.propagate_gen_mrw = final_defer_kernel<NDT, GEOM, true, false, true, true>; k.peel_gen = peel_kernel<NDT, GEOM, false, true>; k.propagate_pre = final_defer_kernel<NDT, GEOM, false>; k.ff_walk = ff_walk_kernel<NDT, GEOM>; k.peel = peel_kernel<NDT, GEOM, false>; k.peel_inside = peel_kernel<NDT, GEOM, true>; k.reset = defer_reset_kernel<GEOM>;
     k.event_bytes = sizeof(PeelEvent<NDT, GEOM>); k.susp_bytes = sizeof(SuspRec<NDT, GEOM>); k.ff_bytes = sizeof(EmitRec<NDT>);
     k.direct = direct_column_kernel<NDT, GEOM>; k.sort_hist = peel_sort_hist_kernel<NDT, GEOM>; k.sort_scatter = peel_sort_scatter_kernel<NDT, GEOM>; k.sort_scan = peel_sort_scan_kernel;
     return k;

@@ -18,7 +18,7 @@ using PeelKernel = void (*)(const DProblem *, DeferBuf, uint32_t);
 using PeelSortK = void (*)(const DProblem *, DeferBuf);
 struct DeferKernels {
     DeferKernel propagate, propagate_pre, ff_walk;       // propagate_pre: with the forced-first walks made ahead (ff_walk)
-    DeferKernel propagate_gen, propagate_mono_gen; PeelKernel peel_gen;      // sources with a surface (final_defer_kernel<.., true, false, true>, peel_kernel<.., false, true>)
+    DeferKernel propagate_gen, propagate_mono_gen, propagate_gen_mrw; PeelKernel peel_gen;      // sources with a surface (final_defer_kernel<.., true, false, true>, peel_kernel<.., false, true>)
     DeferKernel propagate_mono;                          // a launch of the monochromatic iteration (final_defer_kernel<.., true, true>)
     PeelKernel peel, peel_inside; void (*reset)(PeelCtl *, int, int); size_t event_bytes, susp_bytes, ff_bytes;
     void (*direct)(const DProblem *, DirectCol *);       // direct_column_kernel<nd, GEOM>

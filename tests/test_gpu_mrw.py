@@ -180,3 +180,39 @@ def test_errors():
     with pytest.raises(hyperion_amd.EngineError, match="not implemented for Voronoi"):
         eng.lucy_iteration(100, 1)
     eng.close()
+
+
+def test_imaging_with_mrw_on_the_deferred_schedule():
+    """Round 4: the polychromatic imaging iteration of a run with the modified random walk on the deferred schedule
+    (final_defer_kernel<.., GEN, MRWF>: every MRW step peeled off as isotropic emission, iter_final.f90:165-183; a packet set
+    aside between rounds remembers the step it is at): = the general kernel = the oracle, one round and many."""
+    from hyperion_amd.benchmark import PC
+    p = thicken(make_benchmark_problem(8, n_photons=2000, n_iter=2), n_species=2)
+    p.peeled = [PeeledImages(theta=[45.0, 120.0], phi=[45.0, 200.0], n_wav=5, wav_min=0.1, wav_max=3000.0, n_x=8, n_y=8,
+                             x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC, n_ap=2, ap_min=0.2 * PC,
+                             ap_max=2.0 * PC, compute_stokes=True, track_origin="basic")]
+    for peel_events in (0, 4096):
+        out = []
+        for defer in (1, 0):
+            eng = hyperion_amd.Engine(p)
+            eng.set_option("gen_defer", defer)
+            if peel_events and defer:
+                eng.set_option("peel_events", peel_events)
+            eng.lucy_iteration(2000, 1)
+            res, st = eng.final_iteration(3000)
+            rounds = eng.get_option("last_defer_rounds")
+            assert (rounds >= (3 if peel_events else 1)) if defer else rounds == 0
+            eng.close()
+            out.append((res, st))
+        (ra, sa), (rb, sb) = out
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (k, sa, sb)
+        for ga, gb in zip(ra, rb):
+            for name in gb:
+                np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-10 * np.nanmax(np.abs(gb[name])), err_msg=name)
+    orc = Oracle(p)
+    orc.lucy_iteration(2000, 1)
+    ro, so = orc.final_iteration(3000)
+    orc.close()
+    for k in INT_KEYS:
+        assert sa[k] == so[k], (k, sa, so)
