@@ -1986,7 +1986,8 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
         {
             bool lean = !pr->config.mrw && !pr->config.monochromatic && !pr->binned;
             for (int g = 0; g < pr->n_peeled; g++) lean = lean && !pr->peeled[g].inside_observer;
-            h->lean_imaging = lean && h->n_dust <= 4;
+            (void)lean;
+            h->lean_imaging = false;      // round 4: the lean kernel's problems image on the deferred schedule (GEN kernels); with gen_defer = 0 they run on the general kernel
         }
         bool simple = pr->n_sources > 0, ext = pr->n_sources > 0;
         for (int i = 0; i < pr->n_sources; i++) {

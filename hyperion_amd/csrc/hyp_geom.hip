@@ -76,9 +76,9 @@ LucyKernel pick_final_kernel_g(int nd)      // the general imaging kernel final_
 
 #if HYP_PART == 5
 template <int GEOM>
-LucyKernel pick_final_special_g(int nd, int mode)      // mode 1: plain (final_kernel<.., true>), 2: lean (final_kernel<.., false, true>); one to four species
+LucyKernel pick_final_special_g(int nd, int mode)      // mode 1: plain (final_kernel<.., true>); one to four species
 {
-#define HYP_FINAL_PICK(N) (mode == 1 ? final_kernel<N, GEOM, true> : final_kernel<N, GEOM, false, true>)
+#define HYP_FINAL_PICK(N) ((void)mode, final_kernel<N, GEOM, true>)      // (mode 2, the lean specialisation of round 3, is gone: its problems run on the deferred schedule's GEN kernels)
 #ifdef HYP_ONLY_ND
     (void)nd;
     return HYP_FINAL_PICK(HYP_ONLY_ND);

@@ -168,10 +168,10 @@ def test_spotted_star_parity_and_spectrum():
         np.testing.assert_allclose(ra[0][name], rb[0][name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(rb[0][name])), err_msg=name)
 
 
-def test_lean_imaging_kernel_is_the_general_kernel_on_a_star():
-    """final_kernel<.., false, LEAN>: the general imaging kernel with the modified random walk, the monochromatic launch, binned
-    images and inside observers compiled out (the host picks it when the problem has none of them).  Same packets, same code
-    for everything a star with a radius needs: tallies identical to the general kernel's, cubes equal to summation order."""
+def test_star_images_on_the_deferred_schedule_like_on_the_general_kernel():
+    """A star with a radius (limb darkening, re-absorption): the imaging iteration on the deferred schedule's GEN kernels (default since
+    round 4; the lean specialisation of the general kernel that round 3 used here is gone) against the general kernel: tallies
+    identical, cubes equal to summation order."""
     from hyperion_amd.problem import PeeledImages
     prob = star_problem(True, tau=2.0, n=12)
     prob.peeled = [PeeledImages(theta=[30.0, 100.0], phi=[20.0, 250.0], n_wav=3, wav_min=0.1, wav_max=1000.0, n_x=8, n_y=8,
@@ -179,14 +179,16 @@ def test_lean_imaging_kernel_is_the_general_kernel_on_a_star():
                                 compute_stokes=True, uncertainties=True, track_origin="detailed")]
     eng = hyperion_amd.Engine(prob)
     eng.lucy_iteration(20000, 1, want_output=False)
-    assert eng.get_option("plain_imaging") == 0 and eng.get_option("lean_imaging") == 1
+    assert eng.get_option("plain_imaging") == 0 and eng.get_option("gen_defer") == 1
     ra, sa = eng.final_iteration(30000)
-    eng.set_option("lean_imaging", 0)
+    assert eng.get_option("last_defer_rounds") >= 1
+    eng.set_option("gen_defer", 0)
     rb, sb = eng.final_iteration(30000)
+    assert eng.get_option("last_defer_rounds") == 0
     eng.close()
     for k in INT_KEYS:
         assert sa[k] == sb[k], (k, sa, sb)
-    assert sa["energy_current"] == sb["energy_current"]
+    assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
     for ga, gb in zip(ra, rb):
         for name in gb:
-            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-10, atol=1e-13 * np.nanmax(np.abs(gb[name])), err_msg=name)   # sums in another order
+            np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[name])), err_msg=name)   # sums in another order
