@@ -365,9 +365,9 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * "mono_defer" (1, the default: the launches of a monochromatic run whose problem is plain otherwise -- point sources, no MRW, no binned
  * images -- run on the deferred schedule; 0: the general kernel with inline peel-off; "last_mono_deferred" reports which one the last
  * hyp_mono_launch took), "oct_neighbours" (0: the
- * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" / "lean_imaging" (the
- * specialisations of the imaging kernel the problem qualifies for -- point sources only / any sources, both without MRW, monochromatic launch,
- * binned images and inside observers; can only be switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
+ * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (the specialisation of the inline imaging kernel for point sources without MRW, monochromatic launch,
+ * binned images and inside observers; "lean_imaging", round 3's specialisation for any sources, reads 0 since round 4: those problems run on
+ * the deferred schedule, "gen_defer"; can only be switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
  * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more
  * cells than its visited set holds: the n_photons of the last iteration are an upper bound) and, for sharded runs, the
  * geometry of the blocks that hyp_*_accumulators hand out: "lucy_block_doubles" / "image_block_doubles" (their lengths) and
