@@ -3073,7 +3073,9 @@ static int defer_buffers(hyp_handle h, const DeferKernels &dk, size_t lanes, uin
     // `peel_events` is the ceiling; a small iteration does not need it (8 events per packet in one round, more rounds
     // beyond that) and the buffer only grows
     size_t cap = (size_t)h->peel_events;
-    const size_t want = n_local > (1ull << 40) ? cap : std::max<size_t>((size_t)n_local * 8, (size_t)1 << 16);
+    // (at least 4 Mi slots, ~0.9 GB: a packet of an optically thick run leaves thousands of events, and every round costs a host
+    // synchronisation and three sort launches -- 2e4 packets with 1e4 events each took 1 413 rounds with the 8-per-packet rule alone)
+    const size_t want = n_local > (1ull << 40) ? cap : std::max<size_t>((size_t)n_local * 8, (size_t)1 << 22);
     if (want < cap && !h->peel_events_exact) cap = want;
     cap = (cap + HYP_PEEL_CHUNK - 1) / HYP_PEEL_CHUNK * HYP_PEEL_CHUNK;
     if (h->d_peel_events && h->peel_event_bytes == dk.event_bytes && h->peel_lanes >= lanes &&
