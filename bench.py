@@ -182,6 +182,72 @@ def extras(n, passes=3):
                 "schedule": "cluster-tiled (hyp_vtile.h), %d clusters" % e.get_option("vt_clusters") if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
                 **common(st, n, dt, dts, k_ms, 24.0 * 2 * st["crossings"]), **pmc_fields("vor", 48.0)})
     e.close()
+    res += other_iterations(passes)
+    return res
+
+
+def other_iterations(passes=3):
+    """Iterations no BASELINE config names, so that the driver's own run carries them (profiles/r04_other_iterations.md,
+    tools/mono_bench.py, tools/yso_probe.py have the same workloads): the monochromatic final iteration on a 64^3 Cartesian grid
+    (5 wavelengths x source + thermal packets), and what an AnalyticalYSOModel-like run costs -- a 400 x 200 spherical polar grid lit by
+    a star WITH A RADIUS, Lucy iteration and imaging iteration (SEDs for two views).  Kernel time from HIP events, mean of `passes`."""
+    import numpy as np
+    import hyperion_amd
+    from hyperion_amd.benchmark import LSUN, PC, make_benchmark_problem
+    from hyperion_amd.problem import PeeledImages, Source
+    res = []
+    try:
+        n = 20_000_000
+        p = make_benchmark_problem(64, tau=1.0)
+        p.config.monochromatic = True
+        p.config.frequencies = 2.99792458e14 / np.array([1.0, 3.0, 10.0, 30.0, 100.0])
+        p.peeled = [PeeledImages(theta=[45.0], phi=[45.0], n_x=256, n_y=256, x_min=-1.5 * PC, x_max=1.5 * PC, y_min=-1.5 * PC, y_max=1.5 * PC,
+                                 n_ap=1, ap_min=3 * PC, ap_max=3 * PC, n_wav=5, wav_min=1.0, wav_max=100.0, inu_min=1, inu_max=5)]
+        e = hyperion_amd.Engine(p)
+        e.lucy_iteration(10_000_000, 1, want_output=False)
+        e.mono_iteration(n // 100, n // 100)
+        ms, st = [], None
+        for _ in range(passes):
+            _, st = e.mono_iteration(n // 10, n // 10)
+            ms.append(e.last_kernel_ms()[0])
+        k = sum(ms) / len(ms)
+        res.append({"config": "monochromatic final iteration: 64^3 Cartesian grid, 5 wavelengths x (source + thermal packets), one 256^2 image",
+                    "schedule": "deferred peel-off, one launch per (part, wavelength)" if e.get_option("last_mono_deferred") else "general kernel, inline peel-off",
+                    "packets": n, "kernel_ms": k, "pass_ms": ms, "packets_per_s": n / k * 1e3, "crossings_per_packet": st["crossings"] / n,
+                    "crossings_per_s": st["crossings"] / k * 1e3})
+        e.close()
+    except Exception as ex:
+        res.append({"config": "monochromatic final iteration", "error": str(ex)})
+    try:
+        from test_gpu_polar import config0_problem
+        n = 10_000_000
+        p = config0_problem(n_r=400, n_t=200, tau=3.0, log_r=True, peeled=True)
+        p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.002 * PC)]
+        e = hyperion_amd.Engine(p)
+        e.lucy_iteration(n // 10, 1, want_output=False)
+        ms, st = [], None
+        for i in range(passes):
+            _, st = e.lucy_iteration(n, 2 + i, want_output=False)
+            ms.append(e.last_kernel_ms()[0])
+        k = sum(ms) / len(ms)
+        res.append({"config": "spherical polar grid 400 x 200 (log r, cavity), star with a radius: Lucy iteration",
+                    "schedule": "brick-tiled (hyp_ptile.h)" if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
+                    "packets": n, "kernel_ms": k, "pass_ms": ms, "packets_per_s": n / k * 1e3, "crossings_per_packet": st["crossings"] / n,
+                    "crossings_per_s": st["crossings"] / k * 1e3})
+        e.final_iteration(n // 10)
+        ms = []
+        for _ in range(passes):
+            _, st = e.final_iteration(n)
+            ms.append(e.last_kernel_ms()[0])
+        k = sum(ms) / len(ms)
+        res.append({"config": "... imaging iteration: peeled SEDs for two views, forced first interaction",
+                    "schedule": ("deferred peel-off with the general-source kernels (hyp_defer.h: GEN), %d rounds" % e.get_option("last_defer_rounds"))
+                                if e.get_option("last_defer_rounds") else "general kernel, inline peel-off",
+                    "packets": n, "kernel_ms": k, "pass_ms": ms, "packets_per_s": n / k * 1e3, "crossings_per_packet": st["crossings"] / n,
+                    "crossings_per_s": st["crossings"] / k * 1e3})
+        e.close()
+    except Exception as ex:
+        res.append({"config": "spherical polar grid, star with a radius", "error": str(ex)})
     return res
 
 
