@@ -385,12 +385,14 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
     const double pC = r2_xy / v2_xy;
     double t1, t2;
     const int i1 = c.ic[0], i2 = c.ic[1];
-    quad_reduced(pB, pC - P.wr2[i1] / v2_xy, t1, t2);
-    insert_pair(ws, t1, t2, c.ow[0] == -1, 0, -1, P.ew[0][i1]);
-    quad_reduced(pB, pC - P.wr2[i1 + 1] / v2_xy, t1, t2);
-    insert_pair(ws, t1, t2, c.ow[0] == +1, 0, +1, P.ew[0][i1 + 1]);
-    if (c.ow[1] != -1) insert_t(ws, (P.w[1][i2] - r[2]) / v[2], 1, -1, 0.0);
-    if (c.ow[1] != +1) insert_t(ws, (P.w[1][i2 + 1] - r[2]) / v[2], 1, +1, 0.0);
+    // (loading these up front behind a compiler fence, as sph_find_wall does, measured 93.7 against 90.9 ms on a 400 x 200 disc: not done)
+    const double wr2_a = P.wr2[i1], wr2_b = P.wr2[i1 + 1], e0_a = P.ew[0][i1], e0_b = P.ew[0][i1 + 1], wz_a = P.w[1][i2], wz_b = P.w[1][i2 + 1];
+    quad_reduced(pB, pC - wr2_a / v2_xy, t1, t2);
+    insert_pair(ws, t1, t2, c.ow[0] == -1, 0, -1, e0_a);
+    quad_reduced(pB, pC - wr2_b / v2_xy, t1, t2);
+    insert_pair(ws, t1, t2, c.ow[0] == +1, 0, +1, e0_b);
+    if (c.ow[1] != -1) insert_t(ws, (wz_a - r[2]) / v[2], 1, -1, 0.0);
+    if (c.ow[1] != +1) insert_t(ws, (wz_b - r[2]) / v[2], 1, +1, 0.0);
     polar_wall_phi<GEOM_CYL>(P, r, v, c, r2_xy, ws);
     tnear = ws.tmin;
 #pragma unroll

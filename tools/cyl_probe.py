@@ -1,0 +1,27 @@
+"""Cylindrical polar grid 400 x 200 (a flared disc, central point source): tiled Lucy iteration.
+   [HYP_LIB=...] python tools/cyl_probe.py [packets]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import hyperion_amd
+if os.environ.get("HYP_LIB"):
+    import hyperion_amd.engine as E
+    E._lib = E.load_library(os.environ["HYP_LIB"])
+from hyperion_amd.benchmark import LSUN, PC, load_test_dust
+from hyperion_amd.problem import Problem, RunConfig, Source
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
+w = np.hstack([0.0, np.logspace(np.log10(0.01 * PC), np.log10(PC), 400)])
+z = np.linspace(-0.5 * PC, 0.5 * PC, 201)
+ph = np.array([0.0, 2 * np.pi])
+wc = 0.5 * (w[1:] + w[:-1]); zc = 0.5 * (z[1:] + z[:-1])
+h = 0.1 * PC * (wc / PC) ** 1.2 + 0.01 * PC
+dens = (6.0 / PC) * np.exp(-0.5 * (zc[:, None] / h[None, :]) ** 2) * (wc[None, :] > 0.02 * PC) + 0.05 / PC
+p = Problem(walls=[w, z, ph], density=dens[None, None], dust=[load_test_dust()], sources=[Source(type="point", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0))],
+            config=RunConfig(), grid_type="cyl_pol")
+e = hyperion_amd.Engine(p)
+e.lucy_iteration(n // 10, 1, want_output=False)
+for it in (2, 3):
+    _, st = e.lucy_iteration(n, it, want_output=False)
+    ms = e.last_kernel_ms()[0]
+    print("cyl 400 x 200: %.1f ms, %.3g packets/s, %.0f crossings/packet, %.3g crossings/s, mode %d, killed_geo %d" % (ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3, e.get_option("last_lucy_mode"), st["killed_geo"]), flush=True)
