@@ -89,7 +89,7 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
     bool v_ok = true;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
-    int slot = -1;
+    int slot = -1, kind = 0;                  // kind: HotRec::pad, the kind of the packet's next interaction (store_records, TileGeom::presort)
     int st = LS_IDLE;
     bool exhausted = false;
 #pragma unroll
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
                     else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                     else if (cl < AT_HIST) atomicAdd(&nb_cnt[cl], 1u);                // parked: same brick again
                     else atomicAdd(&counts[cl], 1u);
-                    if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
+                    if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? (slot | (kind << 30)) : slot;
                 }
                 st = LS_IDLE;
             }
@@ -237,6 +237,7 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
                     const unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
+                    kind = H.pad;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     st = LS_WALK;
                 }

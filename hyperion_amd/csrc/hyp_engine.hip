@@ -247,6 +247,7 @@ struct hyp_engine {
     int tile_poll = 8;              // option: generations between two looks at the finished counter (a host sync)
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
+    int tile_presort = 1;           // option: 1 = the Cartesian walk passes the kind of a packet's next interaction on with its slot (one species)
     int tile_fused_sort = 1;        // option: 1 = tile_scan + tile_scatter in one launch (tile_sort_kernel)
     int pt_vsplit = 1;              // option: spherical grids, 1 = two sort entries per brick (not yet interacted / the others)
     int pt_lds_kb = 128;            // option: LDS of the densities and accumulators of one polar-grid brick in KB (hyp_ptile.h)
@@ -672,9 +673,11 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     } else if (P.grid_type == 4) {
         T.bx = h->at_max_cells; T.by = h->at_max_go; T.bz = h->at_max_walls;
         T.nbx = T.n_bricks = h->at_slabs_n; T.nby = T.nbz = 1;
+        T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     } else if (P.grid_type == 2) {
         T.bx = h->ot_max_cells; T.by = h->ot_max_kids; T.bz = 1;
         T.nbx = T.n_bricks = h->ot_clusters; T.nby = T.nbz = 1;
+        T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     } else if (P.grid_type == 5 || P.grid_type == 6) {
         polar_tile_shape(P, nd, h->pt_lds_kb, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
@@ -686,6 +689,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         tile_shape(nd, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;
         T.n_bricks = T.nbx * T.nby * T.nbz;
+        T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     }
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
     const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
@@ -2983,6 +2987,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "pt_vsplit") h->pt_vsplit = value ? 1 : 0;
     else if (n == "tile_fused_sort") h->tile_fused_sort = value ? 1 : 0;
+    else if (n == "tile_presort") h->tile_presort = value ? 1 : 0;
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
@@ -3044,6 +3049,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "ot_max_cells") *value = h->ot_max_cells;
     else if (n == "pt_vsplit") *value = h->pt_vsplit;
     else if (n == "tile_fused_sort") *value = h->tile_fused_sort;
+    else if (n == "tile_presort") *value = h->tile_presort;
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
     bool v_ok = true;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
-    int slot = -1;
+    int slot = -1, kind = 0;                  // kind: HotRec::pad, the kind of the packet's next interaction (store_records, TileGeom::presort)
     int st = LS_IDLE;
     bool exhausted = false;
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                     else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
                     else if (cl < OT_HIST) atomicAdd(&nb_cnt[cl], 1u);                // parked: same cluster again
                     else atomicAdd(&counts[cl], 1u);
-                    if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
+                    if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? (slot | (kind << 30)) : slot;
                 }
                 st = LS_IDLE;
             }
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                     const unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
+                    kind = H.pad;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     const OctCell o = rec[loc];
                     cc[0] = o.x; cc[1] = o.y; cc[2] = o.z; level = o.level;

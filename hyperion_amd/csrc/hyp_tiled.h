@@ -152,6 +152,7 @@ struct TileGeom {
     int gen;                     // generation number (split schedule: which of the two extra lists is read)
     int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
     int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
+    int presort;                 // 1: the walk writes slot | kind << 30 into the interaction lists (HotRec::pad; one species, Cartesian walk)
     int vsplit;                  // 2: every brick is two entries of the sort -- 2 b for packets that have not interacted yet, 2 b + 1 for the others
 };                               //    (spherical grids: waves of one kind, hyp_ptile.h); 0 / 1: one entry per brick
 
@@ -552,6 +553,13 @@ __device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, 
 #pragma unroll
     for (int d = 0; d < ND; d++) { H.chi[d] = p.chi[d]; H.kappa[d] = p.kappa[d]; C.albedo[d] = p.albedo[d]; }
     H.id = id; H.countdown = g.countdown; H.blk_b = g.blk_b; H.state = state;
+    if (ND == 1) {
+        // the kind of the packet's NEXT interaction (absorption: the first number of its stream exceeds the albedo) is known already --
+        // the walk draws from the other stream --: the walk passes it on with the slot (TileGeom::presort), and tile_interact orders its
+        // chunk by kind without reading the records a first time
+        Rng g2 = g;
+        H.pad = rng_uniform(g2) > p.albedo[0] ? 1 : 0;
+    }
     C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
     C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
     if (P.any_intersect) { C.t_src = p.t_src; C.t_ach = p.t_ach; C.reabs_id = p.reabs_id; C.reabs = p.reabs; }
@@ -655,7 +663,13 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         if (threadIdx.x == 0) n_abs = n_chunk;
 #else
         for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) {
-            const int slot = list[c0 + k];
+            const int entry = list[c0 + k];
+            const int slot = entry & 0x3fffffff;
+            if (T.presort) {        // the kind came with the slot: no look at the records
+                if ((entry >> 30) & 1) sorted[atomicAdd(&n_abs, 1)] = slot;
+                else sorted[CH - 1 - atomicAdd(&n_oth, 1)] = slot;
+                continue;
+            }
             const HotRec<ND> &H = hot[slot];
             const ColdRec<ND> &C = cold[slot];
             bool absorb = false;
@@ -1560,7 +1574,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
     Cell<GEOM_CAR> cell;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
-    int slot = -1;
+    int slot = -1, kind = 0;                  // kind: HotRec::pad, see store_records
     int st = LS_IDLE;
     bool exhausted = loader, pre = false;
 #pragma unroll
@@ -1668,7 +1682,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                         atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
                     } else slot_brick[slot] = brick_of(T, cell.ic);
                 } else if (T.split) atomicAdd(&nb_cnt[13], 1u);                      // parked: same brick again
-                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
+                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? (slot | (kind << 30)) : slot;
                 st = LS_IDLE;
             }
             if (park) break;
@@ -1760,6 +1774,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
+                    kind = H.pad;
                     if (any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     if (RING) ring.taken(j);
                     if (HYP_TILE_PREFETCH > 0 && !RING) {
