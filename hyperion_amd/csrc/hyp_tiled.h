@@ -1574,7 +1574,9 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
     Cell<GEOM_CAR> cell;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
-    int slot = -1, kind = 0;                  // kind: HotRec::pad, see store_records
+    int slot = -1;                            // (bit 30: HotRec::pad, the kind of the packet's next interaction -- see store_records; a register of its own
+                                              //  took the kernel from 119 to 124 VGPRs and cost more than the ordering saves)
+#define SLOT (slot & 0x3fffffff)
     int st = LS_IDLE;
     bool exhausted = loader, pre = false;
 #pragma unroll
@@ -1660,29 +1662,29 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 }
             }
             if (st == LS_DEAD) {
-                hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
-                if (T.split) dlist[tk.start + atomicAdd(&n_dead_l, 1)] = slot;
+                hot[SLOT].state = TS_DEAD; slot_brick[SLOT] = TILE_NEEDS_PREPARE;
+                if (T.split) dlist[tk.start + atomicAdd(&n_dead_l, 1)] = SLOT;
                 finished++; st = LS_IDLE;
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
-                HotRec<ND> &H = hot[slot];
+                HotRec<ND> &H = hot[SLOT];
 #pragma unroll
                 for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
                 H.ow = pack_ow(cell.ow);
                 H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
-                if (any_intersect) cold[slot].t_ach = t_ach;
-                if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
-                else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
+                if (any_intersect) cold[SLOT].t_ach = t_ach;
+                if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[SLOT] = TILE_NEEDS_REEMIT; }
+                else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[SLOT] = TILE_NEEDS_INTERACT; }
                 else if (st == LS_LEFT) {                                             // H.state stays TS_WALK
                     if (T.split) {
                         // one cell step leaves the brick through a face, an edge or a corner
                         const int dx = cell.ic[0] < x0 ? -1 : (cell.ic[0] >= x1 ? 1 : 0);
                         const int dy = cell.ic[1] < y0 ? -1 : (cell.ic[1] >= y1 ? 1 : 0);
                         const int dz = cell.ic[2] < z0 ? -1 : (cell.ic[2] >= z1 ? 1 : 0);
-                        slot_brick[slot] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
+                        slot_brick[SLOT] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
                         atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
-                    } else slot_brick[slot] = brick_of(T, cell.ic);
+                    } else slot_brick[SLOT] = brick_of(T, cell.ic);
                 } else if (T.split) atomicAdd(&nb_cnt[13], 1u);                      // parked: same brick again
-                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? (slot | (kind << 30)) : slot;
+                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? slot : SLOT;
                 st = LS_IDLE;
             }
             if (park) break;
@@ -1746,7 +1748,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     union RecWords { uint4 q[sizeof(HotRec<ND>) / 16]; HotRec<ND> h; };
                     RecWords U;
                     if (!RING) {
-                        const uint4 *__restrict__ src = (const uint4 *)&hot[slot];
+                        const uint4 *__restrict__ src = (const uint4 *)&hot[SLOT];
 #pragma unroll
                         for (int i = 0; i < (int)(sizeof(HotRec<ND>) / 16); i++) U.q[i] = src[i];
 #pragma unroll
@@ -1756,7 +1758,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     }
                     const HotRec<ND> &H = RING ? ring.record(j) : U.h;
 #else
-                    const HotRec<ND> &H = RING ? ring.record(j) : hot[slot];
+                    const HotRec<ND> &H = RING ? ring.record(j) : hot[SLOT];
 #endif
                     claim = -1;
                     v_ok = true;
@@ -1774,8 +1776,10 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-                    kind = H.pad;
-                    if (any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
+#ifndef HYP_TILE_NO_KIND      // (tuning builds: the walk without it)
+                    slot |= (H.pad & 1) << 30;
+#endif
+                    if (any_intersect) { t_src = cold[SLOT].t_src; t_ach = cold[SLOT].t_ach; }
                     if (RING) ring.taken(j);
                     if (HYP_TILE_PREFETCH > 0 && !RING) {
                         // every value loaded above is "used" here: the compiler waits for them now and has nothing in flight
@@ -1896,5 +1900,6 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
         if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
     }
 #endif
+#undef SLOT
     block_tally_flush(P, ctl, red, cnt, finished);
 }
