@@ -349,7 +349,11 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb", "at_cells" / "at_lds_kb" (most cells per Voronoi / octree cluster / AMR brick; LDS
  * budget of a walk workgroup in KB: 156 = one workgroup per CU), "pt_lds_kb" (LDS of a polar-grid brick's densities and accumulators),
  * "tile_time_walk" (1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches"; off by
- * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only),
+ * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only), "tile_fused_sort" (1: scan + scatter of the
+ * per-generation sort in one launch), "tile_presort" (1: with one species the walk hands the kind of a packet's next interaction on with its slot and
+ * tile_interact orders its chunk without reading the records first), "tile_drain" (packets in flight below which the last ones are finished in one
+ * launch; -1: 400 000 on Cartesian and Voronoi grids, 1 000 000 elsewhere), "pt_vsplit" (1: spherical grids sort packets that have not
+ * interacted yet apart from the others),
  * "final_interact_threshold" /
  * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
  * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer: at most
