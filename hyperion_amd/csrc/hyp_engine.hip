@@ -685,6 +685,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         // spherical grids: packets that have not interacted yet (radial for a central source: no cone wall is ever in reach, hyp_polar.h:
         // sph_cone_out_of_reach) sorted apart from the others, so that their waves skip the cone quadratics
         if (P.grid_type == 5 && h->pt_vsplit && 2 * T.n_bricks <= HYP_TILE_MAX_BRICKS) { T.vsplit = 2; T.n_bricks *= 2; }
+        T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     } else {
         tile_shape(nd, T.bx, T.by, T.bz);
         T.nbx = (P.n1 + T.bx - 1) / T.bx; T.nby = (P.n2 + T.by - 1) / T.by; T.nbz = (P.n3 + T.bz - 1) / T.bz;

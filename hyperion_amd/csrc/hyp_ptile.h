@@ -287,7 +287,8 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
     if constexpr (GEOM == GEOM_SPH) cell.radial = 0;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
     g.id_lo = g.id_hi = 0; g.blk_b = 0; g.countdown = 0;
-    int slot = -1;
+    int slot = -1;                            // (bit 30: HotRec::pad, the kind of the packet's next interaction: TileGeom::presort, hyp_tiled.h)
+#define SLOT (slot & 0x3fffffff)
     int st = LS_IDLE;
     bool exhausted = false;
 #pragma unroll
@@ -317,21 +318,21 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                 else { cnt.killed_geo++; st = LS_DEAD; }
             }
             if (st == LS_DEAD) {
-                hot[slot].state = TS_DEAD; slot_brick[slot] = TILE_NEEDS_PREPARE;
-                dlist[tk.start + atomicAdd(&n_dead_l, 1)] = slot;
+                hot[SLOT].state = TS_DEAD; slot_brick[SLOT] = TILE_NEEDS_PREPARE;
+                dlist[tk.start + atomicAdd(&n_dead_l, 1)] = SLOT;
                 finished++; st = LS_IDLE;
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
-                HotRec<ND> &H = hot[slot];
-                if (P.any_intersect) cold[slot].t_ach = t_ach;
+                HotRec<ND> &H = hot[SLOT];
+                if (P.any_intersect) cold[SLOT].t_ach = t_ach;
                 int state = TS_WALK;
-                if (st == LS_REABS) { state = TS_REEMIT; slot_brick[slot] = TILE_NEEDS_REEMIT; }
-                else if (st == LS_HIT) { state = TS_INTERACT; slot_brick[slot] = TILE_NEEDS_INTERACT; }
+                if (st == LS_REABS) { state = TS_REEMIT; slot_brick[SLOT] = TILE_NEEDS_REEMIT; }
+                else if (st == LS_HIT) { state = TS_INTERACT; slot_brick[SLOT] = TILE_NEEDS_INTERACT; }
                 else {
                     const int nb = st == LS_LEFT ? brick_of(T, cell.ic) * vs + tk.brick % vs : tk.brick;           // parked: same brick again
-                    if (st == LS_LEFT) slot_brick[slot] = nb;
+                    if (st == LS_LEFT) slot_brick[SLOT] = nb;
                     if (nb < PT_HIST) atomicAdd(&nb_cnt[nb], 1u); else atomicAdd(&counts[nb], 1u);
                 }
-                if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = slot;
+                if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? slot : SLOT;
                 // the 64-byte line a visit changes, as four 16-byte stores (r | r, tau_ach | ic, ow | countdown, blk_b, state, pad)
                 int ow = pack_ow(cell.ow);
                 if constexpr (GEOM == GEOM_SPH) ow |= cell.radial << 6;
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                 line[0] = make_double2(r[0], r[1]);
                 line[1] = make_double2(r[2], tau_ach);
                 ((int4 *)line)[2] = make_int4(cell.ic[0], cell.ic[1], cell.ic[2], ow);
-                ((int4 *)line)[3] = make_int4(g.countdown, (int)g.blk_b, state, 0);
+                ((int4 *)line)[3] = make_int4(g.countdown, (int)g.blk_b, state, (slot >> 30) & 1);
                 st = LS_IDLE;
             }
             if (park) break;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                 if (j >= tk.len) exhausted = true;
                 else {
                     slot = order[tk.start + j];
-                    const HotRec<ND> &H = hot[slot];
+                    const HotRec<ND> &H = hot[SLOT];
 #pragma unroll
                     for (int a = 0; a < 3; a++) { r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a]; }
                     const int ow = H.ow;
@@ -360,7 +361,8 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                     const unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-                    if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
+                    slot |= (H.pad & 1) << 30;
+                    if (P.any_intersect) { t_src = cold[SLOT].t_src; t_ach = cold[SLOT].t_ach; }
                     st = LS_WALK;
                 }
             }
@@ -461,5 +463,6 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
             if (val != 0.0) hyp_atomic_add_g(&sum[gid * ND + d], val);
         }
     }
+#undef SLOT
     block_tally_flush(P, ctl, red, cnt, finished);
 }
