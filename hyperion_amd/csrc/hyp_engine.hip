@@ -239,7 +239,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 400 000 packets in flight on Cartesian and Voronoi grids, 1 000 000 elsewhere (profiles/r04_tiled_log.md) */, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16, tile_prep_blocks = 1;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -599,14 +599,18 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
             // few packets left and no ids to hand out: finish them in one launch
             const uint64_t in_flight = n_local - h->h_ctl->n_finished;
-            const uint64_t drain_at = h->tile_drain >= 0 ? (uint64_t)h->tile_drain : (h->hp.grid_type == 1 || h->hp.grid_type == 3) ? 400000ull : 1000000ull;
+            const uint64_t drain_at = h->tile_drain >= 0 ? (uint64_t)h->tile_drain : 1000000ull;      // (flat between 4e5 and 1.5e6 since the drain takes its packets from one list, profiles/r04_tiled_log.md)
             if (!img && h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= drain_at) {      // (the drain kernel deposits: Lucy only)
                 for (int pool = 1; pool < n_pools; pool++) {
                     (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
                     (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
                 }
                 TileGeom T = T0; T.n_slots = T0.n_slots * n_pools;
-                const int grid_d = std::min((T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * 8);
+                // the slots that still hold a packet as one list (in the sort's order[] array: nobody sorts any more), then the drain
+                (void)hipMemsetAsync(&h->d_ctl->n_live, 0, 2 * sizeof(unsigned int), h->stream);
+                tile_live_kernel<<<(T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_order, h->d_ctl);
+                T.drain_list = h->d_order;
+                const int grid_d = (int)std::min<uint64_t>((in_flight + 255) / 256 + 1, (uint64_t)h->n_cu * 8);
                 K.drain[ri][mi]<<<grid_d, 256, lds_w, h->stream>>>(h->d_problem, T, h->d_ctl, h->d_hot, h->d_cold, h->d_slot_brick);
                 e = hipStreamSynchronize(h->stream);
                 if (e != hipSuccess) return h->set_error(std::string("tiled drain failed: ") + hipGetErrorString(e));

@@ -139,6 +139,7 @@ struct TileCtl {
     // slots that wait for an interaction / are free, listed by the walk of the previous generation (and by tile_interact for
     // the packets it ends): counters by generation parity, see tile_walk_publish_lists
     unsigned int n_gil[HYP_TILE_MAX_POOLS][2], n_gdl[HYP_TILE_MAX_POOLS][2];
+    unsigned int n_live, live_cursor;             // the drain: slots that still hold a packet (TileGeom::drain_list), and how many of them have been handed out
     unsigned long long dbg[40];                   // debug builds only
 };
 
@@ -152,6 +153,7 @@ struct TileGeom {
     int gen;                     // generation number (split schedule: which of the two extra lists is read)
     int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
     int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
+    const int *drain_list;       // tile_drain: the slots that still hold a packet (tile_live_kernel), TileCtl::n_live of them
     int presort;                 // 1: the walk writes slot | kind << 30 into the interaction lists (HotRec::pad; one species, Cartesian walk)
     int vsplit;                  // 2: every brick is two entries of the sort -- 2 b for packets that have not interacted yet, 2 b + 1 for the others
 };                               //    (spherical grids: waves of one kind, hyp_ptile.h); 0 / 1: one entry per brick
@@ -1011,54 +1013,60 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
-    __shared__ int list[HYP_PREP_CHUNK];
-    __shared__ int n_list;
-    const int n_chunks = (T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK;
-    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-        __syncthreads();
-        if (threadIdx.x == 0) n_list = 0;
-        __syncthreads();
-        for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
-            const int s = ch * HYP_PREP_CHUNK + k;
-            const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
-            if (sb >= 0 || sb == TILE_NEEDS_INTERACT || sb == TILE_NEEDS_REEMIT) list[atomicAdd(&n_list, 1)] = s;
-        }
-        __syncthreads();
-        const int nl = n_list;
-        for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
-            const int k = k0 + (int)threadIdx.x;
-            int st = ST_DONE, slot = 0;
-            Packet<ND, GEOM> p;
-            Rng g;
-            if (k < nl) {
-                slot = list[k];
-                const HotRec<ND> &H = hot[slot];
-                const ColdRec<ND> &C = cold[slot];
-#pragma unroll
-                for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
-                TileCellIO<GEOM>::load(P, H, p.cell);
-                p.a = C.a;
-                p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
-                p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
-#pragma unroll
-                for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
-                p.inter = C.inter;
-                const unsigned long long id = H.id;
-                g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
-                g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
-                p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
-                if (REABS) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }
-                st = H.state == TS_INTERACT ? ST_NEED_INTERACT : (REABS && H.state == TS_REEMIT) ? ST_NEED_REEMIT : ST_WALK;
-            } else {
-                rng_init(g, P.seed_key, T.iter_tag, 0);
-                p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
-                p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
-            }
+    // The slots that still hold a packet come as one list (tile_live_kernel); a lane takes the next entry as soon as its packet has
+    // ended (a wave refills when half of it is idle).  Round 3 gave every workgroup chunks of 2048 SLOTS to look through and ran the
+    // packets it found 256 at a time to the end of the longest one: 18 passes at 40 % of the lanes, 10.6 ms for the last 1e6 packets
+    // of configs[1] (profiles/r04_tiled_log.md).
+    const int *__restrict__ live = T.drain_list;
+    const unsigned int nl = ctl->n_live;
+    const unsigned long long lt = (1ull << __lane_id()) - 1ull;
+    int st = ST_DONE, slot = -1;
+    bool exhausted = false;
+    Packet<ND, GEOM> p;
+    Rng g;
+    rng_init(g, P.seed_key, T.iter_tag, 0);
+    p.inter = 1; p.tau_req = 0.0; p.tau_ach = 0.0;
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+    {
+        {
             for (;;) {
                 unsigned long long m_walk = __ballot(st == ST_WALK);
                 unsigned long long m_int = __ballot(st == ST_NEED_INTERACT);
                 unsigned long long m_re = REABS ? __ballot(st == ST_NEED_REEMIT) : 0ull;
-                if (!(m_walk | m_int | m_re)) break;
+                const unsigned long long m_done = __ballot(st == ST_DONE);
+                if (!exhausted && m_done && (__popcll(m_done) >= 32 || !(m_walk | m_int | m_re))) {
+                    if (st == ST_DONE && slot >= 0) { hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE; slot = -1; }
+                    const int want = __popcll(m_done);
+                    unsigned int base = 0;
+                    if (__lane_id() == 0) base = atomicAdd(&ctl->live_cursor, (unsigned int)want);
+                    base = __shfl(base, 0, 64);
+                    if (base + (unsigned int)want >= nl) exhausted = true;
+                    const unsigned int kq = base + (unsigned int)__popcll(m_done & lt);
+                    if (st == ST_DONE && kq < nl) {
+                        slot = live[kq];
+                        const HotRec<ND> &H = hot[slot];
+                        const ColdRec<ND> &C = cold[slot];
+#pragma unroll
+                        for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
+                        TileCellIO<GEOM>::load(P, H, p.cell);
+                        p.a = C.a;
+                        p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
+                        p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
+#pragma unroll
+                        for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
+                        p.inter = C.inter;
+                        const unsigned long long id = H.id;
+                        g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+                        g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
+                        p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+                        if (REABS) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }
+                        st = H.state == TS_INTERACT ? ST_NEED_INTERACT : (REABS && H.state == TS_REEMIT) ? ST_NEED_REEMIT : ST_WALK;
+                    }
+                    m_walk = __ballot(st == ST_WALK);
+                    m_int = __ballot(st == ST_NEED_INTERACT);
+                    m_re = REABS ? __ballot(st == ST_NEED_REEMIT) : 0ull;
+                }
+                if (!(m_walk | m_int | m_re)) { if (exhausted || nl == 0) break; else continue; }
                 if (REABS && m_re && (__popcll(m_re) >= 16 || !m_walk)) {      // iter_lucy.f90:155-185
                     if (st == ST_NEED_REEMIT) {
                         if ((long long)p.reabs == P.n_reabs_max) { cnt.killed_int++; st = ST_DONE; finished++; }
@@ -1106,7 +1114,7 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
                     }
                 }
             }
-            if (k < nl) { hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE; }
+            if (st == ST_DONE && slot >= 0) { hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE; }
         }
     }
     double c = wave_sum((double)cnt.crossings);
@@ -1121,6 +1129,24 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
         if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
         if (nf != 0.0) atomicAdd(&ctl->n_finished, (unsigned long long)nf);
     }
+}
+
+// the slots that still hold a packet, for tile_drain_kernel: 2048 slots per workgroup, one reservation in the list per workgroup
+static __global__ __launch_bounds__(256) void tile_live_kernel(TileGeom T, const int *__restrict__ slot_brick, int *__restrict__ live, TileCtl *__restrict__ ctl)
+{
+    __shared__ int list[HYP_PREP_CHUNK];
+    __shared__ int n_list, base;
+    if (threadIdx.x == 0) n_list = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
+        const int s = blockIdx.x * HYP_PREP_CHUNK + k;
+        const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
+        if (sb >= 0 || sb == TILE_NEEDS_INTERACT || sb == TILE_NEEDS_REEMIT) list[atomicAdd(&n_list, 1)] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base = n_list ? (int)atomicAdd(&ctl->n_live, (unsigned int)n_list) : 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_list; i += blockDim.x) live[base + i] = list[i];
 }
 
 // ---------------------------------------------------------------------------
