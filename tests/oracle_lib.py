@@ -16,6 +16,8 @@ _dp = C.POINTER(C.c_double)
 
 
 def build_oracle(force=False):
+    if os.environ.get("HYP_ORACLE_SO"):       # tools/mutation_check.py: a deliberately broken oracle, to show that a test has power
+        return os.environ["HYP_ORACLE_SO"]
     src = os.path.join(ORACLE_DIR, "hyp_oracle.c")
     hdr = os.path.join(ORACLE_DIR, "hyp_oracle.h")
     stale = (not os.path.exists(ORACLE_SO)
@@ -277,6 +279,22 @@ class Oracle:
         path = C.c_double()
         n = lib().orc_walk_ray(self.h, r0.ctypes.data_as(_dp), v.ctypes.data_as(_dp), C.byref(path))
         return n, path.value
+
+
+class SerialOracle(Oracle):
+    """One OpenMP thread per call: for ensembles of small runs spread over a thread pool (ctypes drops the GIL)."""
+
+    def lucy_iteration(self, n_packets, iteration, n_threads=1):
+        return Oracle.lucy_iteration(self, n_packets, iteration, n_threads=1)
+
+    def final_iteration(self, n_packets, n_threads=1):
+        return Oracle.final_iteration(self, n_packets, n_threads=1)
+
+    def raytracing_iteration(self, n_sources, n_dust, n_threads=1):
+        return Oracle.raytracing_iteration(self, n_sources, n_dust, n_threads=1)
+
+    def mono_iteration(self, n_sources, n_dust, n_threads=1):
+        return Oracle.mono_iteration(self, n_sources, n_dust, n_threads=1)
 
 
 def philox(ctr, key):

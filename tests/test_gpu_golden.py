@@ -36,7 +36,7 @@ def test_all_five_iterations_match_reference_golden(name):
     assert (gold * w).sum() == pytest.approx((big * w).sum(), rel=0.02)
 
 
-@pytest.mark.parametrize("tau", ["1000", "100000", "1000000"])
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
 def test_pinte_benchmark_run_matches_reference_golden(tau):
     """The whole run() sequence on the GPU for the reference's Pinte benchmark model (cylindrical polar grid,
     stellar sphere, polarising dust, Lucy iterations with the convergence test and the modified random walk,
@@ -46,7 +46,7 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
     gold = z["golden/seds"]
     K = 12
-    S, n_it, e_last, se_last = [], [], [], []
+    S, n_it, e_last, se_last, killed_int, killed_geo = [], [], [], [], [], []
     w = prob.density * prob.volumes
     for k in range(K):
         prob.config.seed = -(900 + k)
@@ -55,6 +55,7 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
         e_last.append((r.iterations[-1].specific_energy * w).sum())
         se_last.append(r.iterations[-1].specific_energy[0])
         assert r.final_stats["killed_geo"] == 0
+        killed_int.append([it.killed_int for it in r.iterations]); killed_geo.append(sum(it.killed_geo for it in r.iterations))
     # the golden ran all 10 iterations without converging (99th percentile rule at 5000 packets); so does the GPU
     assert int(z["golden/iterations"]) == 10 and not bool(z["golden/converged"])
     assert min(n_it) >= 9
@@ -81,15 +82,25 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     assert okc.sum() > 100
     assert abs(np.median(np.log10(gold_se[okc] / m[okc]))) < 0.05
     e_gold = (z["golden/specific_energy_last"] * w).sum()
-    if tau == "1000000":
-        # the mid-plane cells of the thickest disc hold almost all the mass and are reached by a handful of the 5000 packets:
-        # the absorbed luminosity of ONE iteration scatters by a factor of two between seeds, the golden is one such draw
-        # (12 GPU realisations: 7.0e35 .. 1.25e36 in one run of this test, the golden 4.63e35; the realisations themselves move
-        # from run to run -- summation order of the atomics feeds back through the temperatures -- hence the factor two)
-        assert min(e_last) / 2.0 < e_gold < max(e_last) * 2.0, (e_gold, sorted(e_last))
-    else:
-        # (the absorbed luminosity of a 5000-packet iteration of this model scatters by ~10 %: 5.8e33 .. 7.4e33 over seeds and iterations)
-        assert e_gold == pytest.approx(e_last[-1], rel=0.35)
+    # The absorbed luminosity of the LAST iteration against the K realisations, in log space (the total is a product of
+    # feedbacks through the temperatures of a few mid-plane cells and scatters log-normally: sigma = 0.02 dex at tau = 1e3,
+    # 0.10 dex at tau = 1e6).  |z| < 4.5.  Measured with the oracle over 32 realisations: z = +3.0 at tau = 1e3 (one packet's
+    # random walk through six adjacent inner mid-plane cells leaves 5-18 x their mean energy in the golden: +18 % on the
+    # total), +0.7, -0.5, and -3.0 at tau = 1e6 (the ten cells that hold two thirds of the total sit at ranks 0.0-0.67,
+    # mean 0.21, of the realisations' heavy-tailed distributions: sd / mean 0.4-1.4 per cell).  Two 3 sigma excursions of
+    # opposite sign, both in cells fed by rare long random walks: the largest standing excursions of the whole pin, not
+    # understood beyond that; the killed-packet counts of the same runs (below) agree to a few per cent.  This replaces the
+    # round-4 bracket min / 2 < golden < 2 max.
+    le = np.log10(np.array(e_last))
+    z_tot = (np.log10(e_gold) - le.mean()) / (le.std(ddof=1) * np.sqrt(1.0 + 1.0 / K))
+    assert abs(z_tot) < 4.5, (e_gold, sorted(e_last), z_tot)
+    # killed_photons_int of the ten Lucy iterations (tests/golden/killed_counts.json): the reference's own counters
+    from test_oracle_golden import check_killed_counts, killed_counts
+    gk = killed_counts("test_pinte_seds.tau=%s" % tau)
+    assert [g[0] for g in gk["iterations"]] == [0] * 10 and all(k_geo == 0 for k_geo in killed_geo)
+    n_common = min(len(k) for k in killed_int)          # (a realisation may meet the convergence rule after nine iterations)
+    assert n_common >= 9
+    check_killed_counts([g[1] for g in gk["iterations"]][:n_common], [k[:n_common] for k in killed_int], ("gpu", tau))
 
 
 class _EngineRunner:
@@ -112,6 +123,29 @@ def test_pooled_bias_over_all_specific_energy_goldens():
     assert abs(mean - 1.0) < 0.01, (mean, per)
     for grid, r in per.items():
         assert abs(r - 1.0) < 0.025, (grid, r, per)
+
+
+@pytest.mark.parametrize("ray", [False, True])
+@pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
+@pytest.mark.parametrize("evenly", [False, True])
+def test_peeloff_goldens_pixel_by_pixel_and_polarisation_amplitude(grid, evenly, ray):
+    """The reference's twenty peel-off goldens against realisations of the HIP engine at their own packet numbers: image
+    geometry pixel by pixel with the mirror-image rejection, and the amplitude of the polarised signal -- the same checks,
+    with the same bounds, that tests/test_oracle_golden.py applies to the oracle."""
+    from golden_stats import peeloff_golden_stats
+    from test_oracle_golden import check_image_geometry, check_polarisation_amplitude
+    S = peeloff_golden_stats(hyperion_amd.Engine, grid, evenly, ray)
+    assert S["killed"] == 0
+    check_image_geometry(S, ("gpu", grid, evenly, ray))
+    check_polarisation_amplitude(S, ("gpu", grid, evenly, ray))
+
+
+def test_pooled_polarisation_amplitude_and_flux_over_all_peeloff_goldens():
+    """Polarisation amplitude (1 = the reference's), total / direct / scattered / thermal flux ratios pooled over the twenty
+    goldens, HIP engine: bounds of test_oracle_golden.check_pooled_peeloff_statistics."""
+    from golden_stats import pooled_peeloff_statistics
+    from test_oracle_golden import check_pooled_peeloff_statistics
+    check_pooled_peeloff_statistics(pooled_peeloff_statistics(hyperion_amd.Engine))
 
 
 @pytest.mark.parametrize("tau", [1000, 1000000])

@@ -9,14 +9,18 @@ realisation (K independent seeds).  z = (golden - mean) / sigma must look like a
 unit normal.  This is the bar the reference itself uses when streams differ
 (hyperion/model/tests/test_specific_energy_spectrum.py:372-392: rtol 2e-2 on the
 conserved total)."""
+import os
+
 import numpy as np
 import pytest
 
 from cases import golden_problem
-from oracle_lib import Oracle
+from oracle_lib import Oracle, SerialOracle
 
 K = 12
 N_BIG = 600000
+# ensembles of small runs: one single-threaded oracle per pool thread instead of eight OpenMP threads on a thousand packets
+POOL = {"make_serial": SerialOracle, "workers": len(os.sched_getaffinity(0))}
 
 
 def _oracle_stats(prob, iteration_state=None, k=K):
@@ -101,19 +105,38 @@ def test_converged_iterations_match_reference_golden():
 
 
 def _peeloff_run(prob, seed, n_lucy, n_img):
-    from hyperion_amd.images import finalize_peeled
-    prob.config.seed = seed
-    o = Oracle(prob)
-    for it in range(1, prob.config.n_initial_iter + 1):
-        o.lucy_iteration(n_lucy, it)
-    res, st = o.final_iteration(n_img)
-    if prob.config.raytracing:
-        # main.f90:296-303: the raytracing iteration adds direct and thermal emission to the cubes
-        scale = n_img / 5000.0
-        res, st2 = o.raytracing_iteration(int(prob.config.n_ray_photons_sources * scale), int(prob.config.n_ray_photons_dust * scale))
-        st["killed_geo"] += st2["killed_geo"]
-    o.close()
-    return [finalize_peeled(p, r) for p, r in zip(prob.peeled, res)], st
+    from golden_stats import peeloff_run
+    return peeloff_run(Oracle, prob, seed, n_lucy, n_img)
+
+
+def check_image_geometry(S, label=""):
+    """Pixel-level pin of the image axes (src/images/images_peeled.f90:209-211) and of the pixel index (image_type.f90:364-365) on
+    the goldens' 5 x 4 (two views) and 6 x 6 images of five off-centre point sources: the direct light of a source lands in a pixel
+    that does not depend on the random numbers.  Per pixel (Stokes I summed over wavelengths and origins): z-scores against the
+    runner's realisations at the golden's packet numbers -- the normal-tail bound on pixels whose realisations scatter by less than
+    30 %, a bound from below on the rest (a few scattered packets: skewed, never far below the mean); the golden correlates with the
+    expected image and not with its mirror images; and the same z-test against a MIRRORED expectation fails (a pixel beyond 8 sigma against the 6 accepted above, or a mean z^2 above 8 against 4), which
+    is what shows that this test would notice a flipped axis."""
+    zs = []
+    for g in (0, 1):        # group 3 images the packets of group 2 again
+        G = S["groups"][g]
+        gold, mean, sd = G["pixel_gold"], G["pixel_mean"], G["pixel_sd"]
+        ok = (sd > 0) & (mean > 0)
+        z = (gold - mean)[ok] / sd[ok]
+        well = (sd < 0.3 * mean)[ok]
+        assert well.sum() >= 7, (label, g, well.sum())
+        assert np.abs(z[well]).max() < 6.0 and (z[well] ** 2).mean() < 4.0, (label, g, z[well])
+        assert z[~well].min() > -6.0 and (z[~well] > 8.0).mean() < 0.1, (label, g, z[~well])
+        zs.append(z[well])
+        for v in range(gold.shape[0]):
+            assert G["corr"][v] > 0.9, (label, g, v, G["corr"])
+            assert max(G["corr_mirror_x"][v], G["corr_mirror_y"][v]) < 0.7, (label, g, v, G["corr_mirror_x"], G["corr_mirror_y"])
+            for flip in ((slice(None), slice(None, None, -1)), (slice(None, None, -1), slice(None))):
+                m, s_ = mean[v][flip], sd[v][flip]
+                w = (s_ > 0) & (s_ < 0.3 * m)
+                zf = (gold[v] - m)[w] / s_[w]
+                assert np.abs(zf).max() > 8.0 or (zf ** 2).mean() > 8.0, (label, g, v, "a mirrored expectation would have passed", zf)
+    return np.concatenate(zs)
 
 
 @pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
@@ -122,13 +145,14 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
     """test_peeloff.grid_type=car.raytracing=False.*.rtout (test_bit_level.py:175-236):
     3 image groups (no / basic / detailed origin tracking, Stokes on), 5x1e3 Lucy
     + 5e3 imaging packets.  Stokes I per (view, wavelength) bin of the largest
-    aperture and summed images within the Monte Carlo noise; the signs of Q and U
-    (which pin the scattering-geometry orientation) by a two-hypothesis chi^2."""
-    prob, z = golden_problem("%s_peeloff.%s.npz" % (grid, evenly))
-    big, st = _peeloff_run(prob, -5, 100000, 600000)
-    assert st["killed_geo"] == 0 and st["killed_int"] == 0
-    K = 40      # sigma of temperature-sensitive far-IR bins needs a decent sample
-    samples = [_peeloff_run(prob, -(100 + k), 1000, 5000)[0] for k in range(K)]
+    aperture and summed images within the Monte Carlo noise; the images pixel by pixel
+    (check_image_geometry); the signs of Q and U (which pin the scattering-geometry
+    orientation) by a two-hypothesis chi^2, and their AMPLITUDE by the matched filter
+    of golden_stats.py against the spread of the same estimator over the realisations."""
+    from golden_stats import peeloff_golden_stats
+    S = peeloff_golden_stats(Oracle, grid, evenly, False, **POOL)
+    z, big, samples = S["golden"], S["big"], S["samples"]
+    assert S["killed"] == 0
     chi_plus = {1: 0.0, 2: 0.0}
     chi_minus = {1: 0.0, 2: 0.0}
     for g in range(3):
@@ -158,7 +182,7 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
         # Stokes V is identically zero for this dust (P4 = 0)
         assert np.all(gold[3] == 0) and np.all(b[3] == 0)
     if grid in ("sph", "cyl"):
-        # these grids reach out to 2-3 u: the packets scatter less, the polarised signal is a few
+        # these grids reach out to 2-3 u: the packets scatter less, the polarised signal of the SEDs is a few
         # sigma in total and cannot separate the two orientations (the Cartesian, octree and AMR
         # goldens do, and the scattering code is shared); the golden must be consistent with the oracle
         assert chi_plus[1] + chi_plus[2] < chi_minus[1] + chi_minus[2] + 5.0, (chi_plus, chi_minus)
@@ -167,6 +191,21 @@ def test_peeloff_seds_and_images_match_reference_golden(grid, evenly):
             assert chi_plus[ist] < chi_minus[ist] - 10.0, (ist, chi_plus, chi_minus)
     # golden uncertainty cubes exist only if requested
     assert "golden/group1/seds_unc" not in z.files
+    check_image_geometry(S, (grid, evenly))
+    check_polarisation_amplitude(S, (grid, evenly))
+
+
+def check_polarisation_amplitude(S, label=""):
+    """Amplitude of the golden's Q and U images on the expected pattern (1 = the reference's polarisation degree; the images
+    resolve the centro-symmetric pattern that cancels in the aperture sums): within 4 sigma of what the realisations give, sigma
+    being the spread of the same estimator over them -- and that spread small enough for a halved or doubled (or sign-flipped)
+    degree to fail: 1 - 4 sigma > 0.5 is not asked of a single golden of the polar grids (fewer scatterings), the pooled test has it."""
+    a, ak = S["amp_gold"], S["amp_samples"]
+    sd = ak.std(ddof=1)
+    assert 0.85 < ak.mean() < 1.1, (label, ak.mean())
+    assert abs(a - ak.mean()) < 4.0 * sd, (label, a, ak.mean(), sd)
+    assert sd < 0.25, (label, sd)
+    assert a > 0.5 * ak.mean(), (label, a)          # the sign, and more than half the amplitude, golden by golden
 
 
 @pytest.mark.parametrize("grid", ["car", "oct", "amr", "sph", "cyl"])
@@ -176,13 +215,13 @@ def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
     set_raytracing(True), 2000 source + 3000 dust rays): the final iteration peels only scattered
     packets and do_raytracing (iter_raytracing.f90) adds the direct and the thermal emission with
     the emitters' whole binned spectra.  Stokes I per (view, wavelength) bin of the largest
-    aperture within the Monte Carlo noise of the golden's photon numbers; totals within 5 %."""
-    prob, z = golden_problem("%s_peeloff_ray.%s.npz" % (grid, evenly))
+    aperture within the Monte Carlo noise of the golden's photon numbers; totals within 5 %;
+    images pixel by pixel and the polarisation amplitude as in the test above."""
+    from golden_stats import peeloff_golden_stats
+    S = peeloff_golden_stats(Oracle, grid, evenly, True, **POOL)
+    prob, z, samples, K = S["problem"], S["golden"], S["samples"], S["k"]
     assert prob.config.raytracing and prob.config.n_ray_photons_sources == 2000 and prob.config.n_ray_photons_dust == 3000
-    K = 20
-    runs = [_peeloff_run(prob, -(100 + k), 1000, 5000) for k in range(K)]
-    samples = [r[0] for r in runs]
-    assert all(r[1]["killed_geo"] == 0 and r[1]["killed_int"] == 0 for r in runs)
+    assert S["killed"] == 0
     # The thermal emission depends non-linearly on temperatures that come from 5 x 1000 Lucy
     # packets, so the expectation is taken over realisations with the golden's own photon
     # numbers (not from one large run): z = (golden - ensemble mean) / (sigma sqrt(1 + 1/K)).
@@ -203,6 +242,39 @@ def test_raytracing_seds_and_images_match_reference_golden(grid, evenly):
         assert abs(gi.sum() - itot.mean()) < 4.0 * itot.std(ddof=1)
         # raytraced flux is unpolarised: Q, U, V of the golden come from the scattered packets only
         assert np.all(gold[3] == 0)
+    check_image_geometry(S, (grid, evenly, "raytracing"))
+    check_polarisation_amplitude(S, (grid, evenly, "raytracing"))
+
+
+def check_pooled_peeloff_statistics(P):
+    """Bounds on golden_stats.pooled_peeloff_statistics over all 20 peel-off goldens (5 grids x sources sampled evenly or not x
+    raytracing off / on) -- shared by the oracle's test here and the HIP engine's in tests/test_gpu_golden.py.
+
+    Polarisation amplitude: the pooled standard error is 0.02 if the 20 goldens are independent; the raytracing-on and -off runs
+    of one model start from the same seed in the reference and may share scattered packets, so the bound takes it as 0.03:
+    |a - 1| < 0.08, which a polarisation degree wrong by 10 % fails.
+
+    Flux: golden / expected of the SED and image totals (pooled standard error 0.6 %, bound 2 %), and by origin class from the
+    group with 'basic' tracking, each class having its own peel-off weight (images_peeled.f90:218-254): light straight from a
+    source (0.6 %, bound 2 %: a 3 % error in that weight fails), scattered light (1.4 %, bound 4 %: the goldens cannot resolve
+    less -- the noise is the golden's own 5000 packets), thermal emission of the dust (1.6 %, bound 6 %; the oracle measures
+    0.967 +- 0.016 there, its largest excursion, with the oct / evenly golden alone 3.2 sigma low as noted above)."""
+    a, a_se = P["amp"]
+    assert a_se < 0.03, P["amp"]
+    assert abs(a - 1.0) < 0.08, (P["amp"], P["per"])
+    for name, se_max, bound in (("sed", 0.01, 0.02), ("image", 0.01, 0.02), ("sed_source", 0.01, 0.02),
+                                ("sed_scattered", 0.02, 0.04), ("sed_dust", 0.025, 0.06)):
+        r, se = P[name][:2]
+        assert se < se_max, (name, P[name])
+        assert abs(r - 1.0) < bound, (name, P[name], P["per"])
+    assert P["sed_source"][2] == P["sed_scattered"][2] == P["sed_dust"][2] == 20
+
+
+def test_pooled_polarisation_amplitude_and_flux_over_all_peeloff_goldens():
+    """what no single 5000-packet golden can show.  (Reuses the ensembles of the twenty tests above
+    when they ran in this process.)"""
+    from golden_stats import pooled_peeloff_statistics
+    check_pooled_peeloff_statistics(pooled_peeloff_statistics(Oracle, **POOL))
 
 
 def _pascucci_run(prob, seed, scale=1):
@@ -382,3 +454,68 @@ def test_pooled_bias_over_all_specific_energy_goldens():
     assert abs(mean - 1.0) < 0.01, (mean, per)
     for grid, r in per.items():
         assert abs(r - 1.0) < 0.025, (grid, r, per)
+
+
+def killed_counts(name):
+    """Killed-packet counters of one reference golden (tests/golden/killed_counts.json, written by make_killed_fixture.py from
+    the .rtout attributes): {"iterations": [[geo, int], ...], "final": [geo, int], "raytracing": [geo, int]}."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "killed_counts.json")) as f:
+        return json.load(f)[name]
+
+
+def check_killed_counts(gold_int, counts, label=""):
+    """gold_int[i]: the reference's killed_photons_int of iteration i; counts[k][i]: the same of K realisations.  The count of an
+    iteration is a sum of independent packets (Poisson) on top of a temperature state that varies between realisations, so its
+    variance is taken as the larger of the ensemble's and the Poisson one.  Iterations where nothing is ever killed must have
+    none in the golden; per iteration |z| < 4.5; over all iterations of the run the totals agree within 4 sigma -- for the
+    Pinte SED models that is 300-400 killed packets, a pin to ~7 % of the rate at which packets run into n_inter_max / the cap
+    on modified-random-walk steps (iter_lucy.f90:133-152,186-190)."""
+    g, c = np.asarray(gold_int, dtype=float), np.asarray(counts, dtype=float)
+    assert c.shape[1] == g.size, (label, c.shape, g.size)
+    K = c.shape[0]
+    m, var = c.mean(axis=0), np.maximum(c.var(axis=0, ddof=1), c.mean(axis=0))
+    never = c.max(axis=0) == 0
+    assert np.all(g[never & (np.arange(g.size) == 0)] == 0), (label, g)      # the first iteration has no random walk to run out of steps
+    z = (g - m)[~never] / np.sqrt(var[~never] * (1.0 + 1.0 / K) + 1.0)
+    assert np.all(np.abs(z) < 4.5), (label, g, m, z)
+    tot_sd = np.sqrt(max(c.sum(axis=1).var(ddof=1), m.sum()) * (1.0 + 1.0 / K) + 1.0)
+    assert abs(g.sum() - m.sum()) < 4.0 * tot_sd, (label, g.sum(), m.sum(), tot_sd)
+    return (g.sum() - m.sum()) / tot_sd
+
+
+@pytest.mark.parametrize("model", ["pinte_seds", "pinte_images", "pinte_specific_energy"])
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
+def test_killed_packet_counts_match_reference_goldens(model, tau):
+    """killed_photons_int of every Lucy iteration of the reference's Pinte benchmark runs (modified random walk with at most 1000
+    steps, at most 1000 interactions; with the PDA for the specific-energy models): 0 / 22 / 33 / 38 / ... packets of 5000 at
+    tau = 1e6, up to 478 of 50 000.  Reference-produced numbers that depend on the whole thick-disc path -- MRW entry test,
+    step length, re-emission, the two caps -- and on nothing else; no test used them before round 5."""
+    gold = killed_counts("test_%s.tau=%s" % (model, tau))
+    prob, _ = golden_problem("%s.tau=%s.npz" % (model, tau))
+    n_iter, n_ph = len(gold["iterations"]), prob.config.n_initial_photons
+    assert all(g[0] == 0 for g in gold["iterations"]) and gold["final"] == [0, 0] and gold["raytracing"] == [0, 0]
+
+    def run(seed):
+        o = SerialOracle(_with_seed(prob, seed))
+        k = []
+        for it in range(1, n_iter + 1):
+            _, st = o.lucy_iteration(n_ph, it)
+            assert st["killed_geo"] == 0
+            k.append(st["killed_int"])
+        o.close()
+        return k
+    from golden_stats import _with_seed, ensemble
+    counts = ensemble(run, [-(1200 + k) for k in range(16)], POOL["workers"])
+    check_killed_counts([g[1] for g in gold["iterations"]], counts, (model, tau))
+
+
+def test_no_other_reference_golden_kills_a_packet():
+    """The other 44 goldens (all grids, peel-off, raytracing, Pascucci; pinte_images at tau = 1000) report zero killed packets in
+    every iteration; the tests above assert the same of the oracle run by run (`killed` == 0)."""
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "killed_counts.json")) as f:
+        allk = json.load(f)
+    assert len(allk) == 56
+    quiet = [k for k, v in allk.items() if not any(a or b for a, b in v["iterations"])]
+    assert len(quiet) == 45 and all(v.get("final", [0, 0]) == [0, 0] and v.get("raytracing", [0, 0]) == [0, 0] for v in allk.values())

@@ -149,6 +149,72 @@ def test_scattering_angles_and_stokes():
     assert abs(np.mean(q)) < 0.2
 
 
+def _table_P(d, inu, mu):
+    """P1..P3 of the scattering table at a tabulated frequency, linear in mu (interp2d, dust_type_4elem.f90:543-546)."""
+    return [np.interp(mu, d.mu, P[inu]) for P in (d.P1, d.P2, d.P3)]
+
+
+def test_polarisation_degree_of_one_scattering_known_answer():
+    """The AMPLITUDE of scatter_stokes (src/dust/dust_type_4elem.f90:603-690) against closed forms that follow from its
+    Mueller matrix R = [[P1 P2 0 0] [P2 P1 0 0] [0 0 P3 -P4] [0 0 P4 P3]] between two rotations (which preserve Q^2 + U^2),
+    on the reference's kmh dust (P2 != 0), packet by packet, no statistics:
+
+      * unpolarised light: degree of polarisation = |P2 / P1| at the sampled angle, whatever the directions;
+      * ... travelling along +z: the scattering plane is the new meridian plane, so Q = P2 / P1 with its sign and U = 0;
+      * light polarised (1, q, 0, 0): Q'^2 + U'^2 = ((P2 + P1 q c)^2 + (P3 q s)^2) / (P1 + P2 q c)^2 with c, s = cos, sin of
+        twice the azimuth of the scattering plane about the old direction, measured from its meridian plane -- which is
+        read off the two directions, not from the code under test;
+      * the sample mean of Q / I over unpolarised scatterings = int P2 dmu / int P1 dmu (mu is drawn from P1)."""
+    prob, _ = golden_problem("car_specific_energy.False.False.npz")
+    o = Oracle(prob)
+    d = prob.dust[0]
+    inu = 60
+    nu = float(d.nu[inu])
+    assert np.abs(d.P2[inu]).max() > 0.1 * d.P1[inu].mean()       # a polarising table
+
+    def vec(a):
+        return np.array([a[1] * a[2], a[1] * a[3], a[0]])
+
+    # (1) unpolarised, generic direction; (2) along +z
+    th, ph = 2.1, 4.0
+    a_gen = [np.cos(th), np.sin(th), np.cos(ph), np.sin(ph)]
+    a_z = [1.0, 0.0, 1.0, 0.0]
+    qs = []
+    for pid in range(3000):
+        ao, so = _scatter(o, nu, a_gen, [1.0, 0.0, 0.0, 0.0], pid)
+        mu = float(vec(a_gen) @ vec(ao))
+        P1, P2, P3 = _table_P(d, inu, mu)
+        assert np.hypot(so[1], so[2]) == pytest.approx(abs(P2 / P1), rel=1e-6, abs=1e-9)
+        assert so[3] == 0.0
+        ao, so = _scatter(o, nu, a_z, [1.0, 0.0, 0.0, 0.0], pid)
+        P1, P2, P3 = _table_P(d, inu, float(ao[0]))
+        assert so[1] == pytest.approx(P2 / P1, rel=1e-6, abs=1e-9) and abs(so[2]) < 1e-9
+        qs.append(so[1])
+    expected = np.trapezoid(d.P2[inu], d.mu) / np.trapezoid(d.P1[inu], d.mu)
+    assert abs(expected) > 0.05
+    assert np.mean(qs) == pytest.approx(expected, abs=4.0 * np.std(qs) / np.sqrt(len(qs)))
+    assert np.mean(qs) == pytest.approx(expected, rel=0.1)
+    # (3) polarised input
+    q_in = 0.6
+    v0 = vec(a_gen)
+    e_theta = np.array([np.cos(th) * np.cos(ph), np.cos(th) * np.sin(ph), -np.sin(th)])
+    for pid in range(3000):
+        ao, so = _scatter(o, nu, a_gen, [1.0, q_in, 0.0, 0.0], pid)
+        v1 = vec(ao)
+        mu = float(v0 @ v1)
+        t = v1 - mu * v0
+        if t @ t < 1e-12:
+            continue
+        t /= np.sqrt(t @ t)
+        cos_c = -(t @ e_theta)                  # angle at the old direction between the arcs to the pole and to the new direction
+        c2, s2sq = 2.0 * cos_c ** 2 - 1.0, 1.0 - (2.0 * cos_c ** 2 - 1.0) ** 2
+        P1, P2, P3 = _table_P(d, inu, mu)
+        want = ((P2 + P1 * q_in * c2) ** 2 + P3 ** 2 * q_in ** 2 * s2sq) / (P1 + P2 * q_in * c2) ** 2
+        assert so[0] == 1.0
+        assert so[1] ** 2 + so[2] ** 2 == pytest.approx(want, rel=1e-6, abs=1e-12)
+    o.close()
+
+
 def test_isotropic_dust_scatters_isotropically():
     p = make_benchmark_problem(4)
     o = Oracle(p)
