@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# The CPU baseline's OpenMP threads: one per physical core, spread over the sockets and pinned (read by libgomp when it is loaded, so
+# set before anything imports it).  The GPU path does not use host threads.
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -69,30 +74,59 @@ def traffic_fields(pmc):
     return out
 
 
+def physical_cores():
+    """Distinct (socket, core) pairs of /proc/cpuinfo that this process may run on; half the logical CPUs if that cannot be read."""
+    allowed = os.sched_getaffinity(0)
+    try:
+        seen, cpu, phys = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for l in f:
+                if l.startswith("processor"):
+                    cpu, phys = int(l.split(":")[1]), None
+                elif l.startswith("physical id"):
+                    phys = int(l.split(":")[1])
+                elif l.startswith("core id") and cpu in allowed:
+                    seen.add((phys, int(l.split(":")[1])))
+        if seen:
+            return len(seen)
+    except (OSError, ValueError):
+        pass
+    return max(1, len(allowed) // 2)
+
+
 def cpu_baseline(prob, n_sample):
-    """Oracle (CPU restatement) timed on this host's cores on a bounded sample
-    of the same workload, on all the threads it can use and on ONE core.  Test
+    """Oracle (CPU restatement) timed on this host's cores on a bounded sample of the same workload: on every physical core
+    (the reported value), on 64 threads (what round 4 reported) and on ONE core, threads pinned one per core and spread over
+    the sockets (OMP_PROC_BIND=spread, OMP_PLACES=cores), per-thread accumulators first touched by their own thread.  Test
     infrastructure used as the reported baseline, never as the product."""
     from oracle_lib import Oracle
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)         # per-thread accumulators: 64 x 16 MiB at 128^3
+    logical = os.cpu_count() or 1
+    cores = physical_cores()
     orc = Oracle(prob)
-    orc.lucy_iteration(min(n_sample, 20000), 1, n_threads=threads)   # warm-up (page faults, thread pool)
-    t0 = time.time()
-    _, st = orc.lucy_iteration(n_sample, 1, n_threads=threads)
-    dt = time.time() - t0
-    n_one = max(min(n_sample // 80, 250000), 1000)
-    t1 = time.time()
-    _, s1 = orc.lucy_iteration(n_one, 1, n_threads=1)
-    d1 = time.time() - t1
+
+    def timed(n, threads):
+        orc.lucy_iteration(min(n, 2000 * threads), 1, n_threads=threads)   # warm-up (page faults of the accumulators, thread pool)
+        t0 = time.time()
+        _, st = orc.lucy_iteration(n, 1, n_threads=threads)
+        dt = time.time() - t0
+        return {"value": n / dt, "unit": "packets/s", "cores": threads, "crossings_per_s": st["crossings"] / dt,
+                "sample": "%d packets of the same workload, 1 Lucy iteration, %d OpenMP thread(s) (%.1f s)" % (n, threads, dt)}
+    one = timed(max(min(n_sample // 80, 250000), 1000), 1)
+    # (the sample scales with the threads so that each leg stays near ten seconds whatever the host)
+    per_thread = max(min(n_sample // 64, 400000), 2000)
+    allc = timed(min(n_sample, per_thread * cores), cores)
+    legs = {"1": one, str(cores): allc}
+    if cores > 64:
+        legs["64"] = timed(min(n_sample, per_thread * 64), 64)
     orc.close()
-    return {"value": n_sample / dt, "unit": "packets/s", "cores": threads, "kind": "port", "host_cpu": host_cpu(), "host_logical_cpus": cores,
-            "sample": "%d packets of the same 128^3 workload, 1 Lucy iteration, %d OpenMP threads (%.1f s)" % (n_sample, threads, dt),
-            "crossings_per_s": st["crossings"] / dt,
-            "one_core": {"value": n_one / d1, "unit": "packets/s", "cores": 1, "crossings_per_s": s1["crossings"] / d1,
-                         "sample": "%d packets of the same workload on one thread (%.1f s)" % (n_one, d1)},
-            "note": "the CPU restatement (oracle/hyp_oracle.c), not the Fortran: the reference needs its absent fortranlib submodule to build "
-                    "(DESIGN.md section 6 has the survey's probe of the reference's own geometry loop for calibration)"}
+    out = dict(allc)
+    out.update({"kind": "port", "host_cpu": host_cpu(), "host_logical_cpus": logical, "host_physical_cores": cores,
+                "one_core": one, "threads": legs, "scaling_over_one_core": allc["value"] / one["value"],
+                "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
+                "note": "the CPU restatement (oracle/hyp_oracle.c), not the Fortran: the reference needs its absent fortranlib submodule to build "
+                        "(DESIGN.md section 6 has the survey's probe of the reference's own geometry loop for calibration); every thread deposits "
+                        "into its own 16 MiB accumulator copy, reduced in parallel at the end"})
+    return out
 
 
 def extras(n, passes=3):

@@ -469,6 +469,20 @@ void polar_tile_shape(const DProblem &P, int nd, int lds_kb, int &x, int &y, int
     while ((long long)y * z * 16 > cells && y > 1) y = (y + 1) / 2;
     while ((long long)y * z * 16 > cells && z > 1) z = (z + 1) / 2;
     x = (int)std::max<long long>(1, std::min<long long>(P.n1, cells / ((long long)y * z)));
+    // the FP32 wall tables of the brick (tile_walk_lds) come out of the same budget
+    const long long budget = (long long)lds_kb * 1024 - 4ll * (2 * y + 8);
+    x = (int)std::max<long long>(1, std::min<long long>(x, budget / (16ll * nd * y * z + 4)));
+}
+
+// Number of bricks of a polar grid on the tiled schedule, or -1 when the grid has no such schedule: more bricks than the sort's
+// tables hold (HYP_TILE_MAX_BRICKS), or a brick beyond the LDS of a CU (pt_lds_kb is an option; 160 KB per CU on gfx950)
+long long polar_tile_bricks(const DProblem &P, int nd, int lds_kb)
+{
+    int bx, by, bz;
+    polar_tile_shape(P, nd, lds_kb, bx, by, bz);
+    const long long nb = (long long)((P.n1 + bx - 1) / bx) * ((P.n2 + by - 1) / by) * ((P.n3 + bz - 1) / bz);
+    const size_t lds = sizeof(double) * 2 * (size_t)bx * by * bz * nd + sizeof(float) * (size_t)(bx + 2 * by + 8);
+    return (nb <= HYP_TILE_MAX_BRICKS && lds <= 160u * 1024u) ? nb : -1;
 }
 
 // LDS of one AMR brick (hyp_atile.h): n cells, g goto entries (16 bits), w walls
@@ -523,6 +537,14 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
     // packet-id dispenser, the finished counter and the (atomic) accumulators.
     const size_t tasks_cap = (size_t)T0.n_slots / 256 + HYP_TILE_MAX_BRICKS + 2;
     int gen = 0, next_check = h->tile_poll;
+    // Every packet in a slot makes one interaction per generation and is killed at n_inter_max of them (iter_lucy.f90:186-190,
+    // iter_final.f90:255-259), and a slot takes a new id when its packet has ended: the generations are bounded by the interactions
+    // of the packets that pass through one slot.  A sanity bound, not a schedule: a run that needs 1e6 generations is slow here
+    // (launch-bound generations for a handful of packets; the Lucy iteration drains them in one kernel, the imaging iteration
+    // has no such kernel) but it ends with the reference's result, not with an error.
+    const long long per_slot = (long long)(n_local / ((uint64_t)T0.n_slots * (uint64_t)n_pools)) + 2;
+    const long long max_gen_ll = std::max<long long>(200000, ((long long)h->cfg.n_inter_max + 2) * per_slot + 16);
+    const int max_gen = (int)std::min<long long>(max_gen_ll, 2000000000ll);
     size_t n_timed = 0;
     // imaging: every generation can add at most one event per slot (plus the padding of the interaction chunks)
     const unsigned long long ev_per_gen = (unsigned long long)n_pools * ((unsigned long long)T0.n_slots + 64ull * (unsigned long long)grid_i);
@@ -575,7 +597,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             walk_k<<<grid_w, K.walk_threads, lds_walk, st>>>(h->d_problem, T, h->d_ctl, hot, cold, order, tasks, slot_brick, ilist, dlist, tcount, counts_next);
             if (timed) { (void)hipEventRecord(h->walk_events[n_timed + 1], st); n_timed += 2; }
         }
-        if (gen + 1 >= next_check || gen > 200000) {
+        if (gen + 1 >= next_check || gen > max_gen) {
             next_check = gen + 1 + h->tile_poll;
             hipError_t e = hipMemcpyAsync(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -596,7 +618,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 next_check = gen + 1 + (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)h->tile_poll, room));
             }
             if (h->h_ctl->n_finished >= n_local) break;
-            if (gen > 200000) return h->set_error("tiled Lucy iteration did not terminate");
+            if (gen > max_gen) return h->set_error(img ? "tiled imaging iteration did not terminate" : "tiled Lucy iteration did not terminate");
             // few packets left and no ids to hand out: finish them in one launch
             const uint64_t in_flight = n_local - h->h_ctl->n_finished;
             const uint64_t drain_at = h->tile_drain >= 0 ? (uint64_t)h->tile_drain : 1000000ull;      // (flat between 4e5 and 1.5e6 since the drain takes its packets from one list, profiles/r04_tiled_log.md)
@@ -696,6 +718,8 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         T.n_bricks = T.nbx * T.nby * T.nbz;
         T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     }
+    // the sort's tables (d_counts / d_cursor / d_offsets, tile_sort_kernel's LDS) hold HYP_TILE_MAX_BRICKS entries per pool
+    if (T.n_bricks < 1 || T.n_bricks > HYP_TILE_MAX_BRICKS) return h->set_error("grid has too many bricks for the tiled schedule");
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
     const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
     long long slots = std::min<long long>(want_slots, (long long)n_local);
@@ -2739,10 +2763,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     }
     else if (P.grid_type == 5 || P.grid_type == 6) {
         // spherical / cylindrical polar grids: index bricks in LDS (hyp_ptile.h)
-        int bx, by, bz;
-        polar_tile_shape(P, h->n_dust, h->pt_lds_kb, bx, by, bz);
-        const long long nb = (long long)((P.n1 + bx - 1) / bx) * ((P.n2 + by - 1) / by) * ((P.n3 + bz - 1) / bz);
-        tile_ok = h->n_dust <= 4 && nb <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
+        tile_ok = h->n_dust <= 4 && polar_tile_bricks(P, h->n_dust, h->pt_lds_kb) > 0 && !h->count_photons && !h->n_bins;
         tile_auto = tile_ok && h->n_cells >= 4096 && n_local >= 3000000ull;      // (400 x 200: 91 against 81 ms at 2e6 packets, 140 against 150 at 4e6)
     }
     else if (P.grid_type == 4) {
@@ -3240,6 +3261,7 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
     const TileKernels K = pick_tile_kernels(h->n_dust, P.grid_type);
     if (!K.walk || !K.interact_img || !K.emit_img || K.event_bytes != dk.event_bytes) return 2;
     if (P.grid_type == 1 && tile_bricks(P, h->n_dust) > HYP_TILE_MAX_BRICKS) return 2;
+    if ((P.grid_type == 5 || P.grid_type == 6) && polar_tile_bricks(P, h->n_dust, h->pt_lds_kb) < 0) return 2;
     if (P.grid_type == 2 && !h->oct_neighbours) return 2;
     if (P.grid_type == 2 || P.grid_type == 3 || P.grid_type == 4) {
         const int rc = P.grid_type == 4 ? build_amr_slabs(h) : P.grid_type == 3 ? build_vor_clusters(h) : build_oct_clusters(h);

@@ -25,6 +25,7 @@
 #include <sys/wait.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -34,6 +35,7 @@
 #include <deque>
 #include <limits>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -838,8 +840,13 @@ struct Comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     double *zero = nullptr; size_t zero_n = 0;
+    int ranks_seen = 0;              // result of the first collective: a sum of ones
     std::string id_file, abort_file;
-    volatile bool leaving = false;   // this rank wrote the abort file itself (or finished): its watcher stands down
+    // What the watcher thread reads: its own copies, shared with this object, so that the thread (detached: it may be asleep when
+    // main returns) never touches a Comm that is gone.  `leaving`: this rank wrote the abort file itself, or finished -- its
+    // watcher stands down.
+    struct Watch { std::string id_file, abort_file; int rank = 0; std::atomic<bool> leaving{false}; };
+    std::shared_ptr<Watch> w = std::make_shared<Watch>();
 
     static bool env_int(std::initializer_list<const char *> names, int &out)
     {
@@ -866,7 +873,8 @@ struct Comm {
         const char *e = getenv("HYP_NCCL_ID_FILE");
         id_file = (e && *e ? std::string(e) : output + ".ncclid") + "." + std::to_string(launch_id());
         abort_file = output + ".abort." + std::to_string(launch_id());
-        if (on && size > 1) std::thread([this] { watch(); }).detach();
+        w->id_file = id_file; w->abort_file = abort_file; w->rank = rank;
+        if (on && size > 1) { std::shared_ptr<Watch> ws = w; std::thread([ws] { watch(ws); }).detach(); }
     }
     bool main_process() const { return rank == 0; }
 
@@ -891,27 +899,32 @@ struct Comm {
     void abort_others(const std::string &why)
     {
         if (!on || size == 1 || abort_file.empty()) return;
-        const std::string tmp = abort_file + fmt(".%d.tmp", rank);
+        w->leaving = true;       // BEFORE the file appears: this rank's own watcher must not report it as another rank's
+        const std::string tmp = abort_file + fmt(".%d.tmp", rank), mine = fmt("rank %d: ", rank);
         FILE *fp = fopen(tmp.c_str(), "w");
-        if (fp) { fprintf(fp, "rank %d: %s\n", rank, why.c_str()); fclose(fp); (void)rename(tmp.c_str(), abort_file.c_str()); }
-        leaving = true;
+        if (fp) { fprintf(fp, "%s%s\n", mine.c_str(), why.c_str()); fclose(fp); (void)rename(tmp.c_str(), abort_file.c_str()); }
         usleep(1500000);
-        unlink(abort_file.c_str());
+        // several ranks may fail together and each renames its own message over the file: only the writer of what the file holds
+        // NOW removes it, so that a later rank's message stays for its full grace period
+        char head[64] = "";
+        fp = fopen(abort_file.c_str(), "r");
+        if (fp) { if (!fgets(head, sizeof head, fp)) head[0] = 0; fclose(fp); }
+        if (!std::strncmp(head, mine.c_str(), mine.size())) unlink(abort_file.c_str());
         if (rank == 0) unlink(id_file.c_str());
     }
-    void watch() const
+    static void watch(std::shared_ptr<Watch> ws)
     {
         for (;;) {
             usleep(100000);
-            if (leaving) return;
-            FILE *fp = fopen(abort_file.c_str(), "r");
+            if (ws->leaving) return;
+            FILE *fp = fopen(ws->abort_file.c_str(), "r");
             if (!fp) continue;
             char msg[512] = "";
             if (!fgets(msg, sizeof msg, fp)) msg[0] = 0;
             fclose(fp);
-            if (leaving) return;
+            if (ws->leaving) return;
             fprintf(stderr, " ERROR: another rank stopped the run: %sAn error occurred, and the run did not complete\n", msg);
-            if (rank == 0) unlink(id_file.c_str());
+            if (ws->rank == 0) unlink(ws->id_file.c_str());
             _exit(1);
         }
     }
@@ -941,9 +954,19 @@ struct Comm {
         // everybody has read the id once this first collective returns: rank 0 removes the file
         double *one = nullptr;
         if (hipMalloc((void **)&one, sizeof(double)) != hipSuccess) throw Fail("hipMalloc failed");
-        (void)hipMemset(one, 0, sizeof(double));
+        // ... and it is a sum of ones: what comes back is the number of ranks RCCL actually joined (mp_initialize prints the
+        // same of MPI_Comm_size, src/mpi/mpi_core.f90); anything but `size` is an error, not a slow run on fewer GPUs
+        const double unit = 1.0;
+        (void)hipMemcpy(one, &unit, sizeof unit, hipMemcpyHostToDevice);
         sum(one, 1);
+        double seen = 0.0;
+        (void)hipMemcpy(&seen, one, sizeof seen, hipMemcpyDeviceToHost);
         (void)hipFree(one);
+        ranks_seen = (int)(seen + 0.5);
+        if (ranks_seen != size) throw Fail(fmt("the all-reduce joined %d ranks, the launcher named %d", ranks_seen, size));
+        char bus[32] = "";
+        (void)hipDeviceGetPCIBusId(bus, sizeof bus, device);
+        if (size > 1 || getenv("HYP_VERBOSE_RANKS")) printf(" [mpi] rank %d of %d: device %d (%s); all-reduce of ones over RCCL = %d ranks seen\n", rank, size, device, bus, ranks_seen);
         if (rank == 0 && size > 1) unlink(id_file.c_str());
     }
     void sum(void *ptr, size_t n)
@@ -981,7 +1004,7 @@ struct Comm {
     }
     void finalize()
     {
-        leaving = true;
+        w->leaving = true;
         if (zero) (void)hipFree(zero);
         if (comm) ncclCommDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);

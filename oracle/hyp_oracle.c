@@ -3141,9 +3141,18 @@ int orc_lucy_accumulate(orc_state *st, uint64_t first_id, uint64_t n_local, int 
     }
     memset(&st->pending, 0, sizeof st->pending);
     int fatal = 0;
+    /* the threads' copies summed in thread order, cell by cell (the order of the additions, and so the result, does not
+     * depend on how the cells are spread over the threads that do it) */
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nt) schedule(static)
+#endif
+    for (int64_t k = 0; k < (int64_t)ntot; k++) {
+        double v = st->specific_energy_sum[k];
+        for (int t = 1; t < nt; t++) v += accs[t].sum[k];
+        st->specific_energy_sum[k] = v;
+    }
     for (int t = 0; t < nt; t++) {
         if (t > 0) {
-            for (size_t k = 0; k < ntot; k++) st->specific_energy_sum[k] += accs[t].sum[k];
             free(accs[t].sum);
             if (nspec) { for (size_t k = 0; k < nspec; k++) st->spec_sum[k] += accs[t].sum_spec[k]; free(accs[t].sum_spec); }
         }
