@@ -320,6 +320,23 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    rccl = None
+    if dist is not None:
+        # What RCCL itself saw, so that the line cannot claim N GPUs on the strength of WORLD_SIZE alone: an all-reduce of ones,
+        # the process group's size, and every rank's device (index, PCI bus id) gathered through the same backend.
+        ones = torch.ones(1, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "device": torch.cuda.current_device(), "name": props.name,
+                "pci": ("%04x:%02x:%02x" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)) if hasattr(props, "pci_bus_id")
+                       else "device-%d" % torch.cuda.current_device()}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rccl = {"backend": dist.get_backend(), "ranks_seen": int(round(float(ones.item()))), "world_size": dist.get_world_size(), "devices": gathered,
+                "distinct_devices": len({g["pci"] for g in gathered})}
+        if rccl["ranks_seen"] != world or rccl["world_size"] != world or rccl["distinct_devices"] != world:
+            raise SystemExit("RCCL joined %d ranks on %d distinct devices, the launcher named %d" % (rccl["ranks_seen"], rccl["distinct_devices"], world))
+
     if args.photons is None:
         n_total = 100000000 if world == 1 else 1000000000      # configs[1] / configs[2]
         config_name, scaling = ("configs[1]", "weak") if world == 1 else ("configs[2]", "strong")
@@ -369,6 +386,20 @@ def main():
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    if dist is not None:
+        # Every rank applied update_energy_abs to the same all-reduced block (no broadcast): the specific energy must be the same
+        # bits everywhere.  A 64-bit digest of each rank's array, min and max over the ranks in one all-reduce of two numbers.
+        import hashlib
+        import numpy as np
+        se = eng.specific_energy()
+        dig = int.from_bytes(hashlib.blake2b(np.ascontiguousarray(se).tobytes(), digest_size=6).digest(), "little")     # 48 bits: exact in a double
+        d2 = torch.tensor([float(dig), -float(dig)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+        rccl["specific_energy_digest_rank0"] = "%012x" % dig
+        rccl["specific_energy_identical_on_all_ranks"] = bool(d2[0].item() == -d2[1].item())
+        rccl["allreduce_bytes_per_step"] = int(eng.get_option("lucy_block_doubles")) * 8
+        if not rccl["specific_energy_identical_on_all_ranks"]:
+            raise SystemExit("the ranks hold different specific energies after the all-reduce")
     # where each rank's time went (ms per step): launches (host side of the generations, which includes most of the
     # propagation: the tiled schedule polls the device), waiting for the kernels, the all-reduce, the epilogue; device
     # time of the propagation from HIP events.  Gathered after the timed region.
@@ -400,6 +431,8 @@ def main():
             "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_scan / tile_scatter / tile_walk on %d slot pools (streams)"
                               % eng.get_option("tile_pools")) if tiled else "persistent kernel, global atomics",
         }
+        if rccl is not None:
+            out["rccl"] = rccl
         if world > 1:
             out["ms_per_step_note"] = "max over ranks of the barrier-to-barrier time of the timed steps / steps"
         names = ("launch_ms", "kernel_wait_ms", "allreduce_ms", "finish_ms", "device_propagate_ms", "device_finish_ms")

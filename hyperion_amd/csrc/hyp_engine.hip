@@ -223,13 +223,10 @@ struct hyp_engine {
     // brick-tiled Lucy iteration (hyp_tiled.h)
     void *d_hot = nullptr, *d_cold = nullptr;
     int *d_slot_brick = nullptr, *d_order = nullptr;
-    unsigned int *d_counts = nullptr, *d_offsets = nullptr, *d_cursor = nullptr;
+    unsigned int *d_counts = nullptr, *d_cursor = nullptr;
     TileTask *d_tasks = nullptr;
     int *d_ilist = nullptr, *d_dlist = nullptr, *d_extra = nullptr;     // split schedule: per-task work lists
     TileCount *d_tcount = nullptr;
-    int tile_split = 1;
-    int tile_ring = 0;              // option: walk workgroups take their packets from an LDS ring fed by a loader wave (RecRing; tuning builds only)
-    int last_tile_ring = 0;
     // option (off): live timing of the dominant kernel for bench.py's roofline -- HIP events around every tile_walk launch on its
     // own stream and a device synchronisation at the end of the iteration; bench.py switches it on for one extra step
     int tile_time_walk = 0;
@@ -239,7 +236,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16, tile_prep_blocks = 1;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16;
     int last_lucy_mode = 0;
     hipStream_t pool_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_pool = nullptr;   // lucy_mode: -1 auto, 0 persistent, 1 brick-tiled
@@ -248,7 +245,6 @@ struct hyp_engine {
     // cluster-tiled Voronoi schedule (hyp_vtile.h): tables built by build_vor_clusters()
     int vt_cells = 0;               // option: target cells per cluster (0: as many as the LDS budget allows)
     int tile_presort = 1;           // option: 1 = the Cartesian walk passes the kind of a packet's next interaction on with its slot (one species)
-    int tile_fused_sort = 1;        // option: 1 = tile_scan + tile_scatter in one launch (tile_sort_kernel)
     int pt_vsplit = 1;              // option: spherical grids, 1 = two sort entries per brick (not yet interacted / the others)
     int pt_lds_kb = 128;            // option: LDS of the densities and accumulators of one polar-grid brick in KB (hyp_ptile.h)
     int vt_lds_kb = 156;            // option: LDS budget of one walk workgroup in KB (156: one 1024-thread workgroup per CU; 78: room for two of 512 threads)
@@ -492,7 +488,7 @@ size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd) { return sizeof(double
 size_t oct_cluster_lds(size_t n, size_t k, int nd) { return (sizeof(OctCell) + sizeof(double) * 2 * nd + sizeof(short) * 6) * n + sizeof(short) * 8 * k + 16; }
 
 // LDS of one walk workgroup
-size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool ring)
+size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T)
 {
     if (h->hp.grid_type == 3)       // cluster: its tables (VtInfo) + densities + accumulators
         return h->vt_max_lds;
@@ -502,9 +498,7 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T, bool
         return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
         return oct_cluster_lds((size_t)T.bx, (size_t)T.by, K.nd);
-    if (ring)                       // the brick's own walls + brick + record ring (hyp_tiled.h: RecRing)
-        return sizeof(double) * (2 * ((size_t)K.bx + K.by + K.bz + 3) + 6) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd + HYP_RING_BYTES;
-    return lds_bytes(h->hp) + sizeof(double) * (1 + HYP_TILE_DENS_LDS) * (size_t)K.bx * K.by * K.bz * K.nd;
+    return lds_bytes(h->hp) + sizeof(double) * 2 * (size_t)K.bx * K.by * K.bz * K.nd;      // walls + densities + accumulators of the brick
 }
 
 // `img`: the imaging iteration on the tiled schedule -- the event buffer the IMG kernels append to; `flush` empties it (sort +
@@ -516,12 +510,8 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
     std::memset(&no_events, 0, sizeof no_events);
     const size_t lds_w = lds_bytes(h->hp);
     const size_t lds_int = lds_w;
-    // record ring (one loader wave per walk workgroup) where the kernel has that form and two workgroups still fit a CU
-    const bool ring = h->tile_ring && K.walk_ring && tile_walk_lds(h, K, T0, true) <= 80 * 1024;
-    const TileWalkK walk_k = ring ? K.walk_ring : K.walk;
-    const size_t lds_walk = tile_walk_lds(h, K, T0, ring);
-    h->last_tile_ring = ring ? 1 : 0;
-    const int grid_p = std::min((T0.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, h->n_cu * h->tile_prep_blocks);
+    const TileWalkK walk_k = K.walk;
+    const size_t lds_walk = tile_walk_lds(h, K, T0);
     const int grid_s = (T0.n_slots + 256 * HYP_SORT_PER_THREAD - 1) / (256 * HYP_SORT_PER_THREAD);
     const int grid_w = T0.n_slots / T0.task_size + T0.n_bricks + 1;
     // tile_interact: one workgroup per HYP_INTERACT_CHUNK entries of the pool's list (+ one for the extra list); tile_emit:
@@ -558,33 +548,22 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             int *slot_brick = h->d_slot_brick + (size_t)pool * T.n_slots;
             int *order = h->d_order + (size_t)pool * T.n_slots;
             TileTask *tasks = h->d_tasks + pool * tasks_cap;
-            // split schedule: counts and cursors by generation parity (tile_sort_kernel); `counts` = what this generation's sort reads
+            // counts and cursors by generation parity (tile_sort_kernel); `counts` = what this generation's sort reads
             const size_t par_off = (size_t)HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
-            const int gp = T0.split && h->tile_fused_sort ? (gen & 1) : 0, gn = T0.split && h->tile_fused_sort ? ((gen + 1) & 1) : 0;
-            unsigned *counts = h->d_counts + gp * par_off + pool * HYP_TILE_MAX_BRICKS, *offsets = h->d_offsets + pool * HYP_TILE_MAX_BRICKS,
-                     *cursor = h->d_cursor + gp * par_off + pool * HYP_TILE_MAX_BRICKS;
+            const int gp = gen & 1, gn = (gen + 1) & 1;
+            unsigned *counts = h->d_counts + gp * par_off + pool * HYP_TILE_MAX_BRICKS, *cursor = h->d_cursor + gp * par_off + pool * HYP_TILE_MAX_BRICKS;
             unsigned *counts_next = h->d_counts + gn * par_off + pool * HYP_TILE_MAX_BRICKS, *cursor_next = h->d_cursor + gn * par_off + pool * HYP_TILE_MAX_BRICKS;
             int *ilist = h->d_ilist + (size_t)pool * 2 * T.n_slots, *dlist = h->d_dlist + (size_t)pool * 2 * T.n_slots;      // [staging | pool-wide list]
             int *extra = h->d_extra + (size_t)pool * 3 * HYP_TILE_EXTRA;
             T.gen = gen;
             TileCount *tcount = h->d_tcount + pool * tasks_cap;
-            if (T.split) {
-                // walk (previous generation) left per-task lists: interactions, then emission into the freed slots
-                if (gen == 0) tile_init_kernel<<<(T.n_slots + 255) / 256, 256, 0, st>>>(T, h->d_ctl, tasks, tcount, dlist);
-                else
-                    (img ? K.interact_img : K.interact[ri][mi])<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
-                                                                                         tcount, counts, extra, img ? *img : no_events);
-                (img ? K.emit_img : h->simple_sources && K.emit_simple ? K.emit_simple : h->ext_sources && K.emit_ext ? K.emit_ext : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra, img ? *img : no_events);
-            } else {
-                K.prepare<<<grid_p, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick);
-                tile_count_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, counts);
-            }
-            if (T.split && h->tile_fused_sort)
-                tile_sort_kernel<<<grid_s, 256, sizeof(unsigned) * (2 * (size_t)T.n_bricks + 512), st>>>(T, slot_brick, counts, counts_next, cursor, cursor_next, order, tasks, h->d_ctl);
-            else {
-                tile_scan_kernel<<<1, 1024, 0, st>>>(T, counts, offsets, cursor, tasks, h->d_ctl);
-                tile_scatter_kernel<<<grid_s, 256, 0, st>>>(T, slot_brick, offsets, cursor, order);
-            }
+            // walk (previous generation) left per-task lists: interactions, then emission into the freed slots
+            if (gen == 0) tile_init_kernel<<<(T.n_slots + 255) / 256, 256, 0, st>>>(T, h->d_ctl, tasks, tcount, dlist);
+            else
+                (img ? K.interact_img : K.interact[ri][mi])<<<grid_i, 256, lds_int, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, ilist, dlist,
+                                                                                     tcount, counts, extra, img ? *img : no_events);
+            (img ? K.emit_img : h->simple_sources && K.emit_simple ? K.emit_simple : h->ext_sources && K.emit_ext ? K.emit_ext : K.emit)<<<grid_e, 256, lds_w, st>>>(h->d_problem, T, h->d_ctl, hot, cold, slot_brick, tasks, dlist, tcount, counts, extra, img ? *img : no_events);
+            tile_sort_kernel<<<grid_s, 256, sizeof(unsigned) * (2 * (size_t)T.n_bricks + 512), st>>>(T, slot_brick, counts, counts_next, cursor, cursor_next, order, tasks, h->d_ctl);
             const bool timed = h->tile_time_walk && n_timed + 2 <= 16384;
             if (timed) {
                 while (h->walk_events.size() < n_timed + 2) {
@@ -718,7 +697,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         T.n_bricks = T.nbx * T.nby * T.nbz;
         T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     }
-    // the sort's tables (d_counts / d_cursor / d_offsets, tile_sort_kernel's LDS) hold HYP_TILE_MAX_BRICKS entries per pool
+    // the sort's tables (d_counts / d_cursor, tile_sort_kernel's LDS) hold HYP_TILE_MAX_BRICKS entries per pool
     if (T.n_bricks < 1 || T.n_bricks > HYP_TILE_MAX_BRICKS) return h->set_error("grid has too many bricks for the tiled schedule");
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
     const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
@@ -728,7 +707,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
     T.task_size = h->tile_task <= 0 ? 8192 : h->tile_task < 256 ? 256 : h->tile_task;
-    T.iter_tag = iter_tag; T.pool = 0; T.park = h->tile_park; T.split = (h->tile_split || !K.prepare || img) ? 1 : 0;
+    T.iter_tag = iter_tag; T.pool = 0; T.park = h->tile_park;
     T.imaging = img ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
@@ -746,7 +725,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     }
     if (!h->d_counts) {
         const size_t nb = sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
-        if (hipMalloc(&h->d_counts, 2 * nb) != hipSuccess || hipMalloc(&h->d_offsets, nb) != hipSuccess || hipMalloc(&h->d_cursor, 2 * nb) != hipSuccess ||
+        if (hipMalloc(&h->d_counts, 2 * nb) != hipSuccess || hipMalloc(&h->d_cursor, 2 * nb) != hipSuccess ||
             hipMalloc(&h->d_ctl, sizeof(TileCtl)) != hipSuccess || hipHostMalloc(&h->h_ctl, sizeof(TileCtl)) != hipSuccess)
             return h->set_error("cannot allocate the control blocks of the tiled Lucy iteration");
         if (hipEventCreateWithFlags(&h->ev_pool, hipEventDisableTiming) != hipSuccess)
@@ -928,7 +907,7 @@ void hyp_destroy(hyp_handle h)
     if (h->h_peel_counter) (void)hipHostFree(h->h_peel_counter);
     free_dev(h->d_img_accum);
     free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order);
-    free_dev(h->d_counts); free_dev(h->d_offsets); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
+    free_dev(h->d_counts); free_dev(h->d_cursor); free_dev(h->d_tasks); free_dev(h->d_ctl);
     free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
     for (hipEvent_t e : h->walk_events) (void)hipEventDestroy(e);
     free_dev(h->d_nphot); free_dev(h->d_visit); free_dev(h->d_nphot_inexact); free_dev(h->d_log_edges); free_dev(h->d_bin_frac); free_dev(h->d_spec);
@@ -1284,6 +1263,11 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
     }
 
     // walls + 3*spacing(w): grid_geometry_cartesian_3d.f90:97-132
+    // (Cartesian walls beyond 2^300: the reference's cell volumes dx dy dz overflow there; the wall search relies on path lengths
+    // (w - r) / v staying finite, find_wall_ahead in hyp_kernels.h)
+    for (int a = 0; a < 3 && is_car && !is_polar; a++)
+        for (int i = 0; i <= n[a]; i++)
+            if (!(std::fabs(win[a][i]) < 0x1p300)) return set_error("grid walls beyond 2^300 are not supported (cell volumes overflow)");
     size_t w_off[3] = {0, 0, 0}, ew_off[3] = {0, 0, 0};
     for (int a = 0; a < 3 && is_car; a++) {
         w_off[a] = B.put(win[a], n[a] + 1);
@@ -2986,8 +2970,6 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
-    else if (n == "tile_split") h->tile_split = (int)value;
-    else if (n == "tile_ring") h->tile_ring = (int)value;
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
     else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
@@ -3012,13 +2994,11 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "pt_vsplit") h->pt_vsplit = value ? 1 : 0;
-    else if (n == "tile_fused_sort") h->tile_fused_sort = value ? 1 : 0;
     else if (n == "tile_presort") h->tile_presort = value ? 1 : 0;
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
     else if (n == "tile_park") h->tile_park = (int)value;
-    else if (n == "tile_prep_blocks") h->tile_prep_blocks = (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
 }
@@ -3042,9 +3022,6 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "lucy_flag_index") *value = (int64_t)(h->n_elem + TAIL_RANK_ERROR);
     else if (n == "image_block_doubles") *value = (int64_t)(h->d_img_accum ? h->img_accum_n : (size_t)TAIL_SIZE);
     else if (n == "image_flag_index") *value = (int64_t)((h->d_img_accum ? h->img_accum_n - TAIL_SIZE : (size_t)0) + TAIL_RANK_ERROR);
-    else if (n == "tile_split") *value = h->tile_split;
-    else if (n == "tile_ring") *value = h->tile_ring;
-    else if (n == "last_tile_ring") *value = h->last_tile_ring;
     else if (n == "last_walk_us") *value = (int64_t)(h->last_walk_ms * 1000.0);
     else if (n == "last_walk_launches") *value = h->last_walk_launches;
     else if (n == "pda_last_cells") *value = h->pda_last_cells;
@@ -3074,7 +3051,6 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "ot_clusters") *value = h->ot_clusters;
     else if (n == "ot_max_cells") *value = h->ot_max_cells;
     else if (n == "pt_vsplit") *value = h->pt_vsplit;
-    else if (n == "tile_fused_sort") *value = h->tile_fused_sort;
     else if (n == "tile_presort") *value = h->tile_presort;
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
@@ -3088,7 +3064,6 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_walk_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;       //   and disagreements of the two
     else if (n == "last_vt_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;         // -DHYP_VTILE_VERIFY builds: filter and loop disagreed
     else if (n == "tile_park") *value = h->tile_park;
-    else if (n == "tile_prep_blocks") *value = h->tile_prep_blocks;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with
     else if (n == "last_generations") *value = h->last_generations;   // generations of the last tiled iteration
     else return h->set_error("unknown option: " + n);

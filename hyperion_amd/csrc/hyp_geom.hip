@@ -177,11 +177,7 @@ static TileKernels tile_kernels()
     {
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
-        k.prepare = tile_prepare_kernel<NDT>;
-        k.walk = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z, false>;
-#ifdef HYP_TILE_RING_BUILD   // the record-ring form of the walk (hyp_tiled.h: RecRing) measured slower: only tuning builds carry it
-        k.walk_ring = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z, true>;
-#endif
+        k.walk = tile_walk_kernel<NDT, TileShape<NDT>::X, TileShape<NDT>::Y, TileShape<NDT>::Z>;
         k.walk_threads = HYP_TILE_WG;
         k.bx = TileShape<NDT>::X; k.by = TileShape<NDT>::Y; k.bz = TileShape<NDT>::Z;
     }

@@ -229,18 +229,23 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
     for (int a = 0; a < 3; a++) { c.ic[a] += im[a]; c.ow[a] = -im[a]; }
 }
 
-#ifndef HYP_TILE_LDS_FRONT
-#define HYP_TILE_LDS_FRONT 0     // find_wall_ahead: the step's nine wall reads issued together (measured neutral)
-#endif
+// max of two values neither of which is a NaN: ONE v_max_f64.  (fmax() costs three: the compiler first makes each operand
+// "canonical" -- v_max_f64 x, x, x -- because a signalling NaN would have to be quieted.)
+__device__ __forceinline__ double max_no_nan(double a, double b)
+{
+    double m;
+    asm("v_max_f64 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+
 // find_wall for the common case that, on every axis, the wall *behind* the packet is not a
 // candidate of geo_find_wall (it is one only if round-off left the packet outside its cell on
 // an axis where it is not flagged as sitting on that wall).  Then at most the wall ahead is a
 // candidate on each axis, with exactly geo_find_wall's condition, and the candidates are merged
 // in the same order with the same epsilon rules.  Written without control flow: the wall ahead
-// is picked by index arithmetic (iu = 1 where v > 0) and the sign tests are products with
-// sgn = +-1 or 0 (exact), so that the three IEEE divisions can be scheduled together and no
-// lane-divergent branch is left in the step.  Returns false when the precondition fails; the
-// caller then uses geo_find_wall.
+// is picked by index arithmetic (iu = 1 where v > 0), so that the three quotients can be
+// scheduled together and no lane-divergent branch is left in the step.  Returns false when the
+// precondition fails; the caller then uses geo_find_wall.
 //
 // The three quotients d / v are formed with the reciprocals inv = RN(1 / v) that the lane
 // computed (with a true IEEE division) when it took the packet -- the direction is fixed during
@@ -255,53 +260,52 @@ __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3]
 // with v = 0 is never a candidate, so its inf/NaN quotient is not looked at.
 // tools/ubench/markstein_check.c compares the sequence with the division on 4e8 operand pairs
 // including all-ones / near-power-of-two / short mantissas: no mismatch.
+//
+// The sign tests of the reference -- a wall is a candidate when (w - r) and v have the same sign -- cost no arithmetic of
+// their own (round 5; they were two FP64 products with sgn(v) per axis):
+//   * wall AHEAD: d and v have the same sign and are both non-zero exactly when the quotient t = RN(d / v) is > 0: the exact
+//     quotient is then positive and at least |d| (|v| <= 1: no underflow to zero); opposite signs give t <= -0, d = 0 gives
+//     t = +-0, and v = 0 gives inv = inf, rem = NaN, t = NaN -- every comparison with it false, as the reference's `v > 0`.
+//   * wall BEHIND: db with its sign flipped where v <= 0 (one XOR of the high word with smask, the sign bit where v <= 0) is
+//     > 0 exactly when db and v have the same sign; where v = 0 the flipped value is > 0 only for a packet beyond the upper
+//     wall of its cell, which then takes the general search like any packet outside its cell (the same result, slower).
+// The first axis meets tmin = DBL_MAX, emin = 0: t0 < DBL_MAX -+ e0 holds for every finite t0 (hyp_create refuses walls beyond
+// 2^300, and |1 / v| <= 2^400 under v_ok, so t0 < 2^701), and max(e0, 0) = e0 (an epsilon is 3 x spacing(w) > 0), so its
+// candidate is taken without the two sums and comparisons.
 __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3], const double v[3], const double inv[3],
-                                                const int iu[3], const double sgn[3],
+                                                const int iu[3], const int smask[3],
                                                 const Cell<GEOM_CAR> &c, double &tnear, int im[3], bool &found)
 {
     double tmin = HYP_DBL_MAX, emin = 0.0;
     int m0 = 0, m1 = 0, m2 = 0;
     bool simple = true;
-#if HYP_TILE_LDS_FRONT
-    // all nine LDS reads of the step before the arithmetic (one wait instead of five)
-    double wa_[3], wb_[3], ea_[3];
-#pragma unroll
-    for (int a = 0; a < 3; a++) { wa_[a] = W.w[a][c.ic[a] + iu[a]]; wb_[a] = W.w[a][c.ic[a] + 1 - iu[a]]; ea_[a] = W.ew[a][c.ic[a] + iu[a]]; }
-    asm volatile("" : "+v"(wa_[0]), "+v"(wa_[1]), "+v"(wa_[2]), "+v"(wb_[0]), "+v"(wb_[1]), "+v"(wb_[2]), "+v"(ea_[0]), "+v"(ea_[1]), "+v"(ea_[2]));
-#endif
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const int ia = c.ic[a] + iu[a], ib = c.ic[a] + 1 - iu[a];
-#if HYP_TILE_LDS_FRONT
-        const double d = wa_[a] - r[a], db = wb_[a] - r[a];
-        (void)ib;
-#else
         const double d = W.w[a][ia] - r[a], db = W.w[a][ib] - r[a];
-#endif
         const int dir = 2 * iu[a] - 1, ow = c.ow[a];
-        // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
-        const bool cand = (ow != dir) & (d * sgn[a] > 0.0);
-        // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
-        simple = simple & !((ow != -dir) & (db * sgn[a] > 0.0));
-#ifdef HYP_TILE_TRUE_DIV
-        const double t = d / v[a];
-#else
         const double q0 = d * inv[a];
         const double t = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
-#endif
-#if HYP_TILE_LDS_FRONT
-        const double emax = fmax(ea_[a], emin);
-#else
-        const double emax = fmax(W.ew[a][ia], emin);
-#endif
-        const bool lt = cand & (t < tmin - emax);
-        const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
-        tmin = lt ? t : tmin;
-        emin = any ? emax : emin;
-        const int mine = any ? dir : 0;
-        if (a == 0) m0 = mine;
-        if (a == 1) { m0 = lt ? 0 : m0; m1 = mine; }
-        if (a == 2) { m0 = lt ? 0 : m0; m1 = lt ? 0 : m1; m2 = mine; }
+        // wall ahead: c2 = (ow != +1) && d2 > 0 for v > 0;  c1 = (ow != -1) && d1 < 0 for v < 0
+        const bool cand = (ow != dir) & (t > 0.0);
+        // wall behind: c1 = (ow != -1) && d1 > 0 for v > 0;  c2 = (ow != +1) && d2 < 0 for v < 0
+        const double db_s = __hiloint2double(__double2hiint(db) ^ smask[a], __double2loint(db));
+        simple = simple & !((ow != -dir) & (db_s > 0.0));
+        const double e = W.ew[a][ia];
+        if (a == 0) {
+            tmin = cand ? t : tmin;
+            emin = cand ? e : emin;
+            m0 = cand ? dir : 0;
+        } else {
+            const double emax = max_no_nan(e, emin);
+            const bool lt = cand & (t < tmin - emax);
+            const bool any = cand & (t < tmin + emax);          // lt or within epsilon of the current minimum
+            tmin = lt ? t : tmin;
+            emin = any ? emax : emin;
+            const int mine = any ? dir : 0;
+            if (a == 1) { m0 = lt ? 0 : m0; m1 = mine; }
+            if (a == 2) { m0 = lt ? 0 : m0; m1 = lt ? 0 : m1; m2 = mine; }
+        }
     }
     tnear = tmin;
     im[0] = m0; im[1] = m1; im[2] = m2;
@@ -315,11 +319,11 @@ __device__ __forceinline__ bool find_wall_ahead(const Walls &W, const double r[3
 __device__ __forceinline__ bool car_find_wall_inv(const DProblem &P, const Walls &W, const double r[3], const double v[3], const double inv[3],
                                                   const Cell<GEOM_CAR> &c, double &tnear, int im[3])
 {
-    int iu[3]; double sgn[3];
+    int iu[3], smask[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) { iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0); }
+    for (int a = 0; a < 3; a++) { iu[a] = v[a] > 0.0 ? 1 : 0; smask[a] = v[a] > 0.0 ? 0 : (int)0x80000000; }
     bool found;
-    if (find_wall_ahead(W, r, v, inv, iu, sgn, c, tnear, im, found)) return found;
+    if (find_wall_ahead(W, r, v, inv, iu, smask, c, tnear, im, found)) return found;
     return geo_find_wall(P, W, r, v, c, tnear, im);
 }
 

@@ -42,9 +42,7 @@ struct TileKernels {
     TileInteractK interact_img; TileEmitK emit_img;      // the imaging iteration on this schedule (IMG kernels of hyp_tiled.h); event_bytes = sizeof(PeelEvent)
     size_t event_bytes;
     TileDrainK drain[2][2];
-    TileDrainK prepare;                 // unsplit schedule (Cartesian only), else null
     TileWalkK walk;
-    TileWalkK walk_ring;                // the same with the record ring (hyp_tiled.h: RecRing), or null
     size_t hot_bytes, cold_bytes;
     int walk_threads;
     int bx, by, bz;                     // Cartesian: brick shape; LDS of the walk = walls + 2 x 8 B x bx by bz nd

@@ -6,8 +6,8 @@
 // and accumulators live in LDS while a workgroup walks, with ds_add_f64, every
 // packet that currently sits in that brick; a packet that leaves the brick is
 // written back (128-byte "hot" record) and continues in the next generation.
-// Per generation:  tile_prepare (interactions + emission, one lane per slot)
-//   -> tile_count / tile_scan / tile_scatter (counting sort of slots by brick)
+// Per generation and slot pool:  tile_interact (the packets that reached their interaction point) -> tile_emit (new packets
+//   into the freed slots) -> tile_sort (counting sort of the walking slots by brick, task list)
 //   -> tile_walk (one workgroup per task = up to TASK packets of one brick).
 // Per-packet physics and random streams are the ones of hyp_kernels.h, so the
 // result equals the persistent kernel's up to FP64 summation order.
@@ -97,37 +97,13 @@ __device__ __forceinline__ void write_peel_event(PeelEvent<ND, GEOM> &E, const P
 #ifndef HYP_TILE_OCC
 #define HYP_TILE_OCC 4           // waves per SIMD the walk kernel's registers are budgeted for (16 waves per CU)
 #endif
-#ifndef HYP_TILE_DENS_LDS
-#define HYP_TILE_DENS_LDS 1      // 1: brick densities staged in LDS, 0: read through L1/L2
-#endif
 #ifndef HYP_TILE_SERVICE
 #define HYP_TILE_SERVICE 16      // lanes that must wait (visit finished / idle) before a wave runs its service phase
 #endif
 #ifndef HYP_TILE_STEPS
 #define HYP_TILE_STEPS 4         // cell steps between two scheduling decisions of a wave
 #endif
-// timing experiments only (results are wrong with these): tools/variants.py
-#ifdef HYP_TILE_ABLATE_DEPOSIT
-#define TILE_DEPOSIT(p, v) ((void)(p), (void)(v))
-#else
 #define TILE_DEPOSIT(p, v) do { if (!T.imaging) unsafeAtomicAdd(p, v); } while (0)      // (T: the walk kernel's TileGeom)
-#endif
-
-#ifndef HYP_WALK_ATTR
-#define HYP_WALK_ATTR
-#endif
-#ifndef HYP_TILE_PREFETCH
-#define HYP_TILE_PREFETCH 0      // look-ahead of tile_walk's record prefetch, in packets of the task's queue (0: none; measured: no gain, profiles/r03_tiled_log.md)
-#endif
-#ifndef HYP_TILE_WCLAIM
-#define HYP_TILE_WCLAIM 0        // 1: a wave takes the task's queue in blocks of 64 entries (one LDS atomic and one coalesced load of order[] per block, the
-#endif                           //    records of the block prefetched), its lanes are served from the block by rank; 0: one atomic + one load of order[] per lane
-#ifndef HYP_TILE_LDS_FRONT
-#define HYP_TILE_LDS_FRONT 0     // find_wall_ahead: the step's nine wall reads issued together
-#endif
-#ifndef HYP_TILE_BULK_LOAD
-#define HYP_TILE_BULK_LOAD 0     // tile_walk takes a packet's record with one batch of 16-byte loads (0: field by field)
-#endif
 #define HYP_TILE_MAX_POOLS 4
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
@@ -151,7 +127,6 @@ struct TileGeom {
     int pool;                    // which slot pool (and stream) this launch belongs to
     int park;                    // tile_walk: park the last packets of a wave once this few lanes still walk
     int gen;                     // generation number (split schedule: which of the two extra lists is read)
-    int split;                   // 1: tile_walk lists the slots that wait per task for tile_interact / tile_emit and counts bricks
     int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
     const int *drain_list;       // tile_drain: the slots that still hold a packet (tile_live_kernel), TileCtl::n_live of them
     int presort;                 // 1: the walk writes slot | kind << 30 into the interaction lists (HotRec::pad; one species, Cartesian walk)
@@ -274,202 +249,10 @@ template <> struct TileCellIO<GEOM_OCT> {
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_OCT> &c) { return P.ot_cluster[c.id]; }
 };
 
-// ---------------------------------------------------------------------------
-// tile_prepare: interactions and (re-)emission, one lane per slot; writes the
-// brick of every walking packet.
-// ---------------------------------------------------------------------------
-#ifndef HYP_PREP_WAVES
 #define HYP_PREP_WAVES 2
-#endif
-#ifdef HYP_PREP_STATS
-#define PREP_T(i) do { long long t_now = clock64(); t_acc[i] += t_now - t_last; t_last = t_now; } while (0)
-#else
-#define PREP_T(i) do { } while (0)
-#endif
-template <int ND>
-__global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_prepare_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
-                                                         void *__restrict__ hot_v, void *__restrict__ cold_v,
-                                                         int *__restrict__ slot_brick)
-{
-    extern __shared__ double lds[];
-    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
-    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
-    const DProblem &P = *Pp;
-    Walls W;
-    stage_walls<GEOM_CAR>(P, lds, W);
-    Counters cnt;
-    cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
-    unsigned int finished = 0;
-#ifdef HYP_PREP_STATS
-    long long t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = clock64();
-    unsigned long long n_pass_int = 0, n_pass_emit = 0, n_lane_int = 0, n_lane_emit = 0;
-#endif
-    // Each workgroup scans a chunk of slot_brick[] (coalesced), gathers the slots marked
-    // TILE_NEEDS_PREPARE into an LDS list and then works through that list with full waves.
-    __shared__ int list[HYP_PREP_CHUNK];
-    __shared__ int n_list, n_back;
-    const int n_chunks = (T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK;
-    for (int ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
-    __syncthreads();
-    if (threadIdx.x == 0) { n_list = 0; n_back = 0; }
-    __syncthreads();
-    for (int k = threadIdx.x; k < HYP_PREP_CHUNK; k += blockDim.x) {
-        const int s = ch * HYP_PREP_CHUNK + k;
-        // interactions from the front, emissions from the back: waves see one kind of work
-        const int sb = s < T.n_slots ? slot_brick[s] : TILE_IDLE;
-        if (sb == TILE_NEEDS_INTERACT || sb == TILE_NEEDS_REEMIT) list[atomicAdd(&n_list, 1)] = s;
-        else if (sb == TILE_NEEDS_PREPARE) list[HYP_PREP_CHUNK - 1 - atomicAdd(&n_back, 1)] = s;
-    }
-    __syncthreads();
-    const int n_front = n_list, n_emit = n_back;
-    PREP_T(0);      // scan + barriers
-    // emissions start on a wave boundary
-    const int emit0 = (n_front + 63) & ~63;
-    const int nl = emit0 + n_emit;
-    for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
-        const int k = k0 + (int)threadIdx.x;
-        const bool valid = k < n_front || (k >= emit0 && k < nl);
-        const int slot = !valid ? 0 : k < n_front ? list[k] : list[HYP_PREP_CHUNK - 1 - (k - emit0)];
-        int state = valid ? hot[slot].state : TS_DONE;
-        Packet<ND, GEOM_CAR> p;
-        Rng g;
-        unsigned long long id = 0;
-        bool touched = false;
-#ifdef HYP_PREP_STATS
-        { unsigned long long mi = __ballot(state == TS_INTERACT), me = __ballot(state == TS_DEAD && valid);
-          if (mi) { n_pass_int++; n_lane_int += __popcll(mi); } if (me) { n_pass_emit++; n_lane_emit += __popcll(me); } }
-        if (__ballot(state == TS_INTERACT) == 0 || true) PREP_T(1);   // state load
-#endif
-        p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
-        if (state == TS_REEMIT) {
-            // iter_lucy.f90:155-185: re-emission from the source that absorbed the packet
-            touched = true;
-            const HotRec<ND> &H = hot[slot];
-            const ColdRec<ND> &C = cold[slot];
-            id = H.id;
-            g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
-            g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
-            const int inter = C.inter, reabs = C.reabs, rid = C.reabs_id;
-            const double e = H.energy;
-            if ((long long)reabs == P.n_reabs_max) { cnt.killed_int++; state = TS_DEAD; finished++; }
-            else {
-                int source_id; Angle src_normal;
-                bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal, rid, e);
-                p.inter = inter; p.reabs = reabs + 1;
-                if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
-                else {
-                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                    begin_integrate(P, p);
-                    state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
-                }
-            }
-        } else if (state == TS_INTERACT) {
-            touched = true;
-            const HotRec<ND> &H = hot[slot];
-            const ColdRec<ND> &C = cold[slot];
-#pragma unroll
-            for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; p.cell.ic[a] = H.ic[a]; }
-            unpack_ow(H.ow, p.cell.ow);
-            p.a = C.a;
-            p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
-            p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
-#pragma unroll
-            for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
-            p.inter = C.inter;
-            id = H.id;
-            g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
-            g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
-            if ((long long)p.inter == P.n_inter_max + 1) {
-                cnt.killed_int++; state = TS_DEAD; finished++;
-            } else {
-                int scattered, dust_id;
-                bool ok = interact<ND, GEOM_CAR>(P, p, g, cnt, scattered, dust_id);
-                bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
-                if (killed) { state = TS_DEAD; finished++; }
-                else if (P.mrw && mrw_loop_lucy<ND, GEOM_CAR>(P, W, p, g, P.sum, cnt)) { state = TS_DEAD; finished++; }
-                else {
-                    p.inter++;
-                    p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                    begin_integrate(P, p);
-                    state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
-                }
-            }
-        }
-        PREP_T(2);      // interactions (record load + interact)
-        // (re-)emission into free slots while packet ids remain
-        bool want = state == TS_DEAD && valid;
-        unsigned long long m = __ballot(want);
-        if (m) {
-            const unsigned lane = __lane_id();
-            unsigned long long base = 0;
-            if (lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(&ctl->next_id, (unsigned long long)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1, 64);
-            if (want) {
-                touched = true;
-                id = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (id >= ctl->end_id) state = TS_DONE;
-                else {
-                    rng_init(g, P.seed_key, T.iter_tag, id);
-                    int source_id; Angle src_normal;
-                    bool ok = emit_packet<ND, GEOM_CAR>(P, W, p, g, cnt, source_id, src_normal);
-                    if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
-                    else {
-                        p.tau_req = rng_exp(g); p.tau_ach = 0.0;
-                        begin_integrate(P, p);
-                        state = (p.tau_req == 0.0) ? TS_INTERACT : TS_WALK;
-                    }
-                }
-            }
-        }
-        PREP_T(3);      // emission
-        if (valid && touched) {
-            if (state == TS_WALK || state == TS_INTERACT) {
-                HotRec<ND> &H = hot[slot];
-                ColdRec<ND> &C = cold[slot];
-#pragma unroll
-                for (int a = 0; a < 3; a++) { H.r[a] = p.r[a]; H.v[a] = p.v[a]; H.ic[a] = p.cell.ic[a]; }
-                H.ow = pack_ow(p.cell.ow);
-                H.tau_req = p.tau_req; H.tau_ach = p.tau_ach; H.energy = p.energy;
-#pragma unroll
-                for (int d = 0; d < ND; d++) { H.chi[d] = p.chi[d]; H.kappa[d] = p.kappa[d]; C.albedo[d] = p.albedo[d]; }
-                H.id = id; H.countdown = g.countdown; H.blk_b = g.blk_b; H.state = state;
-                C.a = p.a; C.s[0] = p.s[0]; C.s[1] = p.s[1]; C.s[2] = p.s[2]; C.s[3] = p.s[3];
-                C.nu = p.nu; C.buf_a = g.buf_a; C.blk_a = g.blk_a; C.have_a = g.have_a; C.inter = p.inter;
-                if (P.any_intersect) { C.t_src = p.t_src; C.t_ach = p.t_ach; C.reabs_id = p.reabs_id; C.reabs = p.reabs; }
-                // zero optical depth drawn: interact again in the next generation
-                slot_brick[slot] = state == TS_WALK ? brick_of(T, p.cell.ic) : TILE_NEEDS_INTERACT;
-            } else {
-                hot[slot].state = state;
-                // a new packet that left the grid at once frees the slot again; TS_DONE retires it
-                slot_brick[slot] = state == TS_DEAD ? TILE_NEEDS_PREPARE : TILE_IDLE;
-            }
-        }
-        PREP_T(4);      // record store
-    }
-    }
-#ifdef HYP_PREP_STATS
-    if (__lane_id() == 0) {
-        for (int i = 0; i < 5; i++) atomicAdd(&ctl->dbg[16 + i], (unsigned long long)t_acc[i]);
-        atomicAdd(&ctl->dbg[24], n_pass_int); atomicAdd(&ctl->dbg[25], n_pass_emit);
-        atomicAdd(&ctl->dbg[26], n_lane_int); atomicAdd(&ctl->dbg[27], n_lane_emit); atomicAdd(&ctl->dbg[28], 1ull);
-    }
-#endif
-    double e = wave_sum(cnt.energy_current);
-    double kg = wave_sum((double)cnt.killed_geo);
-    double ki = wave_sum((double)cnt.killed_int);
-    double ni = wave_sum((double)cnt.interactions);
-    double nf = wave_sum((double)finished);
-    if (__lane_id() == 0) {
-        if (e != 0.0) unsafeAtomicAdd(&P.tail[TAIL_ENERGY], e);
-        if (kg != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_GEO], kg);
-        if (ki != 0.0) unsafeAtomicAdd(&P.tail[TAIL_KILLED_INT], ki);
-        if (ni != 0.0) unsafeAtomicAdd(&P.tail[TAIL_INTERACTIONS], ni);
-        if (nf != 0.0) atomicAdd(&ctl->n_finished, (unsigned long long)nf);
-    }
-}
 
 // ---------------------------------------------------------------------------
-// Split schedule (T.split): every task of tile_walk collects the slots whose packets wait for an
+// The lists between the kernels: every task of tile_walk collects the slots whose packets wait for an
 // interaction (or for re-emission by a source that absorbed them) and the slots it freed, appends
 // both to the pool's two lists with ONE reservation per task (tile_walk_publish_lists), and adds the
 // packets that move on to the brick histogram itself.  tile_interact and tile_emit work through the
@@ -1152,84 +935,13 @@ static __global__ __launch_bounds__(256) void tile_live_kernel(TileGeom T, const
 // ---------------------------------------------------------------------------
 // counting sort of the walking slots by brick
 // ---------------------------------------------------------------------------
-// slots per thread of tile_scatter / tile_count.  Every workgroup makes one returning atomic per brick on cursor[], and
+// slots per thread of tile_sort.  Every workgroup makes one returning atomic per brick on cursor[], and
 // atomics on one address are served one after the other by the memory side: the fewer workgroups, the shorter that queue.
 #ifndef HYP_SORT_PER_THREAD
 #define HYP_SORT_PER_THREAD 32
 #endif
 
-static __global__ __launch_bounds__(256) void tile_count_kernel(TileGeom T, const int *__restrict__ slot_brick, unsigned int *__restrict__ counts)
-{
-    __shared__ unsigned int hist[HYP_TILE_MAX_BRICKS];
-    for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * blockDim.x * HYP_SORT_PER_THREAD;
-    for (int k = 0; k < HYP_SORT_PER_THREAD; k++) {
-        int slot = base + k * blockDim.x + threadIdx.x;
-        if (slot < T.n_slots) { int b = slot_brick[slot]; if (b >= 0) atomicAdd(&hist[b], 1u); }
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x) if (hist[b]) atomicAdd(&counts[b], hist[b]);
-}
-
-// exclusive scan of the brick counts, task list, reset of the cursors
-static __global__ __launch_bounds__(1024) void tile_scan_kernel(TileGeom T, unsigned int *__restrict__ counts, unsigned int *__restrict__ offsets,
-                                                        unsigned int *__restrict__ cursor, TileTask *__restrict__ tasks,
-                                                        TileCtl *__restrict__ ctl)
-{
-    __shared__ unsigned int part_c[1024], part_t[1024];
-    const int per = (T.n_bricks + 1023) / 1024;
-    const int b0 = threadIdx.x * per, b1 = min(b0 + per, T.n_bricks);
-    unsigned int sc = 0, stt = 0;
-    for (int b = b0; b < b1; b++) { sc += counts[b]; stt += (counts[b] + T.task_size - 1) / T.task_size; }
-    part_c[threadIdx.x] = sc; part_t[threadIdx.x] = stt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int ac = 0, at = 0;
-        for (int i = 0; i < 1024; i++) { unsigned int c = part_c[i], t = part_t[i]; part_c[i] = ac; part_t[i] = at; ac += c; at += t; }
-        ctl->n_tasks[T.pool] = at;
-        ctl->n_gil[T.pool][T.gen & 1] = 0; ctl->n_gdl[T.pool][T.gen & 1] = 0;      // the walk of this generation fills them
-    }
-    __syncthreads();
-    unsigned int oc = part_c[threadIdx.x], ot = part_t[threadIdx.x];
-    for (int b = b0; b < b1; b++) {
-        unsigned int c = counts[b];
-        offsets[b] = oc; cursor[b] = 0;
-        for (unsigned int s = 0; s < c; s += T.task_size) {
-            TileTask tk; tk.brick = b; tk.start = (int)(oc + s); tk.len = (int)min((unsigned int)T.task_size, c - s); tk.pad = 0;
-            tasks[ot++] = tk;
-        }
-        oc += c;
-        counts[b] = 0;          // ready for the next generation
-    }
-}
-
-static __global__ __launch_bounds__(256) void tile_scatter_kernel(TileGeom T, const int *__restrict__ slot_brick, const unsigned int *__restrict__ offsets,
-                                                          unsigned int *__restrict__ cursor, int *__restrict__ order)
-{
-    __shared__ unsigned int hist[HYP_TILE_MAX_BRICKS];
-    for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x) hist[b] = 0;
-    __syncthreads();
-    const int base = blockIdx.x * blockDim.x * HYP_SORT_PER_THREAD;
-    int br[HYP_SORT_PER_THREAD]; unsigned int rank[HYP_SORT_PER_THREAD];
-#pragma unroll
-    for (int k = 0; k < HYP_SORT_PER_THREAD; k++) {
-        int slot = base + k * blockDim.x + threadIdx.x;
-        br[k] = slot < T.n_slots ? slot_brick[slot] : -1;
-        rank[k] = br[k] >= 0 ? atomicAdd(&hist[br[k]], 1u) : 0u;
-    }
-    __syncthreads();
-    for (int b = threadIdx.x; b < T.n_bricks; b += blockDim.x)
-        if (hist[b]) hist[b] = atomicAdd(&cursor[b], hist[b]);      // hist[] now holds this workgroup's base
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < HYP_SORT_PER_THREAD; k++) {
-        int slot = base + k * blockDim.x + threadIdx.x;
-        if (br[k] >= 0) order[offsets[br[k]] + hist[br[k]] + rank[k]] = slot;
-    }
-}
-
-// tile_scan + tile_scatter in one launch (round 4: one launch less on every pool's chain of five per generation).  Every workgroup
+// Exclusive scan of the brick counts, task list and scatter of the slots in ONE launch.  Every workgroup
 // scans the brick counts itself (a few hundred values; the offsets stay in LDS), workgroup 0 also writes the task list and resets
 // what the next generation accumulates into.  The counts and the scatter cursors are kept twice, by generation parity: this
 // generation's (`counts`, read by every workgroup for as long as the launch runs) and the next one's (`counts_next`: what the walk
@@ -1304,107 +1016,6 @@ static __global__ __launch_bounds__(256) void tile_sort_kernel(TileGeom T, const
 }
 
 
-// ---------------------------------------------------------------------------
-// Record ring (EXPERIMENT, off: built only with -DHYP_TILE_RING_BUILD, option tile_ring).  The LAST wave of a walk
-// workgroup does not walk: it streams the slot records of the task's packets, in queue order, into a ring of LDS batches
-// with global_load_lds (DMA: no registers, 1 KB = 64 lanes x 16 B per instruction, each record read from wherever its slot
-// lies), several batches in flight, and publishes how many records have landed; the walking waves take their next packet
-// from the ring (ds_read) instead of following order[] -> HotRec through global memory.  Motive: a wave spends 46 % of its
-// clocks in the service phase (-DHYP_TILE_STATS), much of it waiting for those two dependent loads with its walking
-// lanes idle.  Measured (profiles/r03_tiled_log.md): parity green, but with the 13 KB that a 16^3 brick leaves of a CU's
-// LDS at two workgroups per CU the ring holds ~100 records, less than a loader needs in flight plus what the walkers
-// have claimed and not yet picked up: walk kernels 367 ms against 205 ms (one pool).  Kept for bricks that leave room.
-// Batch = the records one DMA instruction moves: 8 of 128 B (one species) or 5 of 192 B.
-// ---------------------------------------------------------------------------
-#ifndef HYP_RING_BATCHES
-#define HYP_RING_BATCHES 13      // ring size in batches of 1 KB
-#endif
-#ifndef HYP_RING_FLY
-#define HYP_RING_FLY 8           // DMAs the loader keeps in flight (at most 8: the switch in load_task)
-#endif
-#define HYP_RING_BYTES (HYP_RING_BATCHES * 1024 + HYP_RING_BATCHES * 8 * 4 + HYP_RING_BATCHES * 4 + 16)
-
-template <int ND>
-struct RecRing {
-    static constexpr int RS = (int)sizeof(HotRec<ND>), LPR = RS / 16, RPB = 64 / LPR;
-    char *data; int *slot; int *cons; int *tail;
-    __device__ __forceinline__ void carve(char *base)
-    {
-        data = base; slot = (int *)(base + HYP_RING_BATCHES * 1024); cons = slot + HYP_RING_BATCHES * 8; tail = cons + HYP_RING_BATCHES;
-    }
-    __device__ __forceinline__ void reset()      // by the whole workgroup, before the barrier that starts the task
-    {
-        if (threadIdx.x < HYP_RING_BATCHES) cons[threadIdx.x] = 0;
-        if (threadIdx.x == 64) *tail = 0;
-    }
-    // the loader wave's whole life: a DMA per batch as soon as its place in the ring is free, up to HYP_RING_FLY of them in
-    // flight, the oldest retired (and published) with a counted s_waitcnt.  The slot indices come through the scalar cache
-    // (the batch's 8 consecutive entries of order[] are wave-uniform), so the vector-memory counter holds the DMAs only.
-    __device__ __forceinline__ void load_task(const void *__restrict__ hot, const int *__restrict__ order, const TileTask &tk) const
-    {
-        constexpr int NB = HYP_RING_BATCHES, FLY = HYP_RING_FLY;
-        const int lane = (int)__lane_id();
-        const int rib = lane / LPR, part = lane % LPR;
-        const int n_batches = (tk.len + RPB - 1) / RPB;
-        const int *__restrict__ ord = order + tk.start;
-        int issued = 0, landed = 0;
-#ifdef HYP_RING_PRIO
-        __builtin_amdgcn_s_setprio(HYP_RING_PRIO);
-#endif
-        while (landed < n_batches) {
-            // issue while there is room in the ring and in the queue
-            while (issued < n_batches && issued - landed < FLY) {
-                const int rs = issued % NB;
-                if (issued >= NB) {      // the batch that lived here (always a full one) must have been taken entirely
-                    if (__hip_atomic_load(&cons[rs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < RPB) break;
-                    if (lane == 0) __hip_atomic_store(&cons[rs], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-                const int j0 = issued * RPB;
-                int mine = -1;
-#pragma unroll
-                for (int c = 0; c < RPB; c++) {
-#ifdef HYP_RING_ABLATE_IDX      // timing experiment only (wrong results): no order[] indirection
-                    const int sc = j0 + c < tk.len ? ((tk.start + j0 + c) & 0xfffff) : -1;
-#else
-                    const int sc = j0 + c < tk.len ? ord[j0 + c] : -1;      // uniform address: s_load
-#endif
-                    if (rib == c) mine = sc;
-                }
-                if (mine >= 0) {
-                    const char *src = (const char *)hot + (size_t)mine * RS + part * 16;
-                    // global_load_lds_dwordx4: LDS address = M0 + 16 x lane.  In asm so that hipcc neither counts it nor orders the
-                    // LDS traffic of this loop behind it (/opt/skills/guides/cdna_hip_programming.md, "LDS-DMA recipe")
-                    const unsigned lds_dst = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)(data + rs * 1024));
-                    unsigned keep;
-                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-                    if (part == 0) slot[rs * 8 + rib] = mine;
-                }
-                issued++;
-            }
-            if (issued == landed) { __builtin_amdgcn_s_sleep(2); continue; }      // ring full of untaken records
-            // retire the oldest batch in flight: all but the (issued - landed - 1) youngest DMAs have landed
-            switch (issued - landed - 1) {
-            case 0: __builtin_amdgcn_s_waitcnt(0x0070 | 0); break;       // vmcnt(0) lgkmcnt(0) (the slot indices too)
-            case 1: __builtin_amdgcn_s_waitcnt(0x0070 | 1); break;
-            case 2: __builtin_amdgcn_s_waitcnt(0x0070 | 2); break;
-            case 3: __builtin_amdgcn_s_waitcnt(0x0070 | 3); break;
-            case 4: __builtin_amdgcn_s_waitcnt(0x0070 | 4); break;
-            case 5: __builtin_amdgcn_s_waitcnt(0x0070 | 5); break;
-            case 6: __builtin_amdgcn_s_waitcnt(0x0070 | 6); break;
-            default: __builtin_amdgcn_s_waitcnt(0x0070 | 7); break;
-            }
-            landed++;
-            if (lane == 0) __hip_atomic_store(tail, min(landed * RPB, tk.len), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    // a walking lane with claim j (0 <= j < tk.len): has its record landed?  Then where it is.
-    __device__ __forceinline__ bool ready(int j) const { return j < __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    __device__ __forceinline__ const HotRec<ND> &record(int j) const { return *(const HotRec<ND> *)(data + ((j / RPB) % HYP_RING_BATCHES) * 1024 + (j % RPB) * RS); }
-    __device__ __forceinline__ int slot_of(int j) const { return slot[((j / RPB) % HYP_RING_BATCHES) * 8 + j % RPB]; }
-    __device__ __forceinline__ void taken(int j) const { atomicAdd(&cons[(j / RPB) % HYP_RING_BATCHES], 1); }
-};
-
 // brick shape per number of species: density + accumulators (16 B per cell and
 // species) must leave room for two workgroups per CU in the 160 KB LDS
 // Round 3: 32 x 16 x 16 bricks walked by ONE 1024-thread workgroup per CU instead of two 512-thread workgroups on 16^3 bricks:
@@ -1432,71 +1043,20 @@ template <> struct TileShape<4> { static constexpr int X = 32, Y = 8, Z = 8; }; 
 
 // (find_wall_ahead, the branch-free wall search of the step, lives in hyp_kernels.h: the deferred imaging kernels use it too)
 
-// geo_in_correct_cell (grid_geometry_cartesian_3d.f90:330-381) for a packet whose cell lies in the brick [x0, x1) when only the
-// brick's own walls are at hand (W indexed by grid position, valid on [x0, x1] per axis) plus the grid's outer walls gb =
-// {lo0, hi0, lo1, hi1, lo2, hi2}.  locate() over the whole wall array and the search over the brick's walls name the same cell
-// whenever the position lies inside the brick's extent; outside it the cell found cannot be the packet's.
-__device__ __forceinline__ bool in_correct_cell_brick(const Walls &W, const double *gb, const int x0[3], const int x1[3],
-                                                      const double r[3], const Cell<GEOM_CAR> &c)
-{
-    int act[3];
-    bool found = true;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        const double lo = gb[2 * a], hi = gb[2 * a + 1];
-        const bool in_grid = (r[a] >= lo) && (r[a] <= hi);
-        found = found && in_grid;
-        int j = -2;
-        if (r[a] == hi) j = W.n[a] - 1;
-        else if (r[a] >= W.w[a][x0[a]] && r[a] < W.w[a][x1[a]]) {
-            int jl = x0[a], ju = x1[a];
-            while (ju - jl > 1) {
-                const int jm = (ju + jl) >> 1;
-                if (r[a] >= W.w[a][jm]) jl = jm; else ju = jm;
-            }
-            j = jl;
-        }
-        act[a] = j;
-    }
-    const double thr = 1e-3;
-    if (c.ow[0] | c.ow[1] | c.ow[2]) {
-        bool ok = true;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const int i = c.ic[a];
-            const double wl = W.w[a][i], wu = W.w[a][i + 1];
-            if (c.ow[a] == -1) ok = ok && fabs((r[a] - wl) / (wu - wl)) < thr;
-            else if (c.ow[a] == +1) ok = ok && fabs((r[a] - wu) / (wu - wl)) < thr;
-            else ok = ok && found && act[a] == i;
-        }
-        return ok;
-    }
-    return found && act[0] == c.ic[0] && act[1] == c.ic[1] && act[2] == c.ic[2];
-}
-
-// fire-and-forget load of one dword into a junk LDS word per lane (LDS address = M0 + 4 x lane): pulls the line towards the CU
-__device__ __forceinline__ void tile_prefetch(const void *src, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
-}
-
 // lane states of tile_walk_kernel
 // LS_CHECK: the propagation check is due; LS_SLOW: geo_find_wall is needed for this step
 // LS_REABS: the step would run into a source (grid_propagate_3d.f90:139-143)
 enum { LS_IDLE = 0, LS_WALK = 1, LS_LEFT = 2, LS_DEAD = 3, LS_HIT = 4, LS_CHECK = 5, LS_SLOW = 6, LS_REABS = 7 };
 
-template <int ND, int BX, int BY, int BZ, bool RING>
-__global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+template <int ND, int BX, int BY, int BZ>
+__global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                       void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                       const int *__restrict__ order,
                                                       const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,
                                                       int *__restrict__ ilist, int *__restrict__ dlist,
                                                       TileCount *__restrict__ tcount, unsigned int *__restrict__ counts)
 {
-    extern __shared__ float4 lds16[];        // 16-byte aligned base (the record ring is read with ds_read_b128)
-    double *lds = (double *)lds16;
+    extern __shared__ double lds[];
     HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
     ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
     const DProblem &P = *Pp;
@@ -1505,40 +1065,11 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
     const bool any_intersect = P.any_intersect != 0;      // read once: inside the loops it would be a scalar load and a wait per cell step
     constexpr int NC = BX * BY * BZ;
     Walls W;
-    RecRing<ND> ring;
-    double *after_walls;
-    const double *grid_bounds = nullptr;
-    if (RING) {
-        // only the brick's own walls (BX + 1, BY + 1, BZ + 1 of them, and their epsilons) are staged: the ring needs the room.
-        // W.w[a] is offset so that it is still indexed by the cell's position in the grid.
-        const int bi = tk.brick % T.nbx, bj = (tk.brick / T.nbx) % T.nby, bk = tk.brick / (T.nbx * T.nby);
-        const int o[3] = {bi * BX, bj * BY, bk * BZ}, m[3] = {BX + 1, BY + 1, BZ + 1}, n[3] = {P.n1, P.n2, P.n3};
-        double *q = lds;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            for (int i = threadIdx.x; i < m[a]; i += blockDim.x) {
-                const int gi = min(o[a] + i, n[a]);
-                q[i] = P.w[a][gi]; q[m[a] + i] = P.ew[a][gi];
-            }
-            W.w[a] = q - o[a]; W.ew[a] = q + m[a] - o[a]; W.n[a] = n[a];
-            q += 2 * m[a];
-        }
-        if (threadIdx.x < 6) q[threadIdx.x] = P.w[threadIdx.x >> 1][(threadIdx.x & 1) ? n[threadIdx.x >> 1] : 0];      // the grid's outer walls
-        grid_bounds = q;
-        after_walls = lds + 2 * (BX + BY + BZ + 3) + 6;
-    } else {
-        stage_walls<GEOM_CAR>(P, lds, W);
-        after_walls = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
-    }
-#if HYP_TILE_DENS_LDS
-    double *dens = after_walls;
+    stage_walls<GEOM_CAR>(P, lds, W);
+    double *dens = lds + 2 * ((size_t)P.n1 + P.n2 + P.n3 + 3);
     double *accum = dens + (size_t)NC * ND;
-#else
-    double *accum = after_walls;
-#endif
-    if (RING) { ring.carve((char *)(accum + (size_t)NC * ND)); ring.reset(); }
     __shared__ int next_pkt;
-    // split schedule: this task's lists of waiting / free slots and the bricks its packets move to
+    // this task's lists of waiting / free slots and the bricks its packets move to
     // (index (dz+1)*9 + (dy+1)*3 + dx+1; 13 = packets parked in this brick)
     __shared__ int n_int_l, n_dead_l, pub_base[2];
     __shared__ unsigned int nb_cnt[27];
@@ -1555,44 +1086,21 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
         bool in = gx < P.n1 && gy < P.n2 && gz < P.n3;
         size_t gidx = ((size_t)gz * P.n2 + gy) * P.n1 + gx;
         for (int d = 0; d < ND; d++) {
-#if HYP_TILE_DENS_LDS
             dens[c * ND + d] = in ? P.density[gidx * ND + d] : 0.0;
-#else
-            (void)in; (void)gidx;
-#endif
             accum[c * ND + d] = 0.0;
         }
     }
     if (threadIdx.x == 0) next_pkt = 0;
-    // Record prefetch: the packets of a task are taken in queue order, so the record a lane will need HYP_TILE_PREFETCH claims
-    // from now can be pulled towards the CU while the packets at hand walk; the claim's own loads of order[] and hot[] then hit
-    // L2 instead of waiting for HBM in the service phase.  The prefetch is a global_load_lds_dword into a junk word per lane:
-    // no destination register, and -- being inline asm -- no s_waitcnt of the compiler's is attributed to it.  vmcnt counts in
-    // order, so it is issued after every load of the claim has been waited for (tile_prefetch_fence) and nothing waits on it
-    // before the next service phase.
-    __shared__ int pf_junk[64];
-    const unsigned pf_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char *)pf_junk);
-    if (HYP_TILE_PREFETCH > 0 && !RING) {
-        for (int j = threadIdx.x; j < 2 * HYP_TILE_PREFETCH && j < tk.len; j += blockDim.x) {
-            const int sp = order[tk.start + j];
-            if (j < HYP_TILE_PREFETCH) tile_prefetch(&hot[sp], pf_lds);
-            else asm volatile("" :: "v"(sp));
-        }
-    }
     __syncthreads();
 
     Counters cnt;
     cnt.energy_current = 0.0; cnt.crossings = 0; cnt.killed_geo = 0; cnt.killed_int = 0; cnt.interactions = 0;
     unsigned int finished = 0;
-    // the last wave feeds the record ring and takes no packets
-    const bool loader = RING && (threadIdx.x >> 6) == (blockDim.x >> 6) - 1;
-    if (loader) ring.load_task(hot_v, order, tk);
-    int claim = -1;                           // RING: index in the task's queue of the packet this lane waits for
-    // lane state: the walking part of a packet (the rest stays in its ColdRec)
-    double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
-    double sgn[3];                            // sign of v per axis (+1, -1, 0) and iu = 1 where v > 0: fixed during a visit
+    // lane state: the walking part of a packet (the rest stays in its records).  ke = kappa x energy: what a deposit multiplies the
+    // path length with (the records keep the two apart; the product is formed once per visit instead of once per crossing)
+    double r[3], v[3], tau_req = 0.0, tau_ach = 0.0, chi[ND], ke[ND];
     double inv[3];                            // RN(1 / v) per axis, see find_wall_ahead
-    int iu[3];
+    int iu[3], smask[3];                      // iu = 1 where v > 0; smask = the sign bit where v <= 0: fixed during a visit
     bool v_ok = true;                         // no direction component is so small that 1 / v or d / v could overflow
     double hit_t = 0.0, hit_tau = 0.0;       // LS_HIT: step length to the wall and optical depth of the cell
     double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
@@ -1604,38 +1112,27 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                                               //  took the kernel from 119 to 124 VGPRs and cost more than the ordering saves)
 #define SLOT (slot & 0x3fffffff)
     int st = LS_IDLE;
-    bool exhausted = loader, pre = false;
+    bool exhausted = false, pre = false;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; inv[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; sgn[a] = 1.0; iu[a] = 1; }
+    for (int a = 0; a < 3; a++) { r[a] = 0.0; v[a] = 1.0; inv[a] = 1.0; cell.ic[a] = 0; cell.ow[a] = 0; smask[a] = 0; iu[a] = 1; }
 #pragma unroll
-    for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
+    for (int d = 0; d < ND; d++) { chi[d] = 0.0; ke[d] = 0.0; }
 
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
-    int wl_slots = -1, wl_pos = 0, wl_n = 0;      // HYP_TILE_WCLAIM: the wave's block of the queue (wl_pos, wl_n, wl_end wave-uniform)
-    bool wl_end = false;
-    static_assert(!(HYP_TILE_WCLAIM && HYP_TILE_PREFETCH > 0), "the per-lane record prefetch belongs to the per-lane claim");
 #ifdef HYP_TILE_STATS
     unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_wb = 0, dbg_claim = 0, dbg_nclaim = 0, dbg_nwb = 0, dbg_ncheck = 0, dbg_chk = 0;
     const long long dbg_t0 = clock64();
 #endif
     for (;;) {
-        if (queue_empty && st == LS_IDLE && claim < 0) exhausted = true;
-        // RING: records [0, tail_now) of the task's queue have landed; a lane whose claimed record has not waits without
-        // asking for a service phase
-        const int tail_now = RING ? __hip_atomic_load(ring.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-        // landed records nobody has claimed yet: an idle lane asks for a packet only when there is one to be had
-        const int next_now = RING ? __hip_atomic_load(&next_pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0;
-        const bool can_take = !RING || next_now < tail_now || next_now >= tk.len;
+        if (queue_empty && st == LS_IDLE) exhausted = true;
         const unsigned long long m_walk = __ballot(st == LS_WALK);
         const unsigned long long m_out = __ballot(st >= LS_LEFT);      // anything the service phase must look at
-        const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted && (!RING || (claim >= 0 ? claim < tail_now : can_take)));
-        const unsigned long long m_wait = RING ? __ballot(st == LS_IDLE && !exhausted && (claim >= 0 ? claim >= tail_now : !can_take)) : 0ull;
-        if (!(m_walk | m_out | m_idle | m_wait)) break;
-        if (RING && !(m_walk | m_out | m_idle)) __builtin_amdgcn_s_sleep(8);      // everybody waits for the loader (nothing below runs)
+        const unsigned long long m_idle = __ballot(st == LS_IDLE && !exhausted);
+        if (!(m_walk | m_out | m_idle)) break;
         // Tail of a task: the queue is empty and only a few lanes of this wave still walk.  Their
         // packets go back to their slots as they are (same brick) and continue in the next
         // generation in a full wave, instead of dragging a nearly empty wave along.
-        const bool park = !(m_idle | m_wait) && queue_empty && __popcll(m_walk) <= T.park;
+        const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_TILE_SERVICE || !m_walk))) {
 #ifdef HYP_TILE_STATS
@@ -1646,8 +1143,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             if (st == LS_CHECK) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
-                const int bx0[3] = {x0, y0, z0}, bx1[3] = {x1, y1, z1};
-                if (RING ? in_correct_cell_brick(W, grid_bounds, bx0, bx1, r, cell) : geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
+                if (geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
                 else { cnt.killed_geo++; st = LS_DEAD; }
             }
             // packets that round-off left outside their cell: the general wall search, handed to the
@@ -1678,18 +1174,12 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 tau_ach += tau_needed;
                 geo_clear_wall(cell);
 #pragma unroll
-                for (int d = 0; d < ND; d++) {
-#if HYP_TILE_DENS_LDS
-                    const double rho = dens[hit_lc * ND + d];
-#else
-                    const double rho = P.density[(((size_t)cell.ic[2] * P.n2 + cell.ic[1]) * P.n1 + cell.ic[0]) * ND + d];
-#endif
-                    if (rho > 0.0) TILE_DEPOSIT(&accum[hit_lc * ND + d], tact * kappa[d] * energy);
-                }
+                for (int d = 0; d < ND; d++)
+                    if (dens[hit_lc * ND + d] > 0.0) TILE_DEPOSIT(&accum[hit_lc * ND + d], tact * ke[d]);
             }
             if (st == LS_DEAD) {
                 hot[SLOT].state = TS_DEAD; slot_brick[SLOT] = TILE_NEEDS_PREPARE;
-                if (T.split) dlist[tk.start + atomicAdd(&n_dead_l, 1)] = SLOT;
+                dlist[tk.start + atomicAdd(&n_dead_l, 1)] = SLOT;
                 finished++; st = LS_IDLE;
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[SLOT];
@@ -1701,16 +1191,14 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 if (st == LS_REABS) { H.state = TS_REEMIT; slot_brick[SLOT] = TILE_NEEDS_REEMIT; }
                 else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[SLOT] = TILE_NEEDS_INTERACT; }
                 else if (st == LS_LEFT) {                                             // H.state stays TS_WALK
-                    if (T.split) {
-                        // one cell step leaves the brick through a face, an edge or a corner
-                        const int dx = cell.ic[0] < x0 ? -1 : (cell.ic[0] >= x1 ? 1 : 0);
-                        const int dy = cell.ic[1] < y0 ? -1 : (cell.ic[1] >= y1 ? 1 : 0);
-                        const int dz = cell.ic[2] < z0 ? -1 : (cell.ic[2] >= z1 ? 1 : 0);
-                        slot_brick[SLOT] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
-                        atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
-                    } else slot_brick[SLOT] = brick_of(T, cell.ic);
-                } else if (T.split) atomicAdd(&nb_cnt[13], 1u);                      // parked: same brick again
-                if (T.split && (st == LS_REABS || st == LS_HIT)) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? slot : SLOT;
+                    // one cell step leaves the brick through a face, an edge or a corner
+                    const int dx = cell.ic[0] < x0 ? -1 : (cell.ic[0] >= x1 ? 1 : 0);
+                    const int dy = cell.ic[1] < y0 ? -1 : (cell.ic[1] >= y1 ? 1 : 0);
+                    const int dz = cell.ic[2] < z0 ? -1 : (cell.ic[2] >= z1 ? 1 : 0);
+                    slot_brick[SLOT] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
+                    atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
+                } else atomicAdd(&nb_cnt[13], 1u);                                    // parked: same brick again
+                if (st == LS_REABS || st == LS_HIT) ilist[tk.start + atomicAdd(&n_int_l, 1)] = (T.presort && st == LS_HIT) ? slot : SLOT;
                 st = LS_IDLE;
             }
             if (park) break;
@@ -1719,109 +1207,33 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             const long long dbg_tw = clock64();
             dbg_wb += (unsigned long long)(dbg_tw - dbg_tc); dbg_nclaim += __popcll(__ballot(st == LS_IDLE && !exhausted));
 #endif
-            // the wave's block of the task's queue: lane i holds the slot of entry wl_base + i; entries [wl_pos, wl_n) are still to be had
-            int wslot = -1;
-            if (HYP_TILE_WCLAIM && !RING) {
-                const bool wants = st == LS_IDLE && !exhausted;
-                const unsigned long long want = __ballot(wants);
-                if (want) {
-                    if (wl_pos == wl_n && !wl_end) {
-                        int base = 0;
-                        if (__lane_id() == 0) base = atomicAdd(&next_pkt, 64);
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        wl_n = max(0, min(64, tk.len - base)); wl_pos = 0;
-                        wl_end = wl_n == 0;
-                        wl_slots = (int)__lane_id() < wl_n ? order[tk.start + base + (int)__lane_id()] : -1;
-                        if (HYP_TILE_WCLAIM > 1 && wl_slots >= 0) tile_prefetch(&hot[wl_slots], pf_lds);
-                    }
-                    const int rank = __popcll(want & ((1ull << __lane_id()) - 1ull));
-                    const int avail = wl_n - wl_pos;
-                    const int s_of = __shfl(wl_slots, (wl_pos + rank) & 63, 64);
-                    if (wants && rank < avail) wslot = s_of;
-                    wl_pos += min(avail, (int)__popcll(want));
-                }
-            }
             if (st == LS_IDLE && !exhausted) {
-                int j = RING ? claim : -1;
-                if (HYP_TILE_WCLAIM && !RING) j = wslot >= 0 ? 0 : (wl_end ? tk.len : -2);      // -2: the block ran out, served in the next service phase
-                else
-                if (RING && j < 0) {
-                    // the lanes that want a packet share the landed, unclaimed records between them (rank order); the others
-                    // keep waiting.  Another wave may get in between the look and the reservation: a lane that ends up
-                    // with a record still in flight holds on to the claim.
-                    const unsigned long long want = __ballot(true);
-                    const int rank = __popcll(want & ((1ull << __lane_id()) - 1ull)), first = __ffsll((long long)want) - 1;
-                    int take = 0, base = 0;
-                    if (rank == 0) {
-                        const int cur = __hip_atomic_load(&next_pkt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        take = cur >= tk.len ? __popcll(want) : min(__popcll(want), max(tail_now - cur, 0));
-                        if (take > 0) base = atomicAdd(&next_pkt, take);
-                    }
-                    take = __shfl(take, first, 64); base = __shfl(base, first, 64);
-                    j = rank < take ? base + rank : -2;
-                } else if (j < 0) j = atomicAdd(&next_pkt, 1);
-                if (j == -2) { }                                   // RING: nothing landed for this lane yet
-                else if (j >= tk.len) exhausted = true;
-                else if (RING && j >= tail_now) claim = j;        // not landed yet: the lane waits (m_wait)
+                const int j = atomicAdd(&next_pkt, 1);
+                if (j >= tk.len) exhausted = true;
                 else {
-                    if (RING) slot = ring.slot_of(j); else if (HYP_TILE_WCLAIM) slot = wslot; else slot = order[tk.start + j];
-                    int slot_ahead = 0;
-                    if (HYP_TILE_PREFETCH > 0 && !RING && j + HYP_TILE_PREFETCH < tk.len) slot_ahead = order[tk.start + j + HYP_TILE_PREFETCH];
-#if HYP_TILE_BULK_LOAD
-                    // the whole record in one batch of 16-byte loads and ONE wait: read field by field, the compiler issues the loads
-                    // where the fields are first used -- three batches with a wait each, behind the branches of the v_ok test
-                    // (profiles/r04_tiled_log.md: the claim was 60 % of a service phase's clocks)
-                    union RecWords { uint4 q[sizeof(HotRec<ND>) / 16]; HotRec<ND> h; };
-                    RecWords U;
-                    if (!RING) {
-                        const uint4 *__restrict__ src = (const uint4 *)&hot[SLOT];
-#pragma unroll
-                        for (int i = 0; i < (int)(sizeof(HotRec<ND>) / 16); i++) U.q[i] = src[i];
-#pragma unroll
-                        for (int i = 0; i < (int)(sizeof(HotRec<ND>) / 16); i += 2)
-                            asm volatile("" : "+v"(U.q[i].x), "+v"(U.q[i].y), "+v"(U.q[i].z), "+v"(U.q[i].w),
-                                              "+v"(U.q[i + 1].x), "+v"(U.q[i + 1].y), "+v"(U.q[i + 1].z), "+v"(U.q[i + 1].w));
-                    }
-                    const HotRec<ND> &H = RING ? ring.record(j) : U.h;
-#else
-                    const HotRec<ND> &H = RING ? ring.record(j) : hot[SLOT];
-#endif
-                    claim = -1;
+                    slot = order[tk.start + j];
+                    const HotRec<ND> &H = hot[SLOT];
                     v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
                         r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a];
-                        iu[a] = v[a] > 0.0 ? 1 : 0; sgn[a] = v[a] > 0.0 ? 1.0 : (v[a] < 0.0 ? -1.0 : 0.0);
+                        iu[a] = v[a] > 0.0 ? 1 : 0; smask[a] = v[a] > 0.0 ? 0 : (int)0x80000000;
                         inv[a] = 1.0 / v[a];
                         v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400));
                     }
                     unpack_ow(H.ow, cell.ow);
-                    tau_req = H.tau_req; tau_ach = H.tau_ach; energy = H.energy;
+                    tau_req = H.tau_req; tau_ach = H.tau_ach;
 #pragma unroll
-                    for (int d = 0; d < ND; d++) { chi[d] = H.chi[d]; kappa[d] = H.kappa[d]; }
+                    for (int d = 0; d < ND; d++) { chi[d] = H.chi[d]; ke[d] = H.kappa[d] * H.energy; }
                     unsigned long long id = H.id;
                     g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
-#ifndef HYP_TILE_NO_KIND      // (tuning builds: the walk without it)
                     slot |= (H.pad & 1) << 30;
-#endif
                     if (any_intersect) { t_src = cold[SLOT].t_src; t_ach = cold[SLOT].t_ach; }
-                    if (RING) ring.taken(j);
-                    if (HYP_TILE_PREFETCH > 0 && !RING) {
-                        // every value loaded above is "used" here: the compiler waits for them now and has nothing in flight
-                        // when the prefetches go out
-                        asm volatile("" :: "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(tau_req), "v"(tau_ach), "v"(energy),
-                                     "v"(g.id_lo), "v"(g.id_hi), "v"(g.countdown), "v"(g.blk_b), "v"(cell.ic[0]), "v"(cell.ic[1]), "v"(cell.ic[2]),
-                                     "v"(cell.ow[0]), "v"(cell.ow[1]), "v"(cell.ow[2]), "v"(t_src), "v"(t_ach), "v"(slot_ahead));
-#pragma unroll
-                        for (int d = 0; d < ND; d++) asm volatile("" :: "v"(chi[d]), "v"(kappa[d]));
-                        if (j + HYP_TILE_PREFETCH < tk.len) tile_prefetch(&hot[slot_ahead], pf_lds);
-                        if (j + 2 * HYP_TILE_PREFETCH < tk.len) tile_prefetch(&order[tk.start + j + 2 * HYP_TILE_PREFETCH], pf_lds);
-                    }
                     st = LS_WALK; pre = false;
                 }
             }
-            if (__ballot(exhausted && !loader)) queue_empty = true;
+            if (__ballot(exhausted)) queue_empty = true;
 #ifdef HYP_TILE_STATS
             __builtin_amdgcn_s_waitcnt(0);      // charge the loads of the refill to the service phase
             dbg_service += (unsigned long long)(clock64() - dbg_ts); dbg_nservice++; dbg_claim += (unsigned long long)(clock64() - dbg_tw);
@@ -1840,7 +1252,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                 // rare events wait for the service phase: they would cost every step of the wave
                 // their full code path for one or two lanes
                 double tmin; int im[3]; bool found;
-                bool simple = find_wall_ahead(W, r, v, inv, iu, sgn, cell, tmin, im, found) && v_ok;
+                bool simple = find_wall_ahead(W, r, v, inv, iu, smask, cell, tmin, im, found) && v_ok;
                 if (pre) {      // wall found by geo_find_wall in the service phase
                     tmin = hit_t; im[0] = (hit_lc & 3) - 1; im[1] = ((hit_lc >> 2) & 3) - 1; im[2] = ((hit_lc >> 4) & 3) - 1;
                     found = true; simple = true;
@@ -1852,15 +1264,11 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                     pre = false;
                     g.countdown--;
                     const int lc = ((cell.ic[2] - z0) * BY + (cell.ic[1] - y0)) * BX + (cell.ic[0] - x0);
-                    double rho[ND], chi_rho = 0.0;
+                    double rho[ND], chi_rho;
 #pragma unroll
                     for (int d = 0; d < ND; d++) {
-#if HYP_TILE_DENS_LDS
                         rho[d] = dens[lc * ND + d];
-#else
-                        rho[d] = P.density[(((size_t)cell.ic[2] * P.n2 + cell.ic[1]) * P.n1 + cell.ic[0]) * ND + d];
-#endif
-                        chi_rho += chi[d] * rho[d];
+                        chi_rho = d == 0 ? chi[0] * rho[0] : chi_rho + chi[d] * rho[d];      // (the reference's sum starts at +0: the same value, a signed zero aside, which no comparison below tells apart)
                     }
                     const double tau_cell = chi_rho * tmin;
                     cnt.crossings++;
@@ -1872,7 +1280,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
                         for (int a = 0; a < 3; a++) r[a] = r[a] + tmin * v[a];
                         tau_ach += tau_cell;
 #pragma unroll
-                        for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[lc * ND + d], tmin * kappa[d] * energy);
+                        for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[lc * ND + d], tmin * ke[d]);
                         geo_advance(P, r, cell, im);
                         // x1, y1, z1 are clipped to the grid, so leaving the grid is leaving the brick
                         if (cell.ic[0] < x0 || cell.ic[0] >= x1 || cell.ic[1] < y0 || cell.ic[1] >= y1 ||
@@ -1885,15 +1293,12 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             }
         }
     }
-    if ((HYP_TILE_PREFETCH > 0 || HYP_TILE_WCLAIM > 1) && !RING) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // prefetches still in flight
     __syncthreads();
-    if (T.split) {
-        if (threadIdx.x < 27 && nb_cnt[threadIdx.x]) {
-            const int dx = (int)threadIdx.x % 3 - 1, dy = ((int)threadIdx.x / 3) % 3 - 1, dz = (int)threadIdx.x / 9 - 1;
-            atomicAdd(&counts[tk.brick + dx + T.nbx * (dy + T.nby * dz)], nb_cnt[threadIdx.x]);
-        }
-        tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);
+    if (threadIdx.x < 27 && nb_cnt[threadIdx.x]) {
+        const int dx = (int)threadIdx.x % 3 - 1, dy = ((int)threadIdx.x / 3) % 3 - 1, dz = (int)threadIdx.x / 9 - 1;
+        atomicAdd(&counts[tk.brick + dx + T.nbx * (dy + T.nby * dz)], nb_cnt[threadIdx.x]);
     }
+    tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);
     // flush the brick's accumulators (replica chosen like in the persistent kernel)
     double *sum = P.sum;
     if (P.n_copies > 1) {
@@ -1908,11 +1313,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) HYP_WALK_ATTR void tile_
             size_t gidx = ((size_t)gz * P.n2 + gy) * P.n1 + gx;
             for (int d = 0; d < ND; d++) {
                 double val = accum[c * ND + d];
-#ifndef HYP_TILE_ABLATE_FLUSH
                 if (val != 0.0) hyp_atomic_add_g(&sum[gidx * ND + d], val);
-#else
-                (void)val; (void)sum;
-#endif
             }
         }
     }
