@@ -17,19 +17,11 @@
 
 #include "hyp_tiled.h"
 
-#ifndef HYP_ATILE_WG
-#define HYP_ATILE_WG 768          // threads per workgroup (one workgroup per task; one per CU with bricks of 32 x 16 x 16 cells: two of 512 threads ->
+constexpr int HYP_ATILE_WG = 768;          // threads per workgroup (one workgroup per task; one per CU with bricks of 32 x 16 x 16 cells: two of 512 threads ->
                                   // one of 1024: 216.1 -> 200.9 ms on the three-level nest; 768 threads at 167 VGPRs, nothing spilled: 204.0 -> 177.9 ms)
-#endif
-#ifndef HYP_ATILE_OCC
-#define HYP_ATILE_OCC 3          // waves per SIMD the register budget is set for (12 waves per CU; at 4 the walk spilled 40 VGPRs in the step loop)
-#endif
-#ifndef HYP_ATILE_SERVICE
-#define HYP_ATILE_SERVICE 24      // lanes that must wait before a wave runs its service phase (16 with 4 steps: 235.5 ms, 24 with 8: 224.2)
-#endif
-#ifndef HYP_ATILE_STEPS
-#define HYP_ATILE_STEPS 8         // cell steps between two scheduling decisions of a wave
-#endif
+constexpr int HYP_ATILE_OCC = 3;          // waves per SIMD the register budget is set for (12 waves per CU; at 4 the walk spilled 40 VGPRs in the step loop)
+constexpr int HYP_ATILE_SERVICE = 24;      // lanes that must wait before a wave runs its service phase (16 with 4 steps: 235.5 ms, 24 with 8: 224.2)
+constexpr int HYP_ATILE_STEPS = 8;         // cell steps between two scheduling decisions of a wave
 #define AT_HIST 256               // slabs whose packet counts a task collects in LDS (the others: global atomics)
 
 enum { LS_ASLOW = 8, LS_AGRID = 9 };      // a whole step / the arrival in another grid through the general functions

@@ -18,26 +18,13 @@
 #pragma once
 #include "hyp_kernels.h"
 
-#ifndef HYP_PAIR_CHUNK
-#define HYP_PAIR_CHUNK 256      // (event, view) pairs a wave of the peel kernel reserves at a time
-#endif
-#ifndef HYP_PEEL_REFILL
-#define HYP_PEEL_REFILL 32      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
-#endif
-#ifndef HYP_PEEL_OCC
-#define HYP_PEEL_OCC 3        // workgroups of the peel kernel per CU the register budget is set for
-#endif
-#ifndef HYP_DEFER_STEPS
+constexpr int HYP_PAIR_CHUNK = 256;      // (event, view) pairs a wave of the peel kernel reserves at a time
+constexpr int HYP_PEEL_REFILL = 32;      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
+constexpr int HYP_PEEL_OCC = 3;        // workgroups of the peel kernel per CU the register budget is set for
 // cell crossings of the propagation kernel between two state checks (configs[3], 1e8 packets, emission and forced first interaction made
 // ahead of the rounds: 8 / 12 / 16 crossings 331.8 / 325.4 / 326.0 ms)
-#define HYP_DEFER_STEPS (GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>())
-#endif
-#ifndef HYP_CAR_INV
-#define HYP_CAR_INV 1           // Cartesian grids: the walks of the deferred schedule search the wall with one reciprocal per direction (car_find_wall_inv)
-#endif
-#ifndef HYP_PEEL_STEPS
-#define HYP_PEEL_STEPS 16       // cell crossings between two refill / deposit checks
-#endif
+template <int GEOM> __host__ __device__ constexpr int defer_steps() { return GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>(); }
+constexpr int HYP_PEEL_STEPS = 16;       // cell crossings between two refill / deposit checks
 
 template <int NDT, int GEOM>
 struct alignas(16) PeelEvent {
@@ -102,7 +89,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
     double tmin; int im[3];
     bool found;
     if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
-    else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
+    else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
     else found = geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
     if (!found) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
     const size_t base = geo_index(P, p.cell) * (size_t)nd;
@@ -405,12 +392,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
             const bool do_peel = peel != 0 && (!P.peel_scattered_only || (peel == 2 && last == LAST_DS) || peel == 3);       // (a re-emission is peeled in any case: "a kind of scattering", iter_final.f90:226-227)
             const unsigned long long m = __ballot(do_peel);
             if (m) {
-#ifdef HYP_DEFER_NO_WRITE       // tuning builds: what writing the events costs (the images are wrong)
-                if (do_peel) p.peel_seq++;
-                if (false) {
-#else
                 if (do_peel) {
-#endif
                     PeelEvent<NDT, GEOM> &E = ev[w_pos + __popcll(m & lt)];
                     E.r[0] = p.r[0]; E.r[1] = p.r[1]; E.r[2] = p.r[2]; E.nu = p.nu; E.energy = p.energy;
                     E.a_prev = a_prev;
@@ -427,7 +409,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 w_pos += __popcll(m); n_written += __popcll(m);
             }
             if (peel != 0) {
-                if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {         // the direction is new
+                if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {         // the direction is new
                     v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
@@ -484,7 +466,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
         }
 
 #pragma unroll 1
-        for (int k = 0; k < HYP_DEFER_STEPS; k++) {
+        for (int k = 0; k < defer_steps<GEOM>(); k++) {
             if (FFS) { if (st == ST_WALK || st == ST_FF) st = defer_step<NDT, GEOM>(P, W, p, g, cnt, st == ST_FF, inv, v_ok); }
             else if (st == ST_WALK) st = defer_step<NDT, GEOM, GEN>(P, W, p, g, cnt, false, inv, v_ok);
         }
@@ -519,12 +501,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 // code nor the ST_FF state: a lane that takes an id loads the record, writes the emission's peel-off event and walks.
 // Crossings and packets killed by the escape walk are counted here, once; energy_current by the propagation kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef HYP_FF_OCC
-#define HYP_FF_OCC 3
-#endif
-#ifndef HYP_FF_REFILL
-#define HYP_FF_REFILL 32
-#endif
+constexpr int HYP_FF_OCC = 3;
+constexpr int HYP_FF_REFILL = 32;
 
 template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem *__restrict__ Pp, LaunchParams L, DeferBuf B)
@@ -606,7 +584,7 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
                         R.energy = p.energy; R.tau_req = 0.0;
                         R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b; R.code = (g.have_a & 1) | (1 << 1); R.countdown = g.countdown;
                     } else {
-                        if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
+                        if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
                             v_ok = true;
 #pragma unroll
                             for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
@@ -758,7 +736,7 @@ __global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__res
             angle_to_vector(a_req, v[0], v[1], v[2]);
             double inv[3] = {1.0, 1.0, 1.0};
             bool v_ok = true;
-            if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
+            if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
 #pragma unroll
                 for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
             }
@@ -775,7 +753,7 @@ __global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__res
                     double tmin = 0.0; int im[3];
                     bool found;
                     if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                    else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                    else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
                     else found = geo_find_wall(P, W, r, v, c, tmin, im);
                     if (!found) { status = 2; break; }
                     const size_t base = geo_index(P, c) * (size_t)nd;
@@ -919,7 +897,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         }
                     }
                     angle_to_vector(a_req, v[0], v[1], v[2]);
-                    if (GEOM == GEOM_OCT || (GEOM == GEOM_CAR && HYP_CAR_INV)) {
+                    if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
                         v_ok = true;
 #pragma unroll
                         for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
@@ -991,7 +969,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 double tmin = 0.0; int im[3];
                 bool found;
                 if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                else if constexpr (GEOM == GEOM_CAR && HYP_CAR_INV) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+                else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
                 else found = geo_find_wall(P, W, r, v, c, tmin, im);
                 if (!check_ok || !found) { cnt.killed_geo++; st = 0; }
                 else {
@@ -1016,9 +994,6 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
             }
         }
 
-#ifdef HYP_PEEL_NO_DEPOSIT      // tuning builds: what the image atomics cost
-        if (st == 2) st = 0;
-#endif
         if (__ballot(st == 2)) {
             double sa[4] = {0.0, 0.0, 0.0, 0.0};
             bool live = false;

@@ -5,17 +5,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define HYP_MAXD 8
+constexpr int HYP_MAXD = 8;
 #define SPOT_STRIDE 11
-#define HYP_PI 3.14159265358979323846
-#define HYP_TWOPI 6.28318530717958647692
-#define HYP_H_CGS 6.6260755e-27
-#define HYP_K_CGS 1.380658e-16
-#define HYP_C_CGS 29979245800.0
-#define HYP_STEF_BOLTZ 5.67051e-5
-#define HYP_DBL_MAX 1.7976931348623157e308
-#define HYP_INF __builtin_huge_val()
-#define HYP_DBL_MIN 2.2250738585072014e-308
+constexpr double HYP_PI = 3.14159265358979323846;
+constexpr double HYP_TWOPI = 6.28318530717958647692;
+constexpr double HYP_H_CGS = 6.6260755e-27;
+constexpr double HYP_K_CGS = 1.380658e-16;
+constexpr double HYP_C_CGS = 29979245800.0;
+constexpr double HYP_STEF_BOLTZ = 5.67051e-5;
+constexpr double HYP_DBL_MAX = 1.7976931348623157e308;
+constexpr double HYP_INF = __builtin_huge_val();
+constexpr double HYP_DBL_MIN = 2.2250738585072014e-308;
 
 // One dust species, tables resident in HBM (read-mostly, L2/MALL cached).
 // Built on the host by build_dust_tables() following dust_type_4elem.f90:78-293.
@@ -316,9 +316,7 @@ struct LaunchParams {
 };
 
 // Deferred peel-off (hyp_defer.h): control block and buffers of one {propagate, peel} round
-#ifndef HYP_PEEL_CHUNK
-#define HYP_PEEL_CHUNK 512      // event slots a wave reserves at a time (one same-address atomic per chunk)
-#endif
+constexpr int HYP_PEEL_CHUNK = 512;      // event slots a wave reserves at a time (one same-address atomic per chunk)
 struct PeelCtl {
     unsigned long long reserved;        // event slots reserved in this round (failed reservations count: may exceed the capacity)
     unsigned long long pair_cursor;     // (event, view) pairs handed out by the peel kernel
@@ -354,11 +352,9 @@ struct DeferBuf {
     void *ff;
     const DirectCol *direct;            // [n_sources x n_views_total] or null (option direct_memo = 0, memory)
 };
-#define HYP_SORT_EMPTY 0xffffffffu
-#ifndef HYP_SORT_MAX_BINS
-#define HYP_SORT_MAX_BINS 4096
-#endif
-#define HYP_SORT_PER_WG 8192      // event slots per workgroup of the sort kernels
+constexpr unsigned int HYP_SORT_EMPTY = 0xffffffffu;
+constexpr int HYP_SORT_MAX_BINS = 4096;
+constexpr int HYP_SORT_PER_WG = 8192;      // event slots per workgroup of the sort kernels
 
 // ---------------------------------------------------------------------------
 // Philox4x32-10, one stream pair per packet (counter = packet id, block, stream)
@@ -510,7 +506,7 @@ __device__ __forceinline__ double sample_log_pdf(const double *__restrict__ x, c
 // log2(n / HYP_COARSE) short-latency steps plus ONE trip to the row itself, instead of log2(n)
 // dependent trips.  Both searches return the last j with cdf[j] <= xi, like locate() (whose
 // edge rules are reproduced), so the result is the same number.
-#define HYP_COARSE 8
+constexpr int HYP_COARSE = 8;
 __device__ __forceinline__ void sample_log_pdf_pair(const double *__restrict__ x, const double *__restrict__ cdf_a, const double *__restrict__ cdf_b,
                                                     const double *__restrict__ bp1_a, const double *__restrict__ bp1_b,
                                                     const double *__restrict__ co_a, const double *__restrict__ co_b, int n, int nc, double xi,

@@ -400,19 +400,19 @@ DeferKernels pick_defer_kernels(int nd, int grid_type)
 
 LucyKernel pick_final_kernel(int nd, int grid_type, int mode)
 {
-#define HYP_PICK_FINAL(G) (mode == 0 || nd > 4 ? pick_final_kernel_g<G>(nd) : pick_final_special_g<G>(nd, mode))
+#define PICK_FINAL(G) (mode == 0 || nd > 4 ? pick_final_kernel_g<G>(nd) : pick_final_special_g<G>(nd, mode))
 #ifdef HYP_VARIANT_GEOM
-    return HYP_PICK_FINAL(HYP_VARIANT_GEOM);
+    return PICK_FINAL(HYP_VARIANT_GEOM);
 #endif
     switch (grid_type) {
-    case 2: return HYP_PICK_FINAL(GEOM_OCT);
-    case 3: return HYP_PICK_FINAL(GEOM_VOR);
-    case 4: return HYP_PICK_FINAL(GEOM_AMR);
-    case 5: return HYP_PICK_FINAL(GEOM_SPH);
-    case 6: return HYP_PICK_FINAL(GEOM_CYL);
-    default: return HYP_PICK_FINAL(GEOM_CAR);
+    case 2: return PICK_FINAL(GEOM_OCT);
+    case 3: return PICK_FINAL(GEOM_VOR);
+    case 4: return PICK_FINAL(GEOM_AMR);
+    case 5: return PICK_FINAL(GEOM_SPH);
+    case 6: return PICK_FINAL(GEOM_CYL);
+    default: return PICK_FINAL(GEOM_CAR);
     }
-#undef HYP_PICK_FINAL
+#undef PICK_FINAL
 }
 
 }  // namespace
@@ -465,9 +465,6 @@ void polar_tile_shape(const DProblem &P, int nd, int lds_kb, int &x, int &y, int
     while ((long long)y * z * 16 > cells && y > 1) y = (y + 1) / 2;
     while ((long long)y * z * 16 > cells && z > 1) z = (z + 1) / 2;
     x = (int)std::max<long long>(1, std::min<long long>(P.n1, cells / ((long long)y * z)));
-    // the FP32 wall tables of the brick (tile_walk_lds) come out of the same budget
-    const long long budget = (long long)lds_kb * 1024 - 4ll * (2 * y + 8);
-    x = (int)std::max<long long>(1, std::min<long long>(x, budget / (16ll * nd * y * z + 4)));
 }
 
 // Number of bricks of a polar grid on the tiled schedule, or -1 when the grid has no such schedule: more bricks than the sort's
@@ -477,8 +474,8 @@ long long polar_tile_bricks(const DProblem &P, int nd, int lds_kb)
     int bx, by, bz;
     polar_tile_shape(P, nd, lds_kb, bx, by, bz);
     const long long nb = (long long)((P.n1 + bx - 1) / bx) * ((P.n2 + by - 1) / by) * ((P.n3 + bz - 1) / bz);
-    const size_t lds = sizeof(double) * 2 * (size_t)bx * by * bz * nd + sizeof(float) * (size_t)(bx + 2 * by + 8);
-    return (nb <= HYP_TILE_MAX_BRICKS && lds <= 160u * 1024u) ? nb : -1;
+    const size_t lds = sizeof(double) * 2 * (size_t)bx * by * bz * nd;
+    return (nb <= HYP_TILE_MAX_BRICKS && lds + 4096 <= 160u * 1024u) ? nb : -1;      // (4 KB: the kernel's static LDS -- counters, brick histogram)
 }
 
 // LDS of one AMR brick (hyp_atile.h): n cells, g goto entries (16 bits), w walls
@@ -493,7 +490,7 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T)
     if (h->hp.grid_type == 3)       // cluster: its tables (VtInfo) + densities + accumulators
         return h->vt_max_lds;
     if (h->hp.grid_type == 5 || h->hp.grid_type == 6)      // polar brick: densities + accumulators
-        return sizeof(double) * 2 * (size_t)T.bx * T.by * T.bz * K.nd + sizeof(float) * (size_t)(T.bx + 2 * T.by + 8);      // + the FP32 wall tables of sph_fast_wall
+        return sizeof(double) * 2 * (size_t)T.bx * T.by * T.bz * K.nd;
     if (h->hp.grid_type == 4)       // slab: densities + accumulators + walls + goto slice
         return amr_slab_lds((size_t)T.bx, (size_t)T.by, (size_t)T.bz, K.nd);
     if (h->hp.grid_type == 2)       // cluster: cell records + densities + accumulators + children of the refined cells + neighbour table
@@ -631,17 +628,6 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
             if (hipEventElapsedTime(&ms, h->walk_events[i], h->walk_events[i + 1]) == hipSuccess) { h->last_walk_ms += ms; h->last_walk_launches++; }
         }
     }
-#ifdef HYP_PREP_STATS
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
-    {
-        const unsigned long long *d = h->h_ctl->dbg;
-        double tot = 0; for (int i = 0; i < 5; i++) tot += (double)d[16 + i];
-        fprintf(stderr, "prepare stats: waves %llu; wave-clock share scan %.3f state-load %.3f interact %.3f emit %.3f store %.3f (total %.3e ticks); "
-                        "interact passes %llu (%.1f lanes), emit passes %llu (%.1f lanes)\n", d[28], d[16] / tot, d[17] / tot, d[18] / tot, d[19] / tot,
-                d[20] / tot, tot, d[24], (double)d[26] / (d[24] ? d[24] : 1), d[25], (double)d[27] / (d[25] ? d[25] : 1));
-    }
-#endif
 #ifdef HYP_TILE_STATS
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h->h_ctl, h->d_ctl, sizeof(TileCtl), hipMemcpyDeviceToHost);
@@ -2960,19 +2946,15 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     std::string n(name);
     if (n == "interact_threshold") h->interact_threshold = (int)value;
     else if (n == "emit_threshold") h->emit_threshold = (int)value;
-    else if (n == "final_interact_threshold") h->final_interact_threshold = (int)value;
-    else if (n == "final_emit_threshold") h->final_emit_threshold = (int)value;
     else if (n == "accum_copies") h->accum_copies = (int)value;
     else if (n == "blocks_per_cu") h->blocks_per_cu = (int)value;
     else if (n == "chunk") h->chunk = (int)value;
     else if (n == "lucy_mode") h->lucy_mode = (int)value;       // -1 auto, 0 persistent atomics kernel, 1 brick-tiled
     else if (n == "tile_slots") h->tile_slots = (int)value;
-    else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else if (n == "tile_task") h->tile_task = (int)value;
     else if (n == "tile_pools") h->tile_pools = (int)value;
     else if (n == "tile_time_walk") h->tile_time_walk = (int)value;
     else if (n == "plain_imaging") h->plain_imaging = value != 0 && h->plain_imaging;      // can only be switched off
-    else if (n == "lean_imaging") h->lean_imaging = value != 0 && h->lean_imaging;         // can only be switched off
     else if (n == "defer_peel") h->defer_peel = value < 0 ? 0 : value > 3 ? 3 : (int)value;
     else if (n == "mono_defer") h->mono_defer_opt = value ? 1 : 0;
     else if (n == "gen_defer") h->gen_defer_opt = value ? 1 : 0;
@@ -2988,17 +2970,13 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
         }
         h->peel_events = value; h->peel_events_exact = true;
     }
-    else if (n == "tile_drain") h->tile_drain = (int)value;
-    else if (n == "at_cells") { h->at_cells = (int)value; h->at_built_for = -1; h->tile_unbuildable = false; }
-    else if (n == "at_lds_kb") { h->at_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->at_built_for = -1; h->tile_unbuildable = false; }
-    else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
-    else if (n == "ot_lds_kb") { h->ot_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->ot_built_for = -1; h->tile_unbuildable = false; }
-    else if (n == "pt_vsplit") h->pt_vsplit = value ? 1 : 0;
-    else if (n == "tile_presort") h->tile_presort = value ? 1 : 0;
-    else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "vt_cells") { h->vt_cells = (int)value; h->vt_built_for = -1; h->tile_unbuildable = false; }
-    else if (n == "vt_lds_kb") { h->vt_lds_kb = (int)std::max<int64_t>(8, std::min<int64_t>(156, value)); h->vt_built_for = -1; h->tile_unbuildable = false; }      // cells per Voronoi cluster (0: fill the LDS budget)
-    else if (n == "tile_park") h->tile_park = (int)value;
+    // (the tests' handles on the tiled schedules: small clusters / bricks, early drain, a look at the device after every generation)
+    else if (n == "at_cells") { h->at_cells = (int)value; h->at_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
+    else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
+    else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
 }
@@ -3009,8 +2987,6 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     std::string n(name);
     if (n == "interact_threshold") *value = h->interact_threshold;
     else if (n == "emit_threshold") *value = h->emit_threshold;
-    else if (n == "final_interact_threshold") *value = h->final_interact_threshold;
-    else if (n == "final_emit_threshold") *value = h->final_emit_threshold;
     else if (n == "accum_copies") *value = h->accum_copies;
     else if (n == "blocks_per_cu") *value = h->blocks_per_cu;
     else if (n == "chunk") *value = h->chunk;
@@ -3038,32 +3014,15 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "n_photons_inexact") *value = h->nphot_inexact;
     else if (n == "peel_events") *value = h->peel_events;
     else if (n == "plain_imaging") *value = h->plain_imaging ? 1 : 0;
-    else if (n == "lean_imaging") *value = h->lean_imaging ? 1 : 0;
     else if (n == "last_defer_rounds") *value = h->last_defer_rounds;
     else if (n == "last_defer_events") *value = (int64_t)h->last_defer_events;
-    else if (n == "pda_last_outer") *value = h->pda_last_outer;
-    else if (n == "pda_last_sweeps") *value = h->pda_last_sweeps;
-    else if (n == "tile_drain") *value = h->tile_drain;
-    else if (n == "at_cells") *value = h->at_cells;
     else if (n == "at_slabs") *value = h->at_slabs_n;
-    else if (n == "at_max_cells") *value = h->at_max_cells;
-    else if (n == "ot_cells") *value = h->ot_cells;
     else if (n == "ot_clusters") *value = h->ot_clusters;
-    else if (n == "ot_max_cells") *value = h->ot_max_cells;
-    else if (n == "pt_vsplit") *value = h->pt_vsplit;
-    else if (n == "tile_presort") *value = h->tile_presort;
-    else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;
     else if (n == "vt_max_cells") *value = h->vt_max_cells;
-    else if (n == "vt_max_lds") *value = (int64_t)h->vt_max_lds;
     else if (n == "last_vt_exact_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;      // steps of the Voronoi walk that ran the reference's loop
     else if (n.rfind("last_walk_why", 0) == 0 && n.size() == 14 && n[13] >= '0' && n[13] <= '7') *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[30 + (n[13] - '0')] : 0;
-    else if (n == "last_walk_fast_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[37] : 0;     // -DHYP_PTILE_VERIFY builds: steps answered by sph_fast_wall,
-    else if (n == "last_walk_slow_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;     //   by the reference's search,
-    else if (n == "last_walk_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;       //   and disagreements of the two
-    else if (n == "last_vt_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;         // -DHYP_VTILE_VERIFY builds: filter and loop disagreed
-    else if (n == "tile_park") *value = h->tile_park;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with
     else if (n == "last_generations") *value = h->last_generations;   // generations of the last tiled iteration
     else return h->set_error("unknown option: " + n);

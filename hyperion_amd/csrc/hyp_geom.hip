@@ -10,9 +10,6 @@
 #ifndef HYP_GEOM_TU
 #define HYP_GEOM_TU 0   // GEOM_CAR
 #endif
-#ifdef HYP_ONLY_ND1
-#define HYP_ONLY_ND 1
-#endif
 #ifndef HYP_PART
 #error "compile with -DHYP_PART=0..5 (hyperion_amd/build.py)"
 #endif
@@ -78,19 +75,19 @@ LucyKernel pick_final_kernel_g(int nd)      // the general imaging kernel final_
 template <int GEOM>
 LucyKernel pick_final_special_g(int nd, int mode)      // mode 1: plain (final_kernel<.., true>); one to four species
 {
-#define HYP_FINAL_PICK(N) ((void)mode, final_kernel<N, GEOM, true>)      // (mode 2, the lean specialisation of round 3, is gone: its problems run on the deferred schedule's GEN kernels)
+#define FINAL_PICK(N) ((void)mode, final_kernel<N, GEOM, true>)      // (mode 2, the lean specialisation of round 3, is gone: its problems run on the deferred schedule's GEN kernels)
 #ifdef HYP_ONLY_ND
     (void)nd;
-    return HYP_FINAL_PICK(HYP_ONLY_ND);
+    return FINAL_PICK(HYP_ONLY_ND);
 #else
     switch (nd) {
-    case 1: return HYP_FINAL_PICK(1);
-    case 2: return HYP_FINAL_PICK(2);
-    case 3: return HYP_FINAL_PICK(3);
-    default: return HYP_FINAL_PICK(4);
+    case 1: return FINAL_PICK(1);
+    case 2: return FINAL_PICK(2);
+    case 3: return FINAL_PICK(3);
+    default: return FINAL_PICK(4);
     }
 #endif
-#undef HYP_FINAL_PICK
+#undef FINAL_PICK
 }
 #endif
 

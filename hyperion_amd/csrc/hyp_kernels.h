@@ -583,13 +583,7 @@ __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W,
     const int k0 = P.vor_idx[ic], k1 = P.vor_idx[ic + 1];
 #pragma unroll 4
     for (int k = k0; k < k1; k++) {
-#ifdef HYP_VOR_NO_GATHER        // tuning builds: the neighbour's id, then its site from the (L2-resident) site table
-        VorWall w;
-        w.nb = P.vor_neigh[k];
-        { const double *so = P.vor_sites + 3 * (size_t)(w.nb < 0 ? ic : w.nb); w.x = so[0]; w.y = so[1]; w.z = so[2]; }
-#else
         const VorWall w = P.vor_walls[k];
-#endif
         const int nb = w.nb;
         double t; int cand; bool ahead;
         if (nb < 0) {
@@ -831,7 +825,7 @@ __device__ __forceinline__ void begin_integrate(const DProblem &P, Packet<NDT, G
 // recognised by their tag and overwritten.  Exact and independent of the order packets run in; a packet that visits
 // more than 3/4 HYP_VISIT_SLOTS distinct cells (never seen) is counted on every entry from then on and raises
 // DProblem::nphot_inexact.
-#define HYP_VISIT_SLOTS 4096
+constexpr int HYP_VISIT_SLOTS = 4096;
 __device__ __forceinline__ void count_photon(const DProblem &P, size_t ic, unsigned int tag, int &n_visited)
 {
     unsigned long long *tab = P.visit_tab + (size_t)(blockIdx.x * blockDim.x + threadIdx.x) * HYP_VISIT_SLOTS;
@@ -1450,37 +1444,21 @@ __device__ __forceinline__ void stage_walls(const DProblem &P, double *lds, Wall
 // Workgroups per CU the register budget of the persistent kernels is set for (x 4 waves / 4 SIMDs = waves per SIMD).
 // The Cartesian walk is atomic-bound and keeps everything in registers at 2; the Voronoi walk waits on memory (a stream
 // of wall records per crossing) and gains from more waves even though they spill (measured: 167 / 141 / 138 ms at 2 / 3 / 4).
-#ifndef HYP_LUCY_WAVES
-#define HYP_LUCY_WAVES 2
-#endif
-#ifndef HYP_LUCY_WAVES_VOR
-#define HYP_LUCY_WAVES_VOR 4
-#endif
-#ifndef HYP_LUCY_WAVES_OCT
-#define HYP_LUCY_WAVES_OCT 2
-#endif
-#ifndef HYP_FINAL_WAVES
-#define HYP_FINAL_WAVES 2
-#endif
+constexpr int HYP_LUCY_WAVES = 2;
+constexpr int HYP_LUCY_WAVES_VOR = 4;
+constexpr int HYP_LUCY_WAVES_OCT = 2;
+constexpr int HYP_FINAL_WAVES = 2;
 template <int GEOM> constexpr int lucy_waves() { return GEOM == GEOM_VOR ? HYP_LUCY_WAVES_VOR : GEOM == GEOM_OCT ? HYP_LUCY_WAVES_OCT : HYP_LUCY_WAVES; }
-#ifndef HYP_WALK_STEPS
-#define HYP_WALK_STEPS 4        // cell crossings between two looks at the lanes' states, Cartesian grid
-#endif
-#ifndef HYP_WALK_STEPS_TREE
-#define HYP_WALK_STEPS_TREE 16  // octree, Voronoi: a crossing is several dependent loads, fewer state checks pay (configs[3]
-#endif                          // imaging 52.7 -> 50 ms; the Lucy kernels do not care)
-#ifndef HYP_WALK_STEPS_OTHER
-#define HYP_WALK_STEPS_OTHER 8  // AMR, polar grids
-#endif
+constexpr int HYP_WALK_STEPS = 4;        // cell crossings between two looks at the lanes' states, Cartesian grid
+constexpr int HYP_WALK_STEPS_TREE = 16;  // octree, Voronoi: a crossing is several dependent loads, fewer state checks pay (configs[3]                          // imaging 52.7 -> 50 ms; the Lucy kernels do not care)
+constexpr int HYP_WALK_STEPS_OTHER = 8;  // AMR, polar grids
 template <int GEOM> constexpr int walk_steps()
 {
     return GEOM == GEOM_CAR ? HYP_WALK_STEPS : (GEOM == GEOM_OCT || GEOM == GEOM_VOR) ? HYP_WALK_STEPS_TREE : HYP_WALK_STEPS_OTHER;
 }
 // the imaging kernels deposit nothing, so on a Cartesian grid too a longer run between state checks pays (64^3, tau = 1:
 // inline 50.6 -> 47.9 ms, deferred 32.5 -> 31.5 ms; tau = 5 with three views: 533 -> 469, 251 -> 245 ms)
-#ifndef HYP_WALK_STEPS_FINAL_CAR
-#define HYP_WALK_STEPS_FINAL_CAR 16
-#endif
+constexpr int HYP_WALK_STEPS_FINAL_CAR = 16;
 template <int GEOM> constexpr int final_walk_steps() { return GEOM == GEOM_CAR ? HYP_WALK_STEPS_FINAL_CAR : walk_steps<GEOM>(); }
 template <int NDT, int GEOM>
 __global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DProblem *__restrict__ Pp, LaunchParams L)
@@ -1497,11 +1475,7 @@ __global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DPr
         if (P.n_copies > 8) c += 8u * ((blockIdx.x >> 3) % (unsigned)(P.n_copies >> 3));
         sum += (size_t)(c % (unsigned)P.n_copies) * P.copy_stride;
     }
-#ifdef HYP_NO_DEPOSIT
-    constexpr bool kDeposit = false;
-#else
     constexpr bool kDeposit = true;
-#endif
 
     Packet<NDT, GEOM> p;
     Rng g;
@@ -1710,7 +1684,7 @@ struct PeelFlags { int scattered, reprocessed, n_scat, dust_id, source_id; };
 // workgroup therefore keeps partial sums of the addresses its waves hit together in a small LDS table (open hashing
 // without probing: an address that finds its slot taken goes to HBM directly) and adds them to the cube once, when the
 // workgroup ends.
-#define HYP_IMG_CACHE 256       // entries (4 KB of LDS)
+constexpr int HYP_IMG_CACHE = 256;       // entries (4 KB of LDS)
 struct ImgCache { unsigned long long *keys; double *vals; };
 
 __device__ __forceinline__ void img_cache_init(ImgCache &ic, unsigned long long *keys, double *vals)

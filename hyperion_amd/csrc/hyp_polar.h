@@ -299,13 +299,9 @@ __device__ __forceinline__ void sph_wall_cone(const DProblem &P, const double r[
 // flies radially -- every packet until its first interaction, 60 % of the steps -- has pA, pB / 2 rho, pC / rho^2 all equal and the
 // (meaningless) roots at the apex: p(0) and p(T) agree in sign by five orders of magnitude more than needed.  Not applied to the
 // wall the packet sits on (insert_pair and the extension rule look at both roots) nor to the mid-plane (a plane, one division).
-#ifndef HYP_POLAR_HOIST
-#define HYP_POLAR_HOIST 1
-#endif
-#ifndef HYP_POLAR_REACH
-#define HYP_POLAR_REACH 0      // 1: the test in EVERY find_wall.  Measured: 528 against 493 ms on the 400 x 200 grid -- a wave mixes radial and scattered
-#endif                         // packets, so both cones are solved for some lane in almost every wave-step and the test comes on top (profiles/r04_tiled_log.md);
-                               // the tiled walk applies it to the tasks of packets that have not interacted yet (TileGeom::vsplit, hyp_ptile.h)
+// Measured: applied in EVERY find_wall it costs (528 against 493 ms on the 400 x 200 grid: a wave mixes radial and scattered packets, so both
+// cones are solved for some lane in almost every wave-step and the test comes on top, profiles/r04_tiled_log.md); the tiled walk applies it to
+// the tasks of packets that have not interacted yet (TileGeom::vsplit, hyp_ptile.h).
 __device__ __forceinline__ bool sph_cone_out_of_reach(const DProblem &P, const Cell<GEOM_SPH> &c, int side, double v2_xy, double v2_z, double rv_xy, double rv_z,
                                                       double r2_xy, double r2_z, const WallSel &ws)
 {
@@ -336,29 +332,19 @@ __device__ __forceinline__ bool sph_find_wall(const DProblem &P, const Walls &W,
     const double pC = r2_xy + r2_z;
     double t1, t2;
     const int i1 = c.ic[0];
-#if HYP_POLAR_HOIST
     // every table value of the step loaded up front (the cone walls' behind their `if`s came as further dependent batches)
     const int i2 = c.ic[1];
     const double wr2_a = P.wr2[i1], wr2_b = P.wr2[i1 + 1], e0_a = P.ew[0][i1], e0_b = P.ew[0][i1 + 1];
     double e1_a = P.ew[1][i2], e1_b = P.ew[1][i2 + 1], tt_a = P.wtant[i2], tt_b = P.wtant[i2 + 1], tt2_a = P.wtant2[i2], tt2_b = P.wtant2[i2 + 1];
     asm volatile("" : "+v"(e1_a), "+v"(e1_b), "+v"(tt_a), "+v"(tt_b), "+v"(tt2_a), "+v"(tt2_b));
-#else
-    const int i2 = c.ic[1];
-    const double wr2_a = P.wr2[i1], wr2_b = P.wr2[i1 + 1], e0_a = P.ew[0][i1], e0_b = P.ew[0][i1 + 1];
-#endif
     if (!c.radial) {
         quad_reduced(pB, pC - wr2_a, t1, t2);
         insert_pair(ws, t1, t2, c.ow[0] == -1, 0, -1, e0_a);
     }
     quad_reduced(pB, pC - wr2_b, t1, t2);
     insert_pair(ws, t1, t2, c.ow[0] == +1, 0, +1, e0_b);
-#if HYP_POLAR_HOIST
     if (c.ic[1] > 0 && !(reach && sph_cone_out_of_reach(P, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws, e1_a, tt_a, tt2_a);
     if (c.ic[1] < P.n2 - 1 && !(reach && sph_cone_out_of_reach(P, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws, e1_b, tt_b, tt2_b);
-#else
-    if (c.ic[1] > 0 && !(reach && sph_cone_out_of_reach(P, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 0, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws, P.ew[1][i2], P.wtant[i2], P.wtant2[i2]);
-    if (c.ic[1] < P.n2 - 1 && !(reach && sph_cone_out_of_reach(P, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws))) sph_wall_cone(P, r, v, c, 1, v2_xy, v2_z, rv_xy, rv_z, r2_xy, r2_z, ws, P.ew[1][i2 + 1], P.wtant[i2 + 1], P.wtant2[i2 + 1]);
-#endif
     polar_wall_phi<GEOM_SPH>(P, r, v, c, r2_xy, ws);
     tnear = ws.tmin;
 #pragma unroll
@@ -369,7 +355,7 @@ __device__ __forceinline__ bool sph_find_wall(const DProblem &P, const Walls &W,
 __device__ __forceinline__ bool geo_find_wall(const DProblem &P, const Walls &W, const double r[3], const double v[3],
                                               const Cell<GEOM_SPH> &c, double &tnear, int im[3])
 {
-    return sph_find_wall(P, W, r, v, c, tnear, im, HYP_POLAR_REACH != 0);
+    return sph_find_wall(P, W, r, v, c, tnear, im, false);
 }
 
 // find_wall: cylindrical_3d.f90:593-771

@@ -18,7 +18,7 @@
 
 enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3, TS_REEMIT = 4 };   // TS_REEMIT: re-absorbed by a source
 
-#define HYP_TILE_MAX_BRICKS 8192
+constexpr int HYP_TILE_MAX_BRICKS = 8192;
 
 template <int ND>
 struct alignas(64) HotRec {      // what the walk needs (128 B for ND = 1)
@@ -89,22 +89,14 @@ __device__ __forceinline__ void write_peel_event(PeelEvent<ND, GEOM> &E, const P
 #define TILE_NEEDS_PREPARE (-2)   // the slot is free for a new packet
 #define TILE_NEEDS_INTERACT (-3)  // the packet in the slot awaits an interaction
 #define TILE_NEEDS_REEMIT (-4)    // the packet was re-absorbed by a source and awaits its re-emission
-#define HYP_PREP_CHUNK 2048
+constexpr int HYP_PREP_CHUNK = 2048;
 // build-time shape of tile_walk_kernel (tools/variants.py sweeps these)
-#ifndef HYP_TILE_WG
-#define HYP_TILE_WG 1024         // threads per workgroup (one workgroup per task; with 32 x 16 x 16 bricks one workgroup per CU)
-#endif
-#ifndef HYP_TILE_OCC
-#define HYP_TILE_OCC 4           // waves per SIMD the walk kernel's registers are budgeted for (16 waves per CU)
-#endif
-#ifndef HYP_TILE_SERVICE
-#define HYP_TILE_SERVICE 16      // lanes that must wait (visit finished / idle) before a wave runs its service phase
-#endif
-#ifndef HYP_TILE_STEPS
-#define HYP_TILE_STEPS 4         // cell steps between two scheduling decisions of a wave
-#endif
+constexpr int HYP_TILE_WG = 1024;         // threads per workgroup (one workgroup per task; with 32 x 16 x 16 bricks one workgroup per CU)
+constexpr int HYP_TILE_OCC = 4;           // waves per SIMD the walk kernel's registers are budgeted for (16 waves per CU)
+constexpr int HYP_TILE_SERVICE = 16;      // lanes that must wait (visit finished / idle) before a wave runs its service phase
+constexpr int HYP_TILE_STEPS = 4;         // cell steps between two scheduling decisions of a wave
 #define TILE_DEPOSIT(p, v) do { if (!T.imaging) unsafeAtomicAdd(p, v); } while (0)      // (T: the walk kernel's TileGeom)
-#define HYP_TILE_MAX_POOLS 4
+constexpr int HYP_TILE_MAX_POOLS = 4;
 struct TileCtl {
     unsigned long long next_id, end_id, n_finished;
     unsigned long long first_id;                  // first packet id of the launch (imaging: index of a packet's EmitRec)
@@ -136,7 +128,7 @@ struct TileGeom {
 // per task of the current generation: how many of its packets ended the visit waiting for an interaction
 // (or a re-emission by a source) and how many slots it left free
 struct TileCount { int n_int, n_dead; };
-#define HYP_TILE_EXTRA 1024       // capacity of each per-pool list behind TileCtl::n_extra; layout [list 0][list 1][freed slots]
+constexpr int HYP_TILE_EXTRA = 1024;       // capacity of each per-pool list behind TileCtl::n_extra; layout [list 0][list 1][freed slots]
 
 struct TileTask { int brick, start, len, pad; };
 
@@ -249,7 +241,7 @@ template <> struct TileCellIO<GEOM_OCT> {
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_OCT> &c) { return P.ot_cluster[c.id]; }
 };
 
-#define HYP_PREP_WAVES 2
+constexpr int HYP_PREP_WAVES = 2;
 
 // ---------------------------------------------------------------------------
 // The lists between the kernels: every task of tile_walk collects the slots whose packets wait for an
@@ -363,15 +355,9 @@ static __global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileC
     }
 }
 
-#ifndef HYP_INTERACT_WAVES
-#define HYP_INTERACT_WAVES 2
-#endif
-#ifndef HYP_EMIT_WAVES
-#define HYP_EMIT_WAVES 2
-#endif
-#ifndef HYP_EMIT_WAVES_SIMPLE
-#define HYP_EMIT_WAVES_SIMPLE 3     // 167 VGPRs, nothing spilled (4: 128 + 74 spilled; configs[1] 254.0-254.2 -> 251.5-252.5 ms; 2: 254.0)
-#endif
+constexpr int HYP_INTERACT_WAVES = 2;
+constexpr int HYP_EMIT_WAVES = 2;
+constexpr int HYP_EMIT_WAVES_SIMPLE = 3;     // 167 VGPRs, nothing spilled (4: 128 + 74 spilled; configs[1] 254.0-254.2 -> 251.5-252.5 ms; 2: 254.0)
 // end of a walk task: its two lists (staged in the task's own range) go to the pool-wide lists, one reservation each
 __device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileCtl *__restrict__ ctl, const TileTask &tk, int *__restrict__ ilist,
                                                         int *__restrict__ dlist, int n_int, int n_dead, int *base /* 2 ints of LDS */)
@@ -382,10 +368,7 @@ __device__ __forceinline__ void tile_walk_publish_lists(const TileGeom &T, TileC
     for (int i = threadIdx.x; i < n_int; i += blockDim.x) ilist[T.n_slots + base[0] + i] = ilist[tk.start + i];
     for (int i = threadIdx.x; i < n_dead; i += blockDim.x) dlist[T.n_slots + base[1] + i] = dlist[tk.start + i];
 }
-#ifndef HYP_INTERACT_SORT
-#define HYP_INTERACT_SORT 1          // 1: a chunk's entries ordered by kind (absorption / scattering) on a peek at their random streams; 0: taken as listed
-#endif
-#define HYP_INTERACT_CHUNK 1024     // list entries that tile_interact orders by kind at a time
+constexpr int HYP_INTERACT_CHUNK = 1024;     // list entries that tile_interact orders by kind at a time
 
 // REABS: the problem has sources that can absorb packets (P.any_intersect), so slots may wait for a re-emission;
 // MRW: the modified random walk is on (P.mrw).  Without them that code stays out of this kernel.
@@ -443,10 +426,6 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         if (threadIdx.x == 0) { n_abs = 0; n_oth = 0; }
         __syncthreads();
         const int n_chunk = min(CH, n_int - c0);
-#if !HYP_INTERACT_SORT
-        for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) sorted[k] = list[c0 + k];
-        if (threadIdx.x == 0) n_abs = n_chunk;
-#else
         for (int k = threadIdx.x; k < n_chunk; k += (int)blockDim.x) {
             const int entry = list[c0 + k];
             const int slot = entry & 0x3fffffff;
@@ -488,7 +467,6 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if (absorb) sorted[atomicAdd(&n_abs, 1)] = slot;
             else sorted[CH - 1 - atomicAdd(&n_oth, 1)] = slot;
         }
-#endif
         __syncthreads();
         const int na = n_abs, oth0 = (na + 63) & ~63, nl = oth0 + n_oth;      // the other kind starts on a wave boundary
     for (int k0 = 0; k0 < nl; k0 += (int)blockDim.x) {
@@ -545,11 +523,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if ((long long)p.inter == P.n_inter_max + 1) { cnt.killed_int++; state = TS_DEAD; finished++; }
             else {
                 int scattered, dust_id;
-#ifdef HYP_ABLATE_INTERACT   // timing experiment (wrong results): the kernel without the physics
-                bool ok = true; scattered = 1; dust_id = 0; cnt.interactions++;
-#else
                 bool ok = interact<ND, GEOM>(P, p, g, cnt, scattered, dust_id);
-#endif
                 bool killed = !ok || (P.kill_on_scatter && scattered) || (P.kill_on_absorb && !scattered);
                 if (IMG) {          // iter_final.f90:245-268: the origin flags of the peel-off
                     f.dust_id = dust_id;
@@ -937,9 +911,7 @@ static __global__ __launch_bounds__(256) void tile_live_kernel(TileGeom T, const
 // ---------------------------------------------------------------------------
 // slots per thread of tile_sort.  Every workgroup makes one returning atomic per brick on cursor[], and
 // atomics on one address are served one after the other by the memory side: the fewer workgroups, the shorter that queue.
-#ifndef HYP_SORT_PER_THREAD
-#define HYP_SORT_PER_THREAD 32
-#endif
+constexpr int HYP_SORT_PER_THREAD = 32;
 
 // Exclusive scan of the brick counts, task list and scatter of the slots in ONE launch.  Every workgroup
 // scans the brick counts itself (a few hundred values; the offsets stay in LDS), workgroup 0 also writes the task list and resets
@@ -1022,11 +994,9 @@ static __global__ __launch_bounds__(256) void tile_sort_kernel(TileGeom T, const
 // the mean chord grows from 10.7 to 12.8 cells, a fifth fewer visits (record traffic, sort, service phases); with the
 // interaction / emission work in kernels of their own a CU that drains a task's tail alone costs less than it did in
 // round 1 (311 against 298 ms then; now 255-259 against 268-277 at tasks of 8192 packets, profiles/r03_tiled_log.md).
-#ifndef HYP_TILE_BX
-#define HYP_TILE_BX 32
-#define HYP_TILE_BY 16
-#define HYP_TILE_BZ 16
-#endif
+constexpr int HYP_TILE_BX = 32;
+constexpr int HYP_TILE_BY = 16;
+constexpr int HYP_TILE_BZ = 16;
 template <int ND> struct TileShape { static constexpr int X = HYP_TILE_BX, Y = HYP_TILE_BY, Z = HYP_TILE_BZ; };      // 128 KB
 template <> struct TileShape<2> { static constexpr int X = 32, Y = 16, Z = 8; };         // 128 KB
 template <> struct TileShape<3> { static constexpr int X = 32, Y = 8, Z = 8; };          // 96 KB

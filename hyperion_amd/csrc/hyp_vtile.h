@@ -34,21 +34,11 @@
 
 #include "hyp_tiled.h"
 
-#ifndef HYP_VTILE_WG
-#define HYP_VTILE_WG 1024        // threads per workgroup (one workgroup per task, one per CU with vt_lds_kb = 156)
-#endif
-#ifndef HYP_VTILE_OCC
-#define HYP_VTILE_OCC 4          // waves per SIMD the register budget is set for (128 VGPRs, nothing spilled at one and two species)
-#endif
-#ifndef HYP_VTILE_SERVICE
-#define HYP_VTILE_SERVICE 16     // lanes that must wait before a wave runs its service phase
-#endif
-#ifndef HYP_VTILE_UNROLL
-#define HYP_VTILE_UNROLL 2       // unrolling of the filter loop (more LDS reads in flight per lane)
-#endif
-#ifndef HYP_VTILE_STEPS
-#define HYP_VTILE_STEPS 2        // cell steps between two scheduling decisions of a wave
-#endif
+constexpr int HYP_VTILE_WG = 1024;        // threads per workgroup (one workgroup per task, one per CU with vt_lds_kb = 156)
+constexpr int HYP_VTILE_OCC = 4;          // waves per SIMD the register budget is set for (128 VGPRs, nothing spilled at one and two species)
+constexpr int HYP_VTILE_SERVICE = 16;     // lanes that must wait before a wave runs its service phase
+constexpr int HYP_VTILE_UNROLL = 2;       // unrolling of the filter loop (more LDS reads in flight per lane)
+constexpr int HYP_VTILE_STEPS = 2;        // cell steps between two scheduling decisions of a wave
 
 // the cluster's tables in LDS (layout of the blob: hyp_device.h, VtInfo)
 struct VtLds {
@@ -160,82 +150,6 @@ __device__ __forceinline__ int vt_filter(const VtLds &L, int k0, int nk, int pre
     return (!unc && k1 >= 0 && lo2 > U) ? k1 : -1;
 }
 
-#ifdef HYP_VTILE_COOP
-// The same filter with SIXTEEN LANES PER PACKET (north_star: lanes that share one packet's work; measured, not the default --
-// profiles/r04_tiled_log.md).  The wave still carries 64 packets, one per lane, but searches cooperatively: in round j the
-// four 16-lane groups take the packets of lanes 4j .. 4j + 3, lane s of a group tests walls s, s + 16, ... of its packet's
-// cell (sixteen consecutive 16-byte records per group: conflict-free ds_read_b128), the groups reduce (U, the two smallest
-// lo, their wall) with DPP row rotations, and the owner lanes take the result back.  Every lane of the wave must call it.
-__device__ __forceinline__ float vt_row_min(float x)
-{
-    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false)));      // row_ror:8
-    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x124, 0xf, 0xf, false)));      // row_ror:4
-    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x122, 0xf, 0xf, false)));      // row_ror:2
-    x = fminf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x121, 0xf, 0xf, false)));      // row_ror:1
-    return x;
-}
-__device__ __forceinline__ int vt_row_min_i(int x)
-{
-    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false));
-    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x124, 0xf, 0xf, false));
-    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x122, 0xf, 0xf, false));
-    x = min(x, __builtin_amdgcn_update_dpp(0, x, 0x121, 0xf, 0xf, false));
-    return x;
-}
-__device__ __forceinline__ int vt_filter_coop(const VtLds &L, bool active, int k0, int nk, int prev_k, float q0, float q1, float q2, float Q, float abs_eps,
-                                              float v0, float v1, float v2)
-{
-    const int lane = (int)__lane_id(), sub = lane & 15, grp = lane >> 4;
-    const float inf = __builtin_inff();
-    const unsigned long long m_act = __ballot(active);
-    int result = -1;
-    for (int round = 0; round < 16; round++) {
-        if (((m_act >> (round * 4)) & 0xfull) == 0) continue;          // wave-uniform
-        const int p = round * 4 + grp;                                 // the packet this group serves
-        const bool pa = (m_act >> p) & 1ull;
-        const float pq0 = __shfl(q0, p), pq1 = __shfl(q1, p), pq2 = __shfl(q2, p), pQ = __shfl(Q, p);
-        const float pv0 = __shfl(v0, p), pv1 = __shfl(v1, p), pv2 = __shfl(v2, p);
-        const int pk0 = __shfl(k0, p), pnk = pa ? __shfl(nk, p) : 0, pprev = __shfl(prev_k, p);
-        const float cq = fmaf(10.0f * VT_U, pQ, abs_eps);
-        float lo1 = inf, lo2 = inf, U = inf;
-        int k1 = 0x7fffffff;
-        bool unc = false;
-        for (int base = 0; __ballot(base < pnk) != 0; base += 16) {
-            const int k = base + sub;
-            const bool have = k < pnk;
-            const float4 w = L.wrec[pk0 + (have ? k : 0)];
-            const float len = fabsf(w.w);
-            const float dq = fmaf(w.z, pq2, fmaf(w.y, pq1, w.x * pq0));
-            const float num = 0.5f * len * len - dq;
-            const float den = fmaf(w.z, pv2, fmaf(w.y, pv1, w.x * pv0));
-            const float dn = len * fmaf(12.0f * VT_U, len, cq);
-            const float dd = 8.0f * VT_U * len;
-            const float rcp = __builtin_amdgcn_rcpf(den);
-            const float t = num * rcp, at = fabsf(t);
-            const float eps = fmaf(2.5f * fmaf(at, dd, dn), fabsf(rcp), 16.0f * VT_U * at);
-            const float lo = t - eps, hi = t + eps;
-            const bool valid = have & (k != pprev) & !((w.w < 0.0f) & (den < 0.0f));
-            const bool good = (fabsf(den) > 4.0f * dd) & (eps < inf);
-            unc |= valid & !good;
-            const bool cand = valid & good & (hi > 0.0f), sure = valid & good & (lo > 0.0f);
-            U = sure ? fminf(U, hi) : U;
-            const bool lt1 = cand & (lo < lo1), lt2 = cand & (lo < lo2);
-            lo2 = lt1 ? lo1 : lt2 ? lo : lo2;
-            lo1 = lt1 ? lo : lo1;
-            k1 = lt1 ? k : k1;
-        }
-        // the group's sixteen partial results -> one
-        const float gU = vt_row_min(U), g1 = vt_row_min(lo1);
-        const int gk = vt_row_min_i(lo1 == g1 && g1 < inf ? k1 : 0x7fffffff);
-        const float g2 = vt_row_min(k1 == gk ? lo2 : lo1);              // the second smallest lo of all the walls
-        const bool gunc = ((__ballot(unc) >> (grp * 16)) & 0xffffull) != 0;
-        const int res = (!gunc && gk != 0x7fffffff && g2 > gU) ? gk : -1;
-        const int back = __shfl(res, (lane & 3) * 16);                   // lane l belongs to round l >> 2, group l & 3
-        if ((lane >> 2) == round) result = back;
-    }
-    return result;
-}
-#endif
 
 // the search of one step: filter, then the reference's expression for the wall it names, or the reference's loop
 __device__ __forceinline__ bool vt_find_wall(const DProblem &P, const VtLds &L, const VtInfo &I, int loc, int k0, int nk, bool exact_only, int prev_k,
@@ -469,18 +383,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #pragma unroll 1
         for (int q = 0; q < HYP_VTILE_STEPS; q++) {
-#ifdef HYP_VTILE_COOP
-            int k1_coop;
-            {
-                const bool stepping = st == LS_WALK && g.countdown != 0;
-                const double s0 = L.sx[loc], s1 = L.sy[loc], s2 = L.sz[loc];
-                const float q0 = (float)((r0 - s0) * (double)I.scale), q1 = (float)((r1 - s1) * (double)I.scale), q2 = (float)((r2 - s2) * (double)I.scale);
-                const float Q = sqrtf(fmaf(q2, q2, fmaf(q1, q1, q0 * q0))) * 1.000001f;
-                k1_coop = vt_filter_coop(L, stepping && !hexact, hk0, hnk, prev_k, q0, q1, q2, Q, I.abs_eps, (float)v0, (float)v1, (float)v2);
-            }
-#else
             const int k1_coop = -2;
-#endif
             if (st == LS_WALK) {
                 if (g.countdown == 0) st = LS_CHECK;
                 else {

@@ -65,7 +65,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB
+    path = path or os.environ.get("HYPERION_AMD_LIB") or LIB      # (the variable: tuning and diagnostic builds of tools/variants.py)
     if not os.path.exists(path):
         raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % path)
@@ -109,7 +109,7 @@ def load_library(path=None):
     if L.hyp_abi_version() != ABI_VERSION:      # the struct mirrors of _abi.py are for one version of include/hyperion_amd.h
         raise EngineError("%s has ABI version %d, this binding was written for %d: rebuild the extension"
                           % (path, L.hyp_abi_version(), ABI_VERSION))
-    if path == LIB:
+    if path == (os.environ.get("HYPERION_AMD_LIB") or LIB):
         _lib = L
     return L
 

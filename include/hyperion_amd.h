@@ -340,45 +340,40 @@ int  hyp_convergence_value(hyp_handle h, double percentile, double *value, int *
  * stream) of the last propagation kernel and of the last finish step.  After a raytracing or monochromatic
  * iteration: the sum over the propagation kernels of all its launches (sources + dust, every wavelength), finish 0. */
 int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
-/* tuning knobs (environment-independent): name in {"interact_threshold",
- * "emit_threshold", "accum_copies", "blocks_per_cu", "chunk", "lucy_mode"
- * (-1 auto, 0 persistent kernel with global atomics, 1 tiled: bricks of a Cartesian grid, hyp_tiled.h; clusters of Voronoi
- * cells, hyp_vtile.h; runs of sibling subtrees of an octree, hyp_otile.h; bricks of an AMR hierarchy's grids, hyp_atile.h; index bricks of a
- * spherical / cylindrical polar grid, hyp_ptile.h),
- * "tile_slots" (0: 3 << 21, octree 3 << 22), "tile_task", "tile_pools", "tile_drain", "tile_split", "tile_poll", "tile_park",
- * "vt_cells" / "vt_lds_kb", "ot_cells" / "ot_lds_kb", "at_cells" / "at_lds_kb" (most cells per Voronoi / octree cluster / AMR brick; LDS
- * budget of a walk workgroup in KB: 156 = one workgroup per CU), "pt_lds_kb" (LDS of a polar-grid brick's densities and accumulators),
- * "tile_time_walk" (1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches"; off by
- * default, bench.py switches it on for one extra step), "tile_ring" (tuning builds only), "tile_fused_sort" (1: scan + scatter of the
- * per-generation sort in one launch), "tile_presort" (1: with one species the walk hands the kind of a packet's next interaction on with its slot and
- * tile_interact orders its chunk without reading the records first), "tile_drain" (packets in flight below which the last ones are finished in one
- * launch; -1: 400 000 on Cartesian and Voronoi grids, 1 000 000 elsewhere), "pt_vsplit" (1: spherical grids sort packets that have not
- * interacted yet apart from the others),
- * "final_interact_threshold" /
- * "final_emit_threshold" (batch sizes of the imaging kernels, -1 = measured optimum), "defer_peel" (1: deferred peel-off where the plain
- * imaging kernel applies, hyp_defer.h; 0: inline), "peel_events" (capacity of its event buffer: at most
- * 128 Mi events by default, fewer if the memory is not there),
- * "peel_sort" (1, the default: the peel kernel takes a round's events ordered by the cell they happened in), "ff_prepass" (1, the
- * default: with forced first interaction on, every packet's emission, escape walk and first optical depth are made ahead of the rounds by a
- * kernel of their own, one record of 96 + 24 n_dust bytes (rounded up to 16) per packet id of the launch; "last_ff_prepass" reports whether the last imaging
- * iteration did so), "direct_memo" (1, the default: the peel-off walk of a point source's direct light is made once per (source, view) and
- * reused for every emission event whose first propagation check falls behind it, hyp_defer.h: direct_column_kernel; "last_direct_memo"),
- * "gen_defer" (1, the default: a problem with sources other than isotropic points, without MRW / binned images / inside
- * observers, images on the deferred schedule -- re-absorption, re-emission and the limb-darkened peel-off included; 0: the general kernel
- * with inline peel-off; reads back 1 only where the problem qualifies),
- * "mono_defer" (1, the default: the launches of a monochromatic run whose problem is plain otherwise -- point sources, no MRW, no binned
- * images -- run on the deferred schedule; 0: the general kernel with inline peel-off; "last_mono_deferred" reports which one the last
- * hyp_mono_launch took), "oct_neighbours" (0: the
- * octree walk climbs and descends like the reference instead of using the neighbour table), "plain_imaging" (the specialisation of the inline imaging kernel for point sources without MRW, monochromatic launch,
- * binned images and inside observers; "lean_imaging", round 3's specialisation for any sources, reads 0 since round 4: those problems run on
- * the deferred schedule, "gen_defer"; can only be switched off)}.  hyp_get_option also reports "last_lucy_mode", "last_generations", "vt_clusters", "ot_clusters",
- * "last_defer_rounds", "last_defer_events", "pda_last_cells / _outer / _sweeps", "n_photons_inexact" (a packet visited more
- * cells than its visited set holds: the n_photons of the last iteration are an upper bound) and, for sharded runs, the
- * geometry of the blocks that hyp_*_accumulators hand out: "lucy_block_doubles" / "image_block_doubles" (their lengths) and
- * "lucy_flag_index" / "image_flag_index" -- the index of a spare slot of the block's scalar tail that is never written on
- * the device: a rank whose launch failed adds 1 there before the all-reduce (to a zero block of the same length), and
- * hyp_*_finish on every rank returns "another rank reported an engine error" when the summed slot is not zero.  That is
- * mp_join's role (src/mpi/mpi_routines.f90) without a second collective. */
+/* Options (integers; nothing in the environment changes the engine's behaviour).  The defaults are the measured optima; the tests
+ * use the switches to show that the schedules agree with one another.
+ *
+ *   set and get
+ *     "lucy_mode"           -1 auto (default), 0 persistent kernel with global atomics, 1 the tiled schedule of the grid (bricks of a
+ *                           Cartesian / polar / AMR grid, clusters of Voronoi cells or octree subtrees in LDS)
+ *     "tile_slots" "tile_task" "tile_pools"   slot pool of the tiled schedule: slots (0: 3 << 21, trees 3 << 22), packets per walk
+ *                           task (0: 8192), pools = streams (3)
+ *     "tile_time_walk"      1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches" (bench.py)
+ *     "vt_cells" "ot_cells" "at_cells" "pt_lds_kb"   most cells per Voronoi / octree cluster / AMR brick, LDS of a polar brick in KB
+ *                           (0 / default: what 156 KB of LDS hold); "tile_drain" (packets in flight below which the Lucy iteration ends
+ *                           in one drain launch; -1: 1 000 000), "tile_poll" (generations between two looks at the device): set only,
+ *                           the tests' handles for exercising every path of the schedule on small problems
+ *     "interact_threshold" "emit_threshold" "accum_copies" "blocks_per_cu" "chunk"   launch shape of the persistent kernels
+ *     "defer_peel"          imaging iteration: 0 inline peel-off, 1 deferred (hyp_defer.h; default), 2 force / 3 forbid the
+ *                           propagation half on the tiled schedule (default: from 4e6 packets)
+ *     "peel_events"         capacity of the event buffer (default: at most 128 Mi events, fewer if the memory is not there)
+ *     "peel_sort" "ff_prepass" "direct_memo"   1 (default): events peeled in cell order; emission + forced first interaction ahead of
+ *                           the rounds; a point source's direct light walked once per (source, view)
+ *     "gen_defer" "mono_defer"   1 (default): problems with extended sources / monochromatic launches image on the deferred schedule
+ *     "plain_imaging"       the inline imaging kernel specialised for point sources (can only be switched off)
+ *     "oct_neighbours"      0: the octree walk climbs and descends like the reference instead of using the neighbour table
+ *   get only: what the last iteration did
+ *     "last_lucy_mode" "last_generations" "last_walk_us" "last_walk_launches" "last_defer_rounds" "last_defer_events"
+ *     "last_ff_prepass" "last_direct_memo" "last_tiled_imaging" "last_mono_deferred" "last_vt_exact_steps"
+ *     "vt_clusters" "vt_max_cells" "ot_clusters" "at_slabs"   shape of the tiled schedule that was built
+ *     "pda_last_cells"      cells the partial diffusion approximation solved
+ *     "n_photons_inexact"   a packet visited more cells than its visited set holds: the n_photons of the last iteration are an upper bound
+ *   get only: sharded runs, the geometry of the blocks that hyp_*_accumulators hand out
+ *     "lucy_block_doubles" "image_block_doubles"   their lengths
+ *     "lucy_flag_index" "image_flag_index"         index of a spare slot of the block's scalar tail that is never written on the
+ *                           device: a rank whose launch failed adds 1 there before the all-reduce (to a zero block of the same
+ *                           length), and hyp_*_finish on every rank returns "another rank reported an engine error" when the summed
+ *                           slot is not zero.  That is mp_join's role (src/mpi/mpi_routines.f90) without a second collective. */
 int  hyp_set_option(hyp_handle h, const char *name, int64_t value);
 int  hyp_get_option(hyp_handle h, const char *name, int64_t *value);
 
