@@ -1,11 +1,11 @@
 #!/bin/bash
-# rocprofv3 capture on the GPU box (ROUND=r04 by default; tools/r03_profile.sh is the round-3 original): for each workload one kernel-trace pass and one --pmc pass per counter set
+# rocprofv3 capture on the GPU box (ROUND=r05 by default): for each workload one kernel-trace pass and one --pmc pass per counter set
 # (counters only alongside --kernel-trace), condensed on the box by tools/summarize_profile_round.py into
 # gpurun_out/${ROUND}prof/<workload>_summary.md and ${ROUND}_pmc.json (copy both into profiles/).
-#   usage: [ROUND=r04] [PMC=0] [PACKETS=1e8] bash tools/profile_round.sh [workload ...]      workloads: car car1 oct_lucy oct_img vor vor1 amr sph
+#   usage: [ROUND=r05] [PMC=0] [PACKETS=1e8] bash tools/profile_round.sh [workload ...]      workloads: car car1 oct_lucy oct_img vor vor1 amr sph
 #   (<name>1 = the same with one slot pool: kernels do not overlap, per-kernel durations divide cleanly; PMC=0: trace pass only)
 set -u
-export ROUND=${ROUND:-r04}
+export ROUND=${ROUND:-r05}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/${ROUND}prof; mkdir -p $OUT
 # the box starts without gpurun_out/: continue from the committed summary so that a partial re-run keeps the other workloads
@@ -21,8 +21,8 @@ for w in $WL; do
   case $w in
     car)  CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" ;;
     car1) CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --option tile_pools=1" ;;
-    vor1|oct_lucy1|amr1) CMD="python $REPO/tools/r03_workload.py ${w%1} ${PACKETS:-1e8} tile_pools=1" ;;
-    *)    CMD="python $REPO/tools/r03_workload.py $w ${PACKETS:-1e8} ${WOPTS:-}" ;;
+    vor1|oct_lucy1|amr1) CMD="python $REPO/tools/workload.py ${w%1} ${PACKETS:-1e8} tile_pools=1" ;;
+    *)    CMD="python $REPO/tools/workload.py $w ${PACKETS:-1e8} ${WOPTS:-}" ;;
   esac
   D=$OUT/raw_$w; rm -rf $D; mkdir -p $D
   echo "== $w: kernel trace"

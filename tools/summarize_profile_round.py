@@ -1,9 +1,9 @@
-"""Condense one workload of tools/profile_round.sh (round label from env ROUND, default r04): kernel table of the trace pass, counter sums of the PMC passes per kernel,
+"""Condense one workload of tools/profile_round.sh (round label from env ROUND, default r05): kernel table of the trace pass, counter sums of the PMC passes per kernel,
 and their reduction per cell crossing (crossings of the whole profiled process, from the workload's own PROFILE_TOTALS /
 bench line).  Writes <out>/<workload>_summary.md and merges <out>/<round>_pmc.json.
 usage: python tools/summarize_profile_round.py <workload> <raw dir> <out dir>"""
 import glob, json, os, re, sqlite3, sys
-ROUND = os.environ.get("ROUND", "r04")
+ROUND = os.environ.get("ROUND", "r05")
 w, raw, out = sys.argv[1:4]
 KEEP = ("tile_", "vtile_", "otile_", "atile_", "lucy_kernel", "final_kernel", "final_defer_kernel", "ff_walk_kernel", "peel_kernel", "reduce_copies", "finish_kernel")
 

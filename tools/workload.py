@@ -1,5 +1,5 @@
-"""The single-GPU workloads of BASELINE.json that are profiled besides the bench command (tools/r03_profile.sh):
-   python tools/r03_workload.py oct_lucy|oct_img|vor|amr|sph [packets] [opt=value ...]
+"""The single-GPU workloads of BASELINE.json that are profiled besides the bench command (tools/profile_round.sh):
+   python tools/workload.py oct_lucy|oct_img|vor|amr|sph [packets] [opt=value ...]
 Runs one warm-up (a tenth of the packets) and two timed iterations; prints the timings and one line
 `PROFILE_TOTALS {json}` with the crossings / packets of ALL iterations of the process (what a rocprofv3 pass sees)."""
 import json, os, sys
