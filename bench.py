@@ -428,7 +428,7 @@ def main():
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),
             "iterations_in_process": it,        # warm-up + timed steps + the extra walk-timing step: what a rocprofv3 pass of this command sees
-            "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_scan / tile_scatter / tile_walk on %d slot pools (streams)"
+            "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_sort / tile_walk on %d slot pools (streams)"
                               % eng.get_option("tile_pools")) if tiled else "persistent kernel, global atomics",
         }
         if rccl is not None:
