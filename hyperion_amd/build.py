@@ -24,6 +24,7 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP extension cannot be built")
 
 
+HOST_UNITS = ("create", "lucy", "imaging", "engine")      # the host side of the C-ABI (hyp_engine.h); heaviest first
 PARTS = {"lucy": 0, "tile": 1, "final": 2, "defer": 3, "ray": 4, "finalp": 5}
 # heaviest first: the pool starts them first so that the long poles do not land at the end
 _COST = {"finalp": 6, "final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
@@ -31,7 +32,7 @@ _COST = {"finalp": 6, "final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
 
 def units():
     """(name, source, defines): the host side + one unit per (geometry, kernel family) -- hyp_geom.hip's header."""
-    u = [("engine", "hyp_engine.hip", [])]
+    u = [(name, "hyp_%s.hip" % name, []) for name in HOST_UNITS]
     for part in sorted(PARTS, key=lambda k: -_COST[k]):
         for g, k in GEOMS.items():
             u.append(("%s_%s" % (part, g), "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % k, "-DHYP_PART=%d" % PARTS[part]]))

@@ -12,7 +12,7 @@
 // n_photons: the u32 device counters as doubles in the accumulator block (the block is what the ranks all-reduce,
 // mpi_routines.f90:303-310), and back after the collective
 // ---------------------------------------------------------------------------
-__global__ void nphot_to_block_kernel(const unsigned int *__restrict__ n, double *__restrict__ out, size_t n_cells)
+static __global__ void nphot_to_block_kernel(const unsigned int *__restrict__ n, double *__restrict__ out, size_t n_cells)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_cells; i += step) out[i] = (double)n[i];
@@ -21,7 +21,7 @@ __global__ void nphot_to_block_kernel(const unsigned int *__restrict__ n, double
 // ---------------------------------------------------------------------------
 // update_energy_abs for the spectrum (:517-524): spec = sum_spec * scale / volume, 0 where the volume is 0
 // ---------------------------------------------------------------------------
-__global__ void spectrum_update_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ sum_spec, double *__restrict__ spec,
+static __global__ void spectrum_update_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ sum_spec, double *__restrict__ spec,
                                        double scale, int n_bins)
 {
     const DProblem &P = *Pp;
@@ -38,7 +38,7 @@ __global__ void spectrum_update_kernel(const DProblem *__restrict__ Pp, const do
 }
 
 // [n_bins][n_cells][n_dust] (device) -> [n_bins][n_dust][n_cells] (reference layout)
-__global__ void spectrum_to_ref_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd, int n_bins)
+static __global__ void spectrum_to_ref_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd, int n_bins)
 {
     const size_t n = n_cells * nd, step = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n * n_bins; k += step) {
@@ -132,7 +132,7 @@ __device__ __forceinline__ double pda_e_mean(const DProblem &P, const double *__
     return e / sr;
 }
 
-__global__ void pda_total_kernel(const double *__restrict__ nphot, size_t n_cells, PdaCtl *__restrict__ ctl)
+static __global__ void pda_total_kernel(const double *__restrict__ nphot, size_t n_cells, PdaCtl *__restrict__ ctl)
 {
     double s = 0.0;
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -143,7 +143,7 @@ __global__ void pda_total_kernel(const double *__restrict__ nphot, size_t n_cell
 
 // do_pda = n_photons < threshold and some dust in the cell, minus the cells on the outer faces (check_allowed_pda);
 // e_mean of every cell; histogram of the PDA cells over the hyperplanes i1 + i2 + i3
-__global__ void pda_mask_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ nphot, double threshold,
+static __global__ void pda_mask_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ nphot, double threshold,
                                 const double *__restrict__ se, const double *__restrict__ rho, unsigned char *__restrict__ mask,
                                 double *__restrict__ e_mean, unsigned int *__restrict__ hp_count, PdaCtl *__restrict__ ctl)
 {
@@ -166,7 +166,7 @@ __global__ void pda_mask_kernel(const DProblem *__restrict__ Pp, const double *_
 }
 
 // exclusive scan of the hyperplane histogram (a few hundred entries): one thread
-__global__ void pda_scan_kernel(const unsigned int *__restrict__ hp_count, unsigned int *__restrict__ hp_off, unsigned int *__restrict__ hp_cursor,
+static __global__ void pda_scan_kernel(const unsigned int *__restrict__ hp_count, unsigned int *__restrict__ hp_off, unsigned int *__restrict__ hp_cursor,
                                 int n_hp)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -176,7 +176,7 @@ __global__ void pda_scan_kernel(const unsigned int *__restrict__ hp_count, unsig
     }
 }
 
-__global__ void pda_list_kernel(const DProblem *__restrict__ Pp, const unsigned char *__restrict__ mask, const unsigned int *__restrict__ hp_off,
+static __global__ void pda_list_kernel(const DProblem *__restrict__ Pp, const unsigned char *__restrict__ mask, const unsigned int *__restrict__ hp_off,
                                 unsigned int *__restrict__ hp_cursor, unsigned int *__restrict__ cells)
 {
     const DProblem &P = *Pp;
@@ -192,7 +192,7 @@ __global__ void pda_list_kernel(const DProblem *__restrict__ Pp, const unsigned 
 
 // start of solve_pda_indiv_*: e_mean of the PDA cells from the current specific energy, and the coefficient of every
 // wall of every PDA cell (they depend on the specific energy, which only changes after the solve)
-__global__ void pda_coef_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
+static __global__ void pda_coef_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
                                 const double *__restrict__ se, const double *__restrict__ rho, double *__restrict__ e_mean,
                                 double *__restrict__ coef, int exact)
 {
@@ -225,7 +225,7 @@ __global__ void pda_coef_kernel(const DProblem *__restrict__ Pp, const unsigned 
 // so updating hyperplane after hyperplane, all cells of one in parallel, gives every cell exactly the operands the
 // sequential loop gives it: same result, bit for bit.  One workgroup (the barrier between hyperplanes is a
 // __syncthreads); sweeps until the largest relative change of a sweep is below `tol`.
-__global__ __launch_bounds__(1024) void pda_gs_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells,
+static __global__ __launch_bounds__(1024) void pda_gs_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells,
                                                       const unsigned int *__restrict__ hp_off, int n_hp, const double *__restrict__ coef,
                                                       double *__restrict__ e_mean, double tol, int max_sweeps, PdaCtl *__restrict__ ctl)
 {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(1024) void pda_gs_kernel(const DProblem *__restrict
 // >= the sum of its off-diagonal entries), so the pivot search normally confirms the diagonal; it matters where the 1e-100
 // clamp of pda_coef leaves rows of wildly different scale.  The matrix is sparse (7-point stencil); rows whose entry in the
 // pivot column is zero are skipped, so the work follows the fill-in, not n^3.
-__global__ void pda_dense_build_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
+static __global__ void pda_dense_build_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
                                        const unsigned int *__restrict__ id_of_cell, const double *__restrict__ coef,
                                        const double *__restrict__ e_mean, double *__restrict__ a, double *__restrict__ b)
 {
@@ -306,7 +306,7 @@ __global__ void pda_dense_build_kernel(const DProblem *__restrict__ Pp, const un
     }
 }
 
-__global__ void pda_id_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, unsigned int *__restrict__ id_of_cell)
+static __global__ void pda_id_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, unsigned int *__restrict__ id_of_cell)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n_pda; q += step) id_of_cell[cells[q]] = (unsigned int)q;
@@ -314,7 +314,7 @@ __global__ void pda_id_kernel(const unsigned int *__restrict__ cells, unsigned i
 
 // elimination step k, partial pivoting (the reference calls fortranlib's lineq_gausselim, grid_pda_3d.f90:246): the row at or
 // below k with the largest |a[r][k]| -- the first of them, like the oracle's search -- is found by one workgroup ...
-__global__ __launch_bounds__(1024) void pda_pivot_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, unsigned int *__restrict__ piv)
+static __global__ __launch_bounds__(1024) void pda_pivot_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, unsigned int *__restrict__ piv)
 {
     __shared__ double big_s[16];
     __shared__ unsigned int row_s[16];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(1024) void pda_pivot_kernel(const double *__restric
     }
 }
 // ... and exchanged with row k (columns >= k: the others are already zero in both; and the right-hand side)
-__global__ void pda_swap_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const unsigned int *__restrict__ piv)
+static __global__ void pda_swap_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const unsigned int *__restrict__ piv)
 {
     const unsigned int p = *piv;
     if (p == k) return;
@@ -345,13 +345,13 @@ __global__ void pda_swap_kernel(double *__restrict__ a, double *__restrict__ b, 
     if (blockIdx.x == 0 && threadIdx.x == 0) { const double t = b[k]; b[k] = b[p]; b[p] = t; }
 }
 // then the factors f[r] = a[r][k] / a[k][k] for the rows below the pivot ...
-__global__ void pda_elim_factor_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, double *__restrict__ f)
+static __global__ void pda_elim_factor_kernel(const double *__restrict__ a, unsigned int n, unsigned int k, double *__restrict__ f)
 {
     const unsigned int r = k + 1 + blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) f[r] = a[(size_t)r * n + k] / a[(size_t)k * n + k];
 }
 // ... and row r -= f[r] * row k (one workgroup row of the grid per matrix row; rows with a zero factor return at once)
-__global__ void pda_elim_update_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const double *__restrict__ f)
+static __global__ void pda_elim_update_kernel(double *__restrict__ a, double *__restrict__ b, unsigned int n, unsigned int k, const double *__restrict__ f)
 {
     const unsigned int r = k + 1 + blockIdx.y;
     const double fr = f[r];
@@ -365,7 +365,7 @@ __global__ void pda_elim_update_kernel(double *__restrict__ a, double *__restric
     if (blockIdx.x == 0 && threadIdx.x == 0) { b[r] -= fr * b[k]; pr[k] = 0.0; }
 }
 // back substitution, one workgroup: x overwrites b
-__global__ __launch_bounds__(1024) void pda_backsub_kernel(const double *__restrict__ a, double *__restrict__ b, unsigned int n)
+static __global__ __launch_bounds__(1024) void pda_backsub_kernel(const double *__restrict__ a, double *__restrict__ b, unsigned int n)
 {
     __shared__ double red[16];
     for (unsigned int kk = n; kk-- > 0;) {
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(1024) void pda_backsub_kernel(const double *__restr
         __syncthreads();
     }
 }
-__global__ void pda_scatter_solution_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, const double *__restrict__ x,
+static __global__ void pda_scatter_solution_kernel(const unsigned int *__restrict__ cells, unsigned int n_pda, const double *__restrict__ x,
                                             double *__restrict__ e_mean)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -392,7 +392,7 @@ __global__ void pda_scatter_solution_kernel(const unsigned int *__restrict__ cel
 }
 
 // update_specific_energy :36-70 for the PDA cells + the rescaling of their spectrum; the largest relative change
-__global__ void pda_update_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
+static __global__ void pda_update_kernel(const DProblem *__restrict__ Pp, const unsigned int *__restrict__ cells, unsigned int n_pda,
                                   const double *__restrict__ e_mean, double *__restrict__ se, double *__restrict__ spec, int n_bins,
                                   PdaCtl *__restrict__ ctl)
 {
@@ -442,7 +442,7 @@ struct ConvCtl {
 };
 
 // ratio[k] = max(a / b, b / a) of the pairs that count, 0 elsewhere (every valid ratio is > 1)
-__global__ void conv_ratio_kernel(const double *__restrict__ prev, const double *__restrict__ cur, size_t n, double *__restrict__ ratio,
+static __global__ void conv_ratio_kernel(const double *__restrict__ prev, const double *__restrict__ cur, size_t n, double *__restrict__ ratio,
                                   ConvCtl *__restrict__ ctl)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -466,7 +466,7 @@ __global__ void conv_ratio_kernel(const double *__restrict__ prev, const double 
 }
 
 // how many valid ratios have a bit pattern below `limit` (positive doubles order like their bits)
-__global__ void conv_count_kernel(const double *__restrict__ ratio, size_t n, unsigned long long limit, ConvCtl *__restrict__ ctl)
+static __global__ void conv_count_kernel(const double *__restrict__ ratio, size_t n, unsigned long long limit, ConvCtl *__restrict__ ctl)
 {
     const size_t step = (size_t)gridDim.x * blockDim.x;
     unsigned long long c = 0;

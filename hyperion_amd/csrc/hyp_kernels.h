@@ -2590,9 +2590,9 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_kernel(const DProb
     }
 }
 
-#ifndef HYP_GEOM_TU   // the geometry-independent kernels are compiled once, in hyp_engine.hip
+#ifndef HYP_GEOM_TU   // the geometry-independent kernels: static, each host unit (hyp_engine.h) compiles the ones it launches
 // image_scale: image_type.f90:136-151 -- x *= scale over [0,n), x *= scale^2 over [n,2n)
-__global__ void image_scale_kernel(double *__restrict__ a, size_t n, double scale)
+static __global__ void image_scale_kernel(double *__restrict__ a, size_t n, double scale)
 {
     size_t step = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < 2 * n; k += step)
@@ -2604,7 +2604,7 @@ __global__ void image_scale_kernel(double *__restrict__ a, size_t n, double scal
 // ---------------------------------------------------------------------------
 
 // sum[0][k] += sum[c][k], c = 1..n_copies-1  (before the collective)
-__global__ void reduce_copies_kernel(double *__restrict__ sum, size_t n, size_t stride, int n_copies)
+static __global__ void reduce_copies_kernel(double *__restrict__ sum, size_t n, size_t stride, int n_copies)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     size_t step = (size_t)gridDim.x * blockDim.x;
@@ -2617,7 +2617,7 @@ __global__ void reduce_copies_kernel(double *__restrict__ sum, size_t n, size_t 
 
 // setup_monochromatic_grid_pdfs (grid_monochromatic.f90:51-117), part 1: w[d][ic] = emission probability at the
 // frequency x energy emitted in the cell x n_cells / energy_abs_tot(d).  Masked cells carry no density.
-__global__ void mono_weight_kernel(const DProblem *__restrict__ Pp, double *__restrict__ w)
+static __global__ void mono_weight_kernel(const DProblem *__restrict__ Pp, double *__restrict__ w)
 {
     const DProblem &P = *Pp;
     const size_t nc = (size_t)P.n_cells, n = nc * (size_t)P.n_dust;
@@ -2634,7 +2634,7 @@ __global__ void mono_weight_kernel(const DProblem *__restrict__ Pp, double *__re
 
 // part 2: in-place cumulative sum over the cells of dust type blockIdx.x, normalised to 1 (set_pdf of a discrete
 // pdf); mean[d] = total / n_cells.  One 1024-thread block per dust type: each thread owns a contiguous chunk.
-__global__ __launch_bounds__(1024) void mono_scan_kernel(double *__restrict__ w, size_t nc, double *__restrict__ mean)
+static __global__ __launch_bounds__(1024) void mono_scan_kernel(double *__restrict__ w, size_t nc, double *__restrict__ mean)
 {
     __shared__ double part[1024];
     double *a = w + (size_t)blockIdx.x * nc;
@@ -2712,7 +2712,7 @@ __device__ __forceinline__ double mean_opacity(const DDust &D, const double *__r
 // prepare_mrw (grid_mrw_3d.f90:29-53) + update_alpha_inv_planck (grid_physics_3d.f90:397-418),
 // plus kappa_planck(specific_energy) of every (cell, dust) for the deposits of grid_do_mrw.
 // One thread per cell.
-__global__ void mrw_prepare_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ specific_energy,
+static __global__ void mrw_prepare_kernel(const DProblem *__restrict__ Pp, const double *__restrict__ specific_energy,
                                    const double *__restrict__ density, double *__restrict__ alpha, double *__restrict__ diff,
                                    double *__restrict__ kp)
 {
@@ -2742,7 +2742,7 @@ __global__ void mrw_prepare_kernel(const DProblem *__restrict__ Pp, const double
 // mode 2: update_energy_abs only (no sublimation: solve_pda comes in between, iter_lucy.f90:224-235);
 // mode 3: sublimate_dust from the current specific energy.  `spec` = the frequency-resolved specific
 // energy [n_bins][n_cells][n_dust], rescaled or reset where dust sublimates (:441-447,463-464,479-480).
-__global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, int mode,
+static __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, int mode,
                               double *__restrict__ specific_energy, double *__restrict__ density,
                               const double *__restrict__ additional, int *__restrict__ jnu_id,
                               double *__restrict__ jnu_frac, double *__restrict__ energy_abs_tot,
@@ -2804,7 +2804,7 @@ __global__ void finish_kernel(const DProblem *__restrict__ Pp, FinishParams F, i
 }
 
 // [n_dust][n_cells] (reference layout) <-> [n_cells][n_dust] (device layout)
-__global__ void to_cell_major_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
+static __global__ void to_cell_major_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
 {
     size_t n = n_cells * nd, step = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {
@@ -2813,7 +2813,7 @@ __global__ void to_cell_major_kernel(const double *__restrict__ in, double *__re
     }
 }
 
-__global__ void to_ref_layout_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
+static __global__ void to_ref_layout_kernel(const double *__restrict__ in, double *__restrict__ out, size_t n_cells, int nd)
 {
     size_t n = n_cells * nd, step = (size_t)gridDim.x * blockDim.x;
     for (size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += step) {

@@ -24,7 +24,8 @@ def build(specs):
         name, _, flags = spec.partition(":")
         out = os.path.join(VDIR, name + ".so")
         objs = []
-        units = [("engine", "hyp_engine.hip", ["-DHYP_VARIANT_GEOM=%d" % geom])]
+        from hyperion_amd.build import HOST_UNITS
+        units = [("host_" + u, "hyp_%s.hip" % u, ["-DHYP_VARIANT_GEOM=%d" % geom]) for u in HOST_UNITS]
         for part, k in PARTS.items():
             if part in mine:
                 units.append((part, "hyp_geom.hip", ["-DHYP_GEOM_TU=%d" % geom, "-DHYP_PART=%d" % k, "-DHYP_ONLY_ND=" + nd]))
