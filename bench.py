@@ -345,6 +345,11 @@ def main():
 
     rccl = None
     if dist is not None:
+        # RCCL writes a version banner to STDOUT when the first communicator is created (the all-reduce below): sent to stderr, so
+        # that the JSON line is the only thing this command prints
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
         # What RCCL itself saw, so that the line cannot claim N GPUs on the strength of WORLD_SIZE alone: an all-reduce of ones,
         # the process group's size, and every rank's device (index, PCI bus id) gathered through the same backend.
         ones = torch.ones(1, dtype=torch.float64, device="cuda")
@@ -355,6 +360,10 @@ def main():
                        else "device-%d" % torch.cuda.current_device()}
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
+        torch.cuda.synchronize()
+        sys.stdout.flush()
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
         rccl = {"backend": dist.get_backend(), "ranks_seen": int(round(float(ones.item()))), "world_size": dist.get_world_size(), "devices": gathered,
                 "distinct_devices": len({g["pci"] for g in gathered})}
         if rccl["ranks_seen"] != world or rccl["world_size"] != world or rccl["distinct_devices"] != world:
