@@ -257,7 +257,12 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
         T.n_bricks = T.nbx * T.nby * T.nbz;
         // spherical grids: packets that have not interacted yet (radial for a central source: no cone wall is ever in reach, hyp_polar.h:
         // sph_cone_out_of_reach) sorted apart from the others, so that their waves skip the cone quadratics
-        if (P.grid_type == 5 && h->pt_vsplit && 2 * T.n_bricks <= HYP_TILE_MAX_BRICKS) { T.vsplit = 2; T.n_bricks *= 2; }
+        if (P.grid_type == 5 && h->pt_vsplit) {
+            // (and the flights that start outwards apart from those that start inwards: the reference's find_wall leaves the inner sphere out
+            // for the former, `radial`, which a wave can only skip when all its lanes do)
+            const int vs = 3 * T.n_bricks <= HYP_TILE_MAX_BRICKS ? 3 : 2 * T.n_bricks <= HYP_TILE_MAX_BRICKS ? 2 : 1;
+            if (vs > 1) { T.vsplit = vs; T.n_bricks *= vs; }
+        }
         T.presort = nd == 1 && h->tile_presort ? 1 : 0;
     } else {
         tile_shape(nd, T.bx, T.by, T.bz);

@@ -277,6 +277,10 @@ __device__ __forceinline__ void sph_wall_cone(const DProblem &P, const double r[
     const double pA = v2_xy - v2_z * tt2;
     double pB = rv_xy - rv_z * tt2; pB = pB + pB;
     const double pC = r2_xy - r2_z * tt2;
+    // Three coefficients of one strict sign: no positive root (Descartes), and the formulas below say so too -- q has the sign of -pB, so
+    // q / pA and pC / q are negative (or -huge without real roots), the side test can only turn them into +huge, and insert_t takes
+    // neither a negative value nor +huge.  Exact, and it spares the square root and both divisions.
+    if ((pA > 0.0 && pB > 0.0 && pC > 0.0) || (pA < 0.0 && pB < 0.0 && pC < 0.0)) return;
     if (fabs(pA) > 0.0) {
         double t1, t2;
         quad_full(pA, pB, pC, t1, t2);
@@ -337,7 +341,9 @@ __device__ __forceinline__ bool sph_find_wall(const DProblem &P, const Walls &W,
     const double wr2_a = P.wr2[i1], wr2_b = P.wr2[i1 + 1], e0_a = P.ew[0][i1], e0_b = P.ew[0][i1 + 1];
     double e1_a = P.ew[1][i2], e1_b = P.ew[1][i2 + 1], tt_a = P.wtant[i2], tt_b = P.wtant[i2 + 1], tt2_a = P.wtant2[i2], tt2_b = P.wtant2[i2 + 1];
     asm volatile("" : "+v"(e1_a), "+v"(e1_b), "+v"(tt_a), "+v"(tt_b), "+v"(tt2_a), "+v"(tt2_b));
-    if (!c.radial) {
+    // (inner sphere; with pB >= 0 and pC - w^2 >= 0 -- outside it and moving away -- both roots are <= 0 (sum -pB, product >= 0), in
+    // quad_reduced's arithmetic too: q = -(pB + sqrt) / 2 <= 0 and c / q <= 0; insert_t takes neither)
+    if (!c.radial && !(pB >= 0.0 && pC - wr2_a >= 0.0)) {
         quad_reduced(pB, pC - wr2_a, t1, t2);
         insert_pair(ws, t1, t2, c.ow[0] == -1, 0, -1, e0_a);
     }

@@ -122,7 +122,7 @@ struct TileGeom {
     int imaging;                 // 1: the imaging iteration on this schedule -- walks deposit nothing (grid_integrate_noenergy)
     const int *drain_list;       // tile_drain: the slots that still hold a packet (tile_live_kernel), TileCtl::n_live of them
     int presort;                 // 1: the walk writes slot | kind << 30 into the interaction lists (HotRec::pad; one species, Cartesian walk)
-    int vsplit;                  // 2: every brick is two entries of the sort -- 2 b for packets that have not interacted yet, 2 b + 1 for the others
+    int vsplit;                  // 3 (2): every brick is three (two) entries of the sort -- 3 b for packets that have not interacted yet, 3 b + 1 for flights that start outwards, 3 b + 2 inwards
 };                               //    (spherical grids: waves of one kind, hyp_ptile.h); 0 / 1: one entry per brick
 
 // per task of the current generation: how many of its packets ended the visit waiting for an interaction
@@ -548,7 +548,12 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
                 if (IMG) cold_flags_store(cold[slot], f, peel_seq);
-                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) brick = brick * T.vsplit + 1; slot_brick[slot] = brick; }
+                if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) {
+                        int kind = 1;      // spherical grids: 1 = the integration starts outwards (find_wall skips the inner sphere for the whole flight), 2 = inwards
+                        if constexpr (GEOM == GEOM_SPH) kind = (T.vsplit > 2 && !p.cell.radial) ? 2 : 1;
+                        brick = brick * T.vsplit + kind;
+                    }
+                    slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts again
                     slot_brick[slot] = TILE_NEEDS_INTERACT;
