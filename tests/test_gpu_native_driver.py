@@ -96,8 +96,10 @@ def test_native_driver_writes_what_the_python_adapter_writes(suffix, name, tmp_p
         shutil.copy(native, os.path.join(keep, "native_oct.native.rtout"))
 
 
-def test_reference_model_output_reads_the_native_rtout(tmp_path):
-    """the physical content, not just the layout: flux arrives in the SED, the specific energy is positive where there is dust"""
+def test_native_rtout_holds_physical_content_read_with_h5py(tmp_path):
+    """The physical content of the native driver's output, read with plain h5py (not with the reference's ModelOutput: the reference
+    does not travel to the GPU box; tools/validate_rtout_with_reference.py does that round trip in the build container): flux arrives
+    in the SED, the specific energy is positive where there is dust, the apertures accumulate outwards."""
     native = str(tmp_path / "native.rtout")
     r = subprocess.run([os.path.join(BIN, "hyperion_oct"), "-f", os.path.join(GOLDEN, "native_oct.rtin"), native], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr
