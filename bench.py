@@ -20,8 +20,26 @@ import time
 
 # The CPU baseline's OpenMP threads: one per physical core, spread over the sockets and pinned (read by libgomp when it is loaded, so
 # set before anything imports it).  The GPU path does not use host threads.
-os.environ.setdefault("OMP_PROC_BIND", "spread")
-os.environ.setdefault("OMP_PLACES", "cores")
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max or v1 cfs quota), or None without a limit: a box can show 256
+    logical CPUs and allow 16 of them at a time -- threads beyond the quota are throttled, not run."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+if cpu_quota() is None:      # the whole machine is ours: pin; under a quota on a shared host the scheduler places the few threads better
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
 
 HOST_CPUS = sorted(os.sched_getaffinity(0))      # taken now: with the variables above libgomp pins this (main) thread to its first place when it loads
 
@@ -96,19 +114,17 @@ def physical_cores():
     return max(1, len(allowed) // 2)
 
 
-def make_small(n, n_sample):
-    from hyperion_amd.benchmark import make_benchmark_problem
-    return make_benchmark_problem(n, n_photons=int(n_sample), n_iter=1)
-
-
 def cpu_baseline(prob, n_sample):
-    """Oracle (CPU restatement) timed on this host's cores on a bounded sample of the same workload: on every physical core
-    (the reported value), on 64 threads (what round 4 reported) and on ONE core, threads pinned one per core and spread over
-    the sockets (OMP_PROC_BIND=spread, OMP_PLACES=cores), per-thread accumulators first touched by their own thread.  Test
+    """Oracle (CPU restatement) timed on this host on a bounded sample of the same workload: on as many threads as the host gives
+    this process -- physical cores, or the container's CPU quota when there is one (the GPU boxes of this pool show 256 logical
+    CPUs and allow 16) --, on four times as many (what oversubscription does) and on ONE thread; without a quota the threads are
+    pinned one per core and spread over the sockets; per-thread accumulators are first touched by their own thread.  Test
     infrastructure used as the reported baseline, never as the product."""
     from oracle_lib import Oracle
     logical = len(HOST_CPUS)
     cores = physical_cores()
+    quota = cpu_quota()
+    usable = cores if quota is None else max(1, min(cores, int(quota + 0.5)))
     orc = Oracle(prob)
 
     def timed(n, threads):
@@ -120,35 +136,22 @@ def cpu_baseline(prob, n_sample):
                 "sample": "%d packets of the same workload, 1 Lucy iteration, %d OpenMP thread(s) (%.1f s)" % (n, threads, dt)}
     one = timed(max(min(n_sample // 80, 250000), 1000), 1)
     # (the sample scales with the threads so that each leg stays near ten seconds whatever the host)
-    per_thread = max(min(n_sample // 64, 400000), 2000)
-    allc = timed(min(n_sample, per_thread * cores), cores)
-    legs = {"1": one, str(cores): allc}
-    if cores > 64:
-        legs["64"] = timed(min(n_sample, per_thread * 64), 64)
+    per_thread = max(min(n_sample // 16, 400000), 2000)
+    legs = {"1": one, str(usable): timed(min(n_sample, per_thread * usable), usable)}
+    if usable < cores:      # what oversubscribing the quota gives (round 4 ran 64 threads on a box that allows 16 CPUs)
+        more = min(cores, 4 * usable)
+        legs[str(more)] = timed(min(n_sample, per_thread * usable), more)
     orc.close()
     best = max(legs.values(), key=lambda l: l["value"])
-    # Why it scales the way it does: every thread scatters into its own 16 MiB accumulator copy, so beyond a few threads per
-    # L3 slice each crossing is a DRAM round trip.  The same oracle on a 32^3 grid (256 KB per copy: cache resident) shows what
-    # the cores do when memory is out of the way.
-    small_prob = make_small(32, n_sample)
-    so = Oracle(small_prob)
-    so.lucy_iteration(2000 * cores, 1, n_threads=cores)
-
-    def timed_small(n, threads):
-        t0 = time.time()
-        so.lucy_iteration(n, 1, n_threads=threads)
-        return n / (time.time() - t0)
-    s_one, s_all = timed_small(200000, 1), timed_small(200000 * min(cores, 64), cores)
-    so.close()
     out = dict(best)
     out.update({"kind": "port", "host_cpu": host_cpu(), "host_logical_cpus": logical, "host_physical_cores": cores,
                 "one_core": one, "threads": legs, "scaling_over_one_core": best["value"] / one["value"],
-                "cache_resident_check": {"grid": "32^3, same source and dust (tau = 1 centre to face)", "one_core_packets_per_s": s_one, "all_cores_packets_per_s": s_all,
-                                         "cores": cores, "scaling_over_one_core": s_all / s_one},
+                "host_cpu_quota": quota, "host_load_average": os.getloadavg()[0],
                 "omp": {k: os.environ.get(k) for k in ("OMP_PROC_BIND", "OMP_PLACES")},
                 "note": "the CPU restatement (oracle/hyp_oracle.c), not the Fortran: the reference needs its absent fortranlib submodule to build "
                         "(DESIGN.md section 6 has the survey's probe of the reference's own geometry loop for calibration); every thread deposits "
-                        "into its own 16 MiB accumulator copy, reduced in parallel at the end; the value is the best of the thread counts tried"})
+                        "into its own 16 MiB accumulator copy, reduced in parallel at the end; threads = min(physical cores, the container's CPU quota) -- the box shows "
+                        "host_logical_cpus and lets the container use host_cpu_quota of them at a time; the value is the best of the thread counts tried"})
     return out
 
 
