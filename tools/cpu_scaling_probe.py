@@ -1,5 +1,5 @@
 import os, sys, time
-os.environ.setdefault("OMP_PROC_BIND", "spread"); os.environ.setdefault("OMP_PLACES", "cores")
+
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from oracle_lib import Oracle
 from hyperion_amd.benchmark import make_benchmark_problem
