@@ -103,6 +103,22 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     check_killed_counts([g[1] for g in gk["iterations"]][:n_common], [k[:n_common] for k in killed_int], ("gpu", tau))
 
 
+@pytest.mark.parametrize("tau", ["0.1", "1", "10", "100"])
+def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
+    """The reference's Pascucci benchmark outputs (spherical polar grid, stellar sphere, monochromatic final iteration at 61
+    wavelengths + raytracing) against realisations of the HIP engine: the statistics of tests/test_oracle_golden.py."""
+    from test_oracle_golden import check_pascucci_golden
+    check_pascucci_golden(hyperion_amd.Engine, tau)
+
+
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
+def test_pinte_benchmark_images_match_reference_golden(tau):
+    """The reference's Pinte benchmark IMAGES (cylindrical polar grid, MRW, monochromatic + raytracing, 51 x 51 Stokes images of
+    two nearly edge-on views) against realisations of the HIP engine: annuli, peak pixel and totals as in tests/test_oracle_golden.py."""
+    from test_oracle_golden import check_pinte_images_golden
+    check_pinte_images_golden(hyperion_amd.Engine, tau)
+
+
 class _EngineRunner:
     def __init__(self, prob):
         self.e = hyperion_amd.Engine(prob)

@@ -277,11 +277,11 @@ def test_pooled_polarisation_amplitude_and_flux_over_all_peeloff_goldens():
     check_pooled_peeloff_statistics(pooled_peeloff_statistics(Oracle, **POOL))
 
 
-def _pascucci_run(prob, seed, scale=1):
+def _pascucci_run(make, prob, seed, scale=1):
     """program main's sequence for the Pascucci model: 5 Lucy iterations, the monochromatic final
     iteration (scattered light only, raytracing is on), the raytracing iteration."""
-    prob.config.seed = seed
-    o = Oracle(prob)
+    from golden_stats import _with_seed
+    o = make(_with_seed(prob, seed))
     for it in range(1, 6):
         o.lucy_iteration(1000 * scale, it)
     o.mono_iteration(1000 * scale, 1000 * scale)
@@ -291,23 +291,23 @@ def _pascucci_run(prob, seed, scale=1):
     return res[0]["sed"]
 
 
-@pytest.mark.parametrize("tau", ["0.1", "1", "10", "100"])
-def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
+def check_pascucci_golden(make, tau, workers=1, make_big=None):
     """test_pascucci.tau=*.rtout (test_bit_level.py:341-427): MONOCHROMATIC final iteration
     (iter_final_mono.f90) at 61 wavelengths + raytracing on a 100 x 30 spherical polar grid around
     a stellar sphere.  The golden is one realisation with 1000 packets per part; all wavelengths
     share the raytraced packets, so its noise is coherent in wavelength (a sphere's peel-off weight
-    4 mu scatters by 4 % over 1000 packets): per (view, wavelength) z-scores against K oracle
-    realisations, and the write-time normalisation nu * F_nu of exact-frequency cubes
-    (image_type.f90:675-683)."""
+    4 mu scatters by 4 % over 1000 packets): per (view, wavelength) z-scores against K realisations of the runner
+    `make` (the oracle here, the HIP engine in tests/test_gpu_golden.py), and the write-time normalisation nu * F_nu of
+    exact-frequency cubes (image_type.f90:675-683)."""
+    from golden_stats import ensemble
     prob, z = golden_problem("pascucci.tau=%s.npz" % tau)
     assert prob.grid_type == "sph_pol" and prob.config.monochromatic and prob.config.raytracing
     np.testing.assert_allclose(z["golden/frequencies"], prob.config.frequencies, rtol=1e-14)
     gold = z["golden/seds"]
     nu = prob.config.frequencies
     K = 12 if tau != "100" else 8          # (the optically thick disc costs the oracle 4 x more per packet)
-    samples = np.array([_pascucci_run(prob, -(300 + k)) for k in range(K)]) * nu
-    mean = _pascucci_run(prob, -7, scale=12 if tau != "100" else 5) * nu
+    samples = np.array(ensemble(lambda seed: _pascucci_run(make, prob, seed), [-(300 + k) for k in range(K)], workers)) * nu
+    mean = _pascucci_run(make_big or make, prob, -7, scale=12 if tau != "100" else 5) * nu
     assert gold.shape == mean.shape
     sig = samples.std(axis=0, ddof=1)
     I, g = mean[0, 0, :, 0, :], gold[0, 0, :, 0, :]
@@ -323,9 +323,14 @@ def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
         assert abs(g[iv].sum() - I[iv].sum()) < 4.0 * tot_s[:, iv].std(ddof=1) + 0.02 * I[iv].sum()
 
 
+@pytest.mark.parametrize("tau", ["0.1", "1", "10", "100"])
+def test_monochromatic_pascucci_benchmark_matches_reference_golden(tau):
+    check_pascucci_golden(SerialOracle, tau, POOL["workers"], make_big=Oracle)
+
+
 def _pinte_run(prob, n_iter, seed):
-    prob.config.seed = seed
-    o = Oracle(prob)
+    from golden_stats import _with_seed
+    o = SerialOracle(_with_seed(prob, seed))
     for it in range(1, n_iter + 1):
         o.lucy_iteration(5000, it)
     o.mono_iteration(100, 200)
@@ -349,7 +354,8 @@ def test_pinte_benchmark_seds_match_reference_golden(tau):
     gold = z["golden/seds"]
     nu = c.frequencies
     K = 12
-    S = np.array([_pinte_run(prob, n_iter, -(500 + k)) for k in range(K)]) * nu
+    from golden_stats import ensemble
+    S = np.array(ensemble(lambda seed: _pinte_run(prob, n_iter, seed), [-(500 + k) for k in range(K)], POOL["workers"])) * nu
     assert S.shape[1:] == gold.shape == (4, 1, 4, 1, 51)
     I, sg = S.mean(axis=0)[0, 0, :, 0, :], S.std(axis=0, ddof=1)[0, 0, :, 0, :]
     g = gold[0, 0, :, 0, :]
@@ -366,9 +372,9 @@ def test_pinte_benchmark_seds_match_reference_golden(tau):
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
 
 
-def _pinte_image_run(prob, seed):
-    prob.config.seed = seed
-    o = Oracle(prob)
+def _pinte_image_run(make, prob, seed):
+    from golden_stats import _with_seed
+    o = make(_with_seed(prob, seed))
     for it in range(1, 4):
         o.lucy_iteration(10000, it)
     o.mono_iteration(10000, 10000)
@@ -377,9 +383,9 @@ def _pinte_image_run(prob, seed):
     return res[0]["img"] * prob.config.frequencies[0]
 
 
-@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
-def test_pinte_benchmark_images_match_reference_golden(tau):
-    """test_pinte_images.tau=*.rtout (test_bit_level.py:549-637): 51 x 51 Stokes images of the Pinte disc at 1 micron,
+def check_pinte_images_golden(make, tau, workers=1):
+    """(`make`: the oracle here, the HIP engine in tests/test_gpu_golden.py.)
+    test_pinte_images.tau=*.rtout (test_bit_level.py:549-637): 51 x 51 Stokes images of the Pinte disc at 1 micron,
     two nearly edge-on views -- cylindrical polar grid, stellar sphere, MRW, MONOCHROMATIC final iteration and
     raytracing, imaged.  The golden's surface brightness in annuli around the star against K oracle realisations
     at its own packet numbers, the peak pixel, and the total flux of each view."""
@@ -387,7 +393,8 @@ def test_pinte_benchmark_images_match_reference_golden(tau):
     assert prob.grid_type == "cyl_pol" and prob.config.monochromatic and prob.peeled[0].n_x == 51
     gold = z["golden/images"]
     K = 10
-    S = np.array([_pinte_image_run(prob, -(700 + k)) for k in range(K)])
+    from golden_stats import ensemble
+    S = np.array(ensemble(lambda seed: _pinte_image_run(make, prob, seed), [-(700 + k) for k in range(K)], workers))
     assert S.shape[1:] == gold.shape == (4, 1, 2, 51, 51, 1)
     yy, xx = np.mgrid[0:51, 0:51]
     rad = np.hypot(yy - 25, xx - 25)
@@ -409,6 +416,11 @@ def test_pinte_benchmark_images_match_reference_golden(tau):
         assert abs(g.sum() - tot.mean()) < 5.0 * tot.std(ddof=1) + 0.02 * tot.mean()
     # the SED of the single aperture is the summed image
     np.testing.assert_allclose(z["golden/seds"][0, 0, :, 0, 0], gold[0, 0].sum(axis=(1, 2, 3)), rtol=1e-6)
+
+
+@pytest.mark.parametrize("tau", ["1000", "10000", "100000", "1000000"])
+def test_pinte_benchmark_images_match_reference_golden(tau):
+    check_pinte_images_golden(SerialOracle, tau, POOL["workers"])
 
 
 def pooled_specific_energy_bias(make_runner, n_packets=200000):
