@@ -113,21 +113,23 @@ def compile_units(out, extra_flags=(), objdir=OBJDIR, verbose=False, force=False
             for stale in (obj + ".cmd", obj):
                 if os.path.exists(stale):
                     os.remove(stale)
-            running.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+            running.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC), time.time()))
         still = []
-        for cmd, obj, p in running:
+        for cmd, obj, p, t_start in running:
             rc = p.poll()
             if rc is None:
-                still.append((cmd, obj, p))
+                still.append((cmd, obj, p, t_start))
             elif rc != 0:
                 failed = failed or (rc, cmd)
             else:
                 with open(obj + ".cmd", "w") as f:
                     f.write(" ".join(cmd))
+                if os.environ.get("HYP_BUILD_TIMES"):      # which units the cold build waits for
+                    print("%6.1f s  %s" % (time.time() - t_start, os.path.basename(obj)), flush=True)
         running = still
         if running and failed is None:
             time.sleep(0.2)
-    for _, _, p in running:
+    for _, _, p, _ in running:
         p.wait()
     if failed:
         raise subprocess.CalledProcessError(*failed)
