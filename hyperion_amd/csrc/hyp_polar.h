@@ -402,6 +402,49 @@ __device__ __forceinline__ void polar_advance(const DProblem &P, Cell<GEOM> &c, 
     else if (c.ic[2] == P.n3) c.ic[2] = 0;
 }
 __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_SPH> &c, const int im[3]) { polar_advance<GEOM_SPH>(P, c, im); }
+// RN(a / b) from y = RN(1 / b) formed once with a true division (Markstein, as in find_wall_ahead of hyp_kernels.h): q0 = RN(a y),
+// rem = a - q0 b exactly (one FMA), q = RN(q0 + rem y) is the correctly rounded quotient -- 3 operations instead of the ~14 of an
+// IEEE division.  No underflow or overflow may occur on the way: see cyl_find_wall_inv's caller.
+__device__ __forceinline__ double quot_inv(double a, double b, double y)
+{
+    const double q0 = a * y;
+    return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+}
+
+// geo_find_wall<GEOM_CYL> for a direction that stays fixed over many steps (round 5): six of a step's eight divisions have a divisor that
+// belongs to the flight -- v_xy^2 four times, v_z twice -- and are formed from its reciprocal, bit for bit the quotients above.  The inner
+// cylinder is left unsolved when the packet is outside it and moving away (pB >= 0 and its constant term >= 0: both roots <= 0 in
+// quad_reduced's arithmetic too, see sph_find_wall).  The caller guarantees v2_xy = v_x^2 + v_y^2 >= 2^-200, |v_z| >= 2^-200 and an outer radius
+// in [2^-250, 2^250], which keeps every non-zero operand (squares and differences of coordinates, multiples of a coordinate's ulp)
+// and every intermediate product hundreds of binades away from underflow and overflow.
+__device__ __forceinline__ bool cyl_find_wall_inv(const DProblem &P, const double r[3], const double v[3], const Cell<GEOM_CYL> &c,
+                                                  double v2_xy, double inv_v2, double inv_vz, double &tnear, int im[3])
+{
+    WallSel ws; ws.tmin = HYP_DBL_MAX; ws.emin = 0.0;
+    ws.imin[0] = ws.imin[1] = ws.imin[2] = 0; ws.iext[0] = ws.iext[1] = ws.iext[2] = 0;
+    const double rv_xy = r[0] * v[0] + r[1] * v[1];
+    const double r2_xy = r[0] * r[0] + r[1] * r[1];
+    double pB = quot_inv(rv_xy, v2_xy, inv_v2); pB = pB + pB;
+    const double pC = quot_inv(r2_xy, v2_xy, inv_v2);
+    double t1, t2;
+    const int i1 = c.ic[0], i2 = c.ic[1];
+    const double wr2_a = P.wr2[i1], wr2_b = P.wr2[i1 + 1], e0_a = P.ew[0][i1], e0_b = P.ew[0][i1 + 1], wz_a = P.w[1][i2], wz_b = P.w[1][i2 + 1];
+    const double ca = pC - quot_inv(wr2_a, v2_xy, inv_v2);
+    if (!(pB >= 0.0 && ca >= 0.0)) {
+        quad_reduced(pB, ca, t1, t2);
+        insert_pair(ws, t1, t2, c.ow[0] == -1, 0, -1, e0_a);
+    }
+    quad_reduced(pB, pC - quot_inv(wr2_b, v2_xy, inv_v2), t1, t2);
+    insert_pair(ws, t1, t2, c.ow[0] == +1, 0, +1, e0_b);
+    if (c.ow[1] != -1) insert_t(ws, quot_inv(wz_a - r[2], v[2], inv_vz), 1, -1, 0.0);
+    if (c.ow[1] != +1) insert_t(ws, quot_inv(wz_b - r[2], v[2], inv_vz), 1, +1, 0.0);
+    polar_wall_phi<GEOM_CYL>(P, r, v, c, r2_xy, ws);
+    tnear = ws.tmin;
+#pragma unroll
+    for (int a = 0; a < 3; a++) im[a] = ws.imin[a] + ws.iext[a];
+    return (im[0] | im[1] | im[2]) != 0;
+}
+
 __device__ __forceinline__ void geo_advance(const DProblem &P, const double r[3], Cell<GEOM_CYL> &c, const int im[3]) { polar_advance<GEOM_CYL>(P, c, im); }
 
 // distance_to_closest_wall: spherical_3d.f90:675-739, cylindrical_3d.f90:552-591

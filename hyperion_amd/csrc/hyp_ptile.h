@@ -69,6 +69,9 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
     // lane state: the walking part of a packet (the rest stays in its ColdRec)
     double r[3] = {0.0, 0.0, 0.0}, v[3] = {1.0, 0.0, 0.0}, tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
     double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
+    double cyl_v2 = 1.0, cyl_inv_v2 = 1.0, cyl_inv_vz = 1.0;      // cylindrical grids: v_xy^2 and the reciprocals of the flight
+    bool cyl_ok = false;
+    const bool grid_tame = P.w[0][P.n1] >= 0x1p-250 && P.w[0][P.n1] <= 0x1p250;
     Cell<GEOM> cell;
     cell.ic[0] = x0; cell.ic[1] = y0; cell.ic[2] = z0; cell.ow[0] = cell.ow[1] = cell.ow[2] = 0;
     if constexpr (GEOM == GEOM_SPH) cell.radial = 0;
@@ -146,6 +149,11 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                     g.countdown = H.countdown; g.blk_b = H.blk_b;
                     slot |= (H.pad & 1) << 30;
                     if (P.any_intersect) { t_src = cold[SLOT].t_src; t_ach = cold[SLOT].t_ach; }
+                    if constexpr (GEOM == GEOM_CYL) {      // the flight's reciprocals (cyl_find_wall_inv)
+                        cyl_v2 = v[0] * v[0] + v[1] * v[1];
+                        cyl_ok = grid_tame && cyl_v2 >= 0x1p-200 && fabs(v[2]) >= 0x1p-200;
+                        cyl_inv_v2 = 1.0 / cyl_v2; cyl_inv_vz = 1.0 / v[2];
+                    }
                     st = LS_WALK;
                 }
             }
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
                     double tmin; int im[3];
                     bool found;
                     if constexpr (GEOM == GEOM_SPH) found = sph_find_wall(P, W, r, v, cell, tmin, im, reach_task);
-                    else found = geo_find_wall(P, W, r, v, cell, tmin, im);
+                    else found = cyl_ok ? cyl_find_wall_inv(P, r, v, cell, cyl_v2, cyl_inv_v2, cyl_inv_vz, tmin, im) : geo_find_wall(P, W, r, v, cell, tmin, im);
                     if (!found) { cnt.killed_geo++; st = LS_DEAD; }
                     else {
                         const int loc = ((cell.ic[2] - z0) * by + (cell.ic[1] - y0)) * bx + (cell.ic[0] - x0);
