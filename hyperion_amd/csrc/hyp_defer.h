@@ -88,9 +88,7 @@ __device__ __forceinline__ int defer_step(const DProblem &P, const Walls &W, Pac
     } else g.countdown--;
     double tmin; int im[3];
     bool found;
-    if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
-    else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, p.r, p.v, inv, p.cell, tmin, im) : geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
-    else found = geo_find_wall(P, W, p.r, p.v, p.cell, tmin, im);
+    found = find_wall_fixed_dir<GEOM>(P, W, p.r, p.v, inv, v_ok, p.cell, tmin, im);
     if (!found) { cnt.killed_geo++; return ff ? ST_FF_KILLED : ST_NEED_EMIT; }
     const size_t base = geo_index(P, p.cell) * (size_t)nd;
     double rho[NDT];
@@ -409,11 +407,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 w_pos += __popcll(m); n_written += __popcll(m);
             }
             if (peel != 0) {
-                if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {         // the direction is new
-                    v_ok = true;
-#pragma unroll
-                    for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
-                }
+                walk_reciprocals<GEOM>(P, p.v, inv, v_ok);      // the direction is new
                 if (peel == 1) {
                     // first propagation after emission: iter_final.f90:191-209
                     if (geo_escaped(P, p.cell)) st = ST_ESCAPED;
@@ -584,11 +578,7 @@ __global__ __launch_bounds__(256, HYP_FF_OCC) void ff_walk_kernel(const DProblem
                         R.energy = p.energy; R.tau_req = 0.0;
                         R.buf_a = g.buf_a; R.blk_a = g.blk_a; R.blk_b = g.blk_b; R.code = (g.have_a & 1) | (1 << 1); R.countdown = g.countdown;
                     } else {
-                        if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
-                            v_ok = true;
-#pragma unroll
-                            for (int a = 0; a < 3; a++) { inv[a] = 1.0 / p.v[a]; v_ok = v_ok & ((p.v[a] == 0.0) | (fabs(p.v[a]) >= 0x1p-400)); }
-                        }
+                        walk_reciprocals<GEOM>(P, p.v, inv, v_ok);      // the direction is new
                         p.tau_ach = 0.0; p.tau_req = 0.0;
                         geo_begin(p.r, p.v, p.cell);
                         st = ST_FF;
@@ -736,10 +726,7 @@ __global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__res
             angle_to_vector(a_req, v[0], v[1], v[2]);
             double inv[3] = {1.0, 1.0, 1.0};
             bool v_ok = true;
-            if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
-#pragma unroll
-                for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
-            }
+            walk_reciprocals<GEOM>(P, v, inv, v_ok);
             Cell<GEOM> c;
             memset(&c, 0, sizeof c);
             if (geo_place(P, W, r, v, c)) {        // (not placed: the peel kernel counts a killed packet per event and does not walk)
@@ -752,9 +739,7 @@ __global__ __launch_bounds__(64) void direct_column_kernel(const DProblem *__res
                 if (!geo_escaped(P, c)) for (;;) {
                     double tmin = 0.0; int im[3];
                     bool found;
-                    if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                    else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                    else found = geo_find_wall(P, W, r, v, c, tmin, im);
+                    found = find_wall_fixed_dir<GEOM>(P, W, r, v, inv, v_ok, c, tmin, im);
                     if (!found) { status = 2; break; }
                     const size_t base = geo_index(P, c) * (size_t)nd;
 #pragma unroll
@@ -897,11 +882,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                         }
                     }
                     angle_to_vector(a_req, v[0], v[1], v[2]);
-                    if (GEOM == GEOM_OCT || GEOM == GEOM_CAR) {
-                        v_ok = true;
-#pragma unroll
-                        for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
-                    }
+                    walk_reciprocals<GEOM>(P, v, inv, v_ok);
                     c = E.cell;
                     bool ok = geo_place(P, W, r, v, c);
                     if (!ok) cnt.killed_geo++;
@@ -968,9 +949,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
                 } else gp.countdown--;
                 double tmin = 0.0; int im[3];
                 bool found;
-                if constexpr (GEOM == GEOM_OCT) found = v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                else if constexpr (GEOM == GEOM_CAR) found = v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
-                else found = geo_find_wall(P, W, r, v, c, tmin, im);
+                found = find_wall_fixed_dir<GEOM>(P, W, r, v, inv, v_ok, c, tmin, im);
                 if (!check_ok || !found) { cnt.killed_geo++; st = 0; }
                 else {
                     const size_t base = geo_index(P, c) * (size_t)nd;

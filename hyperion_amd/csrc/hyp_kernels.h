@@ -1597,17 +1597,23 @@ __global__ __launch_bounds__(256, lucy_waves<GEOM>()) void lucy_kernel(const DPr
 // peeloff_photon (images_peeled.f90:95-270)
 // ---------------------------------------------------------------------------
 
-// One walk along a fixed direction (grid_escape_tau, grid_escape_column_density): on Cartesian grids and octrees the wall search with one
+// One walk along a fixed direction (grid_escape_tau, grid_escape_column_density): on Cartesian and cylindrical grids and octrees the wall search with one
 // reciprocal per direction (car_find_wall_inv / oct_find_wall_inv: the same wall, the same t bit for bit, three operations per quotient
 // instead of an IEEE division); inv = RN(1 / v), v_ok = every non-zero component at least 2^-400 in magnitude.
 template <int GEOM>
-__device__ __forceinline__ void walk_reciprocals(const double v[3], double inv[3], bool &v_ok)
+__device__ __forceinline__ void walk_reciprocals(const DProblem &P, const double v[3], double inv[3], bool &v_ok)
 {
     v_ok = false;
     if constexpr (GEOM == GEOM_CAR || GEOM == GEOM_OCT) {
         v_ok = true;
 #pragma unroll
         for (int a = 0; a < 3; a++) { inv[a] = 1.0 / v[a]; v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400)); }
+    }
+    if constexpr (GEOM == GEOM_CYL) {
+        // cyl_find_wall_inv (hyp_polar.h): inv = (1 / v_xy^2, v_xy^2, 1 / v_z); its range conditions
+        const double v2 = v[0] * v[0] + v[1] * v[1], r_out = P.w[0][P.n1];
+        v_ok = r_out >= 0x1p-250 && r_out <= 0x1p250 && v2 >= 0x1p-200 && fabs(v[2]) >= 0x1p-200;
+        inv[0] = 1.0 / v2; inv[1] = v2; inv[2] = 1.0 / v[2];
     }
 }
 template <int GEOM>
@@ -1616,6 +1622,7 @@ __device__ __forceinline__ bool find_wall_fixed_dir(const DProblem &P, const Wal
 {
     if constexpr (GEOM == GEOM_OCT) return v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
     else if constexpr (GEOM == GEOM_CAR) return v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+    else if constexpr (GEOM == GEOM_CYL) return v_ok ? cyl_find_wall_inv(P, r, v, c, inv[1], inv[0], inv[2], tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
     else return geo_find_wall(P, W, r, v, c, tmin, im);
 }
 
@@ -1641,7 +1648,7 @@ __device__ __forceinline__ double escape_tau(const DProblem &P, const Walls &W, 
     }
     double t_achieved = 0.0;       // inside observers stop at the observer: grid_propagate_3d.f90:446-452
     double inv[3] = {1.0, 1.0, 1.0}; bool v_ok;
-    walk_reciprocals<GEOM>(v, inv, v_ok);
+    walk_reciprocals<GEOM>(P, v, inv, v_ok);
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp, stream);
@@ -2010,7 +2017,7 @@ __device__ __forceinline__ void escape_column(const DProblem &P, const Walls &W,
     }
     double t_current = 0.0;
     double inv[3] = {1.0, 1.0, 1.0}; bool v_ok;
-    walk_reciprocals<GEOM>(v, inv, v_ok);
+    walk_reciprocals<GEOM>(P, v, inv, v_ok);
     for (;;) {
         if (g.countdown == 0) {
             g.countdown = rng_check_gap(g, P.check_p, P.check_log1mp);

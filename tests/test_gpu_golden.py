@@ -45,7 +45,7 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     from hyperion_amd.run import run_problem
     prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
     gold = z["golden/seds"]
-    K = 12
+    K = 32      # (12 until round 5: the statistic on the last iteration's absorbed luminosity below needs sigma to 13 %, not 21 %)
     S, n_it, e_last, se_last, killed_int, killed_geo = [], [], [], [], [], []
     w = prob.density * prob.volumes
     for k in range(K):
@@ -84,7 +84,8 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     e_gold = (z["golden/specific_energy_last"] * w).sum()
     # The absorbed luminosity of the LAST iteration against the K realisations, in log space (the total is a product of
     # feedbacks through the temperatures of a few mid-plane cells and scatters log-normally: sigma = 0.02 dex at tau = 1e3,
-    # 0.10 dex at tau = 1e6).  |z| < 4.5.  Measured with the oracle over 32 realisations: z = +3.0 at tau = 1e3 (one packet's
+    # 0.10 dex at tau = 1e6).  |z| < 5 with K = 32 (a true offset of 3 sigma, as measured below, then fails once in 1e5 runs; with
+    # K = 12 and a bound of 4.5 it failed once in about twenty).  Measured with the oracle over 32 realisations: z = +3.0 at tau = 1e3 (one packet's
     # random walk through six adjacent inner mid-plane cells leaves 5-18 x their mean energy in the golden: +18 % on the
     # total), +0.7, -0.5, and -3.0 at tau = 1e6 (the ten cells that hold two thirds of the total sit at ranks 0.0-0.67,
     # mean 0.21, of the realisations' heavy-tailed distributions: sd / mean 0.4-1.4 per cell).  Two 3 sigma excursions of
@@ -93,7 +94,7 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     # round-4 bracket min / 2 < golden < 2 max.
     le = np.log10(np.array(e_last))
     z_tot = (np.log10(e_gold) - le.mean()) / (le.std(ddof=1) * np.sqrt(1.0 + 1.0 / K))
-    assert abs(z_tot) < 4.5, (e_gold, sorted(e_last), z_tot)
+    assert abs(z_tot) < 5.0, (e_gold, sorted(e_last), z_tot)
     # killed_photons_int of the ten Lucy iterations (tests/golden/killed_counts.json): the reference's own counters
     from test_oracle_golden import check_killed_counts, killed_counts
     gk = killed_counts("test_pinte_seds.tau=%s" % tau)

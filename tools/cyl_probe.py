@@ -25,3 +25,14 @@ for it in (2, 3):
     _, st = e.lucy_iteration(n, it, want_output=False)
     ms = e.last_kernel_ms()[0]
     print("cyl 400 x 200: %.1f ms, %.3g packets/s, %.0f crossings/packet, %.3g crossings/s, mode %d, killed_geo %d" % (ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3, e.get_option("last_lucy_mode"), st["killed_geo"]), flush=True)
+# imaging iteration on the same disc: peeled SEDs for two views (walks along fixed directions: cyl_find_wall_inv through find_wall_fixed_dir)
+from hyperion_amd.problem import PeeledImages
+p.peeled = [PeeledImages(theta=[30.0, 80.0], phi=[10.0, 200.0], n_wav=20, wav_min=0.1, wav_max=1000.0, compute_image=False,
+                         n_ap=2, ap_min=0.5 * PC, ap_max=2.0 * PC)]
+e2 = hyperion_amd.Engine(p)
+e2.lucy_iteration(n // 10, 1, want_output=False)
+m = n // 4
+e2.final_iteration(m // 10)
+_, st = e2.final_iteration(m)
+ms = e2.last_kernel_ms()[0]
+print("cyl 400 x 200 imaging, two views: %.1f ms, %.3g packets/s, %.0f crossings/packet, %.3g crossings/s, deferred rounds %d" % (ms, m / ms * 1e3, st["crossings"] / m, st["crossings"] / ms * 1e3, e2.get_option("last_defer_rounds")), flush=True)
