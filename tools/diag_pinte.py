@@ -3,7 +3,7 @@ sys.path.insert(0, "."); sys.path.insert(0, "tests")
 from cases import golden_problem
 from hyperion_amd.run import run_problem
 from test_oracle_golden import killed_counts
-tau = "1000000"
+tau = sys.argv[2] if len(sys.argv) > 2 else "1000000"
 prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
 gold = z["golden/seds"]; w = prob.density * prob.volumes
 for rep in range(int(sys.argv[1])):
