@@ -308,6 +308,34 @@ def other_iterations(passes=3):
         e.close()
     except Exception as ex:
         res.append({"config": "spherical polar grid, star with a radius", "error": str(ex)})
+    try:
+        from hyperion_amd.benchmark import make_cyl_disc_problem
+        n = 20_000_000
+        e = hyperion_amd.Engine(make_cyl_disc_problem(peeled=True))
+        e.lucy_iteration(n // 10, 1, want_output=False)
+        ms, st = [], None
+        for i in range(passes):
+            _, st = e.lucy_iteration(n, 2 + i, want_output=False)
+            ms.append(e.last_kernel_ms()[0])
+        k = sum(ms) / len(ms)
+        res.append({"config": "cylindrical polar grid 400 x 200 (flared disc, log w), central point source: Lucy iteration",
+                    "schedule": "brick-tiled (hyp_ptile.h), the flight's reciprocals in the wall search" if e.get_option("last_lucy_mode") == 1 else "persistent kernel",
+                    "packets": n, "kernel_ms": k, "pass_ms": ms, "packets_per_s": n / k * 1e3, "crossings_per_packet": st["crossings"] / n,
+                    "crossings_per_s": st["crossings"] / k * 1e3})
+        m = n // 4
+        e.final_iteration(m // 10)
+        ms = []
+        for _ in range(passes):
+            _, st = e.final_iteration(m)
+            ms.append(e.last_kernel_ms()[0])
+        k = sum(ms) / len(ms)
+        res.append({"config": "... imaging iteration: peeled SEDs for two views, forced first interaction",
+                    "schedule": ("deferred peel-off, %d rounds" % e.get_option("last_defer_rounds")) if e.get_option("last_defer_rounds") else "inline peel-off",
+                    "packets": m, "kernel_ms": k, "pass_ms": ms, "packets_per_s": m / k * 1e3, "crossings_per_packet": st["crossings"] / m,
+                    "crossings_per_s": st["crossings"] / k * 1e3})
+        e.close()
+    except Exception as ex:
+        res.append({"config": "cylindrical polar grid, flared disc", "error": str(ex)})
     return res
 
 

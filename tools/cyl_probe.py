@@ -11,14 +11,8 @@ if os.environ.get("HYP_LIB"):
 from hyperion_amd.benchmark import LSUN, PC, load_test_dust
 from hyperion_amd.problem import Problem, RunConfig, Source
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-w = np.hstack([0.0, np.logspace(np.log10(0.01 * PC), np.log10(PC), 400)])
-z = np.linspace(-0.5 * PC, 0.5 * PC, 201)
-ph = np.array([0.0, 2 * np.pi])
-wc = 0.5 * (w[1:] + w[:-1]); zc = 0.5 * (z[1:] + z[:-1])
-h = 0.1 * PC * (wc / PC) ** 1.2 + 0.01 * PC
-dens = (6.0 / PC) * np.exp(-0.5 * (zc[:, None] / h[None, :]) ** 2) * (wc[None, :] > 0.02 * PC) + 0.05 / PC
-p = Problem(walls=[w, z, ph], density=dens[None, None], dust=[load_test_dust()], sources=[Source(type="point", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0))],
-            config=RunConfig(), grid_type="cyl_pol")
+from hyperion_amd.benchmark import make_cyl_disc_problem
+p = make_cyl_disc_problem()
 e = hyperion_amd.Engine(p)
 e.lucy_iteration(n // 10, 1, want_output=False)
 for it in (2, 3):
@@ -26,9 +20,7 @@ for it in (2, 3):
     ms = e.last_kernel_ms()[0]
     print("cyl 400 x 200: %.1f ms, %.3g packets/s, %.0f crossings/packet, %.3g crossings/s, mode %d, killed_geo %d" % (ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3, e.get_option("last_lucy_mode"), st["killed_geo"]), flush=True)
 # imaging iteration on the same disc: peeled SEDs for two views (walks along fixed directions: cyl_find_wall_inv through find_wall_fixed_dir)
-from hyperion_amd.problem import PeeledImages
-p.peeled = [PeeledImages(theta=[30.0, 80.0], phi=[10.0, 200.0], n_wav=20, wav_min=0.1, wav_max=1000.0, compute_image=False,
-                         n_ap=2, ap_min=0.5 * PC, ap_max=2.0 * PC)]
+p = make_cyl_disc_problem(peeled=True)
 e2 = hyperion_amd.Engine(p)
 e2.lucy_iteration(n // 10, 1, want_output=False)
 m = n // 4
