@@ -198,7 +198,7 @@ struct WallSel { double tmin, emin; int imin[3], iext[3]; };
 __device__ __forceinline__ void insert_t(WallSel &ws, double t, int iw, int i, double e)
 {
     if (t > 0.0) {
-        const double emax = fmax(e, ws.emin);
+        const double emax = max_no_nan(e, ws.emin);      // (neither is a NaN: one v_max_f64 instead of fmax's three)
         if (t < ws.tmin - emax) {
             ws.tmin = t; ws.emin = emax;
             ws.imin[0] = iw == 0 ? i : 0; ws.imin[1] = iw == 1 ? i : 0; ws.imin[2] = iw == 2 ? i : 0;
@@ -315,7 +315,7 @@ __device__ __forceinline__ bool sph_cone_out_of_reach(const DProblem &P, const C
     const double pA = v2_xy - v2_z * tt2;
     double pB = rv_xy - rv_z * tt2; pB = pB + pB;
     const double pC = r2_xy - r2_z * tt2;
-    const double T = ws.tmin + fmax(P.ew[1][iw], ws.emin);
+    const double T = ws.tmin + max_no_nan(P.ew[1][iw], ws.emin);
     const double aT2 = fabs(pA) * T * T, pT = (pA * T + pB) * T + pC;
     const double lim = 0.25 * aT2 + 0x1p-46 * (aT2 + fabs(pB) * T + fabs(pC));
     // (a NaN or an infinity anywhere -- no sphere ahead, ws.tmin = huge -- fails the comparisons: the wall is solved)
