@@ -108,7 +108,8 @@ __global__ __launch_bounds__(HYP_ATILE_WG, HYP_ATILE_OCC) void atile_walk_kernel
         // ---- service phase: rare events, write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_ATILE_SERVICE || !m_walk))) {
             int left_cell = -1, left_grid = -1, left_i[3] = {0, 0, 0};      // LS_LEFT: where the packet goes on
-            if (st == LS_CHECK) {
+            // (a lane whose check is due waits until four are, or nobody walks any more: tile_walk_kernel, hyp_tiled.h)
+            if (st == LS_CHECK && (__popcll(__ballot(st == LS_CHECK)) >= 4 || !m_walk || park)) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
                 Cell<GEOM_AMR> c; full_cell(c);

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_PTILE_SERVICE || !m_walk))) {
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
-            if (st == LS_CHECK) {
+            // (a lane whose check is due waits until four are, or nobody walks any more: tile_walk_kernel, hyp_tiled.h)
+            if (st == LS_CHECK && (__popcll(__ballot(st == LS_CHECK)) >= 4 || !m_walk || park)) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
                 if (geo_check_cell(P, W, r, v, cell)) st = LS_WALK;

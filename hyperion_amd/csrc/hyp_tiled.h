@@ -1114,8 +1114,11 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
             const long long dbg_ts = clock64();
             dbg_nwb += __popcll(m_out); if (__ballot(st == LS_CHECK || st == LS_SLOW)) dbg_ncheck++;
 #endif
-            // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
-            if (st == LS_CHECK) {
+            // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual.  The gap to a lane's next check costs a
+            // Philox block and a logarithm whether one lane asks or sixty-four, and with the reference's default frequency a quarter of
+            // the service phases would find ONE lane asking: a lane whose check is due waits until four are, or nobody walks any more
+            const unsigned long long m_chk = __ballot(st == LS_CHECK);
+            if (st == LS_CHECK && (__popcll(m_chk) >= 4 || !m_walk || park)) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
                 if (geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;

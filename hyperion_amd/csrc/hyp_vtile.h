@@ -277,7 +277,8 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
             const long long dbg_ts = clock64();
 #endif
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
-            if (st == LS_CHECK) {
+            // (a lane whose check is due waits until four are, or nobody walks any more: tile_walk_kernel, hyp_tiled.h)
+            if (st == LS_CHECK && (__popcll(__ballot(st == LS_CHECK)) >= 4 || !m_walk || park)) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
                 // in_correct_cell (:274-283) first asks whether the nearest-site walk from the packet's cell stays there, i.e. whether
