@@ -1054,7 +1054,10 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
     if (threadIdx.x == 32) { n_int_l = 0; n_dead_l = 0; }
     const int bi = tk.brick % T.nbx, bj = (tk.brick / T.nbx) % T.nby, bk = tk.brick / (T.nbx * T.nby);
     const int x0 = bi * BX, y0 = bj * BY, z0 = bk * BZ;
-    const int x1 = min(x0 + BX, P.n1), y1 = min(y0 + BY, P.n2), z1 = min(z0 + BZ, P.n3);
+    // (the grid's size in registers: read through P inside the step loop it was three dependent scalar loads, each with its wait, in
+    // every wave-step in which some lane left the brick -- most of them)
+    const int gn1 = P.n1, gn2 = P.n2, gn3 = P.n3;
+    const int x1 = min(x0 + BX, gn1), y1 = min(y0 + BY, gn2), z1 = min(z0 + BZ, gn3);
     for (int c = threadIdx.x; c < NC; c += blockDim.x) {
         int lx = c % BX, ly = (c / BX) % BY, lz = c / (BX * BY);
         int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
@@ -1263,7 +1266,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
                         // x1, y1, z1 are clipped to the grid, so leaving the grid is leaving the brick
                         if (cell.ic[0] < x0 || cell.ic[0] >= x1 || cell.ic[1] < y0 || cell.ic[1] >= y1 ||
                             cell.ic[2] < z0 || cell.ic[2] >= z1)
-                            st = geo_escaped(P, cell) ? LS_DEAD : LS_LEFT;
+                            st = (cell.ic[0] < 0 || cell.ic[0] >= gn1 || cell.ic[1] < 0 || cell.ic[1] >= gn2 || cell.ic[2] < 0 || cell.ic[2] >= gn3) ? LS_DEAD : LS_LEFT;      // geo_escaped, on copies of the grid's size
                     } else {
                         st = LS_HIT; hit_t = tmin; hit_tau = tau_cell; hit_lc = lc;      // finished in the service phase
                     }
