@@ -540,8 +540,8 @@ def main():
             roof["limiter"] = "valu_issue + service-phase latency"
             roof["note"] = ("density and accumulators of a 32 x 16 x 16 brick live in LDS, so the 24 B per crossing never go to memory: `bound` names the "
                             "nominal roofline of the path (HBM), the fraction says how far it is from a streaming bound it does not have; the counters "
-                            "name the limiter: VALU issue (issue_roofline) and the service phase of tile_walk, 46 % of a wave's clocks "
-                            "(profiles/r03_tiled_log.md)")
+                            "name the limiter: VALU issue (issue_roofline) and the service phase of tile_walk, 38 % of a wave's clocks "
+                            "(-DHYP_TILE_STATS build of round 5, DESIGN.md section 4.1)")
         else:
             roof["limiter"] = "memory-side atomics"
             roof["note"] = ("bound by the memory-side scattered-atomic rate (2.38e10/s, profiles/r01_atomic_rate_ubench.md): fraction %.2f"
