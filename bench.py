@@ -367,12 +367,19 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine has no CPU fallback")
+    # (HYP_BENCH_BACKEND=gloo: the N > 1 path of this script on a box with ONE GPU -- every rank on device local_rank modulo the
+    # device count, the all-reduce through gloo on the same device tensors; tests/test_gpu_rccl.py.  The driver's runs use RCCL.)
+    backend = os.environ.get("HYP_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: always exercise RCCL
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     rccl = None
     if dist is not None:

@@ -12,9 +12,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _torchrun(args, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+def _torchrun(args, port, nproc=1, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
@@ -32,3 +32,19 @@ def test_bench_under_torchrun_world_size_1():
 def test_sharded_iterations_with_real_all_reduce():
     r = _torchrun([os.path.join("tests", "rccl_ws1_check.py")], 29614)
     assert r.returncode == 0 and "RCCL_WS1_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_bench_at_world_size_2_on_one_gpu_through_gloo():
+    """The N > 1 path of bench.py end to end with two processes and real kernels -- id ranges per rank, the all-reduce of the device
+    block (gloo here: one GPU cannot hold two RCCL ranks), the epilogue on every rank, the self-checks of the line: ranks seen, one digest
+    of the specific energy on all ranks, per-rank times."""
+    r = _torchrun(["bench.py", "--gpus", "2", "--grid", "64", "--photons", "2e6", "--steps", "2", "--warmup", "1"], 29615, nproc=2,
+                  HYP_BENCH_BACKEND="gloo")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["packets_per_iteration"] == 4000000 and d["value"] > 1e6
+    assert d["rccl"]["ranks_seen"] == 2 and d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo"
+    assert d["rccl"]["specific_energy_identical_on_all_ranks"] is True
+    assert len(d["per_rank_ms_per_step"]["launch_ms"]["ranks"]) == 2
+    assert "cpu_baseline" not in d and "extra" not in d          # N = 1 only
