@@ -370,7 +370,10 @@ def main():
     # (HYP_BENCH_BACKEND=gloo: the N > 1 path of this script on a box with ONE GPU -- every rank on device local_rank modulo the
     # device count, the all-reduce through gloo on the same device tensors; tests/test_gpu_rccl.py.  The driver's runs use RCCL.)
     backend = os.environ.get("HYP_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % torch.cuda.device_count()
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():       # (never wrap RCCL ranks onto shared devices)
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPUs are visible -- an N-GPU line needs N devices" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: always exercise RCCL

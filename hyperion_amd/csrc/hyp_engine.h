@@ -281,6 +281,7 @@ inline LucyKernel pick_final_kernel(int nd, int grid_type, int mode)
 TileKernels pick_tile_kernels(int nd, int grid_type);
 int tile_bricks(const DProblem &P, int nd);
 long long polar_tile_bricks(const DProblem &P, int nd, int lds_kb);
+long long car_tile_bricks(const DProblem &P, int nd);
 size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd);
 size_t oct_cluster_lds(size_t n, size_t k, int nd);
 int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t iter_tag, const DeferBuf *img = nullptr,

@@ -299,6 +299,16 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "vt_cells") *value = h->vt_cells;
     else if (n == "vt_clusters") *value = h->vt_clusters;
     else if (n == "vt_max_cells") *value = h->vt_max_cells;
+    else if (n == "vt_max_lds") *value = (int64_t)h->vt_max_lds;
+    else if (n == "ot_max_cells") *value = h->ot_max_cells;
+    else if (n == "at_max_cells") *value = h->at_max_cells;
+    else if (n == "ot_cells") *value = h->ot_cells;
+    else if (n == "at_cells") *value = h->at_cells;
+    else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
+    else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "tile_poll") *value = h->tile_poll;
+    else if (n == "tile_time_walk") *value = h->tile_time_walk;
+    else if (n == "oct_neighbours") *value = h->oct_neighbours ? 1 : 0;
     else if (n == "last_vt_exact_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;      // steps of the Voronoi walk that ran the reference's loop
     else if (n.rfind("last_walk_why", 0) == 0 && n.size() == 14 && n[13] >= '0' && n[13] <= '7') *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[30 + (n[13] - '0')] : 0;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with

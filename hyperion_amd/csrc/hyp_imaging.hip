@@ -166,7 +166,7 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
     const DProblem &P = h->hp;
     const TileKernels K = pick_tile_kernels(h->n_dust, P.grid_type);
     if (!K.walk || !K.interact_img || !K.emit_img || K.event_bytes != dk.event_bytes) return 2;
-    if (P.grid_type == 1 && tile_bricks(P, h->n_dust) > HYP_TILE_MAX_BRICKS) return 2;
+    if (P.grid_type == 1 && car_tile_bricks(P, h->n_dust) < 0) return 2;
     if ((P.grid_type == 5 || P.grid_type == 6) && polar_tile_bricks(P, h->n_dust, h->pt_lds_kb) < 0) return 2;
     if (P.grid_type == 2 && !h->oct_neighbours) return 2;
     if (P.grid_type == 2 || P.grid_type == 3 || P.grid_type == 4) {

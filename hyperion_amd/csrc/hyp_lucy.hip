@@ -37,6 +37,18 @@ int tile_bricks(const DProblem &P, int nd)
     return ((P.n1 + x - 1) / x) * ((P.n2 + y - 1) / y) * ((P.n3 + z - 1) / z);
 }
 
+// Bricks of a Cartesian grid on the tiled schedule, or -1 when the grid has no such schedule: more bricks than the sort's tables
+// hold, or wall arrays that do not fit the LDS next to a brick (16 (n1 + n2 + n3 + 3) bytes on top of 128 KB: grids with
+// n1 + n2 + n3 beyond ~1800 run on the persistent kernel in auto mode instead of failing in hipFuncSetAttribute)
+long long car_tile_bricks(const DProblem &P, int nd)
+{
+    int x, y, z;
+    tile_shape(nd, x, y, z);
+    const long long nb = tile_bricks(P, nd);
+    const size_t lds = lds_bytes(P) + sizeof(double) * 2 * (size_t)x * y * z * nd;
+    return (nb <= HYP_TILE_MAX_BRICKS && lds + 4096 <= 160u * 1024u) ? nb : -1;
+}
+
 // Bricks of a polar grid (hyp_ptile.h): boxes of (r, theta, phi) / (w, z, phi) indices whose densities and accumulators fit `cells`
 // cells of LDS.  Packets move mostly along r, so the brick is long in the first index: at most 8 cells in phi, 32 in theta / z,
 // and what is left of the budget in r; theta / z shrink before r falls below 16 cells.
@@ -607,7 +619,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     // (the per-cell packet counter and the spectrum planes live in global memory: those runs use the persistent kernel)
     bool tile_ok = false, tile_auto = false;
     if (P.grid_type == 1) {
-        tile_ok = h->n_dust <= 4 && tile_bricks(P, h->n_dust) <= HYP_TILE_MAX_BRICKS && !h->count_photons && !h->n_bins;
+        tile_ok = h->n_dust <= 4 && car_tile_bricks(P, h->n_dust) > 0 && !h->count_photons && !h->n_bins;
         tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 32 && n_local >= 1500000ull;      // (128^3: 14.2 against 18.0 ms at 2e6 packets, even at 1e6; tools/small_probe.py)
     } else if (P.grid_type == 3) {
         // Voronoi: clusters of cells in LDS (hyp_vtile.h); the modified random walk does not exist on these grids

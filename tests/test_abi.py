@@ -82,3 +82,31 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in txt and "hyp_oracle" not in txt and "libhyp_oracle" not in txt, f
+
+
+def test_every_option_name_used_by_tools_tests_and_bench_is_known_to_the_engine():
+    """a pruned option left tools reading names the engine no longer answers.  Source-level check (runs without
+    a GPU): every literal name passed to get_option / set_option under tools/, tests/ and bench.py appears in
+    hyp_get_option / hyp_set_option of hyp_engine.hip."""
+    import glob
+    import re
+    src = open(os.path.join(ROOT, "hyperion_amd", "csrc", "hyp_engine.hip")).read()
+    body = {}
+    for which in ("set", "get"):
+        start = src.index("int hyp_%s_option(" % which)
+        body[which] = src[start:src.index("\n}\n", start)]
+    known = {w: set(re.findall(r'n == "([a-z_0-9]+)"', body[w])) for w in body}
+    known["get"].update("last_walk_why%d" % i for i in range(8))
+    files = glob.glob(os.path.join(ROOT, "tools", "*.py")) + glob.glob(os.path.join(ROOT, "tests", "*.py")) + [os.path.join(ROOT, "bench.py")]
+    bad = []
+    for f in files:
+        text = open(f).read()
+        for which, name in re.findall(r'\b(get|set)_option\(\s*"([a-z_0-9]+)"', text):
+            if name not in known[which]:
+                bad.append((os.path.relpath(f, ROOT), which, name))
+        for blob in re.findall(r'dict\(((?:\s*[a-z_0-9]+=[^,()]+,?)+)\)', text) if "set_option(k, v)" in text else []:
+            for name in re.findall(r'([a-z_0-9]+)=', blob):
+                if name.startswith(("tile_", "vt_", "ot_", "at_", "lucy_mode")) and name not in known["set"]:
+                    bad.append((os.path.relpath(f, ROOT), "set", name))
+    assert not bad, bad
+    assert len(known["get"]) > 40 and len(known["set"]) > 20

@@ -17,8 +17,8 @@ eng.lucy_iteration(n // 10, 1, want_output=False)
 for it in (2, 3):
     _, st = eng.lucy_iteration(n, it, want_output=False)
     ms = eng.last_kernel_ms()[0]
-    print("mode %d gens %d clusters %d (<= %d cells, %d B of LDS) exact-loop steps %.2e of %.2e mismatches %d " % (
+    print("mode %d gens %d clusters %d (<= %d cells, %d B of LDS) exact-loop steps %.2e of %.2e " % (
         eng.get_option("last_lucy_mode"), eng.get_option("last_generations"), eng.get_option("vt_clusters"), eng.get_option("vt_max_cells"),
-        eng.get_option("vt_max_lds"), eng.get_option("last_vt_exact_steps"), st["crossings"], eng.get_option("last_vt_mismatch")), end="")
+        eng.get_option("vt_max_lds"), eng.get_option("last_vt_exact_steps"), st["crossings"]), end="")
     print("lucy  n=%d kernel %.1f ms -> %.3e packets/s, %.1f crossings/packet, %.3e crossings/s, killed_geo %d, interactions/packet %.2f"
           % (n, ms, n / ms * 1e3, st["crossings"] / n, st["crossings"] / ms * 1e3, st["killed_geo"], st["interactions"] / n))

@@ -27,7 +27,7 @@ for kind in ("point", "sphere"):
     e.final_iteration(n // 10)
     _, st = e.final_iteration(n)
     ms = e.last_kernel_ms()[0]
-    print("%s source: imaging %.1f ms (%.3g packets/s, %.0f crossings/packet, deferred rounds %d, plain %d, lean %d)"
+    print("%s source: imaging %.1f ms (%.3g packets/s, %.0f crossings/packet, deferred rounds %d, plain %d)"
           % (kind, ms, n / ms * 1e3, st["crossings"] / n, e.get_option("last_defer_rounds"), e.get_option("plain_imaging")), flush=True)
     e.close()
 # the same with raytracing on (the usual choice for SEDs): the imaging iteration peels scattered light only, the raytracing iteration adds
