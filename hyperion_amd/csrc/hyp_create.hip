@@ -1333,7 +1333,7 @@ int hyp_create(const hyp_problem *pr, int device, hyp_handle *out)
 // budget of one walk workgroup.
 static size_t vt_blob16(size_t n_own, size_t n_site, size_t n_wall)
 {
-    return 3 * ((n_site + 1) / 2) + n_wall + (n_wall + 3) / 4 + 2 * ((n_own + 3) / 4) + 3 * ((n_site - n_own + 3) / 4);
+    return 3 * ((n_site + 1) / 2) + n_wall + (n_wall + 3) / 4 + 3 * ((n_own + 3) / 4) + 3 * ((n_site - n_own + 3) / 4);
 }
 
 int build_vor_clusters(hyp_handle h)
@@ -1441,7 +1441,8 @@ int build_vor_clusters(hyp_handle h)
         float4 *wrec = (float4 *)(sz + ns);
         uint32_t *wlink = (uint32_t *)(wrec + I.n_wall), *hdr = wlink + ((I.n_wall + 3) & ~3);
         const int ng = I.n_site - I.n_own, ngp = (ng + 3) & ~3;
-        int *mem = (int *)(hdr + ((I.n_own + 3) & ~3)), *gcell = mem + ((I.n_own + 3) & ~3), *gpacked = gcell + ngp, *gadj = gpacked + ngp;
+        float *lmax = (float *)(hdr + ((I.n_own + 3) & ~3));
+        int *mem = (int *)(lmax + ((I.n_own + 3) & ~3)), *gcell = mem + ((I.n_own + 3) & ~3), *gpacked = gcell + ngp, *gadj = gpacked + ngp;
         for (int j = 0; j < I.n_own; j++) mem[j] = members[I.cell0 + j];
         for (int gI = 0; gI < ng; gI++) {
             const VtGhost &gh = ghosts[(size_t)I.ghost0 + gI];
@@ -1475,7 +1476,8 @@ int build_vor_clusters(hyp_handle h)
         for (int j = 0; j < I.n_own; j++) {
             const int cell = members[I.cell0 + j];
             const int k0 = kw;
-            bool exact = false;
+            bool exact = idx[cell + 1] - idx[cell] > 32;        // (the filter keeps a 32-bit history of its comparisons)
+            double cell_lmax = 0.0;
             for (int k = idx[cell]; k < idx[cell + 1]; k++, kw++) {
                 const int nb = nei[k];
                 double n[3];
@@ -1493,10 +1495,16 @@ int build_vor_clusters(hyp_handle h)
                     link = 0xffffu | ((uint32_t)VT_NO_BACK << 16) | ((uint32_t)(iw + 1) << 24);
                 }
                 const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) * scale * (1.0 + 4.0 * 5.9604645e-8);
-                wrec[kw] = make_float4((float)(n[0] * scale), (float)(n[1] * scale), (float)(n[2] * scale), nb >= 0 ? (float)len : -(float)len);
+                // the filter's bounds assume FP32 values far from overflow and underflow: a wall 2^30 times shorter or longer than the
+                // cluster's mean (coincident sites, absurd aspect ratios) sends its cell through the reference's loop
+                if (!(len > 9.3e-10 && len < 1.07e9)) exact = true;
+                const double hl2 = 0.5 * (n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) * scale * scale;
+                wrec[kw] = make_float4((float)(n[0] * scale), (float)(n[1] * scale), (float)(n[2] * scale), (float)hl2);
+                if (std::isfinite(len)) cell_lmax = std::max(cell_lmax, len);
                 wlink[kw] = link;
             }
             hdr[j] = (uint32_t)k0 | ((uint32_t)(kw - k0) << 20) | (exact ? VT_HDR_EXACT : 0u);
+            lmax[j] = std::nextafter((float)cell_lmax, INFINITY);
         }
         for (int j = 0; j < I.n_own; j++) local[members[I.cell0 + j]] = -1;
         for (int gI = 0; gI < I.n_site - I.n_own; gI++) local[lay[c].ghosts[gI]] = -1;

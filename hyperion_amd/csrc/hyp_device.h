@@ -100,13 +100,12 @@ struct alignas(32) VorWall { double x, y, z; int nb, loc; };
 // into LDS with 16-byte loads; sections, each padded to 16 bytes, in this order:
 //   sx, sy, sz   [n_site] double   sites of the cluster's own cells (index < n_own) and of the cells of OTHER clusters that
 //                                  share a wall with one of them ("ghosts", index >= n_own): the exact wall test needs them
-//   wrec         [n_wall] float4   per wall of an own cell, in the cell's CSR order: (n.x, n.y, n.z, +-|n|) x scale in FP32,
-//                                  n = neighbour's site - own site (a face of the box: the site's mirror image in it, and
-//                                  the sign bit of the fourth component set) --
-//                                  the FP32 filter of the wall search
+//   wrec         [n_wall] float4   FP32 filter of the wall search: (n.x, n.y, n.z, |n|^2 / 2) x scale (x scale^2) per wall of an own cell, in
+//                                  the cell's CSR order; n = neighbour's site - own site (a face of the box: the site's mirror image in it)
 //   wlink        [n_wall] uint32   neighbour's index in the site table (bits 0-15) | position of THIS cell in the neighbour's
 //                                  CSR list (bits 16-23; 255: none) | 1 + face for a face of the box (bits 24-27)
 //   hdr          [n_own]  uint32   first wall record of the cell (bits 0-19) | number of walls (bits 20-27) | VT_HDR_EXACT
+//   lmax         [n_own]  float    the cell's longest |n| x scale, rounded up: the error bounds of the filter use it for every wall of the cell
 //   members      [n_own]  int      cell ids of the own cells
 //   gcell, gpacked, gadj [n_site - n_own] int   per ghost: cell id, its vt_cluster word, slot of its cluster in vt_adj (VT_MAX_ADJ: none)
 struct VtInfo {
@@ -117,7 +116,7 @@ struct VtInfo {
     float scale;             // power of two that brings the cluster's wall normals to order one (FP32 filter only)
     float abs_eps;           // 2^-49 x largest |coordinate| of the cluster x scale: the reference's own rounding of m - r
 };
-#define VT_HDR_EXACT 0x10000000u    // a neighbour listed twice, or more than 64 walls: this cell's search skips the filter
+#define VT_HDR_EXACT 0x10000000u    // a neighbour listed twice, more than 32 walls, a wall 2^30 times shorter or longer than the mean: this cell's search skips the filter
 #define VT_LINK_LOC(l) ((int)((l) & 0xffffu))
 #define VT_LINK_BACK(l) ((int)(((l) >> 16) & 0xffu))
 #define VT_LINK_BOX(l) ((int)(((l) >> 24) & 0xfu))       // 0: a neighbouring cell; 1 + face otherwise

@@ -254,6 +254,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "ot_cells") { h->ot_cells = (int)value; h->ot_built_for = -1; h->tile_unbuildable = false; }
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "tile_drain") h->tile_drain = (int)value;
+    else if (n == "tile_park") h->tile_park = value < 0 ? 0 : value > 64 ? 64 : (int)value;
     else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
@@ -306,10 +307,12 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "at_cells") *value = h->at_cells;
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "tile_drain") *value = h->tile_drain;
+    else if (n == "tile_park") *value = h->tile_park;
     else if (n == "tile_poll") *value = h->tile_poll;
     else if (n == "tile_time_walk") *value = h->tile_time_walk;
     else if (n == "oct_neighbours") *value = h->oct_neighbours ? 1 : 0;
     else if (n == "last_vt_exact_steps") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[38] : 0;      // steps of the Voronoi walk that ran the reference's loop
+    else if (n == "last_vt_mismatch") *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[39] : 0;         // -DHYP_VTILE_VERIFY builds: steps on which the filter and the reference's loop disagreed
     else if (n.rfind("last_walk_why", 0) == 0 && n.size() == 14 && n[13] >= '0' && n[13] <= '7') *value = h->h_ctl ? (int64_t)h->h_ctl->dbg[30 + (n[13] - '0')] : 0;
     else if (n == "last_lucy_mode") *value = h->last_lucy_mode;         // schedule the last Lucy iteration ran with
     else if (n == "last_generations") *value = h->last_generations;   // generations of the last tiled iteration

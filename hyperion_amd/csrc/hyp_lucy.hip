@@ -236,6 +236,10 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
         if (d[10]) fprintf(stderr, "tile stats: service phase = check + write-back %.3f (%.1f lanes), claim %.3f (%.1f lanes) of its clocks\n", (double)d[10] / d[6], (double)d[12] / d[7],
                            (double)d[11] / d[6], (double)d[13] / d[7]);
         if (d[15]) fprintf(stderr, "tile stats: propagation check / general wall search ran in %.3f of the service phases and took %.3f of their clocks\n", (double)d[14] / d[7], (double)d[15] / d[6]);
+        if (d[17]) fprintf(stderr, "tile stats: wall search (busiest lane of each wave): %.0f clocks per search, %.3f of the loop's clocks; %.2f walls per lane-search\n",
+                           (double)d[16] / d[17], (double)d[16] / d[8], (double)d[18] / std::max(1ull, d[19]));
+        if (d[17] && d[21]) fprintf(stderr, "tile stats: of a search's clocks: site + q %.0f, filter loop %.0f, the winner's FP64 evaluation and the rest %.0f\n",
+                                    (double)d[20] / d[17], (double)d[21] / d[17], (double)(d[16] - d[20] - d[21]) / d[17]);
         fprintf(stderr, "tile stats: wave clocks waiting at the end of the task for the workgroup's last wave %.3f of the loop's\n", (double)d[9] / d[8]);
     }
 #endif

@@ -171,6 +171,26 @@ template <> struct TileCellIO<GEOM_VOR> {
         const int prev = -c.ow[1] - 1;
         H.ic[0] = c.id; H.ic[1] = prev; H.ic[2] = P.vt_cluster[c.id]; H.ow = prev < 0 ? VT_NO_BACK : VT_FIND_BACK;
     }
+    // A packet that an external source emits ON a face of the box (emit_from_extern_box, source_type.f90:822-907: the coordinate IS
+    // the face's) moves away from it, and the reference's wall search never looks at that face (`ahead`, grid_geometry_voronoi.f90:
+    // 362-371: the sign of one component of v).  The walk's FP32 filter leaves out ONE wall per step, the one the packet came
+    // through: for such a packet that wall is the face -- its position in the cell's list goes into the record (round 6; before, the
+    // filter carried the reference's rule for faces on every wall of every step).  Anything else keeps VT_NO_BACK; a packet on a
+    // face without this (never seen: interaction points are interior) costs one pass of the reference's loop, not a wrong wall.
+    template <int ND> static __device__ __forceinline__ void mark_face_behind(const DProblem &P, HotRec<ND> &H, const double r[3], const double v[3])
+    {
+        if (H.ow != VT_NO_BACK) return;
+        int iw = -1;
+#pragma unroll
+        for (int a = 2; a >= 0; a--) {
+            if (r[a] == P.vor_box[2 * a] && !(v[a] < 0.0)) iw = 2 * a;
+            if (r[a] == P.vor_box[2 * a + 1] && !(v[a] > 0.0)) iw = 2 * a + 1;
+        }
+        if (iw < 0) return;
+        const int k0 = P.vor_idx[H.ic[0]], k1 = P.vor_idx[H.ic[0] + 1];
+        for (int k = k0; k < k1; k++)
+            if (P.vor_neigh[k] == -(iw + 1) && k - k0 < VT_FIND_BACK) { H.ow = k - k0; break; }
+    }
     static __device__ __forceinline__ int brick(const DProblem &P, const TileGeom &T, const Cell<GEOM_VOR> &c) { return P.vt_cluster[c.id] >> 16; }
 };
 // Polar grids (hyp_ptile.h): cells are numbered (i1, i2, i3) like on Cartesian grids; the spherical grid's `radial` (the sign of
@@ -326,6 +346,7 @@ __device__ __forceinline__ void store_records(const DProblem &P, HotRec<ND> &H, 
 #pragma unroll
     for (int a = 0; a < 3; a++) { H.r[a] = p.r[a]; H.v[a] = p.v[a]; }
     TileCellIO<GEOM>::store(P, H, p.cell);
+    if constexpr (GEOM == GEOM_VOR) TileCellIO<GEOM_VOR>::mark_face_behind(P, H, p.r, p.v);
     H.tau_req = p.tau_req; H.tau_ach = p.tau_ach; H.energy = p.energy;
 #pragma unroll
     for (int d = 0; d < ND; d++) { H.chi[d] = p.chi[d]; H.kappa[d] = p.kappa[d]; C.albedo[d] = p.albedo[d]; }

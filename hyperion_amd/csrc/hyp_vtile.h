@@ -37,7 +37,9 @@
 constexpr int HYP_VTILE_WG = 1024;        // threads per workgroup (one workgroup per task, one per CU with vt_lds_kb = 156)
 constexpr int HYP_VTILE_OCC = 4;          // waves per SIMD the register budget is set for (128 VGPRs, nothing spilled at one and two species)
 constexpr int HYP_VTILE_SERVICE = 16;     // lanes that must wait before a wave runs its service phase
-constexpr int HYP_VTILE_UNROLL = 2;       // unrolling of the filter loop (more LDS reads in flight per lane)
+#ifndef HYP_VTILE_UNROLL
+#define HYP_VTILE_UNROLL 4                // unrolling of the filter loop (1: 361.5, 2: 355.6, 3: 354.1, 4: 351.2 ms on one box; no spills at 128 VGPRs)
+#endif
 constexpr int HYP_VTILE_STEPS = 2;        // cell steps between two scheduling decisions of a wave
 
 // the cluster's tables in LDS (layout of the blob: hyp_device.h, VtInfo)
@@ -45,6 +47,7 @@ struct VtLds {
     const double *sx, *sy, *sz;
     const float4 *wrec;
     const uint32_t *wlink, *hdr;
+    const float *lmax;                       // per own cell: its longest |n| x scale
     const int *members;                      // cell ids of the own cells
     const int *gcell, *gpacked, *gadj;       // per ghost: cell id, its vt_cluster word, slot of its cluster in the adjacency list
     int blob16;                              // size of all of it in units of 16 bytes
@@ -58,7 +61,8 @@ __device__ __forceinline__ void vt_lds_view(const VtInfo &I, const float4 *base,
     L.wlink = (const uint32_t *)(L.wrec + I.n_wall);
     L.hdr = L.wlink + ((I.n_wall + 3) & ~3);
     const int ng = I.n_site - I.n_own, ngp = (ng + 3) & ~3;
-    L.members = (const int *)(L.hdr + ((I.n_own + 3) & ~3));
+    L.lmax = (const float *)(L.hdr + ((I.n_own + 3) & ~3));
+    L.members = (const int *)(L.lmax + ((I.n_own + 3) & ~3));
     L.gcell = L.members + ((I.n_own + 3) & ~3); L.gpacked = L.gcell + ngp; L.gadj = L.gpacked + ngp;
     L.blob16 = (int)(((const char *)(L.gadj + ngp) - (const char *)base) >> 4);
 }
@@ -91,7 +95,7 @@ __device__ __forceinline__ bool vt_find_wall_exact(const DProblem &P, const VtLd
                                                    double r0, double r1, double r2, double v0, double v1, double v2, double &tnear, int &kmin)
 {
     // `ahead = neighbour /= previous cell`: compared through the neighbours' places in the site table (one per cell id)
-    const int prev_site = prev_k < nk ? VT_LINK_LOC(L.wlink[k0 + prev_k]) : -1;
+    const int prev_site = prev_k < nk ? VT_LINK_LOC(L.wlink[k0 + prev_k]) : -1;      // (a face of the box, mark_face_behind: 0xffff, nobody's index)
     double tmin = HYP_DBL_MAX; int imin = -1;
     for (int k = 0; k < nk; k++) {
         const uint32_t link = L.wlink[k0 + k];
@@ -104,65 +108,92 @@ __device__ __forceinline__ bool vt_find_wall_exact(const DProblem &P, const VtLd
     return imin >= 0;
 }
 
-// The FP32 filter.  Inputs: q = (r - site) x scale and v rounded to FP32, Q >= |q|.  With u = 2^-24 and a wall record
-// (n, len) -- n within u of N x scale componentwise, len in [|N|, |N| (1 + 8u)] x scale -- the computed quantities obey
-//   |num32 - num| <= len (8u len + 7u Q + abs_eps)        (three fma for n.q: 5.5u len Q; len^2 / 2: 7u len^2; the subtraction)
-//   |den32 - den| <= 5.5u len                             (three fma for n.v, |v| = 1)
-// where num / den is the real-number quotient and the reference's FP64 value lies within abs_eps len of num (its m - r is
+// The FP32 filter.  Inputs: q = (r - site) x scale and v rounded to FP32, Q >= |q|, L >= the cell's longest |n| x scale.  With
+// u = 2^-24 and a wall record (n, h) -- n within u of N x scale componentwise, h within u of |N|^2 / 2 x scale^2 -- the computed
+//   num32 = h - n.q    obeys   |num32 - num| <= dn = L (12u L + 10u Q + abs_eps)   (three fma for n.q: 5.5u |n| Q; h: u |n|^2 / 2; the
+//                                                                                  subtraction), every term bounded with |n| <= L
+//   den32 = n.v        obeys   |den32 - den| <= dd = 8u L                          (three fma, |v| = 1: 5.5u |n|)
+// where num / den is the real-number quotient and the reference's FP64 value lies within abs_eps |n| of num (its m - r is
 // formed from absolute coordinates).  For |den32| > 4 dd:  |num32 / den32 - num / den| <= 2 (dn + |t| dd) / |den32|, and
 // v_rcp_f32 (1 ulp) times one multiplication adds 4u |t|.  The constants below are those with a margin of 1.4 - 2.
-// Returns the index of the only wall that can be the reference's minimum, or -1 when there is more than one or none.
+//
+// Round 6: the bounds take the cell's longest wall for every wall (they grow with |n|, so they hold; a short wall is "undecided" a
+// little more often) -- dn and dd become constants of the step, the record carries |n|^2 / 2 instead of |n| -- and a
+// classification that needs neither |t| nor a rule for the faces of the box:
+//   P: den32 >  4 dd  (the wall is surely approached)     N: den32 < -4 dd  (surely receding)      M: num32 > dn  (the packet is
+//   surely on the near side of the plane, i.e. inside as far as this wall is concerned)
+//   P & M   a candidate: t > 0, its interval [t - eps, t + eps] holds the reference's t;
+//   N & M   the reference's t is negative: never its minimum (a face of the box the packet moves away from is of this kind:
+//           its den is the single product that decides the reference's `ahead`, grid_geometry_voronoi.f90:362-371);
+//   else    undecided (within ~1e-6 of a plane other than the one it came through, a wall nearly parallel to the flight,
+//           non-finite values): the step runs the reference's loop.
+// With lo1 <= lo2 the two smallest lower ends among the candidates and hi1 = lo1 + 2 eps1 the upper end of the first: lo2 > hi1
+// says every other candidate's t exceeds the first one's, which is then the reference's minimum -- the only wall whose t the
+// reference would keep.  eps = 2.5 (t dd + dn) / den + 16u t is formed as t (2.5 dd rcp + 16u) + 2.5 dn rcp.  Which wall was
+// the first is read off a history of the comparisons (one add-with-carry per wall: bit b = "wall nk - 1 - b became the first").
+// 23 VALU instructions per wall (38 in round 5).  Measured and rejected (profiles/r06_tiled_log.md): the loop on pairwise-SoA
+// records with v_pk_fma/mul/add_f32 -- 17.4 instead of 25.3 VALU wave-instructions per crossing, and 3 % SLOWER than the scalar
+// form of the same classification (365 against 352 ms): a packed instruction is not cheaper here than the two it replaces.
+// Returns the index of that wall, or -1 when there is more than one candidate or none.
 #define VT_U 5.9604645e-8f
-__device__ __forceinline__ int vt_filter(const VtLds &L, int k0, int nk, int prev_k, float q0, float q1, float q2, float Q, float abs_eps,
+__device__ __forceinline__ int vt_filter(const VtLds &L, int k0, int nk, int prev_k, float q0, float q1, float q2, float Q, float abs_eps, float Lm,
                                          float v0, float v1, float v2)
 {
     const float cq = fmaf(10.0f * VT_U, Q, abs_eps);
+    const float dn4 = Lm * fmaf(Lm, 48.0f * VT_U, 4.0f * cq);      // 4 dn
+    const float dd4 = (32.0f * VT_U) * Lm;                          // 4 dd
+    const float ea = 0.625f * dd4, eb = 0.625f * dn4, dn1 = 0.25f * dn4;
     const float inf = __builtin_inff();
-    float lo1 = inf, lo2 = inf, U = inf;
-    int k1 = -1;
+    float lo1 = inf, lo2 = inf, eps1 = 0.0f;
+    uint32_t hist = 0;
     bool unc = false;
     // written without branches: a wave's lanes are in different cells, every `if` here would be a pair of exec-mask updates
 #pragma unroll HYP_VTILE_UNROLL
     for (int k = 0; k < nk; k++) {
         const float4 w = L.wrec[k0 + k];
-        const float len = fabsf(w.w);        // (the sign bit marks a face of the box)
         const float dq = fmaf(w.z, q2, fmaf(w.y, q1, w.x * q0));
-        const float num = 0.5f * len * len - dq;
         const float den = fmaf(w.z, v2, fmaf(w.y, v1, w.x * v0));
-        const float dn = len * fmaf(12.0f * VT_U, len, cq);
-        const float dd = 8.0f * VT_U * len;
+        const float num = w.w - dq;
         const float rcp = __builtin_amdgcn_rcpf(den);
-        const float t = num * rcp, at = fabsf(t);
-        const float eps = fmaf(2.5f * fmaf(at, dd, dn), fabsf(rcp), 16.0f * VT_U * at);
-        const float lo = t - eps, hi = t + eps;
-        // a face of the box is ahead when the packet moves towards it (:362-371: the sign of one component of v, which the
-        // single product of its record's den keeps): a packet emitted ON a face by an external source is not held up by it
-        const bool valid = (k != prev_k) & !((w.w < 0.0f) & (den < 0.0f));
-        const bool good = (fabsf(den) > 4.0f * dd) & (eps < inf);        // false for NaN
-        unc |= valid & !good;
-        const bool cand = valid & good & (hi > 0.0f), sure = valid & good & (lo > 0.0f);
-        U = sure ? fminf(U, hi) : U;
-        const bool lt1 = cand & (lo < lo1), lt2 = cand & (lo < lo2);
-        lo2 = lt1 ? lo1 : lt2 ? lo : lo2;
-        lo1 = lt1 ? lo : lo1;
-        k1 = lt1 ? k : k1;
+        const float t = num * rcp;
+        const float eps = fmaf(t, fmaf(ea, rcp, 16.0f * VT_U), eb * rcp);
+        const float lo = t - eps;
+        const bool pos = den > dd4, neg = den < -dd4, inside = num > dn1;
+        unc |= (k != prev_k) & !(inside & (pos | neg));
+        // (the wall the packet came through is never `pos`: it moves away from it)
+        const float c = (pos & inside) ? lo : inf;
+        const bool first = c < lo1;
+        lo2 = __builtin_amdgcn_fmed3f(lo1, lo2, c);         // the second smallest of three
+        lo1 = first ? c : lo1;
+        eps1 = first ? eps : eps1;
+        hist = (hist + hist) + (first ? 1u : 0u);          // (one v_addc_co_u32: the comparison's mask is the carry)
     }
-    return (!unc && k1 >= 0 && lo2 > U) ? k1 : -1;
+    const float hi1 = fmaf(2.000001f, eps1, lo1);
+    return (!unc && hist != 0u && lo2 > hi1) ? nk - 1 - (int)__builtin_ctz(hist) : -1;
 }
 
 
 // the search of one step: filter, then the reference's expression for the wall it names, or the reference's loop
 __device__ __forceinline__ bool vt_find_wall(const DProblem &P, const VtLds &L, const VtInfo &I, int loc, int k0, int nk, bool exact_only, int prev_k,
                                              double r0, double r1, double r2, double v0, double v1, double v2, double &tnear, int &kmin,
-                                             unsigned int &n_exact, int k1_coop = -2)
+                                             unsigned int &n_exact, int k1_coop = -2, unsigned long long *dbg_t = nullptr)
 {
+#ifdef HYP_TILE_STATS
+    const long long dbg_c0 = clock64();
+#endif
     const double s0 = L.sx[loc], s1 = L.sy[loc], s2 = L.sz[loc];       // the cell's site (three ds_read_b64 per step: registers are scarcer)
     int k1 = -1;
     if (k1_coop != -2) k1 = exact_only ? -1 : k1_coop;
     else if (!exact_only) {
         const float q0 = (float)((r0 - s0) * (double)I.scale), q1 = (float)((r1 - s1) * (double)I.scale), q2 = (float)((r2 - s2) * (double)I.scale);
-        const float Q = sqrtf(fmaf(q2, q2, fmaf(q1, q1, q0 * q0))) * 1.000001f;
-        k1 = vt_filter(L, k0, nk, prev_k, q0, q1, q2, Q, I.abs_eps, (float)v0, (float)v1, (float)v2);
+        const float Q = (fabsf(q0) + fabsf(q1) + fabsf(q2)) * 1.000001f;        // >= |q| (two additions instead of the expansion of sqrtf)
+#ifdef HYP_TILE_STATS
+        const long long dbg_c1 = clock64();
+#endif
+        k1 = vt_filter(L, k0, nk, prev_k, q0, q1, q2, Q, I.abs_eps, L.lmax[loc], (float)v0, (float)v1, (float)v2);
+#ifdef HYP_TILE_STATS
+        if (dbg_t) { dbg_t[0] += (unsigned long long)(dbg_c1 - dbg_c0); dbg_t[1] += (unsigned long long)(clock64() - dbg_c1); }
+#endif
     }
     bool ok = false;
     if (k1 >= 0) {
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
     for (int d = 0; d < ND; d++) { chi[d] = 0.0; kappa[d] = 0.0; }
 
 #ifdef HYP_TILE_STATS
-    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_visits = 0, dbg_wb = 0, dbg_claim = 0, dbg_nclaim = 0, dbg_nwb = 0;
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_visits = 0, dbg_wb = 0, dbg_claim = 0, dbg_nclaim = 0, dbg_nwb = 0, dbg_find = 0, dbg_nfind = 0, dbg_walls = 0, dbg_sect[2] = {0, 0};
     const long long dbg_t0 = clock64();
 #endif
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
@@ -390,7 +421,14 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
                 else {
                     g.countdown--;
                     double tmin; int kmin;
+#ifdef HYP_TILE_STATS
+                    const long long dbg_tf = clock64();
+                    const bool fw_ok = vt_find_wall(P, L, I, loc, hk0, hnk, hexact, prev_k, r0, r1, r2, v0, v1, v2, tmin, kmin, n_exact, k1_coop, dbg_sect);
+                    dbg_find += (unsigned long long)(clock64() - dbg_tf); dbg_nfind++; dbg_walls += (unsigned long long)hnk;
+                    if (!fw_ok) { cnt.killed_geo++; st = LS_DEAD; }
+#else
                     if (!vt_find_wall(P, L, I, loc, hk0, hnk, hexact, prev_k, r0, r1, r2, v0, v1, v2, tmin, kmin, n_exact, k1_coop)) { cnt.killed_geo++; st = LS_DEAD; }
+#endif
                     else {
                         double rho[ND], chi_rho = 0.0;
 #pragma unroll
@@ -444,6 +482,15 @@ __global__ __launch_bounds__(HYP_VTILE_WG, HYP_VTILE_OCC) void vtile_walk_kernel
         atomicAdd(&ctl->dbg[3], 1ull); atomicAdd(&ctl->dbg[10], dbg_wb); atomicAdd(&ctl->dbg[11], dbg_claim); atomicAdd(&ctl->dbg[12], dbg_nwb); atomicAdd(&ctl->dbg[13], dbg_nclaim);
         atomicAdd(&ctl->dbg[6], dbg_service); atomicAdd(&ctl->dbg[7], dbg_nservice); atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
         if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
+    }
+    {   // the wall search: clocks of the lane that searched most often, its searches, the walls of all lanes' searches
+        const double wsum = wave_sum((double)dbg_walls), nsum = wave_sum((double)dbg_nfind);
+        unsigned long long fmax = dbg_find, nmax = dbg_nfind;
+        for (int o = 32; o; o >>= 1) { const unsigned long long f2 = __shfl_xor(fmax, o, 64), n2 = __shfl_xor(nmax, o, 64); if (n2 > nmax) { nmax = n2; fmax = f2; } }
+        unsigned long long s0m = dbg_sect[0], s1m = dbg_sect[1], n3 = dbg_nfind;
+        for (int o = 32; o; o >>= 1) { const unsigned long long a2 = __shfl_xor(s0m, o, 64), b2 = __shfl_xor(s1m, o, 64), n2 = __shfl_xor(n3, o, 64); if (n2 > n3) { n3 = n2; s0m = a2; s1m = b2; } }
+        if (__lane_id() == 0) { atomicAdd(&ctl->dbg[16], fmax); atomicAdd(&ctl->dbg[17], nmax); atomicAdd(&ctl->dbg[18], (unsigned long long)wsum); atomicAdd(&ctl->dbg[19], (unsigned long long)nsum);
+                                atomicAdd(&ctl->dbg[20], s0m); atomicAdd(&ctl->dbg[21], s1m); }
     }
     const long long dbg_te = clock64();
 #endif
