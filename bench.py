@@ -457,6 +457,15 @@ def main():
         it += 1
         lucy_iteration_sharded(eng, n_total, it, rank, world, want_output=False, force_collective=dist is not None)
         eng.set_option("tile_time_walk", 0)
+    # what the C-ABI's specific_energy_out costs on top of a step (the timed steps run with want_output=False, the
+    # inputs / outputs of `value` are resident): the device -> host copy of the result array in the reference's layout, measured here
+    d2h = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        eng.specific_energy()
+        d2h.append((time.perf_counter() - t_c) * 1e3)
+    d2h_ms = sorted(d2h)[len(d2h) // 2]
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,11 +511,16 @@ def main():
                        "packets_per_iteration": n_total, "parallelism": "packets sharded by id range over %d GPU(s), one f64 all-reduce per iteration" % world,
                        "crossings_per_packet": crossings / n_total},
             "lucy_kernel_ms": k_ms, "finish_ms": sum(finish_ms) / len(finish_ms),
+            "d2h_ms": d2h_ms,
+            "d2h_note": "median of 5 copies of specific_energy (%d doubles) device -> host in the reference's layout = what hyp_lucy_iteration's specific_energy_out adds to a step; "
+                        "not inside the timed steps (want_output=False): value x ms_per_step / (ms_per_step + d2h_ms) is the rate with the copy" % int(prob.density.size),
             "iterations_in_process": it,        # warm-up + timed steps + the extra walk-timing step: what a rocprofv3 pass of this command sees
             "lucy_schedule": ("brick-tiled: generations of tile_interact / tile_emit / tile_sort / tile_walk on %d slot pools (streams)"
                               % eng.get_option("tile_pools")) if tiled else "persistent kernel, global atomics",
         }
         if rccl is not None:
+            from hyperion_amd.distributed import shard_range
+            rccl["shards"] = [list(shard_range(n_total, r, world)) for r in range(world)]       # [first id, packets] per rank
             out["rccl"] = rccl
         if world > 1:
             out["ms_per_step_note"] = "max over ranks of the barrier-to-barrier time of the timed steps / steps"

@@ -12,10 +12,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _torchrun(args, port, nproc=1, **extra_env):
+def _torchrun(args, port, nproc=1, prefix=(), **extra_env):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
+    cmd = list(prefix) + [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
 
 
@@ -48,3 +48,27 @@ def test_bench_at_world_size_2_on_one_gpu_through_gloo():
     assert d["rccl"]["specific_energy_identical_on_all_ranks"] is True
     assert len(d["per_rank_ms_per_step"]["launch_ms"]["ranks"]) == 2
     assert "cpu_baseline" not in d and "extra" not in d          # N = 1 only
+
+
+def test_bench_at_world_size_8_on_one_gpu_inside_16_cpus():
+    """configs[2]'s process layout under the GPU box's real constraint: EIGHT ranks -- eight host-driven generation
+    loops, eight engines, the all-reduce and the epilogue on every rank -- pinned to at most 16 CPUs (the cgroup quota of the pool's
+    boxes), on the one GPU through gloo.  The line must show 8 ranks seen, one digest of the specific energy on all ranks, id ranges
+    that tile [0, N) exactly, and per-rank host times whose spread stays bounded (nobody starved)."""
+    import shutil
+    cpus = sorted(os.sched_getaffinity(0))[:16]
+    prefix = ["taskset", "-c", ",".join(map(str, cpus))] if shutil.which("taskset") else []
+    r = _torchrun(["bench.py", "--gpus", "8", "--photons", "2e6", "--steps", "2", "--warmup", "1"], 29616, nproc=8, prefix=prefix,
+                  HYP_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    n = 8 * 2000000
+    assert d["n_gpus"] == 8 and d["config"]["packets_per_iteration"] == n and d["value"] > 1e6
+    assert d["rccl"]["ranks_seen"] == 8 and d["rccl"]["world_size"] == 8
+    assert d["rccl"]["specific_energy_identical_on_all_ranks"] is True
+    shards = d["rccl"]["shards"]
+    assert len(shards) == 8 and shards[0][0] == 0 and sum(s[1] for s in shards) == n
+    assert all(shards[i][0] + shards[i][1] == shards[i + 1][0] for i in range(7))
+    launch = d["per_rank_ms_per_step"]["launch_ms"]["ranks"]
+    assert len(launch) == 8 and max(launch) < 4.0 * min(launch) + 50.0, launch          # eight loops share the CPUs: nobody starves
+    assert d["d2h_ms"] > 0
