@@ -255,6 +255,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = value < 0 ? 0 : value > 64 ? 64 : (int)value;
+    else if (n == "reproducible") h->reproducible = value ? 1 : 0;
     else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;
@@ -308,6 +309,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
+    else if (n == "reproducible") *value = h->reproducible;
     else if (n == "tile_poll") *value = h->tile_poll;
     else if (n == "tile_time_walk") *value = h->tile_time_walk;
     else if (n == "oct_neighbours") *value = h->oct_neighbours ? 1 : 0;

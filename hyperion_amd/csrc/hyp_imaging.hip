@@ -231,7 +231,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     LucyKernel k = pick_final_kernel(h->n_dust, h->hp.grid_type, h->plain_imaging && !h->inside_observers && !h->hp.mono_which ? 1 : h->lean_imaging && !h->hp.mono_which ? 2 : 0);
     // deferred peel-off where the plain kernel applies and there is something to peel into (hyp_defer.h)
     const bool gen = !h->plain_imaging && h->gen_defer && h->gen_defer_opt;
-    bool deferred = (h->plain_imaging || gen) && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    bool deferred = (h->plain_imaging || gen) && !h->hp.mono_which && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0 && !h->reproducible;
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
@@ -249,6 +249,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
+    if (h->reproducible) blocks = 1;          // one wave, inline peel-off: see hyp_engine.h
     LaunchParams L;
     L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = 0x10000u;
     int chunk = h->chunk;
@@ -282,7 +283,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         return 0;
     }
     (void)hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(h->reproducible ? 64 : 256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
     (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("final_kernel launch: ") + hipGetErrorString(e));
@@ -383,6 +384,7 @@ int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
+    if (h->reproducible) blocks = 1;
     LaunchParams L;
     L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = which == 0 ? 0x20000u : 0x30000u;
     unsigned long long c = n_local / ((unsigned long long)blocks * 32ull);
@@ -391,7 +393,7 @@ int hyp_raytracing_launch(hyp_handle h, int which, uint64_t first_id, uint64_t n
     L.chunk = (int)c;
     L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
     (void)hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, which, (double)n_total);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(h->reproducible ? 64 : 256), lds, h->stream, (const DProblem *)h->d_problem, L, which, (double)n_total);
     e = hipGetLastError();
     (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("ray_kernel launch: ") + hipGetErrorString(e));
@@ -495,7 +497,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     // problems that are plain apart from being monochromatic: the launch on the deferred schedule (hyp_defer.h: the propagation
     // kernel writes events, the peel kernel walks them sorted by cell into the launch's frequency plane); option mono_defer = 0: inline
     const bool mgen = h->mono_gen_defer && h->gen_defer_opt;
-    bool deferred = (h->mono_defer || mgen) && h->mono_defer_opt && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0;
+    bool deferred = (h->mono_defer || mgen) && h->mono_defer_opt && h->defer_peel && P.n_peeled > 0 && P.n_views_total > 0 && !h->reproducible;
     DeferKernels dk;
     std::memset(&dk, 0, sizeof dk);
     if (deferred) dk = pick_defer_kernels(h->n_dust, h->hp.grid_type);
@@ -511,6 +513,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
+    if (h->reproducible) blocks = 1;
     LaunchParams L;
     L.first_id = first_id; L.end_id = first_id + n_local; L.iter_tag = (which == 0 ? 0x40000u : 0x50000u) + (uint32_t)inu;
     unsigned long long c = n_local / ((unsigned long long)blocks * 32ull);
@@ -528,7 +531,7 @@ int hyp_mono_launch(hyp_handle h, int which, int inu, uint64_t first_id, uint64_
         dk.propagate = dk.propagate_mono;
         if (run_deferred_rounds(h, dk, L, (unsigned)blocks, lds, false)) { P.mono_which = 0; h->mono_pending = false; return 1; }
     } else
-        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(h->reproducible ? 64 : 256), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
     (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("final_kernel (monochromatic) launch: ") + hipGetErrorString(e));

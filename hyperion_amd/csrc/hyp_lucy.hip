@@ -599,7 +599,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     if (hipSetDevice(h->device) != hipSuccess) return h->set_error("hipSetDevice failed");
     DProblem &P = h->hp;
     if (P.n_sources == 0) return h->set_error("no sources set up - need sources for initial iteration(s)");      // setup_rt.f90:230
-    int copies = h->accum_copies;
+    int copies = h->reproducible ? 1 : h->accum_copies;
     if (copies < 1) copies = 1;
     if (copies > 256) copies = 256;
     if (copies > h->accum_copies_alloc) {   // grow the replica pool on demand
@@ -645,7 +645,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins;
         tile_auto = tile_ok && h->n_cells >= 32768 && n_local >= 2000000ull;
     }
-    bool tiled = tile_ok && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto && !h->tile_unbuildable));
+    bool tiled = tile_ok && !h->reproducible && (h->lucy_mode == 1 || (h->lucy_mode < 0 && tile_auto && !h->tile_unbuildable));
     if (tiled && (P.grid_type == 2 || P.grid_type == 3 || P.grid_type == 4)) {
         // the builders have limits of their own (HYP_TILE_MAX_BRICKS clusters / bricks, the LDS budget, 16-bit grid numbers):
         // a grid beyond them runs on the persistent kernel as before; only a FORCED tiled iteration (lucy_mode = 1) reports the limit
@@ -684,6 +684,8 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     long long need_blocks = (long long)((n_local + 255) / 256);
     if (need_blocks < 1) need_blocks = 1;
     if (blocks > need_blocks) blocks = need_blocks;
+    const unsigned threads = h->reproducible ? 64u : 256u;       // "reproducible": one wave takes the ids in order and makes every deposit in program order
+    if (h->reproducible) blocks = 1;
     if (h->count_photons) {
         // one visited set per lane of THIS launch (HYP_VISIT_SLOTS words each); with less memory than that, fewer workgroups
         for (;;) {
@@ -713,7 +715,7 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     L.chunk = chunk;
     L.interact_threshold = h->interact_threshold; L.emit_threshold = h->emit_threshold;
     (void)hipEventRecord(h->ev0, h->stream);
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(threads), lds, h->stream, (const DProblem *)h->d_problem, L);
     e = hipGetLastError();
     (void)hipEventRecord(h->ev1, h->stream);
     if (e != hipSuccess) return h->set_error(std::string("lucy_kernel launch: ") + hipGetErrorString(e));

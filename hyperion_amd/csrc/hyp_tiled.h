@@ -1079,6 +1079,14 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
     // every wave-step in which some lane left the brick -- most of them)
     const int gn1 = P.n1, gn2 = P.n2, gn3 = P.n3;
     const int x1 = min(x0 + BX, gn1), y1 = min(y0 + BY, gn2), z1 = min(z0 + BZ, gn3);
+    // Round 6: a lane keeps its cell as indices RELATIVE to the brick (cell.ic = global index - origin while it walks): the LDS index
+    // of the cell is two shift-adds instead of three subtractions and two, "left the brick" three unsigned comparisons instead of
+    // six signed ones, and the grid's edge is looked at only by packets that leave.  The wall tables are addressed through pointers
+    // moved by the origin; records and the general functions of the service phase see global indices (to_global).
+    const int ex = x1 - x0, ey = y1 - y0, ez = z1 - z0;          // the brick's extent (clipped to the grid)
+    Walls Wl = W;
+    Wl.w[0] += x0; Wl.w[1] += y0; Wl.w[2] += z0; Wl.ew[0] += x0; Wl.ew[1] += y0; Wl.ew[2] += z0;
+    auto to_global = [&](const Cell<GEOM_CAR> &c) { Cell<GEOM_CAR> gcell = c; gcell.ic[0] += x0; gcell.ic[1] += y0; gcell.ic[2] += z0; return gcell; };
     for (int c = threadIdx.x; c < NC; c += blockDim.x) {
         int lx = c % BX, ly = (c / BX) % BY, lz = c / (BX * BY);
         int gx = x0 + lx, gy = y0 + ly, gz = z0 + lz;
@@ -1145,14 +1153,14 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
             if (st == LS_CHECK && (__popcll(m_chk) >= 4 || !m_walk || park)) {
                 const int gap = rng_check_gap(g, P.check_p, P.check_log1mp);
                 g.countdown = gap < 0x7fffffff ? gap + 1 : gap;      // the step below takes one off again
-                if (geo_in_correct_cell(P, W, r, cell)) st = LS_WALK;
+                if (geo_in_correct_cell(P, W, r, to_global(cell))) st = LS_WALK;
                 else { cnt.killed_geo++; st = LS_DEAD; }
             }
             // packets that round-off left outside their cell: the general wall search, handed to the
             // next step through (hit_t, hit_lc)
             if (st == LS_SLOW) {
                 double tmin; int im[3];
-                if (geo_find_wall(P, W, r, v, cell, tmin, im)) {
+                if (geo_find_wall(P, W, r, v, to_global(cell), tmin, im)) {
                     hit_t = tmin; hit_lc = (im[0] + 1) | ((im[1] + 1) << 2) | ((im[2] + 1) << 4);
                     pre = true; st = LS_WALK;
                 } else { cnt.killed_geo++; st = LS_DEAD; }
@@ -1186,7 +1194,8 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
             } else if (st == LS_LEFT || st == LS_HIT || st == LS_REABS || (park && st == LS_WALK)) {
                 HotRec<ND> &H = hot[SLOT];
 #pragma unroll
-                for (int a = 0; a < 3; a++) { H.r[a] = r[a]; H.ic[a] = cell.ic[a]; }
+                for (int a = 0; a < 3; a++) H.r[a] = r[a];
+                H.ic[0] = cell.ic[0] + x0; H.ic[1] = cell.ic[1] + y0; H.ic[2] = cell.ic[2] + z0;
                 H.ow = pack_ow(cell.ow);
                 H.tau_ach = tau_ach; H.countdown = g.countdown; H.blk_b = g.blk_b;
                 if (any_intersect) cold[SLOT].t_ach = t_ach;
@@ -1194,9 +1203,9 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
                 else if (st == LS_HIT) { H.state = TS_INTERACT; slot_brick[SLOT] = TILE_NEEDS_INTERACT; }
                 else if (st == LS_LEFT) {                                             // H.state stays TS_WALK
                     // one cell step leaves the brick through a face, an edge or a corner
-                    const int dx = cell.ic[0] < x0 ? -1 : (cell.ic[0] >= x1 ? 1 : 0);
-                    const int dy = cell.ic[1] < y0 ? -1 : (cell.ic[1] >= y1 ? 1 : 0);
-                    const int dz = cell.ic[2] < z0 ? -1 : (cell.ic[2] >= z1 ? 1 : 0);
+                    const int dx = cell.ic[0] < 0 ? -1 : (cell.ic[0] >= ex ? 1 : 0);
+                    const int dy = cell.ic[1] < 0 ? -1 : (cell.ic[1] >= ey ? 1 : 0);
+                    const int dz = cell.ic[2] < 0 ? -1 : (cell.ic[2] >= ez ? 1 : 0);
                     slot_brick[SLOT] = tk.brick + dx + T.nbx * (dy + T.nby * dz);
                     atomicAdd(&nb_cnt[(dz + 1) * 9 + (dy + 1) * 3 + dx + 1], 1u);
                 } else atomicAdd(&nb_cnt[13], 1u);                                    // parked: same brick again
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
                     v_ok = true;
 #pragma unroll
                     for (int a = 0; a < 3; a++) {
-                        r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a];
+                        r[a] = H.r[a]; v[a] = H.v[a]; cell.ic[a] = H.ic[a] - (a == 0 ? x0 : a == 1 ? y0 : z0);
                         iu[a] = v[a] > 0.0 ? 1 : 0; smask[a] = v[a] > 0.0 ? 0 : (int)0x80000000;
                         inv[a] = 1.0 / v[a];
                         v_ok = v_ok & ((v[a] == 0.0) | (fabs(v[a]) >= 0x1p-400));
@@ -1254,7 +1263,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
                 // rare events wait for the service phase: they would cost every step of the wave
                 // their full code path for one or two lanes
                 double tmin; int im[3]; bool found;
-                bool simple = find_wall_ahead(W, r, v, inv, iu, smask, cell, tmin, im, found) && v_ok;
+                bool simple = find_wall_ahead(Wl, r, v, inv, iu, smask, cell, tmin, im, found) && v_ok;
                 if (pre) {      // wall found by geo_find_wall in the service phase
                     tmin = hit_t; im[0] = (hit_lc & 3) - 1; im[1] = ((hit_lc >> 2) & 3) - 1; im[2] = ((hit_lc >> 4) & 3) - 1;
                     found = true; simple = true;
@@ -1265,7 +1274,7 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
                 else {
                     pre = false;
                     g.countdown--;
-                    const int lc = ((cell.ic[2] - z0) * BY + (cell.ic[1] - y0)) * BX + (cell.ic[0] - x0);
+                    const int lc = (cell.ic[2] * BY + cell.ic[1]) * BX + cell.ic[0];
                     double rho[ND], chi_rho;
 #pragma unroll
                     for (int d = 0; d < ND; d++) {
@@ -1284,10 +1293,11 @@ __global__ __launch_bounds__(HYP_TILE_WG, HYP_TILE_OCC) void tile_walk_kernel(co
 #pragma unroll
                         for (int d = 0; d < ND; d++) if (rho[d] > 0.0) TILE_DEPOSIT(&accum[lc * ND + d], tmin * ke[d]);
                         geo_advance(P, r, cell, im);
-                        // x1, y1, z1 are clipped to the grid, so leaving the grid is leaving the brick
-                        if (cell.ic[0] < x0 || cell.ic[0] >= x1 || cell.ic[1] < y0 || cell.ic[1] >= y1 ||
-                            cell.ic[2] < z0 || cell.ic[2] >= z1)
-                            st = (cell.ic[0] < 0 || cell.ic[0] >= gn1 || cell.ic[1] < 0 || cell.ic[1] >= gn2 || cell.ic[2] < 0 || cell.ic[2] >= gn3) ? LS_DEAD : LS_LEFT;      // geo_escaped, on copies of the grid's size
+                        // the extents are clipped to the grid, so leaving the grid is leaving the brick (one unsigned comparison per axis)
+                        if ((unsigned)cell.ic[0] >= (unsigned)ex || (unsigned)cell.ic[1] >= (unsigned)ey || (unsigned)cell.ic[2] >= (unsigned)ez) {
+                            const int gx = cell.ic[0] + x0, gy = cell.ic[1] + y0, gz = cell.ic[2] + z0;
+                            st = (gx < 0 || gx >= gn1 || gy < 0 || gy >= gn2 || gz < 0 || gz >= gn3) ? LS_DEAD : LS_LEFT;      // geo_escaped, on copies of the grid's size
+                        }
                     } else {
                         st = LS_HIT; hit_t = tmin; hit_tau = tau_cell; hit_lc = lc;      // finished in the service phase
                     }

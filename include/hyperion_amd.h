@@ -363,6 +363,9 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  *     "gen_defer" "mono_defer"   1 (default): problems with extended sources / monochromatic launches image on the deferred schedule
  *     "plain_imaging"       the inline imaging kernel specialised for point sources (can only be switched off)
  *     "oct_neighbours"      0: the octree walk climbs and descends like the reference instead of using the neighbour table
+ *     "reproducible"        1: every iteration runs as ONE wave on the persistent kernels (no tiled / deferred schedule, one accumulator
+ *                           copy): floating-point sums are made in that wave's program order, so a seed gives the same bits on every
+ *                           run, as the reference's serial binary does (src/main/main.f90:157-161).  For tests: ~1000 times slower
  *   get only: what the last iteration did
  *     "last_lucy_mode" "last_generations" "last_walk_us" "last_walk_launches" "last_defer_rounds" "last_defer_events"
  *     "last_ff_prepass" "last_direct_memo" "last_tiled_imaging" "last_mono_deferred" "last_vt_exact_steps"
