@@ -26,8 +26,9 @@ def _hipcc():
 
 HOST_UNITS = ("create", "lucy", "imaging", "engine")      # the host side of the C-ABI (hyp_engine.h); heaviest first
 PARTS = {"lucy": 0, "tile": 1, "final": 2, "defer": 3, "ray": 4, "finalp": 5}
-# heaviest first: the pool starts them first so that the long poles do not land at the end
-_COST = {"finalp": 6, "final": 5, "defer": 4, "tile": 3, "lucy": 2, "ray": 1}
+# heaviest first: the pool starts them first so that the long poles do not land at the end (seconds per unit on this container's
+# cores, HYP_BUILD_TIMES=1, round 6: defer 100-139, tile 49-83, final 45-64, lucy 33, finalp 14-18, ray < 14)
+_COST = {"defer": 6, "tile": 5, "final": 4, "lucy": 3, "finalp": 2, "ray": 1}
 
 
 def units():

@@ -72,7 +72,7 @@ struct DPeeled {
     int n_view, ignore_optical_depth, compute_image, compute_sed;
     int n_x, n_y, n_ap, n_nu;
     int track_origin, track_n_scat, uncertainties, n_stokes;
-    int n_orig, pad0;
+    int n_orig, serial;     // serial: option "reproducible" -- deposits into the cubes lane by lane, in lane order (wave_accumulate)
     double x_min, x_max, y_min, y_max, ap_min, ap_max;
     double log10_nu_min, log10_nu_max, log10_ap_min, log10_ap_max;
     double d_min, d_max, origin[3];

@@ -255,7 +255,13 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = value < 0 ? 0 : value > 64 ? 64 : (int)value;
-    else if (n == "reproducible") h->reproducible = value ? 1 : 0;
+    else if (n == "reproducible") {
+        h->reproducible = value ? 1 : 0;
+        for (auto &G : h->h_peeled) G.serial = h->reproducible;
+        if (h->d_peeled && !h->h_peeled.empty() &&
+            hipMemcpy(h->d_peeled, h->h_peeled.data(), sizeof(DPeeled) * h->h_peeled.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return h->set_error("cannot update the image groups on the device");
+    }
     else if (n == "tile_poll") h->tile_poll = value < 1 ? 1 : (int)value;
     else return h->set_error("unknown option: " + n);
     return 0;

@@ -1730,8 +1730,22 @@ __device__ __forceinline__ void img_add(const ImgCache *ic, double *addr, double
 // serialise as same-address atomics), the rest falls back to one atomic per lane.
 // Must be called with all 64 lanes active; `key < 0` = nothing to add.
 __device__ __forceinline__ void wave_accumulate(double *__restrict__ cube, double *__restrict__ cube2, long long key,
-                                                size_t stride, int n, const double val[4], const ImgCache *ic = nullptr)
+                                                size_t stride, int n, const double val[4], const ImgCache *ic = nullptr, bool serial = false)
 {
+    if (serial) {
+        // option "reproducible": one lane at a time, in lane order, each lane's additions finished before the next lane's start -- the
+        // sums in the cubes are then made in the program order of the (single) wave of the launch
+        for (unsigned long long m = __ballot(key >= 0); m; m &= m - 1ull) {
+            if ((int)__lane_id() == __ffsll((long long)m) - 1) {
+                for (int i = 0; i < n; i++) {
+                    unsafeAtomicAdd(&cube[key + (long long)i * (long long)stride], val[i]);
+                    if (cube2) unsafeAtomicAdd(&cube2[key + (long long)i * (long long)stride], val[i] * val[i]);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        return;
+    }
     unsigned long long todo = __ballot(key >= 0);
     for (int round = 0; round < 3 && todo; round++) {
         int leader = __ffsll((long long)todo) - 1;
@@ -1829,8 +1843,8 @@ __device__ __forceinline__ void deposit_images(const DProblem &P, const DPeeled 
             }
         }
         // wave-uniform from here: combine lanes that hit the same pixel / SED bin
-        if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img, stride_img, G.n_stokes, val, ic);
-        if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed, stride_sed, G.n_stokes, val, ic);
+        if (G.compute_image) wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img, stride_img, G.n_stokes, val, ic, G.serial != 0);
+        if (G.compute_sed) wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed, stride_sed, G.n_stokes, val, ic, G.serial != 0);
     }
 }
 
@@ -2207,9 +2221,9 @@ __device__ __forceinline__ void peeloff_poly(const DProblem &P, const Walls &W, 
                     val[0] = sp;
                 }
                 if (G.compute_image)
-                    wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img >= 0 ? k_img + iw : -1, 0, 1, val, ic);
+                    wave_accumulate(G.img, G.uncertainties ? G.img2 : nullptr, k_img >= 0 ? k_img + iw : -1, 0, 1, val, ic, G.serial != 0);
                 if (G.compute_sed)
-                    wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed >= 0 ? k_sed + iw : -1, 0, 1, val, ic);
+                    wave_accumulate(G.sed, G.uncertainties ? G.sed2 : nullptr, k_sed >= 0 ? k_sed + iw : -1, 0, 1, val, ic, G.serial != 0);
             }
         }
     }

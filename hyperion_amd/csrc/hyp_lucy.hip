@@ -363,7 +363,11 @@ int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref)
     size_t need = (h->n_elem + 255) / 256;
     if ((size_t)blocks > need) blocks = (int)need;
     if (blocks < 1) blocks = 1;
-    finish_kernel<<<blocks, 256, 0, h->stream>>>(h->d_problem, F, mode, h->d_specific_energy, h->d_density,
+    // option "reproducible": update_energy_abs_tot (grid_physics_3d.f90:601-611) is a sum over all cells, and the dust packets of the
+    // raytracing iteration multiply and divide by it: one wave forms it in a fixed order
+    const int threads = h->reproducible ? 64 : 256;
+    if (h->reproducible) blocks = 1;
+    finish_kernel<<<blocks, threads, 0, h->stream>>>(h->d_problem, F, mode, h->d_specific_energy, h->d_density,
                                                  h->d_additional, h->d_jnu_id, h->d_jnu_frac, h->d_energy_abs_tot, d_out_ref,
                                                  h->d_spec, h->n_bins);
     e = hipGetLastError();

@@ -46,16 +46,22 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     prob, z = golden_problem("pinte_seds.tau=%s.npz" % tau)
     gold = z["golden/seds"]
     K = 32      # (12 until round 5: the statistic on the last iteration's absorbed luminosity below needs sigma to 13 %, not 21 %)
-    S, n_it, e_last, se_last, killed_int, killed_geo = [], [], [], [], [], []
+    # Round 6: the realisations run with `reproducible = 1` (one wave, sums in program order: tests/test_gpu_reproducible.py), eight
+    # engines side by side on host threads -- a seed gives the same realisation, and this test the same numbers, on every run.  The
+    # bounds that round 5 had loosened after run-to-run failures (well-sampled bins, |z| of the last iteration) are back where they were.
+    import copy
+    from golden_stats import ensemble
     w = prob.density * prob.volumes
-    for k in range(K):
-        prob.config.seed = -(900 + k)
-        r = run_problem(prob)
-        S.append(r.peeled[0]["seds"]); n_it.append(r.n_iterations)
-        e_last.append((r.iterations[-1].specific_energy * w).sum())
-        se_last.append(r.iterations[-1].specific_energy[0])
+
+    def one(k):
+        p = copy.deepcopy(prob)
+        p.config.seed = -(900 + k)
+        r = run_problem(p, engine_options={"reproducible": 1})
         assert r.final_stats["killed_geo"] == 0
-        killed_int.append([it.killed_int for it in r.iterations]); killed_geo.append(sum(it.killed_geo for it in r.iterations))
+        return (r.peeled[0]["seds"], r.n_iterations, (r.iterations[-1].specific_energy * w).sum(), r.iterations[-1].specific_energy[0],
+                [it.killed_int for it in r.iterations], sum(it.killed_geo for it in r.iterations))
+    runs = ensemble(one, list(range(K)), 8)
+    S, n_it, e_last, se_last, killed_int, killed_geo = (list(x) for x in zip(*runs))
     # the golden ran all 10 iterations without converging (99th percentile rule at 5000 packets); so does the GPU
     assert int(z["golden/iterations"]) == 10 and not bool(z["golden/converged"])
     assert min(n_it) >= 9
@@ -66,9 +72,8 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     sel = (sg > 0) & (I > 1e-3 * I.max())
     zs = (g - I)[sel] / sg[sel]
     well = sg[sel] < 0.3 * I[sel]
-    # (the thickest disc: only the face-on view is well sampled -- 11 to 14 bins from run to run, the realisations of an MRW-thick model are
-    # not bit-reproducible; the count is a sanity check on the selection, not a physical statement)
-    assert well.sum() > (6 if tau == "1000000" else 20)
+    # (the thickest disc: only the face-on view is well sampled; the count is a sanity check on the selection, not a physical statement)
+    assert well.sum() > (10 if tau == "1000000" else 20), well.sum()
     assert np.abs(zs[well]).max() < 6.0 and (zs[well] ** 2).mean() < 3.0 and abs(zs[well].mean()) < 1.0
     if (~well).any():
         assert zs[~well].min() > -6.0 and (zs[~well] > 6.0).mean() < 0.1
@@ -86,17 +91,21 @@ def test_pinte_benchmark_run_matches_reference_golden(tau):
     e_gold = (z["golden/specific_energy_last"] * w).sum()
     # The absorbed luminosity of the LAST iteration against the K realisations, in log space (the total is a product of
     # feedbacks through the temperatures of a few mid-plane cells and scatters log-normally: sigma = 0.02 dex at tau = 1e3,
-    # 0.10 dex at tau = 1e6).  |z| < 5 with K = 32 (a true offset of 3 sigma, as measured below, then fails once in 1e5 runs; with
-    # K = 12 and a bound of 4.5 it failed once in about twenty).  Measured with the oracle over 32 realisations: z = +3.0 at tau = 1e3 (one packet's
-    # random walk through six adjacent inner mid-plane cells leaves 5-18 x their mean energy in the golden: +18 % on the
-    # total), +0.7, -0.5, and -3.0 at tau = 1e6 (the ten cells that hold two thirds of the total sit at ranks 0.0-0.67,
-    # mean 0.21, of the realisations' heavy-tailed distributions: sd / mean 0.4-1.4 per cell).  Two 3 sigma excursions of
-    # opposite sign, both in cells fed by rare long random walks: the largest standing excursions of the whole pin, not
-    # understood beyond that; the killed-packet counts of the same runs (below) agree to a few per cent.  This replaces the
-    # round-4 bracket min / 2 < golden < 2 max.
+    # 0.10 dex at tau = 1e6).  With the reproducible realisations of round 6 the statistic is a fixed number per model:
+    # z = +2.26, +0.83, -0.42, -2.41 for tau = 1e3 ... 1e6 (the oracle's own 32 seeds gave +3.0, +0.7, -0.5, -3.0 in round 5: the
+    # same golden against another sample of the same distribution).  Bound |z| < 4.  The two ends keep their signs:
+    # the golden's last iteration is brighter than the ensemble at tau = 1e3 (one packet's random walk through six adjacent inner
+    # mid-plane cells leaves 5-18 x their mean energy in the golden: +18 % on the total) and fainter at tau = 1e6 (the ten cells
+    # that hold two thirds of the total sit at ranks 0.0-0.67 of the realisations' heavy-tailed distributions, sd / mean 0.4-1.4
+    # per cell).  A line-by-line review of the random walk against grid_mrw_3d.f90:29-202, iter_lucy.f90:133-152 and
+    # dust_type_4elem.f90:286-291,400-419 in round 6 (entry test alpha_inv_planck x distance > gamma with density > 0 only,
+    # diff_coeff over ALL species, ct = -ln(y) / D (R0 / pi)^2, deposit E ct kappa_planck(E_cell), b_nu = j_nu / kappa_nu sampled at the
+    # cell's bracket, opacities NOT refreshed after the walk, the 1000-step cap) found no difference; the killed-packet counters of
+    # the same runs (below), which depend on exactly that path, agree with the reference's to a few per cent.
     le = np.log10(np.array(e_last))
     z_tot = (np.log10(e_gold) - le.mean()) / (le.std(ddof=1) * np.sqrt(1.0 + 1.0 / K))
-    assert abs(z_tot) < 5.0, (e_gold, sorted(e_last), z_tot)
+    print("pinte tau=%s: z of the last iteration's absorbed luminosity %.2f, well-sampled bins %d" % (tau, z_tot, well.sum()))
+    assert abs(z_tot) < 4.0, (e_gold, sorted(e_last), z_tot)
     # killed_photons_int of the ten Lucy iterations (tests/golden/killed_counts.json): the reference's own counters
     from test_oracle_golden import check_killed_counts, killed_counts
     gk = killed_counts("test_pinte_seds.tau=%s" % tau)
