@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
             p = R.p; g = R.g; f = R.f;
             // (spec_idx, unused by the imaging iteration, says what the packet was set aside before: 0 an interaction, 1 its re-emission
             // by a source, 2 + k the k-th step of its modified random walk)
-            st = (GEN && p.spec_idx == 1) ? ST_NEED_REEMIT : (MRWF && p.spec_idx >= 2) ? ST_MRW : ST_NEED_INTERACT;
+            // (-3: a packet on its way between two interactions, handed over by the tiled schedule's end-game, tile_to_susp_kernel)
+            st = p.spec_idx == -3 ? ST_WALK : (GEN && p.spec_idx == 1) ? ST_NEED_REEMIT : (MRWF && p.spec_idx >= 2) ? ST_MRW : ST_NEED_INTERACT;
             if (MRWF && p.spec_idx >= 2) mrw_k = p.spec_idx - 2;
         }
         const unsigned int wv = gl >> 6;
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
                 base = __shfl(base, __ffsll((long long)m) - 1, 64);
                 if (st == ST_NEED_INTERACT || (GEN && st == ST_NEED_REEMIT) || (MRWF && st == ST_MRW)) {
                     SuspRec<NDT, GEOM> &R = ((SuspRec<NDT, GEOM> *)B.susp[B.cur])[base + __popcll(m & lt)];
-                    if (GEN) p.spec_idx = st == ST_NEED_REEMIT ? 1 : (MRWF && st == ST_MRW) ? 2 + mrw_k : 0;
+                    p.spec_idx = (GEN && st == ST_NEED_REEMIT) ? 1 : (MRWF && st == ST_MRW) ? 2 + mrw_k : 0;
                     R.p = p; R.g = g; R.f = f;
                     st = ST_DONE;
                 }

@@ -81,6 +81,7 @@ struct hyp_engine {
     uint64_t pending_packets = 0;
     float last_propagate_ms = 0.f, last_finish_ms = 0.f, ray_ms = 0.f;
     hyp_iter_stats last_stats{};
+    double lucy_cross_per_flight = 0.0;      // of the last Lucy iteration (0: none ran); hyp_final_launch's choice of schedule
 
     // brick-tiled Lucy iteration (hyp_tiled.h)
     void *d_hot = nullptr, *d_cold = nullptr;
@@ -99,6 +100,7 @@ struct hyp_engine {
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
     int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 21 slots (octree and AMR: 3 << 22, configs[3] 119 -> 113 ms) */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16;
+    int img_end_game = 1;           // option: the tiled imaging iteration hands its last packets to the deferred rounds (0: generations to the end, as until round 5)
     int reproducible = 0;           // option: every persistent kernel runs as ONE wave (one workgroup of 64 threads), no tiled / deferred schedule, one accumulator copy:
                                     // the order of every floating-point sum is the program order of that wave -- a seed gives the same bits on every run (tests; ~1000x slower)
     int last_lucy_mode = 0;
@@ -165,6 +167,7 @@ struct hyp_engine {
     int defer_peel = 1;             // option: 1 = deferred peel-off where plain_imaging holds (hyp_defer.h; large launches: propagation on the tiled schedule),
                                     //   2 = always on the tiled schedule where there is one, 3 = never, 0 = inline peel-off
     int last_tiled_imaging = 0;
+    long long last_end_game = 0;      // packets the last tiled imaging iteration handed to the deferred rounds at its end
     long long peel_events = 128ll << 20;    // option: capacity of the event buffer, in events (the ceiling: 8 per packet are asked for, and half as many
                                             // again and again while the allocation fails; 16 Mi until round 3: 1e8 packets then took 15 rounds)
     int peel_sort = 1;              // option: 1 = the peel kernel takes a round's events ordered by cell (hyp_defer.h: sorted peel-off)
@@ -286,8 +289,11 @@ long long polar_tile_bricks(const DProblem &P, int nd, int lds_kb);
 long long car_tile_bricks(const DProblem &P, int nd);
 size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd);
 size_t oct_cluster_lds(size_t n, size_t k, int nd);
+// the imaging iteration's end-game on the tiled schedule: at most max_packets live packets become SuspRec of the deferred schedule
+// (tile_to_susp_kernel), then run() finishes them in its rounds (hyp_imaging.hip)
+struct TiledEndGame { uint64_t max_packets; std::function<int()> run; };
 int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t iter_tag, const DeferBuf *img = nullptr,
-                 const std::function<int()> &flush = std::function<int()>());
+                 const std::function<int()> &flush = std::function<int()>(), const TiledEndGame *end_game = nullptr);
 int run_finish_kernel(hyp_handle h, int mode, double scale, double *d_out_ref);
 int solve_pda(hyp_handle h);
 int sync_problem(hyp_handle h);

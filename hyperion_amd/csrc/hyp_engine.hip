@@ -255,6 +255,7 @@ int hyp_set_option(hyp_handle h, const char *name, int64_t value)
     else if (n == "pt_lds_kb") h->pt_lds_kb = (int)std::max<int64_t>(1, std::min<int64_t>(150, value));
     else if (n == "tile_drain") h->tile_drain = (int)value;
     else if (n == "tile_park") h->tile_park = value < 0 ? 0 : value > 64 ? 64 : (int)value;
+    else if (n == "img_end_game") h->img_end_game = value ? 1 : 0;
     else if (n == "reproducible") {
         h->reproducible = value ? 1 : 0;
         for (auto &G : h->h_peeled) G.serial = h->reproducible;
@@ -294,6 +295,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "last_direct_memo") *value = h->last_direct_memo;
     else if (n == "last_mono_deferred") *value = h->last_mono_deferred;
     else if (n == "last_tiled_imaging") *value = h->last_tiled_imaging;
+    else if (n == "last_end_game") *value = h->last_end_game;
     else if (n == "peel_sort") *value = h->peel_sort;
     else if (n == "ff_prepass") *value = h->ff_prepass;
     else if (n == "last_ff_prepass") *value = h->last_ff_prepass;
@@ -316,6 +318,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
     else if (n == "reproducible") *value = h->reproducible;
+    else if (n == "img_end_game") *value = h->img_end_game;
     else if (n == "tile_poll") *value = h->tile_poll;
     else if (n == "tile_time_walk") *value = h->tile_time_walk;
     else if (n == "oct_neighbours") *value = h->oct_neighbours ? 1 : 0;

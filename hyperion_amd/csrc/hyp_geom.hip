@@ -155,6 +155,7 @@ static TileKernels tile_kernels()
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
         k.interact_img = tile_interact_kernel<NDT, false, false, GEOM, true>; k.emit_img = tile_emit_kernel<NDT, GEOM, 1, true>;
         k.event_bytes = sizeof(PeelEvent<NDT, GEOM>);
+        k.to_susp = tile_to_susp_kernel<NDT, GEOM>;
     }
 #if HYP_GEOM_TU == 3
     {

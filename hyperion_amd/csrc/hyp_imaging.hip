@@ -201,7 +201,45 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
         h->last_defer_events += B.order ? h->h_peel_ctl->n_sorted : h->h_peel_ctl->reserved;
         return 0;
     };
-    const int rc = launch_tiled(h, L.first_id, n_local, iter_tag, &B, flush);
+    // End-game (round 6): with no packet id left and at most one packet per lane of the deferred schedule's grid in flight, the live
+    // slots are resumed by final_defer_kernel like packets a round set aside, and run to their ends in its rounds of {propagate,
+    // sort, peel} -- instead of generations of four launches per pool for a handful of packets (an optically thick model with a high
+    // albedo: hundreds of interactions per packet after the last id was handed out).
+    int occ_p = 0;
+    const DeferKernel prop = B.ff ? dk.propagate_pre : dk.propagate;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_p, (const void *)prop, 256, lds) != hipSuccess || occ_p <= 0) occ_p = 2;
+    const unsigned prop_blocks = (unsigned)std::min<size_t>((size_t)h->n_cu * occ_p, h->peel_lanes / 256);
+    TiledEndGame eg;
+    eg.max_packets = (uint64_t)prop_blocks * 256ull;
+    eg.run = [&]() -> int {
+        // the tiled schedule took its ids from its own dispenser: the deferred kernel's must read "none left"
+        const unsigned long long none = L.end_id;
+        if (hipMemcpyAsync(h->d_counter, &none, sizeof none, hipMemcpyHostToDevice, h->stream) != hipSuccess) return h->set_error("tiled imaging: end-game set-up failed");
+        int idle_rounds = 0;
+        for (int round = 0;; round++) {
+            DeferBuf R = B; R.cur = round & 1;
+            hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, R.cur, 0);       // (round 0 resumes what tile_to_susp_kernel left in the other parity)
+            hipLaunchKernelGGL(prop, dim3(prop_blocks), dim3(256), lds, h->stream, (const DProblem *)h->d_problem, L, R);
+            defer_peel_events(h, dk, R, peel_blocks, lds, iter_tag);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return h->set_error(std::string("tiled imaging end-game launch: ") + hipGetErrorString(e));
+            (void)hipMemcpyAsync(h->h_peel_ctl, h->d_peel_ctl, sizeof(PeelCtl), hipMemcpyDeviceToHost, h->stream);
+            e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess) return h->set_error(std::string("tiled imaging end-game failed: ") + hipGetErrorString(e));
+            const PeelCtl &C = *h->h_peel_ctl;
+            h->last_defer_rounds++;
+            h->last_defer_events += C.written;
+            if (C.n_susp[R.cur] == 0 && C.n_ret[R.cur] == 0) break;
+            idle_rounds = C.written == 0 ? idle_rounds + 1 : 0;
+            if (idle_rounds > 64) return h->set_error("tiled imaging end-game makes no progress (event buffer too small?)");
+            int err = 0;
+            if (hipMemcpy(&err, h->d_err, sizeof err, hipMemcpyDeviceToHost) != hipSuccess || err != 0) break;
+        }
+        hipLaunchKernelGGL(dk.reset, dim3(1), dim3(1), 0, h->stream, h->d_peel_ctl, 0, 1);
+        return 0;
+    };
+    h->last_end_game = 0;
+    const int rc = launch_tiled(h, L.first_id, n_local, iter_tag, &B, flush, h->img_end_game && prop && prop_blocks > 0 ? &eg : nullptr);
     h->last_tiled_imaging = rc == 0 ? 1 : 0;
     return rc ? 1 : 0;
 }
@@ -268,7 +306,11 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         (void)hipEventRecord(h->ev0, h->stream);
         // large launches of problems whose grid has a tiled schedule: the propagation half on it (defer_peel = 2 forces, 3 forbids)
         int rc = 2;
-        if (!gen && !h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || n_local >= 4000000ull)) rc = run_tiled_imaging(h, dk, L, lds, n_local);
+        // ... where flights are long: the tiled schedule trades a generation (four launches per pool, a record written and read) per
+        // flight for walks from LDS.  A thick scattering medium -- 5 crossings per flight on a 64^3 grid at tau = 6, albedo 0.9 --
+        // runs 0.162 s on it against 0.122 s on the deferred rounds (4e6 packets, profiles/r06_tiled_log.md); configs[3] has 29.
+        const bool long_flights = h->lucy_cross_per_flight <= 0.0 || h->lucy_cross_per_flight >= 12.0;
+        if (!gen && !h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || (n_local >= 4000000ull && long_flights))) rc = run_tiled_imaging(h, dk, L, lds, n_local);
         if (rc == 1) return 1;
         if (rc == 0) {
             (void)hipEventRecord(h->ev1, h->stream);

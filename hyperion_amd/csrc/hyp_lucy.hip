@@ -96,7 +96,7 @@ size_t tile_walk_lds(hyp_handle h, const TileKernels &K, const TileGeom &T)
 // `img`: the imaging iteration on the tiled schedule -- the event buffer the IMG kernels append to; `flush` empties it (sort +
 // peel_kernel) and is called with every pool's stream idle, when the buffer could overflow before the next look and at the end
 int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0, uint64_t n_local, int n_pools, const DeferBuf *img = nullptr,
-                          const std::function<int()> &flush = std::function<int()>())
+                          const std::function<int()> &flush = std::function<int()>(), const TiledEndGame *end_game = nullptr)
 {
     DeferBuf no_events;
     std::memset(&no_events, 0, sizeof no_events);
@@ -209,6 +209,21 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                 if (e != hipSuccess) return h->set_error(std::string("tiled drain failed: ") + hipGetErrorString(e));
                 break;
             }
+            // imaging: the same moment -- no id left, few packets in flight -- hands the live slots to the deferred schedule's rounds
+            // (tile_to_susp_kernel; every pool's stream is idle here, see above)
+            if (img && end_game && K.to_susp && h->h_ctl->next_id >= h->h_ctl->end_id && in_flight <= std::min<uint64_t>(drain_at, end_game->max_packets)) {
+                if (flush()) return 1;                       // what the generations left in the event buffer
+                TileGeom T = T0; T.n_slots = T0.n_slots * n_pools;
+                (void)hipMemsetAsync(&h->d_ctl->n_live, 0, 2 * sizeof(unsigned int), h->stream);
+                tile_live_kernel<<<(T.n_slots + HYP_PREP_CHUNK - 1) / HYP_PREP_CHUNK, 256, 0, h->stream>>>(T, h->d_slot_brick, h->d_order, h->d_ctl);
+                T.drain_list = h->d_order;
+                DeferBuf B = *img; B.cur = 0;
+                K.to_susp<<<(unsigned)((in_flight + 255) / 256 + 1), 256, 0, h->stream>>>(h->d_problem, T, h->d_ctl, h->d_hot, h->d_cold, h->d_slot_brick, B);
+                if (hipGetLastError() != hipSuccess) return h->set_error("tiled imaging: the end-game's hand-over failed to launch");
+                h->last_end_game = (long long)in_flight;
+                if (end_game->run()) return 1;
+                break;
+            }
             int err = 0;
             (void)hipMemcpy(&err, h->d_err, sizeof(int), hipMemcpyDeviceToHost);
             if (err) break;
@@ -248,7 +263,7 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
 
 // One iteration on the slot-pool schedule: the Lucy iteration (img == nullptr; `iter_tag` = the iteration number), or the imaging
 // iteration's propagation half with its events appended to *img (run_tiled_imaging below)
-int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t iter_tag, const DeferBuf *img, const std::function<int()> &flush)
+int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t iter_tag, const DeferBuf *img, const std::function<int()> &flush, const TiledEndGame *end_game)
 {
     const DProblem &P = h->hp;
     const int nd = h->n_dust;
@@ -336,7 +351,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     (void)hipMemsetAsync(h->d_cursor, 0, 2 * sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS, h->stream);
     (void)hipMemcpyAsync(h->d_ctl, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream);
     (void)hipStreamSynchronize(h->stream);      // c0 lives on this stack frame; the other pools start after the resets
-    const int rc = run_tiled_generations(h, K, T, n_local, n_pools, img, flush);
+    const int rc = run_tiled_generations(h, K, T, n_local, n_pools, img, flush, end_game);
     for (int pool = 1; pool < n_pools; pool++) {      // join the other pools into the engine's stream
         (void)hipEventRecord(h->ev_pool, h->pool_stream[pool]);
         (void)hipStreamWaitEvent(h->stream, h->ev_pool, 0);
@@ -790,6 +805,9 @@ int hyp_lucy_finish(hyp_handle h, double *specific_energy_out, hyp_iter_stats *s
     (void)hipEventElapsedTime(&h->last_finish_ms, h->ev2, h->ev3);
     for (int d = 0; d < h->n_dust; d++) st.energy_abs_tot[d] = tot[d];
     h->last_stats = st;
+    // cell crossings per flight (emission or interaction -> next interaction or escape) of this iteration: what the imaging iteration's
+    // choice of schedule looks at (hyp_final_launch)
+    if (st.n_packets + st.interactions > 0) h->lucy_cross_per_flight = (double)st.crossings / (double)(st.n_packets + st.interactions);
     if (stats) *stats = st;
     return 0;
 }

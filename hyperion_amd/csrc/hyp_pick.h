@@ -34,11 +34,13 @@ using TileInteractK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, vo
 using TileEmitK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, const TileTask *, const int *, const TileCount *,
                            unsigned int *, int *, DeferBuf);
 using TileDrainK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *);
+using TileToSuspK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, int *, DeferBuf);
 using TileWalkK = void (*)(const DProblem *, TileGeom, TileCtl *, void *, void *, const int *, const TileTask *, int *, int *, int *, TileCount *,
                            unsigned int *);
 struct TileKernels {
     TileInteractK interact[2][2];       // [sources can re-absorb][modified random walk]
     TileEmitK emit, emit_simple, emit_ext;      // emit_simple: point sources with tabulated / blackbody spectra only; emit_ext: those + external sources
+    TileToSuspK to_susp;                // the imaging iteration's end-game: live slots -> SuspRec of the deferred schedule (tile_to_susp_kernel)
     TileInteractK interact_img; TileEmitK emit_img;      // the imaging iteration on this schedule (IMG kernels of hyp_tiled.h); event_bytes = sizeof(PeelEvent)
     size_t event_bytes;
     TileDrainK drain[2][2];

@@ -914,6 +914,50 @@ __global__ __launch_bounds__(256, HYP_PREP_WAVES) void tile_drain_kernel(const D
     }
 }
 
+// End-game of the imaging iteration on this schedule (round 6; iter_final.f90:255-259 bounds a packet's interactions, not its
+// generations): when no packet id is left and few packets are in flight, a generation is four launches per pool for a handful of
+// packets.  The live slots (tile_live_kernel's list) become SuspRec of the deferred schedule -- "about to interact", or -3 "on its
+// way" -- and final_defer_kernel resumes them as it resumes what a round set aside (hyp_defer.h): the packets end in a few
+// persistent launches with their peel-off events sorted and peeled as always.  Entry k of the list goes to lane k of the next round.
+template <int ND, int GEOM>
+__global__ __launch_bounds__(256) void tile_to_susp_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+                                                          void *__restrict__ hot_v, void *__restrict__ cold_v, int *__restrict__ slot_brick, DeferBuf B)
+{
+    const DProblem &P = *Pp;
+    HotRec<ND> *__restrict__ hot = (HotRec<ND> *)hot_v;
+    ColdRec<ND> *__restrict__ cold = (ColdRec<ND> *)cold_v;
+    const unsigned int nl = ctl->n_live;
+    const unsigned int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) B.ctl->n_susp[B.cur ^ 1] = nl;
+    if (k >= nl) return;
+    const int slot = T.drain_list[k];
+    const HotRec<ND> &H = hot[slot];
+    const ColdRec<ND> &C = cold[slot];
+    SuspRec<ND, GEOM> &R = ((SuspRec<ND, GEOM> *)B.susp[B.cur ^ 1])[k];
+    Packet<ND, GEOM> p;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { p.r[a] = H.r[a]; p.v[a] = H.v[a]; }
+    TileCellIO<GEOM>::load(P, H, p.cell);
+    p.a = C.a;
+    p.s[0] = C.s[0]; p.s[1] = C.s[1]; p.s[2] = C.s[2]; p.s[3] = C.s[3];
+    p.nu = C.nu; p.energy = H.energy; p.tau_req = H.tau_req; p.tau_ach = H.tau_ach;
+#pragma unroll
+    for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
+    p.inter = C.inter; p.emiss_dust = -1;
+    p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+    p.n_visited = 0; p.e_init = 0.0;
+    PeelFlags f; unsigned int peel_seq;
+    cold_flags_load(C, f, peel_seq);
+    p.peel_seq = peel_seq;
+    p.spec_idx = H.state == TS_INTERACT ? 0 : -3;
+    Rng g;
+    const unsigned long long id = H.id;
+    g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
+    g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
+    R.p = p; R.g = g; R.f = f;
+    hot[slot].state = TS_DONE; slot_brick[slot] = TILE_IDLE;
+}
+
 // the slots that still hold a packet, for tile_drain_kernel: 2048 slots per workgroup, one reservation in the list per workgroup
 static __global__ __launch_bounds__(256) void tile_live_kernel(TileGeom T, const int *__restrict__ slot_brick, int *__restrict__ live, TileCtl *__restrict__ ctl)
 {
