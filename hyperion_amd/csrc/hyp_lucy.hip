@@ -186,7 +186,10 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                     if (flush()) return 1;
                     room = img->cap / ev_per_gen;
                 }
-                next_check = gen + 1 + (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)h->tile_poll, room));
+                // (once the last id is out the end-game is near: look every other generation, so that it starts with as many packets
+                // as it may take rather than with what eight more generations leave of them)
+                const unsigned long long poll = h->h_ctl->next_id >= h->h_ctl->end_id ? std::min<unsigned long long>(2, (unsigned long long)h->tile_poll) : (unsigned long long)h->tile_poll;
+                next_check = gen + 1 + (int)std::max<unsigned long long>(1, std::min<unsigned long long>(poll, room));
             }
             if (h->h_ctl->n_finished >= n_local) break;
             if (gen > max_gen) return h->set_error(img ? "tiled imaging iteration did not terminate" : "tiled Lucy iteration did not terminate");

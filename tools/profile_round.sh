@@ -21,7 +21,7 @@ for w in $WL; do
   case $w in
     car)  CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras" ;;
     car1) CMD="python $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --option tile_pools=1" ;;
-    vor1|oct_lucy1|amr1|sph1) CMD="python $REPO/tools/workload.py ${w%1} ${PACKETS:-1e8} tile_pools=1" ;;
+    vor1|oct_lucy1|oct_img1|amr1|sph1) CMD="python $REPO/tools/workload.py ${w%1} ${PACKETS:-1e8} tile_pools=1" ;;
     *)    CMD="python $REPO/tools/workload.py $w ${PACKETS:-1e8} ${WOPTS:-}" ;;
   esac
   D=$OUT/raw_$w; rm -rf $D; mkdir -p $D
