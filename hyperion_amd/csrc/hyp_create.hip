@@ -1648,6 +1648,18 @@ int build_oct_clusters(hyp_handle h)
     for (int c = 0; c < n_cl; c++) { max_cells = std::max(max_cells, ncv[c]); max_kids = std::max(max_kids, kid_off[c + 1] - kid_off[c]); }
     // per-cluster images: records with the row of a refined cell's children in `parent`, children and neighbours as local indices
     std::vector<OctCell> rec(C);
+    // `pad` of the cluster's copy: bit b set where the cell passes the second half of geo_advance's edge test on axis b,
+    // h 1e-6 > 1e-14 (|c| + h) -- a property of the cell, formed here with the walk's own operations (otile_walk_kernel looks it up
+    // instead of evaluating it at every step)
+    for (size_t i = 0; i < rec.size(); i++) {
+        const double cxyz[3] = {rec[i].x, rec[i].y, rec[i].z};
+        unsigned char bits = 0;
+        for (int b = 0; b < 3; b++) {
+            const double hb = std::ldexp(h->hp.oct_half[b], -(int)rec[i].level);
+            if (hb * 1e-6 > 1e-14 * (std::fabs(cxyz[b]) + hb)) bits |= (unsigned char)(1u << b);
+        }
+        rec[i].pad = bits;
+    }
     std::vector<short> kid((size_t)std::max(1, kid_off[n_cl]) * 8, (short)-1), nb(6 * nc, (short)-2);
     for (int c = 0; c < n_cl; c++) {
         int row = 0;

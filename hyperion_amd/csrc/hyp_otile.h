@@ -80,7 +80,14 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
     double r[3] = {0.0, 0.0, 0.0}, v[3] = {1.0, 1.0, 1.0}, inv[3] = {1.0, 1.0, 1.0}, tau_req = 0.0, tau_ach = 0.0, energy = 0.0, chi[ND], kappa[ND];
     double cc[3] = {0.0, 0.0, 0.0};          // centre of the current cell
     double t_src = HYP_INF, t_ach = 0.0;     // re-absorption by sources (P.any_intersect): see Packet
-    int level = 0, loc = 0, ow_axis = 0;     // ow_axis: (axis + 1) * sign of the wall the packet sits on (0: none), the packed on_wall_id
+    // the record's last word as it is (subcell | level << 8 | refined << 16 | pad << 24): the level, and in `pad` of the cluster's copy the axes
+    // on which the cell passes the size half of geo_advance's edge test (build_oct_clusters) -- one register for both
+    int meta = 0;
+#define OT_LEVEL ((meta >> 8) & 255)
+#define OT_EDGE_OK ((unsigned)meta >> 24)
+    auto meta_of = [](const OctCell &o) { int m; __builtin_memcpy(&m, &o.subcell, 4); return m; };
+    static_assert(offsetof(OctCell, subcell) == 28 && offsetof(OctCell, level) == 29 && offsetof(OctCell, pad) == 31, "OctCell layout");
+    int loc = 0, ow_axis = 0;     // ow_axis: (axis + 1) * sign of the wall the packet sits on (0: none), the packed on_wall_id
     int next_cell = 0;                       // LS_LEFT: where the neighbour table points (a cell of another cluster)
     bool v_ok = true;
     Rng g; g.key0 = P.seed_key; g.key1 = T.iter_tag; g.blk_a = 0; g.have_a = 0; g.buf_a = 0.0;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
 
     // the general cell record of the lane's packet (for the functions of hyp_kernels.h)
     auto full_cell = [&](Cell<GEOM_OCT> &c) {
-        c.id = c0 + loc; c.c[0] = cc[0]; c.c[1] = cc[1]; c.c[2] = cc[2]; c.level = level;
+        c.id = c0 + loc; c.c[0] = cc[0]; c.c[1] = cc[1]; c.c[2] = cc[2]; c.level = OT_LEVEL;
         c.parent = P.oct_cells[c.id].parent; c.subcell = rec[loc].subcell;
         c.ow[0] = c.ow[1] = c.ow[2] = 0;
         if (ow_axis > 0) c.ow[ow_axis - 1] = 1; else if (ow_axis < 0) c.ow[-ow_axis - 1] = -1;
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                             ow_axis = c.ow[0] ? c.ow[0] : c.ow[1] ? 2 * c.ow[1] : 3 * c.ow[2];
                             if (geo_escaped(P, c)) st = LS_DEAD;
                             else if (c.id >= c0 && c.id < c0 + nc) {
-                                loc = c.id - c0; cc[0] = c.c[0]; cc[1] = c.c[1]; cc[2] = c.c[2]; level = c.level; st = LS_WALK;
+                                loc = c.id - c0; cc[0] = c.c[0]; cc[1] = c.c[1]; cc[2] = c.c[2]; meta = meta_of(rec[loc]); st = LS_WALK;
                             } else { left_cell = c.id; st = LS_LEFT; }
                         }
                     } else {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                     kind = H.pad;
                     if (P.any_intersect) { t_src = cold[slot].t_src; t_ach = cold[slot].t_ach; }
                     const OctCell o = rec[loc];
-                    cc[0] = o.x; cc[1] = o.y; cc[2] = o.z; level = o.level;
+                    cc[0] = o.x; cc[1] = o.y; cc[2] = o.z; meta = meta_of(o);
                     st = LS_WALK;
                 }
             }
@@ -241,8 +248,10 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                 double t[3], h[3];
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    h[a] = ldexp(P.oct_half[a], -level);
-                    const double wall = v[a] > 0.0 ? cc[a] + h[a] : cc[a] - h[a];
+                    h[a] = ldexp(P.oct_half[a], -OT_LEVEL);
+                    // (c - h is c + (-h), bit for bit: the face ahead is c + copysign(h, v) -- one v_bfi_b32 and one addition instead of
+                    // two additions, a comparison and a 64-bit select; v = 0 is overridden below)
+                    const double wall = cc[a] + __builtin_copysign(h[a], v[a]);
                     const double d = wall - r[a];
                     const double q0 = d * inv[a];
                     const double tq = __builtin_fma(__builtin_fma(-q0, v[a], d), inv[a], q0);
@@ -274,11 +283,11 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                         double rn[3];
 #pragma unroll
                         for (int b = 0; b < 3; b++) rn[b] = r[b] + tmin * v[b];
-                        bool fast = true;
+                        bool fast = ((OT_EDGE_OK | (1u << a)) & 7u) == 7u;      // h 1e-6 > 1e-14 (|c| + h) on the two other axes: the builder's bits
 #pragma unroll
                         for (int b = 0; b < 3; b++) {
                             const double d = fabs(rn[b] - cc[b]);
-                            if (b != a && !(d < h[b] * (1.0 - 1e-6) && h[b] * 1e-6 > 1e-14 * (fabs(cc[b]) + h[b]))) fast = false;
+                            if (b != a && !(d < h[b] * (1.0 - 1e-6))) fast = false;
                         }
                         if (!fast) st = LS_OSLOW;       // nothing of this step has been applied yet
                         else {
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
                                         n = kid[o.parent * 8 + sub];
                                         o = rec[n];
                                     }
-                                    loc = n; cc[0] = o.x; cc[1] = o.y; cc[2] = o.z; level = o.level;
+                                    loc = n; cc[0] = o.x; cc[1] = o.y; cc[2] = o.z; meta = meta_of(o);
                                 }
                             }
                         }
@@ -347,3 +356,5 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
     }
     block_tally_flush(P, ctl, red, cnt, finished);
 }
+#undef OT_LEVEL
+#undef OT_EDGE_OK
