@@ -53,11 +53,11 @@ N_SIMD, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs, peak engine clock
 # SIMD cycles per wave64 instruction at 4 waves per SIMD, measured with tools/ubench/valu_issue.hip (profiles/r03_tiled_log.md):
 # FP64 add / mul / fma / compare / ldexp and 64-bit integer 4.2-4.9 -> 4.3; 32-bit 2.2-2.6 -> 2.4; v_rcp_f64 16
 CYC_F64, CYC_32, CYC_TRANS_F64 = 4.3, 2.4, 16.0
-PMC_FILE = "profiles/r05_pmc.json"
+PMC_FILE = "profiles/r06_pmc.json"
 
 
 def committed_pmc(workload):
-    """Counter sums of the committed rocprofv3 passes of one workload (profiles/r05_pmc.json, written on the GPU box by
+    """Counter sums of the committed rocprofv3 passes of one workload (profiles/r06_pmc.json, written on the GPU box by
     tools/profile_round.sh + tools/summarize_profile_round.py: `car` = THIS bench command, `oct_lucy` / `oct_img` / `vor` = the extra
     configurations at 1e8 packets).  Counters cannot be read inside the timed run, so the bench line carries them with
     their source; None when the file is not there."""
@@ -81,7 +81,7 @@ def host_cpu():
 
 def traffic_fields(pmc):
     """bytes per crossing (L2 <-> fabric, FETCH_SIZE / WRITE_SIZE in KiB as reported; reads also with the guide's x2 for wide
-    streaming loads) and their ratio to the algorithmic 24 B x n_dust, from a workload entry of profiles/r05_pmc.json."""
+    streaming loads) and their ratio to the algorithmic 24 B x n_dust, from a workload entry of profiles/r06_pmc.json."""
     if not pmc or "bytes_per_crossing" not in pmc:
         return {"bytes_per_crossing": None}
     b = pmc["bytes_per_crossing"]
@@ -560,7 +560,7 @@ def main():
                     "avg_launch_us": walk_ms * 1e3 / max(n_walk, 1),
                     "achieved_GBs_over_its_own_time": alg_bytes / (walk_ms * 1e-3) / 1e9 if walk_ms > 0 else None,
                     "note": "HIP events around every tile_walk launch on its pool's stream, in one extra step after the timed region (option tile_time_walk, off in the timed steps); with several "
-                            "pools the launches overlap other kernels and stretch -- profiles/r05_car1_summary.md has the one-pool trace"}
+                            "pools the launches overlap other kernels and stretch -- profiles/r06_car1_summary.md has the one-pool trace"}
             roof["limiter"] = "valu_issue + service-phase latency"
             roof["note"] = ("density and accumulators of a 32 x 16 x 16 brick live in LDS, so the 24 B per crossing never go to memory: `bound` names the "
                             "nominal roofline of the path (HBM), the fraction says how far it is from a streaming bound it does not have; the counters "

@@ -28,7 +28,13 @@ if tot is None:
 X = float(tot["crossings"])
 L = ["# rocprofv3 summary, round %s: `%s`" % (ROUND.lstrip("r0"), w), "", "Workload output:", "", "```"]
 L += [l for l in log.splitlines() if l and not l.startswith(("W2", "E2", "I2", "/opt/amdgpu")) and "amdgpu.ids" not in l][-8:]
-L += ["```", "", "Crossings of the whole profiled process (warm-up included): %.6g; packets %.4g; algorithmic bytes 24 B x %d species per crossing." % (X, tot["packets"], tot["n_dust"]), ""]
+# SURVEY section 8d, the rule bench.py uses too: a Lucy iteration moves 24 B x n_dust per crossing; an imaging iteration deposits nothing on its
+# crossings -- 8 B x n_dust per crossing + 16 B x n_stokes per binned peel-off event
+imaging = tot.get("events", 0) > 0
+alg_per_crossing = (8.0 * tot["n_dust"] + 16.0 * tot["n_stokes"] * tot["events"] / X) if imaging else 24.0 * tot["n_dust"]
+L += ["```", "", "Crossings of the whole profiled process (warm-up included): %.6g; packets %.4g; algorithmic bytes %s." % (X, tot["packets"],
+      ("8 B x %d species per crossing + 16 B x %d Stokes x %.4g binned events = %.2f B per crossing (imaging iteration, SURVEY 8d)" % (tot["n_dust"], tot["n_stokes"], tot["events"], alg_per_crossing))
+      if imaging else "24 B x %d species per crossing" % tot["n_dust"]), ""]
 res = {"crossings": X, "packets": tot["packets"], "n_dust": tot["n_dust"], "timed_ms": tot.get("timed_ms"), "kernels": {}, "counters": {}}
 for db in glob.glob(os.path.join(raw, "trace", "**", "*.db"), recursive=True):
     c = sqlite3.connect(db)
@@ -68,7 +74,7 @@ if res["counters"]:
     res["per_crossing"] = per
     if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
         f, wr = per["FETCH_SIZE"] * 1024.0, per["WRITE_SIZE"] * 1024.0
-        alg = 24.0 * tot["n_dust"]
+        alg = alg_per_crossing
         res["bytes_per_crossing"] = {"fetched": f, "fetched_x2": 2 * f, "written": wr, "algorithmic": alg, "traffic_over_algorithmic": (f + wr) / alg,
                                      "traffic_over_algorithmic_reads_x2": (2 * f + wr) / alg}
         L += ["", "L2<->fabric bytes per crossing: fetched %.1f B (%.1f B with the guide's x2 for wide streaming reads), written %.1f B; algorithmic %.0f B -> traffic / algorithmic = %.2f (%.2f)."

@@ -32,7 +32,8 @@ else:
 eng = hyperion_amd.Engine(p)
 for a in sys.argv[3:]:
     eng.set_option(a.split("=")[0], int(a.split("=")[1]))
-tot = {"workload": which, "packets": 0, "crossings": 0, "n_dust": n_dust, "timed_ms": [], "timed_crossings": 0, "timed_packets": 0}
+tot = {"workload": which, "packets": 0, "crossings": 0, "n_dust": n_dust, "timed_ms": [], "timed_crossings": 0, "timed_packets": 0,
+       "events": 0, "n_stokes": 4 if which == "oct_img" else 0}      # events: binned peel-off events x views of the imaging iterations (16 B x n_stokes each)
 
 
 def run(m, it, timed):
@@ -41,6 +42,8 @@ def run(m, it, timed):
     else:
         _, st = eng.lucy_iteration(m, it, want_output=False)
     tot["packets"] += m; tot["crossings"] += st["crossings"]
+    if which == "oct_img":
+        tot["events"] += eng.get_option("last_defer_events") * sum(len(g.theta) for g in p.peeled)
     if timed:
         ms = eng.last_kernel_ms()[0]
         tot["timed_ms"].append(ms); tot["timed_crossings"] += st["crossings"]; tot["timed_packets"] += m
