@@ -105,3 +105,42 @@ def test_random_combination_matches_oracle(case):
         for name in xb:
             np.testing.assert_allclose(xa[name], xb[name], rtol=1e-9, atol=1e-10 * np.nanmax(np.abs(xb[name])), err_msg="case %d %s %s" % (case, opts, name))
     eng.close(); orc.close()
+
+
+@pytest.mark.parametrize("case", range(110, 176))
+def test_random_combination_with_extended_sources_and_raytracing(case):
+    """The same draw plus, per case: one source turned into a sphere with a radius (re-absorption and re-emission by the source,
+    the general emitters and the GEN kernels of the deferred schedule), limb darkening, and the raytracing iteration on top of the
+    imaging iteration (thermal emission of the dust and the sources' own light peeled off per frequency bin)."""
+    prob, opts = random_case(case)
+    rng = np.random.RandomState(5000 + case)
+    half = {"car": 3.08568025e18, "oct": None, "amr": None, "sph_pol": None, "cyl_pol": None, "vor": None}[prob.grid_type]
+    if prob.grid_type != "vor" and rng.uniform() < 0.6:       # (the Voronoi model's external source stays as it is)
+        s = prob.sources[int(rng.randint(0, len(prob.sources)))]
+        s.type = "sphere"
+        s.radius = float(10.0 ** rng.uniform(15.0, 16.5))     # 3e-4 .. 1e-2 of the grids' half-width: inside one cell or across a few
+        s.limb_darkening = bool(rng.uniform() < 0.5)
+    ray = bool(rng.uniform() < 0.6)
+    prob.config.raytracing = ray
+    n_lucy, n_img = 10000, 6000
+    eng, orc = hyperion_amd.Engine(prob), Oracle(prob)
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    for it in (1, 2):
+        a, sa = eng.lucy_iteration(n_lucy, it)
+        b, sb = orc.lucy_iteration(n_lucy, it)
+        for k in INT_KEYS:
+            assert sa[k] == sb[k], (case, opts, it, k, sa, sb)
+        assert_parity(a, b, atol_rel=1e-10)
+    ga, sa = eng.final_iteration(n_img)
+    gb, sb = orc.final_iteration(n_img)
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (case, opts, "final", k, sa, sb)
+    if ray:
+        ga, sa = eng.raytracing_iteration(4000, 4000)
+        gb, sb = orc.raytracing_iteration(4000, 4000)
+        assert sa["crossings"] == sb["crossings"] and sa["killed_geo"] == sb["killed_geo"], (case, sa, sb)
+    for xa, xb in zip(ga, gb):
+        for name in xb:
+            np.testing.assert_allclose(xa[name], xb[name], rtol=1e-9, atol=1e-10 * np.nanmax(np.abs(xb[name])), err_msg="case %d %s %s" % (case, opts, name))
+    eng.close(); orc.close()
