@@ -108,7 +108,14 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
     };
 
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
+#ifdef HYP_TILE_STATS
+    unsigned long long dbg_wsteps = 0, dbg_lsteps = 0, dbg_outer = 0;
+    const long long dbg_t0 = clock64();
+#endif
     for (;;) {
+#ifdef HYP_TILE_STATS
+        dbg_outer++;
+#endif
         if (queue_empty && st == LS_IDLE) exhausted = true;
         const unsigned long long m_walk = __ballot(st == LS_WALK);
         const unsigned long long m_out = __ballot(st >= LS_LEFT);      // anything the service phase must look at
@@ -243,6 +250,9 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #pragma unroll 1
         for (int q = 0; q < HYP_OTILE_STEPS; q++) {
+#ifdef HYP_TILE_STATS
+            { const unsigned long long mw = __ballot(st == LS_WALK); if (mw) { dbg_wsteps++; dbg_lsteps += __popcll(mw); } }
+#endif
             if (st == LS_WALK) {
                 // find_wall :438-537 -- the face ahead on each axis, t = (c +- h - r) / v as the correctly rounded quotient
                 double t[3], h[3];
@@ -340,6 +350,13 @@ __global__ __launch_bounds__(HYP_OTILE_WG, HYP_OTILE_OCC) void otile_walk_kernel
             }
         }
     }
+#ifdef HYP_TILE_STATS
+    if (__lane_id() == 0) {
+        atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps); atomicAdd(&ctl->dbg[3], 1ull);
+        atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
+        if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
+    }
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < OT_HIST; i += blockDim.x) if (nb_cnt[i]) atomicAdd(&counts[i], nb_cnt[i]);
     tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);
