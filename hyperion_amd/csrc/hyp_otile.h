@@ -21,8 +21,14 @@
 
 constexpr int HYP_OTILE_WG = 1024;         // threads per workgroup (one workgroup per task; one per CU with clusters of up to 156 KB: 104.5 -> 97.3 ms on configs[3] against two 512-thread workgroups on 78 KB clusters)
 constexpr int HYP_OTILE_OCC = 4;          // waves per SIMD the register budget is set for (16 waves per CU)
-constexpr int HYP_OTILE_SERVICE = 24;      // lanes that must wait before a wave runs its service phase (8 / 16 / 24 / 32: 118.9 / 119.1 / 114.2 / - ms at 4 steps)
-constexpr int HYP_OTILE_STEPS = 8;         // cell steps between two scheduling decisions of a wave (2 / 4 / 8: 125.5 / 119.1 / 108.9 ms; 8 with 24 lanes: 103.2)
+#ifndef HYP_OTILE_SERVICE_N
+#define HYP_OTILE_SERVICE_N 24
+#endif
+#ifndef HYP_OTILE_STEPS_N
+#define HYP_OTILE_STEPS_N 8
+#endif
+constexpr int HYP_OTILE_SERVICE = HYP_OTILE_SERVICE_N;      // lanes that must wait before a wave runs its service phase (8 / 16 / 24 / 32: 118.9 / 119.1 / 114.2 / - ms at 4 steps)
+constexpr int HYP_OTILE_STEPS = HYP_OTILE_STEPS_N;         // cell steps between two scheduling decisions of a wave (2 / 4 / 8: 125.5 / 119.1 / 108.9 ms; 8 with 24 lanes: 103.2)
 #define OT_HIST 256               // clusters whose packet counts a task collects in LDS (the others: global atomics)
 
 // lane states beyond those of tile_walk_kernel: LS_LEFT = the neighbour is in another cluster (found through the global
