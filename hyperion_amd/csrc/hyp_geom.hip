@@ -184,7 +184,7 @@ static TileKernels tile_kernels()
         k.interact[0][1] = tile_interact_kernel<NDT, false, true, GEOM>; k.interact[1][1] = tile_interact_kernel<NDT, true, true, GEOM>;
         k.drain[0][1] = tile_drain_kernel<NDT, false, true, GEOM>; k.drain[1][1] = tile_drain_kernel<NDT, true, true, GEOM>;
         k.walk = ptile_walk_kernel<NDT, GEOM>;
-        k.walk_threads = HYP_PTILE_WG;
+        k.walk_threads = ptile_wg<NDT>();
     }
 #elif HYP_GEOM_TU == 2
     {      // the modified random walk is not defined on Voronoi grids (the engine refuses it)

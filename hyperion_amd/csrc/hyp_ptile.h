@@ -15,10 +15,14 @@
 
 #include "hyp_tiled.h"
 
-constexpr int HYP_PTILE_WG = 768;         // threads per workgroup (one workgroup per task, one per CU)
-constexpr int HYP_PTILE_OCC = 3;          // waves per SIMD the register budget is set for
+// Round 6 (same-box A/Bs on the 400 x 200 grids, one species): one 1024-thread workgroup per CU at the 4-waves budget (128 VGPRs, 39 spilled) with 8 steps
+// per scheduling decision against 768 threads at the 3-waves budget (168 VGPRs) with 4 -- spherical 548.0 -> 528.0 ms per 3e7 packets, cylindrical 140.4 ->
+// 129.5 ms per 2e7; 8 steps alone 538.9 / 135.9; 1024 threads alone 538.1; 2 steps / 8 lanes and 6 / 24: 566-568.  Two to four species keep the shape
+// they were measured with.
+template <int ND> constexpr int ptile_wg() { return ND == 1 ? 1024 : 768; }       // threads per workgroup (one workgroup per task, one per CU)
+template <int ND> constexpr int ptile_occ() { return ND == 1 ? 4 : 3; }           // waves per SIMD the register budget is set for
 constexpr int HYP_PTILE_SERVICE = 16;     // lanes that must wait before a wave runs its service phase
-constexpr int HYP_PTILE_STEPS = 4;        // cell steps between two scheduling decisions of a wave
+template <int ND> constexpr int ptile_steps() { return ND == 1 ? 8 : 4; }         // cell steps between two scheduling decisions of a wave
 #define PT_HIST 256              // bricks whose packet counts a task collects in LDS (the others: global atomics)
 
 
@@ -28,7 +32,7 @@ constexpr int HYP_PTILE_STEPS = 4;        // cell steps between two scheduling d
 
 // TileGeom: bx, by, bz = brick size in cells (the last brick of an axis is ragged), nbx, nby, nbz = bricks per axis
 template <int ND, int GEOM>
-__global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
+__global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_kernel(const DProblem *__restrict__ Pp, TileGeom T, TileCtl *__restrict__ ctl,
                                                                   void *__restrict__ hot_v, void *__restrict__ cold_v,
                                                                   const int *__restrict__ order,
                                                                   const TileTask *__restrict__ tasks, int *__restrict__ slot_brick,
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(HYP_PTILE_WG, HYP_PTILE_OCC) void ptile_walk_kernel
         }
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #pragma unroll 1
-        for (int q = 0; q < HYP_PTILE_STEPS; q++) {
+        for (int q = 0; q < ptile_steps<ND>(); q++) {
             if (st == LS_WALK) {
                 if (g.countdown == 0) st = LS_CHECK;
                 else {
