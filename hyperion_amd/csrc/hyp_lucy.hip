@@ -258,6 +258,11 @@ int run_tiled_generations(hyp_handle h, const TileKernels &K, const TileGeom &T0
                            (double)d[16] / d[17], (double)d[16] / d[8], (double)d[18] / std::max(1ull, d[19]));
         if (d[17] && d[21]) fprintf(stderr, "tile stats: of a search's clocks: site + q %.0f, filter loop %.0f, the winner's FP64 evaluation and the rest %.0f\n",
                                     (double)d[20] / d[17], (double)d[21] / d[17], (double)(d[16] - d[20] - d[21]) / d[17]);
+        if (d[32]) fprintf(stderr, "tile stats (polar walk): %.0f clocks per wave-step (%.3f of the loop's)\n", (double)d[32] / d[1], (double)d[32] / d[8]);
+        if (d[31]) fprintf(stderr, "tile stats (polar walk): wall search %.0f clocks per wave-step (%.3f of the loop's); per wave-step: inner sphere solved in %.3f (%.1f lanes), "
+                                   "cones solved %.3f of 2 (%.1f lanes each), a lane on a cone wall in %.3f (%.1f lanes), lanes on a sphere wall %.1f\n",
+                           (double)d[31] / d[1], (double)d[31] / d[8], (double)d[24] / d[1], (double)d[25] / std::max(1ull, d[24]), (double)d[26] / d[1], (double)d[27] / std::max(1ull, d[26]),
+                           (double)d[28] / d[1], (double)d[29] / std::max(1ull, d[28]), (double)d[30] / d[1]);
         fprintf(stderr, "tile stats: wave clocks waiting at the end of the task for the workgroup's last wave %.3f of the loop's\n", (double)d[9] / d[8]);
     }
 #endif

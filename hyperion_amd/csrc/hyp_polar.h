@@ -269,12 +269,18 @@ __device__ __forceinline__ void sph_wall_cone(const DProblem &P, const double r[
                                               double e, double tt, double tt2)
 {
     const int iw = c.ic[1] + side, dir = side ? +1 : -1;
-    if (c.ow[1] == dir && equal_nulp(tt, sqrt(v2_xy) / v[2], 10) && equal_nulp(sqrt(r2_xy) * v[2] * tt, rv_xy, 10)) { ws.iext[1] = dir; return; }
+    const double pA = v2_xy - v2_z * tt2;
+    // The packet sits on this wall: does it fly along the cone (:846-853)?  equal_nulp(tt, s, 10) with s = sqrt(v2_xy) / v_z means
+    // tt = s (1 + d), |d| < 10.01 * 2^-52; s carries two roundings, tt2 = RN(tt^2) one, v2_z one, the product one: v2_z tt2 = v2_xy (1 + h)
+    // with |h| < 24 * 2^-52, so |pA| <= 2^-47 v2_xy.  A pA above 2^-40 v2_xy (v2_xy normal, so that the bounds hold) therefore says "no"
+    // without the square root and the division -- which every wave-step of scattered packets paid twice for the lanes that had come in
+    // through a cone (round 6).
+    const bool maybe_along = !(v2_xy >= 0x1p-1000 && fabs(pA) > 0x1p-40 * v2_xy);
+    if (c.ow[1] == dir && maybe_along && equal_nulp(tt, sqrt(v2_xy) / v[2], 10) && equal_nulp(sqrt(r2_xy) * v[2] * tt, rv_xy, 10)) { ws.iext[1] = dir; return; }
     if (iw == P.midplane && v[2] != 0.0) {
         if (c.ow[1] != dir) insert_t(ws, -r[2] / v[2], 1, dir, e);
         return;
     }
-    const double pA = v2_xy - v2_z * tt2;
     double pB = rv_xy - rv_z * tt2; pB = pB + pB;
     const double pC = r2_xy - r2_z * tt2;
     // Three coefficients of one strict sign: no positive root (Descartes), and the formulas below say so too -- q has the sign of -pB, so

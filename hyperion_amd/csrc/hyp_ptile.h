@@ -19,10 +19,13 @@
 // per scheduling decision against 768 threads at the 3-waves budget (168 VGPRs) with 4 -- spherical 548.0 -> 528.0 ms per 3e7 packets, cylindrical 140.4 ->
 // 129.5 ms per 2e7; 8 steps alone 538.9 / 135.9; 1024 threads alone 538.1; 2 steps / 8 lanes and 6 / 24: 566-568.  Two to four species keep the shape
 // they were measured with.
-template <int ND> constexpr int ptile_wg() { return ND == 1 ? 1024 : 768; }       // threads per workgroup (one workgroup per task, one per CU)
-template <int ND> constexpr int ptile_occ() { return ND == 1 ? 4 : 3; }           // waves per SIMD the register budget is set for
+#ifndef HYP_PTILE_WIDE_ND
+#define HYP_PTILE_WIDE_ND 1      // species counts up to this one walk in the 1024 / 4 / 8 shape
+#endif
+template <int ND> constexpr int ptile_wg() { return ND <= HYP_PTILE_WIDE_ND ? 1024 : 768; }       // threads per workgroup (one workgroup per task, one per CU)
+template <int ND> constexpr int ptile_occ() { return ND <= HYP_PTILE_WIDE_ND ? 4 : 3; }           // waves per SIMD the register budget is set for
 constexpr int HYP_PTILE_SERVICE = 16;     // lanes that must wait before a wave runs its service phase
-template <int ND> constexpr int ptile_steps() { return ND == 1 ? 8 : 4; }         // cell steps between two scheduling decisions of a wave
+template <int ND> constexpr int ptile_steps() { return ND <= HYP_PTILE_WIDE_ND ? 8 : 4; }         // cell steps between two scheduling decisions of a wave
 #define PT_HIST 256              // bricks whose packet counts a task collects in LDS (the others: global atomics)
 
 
@@ -90,7 +93,14 @@ __global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_ke
     const Walls W = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, {0, 0, 0}};
 
     bool queue_empty = false;        // wave-uniform: some lane found the task's queue empty
+#ifdef HYP_TILE_STATS
+    unsigned long long dbg_outer = 0, dbg_wsteps = 0, dbg_lsteps = 0, dbg_service = 0, dbg_nservice = 0, dbg_step = 0, dbg_q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long dbg_t0 = clock64();
+#endif
     for (;;) {
+#ifdef HYP_TILE_STATS
+        dbg_outer++;
+#endif
         if (queue_empty && st == LS_IDLE) exhausted = true;
         const unsigned long long m_walk = __ballot(st == LS_WALK);
         const unsigned long long m_out = __ballot(st >= LS_LEFT);      // anything the service phase must look at
@@ -100,6 +110,9 @@ __global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_ke
         const bool park = !m_idle && queue_empty && __popcll(m_walk) <= T.park;
         // ---- service phase: write finished visits back, take new packets ----
         if (park || ((m_out | m_idle) && (__popcll(m_out | m_idle) >= HYP_PTILE_SERVICE || !m_walk))) {
+#ifdef HYP_TILE_STATS
+            const long long dbg_ts = clock64();
+#endif
             // propagation check (grid_propagate_3d.f90:112-120), then the step goes on as usual
             // (a lane whose check is due waits until four are, or nobody walks any more: tile_walk_kernel, hyp_tiled.h)
             if (st == LS_CHECK && (__popcll(__ballot(st == LS_CHECK)) >= 4 || !m_walk || park)) {
@@ -163,10 +176,44 @@ __global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_ke
                 }
             }
             if (__ballot(exhausted)) queue_empty = true;
+#ifdef HYP_TILE_STATS
+            dbg_service += clock64() - dbg_ts; dbg_nservice++;
+#endif
         }
         // ---- a few cell steps (the body of grid_integrate, grid_propagate_3d.f90:106-232) ----
 #pragma unroll 1
         for (int q = 0; q < ptile_steps<ND>(); q++) {
+#ifdef HYP_TILE_STATS
+            long long dbg_tf = 0;
+            {
+                const unsigned long long mw = __ballot(st == LS_WALK);
+                if (mw) { dbg_wsteps++; dbg_lsteps += __popcll(mw); }
+#ifdef HYP_TILE_STATS_Q
+                if constexpr (GEOM == GEOM_SPH) {      // which quadratics this step solves (the conditions of sph_find_wall / sph_wall_cone)
+                    const bool wk = st == LS_WALK && g.countdown != 0;
+                    const double v2_xy = v[0] * v[0] + v[1] * v[1], v2_z = v[2] * v[2], rv_xy = r[0] * v[0] + r[1] * v[1], rv_z = r[2] * v[2];
+                    const double r2_xy = r[0] * r[0] + r[1] * r[1], r2_z = r[2] * r[2];
+                    const double pB = 2.0 * (rv_xy + rv_z), pC = r2_xy + r2_z;
+                    const bool inner = wk && !cell.radial && !(pB >= 0.0 && pC - P.wr2[cell.ic[0]] >= 0.0);
+                    bool cone[2], onw[2];
+                    for (int side = 0; side < 2; side++) {
+                        const int iw = cell.ic[1] + side;
+                        const double tt2 = P.wtant2[iw];
+                        const double pA = v2_xy - v2_z * tt2, pB2 = 2.0 * (rv_xy - rv_z * tt2), pC2 = r2_xy - r2_z * tt2;
+                        const bool there = wk && (side ? cell.ic[1] < P.n2 - 1 : cell.ic[1] > 0);
+                        cone[side] = there && iw != P.midplane && !((pA > 0.0 && pB2 > 0.0 && pC2 > 0.0) || (pA < 0.0 && pB2 < 0.0 && pC2 < 0.0));
+                        onw[side] = there && cell.ow[1] == (side ? +1 : -1);
+                    }
+                    const unsigned long long b0 = __ballot(inner), b1 = __ballot(cone[0]), b2 = __ballot(cone[1]), b3 = __ballot(onw[0] || onw[1]);
+                    dbg_q[0] += b0 != 0; dbg_q[1] += __popcll(b0); dbg_q[2] += (b1 != 0) + (b2 != 0); dbg_q[3] += __popcll(b1) + __popcll(b2);
+                    dbg_q[4] += b3 != 0; dbg_q[5] += __popcll(b3);
+                    const unsigned long long b4 = __ballot(wk && cell.ow[0] != 0);
+                    dbg_q[6] += __popcll(b4);
+                }
+#endif
+                dbg_tf = clock64();
+            }
+#endif
             if (st == LS_WALK) {
                 if (g.countdown == 0) st = LS_CHECK;
                 else {
@@ -175,6 +222,9 @@ __global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_ke
                     bool found;
                     if constexpr (GEOM == GEOM_SPH) found = sph_find_wall(P, W, r, v, cell, tmin, im, reach_task);
                     else found = cyl_ok ? cyl_find_wall_inv(P, r, v, cell, cyl_v2, cyl_inv_v2, cyl_inv_vz, tmin, im) : geo_find_wall(P, W, r, v, cell, tmin, im);
+#ifdef HYP_TILE_STATS
+                    dbg_q[7] += clock64() - dbg_tf;      // (lanes of the wave agree on the clock: the busiest lane's path)
+#endif
                     if (!found) { cnt.killed_geo++; st = LS_DEAD; }
                     else {
                         const int loc = ((cell.ic[2] - z0) * by + (cell.ic[1] - y0)) * bx + (cell.ic[0] - x0);
@@ -217,8 +267,20 @@ __global__ __launch_bounds__(ptile_wg<ND>(), ptile_occ<ND>()) void ptile_walk_ke
                     }
                 }
             }
+#ifdef HYP_TILE_STATS
+            dbg_step += clock64() - dbg_tf;
+#endif
         }
     }
+#ifdef HYP_TILE_STATS
+    if (__lane_id() == 0) {
+        atomicAdd(&ctl->dbg[32], dbg_step);
+        atomicAdd(&ctl->dbg[0], dbg_outer); atomicAdd(&ctl->dbg[1], dbg_wsteps); atomicAdd(&ctl->dbg[2], dbg_lsteps); atomicAdd(&ctl->dbg[3], 1ull);
+        atomicAdd(&ctl->dbg[6], dbg_service); atomicAdd(&ctl->dbg[7], dbg_nservice); atomicAdd(&ctl->dbg[8], (unsigned long long)(clock64() - dbg_t0));
+        for (int i = 0; i < 8; i++) atomicAdd(&ctl->dbg[24 + i], dbg_q[i]);
+        if (threadIdx.x == 0) { atomicAdd(&ctl->dbg[4], 1ull); atomicAdd(&ctl->dbg[5], (unsigned long long)tk.len); }
+    }
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < PT_HIST; i += blockDim.x) if (nb_cnt[i]) atomicAdd(&counts[i], nb_cnt[i]);
     tile_walk_publish_lists(T, ctl, tk, ilist, dlist, n_int_l, n_dead_l, pub_base);

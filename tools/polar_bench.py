@@ -10,6 +10,11 @@ if os.environ.get("HYP_LIB"):
 from test_gpu_polar import config0_problem
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 20_000_000
 p = config0_problem(n_r=400, n_t=200, tau=3.0)
+nd = int(os.environ.get("SPECIES", "1"))      # the same medium as `nd` identical species
+if nd > 1:
+    import numpy as np
+    p.density = np.repeat(p.density / nd, nd, axis=0)
+    p.dust = [p.dust[0]] * nd
 for mode in ((0, -1) if "tiled_only" not in sys.argv else (-1,)):
     e = hyperion_amd.Engine(p)
     e.set_option("lucy_mode", mode)
