@@ -75,6 +75,43 @@ def test_reproducible_mode_equals_oracle_and_itself(grid):
             np.testing.assert_allclose(ga[k], gb[k], rtol=1e-9, atol=1e-11 * np.nanmax(np.abs(gb[k])), err_msg=k)
 
 
+def repro_digests():
+    """blake2b of the bits the reproducible mode produces on the reference's small regression models (Lucy iterations 1-3 and the
+    imaging iteration, 5 000 packets each) -- `python tests/test_gpu_reproducible.py` on a GPU box prints the JSON that is committed
+    as tests/golden/repro_digests.json."""
+    import hashlib
+    out = {}
+    for grid, name in (("car", "car_peeloff.False.npz"), ("oct", "oct_peeloff.False.npz"), ("sph", "sph_peeloff.False.npz"),
+                       ("cyl", "cyl_peeloff.False.npz"), ("amr", "amr_peeloff.False.npz"), ("vor", "vor_config5.npz")):
+        prob, _ = golden_problem(name)
+        eng = hyperion_amd.Engine(prob)
+        eng.set_option("reproducible", 1)
+        h = hashlib.blake2b(digest_size=16)
+        for it in (1, 2, 3):
+            se, st = eng.lucy_iteration(5000, it)
+            h.update(np.ascontiguousarray(se).tobytes())
+            h.update(repr([int(st[k]) for k in ("crossings", "interactions", "killed_geo", "killed_int")]).encode())
+        img, st = eng.final_iteration(5000)
+        for g in img:
+            for k in sorted(g):
+                h.update(np.ascontiguousarray(g[k]).tobytes())
+        eng.close()
+        out[grid] = h.hexdigest()
+    return out
+
+
+def test_reproducible_bits_equal_the_committed_digests():
+    """GPU-vs-GPU regression across builds: the one-wave schedule makes every sum in program order, so a build produces the same bits
+    as the build that wrote tests/golden/repro_digests.json unless the ARITHMETIC of a packet's history changed (a reordered
+    expression in a wall search, another contraction, another device libm).  A deliberate change of that kind regenerates the file
+    (`python tests/test_gpu_reproducible.py`) in the same commit; the parity tests against the oracle say whether it was right."""
+    import json, os
+    path = os.path.join(os.path.dirname(__file__), "golden", "repro_digests.json")
+    want = json.load(open(path))
+    got = repro_digests()
+    assert got == want["digests"], "bits of the reproducible mode changed against %s (written by %s)" % (path, want.get("written_by"))
+
+
 def test_fast_schedule_agrees_with_the_reproducible_one_to_rounding():
     """Same seed, same packets: the default schedule and the one-wave schedule differ by summation order only."""
     prob = make_benchmark_problem(24, tau=2.0)
@@ -89,3 +126,11 @@ def test_fast_schedule_agrees_with_the_reproducible_one_to_rounding():
     for k in ("crossings", "interactions", "killed_geo", "killed_int"):
         assert sa[k] == sb[k]
     assert_parity(a, b)
+
+
+if __name__ == "__main__":
+    import json, subprocess, sys
+    rev = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or "the working tree"
+    json.dump({"written_by": "tests/test_gpu_reproducible.py on an MI355X, ROCm 7.2.0, " + (sys.argv[1] if len(sys.argv) > 1 else rev),
+               "digests": repro_digests()}, sys.stdout, indent=1)
+    print()
