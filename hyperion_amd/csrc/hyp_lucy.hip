@@ -312,7 +312,24 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     // the sort's tables (d_counts / d_cursor, tile_sort_kernel's LDS) hold HYP_TILE_MAX_BRICKS entries per pool
     if (T.n_bricks < 1 || T.n_bricks > HYP_TILE_MAX_BRICKS) return h->set_error("grid has too many bricks for the tiled schedule");
     int n_pools = std::max(1, std::min(h->tile_pools, HYP_TILE_MAX_POOLS));
-    const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
+    // Pool size.  A walk workgroup loads its brick's densities into LDS and flushes its accumulators for however many packets its task
+    // holds, and every generation costs four launches per pool with their tails: what counts is packets in flight per brick and per launch.
+    // Rounds 2-3 settled on 6.3e6 slots (12.6e6 on trees) when the schedule was younger; round 6 swept again at 1e8 packets
+    // (profiles/r06_tiled_log.md): 128^3 215.2 -> 200.1 ms at 25e6 slots, tessellation 346 -> 331, AMR 163 -> 159, spherical 1 658 -> 1 517,
+    // octree flat; Cartesian grids with thousands of bricks want 50e6 (256^3 1 476 -> 994 ms, 400^3 4 357 -> 1 971, 512^3 10 236 -> 3 738;
+    // 1e8 slots: no further gain).  280 B per slot at one species: 7 / 14 GB of the 288 -- within a third of the free memory.
+    // The imaging iteration keeps the smaller pool: its event buffer holds three generations of events (run_tiled_imaging).
+    long long def_slots = (P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21;
+    if (!img) {
+        def_slots = (P.grid_type == 1 && T.n_bricks >= 1024) ? 3ll << 24 : 3ll << 23;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const long long per_slot = (long long)(K.hot_bytes + K.cold_bytes + 6 * sizeof(int));
+            const long long have = (long long)h->tile_slots_alloc * per_slot;       // (a pool of an earlier iteration is given back first)
+            def_slots = std::min(def_slots, std::max(3ll << 21, ((long long)free_b + have) / 3 / per_slot));
+        }
+    }
+    const long long want_slots = h->tile_slots > 0 ? h->tile_slots : def_slots;
     long long slots = std::min<long long>(want_slots, (long long)n_local);
     if (slots < 65536) n_pools = 1;
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
@@ -651,7 +668,10 @@ int hyp_lucy_launch(hyp_handle h, uint64_t first_id, uint64_t n_local, int itera
     bool tile_ok = false, tile_auto = false;
     if (P.grid_type == 1) {
         tile_ok = h->n_dust <= 4 && car_tile_bricks(P, h->n_dust) > 0 && !h->count_photons && !h->n_bins;
-        tile_auto = tile_ok && tile_bricks(P, h->n_dust) >= 32 && n_local >= 1500000ull;      // (128^3: 14.2 against 18.0 ms at 2e6 packets, even at 1e6; tools/small_probe.py)
+        // (128^3: 14.2 against 18.0 ms at 2e6 packets, even at 1e6; tools/small_probe.py.  Large grids: a brick's load and flush must be shared by
+        // enough packets -- break-even against the persistent kernel at ~1 200 packets in flight per brick, 400^3 and 512^3, tools/big_grid_probe.py)
+        const unsigned long long nbk = (unsigned long long)tile_bricks(P, h->n_dust);
+        tile_auto = tile_ok && nbk >= 32 && n_local >= std::max(1500000ull, 1500ull * nbk);
     } else if (P.grid_type == 3) {
         // Voronoi: clusters of cells in LDS (hyp_vtile.h); the modified random walk does not exist on these grids
         tile_ok = h->n_dust <= 4 && !h->count_photons && !h->n_bins && !P.mrw;

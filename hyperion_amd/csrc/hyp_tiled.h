@@ -18,7 +18,9 @@
 
 enum { TS_DEAD = 0, TS_WALK = 1, TS_INTERACT = 2, TS_DONE = 3, TS_REEMIT = 4 };   // TS_REEMIT: re-absorbed by a source
 
-constexpr int HYP_TILE_MAX_BRICKS = 8192;
+// bricks (clusters, slabs) per grid on the tiled schedules: tile_sort_kernel keeps two 4-byte tables of them in LDS (2 x 4 B x 18 432 + 2 KB = 146 KB of the
+// CU's 160 KB) -- a 512^3 Cartesian grid has 16 384 bricks of 32 x 16 x 16 cells; larger grids run on the persistent kernel
+constexpr int HYP_TILE_MAX_BRICKS = 18432;
 
 template <int ND>
 struct alignas(64) HotRec {      // what the walk needs (128 B for ND = 1)
