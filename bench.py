@@ -284,7 +284,7 @@ def other_iterations(passes=3):
         p = config0_problem(n_r=400, n_t=200, tau=3.0, log_r=True, peeled=True)
         p.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.002 * PC)]
         e = hyperion_amd.Engine(p)
-        e.lucy_iteration(n // 10, 1, want_output=False)
+        e.lucy_iteration(n, 1, want_output=False)       # (full size, like --warmup: the slot pool is allocated and touched here, as in a run's first iteration)
         ms, st = [], None
         for i in range(passes):
             _, st = e.lucy_iteration(n, 2 + i, want_output=False)
@@ -312,7 +312,7 @@ def other_iterations(passes=3):
         from hyperion_amd.benchmark import make_cyl_disc_problem
         n = 20_000_000
         e = hyperion_amd.Engine(make_cyl_disc_problem(peeled=True))
-        e.lucy_iteration(n // 10, 1, want_output=False)
+        e.lucy_iteration(n, 1, want_output=False)
         ms, st = [], None
         for i in range(passes):
             _, st = e.lucy_iteration(n, 2 + i, want_output=False)

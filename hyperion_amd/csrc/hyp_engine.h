@@ -99,7 +99,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 23 slots, 3 << 24 on Cartesian grids from 1024 bricks (imaging: 3 << 21, trees 3 << 22): launch_tiled */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 23 slots, 3 << 24 on Cartesian grids from 1024 bricks (imaging: 3 << 22, trees 3 << 23): launch_tiled */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 16;
     int img_end_game = 1;           // option: the tiled imaging iteration hands its last packets to the deferred rounds (0: generations to the end, as until round 5)
     int reproducible = 0;           // option: every persistent kernel runs as ONE wave (one workgroup of 64 threads), no tiled / deferred schedule, one accumulator copy:
                                     // the order of every floating-point sum is the program order of that wave -- a seed gives the same bits on every run (tests; ~1000x slower)
@@ -287,6 +287,7 @@ TileKernels pick_tile_kernels(int nd, int grid_type);
 int tile_bricks(const DProblem &P, int nd);
 long long polar_tile_bricks(const DProblem &P, int nd, int lds_kb);
 long long car_tile_bricks(const DProblem &P, int nd);
+long long tiled_imaging_slots(const DProblem &P);
 size_t amr_slab_lds(size_t n, size_t g, size_t w, int nd);
 size_t oct_cluster_lds(size_t n, size_t k, int nd);
 // the imaging iteration's end-game on the tiled schedule: at most max_packets live packets become SuspRec of the deferred schedule

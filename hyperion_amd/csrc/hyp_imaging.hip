@@ -179,7 +179,7 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
     {
         // the event buffer must hold a few generations' worth of events (one per slot and generation at most); decided BEFORE the
         // pre-pass runs: it counts its crossings and kills, and the caller's fall-back runs it again
-        const long long want_slots = h->tile_slots > 0 ? h->tile_slots : ((P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21);
+        const long long want_slots = h->tile_slots > 0 ? h->tile_slots : tiled_imaging_slots(P);
         const unsigned long long slots = (unsigned long long)std::min<long long>(want_slots, (long long)n_local) + 4096ull;
         if (B.cap < 3ull * (slots + slots / 8)) return 2;
     }

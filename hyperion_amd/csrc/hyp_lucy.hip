@@ -40,6 +40,9 @@ int tile_bricks(const DProblem &P, int nd)
 // Bricks of a Cartesian grid on the tiled schedule, or -1 when the grid has no such schedule: more bricks than the sort's tables
 // hold, or wall arrays that do not fit the LDS next to a brick (16 (n1 + n2 + n3 + 3) bytes on top of 128 KB: grids with
 // n1 + n2 + n3 beyond ~1800 run on the persistent kernel in auto mode instead of failing in hipFuncSetAttribute)
+// slots of the imaging iteration's tiled half when the option tile_slots is 0 (run_tiled_imaging sizes its event buffer by it)
+long long tiled_imaging_slots(const DProblem &P) { return (P.grid_type == 2 || P.grid_type == 4) ? 3ll << 23 : 3ll << 22; }
+
 long long car_tile_bricks(const DProblem &P, int nd)
 {
     int x, y, z;
@@ -318,8 +321,8 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     // (profiles/r06_tiled_log.md): 128^3 215.2 -> 200.1 ms at 25e6 slots, tessellation 346 -> 331, AMR 163 -> 159, spherical 1 658 -> 1 517,
     // octree flat; Cartesian grids with thousands of bricks want 50e6 (256^3 1 476 -> 994 ms, 400^3 4 357 -> 1 971, 512^3 10 236 -> 3 738;
     // 1e8 slots: no further gain).  280 B per slot at one species: 7 / 14 GB of the 288 -- within a third of the free memory.
-    // The imaging iteration keeps the smaller pool: its event buffer holds three generations of events (run_tiled_imaging).
-    long long def_slots = (P.grid_type == 2 || P.grid_type == 4) ? 3ll << 22 : 3ll << 21;
+    // The imaging iteration keeps a smaller pool: its event buffer holds three generations of events (run_tiled_imaging).
+    long long def_slots = tiled_imaging_slots(P);       // (imaging: 354.5 -> 348.0 ms on 128^3 / 5e7 packets and 296.4 -> 290.5 ms on configs[3] for the doubled pool)
     if (!img) {
         def_slots = (P.grid_type == 1 && T.n_bricks >= 1024) ? 3ll << 24 : 3ll << 23;
         size_t free_b = 0, total_b = 0;

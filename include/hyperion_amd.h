@@ -347,7 +347,7 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  *     "lucy_mode"           -1 auto (default), 0 persistent kernel with global atomics, 1 the tiled schedule of the grid (bricks of a
  *                           Cartesian / polar / AMR grid, clusters of Voronoi cells or octree subtrees in LDS)
  *     "tile_slots" "tile_task" "tile_pools"   slot pool of the tiled schedule: slots (0: 3 << 23, Cartesian grids from 1024 bricks 3 << 24,
- *                           within a third of the free memory and the packet count; imaging iteration 3 << 21, trees 3 << 22),
+ *                           within a third of the free memory and the packet count; imaging iteration 3 << 22, trees 3 << 23),
  *                           packets per walk task (0: 8192), pools = streams (3)
  *     "tile_time_walk"      1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches" (bench.py)
  *     "vt_cells" "ot_cells" "at_cells" "pt_lds_kb"   most cells per Voronoi / octree cluster / AMR brick, LDS of a polar brick in KB
