@@ -95,8 +95,14 @@ constexpr int HYP_PREP_CHUNK = 2048;
 // build-time shape of tile_walk_kernel (tools/variants.py sweeps these)
 constexpr int HYP_TILE_WG = 1024;         // threads per workgroup (one workgroup per task; with 32 x 16 x 16 bricks one workgroup per CU)
 constexpr int HYP_TILE_OCC = 4;           // waves per SIMD the walk kernel's registers are budgeted for (16 waves per CU)
-constexpr int HYP_TILE_SERVICE = 16;      // lanes that must wait (visit finished / idle) before a wave runs its service phase
-constexpr int HYP_TILE_STEPS = 4;         // cell steps between two scheduling decisions of a wave
+#ifndef HYP_TILE_SERVICE_N
+#define HYP_TILE_SERVICE_N 16
+#endif
+#ifndef HYP_TILE_STEPS_N
+#define HYP_TILE_STEPS_N 8      // (round 6, 25e6-slot pool: 3: 201.0, 4: 198.8 - 201.2, 6: 197.7, 8: 196.0 - 197.3 ms; 24 service lanes 197.9, with 6 steps 198.7)
+#endif
+constexpr int HYP_TILE_SERVICE = HYP_TILE_SERVICE_N;      // lanes that must wait (visit finished / idle) before a wave runs its service phase
+constexpr int HYP_TILE_STEPS = HYP_TILE_STEPS_N;         // cell steps between two scheduling decisions of a wave
 #define TILE_DEPOSIT(p, v) do { if (!T.imaging) unsafeAtomicAdd(p, v); } while (0)      // (T: the walk kernel's TileGeom)
 constexpr int HYP_TILE_MAX_POOLS = 4;
 struct TileCtl {

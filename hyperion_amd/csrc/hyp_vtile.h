@@ -36,11 +36,17 @@
 
 constexpr int HYP_VTILE_WG = 1024;        // threads per workgroup (one workgroup per task, one per CU with vt_lds_kb = 156)
 constexpr int HYP_VTILE_OCC = 4;          // waves per SIMD the register budget is set for (128 VGPRs, nothing spilled at one and two species)
-constexpr int HYP_VTILE_SERVICE = 16;     // lanes that must wait before a wave runs its service phase
+#ifndef HYP_VTILE_SERVICE_N
+#define HYP_VTILE_SERVICE_N 16
+#endif
+#ifndef HYP_VTILE_STEPS_N
+#define HYP_VTILE_STEPS_N 2
+#endif
+constexpr int HYP_VTILE_SERVICE = HYP_VTILE_SERVICE_N;     // lanes that must wait before a wave runs its service phase
 #ifndef HYP_VTILE_UNROLL
 #define HYP_VTILE_UNROLL 4                // unrolling of the filter loop (1: 361.5, 2: 355.6, 3: 354.1, 4: 351.2 ms on one box; no spills at 128 VGPRs)
 #endif
-constexpr int HYP_VTILE_STEPS = 2;        // cell steps between two scheduling decisions of a wave
+constexpr int HYP_VTILE_STEPS = HYP_VTILE_STEPS_N;        // cell steps between two scheduling decisions of a wave
 
 // the cluster's tables in LDS (layout of the blob: hyp_device.h, VtInfo)
 struct VtLds {
