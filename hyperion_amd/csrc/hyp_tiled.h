@@ -384,7 +384,10 @@ static __global__ __launch_bounds__(256) void tile_init_kernel(TileGeom T, TileC
     }
 }
 
-constexpr int HYP_INTERACT_WAVES = 2;
+#ifndef HYP_INTERACT_WAVES_N
+#define HYP_INTERACT_WAVES_N 2
+#endif
+constexpr int HYP_INTERACT_WAVES = HYP_INTERACT_WAVES_N;
 constexpr int HYP_EMIT_WAVES = 2;
 constexpr int HYP_EMIT_WAVES_SIMPLE = 3;     // 167 VGPRs, nothing spilled (4: 128 + 74 spilled; configs[1] 254.0-254.2 -> 251.5-252.5 ms; 2: 254.0)
 // end of a walk task: its two lists (staged in the task's own range) go to the pool-wide lists, one reservation each
