@@ -353,7 +353,7 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  *     "vt_cells" "ot_cells" "at_cells" "pt_lds_kb"   most cells per Voronoi / octree cluster / AMR brick, LDS of a polar brick in KB
  *                           (0 / default: what 156 KB of LDS hold; the shapes built: "vt_max_cells" "vt_max_lds" "ot_max_cells" "at_max_cells"); "tile_drain" (packets in flight below which the Lucy iteration ends
  *                           in one drain launch; -1: 1 000 000), "tile_poll" (generations between two looks at the device), "tile_park" (a wave
- *                           whose task's queue is empty sends its last <= 16 walking packets back to their slots):
+ *                           whose task's queue is empty sends its last <= 48 walking packets back to their slots):
  *                           the tests' handles for exercising every path of the schedule on small problems
  *     "interact_threshold" "emit_threshold" "accum_copies" "blocks_per_cu" "chunk"   launch shape of the persistent kernels
  *     "defer_peel"          imaging iteration: 0 inline peel-off, 1 deferred (hyp_defer.h; default), 2 force / 3 forbid the
