@@ -99,7 +99,7 @@ struct hyp_engine {
     TileCtl *d_ctl = nullptr;
     TileCtl *h_ctl = nullptr;           // pinned host copy
     int tile_slots_alloc = 0, tile_nd_alloc = 0;
-    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 23 slots, 3 << 24 on Cartesian grids from 1024 bricks (imaging: 3 << 22, trees 3 << 23): launch_tiled */, tile_task = 0 /* 0: 8192 packets per task, 4096 on Voronoi grids */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 48 /* round 6, 25e6-slot pools: 16 -> 48: spherical 1 517 -> 1 458 ms, configs[1] 196.2 -> 194.1, octree 85.3 -> 84.6, tessellation 325 -> 323 */;
+    int lucy_mode = -1, tile_slots = 0 /* 0: 3 << 23 slots, 3 << 24 on Cartesian grids from 1024 bricks (imaging: 3 << 22, trees 3 << 23): launch_tiled */, tile_task = 0 /* 0: 8192 packets per task, 16384 on Voronoi grids (Lucy iteration) */, tile_pools = 3, tile_drain = -1 /* -1: 1 000 000 packets in flight (profiles/r04_tiled_log.md) */, tile_park = 48 /* round 6, 25e6-slot pools: 16 -> 48: spherical 1 517 -> 1 458 ms, configs[1] 196.2 -> 194.1, octree 85.3 -> 84.6, tessellation 325 -> 323 */;
     int img_end_game = 1;           // option: the tiled imaging iteration hands its last packets to the deferred rounds (0: generations to the end, as until round 5)
     int reproducible = 0;           // option: every persistent kernel runs as ONE wave (one workgroup of 64 threads), no tiled / deferred schedule, one accumulator copy:
                                     // the order of every floating-point sum is the program order of that wave -- a seed gives the same bits on every run (tests; ~1000x slower)

@@ -338,7 +338,9 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
     const size_t all_slots = (size_t)slots * n_pools;
-    T.task_size = h->tile_task <= 0 ? 8192 : h->tile_task < 256 ? 256 : h->tile_task;
+    // packets per walk task: 8 192; Voronoi clusters (156 KB of wall records loaded per task) 16 384 in the Lucy iteration -- round 6, 25e6 slots: 2 048 / 4 096 /
+    // 8 192 / 16 384 / 32 768 / 65 536: 405 / 352 / 316-325 / 308-309 / 305-314 / 330-332 ms on configs[4]; the other geometries are best at 8 192
+    T.task_size = h->tile_task <= 0 ? (P.grid_type == 3 && !img ? 16384 : 8192) : h->tile_task < 256 ? 256 : h->tile_task;
     T.iter_tag = iter_tag; T.pool = 0; T.park = h->tile_park;
     T.imaging = img ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;

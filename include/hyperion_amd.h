@@ -348,7 +348,7 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  *                           Cartesian / polar / AMR grid, clusters of Voronoi cells or octree subtrees in LDS)
  *     "tile_slots" "tile_task" "tile_pools"   slot pool of the tiled schedule: slots (0: 3 << 23, Cartesian grids from 1024 bricks 3 << 24,
  *                           within a third of the free memory and the packet count; imaging iteration 3 << 22, trees 3 << 23),
- *                           packets per walk task (0: 8192), pools = streams (3)
+ *                           packets per walk task (0: 8192, Voronoi grids 16384), pools = streams (3)
  *     "tile_time_walk"      1: HIP events around every walk launch, read back as "last_walk_us" / "last_walk_launches" (bench.py)
  *     "vt_cells" "ot_cells" "at_cells" "pt_lds_kb"   most cells per Voronoi / octree cluster / AMR brick, LDS of a polar brick in KB
  *                           (0 / default: what 156 KB of LDS hold; the shapes built: "vt_max_cells" "vt_max_lds" "ot_max_cells" "at_max_cells"); "tile_drain" (packets in flight below which the Lucy iteration ends
