@@ -301,7 +301,8 @@ def other_iterations(passes=3):
             ms.append(e.last_kernel_ms()[0])
         k = sum(ms) / len(ms)
         res.append({"config": "... imaging iteration: peeled SEDs for two views, forced first interaction",
-                    "schedule": ("deferred peel-off with the general-source kernels (hyp_defer.h: GEN), %d rounds" % e.get_option("last_defer_rounds"))
+                    "schedule": (("deferred peel-off with the general-source kernels (hyp_defer.h: GEN), %d rounds" % e.get_option("last_defer_rounds"))
+                                 + (", propagation half on the slot-pool schedule (GEN instances of tile_emit / tile_interact <IMG>, brick walk)" if e.get_option("last_tiled_imaging") else ""))
                                 if e.get_option("last_defer_rounds") else "general kernel, inline peel-off",
                     "packets": n, "kernel_ms": k, "pass_ms": ms, "packets_per_s": n / k * 1e3, "crossings_per_packet": st["crossings"] / n,
                     "crossings_per_s": st["crossings"] / k * 1e3})

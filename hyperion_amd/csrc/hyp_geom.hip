@@ -154,6 +154,7 @@ static TileKernels tile_kernels()
         k.emit = tile_emit_kernel<NDT, GEOM, 0>; k.emit_simple = tile_emit_kernel<NDT, GEOM, 1>; k.emit_ext = tile_emit_kernel<NDT, GEOM, 2>;
         k.hot_bytes = sizeof(HotRec<NDT>); k.cold_bytes = sizeof(ColdRec<NDT>);
         k.interact_img = tile_interact_kernel<NDT, false, false, GEOM, true>; k.emit_img = tile_emit_kernel<NDT, GEOM, 1, true>;
+        k.interact_img_gen = tile_interact_kernel<NDT, true, false, GEOM, true>; k.emit_img_gen = tile_emit_kernel<NDT, GEOM, 0, true>;
         k.event_bytes = sizeof(PeelEvent<NDT, GEOM>);
         k.to_susp = tile_to_susp_kernel<NDT, GEOM>;
     }

@@ -161,11 +161,17 @@ static int run_deferred_rounds(hyp_handle h, const DeferKernels &dk, const Launc
 // final_defer_kernel (scattered loads) --, events appended to the buffer and peeled (sorted) when it could overflow and at the
 // end.  Returns 0 done, 1 error, 2 not applicable (no tiled schedule for the grid, tables too large, forced first interaction
 // without room for its records): the caller runs the rounds of hyp_defer.h instead.
-static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, size_t lds, uint64_t n_local)
+// `gen`: the problem has general sources (a surface that emits with limb darkening and re-absorbs packets; dk holds the GEN kernels): the IMG
+// kernels' GEN instances emit with the general emitter and make the escape walk of the forced first interaction themselves (no pre-pass: a
+// packet starts on its source's surface), re-emissions from a source leave their event in tile_interact, and the walks watch t_src as in the
+// Lucy iteration (round 6; before, such problems ran final_defer_kernel<.., GEN>'s own walks from global memory: 1.25e10 crossings/s on the
+// 400 x 200 spherical grid against the brick walk's 4.3e10).
+static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchParams &L, size_t lds, uint64_t n_local, bool gen)
 {
     const DProblem &P = h->hp;
     const TileKernels K = pick_tile_kernels(h->n_dust, P.grid_type);
     if (!K.walk || !K.interact_img || !K.emit_img || K.event_bytes != dk.event_bytes) return 2;
+    if (gen && (!K.interact_img_gen || !K.emit_img_gen)) return 2;
     if (P.grid_type == 1 && car_tile_bricks(P, h->n_dust) < 0) return 2;
     if ((P.grid_type == 5 || P.grid_type == 6) && polar_tile_bricks(P, h->n_dust, h->pt_lds_kb) < 0) return 2;
     if (P.grid_type == 2 && !h->oct_neighbours) return 2;
@@ -183,8 +189,11 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
         const unsigned long long slots = (unsigned long long)std::min<long long>(want_slots, (long long)n_local) + 4096ull;
         if (B.cap < 3ull * (slots + slots / 8)) return 2;
     }
-    defer_ff_prepass(h, dk, L, B, lds);
-    if (P.forced_first && !B.ff) return 2;          // (no room for the records: the pre-pass did not run)
+    if (gen) { B.ff = nullptr; h->last_ff_prepass = 0; }
+    else {
+        defer_ff_prepass(h, dk, L, B, lds);
+        if (P.forced_first && !B.ff) return 2;          // (no room for the records: the pre-pass did not run)
+    }
     int occ = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)(h->inside_observers ? dk.peel_inside : dk.peel), 256, lds) != hipSuccess || occ <= 0) occ = 2;
     const unsigned peel_blocks = (unsigned)(h->n_cu * occ);
@@ -239,7 +248,9 @@ static int run_tiled_imaging(hyp_handle h, const DeferKernels &dk, const LaunchP
         return 0;
     };
     h->last_end_game = 0;
+    h->tiled_img_gen = gen;
     const int rc = launch_tiled(h, L.first_id, n_local, iter_tag, &B, flush, h->img_end_game && prop && prop_blocks > 0 ? &eg : nullptr);
+    h->tiled_img_gen = false;
     h->last_tiled_imaging = rc == 0 ? 1 : 0;
     return rc ? 1 : 0;
 }
@@ -310,7 +321,7 @@ int hyp_final_launch(hyp_handle h, uint64_t first_id, uint64_t n_local)
         // flight for walks from LDS.  A thick scattering medium -- 5 crossings per flight on a 64^3 grid at tau = 6, albedo 0.9 --
         // runs 0.162 s on it against 0.122 s on the deferred rounds (4e6 packets, profiles/r06_tiled_log.md); configs[3] has 29.
         const bool long_flights = h->lucy_cross_per_flight <= 0.0 || h->lucy_cross_per_flight >= 12.0;
-        if (!gen && !h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || (n_local >= 4000000ull && long_flights))) rc = run_tiled_imaging(h, dk, L, lds, n_local);
+        if ((!gen || !h->cfg.mrw) && !h->inside_observers && h->defer_peel != 3 && (h->defer_peel == 2 || (n_local >= 4000000ull && long_flights))) rc = run_tiled_imaging(h, dk, L, lds, n_local, gen);
         if (rc == 1) return 1;
         if (rc == 0) {
             (void)hipEventRecord(h->ev1, h->stream);

@@ -42,6 +42,7 @@ struct TileKernels {
     TileEmitK emit, emit_simple, emit_ext;      // emit_simple: point sources with tabulated / blackbody spectra only; emit_ext: those + external sources
     TileToSuspK to_susp;                // the imaging iteration's end-game: live slots -> SuspRec of the deferred schedule (tile_to_susp_kernel)
     TileInteractK interact_img; TileEmitK emit_img;      // the imaging iteration on this schedule (IMG kernels of hyp_tiled.h); event_bytes = sizeof(PeelEvent)
+    TileInteractK interact_img_gen; TileEmitK emit_img_gen;      // ... of problems with general sources (a surface that emits with limb darkening and re-absorbs)
     size_t event_bytes;
     TileDrainK drain[2][2];
     TileWalkK walk;

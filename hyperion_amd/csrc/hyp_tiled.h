@@ -52,22 +52,22 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
     // re-absorption by sources (only used when P.any_intersect): see Packet
     double t_src, t_ach;
     int reabs_id, reabs;
+    // imaging iteration (IMG kernels): the origin flags of peeloff_photon; the packet's event counter rides in `pad`.  (In the alignment
+    // padding of the record: 136 + 8 ND bytes of fields in 192.)
+    int img_f[5];
 };
+static_assert(sizeof(ColdRec<1>) == 192 && sizeof(ColdRec<4>) == 192, "ColdRec: three cache-line halves");
 
-// Imaging iteration (IMG kernels): the origin flags of peeloff_photon and the packet's event counter ride in fields the
-// plain problems it runs on never use -- the re-absorption block (no source has a radius) and the pad word.
 template <int ND>
 __device__ __forceinline__ void cold_flags_store(ColdRec<ND> &C, const PeelFlags &f, unsigned int peel_seq)
 {
-    int *q = (int *)&C.t_src;
-    q[0] = f.scattered; q[1] = f.reprocessed; q[2] = f.n_scat; q[3] = f.dust_id; q[4] = f.source_id;
+    C.img_f[0] = f.scattered; C.img_f[1] = f.reprocessed; C.img_f[2] = f.n_scat; C.img_f[3] = f.dust_id; C.img_f[4] = f.source_id;
     C.pad = (int)peel_seq;
 }
 template <int ND>
 __device__ __forceinline__ void cold_flags_load(const ColdRec<ND> &C, PeelFlags &f, unsigned int &peel_seq)
 {
-    const int *q = (const int *)&C.t_src;
-    f.scattered = q[0]; f.reprocessed = q[1]; f.n_scat = q[2]; f.dust_id = q[3]; f.source_id = q[4];
+    f.scattered = C.img_f[0]; f.reprocessed = C.img_f[1]; f.n_scat = C.img_f[2]; f.dust_id = C.img_f[3]; f.source_id = C.img_f[4];
     peel_seq = (unsigned int)C.pad;
 }
 template <int ND, int GEOM>
@@ -543,6 +543,13 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
                 int source_id; Angle src_normal;
                 bool ok = emit_packet<ND, GEOM>(P, W, p, g, cnt, source_id, src_normal, rid, e);
                 p.inter = inter; p.reabs = reabs + 1;
+                if (IMG && ok) {
+                    // the re-emission is peeled off like a scattering, also with peel_scattered_only (iter_final.f90:213-243), weighed with the angle to the
+                    // surface normal (a_prev of the event), before the packet may turn out to have left the grid: final_defer_kernel<.., GEN>, peel == 3
+                    f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
+                    if (ev_base != ~0ull) write_peel_event<ND, GEOM>(ev[ev_base + (unsigned long long)k], p, g, src_normal, s_prev, f, peel_seq, LAST_SR, false);
+                    peel_seq++; do_peel = true;
+                }
                 if (!ok || geo_escaped(P, p.cell)) { state = TS_DEAD; finished++; }
                 else {
                     p.tau_req = rng_exp(g); p.tau_ach = 0.0;
@@ -702,9 +709,10 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
                 } else {
                     // iter_final.f90:160-209: emission, its peel-off event, the first optical depth (forced first interaction or not)
                     rng_init(g, P.seed_key, T.iter_tag, id);
-                    bool ok = true;
+                    bool ok = true, emit_iso = true;
                     double tau_first = 0.0, energy_after = 0.0;
                     int source_id = 0;
+                    Angle src_normal = p.a;
                     if (B.ff) {
                         const EmitRec<ND> &R = ((const EmitRec<ND> *)B.ff)[id - ctl->first_id];
                         ok = (R.code >> 1) != 0;          // 0: the emission failed ahead of the rounds (its error is raised: the launch stops)
@@ -731,8 +739,10 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
                             p.inter = 1; p.n_visited = 0;
                         }
                     } else {
-                        Angle src_normal;
-                        ok = emit_packet<ND, GEOM, true>(P, W, p, g, cnt, source_id, src_normal);
+                        // SIMPLE == 0: the general emitters (sources with a surface -- the emission's peel-off weighs with the angle to the
+                        // normal, which the event carries in a_prev: final_defer_kernel<.., GEN>, hyp_defer.h)
+                        ok = emit_packet<ND, GEOM, SIMPLE>(P, W, p, g, cnt, source_id, src_normal);
+                        if (SIMPLE == 0 && ok) emit_iso = P.sources[source_id].type == 1 || P.sources[source_id].type == 8 || P.sources[source_id].type == 4;
                     }
                     f.scattered = 0; f.reprocessed = 0; f.n_scat = 0; f.dust_id = 0; f.source_id = source_id;
                     peel_seq = 0; p.reabs = 0;
@@ -743,12 +753,24 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
                             unsigned long long e_idx = ev_base == ~0ull ? ~0ull : ev_base + (unsigned long long)k;
                             if (wrote) { e_idx = atomicAdd(&B.ctl->reserved, 1ull); if (e_idx >= B.cap) { raise_error(P, ERR_INTERNAL, (double)e_idx, (double)B.cap, 3.0); e_idx = ~0ull; } }
                             const double s0[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
-                            if (e_idx != ~0ull) write_peel_event<ND, GEOM>(ev[e_idx], p, g, p.a, s0, f, peel_seq, LAST_SR, true);
+                            if (e_idx != ~0ull) write_peel_event<ND, GEOM>(ev[e_idx], p, g, emit_iso ? p.a : src_normal, s0, f, peel_seq, LAST_SR, emit_iso);
                             peel_seq++; wrote = true;
                         }
                         if (geo_escaped(P, p.cell)) finished++;
                         else {
                             if (B.ff) { p.tau_req = tau_first; p.energy = energy_after; }
+                            else if (SIMPLE == 0 && P.forced_first) {
+                                // forced first interaction of a packet that starts on its source's surface: the escape walk here, as final_defer_kernel<.., GEN>
+                                // makes it (iter_final.f90:191-209)
+                                bool killed = false, sampled = false;
+                                const double tau_escape = escape_tau<ND, GEOM>(P, W, p.r, p.v, p.cell, p.chi, g, cnt, killed);
+                                if (tau_escape > 1e-10 && !killed) {
+                                    double weight, tau;
+                                    forced_interaction(P, tau_escape, rng_uniform(g), tau, weight);
+                                    p.tau_req = tau; p.energy *= weight; sampled = true;
+                                }
+                                if (!sampled) p.tau_req = rng_exp(g);
+                            }
                             else p.tau_req = rng_exp(g);
                             p.tau_ach = 0.0;
                             begin_integrate(P, p);
@@ -956,11 +978,12 @@ __global__ __launch_bounds__(256) void tile_to_susp_kernel(const DProblem *__res
     for (int d = 0; d < ND; d++) { p.chi[d] = H.chi[d]; p.kappa[d] = H.kappa[d]; p.albedo[d] = C.albedo[d]; }
     p.inter = C.inter; p.emiss_dust = -1;
     p.t_src = HYP_INF; p.t_ach = 0.0; p.reabs_id = -1; p.reabs = 0;
+    if (P.any_intersect) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }      // (sources with a surface: final_defer_kernel<.., GEN> resumes)
     p.n_visited = 0; p.e_init = 0.0;
     PeelFlags f; unsigned int peel_seq;
     cold_flags_load(C, f, peel_seq);
     p.peel_seq = peel_seq;
-    p.spec_idx = H.state == TS_INTERACT ? 0 : -3;
+    p.spec_idx = H.state == TS_INTERACT ? 0 : H.state == TS_REEMIT ? 1 : -3;
     Rng g;
     const unsigned long long id = H.id;
     g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);

@@ -552,6 +552,23 @@ def _gen_deferred_vs_general(prob, n_lucy, n_img, peel_events=0, oracle=True):
         assert sa[k] == sb[k], (k, sa, sb)
     assert sa["energy_current"] == pytest.approx(sb["energy_current"], rel=1e-12)
     _images_equal(ra, rb)
+    # ... and with the propagation half on the slot-pool schedule (round 6: the GEN instances of tile_emit / tile_interact <IMG> -- general
+    # emitter, the escape walk of the forced first interaction in the emission kernel, re-emission events, walks that watch t_src), pools
+    # far smaller than the packet count, with and without the end-game on the deferred rounds
+    for end_game in (1, 0):
+        eng = hyperion_amd.Engine(prob)
+        for k, v in dict(defer_peel=2, tile_slots=6144, tile_task=256, tile_pools=2, img_end_game=end_game).items():
+            eng.set_option(k, v)
+        if peel_events:
+            eng.set_option("peel_events", max(peel_events, 65536))
+        eng.lucy_iteration(n_lucy, 1, want_output=False)
+        rt, stt = eng.final_iteration(n_img)
+        assert eng.get_option("last_tiled_imaging") == 1, "the tiled imaging schedule did not run"
+        eng.close()
+        for k in INT_KEYS:
+            assert sa[k] == stt[k], ("tiled", end_game, k, sa, stt)
+        assert sa["energy_current"] == pytest.approx(stt["energy_current"], rel=1e-12)
+        _images_equal(ra, rt)
     if oracle:
         orc = Oracle(prob)
         orc.lucy_iteration(n_lucy, 1)
