@@ -105,3 +105,43 @@ def test_configs4_voronoi_100000_sites_two_species():
     res = lucy_against_oracle(prob, 2_000_000, 1, [dict(), dict(lucy_mode=1, tile_pools=3, tile_slots=3 * 131072, tile_drain=0)],
                               atol_rel=1e-10)
     assert res[0][1]["killed_geo"] == 0 and res[0][1]["killed_int"] == 0
+
+
+@pytest.mark.parametrize("grid", ["sph", "cyl"])
+def test_polar_grids_of_the_bench_rows_with_a_stellar_sphere(grid):
+    """The polar rows of bench.py at their own size: the 400 x 200 spherical grid (log r with a cavity; SURVEY section 8 f3, "the
+    geometries most YSO users run") lit by a star WITH A RADIUS -- emission from the surface with limb darkening, re-absorption by
+    the star, re-emission -- and the 400 x 200 cylindrical flared disc.  Lucy iteration on the brick-tiled schedule (auto from 3e6
+    packets, and forced with small pools), then the imaging iteration (SEDs, two views, forced first interaction) with its
+    propagation half on the tiled schedule -- the GEN instances of the IMG kernels on the spherical grid -- and on the deferred
+    rounds, against the oracle on identical streams.  Reference: src/grid/grid_geometry_spherical_3d.f90:741-1073,
+    src/grid/grid_geometry_cylindrical_3d.f90:593-771, src/sources/source_type.f90:604-976, src/main/iter_final.f90:160-273."""
+    from hyperion_amd.benchmark import LSUN, make_cyl_disc_problem
+    from hyperion_amd.problem import Source
+    if grid == "sph":
+        from test_gpu_polar import config0_problem
+        prob = config0_problem(n_r=400, n_t=200, tau=3.0, log_r=True, peeled=True)
+        prob.sources = [Source(type="sphere", luminosity=LSUN, temperature=6000.0, position=(0.0, 0.0, 0.0), radius=0.002 * PC, limb_darkening=True)]
+    else:
+        prob = make_cyl_disc_problem(peeled=True)
+    assert prob.n_cells == 80000
+    n, m = 3_000_000, 600_000
+    lucy_against_oracle(prob, n, 1, [dict(), dict(lucy_mode=1, tile_pools=3, tile_slots=3 * 65536, tile_drain=0)], atol_rel=1e-10)
+    orc = Oracle(prob)
+    orc.lucy_iteration(n, 1)
+    want, sw = orc.final_iteration(m)
+    orc.close()
+    eng = hyperion_amd.Engine(prob)
+    eng.lucy_iteration(n, 1)
+    for defer in (2, 1):
+        eng.set_option("defer_peel", defer)
+        got, sg = eng.final_iteration(m)
+        assert eng.get_option("last_tiled_imaging") == (1 if defer == 2 else 0), defer
+        for k in INT_KEYS:
+            assert sg[k] == sw[k], (defer, k, sg, sw)
+        assert sg["energy_current"] == pytest.approx(sw["energy_current"], rel=1e-13)
+        for ga, gb in zip(got, want):
+            for name in gb:
+                np.testing.assert_allclose(ga[name], gb[name], rtol=1e-9, atol=1e-10 * np.nanmax(np.abs(gb[name])),
+                                           err_msg="defer_peel=%d %s" % (defer, name))
+    eng.close()
