@@ -14,6 +14,8 @@ n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
 from hyperion_amd.benchmark import make_cyl_disc_problem
 p = make_cyl_disc_problem()
 e = hyperion_amd.Engine(p)
+for a in sys.argv[2:]:
+    e.set_option(a.split("=")[0], int(a.split("=")[1]))
 e.lucy_iteration(n // 10, 1, want_output=False)
 for it in (2, 3):
     _, st = e.lucy_iteration(n, it, want_output=False)
