@@ -159,6 +159,7 @@ struct hyp_engine {
     bool inside_observers = false;  // a peeled group has an inside observer: deferred schedule or the general kernel, not the inline plain one
     bool ext_sources = false;       // point and external (box / sphere) sources with tabulated or blackbody spectra only: tile_emit_kernel<.., 2>
     bool mono_gen_defer = false;    // ... in a monochromatic run (final_defer_kernel<.., true, true, true>)
+    long long last_tile_slots = 0;  // slots of the last tiled iteration's pools together (get-only option)
     bool tiled_img_gen = false;     // run_tiled_imaging of a problem with general sources is under way: the GEN instances of the IMG kernels (run_tiled_generations)
     bool gen_defer = false;         // sources with a surface: the imaging iteration on the deferred schedule (final_defer_kernel<.., GEN>, peel_kernel<.., GEN>)
     bool mono_defer = false;        // a monochromatic run of a problem that is plain otherwise: its launches run on the deferred schedule (final_defer_kernel<.., true, true>)

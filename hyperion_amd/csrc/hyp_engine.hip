@@ -317,6 +317,7 @@ int hyp_get_option(hyp_handle h, const char *name, int64_t *value)
     else if (n == "pt_lds_kb") *value = h->pt_lds_kb;
     else if (n == "tile_drain") *value = h->tile_drain;
     else if (n == "tile_park") *value = h->tile_park;
+    else if (n == "last_tile_slots") *value = h->last_tile_slots;
     else if (n == "reproducible") *value = h->reproducible;
     else if (n == "img_end_game") *value = h->img_end_game;
     else if (n == "tile_poll") *value = h->tile_poll;

@@ -337,7 +337,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     if (slots < 65536) n_pools = 1;
     slots = (((slots + n_pools - 1) / n_pools + 255) / 256) * 256;       // per pool
     T.n_slots = (int)slots;
-    const size_t all_slots = (size_t)slots * n_pools;
+    size_t all_slots = (size_t)slots * n_pools;
     // packets per walk task: 8 192; Voronoi clusters (156 KB of wall records loaded per task) 16 384 in the Lucy iteration -- round 6, 25e6 slots: 2 048 / 4 096 /
     // 8 192 / 16 384 / 32 768 / 65 536: 405 / 352 / 316-325 / 308-309 / 305-314 / 330-332 ms on configs[4]; the other geometries are best at 8 192
     T.task_size = h->tile_task <= 0 ? (P.grid_type == 3 && !img ? 16384 : 8192) : h->tile_task < 256 ? 256 : h->tile_task;
@@ -345,18 +345,32 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
     T.imaging = img ? 1 : 0;
     const size_t hot_sz = K.hot_bytes, cold_sz = K.cold_bytes;
     if (all_slots > (size_t)h->tile_slots_alloc || nd != h->tile_nd_alloc) {
-        free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
-        free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
-        const size_t n_tasks_max = HYP_TILE_MAX_POOLS * ((size_t)all_slots / 256 + HYP_TILE_MAX_BRICKS + 2);
-        if (hipMalloc(&h->d_hot, hot_sz * all_slots) != hipSuccess || hipMalloc(&h->d_cold, cold_sz * all_slots) != hipSuccess ||
-            hipMalloc(&h->d_slot_brick, sizeof(int) * all_slots) != hipSuccess || hipMalloc(&h->d_order, sizeof(int) * all_slots) != hipSuccess ||
-            hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) != hipSuccess ||
-            hipMalloc(&h->d_ilist, sizeof(int) * 2 * all_slots) != hipSuccess || hipMalloc(&h->d_dlist, sizeof(int) * 2 * all_slots) != hipSuccess ||
-            hipMalloc(&h->d_tcount, sizeof(TileCount) * n_tasks_max) != hipSuccess ||
-            hipMalloc(&h->d_extra, sizeof(int) * 3 * HYP_TILE_EXTRA * HYP_TILE_MAX_POOLS) != hipSuccess)
-            return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
+        // (a pool of the default size that the device cannot give -- other handles or processes hold its memory -- is halved until it fits:
+        // fewer packets in flight are slower, not wrong; a size asked for by the option tile_slots is an error when it cannot be had)
+        for (;;) {
+            free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
+            free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
+            h->tile_slots_alloc = 0;
+            const size_t n_tasks_max = HYP_TILE_MAX_POOLS * ((size_t)all_slots / 256 + HYP_TILE_MAX_BRICKS + 2);
+            if (hipMalloc(&h->d_hot, hot_sz * all_slots) == hipSuccess && hipMalloc(&h->d_cold, cold_sz * all_slots) == hipSuccess &&
+                hipMalloc(&h->d_slot_brick, sizeof(int) * all_slots) == hipSuccess && hipMalloc(&h->d_order, sizeof(int) * all_slots) == hipSuccess &&
+                hipMalloc(&h->d_tasks, sizeof(TileTask) * n_tasks_max) == hipSuccess &&
+                hipMalloc(&h->d_ilist, sizeof(int) * 2 * all_slots) == hipSuccess && hipMalloc(&h->d_dlist, sizeof(int) * 2 * all_slots) == hipSuccess &&
+                hipMalloc(&h->d_tcount, sizeof(TileCount) * n_tasks_max) == hipSuccess &&
+                hipMalloc(&h->d_extra, sizeof(int) * 3 * HYP_TILE_EXTRA * HYP_TILE_MAX_POOLS) == hipSuccess) break;
+            (void)hipGetLastError();
+            if (h->tile_slots > 0 || slots * n_pools <= (3ll << 20)) {
+                free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
+                free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
+                return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
+            }
+            slots = ((slots / 2 + 255) / 256) * 256;
+            T.n_slots = (int)slots;
+            all_slots = (size_t)slots * n_pools;
+        }
         h->tile_slots_alloc = all_slots; h->tile_nd_alloc = nd;
     }
+    h->last_tile_slots = (long long)all_slots;
     if (!h->d_counts) {
         const size_t nb = sizeof(unsigned) * HYP_TILE_MAX_BRICKS * HYP_TILE_MAX_POOLS;
         if (hipMalloc(&h->d_counts, 2 * nb) != hipSuccess || hipMalloc(&h->d_cursor, 2 * nb) != hipSuccess ||

@@ -368,7 +368,7 @@ int  hyp_last_kernel_ms(hyp_handle h, float *propagate_ms, float *finish_ms);
  *                           copy): floating-point sums are made in that wave's program order, so a seed gives the same bits on every
  *                           run, as the reference's serial binary does (src/main/main.f90:157-161).  For tests: ~1000 times slower
  *   get only: what the last iteration did
- *     "last_lucy_mode" "last_generations" "last_walk_us" "last_walk_launches" "last_defer_rounds" "last_defer_events"
+ *     "last_lucy_mode" "last_generations" "last_tile_slots" "last_walk_us" "last_walk_launches" "last_defer_rounds" "last_defer_events"
  *     "last_ff_prepass" "last_direct_memo" "last_tiled_imaging" "last_mono_deferred" "last_vt_exact_steps"
  *     "vt_clusters" "vt_max_cells" "ot_clusters" "at_slabs"   shape of the tiled schedule that was built
  *     "pda_last_cells"      cells the partial diffusion approximation solved

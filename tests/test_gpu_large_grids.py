@@ -67,3 +67,34 @@ def test_two_schedules_agree_on_a_grid_of_maximum_size(shape):
     # every cell a packet can reach has been crossed at this packet count only on the small grid; on both: empty cells stay at the floor
     assert np.isfinite(a).all() and (a >= 0).all()
     np.testing.assert_allclose(sa["energy_abs_tot"], sb["energy_abs_tot"], rtol=1e-10)
+
+
+def test_slot_pool_shrinks_when_the_device_memory_is_taken():
+    """The tiled schedule's pool defaults to 25e6 slots (7 GB), within a third of the free memory and never below 6.3e6; on a device whose
+    memory other handles or processes hold even that may not be there.  The pool is then halved until it fits -- fewer packets in flight,
+    the same packets and the same answer -- instead of failing the iteration."""
+    import torch
+    from hyperion_amd.benchmark import make_benchmark_problem
+    prob = make_benchmark_problem(64)
+    n = 20_000_000
+    ref = hyperion_amd.Engine(prob)
+    ref.set_option("lucy_mode", 1)
+    a, sa = ref.lucy_iteration(n, 1)
+    assert ref.get_option("last_tile_slots") >= n       # (every packet of this iteration has its slot: fewer than the default 25e6)
+    ref.close()
+    eng = hyperion_amd.Engine(prob)
+    eng.set_option("lucy_mode", 1)
+    torch.cuda.synchronize()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(int(free - 1.4e9), dtype=torch.uint8, device="cuda")       # leaves less than the 1.76 GB of the smallest default pool
+    try:
+        b, sb = eng.lucy_iteration(n, 1)
+        assert eng.get_option("last_lucy_mode") == 1
+        assert 0 < eng.get_option("last_tile_slots") < (3 << 21), "the pool was not halved"
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+        eng.close()
+    for k in INT_KEYS:
+        assert sa[k] == sb[k], (k, sa, sb)
+    assert_parity(a, b)
