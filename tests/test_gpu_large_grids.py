@@ -85,8 +85,14 @@ def test_slot_pool_shrinks_when_the_device_memory_is_taken():
     eng = hyperion_amd.Engine(prob)
     eng.set_option("lucy_mode", 1)
     torch.cuda.synchronize()
-    free, _ = torch.cuda.mem_get_info()
-    hog = torch.empty(int(free - 1.4e9), dtype=torch.uint8, device="cuda")       # leaves less than the 1.76 GB of the smallest default pool
+    torch.cuda.empty_cache()           # (what earlier tests left in torch's cache would be handed out again instead of taken from the device)
+    hog = []
+    for _ in range(8):                 # leave less than the 1.76 GB of the smallest default pool
+        free, _ = torch.cuda.mem_get_info()
+        if free < 1.5e9:
+            break
+        hog.append(torch.empty(int(free - 1.4e9), dtype=torch.uint8, device="cuda"))
+    assert torch.cuda.mem_get_info()[0] < 1.6e9
     try:
         b, sb = eng.lucy_iteration(n, 1)
         assert eng.get_option("last_lucy_mode") == 1
