@@ -359,7 +359,7 @@ int launch_tiled(hyp_handle h, uint64_t first_id, uint64_t n_local, uint32_t ite
                 hipMalloc(&h->d_tcount, sizeof(TileCount) * n_tasks_max) == hipSuccess &&
                 hipMalloc(&h->d_extra, sizeof(int) * 3 * HYP_TILE_EXTRA * HYP_TILE_MAX_POOLS) == hipSuccess) break;
             (void)hipGetLastError();
-            if (h->tile_slots > 0 || slots * n_pools <= (3ll << 20)) {
+            if (h->tile_slots > 0 || slots * n_pools <= (3ll << 18)) {
                 free_dev(h->d_hot); free_dev(h->d_cold); free_dev(h->d_slot_brick); free_dev(h->d_order); free_dev(h->d_tasks);
                 free_dev(h->d_ilist); free_dev(h->d_dlist); free_dev(h->d_tcount); free_dev(h->d_extra);
                 return h->set_error("cannot allocate the packet pool of the tiled Lucy iteration");
