@@ -20,7 +20,10 @@
 
 constexpr int HYP_PAIR_CHUNK = 256;      // (event, view) pairs a wave of the peel kernel reserves at a time
 constexpr int HYP_PEEL_REFILL = 32;      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
-constexpr int HYP_PEEL_OCC = 3;        // workgroups of the peel kernel per CU the register budget is set for
+#ifndef HYP_PEEL_OCC_N
+#define HYP_PEEL_OCC_N 3
+#endif
+constexpr int HYP_PEEL_OCC = HYP_PEEL_OCC_N;        // workgroups of the peel kernel per CU the register budget is set for
 // cell crossings of the propagation kernel between two state checks (configs[3], 1e8 packets, emission and forced first interaction made
 // ahead of the rounds: 8 / 12 / 16 crossings 331.8 / 325.4 / 326.0 ms)
 template <int GEOM> __host__ __device__ constexpr int defer_steps() { return GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>(); }

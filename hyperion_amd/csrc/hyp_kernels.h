@@ -1623,6 +1623,8 @@ __device__ __forceinline__ bool find_wall_fixed_dir(const DProblem &P, const Wal
     if constexpr (GEOM == GEOM_OCT) return v_ok ? oct_find_wall_inv(P, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
     else if constexpr (GEOM == GEOM_CAR) return v_ok ? car_find_wall_inv(P, W, r, v, inv, c, tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
     else if constexpr (GEOM == GEOM_CYL) return v_ok ? cyl_find_wall_inv(P, r, v, c, inv[1], inv[0], inv[2], tmin, im) : geo_find_wall(P, W, r, v, c, tmin, im);
+    // (spherical grids: dismissing the cone walls before solving them, as the tiled walk does for packets that have not interacted yet, was
+    // measured in the peel-off walks too -- 703.7 -> 766.1 ms on the 400 x 200 imaging iteration: not done)
     else return geo_find_wall(P, W, r, v, c, tmin, im);
 }
 
