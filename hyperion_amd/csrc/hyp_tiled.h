@@ -52,22 +52,26 @@ struct alignas(64) ColdRec {     // only touched at interactions / emission
     // re-absorption by sources (only used when P.any_intersect): see Packet
     double t_src, t_ach;
     int reabs_id, reabs;
-    // imaging iteration (IMG kernels): the origin flags of peeloff_photon; the packet's event counter rides in `pad`.  (In the alignment
-    // padding of the record: 136 + 8 ND bytes of fields in 192.)
+    // imaging iteration (IMG kernels): the origin flags of peeloff_photon of problems whose sources can absorb packets (P.any_intersect); the
+    // others keep them in the re-absorption block above, which they never use, so that an interaction touches two of the record's three
+    // 64-byte lines (configs[3] imaging: 292 against 302 ms).  The packet's event counter rides in `pad`.  (In the alignment padding of the
+    // record: 136 + 8 ND bytes of fields in 192.)
     int img_f[5];
 };
 static_assert(sizeof(ColdRec<1>) == 192 && sizeof(ColdRec<4>) == 192, "ColdRec: three cache-line halves");
 
 template <int ND>
-__device__ __forceinline__ void cold_flags_store(ColdRec<ND> &C, const PeelFlags &f, unsigned int peel_seq)
+__device__ __forceinline__ void cold_flags_store(ColdRec<ND> &C, const PeelFlags &f, unsigned int peel_seq, bool own_bytes)
 {
-    C.img_f[0] = f.scattered; C.img_f[1] = f.reprocessed; C.img_f[2] = f.n_scat; C.img_f[3] = f.dust_id; C.img_f[4] = f.source_id;
+    int *q = own_bytes ? C.img_f : (int *)&C.t_src;
+    q[0] = f.scattered; q[1] = f.reprocessed; q[2] = f.n_scat; q[3] = f.dust_id; q[4] = f.source_id;
     C.pad = (int)peel_seq;
 }
 template <int ND>
-__device__ __forceinline__ void cold_flags_load(const ColdRec<ND> &C, PeelFlags &f, unsigned int &peel_seq)
+__device__ __forceinline__ void cold_flags_load(const ColdRec<ND> &C, PeelFlags &f, unsigned int &peel_seq, bool own_bytes)
 {
-    f.scattered = C.img_f[0]; f.reprocessed = C.img_f[1]; f.n_scat = C.img_f[2]; f.dust_id = C.img_f[3]; f.source_id = C.img_f[4];
+    const int *q = own_bytes ? C.img_f : (const int *)&C.t_src;
+    f.scattered = q[0]; f.reprocessed = q[1]; f.n_scat = q[2]; f.dust_id = q[3]; f.source_id = q[4];
     peel_seq = (unsigned int)C.pad;
 }
 template <int ND, int GEOM>
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
             g.key0 = P.seed_key; g.key1 = T.iter_tag; g.id_lo = (uint32_t)id; g.id_hi = (uint32_t)(id >> 32);
             g.blk_a = C.blk_a; g.blk_b = H.blk_b; g.buf_a = C.buf_a; g.have_a = C.have_a; g.countdown = H.countdown;
             if (REABS) { p.reabs = C.reabs; p.reabs_id = C.reabs_id; }
-            if (IMG) cold_flags_load(C, f, peel_seq);
+            if (IMG) cold_flags_load(C, f, peel_seq, P.any_intersect != 0);
         }
         const Angle a_prev = p.a;
         const double s_prev[4] = {p.s[0], p.s[1], p.s[2], p.s[3]};
@@ -586,7 +590,7 @@ __global__ __launch_bounds__(256, HYP_INTERACT_WAVES) void tile_interact_kernel(
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
-                if (IMG) cold_flags_store(cold[slot], f, peel_seq);
+                if (IMG) cold_flags_store(cold[slot], f, peel_seq, P.any_intersect != 0);
                 if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) {
                         int kind = 1;      // spherical grids: 1 = the integration starts outwards (find_wall skips the inner sphere for the whole flight), 2 = inwards
                         if constexpr (GEOM == GEOM_SPH) kind = (T.vsplit > 2 && !p.cell.radial) ? 2 : 1;
@@ -786,7 +790,7 @@ __global__ __launch_bounds__(256, SIMPLE ? HYP_EMIT_WAVES_SIMPLE : HYP_EMIT_WAVE
         if (valid) {
             if (state == TS_WALK || state == TS_INTERACT) {
                 store_records<ND, GEOM>(P, hot[slot], cold[slot], p, g, id, state);
-                if (IMG) cold_flags_store(cold[slot], f, peel_seq);
+                if (IMG) cold_flags_store(cold[slot], f, peel_seq, P.any_intersect != 0);
                 if (state == TS_WALK) { brick = TileCellIO<GEOM>::brick(P, T, p.cell); if (T.vsplit > 1) brick = brick * T.vsplit; slot_brick[slot] = brick; }
                 else {
                     // zero optical depth drawn (probability 2^-53): the next generation's extra workgroup interacts
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(256) void tile_to_susp_kernel(const DProblem *__res
     if (P.any_intersect) { p.t_src = C.t_src; p.t_ach = C.t_ach; p.reabs_id = C.reabs_id; p.reabs = C.reabs; }      // (sources with a surface: final_defer_kernel<.., GEN> resumes)
     p.n_visited = 0; p.e_init = 0.0;
     PeelFlags f; unsigned int peel_seq;
-    cold_flags_load(C, f, peel_seq);
+    cold_flags_load(C, f, peel_seq, P.any_intersect != 0);
     p.peel_seq = peel_seq;
     p.spec_idx = H.state == TS_INTERACT ? 0 : H.state == TS_REEMIT ? 1 : -3;
     Rng g;
