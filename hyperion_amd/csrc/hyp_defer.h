@@ -19,7 +19,13 @@
 #include "hyp_kernels.h"
 
 constexpr int HYP_PAIR_CHUNK = 256;      // (event, view) pairs a wave of the peel kernel reserves at a time
-constexpr int HYP_PEEL_REFILL = 32;      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
+#ifndef HYP_PEEL_REFILL_N
+#define HYP_PEEL_REFILL_N 32
+#endif
+#ifndef HYP_PEEL_STEPS_N
+#define HYP_PEEL_STEPS_N 16
+#endif
+constexpr int HYP_PEEL_REFILL = HYP_PEEL_REFILL_N;      // idle lanes that trigger a refill in the peel kernel (its set-up runs with those lanes only)
 #ifndef HYP_PEEL_OCC_N
 #define HYP_PEEL_OCC_N 3
 #endif
@@ -27,7 +33,16 @@ constexpr int HYP_PEEL_OCC = HYP_PEEL_OCC_N;        // workgroups of the peel ke
 // cell crossings of the propagation kernel between two state checks (configs[3], 1e8 packets, emission and forced first interaction made
 // ahead of the rounds: 8 / 12 / 16 crossings 331.8 / 325.4 / 326.0 ms)
 template <int GEOM> __host__ __device__ constexpr int defer_steps() { return GEOM == GEOM_OCT ? 12 : final_walk_steps<GEOM>(); }
-constexpr int HYP_PEEL_STEPS = 16;       // cell crossings between two refill / deposit checks
+constexpr int HYP_PEEL_STEPS = HYP_PEEL_STEPS_N;       // cell crossings between two refill / deposit checks
+// ... of the peel kernel by geometry (round 6: walks of hundreds of crossings on the 400 x 200 polar grids want longer runs of steps and an earlier refill --
+// spherical 707 -> 664 ms, with a stellar sphere 802 -> 761, cylindrical 158.7 -> 154.7; the octree loses with them, 292 -> 307; Cartesian 213.5 -> 212)
+#ifdef HYP_PEEL_SHAPE_ALL
+template <int GEOM> __host__ __device__ constexpr int peel_steps() { return HYP_PEEL_STEPS_N; }
+template <int GEOM> __host__ __device__ constexpr int peel_refill() { return HYP_PEEL_REFILL_N; }
+#else
+template <int GEOM> __host__ __device__ constexpr int peel_steps() { return (GEOM == GEOM_SPH || GEOM == GEOM_CYL) ? 32 : HYP_PEEL_STEPS_N; }
+template <int GEOM> __host__ __device__ constexpr int peel_refill() { return (GEOM == GEOM_SPH || GEOM == GEOM_CYL) ? 16 : HYP_PEEL_REFILL_N; }
+#endif
 
 template <int NDT, int GEOM>
 struct alignas(16) PeelEvent {
@@ -815,7 +830,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
     for (;;) {
         const unsigned long long m_idle = __ballot(st == 0);
         const unsigned long long m_walk = __ballot(st == 1);
-        if (!exhausted && (__popcll(m_idle) >= HYP_PEEL_REFILL || !m_walk)) {
+        if (!exhausted && (__popcll(m_idle) >= peel_refill<GEOM>() || !m_walk)) {
             // hand pairs to the idle lanes
             unsigned long long mask = m_idle, pair = 0;
             bool got = false;
@@ -944,7 +959,7 @@ __global__ __launch_bounds__(256, HYP_PEEL_OCC) void peel_kernel(const DProblem 
         if (!__ballot(st != 0)) { if (exhausted) break; else continue; }
 
 #pragma unroll 1
-        for (int k = 0; k < HYP_PEEL_STEPS; k++) {
+        for (int k = 0; k < peel_steps<GEOM>(); k++) {
             if (st == 1) {
                 bool check_ok = true;
                 if (gp.countdown == 0) {
