@@ -1451,7 +1451,10 @@ constexpr int HYP_FINAL_WAVES = 2;
 template <int GEOM> constexpr int lucy_waves() { return GEOM == GEOM_VOR ? HYP_LUCY_WAVES_VOR : GEOM == GEOM_OCT ? HYP_LUCY_WAVES_OCT : HYP_LUCY_WAVES; }
 constexpr int HYP_WALK_STEPS = 4;        // cell crossings between two looks at the lanes' states, Cartesian grid
 constexpr int HYP_WALK_STEPS_TREE = 16;  // octree, Voronoi: a crossing is several dependent loads, fewer state checks pay (configs[3]                          // imaging 52.7 -> 50 ms; the Lucy kernels do not care)
-constexpr int HYP_WALK_STEPS_OTHER = 8;  // AMR, polar grids
+#ifndef HYP_WALK_STEPS_OTHER_N
+#define HYP_WALK_STEPS_OTHER_N 8
+#endif
+constexpr int HYP_WALK_STEPS_OTHER = HYP_WALK_STEPS_OTHER_N;  // AMR, polar grids
 template <int GEOM> constexpr int walk_steps()
 {
     return GEOM == GEOM_CAR ? HYP_WALK_STEPS : (GEOM == GEOM_OCT || GEOM == GEOM_VOR) ? HYP_WALK_STEPS_TREE : HYP_WALK_STEPS_OTHER;
