@@ -1019,7 +1019,10 @@ static __global__ __launch_bounds__(256) void tile_live_kernel(TileGeom T, const
 // ---------------------------------------------------------------------------
 // slots per thread of tile_sort.  Every workgroup makes one returning atomic per brick on cursor[], and
 // atomics on one address are served one after the other by the memory side: the fewer workgroups, the shorter that queue.
-constexpr int HYP_SORT_PER_THREAD = 32;
+#ifndef HYP_SORT_PER_THREAD_N
+#define HYP_SORT_PER_THREAD_N 32
+#endif
+constexpr int HYP_SORT_PER_THREAD = HYP_SORT_PER_THREAD_N;
 
 // Exclusive scan of the brick counts, task list and scatter of the slots in ONE launch.  Every workgroup
 // scans the brick counts itself (a few hundred values; the offsets stay in LDS), workgroup 0 also writes the task list and resets
