@@ -18,7 +18,10 @@
 #pragma once
 #include "hyp_kernels.h"
 
-constexpr int HYP_PAIR_CHUNK = 256;      // (event, view) pairs a wave of the peel kernel reserves at a time
+#ifndef HYP_PAIR_CHUNK_N
+#define HYP_PAIR_CHUNK_N 256
+#endif
+constexpr int HYP_PAIR_CHUNK = HYP_PAIR_CHUNK_N;      // (event, view) pairs a wave of the peel kernel reserves at a time
 #ifndef HYP_PEEL_REFILL_N
 #define HYP_PEEL_REFILL_N 32
 #endif
@@ -514,7 +517,10 @@ __global__ __launch_bounds__(256, HYP_FINAL_WAVES) void final_defer_kernel(const
 // code nor the ST_FF state: a lane that takes an id loads the record, writes the emission's peel-off event and walks.
 // Crossings and packets killed by the escape walk are counted here, once; energy_current by the propagation kernel.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int HYP_FF_OCC = 3;
+#ifndef HYP_FF_OCC_N
+#define HYP_FF_OCC_N 3
+#endif
+constexpr int HYP_FF_OCC = HYP_FF_OCC_N;
 constexpr int HYP_FF_REFILL = 32;
 
 template <int NDT, int GEOM>
